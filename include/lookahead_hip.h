@@ -1,0 +1,234 @@
+/*
+ * lookahead_hip.h — C ABI of liblookahead_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for LOOKAHEAD's trie-draft / tree-verify decoding loop
+ * (alipay/PainlessInferenceAcceleration, lookahead/).  The reference has no
+ * native boundary: its hot path is two Python surfaces.  Every entry point
+ * below names the reference symbol (file:line, relative to the reference
+ * checkout) whose behaviour it replaces; the Python package
+ * painlessinferenceacceleration_amd/ re-exposes them under the reference's
+ * own names (LookaheadCache, lookahead_generation).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - every function returns int: 0 = ok, <0 = LA_E_* error (never throws).
+ *   - handles are opaque; buffers are caller-owned; device pointers are raw
+ *     HIP device addresses; `stream` is a hipStream_t passed as void*.
+ *   - no allocation on the per-step path (la_llama_step / la_cache_*_get).
+ *   - la_cache_* is host code (works without a GPU); everything taking a
+ *     `stream` launches hand-written gfx950 kernels and needs a device.
+ */
+#ifndef LOOKAHEAD_HIP_H
+#define LOOKAHEAD_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LA_OK            0
+#define LA_E_ARG        -1   /* bad argument (the reference would `assert`)          */
+#define LA_E_RANGE      -2   /* output buffer too small / size over a device limit   */
+#define LA_E_HIP        -3   /* HIP runtime error (see la_last_error)                */
+#define LA_E_STATE      -4   /* call order violated (e.g. step before create)        */
+#define LA_E_IO         -5   /* save/load failure                                    */
+
+#define LA_MODE_INPUT    0
+#define LA_MODE_OUTPUT   1
+#define LA_MODE_MIX      2
+
+#define LA_TREE_MAX     64   /* tree tokens per sequence handled by the device path  */
+
+/* ABI version: bumped when a signature changes. */
+int          la_abi_version(void);
+const char*  la_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * 1. Trie cache (host).  Replaces class LookaheadCache / Tree / Node,
+ *    lookahead/lookahead/common/lookahead_cache.py:13-587.
+ * --------------------------------------------------------------------- */
+typedef struct la_cache la_cache;
+
+/* LookaheadCache.__init__ (lookahead_cache.py:337-347). */
+la_cache* la_cache_create(int max_node, int max_output_node);
+void      la_cache_destroy(la_cache* c);
+/* attrs mutated by callers: .max_node/.max_output_node (benchmarks/benchmark.py:271-272),
+ * .eos_ids/.stop_words (pretrained_model.py:1088-1089).  n_eos==0 <=> eos_ids=[None]. */
+int la_cache_set_limits(la_cache* c, int max_node, int max_output_node);
+int la_cache_set_eos(la_cache* c, const int32_t* eos_ids, int n_eos);
+int la_cache_set_stop_words(la_cache* c, const int32_t* ids, int n);
+/* fresh() (lookahead_cache.py:563-564): drops the forest, keeps dirty-set counts and stream buffers. */
+int la_cache_fresh(la_cache* c);
+/* put() (lookahead_cache.py:349-373) -> Tree.put/_put/_pack (:33-63). mode: LA_MODE_INPUT|OUTPUT. */
+int la_cache_put(la_cache* c, const int32_t* token_ids, int n, int branch_length,
+                 int final_, int mode, int idx);
+/* stream_put() (lookahead_cache.py:375-406). */
+int la_cache_stream_put(la_cache* c, const int32_t* token_ids, int n, int branch_length,
+                        int final_, int idx);
+/* hier_get() (lookahead_cache.py:408-439) -> Tree.get/_match/_dfs_get_freqs/_ravel (:65-154, 224-293).
+ * Outputs (caller-owned): out_ids[cap], out_parent[cap] (index of the parent row, -1 for row 0),
+ * out_rowmask[cap] (bit j of row i <=> mask[i][j]; only filled when *out_n <= 64),
+ * out_mask (optional, row-major int64 [*out_n][*out_n], needs cap*cap entries),
+ * out_sizes[2], *out_nsizes in {0,2} (the reference returns [] on the early exit, :413-414). */
+int la_cache_hier_get(la_cache* c, const int32_t* token_ids, int n,
+                      int decoding_length, int branch_length,
+                      int min_input_size, int min_output_size, int mode, int idx,
+                      int cap, int32_t* out_ids, int32_t* out_parent, uint64_t* out_rowmask,
+                      int64_t* out_mask, int32_t out_sizes[2], int32_t* out_nsizes, int32_t* out_n);
+/* one_get() (lookahead_cache.py:490-517) -> Tree.get_one_branch (:171-222).
+ * *out_nsizes in {0,1,2}; the mask is lower-triangular of size *out_n. */
+int la_cache_one_get(la_cache* c, const int32_t* token_ids, int n,
+                     int decoding_length, int branch_length, int mode, int idx,
+                     int cap, int32_t* out_ids, int32_t out_sizes[2], int32_t* out_nsizes,
+                     int32_t* out_n);
+/* reset_input_freqs() (:566-570), squeeze_branch_counts() (:572-576). */
+int la_cache_reset_input_freqs(la_cache* c, int idx);
+int la_cache_squeeze(la_cache* c);
+/* Introspection used by tests/benchmarks (len(cache.mem), sum of tree.n_node, ...). */
+int la_cache_stats(la_cache* c, int64_t* n_trees, int64_t* n_nodes_live,
+                   int64_t* n_dirty_trees, int64_t* n_dirty_input_trees);
+int la_cache_tree_counters(la_cache* c, int32_t token, int64_t* n_node, int64_t* n_output_node);
+/* save_mem()/load_mem() (:578-587): the reference pickles Python objects; this is a portable
+ * little-endian arena snapshot ("LATRIE01").  Same role, different wire format. */
+int la_cache_save(la_cache* c, const char* path);
+int la_cache_load(la_cache* c, const char* path);
+
+/* ------------------------------------------------------------------------
+ * 2. Step kernels (device).  Each is also reachable through la_llama_step;
+ *    exported singly for unit parity tests.
+ * --------------------------------------------------------------------- */
+
+/* Device-resident per-sequence step state (int32 words). */
+#define LA_ST_NKEYS      0   /* committed keys in the main KV cache (= context_length-1) */
+#define LA_ST_T          1   /* valid tree tokens in this block (1..64)                   */
+#define LA_ST_MODE       2   /* 0 = verify (accept scan), 1 = prefill chain (commit all)  */
+#define LA_ST_NOUT       3   /* out: number of emitted tokens (= matches+1)               */
+#define LA_ST_DSTBASE    4   /* out: first main-cache row written by the commit           */
+#define LA_ST_NCOMMIT    5   /* out: rows committed                                       */
+#define LA_ST_MAXKEYS    6   /* capacity of the main KV cache in keys (multiple of 32)    */
+#define LA_ST_OUTTOK     8   /* out: [64] emitted tokens, path order then bonus           */
+#define LA_ST_SRCIDX    72   /* out: [64] tree rows committed, in order                   */
+#define LA_ST_ARGMAX   136   /* out: [64] argmax token per tree row                       */
+#define LA_ST_WORDS    200
+
+/* Host->device step input block: {T, mode, pad, pad, ids[64] (int32), rowmask[64] (uint64)}. */
+#define LA_IN_T          0
+#define LA_IN_MODE       1
+#define LA_IN_IDS        4
+#define LA_IN_ROWMASK   68   /* int32 word offset; 8-byte aligned */
+#define LA_IN_WORDS    196
+
+/* Tree-mask / position construction.  Replaces lookahead_prepare_inputs_for_generation's mask
+ * concat (pretrained_model.py:725-734) + the model hook (models/llama/modeling_llama.py:584-588):
+ * pos[t] = nkeys + popcount(rowmask[t]) - 1; pad rows (t >= T) get rowmask = 1<<t. */
+int la_build_tree_inputs(void* stream, const int32_t* d_in, int32_t* d_state,
+                         int32_t* d_pos /*[64]*/, uint64_t* d_rowmask /*[64]*/, int32_t* d_ids /*[64]*/);
+
+/* Accept scan.  Replaces _lookahead_update_model_kwargs_for_generation
+ * (pretrained_model.py:764-892) with an empty logits-processor list. */
+int la_accept_scan(void* stream, const int32_t* d_ids, const uint64_t* d_rowmask, int32_t* d_state);
+
+/* KV commit ("compaction").  Replaces _update_cache_with_axis_2 (pretrained_model.py:894-907):
+ * rows state[SRCIDX][0..NCOMMIT) of the fresh (tree) K/V tiles become main-cache rows
+ * DSTBASE.. ; all layers in one launch. */
+int la_kv_commit(void* stream, const void* d_kfresh, const void* d_vfresh, void* d_kmain, void* d_vmain,
+                 const int32_t* d_state, int n_layers, int n_kv_heads, int max_keys);
+
+/* Weight repack into MFMA-fragment tile order (one-off at load).  W: [N][K] bf16 row-major
+ * (torch nn.Linear layout), N%32==0, K%16==0.  interleave2=1 packs two [N][K] matrices
+ * (gate, up) as alternating 32-row blocks. */
+int la_pack_weight(void* stream, const void* d_w, const void* d_w2, int N, int K, int interleave2,
+                   void* d_out);
+/* Activations [64][K] bf16 row-major -> packed operand order (tests / debugging). */
+int la_pack_x(void* stream, const void* d_x, int K, void* d_out);
+
+/* Skinny GEMM  out[64][N] = x[64][K] . W[N][K]^T  (bf16 in, fp32 accumulate), split-K slabs.
+ * Replaces the nn.Linear calls of LlamaAttention/LlamaMLP (modeling_llama.py:172-186, 222-224, 296). */
+int la_gemm64_slab(void* stream, const void* d_wp, const void* d_xp, int N, int K, int rb, int ksplit,
+                   float* d_slabs /*[ksplit][64][N]*/);
+int la_gemm64_swiglu(void* stream, const void* d_wp_gateup, const void* d_xp, int F, int K,
+                     void* d_act_packed /*[64][F] packed*/);
+int la_gemm64_logits(void* stream, const void* d_wp, const void* d_xp, int V, int K, int rb,
+                     void* d_logits_bf16 /*[64][V] or NULL*/, float* d_cand_val, int32_t* d_cand_idx);
+int la_argmax_finalize(void* stream, const float* d_cand_val, const int32_t* d_cand_idx, int n_tiles,
+                       int32_t* d_state);
+
+/* Fused elementwise stages (RMSNorm: modeling_llama.py:76-90; RoPE: :93-169). */
+int la_embed_norm(void* stream, const void* d_embed, const int32_t* d_ids, const void* d_norm_w,
+                  int hidden, float eps, void* d_h, void* d_xp);
+int la_resid_norm(void* stream, void* d_h, const float* d_slabs, int n_slabs, const void* d_norm_w,
+                  int hidden, float eps, void* d_xp);
+int la_qkv_post(void* stream, const float* d_slabs, int n_slabs, int n_heads, int n_kv_heads,
+                const int32_t* d_pos, const void* d_rope_cos, const void* d_rope_sin,
+                void* d_qf, void* d_kfresh, void* d_vfresh);
+/* Tree attention: mask-free prefix from the packed main cache + 64 fresh keys under rowmask. */
+int la_tree_attn(void* stream, const void* d_qf, const void* d_kmain, const void* d_vmain,
+                 const void* d_kfresh, const void* d_vfresh, const uint64_t* d_rowmask,
+                 const int32_t* d_state, int n_heads, int n_kv_heads, int max_keys, int n_split,
+                 float* d_opart, float* d_mpart, float* d_lpart, void* d_attn_xp);
+
+/* ------------------------------------------------------------------------
+ * 3. Whole verify step for Llama-family models (captured as one hipGraph).
+ *    Replaces LlamaForCausalLM.forward under the rank-4 mask hook
+ *    (models/llama/modeling_llama.py:544-677, 710-794) + a16/a17 above.
+ * --------------------------------------------------------------------- */
+typedef struct la_llama la_llama;
+
+typedef struct la_llama_config {
+    int32_t n_layers, hidden, n_heads, n_kv_heads, head_dim, ffn, vocab;
+    int32_t max_keys;        /* KV capacity per sequence, multiple of 32, >= max_length + 64 */
+    int32_t max_pos;         /* rows in the RoPE tables                                       */
+    int32_t attn_split;      /* key-range splits per head (0 = auto)                          */
+    float   rms_eps;
+    int32_t gemm_cfg[8];     /* {qkv_rb,qkv_ks,o_rb,o_ks,down_rb,down_ks,lm_rb,reserved}; 0 = auto */
+} la_llama_config;
+
+typedef struct la_llama_layer_weights {   /* device pointers, packed by la_pack_weight */
+    const void* wqkv;        /* [(nh+2*nkv)*hd][hidden]        */
+    const void* wo;          /* [hidden][nh*hd]                */
+    const void* wgateup;     /* interleaved gate/up [2*ffn][hidden] */
+    const void* wdown;       /* [hidden][ffn]                  */
+    const void* norm1;       /* input_layernorm weight bf16 [hidden]          */
+    const void* norm2;       /* post_attention_layernorm weight bf16 [hidden] */
+} la_llama_layer_weights;
+
+typedef struct la_llama_weights {
+    const void* embed;       /* [vocab][hidden] bf16 row-major (gather source) */
+    const void* lm_head;     /* packed [vocab][hidden]                         */
+    const void* final_norm;  /* bf16 [hidden]                                  */
+    const void* rope_cos;    /* bf16 [max_pos][head_dim/2]                     */
+    const void* rope_sin;    /* bf16 [max_pos][head_dim/2]                     */
+    const la_llama_layer_weights* layers;   /* host array [n_layers]           */
+} la_llama_weights;
+
+/* Bytes of device memory the caller must provide for KV caches + scratch. */
+int64_t   la_llama_workspace_bytes(const la_llama_config* cfg);
+la_llama* la_llama_create(const la_llama_config* cfg, const la_llama_weights* w,
+                          void* d_workspace, int64_t workspace_bytes);
+void      la_llama_destroy(la_llama* m);
+/* Reset the sequence (nkeys = 0). */
+int la_llama_reset(la_llama* m, void* stream);
+/* One block: h2d of the step input (host_in: LA_IN_WORDS int32), the captured graph
+ * (embed -> L x {qkv, rope+kv, tree-attn, o, norm, gate/up, down, norm} -> lm_head+argmax ->
+ * accept scan -> kv commit), d2h of the first 8+64 state words into host_out.  Asynchronous on
+ * `stream`; the caller synchronises before reading host_out.  host_in/host_out should be pinned. */
+int la_llama_step(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);
+/* Same work launched kernel-by-kernel (no graph): for profiling and as a cross-check. */
+int la_llama_step_eager(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);
+/* Device addresses of internal buffers for parity tests: 0 logits bf16 [64][vocab], 1 state,
+ * 2 hidden h bf16 [64][hidden], 3 final normed x (packed), 4/5 main K/V cache, 6/7 fresh K/V tiles. */
+void* la_llama_buffer(la_llama* m, int which);
+/* Kernel-class timing of one block with HIP events recorded on `stream` between eager launches
+ * (bench.py's roofline block).  out_ms[0..6] = per-step time summed over the launches of
+ * {qkv GEMM, o GEMM, gate/up GEMM, down GEMM, lm_head GEMM, tree attention(+combine), everything else},
+ * out_ms[7] = the whole step; out_launches[0..6] = intervals of that class per step.  Mean over `iters`
+ * steps; the sequence state is saved and restored, so the context does not advance. */
+int la_llama_profile(la_llama* m, void* stream, const int32_t* host_in, int iters,
+                     float* out_ms /*[8]*/, int32_t* out_launches /*[7] or NULL*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOOKAHEAD_HIP_H */

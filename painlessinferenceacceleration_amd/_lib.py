@@ -1,0 +1,123 @@
+# -*- coding: utf-8 -*-
+"""ctypes binding of liblookahead_hip.so (the C ABI declared in include/lookahead_hip.h).
+
+The library is the product: there is no Python/CPU fallback for any device entry point.  If the
+shared object is missing this module raises at import time with the build command.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblookahead_hip.so")
+
+LA_OK = 0
+LA_MODE_INPUT, LA_MODE_OUTPUT, LA_MODE_MIX = 0, 1, 2
+LA_TREE_MAX = 64
+# device step-state words (include/lookahead_hip.h)
+LA_ST_NKEYS, LA_ST_T, LA_ST_MODE, LA_ST_NOUT, LA_ST_DSTBASE, LA_ST_NCOMMIT, LA_ST_MAXKEYS = 0, 1, 2, 3, 4, 5, 6
+LA_ST_OUTTOK, LA_ST_SRCIDX, LA_ST_ARGMAX, LA_ST_WORDS = 8, 72, 136, 200
+LA_IN_T, LA_IN_MODE, LA_IN_IDS, LA_IN_ROWMASK, LA_IN_WORDS = 0, 1, 4, 68, 196
+
+
+class LookaheadHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with "
+            f"`bash {os.path.join(_HERE, 'csrc', 'build.sh')}` (hipcc --offload-arch=gfx950) or "
+            f"`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback.")
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+pi32, pi64, pu64, pf32 = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.POINTER(C.c_float)
+
+
+class LlamaConfigC(C.Structure):
+    _fields_ = [("n_layers", i32), ("hidden", i32), ("n_heads", i32), ("n_kv_heads", i32), ("head_dim", i32),
+                ("ffn", i32), ("vocab", i32), ("max_keys", i32), ("max_pos", i32), ("attn_split", i32),
+                ("rms_eps", f32), ("gemm_cfg", i32 * 8)]
+
+
+class LlamaLayerWeightsC(C.Structure):
+    _fields_ = [("wqkv", vp), ("wo", vp), ("wgateup", vp), ("wdown", vp), ("norm1", vp), ("norm2", vp)]
+
+
+class LlamaWeightsC(C.Structure):
+    _fields_ = [("embed", vp), ("lm_head", vp), ("final_norm", vp), ("rope_cos", vp), ("rope_sin", vp),
+                ("layers", C.POINTER(LlamaLayerWeightsC))]
+
+
+def _proto(name, restype, *argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+# every symbol declared in include/lookahead_hip.h (tests/test_abi.py checks this list against the header)
+PROTOTYPES = {
+    "la_abi_version": (i32,),
+    "la_last_error": (C.c_char_p,),
+    "la_cache_create": (vp, i32, i32),
+    "la_cache_destroy": (None, vp),
+    "la_cache_set_limits": (i32, vp, i32, i32),
+    "la_cache_set_eos": (i32, vp, pi32, i32),
+    "la_cache_set_stop_words": (i32, vp, pi32, i32),
+    "la_cache_fresh": (i32, vp),
+    "la_cache_put": (i32, vp, pi32, i32, i32, i32, i32, i32),
+    "la_cache_stream_put": (i32, vp, pi32, i32, i32, i32, i32),
+    "la_cache_hier_get": (i32, vp, pi32, i32, i32, i32, i32, i32, i32, i32, i32, pi32, pi32, pu64, pi64, pi32, pi32, pi32),
+    "la_cache_one_get": (i32, vp, pi32, i32, i32, i32, i32, i32, i32, pi32, pi32, pi32, pi32),
+    "la_cache_reset_input_freqs": (i32, vp, i32),
+    "la_cache_squeeze": (i32, vp),
+    "la_cache_stats": (i32, vp, pi64, pi64, pi64, pi64),
+    "la_cache_tree_counters": (i32, vp, i32, pi64, pi64),
+    "la_cache_save": (i32, vp, C.c_char_p),
+    "la_cache_load": (i32, vp, C.c_char_p),
+    "la_build_tree_inputs": (i32, vp, vp, vp, vp, vp, vp),
+    "la_accept_scan": (i32, vp, vp, vp, vp),
+    "la_kv_commit": (i32, vp, vp, vp, vp, vp, vp, i32, i32, i32),
+    "la_pack_weight": (i32, vp, vp, vp, i32, i32, i32, vp),
+    "la_pack_x": (i32, vp, vp, i32, vp),
+    "la_gemm64_slab": (i32, vp, vp, vp, i32, i32, i32, i32, vp),
+    "la_gemm64_swiglu": (i32, vp, vp, vp, i32, i32, vp),
+    "la_gemm64_logits": (i32, vp, vp, vp, i32, i32, i32, vp, vp, vp),
+    "la_argmax_finalize": (i32, vp, vp, vp, i32, vp),
+    "la_embed_norm": (i32, vp, vp, vp, vp, i32, f32, vp, vp),
+    "la_resid_norm": (i32, vp, vp, vp, i32, vp, i32, f32, vp),
+    "la_qkv_post": (i32, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp),
+    "la_tree_attn": (i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp),
+    "la_llama_workspace_bytes": (i64, C.POINTER(LlamaConfigC)),
+    "la_llama_create": (vp, C.POINTER(LlamaConfigC), C.POINTER(LlamaWeightsC), vp, i64),
+    "la_llama_destroy": (None, vp),
+    "la_llama_reset": (i32, vp, vp),
+    "la_llama_step": (i32, vp, vp, vp, vp),
+    "la_llama_step_eager": (i32, vp, vp, vp, vp),
+    "la_llama_buffer": (vp, vp, i32),
+    "la_llama_profile": (i32, vp, vp, vp, i32, pf32, pi32),
+}
+
+for _n, _sig in PROTOTYPES.items():
+    _proto(_n, _sig[0], *_sig[1:])
+
+
+def last_error() -> str:
+    s = lib.la_last_error()
+    return s.decode("utf-8", "replace") if s else ""
+
+
+def check(rc: int, what: str = ""):
+    """Raise on a negative LA_E_* status.  LA_E_ARG maps to AssertionError, mirroring the reference's
+    `assert` on bad arguments (lookahead_cache.py:34,67,377,521-524)."""
+    if rc == LA_OK:
+        return
+    msg = f"{what or 'liblookahead_hip'}: status {rc}: {last_error()}"
+    if rc == -1:
+        raise AssertionError(msg)
+    raise LookaheadHipError(msg)

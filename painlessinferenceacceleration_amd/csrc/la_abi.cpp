@@ -1,0 +1,82 @@
+// la_abi.cpp — C-ABI glue: error string, argument validation, thin wrappers over the kernel
+// launchers for the single-kernel entry points declared in include/lookahead_hip.h.
+#include <hip/hip_runtime.h>
+#include <string>
+#include "la_kernels.h"
+
+static thread_local std::string g_err;
+void la_set_error(const std::string& s) { g_err = s; }
+
+#define WRAP(call) do { int e_ = (call); if (e_ != 0) { \
+    la_set_error(std::string(#call) + ": " + (e_ > 0 ? hipGetErrorString((hipError_t)e_) : "bad argument")); \
+    return e_ > 0 ? LA_E_HIP : LA_E_ARG; } return LA_OK; } while (0)
+
+extern "C" {
+
+int la_abi_version(void) { return 1; }
+const char* la_last_error(void) { return g_err.c_str(); }
+
+int la_build_tree_inputs(void* stream, const int32_t* d_in, int32_t* d_state, int32_t* d_pos, uint64_t* d_rowmask,
+                         int32_t* d_ids) {
+    if (!d_in || !d_state || !d_pos || !d_rowmask || !d_ids) return LA_E_ARG;
+    WRAP(lk_build_tree_inputs((hipStream_t)stream, d_in, d_state, d_pos, d_rowmask, d_ids));
+}
+int la_accept_scan(void* stream, const int32_t* d_ids, const uint64_t* d_rowmask, int32_t* d_state) {
+    if (!d_ids || !d_rowmask || !d_state) return LA_E_ARG;
+    WRAP(lk_accept_scan((hipStream_t)stream, d_ids, d_rowmask, d_state));
+}
+int la_kv_commit(void* stream, const void* kf, const void* vf, void* km, void* vm, const int32_t* d_state,
+                 int n_layers, int n_kv_heads, int max_keys) {
+    if (!kf || !vf || !km || !vm || !d_state || n_layers <= 0 || n_kv_heads <= 0 || max_keys % 32) return LA_E_ARG;
+    WRAP(lk_kv_commit((hipStream_t)stream, kf, vf, km, vm, d_state, n_layers, n_kv_heads, max_keys));
+}
+int la_pack_weight(void* stream, const void* w, const void* w2, int N, int K, int interleave2, void* out) {
+    if (!w || !out || N % 32 || K % 16 || (interleave2 && !w2)) return LA_E_ARG;
+    WRAP(lk_pack_weight((hipStream_t)stream, w, w2, N, K, interleave2, out));
+}
+int la_pack_x(void* stream, const void* x, int K, void* out) {
+    if (!x || !out || K % 16) return LA_E_ARG;
+    WRAP(lk_pack_x((hipStream_t)stream, x, K, out));
+}
+int la_gemm64_slab(void* stream, const void* wp, const void* xp, int N, int K, int rb, int ksplit, float* slabs) {
+    if (!wp || !xp || !slabs || N % 32 || K % 16 || ksplit < 1 || ksplit > 16 || (rb != 1 && rb != 2)) return LA_E_ARG;
+    WRAP(lk_gemm64_slab((hipStream_t)stream, wp, xp, N, K, rb, ksplit, slabs));
+}
+int la_gemm64_swiglu(void* stream, const void* wp, const void* xp, int F, int K, void* act) {
+    if (!wp || !xp || !act || F % 32 || K % 16) return LA_E_ARG;
+    WRAP(lk_gemm64_swiglu((hipStream_t)stream, wp, xp, F, K, act));
+}
+int la_gemm64_logits(void* stream, const void* wp, const void* xp, int V, int K, int rb, void* logits, float* cv,
+                     int32_t* ci) {
+    if (!wp || !xp || !cv || !ci || V % 32 || K % 16 || (rb != 1 && rb != 2)) return LA_E_ARG;
+    WRAP(lk_gemm64_logits((hipStream_t)stream, wp, xp, V, K, rb, logits, cv, ci));
+}
+int la_argmax_finalize(void* stream, const float* cv, const int32_t* ci, int n_tiles, int32_t* d_state) {
+    if (!cv || !ci || !d_state || n_tiles <= 0) return LA_E_ARG;
+    WRAP(lk_argmax_finalize((hipStream_t)stream, cv, ci, n_tiles, d_state));
+}
+int la_embed_norm(void* stream, const void* embed, const int32_t* ids, const void* nw, int hidden, float eps, void* h,
+                  void* xp) {
+    if (!embed || !ids || !nw || !h || !xp) return LA_E_ARG;
+    WRAP(lk_embed_norm((hipStream_t)stream, embed, ids, nw, hidden, eps, h, xp));
+}
+int la_resid_norm(void* stream, void* h, const float* slabs, int n_slabs, const void* nw, int hidden, float eps,
+                  void* xp) {
+    if (!h || !nw || !xp || n_slabs < 0 || (n_slabs > 0 && !slabs)) return LA_E_ARG;
+    WRAP(lk_resid_norm((hipStream_t)stream, h, slabs, n_slabs, nw, hidden, eps, xp));
+}
+int la_qkv_post(void* stream, const float* slabs, int n_slabs, int nh, int nkv, const int32_t* pos, const void* rcos,
+                const void* rsin, void* qf, void* kf, void* vf) {
+    if (!slabs || n_slabs < 1 || nh <= 0 || nkv <= 0 || !pos || !rcos || !rsin || !qf || !kf || !vf) return LA_E_ARG;
+    WRAP(lk_qkv_post((hipStream_t)stream, slabs, n_slabs, nh, nkv, pos, rcos, rsin, qf, kf, vf));
+}
+int la_tree_attn(void* stream, const void* qf, const void* km, const void* vm, const void* kf, const void* vf,
+                 const uint64_t* rowmask, const int32_t* d_state, int nh, int nkv, int max_keys, int nsplit,
+                 float* opart, float* mpart, float* lpart, void* attn_xp) {
+    if (!qf || !km || !vm || !kf || !vf || !rowmask || !d_state || !opart || !mpart || !lpart || !attn_xp ||
+        nh <= 0 || nkv <= 0 || nh % nkv || max_keys % 32 || nsplit < 1 || nsplit > 64) return LA_E_ARG;
+    WRAP(lk_tree_attn((hipStream_t)stream, qf, km, vm, kf, vf, rowmask, d_state, nh, nkv, max_keys, nsplit, opart,
+                      mpart, lpart, attn_xp));
+}
+
+}  // extern "C"

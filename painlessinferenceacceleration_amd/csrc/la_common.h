@@ -1,0 +1,60 @@
+// la_common.h — shared device helpers and the HBM data layouts of liblookahead_hip (gfx950 only).
+//
+// Layouts (all bf16 unless stated; "tile" = 512 elements = 1 KiB = one wave64 x 16 B load):
+//
+//  WP  packed weight  W[N][K]   : tile (nb=n/32, kb=k/16) at ((nb*(K/16))+kb)*512,
+//                                 inside: lane = (n%32) + 32*((k%16)/8), e = k%8   -> lane*8+e
+//      = the A-operand fragment of v_mfma_f32_32x32x16_bf16, so a wave streams a 32-row block of W
+//      as consecutive, perfectly coalesced 1 KiB loads straight into MFMA operand registers.
+//  XP  packed activations x[64][K] : k-tile kb at kb*1024; token block tb=t/32 at +tb*512;
+//                                 inside: lane = (t%32) + 32*((k%16)/8), e = k%8   (B-operand fragment)
+//  QF / KF  q or k rows [rows][128] per head: 32-row block b, d-step s=d/16 at (b*8+s)*512,
+//                                 inside: lane = (row%32) + 32*((d%16)/8), e = d%8
+//  VF  v rows, transposed fragments : 32-key block b, d-block db=d/32, key-step s2 at (b*8+db*2+s2)*512,
+//                                 inside: lane = (d%32) + 32*hh, e, where key%32 = 16*s2 + (e&3) + 8*(e>>2) + 4*hh
+//      (the key order in which the S^T accumulator registers of the QK MFMA already sit, so P needs
+//       no cross-lane movement before the PV MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define LA_TB 64          // tokens per block (rows of every activation matrix)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even, NaN preserving: same rounding torch uses for float -> bfloat16
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bfr(float f) { return bf2f(f2bf(f)); }
+
+// accumulator register r of a 32x32 MFMA tile -> row inside the tile (col = lane&31)
+__device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__host__ __device__ __forceinline__ size_t xp_offset(int t, int k) {
+    return (size_t)(k >> 4) * 1024 + (size_t)(t >> 5) * 512 + (size_t)(((t & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7));
+}
+// row-fragment layout (QF/KF): element (row, d) of a [rows][128] matrix
+__host__ __device__ __forceinline__ size_t rf_offset(int row, int d) {
+    return ((size_t)(row >> 5) * 8 + (d >> 4)) * 512 + (size_t)(((row & 31) + 32 * ((d >> 3) & 1)) * 8 + (d & 7));
+}
+// transposed-fragment layout (VF): element (key, d)
+__host__ __device__ __forceinline__ size_t vf_offset(int key, int d) {
+    int kk = key & 31, s2 = kk >> 4, rr = kk & 15;
+    int hh = (rr >> 2) & 1, e = (rr & 3) + 4 * (rr >> 3);
+    return ((size_t)(key >> 5) * 8 + (d >> 5) * 2 + s2) * 512 + (size_t)(((d & 31) + 32 * hh) * 8 + e);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

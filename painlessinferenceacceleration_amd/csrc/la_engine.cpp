@@ -1,0 +1,305 @@
+// la_engine.cpp — the whole verify step of a Llama-family model as one hipGraph on one stream.
+// Replaces LlamaForCausalLM.forward under the rank-4 mask hook (modeling_llama.py:544-677, 710-794),
+// the accept scan (pretrained_model.py:764-892) and the KV compaction (:894-907).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "la_kernels.h"
+
+extern void la_set_error(const std::string& s);
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    la_set_error(std::string(#x) + ": " + hipGetErrorString(e_)); return LA_E_HIP; } } while (0)
+#define KCHK(x) do { int e_ = (x); if (e_ != 0) { \
+    la_set_error(std::string(#x) + ": launch error " + std::to_string(e_)); return LA_E_HIP; } } while (0)
+
+struct la_llama {
+    la_llama_config cfg;
+    std::vector<la_llama_layer_weights> layers;
+    la_llama_weights w;
+    // derived
+    int qkv_n, o_k, nsplit;
+    int qkv_rb, qkv_ks, o_rb, o_ks, down_rb, down_ks, lm_rb;
+    // device buffers (carved from the caller's workspace)
+    char* ws;
+    uint16_t *kmain, *vmain, *kfresh, *vfresh, *qf, *h, *xp, *attn_xp, *act_xp, *logits;
+    float *slabs, *opart, *mpart, *lpart, *cand_val;
+    int *cand_idx, *state, *in, *pos, *ids;
+    uint64_t* rowmask;
+    size_t kv_layer_elems, fresh_layer_elems;
+    hipGraphExec_t graph_exec;
+    bool graph_ready;
+    hipStream_t graph_stream;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Carver {
+    char* base; size_t off;
+    template <typename T> T* take(size_t n) {
+        off = align_up(off, 256);
+        T* p = base ? (T*)(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+static void resolve_cfg(la_llama* m) {
+    const la_llama_config& c = m->cfg;
+    m->qkv_n = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim;
+    m->o_k = c.n_heads * c.head_dim;
+    m->nsplit = c.attn_split > 0 ? c.attn_split : 4;
+    auto pick = [](int v, int d) { return v > 0 ? v : d; };
+    m->qkv_rb = pick(c.gemm_cfg[0], 1);
+    m->qkv_ks = pick(c.gemm_cfg[1], 1);
+    m->o_rb = pick(c.gemm_cfg[2], 1);
+    m->o_ks = pick(c.gemm_cfg[3], 2);
+    m->down_rb = pick(c.gemm_cfg[4], 1);
+    m->down_ks = pick(c.gemm_cfg[5], 2);
+    m->lm_rb = pick(c.gemm_cfg[6], 2);
+    if (m->qkv_n % 64) m->qkv_rb = 1;
+    if (c.hidden % 64) { m->o_rb = 1; m->down_rb = 1; }
+    if (c.vocab % 64) m->lm_rb = 1;
+}
+
+static size_t carve(la_llama* m, char* base) {
+    const la_llama_config& c = m->cfg;
+    Carver cv{base, 0};
+    const size_t KB = (size_t)c.max_keys / 32;
+    m->kv_layer_elems = (size_t)c.n_kv_heads * KB * 4096;
+    m->fresh_layer_elems = (size_t)c.n_kv_heads * 2 * 4096;
+    m->kmain = cv.take<uint16_t>(m->kv_layer_elems * c.n_layers);
+    m->vmain = cv.take<uint16_t>(m->kv_layer_elems * c.n_layers);
+    m->kfresh = cv.take<uint16_t>(m->fresh_layer_elems * c.n_layers);
+    m->vfresh = cv.take<uint16_t>(m->fresh_layer_elems * c.n_layers);
+    m->qf = cv.take<uint16_t>((size_t)c.n_heads * 2 * 4096);
+    m->h = cv.take<uint16_t>((size_t)64 * c.hidden);
+    m->xp = cv.take<uint16_t>((size_t)64 * c.hidden);
+    m->attn_xp = cv.take<uint16_t>((size_t)64 * m->o_k);
+    m->act_xp = cv.take<uint16_t>((size_t)64 * c.ffn);
+    m->logits = cv.take<uint16_t>((size_t)64 * c.vocab);
+    size_t slab_n = (size_t)m->qkv_n * m->qkv_ks;
+    if ((size_t)c.hidden * m->o_ks > slab_n) slab_n = (size_t)c.hidden * m->o_ks;
+    if ((size_t)c.hidden * m->down_ks > slab_n) slab_n = (size_t)c.hidden * m->down_ks;
+    m->slabs = cv.take<float>(slab_n * 64);
+    m->opart = cv.take<float>((size_t)c.n_heads * m->nsplit * 64 * 128);
+    m->mpart = cv.take<float>((size_t)c.n_heads * m->nsplit * 64);
+    m->lpart = cv.take<float>((size_t)c.n_heads * m->nsplit * 64);
+    m->cand_val = cv.take<float>((size_t)(c.vocab / 32) * 64);
+    m->cand_idx = cv.take<int>((size_t)(c.vocab / 32) * 64);
+    m->state = cv.take<int>(LA_ST_WORDS);
+    m->in = cv.take<int>(LA_IN_WORDS);
+    m->pos = cv.take<int>(64);
+    m->ids = cv.take<int>(64);
+    m->rowmask = cv.take<uint64_t>(64);
+    return align_up(cv.off, 256);
+}
+
+static int validate(const la_llama_config* c) {
+    if (!c) return LA_E_ARG;
+    if (c->head_dim != 128) { la_set_error("head_dim must be 128"); return LA_E_ARG; }
+    if (c->n_layers <= 0 || c->hidden % 32 || c->hidden > 8192 || c->ffn % 32 || c->vocab % 32 ||
+        c->n_heads % c->n_kv_heads || c->max_keys % 32 || c->max_keys < 96) {
+        la_set_error("unsupported llama config (need hidden%32==0<=8192, ffn%32==0, vocab%32==0, max_keys%32==0)");
+        return LA_E_ARG;
+    }
+    return LA_OK;
+}
+
+extern "C" int64_t la_llama_workspace_bytes(const la_llama_config* cfg) {
+    if (validate(cfg) != LA_OK) return LA_E_ARG;
+    la_llama tmp{};
+    tmp.cfg = *cfg;
+    resolve_cfg(&tmp);
+    return (int64_t)carve(&tmp, nullptr);
+}
+
+extern "C" la_llama* la_llama_create(const la_llama_config* cfg, const la_llama_weights* w, void* ws, int64_t ws_bytes) {
+    if (validate(cfg) != LA_OK || !w || !ws || !w->layers) { if (!w || !ws) la_set_error("null weights/workspace"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        la_set_error("no HIP device: liblookahead_hip has no CPU fallback");
+        return nullptr;
+    }
+    la_llama* m = new la_llama();
+    m->cfg = *cfg;
+    m->w = *w;
+    m->layers.assign(w->layers, w->layers + cfg->n_layers);
+    m->w.layers = m->layers.data();
+    resolve_cfg(m);
+    size_t need = carve(m, (char*)ws);
+    if ((int64_t)need > ws_bytes) { la_set_error("workspace too small"); delete m; return nullptr; }
+    m->ws = (char*)ws;
+    m->graph_ready = false;
+    m->graph_exec = nullptr;
+    m->graph_stream = nullptr;
+    return m;
+}
+
+extern "C" void la_llama_destroy(la_llama* m) {
+    if (!m) return;
+    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    delete m;
+}
+
+extern "C" int la_llama_reset(la_llama* m, void* stream) {
+    if (!m) return LA_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(m->state, 0, LA_ST_WORDS * sizeof(int), st));
+    int mk = m->cfg.max_keys;
+    HIPCHK(hipMemcpyAsync(m->state + LA_ST_MAXKEYS, &mk, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return LA_OK;
+}
+
+// kernel classes for la_llama_profile
+enum { KC_QKV = 0, KC_O, KC_GATEUP, KC_DOWN, KC_LMHEAD, KC_ATTN, KC_OTHER, KC_N };
+
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> cls;
+    size_t used = 0;
+    hipStream_t st;
+    void mark(int c) {
+        if (!on) return;
+        if (used >= ev.size()) { hipEvent_t e; (void)hipEventCreate(&e); ev.push_back(e); }
+        (void)hipEventRecord(ev[used++], st);
+        cls.push_back(c);
+    }
+};
+
+// enqueue every kernel of one block on `st` (used eagerly, under graph capture, and by the profiler)
+static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf) {
+    const la_llama_config& c = m->cfg;
+    auto P = [&](int cls) { if (pf) pf->mark(cls); };
+    P(KC_OTHER);
+    KCHK(lk_build_tree_inputs(st, m->in, m->state, m->pos, m->rowmask, m->ids));
+    KCHK(lk_embed_norm(st, m->w.embed, m->ids, m->layers[0].norm1, c.hidden, c.rms_eps, m->h, m->xp));
+    for (int l = 0; l < c.n_layers; ++l) {
+        const la_llama_layer_weights& L = m->layers[l];
+        uint16_t* kf = m->kfresh + (size_t)l * m->fresh_layer_elems;
+        uint16_t* vf = m->vfresh + (size_t)l * m->fresh_layer_elems;
+        P(KC_QKV);
+        KCHK(lk_gemm64_slab(st, L.wqkv, m->xp, m->qkv_n, c.hidden, m->qkv_rb, m->qkv_ks, m->slabs));
+        P(KC_OTHER);
+        KCHK(lk_qkv_post(st, m->slabs, m->qkv_ks, c.n_heads, c.n_kv_heads, m->pos, m->w.rope_cos, m->w.rope_sin,
+                         m->qf, kf, vf));
+        P(KC_ATTN);
+        KCHK(lk_tree_attn(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
+                          kf, vf, m->rowmask, m->state, c.n_heads, c.n_kv_heads, c.max_keys, m->nsplit,
+                          m->opart, m->mpart, m->lpart, m->attn_xp));
+        P(KC_O);
+        KCHK(lk_gemm64_slab(st, L.wo, m->attn_xp, c.hidden, m->o_k, m->o_rb, m->o_ks, m->slabs));
+        P(KC_OTHER);
+        KCHK(lk_resid_norm(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp));
+        P(KC_GATEUP);
+        KCHK(lk_gemm64_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, m->act_xp));
+        P(KC_DOWN);
+        KCHK(lk_gemm64_slab(st, L.wdown, m->act_xp, c.hidden, c.ffn, m->down_rb, m->down_ks, m->slabs));
+        P(KC_OTHER);
+        const void* nw = (l + 1 < c.n_layers) ? m->layers[l + 1].norm1 : m->w.final_norm;
+        KCHK(lk_resid_norm(st, m->h, m->slabs, m->down_ks, nw, c.hidden, c.rms_eps, m->xp));
+    }
+    P(KC_LMHEAD);
+    KCHK(lk_gemm64_logits(st, m->w.lm_head, m->xp, c.vocab, c.hidden, m->lm_rb, m->logits, m->cand_val, m->cand_idx));
+    P(KC_OTHER);
+    KCHK(lk_argmax_finalize(st, m->cand_val, m->cand_idx, c.vocab / (32 * m->lm_rb), m->state));
+    KCHK(lk_accept_scan(st, m->ids, m->rowmask, m->state));
+    KCHK(lk_kv_commit(st, m->kfresh, m->vfresh, m->kmain, m->vmain, m->state, c.n_layers, c.n_kv_heads, c.max_keys));
+    P(KC_N);
+    return LA_OK;
+}
+
+static int build_graph(la_llama* m, hipStream_t st) {
+    hipGraph_t g = nullptr;
+    HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    int rc = enqueue_step(m, st, nullptr);
+    hipError_t e = hipStreamEndCapture(st, &g);
+    if (rc != LA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+    HIPCHK(e);
+    HIPCHK(hipGraphInstantiate(&m->graph_exec, g, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(g);
+    m->graph_ready = true;
+    m->graph_stream = st;
+    return LA_OK;
+}
+
+extern "C" int la_llama_step(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out) {
+    if (!m || !host_in) return LA_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(m->in, host_in, LA_IN_WORDS * sizeof(int), hipMemcpyHostToDevice, st));
+    if (!m->graph_ready) { int rc = build_graph(m, st); if (rc != LA_OK) return rc; }
+    HIPCHK(hipGraphLaunch(m->graph_exec, st));
+    if (host_out)
+        HIPCHK(hipMemcpyAsync(host_out, m->state, (LA_ST_OUTTOK + 64) * sizeof(int), hipMemcpyDeviceToHost, st));
+    return LA_OK;
+}
+
+extern "C" int la_llama_step_eager(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out) {
+    if (!m || !host_in) return LA_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(m->in, host_in, LA_IN_WORDS * sizeof(int), hipMemcpyHostToDevice, st));
+    int rc = enqueue_step(m, st, nullptr);
+    if (rc != LA_OK) return rc;
+    if (host_out)
+        HIPCHK(hipMemcpyAsync(host_out, m->state, (LA_ST_OUTTOK + 64) * sizeof(int), hipMemcpyDeviceToHost, st));
+    return LA_OK;
+}
+
+extern "C" void* la_llama_buffer(la_llama* m, int which) {
+    if (!m) return nullptr;
+    switch (which) {
+        case 0: return m->logits;
+        case 1: return m->state;
+        case 2: return m->h;
+        case 3: return m->xp;
+        case 4: return m->kmain;
+        case 5: return m->vmain;
+        case 6: return m->kfresh;
+        case 7: return m->vfresh;
+        default: return nullptr;
+    }
+}
+
+// Mean kernel-class durations of one step measured with HIP events on `stream` (eager launches).
+// out_ms[0..6] = per-step sum of {qkv, o, gate/up, down, lm_head, attention(+combine), other};
+// out_ms[7] = whole step; out_launches[0..6] = launches of that class per step.
+// The sequence state is saved and restored so profiling does not advance the context.
+extern "C" int la_llama_profile(la_llama* m, void* stream, const int32_t* host_in, int iters,
+                                float* out_ms, int32_t* out_launches) {
+    if (!m || !host_in || iters <= 0 || !out_ms) return LA_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int saved[LA_ST_WORDS];
+    HIPCHK(hipMemcpyAsync(m->in, host_in, LA_IN_WORDS * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(saved, m->state, sizeof(saved), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    double acc[KC_N + 1] = {0};
+    int launches[KC_N] = {0};
+    Prof pf; pf.on = true; pf.st = st;
+    for (int it = 0; it < iters; ++it) {
+        pf.used = 0; pf.cls.clear();
+        HIPCHK(hipMemcpyAsync(m->state, saved, sizeof(saved), hipMemcpyHostToDevice, st));
+        int rc = enqueue_step(m, st, &pf);
+        if (rc != LA_OK) return rc;
+        HIPCHK(hipStreamSynchronize(st));
+        for (size_t i = 0; i + 1 < pf.used; ++i) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, pf.ev[i], pf.ev[i + 1]));
+            acc[pf.cls[i]] += ms;
+            if (it == 0) launches[pf.cls[i]]++;
+        }
+        float tot = 0;
+        HIPCHK(hipEventElapsedTime(&tot, pf.ev[0], pf.ev[pf.used - 1]));
+        acc[KC_N] += tot;
+    }
+    HIPCHK(hipMemcpyAsync(m->state, saved, sizeof(saved), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < KC_N; ++i) out_ms[i] = (float)(acc[i] / iters);
+    out_ms[KC_N] = (float)(acc[KC_N] / iters);
+    if (out_launches) for (int i = 0; i < KC_N; ++i) out_launches[i] = launches[i];
+    for (auto e : pf.ev) (void)hipEventDestroy(e);
+    return LA_OK;
+}

@@ -1,0 +1,24 @@
+// la_kernels.h — host-callable launchers of the gfx950 kernels in la_kernels.hip (internal; the
+// public surface is include/lookahead_hip.h).  All return 0 or a hipError_t value.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lookahead_hip.h"
+
+int lk_pack_weight(hipStream_t st, const void* w, const void* w2, int N, int K, int interleave2, void* out);
+int lk_pack_x(hipStream_t st, const void* x, int K, void* out);
+int lk_gemm64_slab(hipStream_t st, const void* wp, const void* xp, int N, int K, int rb, int ksplit, float* slabs);
+int lk_gemm64_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, void* act_xp);
+int lk_gemm64_logits(hipStream_t st, const void* wp, const void* xp, int V, int K, int rb, void* logits, float* cv, int* ci);
+int lk_argmax_finalize(hipStream_t st, const float* cv, const int* ci, int n_tiles, int* state);
+int lk_embed_norm(hipStream_t st, const void* embed, const int* ids, const void* nw, int hidden, float eps, void* h, void* xp);
+int lk_resid_norm(hipStream_t st, void* h, const float* slabs, int n_slabs, const void* nw, int hidden, float eps, void* xp);
+int lk_build_tree_inputs(hipStream_t st, const int* in, int* state, int* pos, uint64_t* rowmask, int* ids);
+int lk_qkv_post(hipStream_t st, const float* slabs, int n_slabs, int nh, int nkv, const int* pos, const void* rcos,
+                const void* rsin, void* qf, void* kfresh, void* vfresh);
+int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
+                 const void* vfresh, const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys,
+                 int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp);
+int lk_accept_scan(hipStream_t st, const int* ids, const uint64_t* rowmask, int* state);
+int lk_kv_commit(hipStream_t st, const void* kfresh, const void* vfresh, void* kmain, void* vmain, const int* state,
+                 int n_layers, int nkv, int max_keys);

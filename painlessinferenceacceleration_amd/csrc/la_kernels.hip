@@ -1,0 +1,697 @@
+// la_kernels.hip — hand-written gfx950 (CDNA4) kernels of the LOOKAHEAD verify step.
+// wave64, v_mfma_f32_32x32x16_bf16, weights streamed HBM -> VGPR in MFMA fragment order.
+// Reference semantics: lookahead/lookahead/models/llama/modeling_llama.py (cited per kernel).
+#include "la_common.h"
+#include "la_kernels.h"
+
+// ---------------------------------------------------------------------------------------------
+// Layout converters (one-off at load time / tests)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_pack_weight(const bf16_t* __restrict__ w, const bf16_t* __restrict__ w2, int N, int K,
+                              int interleave2, bf16_t* __restrict__ out) {
+    // one thread per (tile, lane): 16 B in, 16 B out (coalesced on the write side)
+    const int K16 = K >> 4;
+    const int NB = interleave2 ? (2 * N) >> 5 : N >> 5;
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)NB * K16 * 64;
+    if (gid >= total) return;
+    int lane = (int)(gid & 63);
+    size_t tile = gid >> 6;
+    int kb = (int)(tile % K16);
+    int nb = (int)(tile / K16);
+    const bf16_t* src = w;
+    int row_blk = nb;
+    if (interleave2) { src = (nb & 1) ? w2 : w; row_blk = nb >> 1; }
+    int n = row_blk * 32 + (lane & 31);
+    int k = kb * 16 + (lane >> 5) * 8;
+    bf16x8 v = *(const bf16x8*)(src + (size_t)n * K + k);
+    *(bf16x8*)(out + gid * 8) = v;
+}
+
+__global__ void k_pack_x(const bf16_t* __restrict__ x, int K, bf16_t* __restrict__ out) {
+    int gid = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (t, k8)
+    int K8 = K >> 3;
+    if (gid >= LA_TB * K8) return;
+    int t = gid / K8, k = (gid % K8) * 8;
+    *(bf16x8*)(out + xp_offset(t, k)) = *(const bf16x8*)(x + (size_t)t * K + k);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Skinny GEMM: out[64][N] = x[64][K] . W[N][K]^T, W streamed exactly once from HBM.
+//   grid = (N/(32*RB), ksplit); 8 waves per workgroup split the workgroup's K range, each wave
+//   streams RB row-blocks of W (A operand, nontemporal 1 KiB loads) and the matching x tiles
+//   (B operand, L2-resident), D tiles deep; partial sums are tree-reduced through LDS in a fixed
+//   order (deterministic), then wave 0 runs the epilogue.
+//   Replaces nn.Linear in LlamaAttention/LlamaMLP/lm_head (modeling_llama.py:172-186,222-224,296,769).
+// ---------------------------------------------------------------------------------------------
+enum { EPI_SLAB = 0, EPI_SWIGLU = 1, EPI_LOGITS = 2 };
+
+struct GemmArgs {
+    const bf16_t* wp;
+    const bf16_t* xp;
+    int K16;             // K / 16
+    int N;               // output features (for SWIGLU: ffn, the packed matrix has 2*ffn rows)
+    float* slabs;        // EPI_SLAB: [ksplit][64][N] fp32
+    bf16_t* act_xp;      // EPI_SWIGLU: packed [64][N]
+    bf16_t* logits;      // EPI_LOGITS: [64][N] bf16 row-major or null
+    float* cand_val;     // EPI_LOGITS: [gridDim.x][64]
+    int* cand_idx;
+};
+
+template <int RB, int EPI, int D>
+__global__ __launch_bounds__(512) void k_gemm64(GemmArgs a) {
+    __shared__ float red[4][RB * 2 * 16 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nb0 = blockIdx.x * RB;
+    const int ksplit = gridDim.y, ks = blockIdx.y;
+    const int t0 = (int)(((long)a.K16 * ks) / ksplit);
+    const int t1 = (int)(((long)a.K16 * (ks + 1)) / ksplit);
+    const int twg = t1 - t0, q = twg >> 3, r = twg & 7;
+    const int wb = t0 + wave * q + (wave < r ? wave : r);
+    const int cnt = q + (wave < r ? 1 : 0);
+
+    const bf16x8* wptr[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+        wptr[rb] = (const bf16x8*)(a.wp + ((size_t)(nb0 + rb) * a.K16 + wb) * 512) + lane;
+    const bf16x8* xptr = (const bf16x8*)(a.xp + (size_t)wb * 1024) + lane;
+
+    f32x16 acc[RB][2];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rb][tb][i] = 0.f;
+
+    bf16x8 fa[D][RB], fb[D][2];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        if (d < cnt) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wptr[rb] + (size_t)d * 64);
+            fb[d][0] = xptr[(size_t)d * 128];
+            fb[d][1] = xptr[(size_t)d * 128 + 64];
+        }
+    }
+    for (int t = 0; t < cnt; t += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (t + d < cnt) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][0], acc[rb][0], 0, 0, 0);
+                    acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][1], acc[rb][1], 0, 0, 0);
+                }
+                const int tn = t + d + D;
+                if (tn < cnt) {
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+                        fa[d][rb] = __builtin_nontemporal_load(wptr[rb] + (size_t)tn * 64);
+                    fb[d][0] = xptr[(size_t)tn * 128];
+                    fb[d][1] = xptr[(size_t)tn * 128 + 64];
+                }
+            }
+        }
+    }
+
+    // ---- deterministic cross-wave reduction: (4..7)->(0..3), (2,3)->(0,1), 1->0 -------------
+    auto st = [&](int slot) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) red[slot][((rb * 2 + tb) * 16 + i) * 64 + lane] = acc[rb][tb][i];
+    };
+    auto ad = [&](int slot) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[rb][tb][i] += red[slot][((rb * 2 + tb) * 16 + i) * 64 + lane];
+    };
+    if (wave >= 4) st(wave - 4);
+    __syncthreads();
+    if (wave < 4) ad(wave);
+    __syncthreads();
+    if (wave == 2 || wave == 3) st(wave - 2);
+    __syncthreads();
+    if (wave < 2) ad(wave);
+    __syncthreads();
+    if (wave == 1) st(0);
+    __syncthreads();
+    if (wave != 0) return;
+    ad(0);
+
+    // ---- epilogue (wave 0): lane holds token = tb*32 + (lane&31), features mfma_row(i,lane) ----
+    const int tl = lane & 31, hh = lane >> 5;
+    if constexpr (EPI == EPI_SLAB) {
+        float* o = a.slabs + (size_t)ks * LA_TB * a.N;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {acc[rb][tb][4 * g], acc[rb][tb][4 * g + 1], acc[rb][tb][4 * g + 2], acc[rb][tb][4 * g + 3]};
+                    *(f32x4*)(o + (size_t)(tb * 32 + tl) * a.N + (nb0 + rb) * 32 + 8 * g + 4 * hh) = v;
+                }
+    } else if constexpr (EPI == EPI_SWIGLU) {
+        // acc[0] = gate rows, acc[1] = up rows of the same 32 features (interleaved packing).
+        // act = bf16(silu(bf16(g)) * bf16(u))  — LlamaMLP.forward, modeling_llama.py:185-186
+        static_assert(EPI != EPI_SWIGLU || RB == 2, "swiglu needs gate/up pair");
+        const int jb = blockIdx.x;   // feature block
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 pk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float gv = bfr(acc[0][tb][4 * g + j]);
+                    float uv = bfr(acc[RB - 1][tb][4 * g + j]);
+                    float s = bfr(gv / (1.0f + expf(-gv)));
+                    pk[j] = (short)f2bf(s * uv);
+                }
+                const int f = jb * 32 + 8 * g + 4 * hh;    // 4 consecutive features f..f+3
+                *(bf16x4*)(a.act_xp + xp_offset(tb * 32 + tl, f)) = pk;
+            }
+    } else {
+        // logits rounded to bf16 (lm_head output dtype, modeling_llama.py:769); per-token argmax over this
+        // workgroup's features with lowest-index tie-break (torch.argmax on CPU returns the first maximum).
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            float best = -INFINITY;
+            int bidx = 0x7fffffff;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 pk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bf16_t hv = f2bf(acc[rb][tb][4 * g + j]);
+                        pk[j] = (short)hv;
+                        float v = bf2f(hv);
+                        int idx = (nb0 + rb) * 32 + 8 * g + 4 * hh + j;
+                        if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
+                    }
+                    if (a.logits)
+                        *(bf16x4*)(a.logits + (size_t)(tb * 32 + tl) * a.N + (nb0 + rb) * 32 + 8 * g + 4 * hh) = pk;
+                }
+            float ob = __shfl_xor(best, 32, 64);
+            int oi = __shfl_xor(bidx, 32, 64);
+            if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+            if (hh == 0) {
+                a.cand_val[(size_t)blockIdx.x * LA_TB + tb * 32 + tl] = best;
+                a.cand_idx[(size_t)blockIdx.x * LA_TB + tb * 32 + tl] = bidx;
+            }
+        }
+    }
+}
+
+__global__ void k_argmax_finalize(const float* __restrict__ cv, const int* __restrict__ ci, int n_tiles,
+                                  int* __restrict__ state) {
+    const int t = blockIdx.x, lane = threadIdx.x;   // 64 threads, one token per block
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int i = lane; i < n_tiles; i += 64) {
+        float v = cv[(size_t)i * LA_TB + t];
+        int idx = ci[(size_t)i * LA_TB + t];
+        if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(bidx, o, 64);
+        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    if (lane == 0) state[LA_ST_ARGMAX + t] = bidx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row kernels: embedding gather + RMSNorm, residual add + RMSNorm  (LlamaRMSNorm, :76-90;
+// LlamaDecoderLayer residual adds, :352-363).  One workgroup per token row.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float tot = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return tot;
+}
+
+// h_new = bf16(h + bf16(sum slabs)); x = bf16(w * (h_new * rsqrt(mean(h_new^2)+eps)))  (fp32 math)
+__global__ __launch_bounds__(256) void k_row_norm(const bf16_t* __restrict__ embed, const int* __restrict__ ids,
+                                                   bf16_t* __restrict__ h, const float* __restrict__ slabs,
+                                                   int n_slabs, const bf16_t* __restrict__ nw, int hidden, float eps,
+                                                   bf16_t* __restrict__ xp) {
+    __shared__ float sh[4];
+    const int t = blockIdx.x;
+    const int nchunk = hidden >> 3;                // 8-element chunks in the row
+    float vals[4][8];                              // up to hidden = 8192
+    float ss = 0.f;
+    const bf16_t* src = embed ? embed + (size_t)ids[t] * hidden : h + (size_t)t * hidden;
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+        const int c = threadIdx.x + ci * 256;
+        if (c >= nchunk) continue;
+        bf16x8 hv = *(const bf16x8*)(src + c * 8);
+        float add[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < n_slabs; ++s) {
+            const float* sp = slabs + ((size_t)s * LA_TB + t) * hidden + c * 8;
+            f32x4 a0 = *(const f32x4*)sp, a1 = *(const f32x4*)(sp + 4);
+            add[0] += a0[0]; add[1] += a0[1]; add[2] += a0[2]; add[3] += a0[3];
+            add[4] += a1[0]; add[5] += a1[1]; add[6] += a1[2]; add[7] += a1[3];
+        }
+        bf16x8 ho;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = bf2f((bf16_t)hv[j]);
+            if (n_slabs > 0) v = bfr(v + bfr(add[j]));
+            vals[ci][j] = v;
+            ho[j] = (short)f2bf(v);
+            ss += v * v;
+        }
+        *(bf16x8*)(h + (size_t)t * hidden + c * 8) = ho;
+    }
+    float tot = block_sum_256(ss, sh);
+    float rs = 1.0f / sqrtf(tot / (float)hidden + eps);
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+        const int c = threadIdx.x + ci * 256;
+        if (c >= nchunk) continue;
+        bf16x8 wv = *(const bf16x8*)(nw + c * 8);
+        bf16x8 xo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xo[j] = (short)f2bf(bf2f((bf16_t)wv[j]) * (vals[ci][j] * rs));
+        *(bf16x8*)(xp + xp_offset(t, c * 8)) = xo;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Step-input expansion: ids / rowmask / positions.  Replaces the mask concat of
+// lookahead_prepare_inputs_for_generation (pretrained_model.py:725-734) and the model hook
+// position_ids = mask.sum(-1) - 1 (modeling_llama.py:584-588) without materialising [1,1,T,C+T].
+// ---------------------------------------------------------------------------------------------
+__global__ void k_build_tree_inputs(const int* __restrict__ in, int* __restrict__ state, int* __restrict__ pos,
+                                    unsigned long long* __restrict__ rowmask, int* __restrict__ ids) {
+    const int t = threadIdx.x;   // 64 threads
+    const int T = in[LA_IN_T];
+    const unsigned long long* rmin = (const unsigned long long*)(in + LA_IN_ROWMASK);
+    unsigned long long rm = (t < T) ? rmin[t] : (1ull << t);
+    rowmask[t] = rm;
+    ids[t] = (t < T) ? in[LA_IN_IDS + t] : 0;
+    pos[t] = state[LA_ST_NKEYS] + __popcll(rm) - 1;
+    if (t == 0) { state[LA_ST_T] = T; state[LA_ST_MODE] = in[LA_IN_MODE]; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// QKV post-processing: slab sum -> bf16, RoPE (rotate-half, bf16 arithmetic as apply_rotary_pos_emb,
+// modeling_llama.py:154-169, cos/sin tables cast to bf16 as LlamaRotaryEmbedding.forward :110-126),
+// Q -> QF fragments, K/V of the 64 tree tokens -> fresh KF / VF tiles.
+// grid = nh + 2*nkv head slots, 256 threads.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_qkv_post(const float* __restrict__ slabs, int n_slabs, int nh, int nkv,
+                                                   const int* __restrict__ pos, const bf16_t* __restrict__ rcos,
+                                                   const bf16_t* __restrict__ rsin, bf16_t* __restrict__ qf,
+                                                   bf16_t* __restrict__ kfresh, bf16_t* __restrict__ vfresh) {
+    __shared__ bf16_t sh[LA_TB][128 + 8];
+    const int slot = blockIdx.x;
+    const int N = (nh + 2 * nkv) * 128;
+    // stage [64][128] of this head slot, summed over slabs and rounded to bf16 (the nn.Linear output dtype)
+    for (int i = threadIdx.x; i < LA_TB * 32; i += 256) {
+        int t = i >> 5, c4 = (i & 31) * 4;
+        f32x4 s = {0, 0, 0, 0};
+        for (int sl = 0; sl < n_slabs; ++sl) {
+            f32x4 v = *(const f32x4*)(slabs + ((size_t)sl * LA_TB + t) * N + slot * 128 + c4);
+            s += v;
+        }
+        sh[t][c4] = f2bf(s[0]); sh[t][c4 + 1] = f2bf(s[1]); sh[t][c4 + 2] = f2bf(s[2]); sh[t][c4 + 3] = f2bf(s[3]);
+    }
+    __syncthreads();
+    if (slot < nh + nkv) {
+        bf16_t* dst = slot < nh ? qf + (size_t)slot * 2 * 8 * 512 : kfresh + (size_t)(slot - nh) * 2 * 8 * 512;
+        for (int i = threadIdx.x; i < LA_TB * 16; i += 256) {
+            int t = i >> 4, p = i & 15;
+            int d0 = p * 8, dp = ((p + 8) & 15) * 8;
+            int ps = pos[t];
+            const bf16_t* cs = rcos + (size_t)ps * 64 + (p & 7) * 8;
+            const bf16_t* sn = rsin + (size_t)ps * 64 + (p & 7) * 8;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float x = bf2f(sh[t][d0 + e]);
+                float xr = bf2f(sh[t][dp + e]);
+                if (p < 8) xr = -xr;
+                float a = bfr(x * bf2f(cs[e]));
+                float b = bfr(xr * bf2f(sn[e]));
+                o[e] = (short)f2bf(a + b);
+            }
+            *(bf16x8*)(dst + rf_offset(t, d0)) = o;
+        }
+    } else {
+        bf16_t* dst = vfresh + (size_t)(slot - nh - nkv) * 2 * 8 * 512;
+        for (int i = threadIdx.x; i < 2 * 4 * 2 * 64; i += 256) {
+            int ln = i & 63, s2 = (i >> 6) & 1, db = (i >> 7) & 3, tb = i >> 9;
+            int d = db * 32 + (ln & 31), hh = ln >> 5;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int key = tb * 32 + 16 * s2 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                o[e] = (short)sh[key][d];
+            }
+            *(bf16x8*)(dst + ((size_t)(tb * 8 + db * 2 + s2) * 512 + ln * 8)) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tree attention (LlamaAttention.forward, modeling_llama.py:270-296, under the rank-4 mask hook).
+//   S^T = K.Q^T (swapped so a lane owns one token column: softmax reductions stay in-lane + one
+//   xor-32), prefix keys mask-free from the packed main cache, the 64 fresh keys under the 64-bit
+//   ancestor row mask; online softmax in fp32; O^T += V^T.P^T with P^T taken from the S^T
+//   accumulator registers in place (VF key order).  grid = (heads, key splits), 4 waves:
+//   wave = (token block, key-tile parity).
+// ---------------------------------------------------------------------------------------------
+struct AttnArgs {
+    const bf16_t* qf;
+    const bf16_t* kmain;
+    const bf16_t* vmain;
+    const bf16_t* kfresh;
+    const bf16_t* vfresh;
+    const unsigned long long* rowmask;
+    const int* state;
+    int nh, nkv, max_keys, nsplit;
+    float* opart;   // [nh][nsplit][64][128]
+    float* mpart;   // [nh][nsplit][64]
+    float* lpart;
+};
+
+#define LA_NEG (-1.0e30f)
+
+__global__ __launch_bounds__(256) void k_tree_attn(AttnArgs a) {
+    __shared__ float mg[2][66][64];   // merge buffer: per token block, 64 O regs + m + l per lane
+    const int h = blockIdx.x, sp = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tb = wave & 1, par = wave >> 1;
+    const int hk = h / (a.nh / a.nkv);
+    const int KB = a.max_keys >> 5;
+    const int nkeys = a.state[LA_ST_NKEYS];
+    const int NP = (nkeys + 31) >> 5, NT = NP + 2;
+    const int i0 = (NT * sp) / a.nsplit, i1 = (NT * (sp + 1)) / a.nsplit;
+
+    bf16x8 q[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) q[s] = *((const bf16x8*)(a.qf + ((size_t)(h * 2 + tb) * 8 + s) * 512) + lane);
+    const unsigned long long rm = a.rowmask[tb * 32 + (lane & 31)];
+    const int hh = lane >> 5;
+
+    f32x16 o[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+    float m = LA_NEG, l = 0.f;
+
+    for (int it = i0 + par; it < i1; it += 2) {
+        const bool fresh = it >= NP;
+        const int kb = fresh ? it - NP : it;
+        const bf16x8* kt = fresh ? (const bf16x8*)(a.kfresh + ((size_t)hk * 2 + kb) * 4096)
+                                 : (const bf16x8*)(a.kmain + ((size_t)hk * KB + kb) * 4096);
+        const bf16x8* vt = fresh ? (const bf16x8*)(a.vfresh + ((size_t)hk * 2 + kb) * 4096)
+                                 : (const bf16x8*)(a.vmain + ((size_t)hk * KB + kb) * 4096);
+        bf16x8 kf[8], vf[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) kf[s] = kt[s * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) vf[s] = vt[s * 64 + lane];
+        f32x16 sc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], q[s], sc, 0, 0, 0);
+        // attn_weights = bf16(QK^T) / sqrt(head_dim) -> bf16 (modeling_llama.py:270), masked keys excluded
+        float mx = LA_NEG;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kk = (i & 3) + 8 * (i >> 2) + 4 * hh;
+            float v = bfr(__fdiv_rn(bfr(sc[i]), 11.313708498984761f));
+            const bool ok = fresh ? ((rm >> (kb * 32 + kk)) & 1ull) != 0ull : (kb * 32 + kk) < nkeys;
+            v = ok ? v : LA_NEG;
+            sc[i] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float alpha = __expf(m - mn);
+        float ps = 0.f;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float p = (sc[i] > -1.0e29f) ? __expf(sc[i] - mn) : 0.f;
+            bf16_t pb = f2bf(p);
+            ps += p;
+            pf[i >> 3][i & 7] = (short)pb;
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        l = l * alpha + ps;
+        m = mn;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db * 2 + 0], pf[0], o[db], 0, 0, 0);
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db * 2 + 1], pf[1], o[db], 0, 0, 0);
+        }
+    }
+
+    // merge the two key-parity waves of each token block (fixed order), wave par==0 writes the partial
+    if (par == 1) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mg[tb][db * 16 + i][lane] = o[db][i];
+        mg[tb][64][lane] = m;
+        mg[tb][65][lane] = l;
+    }
+    __syncthreads();
+    if (par == 1) return;
+    {
+        const float m1 = mg[tb][64][lane], l1 = mg[tb][65][lane];
+        const float M = fmaxf(m, m1);
+        const float a0 = __expf(m - M), a1 = __expf(m1 - M);
+        l = l * a0 + l1 * a1;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[db][i] = o[db][i] * a0 + mg[tb][db * 16 + i][lane] * a1;
+        m = M;
+    }
+    const int tok = tb * 32 + (lane & 31);
+    float* op = a.opart + (((size_t)h * a.nsplit + sp) * LA_TB + tok) * 128;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = {o[db][4 * g], o[db][4 * g + 1], o[db][4 * g + 2], o[db][4 * g + 3]};
+            *(f32x4*)(op + db * 32 + 8 * g + 4 * hh) = v;
+        }
+    if (hh == 0) {
+        a.mpart[((size_t)h * a.nsplit + sp) * LA_TB + tok] = m;
+        a.lpart[((size_t)h * a.nsplit + sp) * LA_TB + tok] = l;
+    }
+}
+
+// merge key splits, normalise, round to bf16 (attn_output dtype) and emit the packed operand of o_proj
+__global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ opart, const float* __restrict__ mpart,
+                                                       const float* __restrict__ lpart, int nh, int nsplit,
+                                                       bf16_t* __restrict__ attn_xp) {
+    int gid = blockIdx.x * 256 + threadIdx.x;   // (h, tok, d8)
+    if (gid >= nh * LA_TB * 16) return;
+    int d8 = gid & 15, tok = (gid >> 4) & 63, h = gid >> 10;
+    float M = LA_NEG;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, mpart[((size_t)h * nsplit + s) * LA_TB + tok]);
+    float L = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < nsplit; ++s) {
+        float w = __expf(mpart[((size_t)h * nsplit + s) * LA_TB + tok] - M);
+        L += w * lpart[((size_t)h * nsplit + s) * LA_TB + tok];
+        const float* op = opart + (((size_t)h * nsplit + s) * LA_TB + tok) * 128 + d8 * 8;
+        f32x4 a0 = *(const f32x4*)op, a1 = *(const f32x4*)(op + 4);
+        acc[0] += w * a0[0]; acc[1] += w * a0[1]; acc[2] += w * a0[2]; acc[3] += w * a0[3];
+        acc[4] += w * a1[0]; acc[5] += w * a1[1]; acc[6] += w * a1[2]; acc[7] += w * a1[3];
+    }
+    float inv = 1.0f / L;
+    bf16x8 ov;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ov[j] = (short)f2bf(acc[j] * inv);
+    *(bf16x8*)(attn_xp + xp_offset(tok, h * 128 + d8 * 8)) = ov;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Accept scan (one wavefront).  _lookahead_update_model_kwargs_for_generation, pretrained_model.py:806-880
+// with an empty logits-processor list: walk from the root, at each accepted node take the child whose
+// draft token equals that node's argmax (lowest row index = the reference's first surviving branch);
+// emitted tokens = argmax along the path (matches + 1 bonus).  mode 1 (prefill chain): commit all T rows
+// and emit argmax of the last row (pretrained_model.py:783-798).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_accept_scan(const int* __restrict__ ids, const unsigned long long* __restrict__ rowmask,
+                              int* __restrict__ state) {
+    const int j = threadIdx.x;   // 64 threads
+    const int T = state[LA_ST_T], mode = state[LA_ST_MODE];
+    const int nkeys = state[LA_ST_NKEYS];
+    const int am = state[LA_ST_ARGMAX + j];
+    int n_commit;
+    if (mode == 1) {
+        if (j < T) state[LA_ST_SRCIDX + j] = j;
+        const int last = __shfl(am, T - 1, 64);   // executed by all lanes
+        if (j == 0) { state[LA_ST_OUTTOK] = last; state[LA_ST_NOUT] = 1; }
+        n_commit = T;
+    } else {
+        const unsigned long long rm = rowmask[j];
+        const unsigned long long below = rm & ((1ull << j) - 1ull);
+        const int parent = (j == 0 || below == 0ull) ? -1 : 63 - __clzll(below);
+        const int myid = ids[j];
+        int cur = 0, depth = 0;
+        if (j == 0) { state[LA_ST_SRCIDX] = 0; }
+        while (true) {
+            const int want = __shfl(am, cur, 64);
+            if (j == 0) state[LA_ST_OUTTOK + depth] = want;
+            const unsigned long long cand = __ballot(j < T && j > 0 && parent == cur && myid == want);
+            if (cand == 0ull) break;
+            cur = __ffsll((long long)cand) - 1;
+            ++depth;
+            if (j == 0) state[LA_ST_SRCIDX + depth] = cur;
+        }
+        if (j == 0) state[LA_ST_NOUT] = depth + 1;
+        n_commit = depth + 1;
+    }
+    if (j == 0) {
+        state[LA_ST_DSTBASE] = nkeys;
+        state[LA_ST_NCOMMIT] = n_commit;
+        state[LA_ST_NKEYS] = nkeys + n_commit;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// KV commit: accepted fresh rows -> main cache rows DSTBASE.. for every layer and kv head.
+// Replaces _update_cache_with_axis_2 (pretrained_model.py:894-907); moves only the accepted rows
+// (<= branch_length+1) instead of re-materialising the cache.  grid = layers*nkv, 256 threads.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_kv_commit(const bf16_t* __restrict__ kfresh, const bf16_t* __restrict__ vfresh,
+                                                    bf16_t* __restrict__ kmain, bf16_t* __restrict__ vmain,
+                                                    const int* __restrict__ state, int nkv, int max_keys) {
+    const int lh = blockIdx.x;               // layer * nkv + kv head
+    const int n = state[LA_ST_NCOMMIT], base = state[LA_ST_DSTBASE];
+    const size_t KB = (size_t)(max_keys >> 5);
+    const bf16_t* kf = kfresh + (size_t)lh * 2 * 4096;
+    const bf16_t* vf = vfresh + (size_t)lh * 2 * 4096;
+    bf16_t* km = kmain + (size_t)lh * KB * 4096;
+    bf16_t* vm = vmain + (size_t)lh * KB * 4096;
+    for (int i = threadIdx.x; i < n * 16; i += 256) {
+        int r = i >> 4, p = i & 15;
+        int src = state[LA_ST_SRCIDX + r], dst = base + r;
+        if (dst >= max_keys) continue;
+        *(bf16x8*)(km + rf_offset(dst, p * 8)) = *(const bf16x8*)(kf + rf_offset(src, p * 8));
+    }
+    for (int i = threadIdx.x; i < n * 128; i += 256) {
+        int r = i >> 7, d = i & 127;
+        int src = state[LA_ST_SRCIDX + r], dst = base + r;
+        if (dst >= max_keys) continue;
+        vm[vf_offset(dst, d)] = vf[vf_offset(src, d)];
+    }
+}
+
+// =============================================================================================
+// launchers
+// =============================================================================================
+#define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+int lk_pack_weight(hipStream_t st, const void* w, const void* w2, int N, int K, int il, void* out) {
+    size_t total = (size_t)(il ? 2 * N : N) / 32 * (K / 16) * 64;
+    k_pack_weight<<<(unsigned)((total + 255) / 256), 256, 0, st>>>((const bf16_t*)w, (const bf16_t*)w2, N, K, il, (bf16_t*)out);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_pack_x(hipStream_t st, const void* x, int K, void* out) {
+    int total = LA_TB * (K / 8);
+    k_pack_x<<<(total + 255) / 256, 256, 0, st>>>((const bf16_t*)x, K, (bf16_t*)out);
+    LAUNCH_CHECK(); return 0;
+}
+
+template <int RB, int EPI>
+static int launch_gemm(hipStream_t st, const GemmArgs& a, int nblocks, int ksplit) {
+    dim3 g(nblocks, ksplit);
+    k_gemm64<RB, EPI, (RB == 2 ? 4 : 6)><<<g, 512, 0, st>>>(a);
+    LAUNCH_CHECK(); return 0;
+}
+
+int lk_gemm64_slab(hipStream_t st, const void* wp, const void* xp, int N, int K, int rb, int ksplit, float* slabs) {
+    GemmArgs a{}; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = N; a.slabs = slabs;
+    if (rb == 2 && (N % 64) == 0) return launch_gemm<2, EPI_SLAB>(st, a, N / 64, ksplit);
+    return launch_gemm<1, EPI_SLAB>(st, a, N / 32, ksplit);
+}
+int lk_gemm64_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, void* act_xp) {
+    GemmArgs a{}; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = F; a.act_xp = (bf16_t*)act_xp;
+    return launch_gemm<2, EPI_SWIGLU>(st, a, F / 32, 1);
+}
+int lk_gemm64_logits(hipStream_t st, const void* wp, const void* xp, int V, int K, int rb, void* logits,
+                     float* cv, int* ci) {
+    GemmArgs a{}; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = V;
+    a.logits = (bf16_t*)logits; a.cand_val = cv; a.cand_idx = ci;
+    if (rb == 2 && (V % 64) == 0) return launch_gemm<2, EPI_LOGITS>(st, a, V / 64, 1);
+    return launch_gemm<1, EPI_LOGITS>(st, a, V / 32, 1);
+}
+int lk_argmax_finalize(hipStream_t st, const float* cv, const int* ci, int n_tiles, int* state) {
+    k_argmax_finalize<<<LA_TB, 64, 0, st>>>(cv, ci, n_tiles, state);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_embed_norm(hipStream_t st, const void* embed, const int* ids, const void* nw, int hidden, float eps, void* h, void* xp) {
+    if (hidden > 8192 || (hidden & 7)) return -1;
+    k_row_norm<<<LA_TB, 256, 0, st>>>((const bf16_t*)embed, ids, (bf16_t*)h, nullptr, 0, (const bf16_t*)nw, hidden, eps, (bf16_t*)xp);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_resid_norm(hipStream_t st, void* h, const float* slabs, int n_slabs, const void* nw, int hidden, float eps, void* xp) {
+    if (hidden > 8192 || (hidden & 7)) return -1;
+    k_row_norm<<<LA_TB, 256, 0, st>>>(nullptr, nullptr, (bf16_t*)h, slabs, n_slabs, (const bf16_t*)nw, hidden, eps, (bf16_t*)xp);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_build_tree_inputs(hipStream_t st, const int* in, int* state, int* pos, uint64_t* rowmask, int* ids) {
+    k_build_tree_inputs<<<1, 64, 0, st>>>(in, state, pos, (unsigned long long*)rowmask, ids);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_qkv_post(hipStream_t st, const float* slabs, int n_slabs, int nh, int nkv, const int* pos, const void* rcos,
+                const void* rsin, void* qf, void* kfresh, void* vfresh) {
+    k_qkv_post<<<nh + 2 * nkv, 256, 0, st>>>(slabs, n_slabs, nh, nkv, pos, (const bf16_t*)rcos, (const bf16_t*)rsin,
+                                             (bf16_t*)qf, (bf16_t*)kfresh, (bf16_t*)vfresh);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
+                 const void* vfresh, const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys,
+                 int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp) {
+    AttnArgs a{};
+    a.qf = (const bf16_t*)qf; a.kmain = (const bf16_t*)kmain; a.vmain = (const bf16_t*)vmain;
+    a.kfresh = (const bf16_t*)kfresh; a.vfresh = (const bf16_t*)vfresh;
+    a.rowmask = (const unsigned long long*)rowmask; a.state = state;
+    a.nh = nh; a.nkv = nkv; a.max_keys = max_keys; a.nsplit = nsplit;
+    a.opart = opart; a.mpart = mpart; a.lpart = lpart;
+    k_tree_attn<<<dim3(nh, nsplit), 256, 0, st>>>(a);
+    LAUNCH_CHECK();
+    int total = nh * LA_TB * 16;
+    k_attn_combine<<<(total + 255) / 256, 256, 0, st>>>(opart, mpart, lpart, nh, nsplit, (bf16_t*)attn_xp);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_accept_scan(hipStream_t st, const int* ids, const uint64_t* rowmask, int* state) {
+    k_accept_scan<<<1, 64, 0, st>>>(ids, (const unsigned long long*)rowmask, state);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_kv_commit(hipStream_t st, const void* kfresh, const void* vfresh, void* kmain, void* vmain, const int* state,
+                 int n_layers, int nkv, int max_keys) {
+    k_kv_commit<<<n_layers * nkv, 256, 0, st>>>((const bf16_t*)kfresh, (const bf16_t*)vfresh, (bf16_t*)kmain,
+                                                (bf16_t*)vmain, state, nkv, max_keys);
+    LAUNCH_CHECK(); return 0;
+}

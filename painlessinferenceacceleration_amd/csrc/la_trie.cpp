@@ -1,0 +1,650 @@
+// la_trie.cpp — host trie cache behind the la_cache_* C ABI.
+//
+// Semantics follow lookahead/lookahead/common/lookahead_cache.py of the reference, restated on an
+// index arena (no Python objects): every quirk that changes a returned draft is reproduced and
+// tagged with the reference line it comes from.  Children keep dict insertion order through a
+// sibling list; lookups go through one hash index keyed by (parent node, token).
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+#include "../../include/lookahead_hip.h"
+
+extern void la_set_error(const std::string& s);
+
+namespace {
+
+struct Node {
+    int32_t token;
+    int32_t parent;        // node index, -1 for a tree root
+    int32_t first_child, last_child, next_sib, prev_sib;
+    double fo;             // freqs[-1]
+    std::vector<std::pair<int32_t, double>> fi;   // freqs[idx>=0], tiny
+};
+
+struct Tree {
+    int32_t token;
+    int32_t root;          // arena node whose children are Tree.nodes
+    int64_t max_node, max_output_node;   // captured at creation (lookahead_cache.py:365)
+    int64_t n_node, n_output_node;
+    int64_t uid;
+};
+
+static inline uint64_t key_of(int32_t parent, int32_t token) {
+    return ((uint64_t)(uint32_t)parent << 32) | (uint32_t)token;
+}
+
+}  // namespace
+
+struct la_cache {
+    int64_t max_node, max_output_node;
+    std::vector<int32_t> eos;            // empty <=> [None]
+    std::unordered_set<int32_t> stop_words;
+    std::vector<Node> nodes;
+    std::vector<int32_t> free_nodes;
+    std::unordered_map<uint64_t, int32_t> child_index;
+    std::unordered_map<int32_t, int32_t> mem;          // token -> tree slot
+    std::vector<Tree> trees;
+    std::vector<int32_t> free_trees;
+    std::unordered_map<int64_t, int32_t> live_by_uid;  // uid -> tree slot
+    std::unordered_set<int64_t> update_trees, update_input_trees;   // sets of Tree objects (by uid)
+    std::unordered_map<int32_t, std::vector<int32_t>> output_ids;   // _output_ids[idx]
+    int64_t next_uid = 1;
+    int64_t live_nodes = 0;
+
+    // ---- arena ----
+    int32_t new_node(int32_t token, int32_t parent) {
+        int32_t id;
+        if (!free_nodes.empty()) { id = free_nodes.back(); free_nodes.pop_back(); }
+        else { id = (int32_t)nodes.size(); nodes.emplace_back(); }
+        Node& n = nodes[id];
+        n.token = token; n.parent = parent;
+        n.first_child = n.last_child = n.next_sib = n.prev_sib = -1;
+        n.fo = 0.0; n.fi.clear();
+        return id;
+    }
+    void link_child(int32_t parent, int32_t child) {
+        Node& p = nodes[parent];
+        Node& c = nodes[child];
+        c.prev_sib = p.last_child; c.next_sib = -1;
+        if (p.last_child >= 0) nodes[p.last_child].next_sib = child; else p.first_child = child;
+        p.last_child = child;
+        child_index[key_of(parent, c.token)] = child;
+        ++live_nodes;
+    }
+    int32_t find_child(int32_t parent, int32_t token) const {
+        auto it = child_index.find(key_of(parent, token));
+        return it == child_index.end() ? -1 : it->second;
+    }
+    // delete `child` and its whole subtree (dict.pop of a Node drops everything below it)
+    void drop_subtree(int32_t child) {
+        Node& c = nodes[child];
+        Node& p = nodes[c.parent];
+        if (c.prev_sib >= 0) nodes[c.prev_sib].next_sib = c.next_sib; else p.first_child = c.next_sib;
+        if (c.next_sib >= 0) nodes[c.next_sib].prev_sib = c.prev_sib; else p.last_child = c.prev_sib;
+        child_index.erase(key_of(c.parent, c.token));
+        std::vector<int32_t> stack{child};
+        bool top = true;
+        while (!stack.empty()) {
+            int32_t n = stack.back(); stack.pop_back();
+            for (int32_t ch = nodes[n].first_child; ch >= 0; ch = nodes[ch].next_sib) stack.push_back(ch);
+            if (!top) child_index.erase(key_of(nodes[n].parent, nodes[n].token));
+            top = false;
+            nodes[n].fi.clear(); nodes[n].fi.shrink_to_fit();
+            nodes[n].first_child = nodes[n].last_child = -1;
+            free_nodes.push_back(n);
+            --live_nodes;
+        }
+    }
+    static double get_fi(const Node& n, int32_t idx) {
+        if (idx == -1) return n.fo;               // freqs is one dict: idx -1 aliases the output slot
+        for (auto& p : n.fi) if (p.first == idx) return p.second;
+        return 0.0;
+    }
+    static void add_freq(Node& n, int32_t idx, double f) {
+        if (idx == -1) { n.fo += f; return; }
+        for (auto& p : n.fi) if (p.first == idx) { p.second += f; return; }
+        n.fi.emplace_back(idx, f);
+    }
+    static void set_fi(Node& n, int32_t idx, double f) {
+        if (idx == -1) { n.fo = f; return; }
+        for (auto& p : n.fi) if (p.first == idx) { p.second = f; return; }
+        n.fi.emplace_back(idx, f);
+    }
+
+    // ---- Tree ----
+    int32_t tree_get_or_create(int32_t token, bool* created) {
+        auto it = mem.find(token);
+        if (it != mem.end()) { *created = false; return it->second; }
+        int32_t slot;
+        if (!free_trees.empty()) { slot = free_trees.back(); free_trees.pop_back(); }
+        else { slot = (int32_t)trees.size(); trees.emplace_back(); }
+        Tree& t = trees[slot];
+        t.token = token; t.root = new_node(token, -1);
+        t.max_node = max_node; t.max_output_node = max_output_node;
+        t.n_node = 0; t.n_output_node = 0; t.uid = next_uid++;
+        mem[token] = slot;
+        live_by_uid[t.uid] = slot;
+        *created = true;
+        return slot;
+    }
+    // Tree.put/_put/_pack (lookahead_cache.py:33-63)
+    void tree_put(Tree& t, const int32_t* toks, int n, bool output_mode, int32_t idx) {
+        if (output_mode) idx = -1;                                  // :35-36
+        int32_t cur = t.root;
+        for (int i = 0; i < n; ++i) {
+            int32_t ch = find_child(cur, toks[i]);
+            if (ch < 0) {                                           // :45-51 pack the rest as a chain
+                for (int j = i; j < n; ++j) {
+                    int32_t nn = new_node(toks[j], cur);
+                    link_child(cur, nn);
+                    add_freq(nodes[nn], idx, 1.0);
+                    cur = nn;
+                }
+                t.n_node += n - i;
+                if (output_mode) t.n_output_node += n - i;
+                return;
+            }
+            add_freq(nodes[ch], idx, 1.0);                          // :53
+            cur = ch;
+        }
+    }
+
+    struct Thresholds { double min_in, min_out, min_mix, output_weight; };
+
+    // _dfs_get_freqs (:146-154): rows of live nodes reachable through live nodes
+    void dfs_freqs(int32_t parent, int32_t idx, std::vector<double>& fis, std::vector<double>& fos) const {
+        std::vector<int32_t> stack;
+        // iterative pre-order; row order does not matter for the thresholds (only k-th largest values do)
+        for (int32_t ch = nodes[parent].first_child; ch >= 0; ch = nodes[ch].next_sib) stack.push_back(ch);
+        while (!stack.empty()) {
+            int32_t n = stack.back(); stack.pop_back();
+            const Node& nd = nodes[n];
+            double fo = nd.fo, fi = get_fi(nd, idx);
+            if (fo > 0 || fi > 0) {
+                fis.push_back(fi); fos.push_back(fo);
+                for (int32_t ch = nd.first_child; ch >= 0; ch = nodes[ch].next_sib) stack.push_back(ch);
+            }
+        }
+    }
+    // value at position (k-1) of the descending sort; Python's negative index for k==0 -> the minimum
+    static double kth_desc(std::vector<double> v, int k) {
+        size_t pos = (k <= 0) ? v.size() - 1 : (size_t)(k - 1);
+        if (pos >= v.size()) pos = v.size() - 1;   // the reference would raise IndexError here
+        std::nth_element(v.begin(), v.begin() + pos, v.end(), std::greater<double>());
+        return v[pos];
+    }
+
+    struct Out {
+        int cap; int32_t* ids; int32_t* parent; std::vector<std::vector<uint64_t>>* rows; int n;
+        int32_t sizes[2];
+    };
+
+    // _ravel (:248-293)
+    void ravel(int32_t parent_node, int pid, int max_size, int max_length, const Thresholds& th, int mode,
+               int32_t idx, Out& o) const {
+        if (o.n >= max_size || max_length <= 0) return;
+        struct Ent { int32_t node; double fm; };
+        std::vector<Ent> sorts;
+        for (int32_t ch = nodes[parent_node].first_child; ch >= 0; ch = nodes[ch].next_sib) {
+            const Node& nd = nodes[ch];
+            double fm = (1.0 - th.output_weight) * get_fi(nd, idx) + th.output_weight * nd.fo;   // :254
+            sorts.push_back({ch, fm});
+        }
+        std::stable_sort(sorts.begin(), sorts.end(), [](const Ent& a, const Ent& b) { return a.fm > b.fm; });
+        for (const Ent& e : sorts) {
+            if (o.n >= max_size) return;                                                         // :260
+            const Node& nd = nodes[e.node];
+            double fi = get_fi(nd, idx), fo = nd.fo;
+            if (mode == LA_MODE_MIX) {
+                if (fi < th.min_in && fo < th.min_out && e.fm < th.min_mix) continue;            // :265
+            } else if (mode == LA_MODE_INPUT) {
+                if (fi < th.min_in) continue;
+            } else {
+                if (fo < th.min_out) continue;
+            }
+            if (fi > 0.0) o.sizes[0]++;
+            if (fo > 0.0) o.sizes[1]++;
+            int rid = o.n++;
+            o.ids[rid] = nd.token;
+            o.parent[rid] = pid > -1 ? pid : 0;
+            std::vector<uint64_t>& row = (*o.rows)[rid];
+            if (pid > -1) row = (*o.rows)[pid]; else { std::fill(row.begin(), row.end(), 0); row[0] = 1; }
+            row[rid >> 6] |= 1ull << (rid & 63);
+            if (nd.first_child >= 0)
+                ravel(e.node, rid, max_size, max_length - 1, th, mode, idx, o);
+        }
+    }
+
+    // Tree._match (:224-246): returns the node whose children are `nodes`, or -1 for an empty dict
+    int32_t match(const Tree& t, const int32_t* q, int nq, int mode, int32_t idx, bool* have_tok, int32_t* tok) const {
+        *have_tok = false;
+        if (nq == 0) return t.root;
+        int32_t cur = t.root;
+        for (int i = 0; i < nq; ++i) {
+            *have_tok = true; *tok = q[i];
+            if (cur < 0) return -1;                      // nodes = {} -> next get() is None -> break
+            int32_t ch = find_child(cur, q[i]);
+            if (ch < 0) return -1;
+            const Node& nd = nodes[ch];
+            bool live;
+            if (mode == LA_MODE_INPUT) live = get_fi(nd, idx) > 0;
+            else if (mode == LA_MODE_OUTPUT) live = nd.fo > 0;
+            else live = get_fi(nd, idx) > 0 || nd.fo > 0;
+            cur = live ? ch : -1;
+        }
+        return cur;
+    }
+
+    // Tree.get (:65-144).  Returns number of ids written.
+    int tree_get(const Tree& t, const int32_t* q, int nq, int max_size, int max_length, int min_input_size,
+                 int min_output_size, int mode, int32_t idx, Out& o) const {
+        bool have_tok; int32_t tok = 0;
+        int32_t at = match(t, q, nq, mode, idx, &have_tok, &tok);
+        o.n = 0; o.sizes[0] = o.sizes[1] = 0;
+        auto single = [&](int32_t token) {
+            o.ids[0] = token; o.parent[0] = -1;
+            std::fill((*o.rows)[0].begin(), (*o.rows)[0].end(), 0); (*o.rows)[0][0] = 1;
+            o.n = 1;
+            return 1;
+        };
+        if (at < 0 || nodes[at].first_child < 0)                   // len(nodes) == 0  (:70-72)
+            return single(nq > 0 ? q[nq - 1] : t.token);
+
+        std::vector<double> fis, fos;
+        dfs_freqs(at, idx, fis, fos);
+        Thresholds th{1e9, 1e9, 1e9, 1e-4};
+        const size_t rows = fis.size();
+        if (mode == LA_MODE_INPUT) {
+            th.output_weight = 0.0;
+            size_t size = 0; for (double f : fis) if (f > 0) ++size;
+            if ((int64_t)size > max_size) th.min_in = kth_desc(fis, min_input_size); else th.min_in = 0.0;
+        } else if (mode == LA_MODE_OUTPUT) {
+            th.output_weight = 1.0;
+            size_t size = 0; for (double f : fos) if (f > 0) ++size;
+            if ((int64_t)size > max_size) th.min_out = kth_desc(fos, min_output_size); else th.min_out = 0.0;
+        } else {
+            if ((int64_t)rows > max_size) {
+                // every row's index slot is None (:152), so `indices` collapses to {None} and the mix loop
+                // (:111-123) never assigns min_mix_freq: it stays 1e9.
+                if (min_input_size > 0) th.min_in = kth_desc(fis, min_input_size);
+                if (min_output_size > 0) th.min_out = kth_desc(fos, min_output_size);
+            } else {
+                th.min_mix = 0.0;                                                               // :125
+            }
+        }
+        // ids[0] = match_token_id or self.token_id (:129): token 0 is falsy
+        int32_t root_tok = (have_tok && tok != 0) ? tok : t.token;
+        if (max_size <= 0) { o.n = 0; return 0; }
+        single(root_tok);
+        o.parent[0] = -1;
+        ravel(at, -1, max_size, max_length, th, mode, idx, o);
+        return o.n;
+    }
+
+    // squeeze (:295-318)
+    void squeeze_rec(int32_t parent) {
+        int32_t ch = nodes[parent].first_child;
+        while (ch >= 0) {
+            int32_t next = nodes[ch].next_sib;
+            if (nodes[ch].fo > 1.0) {
+                nodes[ch].fo *= 0.5;
+                if (nodes[ch].first_child >= 0) squeeze_rec(ch);
+            } else {
+                drop_subtree(ch);
+            }
+            ch = next;
+        }
+    }
+    int64_t count_nodes(int32_t parent) const {
+        int64_t n = 0;
+        std::vector<int32_t> stack{parent};
+        while (!stack.empty()) {
+            int32_t p = stack.back(); stack.pop_back();
+            for (int32_t ch = nodes[p].first_child; ch >= 0; ch = nodes[ch].next_sib) { ++n; stack.push_back(ch); }
+        }
+        return n;
+    }
+    void tree_squeeze(Tree& t) {
+        if (t.n_node > t.max_node || t.n_output_node > t.max_output_node) {
+            squeeze_rec(t.root);
+            int64_t c = count_nodes(t.root);
+            t.n_node = c; t.n_output_node = c;                     // :300-301
+        }
+    }
+    // reset_input_freq (:320-333): stops descending where the slot is already 0
+    void reset_rec(int32_t parent, int32_t idx) {
+        std::vector<int32_t> stack{parent};
+        while (!stack.empty()) {
+            int32_t p = stack.back(); stack.pop_back();
+            for (int32_t ch = nodes[p].first_child; ch >= 0; ch = nodes[ch].next_sib) {
+                double f = get_fi(nodes[ch], idx);
+                if (f == 0.0) continue;
+                set_fi(nodes[ch], idx, 0.0);
+                if (nodes[ch].first_child >= 0) stack.push_back(ch);
+            }
+        }
+    }
+
+    void reset_input_freqs(int32_t idx) {                          // :566-570
+        for (int64_t uid : update_input_trees) {
+            auto it = live_by_uid.find(uid);
+            if (it != live_by_uid.end()) reset_rec(trees[it->second].root, idx);
+        }
+        update_input_trees.clear();
+    }
+    void squeeze_branch_counts() {                                 // :572-576
+        if (update_trees.size() >= 1024) {
+            for (int64_t uid : update_trees) {
+                auto it = live_by_uid.find(uid);
+                if (it != live_by_uid.end()) tree_squeeze(trees[it->second]);
+            }
+            update_trees.clear();
+        }
+    }
+    void truncate_eos(const int32_t* toks, int& n) const {          // :350-352
+        for (int32_t e : eos)
+            for (int i = 0; i < n; ++i) if (toks[i] == e) { n = i; break; }
+    }
+};
+
+extern "C" {
+
+la_cache* la_cache_create(int max_node, int max_output_node) {
+    la_cache* c = new la_cache();
+    c->max_node = max_node; c->max_output_node = max_output_node;
+    c->eos.push_back(2);
+    return c;
+}
+void la_cache_destroy(la_cache* c) { delete c; }
+
+int la_cache_set_limits(la_cache* c, int max_node, int max_output_node) {
+    if (!c) return LA_E_ARG;
+    c->max_node = max_node; c->max_output_node = max_output_node;
+    return LA_OK;
+}
+int la_cache_set_eos(la_cache* c, const int32_t* eos_ids, int n) {
+    if (!c || n < 0 || (n > 0 && !eos_ids)) return LA_E_ARG;
+    c->eos.assign(eos_ids, eos_ids + n);
+    return LA_OK;
+}
+int la_cache_set_stop_words(la_cache* c, const int32_t* ids, int n) {
+    if (!c || n < 0 || (n > 0 && !ids)) return LA_E_ARG;
+    c->stop_words.clear();
+    for (int i = 0; i < n; ++i) c->stop_words.insert(ids[i]);
+    return LA_OK;
+}
+int la_cache_fresh(la_cache* c) {
+    if (!c) return LA_E_ARG;
+    // self.mem = {} : trees die, the dirty sets keep their (now dead) members, stream buffers stay
+    c->mem.clear(); c->live_by_uid.clear();
+    c->nodes.clear(); c->free_nodes.clear(); c->child_index.clear();
+    c->trees.clear(); c->free_trees.clear();
+    c->live_nodes = 0;
+    return LA_OK;
+}
+
+int la_cache_put(la_cache* c, const int32_t* toks, int n, int branch_length, int final_, int mode, int idx) {
+    if (!c || n < 0 || (n > 0 && !toks)) return LA_E_ARG;
+    if (mode != LA_MODE_INPUT && mode != LA_MODE_OUTPUT) { la_set_error("put: mode must be input|output"); return LA_E_ARG; }
+    c->truncate_eos(toks, n);
+    if (n >= 2) {
+        for (int i = 0; i < n - 1; ++i) {
+            int len = std::min(branch_length, n - (i + 1));
+            if (len < 0) len = 0;
+            bool created;
+            int32_t slot = c->tree_get_or_create(toks[i], &created);
+            Tree& t = c->trees[slot];
+            c->tree_put(t, toks + i + 1, len, mode == LA_MODE_OUTPUT, idx);
+            if (!created) c->update_trees.insert(t.uid);            // :361-367: new trees are not marked
+            if (mode == LA_MODE_INPUT) c->update_input_trees.insert(t.uid);
+        }
+    }
+    if (final_) { c->reset_input_freqs(idx); c->squeeze_branch_counts(); }
+    return LA_OK;
+}
+
+int la_cache_stream_put(la_cache* c, const int32_t* toks, int n, int branch_length, int final_, int idx) {
+    if (!c || n < 0 || (n > 0 && !toks)) return LA_E_ARG;
+    if (idx < 0) { la_set_error("stream_put: idx must be >= 0"); return LA_E_ARG; }
+    c->truncate_eos(toks, n);
+    std::vector<int32_t>& buf = c->output_ids[idx];
+    buf.insert(buf.end(), toks, toks + n);
+    const int ts = (int)buf.size();
+    const int min_bl = final_ ? 1 : branch_length;
+    if (ts > min_bl) {
+        for (int i = 0; i < ts - min_bl; ++i) {
+            int32_t tok = buf[i];
+            if (c->stop_words.count(tok)) continue;
+            int len = std::min(branch_length, ts - (i + 1));
+            if (len < 0) len = 0;
+            bool created;
+            int32_t slot = c->tree_get_or_create(tok, &created);
+            Tree& t = c->trees[slot];
+            c->tree_put(t, buf.data() + i + 1, len, true, idx);
+            c->update_trees.insert(t.uid);
+        }
+        if (!final_) {
+            // output_ids[ts - branch_length:]  (a negative start clamps to 0)
+            int start = ts - branch_length; if (start < 0) start = 0;
+            std::vector<int32_t> rest(buf.begin() + start, buf.end());
+            buf.swap(rest);
+        }
+    }
+    if (final_) {
+        buf.clear();
+        c->reset_input_freqs(idx);
+        c->squeeze_branch_counts();
+    }
+    return LA_OK;
+}
+
+static void emit(const la_cache::Out& o, int n, uint64_t* out_rowmask, int64_t* out_mask) {
+    if (out_rowmask && n <= 64)
+        for (int i = 0; i < n; ++i) out_rowmask[i] = (*o.rows)[i][0];
+    if (out_mask)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) out_mask[(size_t)i * n + j] = ((*o.rows)[i][j >> 6] >> (j & 63)) & 1ull;
+}
+
+int la_cache_hier_get(la_cache* c, const int32_t* q, int nq, int decoding_length, int branch_length,
+                      int min_input_size, int min_output_size, int mode, int idx, int cap, int32_t* out_ids,
+                      int32_t* out_parent, uint64_t* out_rowmask, int64_t* out_mask, int32_t out_sizes[2],
+                      int32_t* out_nsizes, int32_t* out_n) {
+    if (!c || nq < 0 || (nq > 0 && !q) || !out_ids || !out_parent || !out_sizes || !out_nsizes || !out_n || cap < 1)
+        return LA_E_ARG;
+    if (mode < 0 || mode > 2) { la_set_error("hier_get: bad mode"); return LA_E_ARG; }
+    std::vector<std::vector<uint64_t>> rows;
+    la_cache::Out o{cap, out_ids, out_parent, &rows, 0, {0, 0}};
+    auto fallback_last = [&](int nsizes) {                          // token_ids[-1:], default_mask
+        *out_nsizes = nsizes; out_sizes[0] = out_sizes[1] = 0;
+        if (nq == 0) { *out_n = 0; return LA_OK; }
+        out_ids[0] = q[nq - 1]; out_parent[0] = -1; *out_n = 1;
+        if (out_rowmask) out_rowmask[0] = 1;
+        if (out_mask) out_mask[0] = 1;
+        return LA_OK;
+    };
+    if (decoding_length <= 1 || branch_length == 0) return fallback_last(0);    // :413-414
+    if (decoding_length > cap) { la_set_error("hier_get: decoding_length exceeds output capacity"); return LA_E_RANGE; }
+    rows.assign((size_t)decoding_length, std::vector<uint64_t>((size_t)(decoding_length + 63) / 64, 0));
+    bool have = false;
+    int n_out = 0;
+    for (int i = 0; i < nq; ++i) {
+        auto it = c->mem.find(q[i]);
+        if (it == c->mem.end()) continue;
+        const int rest = nq - (i + 1);
+        if (c->stop_words.count(q[i]) && rest == 0) continue;        // :422-423
+        n_out = c->tree_get(c->trees[it->second], q + i + 1, rest, decoding_length, branch_length,
+                            min_input_size, min_output_size, mode, idx, o);
+        have = true;                                                // later lookups overwrite earlier ones
+        if (n_out >= branch_length) break;                          // :433-434
+    }
+    if (!have) return fallback_last(2);                             // :436-437, sizes stays [0,0]
+    *out_n = n_out; *out_nsizes = 2;
+    out_sizes[0] = o.sizes[0]; out_sizes[1] = o.sizes[1];
+    emit(o, n_out, out_rowmask, out_mask);
+    return LA_OK;
+}
+
+// Tree.get_one_branch (:171-222) + one_get (:490-517)
+int la_cache_one_get(la_cache* c, const int32_t* q, int nq, int decoding_length, int branch_length, int mode,
+                     int idx, int cap, int32_t* out_ids, int32_t out_sizes[2], int32_t* out_nsizes, int32_t* out_n) {
+    if (!c || nq < 0 || (nq > 0 && !q) || !out_ids || !out_sizes || !out_nsizes || !out_n || cap < 1) return LA_E_ARG;
+    if (mode < 0 || mode > 2) return LA_E_ARG;
+    out_sizes[0] = out_sizes[1] = 0;
+    if (decoding_length <= 1 || branch_length == 0) {
+        *out_nsizes = 0;
+        if (nq == 0) { *out_n = 0; return LA_OK; }
+        out_ids[0] = q[nq - 1]; *out_n = 1; return LA_OK;
+    }
+    if (branch_length + 1 > cap) return LA_E_RANGE;
+    bool have = false; int n_out = 0; int nsz = 2;
+    for (int i = 0; i < nq; ++i) {
+        auto it = c->mem.find(q[i]);
+        if (it == c->mem.end()) continue;
+        const int rest = nq - (i + 1);
+        if (c->stop_words.count(q[i]) && rest == 0) continue;
+        const Tree& t = c->trees[it->second];
+        bool have_tok; int32_t tok = 0;
+        int32_t at = c->match(t, q + i + 1, rest, mode, idx, &have_tok, &tok);
+        have = true;
+        if (at < 0 || c->nodes[at].first_child < 0) {
+            out_ids[0] = rest > 0 ? q[nq - 1] : t.token; n_out = 1; nsz = 2; out_sizes[0] = out_sizes[1] = 0;
+        } else {
+            out_ids[0] = (have_tok && tok != 0) ? tok : t.token;
+            n_out = 1;
+            int32_t cur = at; int length = 0;
+            while (c->nodes[cur].first_child >= 0 && length < branch_length) {
+                double max_freq = 0.0; int32_t max_node = -1;
+                for (int32_t ch = c->nodes[cur].first_child; ch >= 0; ch = c->nodes[ch].next_sib) {
+                    const Node& nd = c->nodes[ch];
+                    double freq; bool live;
+                    if (mode == LA_MODE_MIX) {
+                        // :190-193 names are swapped in the reference: fo := freqs[idx], fi := freqs[-1]
+                        double a = la_cache::get_fi(nd, idx), b = nd.fo;
+                        live = a > 0 || b > 0; freq = 10000 * b + a;
+                    } else if (mode == LA_MODE_INPUT) { freq = la_cache::get_fi(nd, idx); live = freq > 0; }
+                    else { freq = nd.fo; live = freq > 0; }
+                    if (live && freq > max_freq) { max_freq = freq; max_node = ch; }
+                }
+                if (max_node < 0) break;
+                out_ids[n_out++] = c->nodes[max_node].token;
+                cur = max_node; ++length;
+            }
+            nsz = 1; out_sizes[0] = length;
+        }
+        if (n_out >= branch_length / 2) break;                      // :512
+    }
+    if (!have) {
+        *out_nsizes = 2; out_sizes[0] = out_sizes[1] = 0;
+        if (nq == 0) { *out_n = 0; return LA_OK; }
+        out_ids[0] = q[nq - 1]; *out_n = 1; return LA_OK;
+    }
+    *out_n = n_out; *out_nsizes = nsz;
+    return LA_OK;
+}
+
+int la_cache_reset_input_freqs(la_cache* c, int idx) { if (!c) return LA_E_ARG; c->reset_input_freqs(idx); return LA_OK; }
+int la_cache_squeeze(la_cache* c) { if (!c) return LA_E_ARG; c->squeeze_branch_counts(); return LA_OK; }
+
+int la_cache_stats(la_cache* c, int64_t* n_trees, int64_t* n_nodes_live, int64_t* n_dirty, int64_t* n_dirty_in) {
+    if (!c) return LA_E_ARG;
+    if (n_trees) *n_trees = (int64_t)c->mem.size();
+    if (n_nodes_live) *n_nodes_live = c->live_nodes;
+    if (n_dirty) *n_dirty = (int64_t)c->update_trees.size();
+    if (n_dirty_in) *n_dirty_in = (int64_t)c->update_input_trees.size();
+    return LA_OK;
+}
+int la_cache_tree_counters(la_cache* c, int32_t token, int64_t* n_node, int64_t* n_output_node) {
+    if (!c) return LA_E_ARG;
+    auto it = c->mem.find(token);
+    if (it == c->mem.end()) return LA_E_RANGE;
+    if (n_node) *n_node = c->trees[it->second].n_node;
+    if (n_output_node) *n_output_node = c->trees[it->second].n_output_node;
+    return LA_OK;
+}
+
+// ---- persistence: "LATRIE01" | n_trees | per tree {token, max_node, max_output_node, n_node, n_output_node,
+//      n_rec} | per record (pre-order, insertion order) {token, depth, fo, n_fi, (idx, f)*}
+int la_cache_save(la_cache* c, const char* path) {
+    if (!c || !path) return LA_E_ARG;
+    FILE* f = fopen(path, "wb");
+    if (!f) { la_set_error(std::string("save: cannot open ") + path); return LA_E_IO; }
+    auto w = [&](const void* p, size_t n) { return fwrite(p, 1, n, f) == n; };
+    bool ok = w("LATRIE01", 8);
+    // keep dict order of mem irrelevant: trees are looked up by token only
+    int64_t nt = (int64_t)c->mem.size();
+    ok = ok && w(&nt, 8);
+    for (auto& kv : c->mem) {
+        const Tree& t = c->trees[kv.second];
+        std::vector<std::pair<int32_t, int32_t>> order;   // (node, depth) pre-order
+        std::vector<std::pair<int32_t, int32_t>> stack;
+        std::vector<int32_t> kids;
+        for (int32_t ch = c->nodes[t.root].first_child; ch >= 0; ch = c->nodes[ch].next_sib) kids.push_back(ch);
+        for (auto it = kids.rbegin(); it != kids.rend(); ++it) stack.push_back({*it, 1});
+        while (!stack.empty()) {
+            auto [n, d] = stack.back(); stack.pop_back();
+            order.push_back({n, d});
+            kids.clear();
+            for (int32_t ch = c->nodes[n].first_child; ch >= 0; ch = c->nodes[ch].next_sib) kids.push_back(ch);
+            for (auto it = kids.rbegin(); it != kids.rend(); ++it) stack.push_back({*it, d + 1});
+        }
+        int64_t hdr[6] = {t.token, t.max_node, t.max_output_node, t.n_node, t.n_output_node, (int64_t)order.size()};
+        ok = ok && w(hdr, sizeof(hdr));
+        for (auto& [n, d] : order) {
+            const Node& nd = c->nodes[n];
+            int32_t rec[3] = {nd.token, d, (int32_t)nd.fi.size()};
+            ok = ok && w(rec, sizeof(rec)) && w(&nd.fo, 8);
+            for (auto& p : nd.fi) { ok = ok && w(&p.first, 4) && w(&p.second, 8); }
+        }
+    }
+    fclose(f);
+    if (!ok) { la_set_error("save: short write"); return LA_E_IO; }
+    return LA_OK;
+}
+
+int la_cache_load(la_cache* c, const char* path) {
+    if (!c || !path) return LA_E_ARG;
+    FILE* f = fopen(path, "rb");
+    if (!f) { la_set_error(std::string("load: cannot open ") + path); return LA_E_IO; }
+    auto r = [&](void* p, size_t n) { return fread(p, 1, n, f) == n; };
+    char magic[8];
+    if (!r(magic, 8) || memcmp(magic, "LATRIE01", 8) != 0) { fclose(f); la_set_error("load: bad magic"); return LA_E_IO; }
+    la_cache_fresh(c);                                      // load_mem replaces self.mem only
+    int64_t nt = 0;
+    bool ok = r(&nt, 8);
+    for (int64_t ti = 0; ok && ti < nt; ++ti) {
+        int64_t hdr[6];
+        ok = r(hdr, sizeof(hdr));
+        if (!ok) break;
+        bool created;
+        int32_t slot = c->tree_get_or_create((int32_t)hdr[0], &created);
+        Tree& t = c->trees[slot];
+        t.max_node = hdr[1]; t.max_output_node = hdr[2]; t.n_node = hdr[3]; t.n_output_node = hdr[4];
+        std::vector<int32_t> path_nodes{t.root};
+        for (int64_t i = 0; ok && i < hdr[5]; ++i) {
+            int32_t rec[3]; double fo;
+            ok = r(rec, sizeof(rec)) && r(&fo, 8);
+            if (!ok || rec[1] < 1 || rec[1] > (int32_t)path_nodes.size()) { ok = false; break; }
+            path_nodes.resize(rec[1]);
+            int32_t nn = c->new_node(rec[0], path_nodes.back());
+            c->link_child(path_nodes.back(), nn);
+            c->nodes[nn].fo = fo;
+            for (int k = 0; ok && k < rec[2]; ++k) {
+                int32_t id; double v;
+                ok = r(&id, 4) && r(&v, 8);
+                if (ok) c->nodes[nn].fi.emplace_back(id, v);
+            }
+            path_nodes.push_back(nn);
+        }
+    }
+    fclose(f);
+    if (!ok) { la_set_error("load: truncated or corrupt snapshot"); return LA_E_IO; }
+    return LA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,23 @@
+# -*- coding: utf-8 -*-
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """CPU tests need the in-tree liblookahead_hip.so (hipcc cross-compiles without a GPU)."""
+    so = os.path.join(ROOT, "painlessinferenceacceleration_amd", "liblookahead_hip.so")
+    if not os.path.exists(so):
+        import __graft_entry__
+        __graft_entry__.build()
+    yield
