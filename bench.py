@@ -1,0 +1,262 @@
+# -*- coding: utf-8 -*-
+"""bench.py — accepted tokens/s of the LOOKAHEAD verify loop on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 64 --warmup 8
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (configs[1]): Llama-2-7B (random init, real shape, bf16), bs=1 per GPU, 64-token draft tree /
+~8 branches per verify step, hier mode, decoding_length=64, branch_length=12.  One "step" = trie query ->
+captured verify graph (embed, 32 layers, lm_head+argmax, accept scan, KV commit) -> trie update.
+Synthetic data: the prompt is 512 phrase-bank tokens; the trie is warmed, as the reference's
+Benchmark.warm_up does (benchmarks/benchmark.py:159-169), with 8 noisy copies of the model's own greedy
+continuation (each token replaced with probability rho), so drafts are multi-branch and partially accepted.
+Multi-GPU: one independent sequence per rank (batch sharding, weak scaling); the only exchange is the
+per-step all-gather of accepted tokens over RCCL so that every rank's trie replica sees every sequence.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def phrase_prompt(seed, n, vocab):
+    rs = np.random.RandomState(seed)
+    bank = [rs.randint(3, vocab, size=rs.randint(4, 16)).tolist() for _ in range(400)]
+    w = 1.0 / np.arange(1, 401) ** 1.3
+    w /= w.sum()
+    out = []
+    while len(out) < n:
+        out.extend(bank[rs.choice(400, p=w)])
+    return out[:n]
+
+
+def noisy_copies(truth, n_copies, rho, vocab, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(n_copies):
+        t = np.array(truth)
+        hit = rs.rand(len(t)) < rho
+        t[hit] = rs.randint(3, vocab, size=int(hit.sum()))
+        out.append(t.tolist())
+    return out
+
+
+def algorithmic_bytes(shape, T, ctx, logits_bytes):
+    """W + KVr + KVw + A per verify step (bf16)."""
+    W = 2 * (shape.n_params_no_embed())
+    kv_tok = 2 * shape.n_layers * shape.n_kv_heads * shape.head_dim * 2
+    return W + kv_tok * ctx + kv_tok * T + T * (shape.hidden * 2 + 8) + logits_bytes
+
+
+def cpu_baseline(shape, T, ctx, accept_len, budget_s=20.0):
+    """The oracle's verify forward (oracle/llama_oracle.py, a port of the reference's transformers CPU path) timed
+    on this box's host cores at the full Llama-2-7B layer shape.  Bounded sample: ONE set of layer weights is
+    aliased across the 32 layers (400 MB >> any CPU cache, so DRAM traffic per layer is the real one) and a few
+    steps are timed; accepted tok/s = steps/s x the mean accept-len measured on the GPU run."""
+    from oracle import llama_oracle as lo
+    from painlessinferenceacceleration_amd.llama_engine import LlamaShape, random_weights
+    one = LlamaShape(1, shape.hidden, shape.n_heads, shape.n_kv_heads, shape.ffn, shape.vocab, shape.rms_eps)
+    sd1 = random_weights(one, seed=0, device='cpu')
+    sd = dict(sd1)
+    for i in range(1, shape.n_layers):
+        for k, v in sd1.items():
+            if k.startswith('model.layers.0.'):
+                sd[k.replace('layers.0.', f'layers.{i}.')] = v
+    model = lo.OracleLlama(shape, sd)
+    rs = np.random.RandomState(0)
+    hd = shape.head_dim
+    past = [(torch.randn(shape.n_kv_heads, ctx, hd).to(torch.bfloat16), torch.randn(shape.n_kv_heads, ctx, hd).to(torch.bfloat16))
+            for _ in range(shape.n_layers)]
+    ids = torch.tensor(rs.randint(3, shape.vocab, size=T).tolist())
+    mask = torch.cat([torch.ones((T, ctx), dtype=torch.long), torch.tril(torch.ones((T, T), dtype=torch.long))], 1)
+    model.forward(ids, mask, past)          # warm
+    n, t0 = 0, time.time()
+    while True:
+        model.forward(ids, mask, past)
+        n += 1
+        if time.time() - t0 > budget_s or n >= 32:
+            break
+    dt = (time.time() - t0) / n
+    return {'value': round(accept_len / dt, 3), 'unit': 'tokens/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'ms_per_step': round(dt * 1e3, 1),
+            'sample': f'{n} verify steps (T={T}, ctx={ctx}) of the oracle forward at Llama-2-7B shape, bf16, one layer\'s '
+                      f'weights aliased across {shape.n_layers} layers; steps/s x GPU-run mean accept-len {accept_len:.2f}'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=64)
+    ap.add_argument('--warmup', type=int, default=8)
+    ap.add_argument('--prompt-len', type=int, default=512)
+    ap.add_argument('--rho', type=float, default=0.12)
+    ap.add_argument('--layers', type=int, default=0, help='debug: override layer count (invalidates the metric)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-iters', type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    dev = f'cuda:{local_rank}'
+    torch.cuda.set_device(dev)
+
+    from painlessinferenceacceleration_amd.llama_engine import LlamaShape
+    from painlessinferenceacceleration_amd.lookahead_cache import LookaheadCache
+    from painlessinferenceacceleration_amd.modeling_llama import LlamaForCausalLM
+
+    shape = LlamaShape.llama2_7b()
+    if args.layers:
+        shape.n_layers = args.layers
+    K, W, P = args.steps, args.warmup, args.prompt_len
+    BL, DL = 12, 64
+    n_truth = (K + W) * (BL + 1) + 8
+    max_length = P + n_truth + 2 * DL
+    model = LlamaForCausalLM.random_init(shape, seed=0, device=dev, max_length=max_length, eos_token_id=None)
+    eng = model.engine
+
+    # ---- untimed set-up: prompt, ground-truth continuation (plain greedy on the same engine), trie warm-up
+    prompts = [phrase_prompt(1234 + r, P, shape.vocab) for r in range(world)]
+    prompt = prompts[rank]
+    t0 = time.time()
+    truth = model.greedy_search(torch.tensor([prompt]), P + n_truth, eos_token_id=None)[0].tolist()[P:]
+    t_greedy = time.time() - t0
+    cache = LookaheadCache(eos_ids=[None])
+    model.lookahead_cache = cache
+    if world > 1:                                # every replica is warmed with every rank's (noisy) answers
+        tt = torch.tensor(truth, dtype=torch.int32, device=dev)
+        allt = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        truths = [x.cpu().tolist() for x in allt]
+    else:
+        truths = [truth]
+    for r in range(world):
+        for c in noisy_copies(prompts[r][-2:] + truths[r], 8, args.rho, shape.vocab, seed=99 + r):
+            cache.put(c, branch_length=BL + 1, mode='output', idx=-1)
+
+    # ---- the measured loop ----------------------------------------------------------------------------------
+    seq = list(prompt)
+    cache.put(seq[1:], branch_length=BL + 1, mode='input', idx=rank)
+    eng.reset()
+    seq.append(eng.prefill(seq))
+    gather_in = torch.zeros(16, dtype=torch.int32, device=dev)
+    gather_out = torch.zeros(16 * world, dtype=torch.int32, device=dev) if world > 1 else None
+    edls, dls, qts = [], [], []
+
+    def one_step():
+        tq = time.time()
+        ubl = min(BL, max_length - len(seq) - 1)
+        ids, rowmask, _, _ = cache.hier_get_packed(seq[-2:], decoding_length=DL, branch_length=ubl, min_input_size=0,
+                                                   min_output_size=DL // 2, mode='mix', idx=rank)
+        qts.append(time.time() - tq)
+        toks, _ = eng.step(ids, rowmask, mode=0)
+        seq.extend(toks)
+        dls.append(len(ids)); edls.append(len(toks))
+        if world > 1:
+            gather_in.zero_()
+            gather_in[0] = len(toks)
+            gather_in[1:1 + len(toks)] = torch.tensor(toks, dtype=torch.int32)
+            dist.all_gather_into_tensor(gather_out, gather_in)
+            allv = gather_out.cpu().view(world, 16)
+            for r in range(world):               # global batch-index order keeps every trie replica identical
+                n = int(allv[r, 0])
+                cache.stream_put(allv[r, 1:1 + n].tolist(), branch_length=BL + 1, final=False, idx=r)
+        else:
+            cache.stream_put(toks, branch_length=BL + 1, final=False, idx=rank)
+
+    for _ in range(W):
+        one_step()
+    n0 = len(edls)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(K):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.time() - t0
+    accepted = int(sum(edls[n0:]))
+    if world > 1:
+        v = torch.tensor([elapsed, float(accepted)], dtype=torch.float64, device=dev)
+        mx = v.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = v.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, accepted_all = float(mx[0]), float(sm[1])
+    else:
+        accepted_all = float(accepted)
+    correct = seq[P:P + len(truth)] == truth[:len(seq) - P]       # lookahead output == plain greedy output
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (gate/up GEMM, k_gemm64<2,SWIGLU>) from live HIP events -------------
+    ctx = eng.n_keys
+    ids, rowmask, _, _ = cache.hier_get_packed(seq[-2:], decoding_length=DL, branch_length=BL, min_output_size=DL // 2)
+    T_prof = len(ids)
+    prof = eng.profile(ids, rowmask, iters=args.profile_iters)
+    gu_ms = prof['ms']['gateup'] / max(prof['launches']['gateup'], 1)
+    gu_bytes = 2 * shape.ffn * shape.hidden * 2 + 64 * shape.hidden * 2 + 64 * shape.ffn * 2
+    ms_step = 1e3 * elapsed / K
+    mean_T = float(np.mean(dls[n0:]))
+    step_bytes = algorithmic_bytes(shape, 64, ctx, 64 * shape.vocab * 2)
+    gemm_ms = sum(prof['ms'][k] for k in ('qkv', 'o', 'gateup', 'down', 'lm_head'))
+    roofline = {
+        'bound': 'hbm', 'kernel': 'k_gemm64<RB=2,EPI_SWIGLU> (gate/up projection, 32 launches/step)',
+        'achieved': round(gu_bytes / (gu_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'frac': round(gu_bytes / (gu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': None,
+        'bytes_per_launch': gu_bytes, 'ms_per_launch': round(gu_ms, 5),
+        'verify_step': {'algorithmic_bytes': step_bytes, 'ms_graph_step': round(ms_step, 4),
+                        'achieved_GBps': round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
+                        'frac': round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        'ms_eager_step_events': round(prof['ms_step'], 4),
+                        'ms_by_class_events': {k: round(v, 4) for k, v in prof['ms'].items()},
+                        'all_gemm_GBps_events': round(2 * shape.n_params_no_embed() / (gemm_ms * 1e-3) / 1e9, 1)},
+    }
+    mean_acc = float(np.mean(edls[n0:]))
+    cpu = None
+    if not args.no_cpu_baseline:
+        torch.set_num_threads(os.cpu_count() or 1)
+        cpu = cpu_baseline(shape, 64, ctx, mean_acc)
+    out = {
+        'metric': 'accepted_tokens_per_sec', 'value': round(accepted_all / elapsed, 2), 'unit': 'tokens/s',
+        'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'Llama-2-7B bf16 bs=1/GPU lookahead verify loop, 64-token draft tree / 8 noisy branches '
+                               '(hier, decoding_length=64, branch_length=12), random-init weights, 512-token phrase-bank prompt',
+                   'n_layers': shape.n_layers, 'prompt_len': P, 'rho': args.rho, 'parallelism': f'batch-shard x{world}',
+                   'mean_accept_len': round(mean_acc, 3), 'mean_draft_len': round(mean_T, 2),
+                   'verify_steps_per_sec': round(K * world / elapsed, 2), 'context_at_end': ctx,
+                   'trie_query_ms_mean': round(1e3 * float(np.mean(qts[n0:])), 4),
+                   'lookahead_equals_greedy': bool(correct), 'plain_greedy_tokens_per_sec': round(len(truth) / t_greedy, 2)},
+        'roofline': roofline, 'cpu_baseline': cpu,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,214 @@
+# -*- coding: utf-8 -*-
+"""ORACLE (test infrastructure, not product code): CPU restatement of the verify forward, the accept
+scan and the bs=1 lookahead loop of alipay/PainlessInferenceAcceleration.
+
+  forward      lookahead/lookahead/models/llama/modeling_llama.py:76-90 (RMSNorm), 93-169 (RoPE),
+               172-186 (MLP), 189-308 (attention), 311-376 (layer), 544-677 (model + rank-4 mask hook),
+               769 (lm_head)
+  accept scan  lookahead/lookahead/common/pretrained_model.py:764-892
+  KV keep set  pretrained_model.py:865-875, 894-907
+  loop         pretrained_model.py:947-1268 (+ 666-756 draft retrieval)
+
+Plain torch on CPU in the dtype of the weights (fp32 or bf16), same operation order and the same
+rounding points as the reference (every nn.Linear / elementwise result is materialised in the
+weight dtype).  Pinning: oracle/gen_golden_model.py runs the reference classes (imported from
+/root/reference) on a tiny seeded Llama and commits tokens / dls / edls / per-step argmax rows /
+logits samples to tests/golden/llama_tiny_*.npz + accept_scan.json; tests/test_oracle_llama.py
+checks this file against them.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import math
+import time
+
+import numpy as np
+import torch
+
+
+# ------------------------------------------------------------------------------------------ forward
+def _rms(x, w, eps):
+    var = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
+    return (w * (x * torch.rsqrt(var + eps))).to(x.dtype)
+
+
+def _rope_cos_sin(pos, head_dim, theta, dtype):
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    ang = (inv[:, None].float() @ pos[None, :].float()).transpose(0, 1)
+    emb = torch.cat((ang, ang), dim=-1)
+    return emb.cos().to(dtype), emb.sin().to(dtype)
+
+
+def _rot_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+class OracleLlama(object):
+    """Functional Llama over a HF-named state dict.  KV cache: list of (k, v), each [n_kv, C, hd]."""
+
+    def __init__(self, shape, state_dict):
+        self.s = shape
+        self.w = state_dict
+        self.dtype = state_dict['lm_head.weight'].dtype
+
+    @torch.no_grad()
+    def forward(self, ids, mask, past):
+        """ids: LongTensor [T]; mask: 0/1 LongTensor [T, C+T] (the rank-4 mask without its two unit dims);
+        past: None or list of (k, v).  -> logits [T, V], new past."""
+        s, w, dt = self.s, self.w, self.dtype
+        T, hd, nh, nkv = ids.shape[0], s.head_dim, s.n_heads, s.n_kv_heads
+        lin = torch.nn.functional.linear
+        # batch dim of 1 kept so that the CPU kernels see the reference's tensor shapes ([1,T,*], [1,H,T,hd])
+        h = w['model.embed_tokens.weight'][ids][None]
+        mask4 = mask[None, None]
+        pos = torch.sum(mask4, dim=-1).squeeze(1) - 1                          # model hook, :586
+        bias = (1.0 - mask4.to(dt)) * torch.finfo(dt).min                      # :587
+        cos, sin = _rope_cos_sin(pos[0], hd, s.rope_theta, dt)
+        cos, sin = cos[None, None], sin[None, None]
+        new_past = []
+        for i in range(s.n_layers):
+            p = f'model.layers.{i}.'
+            x = _rms(h, w[p + 'input_layernorm.weight'], s.rms_eps)
+            q = lin(x, w[p + 'self_attn.q_proj.weight']).view(1, T, nh, hd).transpose(1, 2)
+            k = lin(x, w[p + 'self_attn.k_proj.weight']).view(1, T, nkv, hd).transpose(1, 2)
+            v = lin(x, w[p + 'self_attn.v_proj.weight']).view(1, T, nkv, hd).transpose(1, 2)
+            q = (q * cos) + (_rot_half(q) * sin)
+            k = (k * cos) + (_rot_half(k) * sin)
+            if past is not None:
+                k = torch.cat([past[i][0][None], k], dim=2)
+                v = torch.cat([past[i][1][None], v], dim=2)
+            new_past.append((k[0], v[0]))
+            kk, vv = k, v
+            if nkv != nh:                                                      # repeat_kv (mistral/modeling_mistral.py:236-318)
+                rep = nh // nkv
+                kk = k[:, :, None].expand(1, nkv, rep, k.shape[2], hd).reshape(1, nh, -1, hd)
+                vv = v[:, :, None].expand(1, nkv, rep, v.shape[2], hd).reshape(1, nh, -1, hd)
+            att = torch.matmul(q, kk.transpose(2, 3)) / math.sqrt(hd)
+            att = att + bias
+            att = torch.max(att, torch.tensor(torch.finfo(att.dtype).min))
+            att = torch.softmax(att, dim=-1, dtype=torch.float32).to(dt)
+            o = torch.matmul(att, vv).transpose(1, 2).reshape(1, T, nh * hd)
+            h = h + lin(o, w[p + 'self_attn.o_proj.weight'])
+            x = _rms(h, w[p + 'post_attention_layernorm.weight'], s.rms_eps)
+            g = torch.nn.functional.silu(lin(x, w[p + 'mlp.gate_proj.weight']))
+            u = lin(x, w[p + 'mlp.up_proj.weight'])
+            h = h + lin(g * u, w[p + 'mlp.down_proj.weight'])
+        h = _rms(h, w['model.norm.weight'], s.rms_eps)
+        return lin(h, w['lm_head.weight'])[0], new_past
+
+
+# -------------------------------------------------------------------------------------- accept scan
+def parents_from_mask(mask):
+    """Row i's parent = the highest set column below i (rows are DFS-ordered, lookahead_cache.py:278-283)."""
+    T = mask.shape[0]
+    par = [-1] * T
+    for i in range(1, T):
+        cols = np.nonzero(mask[i, :i])[0]
+        par[i] = int(cols[-1]) if len(cols) else -1
+    return par
+
+
+def accept_scan(ids, mask, argmax_rows):
+    """ids: list[T] (ids[0] = root), mask: [T,T] 0/1, argmax_rows[t] = greedy token after tree row t.
+    -> (next_token_list, logit_indices).  Restates pretrained_model.py:806-864: starting at the root, follow
+    the child whose draft token equals the current row's argmax (first such row in DFS order) until none does;
+    the emitted tokens are the argmax of every visited row (matches + 1 bonus)."""
+    T = len(ids)
+    par = parents_from_mask(np.asarray(mask))
+    cur, toks, rows = 0, [], [0]
+    while True:
+        want = int(argmax_rows[cur])
+        toks.append(want)
+        nxt = next((j for j in range(1, T) if par[j] == cur and int(ids[j]) == want), None)
+        if nxt is None:
+            break
+        cur = nxt
+        rows.append(cur)
+    return toks, rows
+
+
+def kv_keep_positions(context_length, n_draft, logit_indices):
+    """Positions of the KV rows the reference keeps (pretrained_model.py:865-875, 894-907): the whole prefix
+    including the root row, then one row per accepted draft token; nothing is dropped when every draft token was
+    accepted."""
+    m = len(logit_indices) - 1
+    if n_draft == m:
+        return list(range(context_length + n_draft))
+    return list(range(context_length)) + [context_length - 1 + i for i in logit_indices[1:]]
+
+
+# --------------------------------------------------------------------------------------------- loop
+@torch.no_grad()
+def lookahead_generate(model, cache, prompt, max_length, eos_token_id=2, decoding_length=64, branch_length=12,
+                       decoding_mode='hier', max_query_length=2, stop_words=None, max_steps=None, record=None):
+    """bs=1 lookahead_generation with an empty logits-processor list and greedy decoding.
+    -> dict(sequences, dls, edls, fts, qts).  `cache` is any object with the LookaheadCache surface."""
+    eos = [eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id)
+    cache.eos_ids = eos
+    cache.stop_words = stop_words if stop_words is not None else {}
+    seq = [int(x) for x in prompt]
+    dls, edls, fts, qts = [], [], [], []
+    cache.put(seq[1:], branch_length=branch_length + 1, mode='input', idx=0)          # :1153-1156
+    past = None
+    ts = time.time()
+    steps = 0
+    while True:
+        if past is None:
+            P = len(seq)
+            mask = torch.tril(torch.ones((P, P), dtype=torch.long))
+            logits, past = model.forward(torch.tensor(seq, dtype=torch.long), mask, None)
+            toks = [int(torch.argmax(logits[-1]))]
+            dls.append(1); edls.append(1)
+            if record is not None:
+                record.append({'ids': list(seq), 'argmax': [int(x) for x in torch.argmax(logits, -1)], 'next': toks})
+        else:
+            ubl = min(branch_length, max_length - len(seq) - 1)                      # :680
+            assert ubl >= 0
+            fmt, mode = (decoding_mode if '_' in decoding_mode else decoding_mode + '_mix').split('_')   # :712-714
+            tq = time.time()
+            d_ids, d_mask, sizes = getattr(cache, fmt + '_get')(seq[-max_query_length:], decoding_length=decoding_length,
+                                                               branch_length=ubl, min_input_size=0,
+                                                               min_output_size=max(decoding_length // 2, 1),
+                                                               mode=mode, idx=0)
+            qts.append(time.time() - tq)
+            T, C = len(d_ids), len(seq) - 1
+            d_mask = np.asarray(d_mask).astype(np.int64)
+            full = torch.cat([torch.ones((T, C), dtype=torch.long), torch.from_numpy(d_mask)], dim=1)
+            logits, past = model.forward(torch.tensor(d_ids, dtype=torch.long), full, past)
+            am = [int(x) for x in torch.argmax(logits, -1)]
+            if T == 1:
+                toks, rows = [am[0]], [0]
+            else:
+                toks, rows = accept_scan(d_ids, d_mask, am)
+            keep = kv_keep_positions(len(seq), T - 1, rows)
+            if len(keep) != past[0][0].shape[1]:
+                idx = torch.tensor(keep, dtype=torch.long)
+                past = [(k[:, idx], v[:, idx]) for k, v in past]
+            dls.append(T); edls.append(len(toks))
+            if record is not None:
+                record.append({'ids': list(d_ids), 'rows': [int(sum(int(b) << j for j, b in enumerate(r))) for r in d_mask],
+                               'argmax': am, 'next': toks, 'accepted_rows': rows, 'sizes': list(sizes)})
+        seq.extend(toks)
+        cache.stream_put(toks, branch_length=branch_length + 1, final=False, mode='output', idx=0)   # :1203
+        finished = len(seq) >= max_length or any(e in toks for e in eos)                         # :1225-1231
+        steps += 1
+        if max_steps is not None and steps >= max_steps:
+            finished = True
+        te = time.time(); fts.append(te - ts); ts = te
+        if finished:
+            cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=0)
+            break
+    return {'sequences': seq, 'dls': dls, 'edls': edls, 'fts': fts, 'qts': qts}
+
+
+@torch.no_grad()
+def greedy_generate(model, prompt, n_new):
+    """Plain greedy decoding with the same forward (lookahead output must equal this in fp32)."""
+    seq = [int(x) for x in prompt]
+    P = len(seq)
+    logits, past = model.forward(torch.tensor(seq), torch.tril(torch.ones((P, P), dtype=torch.long)), None)
+    for _ in range(n_new):
+        t = int(torch.argmax(logits[-1]))
+        seq.append(t)
+        logits, past = model.forward(torch.tensor([t]), torch.ones((1, len(seq)), dtype=torch.long), past)
+    return seq

@@ -1,0 +1,250 @@
+# -*- coding: utf-8 -*-
+"""LlamaVerifyEngine — host-side owner of the device memory behind la_llama_* (the verify forward).
+
+Plumbing only: torch allocates HBM (weights repacked into MFMA-fragment order, KV caches, scratch),
+provides the stream and pinned staging buffers; every kernel of the step is hand-written HIP inside
+liblookahead_hip.so (csrc/la_kernels.hip, csrc/la_engine.cpp).  There is no torch fallback: without a
+GPU the constructor raises.
+
+Reference counterpart: LlamaForCausalLM.forward under the rank-4 mask hook
+(lookahead/lookahead/models/llama/modeling_llama.py:544-677, 710-794), called once per verify step
+from lookahead_generation (common/pretrained_model.py:1176-1181).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+
+class LlamaShape(object):
+    """The fields of LlamaConfig the path uses."""
+
+    def __init__(self, n_layers=32, hidden=4096, n_heads=32, n_kv_heads=None, ffn=11008, vocab=32000,
+                 rms_eps=1e-5, rope_theta=10000.0, head_dim=None):
+        self.n_layers, self.hidden, self.n_heads = n_layers, hidden, n_heads
+        self.n_kv_heads = n_kv_heads if n_kv_heads is not None else n_heads
+        self.ffn, self.vocab, self.rms_eps, self.rope_theta = ffn, vocab, rms_eps, rope_theta
+        self.head_dim = head_dim if head_dim is not None else hidden // n_heads
+
+    @classmethod
+    def llama2_7b(cls):
+        return cls(32, 4096, 32, 32, 11008, 32000, 1e-5)
+
+    @classmethod
+    def llama2_13b(cls):
+        return cls(40, 5120, 40, 40, 13824, 32000, 1e-5)
+
+    @classmethod
+    def from_hf(cls, cfg):
+        return cls(cfg.num_hidden_layers, cfg.hidden_size, cfg.num_attention_heads,
+                   getattr(cfg, 'num_key_value_heads', None), cfg.intermediate_size, cfg.vocab_size,
+                   cfg.rms_norm_eps, getattr(cfg, 'rope_theta', 10000.0))
+
+    def n_params_no_embed(self):
+        hd = self.head_dim
+        per_layer = (self.n_heads + 2 * self.n_kv_heads) * hd * self.hidden + self.n_heads * hd * self.hidden \
+            + 3 * self.ffn * self.hidden + 2 * self.hidden
+        return self.n_layers * per_layer + self.hidden + self.vocab * self.hidden
+
+
+def rope_tables(head_dim, max_pos, theta, device):
+    """cos/sin exactly as LlamaRotaryEmbedding.forward (modeling_llama.py:93-126): fp32 outer product,
+    cos()/sin() in fp32, cast to the activation dtype (bf16).  Only the first head_dim/2 columns are stored
+    (emb = cat(freqs, freqs))."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    pos = torch.arange(max_pos, dtype=torch.int64).float()
+    freqs = (inv_freq[:, None].float() @ pos[None, :].float()).transpose(0, 1)      # [max_pos, hd/2]
+    return freqs.cos().to(torch.bfloat16).to(device).contiguous(), freqs.sin().to(torch.bfloat16).to(device).contiguous()
+
+
+def random_weights(shape, seed=0, std=0.02, device='cpu', dtype=torch.bfloat16):
+    """Random-init weights in HF Llama naming (initializer_range=0.02, norms = 1), generated layer by layer on
+    `device` (no checkpoints are available)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    hd = shape.head_dim
+
+    def w(n, k):
+        return (torch.randn(n, k, generator=g, device=device, dtype=torch.float32) * std).to(dtype)
+
+    sd = {'model.embed_tokens.weight': w(shape.vocab, shape.hidden)}
+    for i in range(shape.n_layers):
+        p = f'model.layers.{i}.'
+        sd[p + 'self_attn.q_proj.weight'] = w(shape.n_heads * hd, shape.hidden)
+        sd[p + 'self_attn.k_proj.weight'] = w(shape.n_kv_heads * hd, shape.hidden)
+        sd[p + 'self_attn.v_proj.weight'] = w(shape.n_kv_heads * hd, shape.hidden)
+        sd[p + 'self_attn.o_proj.weight'] = w(shape.hidden, shape.n_heads * hd)
+        sd[p + 'mlp.gate_proj.weight'] = w(shape.ffn, shape.hidden)
+        sd[p + 'mlp.up_proj.weight'] = w(shape.ffn, shape.hidden)
+        sd[p + 'mlp.down_proj.weight'] = w(shape.hidden, shape.ffn)
+        sd[p + 'input_layernorm.weight'] = torch.ones(shape.hidden, device=device, dtype=dtype)
+        sd[p + 'post_attention_layernorm.weight'] = torch.ones(shape.hidden, device=device, dtype=dtype)
+    sd['model.norm.weight'] = torch.ones(shape.hidden, device=device, dtype=dtype)
+    sd['lm_head.weight'] = w(shape.vocab, shape.hidden)
+    return sd
+
+
+class LlamaVerifyEngine(object):
+    """One sequence (bs=1) on one GPU: packed weights + KV cache + the captured step graph."""
+
+    def __init__(self, shape, state_dict, max_length=2048, device='cuda:0', attn_split=0, gemm_cfg=None,
+                 consume_state_dict=False):
+        if not torch.cuda.is_available():
+            raise RuntimeError('LlamaVerifyEngine needs an MI355X: the verify step has no CPU fallback')
+        self.shape = shape
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.max_keys = int(math.ceil((max_length + 64 + 1) / 32.0)) * 32
+        self.max_pos = self.max_keys + 64
+        self.stream = torch.cuda.current_stream(self.device)
+        sp = C.c_void_p(self.stream.cuda_stream)
+        hd = shape.head_dim
+        self._keep = []
+
+        def dev(t):
+            t = t.to(device=self.device, dtype=torch.bfloat16).contiguous()
+            self._keep.append(t)
+            return t
+
+        def pack(w, w2=None):
+            w = w.to(device=self.device, dtype=torch.bfloat16).contiguous()
+            n, k = w.shape
+            if w2 is not None:
+                w2 = w2.to(device=self.device, dtype=torch.bfloat16).contiguous()
+            out = torch.empty((2 if w2 is not None else 1) * n * k, dtype=torch.bfloat16, device=self.device)
+            check(lib.la_pack_weight(sp, w.data_ptr(), w2.data_ptr() if w2 is not None else None, n, k,
+                                     1 if w2 is not None else 0, out.data_ptr()), 'pack_weight')
+            self._keep.append(out)
+            return out
+
+        def take(name):
+            return state_dict.pop(name) if consume_state_dict else state_dict[name]
+
+        layers = (_lib.LlamaLayerWeightsC * shape.n_layers)()
+        for i in range(shape.n_layers):
+            p = f'model.layers.{i}.'
+            qkv = torch.cat([take(p + 'self_attn.q_proj.weight').to(self.device),
+                             take(p + 'self_attn.k_proj.weight').to(self.device),
+                             take(p + 'self_attn.v_proj.weight').to(self.device)], 0)
+            layers[i].wqkv = pack(qkv).data_ptr()
+            del qkv
+            layers[i].wo = pack(take(p + 'self_attn.o_proj.weight')).data_ptr()
+            layers[i].wgateup = pack(take(p + 'mlp.gate_proj.weight'), take(p + 'mlp.up_proj.weight')).data_ptr()
+            layers[i].wdown = pack(take(p + 'mlp.down_proj.weight')).data_ptr()
+            layers[i].norm1 = dev(take(p + 'input_layernorm.weight')).data_ptr()
+            layers[i].norm2 = dev(take(p + 'post_attention_layernorm.weight')).data_ptr()
+            torch.cuda.synchronize(self.device)
+        self._layers = layers
+        self.embed = dev(take('model.embed_tokens.weight'))
+        self.rope_cos, self.rope_sin = rope_tables(hd, self.max_pos, shape.rope_theta, self.device)
+        w = _lib.LlamaWeightsC()
+        w.embed = self.embed.data_ptr()
+        w.lm_head = pack(take('lm_head.weight')).data_ptr()
+        w.final_norm = dev(take('model.norm.weight')).data_ptr()
+        w.rope_cos, w.rope_sin = self.rope_cos.data_ptr(), self.rope_sin.data_ptr()
+        w.layers = C.cast(layers, C.POINTER(_lib.LlamaLayerWeightsC))
+        torch.cuda.synchronize(self.device)
+
+        cfg = _lib.LlamaConfigC()
+        cfg.n_layers, cfg.hidden, cfg.n_heads, cfg.n_kv_heads = shape.n_layers, shape.hidden, shape.n_heads, shape.n_kv_heads
+        cfg.head_dim, cfg.ffn, cfg.vocab = hd, shape.ffn, shape.vocab
+        cfg.max_keys, cfg.max_pos, cfg.attn_split, cfg.rms_eps = self.max_keys, self.max_pos, attn_split, shape.rms_eps
+        for i, v in enumerate(gemm_cfg or []):
+            cfg.gemm_cfg[i] = int(v)
+        self._cfg = cfg
+        nbytes = lib.la_llama_workspace_bytes(C.byref(cfg))
+        if nbytes <= 0:
+            raise _lib.LookaheadHipError(f'la_llama_workspace_bytes: {_lib.last_error()}')
+        self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        self._h = lib.la_llama_create(C.byref(cfg), C.byref(w), self.workspace.data_ptr(), nbytes)
+        if not self._h:
+            raise _lib.LookaheadHipError(f'la_llama_create: {_lib.last_error()}')
+        self.host_in = torch.zeros(_lib.LA_IN_WORDS, dtype=torch.int32).pin_memory()
+        self.host_out = torch.zeros(_lib.LA_ST_OUTTOK + 64, dtype=torch.int32).pin_memory()
+        self._in_np = self.host_in.numpy()
+        self._out_np = self.host_out.numpy()
+        self._in_rm = self._in_np[_lib.LA_IN_ROWMASK:_lib.LA_IN_ROWMASK + 128].view(np.uint64)
+        self.n_keys = 0
+        self.reset()
+
+    def __del__(self):
+        h = getattr(self, '_h', None)
+        if h:
+            lib.la_llama_destroy(h)
+            self._h = None
+
+    # ------------------------------------------------------------------------------------------------
+    def _sp(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self):
+        check(lib.la_llama_reset(self._h, self._sp()), 'llama_reset')
+        self.n_keys = 0
+
+    def _fill(self, ids, rowmask, mode):
+        T = len(ids)
+        assert 1 <= T <= _lib.LA_TREE_MAX
+        assert self.n_keys + T <= self.max_keys, 'KV cache capacity exceeded'
+        a = self._in_np
+        a[_lib.LA_IN_T] = T
+        a[_lib.LA_IN_MODE] = mode
+        a[_lib.LA_IN_IDS:_lib.LA_IN_IDS + T] = ids
+        self._in_rm[:T] = rowmask
+
+    def step_async(self, ids, rowmask, mode=0, eager=False):
+        """Enqueue one block (tree of T<=64 tokens) on the current stream; results land in host_out."""
+        self._fill(ids, rowmask, mode)
+        fn = lib.la_llama_step_eager if eager else lib.la_llama_step
+        check(fn(self._h, self._sp(), self.host_in.data_ptr(), self.host_out.data_ptr()), 'llama_step')
+
+    def step(self, ids, rowmask, mode=0, eager=False):
+        """-> list of emitted tokens (accepted path + bonus), list of accepted tree rows."""
+        self.step_async(ids, rowmask, mode, eager)
+        torch.cuda.current_stream(self.device).synchronize()
+        o = self._out_np
+        n_out = int(o[_lib.LA_ST_NOUT])
+        self.n_keys = int(o[_lib.LA_ST_NKEYS])
+        return o[_lib.LA_ST_OUTTOK:_lib.LA_ST_OUTTOK + n_out].tolist(), int(o[_lib.LA_ST_NCOMMIT])
+
+    _CHAIN = np.array([(2 << t) - 1 for t in range(63)] + [0xFFFFFFFFFFFFFFFF], dtype=np.uint64)
+
+    def prefill(self, prompt_ids, eager=False):
+        """Process the prompt as chains of <=64 tokens (lower-triangular row masks); returns the first generated
+        token (argmax of the last prompt row, pretrained_model.py:783-798)."""
+        prompt_ids = [int(x) for x in prompt_ids]
+        tok = None
+        for s in range(0, len(prompt_ids), 64):
+            blk = prompt_ids[s:s + 64]
+            toks, _ = self.step(np.asarray(blk, dtype=np.int32), self._CHAIN[:len(blk)], mode=1, eager=eager)
+            tok = toks[0]
+        return tok
+
+    # ---- introspection for parity tests ----------------------------------------------------------------
+    def _view(self, which, nbytes, dtype):
+        ptr = lib.la_llama_buffer(self._h, which)
+        off = ptr - self.workspace.data_ptr()
+        return self.workspace[off:off + nbytes].view(dtype)
+
+    def logits(self):
+        """bf16 [64][vocab] of the last block (row t = tree token t)."""
+        return self._view(0, 64 * self.shape.vocab * 2, torch.bfloat16).view(64, self.shape.vocab)
+
+    def state(self):
+        return self._view(1, _lib.LA_ST_WORDS * 4, torch.int32)
+
+    def hidden(self):
+        return self._view(2, 64 * self.shape.hidden * 2, torch.bfloat16).view(64, self.shape.hidden)
+
+    def profile(self, ids, rowmask, iters=3):
+        """HIP-event timing per kernel class (see la_llama_profile)."""
+        self._fill(ids, rowmask, 0)
+        ms = (C.c_float * 8)()
+        launches = (C.c_int32 * 7)()
+        check(lib.la_llama_profile(self._h, self._sp(), self.host_in.data_ptr(), int(iters), ms, launches), 'profile')
+        names = ['qkv', 'o', 'gateup', 'down', 'lm_head', 'attn', 'other']
+        return {'ms': {n: ms[i] for i, n in enumerate(names)}, 'ms_step': ms[7],
+                'launches': {n: launches[i] for i, n in enumerate(names)}}

@@ -1,0 +1,34 @@
+# -*- coding: utf-8 -*-
+"""LlamaForCausalLM on the MI355X verify engine: the model-wrapper surface of
+lookahead/lookahead/models/llama/modeling_llama.py (generate / lookahead_generation / lookahead_cache) with the
+forward living in liblookahead_hip.so."""
+from types import SimpleNamespace
+
+import torch
+
+from .llama_engine import LlamaShape, LlamaVerifyEngine, random_weights
+from .lookahead_cache import LookaheadCache
+from .pretrained_model import LookaheadPreTrainedModel
+
+
+class LlamaForCausalLM(LookaheadPreTrainedModel):
+    def __init__(self, shape, state_dict, max_length=2048, device='cuda:0', eos_token_id=2, pad_token_id=0,
+                 attn_split=0, gemm_cfg=None, consume_state_dict=False):
+        self.shape = shape
+        self.engine = LlamaVerifyEngine(shape, state_dict, max_length=max_length, device=device,
+                                        attn_split=attn_split, gemm_cfg=gemm_cfg,
+                                        consume_state_dict=consume_state_dict)
+        self.generation_config = SimpleNamespace(eos_token_id=eos_token_id, pad_token_id=pad_token_id,
+                                                 return_dict_in_generate=False)
+        self.config = SimpleNamespace(is_encoder_decoder=False, vocab_size=shape.vocab)
+        self.lookahead_cache = LookaheadCache()
+        self.device = torch.device(device)
+
+    @classmethod
+    def from_hf(cls, hf_model, **kw):
+        """Wrap a transformers LlamaForCausalLM (weights are repacked into HBM; the HF module is not used afterwards)."""
+        return cls(LlamaShape.from_hf(hf_model.config), {k: v.detach() for k, v in hf_model.state_dict().items()}, **kw)
+
+    @classmethod
+    def random_init(cls, shape, seed=0, device='cuda:0', **kw):
+        return cls(shape, random_weights(shape, seed=seed, device=device), device=device, consume_state_dict=True, **kw)

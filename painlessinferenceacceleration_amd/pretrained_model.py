@@ -1,0 +1,213 @@
+# -*- coding: utf-8 -*-
+"""lookahead_generation() on the MI355X engine — same entry point, arguments and outputs as
+LookaheadPreTrainedModel.lookahead_generation (lookahead/lookahead/common/pretrained_model.py:947-1268).
+
+Per verify step the host does exactly three things: one native trie query (la_cache_hier_get), one
+la_llama_step (h2d of ids + 64-bit row masks, the captured graph: forward, accept scan, KV commit; d2h of the
+accepted tokens) and one native trie update (la_cache_stream_put).  The reference's >= 15 host<->device
+synchronisations per step become one.
+"""
+import time
+import warnings
+from threading import Thread
+
+import numpy as np
+import torch
+
+from .lookahead_cache import LookaheadCache
+from .lookahead_generation_utils import GenerationMode, LookaheadDecoderOnlyOutput
+
+_ONE = np.array([1], dtype=np.uint64)
+
+
+def _max_length_of(stopping_criteria, max_length):
+    if max_length is not None:
+        warnings.warn("`max_length` is deprecated in this function, use "
+                      "`stopping_criteria=StoppingCriteriaList([MaxLengthCriteria(max_length=max_length)])` instead.",
+                      UserWarning)
+        return int(max_length)
+    if stopping_criteria is None:
+        return None
+    ml = getattr(stopping_criteria, 'max_length', None)
+    if ml is None and isinstance(stopping_criteria, int):
+        ml = stopping_criteria
+    return None if ml is None else int(ml)
+
+
+class LookaheadPreTrainedModel(object):
+    """Mixin over an object that owns `self.engine` (LlamaVerifyEngine) and optionally `self.lookahead_cache`."""
+
+    engine = None
+    generation_config = None
+
+    # ---------------------------------------------------------------------------------------- draft retrieval
+    def lookahead_prepare_inputs_for_generation(self, tail_ids, decoding_kwargs, seq_len):
+        """pretrained_model.py:666-756, decode branch: query the trie with the last `max_query_length` tokens.
+        Returns (ids int32[T], rowmask uint64[T]) — the rank-4 mask is never materialised (a13/a14)."""
+        decoding_length = decoding_kwargs.get('decoding_length', 64)
+        branch_length = decoding_kwargs.get('branch_length', 12)
+        decoding_mode = decoding_kwargs.get('decoding_mode', 'hier')
+        max_length = decoding_kwargs.get('max_length', 2048)
+        max_query_length = decoding_kwargs.get('max_query_length', 2)
+        update_branch_length = min(branch_length, max_length - seq_len - 1)
+        assert update_branch_length >= 0, f'{branch_length=} {max_length=} {seq_len=} {update_branch_length=}'
+        qids = tail_ids[-max_query_length:]
+        if decoding_mode in ('hier', 'par', 'one'):
+            decoding_mode = decoding_mode + '_mix'
+        fmt, mode = decoding_mode.split('_')
+        ts = time.time()
+        if fmt == 'hier':
+            ids, rowmask, _, sizes = self.lookahead_cache.hier_get_packed(
+                qids, decoding_length=decoding_length, branch_length=update_branch_length, min_input_size=0,
+                min_output_size=max(decoding_length // 2, 1), mode=mode, idx=0)
+        else:
+            lst, mask, sizes = getattr(self.lookahead_cache, fmt + '_get')(
+                qids, decoding_length=decoding_length, branch_length=update_branch_length, min_input_size=0,
+                min_output_size=max(decoding_length // 2, 1), mode=mode, idx=0)
+            ids = np.asarray(lst, dtype=np.int32)
+            m = np.asarray(mask).astype(np.uint64)
+            rowmask = (m << np.arange(m.shape[1], dtype=np.uint64)[None, :]).sum(axis=1).astype(np.uint64)
+        decoding_kwargs['qts'].append(time.time() - ts)
+        decoding_kwargs.update({'decoding_qids': qids, 'decoding_ids': ids, 'sizes': sizes})
+        return ids, rowmask
+
+    # ---------------------------------------------------------------------------------------------- the loop
+    @torch.no_grad()
+    def lookahead_generation(self, input_ids, logits_processor=None, stopping_criteria=None, max_length=None,
+                             pad_token_id=None, eos_token_id=None, output_attentions=None,
+                             output_hidden_states=None, output_scores=None, return_dict_in_generate=None,
+                             synced_gpus=False, streamer=None, **model_kwargs):
+        if logits_processor is not None and len(logits_processor) > 0:
+            raise NotImplementedError('non-empty logits_processor lists need the sequential accept path '
+                                      '(SURVEY H7, next-row N4); the device accept scan is greedy')
+        if output_scores or output_attentions or output_hidden_states:
+            raise NotImplementedError('scores/attentions/hidden_states are not produced by the device path (SURVEY H8)')
+        gc = self.generation_config
+        pad_token_id = pad_token_id if pad_token_id is not None else getattr(gc, 'pad_token_id', None)
+        eos_token_id = eos_token_id if eos_token_id is not None else getattr(gc, 'eos_token_id', None)
+        if isinstance(eos_token_id, int):
+            eos_token_id = [eos_token_id]
+        return_dict_in_generate = bool(return_dict_in_generate) if return_dict_in_generate is not None \
+            else bool(getattr(gc, 'return_dict_in_generate', False))
+
+        if not hasattr(self, 'lookahead_cache') or self.lookahead_cache is None:
+            self.lookahead_cache = LookaheadCache()
+        decoding_kwargs = model_kwargs['decoding_kwargs']
+        self.lookahead_cache.eos_ids = eos_token_id
+        self.lookahead_cache.stop_words = decoding_kwargs.get('stop_words', {})
+        decoding_kwargs.update({'eos': eos_token_id[0] if eos_token_id is not None else 2,
+                                'edls': [], 'dls': [], 'fts': [], 'qts': []})
+        stop_max_length = _max_length_of(stopping_criteria, max_length)
+        if stop_max_length is None:
+            raise ValueError('lookahead_generation needs a MaxLengthCriteria (stopping_criteria.max_length)')
+        decoding_length = decoding_kwargs.get('decoding_length', 64)
+        decoding_kwargs['max_length'] = stop_max_length
+        decoding_kwargs['decoding_max_length'] = stop_max_length + decoding_length + 1
+        attention_mask = model_kwargs.get('attention_mask', None)
+        if attention_mask is not None and attention_mask.dim() == 2 and not bool(attention_mask.bool().all()):
+            raise NotImplementedError('left-padded prompts need the batch path (bs=1 engine assumes no padding)')
+
+        assert input_ids.size(0) == 1
+        out_device = input_ids.device
+        seq = input_ids[0].tolist()
+        branch_length = decoding_kwargs.get('branch_length', 12)
+        eng = self.engine
+        assert stop_max_length + decoding_length + 1 <= eng.max_keys, \
+            f'engine KV capacity {eng.max_keys} < max_length + decoding_length + 1'
+        self.lookahead_cache.put(seq[1:], branch_length=branch_length + 1, mode='input', idx=0)
+        ts = time.time()
+        eng.reset()
+        first = True
+        eos_set = set(eos_token_id) if eos_token_id is not None else set()
+        while True:
+            if first:
+                next_tokens = [eng.prefill(seq)]
+                decoding_kwargs['dls'].append(1)
+                decoding_kwargs['edls'].append(1)
+                first = False
+            else:
+                ids, rowmask = self.lookahead_prepare_inputs_for_generation(seq, decoding_kwargs, len(seq))
+                if len(ids) == 0:
+                    ids, rowmask = np.asarray(seq[-1:], dtype=np.int32), _ONE
+                next_tokens, _ = eng.step(ids, rowmask, mode=0)
+                decoding_kwargs['dls'].append(len(ids))
+                decoding_kwargs['edls'].append(len(next_tokens))
+                if decoding_kwargs.get('debug_lookahead', False):
+                    tok = decoding_kwargs.get('tokenizer', None)
+                    words = '' if tok is None else tok.decode(next_tokens)
+                    print(f'decoding_length:{len(ids)} accept_length:{len(next_tokens)} '
+                          f'query:{decoding_kwargs["decoding_qids"]} hits:{decoding_kwargs["sizes"]} '
+                          f'accept_token:{next_tokens} accept_word:{words}')
+            seq.extend(next_tokens)
+            if streamer is not None:
+                streamer.put(np.array([next_tokens]))
+            self.lookahead_cache.stream_put(next_tokens, branch_length=branch_length + 1, final=False,
+                                            mode='output', idx=0)
+            finished = len(seq) >= stop_max_length or any(t in eos_set for t in next_tokens)
+            te = time.time()
+            decoding_kwargs['fts'].append(te - ts)
+            ts = te
+            if finished:
+                self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=0)
+                break
+        if streamer is not None:
+            streamer.end()
+        sequences = torch.tensor([seq], dtype=torch.long, device=out_device)
+        if return_dict_in_generate:
+            kwargs = {k: decoding_kwargs[k] for k in ('dls', 'edls', 'fts', 'qts')}
+            return LookaheadDecoderOnlyOutput(sequences=sequences, scores=None, attentions=None, hidden_states=None,
+                                              kwargs=kwargs)
+        return sequences
+
+    # ---------------------------------------------------------------------------------- plain greedy (mode off)
+    @torch.no_grad()
+    def greedy_search(self, input_ids, max_length, eos_token_id=None):
+        """Plain greedy decoding through the same engine (T=1 blocks): the `use_lookahead=False` leg of the
+        reference's examples (examples/llama_example.py:39-69)."""
+        eos = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
+        seq = input_ids[0].tolist()
+        eng = self.engine
+        eng.reset()
+        tok = eng.prefill(seq)
+        seq.append(tok)
+        while len(seq) < max_length and tok not in eos:
+            toks, _ = eng.step(np.asarray([tok], dtype=np.int32), _ONE, mode=0)
+            tok = toks[0]
+            seq.append(tok)
+        return torch.tensor([seq], dtype=torch.long, device=input_ids.device)
+
+    # ------------------------------------------------------------------------------------------- front door
+    def _get_generation_mode(self, decoding_kwargs):
+        """pretrained_model.py:55-106 reduced to the two modes this path serves."""
+        dk = decoding_kwargs or {}
+        if dk.get('use_lookahead', False) and dk.get('decoding_length', 64) > 1 and dk.get('branch_length', 12) > 0:
+            return GenerationMode.LOOKAHEAD_GENERATION
+        return GenerationMode.GREEDY_SEARCH
+
+    def generate(self, input_ids=None, attention_mask=None, max_length=None, max_new_tokens=None,
+                 decoding_kwargs=None, eos_token_id=None, pad_token_id=None, return_dict_in_generate=False,
+                 streamer=None, do_sample=False, repetition_penalty=1.0, **unused):
+        """Minimal generate(): the arguments the reference's examples/benchmarks pass
+        (benchmarks/benchmark.py:282-300, examples/llama_example.py:51-60)."""
+        if do_sample or repetition_penalty != 1.0:
+            raise NotImplementedError('sampling / repetition penalty are outside the parity scope (SURVEY H7)')
+        if max_length is None:
+            max_length = input_ids.size(1) + (max_new_tokens if max_new_tokens is not None else 20)
+        dk = dict(decoding_kwargs or {})
+        if self._get_generation_mode(dk) == GenerationMode.LOOKAHEAD_GENERATION:
+            dk['generation_mode'] = GenerationMode.LOOKAHEAD_GENERATION
+            dk['do_sample'] = False
+            return self.lookahead_generation(input_ids, stopping_criteria=int(max_length), pad_token_id=pad_token_id,
+                                             eos_token_id=eos_token_id, return_dict_in_generate=return_dict_in_generate,
+                                             streamer=streamer, attention_mask=attention_mask, decoding_kwargs=dk)
+        out = self.greedy_search(input_ids, max_length, eos_token_id if eos_token_id is not None
+                                 else getattr(self.generation_config, 'eos_token_id', None))
+        return LookaheadDecoderOnlyOutput(sequences=out, kwargs={}) if return_dict_in_generate else out
+
+    def stream_generate(self, *args, **kwargs):
+        """pretrained_model.py:1323-1350: run generate() on a worker thread, yield from the streamer."""
+        streamer = kwargs.get('streamer')
+        assert streamer is not None, 'stream_generate needs a streamer with an iterator interface'
+        Thread(target=self.generate, args=args, kwargs=kwargs).start()
+        for item in streamer:
+            yield item

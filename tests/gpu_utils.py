@@ -1,0 +1,88 @@
+# -*- coding: utf-8 -*-
+"""Helpers for the -m gpu tests: HBM layout index maps (mirrors of csrc/la_common.h) and ctypes plumbing."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from painlessinferenceacceleration_amd import _lib
+from painlessinferenceacceleration_amd._lib import lib, check
+
+DEV = 'cuda:0'
+
+
+def sp():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def xp_index(K):
+    t = np.arange(64)[:, None]
+    k = np.arange(K)[None, :]
+    return ((k >> 4) * 1024 + (t >> 5) * 512 + ((t & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7)).astype(np.int64)
+
+
+def rf_index(rows, d=128):
+    r = np.arange(rows)[:, None]
+    c = np.arange(d)[None, :]
+    return (((r >> 5) * 8 + (c >> 4)) * 512 + ((r & 31) + 32 * ((c >> 3) & 1)) * 8 + (c & 7)).astype(np.int64)
+
+
+def vf_index(keys, d=128):
+    key = np.arange(keys)[:, None]
+    c = np.arange(d)[None, :]
+    kk = key & 31
+    s2, rr = kk >> 4, kk & 15
+    hh, e = (rr >> 2) & 1, (rr & 3) + 4 * (rr >> 3)
+    return (((key >> 5) * 8 + (c >> 5) * 2 + s2) * 512 + ((c & 31) + 32 * hh) * 8 + e).astype(np.int64)
+
+
+def to_packed(dense, index, size=None):
+    """dense tensor [..., R, C] -> flat packed tensor using an index map [R, C]."""
+    idx = torch.from_numpy(index).to(dense.device)
+    size = int(index.max()) + 1 if size is None else size
+    lead = dense.shape[:-2]
+    out = torch.zeros(lead + (size,), dtype=dense.dtype, device=dense.device)
+    out[..., idx.reshape(-1)] = dense.reshape(lead + (-1,))
+    return out
+
+
+def from_packed(flat, index):
+    idx = torch.from_numpy(index).to(flat.device)
+    return flat[..., idx.reshape(-1)].reshape(flat.shape[:-1] + tuple(index.shape))
+
+
+def pack_weight(w, w2=None):
+    n, k = w.shape
+    out = torch.empty((2 if w2 is not None else 1) * n * k, dtype=torch.bfloat16, device=w.device)
+    check(lib.la_pack_weight(sp(), ptr(w), ptr(w2), n, k, 1 if w2 is not None else 0, ptr(out)), 'pack_weight')
+    return out
+
+
+def pack_x(x):
+    out = torch.empty_like(x).reshape(-1)
+    check(lib.la_pack_x(sp(), ptr(x), x.shape[1], ptr(out)), 'pack_x')
+    return out
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def random_tree(rs, T, branch=0.35):
+    """Random DFS-ordered tree of T rows -> (parent list, uint64 row masks)."""
+    parent = [-1]
+    rows = [1]
+    stack = [0]
+    for i in range(1, T):
+        while len(stack) > 1 and rs.rand() < branch:
+            stack.pop()
+        p = stack[-1]
+        parent.append(p)
+        rows.append(rows[p] | (1 << i))
+        stack.append(i)
+    return parent, np.array(rows, dtype=np.uint64)

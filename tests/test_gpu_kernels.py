@@ -1,0 +1,264 @@
+# -*- coding: utf-8 -*-
+"""-m gpu: every hand-written kernel through its C-ABI entry point against plain PyTorch on the same inputs
+(floating point: stated tolerance; integer/index work: bit-exact against the oracle / reference vectors)."""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from painlessinferenceacceleration_amd import _lib
+from painlessinferenceacceleration_amd._lib import lib, check
+from tests import gpu_utils as gu
+from tests.gpu_utils import DEV, ptr, sp
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def test_library_is_the_native_one():
+    assert lib.la_abi_version() == 1
+    assert torch.cuda.is_available()
+    assert 'gfx950' in torch.cuda.get_device_properties(0).gcnArchName
+
+
+def test_pack_layouts_roundtrip():
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = bf(torch.randn(64, 512, generator=g, device=DEV))
+    xp = gu.pack_x(x)
+    assert torch.equal(gu.from_packed(xp, gu.xp_index(512)), x)
+    w = bf(torch.randn(96, 64, generator=g, device=DEV))
+    wp = gu.pack_weight(w)
+    # WP tile (nb, kb): lane = n%32 + 32*((k%16)/8), e = k%8
+    n = np.arange(96)[:, None]; k = np.arange(64)[None, :]
+    idx = (((n >> 5) * (64 // 16) + (k >> 4)) * 512 + ((n & 31) + 32 * ((k >> 3) & 1)) * 8 + (k & 7)).astype(np.int64)
+    assert torch.equal(gu.from_packed(wp, idx), w)
+
+
+@pytest.mark.parametrize('N,K,rb,ks', [(256, 4096, 1, 1), (256, 4096, 2, 1), (4096, 4096, 1, 2), (4096, 4096, 2, 4),
+                                       (512, 11008, 1, 2), (512, 11008, 2, 1), (12288, 4096, 1, 1), (64, 48, 2, 1)])
+def test_gemm64_slab(N, K, rb, ks):
+    """out[64][N] = x . W^T, bf16 in / fp32 accumulate; tolerance: 2e-3 of max|out| vs an fp64 product."""
+    g = torch.Generator(device=DEV).manual_seed(N + K)
+    x = bf(torch.randn(64, K, generator=g, device=DEV))
+    w = bf(torch.randn(N, K, generator=g, device=DEV) * 0.05)
+    slabs = torch.full((ks, 64, N), float('nan'), dtype=torch.float32, device=DEV)
+    check(lib.la_gemm64_slab(sp(), ptr(gu.pack_weight(w)), ptr(gu.pack_x(x)), N, K, rb, ks, ptr(slabs)), 'gemm')
+    torch.cuda.synchronize()
+    got = slabs.sum(0)
+    ref = x.double() @ w.double().t()
+    assert not torch.isnan(got).any()
+    assert gu.rel_err(got, ref) < 2e-3, gu.rel_err(got, ref)
+    # asymmetric check (transpose detector): a one-hot x row must reproduce a W column
+    x2 = torch.zeros(64, K, dtype=torch.bfloat16, device=DEV)
+    x2[5, 7] = 1.0; x2[40, K - 3] = 2.0
+    check(lib.la_gemm64_slab(sp(), ptr(gu.pack_weight(w)), ptr(gu.pack_x(x2)), N, K, rb, ks, ptr(slabs)), 'gemm')
+    got = slabs.sum(0)
+    assert torch.allclose(got[5], w[:, 7].float(), atol=1e-6) and torch.allclose(got[40], 2 * w[:, K - 3].float(), atol=1e-6)
+    assert float(got[6].abs().max()) == 0.0
+
+
+def test_gemm64_swiglu():
+    """act = bf16(silu(bf16(g)) * bf16(u)) (LlamaMLP), written in the packed operand order of down_proj."""
+    F, K = 1024, 512
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = bf(torch.randn(64, K, generator=g, device=DEV))
+    wg = bf(torch.randn(F, K, generator=g, device=DEV) * 0.05)
+    wu = bf(torch.randn(F, K, generator=g, device=DEV) * 0.05)
+    act = torch.zeros(64 * F, dtype=torch.bfloat16, device=DEV)
+    check(lib.la_gemm64_swiglu(sp(), ptr(gu.pack_weight(wg, wu)), ptr(gu.pack_x(x)), F, K, ptr(act)), 'swiglu')
+    torch.cuda.synchronize()
+    got = gu.from_packed(act, gu.xp_index(F)).float()
+    gg, uu = bf(x.float() @ wg.float().t()), bf(x.float() @ wu.float().t())
+    ref = bf(bf(torch.nn.functional.silu(gg.float())).float() * uu.float()).float()
+    assert gu.rel_err(got, ref) < 2e-2, gu.rel_err(got, ref)     # one bf16 ulp of the largest value
+
+
+@pytest.mark.parametrize('rb', [1, 2])
+def test_gemm64_logits_argmax(rb):
+    V, K = 32000, 512
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = bf(torch.randn(64, K, generator=g, device=DEV))
+    w = bf(torch.randn(V, K, generator=g, device=DEV) * 0.05)
+    logits = torch.zeros(64, V, dtype=torch.bfloat16, device=DEV)
+    nt = V // (32 * rb)
+    cv = torch.zeros(nt * 64, dtype=torch.float32, device=DEV)
+    ci = torch.zeros(nt * 64, dtype=torch.int32, device=DEV)
+    state = torch.zeros(_lib.LA_ST_WORDS, dtype=torch.int32, device=DEV)
+    check(lib.la_gemm64_logits(sp(), ptr(gu.pack_weight(w)), ptr(gu.pack_x(x)), V, K, rb, ptr(logits), ptr(cv), ptr(ci)), 'logits')
+    check(lib.la_argmax_finalize(sp(), ptr(cv), ptr(ci), nt, ptr(state)), 'argmax')
+    torch.cuda.synchronize()
+    ref = x.double() @ w.double().t()
+    assert gu.rel_err(logits.float(), ref) < 1e-2
+    # argmax is exact with respect to the bf16 logits the kernel itself produced (first maximum wins)
+    am = state[_lib.LA_ST_ARGMAX:_lib.LA_ST_ARGMAX + 64].cpu()
+    lf = logits.float().cpu()
+    exp = torch.tensor([int((row == row.max()).nonzero()[0]) for row in lf], dtype=torch.int32)
+    assert torch.equal(am, exp)
+
+
+@pytest.mark.parametrize('hidden', [256, 4096, 5120])
+def test_row_norm_kernels(hidden):
+    g = torch.Generator(device=DEV).manual_seed(hidden)
+    V = 1000
+    embed = bf(torch.randn(V, hidden, generator=g, device=DEV))
+    ids = torch.randint(0, V, (64,), generator=g, device=DEV, dtype=torch.int32)
+    nw = bf(1 + 0.1 * torch.randn(hidden, generator=g, device=DEV))
+    h = torch.zeros(64, hidden, dtype=torch.bfloat16, device=DEV)
+    xp = torch.zeros(64 * hidden, dtype=torch.bfloat16, device=DEV)
+    eps = 1e-5
+    check(lib.la_embed_norm(sp(), ptr(embed), ptr(ids), ptr(nw), hidden, eps, ptr(h), ptr(xp)), 'embed_norm')
+    torch.cuda.synchronize()
+    h_ref = embed[ids.long()]
+    assert torch.equal(h, h_ref)
+
+    def rms(hh):
+        v = hh.float().pow(2).mean(-1, keepdim=True)
+        return bf(nw.float() * (hh.float() * torch.rsqrt(v + eps)))
+    got = gu.from_packed(xp, gu.xp_index(hidden))
+    assert gu.rel_err(got.float(), rms(h_ref).float()) < 1e-2
+    # residual add of two fp32 slabs, then norm
+    slabs = torch.randn(2, 64, hidden, generator=g, device=DEV)
+    check(lib.la_resid_norm(sp(), ptr(h), ptr(slabs), 2, ptr(nw), hidden, eps, ptr(xp)), 'resid_norm')
+    torch.cuda.synchronize()
+    h2 = bf(h_ref.float() + bf(slabs.sum(0)).float())
+    assert gu.rel_err(h.float(), h2.float()) < 1e-2 and (h != h2).float().mean() < 0.01
+    got = gu.from_packed(xp, gu.xp_index(hidden))
+    assert gu.rel_err(got.float(), rms(h).float()) < 1e-2
+
+
+def _rope_ref(x, pos, theta=10000.0):
+    """apply_rotary_pos_emb in bf16 arithmetic (modeling_llama.py:154-169) on x [T, H, 128]."""
+    inv = 1.0 / (theta ** (torch.arange(0, 128, 2, dtype=torch.int64).float() / 128))
+    ang = (inv[:, None].float() @ pos[None, :].float().cpu()).transpose(0, 1)
+    emb = torch.cat((ang, ang), -1)
+    cos, sin = bf(emb.cos()).to(x.device)[:, None], bf(emb.sin()).to(x.device)[:, None]
+    rot = torch.cat((-x[..., 64:], x[..., :64]), -1)
+    return (x * cos) + (rot * sin)
+
+
+@pytest.mark.parametrize('nh,nkv', [(2, 2), (8, 2)])
+def test_qkv_post(nh, nkv):
+    from painlessinferenceacceleration_amd.llama_engine import rope_tables
+    g = torch.Generator(device=DEV).manual_seed(11)
+    N = (nh + 2 * nkv) * 128
+    slabs = torch.randn(2, 64, N, generator=g, device=DEV)
+    pos = torch.randint(0, 900, (64,), generator=g, device=DEV, dtype=torch.int32)
+    rc, rs_ = rope_tables(128, 1024, 10000.0, DEV)
+    qf = torch.zeros(nh * 8192, dtype=torch.bfloat16, device=DEV)
+    kf = torch.zeros(nkv * 8192, dtype=torch.bfloat16, device=DEV)
+    vf = torch.zeros(nkv * 8192, dtype=torch.bfloat16, device=DEV)
+    check(lib.la_qkv_post(sp(), ptr(slabs), 2, nh, nkv, ptr(pos), ptr(rc), ptr(rs_), ptr(qf), ptr(kf), ptr(vf)), 'qkv_post')
+    torch.cuda.synchronize()
+    qkv = bf(slabs.sum(0))
+    q = qkv[:, :nh * 128].view(64, nh, 128)
+    k = qkv[:, nh * 128:(nh + nkv) * 128].view(64, nkv, 128)
+    v = qkv[:, (nh + nkv) * 128:].view(64, nkv, 128)
+    q_ref, k_ref = _rope_ref(q, pos.long()), _rope_ref(k, pos.long())
+    got_q = gu.from_packed(qf.view(nh, 8192), gu.rf_index(64)).transpose(0, 1)     # [64, nh, 128]
+    got_k = gu.from_packed(kf.view(nkv, 8192), gu.rf_index(64)).transpose(0, 1)
+    got_v = gu.from_packed(vf.view(nkv, 8192), gu.vf_index(64)).transpose(0, 1)
+    assert torch.equal(got_v, v)
+    assert torch.equal(got_q, q_ref), (got_q.float() - q_ref.float()).abs().max()
+    assert torch.equal(got_k, k_ref)
+
+
+@pytest.mark.parametrize('nh,nkv,nkeys,nsplit,T', [(2, 2, 0, 1, 64), (2, 2, 70, 2, 64), (4, 1, 333, 4, 17), (2, 2, 640, 8, 64),
+                                                   (2, 2, 31, 3, 1)])
+def test_tree_attention(nh, nkv, nkeys, nsplit, T):
+    """softmax(QK^T/sqrt(d) + tree mask) V with a mask-free prefix: tolerance 2e-2 relative to max|out|
+    (bf16 P and bf16 output rounding) against an fp32 torch attention over the same bf16 inputs."""
+    rs = np.random.RandomState(nkeys + T)
+    g = torch.Generator(device=DEV).manual_seed(nkeys)
+    max_keys = 1024
+    q = bf(torch.randn(nh, 64, 128, generator=g, device=DEV))
+    kmain = bf(torch.randn(nkv, max_keys, 128, generator=g, device=DEV))     # rows >= nkeys are stale garbage
+    vmain = bf(torch.randn(nkv, max_keys, 128, generator=g, device=DEV))
+    kfr = bf(torch.randn(nkv, 64, 128, generator=g, device=DEV))
+    vfr = bf(torch.randn(nkv, 64, 128, generator=g, device=DEV))
+    _, rows = gu.random_tree(rs, T)
+    rowmask = np.array([int(rows[t]) if t < T else (1 << t) for t in range(64)], dtype=np.uint64)
+    qf = gu.to_packed(q, gu.rf_index(64), 8192).reshape(-1)
+    km = gu.to_packed(kmain, gu.rf_index(max_keys), max_keys * 128).reshape(-1)
+    vm = gu.to_packed(vmain, gu.vf_index(max_keys), max_keys * 128).reshape(-1)
+    kf = gu.to_packed(kfr, gu.rf_index(64), 8192).reshape(-1)
+    vf = gu.to_packed(vfr, gu.vf_index(64), 8192).reshape(-1)
+    state = torch.zeros(_lib.LA_ST_WORDS, dtype=torch.int32, device=DEV)
+    state[_lib.LA_ST_NKEYS] = nkeys
+    rm = torch.from_numpy(rowmask.view(np.int64)).to(DEV)
+    opart = torch.zeros(nh * nsplit * 64 * 128, dtype=torch.float32, device=DEV)
+    mpart = torch.zeros(nh * nsplit * 64, dtype=torch.float32, device=DEV)
+    lpart = torch.zeros_like(mpart)
+    out = torch.zeros(64 * nh * 128, dtype=torch.bfloat16, device=DEV)
+    check(lib.la_tree_attn(sp(), ptr(qf), ptr(km), ptr(vm), ptr(kf), ptr(vf), ptr(rm), ptr(state), nh, nkv, max_keys,
+                           nsplit, ptr(opart), ptr(mpart), ptr(lpart), ptr(out)), 'tree_attn')
+    torch.cuda.synchronize()
+    got = gu.from_packed(out, gu.xp_index(nh * 128)).float().view(64, nh, 128)
+    rep = nh // nkv
+    K = torch.cat([kmain[:, :nkeys], kfr], 1).float().repeat_interleave(rep, 0)       # [nh, nkeys+64, 128]
+    Vv = torch.cat([vmain[:, :nkeys], vfr], 1).float().repeat_interleave(rep, 0)
+    mask = torch.ones(64, nkeys + 64, dtype=torch.bool, device=DEV)
+    mask[:, nkeys:] = torch.tensor([[(int(rowmask[t]) >> j) & 1 for j in range(64)] for t in range(64)], dtype=torch.bool)
+    s = torch.einsum('htd,hkd->htk', q.float(), K) / math.sqrt(128)
+    s = s.masked_fill(~mask[None], float('-inf'))
+    ref = torch.einsum('htk,hkd->thd', torch.softmax(s, -1), Vv)
+    err = gu.rel_err(got[:T], ref[:T])
+    assert err < 2e-2, err
+    assert not torch.isnan(got).any()
+
+
+def test_accept_scan_matches_reference_vectors():
+    """Bit-exact: the reference's own outputs (tests/golden/accept_scan.json, recorded from
+    _lookahead_update_model_kwargs_for_generation) for tokens, count and kept KV rows."""
+    vecs = json.load(open(os.path.join(GOLDEN, 'accept_scan.json')))
+    for v in vecs:
+        T = len(v['ids'])
+        ids = torch.zeros(64, dtype=torch.int32); ids[:T] = torch.tensor(v['ids'], dtype=torch.int32)
+        rm = np.array([v['rows'][t] if t < T else (1 << t) for t in range(64)], dtype=np.uint64)
+        state = torch.zeros(_lib.LA_ST_WORDS, dtype=torch.int32)
+        ctx = v['context_length']
+        state[_lib.LA_ST_NKEYS] = ctx - 1
+        state[_lib.LA_ST_T] = T
+        state[_lib.LA_ST_ARGMAX:_lib.LA_ST_ARGMAX + T] = torch.tensor(v['argmax'], dtype=torch.int32)
+        d_ids, d_state = ids.to(DEV), state.to(DEV)
+        d_rm = torch.from_numpy(rm.view(np.int64)).to(DEV)
+        check(lib.la_accept_scan(sp(), ptr(d_ids), ptr(d_rm), ptr(d_state)), 'accept')
+        torch.cuda.synchronize()
+        st = d_state.cpu().numpy()
+        n = int(st[_lib.LA_ST_NOUT])
+        assert st[_lib.LA_ST_OUTTOK:_lib.LA_ST_OUTTOK + n].tolist() == v['next_token_list'], v
+        assert n == v['edls'][0] and int(st[_lib.LA_ST_NCOMMIT]) == n
+        src = st[_lib.LA_ST_SRCIDX:_lib.LA_ST_SRCIDX + n].tolist()
+        kept = list(range(ctx - 1)) + [ctx - 1 + s for s in src]           # committed keys after the step
+        assert kept == v['kept_kv'], (kept, v['kept_kv'])
+        assert int(st[_lib.LA_ST_NKEYS]) == ctx - 1 + n and int(st[_lib.LA_ST_DSTBASE]) == ctx - 1
+
+
+def test_kv_commit_moves_rows():
+    L, nkv, max_keys = 3, 2, 256
+    g = torch.Generator(device=DEV).manual_seed(2)
+    kfr = bf(torch.randn(L * nkv, 64, 128, generator=g, device=DEV))
+    vfr = bf(torch.randn(L * nkv, 64, 128, generator=g, device=DEV))
+    kf = gu.to_packed(kfr, gu.rf_index(64), 8192).reshape(-1)
+    vf = gu.to_packed(vfr, gu.vf_index(64), 8192).reshape(-1)
+    km = torch.zeros(L * nkv * max_keys * 128, dtype=torch.bfloat16, device=DEV)
+    vm = torch.zeros_like(km)
+    src = [0, 5, 6, 40, 63]
+    state = torch.zeros(_lib.LA_ST_WORDS, dtype=torch.int32)
+    state[_lib.LA_ST_NCOMMIT] = len(src); state[_lib.LA_ST_DSTBASE] = 30
+    state[_lib.LA_ST_SRCIDX:_lib.LA_ST_SRCIDX + len(src)] = torch.tensor(src, dtype=torch.int32)
+    d_state = state.to(DEV)
+    check(lib.la_kv_commit(sp(), ptr(kf), ptr(vf), ptr(km), ptr(vm), ptr(d_state), L, nkv, max_keys), 'commit')
+    torch.cuda.synchronize()
+    K = gu.from_packed(km.view(L * nkv, -1), gu.rf_index(max_keys))
+    V = gu.from_packed(vm.view(L * nkv, -1), gu.vf_index(max_keys))
+    for i, s in enumerate(src):
+        assert torch.equal(K[:, 30 + i], kfr[:, s]) and torch.equal(V[:, 30 + i], vfr[:, s])
+    assert float(K[:, :30].abs().max()) == 0 and float(K[:, 35:].abs().max()) == 0 and float(V[:, 35:].abs().max()) == 0

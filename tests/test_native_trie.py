@@ -90,7 +90,7 @@ def test_native_matches_oracle_fuzz(seed):
 def test_squeeze_after_warmup_like_benchmark():
     """after a 100x256-token warm-up >= 1024 trees are dirty and final=True prunes the forest."""
     rng = np.random.RandomState(0)
-    a, b = LookaheadCache(), TrieOracle()
+    a, b = LookaheadCache(max_output_node=100), TrieOracle(max_output_node=100)
     for _ in range(100):
         toks = rng.randint(3, 1800, size=256).tolist()
         a.put(toks, branch_length=13, mode='output', idx=-1); b.put(toks, branch_length=13, mode='output', idx=-1)

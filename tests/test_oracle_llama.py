@@ -1,0 +1,78 @@
+# -*- coding: utf-8 -*-
+"""Pin the model-side ORACLE (oracle/llama_oracle.py) against vectors recorded from the reference classes
+(oracle/gen_golden_model.py: LlamaForCausalLM + LookaheadPreTrainedModel.lookahead_generation run on CPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import llama_oracle as lo
+from oracle.trie_oracle import TrieOracle
+from tests.tiny_model import GOLDEN, load_golden, tiny_shape, tiny_weights
+
+
+def _rows_to_mask(rows):
+    T = len(rows)
+    return np.array([[(int(r) >> j) & 1 for j in range(T)] for r in rows], dtype=np.int64)
+
+
+def test_accept_scan_matches_reference_vectors():
+    vecs = json.load(open(os.path.join(GOLDEN, 'accept_scan.json')))
+    assert len(vecs) >= 40
+    partial = 0
+    for v in vecs:
+        mask = _rows_to_mask(v['rows'])
+        toks, rows = lo.accept_scan(v['ids'], mask, v['argmax'])
+        assert toks == v['next_token_list'], v
+        assert lo.kv_keep_positions(v['context_length'], len(v['ids']) - 1, rows) == v['kept_kv'], v
+        assert v['edls'] == [len(toks)] and v['dls'] == [len(v['ids'])]
+        partial += 1 < len(toks) < len(v['ids'])
+    assert partial >= 5      # the vectors exercise partial acceptance, not only 0 / all
+
+
+def test_survey_worked_example():
+    """Tree(1) with [1,2,3],[1,2,4]; argmax rows {0->2, 1->4, 3->9}; ctx=5."""
+    mask = _rows_to_mask([1, 3, 7, 11])
+    toks, rows = lo.accept_scan([1, 2, 3, 4], mask, [2, 4, 0, 9])
+    assert toks == [2, 4, 9] and rows == [0, 1, 3]
+    assert lo.kv_keep_positions(5, 3, rows) == [0, 1, 2, 3, 4, 5, 7]
+
+
+@pytest.mark.parametrize('tag,dtype', [('fp32', torch.float32), ('bf16', torch.bfloat16)])
+def test_oracle_loop_matches_reference_generation(tag, dtype):
+    g = load_golden(tag)
+    torch.set_num_threads(4)
+    model = lo.OracleLlama(tiny_shape(), tiny_weights(0, torch.float32))
+    model.w = {k: v.to(dtype) for k, v in model.w.items()}
+    model.dtype = dtype
+    cache = TrieOracle()
+    prompt = g['prompt'].tolist()
+    max_length = len(prompt) + 96
+    for r in range(int(g['n_runs'])):
+        rec = []
+        out = lo.lookahead_generate(model, cache, prompt, max_length, eos_token_id=2, record=rec)
+        assert out['sequences'] == g[f'r{r}_sequences'].tolist()
+        assert out['dls'] == g[f'r{r}_dls'].tolist() and out['edls'] == g[f'r{r}_edls'].tolist()
+        assert len(rec) == int(g[f'r{r}_nsteps'])
+        for i, st in enumerate(rec):
+            assert st['ids'] == g[f'r{r}_s{i}_ids'].tolist(), (r, i)
+            assert st['next'] == g[f'r{r}_s{i}_next'].tolist(), (r, i)
+            assert st['argmax'] == g[f'r{r}_s{i}_argmax'].tolist(), (r, i)
+            if f'r{r}_s{i}_rows' in g.files:
+                assert st['rows'] == [int(x) for x in g[f'r{r}_s{i}_rows']], (r, i)
+    if dtype == torch.float32:
+        n_new = len(g['greedy']) - len(prompt)
+        assert lo.greedy_generate(model, prompt, n_new) == g['greedy'].tolist()
+        assert out['sequences'][:len(g['greedy'])] == g['greedy'].tolist()[:len(out['sequences'])]
+
+
+def test_oracle_forward_logits_match_reference_sample():
+    g = load_golden('fp32')
+    model = lo.OracleLlama(tiny_shape(), tiny_weights(0, torch.float32))
+    prompt = g['prompt'].tolist()
+    P = len(prompt)
+    logits, _ = model.forward(torch.tensor(prompt), torch.tril(torch.ones((P, P), dtype=torch.long)), None)
+    ref = g['r0_s0_logits']
+    assert np.abs(logits[:, :64].numpy() - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())

@@ -1,0 +1,51 @@
+# -*- coding: utf-8 -*-
+"""The tiny seeded Llama shared by the oracle / golden / GPU parity tests (same recipe as
+oracle/gen_golden_model.py: weights are a pure function of a numpy seed)."""
+import os
+
+import numpy as np
+import torch
+
+from painlessinferenceacceleration_amd.llama_engine import LlamaShape
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+TINY = dict(n_layers=2, hidden=256, n_heads=2, n_kv_heads=2, ffn=512, vocab=512, rms_eps=1e-5)
+
+
+def tiny_shape(**over):
+    c = dict(TINY); c.update(over)
+    return LlamaShape(c['n_layers'], c['hidden'], c['n_heads'], c['n_kv_heads'], c['ffn'], c['vocab'], c['rms_eps'])
+
+
+def tiny_weights(seed=0, dtype=torch.float32, std=0.08, cfg=None):
+    rs = np.random.RandomState(seed)
+    c = dict(TINY)
+    if cfg:
+        c.update(cfg)
+    hd = 128 if cfg and cfg.get('head_dim') else c['hidden'] // c['n_heads']
+
+    def w(n, k):
+        return torch.from_numpy((rs.standard_normal((n, k)) * std).astype(np.float32)).to(dtype)
+
+    def nw():
+        return torch.from_numpy((1.0 + 0.1 * rs.standard_normal(c['hidden'])).astype(np.float32)).to(dtype)
+
+    sd = {'model.embed_tokens.weight': w(c['vocab'], c['hidden'])}
+    for i in range(c['n_layers']):
+        p = f'model.layers.{i}.'
+        sd[p + 'self_attn.q_proj.weight'] = w(c['n_heads'] * hd, c['hidden'])
+        sd[p + 'self_attn.k_proj.weight'] = w(c['n_kv_heads'] * hd, c['hidden'])
+        sd[p + 'self_attn.v_proj.weight'] = w(c['n_kv_heads'] * hd, c['hidden'])
+        sd[p + 'self_attn.o_proj.weight'] = w(c['hidden'], c['n_heads'] * hd)
+        sd[p + 'mlp.gate_proj.weight'] = w(c['ffn'], c['hidden'])
+        sd[p + 'mlp.up_proj.weight'] = w(c['ffn'], c['hidden'])
+        sd[p + 'mlp.down_proj.weight'] = w(c['hidden'], c['ffn'])
+        sd[p + 'input_layernorm.weight'] = nw()
+        sd[p + 'post_attention_layernorm.weight'] = nw()
+    sd['model.norm.weight'] = nw()
+    sd['lm_head.weight'] = w(c['vocab'], c['hidden'])
+    return sd
+
+
+def load_golden(tag):
+    return np.load(os.path.join(GOLDEN, f'llama_tiny_{tag}.npz'))
