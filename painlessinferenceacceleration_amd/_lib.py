@@ -23,7 +23,31 @@ class LookaheadHipError(RuntimeError):
     pass
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7).  liblookahead_hip.so must
+    share that ONE runtime instance with torch (streams and device pointers cross the boundary); if the system copy
+    under /opt/rocm were loaded first the process would hold two HIP runtimes.  Loading torch's copy first (without
+    importing torch) makes the dynamic loader resolve our NEEDED libamdhip64.so.7 to it."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    libdir = os.path.join(os.path.dirname(spec.origin), 'lib')
+    for name in ('libhsa-runtime64.so', 'libamdhip64.so'):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return None
+    return libdir
+
+
 def _load():
+    _preload_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with "

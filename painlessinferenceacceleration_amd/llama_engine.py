@@ -100,7 +100,9 @@ class LlamaVerifyEngine(object):
         torch.cuda.set_device(self.device)
         self.max_keys = int(math.ceil((max_length + 64 + 1) / 32.0)) * 32
         self.max_pos = self.max_keys + 64
-        self.stream = torch.cuda.current_stream(self.device)
+        # a dedicated non-default stream: hipStreamBeginCapture is illegal on the legacy NULL stream that
+        # torch.cuda.current_stream() returns by default
+        self.stream = torch.cuda.Stream(self.device)
         sp = C.c_void_p(self.stream.cuda_stream)
         hd = shape.head_dim
         self._keep = []
@@ -116,8 +118,10 @@ class LlamaVerifyEngine(object):
             if w2 is not None:
                 w2 = w2.to(device=self.device, dtype=torch.bfloat16).contiguous()
             out = torch.empty((2 if w2 is not None else 1) * n * k, dtype=torch.bfloat16, device=self.device)
+            torch.cuda.synchronize(self.device)          # w was produced on torch's stream
             check(lib.la_pack_weight(sp, w.data_ptr(), w2.data_ptr() if w2 is not None else None, n, k,
                                      1 if w2 is not None else 0, out.data_ptr()), 'pack_weight')
+            self.stream.synchronize()                    # w / w2 may be freed by the caller right after
             self._keep.append(out)
             return out
 
@@ -179,7 +183,7 @@ class LlamaVerifyEngine(object):
 
     # ------------------------------------------------------------------------------------------------
     def _sp(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(self.stream.cuda_stream)
 
     def reset(self):
         check(lib.la_llama_reset(self._h, self._sp()), 'llama_reset')
@@ -204,7 +208,7 @@ class LlamaVerifyEngine(object):
     def step(self, ids, rowmask, mode=0, eager=False):
         """-> list of emitted tokens (accepted path + bonus), list of accepted tree rows."""
         self.step_async(ids, rowmask, mode, eager)
-        torch.cuda.current_stream(self.device).synchronize()
+        self.stream.synchronize()
         o = self._out_np
         n_out = int(o[_lib.LA_ST_NOUT])
         self.n_keys = int(o[_lib.LA_ST_NKEYS])

@@ -43,14 +43,16 @@ def test_pack_layouts_roundtrip():
 
 
 @pytest.mark.parametrize('N,K,rb,ks', [(256, 4096, 1, 1), (256, 4096, 2, 1), (4096, 4096, 1, 2), (4096, 4096, 2, 4),
-                                       (512, 11008, 1, 2), (512, 11008, 2, 1), (12288, 4096, 1, 1), (64, 48, 2, 1)])
+                                       (512, 11008, 1, 2), (512, 11008, 2, 1), (12288, 4096, 1, 1), (64, 48, 2, 1),
+                                       (96, 1104, 1, 4), (4096, 11008, 1, 3)])
 def test_gemm64_slab(N, K, rb, ks):
     """out[64][N] = x . W^T, bf16 in / fp32 accumulate; tolerance: 2e-3 of max|out| vs an fp64 product."""
     g = torch.Generator(device=DEV).manual_seed(N + K)
     x = bf(torch.randn(64, K, generator=g, device=DEV))
     w = bf(torch.randn(N, K, generator=g, device=DEV) * 0.05)
     slabs = torch.full((ks, 64, N), float('nan'), dtype=torch.float32, device=DEV)
-    check(lib.la_gemm64_slab(sp(), ptr(gu.pack_weight(w)), ptr(gu.pack_x(x)), N, K, rb, ks, ptr(slabs)), 'gemm')
+    wp, xp = gu.pack_weight(w), gu.pack_x(x)          # keep references: temporaries would be recycled by the allocator
+    check(lib.la_gemm64_slab(sp(), ptr(wp), ptr(xp), N, K, rb, ks, ptr(slabs)), 'gemm')
     torch.cuda.synchronize()
     got = slabs.sum(0)
     ref = x.double() @ w.double().t()
@@ -59,7 +61,8 @@ def test_gemm64_slab(N, K, rb, ks):
     # asymmetric check (transpose detector): a one-hot x row must reproduce a W column
     x2 = torch.zeros(64, K, dtype=torch.bfloat16, device=DEV)
     x2[5, 7] = 1.0; x2[40, K - 3] = 2.0
-    check(lib.la_gemm64_slab(sp(), ptr(gu.pack_weight(w)), ptr(gu.pack_x(x2)), N, K, rb, ks, ptr(slabs)), 'gemm')
+    xp2 = gu.pack_x(x2)
+    check(lib.la_gemm64_slab(sp(), ptr(wp), ptr(xp2), N, K, rb, ks, ptr(slabs)), 'gemm')
     got = slabs.sum(0)
     assert torch.allclose(got[5], w[:, 7].float(), atol=1e-6) and torch.allclose(got[40], 2 * w[:, K - 3].float(), atol=1e-6)
     assert float(got[6].abs().max()) == 0.0
@@ -73,7 +76,8 @@ def test_gemm64_swiglu():
     wg = bf(torch.randn(F, K, generator=g, device=DEV) * 0.05)
     wu = bf(torch.randn(F, K, generator=g, device=DEV) * 0.05)
     act = torch.zeros(64 * F, dtype=torch.bfloat16, device=DEV)
-    check(lib.la_gemm64_swiglu(sp(), ptr(gu.pack_weight(wg, wu)), ptr(gu.pack_x(x)), F, K, ptr(act)), 'swiglu')
+    wp, xp = gu.pack_weight(wg, wu), gu.pack_x(x)
+    check(lib.la_gemm64_swiglu(sp(), ptr(wp), ptr(xp), F, K, ptr(act)), 'swiglu')
     torch.cuda.synchronize()
     got = gu.from_packed(act, gu.xp_index(F)).float()
     gg, uu = bf(x.float() @ wg.float().t()), bf(x.float() @ wu.float().t())
@@ -92,7 +96,8 @@ def test_gemm64_logits_argmax(rb):
     cv = torch.zeros(nt * 64, dtype=torch.float32, device=DEV)
     ci = torch.zeros(nt * 64, dtype=torch.int32, device=DEV)
     state = torch.zeros(_lib.LA_ST_WORDS, dtype=torch.int32, device=DEV)
-    check(lib.la_gemm64_logits(sp(), ptr(gu.pack_weight(w)), ptr(gu.pack_x(x)), V, K, rb, ptr(logits), ptr(cv), ptr(ci)), 'logits')
+    wp, xp = gu.pack_weight(w), gu.pack_x(x)
+    check(lib.la_gemm64_logits(sp(), ptr(wp), ptr(xp), V, K, rb, ptr(logits), ptr(cv), ptr(ci)), 'logits')
     check(lib.la_argmax_finalize(sp(), ptr(cv), ptr(ci), nt, ptr(state)), 'argmax')
     torch.cuda.synchronize()
     ref = x.double() @ w.double().t()
