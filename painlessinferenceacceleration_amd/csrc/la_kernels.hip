@@ -67,15 +67,21 @@ __global__ __launch_bounds__(512) void k_gemm64(GemmArgs a) {
     const int ksplit = gridDim.y, ks = blockIdx.y;
     const int t0 = (int)(((long)a.K16 * ks) / ksplit);
     const int t1 = (int)(((long)a.K16 * (ks + 1)) / ksplit);
-    const int twg = t1 - t0, q = twg >> 3, r = twg & 7;
-    const int wb = t0 + wave * q + (wave < r ? wave : r);
-    const int cnt = q + (wave < r ? 1 : 0);
+    // The workgroup's k-tiles are dealt to its 8 waves in groups of D tiles, so that every wave runs the
+    // branch-free pipelined loop below (counted vmcnt waits); the < D left-over tiles go to wave 7.
+    const int twg = t1 - t0, G = twg / D, R = twg - G * D;
+    const int gq = G >> 3, gr = G & 7;
+    const int ngroups = gq + (wave < gr ? 1 : 0);
+    const int wb = t0 + (wave * gq + (wave < gr ? wave : gr)) * D;
 
-    const bf16x8* wptr[RB];
+    // integer offsets from the kernel-argument bases (not mutated pointers) keep the loads in the global
+    // address space: a loop-carried pointer degrades to flat_load, which ties vmcnt and lgkmcnt together
+    const bf16x8* __restrict__ wbase = (const bf16x8*)a.wp;
+    const bf16x8* __restrict__ xbase = (const bf16x8*)a.xp;
+    unsigned woff[RB];
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-        wptr[rb] = (const bf16x8*)(a.wp + ((size_t)(nb0 + rb) * a.K16 + wb) * 512) + lane;
-    const bf16x8* xptr = (const bf16x8*)(a.xp + (size_t)wb * 1024) + lane;
+    for (int rb = 0; rb < RB; ++rb) woff[rb] = (unsigned)(((nb0 + rb) * a.K16 + wb) * 64 + lane);
+    unsigned xoff = (unsigned)(wb * 128 + lane);
 
     f32x16 acc[RB][2];
 #pragma unroll
@@ -85,33 +91,53 @@ __global__ __launch_bounds__(512) void k_gemm64(GemmArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[rb][tb][i] = 0.f;
 
-    bf16x8 fa[D][RB], fb[D][2];
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        if (d < cnt) {
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wptr[rb] + (size_t)d * 64);
-            fb[d][0] = xptr[(size_t)d * 128];
-            fb[d][1] = xptr[(size_t)d * 128 + 64];
-        }
-    }
-    for (int t = 0; t < cnt; t += D) {
+    if (ngroups > 0) {
+        bf16x8 fa[D][RB], fb[D][2];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            if (t + d < cnt) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wbase + woff[rb] + d * 64);
+            fb[d][0] = xbase[xoff + d * 128];
+            fb[d][1] = xbase[xoff + d * 128 + 64];
+        }
+        for (int g = 1; g < ngroups; ++g) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) woff[rb] += D * 64;
+            xoff += D * 128;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
                     acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][0], acc[rb][0], 0, 0, 0);
                     acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][1], acc[rb][1], 0, 0, 0);
                 }
-                const int tn = t + d + D;
-                if (tn < cnt) {
 #pragma unroll
-                    for (int rb = 0; rb < RB; ++rb)
-                        fa[d][rb] = __builtin_nontemporal_load(wptr[rb] + (size_t)tn * 64);
-                    fb[d][0] = xptr[(size_t)tn * 128];
-                    fb[d][1] = xptr[(size_t)tn * 128 + 64];
-                }
+                for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wbase + woff[rb] + d * 64);
+                fb[d][0] = xbase[xoff + d * 128];
+                fb[d][1] = xbase[xoff + d * 128 + 64];
+                // pin {consume slot d, refill slot d} so the refills stay D-1 slots ahead and hipcc emits
+                // counted vmcnt waits instead of sinking every load below the MFMAs (which drains to vmcnt(0))
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][0], acc[rb][0], 0, 0, 0);
+                acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][1], acc[rb][1], 0, 0, 0);
+            }
+    }
+    if (wave == 7 && R > 0) {      // left-over tiles (only when (K/16)/ksplit is not a multiple of D)
+        const int tb0 = t0 + G * D;
+        for (int i = 0; i < R; ++i) {
+            bf16x8 xa = *((const bf16x8*)(a.xp + (size_t)(tb0 + i) * 1024) + lane);
+            bf16x8 xb = *((const bf16x8*)(a.xp + (size_t)(tb0 + i) * 1024) + 64 + lane);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                bf16x8 wv = *((const bf16x8*)(a.wp + ((size_t)(nb0 + rb) * a.K16 + tb0 + i) * 512) + lane);
+                acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xa, acc[rb][0], 0, 0, 0);
+                acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xb, acc[rb][1], 0, 0, 0);
             }
         }
     }

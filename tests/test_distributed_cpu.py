@@ -1,0 +1,98 @@
+# -*- coding: utf-8 -*-
+"""CPU, world_size=2, gloo: the accepted-token all-gather keeps every rank's trie replica identical to a
+single-process cache that is fed all sequences in global batch-index order (the N>1 path of bench.py)."""
+import os
+import random
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _streams(world, steps):
+    rng = random.Random(3)
+    phrases = [[rng.randrange(3, 60) for _ in range(rng.randint(3, 9))] for _ in range(10)]
+    out = []
+    for r in range(world):
+        rr = random.Random(100 + r)
+        seq = []
+        for _ in range(steps):
+            n = rr.randint(1, 13)
+            step = []
+            while len(step) < n:
+                step.extend(phrases[rr.randrange(10)])
+            seq.append(step[:n])
+        out.append(seq)
+    return out
+
+
+def _worker(rank, world, port, steps, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from painlessinferenceacceleration_amd.distributed import AcceptedTokenGather
+    from painlessinferenceacceleration_amd.lookahead_cache import LookaheadCache
+    cache = LookaheadCache(eos_ids=[None])
+    g = AcceptedTokenGather('cpu')
+    mine = _streams(world, steps)[rank]
+    seen = []
+    for s in range(steps):
+        seen.append(g.update_trie(cache, mine[s], branch_length=12))
+    g.update_trie(cache, [], branch_length=12, final=True)
+    res = []
+    rng = random.Random(9)
+    for _ in range(200):
+        qy = [rng.randrange(3, 60) for _ in range(2)]
+        ids, mask, sizes = cache.hier_get(qy, decoding_length=64, branch_length=12, min_output_size=32, mode='mix', idx=rank)
+        res.append((ids, mask.tolist(), sizes))
+    q.put((rank, seen, res, cache.stats()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_trie_replicas_stay_identical():
+    world, steps = 2, 40
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = {}
+    for _ in range(world):
+        rank, seen, res, stats = q.get(timeout=180)
+        outs[rank] = (seen, res, stats)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # every rank saw every sequence's tokens, in rank order
+    streams = _streams(world, steps)
+    for r in range(world):
+        for s in range(steps):
+            assert outs[r][0][s] == [streams[k][s] for k in range(world)]
+    # replicas agree with each other (queries carry idx=rank, but no input freqs exist, so drafts coincide)
+    assert outs[0][1] == outs[1][1]
+    # ... and with a single-process cache fed in global batch-index order
+    from painlessinferenceacceleration_amd.lookahead_cache import LookaheadCache
+    ref = LookaheadCache(eos_ids=[None])
+    for s in range(steps):
+        for r in range(world):
+            ref.stream_put(streams[r][s], branch_length=13, final=False, idx=r)
+    for r in range(world):
+        ref.stream_put([], branch_length=13, final=True, idx=r)
+    assert ref.stats()['n_nodes'] == outs[0][2]['n_nodes'] == outs[1][2]['n_nodes']
+    rng = random.Random(9)
+    for i in range(200):
+        qy = [rng.randrange(3, 60) for _ in range(2)]
+        ids, mask, sizes = ref.hier_get(qy, decoding_length=64, branch_length=12, min_output_size=32, mode='mix', idx=0)
+        assert (ids, mask.tolist(), sizes) == outs[0][1][i]
