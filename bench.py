@@ -9,8 +9,8 @@ Workload (configs[1]): Llama-2-7B (random init, real shape, bf16), bs=1 per GPU,
 ~8 branches per verify step, hier mode, decoding_length=64, branch_length=12.  One "step" = trie query ->
 captured verify graph (embed, 32 layers, lm_head+argmax, accept scan, KV commit) -> trie update.
 Synthetic data: the prompt is 512 phrase-bank tokens; the trie is warmed, as the reference's
-Benchmark.warm_up does (benchmarks/benchmark.py:159-169), with 8 noisy copies of the model's own greedy
-continuation (each token replaced with probability rho), so drafts are multi-branch and partially accepted.
+Benchmark.warm_up does (benchmarks/benchmark.py:159-169), with 12 noisy copies of the model's own greedy
+continuation (each token replaced with probability rho=0.3), so drafts are multi-branch and partially accepted.
 Multi-GPU: one independent sequence per rank (batch sharding, weak scaling); the only exchange is the
 per-step all-gather of accepted tokens over RCCL so that every rank's trie replica sees every sequence.
 """
@@ -119,7 +119,8 @@ def main():
     ap.add_argument('--steps', type=int, default=64)
     ap.add_argument('--warmup', type=int, default=8)
     ap.add_argument('--prompt-len', type=int, default=512)
-    ap.add_argument('--rho', type=float, default=0.12)
+    ap.add_argument('--rho', type=float, default=0.3, help='token corruption rate of the warm-up copies')
+    ap.add_argument('--copies', type=int, default=12, help='noisy copies of the continuation put into the trie')
     ap.add_argument('--layers', type=int, default=0, help='debug: override layer count (invalidates the metric)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-iters', type=int, default=3)
@@ -168,7 +169,7 @@ def main():
     else:
         truths = [truth]
     for r in range(world):
-        for c in noisy_copies(prompts[r][-2:] + truths[r], 8, args.rho, shape.vocab, seed=99 + r):
+        for c in noisy_copies(prompts[r][-2:] + truths[r], args.copies, args.rho, shape.vocab, seed=99 + r):
             cache.put(c, branch_length=BL + 1, mode='output', idx=-1)
 
     # ---- the measured loop ----------------------------------------------------------------------------------
@@ -176,6 +177,8 @@ def main():
     cache.put(seq[1:], branch_length=BL + 1, mode='input', idx=rank)
     eng.reset()
     seq.append(eng.prefill(seq))
+    if os.environ.get('BENCH_DEBUG'):
+        print(f'[debug] prefill tok {seq[-1]} truth0 {truth[0]} nkeys {eng.n_keys}', file=sys.stderr, flush=True)
     gather_in = torch.zeros(16, dtype=torch.int32, device=dev)
     gather_out = torch.zeros(16 * world, dtype=torch.int32, device=dev) if world > 1 else None
     edls, dls, qts = [], [], []
@@ -187,6 +190,10 @@ def main():
                                                    min_output_size=DL // 2, mode='mix', idx=rank)
         qts.append(time.time() - tq)
         toks, _ = eng.step(ids, rowmask, mode=0)
+        if os.environ.get('BENCH_DEBUG') and len(edls) < 6:
+            k = len(seq) - P
+            print(f'[debug] step {len(edls)} ctx {len(seq)} T {len(ids)} ids {ids[:5].tolist()} -> toks {toks[:6]} '
+                  f'truth {truth[k:k + 6]} prev-truth {truth[max(k - 2, 0):k]}', file=sys.stderr, flush=True)
         seq.extend(toks)
         dls.append(len(ids)); edls.append(len(toks))
         if world > 1:
@@ -261,9 +268,9 @@ def main():
         'metric': 'accepted_tokens_per_sec', 'value': round(accepted_all / elapsed, 2), 'unit': 'tokens/s',
         'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': 'Llama-2-7B bf16 bs=1/GPU lookahead verify loop, 64-token draft tree / 8 noisy branches '
+        'config': {'workload': 'Llama-2-7B bf16 bs=1/GPU lookahead verify loop, 64-token draft tree / 8-12 noisy branches '
                                '(hier, decoding_length=64, branch_length=12), random-init weights, 512-token phrase-bank prompt',
-                   'n_layers': shape.n_layers, 'prompt_len': P, 'rho': args.rho, 'parallelism': f'batch-shard x{world}',
+                   'n_layers': shape.n_layers, 'prompt_len': P, 'rho': args.rho, 'copies': args.copies, 'parallelism': f'batch-shard x{world}',
                    'mean_accept_len': round(mean_acc, 3), 'mean_draft_len': round(mean_T, 2),
                    'verify_steps_per_sec': round(K * world / elapsed, 2), 'context_at_end': ctx,
                    'trie_query_ms_mean': round(1e3 * float(np.mean(qts[n0:])), 4),

@@ -146,10 +146,12 @@ int la_pack_x(void* stream, const void* d_x, int K, void* d_out);
 
 /* Skinny GEMM  out[64][N] = x[64][K] . W[N][K]^T  (bf16 in, fp32 accumulate), split-K slabs.
  * Replaces the nn.Linear calls of LlamaAttention/LlamaMLP (modeling_llama.py:172-186, 222-224, 296). */
+/* `rb`: low byte = 32-row blocks of W per workgroup (1 or 2); bits 8.. = pipeline variant
+ * (0 = 4 waves x 8 tile-sets in flight [default], 1 = 8 waves x 4, 2 = 4 waves x 6, 3 = 8 waves x 8). */
 int la_gemm64_slab(void* stream, const void* d_wp, const void* d_xp, int N, int K, int rb, int ksplit,
                    float* d_slabs /*[ksplit][64][N]*/);
 int la_gemm64_swiglu(void* stream, const void* d_wp_gateup, const void* d_xp, int F, int K,
-                     void* d_act_packed /*[64][F] packed*/);
+                     void* d_act_packed /*[64][F] packed*/, int variant);
 int la_gemm64_logits(void* stream, const void* d_wp, const void* d_xp, int V, int K, int rb,
                      void* d_logits_bf16 /*[64][V] or NULL*/, float* d_cand_val, int32_t* d_cand_idx);
 int la_argmax_finalize(void* stream, const float* d_cand_val, const int32_t* d_cand_idx, int n_tiles,
@@ -182,7 +184,7 @@ typedef struct la_llama_config {
     int32_t max_pos;         /* rows in the RoPE tables                                       */
     int32_t attn_split;      /* key-range splits per head (0 = auto)                          */
     float   rms_eps;
-    int32_t gemm_cfg[8];     /* {qkv_rb,qkv_ks,o_rb,o_ks,down_rb,down_ks,lm_rb,reserved}; 0 = auto */
+    int32_t gemm_cfg[8];     /* {qkv_rb,qkv_ks,o_rb,o_ks,down_rb,down_ks,lm_rb,gateup_variant}; 0 = auto */
 } la_llama_config;
 
 typedef struct la_llama_layer_weights {   /* device pointers, packed by la_pack_weight */

@@ -39,16 +39,16 @@ int la_pack_x(void* stream, const void* x, int K, void* out) {
     WRAP(lk_pack_x((hipStream_t)stream, x, K, out));
 }
 int la_gemm64_slab(void* stream, const void* wp, const void* xp, int N, int K, int rb, int ksplit, float* slabs) {
-    if (!wp || !xp || !slabs || N % 32 || K % 16 || ksplit < 1 || ksplit > 16 || (rb != 1 && rb != 2)) return LA_E_ARG;
+    if (!wp || !xp || !slabs || N % 32 || K % 16 || ksplit < 1 || ksplit > 16 || ((rb & 0xff) != 1 && (rb & 0xff) != 2)) return LA_E_ARG;
     WRAP(lk_gemm64_slab((hipStream_t)stream, wp, xp, N, K, rb, ksplit, slabs));
 }
-int la_gemm64_swiglu(void* stream, const void* wp, const void* xp, int F, int K, void* act) {
+int la_gemm64_swiglu(void* stream, const void* wp, const void* xp, int F, int K, void* act, int variant) {
     if (!wp || !xp || !act || F % 32 || K % 16) return LA_E_ARG;
-    WRAP(lk_gemm64_swiglu((hipStream_t)stream, wp, xp, F, K, act));
+    WRAP(lk_gemm64_swiglu((hipStream_t)stream, wp, xp, F, K, act, variant));
 }
 int la_gemm64_logits(void* stream, const void* wp, const void* xp, int V, int K, int rb, void* logits, float* cv,
                      int32_t* ci) {
-    if (!wp || !xp || !cv || !ci || V % 32 || K % 16 || (rb != 1 && rb != 2)) return LA_E_ARG;
+    if (!wp || !xp || !cv || !ci || V % 32 || K % 16 || ((rb & 0xff) != 1 && (rb & 0xff) != 2)) return LA_E_ARG;
     WRAP(lk_gemm64_logits((hipStream_t)stream, wp, xp, V, K, rb, logits, cv, ci));
 }
 int la_argmax_finalize(void* stream, const float* cv, const int32_t* ci, int n_tiles, int32_t* d_state) {

@@ -21,7 +21,7 @@ struct la_llama {
     la_llama_weights w;
     // derived
     int qkv_n, o_k, nsplit;
-    int qkv_rb, qkv_ks, o_rb, o_ks, down_rb, down_ks, lm_rb;
+    int qkv_rb, qkv_ks, o_rb, o_ks, down_rb, down_ks, lm_rb, gu_variant;
     // device buffers (carved from the caller's workspace)
     char* ws;
     uint16_t *kmain, *vmain, *kfresh, *vfresh, *qf, *h, *xp, *attn_xp, *act_xp, *logits;
@@ -59,9 +59,10 @@ static void resolve_cfg(la_llama* m) {
     m->down_rb = pick(c.gemm_cfg[4], 1);
     m->down_ks = pick(c.gemm_cfg[5], 2);
     m->lm_rb = pick(c.gemm_cfg[6], 2);
-    if (m->qkv_n % 64) m->qkv_rb = 1;
-    if (c.hidden % 64) { m->o_rb = 1; m->down_rb = 1; }
-    if (c.vocab % 64) m->lm_rb = 1;
+    m->gu_variant = c.gemm_cfg[7];
+    if (m->qkv_n % 64) m->qkv_rb = (m->qkv_rb & ~0xff) | 1;
+    if (c.hidden % 64) { m->o_rb = (m->o_rb & ~0xff) | 1; m->down_rb = (m->down_rb & ~0xff) | 1; }
+    if (c.vocab % 64) m->lm_rb = (m->lm_rb & ~0xff) | 1;
 }
 
 static size_t carve(la_llama* m, char* base) {
@@ -196,7 +197,7 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf) {
         P(KC_OTHER);
         KCHK(lk_resid_norm(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp));
         P(KC_GATEUP);
-        KCHK(lk_gemm64_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, m->act_xp));
+        KCHK(lk_gemm64_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, m->act_xp, m->gu_variant));
         P(KC_DOWN);
         KCHK(lk_gemm64_slab(st, L.wdown, m->act_xp, c.hidden, c.ffn, m->down_rb, m->down_ks, m->slabs));
         P(KC_OTHER);
@@ -206,7 +207,7 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf) {
     P(KC_LMHEAD);
     KCHK(lk_gemm64_logits(st, m->w.lm_head, m->xp, c.vocab, c.hidden, m->lm_rb, m->logits, m->cand_val, m->cand_idx));
     P(KC_OTHER);
-    KCHK(lk_argmax_finalize(st, m->cand_val, m->cand_idx, c.vocab / (32 * m->lm_rb), m->state));
+    KCHK(lk_argmax_finalize(st, m->cand_val, m->cand_idx, c.vocab / (32 * (m->lm_rb & 0xff)), m->state));
     KCHK(lk_accept_scan(st, m->ids, m->rowmask, m->state));
     KCHK(lk_kv_commit(st, m->kfresh, m->vfresh, m->kmain, m->vmain, m->state, c.n_layers, c.n_kv_heads, c.max_keys));
     P(KC_N);

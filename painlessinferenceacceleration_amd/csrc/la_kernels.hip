@@ -58,21 +58,21 @@ struct GemmArgs {
     int* cand_idx;
 };
 
-template <int RB, int EPI, int D>
-__global__ __launch_bounds__(512) void k_gemm64(GemmArgs a) {
-    __shared__ float red[4][RB * 2 * 16 * 64];
+template <int RB, int EPI, int D, int NW>
+__global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
+    __shared__ float red[NW / 2][RB * 2 * 16 * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nb0 = blockIdx.x * RB;
     const int ksplit = gridDim.y, ks = blockIdx.y;
     const int t0 = (int)(((long)a.K16 * ks) / ksplit);
     const int t1 = (int)(((long)a.K16 * (ks + 1)) / ksplit);
-    // The workgroup's k-tiles are dealt to its 8 waves in groups of D tiles, so that every wave runs the
-    // branch-free pipelined loop below (counted vmcnt waits); the < D left-over tiles go to wave 7.
-    const int twg = t1 - t0, G = twg / D, R = twg - G * D;
-    const int gq = G >> 3, gr = G & 7;
-    const int ngroups = gq + (wave < gr ? 1 : 0);
-    const int wb = t0 + (wave * gq + (wave < gr ? wave : gr)) * D;
+    // this wave's contiguous k-tile range
+    const int twg = t1 - t0, q = twg / NW, r = twg - q * NW;
+    const int wb = t0 + wave * q + (wave < r ? wave : r);
+    const int cnt = q + (wave < r ? 1 : 0);
+    const int ngroups = (cnt + D - 1) / D;            // groups of D tiles; the last one may be partial
+    const int last_valid = cnt - (ngroups - 1) * D;   // valid slots in the last group (1..D)
 
     // integer offsets from the kernel-argument bases (not mutated pointers) keep the loads in the global
     // address space: a loop-carried pointer degrades to flat_load, which ties vmcnt and lgkmcnt together
@@ -92,18 +92,23 @@ __global__ __launch_bounds__(512) void k_gemm64(GemmArgs a) {
             for (int i = 0; i < 16; ++i) acc[rb][tb][i] = 0.f;
 
     if (ngroups > 0) {
+        // Branch-free software pipeline: D tile-sets (W fragment(s) + 2 x fragments each) are always in flight;
+        // slot d is consumed and immediately refilled with the tile D ahead, so hipcc emits counted
+        // s_waitcnt vmcnt((D-1)*(RB+2)).  Throughput of a weight-streaming wave = bytes in flight / latency,
+        // so D is chosen to fill the 256-VGPR budget.  Slots past the end of the range reload the wave's
+        // first tile (always valid memory) and their MFMAs are skipped by a wave-uniform branch.
         bf16x8 fa[D][RB], fb[D][2];
+        const int n1 = ngroups == 1 ? last_valid : D;     // valid slots of group 0
 #pragma unroll
         for (int d = 0; d < D; ++d) {
+            const int dd = d < n1 ? d : 0;
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wbase + woff[rb] + d * 64);
-            fb[d][0] = xbase[xoff + d * 128];
-            fb[d][1] = xbase[xoff + d * 128 + 64];
+            for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wbase + woff[rb] + dd * 64);
+            fb[d][0] = xbase[xoff + dd * 128];
+            fb[d][1] = xbase[xoff + dd * 128 + 64];
         }
         for (int g = 1; g < ngroups; ++g) {
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) woff[rb] += D * 64;
-            xoff += D * 128;
+            const int nv = (g == ngroups - 1) ? last_valid : D;   // valid slots of the group being fetched
 #pragma unroll
             for (int d = 0; d < D; ++d) {
 #pragma unroll
@@ -111,38 +116,27 @@ __global__ __launch_bounds__(512) void k_gemm64(GemmArgs a) {
                     acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][0], acc[rb][0], 0, 0, 0);
                     acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][1], acc[rb][1], 0, 0, 0);
                 }
+                const int dd = (d < nv ? g * D + d : 0);
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wbase + woff[rb] + d * 64);
-                fb[d][0] = xbase[xoff + d * 128];
-                fb[d][1] = xbase[xoff + d * 128 + 64];
-                // pin {consume slot d, refill slot d} so the refills stay D-1 slots ahead and hipcc emits
-                // counted vmcnt waits instead of sinking every load below the MFMAs (which drains to vmcnt(0))
+                for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wbase + woff[rb] + dd * 64);
+                fb[d][0] = xbase[xoff + dd * 128];
+                fb[d][1] = xbase[xoff + dd * 128 + 64];
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
-        for (int d = 0; d < D; ++d)
+        for (int d = 0; d < D; ++d) {
+            if (d < last_valid) {
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-                acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][0], acc[rb][0], 0, 0, 0);
-                acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][1], acc[rb][1], 0, 0, 0);
-            }
-    }
-    if (wave == 7 && R > 0) {      // left-over tiles (only when (K/16)/ksplit is not a multiple of D)
-        const int tb0 = t0 + G * D;
-        for (int i = 0; i < R; ++i) {
-            bf16x8 xa = *((const bf16x8*)(a.xp + (size_t)(tb0 + i) * 1024) + lane);
-            bf16x8 xb = *((const bf16x8*)(a.xp + (size_t)(tb0 + i) * 1024) + 64 + lane);
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-                bf16x8 wv = *((const bf16x8*)(a.wp + ((size_t)(nb0 + rb) * a.K16 + tb0 + i) * 512) + lane);
-                acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xa, acc[rb][0], 0, 0, 0);
-                acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, xb, acc[rb][1], 0, 0, 0);
+                for (int rb = 0; rb < RB; ++rb) {
+                    acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][0], acc[rb][0], 0, 0, 0);
+                    acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][1], acc[rb][1], 0, 0, 0);
+                }
             }
         }
     }
 
-    // ---- deterministic cross-wave reduction: (4..7)->(0..3), (2,3)->(0,1), 1->0 -------------
+    // ---- deterministic cross-wave tree reduction through LDS (fixed order) -------------------------
     auto st = [&](int slot) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
@@ -159,18 +153,14 @@ __global__ __launch_bounds__(512) void k_gemm64(GemmArgs a) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[rb][tb][i] += red[slot][((rb * 2 + tb) * 16 + i) * 64 + lane];
     };
-    if (wave >= 4) st(wave - 4);
-    __syncthreads();
-    if (wave < 4) ad(wave);
-    __syncthreads();
-    if (wave == 2 || wave == 3) st(wave - 2);
-    __syncthreads();
-    if (wave < 2) ad(wave);
-    __syncthreads();
-    if (wave == 1) st(0);
-    __syncthreads();
+#pragma unroll
+    for (int half = NW / 2; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) st(wave - half);
+        __syncthreads();
+        if (wave < half) ad(wave);
+        if (half > 1) __syncthreads();
+    }
     if (wave != 0) return;
-    ad(0);
 
     // ---- epilogue (wave 0): lane holds token = tb*32 + (lane&31), features mfma_row(i,lane) ----
     const int tl = lane & 31, hh = lane >> 5;
@@ -649,28 +639,37 @@ int lk_pack_x(hipStream_t st, const void* x, int K, void* out) {
     LAUNCH_CHECK(); return 0;
 }
 
+// variant encoding (the `rb` argument of the public entry points): low byte = row-blocks per workgroup (1|2),
+// bits 8.. = pipeline variant: 0 = default (4 waves, D=8), 1 = (8 waves, D=4), 2 = (4 waves, D=6), 3 = (8 waves, D=8)
 template <int RB, int EPI>
-static int launch_gemm(hipStream_t st, const GemmArgs& a, int nblocks, int ksplit) {
+static int launch_gemm(hipStream_t st, const GemmArgs& a, int nblocks, int ksplit, int variant) {
     dim3 g(nblocks, ksplit);
-    k_gemm64<RB, EPI, (RB == 2 ? 4 : 6)><<<g, 512, 0, st>>>(a);
+    switch (variant) {
+        case 1: k_gemm64<RB, EPI, 4, 8><<<g, 512, 0, st>>>(a); break;
+        case 2: k_gemm64<RB, EPI, 6, 4><<<g, 256, 0, st>>>(a); break;
+        case 3: k_gemm64<RB, EPI, 8, 8><<<g, 512, 0, st>>>(a); break;
+        default: k_gemm64<RB, EPI, 8, 4><<<g, 256, 0, st>>>(a); break;
+    }
     LAUNCH_CHECK(); return 0;
 }
 
-int lk_gemm64_slab(hipStream_t st, const void* wp, const void* xp, int N, int K, int rb, int ksplit, float* slabs) {
+int lk_gemm64_slab(hipStream_t st, const void* wp, const void* xp, int N, int K, int rbv, int ksplit, float* slabs) {
+    const int rb = rbv & 0xff, variant = rbv >> 8;
     GemmArgs a{}; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = N; a.slabs = slabs;
-    if (rb == 2 && (N % 64) == 0) return launch_gemm<2, EPI_SLAB>(st, a, N / 64, ksplit);
-    return launch_gemm<1, EPI_SLAB>(st, a, N / 32, ksplit);
+    if (rb == 2 && (N % 64) == 0) return launch_gemm<2, EPI_SLAB>(st, a, N / 64, ksplit, variant);
+    return launch_gemm<1, EPI_SLAB>(st, a, N / 32, ksplit, variant);
 }
-int lk_gemm64_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, void* act_xp) {
+int lk_gemm64_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, void* act_xp, int variant) {
     GemmArgs a{}; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = F; a.act_xp = (bf16_t*)act_xp;
-    return launch_gemm<2, EPI_SWIGLU>(st, a, F / 32, 1);
+    return launch_gemm<2, EPI_SWIGLU>(st, a, F / 32, 1, variant);
 }
-int lk_gemm64_logits(hipStream_t st, const void* wp, const void* xp, int V, int K, int rb, void* logits,
+int lk_gemm64_logits(hipStream_t st, const void* wp, const void* xp, int V, int K, int rbv, void* logits,
                      float* cv, int* ci) {
+    const int rb = rbv & 0xff, variant = rbv >> 8;
     GemmArgs a{}; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = V;
     a.logits = (bf16_t*)logits; a.cand_val = cv; a.cand_idx = ci;
-    if (rb == 2 && (V % 64) == 0) return launch_gemm<2, EPI_LOGITS>(st, a, V / 64, 1);
-    return launch_gemm<1, EPI_LOGITS>(st, a, V / 32, 1);
+    if (rb == 2 && (V % 64) == 0) return launch_gemm<2, EPI_LOGITS>(st, a, V / 64, 1, variant);
+    return launch_gemm<1, EPI_LOGITS>(st, a, V / 32, 1, variant);
 }
 int lk_argmax_finalize(hipStream_t st, const float* cv, const int* ci, int n_tiles, int* state) {
     k_argmax_finalize<<<LA_TB, 64, 0, st>>>(cv, ci, n_tiles, state);

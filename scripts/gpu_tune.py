@@ -33,23 +33,25 @@ def gemm_sweep(name, N, K, kind):
     nrows = 2 * N if kind == 'swiglu' else N
     wps = [torch.randn(nrows * K, generator=g, device=DEV, dtype=torch.float32).to(torch.bfloat16) for _ in range(NBUF)]
     wbytes = nrows * K * 2
-    slabs = torch.zeros(4 * 64 * N, dtype=torch.float32, device=DEV)
+    slabs = torch.zeros(8 * 64 * N, dtype=torch.float32, device=DEV)
     act = torch.zeros(64 * N, dtype=torch.bfloat16, device=DEV)
     logits = torch.zeros(64 * N, dtype=torch.bfloat16, device=DEV)
     cv = torch.zeros((N // 32) * 64, dtype=torch.float32, device=DEV)
     ci = torch.zeros((N // 32) * 64, dtype=torch.int32, device=DEV)
     res = []
-    cfgs = [(2, 1)] if kind == 'swiglu' else [(1, 1), (2, 1)] if kind == 'logits' else [(1, 1), (1, 2), (1, 4), (2, 1), (2, 2), (2, 4)]
-    for rb, ks in cfgs:
-        if kind == 'slab':
-            fn = lambda i: lib.la_gemm64_slab(sp(), ptr(wps[i % NBUF]), ptr(xp), N, K, rb, ks, ptr(slabs))
-        elif kind == 'swiglu':
-            fn = lambda i: lib.la_gemm64_swiglu(sp(), ptr(wps[i % NBUF]), ptr(xp), N, K, ptr(act))
-        else:
-            fn = lambda i: lib.la_gemm64_logits(sp(), ptr(wps[i % NBUF]), ptr(xp), N, K, rb, ptr(logits), ptr(cv), ptr(ci))
-        us = timeit(fn)
-        res.append((rb, ks, us, wbytes / us / 1e3))
-        print(f'{name:8s} N={N:6d} K={K:6d} rb={rb} ks={ks}: {us:8.2f} us  {wbytes / us / 1e3:8.1f} GB/s', flush=True)
+    base = [(2, 1)] if kind == 'swiglu' else [(1, 1), (2, 1)] if kind == 'logits' else [(1, 1), (1, 2), (2, 1), (2, 2), (2, 4), (2, 8)]
+    for rb, ks in base:
+        for var in (0, 1, 2, 3):
+            rbv = rb | (var << 8)
+            if kind == 'slab':
+                fn = lambda i: lib.la_gemm64_slab(sp(), ptr(wps[i % NBUF]), ptr(xp), N, K, rbv, ks, ptr(slabs))
+            elif kind == 'swiglu':
+                fn = lambda i: lib.la_gemm64_swiglu(sp(), ptr(wps[i % NBUF]), ptr(xp), N, K, ptr(act), var)
+            else:
+                fn = lambda i: lib.la_gemm64_logits(sp(), ptr(wps[i % NBUF]), ptr(xp), N, K, rbv, ptr(logits), ptr(cv), ptr(ci))
+            us = timeit(fn)
+            res.append((rb, ks, var, us, wbytes / us / 1e3))
+            print(f'{name:8s} N={N:6d} K={K:6d} rb={rb} ks={ks} var={var}: {us:8.2f} us  {wbytes / us / 1e3:8.1f} GB/s', flush=True)
     return res
 
 

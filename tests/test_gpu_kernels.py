@@ -42,11 +42,13 @@ def test_pack_layouts_roundtrip():
     assert torch.equal(gu.from_packed(wp, idx), w)
 
 
+@pytest.mark.parametrize('variant', [0, 1, 2, 3])
 @pytest.mark.parametrize('N,K,rb,ks', [(256, 4096, 1, 1), (256, 4096, 2, 1), (4096, 4096, 1, 2), (4096, 4096, 2, 4),
                                        (512, 11008, 1, 2), (512, 11008, 2, 1), (12288, 4096, 1, 1), (64, 48, 2, 1),
                                        (96, 1104, 1, 4), (4096, 11008, 1, 3)])
-def test_gemm64_slab(N, K, rb, ks):
+def test_gemm64_slab(N, K, rb, ks, variant):
     """out[64][N] = x . W^T, bf16 in / fp32 accumulate; tolerance: 2e-3 of max|out| vs an fp64 product."""
+    rb = rb | (variant << 8)
     g = torch.Generator(device=DEV).manual_seed(N + K)
     x = bf(torch.randn(64, K, generator=g, device=DEV))
     w = bf(torch.randn(N, K, generator=g, device=DEV) * 0.05)
@@ -68,7 +70,8 @@ def test_gemm64_slab(N, K, rb, ks):
     assert float(got[6].abs().max()) == 0.0
 
 
-def test_gemm64_swiglu():
+@pytest.mark.parametrize('variant', [0, 1, 2, 3])
+def test_gemm64_swiglu(variant):
     """act = bf16(silu(bf16(g)) * bf16(u)) (LlamaMLP), written in the packed operand order of down_proj."""
     F, K = 1024, 512
     g = torch.Generator(device=DEV).manual_seed(3)
@@ -77,7 +80,7 @@ def test_gemm64_swiglu():
     wu = bf(torch.randn(F, K, generator=g, device=DEV) * 0.05)
     act = torch.zeros(64 * F, dtype=torch.bfloat16, device=DEV)
     wp, xp = gu.pack_weight(wg, wu), gu.pack_x(x)
-    check(lib.la_gemm64_swiglu(sp(), ptr(wp), ptr(xp), F, K, ptr(act)), 'swiglu')
+    check(lib.la_gemm64_swiglu(sp(), ptr(wp), ptr(xp), F, K, ptr(act), variant), 'swiglu')
     torch.cuda.synchronize()
     got = gu.from_packed(act, gu.xp_index(F)).float()
     gg, uu = bf(x.float() @ wg.float().t()), bf(x.float() @ wu.float().t())
