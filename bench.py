@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workload (configs[1]): Llama-2-7B (random init, real shape, bf16), bs=1 per GPU, 64-token draft tree /
+Workload (configs[1]): Llama-2-7B (synthetic weights, real shape, bf16; see random_weights(decisive=True)), bs=1 per GPU, 64-token draft tree /
 ~8 branches per verify step, hier mode, decoding_length=64, branch_length=12.  One "step" = trie query ->
 captured verify graph (embed, 32 layers, lm_head+argmax, accept scan, KV commit) -> trie update.
 Synthetic data: the prompt is 512 phrase-bank tokens; the trie is warmed, as the reference's
@@ -122,6 +122,7 @@ def main():
     ap.add_argument('--rho', type=float, default=0.3, help='token corruption rate of the warm-up copies')
     ap.add_argument('--copies', type=int, default=12, help='noisy copies of the continuation put into the trie')
     ap.add_argument('--layers', type=int, default=0, help='debug: override layer count (invalidates the metric)')
+    ap.add_argument('--pure-random', action='store_true', help='plain N(0,0.02) init (greedy/lookahead drift apart in bf16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-iters', type=int, default=3)
     args = ap.parse_args()
@@ -150,7 +151,8 @@ def main():
     BL, DL = 12, 64
     n_truth = (K + W) * (BL + 1) + 8
     max_length = P + n_truth + 2 * DL
-    model = LlamaForCausalLM.random_init(shape, seed=0, device=dev, max_length=max_length, eos_token_id=None)
+    model = LlamaForCausalLM.random_init(shape, seed=0, device=dev, max_length=max_length, eos_token_id=None,
+                                         decisive=not args.pure_random)
     eng = model.engine
 
     # ---- untimed set-up: prompt, ground-truth continuation (plain greedy on the same engine), trie warm-up
@@ -269,7 +271,8 @@ def main():
         'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': 'Llama-2-7B bf16 bs=1/GPU lookahead verify loop, 64-token draft tree / 8-12 noisy branches '
-                               '(hier, decoding_length=64, branch_length=12), random-init weights, 512-token phrase-bank prompt',
+                               '(hier, decoding_length=64, branch_length=12), synthetic permutation-LM weights (N(0,0.02); o/down std 1e-4; '
+                               'lm_head[pi(t)]=embed[t]) for decisive greedy margins, 512-token phrase-bank prompt',
                    'n_layers': shape.n_layers, 'prompt_len': P, 'rho': args.rho, 'copies': args.copies, 'parallelism': f'batch-shard x{world}',
                    'mean_accept_len': round(mean_acc, 3), 'mean_draft_len': round(mean_T, 2),
                    'verify_steps_per_sec': round(K * world / elapsed, 2), 'context_at_end': ctx,

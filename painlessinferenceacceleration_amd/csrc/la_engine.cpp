@@ -52,12 +52,14 @@ static void resolve_cfg(la_llama* m) {
     m->o_k = c.n_heads * c.head_dim;
     m->nsplit = c.attn_split > 0 ? c.attn_split : 4;
     auto pick = [](int v, int d) { return v > 0 ? v : d; };
-    m->qkv_rb = pick(c.gemm_cfg[0], 1);
+    // defaults from scripts/gpu_tune.py on MI355X (Llama-2-7B shapes): per-CU balanced grids (multiples of 256
+    // workgroups) beat everything else; see DESIGN.md section 4
+    m->qkv_rb = pick(c.gemm_cfg[0], 2);
     m->qkv_ks = pick(c.gemm_cfg[1], 1);
-    m->o_rb = pick(c.gemm_cfg[2], 1);
-    m->o_ks = pick(c.gemm_cfg[3], 2);
-    m->down_rb = pick(c.gemm_cfg[4], 1);
-    m->down_ks = pick(c.gemm_cfg[5], 2);
+    m->o_rb = pick(c.gemm_cfg[2], 2);
+    m->o_ks = pick(c.gemm_cfg[3], 4);
+    m->down_rb = pick(c.gemm_cfg[4], 2);
+    m->down_ks = pick(c.gemm_cfg[5], 4);
     m->lm_rb = pick(c.gemm_cfg[6], 2);
     m->gu_variant = c.gemm_cfg[7];
     if (m->qkv_n % 64) m->qkv_rb = (m->qkv_rb & ~0xff) | 1;
@@ -88,8 +90,8 @@ static size_t carve(la_llama* m, char* base) {
     m->opart = cv.take<float>((size_t)c.n_heads * m->nsplit * 64 * 128);
     m->mpart = cv.take<float>((size_t)c.n_heads * m->nsplit * 64);
     m->lpart = cv.take<float>((size_t)c.n_heads * m->nsplit * 64);
-    m->cand_val = cv.take<float>((size_t)(c.vocab / 32) * 64);
-    m->cand_idx = cv.take<int>((size_t)(c.vocab / 32) * 64);
+    m->cand_val = cv.take<float>((size_t)(c.vocab / 32) * 4 * 64);
+    m->cand_idx = cv.take<int>((size_t)(c.vocab / 32) * 4 * 64);
     m->state = cv.take<int>(LA_ST_WORDS);
     m->in = cv.take<int>(LA_IN_WORDS);
     m->pos = cv.take<int>(64);
@@ -207,7 +209,7 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf) {
     P(KC_LMHEAD);
     KCHK(lk_gemm64_logits(st, m->w.lm_head, m->xp, c.vocab, c.hidden, m->lm_rb, m->logits, m->cand_val, m->cand_idx));
     P(KC_OTHER);
-    KCHK(lk_argmax_finalize(st, m->cand_val, m->cand_idx, c.vocab / (32 * (m->lm_rb & 0xff)), m->state));
+    KCHK(lk_argmax_finalize(st, m->cand_val, m->cand_idx, lk_logits_cand_slots(c.vocab, m->lm_rb), m->state));
     KCHK(lk_accept_scan(st, m->ids, m->rowmask, m->state));
     KCHK(lk_kv_commit(st, m->kfresh, m->vfresh, m->kmain, m->vmain, m->state, c.n_layers, c.n_kv_heads, c.max_keys));
     P(KC_N);

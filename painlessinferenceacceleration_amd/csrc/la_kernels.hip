@@ -60,7 +60,7 @@ struct GemmArgs {
 
 template <int RB, int EPI, int D, int NW>
 __global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
-    __shared__ float red[NW / 2][RB * 2 * 16 * 64];
+    __shared__ float red[NW][RB * 2 * 16 * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nb0 = blockIdx.x * RB;
@@ -136,95 +136,89 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
         }
     }
 
-    // ---- deterministic cross-wave tree reduction through LDS (fixed order) -------------------------
-    auto st = [&](int slot) {
+    // ---- deterministic cross-wave reduction: every wave parks its partial tile in LDS, ONE barrier, then wave w
+    //      sums (fixed order p = 0..NW-1) and finishes the slice {token block w&1, register groups of w>>1} for all
+    //      row-blocks — the epilogue runs on all waves instead of serialising on wave 0.
+    {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) red[slot][((rb * 2 + tb) * 16 + i) * 64 + lane] = acc[rb][tb][i];
-    };
-    auto ad = [&](int slot) {
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[rb][tb][i] += red[slot][((rb * 2 + tb) * 16 + i) * 64 + lane];
-    };
-#pragma unroll
-    for (int half = NW / 2; half >= 1; half >>= 1) {
-        if (wave >= half && wave < 2 * half) st(wave - half);
-        __syncthreads();
-        if (wave < half) ad(wave);
-        if (half > 1) __syncthreads();
+                for (int i = 0; i < 16; ++i) red[wave][((rb * 2 + tb) * 16 + i) * 64 + lane] = acc[rb][tb][i];
     }
-    if (wave != 0) return;
-
-    // ---- epilogue (wave 0): lane holds token = tb*32 + (lane&31), features mfma_row(i,lane) ----
+    __syncthreads();
+    constexpr int GPW = 8 / NW;                  // register groups (of 4 features) per wave: NW=4 -> 2, NW=8 -> 1
+    const int tb = wave & 1, g0 = (wave >> 1) * GPW;
     const int tl = lane & 31, hh = lane >> 5;
+    float fin[RB][GPW][4];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int gg = 0; gg < GPW; ++gg)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = 0.f;
+#pragma unroll
+                for (int p = 0; p < NW; ++p) v += red[p][((rb * 2 + tb) * 16 + (g0 + gg) * 4 + j) * 64 + lane];
+                fin[rb][gg][j] = v;
+            }
+    const int tok = tb * 32 + tl;
     if constexpr (EPI == EPI_SLAB) {
         float* o = a.slabs + (size_t)ks * LA_TB * a.N;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v = {acc[rb][tb][4 * g], acc[rb][tb][4 * g + 1], acc[rb][tb][4 * g + 2], acc[rb][tb][4 * g + 3]};
-                    *(f32x4*)(o + (size_t)(tb * 32 + tl) * a.N + (nb0 + rb) * 32 + 8 * g + 4 * hh) = v;
-                }
+            for (int gg = 0; gg < GPW; ++gg) {
+                f32x4 v = {fin[rb][gg][0], fin[rb][gg][1], fin[rb][gg][2], fin[rb][gg][3]};
+                *(f32x4*)(o + (size_t)tok * a.N + (nb0 + rb) * 32 + 8 * (g0 + gg) + 4 * hh) = v;
+            }
     } else if constexpr (EPI == EPI_SWIGLU) {
-        // acc[0] = gate rows, acc[1] = up rows of the same 32 features (interleaved packing).
+        // rb 0 = gate rows, rb 1 = up rows of the same 32 features (interleaved packing).
         // act = bf16(silu(bf16(g)) * bf16(u))  — LlamaMLP.forward, modeling_llama.py:185-186
         static_assert(EPI != EPI_SWIGLU || RB == 2, "swiglu needs gate/up pair");
         const int jb = blockIdx.x;   // feature block
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
+        for (int gg = 0; gg < GPW; ++gg) {
+            bf16x4 pk;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
+            for (int j = 0; j < 4; ++j) {
+                float gv = bfr(fin[0][gg][j]);
+                float uv = bfr(fin[RB - 1][gg][j]);
+                float sv = bfr(gv / (1.0f + expf(-gv)));
+                pk[j] = (short)f2bf(sv * uv);
+            }
+            const int f = jb * 32 + 8 * (g0 + gg) + 4 * hh;    // 4 consecutive features f..f+3
+            *(bf16x4*)(a.act_xp + xp_offset(tok, f)) = pk;
+        }
+    } else {
+        // logits rounded to bf16 (lm_head output dtype, modeling_llama.py:769); per-token argmax candidate over this
+        // wave's features with lowest-index tie-break (torch.argmax on CPU returns the first maximum).
+        float best = -INFINITY;
+        int bidx = 0x7fffffff;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int gg = 0; gg < GPW; ++gg) {
                 bf16x4 pk;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float gv = bfr(acc[0][tb][4 * g + j]);
-                    float uv = bfr(acc[RB - 1][tb][4 * g + j]);
-                    float s = bfr(gv / (1.0f + expf(-gv)));
-                    pk[j] = (short)f2bf(s * uv);
+                    bf16_t hv = f2bf(fin[rb][gg][j]);
+                    pk[j] = (short)hv;
+                    float v = bf2f(hv);
+                    int idx = (nb0 + rb) * 32 + 8 * (g0 + gg) + 4 * hh + j;
+                    if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
                 }
-                const int f = jb * 32 + 8 * g + 4 * hh;    // 4 consecutive features f..f+3
-                *(bf16x4*)(a.act_xp + xp_offset(tb * 32 + tl, f)) = pk;
+                if (a.logits)
+                    *(bf16x4*)(a.logits + (size_t)tok * a.N + (nb0 + rb) * 32 + 8 * (g0 + gg) + 4 * hh) = pk;
             }
-    } else {
-        // logits rounded to bf16 (lm_head output dtype, modeling_llama.py:769); per-token argmax over this
-        // workgroup's features with lowest-index tie-break (torch.argmax on CPU returns the first maximum).
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) {
-            float best = -INFINITY;
-            int bidx = 0x7fffffff;
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bf16x4 pk;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        bf16_t hv = f2bf(acc[rb][tb][4 * g + j]);
-                        pk[j] = (short)hv;
-                        float v = bf2f(hv);
-                        int idx = (nb0 + rb) * 32 + 8 * g + 4 * hh + j;
-                        if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
-                    }
-                    if (a.logits)
-                        *(bf16x4*)(a.logits + (size_t)(tb * 32 + tl) * a.N + (nb0 + rb) * 32 + 8 * g + 4 * hh) = pk;
-                }
-            float ob = __shfl_xor(best, 32, 64);
-            int oi = __shfl_xor(bidx, 32, 64);
-            if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-            if (hh == 0) {
-                a.cand_val[(size_t)blockIdx.x * LA_TB + tb * 32 + tl] = best;
-                a.cand_idx[(size_t)blockIdx.x * LA_TB + tb * 32 + tl] = bidx;
-            }
+        float ob = __shfl_xor(best, 32, 64);
+        int oi = __shfl_xor(bidx, 32, 64);
+        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+        if (hh == 0) {      // candidate slot: (workgroup, register-group owner) x token
+            const size_t slot = (size_t)blockIdx.x * (NW / 2) + (wave >> 1);
+            a.cand_val[slot * LA_TB + tok] = best;
+            a.cand_idx[slot * LA_TB + tok] = bidx;
         }
     }
 }
@@ -336,7 +330,7 @@ __global__ __launch_bounds__(256) void k_qkv_post(const float* __restrict__ slab
                                                    const int* __restrict__ pos, const bf16_t* __restrict__ rcos,
                                                    const bf16_t* __restrict__ rsin, bf16_t* __restrict__ qf,
                                                    bf16_t* __restrict__ kfresh, bf16_t* __restrict__ vfresh) {
-    __shared__ bf16_t sh[LA_TB][128 + 8];
+    __shared__ __attribute__((aligned(16))) bf16_t sh[LA_TB][128 + 8];
     const int slot = blockIdx.x;
     const int N = (nh + 2 * nkv) * 128;
     // stage [64][128] of this head slot, summed over slabs and rounded to bf16 (the nn.Linear output dtype)
@@ -347,7 +341,8 @@ __global__ __launch_bounds__(256) void k_qkv_post(const float* __restrict__ slab
             f32x4 v = *(const f32x4*)(slabs + ((size_t)sl * LA_TB + t) * N + slot * 128 + c4);
             s += v;
         }
-        sh[t][c4] = f2bf(s[0]); sh[t][c4 + 1] = f2bf(s[1]); sh[t][c4 + 2] = f2bf(s[2]); sh[t][c4 + 3] = f2bf(s[3]);
+        bf16x4 pk = {(short)f2bf(s[0]), (short)f2bf(s[1]), (short)f2bf(s[2]), (short)f2bf(s[3])};
+        *(bf16x4*)&sh[t][c4] = pk;
     }
     __syncthreads();
     if (slot < nh + nkv) {
@@ -356,16 +351,18 @@ __global__ __launch_bounds__(256) void k_qkv_post(const float* __restrict__ slab
             int t = i >> 4, p = i & 15;
             int d0 = p * 8, dp = ((p + 8) & 15) * 8;
             int ps = pos[t];
-            const bf16_t* cs = rcos + (size_t)ps * 64 + (p & 7) * 8;
-            const bf16_t* sn = rsin + (size_t)ps * 64 + (p & 7) * 8;
+            const bf16x8 cs = *(const bf16x8*)(rcos + (size_t)ps * 64 + (p & 7) * 8);
+            const bf16x8 sn = *(const bf16x8*)(rsin + (size_t)ps * 64 + (p & 7) * 8);
+            const bf16x8 xv = *(const bf16x8*)&sh[t][d0];
+            const bf16x8 xp = *(const bf16x8*)&sh[t][dp];
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float x = bf2f(sh[t][d0 + e]);
-                float xr = bf2f(sh[t][dp + e]);
+                float x = bf2f((bf16_t)xv[e]);
+                float xr = bf2f((bf16_t)xp[e]);
                 if (p < 8) xr = -xr;
-                float a = bfr(x * bf2f(cs[e]));
-                float b = bfr(xr * bf2f(sn[e]));
+                float a = bfr(x * bf2f((bf16_t)cs[e]));
+                float b = bfr(xr * bf2f((bf16_t)sn[e]));
                 o[e] = (short)f2bf(a + b);
             }
             *(bf16x8*)(dst + rf_offset(t, d0)) = o;
@@ -640,14 +637,15 @@ int lk_pack_x(hipStream_t st, const void* x, int K, void* out) {
 }
 
 // variant encoding (the `rb` argument of the public entry points): low byte = row-blocks per workgroup (1|2),
-// bits 8.. = pipeline variant: 0 = default (4 waves, D=8), 1 = (8 waves, D=4), 2 = (4 waves, D=6), 3 = (8 waves, D=8)
+// bits 8.. = pipeline variant: 0 = default (4 waves, 8 tile-sets in flight), 1 = 8 waves x 8 (rb=1 only), 2 = 4 waves x 6
 template <int RB, int EPI>
 static int launch_gemm(hipStream_t st, const GemmArgs& a, int nblocks, int ksplit, int variant) {
     dim3 g(nblocks, ksplit);
+    if constexpr (RB == 1) {
+        if (variant == 1) { k_gemm64<RB, EPI, 8, 8><<<g, 512, 0, st>>>(a); LAUNCH_CHECK(); return 0; }
+    }
     switch (variant) {
-        case 1: k_gemm64<RB, EPI, 4, 8><<<g, 512, 0, st>>>(a); break;
         case 2: k_gemm64<RB, EPI, 6, 4><<<g, 256, 0, st>>>(a); break;
-        case 3: k_gemm64<RB, EPI, 8, 8><<<g, 512, 0, st>>>(a); break;
         default: k_gemm64<RB, EPI, 8, 4><<<g, 256, 0, st>>>(a); break;
     }
     LAUNCH_CHECK(); return 0;
@@ -670,6 +668,12 @@ int lk_gemm64_logits(hipStream_t st, const void* wp, const void* xp, int V, int 
     a.logits = (bf16_t*)logits; a.cand_val = cv; a.cand_idx = ci;
     if (rb == 2 && (V % 64) == 0) return launch_gemm<2, EPI_LOGITS>(st, a, V / 64, 1, variant);
     return launch_gemm<1, EPI_LOGITS>(st, a, V / 32, 1, variant);
+}
+// number of [64]-token candidate slots la_gemm64_logits writes (input of lk_argmax_finalize)
+int lk_logits_cand_slots(int V, int rbv) {
+    const int rb = ((rbv & 0xff) == 2 && (V % 64) == 0) ? 2 : 1, variant = rbv >> 8;
+    const int nw = (rb == 1 && variant == 1) ? 8 : 4;
+    return V / (32 * rb) * (nw / 2);
 }
 int lk_argmax_finalize(hipStream_t st, const float* cv, const int* ci, int n_tiles, int* state) {
     k_argmax_finalize<<<LA_TB, 64, 0, st>>>(cv, ci, n_tiles, state);

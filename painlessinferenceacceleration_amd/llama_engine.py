@@ -61,30 +61,44 @@ def rope_tables(head_dim, max_pos, theta, device):
     return freqs.cos().to(torch.bfloat16).to(device).contiguous(), freqs.sin().to(torch.bfloat16).to(device).contiguous()
 
 
-def random_weights(shape, seed=0, std=0.02, device='cpu', dtype=torch.bfloat16):
+def random_weights(shape, seed=0, std=0.02, device='cpu', dtype=torch.bfloat16, decisive=False):
     """Random-init weights in HF Llama naming (initializer_range=0.02, norms = 1), generated layer by layer on
-    `device` (no checkpoints are available)."""
+    `device` (no checkpoints are available).
+
+    decisive=True builds the synthetic "permutation LM" used by bench.py: same shapes and byte counts, but
+    o_proj / down_proj are drawn with std 1e-4 (the residual stream stays dominated by the token embedding) and
+    lm_head[pi(t)] = embed[t] for a fixed random permutation pi, so greedy decoding has a logit margin of several
+    units instead of the ~3 bf16 ulps of a pure random-init model.  With pure random init, greedy and tree-verify
+    decoding legitimately drift apart after ~20 tokens in bf16 (the reference README warns of the same in fp16/bf16,
+    lookahead/README.md:45), which would make a trie warmed on the greedy continuation useless."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     hd = shape.head_dim
 
-    def w(n, k):
-        return (torch.randn(n, k, generator=g, device=device, dtype=torch.float32) * std).to(dtype)
+    def w(n, k, s=std):
+        return (torch.randn(n, k, generator=g, device=device, dtype=torch.float32) * s).to(dtype)
 
+    out_std = 1e-4 if decisive else std
     sd = {'model.embed_tokens.weight': w(shape.vocab, shape.hidden)}
     for i in range(shape.n_layers):
         p = f'model.layers.{i}.'
         sd[p + 'self_attn.q_proj.weight'] = w(shape.n_heads * hd, shape.hidden)
         sd[p + 'self_attn.k_proj.weight'] = w(shape.n_kv_heads * hd, shape.hidden)
         sd[p + 'self_attn.v_proj.weight'] = w(shape.n_kv_heads * hd, shape.hidden)
-        sd[p + 'self_attn.o_proj.weight'] = w(shape.hidden, shape.n_heads * hd)
+        sd[p + 'self_attn.o_proj.weight'] = w(shape.hidden, shape.n_heads * hd, out_std)
         sd[p + 'mlp.gate_proj.weight'] = w(shape.ffn, shape.hidden)
         sd[p + 'mlp.up_proj.weight'] = w(shape.ffn, shape.hidden)
-        sd[p + 'mlp.down_proj.weight'] = w(shape.hidden, shape.ffn)
+        sd[p + 'mlp.down_proj.weight'] = w(shape.hidden, shape.ffn, out_std)
         sd[p + 'input_layernorm.weight'] = torch.ones(shape.hidden, device=device, dtype=dtype)
         sd[p + 'post_attention_layernorm.weight'] = torch.ones(shape.hidden, device=device, dtype=dtype)
     sd['model.norm.weight'] = torch.ones(shape.hidden, device=device, dtype=dtype)
-    sd['lm_head.weight'] = w(shape.vocab, shape.hidden)
+    if decisive:
+        perm = torch.randperm(shape.vocab, generator=g, device=device)
+        head = torch.empty_like(sd['model.embed_tokens.weight'])
+        head[perm] = sd['model.embed_tokens.weight']          # lm_head[pi(t)] = embed[t]
+        sd['lm_head.weight'] = head
+    else:
+        sd['lm_head.weight'] = w(shape.vocab, shape.hidden)
     return sd
 
 

@@ -30,5 +30,6 @@ class LlamaForCausalLM(LookaheadPreTrainedModel):
         return cls(LlamaShape.from_hf(hf_model.config), {k: v.detach() for k, v in hf_model.state_dict().items()}, **kw)
 
     @classmethod
-    def random_init(cls, shape, seed=0, device='cuda:0', **kw):
-        return cls(shape, random_weights(shape, seed=seed, device=device), device=device, consume_state_dict=True, **kw)
+    def random_init(cls, shape, seed=0, device='cuda:0', decisive=False, **kw):
+        return cls(shape, random_weights(shape, seed=seed, device=device, decisive=decisive), device=device,
+                   consume_state_dict=True, **kw)

@@ -36,12 +36,12 @@ def gemm_sweep(name, N, K, kind):
     slabs = torch.zeros(8 * 64 * N, dtype=torch.float32, device=DEV)
     act = torch.zeros(64 * N, dtype=torch.bfloat16, device=DEV)
     logits = torch.zeros(64 * N, dtype=torch.bfloat16, device=DEV)
-    cv = torch.zeros((N // 32) * 64, dtype=torch.float32, device=DEV)
-    ci = torch.zeros((N // 32) * 64, dtype=torch.int32, device=DEV)
+    cv = torch.zeros((N // 32) * 4 * 64, dtype=torch.float32, device=DEV)
+    ci = torch.zeros((N // 32) * 4 * 64, dtype=torch.int32, device=DEV)
     res = []
     base = [(2, 1)] if kind == 'swiglu' else [(1, 1), (2, 1)] if kind == 'logits' else [(1, 1), (1, 2), (2, 1), (2, 2), (2, 4), (2, 8)]
     for rb, ks in base:
-        for var in (0, 1, 2, 3):
+        for var in (0, 1, 2):
             rbv = rb | (var << 8)
             if kind == 'slab':
                 fn = lambda i: lib.la_gemm64_slab(sp(), ptr(wps[i % NBUF]), ptr(xp), N, K, rbv, ks, ptr(slabs))

@@ -1,0 +1,102 @@
+// probe_stream.hip — measurement tool (not product code): what bounds a weight-streaming wave on gfx950?
+// Variants of the k_gemm64 inner loop with pieces removed.  hipcc --offload-arch=gfx950 -O3 probe_stream.hip -o probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+// MODE 0: W only, xor-reduce.  MODE 1: W + equal bytes of x (L2-resident), xor-reduce.
+// MODE 2: W + x + 4 MFMA per k-tile (the GEMM loop).  MODE 3: W + MFMA, x fragments loaded once (register-resident).
+// NT: nontemporal W loads.  Each wave streams `tiles` tiles of RB KB, contiguous per wave.
+template <int MODE, int D, int NT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_probe(const bf16x8* __restrict__ w, const bf16x8* __restrict__ x, int tiles,
+                                                    int xtiles, float* out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t gw = (size_t)blockIdx.x * NW + wave;                  // global wave id
+    unsigned woff0 = (unsigned)(gw * tiles * 2 * 64 + lane);           // RB=2: two 1 KiB tiles per k-tile
+    unsigned xoff = (unsigned)(((gw * 37) % 8) * (xtiles / 8) * 128 + lane);
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    bf16x8 fa[D][2], fb[D][2];
+    bf16x8 xr0 = x[lane], xr1 = x[64 + lane];
+    int dead = 0;
+    auto ld = [&](int d, int t) {
+        if (NT) { fa[d][0] = __builtin_nontemporal_load(w + woff0 + t * 128); fa[d][1] = __builtin_nontemporal_load(w + woff0 + t * 128 + 64); }
+        else { fa[d][0] = w[woff0 + t * 128]; fa[d][1] = w[woff0 + t * 128 + 64]; }
+        if (MODE == 1 || MODE == 2) { fb[d][0] = x[xoff + (t % (xtiles / 8)) * 128]; fb[d][1] = x[xoff + (t % (xtiles / 8)) * 128 + 64]; }
+    };
+    auto use = [&](int d) {
+        if (MODE <= 1) {
+            bf16x8 v = fa[d][0] ^ fa[d][1];
+            if (MODE == 1) v ^= fb[d][0] ^ fb[d][1];
+            dead ^= (int)v[0] ^ (int)v[3] ^ (int)v[5] ^ (int)v[7];
+        } else {
+            bf16x8 b0 = MODE == 2 ? fb[d][0] : xr0, b1 = MODE == 2 ? fb[d][1] : xr1;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][0], b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][0], b1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][1], b0, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][1], b1, acc[3], 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) ld(d, d);
+    const int ng = tiles / D;
+    for (int g = 1; g < ng; ++g) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) { use(d); ld(d, g * D + d); __builtin_amdgcn_sched_barrier(0); }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) use(d);
+    float s = (float)dead;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) s += acc[i][j];
+    if (s == 12345.678f) out[gw] = s;      // keep everything live, (almost) never store
+}
+
+template <int MODE, int D, int NT, int NW>
+void run(const char* name, const bf16x8* w, size_t wbytes, const bf16x8* x, int xtiles, float* out, int nwg, size_t bytes_per_launch) {
+    int tiles = (int)(bytes_per_launch / ((size_t)nwg * NW * 2048));
+    tiles = tiles / D * D;
+    size_t per_launch = (size_t)nwg * NW * tiles * 2048;
+    int nrot = (int)(wbytes / per_launch); if (nrot < 1) { printf("%s: buffer too small\n", name); return; }
+    hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) k_probe<MODE, D, NT, NW><<<nwg, NW * 64>>>(w + (size_t)(i % nrot) * per_launch / 16, x, tiles, xtiles, out);
+    CHK(hipDeviceSynchronize());
+    const int iters = 20;
+    CHK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) k_probe<MODE, D, NT, NW><<<nwg, NW * 64>>>(w + (size_t)(i % nrot) * per_launch / 16, x, tiles, xtiles, out);
+    CHK(hipEventRecord(b)); CHK(hipEventSynchronize(b));
+    float ms; CHK(hipEventElapsedTime(&ms, a, b));
+    double us = ms * 1e3 / iters;
+    printf("%-34s nwg=%5d waves/wg=%d D=%d tiles/wave=%4d  %8.2f us  %8.1f GB/s (W bytes %zu MB)\n", name, nwg, NW, D, tiles, us,
+           per_launch / us / 1e3, per_launch >> 20);
+    fflush(stdout);
+}
+
+int main() {
+    size_t wbytes = (size_t)1600 << 20;
+    bf16x8 *w, *x; float* out;
+    CHK(hipMalloc(&w, wbytes)); CHK(hipMalloc(&x, 2 << 20)); CHK(hipMalloc(&out, 1 << 22));
+    CHK(hipMemset(w, 1, wbytes)); CHK(hipMemset(x, 1, 2 << 20));
+    const int xtiles = 256;      // 512 KB of x (K=4096)
+    const size_t B = (size_t)180 << 20;   // ~gate/up sized launch
+    int grids[] = {256, 344, 512, 1024, 2048};
+    for (int nwg : grids) {
+        run<0, 8, 1, 4>("W only, nt, xor", w, wbytes, x, xtiles, out, nwg, B);
+        run<0, 8, 0, 4>("W only, plain loads, xor", w, wbytes, x, xtiles, out, nwg, B);
+        run<1, 8, 1, 4>("W + x(L2), xor", w, wbytes, x, xtiles, out, nwg, B);
+        run<2, 8, 1, 4>("W + x(L2) + MFMA (gemm loop)", w, wbytes, x, xtiles, out, nwg, B);
+        run<3, 8, 1, 4>("W + MFMA, x in regs", w, wbytes, x, xtiles, out, nwg, B);
+    }
+    run<0, 4, 1, 8>("W only, nt, 8 waves D=4", w, wbytes, x, xtiles, out, 256, B);
+    run<0, 4, 1, 8>("W only, nt, 8 waves D=4", w, wbytes, x, xtiles, out, 512, B);
+    run<0, 16, 1, 4>("W only, nt, D=16", w, wbytes, x, xtiles, out, 512, B);
+    run<0, 2, 1, 4>("W only, nt, D=2", w, wbytes, x, xtiles, out, 2048, B);
+    run<0, 8, 1, 4>("W only, nt, small launch 33MB", w, wbytes, x, xtiles, out, 256, (size_t)33 << 20);
+    run<2, 8, 1, 4>("gemm loop, small launch 33MB", w, wbytes, x, xtiles, out, 256, (size_t)33 << 20);
+    return 0;
+}
