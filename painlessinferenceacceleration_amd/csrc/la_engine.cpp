@@ -50,7 +50,7 @@ static void resolve_cfg(la_llama* m) {
     const la_llama_config& c = m->cfg;
     m->qkv_n = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim;
     m->o_k = c.n_heads * c.head_dim;
-    m->nsplit = c.attn_split > 0 ? c.attn_split : 4;
+    m->nsplit = c.attn_split > 0 ? c.attn_split : 8;
     auto pick = [](int v, int d) { return v > 0 ? v : d; };
     // defaults from scripts/gpu_tune.py on MI355X (Llama-2-7B shapes): per-CU balanced grids (multiples of 256
     // workgroups) beat everything else; see DESIGN.md section 4

@@ -223,12 +223,14 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
     }
 }
 
-__global__ void k_argmax_finalize(const float* __restrict__ cv, const int* __restrict__ ci, int n_tiles,
-                                  int* __restrict__ state) {
-    const int t = blockIdx.x, lane = threadIdx.x;   // 64 threads, one token per block
+__global__ __launch_bounds__(256) void k_argmax_finalize(const float* __restrict__ cv, const int* __restrict__ ci,
+                                                        int n_tiles, int* __restrict__ state) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // one token per block
     float best = -INFINITY;
     int bidx = 0x7fffffff;
-    for (int i = lane; i < n_tiles; i += 64) {
+    for (int i = threadIdx.x; i < n_tiles; i += 256) {
         float v = cv[(size_t)i * LA_TB + t];
         int idx = ci[(size_t)i * LA_TB + t];
         if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
@@ -239,67 +241,93 @@ __global__ void k_argmax_finalize(const float* __restrict__ cv, const int* __res
         int oi = __shfl_xor(bidx, o, 64);
         if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
     }
-    if (lane == 0) state[LA_ST_ARGMAX + t] = bidx;
+    if (lane == 0) { sv[wave] = best; si[wave] = bidx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bidx)) { best = sv[w]; bidx = si[w]; }
+        state[LA_ST_ARGMAX + t] = bidx;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // Row kernels: embedding gather + RMSNorm, residual add + RMSNorm  (LlamaRMSNorm, :76-90;
 // LlamaDecoderLayer residual adds, :352-363).  One workgroup per token row.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+template <int NWAVES>
+__device__ __forceinline__ float block_sum(float v, float* sh) {
     v = wave_sum(v);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
-    float tot = sh[0] + sh[1] + sh[2] + sh[3];
-    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NWAVES; ++i) tot += sh[i];
     return tot;
 }
 
-// h_new = bf16(h + bf16(sum slabs)); x = bf16(w * (h_new * rsqrt(mean(h_new^2)+eps)))  (fp32 math)
-__global__ __launch_bounds__(256) void k_row_norm(const bf16_t* __restrict__ embed, const int* __restrict__ ids,
+// h_new = bf16(h + bf16(sum slabs)); x = bf16(w * (h_new * rsqrt(mean(h_new^2)+eps)))  (fp32 math).
+// 512 threads, <= 2 chunks of 8 elements per thread (hidden <= 8192).  NS is a template parameter so that every
+// load of the row (h, NS slabs, norm weight) is issued before the first use: one memory round trip, not NS+2.
+template <int NS>
+__global__ __launch_bounds__(512) void k_row_norm(const bf16_t* __restrict__ embed, const int* __restrict__ ids,
                                                    bf16_t* __restrict__ h, const float* __restrict__ slabs,
-                                                   int n_slabs, const bf16_t* __restrict__ nw, int hidden, float eps,
+                                                   const bf16_t* __restrict__ nw, int hidden, float eps,
                                                    bf16_t* __restrict__ xp) {
-    __shared__ float sh[4];
+    __shared__ float sh[8];
     const int t = blockIdx.x;
-    const int nchunk = hidden >> 3;                // 8-element chunks in the row
-    float vals[4][8];                              // up to hidden = 8192
-    float ss = 0.f;
+    const int nchunk = hidden >> 3;
     const bf16_t* src = embed ? embed + (size_t)ids[t] * hidden : h + (size_t)t * hidden;
+    bf16x8 hv[2], wv[2];
+    f32x4 sl[NS > 0 ? NS : 1][2][2];
 #pragma unroll
-    for (int ci = 0; ci < 4; ++ci) {
-        const int c = threadIdx.x + ci * 256;
-        if (c >= nchunk) continue;
-        bf16x8 hv = *(const bf16x8*)(src + c * 8);
-        float add[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int s = 0; s < n_slabs; ++s) {
-            const float* sp = slabs + ((size_t)s * LA_TB + t) * hidden + c * 8;
-            f32x4 a0 = *(const f32x4*)sp, a1 = *(const f32x4*)(sp + 4);
-            add[0] += a0[0]; add[1] += a0[1]; add[2] += a0[2]; add[3] += a0[3];
-            add[4] += a1[0]; add[5] += a1[1]; add[6] += a1[2]; add[7] += a1[3];
-        }
-        bf16x8 ho;
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 512;
+        if (c < nchunk) {
+            hv[ci] = *(const bf16x8*)(src + c * 8);
+            wv[ci] = *(const bf16x8*)(nw + c * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float v = bf2f((bf16_t)hv[j]);
-            if (n_slabs > 0) v = bfr(v + bfr(add[j]));
-            vals[ci][j] = v;
-            ho[j] = (short)f2bf(v);
-            ss += v * v;
+            for (int s2 = 0; s2 < NS; ++s2) {
+                const float* sp = slabs + ((size_t)s2 * LA_TB + t) * hidden + c * 8;
+                sl[s2][ci][0] = *(const f32x4*)sp;
+                sl[s2][ci][1] = *(const f32x4*)(sp + 4);
+            }
         }
-        *(bf16x8*)(h + (size_t)t * hidden + c * 8) = ho;
     }
-    float tot = block_sum_256(ss, sh);
-    float rs = 1.0f / sqrtf(tot / (float)hidden + eps);
+    float vals[2][8];
+    float ss = 0.f;
 #pragma unroll
-    for (int ci = 0; ci < 4; ++ci) {
-        const int c = threadIdx.x + ci * 256;
-        if (c >= nchunk) continue;
-        bf16x8 wv = *(const bf16x8*)(nw + c * 8);
-        bf16x8 xo;
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 512;
+        if (c < nchunk) {
+            bf16x8 ho;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) xo[j] = (short)f2bf(bf2f((bf16_t)wv[j]) * (vals[ci][j] * rs));
-        *(bf16x8*)(xp + xp_offset(t, c * 8)) = xo;
+            for (int j = 0; j < 8; ++j) {
+                float v = bf2f((bf16_t)hv[ci][j]);
+                if (NS > 0) {
+                    float add = 0.f;
+#pragma unroll
+                    for (int s2 = 0; s2 < NS; ++s2) add += sl[s2][ci][j >> 2][j & 3];
+                    v = bfr(v + bfr(add));
+                }
+                vals[ci][j] = v;
+                ho[j] = (short)f2bf(v);
+                ss += v * v;
+            }
+            *(bf16x8*)(h + (size_t)t * hidden + c * 8) = ho;
+        }
+    }
+    const float tot = block_sum<8>(ss, sh);
+    const float rs = 1.0f / sqrtf(tot / (float)hidden + eps);
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 512;
+        if (c < nchunk) {
+            bf16x8 xo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xo[j] = (short)f2bf(bf2f((bf16_t)wv[ci][j]) * (vals[ci][j] * rs));
+            *(bf16x8*)(xp + xp_offset(t, c * 8)) = xo;
+        }
     }
 }
 
@@ -326,52 +354,70 @@ __global__ void k_build_tree_inputs(const int* __restrict__ in, int* __restrict_
 // Q -> QF fragments, K/V of the 64 tree tokens -> fresh KF / VF tiles.
 // grid = nh + 2*nkv head slots, 256 threads.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_qkv_post(const float* __restrict__ slabs, int n_slabs, int nh, int nkv,
+template <int NS>
+__global__ __launch_bounds__(256) void k_qkv_post(const float* __restrict__ slabs, int nh, int nkv,
                                                    const int* __restrict__ pos, const bf16_t* __restrict__ rcos,
                                                    const bf16_t* __restrict__ rsin, bf16_t* __restrict__ qf,
                                                    bf16_t* __restrict__ kfresh, bf16_t* __restrict__ vfresh) {
     __shared__ __attribute__((aligned(16))) bf16_t sh[LA_TB][128 + 8];
     const int slot = blockIdx.x;
     const int N = (nh + 2 * nkv) * 128;
-    // stage [64][128] of this head slot, summed over slabs and rounded to bf16 (the nn.Linear output dtype)
-    for (int i = threadIdx.x; i < LA_TB * 32; i += 256) {
-        int t = i >> 5, c4 = (i & 31) * 4;
-        f32x4 s = {0, 0, 0, 0};
-        for (int sl = 0; sl < n_slabs; ++sl) {
-            f32x4 v = *(const f32x4*)(slabs + ((size_t)sl * LA_TB + t) * N + slot * 128 + c4);
-            s += v;
+    const bool rope = slot < nh + nkv;
+    // RoPE operands of this thread's 4 (token, 8-dim piece) items: issued first so that the dependent
+    // pos -> cos/sin loads overlap the slab staging below
+    bf16x8 cs[4], sn[4];
+    if (rope) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = threadIdx.x + j * 256, t = i >> 4, p = i & 15;
+            const int ps = pos[t];
+            cs[j] = *(const bf16x8*)(rcos + (size_t)ps * 64 + (p & 7) * 8);
+            sn[j] = *(const bf16x8*)(rsin + (size_t)ps * 64 + (p & 7) * 8);
         }
-        bf16x4 pk = {(short)f2bf(s[0]), (short)f2bf(s[1]), (short)f2bf(s[2]), (short)f2bf(s[3])};
+    }
+    // stage [64][128] of this head slot, summed over slabs and rounded to bf16 (the nn.Linear output dtype)
+    f32x4 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = threadIdx.x + j * 256, t = i >> 5, c4 = (i & 31) * 4;
+        acc[j] = *(const f32x4*)(slabs + (size_t)t * N + slot * 128 + c4);
+#pragma unroll
+        for (int sl = 1; sl < NS; ++sl) acc[j] += *(const f32x4*)(slabs + ((size_t)sl * LA_TB + t) * N + slot * 128 + c4);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = threadIdx.x + j * 256, t = i >> 5, c4 = (i & 31) * 4;
+        bf16x4 pk = {(short)f2bf(acc[j][0]), (short)f2bf(acc[j][1]), (short)f2bf(acc[j][2]), (short)f2bf(acc[j][3])};
         *(bf16x4*)&sh[t][c4] = pk;
     }
     __syncthreads();
-    if (slot < nh + nkv) {
+    if (rope) {
         bf16_t* dst = slot < nh ? qf + (size_t)slot * 2 * 8 * 512 : kfresh + (size_t)(slot - nh) * 2 * 8 * 512;
-        for (int i = threadIdx.x; i < LA_TB * 16; i += 256) {
-            int t = i >> 4, p = i & 15;
-            int d0 = p * 8, dp = ((p + 8) & 15) * 8;
-            int ps = pos[t];
-            const bf16x8 cs = *(const bf16x8*)(rcos + (size_t)ps * 64 + (p & 7) * 8);
-            const bf16x8 sn = *(const bf16x8*)(rsin + (size_t)ps * 64 + (p & 7) * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = threadIdx.x + j * 256, t = i >> 4, p = i & 15;
+            const int d0 = p * 8, dp = ((p + 8) & 15) * 8;
             const bf16x8 xv = *(const bf16x8*)&sh[t][d0];
-            const bf16x8 xp = *(const bf16x8*)&sh[t][dp];
+            const bf16x8 xq = *(const bf16x8*)&sh[t][dp];
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float x = bf2f((bf16_t)xv[e]);
-                float xr = bf2f((bf16_t)xp[e]);
+                float xr = bf2f((bf16_t)xq[e]);
                 if (p < 8) xr = -xr;
-                float a = bfr(x * bf2f((bf16_t)cs[e]));
-                float b = bfr(xr * bf2f((bf16_t)sn[e]));
+                float a = bfr(x * bf2f((bf16_t)cs[j][e]));
+                float b = bfr(xr * bf2f((bf16_t)sn[j][e]));
                 o[e] = (short)f2bf(a + b);
             }
             *(bf16x8*)(dst + rf_offset(t, d0)) = o;
         }
     } else {
         bf16_t* dst = vfresh + (size_t)(slot - nh - nkv) * 2 * 8 * 512;
-        for (int i = threadIdx.x; i < 2 * 4 * 2 * 64; i += 256) {
-            int ln = i & 63, s2 = (i >> 6) & 1, db = (i >> 7) & 3, tb = i >> 9;
-            int d = db * 32 + (ln & 31), hh = ln >> 5;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = threadIdx.x + j * 256;
+            const int ln = i & 63, s2 = (i >> 6) & 1, db = (i >> 7) & 3, tb = i >> 9;
+            const int d = db * 32 + (ln & 31), hh = ln >> 5;
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -432,16 +478,21 @@ __global__ __launch_bounds__(256) void k_tree_attn(AttnArgs a) {
         for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
     float m = LA_NEG, l = 0.f;
 
-    for (int it = i0 + par; it < i1; it += 2) {
+    auto kptr = [&](int it) -> const bf16x8* {
+        return it >= NP ? (const bf16x8*)(a.kfresh + ((size_t)hk * 2 + (it - NP)) * 4096)
+                        : (const bf16x8*)(a.kmain + ((size_t)hk * KB + it) * 4096);
+    };
+    auto vptr = [&](int it) -> const bf16x8* {
+        return it >= NP ? (const bf16x8*)(a.vfresh + ((size_t)hk * 2 + (it - NP)) * 4096)
+                        : (const bf16x8*)(a.vmain + ((size_t)hk * KB + it) * 4096);
+    };
+    // one key tile: S^T = K.Q^T, mask, online softmax, O^T += V^T.P^T.  The V fragments are requested before the
+    // QK^T MFMAs and consumed after the softmax; the NEXT tile's K fragments are requested by the caller first.
+    auto tile = [&](int it, const bf16x8 (&kf)[8]) {
         const bool fresh = it >= NP;
         const int kb = fresh ? it - NP : it;
-        const bf16x8* kt = fresh ? (const bf16x8*)(a.kfresh + ((size_t)hk * 2 + kb) * 4096)
-                                 : (const bf16x8*)(a.kmain + ((size_t)hk * KB + kb) * 4096);
-        const bf16x8* vt = fresh ? (const bf16x8*)(a.vfresh + ((size_t)hk * 2 + kb) * 4096)
-                                 : (const bf16x8*)(a.vmain + ((size_t)hk * KB + kb) * 4096);
-        bf16x8 kf[8], vf[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) kf[s] = kt[s * 64 + lane];
+        const bf16x8* vt = vptr(it);
+        bf16x8 vf[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) vf[s] = vt[s * 64 + lane];
         f32x16 sc;
@@ -468,9 +519,8 @@ __global__ __launch_bounds__(256) void k_tree_attn(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             float p = (sc[i] > -1.0e29f) ? __expf(sc[i] - mn) : 0.f;
-            bf16_t pb = f2bf(p);
             ps += p;
-            pf[i >> 3][i & 7] = (short)pb;
+            pf[i >> 3][i & 7] = (short)f2bf(p);
         }
         ps += __shfl_xor(ps, 32, 64);
         l = l * alpha + ps;
@@ -481,6 +531,34 @@ __global__ __launch_bounds__(256) void k_tree_attn(AttnArgs a) {
             for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
             o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db * 2 + 0], pf[0], o[db], 0, 0, 0);
             o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db * 2 + 1], pf[1], o[db], 0, 0, 0);
+        }
+    };
+    {
+        bf16x8 kA[8], kB[8];
+        int it = i0 + par;
+        if (it < i1) {
+            const bf16x8* kt = kptr(it);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) kA[s] = kt[s * 64 + lane];
+        }
+        while (it < i1) {
+            int nx = it + 2;
+            if (nx < i1) {
+                const bf16x8* kt = kptr(nx);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) kB[s] = kt[s * 64 + lane];
+            }
+            tile(it, kA);
+            it = nx;
+            if (it >= i1) break;
+            nx = it + 2;
+            if (nx < i1) {
+                const bf16x8* kt = kptr(nx);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) kA[s] = kt[s * 64 + lane];
+            }
+            tile(it, kB);
+            it = nx;
         }
     }
 
@@ -676,17 +754,23 @@ int lk_logits_cand_slots(int V, int rbv) {
     return V / (32 * rb) * (nw / 2);
 }
 int lk_argmax_finalize(hipStream_t st, const float* cv, const int* ci, int n_tiles, int* state) {
-    k_argmax_finalize<<<LA_TB, 64, 0, st>>>(cv, ci, n_tiles, state);
+    k_argmax_finalize<<<LA_TB, 256, 0, st>>>(cv, ci, n_tiles, state);
     LAUNCH_CHECK(); return 0;
 }
 int lk_embed_norm(hipStream_t st, const void* embed, const int* ids, const void* nw, int hidden, float eps, void* h, void* xp) {
     if (hidden > 8192 || (hidden & 7)) return -1;
-    k_row_norm<<<LA_TB, 256, 0, st>>>((const bf16_t*)embed, ids, (bf16_t*)h, nullptr, 0, (const bf16_t*)nw, hidden, eps, (bf16_t*)xp);
+    k_row_norm<0><<<LA_TB, 512, 0, st>>>((const bf16_t*)embed, ids, (bf16_t*)h, nullptr, (const bf16_t*)nw, hidden, eps, (bf16_t*)xp);
     LAUNCH_CHECK(); return 0;
 }
 int lk_resid_norm(hipStream_t st, void* h, const float* slabs, int n_slabs, const void* nw, int hidden, float eps, void* xp) {
     if (hidden > 8192 || (hidden & 7)) return -1;
-    k_row_norm<<<LA_TB, 256, 0, st>>>(nullptr, nullptr, (bf16_t*)h, slabs, n_slabs, (const bf16_t*)nw, hidden, eps, (bf16_t*)xp);
+#define RN(NS) k_row_norm<NS><<<LA_TB, 512, 0, st>>>(nullptr, nullptr, (bf16_t*)h, slabs, (const bf16_t*)nw, hidden, eps, (bf16_t*)xp)
+    switch (n_slabs) {
+        case 0: RN(0); break; case 1: RN(1); break; case 2: RN(2); break; case 3: RN(3); break;
+        case 4: RN(4); break; case 6: RN(6); break; case 8: RN(8); break;
+        default: return -1;
+    }
+#undef RN
     LAUNCH_CHECK(); return 0;
 }
 int lk_build_tree_inputs(hipStream_t st, const int* in, int* state, int* pos, uint64_t* rowmask, int* ids) {
@@ -695,8 +779,13 @@ int lk_build_tree_inputs(hipStream_t st, const int* in, int* state, int* pos, ui
 }
 int lk_qkv_post(hipStream_t st, const float* slabs, int n_slabs, int nh, int nkv, const int* pos, const void* rcos,
                 const void* rsin, void* qf, void* kfresh, void* vfresh) {
-    k_qkv_post<<<nh + 2 * nkv, 256, 0, st>>>(slabs, n_slabs, nh, nkv, pos, (const bf16_t*)rcos, (const bf16_t*)rsin,
-                                             (bf16_t*)qf, (bf16_t*)kfresh, (bf16_t*)vfresh);
+#define QP(NS) k_qkv_post<NS><<<nh + 2 * nkv, 256, 0, st>>>(slabs, nh, nkv, pos, (const bf16_t*)rcos, (const bf16_t*)rsin, \
+                                                          (bf16_t*)qf, (bf16_t*)kfresh, (bf16_t*)vfresh)
+    switch (n_slabs) {
+        case 1: QP(1); break; case 2: QP(2); break; case 3: QP(3); break; case 4: QP(4); break; case 8: QP(8); break;
+        default: return -1;
+    }
+#undef QP
     LAUNCH_CHECK(); return 0;
 }
 int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
