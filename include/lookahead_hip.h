@@ -152,6 +152,13 @@ int la_gemm64_slab(void* stream, const void* d_wp, const void* d_xp, int N, int 
                    float* d_slabs /*[ksplit][64][N]*/);
 int la_gemm64_swiglu(void* stream, const void* d_wp_gateup, const void* d_xp, int F, int K,
                      void* d_act_packed /*[64][F] packed*/, int variant);
+/* QKV projection fused with RoPE and the Q / fresh-K / fresh-V fragment writes (replaces la_gemm64_slab +
+ * la_qkv_post; models/llama/modeling_llama.py:222-232).  d_wp must be packed from [Wq;Wk;Wv] with its rows gathered
+ * by la_qkv_row_perm (packed row r <- original row perm[r]) so that every workgroup owns RoPE pairs (d, d+64). */
+int la_gemm64_qkv(void* stream, const void* d_wp, const void* d_xp, int n_heads, int n_kv_heads, int K,
+                  const int32_t* d_pos, const void* d_rope_cos, const void* d_rope_sin,
+                  void* d_qf, void* d_kfresh, void* d_vfresh, int variant);
+int la_qkv_row_perm(int n_heads, int n_kv_heads, int32_t* perm /*[(nh+2*nkv)*128], host*/);
 int la_gemm64_logits(void* stream, const void* d_wp, const void* d_xp, int V, int K, int rb,
                      void* d_logits_bf16 /*[64][V] or NULL*/, float* d_cand_val, int32_t* d_cand_idx);
 int la_argmax_finalize(void* stream, const float* d_cand_val, const int32_t* d_cand_idx, int n_tiles,
@@ -188,7 +195,7 @@ typedef struct la_llama_config {
 } la_llama_config;
 
 typedef struct la_llama_layer_weights {   /* device pointers, packed by la_pack_weight */
-    const void* wqkv;        /* [(nh+2*nkv)*hd][hidden]        */
+    const void* wqkv;        /* [(nh+2*nkv)*hd][hidden], rows gathered by la_qkv_row_perm unless gemm_cfg[1] < 0 */
     const void* wo;          /* [hidden][nh*hd]                */
     const void* wgateup;     /* interleaved gate/up [2*ffn][hidden] */
     const void* wdown;       /* [hidden][ffn]                  */

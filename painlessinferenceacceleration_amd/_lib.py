@@ -111,6 +111,8 @@ PROTOTYPES = {
     "la_pack_x": (i32, vp, vp, i32, vp),
     "la_gemm64_slab": (i32, vp, vp, vp, i32, i32, i32, i32, vp),
     "la_gemm64_swiglu": (i32, vp, vp, vp, i32, i32, vp, i32),
+    "la_gemm64_qkv": (i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32),
+    "la_qkv_row_perm": (i32, i32, i32, pi32),
     "la_gemm64_logits": (i32, vp, vp, vp, i32, i32, i32, vp, vp, vp),
     "la_argmax_finalize": (i32, vp, vp, vp, i32, vp),
     "la_embed_norm": (i32, vp, vp, vp, vp, i32, f32, vp, vp),

@@ -46,6 +46,16 @@ int la_gemm64_swiglu(void* stream, const void* wp, const void* xp, int F, int K,
     if (!wp || !xp || !act || F % 32 || K % 16) return LA_E_ARG;
     WRAP(lk_gemm64_swiglu((hipStream_t)stream, wp, xp, F, K, act, variant));
 }
+int la_gemm64_qkv(void* stream, const void* wp, const void* xp, int nh, int nkv, int K, const int32_t* pos, const void* rcos,
+                  const void* rsin, void* qf, void* kf, void* vf, int variant) {
+    if (!wp || !xp || !pos || !rcos || !rsin || !qf || !kf || !vf || nh <= 0 || nkv <= 0 || K % 16) return LA_E_ARG;
+    WRAP(lk_gemm64_qkv((hipStream_t)stream, wp, xp, nh, nkv, K, pos, rcos, rsin, qf, kf, vf, variant));
+}
+int la_qkv_row_perm(int nh, int nkv, int32_t* perm) {
+    if (!perm || nh <= 0 || nkv <= 0) return LA_E_ARG;
+    lk_qkv_row_perm(nh, nkv, perm);
+    return LA_OK;
+}
 int la_gemm64_logits(void* stream, const void* wp, const void* xp, int V, int K, int rb, void* logits, float* cv,
                      int32_t* ci) {
     if (!wp || !xp || !cv || !ci || V % 32 || K % 16 || ((rb & 0xff) != 1 && (rb & 0xff) != 2)) return LA_E_ARG;

@@ -22,6 +22,7 @@ struct la_llama {
     // derived
     int qkv_n, o_k, nsplit;
     int qkv_rb, qkv_ks, o_rb, o_ks, down_rb, down_ks, lm_rb, gu_variant;
+    bool qkv_fused;
     // device buffers (carved from the caller's workspace)
     char* ws;
     uint16_t *kmain, *vmain, *kfresh, *vfresh, *qf, *h, *xp, *attn_xp, *act_xp, *logits;
@@ -62,6 +63,9 @@ static void resolve_cfg(la_llama* m) {
     m->down_ks = pick(c.gemm_cfg[5], 4);
     m->lm_rb = pick(c.gemm_cfg[6], 2);
     m->gu_variant = c.gemm_cfg[7];
+    // qkv_ks == -1 in the config selects the unfused path (plain [Wq;Wk;Wv] packing + k_qkv_post)
+    m->qkv_fused = c.gemm_cfg[1] >= 0;
+    if (!m->qkv_fused) m->qkv_ks = 1;
     if (m->qkv_n % 64) m->qkv_rb = (m->qkv_rb & ~0xff) | 1;
     if (c.hidden % 64) { m->o_rb = (m->o_rb & ~0xff) | 1; m->down_rb = (m->down_rb & ~0xff) | 1; }
     if (c.vocab % 64) m->lm_rb = (m->lm_rb & ~0xff) | 1;
@@ -186,10 +190,15 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf) {
         uint16_t* kf = m->kfresh + (size_t)l * m->fresh_layer_elems;
         uint16_t* vf = m->vfresh + (size_t)l * m->fresh_layer_elems;
         P(KC_QKV);
-        KCHK(lk_gemm64_slab(st, L.wqkv, m->xp, m->qkv_n, c.hidden, m->qkv_rb, m->qkv_ks, m->slabs));
-        P(KC_OTHER);
-        KCHK(lk_qkv_post(st, m->slabs, m->qkv_ks, c.n_heads, c.n_kv_heads, m->pos, m->w.rope_cos, m->w.rope_sin,
-                         m->qf, kf, vf));
+        if (m->qkv_fused) {
+            KCHK(lk_gemm64_qkv(st, L.wqkv, m->xp, c.n_heads, c.n_kv_heads, c.hidden, m->pos, m->w.rope_cos, m->w.rope_sin,
+                               m->qf, kf, vf, m->qkv_rb >> 8));
+        } else {
+            KCHK(lk_gemm64_slab(st, L.wqkv, m->xp, m->qkv_n, c.hidden, m->qkv_rb, m->qkv_ks, m->slabs));
+            P(KC_OTHER);
+            KCHK(lk_qkv_post(st, m->slabs, m->qkv_ks, c.n_heads, c.n_kv_heads, m->pos, m->w.rope_cos, m->w.rope_sin,
+                             m->qf, kf, vf));
+        }
         P(KC_ATTN);
         KCHK(lk_tree_attn(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
                           kf, vf, m->rowmask, m->state, c.n_heads, c.n_kv_heads, c.max_keys, m->nsplit,

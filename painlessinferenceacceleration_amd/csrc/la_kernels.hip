@@ -44,7 +44,7 @@ __global__ void k_pack_x(const bf16_t* __restrict__ x, int K, bf16_t* __restrict
 //   order (deterministic), then wave 0 runs the epilogue.
 //   Replaces nn.Linear in LlamaAttention/LlamaMLP/lm_head (modeling_llama.py:172-186,222-224,296,769).
 // ---------------------------------------------------------------------------------------------
-enum { EPI_SLAB = 0, EPI_SWIGLU = 1, EPI_LOGITS = 2 };
+enum { EPI_SLAB = 0, EPI_SWIGLU = 1, EPI_LOGITS = 2, EPI_QKV = 3 };
 
 struct GemmArgs {
     const bf16_t* wp;
@@ -56,6 +56,14 @@ struct GemmArgs {
     bf16_t* logits;      // EPI_LOGITS: [64][N] bf16 row-major or null
     float* cand_val;     // EPI_LOGITS: [gridDim.x][64]
     int* cand_idx;
+    // EPI_QKV: fused RoPE + fragment writes (rows permuted at pack time, see lk_qkv_row_perm)
+    const int* pos;
+    const bf16_t* rcos;
+    const bf16_t* rsin;
+    bf16_t* qf;
+    bf16_t* kfresh;
+    bf16_t* vfresh;
+    int nh, nkv;
 };
 
 template <int RB, int EPI, int D, int NW>
@@ -147,10 +155,22 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) red[wave][((rb * 2 + tb) * 16 + i) * 64 + lane] = acc[rb][tb][i];
     }
-    __syncthreads();
     constexpr int GPW = 8 / NW;                  // register groups (of 4 features) per wave: NW=4 -> 2, NW=8 -> 1
     const int tb = wave & 1, g0 = (wave >> 1) * GPW;
     const int tl = lane & 31, hh = lane >> 5;
+    // EPI_QKV: this lane's RoPE operands (dependent pos -> cos/sin loads) are requested before the barrier
+    bf16x4 rc[GPW], rs4[GPW];
+    if constexpr (EPI == EPI_QKV) {
+        const int u = blockIdx.x & 1;
+        const int ps = a.pos[tb * 32 + tl];
+#pragma unroll
+        for (int gg = 0; gg < GPW; ++gg) {
+            const int dlo = 32 * u + 8 * (g0 + gg) + 4 * hh;      // d in [0,64): cos/sin column
+            rc[gg] = *(const bf16x4*)(a.rcos + (size_t)ps * 64 + dlo);
+            rs4[gg] = *(const bf16x4*)(a.rsin + (size_t)ps * 64 + dlo);
+        }
+    }
+    __syncthreads();
     float fin[RB][GPW][4];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
@@ -190,6 +210,36 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
             }
             const int f = jb * 32 + 8 * (g0 + gg) + 4 * hh;    // 4 consecutive features f..f+3
             *(bf16x4*)(a.act_xp + xp_offset(tok, f)) = pk;
+        }
+    } else if constexpr (EPI == EPI_QKV) {
+        // Workgroup b owns head slot b>>1, half u=b&1: row-block 0 = dims 32u+[0,32), row-block 1 = the RoPE
+        // partners 64+32u+[0,32) (rows permuted at pack time).  q/k: rotate-half RoPE in bf16 arithmetic
+        // (apply_rotary_pos_emb, modeling_llama.py:154-169) -> QF / fresh KF fragments; v -> fresh VF fragments.
+        static_assert(EPI != EPI_QKV || RB == 2, "qkv epilogue needs the (d, d+64) row-block pair");
+        const int slot = blockIdx.x >> 1, u = blockIdx.x & 1;
+#pragma unroll
+        for (int gg = 0; gg < GPW; ++gg) {
+            const int dlo = 32 * u + 8 * (g0 + gg) + 4 * hh, dhi = dlo + 64;
+            if (slot < a.nh + a.nkv) {
+                bf16_t* dst = slot < a.nh ? a.qf + (size_t)slot * 8192 : a.kfresh + (size_t)(slot - a.nh) * 8192;
+                bf16x4 olo, ohi;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xl = bfr(fin[0][gg][j]), xh = bfr(fin[RB - 1][gg][j]);
+                    const float c = bf2f((bf16_t)rc[gg][j]), sn = bf2f((bf16_t)rs4[gg][j]);
+                    olo[j] = (short)f2bf(bfr(xl * c) + bfr(-xh * sn));
+                    ohi[j] = (short)f2bf(bfr(xh * c) + bfr(xl * sn));
+                }
+                *(bf16x4*)(dst + rf_offset(tok, dlo)) = olo;
+                *(bf16x4*)(dst + rf_offset(tok, dhi)) = ohi;
+            } else {
+                bf16_t* dst = a.vfresh + (size_t)(slot - a.nh - a.nkv) * 8192;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dst[vf_offset(tok, dlo + j)] = f2bf(fin[0][gg][j]);
+                    dst[vf_offset(tok, dhi + j)] = f2bf(fin[RB - 1][gg][j]);
+                }
+            }
         }
     } else {
         // logits rounded to bf16 (lm_head output dtype, modeling_llama.py:769); per-token argmax candidate over this
@@ -746,6 +796,23 @@ int lk_gemm64_logits(hipStream_t st, const void* wp, const void* xp, int V, int 
     a.logits = (bf16_t*)logits; a.cand_val = cv; a.cand_idx = ci;
     if (rb == 2 && (V % 64) == 0) return launch_gemm<2, EPI_LOGITS>(st, a, V / 64, 1, variant);
     return launch_gemm<1, EPI_LOGITS>(st, a, V / 32, 1, variant);
+}
+// QKV projection with the RoPE / fragment epilogue.  wp must be packed from the row-permuted [Wq;Wk;Wv] (lk_qkv_row_perm).
+int lk_gemm64_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int nkv, int K, const int* pos, const void* rcos,
+                  const void* rsin, void* qf, void* kfresh, void* vfresh, int variant) {
+    GemmArgs a{}; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = (nh + 2 * nkv) * 128;
+    a.pos = pos; a.rcos = (const bf16_t*)rcos; a.rsin = (const bf16_t*)rsin;
+    a.qf = (bf16_t*)qf; a.kfresh = (bf16_t*)kfresh; a.vfresh = (bf16_t*)vfresh; a.nh = nh; a.nkv = nkv;
+    return launch_gemm<2, EPI_QKV>(st, a, a.N / 64, 1, variant);
+}
+// packed row r of the permuted QKV matrix <- original row perm[r]: workgroup b = r/64 holds head slot b>>1, dims
+// {32u + f} (row-block 0) and {64 + 32u + f} (row-block 1), u = b&1.
+void lk_qkv_row_perm(int nh, int nkv, int* perm) {
+    const int N = (nh + 2 * nkv) * 128;
+    for (int r = 0; r < N; ++r) {
+        const int nb = r >> 5, f = r & 31, b = nb >> 1, rb = nb & 1, slot = b >> 1, u = b & 1;
+        perm[r] = slot * 128 + 64 * rb + 32 * u + f;
+    }
 }
 // number of [64]-token candidate slots la_gemm64_logits writes (input of lk_argmax_finalize)
 int lk_logits_cand_slots(int V, int rbv) {

@@ -142,12 +142,21 @@ class LlamaVerifyEngine(object):
         def take(name):
             return state_dict.pop(name) if consume_state_dict else state_dict[name]
 
+        # rows of [Wq;Wk;Wv] are gathered so that each GEMM workgroup owns RoPE pairs (d, d+64): the QKV epilogue
+        # applies RoPE and writes the attention fragments itself (la_gemm64_qkv)
+        self.qkv_fused = not (gemm_cfg and len(gemm_cfg) > 1 and gemm_cfg[1] < 0)
+        n_qkv = (shape.n_heads + 2 * shape.n_kv_heads) * hd
+        perm_np = np.zeros(n_qkv, dtype=np.int32)
+        check(lib.la_qkv_row_perm(shape.n_heads, shape.n_kv_heads, perm_np.ctypes.data_as(_lib.pi32)), 'qkv_row_perm')
+        qkv_perm = torch.from_numpy(perm_np.astype(np.int64)).to(self.device)
         layers = (_lib.LlamaLayerWeightsC * shape.n_layers)()
         for i in range(shape.n_layers):
             p = f'model.layers.{i}.'
             qkv = torch.cat([take(p + 'self_attn.q_proj.weight').to(self.device),
                              take(p + 'self_attn.k_proj.weight').to(self.device),
                              take(p + 'self_attn.v_proj.weight').to(self.device)], 0)
+            if self.qkv_fused:
+                qkv = qkv.index_select(0, qkv_perm)
             layers[i].wqkv = pack(qkv).data_ptr()
             del qkv
             layers[i].wo = pack(take(p + 'self_attn.o_proj.weight')).data_ptr()

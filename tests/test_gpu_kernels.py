@@ -270,3 +270,38 @@ def test_kv_commit_moves_rows():
     for i, s in enumerate(src):
         assert torch.equal(K[:, 30 + i], kfr[:, s]) and torch.equal(V[:, 30 + i], vfr[:, s])
     assert float(K[:, :30].abs().max()) == 0 and float(K[:, 35:].abs().max()) == 0 and float(V[:, 35:].abs().max()) == 0
+
+
+@pytest.mark.parametrize('nh,nkv', [(2, 2), (8, 2)])
+def test_gemm64_qkv_fused_equals_slab_plus_qkv_post(nh, nkv):
+    """The fused QKV epilogue (RoPE + fragment writes inside the GEMM) must reproduce la_gemm64_slab + la_qkv_post
+    bit for bit: same fp32 sums (ksplit 1, same k order), same rounding points."""
+    from painlessinferenceacceleration_amd.llama_engine import rope_tables
+    K = 512
+    N = (nh + 2 * nkv) * 128
+    g = torch.Generator(device=DEV).manual_seed(21)
+    x = bf(torch.randn(64, K, generator=g, device=DEV))
+    w = bf(torch.randn(N, K, generator=g, device=DEV) * 0.05)
+    pos = torch.randint(0, 900, (64,), generator=g, device=DEV, dtype=torch.int32)
+    rc, rs_ = rope_tables(128, 1024, 10000.0, DEV)
+    xp = gu.pack_x(x)
+    outs = []
+    for fused in (False, True):
+        qf = torch.zeros(nh * 8192, dtype=torch.bfloat16, device=DEV)
+        kf = torch.zeros(nkv * 8192, dtype=torch.bfloat16, device=DEV)
+        vf = torch.zeros(nkv * 8192, dtype=torch.bfloat16, device=DEV)
+        if fused:
+            perm = np.zeros(N, dtype=np.int32)
+            check(lib.la_qkv_row_perm(nh, nkv, perm.ctypes.data_as(_lib.pi32)), 'perm')
+            assert sorted(perm.tolist()) == list(range(N))
+            wp = gu.pack_weight(w[torch.from_numpy(perm.astype(np.int64)).to(DEV)].contiguous())
+            check(lib.la_gemm64_qkv(sp(), ptr(wp), ptr(xp), nh, nkv, K, ptr(pos), ptr(rc), ptr(rs_), ptr(qf), ptr(kf), ptr(vf), 0), 'qkv')
+        else:
+            wp = gu.pack_weight(w)
+            slabs = torch.zeros(1, 64, N, dtype=torch.float32, device=DEV)
+            check(lib.la_gemm64_slab(sp(), ptr(wp), ptr(xp), N, K, 2, 1, ptr(slabs)), 'gemm')
+            check(lib.la_qkv_post(sp(), ptr(slabs), 1, nh, nkv, ptr(pos), ptr(rc), ptr(rs_), ptr(qf), ptr(kf), ptr(vf)), 'post')
+        torch.cuda.synchronize()
+        outs.append((qf, kf, vf))
+    for a, b, name in zip(outs[0], outs[1], 'qkv'):
+        assert torch.equal(a, b), (name, int((a != b).sum()))
