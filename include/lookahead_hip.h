@@ -159,6 +159,18 @@ int la_gemm64_qkv(void* stream, const void* d_wp, const void* d_xp, int n_heads,
                   const int32_t* d_pos, const void* d_rope_cos, const void* d_rope_sin,
                   void* d_qf, void* d_kfresh, void* d_vfresh, int variant);
 int la_qkv_row_perm(int n_heads, int n_kv_heads, int32_t* perm /*[(nh+2*nkv)*128], host*/);
+/* Balanced variants: exactly n_wg workgroups (one per CU: n_wg = CU count, 256 on MI355X), each owning
+ * R = rows/n_wg rows per matrix as 32-row blocks with a partial last block.  The weight image is packed with
+ * la_pack_weight from the matrix gathered by la_rowplan (out[i] = source row of packed row i, -1 = zero pad row;
+ * kind 0 = single matrix (lm_head), 1 = gate/up pair (rows >= n_rows index the second matrix), 2 = qkv RoPE pairs).
+ * la_rowplan returns the number of packed rows, or LA_E_RANGE if the shape cannot be balanced this way. */
+int la_rowplan(int kind, int n_rows, int n_wg, int32_t* out /* may be NULL to query */);
+int la_gemm64r_swiglu(void* stream, const void* d_wp, const void* d_xp, int F, int K, int n_wg, void* d_act_packed);
+int la_gemm64r_logits(void* stream, const void* d_wp, const void* d_xp, int V, int K, int n_wg,
+                      void* d_logits_bf16, float* d_cand_val /*[n_wg*8][64]*/, int32_t* d_cand_idx);
+int la_gemm64r_qkv(void* stream, const void* d_wp, const void* d_xp, int n_heads, int n_kv_heads, int K, int n_wg,
+                   const int32_t* d_pos, const void* d_rope_cos, const void* d_rope_sin,
+                   void* d_qf, void* d_kfresh, void* d_vfresh);
 int la_gemm64_logits(void* stream, const void* d_wp, const void* d_xp, int V, int K, int rb,
                      void* d_logits_bf16 /*[64][V] or NULL*/, float* d_cand_val, int32_t* d_cand_idx);
 int la_argmax_finalize(void* stream, const float* d_cand_val, const int32_t* d_cand_idx, int n_tiles,
@@ -192,6 +204,7 @@ typedef struct la_llama_config {
     int32_t attn_split;      /* key-range splits per head (0 = auto)                          */
     float   rms_eps;
     int32_t gemm_cfg[8];     /* {qkv_rb,qkv_ks,o_rb,o_ks,down_rb,down_ks,lm_rb,gateup_variant}; 0 = auto */
+    int32_t balanced_wg[3];  /* {qkv, gate/up, lm_head}: > 0 = weights were packed with la_rowplan for that many workgroups */
 } la_llama_config;
 
 typedef struct la_llama_layer_weights {   /* device pointers, packed by la_pack_weight */

@@ -65,7 +65,7 @@ pi32, pi64, pu64, pf32 = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C
 class LlamaConfigC(C.Structure):
     _fields_ = [("n_layers", i32), ("hidden", i32), ("n_heads", i32), ("n_kv_heads", i32), ("head_dim", i32),
                 ("ffn", i32), ("vocab", i32), ("max_keys", i32), ("max_pos", i32), ("attn_split", i32),
-                ("rms_eps", f32), ("gemm_cfg", i32 * 8)]
+                ("rms_eps", f32), ("gemm_cfg", i32 * 8), ("balanced_wg", i32 * 3)]
 
 
 class LlamaLayerWeightsC(C.Structure):
@@ -113,6 +113,10 @@ PROTOTYPES = {
     "la_gemm64_swiglu": (i32, vp, vp, vp, i32, i32, vp, i32),
     "la_gemm64_qkv": (i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32),
     "la_qkv_row_perm": (i32, i32, i32, pi32),
+    "la_rowplan": (i32, i32, i32, i32, pi32),
+    "la_gemm64r_swiglu": (i32, vp, vp, vp, i32, i32, i32, vp),
+    "la_gemm64r_logits": (i32, vp, vp, vp, i32, i32, i32, vp, vp, vp),
+    "la_gemm64r_qkv": (i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp),
     "la_gemm64_logits": (i32, vp, vp, vp, i32, i32, i32, vp, vp, vp),
     "la_argmax_finalize": (i32, vp, vp, vp, i32, vp),
     "la_embed_norm": (i32, vp, vp, vp, vp, i32, f32, vp, vp),

@@ -56,6 +56,26 @@ int la_qkv_row_perm(int nh, int nkv, int32_t* perm) {
     lk_qkv_row_perm(nh, nkv, perm);
     return LA_OK;
 }
+int la_rowplan(int kind, int n_rows, int n_wg, int32_t* out) {
+    if (kind < 0 || kind > 2 || n_rows <= 0 || n_wg <= 0) return LA_E_ARG;
+    int n = lk_rowplan(kind, n_rows, n_wg, out);
+    return n < 0 ? LA_E_RANGE : n;
+}
+int la_gemm64r_swiglu(void* stream, const void* wp, const void* xp, int F, int K, int n_wg, void* act) {
+    if (!wp || !xp || !act || K % 16 || n_wg <= 0) return LA_E_ARG;
+    if (lk_gemm64r_init() != 0) return LA_E_HIP;
+    WRAP(lk_gemm64r_swiglu((hipStream_t)stream, wp, xp, F, K, n_wg, act));
+}
+int la_gemm64r_logits(void* stream, const void* wp, const void* xp, int V, int K, int n_wg, void* logits, float* cv, int32_t* ci) {
+    if (!wp || !xp || !cv || !ci || K % 16 || n_wg <= 0) return LA_E_ARG;
+    if (lk_gemm64r_init() != 0) return LA_E_HIP;
+    WRAP(lk_gemm64r_logits((hipStream_t)stream, wp, xp, V, K, n_wg, logits, cv, ci));
+}
+int la_gemm64r_qkv(void* stream, const void* wp, const void* xp, int nh, int nkv, int K, int n_wg, const int32_t* pos,
+                   const void* rcos, const void* rsin, void* qf, void* kf, void* vf) {
+    if (!wp || !xp || !pos || !rcos || !rsin || !qf || !kf || !vf || nh <= 0 || nkv <= 0 || K % 16 || n_wg <= 0) return LA_E_ARG;
+    WRAP(lk_gemm64r_qkv((hipStream_t)stream, wp, xp, nh, nkv, K, n_wg, pos, rcos, rsin, qf, kf, vf));
+}
 int la_gemm64_logits(void* stream, const void* wp, const void* xp, int V, int K, int rb, void* logits, float* cv,
                      int32_t* ci) {
     if (!wp || !xp || !cv || !ci || V % 32 || K % 16 || ((rb & 0xff) != 1 && (rb & 0xff) != 2)) return LA_E_ARG;

@@ -94,8 +94,10 @@ static size_t carve(la_llama* m, char* base) {
     m->opart = cv.take<float>((size_t)c.n_heads * m->nsplit * 64 * 128);
     m->mpart = cv.take<float>((size_t)c.n_heads * m->nsplit * 64);
     m->lpart = cv.take<float>((size_t)c.n_heads * m->nsplit * 64);
-    m->cand_val = cv.take<float>((size_t)(c.vocab / 32) * 4 * 64);
-    m->cand_idx = cv.take<int>((size_t)(c.vocab / 32) * 4 * 64);
+    size_t cand = (size_t)(c.vocab / 32) * 4;
+    if ((size_t)c.balanced_wg[2] * 8 > cand) cand = (size_t)c.balanced_wg[2] * 8;
+    m->cand_val = cv.take<float>(cand * 64);
+    m->cand_idx = cv.take<int>(cand * 64);
     m->state = cv.take<int>(LA_ST_WORDS);
     m->in = cv.take<int>(LA_IN_WORDS);
     m->pos = cv.take<int>(64);
@@ -128,6 +130,10 @@ extern "C" la_llama* la_llama_create(const la_llama_config* cfg, const la_llama_
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         la_set_error("no HIP device: liblookahead_hip has no CPU fallback");
+        return nullptr;
+    }
+    if ((cfg->balanced_wg[1] > 0 || cfg->balanced_wg[2] > 0) && lk_gemm64r_init() != 0) {
+        la_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
         return nullptr;
     }
     la_llama* m = new la_llama();
@@ -190,7 +196,10 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf) {
         uint16_t* kf = m->kfresh + (size_t)l * m->fresh_layer_elems;
         uint16_t* vf = m->vfresh + (size_t)l * m->fresh_layer_elems;
         P(KC_QKV);
-        if (m->qkv_fused) {
+        if (c.balanced_wg[0] > 0) {
+            KCHK(lk_gemm64r_qkv(st, L.wqkv, m->xp, c.n_heads, c.n_kv_heads, c.hidden, c.balanced_wg[0], m->pos,
+                                m->w.rope_cos, m->w.rope_sin, m->qf, kf, vf));
+        } else if (m->qkv_fused) {
             KCHK(lk_gemm64_qkv(st, L.wqkv, m->xp, c.n_heads, c.n_kv_heads, c.hidden, m->pos, m->w.rope_cos, m->w.rope_sin,
                                m->qf, kf, vf, m->qkv_rb >> 8));
         } else {
@@ -208,7 +217,8 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf) {
         P(KC_OTHER);
         KCHK(lk_resid_norm(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp));
         P(KC_GATEUP);
-        KCHK(lk_gemm64_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, m->act_xp, m->gu_variant));
+        if (c.balanced_wg[1] > 0) KCHK(lk_gemm64r_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, c.balanced_wg[1], m->act_xp));
+        else KCHK(lk_gemm64_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, m->act_xp, m->gu_variant));
         P(KC_DOWN);
         KCHK(lk_gemm64_slab(st, L.wdown, m->act_xp, c.hidden, c.ffn, m->down_rb, m->down_ks, m->slabs));
         P(KC_OTHER);
@@ -216,9 +226,15 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf) {
         KCHK(lk_resid_norm(st, m->h, m->slabs, m->down_ks, nw, c.hidden, c.rms_eps, m->xp));
     }
     P(KC_LMHEAD);
-    KCHK(lk_gemm64_logits(st, m->w.lm_head, m->xp, c.vocab, c.hidden, m->lm_rb, m->logits, m->cand_val, m->cand_idx));
-    P(KC_OTHER);
-    KCHK(lk_argmax_finalize(st, m->cand_val, m->cand_idx, lk_logits_cand_slots(c.vocab, m->lm_rb), m->state));
+    if (c.balanced_wg[2] > 0) {
+        KCHK(lk_gemm64r_logits(st, m->w.lm_head, m->xp, c.vocab, c.hidden, c.balanced_wg[2], m->logits, m->cand_val, m->cand_idx));
+        P(KC_OTHER);
+        KCHK(lk_argmax_finalize(st, m->cand_val, m->cand_idx, c.balanced_wg[2] * 8, m->state));
+    } else {
+        KCHK(lk_gemm64_logits(st, m->w.lm_head, m->xp, c.vocab, c.hidden, m->lm_rb, m->logits, m->cand_val, m->cand_idx));
+        P(KC_OTHER);
+        KCHK(lk_argmax_finalize(st, m->cand_val, m->cand_idx, lk_logits_cand_slots(c.vocab, m->lm_rb), m->state));
+    }
     KCHK(lk_accept_scan(st, m->ids, m->rowmask, m->state));
     KCHK(lk_kv_commit(st, m->kfresh, m->vfresh, m->kmain, m->vmain, m->state, c.n_layers, c.n_kv_heads, c.max_keys));
     P(KC_N);

@@ -14,6 +14,12 @@ int lk_logits_cand_slots(int V, int rbv);
 int lk_gemm64_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int nkv, int K, const int* pos, const void* rcos,
                   const void* rsin, void* qf, void* kfresh, void* vfresh, int variant);
 void lk_qkv_row_perm(int nh, int nkv, int* perm);
+int lk_gemm64r_init();
+int lk_rowplan(int kind, int n_rows, int n_wg, int* out);
+int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, int n_wg, void* act_xp);
+int lk_gemm64r_logits(hipStream_t st, const void* wp, const void* xp, int V, int K, int n_wg, void* logits, float* cv, int* ci);
+int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int nkv, int K, int n_wg, const int* pos,
+                   const void* rcos, const void* rsin, void* qf, void* kfresh, void* vfresh);
 int lk_argmax_finalize(hipStream_t st, const float* cv, const int* ci, int n_tiles, int* state);
 int lk_embed_norm(hipStream_t st, const void* embed, const int* ids, const void* nw, int hidden, float eps, void* h, void* xp);
 int lk_resid_norm(hipStream_t st, void* h, const float* slabs, int n_slabs, const void* nw, int hidden, float eps, void* xp);

@@ -273,6 +273,178 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Balanced skinny GEMM ("one workgroup per CU"): the per-CU streaming rate is capped (~22 GB/s of the chip's
+// ~5.7 TB/s, scripts/probe_stream.hip), so a launch is as slow as its busiest CU.  Here every workgroup owns exactly
+// R = rows / n_wg weight rows per matrix, stored as RB "virtual" 32-row blocks whose last one is partial: the packed
+// image pads it to 32 rows (zeros, never read), lanes of invalid rows re-read the last valid row (same cache line, no
+// extra HBM bytes) and their accumulator rows are simply never stored.  Full K per workgroup (no split-K slabs);
+// 8 waves split K.  EPI_SWIGLU: blocks {G0,G1,U0,U1} (R = ffn/n_wg <= 64); EPI_LOGITS: 4 blocks (R <= 128);
+// EPI_QKV: blocks {lo,hi} of R RoPE pairs (R <= 32).
+// ---------------------------------------------------------------------------------------------
+struct GemmRArgs {
+    GemmArgs g;
+    int R;          // valid rows per matrix per workgroup
+    int nv[4];      // valid rows of each virtual block
+};
+
+template <int RB, int EPI, int D, int NW>
+__global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
+    extern __shared__ __attribute__((aligned(16))) float redr[];      // [NW][RB][16][64]
+    const GemmArgs& a = ra.g;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nb0 = blockIdx.x * RB;
+    const int twg = a.K16, q = twg / NW, r = twg - q * NW;
+    const int wb = wave * q + (wave < r ? wave : r);
+    const int cnt = q + (wave < r ? 1 : 0);
+    const int ngroups = (cnt + D - 1) / D;
+    const int last_valid = cnt - (ngroups - 1) * D;
+    const bf16x8* __restrict__ wbase = (const bf16x8*)a.wp;
+    const bf16x8* __restrict__ xbase = (const bf16x8*)a.xp;
+    unsigned woff[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int rr = (lane & 31) < ra.nv[rb] ? (lane & 31) : ra.nv[rb] - 1;
+        woff[rb] = (unsigned)(((nb0 + rb) * a.K16 + wb) * 64 + rr + 32 * (lane >> 5));
+    }
+    unsigned xoff = (unsigned)(wb * 128 + lane);
+    f32x16 acc[RB][2];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rb][tb][i] = 0.f;
+    if (ngroups > 0) {
+        bf16x8 fa[D][RB], fb[D][2];
+        const int n1 = ngroups == 1 ? last_valid : D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int dd = d < n1 ? d : 0;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wbase + woff[rb] + dd * 64);
+            fb[d][0] = xbase[xoff + dd * 128];
+            fb[d][1] = xbase[xoff + dd * 128 + 64];
+        }
+        for (int g = 1; g < ngroups; ++g) {
+            const int nv2 = (g == ngroups - 1) ? last_valid : D;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][0], acc[rb][0], 0, 0, 0);
+                    acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][1], acc[rb][1], 0, 0, 0);
+                }
+                const int dd = (d < nv2 ? g * D + d : 0);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wbase + woff[rb] + dd * 64);
+                fb[d][0] = xbase[xoff + dd * 128];
+                fb[d][1] = xbase[xoff + dd * 128 + 64];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (d < last_valid) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][0], acc[rb][0], 0, 0, 0);
+                    acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][1], acc[rb][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- two passes (token block 0, 1): park partial tiles in LDS, barrier, each wave finishes a fixed slice ----
+    const int tl = lane & 31, hh = lane >> 5;
+    constexpr int SL = RB * 4 / NW;            // (row-block, register-group) slices per wave and pass (SWIGLU/QKV pair up)
+    static_assert(RB * 4 % NW == 0 || EPI == EPI_SWIGLU || EPI == EPI_QKV, "slice split");
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        if (tb) __syncthreads();
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) redr[((wave * RB + rb) * 16 + i) * 64 + lane] = acc[rb][tb][i];
+        __syncthreads();
+        const int tok = tb * 32 + tl;
+        auto total = [&](int rb, int gi, int j) {
+            float v = 0.f;
+#pragma unroll
+            for (int p = 0; p < NW; ++p) v += redr[((p * RB + rb) * 16 + gi * 4 + j) * 64 + lane];
+            return v;
+        };
+        if constexpr (EPI == EPI_SWIGLU) {
+            // wave -> (pair q, register group gi): gate block q, up block q + RB/2
+            static_assert(EPI != EPI_SWIGLU || (RB == 4 && NW == 8), "swiglu layout");
+            const int qq = wave >> 2, gi = wave & 3;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = 8 * gi + 4 * hh + j;
+                if (f < ra.nv[qq]) {
+                    const float gv = bfr(total(qq, gi, j)), uv = bfr(total(qq + RB / 2, gi, j));
+                    const float sv = bfr(gv / (1.0f + expf(-gv)));
+                    const int feat = ra.R * blockIdx.x + 32 * qq + f;
+                    a.act_xp[xp_offset(tok, feat)] = f2bf(sv * uv);
+                }
+            }
+        } else if constexpr (EPI == EPI_QKV) {
+            // wave -> register group gi (NW == 4); block 0 = dims dlo of R pairs, block 1 = their +64 partners
+            static_assert(EPI != EPI_QKV || (RB == 2 && NW == 4), "qkv layout");
+            const int gi = wave;
+            const int ps = a.pos[tok];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = 8 * gi + 4 * hh + j;
+                if (f < ra.nv[0]) {
+                    const int pr = ra.R * blockIdx.x + f, slot = pr >> 6, dlo = pr & 63, dhi = dlo + 64;
+                    const float xl = total(0, gi, j), xh = total(1, gi, j);
+                    if (slot < a.nh + a.nkv) {
+                        bf16_t* dst = slot < a.nh ? a.qf + (size_t)slot * 8192 : a.kfresh + (size_t)(slot - a.nh) * 8192;
+                        const float c = bf2f(a.rcos[(size_t)ps * 64 + dlo]), sn = bf2f(a.rsin[(size_t)ps * 64 + dlo]);
+                        const float bl = bfr(xl), bh = bfr(xh);
+                        dst[rf_offset(tok, dlo)] = f2bf(bfr(bl * c) + bfr(-bh * sn));
+                        dst[rf_offset(tok, dhi)] = f2bf(bfr(bh * c) + bfr(bl * sn));
+                    } else {
+                        bf16_t* dst = a.vfresh + (size_t)(slot - a.nh - a.nkv) * 8192;
+                        dst[vf_offset(tok, dlo)] = f2bf(xl);
+                        dst[vf_offset(tok, dhi)] = f2bf(xh);
+                    }
+                }
+            }
+        } else {
+            // EPI_LOGITS: wave -> SL slices (rb, gi); candidates per (workgroup, wave)
+#pragma unroll
+            for (int sidx = 0; sidx < SL; ++sidx) {
+                const int sl = wave * SL + sidx, rb = sl >> 2, gi = sl & 3;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = 8 * gi + 4 * hh + j;
+                    if (f < ra.nv[rb]) {
+                        const bf16_t hv = f2bf(total(rb, gi, j));
+                        const int idx = ra.R * blockIdx.x + 32 * rb + f;
+                        if (a.logits) a.logits[(size_t)tok * a.N + idx] = hv;
+                        const float v = bf2f(hv);
+                        if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
+                    }
+                }
+            }
+            float ob = __shfl_xor(best, 32, 64);
+            int oi = __shfl_xor(bidx, 32, 64);
+            if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+            if (hh == 0) {
+                const size_t slot = (size_t)blockIdx.x * NW + wave;
+                a.cand_val[slot * LA_TB + tok] = best;
+                a.cand_idx[slot * LA_TB + tok] = bidx;
+            }
+            best = -INFINITY; bidx = 0x7fffffff;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_argmax_finalize(const float* __restrict__ cv, const int* __restrict__ ci,
                                                         int n_tiles, int* __restrict__ state) {
     __shared__ float sv[4];
@@ -813,6 +985,82 @@ void lk_qkv_row_perm(int nh, int nkv, int* perm) {
         const int nb = r >> 5, f = r & 31, b = nb >> 1, rb = nb & 1, slot = b >> 1, u = b & 1;
         perm[r] = slot * 128 + 64 * rb + 32 * u + f;
     }
+}
+// ---- balanced variants (one workgroup per CU): weights packed from the row plan of lk_rowplan ----
+static void fill_nv(GemmRArgs& ra, int R, int blocks_per_matrix, int matrices) {
+    for (int m = 0; m < matrices; ++m)
+        for (int b = 0; b < blocks_per_matrix; ++b) {
+            int v = R - 32 * b; if (v > 32) v = 32;
+            ra.nv[m * blocks_per_matrix + b] = v;
+        }
+}
+int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, int n_wg, void* act_xp) {
+    GemmRArgs ra{}; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act_xp;
+    ra.R = F / n_wg; if (F % n_wg || ra.R > 64 || ra.R <= 32) return -1;
+    fill_nv(ra, ra.R, 2, 2);
+    k_gemm64r<4, EPI_SWIGLU, 4, 8><<<n_wg, 512, 8 * 4 * 4096, st>>>(ra);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_gemm64r_logits(hipStream_t st, const void* wp, const void* xp, int V, int K, int n_wg, void* logits, float* cv, int* ci) {
+    GemmRArgs ra{}; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = V;
+    ra.g.logits = (bf16_t*)logits; ra.g.cand_val = cv; ra.g.cand_idx = ci;
+    ra.R = V / n_wg; if (V % n_wg || ra.R > 128 || ra.R <= 96) return -1;
+    fill_nv(ra, ra.R, 4, 1);
+    k_gemm64r<4, EPI_LOGITS, 4, 8><<<n_wg, 512, 8 * 4 * 4096, st>>>(ra);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int nkv, int K, int n_wg, const int* pos,
+                   const void* rcos, const void* rsin, void* qf, void* kfresh, void* vfresh) {
+    GemmRArgs ra{}; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = (nh + 2 * nkv) * 128;
+    ra.g.pos = pos; ra.g.rcos = (const bf16_t*)rcos; ra.g.rsin = (const bf16_t*)rsin;
+    ra.g.qf = (bf16_t*)qf; ra.g.kfresh = (bf16_t*)kfresh; ra.g.vfresh = (bf16_t*)vfresh; ra.g.nh = nh; ra.g.nkv = nkv;
+    const int pairs = (nh + 2 * nkv) * 64;
+    ra.R = pairs / n_wg; if (pairs % n_wg || ra.R > 32) return -1;
+    ra.nv[0] = ra.nv[1] = ra.R;
+    k_gemm64r<2, EPI_QKV, 8, 4><<<n_wg, 256, 4 * 2 * 4096, st>>>(ra);
+    LAUNCH_CHECK(); return 0;
+}
+static bool g_attr_done = false;
+int lk_gemm64r_init() {
+    if (g_attr_done) return 0;
+    hipError_t e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_SWIGLU, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_LOGITS, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
+    if (e != hipSuccess) return (int)e;
+    g_attr_done = true;
+    return 0;
+}
+// Row plan of the balanced packing: out[i] = source row of packed row i (for kind 1 rows >= n_rows address the second
+// matrix: row - n_rows of `up`), or -1 for a zero pad row.  Returns the number of packed rows (n_wg * RB * 32).
+//   kind 0: one matrix [n_rows][K] (lm_head), R = n_rows/n_wg, blocks of 32 per workgroup
+//   kind 1: gate/up pair, R = n_rows/n_wg: blocks {G0, G1, U0, U1}
+//   kind 2: qkv, n_rows = (nh+2nkv)*128: R = pairs/n_wg RoPE pairs per workgroup: blocks {lo, hi}
+int lk_rowplan(int kind, int n_rows, int n_wg, int* out) {
+    if (kind == 2) {
+        const int pairs = n_rows / 2, R = pairs / n_wg;
+        if (pairs % n_wg || R > 32) return -1;
+        if (out)
+            for (int w = 0; w < n_wg; ++w)
+                for (int rb = 0; rb < 2; ++rb)
+                    for (int f = 0; f < 32; ++f) {
+                        int v = -1;
+                        if (f < R) { const int pr = R * w + f, slot = pr >> 6, dlo = pr & 63; v = slot * 128 + dlo + 64 * rb; }
+                        out[(w * 2 + rb) * 32 + f] = v;
+                    }
+        return n_wg * 64;
+    }
+    const int R = n_rows / n_wg;
+    if (n_rows % n_wg) return -1;
+    const int bpm = kind == 1 ? 2 : 4, mats = kind == 1 ? 2 : 1;
+    if (R > 32 * bpm || R <= 32 * (bpm - 1)) return -1;
+    if (out)
+        for (int w = 0; w < n_wg; ++w)
+            for (int m = 0; m < mats; ++m)
+                for (int b = 0; b < bpm; ++b)
+                    for (int f = 0; f < 32; ++f) {
+                        const int rr = 32 * b + f;
+                        out[((w * mats + m) * bpm + b) * 32 + f] = rr < R ? m * n_rows + R * w + rr : -1;
+                    }
+    return n_wg * mats * bpm * 32;
 }
 // number of [64]-token candidate slots la_gemm64_logits writes (input of lk_argmax_finalize)
 int lk_logits_cand_slots(int V, int rbv) {

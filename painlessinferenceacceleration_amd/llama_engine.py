@@ -106,7 +106,7 @@ class LlamaVerifyEngine(object):
     """One sequence (bs=1) on one GPU: packed weights + KV cache + the captured step graph."""
 
     def __init__(self, shape, state_dict, max_length=2048, device='cuda:0', attn_split=0, gemm_cfg=None,
-                 consume_state_dict=False):
+                 consume_state_dict=False, balanced=True):
         if not torch.cuda.is_available():
             raise RuntimeError('LlamaVerifyEngine needs an MI355X: the verify step has no CPU fallback')
         self.shape = shape
@@ -142,6 +142,30 @@ class LlamaVerifyEngine(object):
         def take(name):
             return state_dict.pop(name) if consume_state_dict else state_dict[name]
 
+        # Balanced GEMMs: one workgroup per CU, rows dealt out by la_rowplan (0 = shape not balanceable -> classic grid)
+        n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        self.balanced_wg = [0, 0, 0]
+        plans = {}
+        if balanced and not (gemm_cfg and len(gemm_cfg) > 1 and gemm_cfg[1] < 0):
+            for slot, (kind, n_rows) in enumerate([(2, (shape.n_heads + 2 * shape.n_kv_heads) * hd), (1, shape.ffn),
+                                                   (0, shape.vocab)]):
+                n = lib.la_rowplan(kind, n_rows, n_cu, None)
+                if n > 0:
+                    plan = np.zeros(n, dtype=np.int32)
+                    check(min(lib.la_rowplan(kind, n_rows, n_cu, plan.ctypes.data_as(_lib.pi32)), 0), 'rowplan')
+                    plans[slot] = torch.from_numpy(plan.astype(np.int64)).to(self.device)
+                    self.balanced_wg[slot] = n_cu
+
+        def pack_planned(slot, mats):
+            """gather rows by the plan (-1 -> zero row) and pack the padded image"""
+            mats = [m.to(device=self.device, dtype=torch.bfloat16) for m in mats]
+            full = torch.cat(mats + [torch.zeros(1, mats[0].shape[1], dtype=torch.bfloat16, device=self.device)], 0)
+            idx = plans[slot].clone()
+            idx[idx < 0] = full.shape[0] - 1
+            out = pack(full.index_select(0, idx))
+            del full
+            return out
+
         # rows of [Wq;Wk;Wv] are gathered so that each GEMM workgroup owns RoPE pairs (d, d+64): the QKV epilogue
         # applies RoPE and writes the attention fragments itself (la_gemm64_qkv)
         self.qkv_fused = not (gemm_cfg and len(gemm_cfg) > 1 and gemm_cfg[1] < 0)
@@ -155,12 +179,18 @@ class LlamaVerifyEngine(object):
             qkv = torch.cat([take(p + 'self_attn.q_proj.weight').to(self.device),
                              take(p + 'self_attn.k_proj.weight').to(self.device),
                              take(p + 'self_attn.v_proj.weight').to(self.device)], 0)
-            if self.qkv_fused:
-                qkv = qkv.index_select(0, qkv_perm)
-            layers[i].wqkv = pack(qkv).data_ptr()
+            if self.balanced_wg[0]:
+                layers[i].wqkv = pack_planned(0, [qkv]).data_ptr()
+            else:
+                if self.qkv_fused:
+                    qkv = qkv.index_select(0, qkv_perm)
+                layers[i].wqkv = pack(qkv).data_ptr()
             del qkv
             layers[i].wo = pack(take(p + 'self_attn.o_proj.weight')).data_ptr()
-            layers[i].wgateup = pack(take(p + 'mlp.gate_proj.weight'), take(p + 'mlp.up_proj.weight')).data_ptr()
+            if self.balanced_wg[1]:
+                layers[i].wgateup = pack_planned(1, [take(p + 'mlp.gate_proj.weight'), take(p + 'mlp.up_proj.weight')]).data_ptr()
+            else:
+                layers[i].wgateup = pack(take(p + 'mlp.gate_proj.weight'), take(p + 'mlp.up_proj.weight')).data_ptr()
             layers[i].wdown = pack(take(p + 'mlp.down_proj.weight')).data_ptr()
             layers[i].norm1 = dev(take(p + 'input_layernorm.weight')).data_ptr()
             layers[i].norm2 = dev(take(p + 'post_attention_layernorm.weight')).data_ptr()
@@ -170,7 +200,7 @@ class LlamaVerifyEngine(object):
         self.rope_cos, self.rope_sin = rope_tables(hd, self.max_pos, shape.rope_theta, self.device)
         w = _lib.LlamaWeightsC()
         w.embed = self.embed.data_ptr()
-        w.lm_head = pack(take('lm_head.weight')).data_ptr()
+        w.lm_head = (pack_planned(2, [take('lm_head.weight')]) if self.balanced_wg[2] else pack(take('lm_head.weight'))).data_ptr()
         w.final_norm = dev(take('model.norm.weight')).data_ptr()
         w.rope_cos, w.rope_sin = self.rope_cos.data_ptr(), self.rope_sin.data_ptr()
         w.layers = C.cast(layers, C.POINTER(_lib.LlamaLayerWeightsC))
@@ -182,6 +212,8 @@ class LlamaVerifyEngine(object):
         cfg.max_keys, cfg.max_pos, cfg.attn_split, cfg.rms_eps = self.max_keys, self.max_pos, attn_split, shape.rms_eps
         for i, v in enumerate(gemm_cfg or []):
             cfg.gemm_cfg[i] = int(v)
+        for i in range(3):
+            cfg.balanced_wg[i] = self.balanced_wg[i]
         self._cfg = cfg
         nbytes = lib.la_llama_workspace_bytes(C.byref(cfg))
         if nbytes <= 0:

@@ -86,3 +86,16 @@ def random_tree(rs, T, branch=0.35):
         rows.append(rows[p] | (1 << i))
         stack.append(i)
     return parent, np.array(rows, dtype=np.uint64)
+
+
+def pack_planned(kind, mats, n_wg):
+    """Balanced packing: gather rows by la_rowplan (-1 -> zero row), then la_pack_weight."""
+    n_rows = mats[0].shape[0]
+    n = lib.la_rowplan(kind, n_rows, n_wg, None)
+    assert n > 0, 'shape cannot be balanced'
+    plan = np.zeros(n, dtype=np.int32)
+    assert lib.la_rowplan(kind, n_rows, n_wg, plan.ctypes.data_as(_lib.pi32)) == n
+    full = torch.cat(list(mats) + [torch.zeros(1, mats[0].shape[1], dtype=mats[0].dtype, device=mats[0].device)], 0)
+    idx = torch.from_numpy(plan.astype(np.int64)).to(full.device)
+    idx[idx < 0] = full.shape[0] - 1
+    return pack_weight(full.index_select(0, idx).contiguous())

@@ -305,3 +305,72 @@ def test_gemm64_qkv_fused_equals_slab_plus_qkv_post(nh, nkv):
         outs.append((qf, kf, vf))
     for a, b, name in zip(outs[0], outs[1], 'qkv'):
         assert torch.equal(a, b), (name, int((a != b).sum()))
+
+
+@pytest.mark.parametrize('F,K,nwg', [(344, 512, 8), (11008, 4096, 256), (13824, 256, 256)])
+def test_gemm64r_swiglu_balanced(F, K, nwg):
+    """One workgroup per CU with partial row-blocks (R = F/nwg): same result as the reference formula."""
+    g = torch.Generator(device=DEV).manual_seed(F)
+    x = bf(torch.randn(64, K, generator=g, device=DEV))
+    wg = bf(torch.randn(F, K, generator=g, device=DEV) * 0.05)
+    wu = bf(torch.randn(F, K, generator=g, device=DEV) * 0.05)
+    act = torch.zeros(64 * F, dtype=torch.bfloat16, device=DEV)
+    wp, xp = gu.pack_planned(1, [wg, wu], nwg), gu.pack_x(x)
+    check(lib.la_gemm64r_swiglu(sp(), ptr(wp), ptr(xp), F, K, nwg, ptr(act)), 'swiglu_r')
+    torch.cuda.synchronize()
+    got = gu.from_packed(act, gu.xp_index(F)).float()
+    gg, uu = bf(x.float() @ wg.float().t()), bf(x.float() @ wu.float().t())
+    ref = bf(bf(torch.nn.functional.silu(gg.float())).float() * uu.float()).float()
+    assert gu.rel_err(got, ref) < 2e-2, gu.rel_err(got, ref)
+    assert float((got != ref).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize('V,K,nwg', [(1000, 512, 8), (32000, 512, 256)])
+def test_gemm64r_logits_balanced(V, K, nwg):
+    g = torch.Generator(device=DEV).manual_seed(V)
+    x = bf(torch.randn(64, K, generator=g, device=DEV))
+    w = bf(torch.randn(V, K, generator=g, device=DEV) * 0.05)
+    logits = torch.zeros(64, V, dtype=torch.bfloat16, device=DEV)
+    cv = torch.zeros(nwg * 8 * 64, dtype=torch.float32, device=DEV)
+    ci = torch.zeros(nwg * 8 * 64, dtype=torch.int32, device=DEV)
+    state = torch.zeros(_lib.LA_ST_WORDS, dtype=torch.int32, device=DEV)
+    wp, xp = gu.pack_planned(0, [w], nwg), gu.pack_x(x)
+    check(lib.la_gemm64r_logits(sp(), ptr(wp), ptr(xp), V, K, nwg, ptr(logits), ptr(cv), ptr(ci)), 'logits_r')
+    check(lib.la_argmax_finalize(sp(), ptr(cv), ptr(ci), nwg * 8, ptr(state)), 'argmax')
+    torch.cuda.synchronize()
+    assert gu.rel_err(logits.float(), x.double() @ w.double().t()) < 1e-2
+    lf = logits.float().cpu()
+    exp = torch.tensor([int((row == row.max()).nonzero()[0]) for row in lf], dtype=torch.int32)
+    assert torch.equal(state[_lib.LA_ST_ARGMAX:_lib.LA_ST_ARGMAX + 64].cpu(), exp)
+
+
+@pytest.mark.parametrize('nh,nkv,nwg', [(3, 1, 16), (32, 32, 256), (8, 2, 32)])
+def test_gemm64r_qkv_balanced_equals_unfused(nh, nkv, nwg):
+    """Balanced fused QKV (R RoPE pairs per workgroup, spanning head boundaries) vs la_gemm64_slab + la_qkv_post:
+    same roundings; fp32 sums differ only by the K split (8 tile-sets x 4 waves in both), so bit equality is expected."""
+    from painlessinferenceacceleration_amd.llama_engine import rope_tables
+    K = 512
+    N = (nh + 2 * nkv) * 128
+    g = torch.Generator(device=DEV).manual_seed(nh * 7 + nkv)
+    x = bf(torch.randn(64, K, generator=g, device=DEV))
+    w = bf(torch.randn(N, K, generator=g, device=DEV) * 0.05)
+    pos = torch.randint(0, 900, (64,), generator=g, device=DEV, dtype=torch.int32)
+    rc, rs_ = rope_tables(128, 1024, 10000.0, DEV)
+    xp = gu.pack_x(x)
+    outs = []
+    for bal in (False, True):
+        qf = torch.zeros(nh * 8192, dtype=torch.bfloat16, device=DEV)
+        kf = torch.zeros(nkv * 8192, dtype=torch.bfloat16, device=DEV)
+        vf = torch.zeros(nkv * 8192, dtype=torch.bfloat16, device=DEV)
+        if bal:
+            wp = gu.pack_planned(2, [w], nwg)
+            check(lib.la_gemm64r_qkv(sp(), ptr(wp), ptr(xp), nh, nkv, K, nwg, ptr(pos), ptr(rc), ptr(rs_), ptr(qf), ptr(kf), ptr(vf)), 'qkv_r')
+        else:
+            wp = gu.pack_weight(w)
+            slabs = torch.zeros(1, 64, N, dtype=torch.float32, device=DEV)
+            check(lib.la_gemm64_slab(sp(), ptr(wp), ptr(xp), N, K, 2, 1, ptr(slabs)), 'gemm')
+            check(lib.la_qkv_post(sp(), ptr(slabs), 1, nh, nkv, ptr(pos), ptr(rc), ptr(rs_), ptr(qf), ptr(kf), ptr(vf)), 'post')
+        torch.cuda.synchronize()
+        outs.append((qf, kf, vf))
+    for a, b, name in zip(outs[0], outs[1], 'qkv'):
+        assert torch.equal(a, b), (name, int((a != b).sum()))
