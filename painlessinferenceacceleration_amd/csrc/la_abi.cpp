@@ -74,6 +74,7 @@ int la_gemm64r_logits(void* stream, const void* wp, const void* xp, int V, int K
 int la_gemm64r_qkv(void* stream, const void* wp, const void* xp, int nh, int nkv, int K, int n_wg, const int32_t* pos,
                    const void* rcos, const void* rsin, void* qf, void* kf, void* vf) {
     if (!wp || !xp || !pos || !rcos || !rsin || !qf || !kf || !vf || nh <= 0 || nkv <= 0 || K % 16 || n_wg <= 0) return LA_E_ARG;
+    if (lk_gemm64r_init() != 0) return LA_E_HIP;
     WRAP(lk_gemm64r_qkv((hipStream_t)stream, wp, xp, nh, nkv, K, n_wg, pos, rcos, rsin, qf, kf, vf));
 }
 int la_gemm64_logits(void* stream, const void* wp, const void* xp, int V, int K, int rb, void* logits, float* cv,

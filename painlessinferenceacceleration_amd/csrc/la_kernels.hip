@@ -393,13 +393,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
             }
         } else if constexpr (EPI == EPI_QKV) {
             // wave -> register group gi (NW == 4); block 0 = dims dlo of R pairs, block 1 = their +64 partners
-            static_assert(EPI != EPI_QKV || (RB == 2 && NW == 4), "qkv layout");
-            const int gi = wave;
+            static_assert(EPI != EPI_QKV || RB == 2, "qkv layout");
+            const int gi = wave & 3;
             const int ps = a.pos[tok];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int f = 8 * gi + 4 * hh + j;
-                if (f < ra.nv[0]) {
+                if (wave < 4 && f < ra.nv[0]) {
                     const int pr = ra.R * blockIdx.x + f, slot = pr >> 6, dlo = pr & 63, dhi = dlo + 64;
                     const float xl = total(0, gi, j), xh = total(1, gi, j);
                     if (slot < a.nh + a.nkv) {
@@ -1017,7 +1017,7 @@ int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int n
     const int pairs = (nh + 2 * nkv) * 64;
     ra.R = pairs / n_wg; if (pairs % n_wg || ra.R > 32) return -1;
     ra.nv[0] = ra.nv[1] = ra.R;
-    k_gemm64r<2, EPI_QKV, 8, 4><<<n_wg, 256, 4 * 2 * 4096, st>>>(ra);
+    k_gemm64r<2, EPI_QKV, 8, 8><<<n_wg, 512, 8 * 2 * 4096, st>>>(ra);
     LAUNCH_CHECK(); return 0;
 }
 static bool g_attr_done = false;
@@ -1025,6 +1025,7 @@ int lk_gemm64r_init() {
     if (g_attr_done) return 0;
     hipError_t e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_SWIGLU, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_LOGITS, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<2, EPI_QKV, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 4096);
     if (e != hipSuccess) return (int)e;
     g_attr_done = true;
     return 0;
