@@ -132,7 +132,7 @@ extern "C" la_llama* la_llama_create(const la_llama_config* cfg, const la_llama_
         la_set_error("no HIP device: liblookahead_hip has no CPU fallback");
         return nullptr;
     }
-    if ((cfg->balanced_wg[0] > 0 || cfg->balanced_wg[1] > 0 || cfg->balanced_wg[2] > 0) && lk_gemm64r_init() != 0) {
+    if (lk_gemm64r_init() != 0) {      // kernels with > 64 KiB of dynamic LDS (never inside a stream capture)
         la_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
         return nullptr;
     }

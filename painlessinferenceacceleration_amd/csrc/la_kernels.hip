@@ -675,12 +675,13 @@ struct AttnArgs {
 
 #define LA_NEG (-1.0e30f)
 
-__global__ __launch_bounds__(256) void k_tree_attn(AttnArgs a) {
-    __shared__ float mg[2][66][64];   // merge buffer: per token block, 64 O regs + m + l per lane
+#define LA_ATT_PAR 4      // key-tile parities per workgroup (waves = 2 token blocks x LA_ATT_PAR)
+__global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float mgbuf[];   // [LA_ATT_PAR/2][2][66][64] merge buffer
     const int h = blockIdx.x, sp = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tb = wave & 1, par = wave >> 1;
+    const int tb = wave & 1, par = wave >> 1;      // par in [0, LA_ATT_PAR)
     const int hk = h / (a.nh / a.nkv);
     const int KB = a.max_keys >> 5;
     const int nkeys = a.state[LA_ST_NKEYS];
@@ -764,7 +765,7 @@ __global__ __launch_bounds__(256) void k_tree_attn(AttnArgs a) {
             for (int s = 0; s < 8; ++s) kA[s] = kt[s * 64 + lane];
         }
         while (it < i1) {
-            int nx = it + 2;
+            int nx = it + LA_ATT_PAR;
             if (nx < i1) {
                 const bf16x8* kt = kptr(nx);
 #pragma unroll
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(256) void k_tree_attn(AttnArgs a) {
             tile(it, kA);
             it = nx;
             if (it >= i1) break;
-            nx = it + 2;
+            nx = it + LA_ATT_PAR;
             if (nx < i1) {
                 const bf16x8* kt = kptr(nx);
 #pragma unroll
@@ -784,28 +785,34 @@ __global__ __launch_bounds__(256) void k_tree_attn(AttnArgs a) {
         }
     }
 
-    // merge the two key-parity waves of each token block (fixed order), wave par==0 writes the partial
-    if (par == 1) {
+    // merge the key-parity waves of each token block: fixed-order tree (par p+half -> p), wave par==0 writes
 #pragma unroll
-        for (int db = 0; db < 4; ++db)
+    for (int half = LA_ATT_PAR / 2; half >= 1; half >>= 1) {
+        float* mg = mgbuf + (size_t)(((par - half) * 2 + tb) * 66) * 64;
+        if (par >= half && par < 2 * half) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) mg[tb][db * 16 + i][lane] = o[db][i];
-        mg[tb][64][lane] = m;
-        mg[tb][65][lane] = l;
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mg[(db * 16 + i) * 64 + lane] = o[db][i];
+            mg[64 * 64 + lane] = m;
+            mg[65 * 64 + lane] = l;
+        }
+        __syncthreads();
+        if (par < half) {
+            const float* mr = mgbuf + (size_t)((par * 2 + tb) * 66) * 64;
+            const float m1 = mr[64 * 64 + lane], l1 = mr[65 * 64 + lane];
+            const float M = fmaxf(m, m1);
+            const float a0 = __expf(m - M), a1 = __expf(m1 - M);
+            l = l * a0 + l1 * a1;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[db][i] = o[db][i] * a0 + mr[(db * 16 + i) * 64 + lane] * a1;
+            m = M;
+        }
+        if (half > 1) __syncthreads();
     }
-    __syncthreads();
-    if (par == 1) return;
-    {
-        const float m1 = mg[tb][64][lane], l1 = mg[tb][65][lane];
-        const float M = fmaxf(m, m1);
-        const float a0 = __expf(m - M), a1 = __expf(m1 - M);
-        l = l * a0 + l1 * a1;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o[db][i] = o[db][i] * a0 + mg[tb][db * 16 + i][lane] * a1;
-        m = M;
-    }
+    if (par != 0) return;
     const int tok = tb * 32 + (lane & 31);
     float* op = a.opart + (((size_t)h * a.nsplit + sp) * LA_TB + tok) * 128;
 #pragma unroll
@@ -822,24 +829,35 @@ __global__ __launch_bounds__(256) void k_tree_attn(AttnArgs a) {
 }
 
 // merge key splits, normalise, round to bf16 (attn_output dtype) and emit the packed operand of o_proj
+template <int NS>
 __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ opart, const float* __restrict__ mpart,
-                                                       const float* __restrict__ lpart, int nh, int nsplit,
+                                                       const float* __restrict__ lpart, int nh,
                                                        bf16_t* __restrict__ attn_xp) {
     int gid = blockIdx.x * 256 + threadIdx.x;   // (h, tok, d8)
     if (gid >= nh * LA_TB * 16) return;
     int d8 = gid & 15, tok = (gid >> 4) & 63, h = gid >> 10;
-    float M = LA_NEG;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, mpart[((size_t)h * nsplit + s) * LA_TB + tok]);
-    float L = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int s = 0; s < nsplit; ++s) {
-        float w = __expf(mpart[((size_t)h * nsplit + s) * LA_TB + tok] - M);
-        L += w * lpart[((size_t)h * nsplit + s) * LA_TB + tok];
-        const float* op = opart + (((size_t)h * nsplit + s) * LA_TB + tok) * 128 + d8 * 8;
-        f32x4 a0 = *(const f32x4*)op, a1 = *(const f32x4*)(op + 4);
-        acc[0] += w * a0[0]; acc[1] += w * a0[1]; acc[2] += w * a0[2]; acc[3] += w * a0[3];
-        acc[4] += w * a1[0]; acc[5] += w * a1[1]; acc[6] += w * a1[2]; acc[7] += w * a1[3];
+    float ms[NS], ls[NS];
+    f32x4 o0[NS], o1[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        ms[s] = mpart[((size_t)h * NS + s) * LA_TB + tok];
+        ls[s] = lpart[((size_t)h * NS + s) * LA_TB + tok];
+        const float* op = opart + (((size_t)h * NS + s) * LA_TB + tok) * 128 + d8 * 8;
+        o0[s] = *(const f32x4*)op;
+        o1[s] = *(const f32x4*)(op + 4);
     }
-    float inv = 1.0f / L;
+    float M = LA_NEG;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) M = fmaxf(M, ms[s]);
+    float L = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float w = __expf(ms[s] - M);
+        L += w * ls[s];
+        acc[0] += w * o0[s][0]; acc[1] += w * o0[s][1]; acc[2] += w * o0[s][2]; acc[3] += w * o0[s][3];
+        acc[4] += w * o1[s][0]; acc[5] += w * o1[s][1]; acc[6] += w * o1[s][2]; acc[7] += w * o1[s][3];
+    }
+    const float inv = 1.0f / L;
     bf16x8 ov;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ov[j] = (short)f2bf(acc[j] * inv);
@@ -1023,6 +1041,8 @@ int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int n
 static bool g_attr_done = false;
 int lk_gemm64r_init() {
     if (g_attr_done) return 0;
+    if (hipFuncSetAttribute((const void*)k_tree_attn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (LA_ATT_PAR / 2) * 2 * 66 * 64 * sizeof(float)) != hipSuccess) return -1;
     hipError_t e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_SWIGLU, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_LOGITS, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<2, EPI_QKV, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 4096);
@@ -1113,10 +1133,17 @@ int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* 
     a.rowmask = (const unsigned long long*)rowmask; a.state = state;
     a.nh = nh; a.nkv = nkv; a.max_keys = max_keys; a.nsplit = nsplit;
     a.opart = opart; a.mpart = mpart; a.lpart = lpart;
-    k_tree_attn<<<dim3(nh, nsplit), 256, 0, st>>>(a);
+    if (lk_gemm64r_init() != 0) return -1;
+    k_tree_attn<<<dim3(nh, nsplit), 2 * LA_ATT_PAR * 64, (LA_ATT_PAR / 2) * 2 * 66 * 64 * sizeof(float), st>>>(a);
     LAUNCH_CHECK();
     int total = nh * LA_TB * 16;
-    k_attn_combine<<<(total + 255) / 256, 256, 0, st>>>(opart, mpart, lpart, nh, nsplit, (bf16_t*)attn_xp);
+#define AC(NS) k_attn_combine<NS><<<(total + 255) / 256, 256, 0, st>>>(opart, mpart, lpart, nh, (bf16_t*)attn_xp)
+    switch (nsplit) {
+        case 1: AC(1); break; case 2: AC(2); break; case 3: AC(3); break; case 4: AC(4); break; case 6: AC(6); break;
+        case 8: AC(8); break; case 12: AC(12); break; case 16: AC(16); break;
+        default: return -1;
+    }
+#undef AC
     LAUNCH_CHECK(); return 0;
 }
 int lk_accept_scan(hipStream_t st, const int* ids, const uint64_t* rowmask, int* state) {
