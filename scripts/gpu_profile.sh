@@ -24,8 +24,9 @@ out = 'gpurun_out'
 for f in glob.glob(os.path.join(raw, 'stats', '**', '*kernel_stats*.csv'), recursive=True):
     print('==', f)
     rows = list(csv.DictReader(open(f)))
-    for r in rows[:30]:
-        print(' | '.join(f'{k}={r[k]}' for k in list(r)[:8]))
+    for r in rows:
+        if r['Name'].startswith(('k_', 'void k_')):
+            print(f"{r['Name'][:52]:54s} calls {r['Calls']:>6s} avg {float(r['AverageNs'])/1e3:7.2f} us min {int(r['MinNs'])/1e3:7.2f} max {int(r['MaxNs'])/1e3:7.2f} total {int(r['TotalDurationNs'])/1e6:8.2f} ms")
 # per-kernel mean duration from the trace (ns), steady-state only is not separable here: report all
 for f in glob.glob(os.path.join(raw, 'stats', '**', '*kernel_trace*.csv'), recursive=True):
     agg = collections.defaultdict(lambda: [0, 0])
@@ -46,7 +47,8 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         with open(os.path.join(out, f'pmc_{c}_summary.txt'), 'w') as fo:
             for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 fo.write(f'{k}\t{n}\t{v / n:.1f}\n')
-        for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
-            print(f'{k:70s} n={n:6d} mean={v / n:14.1f}')
+        for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            if k.startswith(('k_', 'void k_')):
+                print(f'{k[:52]:54s} n={n:6d} mean={v / n:14.1f}')
 PY
 du -sh $OUT

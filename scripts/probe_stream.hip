@@ -58,11 +58,12 @@ __global__ __launch_bounds__(NW * 64) void k_probe(const bf16x8* __restrict__ w,
 }
 
 template <int MODE, int D, int NT, int NW>
-void run(const char* name, const bf16x8* w, size_t wbytes, const bf16x8* x, int xtiles, float* out, int nwg, size_t bytes_per_launch) {
+void run(const char* name, const bf16x8* w, size_t wbytes, const bf16x8* x, int xtiles, float* out, int nwg, size_t bytes_per_launch, bool warm = false) {
     int tiles = (int)(bytes_per_launch / ((size_t)nwg * NW * 2048));
     tiles = tiles / D * D;
     size_t per_launch = (size_t)nwg * NW * tiles * 2048;
     int nrot = (int)(wbytes / per_launch); if (nrot < 1) { printf("%s: buffer too small\n", name); return; }
+    if (warm) nrot = 1;
     hipEvent_t a, b; CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
     for (int i = 0; i < 3; ++i) k_probe<MODE, D, NT, NW><<<nwg, NW * 64>>>(w + (size_t)(i % nrot) * per_launch / 16, x, tiles, xtiles, out);
     CHK(hipDeviceSynchronize());
@@ -83,20 +84,12 @@ int main() {
     CHK(hipMalloc(&w, wbytes)); CHK(hipMalloc(&x, 2 << 20)); CHK(hipMalloc(&out, 1 << 22));
     CHK(hipMemset(w, 1, wbytes)); CHK(hipMemset(x, 1, 2 << 20));
     const int xtiles = 256;      // 512 KB of x (K=4096)
-    const size_t B = (size_t)180 << 20;   // ~gate/up sized launch
-    int grids[] = {256, 344, 512, 1024, 2048};
-    for (int nwg : grids) {
-        run<0, 8, 1, 4>("W only, nt, xor", w, wbytes, x, xtiles, out, nwg, B);
-        run<0, 8, 0, 4>("W only, plain loads, xor", w, wbytes, x, xtiles, out, nwg, B);
-        run<1, 8, 1, 4>("W + x(L2), xor", w, wbytes, x, xtiles, out, nwg, B);
-        run<2, 8, 1, 4>("W + x(L2) + MFMA (gemm loop)", w, wbytes, x, xtiles, out, nwg, B);
-        run<3, 8, 1, 4>("W + MFMA, x in regs", w, wbytes, x, xtiles, out, nwg, B);
+    for (size_t mb : {33, 100, 180, 230}) {
+        size_t B = mb << 20;
+        run<2, 8, 1, 4>("gemm loop nt, cold (rotating buffers)", w, wbytes, x, xtiles, out, 256, B);
+        run<2, 8, 1, 4>("gemm loop nt, warm (same buffer)", w, wbytes, x, xtiles, out, 256, B, true);
+        run<2, 8, 0, 4>("gemm loop plain, cold", w, wbytes, x, xtiles, out, 256, B);
+        run<2, 8, 0, 4>("gemm loop plain, warm (same buffer)", w, wbytes, x, xtiles, out, 256, B, true);
     }
-    run<0, 4, 1, 8>("W only, nt, 8 waves D=4", w, wbytes, x, xtiles, out, 256, B);
-    run<0, 4, 1, 8>("W only, nt, 8 waves D=4", w, wbytes, x, xtiles, out, 512, B);
-    run<0, 16, 1, 4>("W only, nt, D=16", w, wbytes, x, xtiles, out, 512, B);
-    run<0, 2, 1, 4>("W only, nt, D=2", w, wbytes, x, xtiles, out, 2048, B);
-    run<0, 8, 1, 4>("W only, nt, small launch 33MB", w, wbytes, x, xtiles, out, 256, (size_t)33 << 20);
-    run<2, 8, 1, 4>("gemm loop, small launch 33MB", w, wbytes, x, xtiles, out, 256, (size_t)33 << 20);
     return 0;
 }

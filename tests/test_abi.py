@@ -52,3 +52,40 @@ def test_device_entry_points_fail_loudly_without_gpu():
     import pytest
     with pytest.raises(RuntimeError):
         LlamaVerifyEngine(None, {}, device='cuda:0')
+
+
+def test_rowplan_covers_every_row_exactly_once():
+    """la_rowplan (host function): balanced packing plans for the Llama-2-7B / 13B shapes and small odd ones."""
+    import numpy as np
+    lib = _lib.lib
+    for kind, n_rows, nwg in [(0, 32000, 256), (1, 11008, 256), (2, 12288, 256), (1, 13824, 256), (2, 15360, 256),
+                              (0, 1000, 8), (1, 688, 16), (2, 5 * 128, 16)]:
+        n = lib.la_rowplan(kind, n_rows, nwg, None)
+        assert n > 0 and n % 32 == 0
+        plan = np.zeros(n, dtype=np.int32)
+        assert lib.la_rowplan(kind, n_rows, nwg, plan.ctypes.data_as(_lib.pi32)) == n
+        valid = plan[plan >= 0]
+        total = n_rows * (2 if kind == 1 else 1)
+        assert sorted(valid.tolist()) == list(range(total))
+        blocks = plan.reshape(-1, 32)
+        # inside a block the valid rows come first (lanes of invalid rows re-read the last valid one)
+        for b in blocks:
+            nv = int((b >= 0).sum())
+            assert nv >= 1 and (b[:nv] >= 0).all() and (b[nv:] < 0).all()
+    # qkv plan: block pairs hold RoPE partners (d, d+64) of the same head slot
+    n = lib.la_rowplan(2, 12288, 256, None)
+    plan = np.zeros(n, dtype=np.int32); lib.la_rowplan(2, 12288, 256, plan.ctypes.data_as(_lib.pi32))
+    b = plan.reshape(256, 2, 32)
+    ok = b[:, 0, :] >= 0
+    assert ((b[:, 1, :] - b[:, 0, :])[ok] == 64).all() and ((b[:, 0, :][ok] % 128) < 64).all()
+    # shapes that cannot be dealt out evenly are refused (the engine then uses the classic grid)
+    assert lib.la_rowplan(1, 11000, 256, None) < 0 and lib.la_rowplan(0, 32000, 7, None) < 0
+
+
+def test_qkv_row_perm_is_a_permutation_of_rope_pairs():
+    import numpy as np
+    perm = np.zeros((4 + 2 * 2) * 128, dtype=np.int32)
+    assert _lib.lib.la_qkv_row_perm(4, 2, perm.ctypes.data_as(_lib.pi32)) == 0
+    assert sorted(perm.tolist()) == list(range(len(perm)))
+    b = perm.reshape(-1, 2, 32)
+    assert ((b[:, 1, :] - b[:, 0, :]) == 64).all()
