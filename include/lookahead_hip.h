@@ -160,11 +160,15 @@ int la_gemm64_qkv(void* stream, const void* d_wp, const void* d_xp, int n_heads,
                   void* d_qf, void* d_kfresh, void* d_vfresh, int variant);
 int la_qkv_row_perm(int n_heads, int n_kv_heads, int32_t* perm /*[(nh+2*nkv)*128], host*/);
 /* Balanced variants: exactly n_wg workgroups (one per CU: n_wg = CU count, 256 on MI355X), each owning
- * R = rows/n_wg rows per matrix as 32-row blocks with a partial last block.  The weight image is packed with
- * la_pack_weight from the matrix gathered by la_rowplan (out[i] = source row of packed row i, -1 = zero pad row;
+ * R = rows/n_wg rows per matrix as 32-row blocks with a partial last block.  The weight image is packed by
+ * la_pack_planned following la_rowplan (out[i] = source row of packed row i, -1 = zero pad row;
  * kind 0 = single matrix (lm_head), 1 = gate/up pair (rows >= n_rows index the second matrix), 2 = qkv RoPE pairs).
  * la_rowplan returns the number of packed rows, or LA_E_RANGE if the shape cannot be balanced this way. */
 int la_rowplan(int kind, int n_rows, int n_wg, int32_t* out /* may be NULL to query */);
+/* Pack for the balanced kernels: workgroup-major, every block stored compactly ([k-tile][half][valid row][8]), output
+ * size = exactly (valid rows) * K elements (no padding).  d_plan = the la_rowplan array copied to the device. */
+int la_pack_planned(void* stream, const void* d_w, const void* d_w2, const int32_t* d_plan, int kind, int n_rows, int K,
+                    int n_wg, void* d_out);
 int la_gemm64r_swiglu(void* stream, const void* d_wp, const void* d_xp, int F, int K, int n_wg, void* d_act_packed);
 int la_gemm64r_logits(void* stream, const void* d_wp, const void* d_xp, int V, int K, int n_wg,
                       void* d_logits_bf16, float* d_cand_val /*[n_wg*8][64]*/, int32_t* d_cand_idx);

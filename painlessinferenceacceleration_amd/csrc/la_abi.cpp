@@ -61,6 +61,12 @@ int la_rowplan(int kind, int n_rows, int n_wg, int32_t* out) {
     int n = lk_rowplan(kind, n_rows, n_wg, out);
     return n < 0 ? LA_E_RANGE : n;
 }
+int la_pack_planned(void* stream, const void* w, const void* w2, const int32_t* d_plan, int kind, int n_rows, int K, int n_wg,
+                    void* out) {
+    if (!w || !d_plan || !out || kind < 0 || kind > 2 || (kind == 1 && !w2) || K % 16 || n_wg <= 0) return LA_E_ARG;
+    if (lk_rowplan(kind, n_rows, n_wg, nullptr) < 0) return LA_E_RANGE;
+    WRAP(lk_pack_planned((hipStream_t)stream, w, w2, d_plan, kind, n_rows, K, n_wg, out));
+}
 int la_gemm64r_swiglu(void* stream, const void* wp, const void* xp, int F, int K, int n_wg, void* act) {
     if (!wp || !xp || !act || K % 16 || n_wg <= 0) return LA_E_ARG;
     if (lk_gemm64r_init() != 0) return LA_E_HIP;

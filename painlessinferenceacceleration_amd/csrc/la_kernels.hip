@@ -28,6 +28,28 @@ __global__ void k_pack_weight(const bf16_t* __restrict__ w, const bf16_t* __rest
     *(bf16x8*)(out + gid * 8) = v;
 }
 
+// Balanced ("planned") packing: workgroup-major, each virtual row-block stored compactly as
+// [k-tile][half][valid row][8 elems] (tile = nv*32 bytes), so a partial block is one contiguous run per k-tile.
+// One thread per 16-byte chunk of the output.
+struct PackPlanArgs { int n_wg, RB, K16, n_rows; int nv[4]; int boff[4]; int wg_chunks; };
+__global__ void k_pack_planned(const bf16_t* __restrict__ w, const bf16_t* __restrict__ w2, const int* __restrict__ plan,
+                               PackPlanArgs pa, bf16_t* __restrict__ out) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)pa.n_wg * pa.wg_chunks) return;
+    const int wgi = (int)(gid / pa.wg_chunks);
+    int c = (int)(gid % pa.wg_chunks);
+    int rb = 0;
+    while (rb + 1 < pa.RB && c >= pa.boff[rb + 1]) ++rb;
+    c -= pa.boff[rb];
+    const int nv = pa.nv[rb];
+    const int kb = c / (2 * nv), rem = c % (2 * nv), h = rem / nv, r = rem % nv;
+    int src = plan[(wgi * pa.RB + rb) * 32 + r];
+    const bf16_t* base = w;
+    if (src >= pa.n_rows) { base = w2; src -= pa.n_rows; }
+    const int K = pa.K16 * 16;
+    *(bf16x8*)(out + gid * 8) = *(const bf16x8*)(base + (size_t)src * K + kb * 16 + h * 8);
+}
+
 __global__ void k_pack_x(const bf16_t* __restrict__ x, int K, bf16_t* __restrict__ out) {
     int gid = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (t, k8)
     int K8 = K >> 3;
@@ -286,6 +308,8 @@ struct GemmRArgs {
     GemmArgs g;
     int R;          // valid rows per matrix per workgroup
     int nv[4];      // valid rows of each virtual block
+    int boff[4];    // 16-byte-chunk offset of each block inside the workgroup's region
+    int wg_chunks;  // 16-byte chunks per workgroup region
 };
 
 template <int RB, int EPI, int D, int NW>
@@ -302,11 +326,14 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
     const int last_valid = cnt - (ngroups - 1) * D;
     const bf16x8* __restrict__ wbase = (const bf16x8*)a.wp;
     const bf16x8* __restrict__ xbase = (const bf16x8*)a.xp;
-    unsigned woff[RB];
+    unsigned woff[RB], wstr[RB];      // per-lane chunk offset of k-tile wb, and chunks per k-tile (2 * valid rows)
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-        const int rr = (lane & 31) < ra.nv[rb] ? (lane & 31) : ra.nv[rb] - 1;
-        woff[rb] = (unsigned)(((nb0 + rb) * a.K16 + wb) * 64 + rr + 32 * (lane >> 5));
+        const int nvb = ra.nv[rb];
+        const int rr = (lane & 31) < nvb ? (lane & 31) : nvb - 1;     // invalid rows re-read the last valid row
+        wstr[rb] = (unsigned)(2 * nvb);
+        woff[rb] = (unsigned)blockIdx.x * (unsigned)ra.wg_chunks + (unsigned)ra.boff[rb] + (unsigned)wb * wstr[rb]
+                   + (unsigned)((lane >> 5) * nvb + rr);
     }
     unsigned xoff = (unsigned)(wb * 128 + lane);
     f32x16 acc[RB][2];
@@ -323,7 +350,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
         for (int d = 0; d < D; ++d) {
             const int dd = d < n1 ? d : 0;
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wbase + woff[rb] + dd * 64);
+            for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wbase + woff[rb] + dd * wstr[rb]);
             fb[d][0] = xbase[xoff + dd * 128];
             fb[d][1] = xbase[xoff + dd * 128 + 64];
         }
@@ -338,7 +365,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
                 }
                 const int dd = (d < nv2 ? g * D + d : 0);
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wbase + woff[rb] + dd * 64);
+                for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wbase + woff[rb] + dd * wstr[rb]);
                 fb[d][0] = xbase[xoff + dd * 128];
                 fb[d][1] = xbase[xoff + dd * 128 + 64];
                 __builtin_amdgcn_sched_barrier(0);
@@ -1011,6 +1038,23 @@ static void fill_nv(GemmRArgs& ra, int R, int blocks_per_matrix, int matrices) {
             int v = R - 32 * b; if (v > 32) v = 32;
             ra.nv[m * blocks_per_matrix + b] = v;
         }
+    int off = 0;
+    for (int i = 0; i < matrices * blocks_per_matrix; ++i) { ra.boff[i] = off; off += ra.nv[i] * 2 * ra.g.K16; }
+    ra.wg_chunks = off;
+}
+// planned packing (see k_pack_planned): kind as lk_rowplan
+int lk_pack_planned(hipStream_t st, const void* w, const void* w2, const int* d_plan, int kind, int n_rows, int K, int n_wg, void* out) {
+    GemmRArgs ra{}; ra.g.K16 = K / 16;
+    PackPlanArgs pa{}; pa.n_wg = n_wg; pa.K16 = K / 16; pa.n_rows = n_rows;
+    if (kind == 2) { const int pairs = n_rows / 2; ra.R = pairs / n_wg; ra.nv[0] = ra.nv[1] = ra.R; pa.RB = 2;
+        ra.boff[0] = 0; ra.boff[1] = ra.R * 2 * ra.g.K16; ra.wg_chunks = 2 * ra.boff[1]; }
+    else if (kind == 1) { ra.R = n_rows / n_wg; fill_nv(ra, ra.R, 2, 2); pa.RB = 4; }
+    else { ra.R = n_rows / n_wg; fill_nv(ra, ra.R, 4, 1); pa.RB = 4; }
+    for (int i = 0; i < 4; ++i) { pa.nv[i] = ra.nv[i]; pa.boff[i] = ra.boff[i]; }
+    pa.wg_chunks = ra.wg_chunks;
+    size_t total = (size_t)n_wg * pa.wg_chunks;
+    k_pack_planned<<<(unsigned)((total + 255) / 256), 256, 0, st>>>((const bf16_t*)w, (const bf16_t*)w2, d_plan, pa, (bf16_t*)out);
+    LAUNCH_CHECK(); return 0;
 }
 int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, int n_wg, void* act_xp) {
     GemmRArgs ra{}; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act_xp;
@@ -1035,6 +1079,7 @@ int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int n
     const int pairs = (nh + 2 * nkv) * 64;
     ra.R = pairs / n_wg; if (pairs % n_wg || ra.R > 32) return -1;
     ra.nv[0] = ra.nv[1] = ra.R;
+    ra.boff[0] = 0; ra.boff[1] = ra.R * 2 * ra.g.K16; ra.wg_chunks = 2 * ra.boff[1];
     k_gemm64r<2, EPI_QKV, 8, 8><<<n_wg, 512, 8 * 2 * 4096, st>>>(ra);
     LAUNCH_CHECK(); return 0;
 }

@@ -146,6 +146,7 @@ class LlamaVerifyEngine(object):
         n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
         self.balanced_wg = [0, 0, 0]
         plans = {}
+        plan_kinds = {}
         if balanced and not (gemm_cfg and len(gemm_cfg) > 1 and gemm_cfg[1] < 0):
             for slot, (kind, n_rows) in enumerate([(2, (shape.n_heads + 2 * shape.n_kv_heads) * hd), (1, shape.ffn),
                                                    (0, shape.vocab)]):
@@ -153,17 +154,21 @@ class LlamaVerifyEngine(object):
                 if n > 0:
                     plan = np.zeros(n, dtype=np.int32)
                     check(min(lib.la_rowplan(kind, n_rows, n_cu, plan.ctypes.data_as(_lib.pi32)), 0), 'rowplan')
-                    plans[slot] = torch.from_numpy(plan.astype(np.int64)).to(self.device)
+                    plans[slot] = torch.from_numpy(plan).to(self.device)
+                    plan_kinds[slot] = (kind, n_rows)
                     self.balanced_wg[slot] = n_cu
 
         def pack_planned(slot, mats):
-            """gather rows by the plan (-1 -> zero row) and pack the padded image"""
-            mats = [m.to(device=self.device, dtype=torch.bfloat16) for m in mats]
-            full = torch.cat(mats + [torch.zeros(1, mats[0].shape[1], dtype=torch.bfloat16, device=self.device)], 0)
-            idx = plans[slot].clone()
-            idx[idx < 0] = full.shape[0] - 1
-            out = pack(full.index_select(0, idx))
-            del full
+            """compact workgroup-major packing by the plan (la_pack_planned)"""
+            kind, n_rows = plan_kinds[slot]
+            mats = [m.to(device=self.device, dtype=torch.bfloat16).contiguous() for m in mats]
+            K = mats[0].shape[1]
+            out = torch.empty(sum(m.shape[0] for m in mats) * K, dtype=torch.bfloat16, device=self.device)
+            torch.cuda.synchronize(self.device)
+            check(lib.la_pack_planned(sp, mats[0].data_ptr(), mats[1].data_ptr() if len(mats) > 1 else None,
+                                      plans[slot].data_ptr(), kind, n_rows, K, n_cu, out.data_ptr()), 'pack_planned')
+            self.stream.synchronize()
+            self._keep.append(out)
             return out
 
         # rows of [Wq;Wk;Wv] are gathered so that each GEMM workgroup owns RoPE pairs (d, d+64): the QKV epilogue

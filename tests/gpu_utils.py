@@ -95,7 +95,11 @@ def pack_planned(kind, mats, n_wg):
     assert n > 0, 'shape cannot be balanced'
     plan = np.zeros(n, dtype=np.int32)
     assert lib.la_rowplan(kind, n_rows, n_wg, plan.ctypes.data_as(_lib.pi32)) == n
-    full = torch.cat(list(mats) + [torch.zeros(1, mats[0].shape[1], dtype=mats[0].dtype, device=mats[0].device)], 0)
-    idx = torch.from_numpy(plan.astype(np.int64)).to(full.device)
-    idx[idx < 0] = full.shape[0] - 1
-    return pack_weight(full.index_select(0, idx).contiguous())
+    d_plan = torch.from_numpy(plan).to(mats[0].device)
+    mats = [m.contiguous() for m in mats]
+    K = mats[0].shape[1]
+    out = torch.empty(sum(m.shape[0] for m in mats) * K, dtype=torch.bfloat16, device=mats[0].device)
+    check(lib.la_pack_planned(sp(), ptr(mats[0]), ptr(mats[1]) if len(mats) > 1 else None, ptr(d_plan), kind, n_rows, K,
+                              n_wg, ptr(out)), 'pack_planned')
+    torch.cuda.synchronize()
+    return out
