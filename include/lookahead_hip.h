@@ -165,8 +165,10 @@ int la_qkv_row_perm(int n_heads, int n_kv_heads, int32_t* perm /*[(nh+2*nkv)*128
  * kind 0 = single matrix (lm_head), 1 = gate/up pair (rows >= n_rows index the second matrix), 2 = qkv RoPE pairs).
  * la_rowplan returns the number of packed rows, or LA_E_RANGE if the shape cannot be balanced this way. */
 int la_rowplan(int kind, int n_rows, int n_wg, int32_t* out /* may be NULL to query */);
-/* Pack for the balanced kernels: workgroup-major, every block stored compactly ([k-tile][half][valid row][8]), output
- * size = exactly (valid rows) * K elements (no padding).  d_plan = the la_rowplan array copied to the device. */
+/* Pack for the balanced kernels: workgroup-major, every block stored compactly as [k-tile][half][stored row][8] where
+ * stored rows = valid rows rounded up to a multiple of 4 (whole 128-byte lines per tile); la_planned_elems gives the
+ * bf16 element count of the image.  d_plan = the la_rowplan array copied to the device. */
+int64_t la_planned_elems(int kind, int n_rows, int K, int n_wg);
 int la_pack_planned(void* stream, const void* d_w, const void* d_w2, const int32_t* d_plan, int kind, int n_rows, int K,
                     int n_wg, void* d_out);
 int la_gemm64r_swiglu(void* stream, const void* d_wp, const void* d_xp, int F, int K, int n_wg, void* d_act_packed);

@@ -114,6 +114,7 @@ PROTOTYPES = {
     "la_gemm64_qkv": (i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32),
     "la_qkv_row_perm": (i32, i32, i32, pi32),
     "la_rowplan": (i32, i32, i32, i32, pi32),
+    "la_planned_elems": (i64, i32, i32, i32, i32),
     "la_pack_planned": (i32, vp, vp, vp, vp, i32, i32, i32, i32, vp),
     "la_gemm64r_swiglu": (i32, vp, vp, vp, i32, i32, i32, vp),
     "la_gemm64r_logits": (i32, vp, vp, vp, i32, i32, i32, vp, vp, vp),

@@ -61,6 +61,10 @@ int la_rowplan(int kind, int n_rows, int n_wg, int32_t* out) {
     int n = lk_rowplan(kind, n_rows, n_wg, out);
     return n < 0 ? LA_E_RANGE : n;
 }
+int64_t la_planned_elems(int kind, int n_rows, int K, int n_wg) {
+    if (kind < 0 || kind > 2 || K % 16 || n_wg <= 0 || lk_rowplan(kind, n_rows, n_wg, nullptr) < 0) return LA_E_RANGE;
+    return (int64_t)lk_planned_elems(kind, n_rows, K, n_wg);
+}
 int la_pack_planned(void* stream, const void* w, const void* w2, const int32_t* d_plan, int kind, int n_rows, int K, int n_wg,
                     void* out) {
     if (!w || !d_plan || !out || kind < 0 || kind > 2 || (kind == 1 && !w2) || K % 16 || n_wg <= 0) return LA_E_ARG;

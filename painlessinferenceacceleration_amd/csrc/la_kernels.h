@@ -16,6 +16,7 @@ int lk_gemm64_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int nk
 void lk_qkv_row_perm(int nh, int nkv, int* perm);
 int lk_gemm64r_init();
 int lk_rowplan(int kind, int n_rows, int n_wg, int* out);
+long lk_planned_elems(int kind, int n_rows, int K, int n_wg);
 int lk_pack_planned(hipStream_t st, const void* w, const void* w2, const int* d_plan, int kind, int n_rows, int K, int n_wg, void* out);
 int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, int n_wg, void* act_xp);
 int lk_gemm64r_logits(hipStream_t st, const void* wp, const void* xp, int V, int K, int n_wg, void* logits, float* cv, int* ci);

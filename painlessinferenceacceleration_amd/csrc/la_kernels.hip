@@ -31,7 +31,7 @@ __global__ void k_pack_weight(const bf16_t* __restrict__ w, const bf16_t* __rest
 // Balanced ("planned") packing: workgroup-major, each virtual row-block stored compactly as
 // [k-tile][half][valid row][8 elems] (tile = nv*32 bytes), so a partial block is one contiguous run per k-tile.
 // One thread per 16-byte chunk of the output.
-struct PackPlanArgs { int n_wg, RB, K16, n_rows; int nv[4]; int boff[4]; int wg_chunks; };
+struct PackPlanArgs { int n_wg, RB, K16, n_rows; int nv[4]; int boff[4]; int wg_chunks; };   // nv = stored rows (multiple of 4)
 __global__ void k_pack_planned(const bf16_t* __restrict__ w, const bf16_t* __restrict__ w2, const int* __restrict__ plan,
                                PackPlanArgs pa, bf16_t* __restrict__ out) {
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -47,7 +47,9 @@ __global__ void k_pack_planned(const bf16_t* __restrict__ w, const bf16_t* __res
     const bf16_t* base = w;
     if (src >= pa.n_rows) { base = w2; src -= pa.n_rows; }
     const int K = pa.K16 * 16;
-    *(bf16x8*)(out + gid * 8) = *(const bf16x8*)(base + (size_t)src * K + kb * 16 + h * 8);
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (src >= 0) v = *(const bf16x8*)(base + (size_t)src * K + kb * 16 + h * 8);      // -1 = alignment pad row
+    *(bf16x8*)(out + gid * 8) = v;
 }
 
 __global__ void k_pack_x(const bf16_t* __restrict__ x, int K, bf16_t* __restrict__ out) {
@@ -307,7 +309,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
 struct GemmRArgs {
     GemmArgs g;
     int R;          // valid rows per matrix per workgroup
-    int nv[4];      // valid rows of each virtual block
+    int nv[4];      // valid rows of each virtual block (epilogue mask)
+    int nvl[4];     // stored rows = nv rounded up to a multiple of 4, so that a tile is a whole number of 128-B lines
     int boff[4];    // 16-byte-chunk offset of each block inside the workgroup's region
     int wg_chunks;  // 16-byte chunks per workgroup region
 };
@@ -329,8 +332,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
     unsigned woff[RB], wstr[RB];      // per-lane chunk offset of k-tile wb, and chunks per k-tile (2 * valid rows)
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-        const int nvb = ra.nv[rb];
-        const int rr = (lane & 31) < nvb ? (lane & 31) : nvb - 1;     // invalid rows re-read the last valid row
+        const int nvb = ra.nvl[rb];
+        const int rr = (lane & 31) < nvb ? (lane & 31) : nvb - 1;     // rows past the stored ones re-read the last one
         wstr[rb] = (unsigned)(2 * nvb);
         woff[rb] = (unsigned)blockIdx.x * (unsigned)ra.wg_chunks + (unsigned)ra.boff[rb] + (unsigned)wb * wstr[rb]
                    + (unsigned)((lane >> 5) * nvb + rr);
@@ -1039,18 +1042,30 @@ static void fill_nv(GemmRArgs& ra, int R, int blocks_per_matrix, int matrices) {
             ra.nv[m * blocks_per_matrix + b] = v;
         }
     int off = 0;
-    for (int i = 0; i < matrices * blocks_per_matrix; ++i) { ra.boff[i] = off; off += ra.nv[i] * 2 * ra.g.K16; }
+    for (int i = 0; i < matrices * blocks_per_matrix; ++i) {
+        ra.nvl[i] = (ra.nv[i] + 3) & ~3;
+        ra.boff[i] = off; off += ra.nvl[i] * 2 * ra.g.K16;
+    }
     ra.wg_chunks = off;
+}
+// elements of the planned image (stored rows x K)
+long lk_planned_elems(int kind, int n_rows, int K, int n_wg) {
+    GemmRArgs ra{}; ra.g.K16 = K / 16;
+    if (kind == 2) { const int R = (n_rows / 2) / n_wg; return (long)n_wg * 2 * ((R + 3) & ~3) * K; }
+    if (kind == 1) { ra.R = n_rows / n_wg; fill_nv(ra, ra.R, 2, 2); }
+    else { ra.R = n_rows / n_wg; fill_nv(ra, ra.R, 4, 1); }
+    return (long)n_wg * ra.wg_chunks * 8;
 }
 // planned packing (see k_pack_planned): kind as lk_rowplan
 int lk_pack_planned(hipStream_t st, const void* w, const void* w2, const int* d_plan, int kind, int n_rows, int K, int n_wg, void* out) {
     GemmRArgs ra{}; ra.g.K16 = K / 16;
     PackPlanArgs pa{}; pa.n_wg = n_wg; pa.K16 = K / 16; pa.n_rows = n_rows;
     if (kind == 2) { const int pairs = n_rows / 2; ra.R = pairs / n_wg; ra.nv[0] = ra.nv[1] = ra.R; pa.RB = 2;
-        ra.boff[0] = 0; ra.boff[1] = ra.R * 2 * ra.g.K16; ra.wg_chunks = 2 * ra.boff[1]; }
+        ra.nvl[0] = ra.nvl[1] = (ra.R + 3) & ~3;
+        ra.boff[0] = 0; ra.boff[1] = ra.nvl[0] * 2 * ra.g.K16; ra.wg_chunks = 2 * ra.boff[1]; }
     else if (kind == 1) { ra.R = n_rows / n_wg; fill_nv(ra, ra.R, 2, 2); pa.RB = 4; }
     else { ra.R = n_rows / n_wg; fill_nv(ra, ra.R, 4, 1); pa.RB = 4; }
-    for (int i = 0; i < 4; ++i) { pa.nv[i] = ra.nv[i]; pa.boff[i] = ra.boff[i]; }
+    for (int i = 0; i < 4; ++i) { pa.nv[i] = ra.nvl[i]; pa.boff[i] = ra.boff[i]; }
     pa.wg_chunks = ra.wg_chunks;
     size_t total = (size_t)n_wg * pa.wg_chunks;
     k_pack_planned<<<(unsigned)((total + 255) / 256), 256, 0, st>>>((const bf16_t*)w, (const bf16_t*)w2, d_plan, pa, (bf16_t*)out);
@@ -1079,7 +1094,8 @@ int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int n
     const int pairs = (nh + 2 * nkv) * 64;
     ra.R = pairs / n_wg; if (pairs % n_wg || ra.R > 32) return -1;
     ra.nv[0] = ra.nv[1] = ra.R;
-    ra.boff[0] = 0; ra.boff[1] = ra.R * 2 * ra.g.K16; ra.wg_chunks = 2 * ra.boff[1];
+    ra.nvl[0] = ra.nvl[1] = (ra.R + 3) & ~3;
+    ra.boff[0] = 0; ra.boff[1] = ra.nvl[0] * 2 * ra.g.K16; ra.wg_chunks = 2 * ra.boff[1];
     k_gemm64r<2, EPI_QKV, 8, 8><<<n_wg, 512, 8 * 2 * 4096, st>>>(ra);
     LAUNCH_CHECK(); return 0;
 }

@@ -163,7 +163,7 @@ class LlamaVerifyEngine(object):
             kind, n_rows = plan_kinds[slot]
             mats = [m.to(device=self.device, dtype=torch.bfloat16).contiguous() for m in mats]
             K = mats[0].shape[1]
-            out = torch.empty(sum(m.shape[0] for m in mats) * K, dtype=torch.bfloat16, device=self.device)
+            out = torch.empty(lib.la_planned_elems(kind, n_rows, K, n_cu), dtype=torch.bfloat16, device=self.device)
             torch.cuda.synchronize(self.device)
             check(lib.la_pack_planned(sp, mats[0].data_ptr(), mats[1].data_ptr() if len(mats) > 1 else None,
                                       plans[slot].data_ptr(), kind, n_rows, K, n_cu, out.data_ptr()), 'pack_planned')

@@ -98,7 +98,7 @@ def pack_planned(kind, mats, n_wg):
     d_plan = torch.from_numpy(plan).to(mats[0].device)
     mats = [m.contiguous() for m in mats]
     K = mats[0].shape[1]
-    out = torch.empty(sum(m.shape[0] for m in mats) * K, dtype=torch.bfloat16, device=mats[0].device)
+    out = torch.empty(lib.la_planned_elems(kind, n_rows, K, n_wg), dtype=torch.bfloat16, device=mats[0].device)
     check(lib.la_pack_planned(sp(), ptr(mats[0]), ptr(mats[1]) if len(mats) > 1 else None, ptr(d_plan), kind, n_rows, K,
                               n_wg, ptr(out)), 'pack_planned')
     torch.cuda.synchronize()
