@@ -239,7 +239,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (gate/up GEMM, k_gemm64<2,SWIGLU>) from live HIP events -------------
+    # ---- roofline of the dominant kernel (gate/up GEMM, k_gemm64r<4,SWIGLU,4,8>) from live HIP events ---------
     ctx = eng.n_keys
     ids, rowmask, _, _ = cache.hier_get_packed(seq[-2:], decoding_length=DL, branch_length=BL, min_output_size=DL // 2)
     T_prof = len(ids)
@@ -251,7 +251,7 @@ def main():
     step_bytes = algorithmic_bytes(shape, 64, ctx, 64 * shape.vocab * 2)
     gemm_ms = sum(prof['ms'][k] for k in ('qkv', 'o', 'gateup', 'down', 'lm_head'))
     roofline = {
-        'bound': 'hbm', 'kernel': 'k_gemm64<RB=2,EPI_SWIGLU> (gate/up projection, 32 launches/step)',
+        'bound': 'hbm', 'kernel': 'k_gemm64r<4,EPI_SWIGLU,4,8> (gate/up projection + fused SwiGLU, 32 launches/step)',
         'achieved': round(gu_bytes / (gu_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(gu_bytes / (gu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': None,
         'bytes_per_launch': gu_bytes, 'ms_per_launch': round(gu_ms, 5),
@@ -264,7 +264,7 @@ def main():
     }
     mean_acc = float(np.mean(edls[n0:]))
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed on rank 0 at N=1 only
         cpu = cpu_baseline(shape, 64, ctx, mean_acc)
     out = {
         'metric': 'accepted_tokens_per_sec', 'value': round(accepted_all / elapsed, 2), 'unit': 'tokens/s',
