@@ -250,10 +250,17 @@ def main():
     mean_T = float(np.mean(dls[n0:]))
     step_bytes = algorithmic_bytes(shape, 64, ctx, 64 * shape.vocab * 2)
     gemm_ms = sum(prof['ms'][k] for k in ('qkv', 'o', 'gateup', 'down', 'lm_head'))
+    traffic, traffic_src = None, None
+    try:        # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py)
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')))
+        traffic = pmc['kernels']['void k_gemm64r<4, 1, 4, 8>(GemmRArgs)']['hbm_bytes_per_launch']
+        traffic_src = pmc['source']
+    except Exception:
+        pass
     roofline = {
         'bound': 'hbm', 'kernel': 'k_gemm64r<4,EPI_SWIGLU,4,8> (gate/up projection + fused SwiGLU, 32 launches/step)',
         'achieved': round(gu_bytes / (gu_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-        'frac': round(gu_bytes / (gu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': None,
+        'frac': round(gu_bytes / (gu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
         'bytes_per_launch': gu_bytes, 'ms_per_launch': round(gu_ms, 5),
         'verify_step': {'algorithmic_bytes': step_bytes, 'ms_graph_step': round(ms_step, 4),
                         'achieved_GBps': round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
