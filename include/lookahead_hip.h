@@ -95,6 +95,20 @@ int la_cache_tree_counters(la_cache* c, int32_t token, int64_t* n_node, int64_t*
 int la_cache_save(la_cache* c, const char* path);
 int la_cache_load(la_cache* c, const char* path);
 
+/* Device-side retrieval.  la_cache_export snapshots the forest for one input slot `idx` into host arrays (call with
+ * cap = 0 to get *n_nodes): live nodes renumbered breadth-first, children of node u = ids [cstart[u], cstart[u]+ccount[u])
+ * in dict insertion order, node 0 = super-root over the per-token trees.  la_trie_hier_get_dev runs hier_get
+ * (lookahead_cache.py:408-439, Tree.get :65-144) for B queries on that mirror, one wavefront per query (ballot prefix
+ * match, wave-parallel live-subtree scan, radix-select cut-offs, ordered DFS); results are bit-identical to
+ * la_cache_hier_get.  Queries are rows of 8 int32 (first nq[b] used).  Scratch: int32[B][n_nodes], double[B][2][n_nodes]. */
+int la_cache_export(la_cache* c, int idx, int32_t cap, int32_t* tok, double* fo, double* fi, int32_t* cstart,
+                    int32_t* ccount, int32_t* n_nodes);
+int la_trie_hier_get_dev(void* stream, const int32_t* d_tok, const double* d_fo, const double* d_fi, const int32_t* d_cstart,
+                         const int32_t* d_ccount, int n_nodes, const int32_t* d_queries, const int32_t* d_nq, int B,
+                         int decoding_length, int branch_length, int min_input_size, int min_output_size, int mode,
+                         const int32_t* d_stop, int n_stop, int32_t* d_scratch_q, double* d_scratch_v, int32_t* d_out_ids,
+                         uint64_t* d_out_rowmask, int32_t* d_out_n, int32_t* d_out_sizes /*[B][2]*/, int32_t* d_out_nsizes);
+
 /* ------------------------------------------------------------------------
  * 2. Step kernels (device).  Each is also reachable through la_llama_step;
  *    exported singly for unit parity tests.

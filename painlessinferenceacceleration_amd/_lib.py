@@ -104,6 +104,8 @@ PROTOTYPES = {
     "la_cache_tree_counters": (i32, vp, i32, pi64, pi64),
     "la_cache_save": (i32, vp, C.c_char_p),
     "la_cache_load": (i32, vp, C.c_char_p),
+    "la_cache_export": (i32, vp, i32, i32, pi32, C.POINTER(C.c_double), C.POINTER(C.c_double), pi32, pi32, pi32),
+    "la_trie_hier_get_dev": (i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp),
     "la_build_tree_inputs": (i32, vp, vp, vp, vp, vp, vp),
     "la_accept_scan": (i32, vp, vp, vp, vp),
     "la_kv_commit": (i32, vp, vp, vp, vp, vp, vp, i32, i32, i32),

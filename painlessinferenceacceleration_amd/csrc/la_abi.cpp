@@ -120,4 +120,18 @@ int la_tree_attn(void* stream, const void* qf, const void* km, const void* vm, c
                       mpart, lpart, attn_xp));
 }
 
+int la_trie_hier_get_dev(void* stream, const int32_t* d_tok, const double* d_fo, const double* d_fi, const int32_t* d_cstart,
+                         const int32_t* d_ccount, int n_nodes, const int32_t* d_queries, const int32_t* d_nq, int B,
+                         int decoding_length, int branch_length, int min_input_size, int min_output_size, int mode,
+                         const int32_t* d_stop, int n_stop, int32_t* d_scratch_q, double* d_scratch_v, int32_t* d_out_ids,
+                         uint64_t* d_out_rowmask, int32_t* d_out_n, int32_t* d_out_sizes, int32_t* d_out_nsizes) {
+    if (!d_tok || !d_fo || !d_fi || !d_cstart || !d_ccount || n_nodes < 1 || !d_queries || !d_nq || B < 1 ||
+        !d_scratch_q || !d_scratch_v || !d_out_ids || !d_out_rowmask || !d_out_n || !d_out_sizes || !d_out_nsizes ||
+        mode < 0 || mode > 2 || (n_stop > 0 && !d_stop)) return LA_E_ARG;
+    if (decoding_length > LA_TREE_MAX) { la_set_error("device hier_get handles decoding_length <= 64"); return LA_E_RANGE; }
+    WRAP(lk_trie_hier_get((hipStream_t)stream, d_tok, d_fo, d_fi, d_cstart, d_ccount, n_nodes, d_queries, d_nq, B,
+                          decoding_length, branch_length, min_input_size, min_output_size, mode, d_stop, n_stop,
+                          d_scratch_q, d_scratch_v, d_out_ids, d_out_rowmask, d_out_n, d_out_sizes, d_out_nsizes));
+}
+
 }  // extern "C"

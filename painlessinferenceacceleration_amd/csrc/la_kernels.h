@@ -34,3 +34,7 @@ int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* 
 int lk_accept_scan(hipStream_t st, const int* ids, const uint64_t* rowmask, int* state);
 int lk_kv_commit(hipStream_t st, const void* kfresh, const void* vfresh, void* kmain, void* vmain, const int* state,
                  int n_layers, int nkv, int max_keys);
+int lk_trie_hier_get(hipStream_t st, const int* tok, const double* fo, const double* fi, const int* cstart, const int* ccount,
+                     int n_nodes, const int* queries, const int* nq, int B, int decoding_length, int branch_length,
+                     int min_in, int min_out, int mode, const int* stop, int n_stop, int* scratch_q, double* scratch_v,
+                     int* out_ids, uint64_t* out_rowmask, int* out_n, int* out_sizes, int* out_nsizes);

@@ -568,6 +568,38 @@ int la_cache_tree_counters(la_cache* c, int32_t token, int64_t* n_node, int64_t*
     return LA_OK;
 }
 
+// ---- device mirror export (for la_trie_hier_get_dev): live nodes renumbered breadth-first so that the children of
+//      a node are consecutive ids in insertion order; node 0 is a super-root whose children are the tree roots.
+int la_cache_export(la_cache* c, int idx, int32_t cap, int32_t* tok, double* fo, double* fi, int32_t* cstart,
+                    int32_t* ccount, int32_t* n_nodes) {
+    if (!c || !n_nodes) return LA_E_ARG;
+    // count: super root + one root per tree + live arena nodes below them
+    int64_t total = 1 + (int64_t)c->mem.size() + c->live_nodes;
+    *n_nodes = (int32_t)total;
+    if (cap == 0) return LA_OK;
+    if (cap < total || !tok || !fo || !fi || !cstart || !ccount) return LA_E_RANGE;
+    std::vector<int32_t> order;           // arena node id per exported id (>= 1)
+    order.reserve((size_t)total);
+    order.push_back(-1);                  // super root
+    // tree roots in a deterministic order (by token); lookups are by token, so the order is free
+    std::vector<std::pair<int32_t, int32_t>> roots;
+    for (auto& kv : c->mem) roots.push_back({kv.first, c->trees[kv.second].root});
+    std::sort(roots.begin(), roots.end());
+    tok[0] = -1; fo[0] = 0; fi[0] = 0; cstart[0] = 1; ccount[0] = (int32_t)roots.size();
+    for (auto& r : roots) order.push_back(r.second);
+    for (size_t i = 1; i < order.size(); ++i) {
+        const Node& nd = c->nodes[order[i]];
+        tok[i] = nd.token; fo[i] = nd.fo; fi[i] = la_cache::get_fi(nd, idx);
+        cstart[i] = (int32_t)order.size();
+        int32_t cnt = 0;
+        for (int32_t ch = nd.first_child; ch >= 0; ch = c->nodes[ch].next_sib) { order.push_back(ch); ++cnt; }
+        ccount[i] = cnt;
+        if ((int64_t)order.size() > total) return LA_E_STATE;
+    }
+    *n_nodes = (int32_t)order.size();
+    return LA_OK;
+}
+
 // ---- persistence: "LATRIE01" | n_trees | per tree {token, max_node, max_output_node, n_node, n_output_node,
 //      n_rec} | per record (pre-order, insertion order) {token, depth, fo, n_fi, (idx, f)*}
 int la_cache_save(la_cache* c, const char* path) {

@@ -1,0 +1,256 @@
+// la_trie_dev.hip — device-side trie retrieval: LookaheadCache.hier_get (lookahead_cache.py:408-439) with
+// Tree.get/_match/_dfs_get_freqs/_ravel (:65-154, 224-293) as ONE WAVEFRONT PER QUERY over a mirrored arena
+// (la_cache_export: breadth-first ids, children of a node = consecutive ids in dict insertion order).
+//   prefix match      : 64 children compared per step, __ballot picks the hit            (:224-246)
+//   live-subtree scan : wave-parallel frontier expansion, ballot prefix sums as queue     (:146-154)
+//   cut-offs          : radix select of the k-th largest fi / fo (bit patterns of non-negative doubles)  (:78-125)
+//   ordered DFS       : "next child in stable (fm desc, insertion asc) order" by a wave arg-max over the sibling
+//                       range, explicit stack (depth <= branch_length), <= 64 emitted rows with 64-bit row masks  (:248-293)
+// Bit-exact to the host trie / the reference: fm uses separately rounded fp64 multiplies and add (no FMA contraction).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "la_kernels.h"
+
+struct TrieDev {
+    const int* tok; const double* fo; const double* fi; const int* cstart; const int* ccount; int n_nodes;
+};
+struct TrieQueryArgs {
+    TrieDev t;
+    const int* queries;   // [B][8]
+    const int* nq;        // [B]
+    int decoding_length, branch_length, min_in, min_out, mode;
+    const int* stop; int n_stop;
+    int* scratch_q;       // [B][n_nodes]
+    double* scratch_v;    // [B][2][n_nodes]
+    int* out_ids;         // [B][64]
+    unsigned long long* out_rowmask;   // [B][64]
+    int* out_n;           // [B]
+    int* out_sizes;       // [B][2]
+    int* out_nsizes;      // [B]
+};
+
+#define TBIG 1e9
+
+__device__ __forceinline__ int wave_first(unsigned long long m) { return m ? __ffsll((long long)m) - 1 : -1; }
+
+// child of node u with token t, or -1 (wave-uniform result)
+__device__ int find_child(const TrieDev& t, int u, int token, int lane) {
+    const int cs = t.cstart[u], cc = t.ccount[u];
+    for (int base = 0; base < cc; base += 64) {
+        const int i = base + lane;
+        const bool hit = i < cc && t.tok[cs + i] == token;
+        const unsigned long long m = __ballot(hit);
+        if (m) return cs + wave_first(m);
+    }
+    return -1;
+}
+
+// value at position r (0-based) of the DESCENDING sort of vals[0..n) (all >= 0): radix select on the bit patterns
+__device__ double select_desc(const double* vals, int n, int r, int lane, unsigned* hist /*LDS[256]*/) {
+    unsigned long long prefix = 0ull, mask = 0ull;
+    int rank = r;
+    for (int byte = 7; byte >= 0; --byte) {
+        for (int i = lane; i < 256; i += 64) hist[i] = 0u;
+        __syncthreads();
+        const int sh = byte * 8;
+        for (int i = lane; i < n; i += 64) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(vals[i]);
+            if ((b & mask) == prefix) atomicAdd(&hist[(unsigned)((b >> sh) & 0xffull)], 1u);
+        }
+        __syncthreads();
+        // walk bins from high to low: find the bin in which the rank falls (done by every lane identically)
+        int bin = 255;
+        int acc = 0;
+        for (; bin > 0; --bin) {
+            const int cnt = (int)hist[bin];
+            if (acc + cnt > rank) break;
+            acc += cnt;
+        }
+        rank -= acc;
+        prefix |= (unsigned long long)bin << sh;
+        mask |= 0xffull << sh;
+        __syncthreads();
+    }
+    return __longlong_as_double((long long)prefix);
+}
+
+__global__ __launch_bounds__(64) void k_trie_hier_get(TrieQueryArgs a) {
+    __shared__ unsigned hist[256];
+    __shared__ int st_node[72], st_pos[72], st_pid[72], st_depth[72];
+    __shared__ double st_fm[72];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const TrieDev& t = a.t;
+    const int* q = a.queries + b * 8;
+    const int nq = a.nq[b];
+    int* oid = a.out_ids + b * 64;
+    unsigned long long* orm = a.out_rowmask + b * 64;
+    int* queue = a.scratch_q + (size_t)b * t.n_nodes;
+    double* vfi = a.scratch_v + (size_t)b * 2 * t.n_nodes;
+    double* vfo = vfi + t.n_nodes;
+    const int max_size = a.decoding_length, max_length = a.branch_length, mode = a.mode;
+
+    auto finish = [&](int n, int s0, int s1, int nsizes) {
+        if (lane == 0) { a.out_n[b] = n; a.out_sizes[b * 2] = s0; a.out_sizes[b * 2 + 1] = s1; a.out_nsizes[b] = nsizes; }
+    };
+    if (a.decoding_length <= 1 || a.branch_length == 0) {                     // :413-414
+        if (nq > 0 && lane == 0) { oid[0] = q[nq - 1]; orm[0] = 1ull; }
+        finish(nq > 0 ? 1 : 0, 0, 0, 0);
+        return;
+    }
+    bool have = false;
+    int n_out = 0, sz0 = 0, sz1 = 0;
+    for (int i = 0; i < nq; ++i) {
+        const int root = find_child(t, 0, q[i], lane);
+        if (root < 0) continue;
+        const int nrest = nq - (i + 1);
+        bool is_stop = false;
+        for (int k = 0; k < a.n_stop; ++k) is_stop |= (a.stop[k] == q[i]);
+        if (is_stop && nrest == 0) continue;                                  // :422-423
+        have = true;
+        // ---- Tree._match
+        int cur = root;
+        for (int k = 0; k < nrest && cur >= 0; ++k) {
+            const int ch = find_child(t, cur, q[i + 1 + k], lane);
+            if (ch < 0) { cur = -1; break; }
+            const double cfi = t.fi[ch], cfo = t.fo[ch];
+            const bool live = mode == LA_MODE_INPUT ? cfi > 0 : mode == LA_MODE_OUTPUT ? cfo > 0 : (cfi > 0 || cfo > 0);
+            cur = live ? ch : -1;
+        }
+        sz0 = sz1 = 0;
+        if (cur < 0 || t.ccount[cur] == 0) {                                  // :70-72
+            if (lane == 0) { oid[0] = nrest > 0 ? q[nq - 1] : t.tok[root]; orm[0] = 1ull; }
+            n_out = 1;
+        } else {
+            // ---- _dfs_get_freqs: rows of live nodes reachable through live nodes
+            int head = 0, tail = 0;
+            {   // seed with the live children of cur
+                const int cs = t.cstart[cur], cc = t.ccount[cur];
+                for (int base = 0; base < cc; base += 64) {
+                    const int c = cs + base + lane;
+                    const bool lv = base + lane < cc && (t.fo[c] > 0 || t.fi[c] > 0);
+                    const unsigned long long m = __ballot(lv);
+                    if (lv) queue[tail + __popcll(m & ((1ull << lane) - 1ull))] = c;
+                    tail += __popcll(m);
+                }
+                __threadfence_block();      // queue entries written by other lanes are read below
+            }
+            while (head < tail) {
+                const int v = head + lane < tail ? queue[head + lane] : -1;
+                int cs = 0, cc = 0;
+                if (v >= 0) { vfi[head + lane] = t.fi[v]; vfo[head + lane] = t.fo[v]; cs = t.cstart[v]; cc = t.ccount[v]; }
+                int mx = cc;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+                const int nproc = min(64, tail - head);
+                head += nproc;
+                for (int k = 0; k < mx; ++k) {
+                    const int c = cs + k;
+                    const bool lv = k < cc && (t.fo[c] > 0 || t.fi[c] > 0);
+                    const unsigned long long m = __ballot(lv);
+                    if (lv) queue[tail + __popcll(m & ((1ull << lane) - 1ull))] = c;
+                    tail += __popcll(m);
+                }
+                __threadfence_block();
+            }
+            const int rows = tail;
+            __threadfence_block();
+            __syncthreads();                                                  // vfi/vfo complete (single wave: ordering only)
+            double w = 1e-4, lo_in = TBIG, lo_out = TBIG, lo_mix = TBIG;
+            if (mode == LA_MODE_INPUT) {
+                w = 0.0;
+                int cnt = 0;
+                for (int k = lane; k < rows; k += 64) cnt += vfi[k] > 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+                lo_in = cnt > max_size ? select_desc(vfi, rows, a.min_in <= 0 ? rows - 1 : min(a.min_in - 1, rows - 1), lane, hist) : 0.0;
+            } else if (mode == LA_MODE_OUTPUT) {
+                w = 1.0;
+                int cnt = 0;
+                for (int k = lane; k < rows; k += 64) cnt += vfo[k] > 0;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+                lo_out = cnt > max_size ? select_desc(vfo, rows, a.min_out <= 0 ? rows - 1 : min(a.min_out - 1, rows - 1), lane, hist) : 0.0;
+            } else if (rows > max_size) {
+                // rows carry None as their index (:152): the mix cut-off loop never fires, lo_mix stays 1e9
+                if (a.min_in > 0) lo_in = select_desc(vfi, rows, min(a.min_in - 1, rows - 1), lane, hist);
+                if (a.min_out > 0) lo_out = select_desc(vfo, rows, min(a.min_out - 1, rows - 1), lane, hist);
+            } else {
+                lo_mix = 0.0;
+            }
+            const double w1 = 1.0 - w;
+            // ---- _ravel
+            const int last_tok = nrest > 0 ? q[nq - 1] : 0;
+            if (lane == 0) { oid[0] = (nrest > 0 && last_tok != 0) ? last_tok : t.tok[root]; orm[0] = 1ull; }   // :129
+            int n = 1, sp = 0;
+            if (lane == 0) { st_node[0] = cur; st_fm[0] = 1e308; st_pos[0] = -1; st_pid[0] = -1; st_depth[0] = max_length; }
+            __syncthreads();
+            sp = 1;
+            while (sp > 0 && n < max_size) {
+                const int u = st_node[sp - 1], pid = st_pid[sp - 1], depth = st_depth[sp - 1];
+                const double cfm = st_fm[sp - 1];
+                const int cpos = st_pos[sp - 1];
+                const int cs = t.cstart[u], cc = t.ccount[u];
+                // next child after the cursor in (fm desc, position asc) order
+                double bfm = -1.0; int bpos = 0x7fffffff;
+                for (int k = lane; k < cc; k += 64) {
+                    const int c = cs + k;
+                    const double fm = __dadd_rn(__dmul_rn(w1, t.fi[c]), __dmul_rn(w, t.fo[c]));      // :254, no FMA
+                    const bool after = fm < cfm || (fm == cfm && k > cpos);
+                    if (after && (fm > bfm || (fm == bfm && k < bpos))) { bfm = fm; bpos = k; }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double ofm = __shfl_xor(bfm, o, 64);
+                    const int op = __shfl_xor(bpos, o, 64);
+                    if (ofm > bfm || (ofm == bfm && op < bpos)) { bfm = ofm; bpos = op; }
+                }
+                __syncthreads();
+                if (bpos == 0x7fffffff) { --sp; continue; }                   // children exhausted
+                if (lane == 0) { st_fm[sp - 1] = bfm; st_pos[sp - 1] = bpos; }
+                const int c = cs + bpos;
+                const double cfi = t.fi[c], cfo = t.fo[c];
+                bool skip;
+                if (mode == LA_MODE_MIX) skip = cfi < lo_in && cfo < lo_out && bfm < lo_mix;            // :265
+                else if (mode == LA_MODE_INPUT) skip = cfi < lo_in;
+                else skip = cfo < lo_out;
+                if (!skip) {
+                    if (cfi > 0.0) ++sz0;
+                    if (cfo > 0.0) ++sz1;
+                    const int rid = n++;
+                    if (lane == 0) {
+                        oid[rid] = t.tok[c];
+                        orm[rid] = (pid > -1 ? orm[pid] : 1ull) | (1ull << rid);
+                    }
+                    if (t.ccount[c] > 0 && depth - 1 > 0 && n < max_size) {
+                        if (lane == 0) { st_node[sp] = c; st_fm[sp] = 1e308; st_pos[sp] = -1; st_pid[sp] = rid; st_depth[sp] = depth - 1; }
+                        ++sp;
+                    }
+                }
+                __syncthreads();
+            }
+            n_out = n;
+        }
+        if (n_out >= a.branch_length) break;                                  // :433-434 (else a later suffix overwrites)
+    }
+    if (!have) {                                                              // :436-437
+        if (nq > 0 && lane == 0) { oid[0] = q[nq - 1]; orm[0] = 1ull; }
+        finish(nq > 0 ? 1 : 0, 0, 0, 2);
+        return;
+    }
+    finish(n_out, sz0, sz1, 2);
+}
+
+int lk_trie_hier_get(hipStream_t st, const int* tok, const double* fo, const double* fi, const int* cstart, const int* ccount,
+                     int n_nodes, const int* queries, const int* nq, int B, int decoding_length, int branch_length,
+                     int min_in, int min_out, int mode, const int* stop, int n_stop, int* scratch_q, double* scratch_v,
+                     int* out_ids, uint64_t* out_rowmask, int* out_n, int* out_sizes, int* out_nsizes) {
+    TrieQueryArgs a{};
+    a.t = TrieDev{tok, fo, fi, cstart, ccount, n_nodes};
+    a.queries = queries; a.nq = nq; a.decoding_length = decoding_length; a.branch_length = branch_length;
+    a.min_in = min_in; a.min_out = min_out; a.mode = mode; a.stop = stop; a.n_stop = n_stop;
+    a.scratch_q = scratch_q; a.scratch_v = scratch_v; a.out_ids = out_ids; a.out_rowmask = (unsigned long long*)out_rowmask;
+    a.out_n = out_n; a.out_sizes = out_sizes; a.out_nsizes = out_nsizes;
+    k_trie_hier_get<<<B, 64, 0, st>>>(a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}

@@ -1,0 +1,87 @@
+# -*- coding: utf-8 -*-
+"""-m gpu: device-side hier_get (csrc/la_trie_dev.hip) must be bit-identical to the reference's golden traces
+(recorded from lookahead_cache.py by oracle/gen_golden.py) and to the host trie on larger forests."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from painlessinferenceacceleration_amd.device_trie import DeviceTrie
+from painlessinferenceacceleration_amd.lookahead_cache import LookaheadCache
+from tests import trie_replay as tr
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(mask_rows):
+    return [int(x) for x in mask_rows]
+
+
+@pytest.mark.parametrize('path', tr.trace_files(), ids=os.path.basename)
+def test_device_hier_get_replays_reference_trace(path):
+    trace = tr.load(path)
+    init = trace['init']
+    cache = LookaheadCache(eos_ids=init['eos_ids'], stop_words={w: 1 for w in init['stop_words']},
+                           max_node=init['max_node'], max_output_node=init['max_output_node'])
+    checked = 0
+    for i, op in enumerate(trace['ops']):
+        name = op['op']
+        if name == 'put':
+            cache.put(list(op['tokens']), branch_length=op['branch_length'], final=op['final'], mode=op['mode'], idx=op['idx'])
+        elif name == 'stream_put':
+            cache.stream_put(list(op['tokens']), branch_length=op['branch_length'], final=op['final'], idx=op['idx'])
+        elif name == 'hier_get':
+            if op['decoding_length'] > 64 or checked >= 60:
+                continue
+            dev = DeviceTrie(cache, idx=op['idx'])
+            got = dev.hier_get([list(op['tokens'])], decoding_length=op['decoding_length'], branch_length=op['branch_length'],
+                               min_input_size=op['min_input_size'], min_output_size=op['min_output_size'], mode=op['mode'])[0]
+            exp = op['out']
+            ctx = f"op {i}: { {k: v for k, v in op.items() if k != 'out'} }"
+            assert got[0] == exp['ids'], ctx
+            assert _rows(got[1]) == exp['rows'], ctx
+            assert got[2] == exp['sizes'], ctx
+            checked += 1
+        elif name == 'reset_input_freqs':
+            cache.reset_input_freqs(op['idx'])
+        elif name == 'squeeze_branch_counts':
+            cache.squeeze_branch_counts()
+        elif name == 'fresh':
+            cache.fresh()
+        elif name == 'limits':
+            cache.max_node, cache.max_output_node = op['max_node'], op['max_output_node']
+    assert checked >= 20
+
+
+def test_device_hier_get_batched_matches_host_on_large_forest():
+    """100 x 256-token warm-up (the reference benchmark's recipe) + an input-mode prompt; 256 queries in one launch,
+    all three modes, oversize subtrees (thresholds) included."""
+    rng = random.Random(0)
+    nr = np.random.RandomState(0)
+    cache = LookaheadCache(eos_ids=[None])
+    phrases = [nr.randint(3, 3000, size=nr.randint(3, 10)).tolist() for _ in range(300)]
+    for _ in range(100):
+        seq = []
+        while len(seq) < 256:
+            seq.extend(phrases[min(int(nr.zipf(1.3)) - 1, 299)])
+        cache.put(seq[:256], branch_length=13, mode='output', idx=-1)
+    prompt = sum((phrases[rng.randrange(300)] for _ in range(60)), [])
+    cache.put(prompt, branch_length=13, mode='input', idx=0)
+    queries = []
+    for _ in range(256):
+        ph = phrases[rng.randrange(300)]
+        k = rng.randrange(1, len(ph))
+        queries.append(ph[max(0, k - 2):k] if rng.random() < 0.8 else [rng.randrange(3, 3000), rng.randrange(3, 3000)])
+    dev = DeviceTrie(cache, idx=0)
+    big = 0
+    for mode, mi, mo in [('mix', 0, 32), ('mix', 2, 8), ('output', 0, 16), ('input', 1, 0)]:
+        got = dev.hier_get(queries, decoding_length=64, branch_length=12, min_input_size=mi, min_output_size=mo, mode=mode)
+        for qy, g in zip(queries, got):
+            ids, rowmask, parent, sizes = cache.hier_get_packed(qy, decoding_length=64, branch_length=12, min_input_size=mi,
+                                                               min_output_size=mo, mode=mode, idx=0)
+            assert g[0] == ids.tolist(), (mode, qy)
+            assert _rows(g[1]) == _rows(rowmask), (mode, qy)
+            assert g[2] == sizes, (mode, qy)
+            big += len(g[0]) == 64
+    assert big > 20        # the budget cap (and with it the cut-off rule) was exercised
