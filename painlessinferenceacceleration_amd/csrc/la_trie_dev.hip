@@ -40,7 +40,7 @@ __device__ int find_child(const TrieDev& t, int u, int token, int lane) {
         const int i = base + lane;
         const bool hit = i < cc && t.tok[cs + i] == token;
         const unsigned long long m = __ballot(hit);
-        if (m) return cs + wave_first(m);
+        if (m) return cs + base + wave_first(m);
     }
     return -1;
 }
