@@ -1,0 +1,29 @@
+import sys, os, time, random
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from painlessinferenceacceleration_amd.device_trie import DeviceTrie
+from painlessinferenceacceleration_amd.lookahead_cache import LookaheadCache
+nr = np.random.RandomState(0); rng = random.Random(0)
+cache = LookaheadCache(eos_ids=[None])
+phrases = [nr.randint(3, 32000, size=nr.randint(3, 10)).tolist() for _ in range(2000)]
+for _ in range(100):
+    seq = []
+    while len(seq) < 256: seq.extend(phrases[min(int(nr.zipf(1.3)) - 1, 1999)])
+    cache.put(seq[:256], branch_length=13, mode='output', idx=-1)
+print('forest', cache.stats())
+qs = []
+for _ in range(256):
+    ph = phrases[min(int(nr.zipf(1.3)) - 1, 1999)]; k = rng.randrange(1, len(ph)); qs.append(ph[max(0, k - 2):k])
+t0 = time.time()
+for q in qs: cache.hier_get_packed(q, 64, 12, 0, 32, 'mix', 0)
+th = (time.time() - t0) / 256
+t0 = time.time(); dev = DeviceTrie(cache, idx=0); torch.cuda.synchronize(); tm = time.time() - t0
+print(f'host hier_get: {th*1e6:.1f} us/query; mirror export+upload: {tm*1e3:.2f} ms for {dev.n_nodes} nodes')
+for B in (1, 8, 64, 256):
+    dev.hier_get(qs[:B], 64, 12, 0, 32, 'mix')
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # time only the kernel: re-issue through the class (includes small H2D/D2H); report wall per call as well
+    t0 = time.time(); n = 20
+    for _ in range(n): dev.hier_get(qs[:B], 64, 12, 0, 32, 'mix')
+    w = (time.time() - t0) / n
+    print(f'device hier_get B={B}: {w*1e6:.0f} us per call incl. transfers ({w*1e6/B:.1f} us/query)')
