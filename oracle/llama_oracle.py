@@ -8,6 +8,8 @@ scan and the bs=1 lookahead loop of alipay/PainlessInferenceAcceleration.
   accept scan  lookahead/lookahead/common/pretrained_model.py:764-892
   KV keep set  pretrained_model.py:865-875, 894-907
   loop         pretrained_model.py:947-1268 (+ 666-756 draft retrieval)
+  batch twin   models/llama/modeling_llama_batch.py:121-138, 190-201, 297-323, 340-420, 913-915 (forward);
+               common/pretrained_model_batch.py:664-759, 767-935, 937-999, 1002-1330 (loop)
 
 Plain torch on CPU in the dtype of the weights (fp32 or bf16), same operation order and the same
 rounding points as the reference (every nn.Linear / elementwise result is materialised in the
@@ -212,3 +214,176 @@ def greedy_generate(model, prompt, n_new):
         seq.append(t)
         logits, past = model.forward(torch.tensor([t]), torch.ones((1, len(seq)), dtype=torch.long), past)
     return seq
+
+
+# ================================================================================ batch (cursor) twin
+class OracleLlamaBatch(OracleLlama):
+    """The "fused" batch forward (models/llama/modeling_llama_batch.py): same network, different schedule —
+    one QKV projection whose Q rows are pre-divided by sqrt(head_dim) (:340-346), RoPE as a gather from a table of
+    2x2 rotations (:121-131, 190-201), scores = K.(Q)^T transposed back plus the additive mask (:311-316), softmax in
+    the storage dtype (:318, NOT fp32), a pre-allocated KV buffer [B, H, decoding_max_length, hd] written in place at
+    each sample's cursor (:384-400), lm_head on the last position only at prefill (:913-915)."""
+
+    def __init__(self, shape, state_dict, max_pos=2048):
+        super().__init__(shape, state_dict)
+        assert shape.n_kv_heads == shape.n_heads, 'the reference batch model assumes MHA (modeling_llama_batch.py:342)'
+        s, dt = shape, self.dtype
+        inv = 1.0 / (s.rope_theta ** (torch.arange(0, s.head_dim, 2).float() / s.head_dim))
+        fr = torch.einsum('i,j->ij', torch.arange(max_pos, dtype=inv.dtype), inv)
+        c, sn = fr.cos(), fr.sin()
+        self.rot = torch.stack([torch.stack([c, -sn], dim=1), torch.stack([sn, c], dim=1)], dim=1).to(dt)   # [pos,2,2,hd/2]
+        coef = math.sqrt(s.head_dim)
+        self.wqkv = [torch.cat([self.w[f'model.layers.{i}.self_attn.q_proj.weight'] / coef,
+                                self.w[f'model.layers.{i}.self_attn.k_proj.weight'],
+                                self.w[f'model.layers.{i}.self_attn.v_proj.weight']], dim=0) for i in range(s.n_layers)]
+
+    def _rope(self, x, pos):
+        c = self.rot[pos.unsqueeze(1)]                                   # [B,1,T,2,2,hd/2]
+        shp = x.shape
+        xv = x.reshape(*shp[:-1], 1, 2, shp[-1] // 2)
+        return (c * xv).sum(-2).view(shp)
+
+    @torch.no_grad()
+    def forward_batch(self, ids, mask, past, cursors=None, decoding_max_length=None):
+        """ids LongTensor [B,T]; mask 0/1 LongTensor [B,1,T,S]; past None (prefill) or list of [k,v] buffers
+        [B,H,Lmax,hd] (updated in place); cursors: write position per sample.  -> logits [B,T|1,V], past."""
+        s, w, dt = self.s, self.w, self.dtype
+        B, T = ids.shape
+        hd, nh = s.head_dim, s.n_heads
+        lin = torch.nn.functional.linear
+        pos = torch.sum(mask, dim=-1).squeeze(1) - 1                         # :731
+        bias = (1.0 - mask.to(dt)) * torch.finfo(dt).min                      # :733
+        h = w['model.embed_tokens.weight'][ids]
+        prefill = past is None
+        new_past = [] if prefill else past
+        for i in range(s.n_layers):
+            p = f'model.layers.{i}.'
+            x = _rms(h, w[p + 'input_layernorm.weight'], s.rms_eps)
+            mat = lin(x, self.wqkv[i]).view(B, T, 3, nh, hd).permute(0, 3, 2, 1, 4)
+            q, k, v = mat.unbind(2)
+            q, k = self._rope(q, pos), self._rope(k, pos)
+            if prefill:
+                keys, vals = k, v
+                zeros = torch.zeros((B, nh, decoding_max_length - T, hd), dtype=dt)
+                new_past.append([torch.cat([k, zeros], 2), torch.cat([v, zeros], 2)])
+            else:
+                pk, pv = past[i]
+                for b, cur in enumerate(cursors):
+                    pk[b, :, cur:cur + T] = k[b]
+                    pv[b, :, cur:cur + T] = v[b]
+                top = max(cursors) + T
+                keys, vals = pk[:, :, :top], pv[:, :, :top]
+            if B == 1:
+                att = torch.baddbmm(bias.squeeze(0), q.squeeze(0), keys.squeeze(0).transpose(-1, -2))[None]
+            else:
+                att = torch.matmul(keys, q.transpose(-1, -2)).transpose(-1, -2)
+                att = att.add_(bias)
+            att = torch.softmax(att, dim=-1)
+            o = torch.matmul(att, vals).permute(0, 2, 1, 3).contiguous().view(B, T, nh * hd)
+            h = h + lin(o, w[p + 'self_attn.o_proj.weight'])
+            x = _rms(h, w[p + 'post_attention_layernorm.weight'], s.rms_eps)
+            g = torch.nn.functional.silu(lin(x, w[p + 'mlp.gate_proj.weight']))
+            h = h + lin(g * lin(x, w[p + 'mlp.up_proj.weight']), w[p + 'mlp.down_proj.weight'])
+        h = _rms(h, w['model.norm.weight'], s.rms_eps)
+        if prefill:
+            h = h[:, -1:]
+        return lin(h, w['lm_head.weight']), new_past
+
+
+def accept_scan_limited(ids, mask, argmax_rows, limit):
+    """Batch variant of the accept scan (pretrained_model_batch.py:829-886): identical walk, but at most `limit`
+    tokens are emitted (the loop bound min(max_branch_length, input_length - cur - 2) + 1, :862)."""
+    toks, rows = accept_scan(ids, mask, argmax_rows)
+    return toks[:limit], rows[:limit]
+
+
+@torch.no_grad()
+def lookahead_generate_batch(model, cache, input_ids, attention_mask, max_length, eos_token_id=2, pad_token_id=0,
+                             decoding_length=64, branch_length=12, decoding_mode='hier', stop_words=None, record=None):
+    """bs>1 lookahead_generation (pretrained_model_batch.py:1002-1330) with an empty logits-processor list and greedy
+    decoding.  input_ids / attention_mask: int arrays [B,P] (left padding allowed).  -> dict(sequences [B,L] array,
+    dls, edls).  Per step: drafts from cache.bat_get with budget decoding_length // active (:713), one batched
+    forward, a per-sample accept walk, in-place KV moves, per-sample stream_put, finished samples leave the batch."""
+    ids0 = np.asarray(input_ids, dtype=np.int64)
+    am = np.asarray(attention_mask, dtype=np.int64)
+    B, P = ids0.shape
+    eos = [eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id)
+    cache.eos_ids = eos
+    cache.stop_words = stop_words if stop_words is not None else {}
+    L = max_length + decoding_length + 1                                         # decoding_max_length (:1168)
+    col = np.concatenate([am, np.ones((B, L - P), dtype=np.int64)], axis=1)
+    full = torch.tril(torch.from_numpy(col)[:, None, None].expand(-1, -1, L, -1), 0).contiguous()   # [B,1,L,L] (:1183)
+    for i in range(B):
+        cache.put(ids0[i, 1:-1].tolist(), branch_length=branch_length + 1, mode='input', idx=i)      # :1207-1209
+    rows = np.concatenate([ids0, np.full((B, max_length - P), pad_token_id, dtype=np.int64)], axis=1)   # padded (:791-793)
+    out_rows = rows.copy()
+    dls, edls = [], []
+    # prefill (:783-812)
+    logits, past = model.forward_batch(torch.from_numpy(ids0), full[:, :, :P, :P], None, decoding_max_length=L)
+    first = torch.argmax(logits[:, -1], dim=-1).tolist()
+    active = list(range(B))                     # batch_indices
+    cursors = [P] * B
+    for b in range(B):
+        rows[b, P] = first[b]
+    dls += [1] * B
+    edls += [1] * B
+    emitted = [[t] for t in first]
+    max_cur = 0
+    fmt, mode = (decoding_mode if '_' in decoding_mode else decoding_mode + '_mix').split('_')
+    while True:
+        # trie update, stop checks, retire finished samples (:1247-1283, 937-980)
+        for k, b in enumerate(active):
+            cache.stream_put([t for t in emitted[k] if t != -1], branch_length=branch_length + 1, final=False,
+                             mode='output', idx=b)
+        max_cur = max(max_cur, max(cursors))
+        keep = []
+        for k, b in enumerate(active):
+            done = cursors[k] + 1 >= max_length or any(e in emitted[k] for e in eos)
+            if done:
+                out_rows[b, :rows.shape[1]] = rows[k]
+            else:
+                keep.append(k)
+        if len(keep) != len(active) and len(keep) > 0:
+            rows = rows[keep]
+            full = full[keep]
+            past = [[kk[keep], vv[keep]] for kk, vv in past]
+        cursors = [cursors[k] for k in keep]
+        active = [active[k] for k in keep]
+        if not active:
+            break
+        # drafts (:706-721) and the cursor-aligned mask (:727-731)
+        n = len(active)
+        qs = [[int(rows[k, c - 1]), int(rows[k, c])] for k, c in enumerate(cursors)]
+        d_ids, d_masks, sizes = cache.bat_get(qs, decoding_length=max(decoding_length // n, 1), branch_length=branch_length,
+                                              decoding_cursors=list(cursors), mode=mode, indices=list(active),
+                                              decoding_mode=fmt)
+        W = len(d_ids[0])
+        lo = min(cursors)
+        step_mask = torch.cat([full[:, :, lo:lo + W, :lo], torch.from_numpy(d_masks[:, None])], dim=-1)
+        logits, past = model.forward_batch(torch.tensor(d_ids, dtype=torch.long), step_mask, past, cursors=cursors)
+        am_rows = torch.argmax(logits, dim=-1).tolist()
+        emitted = []
+        for k in range(n):
+            cur, off = cursors[k], cursors[k] - lo
+            own = d_masks[k][:, off:off + W]
+            T = int(sum(int(own[j, j]) for j in range(W)))      # real rows carry their own diagonal bit; pad rows do not
+            limit = max_length - cur - 1                         # emitted tokens <= min(depth, input_length-cur-2)+1 (:862)
+            toks, acc = accept_scan_limited(d_ids[k][:T], own[:T, :T], am_rows[k], limit)
+            m = len(toks) - 1
+            rows[k, cur + 1:cur + 1 + len(toks)] = toks
+            if acc[-1] != m:                                      # accepted rows are not already contiguous (:893-904)
+                src = torch.tensor([cur + r for r in acc[1:]], dtype=torch.long)
+                for kk, vv in past:
+                    kk[k, :, cur + 1:cur + 1 + m] = kk[k][:, src]
+                    vv[k, :, cur + 1:cur + 1 + m] = vv[k][:, src]
+            dls.append(W)
+            edls.append(len(toks))
+            cursors[k] = cur + len(toks)
+            emitted.append(toks)
+        if record is not None:
+            record.append({'cursors': [c - len(e) for c, e in zip(cursors, emitted)], 'bidx': list(active),
+                           'ids': [list(x) for x in d_ids], 'next': [list(e) for e in emitted],
+                           'logits': logits.float().numpy().copy()})
+    for i in range(B):
+        cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=i)      # :1288-1290
+    return {'sequences': out_rows[:, :max_cur + 1], 'dls': dls, 'edls': edls}

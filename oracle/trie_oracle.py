@@ -249,6 +249,30 @@ class TrieOracle(object):
             return token_ids[-1:], np.ones((1, 1), dtype=np.int64), [0, 0]
         return out
 
+    # ---------------------------------------------------------------- bat_get (:519-561)
+    def bat_get(self, token_id_list, decoding_length=64, branch_length=8, decoding_cursors=None, mode='output',
+                indices=None, decoding_mode='hier'):
+        """Per-sample hierarchical drafts with the budget `decoding_length // bs` (the caller has already divided
+        once, :534 divides again), right-padded with id 0, masks laid on a [bs, W, max_cur-min_cur+W] canvas at the
+        sample's cursor offset; every column up to and including the sample's own root column is forced to 1."""
+        assert decoding_mode == 'hier', 'the oracle restates the hierarchical mode only'
+        bs = len(token_id_list)
+        assert bs == len(decoding_cursors) == len(indices)
+        per = decoding_length // bs
+        got = [self.hier_get(q, decoding_length=per, branch_length=branch_length, min_input_size=0,
+                             min_output_size=max(per // 2, 1), mode=mode, idx=indices[i])
+               for i, q in enumerate(token_id_list)]
+        lo, hi = min(decoding_cursors), max(decoding_cursors)
+        W = max(len(g[0]) for g in got)
+        canvas = np.zeros((bs, W, hi - lo + W), dtype=np.int64)
+        id_list = []
+        for i, (ids, m, _) in enumerate(got):
+            n, off = len(ids), decoding_cursors[i] - lo
+            id_list.append(list(ids) + [0] * (W - n))
+            canvas[i, :n, off:off + n] = m
+            canvas[i, :, :off + 1] = 1
+        return id_list, canvas, [g[2] for g in got]
+
     # ---------------------------------------------------------------- maintenance (:295-333, 563-576)
     def fresh(self):
         self._reset_arena()

@@ -76,3 +76,55 @@ def test_oracle_forward_logits_match_reference_sample():
     logits, _ = model.forward(torch.tensor(prompt), torch.tril(torch.ones((P, P), dtype=torch.long)), None)
     ref = g['r0_s0_logits']
     assert np.abs(logits[:, :64].numpy() - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+
+
+# ------------------------------------------------------------------------------------------ batch twin
+def _load_batch(tag):
+    return np.load(os.path.join(GOLDEN, f'llama_tiny_batch_{tag}.npz'))
+
+
+@pytest.mark.parametrize('tag,dtype', [('fp32', torch.float32), ('bf16', torch.bfloat16)])
+def test_oracle_batch_loop_matches_reference_batch_generation(tag, dtype):
+    """pretrained_model_batch.lookahead_generation on modeling_llama_batch (bs 2/3/4, left padding, budgets 64/128/256):
+    sequences, dls, edls and every step's cursors / batch indices / padded draft ids / emitted tokens."""
+    g = _load_batch(tag)
+    torch.set_num_threads(4)
+    sd = {k: v.to(dtype) for k, v in tiny_weights(0, torch.float32).items()}
+    model = lo.OracleLlamaBatch(tiny_shape(), sd)
+    for name in g['cases'].tolist():
+        bs, dl, max_new = [int(x) for x in g[f'{name}_cfg']]
+        ids, am = g[f'{name}_ids'], g[f'{name}_am']
+        cache = TrieOracle()
+        for r in range(2):
+            rec = []
+            out = lo.lookahead_generate_batch(model, cache, ids, am, ids.shape[1] + max_new, eos_token_id=2, pad_token_id=0,
+                                              decoding_length=dl, branch_length=12, record=rec)
+            assert out['sequences'].tolist() == g[f'{name}_r{r}_sequences'].tolist(), (name, r)
+            assert out['dls'] == g[f'{name}_r{r}_dls'].tolist() and out['edls'] == g[f'{name}_r{r}_edls'].tolist(), (name, r)
+            assert len(rec) + 1 == int(g[f'{name}_r{r}_nsteps'])
+            for i, st in enumerate(rec, start=1):
+                assert st['cursors'] == g[f'{name}_r{r}_s{i}_cursors'].tolist(), (name, r, i)
+                assert st['bidx'] == g[f'{name}_r{r}_s{i}_bidx'].tolist(), (name, r, i)
+                assert st['ids'] == g[f'{name}_r{r}_s{i}_ids'].tolist(), (name, r, i)
+                nx = g[f'{name}_r{r}_s{i}_next']
+                assert st['next'] == [[int(t) for t in row if t >= 0] for row in nx], (name, r, i)
+                key = f'{name}_r{r}_s{i}_logits'
+                if key in g.files:
+                    ref = g[key]
+                    tol = 2e-4 if dtype == torch.float32 else 0.0
+                    assert np.abs(st['logits'][:, :, :64] - ref).max() <= tol * max(1.0, np.abs(ref).max()), (name, r, i)
+
+
+def test_oracle_batch_equals_per_sample_bs1_semantics():
+    """Each sample of a batch run generates exactly what plain greedy decoding of that sample generates (fp32):
+    the property the batch HIP path is held to at sizes without a reference run."""
+    g = _load_batch('fp32')
+    model = lo.OracleLlama(tiny_shape(), tiny_weights(0, torch.float32))
+    ids, am = g['b3pad_ids'], g['b3pad_am']
+    seqs = g['b3pad_r0_sequences']
+    P = ids.shape[1]
+    for b in range(ids.shape[0]):
+        prompt = ids[b][am[b] == 1].tolist()
+        n_gen = int((seqs[b, P:] != 0).sum())
+        gre = lo.greedy_generate(model, prompt, n_gen)
+        assert gre[len(prompt):] == seqs[b, P:P + n_gen].tolist(), b

@@ -46,7 +46,7 @@ def replay(cache, trace, has_batch=True, has_par=True, has_one=True):
             check_get(getattr(cache, name)(list(op['tokens']), **kw), op['out'], ctx)
             n_checked += 1
         elif name == 'bat_get':
-            if not has_batch:
+            if not has_batch or (op['decoding_mode'] != 'hier' and not has_one):
                 continue
             ids, masks, sizes = cache.bat_get([list(x) for x in op['tokens']], decoding_length=op['decoding_length'],
                                               branch_length=op['branch_length'],
