@@ -225,6 +225,8 @@ typedef struct la_llama_config {
     float   rms_eps;
     int32_t gemm_cfg[8];     /* {qkv_rb,qkv_ks,o_rb,o_ks,down_rb,down_ks,lm_rb,gateup_variant}; 0 = auto */
     int32_t balanced_wg[3];  /* {qkv, gate/up, lm_head}: > 0 = weights were packed with la_rowplan for that many workgroups */
+    int32_t n_slots;         /* sequence slots of the cursor-batch path (0/1 = single sequence); each slot owns a
+                                max_keys region of the main KV cache */
 } la_llama_config;
 
 typedef struct la_llama_layer_weights {   /* device pointers, packed by la_pack_weight */
@@ -260,7 +262,8 @@ int la_llama_step(la_llama* m, void* stream, const int32_t* host_in, int32_t* ho
 /* Same work launched kernel-by-kernel (no graph): for profiling and as a cross-check. */
 int la_llama_step_eager(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);
 /* Device addresses of internal buffers for parity tests: 0 logits bf16 [64][vocab], 1 state,
- * 2 hidden h bf16 [64][hidden], 3 final normed x (packed), 4/5 main K/V cache, 6/7 fresh K/V tiles. */
+ * 2 hidden h bf16 [64][hidden], 3 final normed x (packed), 4/5 main K/V cache, 6/7 fresh K/V tiles,
+ * 8 batch state block (LA_BST_*). */
 void* la_llama_buffer(la_llama* m, int which);
 /* Kernel-class timing of one block with HIP events recorded on `stream` between eager launches
  * (bench.py's roofline block).  out_ms[0..6] = per-step time summed over the launches of
@@ -269,6 +272,49 @@ void* la_llama_buffer(la_llama* m, int which);
  * steps; the sequence state is saved and restored, so the context does not advance. */
 int la_llama_profile(la_llama* m, void* stream, const int32_t* host_in, int iters,
                      float* out_ms /*[8]*/, int32_t* out_launches /*[7] or NULL*/);
+
+/* ---- cursor batch (bs>1): several sequences share the 64 rows of one verify block --------------------------------
+ * Replaces the batch twin of the loop: bat_get's padded drafts + [bs,T,W] masks (lookahead_cache.py:519-561,
+ * pretrained_model_batch.py:706-731), the batched forward writing K/V at each sample's cursor
+ * (modeling_llama_batch.py:340-420), the per-sample accept walk (pretrained_model_batch.py:814-886) and the in-place
+ * KV row moves (:893-904, 986-989).  Rows are NOT padded: each active sequence ("slot") contributes its T_b tree rows,
+ * sum(T_b) <= 64 — exactly the budget the reference batch driver allows (decoding_length // bs per sample) —
+ * so the weights are still streamed once per step for the whole batch.  Ancestor bits of a row mask are BLOCK row
+ * indices (the host shifts each sample's local mask by its first row). */
+#define LA_MAX_SEQ      16
+/* batch step input block (int32 words) */
+#define LA_BIN_T          0   /* block rows in use (<= 64)                                   */
+#define LA_BIN_IDS        4   /* [64] token ids                                              */
+#define LA_BIN_ROWMASK   68   /* uint64[64] ancestor masks over block rows                   */
+#define LA_BIN_SEQ      196   /* [64] slot of each row, -1 = row unused                      */
+#define LA_BIN_MODE     260   /* [16] per slot: 0 = verify tree, 1 = prefill chain           */
+#define LA_BIN_LIMIT    276   /* [16] per slot: max tokens to emit (max_length - cursor - 1) */
+#define LA_BIN_WORDS    292
+/* batch device state block (int32 words) */
+#define LA_BST_NKEYS      0   /* [16] committed keys per slot (= the sample's cursor)         */
+#define LA_BST_NOUT      16   /* out: [16] tokens emitted by the last step (0 = slot idle)    */
+#define LA_BST_OUTTOK    32   /* out: [16][16] emitted tokens per slot                        */
+#define LA_BST_DST      288   /* out: [64] main-cache key row each block row was committed to, -1 = dropped */
+#define LA_BST_ARGMAX   352   /* out: [64] argmax token per block row                         */
+#define LA_BST_SEQ      416   /* [64] row -> slot map of the last step                        */
+#define LA_BST_WORDS    480
+/* step-control kernels of the batch path (also used inside la_llama_bstep) */
+int la_build_batch_inputs(void* stream, const int32_t* d_in, int32_t* d_bstate, int32_t* d_pos, uint64_t* d_rowmask,
+                          int32_t* d_ids);
+int la_accept_scan_batch(void* stream, const int32_t* d_in, const int32_t* d_ids, const uint64_t* d_rowmask,
+                         int32_t* d_bstate, int n_slots, int slot_keys);
+int la_kv_commit_batch(void* stream, const void* d_kfresh, const void* d_vfresh, void* d_kmain, void* d_vmain,
+                       const int32_t* d_bstate, int n_layers, int n_kv_heads, int total_keys);
+int la_tree_attn_batch(void* stream, const void* d_qf, const void* d_kmain, const void* d_vmain, const void* d_kfresh,
+                       const void* d_vfresh, const uint64_t* d_rowmask, const int32_t* d_bstate, int n_heads,
+                       int n_kv_heads, int slot_keys, int n_slots, int n_split, float* d_opart, float* d_mpart,
+                       float* d_lpart, void* d_attn_xp);
+/* Whole batch step (needs cfg.n_slots >= 1): h2d of host_in (LA_BIN_WORDS), captured graph, d2h of
+ * LA_BST_DST words (NKEYS, NOUT, OUTTOK) into host_out.  Same asynchrony rules as la_llama_step. */
+int la_llama_bstep(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);
+int la_llama_bstep_eager(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);
+/* Forget a slot's sequence (committed keys = 0); slot < 0 resets every slot. */
+int la_llama_reset_slot(la_llama* m, void* stream, int slot);
 
 #ifdef __cplusplus
 }

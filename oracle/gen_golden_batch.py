@@ -22,8 +22,10 @@ from oracle.gen_golden_model import OUT, TINY, import_reference, tiny_prompt, ti
 # (name, batch size, valid prompt lengths (left-padded to the longest), decoding_length, max_new)
 CASES = [
     ('b2', 2, [40, 40], 64, 64),
-    ('b3pad', 3, [40, 33, 25], 128, 48),
-    ('b4', 4, [24, 24, 24, 24], 256, 40),
+    ('b3pad', 3, [40, 33, 25], 64, 48),
+    ('b4', 4, [24, 24, 24, 24], 64, 40),
+    ('b3pad128', 3, [40, 33, 25], 128, 48),      # budget > 64 rows once samples retire: oracle-only case
+    ('b4w256', 4, [24, 24, 24, 24], 256, 40),
 ]
 
 

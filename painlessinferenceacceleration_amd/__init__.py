@@ -5,6 +5,7 @@ Drop-in surface (reference: alipay/PainlessInferenceAcceleration, lookahead/):
     LookaheadCache                         lookahead/common/lookahead_cache.py
     LookaheadPreTrainedModel.lookahead_generation   lookahead/common/pretrained_model.py
     LlamaForCausalLM                       lookahead/models/llama/modeling_llama.py
+    modeling_llama_batch.LlamaForCausalLM  lookahead/models/llama/modeling_llama_batch.py (bs>1, cursor batch)
 All compute lives in liblookahead_hip.so (csrc/, hand-written gfx950 HIP + the native trie).
 """
 from ._lib import LIB_PATH, LookaheadHipError  # noqa: F401  (raises at import if the library is not built)
@@ -19,6 +20,9 @@ __all__ = ['LookaheadCache', 'GenerationMode', 'LookaheadDecoderOnlyOutput', 'Lo
 def __getattr__(name):          # torch-dependent pieces are imported lazily
     if name in ('LlamaForCausalLM',):
         from .modeling_llama import LlamaForCausalLM
+        return LlamaForCausalLM
+    if name in ('BatchLlamaForCausalLM',):
+        from .modeling_llama_batch import LlamaForCausalLM
         return LlamaForCausalLM
     if name in ('LookaheadPreTrainedModel',):
         from .pretrained_model import LookaheadPreTrainedModel

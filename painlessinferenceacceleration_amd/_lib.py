@@ -17,6 +17,10 @@ LA_TREE_MAX = 64
 LA_ST_NKEYS, LA_ST_T, LA_ST_MODE, LA_ST_NOUT, LA_ST_DSTBASE, LA_ST_NCOMMIT, LA_ST_MAXKEYS = 0, 1, 2, 3, 4, 5, 6
 LA_ST_OUTTOK, LA_ST_SRCIDX, LA_ST_ARGMAX, LA_ST_WORDS = 8, 72, 136, 200
 LA_IN_T, LA_IN_MODE, LA_IN_IDS, LA_IN_ROWMASK, LA_IN_WORDS = 0, 1, 4, 68, 196
+# cursor-batch blocks
+LA_MAX_SEQ = 16
+LA_BIN_T, LA_BIN_IDS, LA_BIN_ROWMASK, LA_BIN_SEQ, LA_BIN_MODE, LA_BIN_LIMIT, LA_BIN_WORDS = 0, 4, 68, 196, 260, 276, 292
+LA_BST_NKEYS, LA_BST_NOUT, LA_BST_OUTTOK, LA_BST_DST, LA_BST_ARGMAX, LA_BST_SEQ, LA_BST_WORDS = 0, 16, 32, 288, 352, 416, 480
 
 
 class LookaheadHipError(RuntimeError):
@@ -65,7 +69,7 @@ pi32, pi64, pu64, pf32 = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C
 class LlamaConfigC(C.Structure):
     _fields_ = [("n_layers", i32), ("hidden", i32), ("n_heads", i32), ("n_kv_heads", i32), ("head_dim", i32),
                 ("ffn", i32), ("vocab", i32), ("max_keys", i32), ("max_pos", i32), ("attn_split", i32),
-                ("rms_eps", f32), ("gemm_cfg", i32 * 8), ("balanced_wg", i32 * 3)]
+                ("rms_eps", f32), ("gemm_cfg", i32 * 8), ("balanced_wg", i32 * 3), ("n_slots", i32)]
 
 
 class LlamaLayerWeightsC(C.Structure):
@@ -135,6 +139,13 @@ PROTOTYPES = {
     "la_llama_step_eager": (i32, vp, vp, vp, vp),
     "la_llama_buffer": (vp, vp, i32),
     "la_llama_profile": (i32, vp, vp, vp, i32, pf32, pi32),
+    "la_build_batch_inputs": (i32, vp, vp, vp, vp, vp, vp),
+    "la_accept_scan_batch": (i32, vp, vp, vp, vp, vp, i32, i32),
+    "la_kv_commit_batch": (i32, vp, vp, vp, vp, vp, vp, i32, i32, i32),
+    "la_tree_attn_batch": (i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp),
+    "la_llama_bstep": (i32, vp, vp, vp, vp),
+    "la_llama_bstep_eager": (i32, vp, vp, vp, vp),
+    "la_llama_reset_slot": (i32, vp, vp, i32),
 }
 
 for _n, _sig in PROTOTYPES.items():

@@ -13,7 +13,7 @@ void la_set_error(const std::string& s) { g_err = s; }
 
 extern "C" {
 
-int la_abi_version(void) { return 1; }
+int la_abi_version(void) { return 2; }
 const char* la_last_error(void) { return g_err.c_str(); }
 
 int la_build_tree_inputs(void* stream, const int32_t* d_in, int32_t* d_state, int32_t* d_pos, uint64_t* d_rowmask,
@@ -94,7 +94,7 @@ int la_gemm64_logits(void* stream, const void* wp, const void* xp, int V, int K,
 }
 int la_argmax_finalize(void* stream, const float* cv, const int32_t* ci, int n_tiles, int32_t* d_state) {
     if (!cv || !ci || !d_state || n_tiles <= 0) return LA_E_ARG;
-    WRAP(lk_argmax_finalize((hipStream_t)stream, cv, ci, n_tiles, d_state));
+    WRAP(lk_argmax_finalize((hipStream_t)stream, cv, ci, n_tiles, d_state + LA_ST_ARGMAX));
 }
 int la_embed_norm(void* stream, const void* embed, const int32_t* ids, const void* nw, int hidden, float eps, void* h,
                   void* xp) {
@@ -118,6 +118,31 @@ int la_tree_attn(void* stream, const void* qf, const void* km, const void* vm, c
         nh <= 0 || nkv <= 0 || nh % nkv || max_keys % 32 || nsplit < 1 || nsplit > 64) return LA_E_ARG;
     WRAP(lk_tree_attn((hipStream_t)stream, qf, km, vm, kf, vf, rowmask, d_state, nh, nkv, max_keys, nsplit, opart,
                       mpart, lpart, attn_xp));
+}
+
+int la_build_batch_inputs(void* stream, const int32_t* d_in, int32_t* d_bstate, int32_t* d_pos, uint64_t* d_rowmask,
+                          int32_t* d_ids) {
+    if (!d_in || !d_bstate || !d_pos || !d_rowmask || !d_ids) return LA_E_ARG;
+    WRAP(lk_build_tree_inputs_b((hipStream_t)stream, d_in, d_bstate, d_pos, d_rowmask, d_ids));
+}
+int la_accept_scan_batch(void* stream, const int32_t* d_in, const int32_t* d_ids, const uint64_t* d_rowmask,
+                         int32_t* d_bstate, int n_slots, int slot_keys) {
+    if (!d_in || !d_ids || !d_rowmask || !d_bstate || n_slots < 1 || n_slots > LA_MAX_SEQ || slot_keys % 32) return LA_E_ARG;
+    WRAP(lk_accept_scan_b((hipStream_t)stream, d_in, d_ids, d_rowmask, d_bstate, n_slots, slot_keys));
+}
+int la_kv_commit_batch(void* stream, const void* kf, const void* vf, void* km, void* vm, const int32_t* d_bstate,
+                       int n_layers, int nkv, int total_keys) {
+    if (!kf || !vf || !km || !vm || !d_bstate || n_layers <= 0 || nkv <= 0 || total_keys % 32) return LA_E_ARG;
+    WRAP(lk_kv_commit_b((hipStream_t)stream, kf, vf, km, vm, d_bstate, n_layers, nkv, total_keys));
+}
+int la_tree_attn_batch(void* stream, const void* qf, const void* km, const void* vm, const void* kf, const void* vf,
+                       const uint64_t* rowmask, const int32_t* d_bstate, int nh, int nkv, int slot_keys, int n_slots,
+                       int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp) {
+    if (!qf || !km || !vm || !kf || !vf || !rowmask || !d_bstate || !opart || !mpart || !lpart || !attn_xp ||
+        nh <= 0 || nkv <= 0 || nh % nkv || slot_keys % 32 || nsplit < 1 || nsplit > 64 || n_slots < 1 ||
+        n_slots > LA_MAX_SEQ) return LA_E_ARG;
+    WRAP(lk_tree_attn_b((hipStream_t)stream, qf, km, vm, kf, vf, rowmask, d_bstate, nh, nkv, slot_keys, n_slots, nsplit,
+                        opart, mpart, lpart, attn_xp));
 }
 
 int la_trie_hier_get_dev(void* stream, const int32_t* d_tok, const double* d_fo, const double* d_fi, const int32_t* d_cstart,

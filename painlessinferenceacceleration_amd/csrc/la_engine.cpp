@@ -27,11 +27,12 @@ struct la_llama {
     char* ws;
     uint16_t *kmain, *vmain, *kfresh, *vfresh, *qf, *h, *xp, *attn_xp, *act_xp, *logits;
     float *slabs, *opart, *mpart, *lpart, *cand_val;
-    int *cand_idx, *state, *in, *pos, *ids;
+    int *cand_idx, *state, *in, *pos, *ids, *bstate, *bin;
     uint64_t* rowmask;
     size_t kv_layer_elems, fresh_layer_elems;
-    hipGraphExec_t graph_exec;
-    bool graph_ready;
+    int n_slots, total_keys;
+    hipGraphExec_t graph_exec, bgraph_exec;
+    bool graph_ready, bgraph_ready;
     hipStream_t graph_stream;
 };
 
@@ -74,7 +75,9 @@ static void resolve_cfg(la_llama* m) {
 static size_t carve(la_llama* m, char* base) {
     const la_llama_config& c = m->cfg;
     Carver cv{base, 0};
-    const size_t KB = (size_t)c.max_keys / 32;
+    m->n_slots = c.n_slots > 1 ? c.n_slots : 1;
+    m->total_keys = m->n_slots * c.max_keys;
+    const size_t KB = (size_t)m->total_keys / 32;
     m->kv_layer_elems = (size_t)c.n_kv_heads * KB * 4096;
     m->fresh_layer_elems = (size_t)c.n_kv_heads * 2 * 4096;
     m->kmain = cv.take<uint16_t>(m->kv_layer_elems * c.n_layers);
@@ -103,6 +106,8 @@ static size_t carve(la_llama* m, char* base) {
     m->pos = cv.take<int>(64);
     m->ids = cv.take<int>(64);
     m->rowmask = cv.take<uint64_t>(64);
+    m->bstate = cv.take<int>(LA_BST_WORDS);
+    m->bin = cv.take<int>(LA_BIN_WORDS);
     return align_up(cv.off, 256);
 }
 
@@ -110,7 +115,7 @@ static int validate(const la_llama_config* c) {
     if (!c) return LA_E_ARG;
     if (c->head_dim != 128) { la_set_error("head_dim must be 128"); return LA_E_ARG; }
     if (c->n_layers <= 0 || c->hidden % 32 || c->hidden > 8192 || c->ffn % 32 || c->vocab % 32 ||
-        c->n_heads % c->n_kv_heads || c->max_keys % 32 || c->max_keys < 96) {
+        c->n_heads % c->n_kv_heads || c->max_keys % 32 || c->max_keys < 96 || c->n_slots < 0 || c->n_slots > LA_MAX_SEQ) {
         la_set_error("unsupported llama config (need hidden%32==0<=8192, ffn%32==0, vocab%32==0, max_keys%32==0)");
         return LA_E_ARG;
     }
@@ -145,8 +150,8 @@ extern "C" la_llama* la_llama_create(const la_llama_config* cfg, const la_llama_
     size_t need = carve(m, (char*)ws);
     if ((int64_t)need > ws_bytes) { la_set_error("workspace too small"); delete m; return nullptr; }
     m->ws = (char*)ws;
-    m->graph_ready = false;
-    m->graph_exec = nullptr;
+    m->graph_ready = m->bgraph_ready = false;
+    m->graph_exec = m->bgraph_exec = nullptr;
     m->graph_stream = nullptr;
     return m;
 }
@@ -154,6 +159,7 @@ extern "C" la_llama* la_llama_create(const la_llama_config* cfg, const la_llama_
 extern "C" void la_llama_destroy(la_llama* m) {
     if (!m) return;
     if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    if (m->bgraph_exec) (void)hipGraphExecDestroy(m->bgraph_exec);
     delete m;
 }
 
@@ -163,6 +169,16 @@ extern "C" int la_llama_reset(la_llama* m, void* stream) {
     HIPCHK(hipMemsetAsync(m->state, 0, LA_ST_WORDS * sizeof(int), st));
     int mk = m->cfg.max_keys;
     HIPCHK(hipMemcpyAsync(m->state + LA_ST_MAXKEYS, &mk, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(m->bstate, 0, LA_BST_WORDS * sizeof(int), st));
+    HIPCHK(hipStreamSynchronize(st));
+    return LA_OK;
+}
+
+extern "C" int la_llama_reset_slot(la_llama* m, void* stream, int slot) {
+    if (!m || slot >= m->n_slots) return LA_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (slot < 0) HIPCHK(hipMemsetAsync(m->bstate, 0, LA_BST_WORDS * sizeof(int), st));
+    else HIPCHK(hipMemsetAsync(m->bstate + LA_BST_NKEYS + slot, 0, sizeof(int), st));
     HIPCHK(hipStreamSynchronize(st));
     return LA_OK;
 }
@@ -185,11 +201,12 @@ struct Prof {
 };
 
 // enqueue every kernel of one block on `st` (used eagerly, under graph capture, and by the profiler)
-static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf) {
+static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = false) {
     const la_llama_config& c = m->cfg;
     auto P = [&](int cls) { if (pf) pf->mark(cls); };
     P(KC_OTHER);
-    KCHK(lk_build_tree_inputs(st, m->in, m->state, m->pos, m->rowmask, m->ids));
+    if (batch) KCHK(lk_build_tree_inputs_b(st, m->bin, m->bstate, m->pos, m->rowmask, m->ids));
+    else KCHK(lk_build_tree_inputs(st, m->in, m->state, m->pos, m->rowmask, m->ids));
     KCHK(lk_embed_norm(st, m->w.embed, m->ids, m->layers[0].norm1, c.hidden, c.rms_eps, m->h, m->xp));
     for (int l = 0; l < c.n_layers; ++l) {
         const la_llama_layer_weights& L = m->layers[l];
@@ -209,9 +226,14 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf) {
                              m->qf, kf, vf));
         }
         P(KC_ATTN);
-        KCHK(lk_tree_attn(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
-                          kf, vf, m->rowmask, m->state, c.n_heads, c.n_kv_heads, c.max_keys, m->nsplit,
-                          m->opart, m->mpart, m->lpart, m->attn_xp));
+        if (batch)
+            KCHK(lk_tree_attn_b(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
+                                kf, vf, m->rowmask, m->bstate, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, m->nsplit,
+                                m->opart, m->mpart, m->lpart, m->attn_xp));
+        else
+            KCHK(lk_tree_attn(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
+                              kf, vf, m->rowmask, m->state, c.n_heads, c.n_kv_heads, m->total_keys, m->nsplit,
+                              m->opart, m->mpart, m->lpart, m->attn_xp));
         P(KC_O);
         KCHK(lk_gemm64_slab(st, L.wo, m->attn_xp, c.hidden, m->o_k, m->o_rb, m->o_ks, m->slabs));
         P(KC_OTHER);
@@ -226,33 +248,62 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf) {
         KCHK(lk_resid_norm(st, m->h, m->slabs, m->down_ks, nw, c.hidden, c.rms_eps, m->xp));
     }
     P(KC_LMHEAD);
+    int* am_rows = batch ? m->bstate + LA_BST_ARGMAX : m->state + LA_ST_ARGMAX;
     if (c.balanced_wg[2] > 0) {
         KCHK(lk_gemm64r_logits(st, m->w.lm_head, m->xp, c.vocab, c.hidden, c.balanced_wg[2], m->logits, m->cand_val, m->cand_idx));
         P(KC_OTHER);
-        KCHK(lk_argmax_finalize(st, m->cand_val, m->cand_idx, c.balanced_wg[2] * 8, m->state));
+        KCHK(lk_argmax_finalize(st, m->cand_val, m->cand_idx, c.balanced_wg[2] * 8, am_rows));
     } else {
         KCHK(lk_gemm64_logits(st, m->w.lm_head, m->xp, c.vocab, c.hidden, m->lm_rb, m->logits, m->cand_val, m->cand_idx));
         P(KC_OTHER);
-        KCHK(lk_argmax_finalize(st, m->cand_val, m->cand_idx, lk_logits_cand_slots(c.vocab, m->lm_rb), m->state));
+        KCHK(lk_argmax_finalize(st, m->cand_val, m->cand_idx, lk_logits_cand_slots(c.vocab, m->lm_rb), am_rows));
     }
-    KCHK(lk_accept_scan(st, m->ids, m->rowmask, m->state));
-    KCHK(lk_kv_commit(st, m->kfresh, m->vfresh, m->kmain, m->vmain, m->state, c.n_layers, c.n_kv_heads, c.max_keys));
+    if (batch) {
+        KCHK(lk_accept_scan_b(st, m->bin, m->ids, m->rowmask, m->bstate, m->n_slots, c.max_keys));
+        KCHK(lk_kv_commit_b(st, m->kfresh, m->vfresh, m->kmain, m->vmain, m->bstate, c.n_layers, c.n_kv_heads, m->total_keys));
+    } else {
+        KCHK(lk_accept_scan(st, m->ids, m->rowmask, m->state));
+        KCHK(lk_kv_commit(st, m->kfresh, m->vfresh, m->kmain, m->vmain, m->state, c.n_layers, c.n_kv_heads, m->total_keys));
+    }
     P(KC_N);
     return LA_OK;
 }
 
-static int build_graph(la_llama* m, hipStream_t st) {
+static int build_graph(la_llama* m, hipStream_t st, bool batch = false) {
     hipGraph_t g = nullptr;
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    int rc = enqueue_step(m, st, nullptr);
+    int rc = enqueue_step(m, st, nullptr, batch);
     hipError_t e = hipStreamEndCapture(st, &g);
     if (rc != LA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
     HIPCHK(e);
-    HIPCHK(hipGraphInstantiate(&m->graph_exec, g, nullptr, nullptr, 0));
+    HIPCHK(hipGraphInstantiate(batch ? &m->bgraph_exec : &m->graph_exec, g, nullptr, nullptr, 0));
     (void)hipGraphDestroy(g);
-    m->graph_ready = true;
+    (batch ? m->bgraph_ready : m->graph_ready) = true;
     m->graph_stream = st;
     return LA_OK;
+}
+
+static int bstep(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out, bool eager) {
+    if (!m || !host_in) return LA_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(m->bin, host_in, LA_BIN_WORDS * sizeof(int), hipMemcpyHostToDevice, st));
+    if (eager) {
+        int rc = enqueue_step(m, st, nullptr, true);
+        if (rc != LA_OK) return rc;
+    } else {
+        if (!m->bgraph_ready) { int rc = build_graph(m, st, true); if (rc != LA_OK) return rc; }
+        HIPCHK(hipGraphLaunch(m->bgraph_exec, st));
+    }
+    if (host_out)
+        HIPCHK(hipMemcpyAsync(host_out, m->bstate, LA_BST_DST * sizeof(int), hipMemcpyDeviceToHost, st));
+    return LA_OK;
+}
+
+extern "C" int la_llama_bstep(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out) {
+    return bstep(m, stream, host_in, host_out, false);
+}
+extern "C" int la_llama_bstep_eager(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out) {
+    return bstep(m, stream, host_in, host_out, true);
 }
 
 extern "C" int la_llama_step(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out) {
@@ -288,6 +339,7 @@ extern "C" void* la_llama_buffer(la_llama* m, int which) {
         case 5: return m->vmain;
         case 6: return m->kfresh;
         case 7: return m->vfresh;
+        case 8: return m->bstate;
         default: return nullptr;
     }
 }

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
 }
 
 __global__ __launch_bounds__(256) void k_argmax_finalize(const float* __restrict__ cv, const int* __restrict__ ci,
-                                                        int n_tiles, int* __restrict__ state) {
+                                                        int n_tiles, int* __restrict__ out) {
     __shared__ float sv[4];
     __shared__ int si[4];
     const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // one token per block
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void k_argmax_finalize(const float* __restrict
 #pragma unroll
         for (int w = 1; w < 4; ++w)
             if (sv[w] > best || (sv[w] == best && si[w] < bidx)) { best = sv[w]; bidx = si[w]; }
-        state[LA_ST_ARGMAX + t] = bidx;
+        out[t] = bidx;
     }
 }
 
@@ -598,6 +598,22 @@ __global__ void k_build_tree_inputs(const int* __restrict__ in, int* __restrict_
     ids[t] = (t < T) ? in[LA_IN_IDS + t] : 0;
     pos[t] = state[LA_ST_NKEYS] + __popcll(rm) - 1;
     if (t == 0) { state[LA_ST_T] = T; state[LA_ST_MODE] = in[LA_IN_MODE]; }
+}
+
+// Multi-sequence form (pretrained_model_batch.py:706-731 + modeling_llama_batch.py:729-734): the 64 block rows are
+// shared by up to LA_MAX_SEQ sequence slots; a row's position counts its own slot's committed keys.
+__global__ void k_build_tree_inputs_b(const int* __restrict__ in, int* __restrict__ bstate, int* __restrict__ pos,
+                                      unsigned long long* __restrict__ rowmask, int* __restrict__ ids) {
+    const int t = threadIdx.x;   // 64 threads
+    const int T = in[LA_BIN_T];
+    const unsigned long long* rmin = (const unsigned long long*)(in + LA_BIN_ROWMASK);
+    int s = (t < T) ? in[LA_BIN_SEQ + t] : -1;
+    if (s >= LA_MAX_SEQ) s = -1;
+    const unsigned long long rm = (s >= 0) ? rmin[t] : (1ull << t);
+    rowmask[t] = rm;
+    ids[t] = (s >= 0) ? in[LA_BIN_IDS + t] : 0;
+    pos[t] = (s >= 0) ? bstate[LA_BST_NKEYS + s] + __popcll(rm) - 1 : 0;
+    bstate[LA_BST_SEQ + t] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -701,6 +717,10 @@ struct AttnArgs {
     float* opart;   // [nh][nsplit][64][128]
     float* mpart;   // [nh][nsplit][64]
     float* lpart;
+    // multi-sequence mode (seq != nullptr): grid.z = slot; a row only sees the committed keys of its own slot
+    const int* seq;       // [64] row -> slot (-1 = unused row)
+    const int* nkeys_b;   // [LA_MAX_SEQ] committed keys per slot
+    int slot_tiles;       // 32-key tiles per slot region of the main cache
 };
 
 #define LA_NEG (-1.0e30f)
@@ -714,14 +734,28 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
     const int tb = wave & 1, par = wave >> 1;      // par in [0, LA_ATT_PAR)
     const int hk = h / (a.nh / a.nkv);
     const int KB = a.max_keys >> 5;
-    const int nkeys = a.state[LA_ST_NKEYS];
+    int nkeys, tile0 = 0;
+    bool mine = true;
+    unsigned long long rm = a.rowmask[tb * 32 + (lane & 31)];
+    if (a.seq) {
+        const int slot = blockIdx.z;
+        if (__ballot(a.seq[lane] == slot) == 0ull) return;          // no row of this slot in the block (uniform)
+        nkeys = a.nkeys_b[slot];
+        tile0 = slot * a.slot_tiles;
+        mine = a.seq[tb * 32 + (lane & 31)] == slot;
+        if (!mine) rm = 0ull;
+    } else {
+        nkeys = a.state[LA_ST_NKEYS];
+    }
     const int NP = (nkeys + 31) >> 5, NT = NP + 2;
-    const int i0 = (NT * sp) / a.nsplit, i1 = (NT * (sp + 1)) / a.nsplit;
+    const int i0 = (NT * sp) / a.nsplit;
+    // a wave whose token block holds no row of the slot contributes nothing: skip its tiles (it still joins the merge)
+    const int i1 = (__ballot(mine) == 0ull) ? i0 : (NT * (sp + 1)) / a.nsplit;
+    const int nk_row = mine ? nkeys : 0;
 
     bf16x8 q[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) q[s] = *((const bf16x8*)(a.qf + ((size_t)(h * 2 + tb) * 8 + s) * 512) + lane);
-    const unsigned long long rm = a.rowmask[tb * 32 + (lane & 31)];
     const int hh = lane >> 5;
 
     f32x16 o[4];
@@ -733,11 +767,11 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
 
     auto kptr = [&](int it) -> const bf16x8* {
         return it >= NP ? (const bf16x8*)(a.kfresh + ((size_t)hk * 2 + (it - NP)) * 4096)
-                        : (const bf16x8*)(a.kmain + ((size_t)hk * KB + it) * 4096);
+                        : (const bf16x8*)(a.kmain + ((size_t)hk * KB + tile0 + it) * 4096);
     };
     auto vptr = [&](int it) -> const bf16x8* {
         return it >= NP ? (const bf16x8*)(a.vfresh + ((size_t)hk * 2 + (it - NP)) * 4096)
-                        : (const bf16x8*)(a.vmain + ((size_t)hk * KB + it) * 4096);
+                        : (const bf16x8*)(a.vmain + ((size_t)hk * KB + tile0 + it) * 4096);
     };
     // one key tile: S^T = K.Q^T, mask, online softmax, O^T += V^T.P^T.  The V fragments are requested before the
     // QK^T MFMAs and consumed after the softmax; the NEXT tile's K fragments are requested by the caller first.
@@ -759,7 +793,7 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
         for (int i = 0; i < 16; ++i) {
             const int kk = (i & 3) + 8 * (i >> 2) + 4 * hh;
             float v = bfr(__fdiv_rn(bfr(sc[i]), 11.313708498984761f));
-            const bool ok = fresh ? ((rm >> (kb * 32 + kk)) & 1ull) != 0ull : (kb * 32 + kk) < nkeys;
+            const bool ok = fresh ? ((rm >> (kb * 32 + kk)) & 1ull) != 0ull : (kb * 32 + kk) < nk_row;
             v = ok ? v : LA_NEG;
             sc[i] = v;
             mx = fmaxf(mx, v);
@@ -842,7 +876,7 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
         }
         if (half > 1) __syncthreads();
     }
-    if (par != 0) return;
+    if (par != 0 || !mine) return;
     const int tok = tb * 32 + (lane & 31);
     float* op = a.opart + (((size_t)h * a.nsplit + sp) * LA_TB + tok) * 128;
 #pragma unroll
@@ -862,10 +896,15 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
 template <int NS>
 __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ opart, const float* __restrict__ mpart,
                                                        const float* __restrict__ lpart, int nh,
-                                                       bf16_t* __restrict__ attn_xp) {
+                                                       const int* __restrict__ seq, bf16_t* __restrict__ attn_xp) {
     int gid = blockIdx.x * 256 + threadIdx.x;   // (h, tok, d8)
     if (gid >= nh * LA_TB * 16) return;
     int d8 = gid & 15, tok = (gid >> 4) & 63, h = gid >> 10;
+    if (seq && seq[tok] < 0) {                   // multi-sequence mode: rows no slot owns carry zeros
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        *(bf16x8*)(attn_xp + xp_offset(tok, h * 128 + d8 * 8)) = z;
+        return;
+    }
     float ms[NS], ls[NS];
     f32x4 o0[NS], o1[NS];
 #pragma unroll
@@ -965,6 +1004,82 @@ __global__ __launch_bounds__(256) void k_kv_commit(const bf16_t* __restrict__ kf
         int src = state[LA_ST_SRCIDX + r], dst = base + r;
         if (dst >= max_keys) continue;
         vm[vf_offset(dst, d)] = vf[vf_offset(src, d)];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-sequence accept scan + commit plan (pretrained_model_batch.py:814-905).  One wavefront per slot: the same
+// walk as k_accept_scan over the rows the slot owns, at most LIMIT[slot] emitted tokens (the loop bound
+// min(max_branch_length, input_length-cur-2)+1, :862); DST[row] = absolute main-cache key row of every row that is
+// kept (root + accepted drafts, or all rows of a prefill chain), -1 otherwise.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_accept_scan_b(const int* __restrict__ in, const int* __restrict__ ids,
+                                const unsigned long long* __restrict__ rowmask, int* __restrict__ bstate, int slot_keys) {
+    const int s = blockIdx.x, j = threadIdx.x;   // 64 threads
+    const int sq = bstate[LA_BST_SEQ + j];
+    const bool mine = sq == s;
+    const unsigned long long own = __ballot(mine);
+    if (s == 0 && sq < 0) bstate[LA_BST_DST + j] = -1;
+    if (own == 0ull) { if (j == 0) bstate[LA_BST_NOUT + s] = 0; return; }
+    const int root = __ffsll((long long)own) - 1;
+    const int mode = in[LA_BIN_MODE + s];
+    int limit = in[LA_BIN_LIMIT + s];
+    limit = limit < 1 ? 1 : (limit > 16 ? 16 : limit);
+    const int nkeys = bstate[LA_BST_NKEYS + s];
+    const int base = s * slot_keys + nkeys;
+    const int am = bstate[LA_BST_ARGMAX + j];
+    int dst = -1, n_commit;
+    if (mode == 1) {
+        const int last = 63 - __clzll((long long)own);
+        const int tok = __shfl(am, last, 64);
+        if (mine) dst = base + __popcll(own & ((1ull << j) - 1ull));
+        if (j == 0) { bstate[LA_BST_OUTTOK + s * 16] = tok; bstate[LA_BST_NOUT + s] = 1; }
+        n_commit = __popcll(own);
+    } else {
+        const unsigned long long below = rowmask[j] & ((1ull << j) - 1ull);
+        const int parent = (!mine || j == root || below == 0ull) ? -1 : 63 - __clzll((long long)below);
+        const int myid = ids[j];
+        int cur = root, depth = 0;
+        if (j == root) dst = base;
+        while (true) {
+            const int want = __shfl(am, cur, 64);
+            if (j == 0) bstate[LA_BST_OUTTOK + s * 16 + depth] = want;
+            if (depth + 1 >= limit) break;
+            const unsigned long long cand = __ballot(mine && j != root && parent == cur && myid == want);
+            if (cand == 0ull) break;
+            cur = __ffsll((long long)cand) - 1;
+            ++depth;
+            if (j == cur) dst = base + depth;
+        }
+        if (j == 0) bstate[LA_BST_NOUT + s] = depth + 1;
+        n_commit = depth + 1;
+    }
+    if (mine) bstate[LA_BST_DST + j] = dst;
+    if (j == 0) bstate[LA_BST_NKEYS + s] = nkeys + n_commit;
+}
+
+// fresh rows -> their DST rows of the main cache (in-place cursor writes of modeling_llama_batch.py:384-400 and the
+// row moves of pretrained_model_batch.py:986-989 in one pass).  grid = layers*nkv, 256 threads.
+__global__ __launch_bounds__(256) void k_kv_commit_b(const bf16_t* __restrict__ kfresh, const bf16_t* __restrict__ vfresh,
+                                                      bf16_t* __restrict__ kmain, bf16_t* __restrict__ vmain,
+                                                      const int* __restrict__ bstate, int total_keys) {
+    const int lh = blockIdx.x;
+    const size_t KB = (size_t)(total_keys >> 5);
+    const bf16_t* kf = kfresh + (size_t)lh * 2 * 4096;
+    const bf16_t* vf = vfresh + (size_t)lh * 2 * 4096;
+    bf16_t* km = kmain + (size_t)lh * KB * 4096;
+    bf16_t* vm = vmain + (size_t)lh * KB * 4096;
+    for (int i = threadIdx.x; i < LA_TB * 16; i += 256) {
+        const int r = i >> 4, p = i & 15;
+        const int dst = bstate[LA_BST_DST + r];
+        if (dst < 0 || dst >= total_keys) continue;
+        *(bf16x8*)(km + rf_offset(dst, p * 8)) = *(const bf16x8*)(kf + rf_offset(r, p * 8));
+    }
+    for (int i = threadIdx.x; i < LA_TB * 128; i += 256) {
+        const int r = i >> 7, d = i & 127;
+        const int dst = bstate[LA_BST_DST + r];
+        if (dst < 0 || dst >= total_keys) continue;
+        vm[vf_offset(dst, d)] = vf[vf_offset(r, d)];
     }
 }
 
@@ -1150,8 +1265,8 @@ int lk_logits_cand_slots(int V, int rbv) {
     const int nw = (rb == 1 && variant == 1) ? 8 : 4;
     return V / (32 * rb) * (nw / 2);
 }
-int lk_argmax_finalize(hipStream_t st, const float* cv, const int* ci, int n_tiles, int* state) {
-    k_argmax_finalize<<<LA_TB, 256, 0, st>>>(cv, ci, n_tiles, state);
+int lk_argmax_finalize(hipStream_t st, const float* cv, const int* ci, int n_tiles, int* out_rows) {
+    k_argmax_finalize<<<LA_TB, 256, 0, st>>>(cv, ci, n_tiles, out_rows);
     LAUNCH_CHECK(); return 0;
 }
 int lk_embed_norm(hipStream_t st, const void* embed, const int* ids, const void* nw, int hidden, float eps, void* h, void* xp) {
@@ -1185,6 +1300,22 @@ int lk_qkv_post(hipStream_t st, const float* slabs, int n_slabs, int nh, int nkv
 #undef QP
     LAUNCH_CHECK(); return 0;
 }
+static int tree_attn_launch(hipStream_t st, AttnArgs a, int n_slots, void* attn_xp);
+
+int lk_tree_attn_b(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
+                   const void* vfresh, const uint64_t* rowmask, const int* bstate, int nh, int nkv, int slot_keys,
+                   int n_slots, int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp) {
+    if (n_slots < 1 || n_slots > LA_MAX_SEQ || (slot_keys & 31)) return -1;
+    AttnArgs a{};
+    a.qf = (const bf16_t*)qf; a.kmain = (const bf16_t*)kmain; a.vmain = (const bf16_t*)vmain;
+    a.kfresh = (const bf16_t*)kfresh; a.vfresh = (const bf16_t*)vfresh;
+    a.rowmask = (const unsigned long long*)rowmask; a.state = nullptr;
+    a.nh = nh; a.nkv = nkv; a.max_keys = slot_keys * n_slots; a.nsplit = nsplit;
+    a.opart = opart; a.mpart = mpart; a.lpart = lpart;
+    a.seq = bstate + LA_BST_SEQ; a.nkeys_b = bstate + LA_BST_NKEYS; a.slot_tiles = slot_keys >> 5;
+    return tree_attn_launch(st, a, n_slots, attn_xp);
+}
+
 int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                  const void* vfresh, const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys,
                  int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp) {
@@ -1194,11 +1325,18 @@ int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* 
     a.rowmask = (const unsigned long long*)rowmask; a.state = state;
     a.nh = nh; a.nkv = nkv; a.max_keys = max_keys; a.nsplit = nsplit;
     a.opart = opart; a.mpart = mpart; a.lpart = lpart;
+    a.seq = nullptr; a.nkeys_b = nullptr; a.slot_tiles = 0;
+    return tree_attn_launch(st, a, 1, attn_xp);
+}
+
+static int tree_attn_launch(hipStream_t st, AttnArgs a, int n_slots, void* attn_xp) {
+    const int nh = a.nh, nsplit = a.nsplit;
+    float *opart = a.opart, *mpart = a.mpart, *lpart = a.lpart;
     if (lk_gemm64r_init() != 0) return -1;
-    k_tree_attn<<<dim3(nh, nsplit), 2 * LA_ATT_PAR * 64, (LA_ATT_PAR / 2) * 2 * 66 * 64 * sizeof(float), st>>>(a);
+    k_tree_attn<<<dim3(nh, nsplit, n_slots), 2 * LA_ATT_PAR * 64, (LA_ATT_PAR / 2) * 2 * 66 * 64 * sizeof(float), st>>>(a);
     LAUNCH_CHECK();
     int total = nh * LA_TB * 16;
-#define AC(NS) k_attn_combine<NS><<<(total + 255) / 256, 256, 0, st>>>(opart, mpart, lpart, nh, (bf16_t*)attn_xp)
+#define AC(NS) k_attn_combine<NS><<<(total + 255) / 256, 256, 0, st>>>(opart, mpart, lpart, nh, a.seq, (bf16_t*)attn_xp)
     switch (nsplit) {
         case 1: AC(1); break; case 2: AC(2); break; case 3: AC(3); break; case 4: AC(4); break; case 6: AC(6); break;
         case 8: AC(8); break; case 12: AC(12); break; case 16: AC(16); break;
@@ -1209,6 +1347,22 @@ int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* 
 }
 int lk_accept_scan(hipStream_t st, const int* ids, const uint64_t* rowmask, int* state) {
     k_accept_scan<<<1, 64, 0, st>>>(ids, (const unsigned long long*)rowmask, state);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_build_tree_inputs_b(hipStream_t st, const int* in, int* bstate, int* pos, uint64_t* rowmask, int* ids) {
+    k_build_tree_inputs_b<<<1, 64, 0, st>>>(in, bstate, pos, (unsigned long long*)rowmask, ids);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_accept_scan_b(hipStream_t st, const int* in, const int* ids, const uint64_t* rowmask, int* bstate, int n_slots,
+                     int slot_keys) {
+    if (n_slots < 1 || n_slots > LA_MAX_SEQ) return -1;
+    k_accept_scan_b<<<n_slots, 64, 0, st>>>(in, ids, (const unsigned long long*)rowmask, bstate, slot_keys);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_kv_commit_b(hipStream_t st, const void* kfresh, const void* vfresh, void* kmain, void* vmain, const int* bstate,
+                   int n_layers, int nkv, int total_keys) {
+    k_kv_commit_b<<<n_layers * nkv, 256, 0, st>>>((const bf16_t*)kfresh, (const bf16_t*)vfresh, (bf16_t*)kmain,
+                                                  (bf16_t*)vmain, bstate, total_keys);
     LAUNCH_CHECK(); return 0;
 }
 int lk_kv_commit(hipStream_t st, const void* kfresh, const void* vfresh, void* kmain, void* vmain, const int* state,

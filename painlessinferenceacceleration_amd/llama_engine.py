@@ -103,10 +103,12 @@ def random_weights(shape, seed=0, std=0.02, device='cpu', dtype=torch.bfloat16, 
 
 
 class LlamaVerifyEngine(object):
-    """One sequence (bs=1) on one GPU: packed weights + KV cache + the captured step graph."""
+    """One GPU: packed weights + KV cache + the captured step graph.  n_slots = 1: one sequence (the bs=1 loop).
+    n_slots > 1: the cursor-batch path — every slot owns a max_keys region of the KV cache and the 64 rows of a
+    verify block are shared by the active slots (bstep)."""
 
     def __init__(self, shape, state_dict, max_length=2048, device='cuda:0', attn_split=0, gemm_cfg=None,
-                 consume_state_dict=False, balanced=True):
+                 consume_state_dict=False, balanced=True, n_slots=1):
         if not torch.cuda.is_available():
             raise RuntimeError('LlamaVerifyEngine needs an MI355X: the verify step has no CPU fallback')
         self.shape = shape
@@ -219,6 +221,9 @@ class LlamaVerifyEngine(object):
             cfg.gemm_cfg[i] = int(v)
         for i in range(3):
             cfg.balanced_wg[i] = self.balanced_wg[i]
+        assert 1 <= n_slots <= _lib.LA_MAX_SEQ
+        self.n_slots = int(n_slots)
+        cfg.n_slots = self.n_slots
         self._cfg = cfg
         nbytes = lib.la_llama_workspace_bytes(C.byref(cfg))
         if nbytes <= 0:
@@ -232,6 +237,12 @@ class LlamaVerifyEngine(object):
         self._in_np = self.host_in.numpy()
         self._out_np = self.host_out.numpy()
         self._in_rm = self._in_np[_lib.LA_IN_ROWMASK:_lib.LA_IN_ROWMASK + 128].view(np.uint64)
+        self.host_bin = torch.zeros(_lib.LA_BIN_WORDS, dtype=torch.int32).pin_memory()
+        self.host_bout = torch.zeros(_lib.LA_BST_DST, dtype=torch.int32).pin_memory()
+        self._bin_np = self.host_bin.numpy()
+        self._bout_np = self.host_bout.numpy()
+        self._bin_rm = self._bin_np[_lib.LA_BIN_ROWMASK:_lib.LA_BIN_ROWMASK + 128].view(np.uint64)
+        self.slot_keys = [0] * self.n_slots
         self.n_keys = 0
         self.reset()
 
@@ -248,6 +259,84 @@ class LlamaVerifyEngine(object):
     def reset(self):
         check(lib.la_llama_reset(self._h, self._sp()), 'llama_reset')
         self.n_keys = 0
+        self.slot_keys = [0] * self.n_slots
+
+    # ---- cursor batch ------------------------------------------------------------------------------------
+    def reset_slot(self, slot):
+        check(lib.la_llama_reset_slot(self._h, self._sp(), int(slot)), 'reset_slot')
+        if slot < 0:
+            self.slot_keys = [0] * self.n_slots
+        else:
+            self.slot_keys[slot] = 0
+
+    def bstep(self, segments, eager=False):
+        """One verify block shared by several sequences.  segments: list of (slot, ids, local_rowmask, mode, limit);
+        local_rowmask bit j of row i = tree row i sees tree row j OF THE SAME SEGMENT.  Rows are laid out segment after
+        segment (sum of lengths <= 64).  -> {slot: list of emitted tokens}."""
+        a = self._bin_np
+        a[_lib.LA_BIN_SEQ:_lib.LA_BIN_SEQ + 64] = -1
+        a[_lib.LA_BIN_MODE:_lib.LA_BIN_MODE + 16] = 0
+        a[_lib.LA_BIN_LIMIT:_lib.LA_BIN_LIMIT + 16] = 16
+        row = 0
+        seen = set()
+        for slot, ids, rowmask, mode, limit in segments:
+            n = len(ids)
+            assert 0 <= slot < self.n_slots and slot not in seen and n >= 1, 'one segment per slot'
+            seen.add(slot)
+            assert row + n <= _lib.LA_TREE_MAX, 'a verify block holds 64 rows'
+            assert self.slot_keys[slot] + n <= self.max_keys, 'KV cache capacity of the slot exceeded'
+            a[_lib.LA_BIN_IDS + row:_lib.LA_BIN_IDS + row + n] = ids
+            self._bin_rm[row:row + n] = np.asarray(rowmask, dtype=np.uint64) << np.uint64(row)
+            a[_lib.LA_BIN_SEQ + row:_lib.LA_BIN_SEQ + row + n] = slot
+            a[_lib.LA_BIN_MODE + slot] = mode
+            a[_lib.LA_BIN_LIMIT + slot] = max(1, min(16, int(limit)))
+            row += n
+        a[_lib.LA_BIN_T] = row
+        fn = lib.la_llama_bstep_eager if eager else lib.la_llama_bstep
+        check(fn(self._h, self._sp(), self.host_bin.data_ptr(), self.host_bout.data_ptr()), 'llama_bstep')
+        self.stream.synchronize()
+        o = self._bout_np
+        out = {}
+        for slot in seen:
+            n_out = int(o[_lib.LA_BST_NOUT + slot])
+            self.slot_keys[slot] = int(o[_lib.LA_BST_NKEYS + slot])
+            out[slot] = o[_lib.LA_BST_OUTTOK + 16 * slot:_lib.LA_BST_OUTTOK + 16 * slot + n_out].tolist()
+        return out
+
+    def bprefill(self, slot, prompt_ids, eager=False):
+        """Prompt of one slot as chains of <= 64 rows; -> first generated token."""
+        prompt_ids = [int(x) for x in prompt_ids]
+        tok = None
+        for s in range(0, len(prompt_ids), 64):
+            blk = prompt_ids[s:s + 64]
+            tok = self.bstep([(slot, np.asarray(blk, dtype=np.int32), self._CHAIN[:len(blk)], 1, 1)], eager=eager)[slot][0]
+        return tok
+
+    def bprefill_many(self, prompts, eager=False):
+        """prompts: {slot: token list}.  The chains of all slots are packed greedily into shared 64-row blocks (a
+        slot contributes one contiguous run per block and continues in the next).  -> {slot: first generated token}."""
+        todo = {s: [int(x) for x in p] for s, p in prompts.items()}
+        assert all(len(p) > 0 for p in todo.values())
+        done, first = {s: 0 for s in todo}, {}
+        order = sorted(todo)
+        while any(done[s] < len(todo[s]) for s in order):
+            segments, room = [], _lib.LA_TREE_MAX
+            for s in order:
+                left = len(todo[s]) - done[s]
+                if left == 0 or room == 0:
+                    continue
+                n = min(left, room)
+                segments.append((s, np.asarray(todo[s][done[s]:done[s] + n], dtype=np.int32), self._CHAIN[:n], 1, 1))
+                done[s] += n
+                room -= n
+            out = self.bstep(segments, eager=eager)
+            for s, _, _, _, _ in segments:
+                if done[s] == len(todo[s]):
+                    first[s] = out[s][0]
+        return first
+
+    def bstate(self):
+        return self._view(8, _lib.LA_BST_WORDS * 4, torch.int32)
 
     def _fill(self, ids, rowmask, mode):
         T = len(ids)

@@ -253,6 +253,33 @@ class LookaheadCache(object):
             out[i, :, :off + 1] = 1
         return id_list, out, size_list
 
+    def bat_get_packed(self, token_id_list, decoding_length=64, branch_length=8, mode='output', indices=None,
+                       decoding_mode='hier'):
+        """Device-path form of bat_get: the same per-sample drafts (same budget rule, :534-541) as
+        [(ids int32[T_b], rowmask uint64[T_b], sizes)], unpadded and without the [bs,T,W] canvas — the batch engine
+        takes each sample's rows as they are."""
+        assert mode in ('input', 'output', 'mix')
+        assert decoding_mode in ('hier', 'one')
+        bs = len(token_id_list)
+        assert bs == len(indices), f'{bs=} {len(indices)=}'
+        per_sample = decoding_length // bs
+        out = []
+        for sub_idx, token_ids in enumerate(token_id_list):
+            if decoding_mode == 'hier':
+                ids, rowmask, _, sizes = self.hier_get_packed(token_ids, decoding_length=per_sample,
+                                                              branch_length=branch_length, min_input_size=0,
+                                                              min_output_size=max(per_sample // 2, 1), mode=mode,
+                                                              idx=indices[sub_idx])
+                out.append((ids.copy(), rowmask.copy(), sizes))
+            else:
+                lst, _, sizes = self.one_get(token_ids, decoding_length=per_sample, branch_length=branch_length,
+                                             min_input_size=0, min_output_size=max(per_sample // 2, 1), mode=mode,
+                                             idx=indices[sub_idx])
+                n = len(lst)
+                chain = ((np.uint64(2) << np.arange(n, dtype=np.uint64)) - np.uint64(1)).astype(np.uint64)
+                out.append((np.asarray(lst, dtype=np.int32), chain, sizes))
+        return out
+
     # ---- maintenance ---------------------------------------------------------------------------------
     def fresh(self):
         """lookahead_cache.py:563-564."""

@@ -1,0 +1,205 @@
+# -*- coding: utf-8 -*-
+"""Batch (bs>1) lookahead_generation() on the MI355X engine — the twin of
+lookahead/lookahead/common/pretrained_model_batch.py:1002-1330 with the same entry point, arguments and outputs.
+
+What changes on the device side (see include/lookahead_hip.h, "cursor batch"): every sample owns a slot of the KV
+cache; the drafts of all active samples are packed, unpadded, into ONE 64-row verify block (the reference's own budget
+rule — decoding_length // bs per sample, halved again inside bat_get, SURVEY H2 — never asks for more), so the weights
+stream through the CUs once per step for the whole batch.  Per step the host does: one native trie query per sample,
+one la_llama_bstep (forward + per-sample accept walk + KV row moves on device), one native trie update per sample.
+
+Deviation (documented): when decoding_length // active_samples exceeds 64 the per-step budget is clamped to
+the 64 rows of a block; tokens are unaffected (lookahead is lossless), only dls/edls differ from the reference there.
+"""
+import time
+import warnings
+
+import numpy as np
+import torch
+
+from . import _lib
+from .lookahead_cache import LookaheadCache
+from .lookahead_generation_utils import LookaheadDecoderOnlyOutput
+from .pretrained_model import _max_length_of
+
+_ONE = np.array([1], dtype=np.uint64)
+
+
+class LookaheadPreTrainedModel(object):
+    """Mixin over an object that owns `self.engine` (LlamaVerifyEngine with n_slots >= batch size)."""
+
+    engine = None
+    generation_config = None
+
+    def lookahead_prepare_inputs_for_generation(self, rows, batch_indices, decoding_kwargs):
+        """pretrained_model_batch.py:706-743: per-sample drafts for the last two tokens at each cursor.
+        -> list of (ids int32[T_b], rowmask uint64[T_b]) in batch order."""
+        decoding_length = decoding_kwargs.get('decoding_length', 64)
+        branch_length = decoding_kwargs.get('branch_length', 12)
+        decoding_mode = decoding_kwargs.get('decoding_mode', 'hier')
+        qids = [r[-2:] for r in rows]
+        if decoding_mode in ('hier', 'par', 'one'):
+            decoding_mode = decoding_mode + '_mix'
+        fmt, mode = decoding_mode.split('_')
+        sub = max(decoding_length // len(qids), 1)
+        if sub > _lib.LA_TREE_MAX:
+            if not decoding_kwargs.get('_warned_budget'):
+                warnings.warn(f'decoding_length // batch = {sub} > 64 rows of a verify block: draft budget clamped to 64')
+                decoding_kwargs['_warned_budget'] = True
+            sub = _lib.LA_TREE_MAX
+        ts = time.time()
+        drafts = self.lookahead_cache.bat_get_packed(qids, decoding_length=sub, branch_length=branch_length, mode=mode,
+                                                     indices=batch_indices, decoding_mode=fmt)
+        decoding_kwargs['qts'].append(time.time() - ts)
+        decoding_kwargs.update({'decoding_qids': qids, 'decoding_ids': [d[0] for d in drafts],
+                                'hit_sizes': [d[2] for d in drafts], 'batch_indices': batch_indices})
+        return [(d[0], d[1]) for d in drafts]
+
+    @torch.no_grad()
+    def lookahead_generation(self, input_ids, logits_processor=None, stopping_criteria=None, max_length=None,
+                             pad_token_id=None, eos_token_id=None, output_attentions=None,
+                             output_hidden_states=None, output_scores=None, return_dict_in_generate=None,
+                             synced_gpus=False, streamer=None, **model_kwargs):
+        if logits_processor is not None and len(logits_processor) > 0:
+            raise NotImplementedError('non-empty logits_processor lists need the sequential accept path (SURVEY H7)')
+        if output_scores or output_attentions or output_hidden_states:
+            raise NotImplementedError('scores/attentions/hidden_states are not produced by the device path (SURVEY H8)')
+        gc = self.generation_config
+        pad_token_id = pad_token_id if pad_token_id is not None else getattr(gc, 'pad_token_id', None)
+        eos_token_id = eos_token_id if eos_token_id is not None else getattr(gc, 'eos_token_id', None)
+        if isinstance(eos_token_id, int):
+            eos_token_id = [eos_token_id]
+        return_dict_in_generate = bool(return_dict_in_generate) if return_dict_in_generate is not None \
+            else bool(getattr(gc, 'return_dict_in_generate', False))
+        if not hasattr(self, 'lookahead_cache') or self.lookahead_cache is None:
+            self.lookahead_cache = LookaheadCache()
+        decoding_kwargs = model_kwargs['decoding_kwargs']
+        self.lookahead_cache.eos_ids = eos_token_id
+        self.lookahead_cache.stop_words = decoding_kwargs.get('stop_words', {})
+        pad = pad_token_id if pad_token_id is not None else 2
+        decoding_kwargs.update({'pad': pad, 'edls': [], 'dls': [], 'fts': [], 'qts': []})
+        stop_max_length = _max_length_of(stopping_criteria, max_length)
+        if stop_max_length is None:
+            raise ValueError('lookahead_generation needs a MaxLengthCriteria (stopping_criteria.max_length)')
+        decoding_length = decoding_kwargs.get('decoding_length', 63)
+        decoding_kwargs['max_length'] = stop_max_length
+        decoding_kwargs['decoding_max_length'] = stop_max_length + decoding_length + 1
+        branch_length = decoding_kwargs.get('branch_length', 8)
+
+        out_device = input_ids.device
+        ids0 = input_ids.cpu().numpy().astype(np.int64)
+        bs, P = ids0.shape
+        attention_mask = model_kwargs.get('attention_mask', None)
+        if attention_mask is None:
+            am = np.ones_like(ids0)
+        elif attention_mask.dim() == 2:
+            am = attention_mask.cpu().numpy().astype(np.int64)
+        else:
+            raise ValueError(f'unsupport attention_mask.shape:{attention_mask.shape}')
+        eng = self.engine
+        assert bs <= eng.n_slots, f'batch of {bs} needs an engine with n_slots >= {bs} (has {eng.n_slots})'
+        assert stop_max_length + 64 + 1 <= eng.max_keys, f'engine KV capacity {eng.max_keys} per slot is too small'
+        for i in range(bs):                                                     # :1204-1207 (pads included, as there)
+            self.lookahead_cache.put(ids0[i, 1:-1].tolist(), branch_length=branch_length + 1, mode='input', idx=i)
+        rows = [ids0[i].tolist() for i in range(bs)]      # padded-coordinate token rows; cursor = len(row) - 1
+        finished_rows = [None] * bs
+        batch_indices = list(range(bs))
+        eos_set = set(eos_token_id) if eos_token_id is not None else set()
+        ts = time.time()
+        eng.reset_slot(-1)
+        # prefill: valid prompt tokens of every sample, packed into shared 64-row chain blocks
+        first = eng.bprefill_many({i: ids0[i][am[i] == 1].tolist() for i in range(bs)})
+        next_token_list = [[first[i]] for i in range(bs)]
+        decoding_kwargs['dls'].extend([1] * bs)
+        decoding_kwargs['edls'].extend([1] * bs)
+        max_cur = 0
+        while True:
+            for k, b in enumerate(batch_indices):
+                rows[b].extend(next_token_list[k])
+            if streamer is not None:
+                streamer.put(np.array(next_token_list[0]))
+            for k, b in enumerate(batch_indices):                               # :1254-1259
+                self.lookahead_cache.stream_put([x for x in next_token_list[k] if x != -1], branch_length=branch_length + 1,
+                                                final=False, mode='output', idx=b)
+            max_cur = max(max_cur, max(len(rows[b]) - 1 for b in batch_indices))
+            keep = []
+            for k, b in enumerate(batch_indices):                               # :1269-1276 + _early_stop :937-980
+                if len(rows[b]) >= stop_max_length or any(t in eos_set for t in next_token_list[k]):
+                    finished_rows[b] = list(rows[b])
+                else:
+                    keep.append(b)
+            batch_indices = keep
+            te = time.time()
+            decoding_kwargs['fts'].append(te - ts)
+            ts = te
+            if not batch_indices:
+                break
+            drafts = self.lookahead_prepare_inputs_for_generation([rows[b] for b in batch_indices], batch_indices,
+                                                                  decoding_kwargs)
+            segments = []
+            for b, (d_ids, d_rm) in zip(batch_indices, drafts):
+                if len(d_ids) == 0:
+                    d_ids, d_rm = np.asarray(rows[b][-1:], dtype=np.int32), _ONE
+                cur = len(rows[b]) - 1
+                segments.append((b, d_ids, d_rm, 0, stop_max_length - cur - 1))
+            emitted = eng.bstep(segments)
+            width = max(len(sg[1]) for sg in segments)
+            next_token_list = [emitted[b] for b in batch_indices]
+            for k in range(len(batch_indices)):
+                decoding_kwargs['dls'].append(width)
+                decoding_kwargs['edls'].append(len(next_token_list[k]))
+        for i in range(bs):                                                     # :1288-1290
+            self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=i)
+        if streamer is not None:
+            streamer.end()
+        seqs = np.full((bs, max_cur + 1), pad, dtype=np.int64)
+        for b in range(bs):
+            r = finished_rows[b][:max_cur + 1]
+            seqs[b, :len(r)] = r
+        sequences = torch.from_numpy(seqs).to(out_device)
+        if return_dict_in_generate:
+            kwargs = {k: decoding_kwargs[k] for k in ('dls', 'edls', 'fts', 'qts')}
+            return LookaheadDecoderOnlyOutput(sequences=sequences, scores=None, attentions=None, hidden_states=None,
+                                              kwargs=kwargs)
+        return sequences
+
+    @torch.no_grad()
+    def greedy_search(self, input_ids, max_length, attention_mask=None, eos_token_id=None, pad_token_id=0):
+        """Plain greedy decoding of the whole batch through the same engine (one row per sample per block)."""
+        ids0 = input_ids.cpu().numpy().astype(np.int64)
+        bs, P = ids0.shape
+        am = np.ones_like(ids0) if attention_mask is None else attention_mask.cpu().numpy().astype(np.int64)
+        eos = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
+        eng = self.engine
+        eng.reset_slot(-1)
+        first = eng.bprefill_many({i: ids0[i][am[i] == 1].tolist() for i in range(bs)})
+        rows = [ids0[i].tolist() + [first[i]] for i in range(bs)]
+        live = [b for b in range(bs) if len(rows[b]) < max_length and rows[b][-1] not in eos]
+        while live:
+            out = eng.bstep([(b, np.asarray(rows[b][-1:], dtype=np.int32), _ONE, 0, 1) for b in live])
+            for b in live:
+                rows[b].append(out[b][0])
+            live = [b for b in live if len(rows[b]) < max_length and rows[b][-1] not in eos]
+        L = max(len(r) for r in rows)
+        seqs = np.full((bs, L), pad_token_id, dtype=np.int64)
+        for b in range(bs):
+            seqs[b, :len(rows[b])] = rows[b]
+        return torch.from_numpy(seqs).to(input_ids.device)
+
+    def generate(self, input_ids=None, attention_mask=None, max_length=None, max_new_tokens=None,
+                 decoding_kwargs=None, eos_token_id=None, pad_token_id=None, return_dict_in_generate=False,
+                 streamer=None, do_sample=False, repetition_penalty=1.0, **unused):
+        if do_sample or repetition_penalty != 1.0:
+            raise NotImplementedError('sampling / repetition penalty are outside the parity scope (SURVEY H7)')
+        if max_length is None:
+            max_length = input_ids.size(1) + (max_new_tokens if max_new_tokens is not None else 20)
+        dk = dict(decoding_kwargs or {})
+        if dk.get('use_lookahead', False) and dk.get('decoding_length', 64) > 1 and dk.get('branch_length', 12) > 0:
+            return self.lookahead_generation(input_ids, stopping_criteria=int(max_length), pad_token_id=pad_token_id,
+                                             eos_token_id=eos_token_id, return_dict_in_generate=return_dict_in_generate,
+                                             streamer=streamer, attention_mask=attention_mask, decoding_kwargs=dk)
+        out = self.greedy_search(input_ids, max_length, attention_mask=attention_mask,
+                                 eos_token_id=eos_token_id if eos_token_id is not None
+                                 else getattr(self.generation_config, 'eos_token_id', None),
+                                 pad_token_id=pad_token_id if pad_token_id is not None else 0)
+        return LookaheadDecoderOnlyOutput(sequences=out, kwargs={}) if return_dict_in_generate else out

