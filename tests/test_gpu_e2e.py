@@ -174,6 +174,31 @@ def test_llama7b_shape_two_layers_vs_oracle():
     _check_rows(eng.logits(), lg, range(T), '7b-shape tree')
 
 
+@pytest.mark.parametrize('name,dims', [('llama2-13b', (5120, 40, 40, 13824, 32000)), ('mistral-7b', (4096, 32, 8, 14336, 32000))])
+def test_other_config_shapes_two_layers_vs_oracle(name, dims):
+    """GEMM / attention shapes of BASELINE configs 3-4 (Llama-2-13B: hidden 5120, 40 heads, ffn 13824; Mistral-7B:
+    8 kv heads, ffn 14336) on a 2-layer model: prefill block and a 64-row tree step against the oracle."""
+    hidden, nh, nkv, ffn, vocab = dims
+    shape = LlamaShape(2, hidden, nh, nkv, ffn, vocab, 1e-5)
+    from painlessinferenceacceleration_amd.llama_engine import random_weights
+    sd = random_weights(shape, seed=3, std=0.02, device='cpu')
+    eng = LlamaVerifyEngine(shape, sd, max_length=256)
+    oracle = lo.OracleLlama(shape, sd)
+    rs = np.random.RandomState(6)
+    prompt = rs.randint(3, vocab, size=40).tolist()
+    tok = eng.prefill(prompt)
+    lg0, past = oracle.forward(torch.tensor(prompt), torch.tril(torch.ones((40, 40), dtype=torch.long)), None)
+    _check_rows(eng.logits()[:40], lg0, range(40), name + ' prefill')
+    T = 64
+    _, rows = random_tree(rs, T)
+    ids = np.concatenate([[tok], rs.randint(3, vocab, size=T - 1)]).astype(np.int32)
+    eng.step(ids, rows)
+    full = torch.cat([torch.ones((T, 40), dtype=torch.long), torch.from_numpy(_mask_from_rows(rows, T))], 1)
+    lg, _ = oracle.forward(torch.tensor(ids.tolist()), full, past)
+    _check_rows(eng.logits(), lg, range(T), name + ' tree')
+    print(name, 'balanced workgroups (qkv, gate/up, lm_head):', eng.balanced_wg)
+
+
 def test_gqa_engine_vs_oracle():
     """Mistral-style grouped-query attention (8 query heads on 2 kv heads)."""
     cfg = dict(n_layers=2, hidden=256, n_heads=8, n_kv_heads=2, ffn=512, vocab=512, head_dim=128)
