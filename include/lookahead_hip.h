@@ -40,6 +40,7 @@ extern "C" {
 #define LA_MODE_MIX      2
 
 #define LA_TREE_MAX     64   /* tree tokens per sequence handled by the device path  */
+#define LA_MOE_MAX_E      8   /* experts per mixture-of-experts layer (Mixtral: 8, top-2) */
 
 /* ABI version: bumped when a signature changes. */
 int          la_abi_version(void);
@@ -227,6 +228,10 @@ typedef struct la_llama_config {
     int32_t balanced_wg[3];  /* {qkv, gate/up, lm_head}: > 0 = weights were packed with la_rowplan for that many workgroups */
     int32_t n_slots;         /* sequence slots of the cursor-batch path (0/1 = single sequence); each slot owns a
                                 max_keys region of the main KV cache */
+    int32_t n_experts;       /* > 0: Mixtral-style sparse MoE MLP (mixtral/modeling_mixtral.py:692-759), <= LA_MOE_MAX_E */
+    int32_t top_k;           /* experts per token (Mixtral: 2) */
+    int32_t norm_cast_first; /* RMSNorm flavour: 0 = LlamaRMSNorm (llama/modeling_llama.py:86-90, one rounding), 1 = Mistral/
+                                MixtralRMSNorm (mixtral/modeling_mixtral.py:160-165, normalised value rounded first) */
 } la_llama_config;
 
 typedef struct la_llama_layer_weights {   /* device pointers, packed by la_pack_weight */
@@ -236,6 +241,10 @@ typedef struct la_llama_layer_weights {   /* device pointers, packed by la_pack_
     const void* wdown;       /* [hidden][ffn]                  */
     const void* norm1;       /* input_layernorm weight bf16 [hidden]          */
     const void* norm2;       /* post_attention_layernorm weight bf16 [hidden] */
+    /* n_experts > 0 (wgateup / wdown above are then unused): */
+    const void* router;              /* block_sparse_moe.gate weight, bf16 [n_experts][hidden] row-major        */
+    const void* const* ex_gateup;    /* host array [n_experts]: packed interleaved w1/w3 of each expert         */
+    const void* const* ex_down;      /* host array [n_experts]: packed w2 of each expert                        */
 } la_llama_layer_weights;
 
 typedef struct la_llama_weights {
@@ -272,6 +281,20 @@ void* la_llama_buffer(la_llama* m, int which);
  * steps; the sequence state is saved and restored, so the context does not advance. */
 int la_llama_profile(la_llama* m, void* stream, const int32_t* host_in, int iters,
                      float* out_ms /*[8]*/, int32_t* out_launches /*[7] or NULL*/);
+
+/* ---- mixture of experts (Mixtral) row stages; the expert GEMMs are the la_gemm64* kernels launched once per expert
+ * with an early exit when no row routes to that expert ------------------------------------------------------- */
+/* post-attention residual + RMSNorm with the router fused: route_w[64][LA_MOE_MAX_E] fp32 (bf16-valued, 0 = not routed);
+ * rows >= *d_n_rows get no expert. */
+int la_resid_norm_router(void* stream, void* d_h, const float* d_slabs, int n_slabs, const void* d_norm_w, int hidden,
+                         float eps, void* d_xp, const void* d_router_w, int n_experts, int top_k, float* d_route_w,
+                         const int32_t* d_n_rows);
+/* acc[t] (+)= bf16(bf16(sum slabs[t]) * route_w[t][expert]) for routed rows; first != 0 zero-fills first. */
+int la_moe_accum(void* stream, const float* d_slabs, int n_slabs, const float* d_route_w, int expert, int hidden,
+                 void* d_acc, int first);
+/* h = bf16(h + addend); xp = RMSNorm(h) packed. */
+int la_resid_norm_addend(void* stream, void* d_h, const void* d_addend, const void* d_norm_w, int hidden, float eps,
+                         void* d_xp);
 
 /* ---- cursor batch (bs>1): several sequences share the 64 rows of one verify block --------------------------------
  * Replaces the batch twin of the loop: bat_get's padded drafts + [bs,T,W] masks (lookahead_cache.py:519-561,

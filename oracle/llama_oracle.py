@@ -8,6 +8,8 @@ scan and the bs=1 lookahead loop of alipay/PainlessInferenceAcceleration.
   accept scan  lookahead/lookahead/common/pretrained_model.py:764-892
   KV keep set  pretrained_model.py:865-875, 894-907
   loop         pretrained_model.py:947-1268 (+ 666-756 draft retrieval)
+  GQA / MoE    models/mistral/modeling_mistral.py:236-318 (repeat_kv attention); models/mixtral/modeling_mixtral.py:
+               668-759 (expert MLP + router)
   batch twin   models/llama/modeling_llama_batch.py:121-138, 190-201, 297-323, 340-420, 913-915 (forward);
                common/pretrained_model_batch.py:664-759, 767-935, 937-999, 1002-1330 (loop)
 
@@ -28,8 +30,12 @@ import torch
 
 
 # ------------------------------------------------------------------------------------------ forward
-def _rms(x, w, eps):
+def _rms(x, w, eps, cast_first=False):
+    """LlamaRMSNorm (models/llama/modeling_llama.py:86-90): one rounding, (w * (x * rsqrt)).to(dtype).  cast_first:
+    Mistral/MixtralRMSNorm (models/mixtral/modeling_mixtral.py:160-165): w * (x_fp32 * rsqrt).to(dtype), two roundings."""
     var = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
+    if cast_first:
+        return w * (x.to(torch.float32) * torch.rsqrt(var + eps)).to(x.dtype)
     return (w * (x * torch.rsqrt(var + eps))).to(x.dtype)
 
 
@@ -68,9 +74,10 @@ class OracleLlama(object):
         cos, sin = _rope_cos_sin(pos[0], hd, s.rope_theta, dt)
         cos, sin = cos[None, None], sin[None, None]
         new_past = []
+        cf = bool(getattr(s, 'norm_cast_first', False))
         for i in range(s.n_layers):
             p = f'model.layers.{i}.'
-            x = _rms(h, w[p + 'input_layernorm.weight'], s.rms_eps)
+            x = _rms(h, w[p + 'input_layernorm.weight'], s.rms_eps, cf)
             q = lin(x, w[p + 'self_attn.q_proj.weight']).view(1, T, nh, hd).transpose(1, 2)
             k = lin(x, w[p + 'self_attn.k_proj.weight']).view(1, T, nkv, hd).transpose(1, 2)
             v = lin(x, w[p + 'self_attn.v_proj.weight']).view(1, T, nkv, hd).transpose(1, 2)
@@ -91,12 +98,38 @@ class OracleLlama(object):
             att = torch.softmax(att, dim=-1, dtype=torch.float32).to(dt)
             o = torch.matmul(att, vv).transpose(1, 2).reshape(1, T, nh * hd)
             h = h + lin(o, w[p + 'self_attn.o_proj.weight'])
-            x = _rms(h, w[p + 'post_attention_layernorm.weight'], s.rms_eps)
-            g = torch.nn.functional.silu(lin(x, w[p + 'mlp.gate_proj.weight']))
-            u = lin(x, w[p + 'mlp.up_proj.weight'])
-            h = h + lin(g * u, w[p + 'mlp.down_proj.weight'])
-        h = _rms(h, w['model.norm.weight'], s.rms_eps)
+            x = _rms(h, w[p + 'post_attention_layernorm.weight'], s.rms_eps, cf)
+            if getattr(s, 'n_experts', 0) > 0:
+                h = h + self._moe(x, p)
+            else:
+                g = torch.nn.functional.silu(lin(x, w[p + 'mlp.gate_proj.weight']))
+                u = lin(x, w[p + 'mlp.up_proj.weight'])
+                h = h + lin(g * u, w[p + 'mlp.down_proj.weight'])
+        h = _rms(h, w['model.norm.weight'], s.rms_eps, cf)
         return lin(h, w['lm_head.weight'])[0], new_past
+
+    def _moe(self, x, p):
+        """MixtralSparseMoeBlock.forward (mixtral/modeling_mixtral.py:717-759): router logits in the activation dtype,
+        softmax in fp32, top-k, renormalise, cast back; experts visited in index order, each adding
+        w2(silu(w1 x) * w3 x) * routing_weight for its rows into a zero buffer of the activation dtype (index_add_)."""
+        s, w = self.s, self.w
+        lin = torch.nn.functional.linear
+        xs = x.reshape(-1, x.shape[-1])
+        logits = lin(xs, w[p + 'block_sparse_moe.gate.weight'])
+        rw = torch.softmax(logits, dim=1, dtype=torch.float)
+        rw, sel = torch.topk(rw, s.top_k, dim=-1)
+        rw = (rw / rw.sum(dim=-1, keepdim=True)).to(xs.dtype)
+        out = torch.zeros_like(xs)
+        self.last_router_logits = logits
+        for e in range(s.n_experts):
+            slot, rows = torch.where((sel == e).t())
+            if rows.shape[0] == 0:
+                continue
+            q = p + f'block_sparse_moe.experts.{e}.'
+            cur = xs[rows]
+            y = lin(torch.nn.functional.silu(lin(cur, w[q + 'w1.weight'])) * lin(cur, w[q + 'w3.weight']), w[q + 'w2.weight'])
+            out.index_add_(0, rows, (rw[rows, slot, None] * y).to(xs.dtype))
+        return out.reshape(x.shape)
 
 
 # -------------------------------------------------------------------------------------- accept scan

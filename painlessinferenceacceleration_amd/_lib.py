@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "liblookahead_hip.so")
 LA_OK = 0
 LA_MODE_INPUT, LA_MODE_OUTPUT, LA_MODE_MIX = 0, 1, 2
 LA_TREE_MAX = 64
+LA_MOE_MAX_E = 8
 # device step-state words (include/lookahead_hip.h)
 LA_ST_NKEYS, LA_ST_T, LA_ST_MODE, LA_ST_NOUT, LA_ST_DSTBASE, LA_ST_NCOMMIT, LA_ST_MAXKEYS = 0, 1, 2, 3, 4, 5, 6
 LA_ST_OUTTOK, LA_ST_SRCIDX, LA_ST_ARGMAX, LA_ST_WORDS = 8, 72, 136, 200
@@ -69,11 +70,13 @@ pi32, pi64, pu64, pf32 = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C
 class LlamaConfigC(C.Structure):
     _fields_ = [("n_layers", i32), ("hidden", i32), ("n_heads", i32), ("n_kv_heads", i32), ("head_dim", i32),
                 ("ffn", i32), ("vocab", i32), ("max_keys", i32), ("max_pos", i32), ("attn_split", i32),
-                ("rms_eps", f32), ("gemm_cfg", i32 * 8), ("balanced_wg", i32 * 3), ("n_slots", i32)]
+                ("rms_eps", f32), ("gemm_cfg", i32 * 8), ("balanced_wg", i32 * 3), ("n_slots", i32),
+                ("n_experts", i32), ("top_k", i32), ("norm_cast_first", i32)]
 
 
 class LlamaLayerWeightsC(C.Structure):
-    _fields_ = [("wqkv", vp), ("wo", vp), ("wgateup", vp), ("wdown", vp), ("norm1", vp), ("norm2", vp)]
+    _fields_ = [("wqkv", vp), ("wo", vp), ("wgateup", vp), ("wdown", vp), ("norm1", vp), ("norm2", vp),
+                ("router", vp), ("ex_gateup", C.POINTER(vp)), ("ex_down", C.POINTER(vp))]
 
 
 class LlamaWeightsC(C.Structure):
@@ -139,6 +142,9 @@ PROTOTYPES = {
     "la_llama_step_eager": (i32, vp, vp, vp, vp),
     "la_llama_buffer": (vp, vp, i32),
     "la_llama_profile": (i32, vp, vp, vp, i32, pf32, pi32),
+    "la_resid_norm_router": (i32, vp, vp, vp, i32, vp, i32, f32, vp, vp, i32, i32, vp, vp),
+    "la_moe_accum": (i32, vp, vp, i32, vp, i32, i32, vp, i32),
+    "la_resid_norm_addend": (i32, vp, vp, vp, vp, i32, f32, vp),
     "la_build_batch_inputs": (i32, vp, vp, vp, vp, vp, vp),
     "la_accept_scan_batch": (i32, vp, vp, vp, vp, vp, i32, i32),
     "la_kv_commit_batch": (i32, vp, vp, vp, vp, vp, vp, i32, i32, i32),

@@ -120,6 +120,22 @@ int la_tree_attn(void* stream, const void* qf, const void* km, const void* vm, c
                       mpart, lpart, attn_xp));
 }
 
+int la_resid_norm_router(void* stream, void* h, const float* slabs, int n_slabs, const void* nw, int hidden, float eps,
+                         void* xp, const void* wr, int n_experts, int top_k, float* route_w, const int32_t* n_rows) {
+    if (!h || !slabs || !nw || !xp || !wr || !route_w || !n_rows || n_experts < 1 || n_experts > LA_MOE_MAX_E ||
+        top_k < 1 || top_k > n_experts) return LA_E_ARG;
+    WRAP(lk_resid_norm_router((hipStream_t)stream, h, slabs, n_slabs, nw, hidden, eps, xp, wr, n_experts, top_k, route_w, n_rows, 1));
+}
+int la_moe_accum(void* stream, const float* slabs, int n_slabs, const float* route_w, int expert, int hidden, void* acc,
+                 int first) {
+    if (!slabs || !route_w || !acc || expert < 0 || expert >= LA_MOE_MAX_E) return LA_E_ARG;
+    WRAP(lk_moe_accum((hipStream_t)stream, slabs, n_slabs, route_w + expert, hidden, acc, first));
+}
+int la_resid_norm_addend(void* stream, void* h, const void* addend, const void* nw, int hidden, float eps, void* xp) {
+    if (!h || !addend || !nw || !xp) return LA_E_ARG;
+    WRAP(lk_resid_norm_addend((hipStream_t)stream, h, addend, nw, hidden, eps, xp, 1));
+}
+
 int la_build_batch_inputs(void* stream, const int32_t* d_in, int32_t* d_bstate, int32_t* d_pos, uint64_t* d_rowmask,
                           int32_t* d_ids) {
     if (!d_in || !d_bstate || !d_pos || !d_rowmask || !d_ids) return LA_E_ARG;

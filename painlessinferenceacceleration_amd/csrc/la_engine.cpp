@@ -18,6 +18,9 @@ extern void la_set_error(const std::string& s);
 struct la_llama {
     la_llama_config cfg;
     std::vector<la_llama_layer_weights> layers;
+    std::vector<const void*> ex_gateup, ex_down;     // [n_layers][n_experts] copies of the caller's pointer arrays
+    uint16_t* moe_acc;
+    float* route_w;
     la_llama_weights w;
     // derived
     int qkv_n, o_k, nsplit;
@@ -108,6 +111,8 @@ static size_t carve(la_llama* m, char* base) {
     m->rowmask = cv.take<uint64_t>(64);
     m->bstate = cv.take<int>(LA_BST_WORDS);
     m->bin = cv.take<int>(LA_BIN_WORDS);
+    m->moe_acc = cv.take<uint16_t>(c.n_experts > 0 ? (size_t)64 * c.hidden : 8);
+    m->route_w = cv.take<float>(64 * LA_MOE_MAX_E);
     return align_up(cv.off, 256);
 }
 
@@ -115,7 +120,8 @@ static int validate(const la_llama_config* c) {
     if (!c) return LA_E_ARG;
     if (c->head_dim != 128) { la_set_error("head_dim must be 128"); return LA_E_ARG; }
     if (c->n_layers <= 0 || c->hidden % 32 || c->hidden > 8192 || c->ffn % 32 || c->vocab % 32 ||
-        c->n_heads % c->n_kv_heads || c->max_keys % 32 || c->max_keys < 96 || c->n_slots < 0 || c->n_slots > LA_MAX_SEQ) {
+        c->n_heads % c->n_kv_heads || c->max_keys % 32 || c->max_keys < 96 || c->n_slots < 0 || c->n_slots > LA_MAX_SEQ ||
+        c->n_experts < 0 || c->n_experts > LA_MOE_MAX_E || (c->n_experts > 0 && (c->top_k < 1 || c->top_k > c->n_experts))) {
         la_set_error("unsupported llama config (need hidden%32==0<=8192, ffn%32==0, vocab%32==0, max_keys%32==0)");
         return LA_E_ARG;
     }
@@ -146,6 +152,13 @@ extern "C" la_llama* la_llama_create(const la_llama_config* cfg, const la_llama_
     m->w = *w;
     m->layers.assign(w->layers, w->layers + cfg->n_layers);
     m->w.layers = m->layers.data();
+    if (cfg->n_experts > 0) {
+        for (int l = 0; l < cfg->n_layers; ++l) {
+            const la_llama_layer_weights& L = w->layers[l];
+            if (!L.router || !L.ex_gateup || !L.ex_down) { la_set_error("MoE layer without router/expert weights"); delete m; return nullptr; }
+            for (int e = 0; e < cfg->n_experts; ++e) { m->ex_gateup.push_back(L.ex_gateup[e]); m->ex_down.push_back(L.ex_down[e]); }
+        }
+    }
     resolve_cfg(m);
     size_t need = carve(m, (char*)ws);
     if ((int64_t)need > ws_bytes) { la_set_error("workspace too small"); delete m; return nullptr; }
@@ -207,7 +220,8 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
     P(KC_OTHER);
     if (batch) KCHK(lk_build_tree_inputs_b(st, m->bin, m->bstate, m->pos, m->rowmask, m->ids));
     else KCHK(lk_build_tree_inputs(st, m->in, m->state, m->pos, m->rowmask, m->ids));
-    KCHK(lk_embed_norm(st, m->w.embed, m->ids, m->layers[0].norm1, c.hidden, c.rms_eps, m->h, m->xp));
+    const int cf = c.norm_cast_first;
+    KCHK(lk_embed_norm(st, m->w.embed, m->ids, m->layers[0].norm1, c.hidden, c.rms_eps, m->h, m->xp, cf));
     for (int l = 0; l < c.n_layers; ++l) {
         const la_llama_layer_weights& L = m->layers[l];
         uint16_t* kf = m->kfresh + (size_t)l * m->fresh_layer_elems;
@@ -237,15 +251,35 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
         P(KC_O);
         KCHK(lk_gemm64_slab(st, L.wo, m->attn_xp, c.hidden, m->o_k, m->o_rb, m->o_ks, m->slabs));
         P(KC_OTHER);
-        KCHK(lk_resid_norm(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp));
+        const void* nw = (l + 1 < c.n_layers) ? m->layers[l + 1].norm1 : m->w.final_norm;
+        if (c.n_experts > 0) {
+            // sparse MoE MLP: router fused into the norm, then per expert {gate/up+SwiGLU, down, weighted accumulate};
+            // an expert no row routes to costs three empty launches and no weight traffic
+            KCHK(lk_resid_norm_router(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp, L.router, c.n_experts,
+                                      c.top_k, m->route_w, batch ? m->bin + LA_BIN_T : m->state + LA_ST_T, cf));
+            for (int e = 0; e < c.n_experts; ++e) {
+                const float* col = m->route_w + e;
+                const void* wgu = m->ex_gateup[(size_t)l * c.n_experts + e];
+                const void* wdn = m->ex_down[(size_t)l * c.n_experts + e];
+                P(KC_GATEUP);
+                if (c.balanced_wg[1] > 0) KCHK(lk_gemm64r_swiglu(st, wgu, m->xp, c.ffn, c.hidden, c.balanced_wg[1], m->act_xp, col));
+                else KCHK(lk_gemm64_swiglu(st, wgu, m->xp, c.ffn, c.hidden, m->act_xp, m->gu_variant, col));
+                P(KC_DOWN);
+                KCHK(lk_gemm64_slab(st, wdn, m->act_xp, c.hidden, c.ffn, m->down_rb, m->down_ks, m->slabs, col));
+                P(KC_OTHER);
+                KCHK(lk_moe_accum(st, m->slabs, m->down_ks, col, c.hidden, m->moe_acc, e == 0));
+            }
+            KCHK(lk_resid_norm_addend(st, m->h, m->moe_acc, nw, c.hidden, c.rms_eps, m->xp, cf));
+            continue;
+        }
+        KCHK(lk_resid_norm(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp, cf));
         P(KC_GATEUP);
         if (c.balanced_wg[1] > 0) KCHK(lk_gemm64r_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, c.balanced_wg[1], m->act_xp));
         else KCHK(lk_gemm64_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, m->act_xp, m->gu_variant));
         P(KC_DOWN);
         KCHK(lk_gemm64_slab(st, L.wdown, m->act_xp, c.hidden, c.ffn, m->down_rb, m->down_ks, m->slabs));
         P(KC_OTHER);
-        const void* nw = (l + 1 < c.n_layers) ? m->layers[l + 1].norm1 : m->w.final_norm;
-        KCHK(lk_resid_norm(st, m->h, m->slabs, m->down_ks, nw, c.hidden, c.rms_eps, m->xp));
+        KCHK(lk_resid_norm(st, m->h, m->slabs, m->down_ks, nw, c.hidden, c.rms_eps, m->xp, cf));
     }
     P(KC_LMHEAD);
     int* am_rows = batch ? m->bstate + LA_BST_ARGMAX : m->state + LA_ST_ARGMAX;

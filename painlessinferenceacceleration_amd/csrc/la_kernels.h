@@ -7,8 +7,10 @@
 
 int lk_pack_weight(hipStream_t st, const void* w, const void* w2, int N, int K, int interleave2, void* out);
 int lk_pack_x(hipStream_t st, const void* x, int K, void* out);
-int lk_gemm64_slab(hipStream_t st, const void* wp, const void* xp, int N, int K, int rb, int ksplit, float* slabs);
-int lk_gemm64_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, void* act_xp, int variant);
+int lk_gemm64_slab(hipStream_t st, const void* wp, const void* xp, int N, int K, int rb, int ksplit, float* slabs,
+                   const float* route_col = nullptr);
+int lk_gemm64_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, void* act_xp, int variant,
+                     const float* route_col = nullptr);
 int lk_gemm64_logits(hipStream_t st, const void* wp, const void* xp, int V, int K, int rb, void* logits, float* cv, int* ci);
 int lk_logits_cand_slots(int V, int rbv);
 int lk_gemm64_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int nkv, int K, const int* pos, const void* rcos,
@@ -18,13 +20,22 @@ int lk_gemm64r_init();
 int lk_rowplan(int kind, int n_rows, int n_wg, int* out);
 long lk_planned_elems(int kind, int n_rows, int K, int n_wg);
 int lk_pack_planned(hipStream_t st, const void* w, const void* w2, const int* d_plan, int kind, int n_rows, int K, int n_wg, void* out);
-int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, int n_wg, void* act_xp);
+int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, int n_wg, void* act_xp,
+                      const float* route_col = nullptr);
 int lk_gemm64r_logits(hipStream_t st, const void* wp, const void* xp, int V, int K, int n_wg, void* logits, float* cv, int* ci);
 int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int nkv, int K, int n_wg, const int* pos,
                    const void* rcos, const void* rsin, void* qf, void* kfresh, void* vfresh);
 int lk_argmax_finalize(hipStream_t st, const float* cv, const int* ci, int n_tiles, int* out_rows);
-int lk_embed_norm(hipStream_t st, const void* embed, const int* ids, const void* nw, int hidden, float eps, void* h, void* xp);
-int lk_resid_norm(hipStream_t st, void* h, const float* slabs, int n_slabs, const void* nw, int hidden, float eps, void* xp);
+int lk_embed_norm(hipStream_t st, const void* embed, const int* ids, const void* nw, int hidden, float eps, void* h, void* xp,
+                  int cast_first = 0);
+int lk_resid_norm(hipStream_t st, void* h, const float* slabs, int n_slabs, const void* nw, int hidden, float eps, void* xp,
+                  int cast_first = 0);
+int lk_resid_norm_router(hipStream_t st, void* h, const float* slabs, int n_slabs, const void* nw, int hidden, float eps,
+                         void* xp, const void* wrouter, int n_experts, int top_k, float* route_w, const int* n_rows,
+                         int cast_first = 0);
+int lk_resid_norm_addend(hipStream_t st, void* h, const void* addend, const void* nw, int hidden, float eps, void* xp,
+                         int cast_first = 0);
+int lk_moe_accum(hipStream_t st, const float* slabs, int n_slabs, const float* route_col, int hidden, void* acc, int first);
 int lk_build_tree_inputs(hipStream_t st, const int* in, int* state, int* pos, uint64_t* rowmask, int* ids);
 int lk_qkv_post(hipStream_t st, const float* slabs, int n_slabs, int nh, int nkv, const int* pos, const void* rcos,
                 const void* rsin, void* qf, void* kfresh, void* vfresh);

@@ -88,11 +88,19 @@ struct GemmArgs {
     bf16_t* kfresh;
     bf16_t* vfresh;
     int nh, nkv;
+    // mixture-of-experts: routing weights of this expert, one float per token row at stride LA_MOE_MAX_E; the whole
+    // launch returns at once when no row routes to the expert (its weights are then never read)
+    const float* route_col;
 };
+
+__device__ __forceinline__ bool expert_unused(const float* route_col) {
+    return route_col != nullptr && __ballot(route_col[(threadIdx.x & 63) * LA_MOE_MAX_E] != 0.f) == 0ull;
+}
 
 template <int RB, int EPI, int D, int NW>
 __global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
     __shared__ float red[NW][RB * 2 * 16 * 64];
+    if (expert_unused(a.route_col)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nb0 = blockIdx.x * RB;
@@ -319,6 +327,7 @@ template <int RB, int EPI, int D, int NW>
 __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
     extern __shared__ __attribute__((aligned(16))) float redr[];      // [NW][RB][16][64]
     const GemmArgs& a = ra.g;
+    if (expert_unused(a.route_col)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nb0 = blockIdx.x * RB;
@@ -521,16 +530,20 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 // h_new = bf16(h + bf16(sum slabs)); x = bf16(w * (h_new * rsqrt(mean(h_new^2)+eps)))  (fp32 math).
 // 512 threads, <= 2 chunks of 8 elements per thread (hidden <= 8192).  NS is a template parameter so that every
 // load of the row (h, NS slabs, norm weight) is issued before the first use: one memory round trip, not NS+2.
-template <int NS>
+template <int NS, bool MOE>
 __global__ __launch_bounds__(512) void k_row_norm(const bf16_t* __restrict__ embed, const int* __restrict__ ids,
                                                    bf16_t* __restrict__ h, const float* __restrict__ slabs,
                                                    const bf16_t* __restrict__ nw, int hidden, float eps,
-                                                   bf16_t* __restrict__ xp) {
+                                                   bf16_t* __restrict__ xp, const bf16_t* __restrict__ addend,
+                                                   const bf16_t* __restrict__ wrouter, int n_experts, int top_k,
+                                                   float* __restrict__ route_w, const int* __restrict__ n_rows,
+                                                   int cast_first) {
     __shared__ float sh[8];
+    __shared__ float shr[MOE ? 8 : 1][LA_MOE_MAX_E];
     const int t = blockIdx.x;
     const int nchunk = hidden >> 3;
     const bf16_t* src = embed ? embed + (size_t)ids[t] * hidden : h + (size_t)t * hidden;
-    bf16x8 hv[2], wv[2];
+    bf16x8 hv[2], wv[2], av[2];
     f32x4 sl[NS > 0 ? NS : 1][2][2];
 #pragma unroll
     for (int ci = 0; ci < 2; ++ci) {
@@ -538,6 +551,7 @@ __global__ __launch_bounds__(512) void k_row_norm(const bf16_t* __restrict__ emb
         if (c < nchunk) {
             hv[ci] = *(const bf16x8*)(src + c * 8);
             wv[ci] = *(const bf16x8*)(nw + c * 8);
+            if (NS == 0 && addend) av[ci] = *(const bf16x8*)(addend + (size_t)t * hidden + c * 8);
 #pragma unroll
             for (int s2 = 0; s2 < NS; ++s2) {
                 const float* sp = slabs + ((size_t)s2 * LA_TB + t) * hidden + c * 8;
@@ -561,6 +575,8 @@ __global__ __launch_bounds__(512) void k_row_norm(const bf16_t* __restrict__ emb
 #pragma unroll
                     for (int s2 = 0; s2 < NS; ++s2) add += sl[s2][ci][j >> 2][j & 3];
                     v = bfr(v + bfr(add));
+                } else if (addend) {
+                    v = bfr(v + bf2f((bf16_t)av[ci][j]));      // MoE: residual + final_hidden_states (bf16 + bf16)
                 }
                 vals[ci][j] = v;
                 ho[j] = (short)f2bf(v);
@@ -571,15 +587,99 @@ __global__ __launch_bounds__(512) void k_row_norm(const bf16_t* __restrict__ emb
     }
     const float tot = block_sum<8>(ss, sh);
     const float rs = 1.0f / sqrtf(tot / (float)hidden + eps);
+    float rl[MOE ? LA_MOE_MAX_E : 1];
+#pragma unroll
+    for (int e = 0; e < (MOE ? LA_MOE_MAX_E : 1); ++e) rl[e] = 0.f;
 #pragma unroll
     for (int ci = 0; ci < 2; ++ci) {
         const int c = threadIdx.x + ci * 512;
         if (c < nchunk) {
             bf16x8 xo;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) xo[j] = (short)f2bf(bf2f((bf16_t)wv[ci][j]) * (vals[ci][j] * rs));
+            for (int j = 0; j < 8; ++j) {
+                // LlamaRMSNorm rounds once; Mistral/MixtralRMSNorm round the normalised value before the weight multiply
+                const float nv = cast_first ? bfr(vals[ci][j] * rs) : vals[ci][j] * rs;
+                xo[j] = (short)f2bf(bf2f((bf16_t)wv[ci][j]) * nv);
+            }
             *(bf16x8*)(xp + xp_offset(t, c * 8)) = xo;
+            if (MOE) {
+#pragma unroll
+                for (int e = 0; e < LA_MOE_MAX_E; ++e) {
+                    if (e < n_experts) {
+                        const bf16x8 gw = *(const bf16x8*)(wrouter + (size_t)e * hidden + c * 8);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) rl[e] += bf2f((bf16_t)xo[j]) * bf2f((bf16_t)gw[j]);
+                    }
+                }
+            }
         }
+    }
+    if (!MOE) return;
+    // Router (MixtralSparseMoeBlock.forward, mixtral/modeling_mixtral.py:723-729): logits = gate(x) in the activation
+    // dtype, softmax in fp32, top-k, renormalise, cast back.  route_w[t][e] = weight of expert e for this row or 0.
+#pragma unroll
+    for (int e = 0; e < LA_MOE_MAX_E; ++e) rl[e] = wave_sum(rl[e]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int e = 0; e < LA_MOE_MAX_E; ++e) shr[threadIdx.x >> 6][e] = rl[e];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float lg[LA_MOE_MAX_E], pr[LA_MOE_MAX_E], outw[LA_MOE_MAX_E];
+        float mx = -INFINITY;
+        for (int e = 0; e < n_experts; ++e) {
+            float v = 0.f;
+            for (int w = 0; w < 8; ++w) v += shr[w][e];
+            lg[e] = bfr(v);
+            mx = fmaxf(mx, lg[e]);
+        }
+        float den = 0.f;
+        for (int e = 0; e < n_experts; ++e) { pr[e] = expf(lg[e] - mx); den += pr[e]; }
+        for (int e = 0; e < n_experts; ++e) { pr[e] = pr[e] / den; outw[e] = 0.f; }
+        unsigned taken = 0u;
+        float ksum = 0.f;
+        int pick[LA_MOE_MAX_E];
+        for (int k = 0; k < top_k; ++k) {
+            int best = -1;
+            for (int e = 0; e < n_experts; ++e)
+                if (!((taken >> e) & 1u) && (best < 0 || pr[e] > pr[best])) best = e;
+            taken |= 1u << best;
+            pick[k] = best;
+            ksum += pr[best];
+        }
+        const bool live = t < n_rows[0];
+        for (int k = 0; k < top_k; ++k) outw[pick[k]] = live ? bfr(pr[pick[k]] / ksum) : 0.f;
+        for (int e = 0; e < LA_MOE_MAX_E; ++e) route_w[t * LA_MOE_MAX_E + e] = e < n_experts ? outw[e] : 0.f;
+    }
+}
+
+// MoE accumulation (MixtralSparseMoeBlock.forward :731-756): final[t] (+)= bf16(bf16(expert_out[t]) * w[t][e]) for the
+// rows routed to expert e, experts visited in index order (index_add_ into a bf16 buffer).  FIRST zero-fills.
+template <int NS, bool FIRST>
+__global__ __launch_bounds__(256) void k_moe_accum(const float* __restrict__ slabs, const float* __restrict__ route_col,
+                                                    int hidden, bf16_t* __restrict__ acc) {
+    const int t = blockIdx.x;
+    const float w = route_col[t * LA_MOE_MAX_E];
+    if (w == 0.f && !FIRST) return;
+    for (int c = threadIdx.x; c < (hidden >> 3); c += 256) {
+        bf16x8 cur = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (!FIRST) cur = *(const bf16x8*)(acc + (size_t)t * hidden + c * 8);
+        if (w != 0.f) {
+            float add[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) {
+                const float* sp = slabs + ((size_t)s2 * LA_TB + t) * hidden + c * 8;
+                const f32x4 a0 = *(const f32x4*)sp, a1 = *(const f32x4*)(sp + 4);
+                add[0] += a0[0]; add[1] += a0[1]; add[2] += a0[2]; add[3] += a0[3];
+                add[4] += a1[0]; add[5] += a1[1]; add[6] += a1[2]; add[7] += a1[3];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float contrib = bfr(bfr(add[j]) * w);
+                cur[j] = (short)f2bf(FIRST ? contrib : bf2f((bf16_t)cur[j]) + contrib);
+            }
+        }
+        *(bf16x8*)(acc + (size_t)t * hidden + c * 8) = cur;
     }
 }
 
@@ -1114,14 +1214,18 @@ static int launch_gemm(hipStream_t st, const GemmArgs& a, int nblocks, int kspli
     LAUNCH_CHECK(); return 0;
 }
 
-int lk_gemm64_slab(hipStream_t st, const void* wp, const void* xp, int N, int K, int rbv, int ksplit, float* slabs) {
+int lk_gemm64_slab(hipStream_t st, const void* wp, const void* xp, int N, int K, int rbv, int ksplit, float* slabs,
+                   const float* route_col) {
     const int rb = rbv & 0xff, variant = rbv >> 8;
     GemmArgs a{}; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = N; a.slabs = slabs;
+    a.route_col = route_col;
     if (rb == 2 && (N % 64) == 0) return launch_gemm<2, EPI_SLAB>(st, a, N / 64, ksplit, variant);
     return launch_gemm<1, EPI_SLAB>(st, a, N / 32, ksplit, variant);
 }
-int lk_gemm64_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, void* act_xp, int variant) {
+int lk_gemm64_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, void* act_xp, int variant,
+                     const float* route_col) {
     GemmArgs a{}; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = F; a.act_xp = (bf16_t*)act_xp;
+    a.route_col = route_col;
     return launch_gemm<2, EPI_SWIGLU>(st, a, F / 32, 1, variant);
 }
 int lk_gemm64_logits(hipStream_t st, const void* wp, const void* xp, int V, int K, int rbv, void* logits,
@@ -1186,8 +1290,10 @@ int lk_pack_planned(hipStream_t st, const void* w, const void* w2, const int* d_
     k_pack_planned<<<(unsigned)((total + 255) / 256), 256, 0, st>>>((const bf16_t*)w, (const bf16_t*)w2, d_plan, pa, (bf16_t*)out);
     LAUNCH_CHECK(); return 0;
 }
-int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, int n_wg, void* act_xp) {
+int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, int n_wg, void* act_xp,
+                      const float* route_col) {
     GemmRArgs ra{}; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act_xp;
+    ra.g.route_col = route_col;
     ra.R = F / n_wg; if (F % n_wg || ra.R > 64 || ra.R <= 32) return -1;
     fill_nv(ra, ra.R, 2, 2);
     k_gemm64r<4, EPI_SWIGLU, 4, 8><<<n_wg, 512, 8 * 4 * 4096, st>>>(ra);
@@ -1269,20 +1375,59 @@ int lk_argmax_finalize(hipStream_t st, const float* cv, const int* ci, int n_til
     k_argmax_finalize<<<LA_TB, 256, 0, st>>>(cv, ci, n_tiles, out_rows);
     LAUNCH_CHECK(); return 0;
 }
-int lk_embed_norm(hipStream_t st, const void* embed, const int* ids, const void* nw, int hidden, float eps, void* h, void* xp) {
+int lk_embed_norm(hipStream_t st, const void* embed, const int* ids, const void* nw, int hidden, float eps, void* h, void* xp,
+                  int cast_first) {
     if (hidden > 8192 || (hidden & 7)) return -1;
-    k_row_norm<0><<<LA_TB, 512, 0, st>>>((const bf16_t*)embed, ids, (bf16_t*)h, nullptr, (const bf16_t*)nw, hidden, eps, (bf16_t*)xp);
+    k_row_norm<0, false><<<LA_TB, 512, 0, st>>>((const bf16_t*)embed, ids, (bf16_t*)h, nullptr, (const bf16_t*)nw, hidden, eps,
+                                                (bf16_t*)xp, nullptr, nullptr, 0, 0, nullptr, nullptr, cast_first);
     LAUNCH_CHECK(); return 0;
 }
-int lk_resid_norm(hipStream_t st, void* h, const float* slabs, int n_slabs, const void* nw, int hidden, float eps, void* xp) {
+int lk_resid_norm(hipStream_t st, void* h, const float* slabs, int n_slabs, const void* nw, int hidden, float eps, void* xp,
+                  int cast_first) {
     if (hidden > 8192 || (hidden & 7)) return -1;
-#define RN(NS) k_row_norm<NS><<<LA_TB, 512, 0, st>>>(nullptr, nullptr, (bf16_t*)h, slabs, (const bf16_t*)nw, hidden, eps, (bf16_t*)xp)
+#define RN(NS) k_row_norm<NS, false><<<LA_TB, 512, 0, st>>>(nullptr, nullptr, (bf16_t*)h, slabs, (const bf16_t*)nw, hidden, eps, \
+                                                            (bf16_t*)xp, nullptr, nullptr, 0, 0, nullptr, nullptr, cast_first)
     switch (n_slabs) {
         case 0: RN(0); break; case 1: RN(1); break; case 2: RN(2); break; case 3: RN(3); break;
         case 4: RN(4); break; case 6: RN(6); break; case 8: RN(8); break;
         default: return -1;
     }
 #undef RN
+    LAUNCH_CHECK(); return 0;
+}
+// residual add + norm + fused MoE router (post-attention norm of a Mixtral layer)
+int lk_resid_norm_router(hipStream_t st, void* h, const float* slabs, int n_slabs, const void* nw, int hidden, float eps,
+                         void* xp, const void* wrouter, int n_experts, int top_k, float* route_w, const int* n_rows,
+                         int cast_first) {
+    if (hidden > 8192 || (hidden & 7) || n_experts < 1 || n_experts > LA_MOE_MAX_E || top_k < 1 || top_k > n_experts) return -1;
+#define RN(NS) k_row_norm<NS, true><<<LA_TB, 512, 0, st>>>(nullptr, nullptr, (bf16_t*)h, slabs, (const bf16_t*)nw, hidden, eps, \
+                                                           (bf16_t*)xp, nullptr, (const bf16_t*)wrouter, n_experts, top_k, route_w, n_rows, cast_first)
+    switch (n_slabs) {
+        case 1: RN(1); break; case 2: RN(2); break; case 3: RN(3); break; case 4: RN(4); break;
+        case 6: RN(6); break; case 8: RN(8); break;
+        default: return -1;
+    }
+#undef RN
+    LAUNCH_CHECK(); return 0;
+}
+// residual + accumulated expert outputs (bf16) + next norm
+int lk_resid_norm_addend(hipStream_t st, void* h, const void* addend, const void* nw, int hidden, float eps, void* xp,
+                         int cast_first) {
+    if (hidden > 8192 || (hidden & 7) || !addend) return -1;
+    k_row_norm<0, false><<<LA_TB, 512, 0, st>>>(nullptr, nullptr, (bf16_t*)h, nullptr, (const bf16_t*)nw, hidden, eps,
+                                                (bf16_t*)xp, (const bf16_t*)addend, nullptr, 0, 0, nullptr, nullptr, cast_first);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_moe_accum(hipStream_t st, const float* slabs, int n_slabs, const float* route_col, int hidden, void* acc, int first) {
+    if (hidden & 7) return -1;
+#define MA(NS) do { if (first) k_moe_accum<NS, true><<<LA_TB, 256, 0, st>>>(slabs, route_col, hidden, (bf16_t*)acc); \
+                    else k_moe_accum<NS, false><<<LA_TB, 256, 0, st>>>(slabs, route_col, hidden, (bf16_t*)acc); } while (0)
+    switch (n_slabs) {
+        case 1: MA(1); break; case 2: MA(2); break; case 3: MA(3); break; case 4: MA(4); break;
+        case 6: MA(6); break; case 8: MA(8); break;
+        default: return -1;
+    }
+#undef MA
     LAUNCH_CHECK(); return 0;
 }
 int lk_build_tree_inputs(hipStream_t st, const int* in, int* state, int* pos, uint64_t* rowmask, int* ids) {

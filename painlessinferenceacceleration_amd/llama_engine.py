@@ -24,8 +24,12 @@ class LlamaShape(object):
     """The fields of LlamaConfig the path uses."""
 
     def __init__(self, n_layers=32, hidden=4096, n_heads=32, n_kv_heads=None, ffn=11008, vocab=32000,
-                 rms_eps=1e-5, rope_theta=10000.0, head_dim=None):
+                 rms_eps=1e-5, rope_theta=10000.0, head_dim=None, n_experts=0, top_k=2, norm_cast_first=False):
         self.n_layers, self.hidden, self.n_heads = n_layers, hidden, n_heads
+        self.n_experts, self.top_k = n_experts, top_k       # > 0: Mixtral sparse-MoE MLP
+        # RMSNorm flavour: False = LlamaRMSNorm (one rounding), True = Mistral/MixtralRMSNorm (normalised value rounded
+        # to the activation dtype before the weight multiply, mixtral/modeling_mixtral.py:160-165)
+        self.norm_cast_first = bool(norm_cast_first)
         self.n_kv_heads = n_kv_heads if n_kv_heads is not None else n_heads
         self.ffn, self.vocab, self.rms_eps, self.rope_theta = ffn, vocab, rms_eps, rope_theta
         self.head_dim = head_dim if head_dim is not None else hidden // n_heads
@@ -39,15 +43,26 @@ class LlamaShape(object):
         return cls(40, 5120, 40, 40, 13824, 32000, 1e-5)
 
     @classmethod
+    def mistral_7b(cls):
+        return cls(32, 4096, 32, 8, 14336, 32000, 1e-5, rope_theta=10000.0, norm_cast_first=True)
+
+    @classmethod
+    def mixtral_8x7b(cls):
+        return cls(32, 4096, 32, 8, 14336, 32000, 1e-5, rope_theta=1e6, n_experts=8, top_k=2, norm_cast_first=True)
+
+    @classmethod
     def from_hf(cls, cfg):
         return cls(cfg.num_hidden_layers, cfg.hidden_size, cfg.num_attention_heads,
                    getattr(cfg, 'num_key_value_heads', None), cfg.intermediate_size, cfg.vocab_size,
-                   cfg.rms_norm_eps, getattr(cfg, 'rope_theta', 10000.0))
+                   cfg.rms_norm_eps, getattr(cfg, 'rope_theta', 10000.0),
+                   n_experts=getattr(cfg, 'num_local_experts', 0) or 0, top_k=getattr(cfg, 'num_experts_per_tok', 2),
+                   norm_cast_first=getattr(cfg, 'model_type', 'llama') in ('mistral', 'mixtral'))
 
     def n_params_no_embed(self):
         hd = self.head_dim
+        mlp = 3 * self.ffn * self.hidden * max(self.n_experts, 1) + self.n_experts * self.hidden
         per_layer = (self.n_heads + 2 * self.n_kv_heads) * hd * self.hidden + self.n_heads * hd * self.hidden \
-            + 3 * self.ffn * self.hidden + 2 * self.hidden
+            + mlp + 2 * self.hidden
         return self.n_layers * per_layer + self.hidden + self.vocab * self.hidden
 
 
@@ -86,9 +101,17 @@ def random_weights(shape, seed=0, std=0.02, device='cpu', dtype=torch.bfloat16, 
         sd[p + 'self_attn.k_proj.weight'] = w(shape.n_kv_heads * hd, shape.hidden)
         sd[p + 'self_attn.v_proj.weight'] = w(shape.n_kv_heads * hd, shape.hidden)
         sd[p + 'self_attn.o_proj.weight'] = w(shape.hidden, shape.n_heads * hd, out_std)
-        sd[p + 'mlp.gate_proj.weight'] = w(shape.ffn, shape.hidden)
-        sd[p + 'mlp.up_proj.weight'] = w(shape.ffn, shape.hidden)
-        sd[p + 'mlp.down_proj.weight'] = w(shape.hidden, shape.ffn, out_std)
+        if shape.n_experts > 0:                      # HF Mixtral naming (w1 = gate, w3 = up, w2 = down)
+            sd[p + 'block_sparse_moe.gate.weight'] = w(shape.n_experts, shape.hidden)
+            for e in range(shape.n_experts):
+                q = p + f'block_sparse_moe.experts.{e}.'
+                sd[q + 'w1.weight'] = w(shape.ffn, shape.hidden)
+                sd[q + 'w3.weight'] = w(shape.ffn, shape.hidden)
+                sd[q + 'w2.weight'] = w(shape.hidden, shape.ffn, out_std)
+        else:
+            sd[p + 'mlp.gate_proj.weight'] = w(shape.ffn, shape.hidden)
+            sd[p + 'mlp.up_proj.weight'] = w(shape.ffn, shape.hidden)
+            sd[p + 'mlp.down_proj.weight'] = w(shape.hidden, shape.ffn, out_std)
         sd[p + 'input_layernorm.weight'] = torch.ones(shape.hidden, device=device, dtype=dtype)
         sd[p + 'post_attention_layernorm.weight'] = torch.ones(shape.hidden, device=device, dtype=dtype)
     sd['model.norm.weight'] = torch.ones(shape.hidden, device=device, dtype=dtype)
@@ -194,11 +217,24 @@ class LlamaVerifyEngine(object):
                 layers[i].wqkv = pack(qkv).data_ptr()
             del qkv
             layers[i].wo = pack(take(p + 'self_attn.o_proj.weight')).data_ptr()
-            if self.balanced_wg[1]:
-                layers[i].wgateup = pack_planned(1, [take(p + 'mlp.gate_proj.weight'), take(p + 'mlp.up_proj.weight')]).data_ptr()
+
+            def pack_gateup(gate, up):
+                return (pack_planned(1, [gate, up]) if self.balanced_wg[1] else pack(gate, up)).data_ptr()
+
+            if shape.n_experts > 0:
+                layers[i].router = dev(take(p + 'block_sparse_moe.gate.weight')).data_ptr()
+                gu = (_lib.vp * shape.n_experts)()
+                dn = (_lib.vp * shape.n_experts)()
+                for e in range(shape.n_experts):
+                    q = p + f'block_sparse_moe.experts.{e}.'
+                    gu[e] = pack_gateup(take(q + 'w1.weight'), take(q + 'w3.weight'))
+                    dn[e] = pack(take(q + 'w2.weight')).data_ptr()
+                self._keep.extend([gu, dn])
+                layers[i].ex_gateup = C.cast(gu, C.POINTER(_lib.vp))
+                layers[i].ex_down = C.cast(dn, C.POINTER(_lib.vp))
             else:
-                layers[i].wgateup = pack(take(p + 'mlp.gate_proj.weight'), take(p + 'mlp.up_proj.weight')).data_ptr()
-            layers[i].wdown = pack(take(p + 'mlp.down_proj.weight')).data_ptr()
+                layers[i].wgateup = pack_gateup(take(p + 'mlp.gate_proj.weight'), take(p + 'mlp.up_proj.weight'))
+                layers[i].wdown = pack(take(p + 'mlp.down_proj.weight')).data_ptr()
             layers[i].norm1 = dev(take(p + 'input_layernorm.weight')).data_ptr()
             layers[i].norm2 = dev(take(p + 'post_attention_layernorm.weight')).data_ptr()
             torch.cuda.synchronize(self.device)
@@ -224,6 +260,8 @@ class LlamaVerifyEngine(object):
         assert 1 <= n_slots <= _lib.LA_MAX_SEQ
         self.n_slots = int(n_slots)
         cfg.n_slots = self.n_slots
+        cfg.n_experts, cfg.top_k = shape.n_experts, shape.top_k
+        cfg.norm_cast_first = int(shape.norm_cast_first)
         self._cfg = cfg
         nbytes = lib.la_llama_workspace_bytes(C.byref(cfg))
         if nbytes <= 0:

@@ -128,3 +128,28 @@ def test_oracle_batch_equals_per_sample_bs1_semantics():
         n_gen = int((seqs[b, P:] != 0).sum())
         gre = lo.greedy_generate(model, prompt, n_gen)
         assert gre[len(prompt):] == seqs[b, P:P + n_gen].tolist(), b
+
+
+# ------------------------------------------------------------------------------------- GQA / sparse MoE (a15c)
+@pytest.mark.parametrize('tag,dtype', [('fp32', torch.float32), ('bf16', torch.bfloat16)])
+@pytest.mark.parametrize('kind', ['mixtral', 'mistral'])
+def test_oracle_gqa_and_moe_match_reference_forward(kind, tag, dtype):
+    """Reference MixtralForCausalLM / MistralForCausalLM (cache-free forward under a prompt+tree rank-4 mask) against
+    the oracle forward: GQA repeat_kv attention, rope_theta, router softmax/top-2/renormalise, expert order."""
+    from tests.tiny_model import TINY_GQA, TINY_MOE, moe_shape, moe_weights
+    g = np.load(os.path.join(GOLDEN, f'moe_tiny_{tag}.npz'))
+    cfg = TINY_MOE if kind == 'mixtral' else TINY_GQA
+    sd = {k: v.to(dtype) for k, v in moe_weights(cfg, 0, torch.float32).items()}
+    model = lo.OracleLlama(moe_shape(cfg), sd)
+    for case in range(3):
+        ids, mask, ref = g[f'{kind}_{case}_ids'], g[f'{kind}_{case}_mask'].astype(np.int64), g[f'{kind}_{case}_logits']
+        logits, _ = model.forward(torch.from_numpy(ids), torch.from_numpy(mask), None)
+        got = logits.float().numpy()
+        if dtype == torch.float32:
+            assert np.abs(got - ref).max() < 2e-4 * np.abs(ref).max(), (kind, case)
+        else:
+            # bf16: same rounding points; allow a few ulps where CPU kernels pick different accumulation orders
+            assert np.abs(got - ref).max() <= 2 ** -5 * 2 and (got.argmax(-1) == ref.argmax(-1)).mean() > 0.97, (kind, case)
+        if kind == 'mixtral' and dtype == torch.float32:
+            rl = g[f'{kind}_{case}_router1']
+            assert np.abs(model.last_router_logits.float().numpy() - rl).max() < 1e-4 * max(1.0, np.abs(rl).max())

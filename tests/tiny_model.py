@@ -49,3 +49,52 @@ def tiny_weights(seed=0, dtype=torch.float32, std=0.08, cfg=None):
 
 def load_golden(tag):
     return np.load(os.path.join(GOLDEN, f'llama_tiny_{tag}.npz'))
+
+
+# tiny Mixtral / Mistral (GQA, head_dim 128; Mixtral: 8 experts top-2, rope_theta 1e6) shared by oracle/gen_golden_moe.py
+TINY_MOE = dict(n_layers=2, hidden=256, n_heads=2, n_kv_heads=1, ffn=512, vocab=512, rms_eps=1e-5, n_experts=8, top_k=2,
+                rope_theta=1e6)
+TINY_GQA = dict(n_layers=2, hidden=512, n_heads=4, n_kv_heads=2, ffn=512, vocab=512, rms_eps=1e-5, n_experts=0, top_k=2,
+                rope_theta=10000.0)
+
+
+def moe_shape(cfg):
+    return LlamaShape(cfg['n_layers'], cfg['hidden'], cfg['n_heads'], cfg['n_kv_heads'], cfg['ffn'], cfg['vocab'],
+                      cfg['rms_eps'], rope_theta=cfg['rope_theta'], n_experts=cfg['n_experts'], top_k=cfg['top_k'],
+                      norm_cast_first=True)
+
+
+def moe_weights(cfg, seed=0, dtype=torch.float32, std=0.08, router_std=0.5):
+    """HF Mixtral / Mistral-named state dict from numpy's MT19937."""
+    rs = np.random.RandomState(seed)
+    hd = cfg['hidden'] // cfg['n_heads']
+
+    def w(n, k, s=std):
+        return torch.from_numpy((rs.standard_normal((n, k)) * s).astype(np.float32)).to(dtype)
+
+    def nw():
+        return torch.from_numpy((1.0 + 0.1 * rs.standard_normal(cfg['hidden'])).astype(np.float32)).to(dtype)
+
+    sd = {'model.embed_tokens.weight': w(cfg['vocab'], cfg['hidden'])}
+    for i in range(cfg['n_layers']):
+        p = f'model.layers.{i}.'
+        sd[p + 'self_attn.q_proj.weight'] = w(cfg['n_heads'] * hd, cfg['hidden'])
+        sd[p + 'self_attn.k_proj.weight'] = w(cfg['n_kv_heads'] * hd, cfg['hidden'])
+        sd[p + 'self_attn.v_proj.weight'] = w(cfg['n_kv_heads'] * hd, cfg['hidden'])
+        sd[p + 'self_attn.o_proj.weight'] = w(cfg['hidden'], cfg['n_heads'] * hd)
+        if cfg['n_experts'] > 0:
+            sd[p + 'block_sparse_moe.gate.weight'] = w(cfg['n_experts'], cfg['hidden'], router_std)
+            for e in range(cfg['n_experts']):
+                q = p + f'block_sparse_moe.experts.{e}.'
+                sd[q + 'w1.weight'] = w(cfg['ffn'], cfg['hidden'])
+                sd[q + 'w2.weight'] = w(cfg['hidden'], cfg['ffn'])
+                sd[q + 'w3.weight'] = w(cfg['ffn'], cfg['hidden'])
+        else:
+            sd[p + 'mlp.gate_proj.weight'] = w(cfg['ffn'], cfg['hidden'])
+            sd[p + 'mlp.up_proj.weight'] = w(cfg['ffn'], cfg['hidden'])
+            sd[p + 'mlp.down_proj.weight'] = w(cfg['hidden'], cfg['ffn'])
+        sd[p + 'input_layernorm.weight'] = nw()
+        sd[p + 'post_attention_layernorm.weight'] = nw()
+    sd['model.norm.weight'] = nw()
+    sd['lm_head.weight'] = w(cfg['vocab'], cfg['hidden'])
+    return sd
