@@ -272,7 +272,8 @@ int la_llama_step(la_llama* m, void* stream, const int32_t* host_in, int32_t* ho
 int la_llama_step_eager(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);
 /* Device addresses of internal buffers for parity tests: 0 logits bf16 [64][vocab], 1 state,
  * 2 hidden h bf16 [64][hidden], 3 final normed x (packed), 4/5 main K/V cache, 6/7 fresh K/V tiles,
- * 8 batch state block (LA_BST_*). */
+ * 8 batch state block (LA_BST_*), 9 routing weights fp32 [n_layers][64][LA_MOE_MAX_E] of the last block, 10 accumulated
+ * expert output bf16 [64][hidden] of the last MoE layer. */
 void* la_llama_buffer(la_llama* m, int which);
 /* Kernel-class timing of one block with HIP events recorded on `stream` between eager launches
  * (bench.py's roofline block).  out_ms[0..6] = per-step time summed over the launches of

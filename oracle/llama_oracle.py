@@ -60,9 +60,11 @@ class OracleLlama(object):
         self.dtype = state_dict['lm_head.weight'].dtype
 
     @torch.no_grad()
-    def forward(self, ids, mask, past):
+    def forward(self, ids, mask, past, forced_routing=None):
         """ids: LongTensor [T]; mask: 0/1 LongTensor [T, C+T] (the rank-4 mask without its two unit dims);
-        past: None or list of (k, v).  -> logits [T, V], new past."""
+        past: None or list of (k, v).  -> logits [T, V], new past.  forced_routing (MoE, tests only): per layer a [T, E]
+        tensor of routing weights (0 = not routed) used INSTEAD of the router's own top-k, so that the continuous part of
+        a device run can be compared row by row although top-k selection is discontinuous."""
         s, w, dt = self.s, self.w, self.dtype
         T, hd, nh, nkv = ids.shape[0], s.head_dim, s.n_heads, s.n_kv_heads
         lin = torch.nn.functional.linear
@@ -74,6 +76,7 @@ class OracleLlama(object):
         cos, sin = _rope_cos_sin(pos[0], hd, s.rope_theta, dt)
         cos, sin = cos[None, None], sin[None, None]
         new_past = []
+        self.router_trace = []
         cf = bool(getattr(s, 'norm_cast_first', False))
         for i in range(s.n_layers):
             p = f'model.layers.{i}.'
@@ -100,7 +103,7 @@ class OracleLlama(object):
             h = h + lin(o, w[p + 'self_attn.o_proj.weight'])
             x = _rms(h, w[p + 'post_attention_layernorm.weight'], s.rms_eps, cf)
             if getattr(s, 'n_experts', 0) > 0:
-                h = h + self._moe(x, p)
+                h = h + self._moe(x, p, None if forced_routing is None else forced_routing[i])
             else:
                 g = torch.nn.functional.silu(lin(x, w[p + 'mlp.gate_proj.weight']))
                 u = lin(x, w[p + 'mlp.up_proj.weight'])
@@ -108,7 +111,7 @@ class OracleLlama(object):
         h = _rms(h, w['model.norm.weight'], s.rms_eps, cf)
         return lin(h, w['lm_head.weight'])[0], new_past
 
-    def _moe(self, x, p):
+    def _moe(self, x, p, forced=None):
         """MixtralSparseMoeBlock.forward (mixtral/modeling_mixtral.py:717-759): router logits in the activation dtype,
         softmax in fp32, top-k, renormalise, cast back; experts visited in index order, each adding
         w2(silu(w1 x) * w3 x) * routing_weight for its rows into a zero buffer of the activation dtype (index_add_)."""
@@ -119,8 +122,13 @@ class OracleLlama(object):
         rw = torch.softmax(logits, dim=1, dtype=torch.float)
         rw, sel = torch.topk(rw, s.top_k, dim=-1)
         rw = (rw / rw.sum(dim=-1, keepdim=True)).to(xs.dtype)
+        if forced is not None:
+            order = torch.argsort((forced != 0).to(torch.int8), dim=-1, descending=True, stable=True)[:, :s.top_k]
+            sel = order
+            rw = torch.gather(forced, 1, order).to(xs.dtype)
         out = torch.zeros_like(xs)
         self.last_router_logits = logits
+        self.router_trace.append(logits)
         for e in range(s.n_experts):
             slot, rows = torch.where((sel == e).t())
             if rows.shape[0] == 0:

@@ -112,7 +112,7 @@ static size_t carve(la_llama* m, char* base) {
     m->bstate = cv.take<int>(LA_BST_WORDS);
     m->bin = cv.take<int>(LA_BIN_WORDS);
     m->moe_acc = cv.take<uint16_t>(c.n_experts > 0 ? (size_t)64 * c.hidden : 8);
-    m->route_w = cv.take<float>(64 * LA_MOE_MAX_E);
+    m->route_w = cv.take<float>((size_t)(c.n_experts > 0 ? c.n_layers : 1) * 64 * LA_MOE_MAX_E);   // kept per layer (parity tests)
     return align_up(cv.off, 256);
 }
 
@@ -255,10 +255,11 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
         if (c.n_experts > 0) {
             // sparse MoE MLP: router fused into the norm, then per expert {gate/up+SwiGLU, down, weighted accumulate};
             // an expert no row routes to costs three empty launches and no weight traffic
+            float* rw = m->route_w + (size_t)l * 64 * LA_MOE_MAX_E;
             KCHK(lk_resid_norm_router(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp, L.router, c.n_experts,
-                                      c.top_k, m->route_w, batch ? m->bin + LA_BIN_T : m->state + LA_ST_T, cf));
+                                      c.top_k, rw, batch ? m->bin + LA_BIN_T : m->state + LA_ST_T, cf));
             for (int e = 0; e < c.n_experts; ++e) {
-                const float* col = m->route_w + e;
+                const float* col = rw + e;
                 const void* wgu = m->ex_gateup[(size_t)l * c.n_experts + e];
                 const void* wdn = m->ex_down[(size_t)l * c.n_experts + e];
                 P(KC_GATEUP);
@@ -374,6 +375,8 @@ extern "C" void* la_llama_buffer(la_llama* m, int which) {
         case 6: return m->kfresh;
         case 7: return m->vfresh;
         case 8: return m->bstate;
+        case 9: return m->route_w;
+        case 10: return m->moe_acc;
         default: return nullptr;
     }
 }

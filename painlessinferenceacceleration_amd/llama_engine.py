@@ -430,6 +430,11 @@ class LlamaVerifyEngine(object):
     def hidden(self):
         return self._view(2, 64 * self.shape.hidden * 2, torch.bfloat16).view(64, self.shape.hidden)
 
+    def route_weights(self):
+        """fp32 [n_layers][64][8]: routing weight of every (layer, block row, expert) of the last block (0 = not routed)."""
+        L = self.shape.n_layers
+        return self._view(9, L * 64 * _lib.LA_MOE_MAX_E * 4, torch.float32).view(L, 64, _lib.LA_MOE_MAX_E)
+
     def profile(self, ids, rowmask, iters=3):
         """HIP-event timing per kernel class (see la_llama_profile)."""
         self._fill(ids, rowmask, 0)

@@ -64,7 +64,7 @@ def moe_shape(cfg):
                       norm_cast_first=True)
 
 
-def moe_weights(cfg, seed=0, dtype=torch.float32, std=0.08, router_std=0.5):
+def moe_weights(cfg, seed=0, dtype=torch.float32, std=0.06, router_std=0.2):
     """HF Mixtral / Mistral-named state dict from numpy's MT19937."""
     rs = np.random.RandomState(seed)
     hd = cfg['hidden'] // cfg['n_heads']
