@@ -119,3 +119,26 @@ def test_batch_loop_reproduces_reference_batch_run():
             assert n >= max_new - 13 and got[b, P:P + n].tolist() == ref[b, P:P + n].tolist(), (name, b)
     gre = m.greedy_search(ids, ids.shape[1] + 20, attention_mask=am, eos_token_id=2)
     assert gre[:, :ids.shape[1] + 20].tolist() == [r[:ids.shape[1] + 20] for r in g['b4w256_r0_sequences'].tolist()]
+
+
+def test_benchmark_harness_perf_check_and_trie_loop(capsys):
+    """painlessinferenceacceleration_amd.benchmark.Benchmark (methodology of lookahead/benchmarks/benchmark.py): warm_up +
+    perf_check over a (decoding_length, branch_length) grid on the oracle-backed model, and the trie-only timing loop."""
+    from painlessinferenceacceleration_amd.benchmark import Benchmark
+    m = Model(torch.float32)
+    g = load_golden('fp32')
+    prompt = g['prompt'].tolist()
+    b = Benchmark(model=m, eos=2)
+    answers = b.save_answers([prompt], max_new_tokens=24)
+    assert answers[0] == g['greedy'].tolist()[len(prompt):len(prompt) + 24][:len(answers[0])]
+    res = b.perf_check([prompt, prompt], answers=[answers[0], answers[0]], warmup_ids=answers, max_new_tokens=24,
+                       sizes=(1, 16), lens=(0, 4))
+    out = capsys.readouterr().out
+    assert set(res) == {(1, 0), (16, 0), (16, 4)} and all(v > 0 for v in res.values())      # (1, 4) skipped: dl < bl * bs
+    line = [ln for ln in out.splitlines() if ln.startswith('mode:hier bs:1 decoding_length:16 branch_length:4')][0]
+    assert 'edl:' in line and 'speed:' in line and 'acc:1.0000' in line      # lookahead answers == greedy answers
+    edl = float(line.split('edl:')[1].split('/')[0])
+    assert edl > 1.5                                                        # warmed trie: multi-token accepts
+    r = Benchmark.perf_check_trie(LookaheadCache(), [answers[0]] * 3, [prompt], [answers[0]], decoding_length=16,
+                                  branch_length=4, edl=4, verbose=False)
+    assert r['gets'] == 6 and r['put_tokens'] == len(prompt) + len(answers[0])
