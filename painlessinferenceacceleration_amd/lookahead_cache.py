@@ -298,6 +298,57 @@ class LookaheadCache(object):
     def load_mem(self, load_dir):
         check(lib.la_cache_load(self._h, str(load_dir).encode()), 'load_mem')
 
+    def load_reference_mem(self, load_dir):
+        """Import a trie written by the REFERENCE's save_mem (lookahead_cache.py:578-582: pickle.dumps(self.mem) as a
+        latin-1 string inside JSON).  The pickle is read with an unpickler that only admits the two record classes
+        (Node / Tree of lookahead.common.lookahead_cache) and is re-encoded as a native snapshot, preserving child
+        insertion order (= dict order) and every per-idx frequency."""
+        import io
+        import json
+        import pickle
+        import struct
+        import tempfile
+
+        class _Node(object):
+            __slots__ = ['freqs', 'children']
+
+        class _Tree(object):
+            pass
+
+        class _Restricted(pickle.Unpickler):
+            def find_class(self, module, name):
+                if module.endswith('lookahead_cache') and name == 'Node':
+                    return _Node
+                if module.endswith('lookahead_cache') and name == 'Tree':
+                    return _Tree
+                raise pickle.UnpicklingError(f'refusing to load {module}.{name}')
+
+        with open(load_dir, 'r') as f:
+            payload = json.loads(json.load(f)).encode('latin-1')
+        mem = _Restricted(io.BytesIO(payload)).load()
+        buf = io.BytesIO()
+        buf.write(b'LATRIE01')
+        buf.write(struct.pack('<q', len(mem)))
+        for token, tree in mem.items():
+            recs = []
+            stack = [(tok, node, 1) for tok, node in reversed(list(tree.nodes.items()))]
+            while stack:
+                tok, node, depth = stack.pop()
+                recs.append((tok, depth, node.freqs))
+                stack.extend((t, n, depth + 1) for t, n in reversed(list(node.children.items())))
+            buf.write(struct.pack('<6q', int(token), int(tree.max_node), int(tree.max_output_node), int(tree.n_node),
+                                  int(tree.n_output_node), len(recs)))
+            for tok, depth, freqs in recs:
+                fi = [(int(k), float(v)) for k, v in freqs.items() if k != -1]
+                buf.write(struct.pack('<3i', int(tok), depth, len(fi)))
+                buf.write(struct.pack('<d', float(freqs.get(-1, 0.0))))
+                for k, v in fi:
+                    buf.write(struct.pack('<id', k, v))
+        with tempfile.NamedTemporaryFile(suffix='.latrie', delete=True) as tmp:
+            tmp.write(buf.getvalue())
+            tmp.flush()
+            self.load_mem(tmp.name)
+
     def stats(self):
         a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         check(lib.la_cache_stats(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))

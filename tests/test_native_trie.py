@@ -127,3 +127,36 @@ def test_argument_errors_match_reference_asserts():
         c.hier_get([1], mode='bogus')
     with pytest.raises(AssertionError):
         c.bat_get([[1]], decoding_cursors=[1, 2], indices=[0])
+
+
+def test_import_of_a_trie_saved_by_the_reference():
+    """tests/golden/ref_mem_sample.json was written by the reference's save_mem (oracle/gen_golden_mem.py); after
+    load_reference_mem the native trie answers the recorded queries exactly as the reference did after load_mem, and a
+    native save/load round trip keeps them."""
+    import json
+    import tempfile
+    g = json.load(open(os.path.join(tr.GOLDEN, 'ref_mem_queries.json')))
+    cache = LookaheadCache(eos_ids=[2])
+    cache.load_reference_mem(os.path.join(tr.GOLDEN, 'ref_mem_sample.json'))
+    assert cache.stats()['n_trees'] == g['n_trees']
+
+    def check(c):
+        hits = 0
+        for q in g['queries']:
+            ids, mask, sizes = c.hier_get(q['q'], decoding_length=q['dl'], branch_length=8, min_input_size=0,
+                                          min_output_size=max(q['dl'] // 2, 1), mode=q['mode'], idx=q['idx'])
+            assert [int(x) for x in ids] == q['ids'] and tr.rows_of(mask) == q['rows'] and list(sizes) == q['sizes'], q
+            hits += len(ids) > 1
+        return hits
+    assert check(cache) >= 10
+    with tempfile.TemporaryDirectory() as d:
+        cache.save_mem(os.path.join(d, 'snap.latrie'))
+        again = LookaheadCache(eos_ids=[2])
+        again.load_mem(os.path.join(d, 'snap.latrie'))
+        check(again)
+    with pytest.raises(Exception):                     # anything but the two record classes is refused
+        import pickle
+        bad = json.dumps(pickle.dumps(os.system).decode('latin-1'))
+        with tempfile.NamedTemporaryFile('w', suffix='.json', delete=False) as f:
+            json.dump(bad, f)
+        LookaheadCache().load_reference_mem(f.name)
