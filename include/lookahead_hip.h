@@ -118,7 +118,7 @@ int la_trie_hier_get_dev(void* stream, const int32_t* d_tok, const double* d_fo,
 /* Device-resident per-sequence step state (int32 words). */
 #define LA_ST_NKEYS      0   /* committed keys in the main KV cache (= context_length-1) */
 #define LA_ST_T          1   /* valid tree tokens in this block (1..64)                   */
-#define LA_ST_MODE       2   /* 0 = verify (accept scan), 1 = prefill chain (commit all)  */
+#define LA_ST_MODE       2   /* 0 = verify (accept scan), 1 = prefill chain (commit all), 2 = forward only */
 #define LA_ST_NOUT       3   /* out: number of emitted tokens (= matches+1)               */
 #define LA_ST_DSTBASE    4   /* out: first main-cache row written by the commit           */
 #define LA_ST_NCOMMIT    5   /* out: rows committed                                       */
@@ -268,6 +268,10 @@ int la_llama_reset(la_llama* m, void* stream);
  * accept scan -> kv commit), d2h of the first 8+64 state words into host_out.  Asynchronous on
  * `stream`; the caller synchronises before reading host_out.  host_in/host_out should be pinned. */
 int la_llama_step(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);
+/* Sequential accept path (non-empty logits-processor list / sampling, pretrained_model.py:825-875): run a step with
+ * host_in[LA_IN_MODE] = 2 (forward only: no accept walk, nothing committed), read the logits rows the walk needs
+ * (la_llama_buffer(m, 0)), then commit the accepted tree rows rows[0..n) (rows[0] = 0, the root).  Synchronous. */
+int la_llama_commit(la_llama* m, void* stream, const int32_t* rows, int n, int32_t* host_out);
 /* Same work launched kernel-by-kernel (no graph): for profiling and as a cross-check. */
 int la_llama_step_eager(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);
 /* Device addresses of internal buffers for parity tests: 0 logits bf16 [64][vocab], 1 state,

@@ -182,10 +182,31 @@ def kv_keep_positions(context_length, n_draft, logit_indices):
 
 # --------------------------------------------------------------------------------------------- loop
 @torch.no_grad()
+def accept_scan_sequential(ids, mask, logits, seq, logits_processor):
+    """The accept walk with a logits-processor list (pretrained_model.py:825-864): the processors see the sequence
+    INCLUDING the tokens accepted so far in this step, so rows are evaluated one after another along the path."""
+    T = len(ids)
+    par = parents_from_mask(np.asarray(mask))
+    cur, toks, rows = 0, [], [0]
+    while True:
+        ctx = torch.tensor([list(seq) + toks], dtype=torch.long)
+        want = int(torch.argmax(logits_processor(ctx, logits[cur][None].clone()), dim=-1)[0])
+        toks.append(want)
+        nxt = next((j for j in range(1, T) if par[j] == cur and int(ids[j]) == want), None)
+        if nxt is None:
+            break
+        cur = nxt
+        rows.append(cur)
+    return toks, rows
+
+
+@torch.no_grad()
 def lookahead_generate(model, cache, prompt, max_length, eos_token_id=2, decoding_length=64, branch_length=12,
-                       decoding_mode='hier', max_query_length=2, stop_words=None, max_steps=None, record=None):
-    """bs=1 lookahead_generation with an empty logits-processor list and greedy decoding.
-    -> dict(sequences, dls, edls, fts, qts).  `cache` is any object with the LookaheadCache surface."""
+                       decoding_mode='hier', max_query_length=2, stop_words=None, max_steps=None, record=None,
+                       logits_processor=None):
+    """bs=1 lookahead_generation, greedy decoding; logits_processor: None / empty (row-parallel argmax) or a
+    LogitsProcessorList (sequential walk).  -> dict(sequences, dls, edls, fts, qts).  `cache` is any object with the
+    LookaheadCache surface."""
     eos = [eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id)
     cache.eos_ids = eos
     cache.stop_words = stop_words if stop_words is not None else {}
@@ -200,7 +221,10 @@ def lookahead_generate(model, cache, prompt, max_length, eos_token_id=2, decodin
             P = len(seq)
             mask = torch.tril(torch.ones((P, P), dtype=torch.long))
             logits, past = model.forward(torch.tensor(seq, dtype=torch.long), mask, None)
-            toks = [int(torch.argmax(logits[-1]))]
+            if logits_processor:
+                toks = [int(torch.argmax(logits_processor(torch.tensor([seq]), logits[-1][None].clone()), dim=-1)[0])]
+            else:
+                toks = [int(torch.argmax(logits[-1]))]
             dls.append(1); edls.append(1)
             if record is not None:
                 record.append({'ids': list(seq), 'argmax': [int(x) for x in torch.argmax(logits, -1)], 'next': toks})
@@ -219,7 +243,9 @@ def lookahead_generate(model, cache, prompt, max_length, eos_token_id=2, decodin
             full = torch.cat([torch.ones((T, C), dtype=torch.long), torch.from_numpy(d_mask)], dim=1)
             logits, past = model.forward(torch.tensor(d_ids, dtype=torch.long), full, past)
             am = [int(x) for x in torch.argmax(logits, -1)]
-            if T == 1:
+            if logits_processor:
+                toks, rows = accept_scan_sequential(d_ids, d_mask, logits, seq, logits_processor)
+            elif T == 1:
                 toks, rows = [am[0]], [0]
             else:
                 toks, rows = accept_scan(d_ids, d_mask, am)

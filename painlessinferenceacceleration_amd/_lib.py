@@ -140,6 +140,7 @@ PROTOTYPES = {
     "la_llama_reset": (i32, vp, vp),
     "la_llama_step": (i32, vp, vp, vp, vp),
     "la_llama_step_eager": (i32, vp, vp, vp, vp),
+    "la_llama_commit": (i32, vp, vp, pi32, i32, vp),
     "la_llama_buffer": (vp, vp, i32),
     "la_llama_profile": (i32, vp, vp, vp, i32, pf32, pi32),
     "la_resid_norm_router": (i32, vp, vp, vp, i32, vp, i32, f32, vp, vp, i32, i32, vp, vp),

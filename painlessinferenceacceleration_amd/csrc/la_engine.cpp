@@ -363,6 +363,28 @@ extern "C" int la_llama_step_eager(la_llama* m, void* stream, const int32_t* hos
     return LA_OK;
 }
 
+// Host-decided commit after a mode-2 (verify only) step: rows[0..n) of the last block become main-cache rows
+// nkeys..nkeys+n (the sequential accept of pretrained_model.py:825-875 with a non-empty logits-processor list).
+extern "C" int la_llama_commit(la_llama* m, void* stream, const int32_t* rows, int n, int32_t* host_out) {
+    if (!m || !rows || n < 1 || n > LA_TREE_MAX) return LA_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int hdr[LA_ST_WORDS];
+    HIPCHK(hipMemcpyAsync(hdr, m->state, sizeof(hdr), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < n; ++i) {
+        if (rows[i] < 0 || rows[i] >= hdr[LA_ST_T]) { la_set_error("commit: row outside the last block"); return LA_E_RANGE; }
+        hdr[LA_ST_SRCIDX + i] = rows[i];
+    }
+    hdr[LA_ST_DSTBASE] = hdr[LA_ST_NKEYS];
+    hdr[LA_ST_NCOMMIT] = n;
+    hdr[LA_ST_NKEYS] += n;
+    HIPCHK(hipMemcpyAsync(m->state, hdr, sizeof(hdr), hipMemcpyHostToDevice, st));
+    KCHK(lk_kv_commit(st, m->kfresh, m->vfresh, m->kmain, m->vmain, m->state, m->cfg.n_layers, m->cfg.n_kv_heads, m->total_keys));
+    if (host_out) HIPCHK(hipMemcpyAsync(host_out, m->state, (LA_ST_OUTTOK + 64) * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));       // hdr lives on this stack frame
+    return LA_OK;
+}
+
 extern "C" void* la_llama_buffer(la_llama* m, int which) {
     if (!m) return nullptr;
     switch (which) {

@@ -1047,7 +1047,10 @@ __global__ void k_accept_scan(const int* __restrict__ ids, const unsigned long l
     const int nkeys = state[LA_ST_NKEYS];
     const int am = state[LA_ST_ARGMAX + j];
     int n_commit;
-    if (mode == 1) {
+    if (mode == 2) {            // verify only: the host walks the tree (sequential logits processors) and commits later
+        if (j == 0) state[LA_ST_NOUT] = 0;
+        n_commit = 0;
+    } else if (mode == 1) {
         if (j < T) state[LA_ST_SRCIDX + j] = j;
         const int last = __shfl(am, T - 1, 64);   // executed by all lanes
         if (j == 0) { state[LA_ST_OUTTOK] = last; state[LA_ST_NOUT] = 1; }

@@ -401,6 +401,20 @@ class LlamaVerifyEngine(object):
         self.n_keys = int(o[_lib.LA_ST_NKEYS])
         return o[_lib.LA_ST_OUTTOK:_lib.LA_ST_OUTTOK + n_out].tolist(), int(o[_lib.LA_ST_NCOMMIT])
 
+    def verify_only(self, ids, rowmask, eager=False):
+        """Forward of one block without the device accept walk (mode 2): logits() holds one row per tree token, nothing is
+        committed until commit()."""
+        self.step_async(ids, rowmask, mode=2, eager=eager)
+        self.stream.synchronize()
+
+    def commit(self, rows):
+        """Keep the K/V of tree rows `rows` (root first) of the last verify_only block."""
+        arr = np.ascontiguousarray(rows, dtype=np.int32)
+        assert self.n_keys + len(arr) <= self.max_keys, 'KV cache capacity exceeded'
+        check(lib.la_llama_commit(self._h, self._sp(), arr.ctypes.data_as(_lib.pi32), len(arr), self.host_out.data_ptr()),
+              'llama_commit')
+        self.n_keys = int(self._out_np[_lib.LA_ST_NKEYS])
+
     _CHAIN = np.array([(2 << t) - 1 for t in range(63)] + [0xFFFFFFFFFFFFFFFF], dtype=np.uint64)
 
     def prefill(self, prompt_ids, eager=False):

@@ -77,9 +77,11 @@ class LookaheadPreTrainedModel(object):
                              pad_token_id=None, eos_token_id=None, output_attentions=None,
                              output_hidden_states=None, output_scores=None, return_dict_in_generate=None,
                              synced_gpus=False, streamer=None, **model_kwargs):
-        if logits_processor is not None and len(logits_processor) > 0:
-            raise NotImplementedError('non-empty logits_processor lists need the sequential accept path '
-                                      '(SURVEY H7, next-row N4); the device accept scan is greedy')
+        # processors are applied sequentially along the accepted path (pretrained_model.py:834), so a non-empty
+        # list (or sampling) takes the host-walked path: device forward only (mode 2), one logits row per accepted token,
+        # host-decided commit.  The empty-list greedy default stays entirely on the device.
+        sequential = (logits_processor is not None and len(logits_processor) > 0) or \
+            bool(model_kwargs.get('decoding_kwargs', {}).get('do_sample', False))
         if output_scores or output_attentions or output_hidden_states:
             raise NotImplementedError('scores/attentions/hidden_states are not produced by the device path (SURVEY H8)')
         gc = self.generation_config
@@ -119,9 +121,21 @@ class LookaheadPreTrainedModel(object):
         eng.reset()
         first = True
         eos_set = set(eos_token_id) if eos_token_id is not None else set()
+        do_sample = bool(decoding_kwargs.get('do_sample', False))
+
+        def pick(scores_ids, row):
+            """next token from one logits row through the processor list (pretrained_model.py:833-839)"""
+            ctx = torch.tensor([scores_ids], dtype=torch.long, device=eng.device)
+            scores = logits_processor(ctx, eng.logits()[row][None].clone()) if logits_processor is not None and \
+                len(logits_processor) > 0 else eng.logits()[row][None]
+            if do_sample:
+                return int(torch.multinomial(torch.softmax(scores.float(), dim=-1), num_samples=1)[0, 0])
+            return int(torch.argmax(scores, dim=-1)[0])
+
         while True:
             if first:
-                next_tokens = [eng.prefill(seq)]
+                tok = eng.prefill(seq)
+                next_tokens = [pick(seq, (len(seq) - 1) % 64)] if sequential else [tok]
                 decoding_kwargs['dls'].append(1)
                 decoding_kwargs['edls'].append(1)
                 first = False
@@ -129,7 +143,25 @@ class LookaheadPreTrainedModel(object):
                 ids, rowmask = self.lookahead_prepare_inputs_for_generation(seq, decoding_kwargs, len(seq))
                 if len(ids) == 0:
                     ids, rowmask = np.asarray(seq[-1:], dtype=np.int32), _ONE
-                next_tokens, _ = eng.step(ids, rowmask, mode=0)
+                if sequential:
+                    eng.verify_only(ids, rowmask)
+                    T = len(ids)
+                    parent = [-1] * T
+                    for j in range(1, T):
+                        below = int(rowmask[j]) & ((1 << j) - 1)
+                        parent[j] = below.bit_length() - 1
+                    cur, rows, next_tokens = 0, [0], []
+                    while True:
+                        t = pick(seq + next_tokens, cur)
+                        next_tokens.append(t)
+                        nxt = next((j for j in range(1, T) if parent[j] == cur and int(ids[j]) == t), None)
+                        if nxt is None:
+                            break
+                        cur = nxt
+                        rows.append(cur)
+                    eng.commit(rows)
+                else:
+                    next_tokens, _ = eng.step(ids, rowmask, mode=0)
                 decoding_kwargs['dls'].append(len(ids))
                 decoding_kwargs['edls'].append(len(next_tokens))
                 if decoding_kwargs.get('debug_lookahead', False):
@@ -161,18 +193,37 @@ class LookaheadPreTrainedModel(object):
 
     # ---------------------------------------------------------------------------------- plain greedy (mode off)
     @torch.no_grad()
-    def greedy_search(self, input_ids, max_length, eos_token_id=None):
-        """Plain greedy decoding through the same engine (T=1 blocks): the `use_lookahead=False` leg of the
-        reference's examples (examples/llama_example.py:39-69)."""
+    def greedy_search(self, input_ids, max_length, eos_token_id=None, logits_processor=None, do_sample=False):
+        """Plain decoding through the same engine (T=1 blocks): the `use_lookahead=False` leg of the reference's
+        examples (examples/llama_example.py:39-69).  With a processor list or sampling each token is picked on the host
+        from the block's logits row (forward-only step + commit)."""
         eos = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
         seq = input_ids[0].tolist()
         eng = self.engine
         eng.reset()
+        host_pick = do_sample or (logits_processor is not None and len(logits_processor) > 0)
+
+        def pick(row):
+            ctx = torch.tensor([seq], dtype=torch.long, device=eng.device)
+            scores = eng.logits()[row][None].clone()
+            if logits_processor is not None and len(logits_processor) > 0:
+                scores = logits_processor(ctx, scores)
+            if do_sample:
+                return int(torch.multinomial(torch.softmax(scores.float(), dim=-1), num_samples=1)[0, 0])
+            return int(torch.argmax(scores, dim=-1)[0])
+
         tok = eng.prefill(seq)
+        if host_pick:
+            tok = pick((len(seq) - 1) % 64)
         seq.append(tok)
         while len(seq) < max_length and tok not in eos:
-            toks, _ = eng.step(np.asarray([tok], dtype=np.int32), _ONE, mode=0)
-            tok = toks[0]
+            if host_pick:
+                eng.verify_only(np.asarray([tok], dtype=np.int32), _ONE)
+                tok = pick(0)
+                eng.commit([0])
+            else:
+                toks, _ = eng.step(np.asarray([tok], dtype=np.int32), _ONE, mode=0)
+                tok = toks[0]
             seq.append(tok)
         return torch.tensor([seq], dtype=torch.long, device=input_ids.device)
 
@@ -189,19 +240,23 @@ class LookaheadPreTrainedModel(object):
                  streamer=None, do_sample=False, repetition_penalty=1.0, **unused):
         """Minimal generate(): the arguments the reference's examples/benchmarks pass
         (benchmarks/benchmark.py:282-300, examples/llama_example.py:51-60)."""
-        if do_sample or repetition_penalty != 1.0:
-            raise NotImplementedError('sampling / repetition penalty are outside the parity scope (SURVEY H7)')
         if max_length is None:
             max_length = input_ids.size(1) + (max_new_tokens if max_new_tokens is not None else 20)
         dk = dict(decoding_kwargs or {})
+        processors = unused.get('logits_processor', None)
+        if repetition_penalty != 1.0:                      # what generate() builds from repetition_penalty
+            from transformers import LogitsProcessorList, RepetitionPenaltyLogitsProcessor
+            processors = LogitsProcessorList(list(processors or []) + [RepetitionPenaltyLogitsProcessor(penalty=repetition_penalty)])
         if self._get_generation_mode(dk) == GenerationMode.LOOKAHEAD_GENERATION:
             dk['generation_mode'] = GenerationMode.LOOKAHEAD_GENERATION
-            dk['do_sample'] = False
-            return self.lookahead_generation(input_ids, stopping_criteria=int(max_length), pad_token_id=pad_token_id,
+            dk['do_sample'] = bool(do_sample)
+            return self.lookahead_generation(input_ids, logits_processor=processors, stopping_criteria=int(max_length),
+                                             pad_token_id=pad_token_id,
                                              eos_token_id=eos_token_id, return_dict_in_generate=return_dict_in_generate,
                                              streamer=streamer, attention_mask=attention_mask, decoding_kwargs=dk)
         out = self.greedy_search(input_ids, max_length, eos_token_id if eos_token_id is not None
-                                 else getattr(self.generation_config, 'eos_token_id', None))
+                                 else getattr(self.generation_config, 'eos_token_id', None),
+                                 logits_processor=processors, do_sample=do_sample)
         return LookaheadDecoderOnlyOutput(sequences=out, kwargs={}) if return_dict_in_generate else out
 
     def stream_generate(self, *args, **kwargs):

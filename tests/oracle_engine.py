@@ -33,13 +33,29 @@ class OracleEngine(object):
             blk = prompt_ids[s:s + 64]
             rows = [(2 << t) - 1 for t in range(len(blk))]
             logits, past, _ = self._forward(blk, rows)
+            self._logits = logits
             self.past = past
             self.n_keys += len(blk)
             tok = int(torch.argmax(logits[-1].float()))
         return tok
 
+    device = torch.device('cpu')
+
+    def verify_only(self, ids, rowmask, eager=False):
+        self._logits, self._pending, _ = self._forward(ids, rowmask)
+
+    def logits(self):
+        return self._logits
+
+    def commit(self, rows):
+        keep = list(range(self.n_keys)) + [self.n_keys + int(r) for r in rows]
+        idx = torch.tensor(keep, dtype=torch.long)
+        self.past = [(k[:, idx], v[:, idx]) for k, v in self._pending]
+        self.n_keys += len(rows)
+
     def step(self, ids, rowmask, mode=0, eager=False):
         logits, past, tree = self._forward(ids, rowmask)
+        self._logits = logits
         am = [int(x) for x in torch.argmax(logits.float(), -1)]
         self.last_argmax = am
         toks, rows = lo.accept_scan([int(x) for x in ids], tree, am)

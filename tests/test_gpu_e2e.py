@@ -235,3 +235,45 @@ def test_full_size_properties_llama7b_roundtrip():
                                       decoding_kwargs=dict(dk))
     assert out2.sequences[0].tolist()[:96 + n_new] == gre[:96 + n_new]
     assert np.mean(out2.kwargs['edls'][1:]) > 8, out2.kwargs['edls']
+
+
+def test_sequential_processor_path_on_device():
+    """Forward-only step (mode 2) + host walk + la_llama_commit: with a repetition penalty the lookahead output equals
+    plain decoding with the same penalty through the same engine (decisive weights), drafts are still multi-token
+    accepted, and an identity walk reproduces the device accept scan bit for bit."""
+    from transformers import LogitsProcessorList, RepetitionPenaltyLogitsProcessor
+    from painlessinferenceacceleration_amd.llama_engine import random_weights
+    shape = tiny_shape()
+    sd = random_weights(shape, seed=2, device='cpu', decisive=True)
+    model = LlamaForCausalLM(shape, sd, max_length=512, eos_token_id=None)
+    rs = np.random.RandomState(3)
+    prompt = torch.tensor([rs.randint(3, shape.vocab, size=50).tolist()])
+    procs = LogitsProcessorList([RepetitionPenaltyLogitsProcessor(1.05)])
+    plain = model.greedy_search(prompt, 50 + 150, eos_token_id=None, logits_processor=procs)[0].tolist()
+    dk = {'use_lookahead': True, 'decoding_length': 64, 'branch_length': 12, 'stop_words': {}}
+    for rep in range(2):
+        out = model.lookahead_generation(prompt, logits_processor=procs, stopping_criteria=50 + 150, eos_token_id=[None],
+                                         return_dict_in_generate=True, decoding_kwargs=dict(dk))
+        seq = out.sequences[0].tolist()
+        assert seq[:200] == plain[:len(seq)][:200], rep
+    assert np.mean(out.kwargs['edls'][1:]) > 2, out.kwargs['edls']
+    # identity walk == device accept scan
+    eng = model.engine
+    eng.reset()
+    tok = eng.prefill(prompt[0].tolist())
+    _, rows = random_tree(rs, 40)
+    ids = np.concatenate([[tok], rs.randint(3, shape.vocab, size=39)]).astype(np.int32)
+    eng.verify_only(ids, rows)
+    lg = eng.logits()[:40].clone()
+    am = lg.float().argmax(-1).tolist()
+    toks, acc = lo.accept_scan(ids.tolist(), _mask_from_rows(rows, 40), am)
+    eng.commit(acc)
+    n1 = eng.n_keys
+    eng2 = LlamaVerifyEngine(shape, random_weights(shape, seed=2, device='cpu', decisive=True), max_length=512)
+    eng2.prefill(prompt[0].tolist())
+    toks2, _ = eng2.step(ids, rows)
+    assert toks2 == toks and eng2.n_keys == n1 and torch.equal(eng2.logits()[:40], lg)
+    nxt = np.asarray([toks[-1]], dtype=np.int32)
+    one = np.array([1], dtype=np.uint64)
+    eng.step(nxt, one); eng2.step(nxt, one)
+    assert torch.equal(eng.logits()[:1], eng2.logits()[:1])        # the committed KV rows are identical

@@ -66,11 +66,8 @@ def test_generate_front_door_and_unsupported_options():
     b = m.generate(input_ids=prompt, max_new_tokens=30, decoding_kwargs={'use_lookahead': False}, eos_token_id=2)
     n = min(a.shape[1], b.shape[1])
     assert a[0, :n].tolist() == b[0, :n].tolist()
-    with pytest.raises(NotImplementedError):
-        m.generate(input_ids=prompt, max_new_tokens=5, decoding_kwargs=dict(DK), do_sample=True)
-    with pytest.raises(NotImplementedError):
-        m.lookahead_generation(prompt, logits_processor=[lambda *a: None], stopping_criteria=60,
-                               decoding_kwargs=dict(DK))
+    with pytest.raises(NotImplementedError):           # scores are not produced by the device path
+        m.lookahead_generation(prompt, stopping_criteria=60, output_scores=True, decoding_kwargs=dict(DK))
 
 
 # ------------------------------------------------------------------------------------------------ batch twin
@@ -142,3 +139,31 @@ def test_benchmark_harness_perf_check_and_trie_loop(capsys):
     r = Benchmark.perf_check_trie(LookaheadCache(), [answers[0]] * 3, [prompt], [answers[0]], decoding_length=16,
                                   branch_length=4, edl=4, verbose=False)
     assert r['gets'] == 6 and r['put_tokens'] == len(prompt) + len(answers[0])
+
+
+def test_loop_with_logits_processors_reproduces_reference_run():
+    """Sequential accept path of the product host loop (forward-only step, host walk, commit) on the oracle-backed engine
+    against the reference run with RepetitionPenaltyLogitsProcessor(1.3); generate(repetition_penalty=...) builds the
+    same list; greedy_search applies it too."""
+    import os
+    from transformers import LogitsProcessorList, RepetitionPenaltyLogitsProcessor
+    from tests.tiny_model import GOLDEN
+    g = np.load(os.path.join(GOLDEN, 'llama_tiny_fp32_rep.npz'))
+    m = Model(torch.float32)
+    prompt = g['prompt'].tolist()
+    procs = LogitsProcessorList([RepetitionPenaltyLogitsProcessor(float(g['penalty']))])
+    for r in range(2):
+        out = m.lookahead_generation(torch.tensor([prompt]), logits_processor=procs, stopping_criteria=len(prompt) + 64,
+                                     eos_token_id=2, return_dict_in_generate=True, decoding_kwargs=dict(DK))
+        assert out.sequences[0].tolist() == g[f'r{r}_sequences'].tolist()
+        assert out.kwargs['dls'] == g[f'r{r}_dls'].tolist() and out.kwargs['edls'] == g[f'r{r}_edls'].tolist()
+    m2 = Model(torch.float32)
+    out = m2.generate(input_ids=torch.tensor([prompt]), max_new_tokens=64, repetition_penalty=float(g['penalty']),
+                      eos_token_id=2, return_dict_in_generate=True, decoding_kwargs=dict(DK))
+    assert out.sequences[0].tolist() == g['r0_sequences'].tolist()
+    plain = m2.generate(input_ids=torch.tensor([prompt]), max_new_tokens=64, repetition_penalty=float(g['penalty']),
+                        eos_token_id=2, decoding_kwargs={'use_lookahead': False})
+    assert plain[0].tolist() == g['r0_sequences'].tolist()          # lookahead with processors == plain decoding with them
+    s = m2.generate(input_ids=torch.tensor([prompt]), max_new_tokens=8, do_sample=True, eos_token_id=2,
+                    decoding_kwargs=dict(DK))
+    assert s.shape[1] >= len(prompt) + 1

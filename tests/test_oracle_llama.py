@@ -153,3 +153,17 @@ def test_oracle_gqa_and_moe_match_reference_forward(kind, tag, dtype):
         if kind == 'mixtral' and dtype == torch.float32:
             rl = g[f'{kind}_{case}_router1']
             assert np.abs(model.last_router_logits.float().numpy() - rl).max() < 1e-4 * max(1.0, np.abs(rl).max())
+
+
+def test_oracle_sequential_processor_path_matches_reference():
+    """RepetitionPenaltyLogitsProcessor(1.3): the reference's sequential accept walk (pretrained_model.py:825-875)."""
+    from transformers import LogitsProcessorList, RepetitionPenaltyLogitsProcessor
+    g = np.load(os.path.join(GOLDEN, 'llama_tiny_fp32_rep.npz'))
+    model = lo.OracleLlama(tiny_shape(), tiny_weights(0, torch.float32))
+    cache = TrieOracle()
+    prompt = g['prompt'].tolist()
+    procs = LogitsProcessorList([RepetitionPenaltyLogitsProcessor(float(g['penalty']))])
+    for r in range(2):
+        out = lo.lookahead_generate(model, cache, prompt, len(prompt) + 64, eos_token_id=2, logits_processor=procs)
+        assert out['sequences'] == g[f'r{r}_sequences'].tolist()
+        assert out['dls'] == g[f'r{r}_dls'].tolist() and out['edls'] == g[f'r{r}_edls'].tolist()
