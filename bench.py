@@ -191,6 +191,12 @@ def main():
         ids, rowmask, _, _ = cache.hier_get_packed(seq[-2:], decoding_length=DL, branch_length=ubl, min_input_size=0,
                                                    min_output_size=DL // 2, mode='mix', idx=rank)
         qts.append(time.time() - tq)
+        if os.environ.get('BENCH_DEBUG'):
+            t1 = time.time()
+            cache.hier_get_packed(seq[-2:], decoding_length=DL, branch_length=ubl, min_input_size=0, min_output_size=DL // 2,
+                                  mode='mix', idx=rank)
+            print(f'[debug] query {1e3 * qts[-1]:.3f} ms, repeated {1e3 * (time.time() - t1):.3f} ms, T {len(ids)} stats {cache.stats()}',
+                  file=sys.stderr, flush=True)
         toks, _ = eng.step(ids, rowmask, mode=0)
         if os.environ.get('BENCH_DEBUG') and len(edls) < 6:
             k = len(seq) - P
@@ -210,6 +216,10 @@ def main():
         else:
             cache.stream_put(toks, branch_length=BL + 1, final=False, idx=rank)
 
+    import gc
+    gc.collect()
+    gc.freeze()          # a generation-2 collection over torch's import graph costs tens of ms on the host thread that
+                         # drives the loop; the serving loop allocates nothing that needs cycle collection
     for _ in range(W):
         one_step()
     n0 = len(edls)

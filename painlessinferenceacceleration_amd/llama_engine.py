@@ -116,10 +116,12 @@ def random_weights(shape, seed=0, std=0.02, device='cpu', dtype=torch.bfloat16, 
         sd[p + 'post_attention_layernorm.weight'] = torch.ones(shape.hidden, device=device, dtype=dtype)
     sd['model.norm.weight'] = torch.ones(shape.hidden, device=device, dtype=dtype)
     if decisive:
-        # pi permutes [3, V) and fixes the special ids 0..2: a sequence that starts from ordinary tokens never emits
-        # token 0, whose drafts the reference mis-roots (`match_token_id or self.token_id`, lookahead_cache.py:129, H1g)
-        perm = torch.cat([torch.arange(3, device=device),
-                          3 + torch.randperm(shape.vocab - 3, generator=g, device=device)])
+        # pi fixes the special ids 0..2 and is ONE cycle over [3, V): a sequence that starts from ordinary tokens never
+        # emits token 0, whose drafts the reference mis-roots (`match_token_id or self.token_id`, lookahead_cache.py:129,
+        # H1g), and never repeats itself within V-3 tokens (a short cycle would turn the warm-up text periodic)
+        order = 3 + torch.randperm(shape.vocab - 3, generator=g, device=device)
+        perm = torch.arange(shape.vocab, device=device)
+        perm[order] = torch.roll(order, -1)
         head = torch.empty_like(sd['model.embed_tokens.weight'])
         head[perm] = sd['model.embed_tokens.weight']          # lm_head[pi(t)] = embed[t]
         sd['lm_head.weight'] = head

@@ -73,7 +73,20 @@ class LookaheadPreTrainedModel(object):
 
     # ---------------------------------------------------------------------------------------------- the loop
     @torch.no_grad()
-    def lookahead_generation(self, input_ids, logits_processor=None, stopping_criteria=None, max_length=None,
+    def lookahead_generation(self, *args, **kwargs):
+        """Entry point (signature of the reference's lookahead_generation, see _lookahead_generation).  The step loop
+        runs with the cyclic garbage collector paused: a generation-2 pass over torch's object graph stalls the host
+        thread for tens of ms (measured 37 ms = 9 verify steps) and the loop creates no reference cycles."""
+        import gc
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            return self._lookahead_generation(*args, **kwargs)
+        finally:
+            if was_enabled:
+                gc.enable()
+
+    def _lookahead_generation(self, input_ids, logits_processor=None, stopping_criteria=None, max_length=None,
                              pad_token_id=None, eos_token_id=None, output_attentions=None,
                              output_hidden_states=None, output_scores=None, return_dict_in_generate=None,
                              synced_gpus=False, streamer=None, **model_kwargs):
