@@ -21,6 +21,8 @@ struct la_llama {
     std::vector<const void*> ex_gateup, ex_down;     // [n_layers][n_experts] copies of the caller's pointer arrays
     uint16_t* moe_acc;
     float* route_w;
+    int* fuse_cnt;      // [2 * n_layers] hand-over counters of the fused norm->GEMM launches (zeroed every step)
+    int fuse;           // bit 0: post-attention norm -> gate/up GEMM, bit 1: input norm of layer l>0 -> QKV GEMM
     la_llama_weights w;
     // derived
     int qkv_n, o_k, nsplit;
@@ -70,6 +72,13 @@ static void resolve_cfg(la_llama* m) {
     // qkv_ks == -1 in the config selects the unfused path (plain [Wq;Wk;Wv] packing + k_qkv_post)
     m->qkv_fused = c.gemm_cfg[1] >= 0;
     if (!m->qkv_fused) m->qkv_ks = 1;
+    // in-kernel norm fusion needs the balanced (one workgroup per CU) GEMM, 4 split-K slabs in front of it, a dense MLP
+    m->fuse = 0;
+    if (c.fuse >= 0 && c.n_experts == 0) {
+        const int want = c.fuse > 0 ? c.fuse : 3;
+        if ((want & 1) && c.balanced_wg[1] >= LA_TREE_MAX && m->o_ks == 4) m->fuse |= 1;
+        if ((want & 2) && c.balanced_wg[0] >= LA_TREE_MAX && m->down_ks == 4) m->fuse |= 2;
+    }
     if (m->qkv_n % 64) m->qkv_rb = (m->qkv_rb & ~0xff) | 1;
     if (c.hidden % 64) { m->o_rb = (m->o_rb & ~0xff) | 1; m->down_rb = (m->down_rb & ~0xff) | 1; }
     if (c.vocab % 64) m->lm_rb = (m->lm_rb & ~0xff) | 1;
@@ -112,6 +121,7 @@ static size_t carve(la_llama* m, char* base) {
     m->bstate = cv.take<int>(LA_BST_WORDS);
     m->bin = cv.take<int>(LA_BIN_WORDS);
     m->moe_acc = cv.take<uint16_t>(c.n_experts > 0 ? (size_t)64 * c.hidden : 8);
+    m->fuse_cnt = cv.take<int>((size_t)2 * c.n_layers + 8);
     m->route_w = cv.take<float>((size_t)(c.n_experts > 0 ? c.n_layers : 1) * 64 * LA_MOE_MAX_E);   // kept per layer (parity tests)
     return align_up(cv.off, 256);
 }
@@ -221,6 +231,7 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
     if (batch) KCHK(lk_build_tree_inputs_b(st, m->bin, m->bstate, m->pos, m->rowmask, m->ids));
     else KCHK(lk_build_tree_inputs(st, m->in, m->state, m->pos, m->rowmask, m->ids));
     const int cf = c.norm_cast_first;
+    if (m->fuse) HIPCHK(hipMemsetAsync(m->fuse_cnt, 0, sizeof(int) * 2 * c.n_layers, st));
     KCHK(lk_embed_norm(st, m->w.embed, m->ids, m->layers[0].norm1, c.hidden, c.rms_eps, m->h, m->xp, cf));
     for (int l = 0; l < c.n_layers; ++l) {
         const la_llama_layer_weights& L = m->layers[l];
@@ -228,8 +239,10 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
         uint16_t* vf = m->vfresh + (size_t)l * m->fresh_layer_elems;
         P(KC_QKV);
         if (c.balanced_wg[0] > 0) {
+            // layers > 0: the input norm (residual + down-projection slabs of the previous layer) runs inside this launch
+            FusedNorm fq{m->slabs, m->down_ks, m->h, L.norm1, c.hidden, c.rms_eps, cf, m->fuse_cnt + 2 * l};
             KCHK(lk_gemm64r_qkv(st, L.wqkv, m->xp, c.n_heads, c.n_kv_heads, c.hidden, c.balanced_wg[0], m->pos,
-                                m->w.rope_cos, m->w.rope_sin, m->qf, kf, vf));
+                                m->w.rope_cos, m->w.rope_sin, m->qf, kf, vf, ((m->fuse & 2) && l > 0) ? &fq : nullptr));
         } else if (m->qkv_fused) {
             KCHK(lk_gemm64_qkv(st, L.wqkv, m->xp, c.n_heads, c.n_kv_heads, c.hidden, m->pos, m->w.rope_cos, m->w.rope_sin,
                                m->qf, kf, vf, m->qkv_rb >> 8));
@@ -273,14 +286,21 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
             KCHK(lk_resid_norm_addend(st, m->h, m->moe_acc, nw, c.hidden, c.rms_eps, m->xp, cf));
             continue;
         }
-        KCHK(lk_resid_norm(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp, cf));
-        P(KC_GATEUP);
-        if (c.balanced_wg[1] > 0) KCHK(lk_gemm64r_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, c.balanced_wg[1], m->act_xp));
-        else KCHK(lk_gemm64_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, m->act_xp, m->gu_variant));
+        if (m->fuse & 1) {
+            FusedNorm fg{m->slabs, m->o_ks, m->h, L.norm2, c.hidden, c.rms_eps, cf, m->fuse_cnt + 2 * l + 1};
+            P(KC_GATEUP);
+            KCHK(lk_gemm64r_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, c.balanced_wg[1], m->act_xp, nullptr, &fg));
+        } else {
+            KCHK(lk_resid_norm(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp, cf));
+            P(KC_GATEUP);
+            if (c.balanced_wg[1] > 0) KCHK(lk_gemm64r_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, c.balanced_wg[1], m->act_xp));
+            else KCHK(lk_gemm64_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, m->act_xp, m->gu_variant));
+        }
         P(KC_DOWN);
         KCHK(lk_gemm64_slab(st, L.wdown, m->act_xp, c.hidden, c.ffn, m->down_rb, m->down_ks, m->slabs));
         P(KC_OTHER);
-        KCHK(lk_resid_norm(st, m->h, m->slabs, m->down_ks, nw, c.hidden, c.rms_eps, m->xp, cf));
+        if (!((m->fuse & 2) && l + 1 < c.n_layers))          // otherwise fused into the next layer's QKV launch
+            KCHK(lk_resid_norm(st, m->h, m->slabs, m->down_ks, nw, c.hidden, c.rms_eps, m->xp, cf));
     }
     P(KC_LMHEAD);
     int* am_rows = batch ? m->bstate + LA_BST_ARGMAX : m->state + LA_ST_ARGMAX;

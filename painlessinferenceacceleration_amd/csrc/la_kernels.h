@@ -5,6 +5,14 @@
 #include <stdint.h>
 #include "../../include/lookahead_hip.h"
 
+// residual + RMSNorm row stage fused into the consuming balanced GEMM (producer workgroups 0..63, in-kernel hand-over)
+struct FusedNorm {
+    const float* slabs; int n_slabs;     // split-K partial sums of the preceding projection
+    void* h; const void* nw;             // residual stream (updated in place), norm weight
+    int hidden; float eps; int cast_first;
+    int* counter;                        // zeroed device int, one per fused launch and step
+};
+
 int lk_pack_weight(hipStream_t st, const void* w, const void* w2, int N, int K, int interleave2, void* out);
 int lk_pack_x(hipStream_t st, const void* x, int K, void* out);
 int lk_gemm64_slab(hipStream_t st, const void* wp, const void* xp, int N, int K, int rb, int ksplit, float* slabs,
@@ -21,10 +29,10 @@ int lk_rowplan(int kind, int n_rows, int n_wg, int* out);
 long lk_planned_elems(int kind, int n_rows, int K, int n_wg);
 int lk_pack_planned(hipStream_t st, const void* w, const void* w2, const int* d_plan, int kind, int n_rows, int K, int n_wg, void* out);
 int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, int n_wg, void* act_xp,
-                      const float* route_col = nullptr);
+                      const float* route_col = nullptr, const FusedNorm* fn = nullptr);
 int lk_gemm64r_logits(hipStream_t st, const void* wp, const void* xp, int V, int K, int n_wg, void* logits, float* cv, int* ci);
 int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int nkv, int K, int n_wg, const int* pos,
-                   const void* rcos, const void* rsin, void* qf, void* kfresh, void* vfresh);
+                   const void* rcos, const void* rsin, void* qf, void* kfresh, void* vfresh, const FusedNorm* fn = nullptr);
 int lk_argmax_finalize(hipStream_t st, const float* cv, const int* ci, int n_tiles, int* out_rows);
 int lk_embed_norm(hipStream_t st, const void* embed, const int* ids, const void* nw, int hidden, float eps, void* h, void* xp,
                   int cast_first = 0);

@@ -2,6 +2,7 @@
 // wave64, v_mfma_f32_32x32x16_bf16, weights streamed HBM -> VGPR in MFMA fragment order.
 // Reference semantics: lookahead/lookahead/models/llama/modeling_llama.py (cited per kernel).
 #include "la_common.h"
+#include <type_traits>
 #include "la_kernels.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -58,6 +59,176 @@ __global__ void k_pack_x(const bf16_t* __restrict__ x, int K, bf16_t* __restrict
     if (gid >= LA_TB * K8) return;
     int t = gid / K8, k = (gid % K8) * 8;
     *(bf16x8*)(out + xp_offset(t, k)) = *(const bf16x8*)(x + (size_t)t * K + k);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row kernels: embedding gather + RMSNorm, residual add + RMSNorm  (LlamaRMSNorm, :76-90;
+// LlamaDecoderLayer residual adds, :352-363).  One workgroup per token row.
+// ---------------------------------------------------------------------------------------------
+template <int NWAVES>
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NWAVES; ++i) tot += sh[i];
+    return tot;
+}
+
+// h_new = bf16(h + bf16(sum slabs)); x = bf16(w * (h_new * rsqrt(mean(h_new^2)+eps)))  (fp32 math).
+// 512 threads, <= 2 chunks of 8 elements per thread (hidden <= 8192).  NS is a template parameter so that every
+// load of the row (h, NS slabs, norm weight) is issued before the first use: one memory round trip, not NS+2.
+template <int NS, bool MOE>
+__device__ __forceinline__ void row_norm_body(const int t, float* sh, float (*shr)[LA_MOE_MAX_E],
+                                              const bf16_t* __restrict__ embed, const int* __restrict__ ids,
+                                              bf16_t* __restrict__ h, const float* __restrict__ slabs,
+                                              const bf16_t* __restrict__ nw, int hidden, float eps,
+                                              bf16_t* __restrict__ xp, const bf16_t* __restrict__ addend,
+                                              const bf16_t* __restrict__ wrouter, int n_experts, int top_k,
+                                              float* __restrict__ route_w, const int* __restrict__ n_rows,
+                                              int cast_first) {
+    const int nchunk = hidden >> 3;
+    const bf16_t* src = embed ? embed + (size_t)ids[t] * hidden : h + (size_t)t * hidden;
+    bf16x8 hv[2], wv[2], av[2];
+    f32x4 sl[NS > 0 ? NS : 1][2][2];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 512;
+        if (c < nchunk) {
+            hv[ci] = *(const bf16x8*)(src + c * 8);
+            wv[ci] = *(const bf16x8*)(nw + c * 8);
+            if (NS == 0 && addend) av[ci] = *(const bf16x8*)(addend + (size_t)t * hidden + c * 8);
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) {
+                const float* sp = slabs + ((size_t)s2 * LA_TB + t) * hidden + c * 8;
+                sl[s2][ci][0] = *(const f32x4*)sp;
+                sl[s2][ci][1] = *(const f32x4*)(sp + 4);
+            }
+        }
+    }
+    float vals[2][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 512;
+        if (c < nchunk) {
+            bf16x8 ho;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = bf2f((bf16_t)hv[ci][j]);
+                if (NS > 0) {
+                    float add = 0.f;
+#pragma unroll
+                    for (int s2 = 0; s2 < NS; ++s2) add += sl[s2][ci][j >> 2][j & 3];
+                    v = bfr(v + bfr(add));
+                } else if (addend) {
+                    v = bfr(v + bf2f((bf16_t)av[ci][j]));      // MoE: residual + final_hidden_states (bf16 + bf16)
+                }
+                vals[ci][j] = v;
+                ho[j] = (short)f2bf(v);
+                ss += v * v;
+            }
+            *(bf16x8*)(h + (size_t)t * hidden + c * 8) = ho;
+        }
+    }
+    const float tot = block_sum<8>(ss, sh);
+    const float rs = 1.0f / sqrtf(tot / (float)hidden + eps);
+    float rl[MOE ? LA_MOE_MAX_E : 1];
+#pragma unroll
+    for (int e = 0; e < (MOE ? LA_MOE_MAX_E : 1); ++e) rl[e] = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 512;
+        if (c < nchunk) {
+            bf16x8 xo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // LlamaRMSNorm rounds once; Mistral/MixtralRMSNorm round the normalised value before the weight multiply
+                const float nv = cast_first ? bfr(vals[ci][j] * rs) : vals[ci][j] * rs;
+                xo[j] = (short)f2bf(bf2f((bf16_t)wv[ci][j]) * nv);
+            }
+            *(bf16x8*)(xp + xp_offset(t, c * 8)) = xo;
+            if (MOE) {
+#pragma unroll
+                for (int e = 0; e < LA_MOE_MAX_E; ++e) {
+                    if (e < n_experts) {
+                        const bf16x8 gw = *(const bf16x8*)(wrouter + (size_t)e * hidden + c * 8);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) rl[e] += bf2f((bf16_t)xo[j]) * bf2f((bf16_t)gw[j]);
+                    }
+                }
+            }
+        }
+    }
+    if (!MOE) return;
+    // Router (MixtralSparseMoeBlock.forward, mixtral/modeling_mixtral.py:723-729): logits = gate(x) in the activation
+    // dtype, softmax in fp32, top-k, renormalise, cast back.  route_w[t][e] = weight of expert e for this row or 0.
+#pragma unroll
+    for (int e = 0; e < LA_MOE_MAX_E; ++e) rl[e] = wave_sum(rl[e]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int e = 0; e < LA_MOE_MAX_E; ++e) shr[threadIdx.x >> 6][e] = rl[e];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float lg[LA_MOE_MAX_E], pr[LA_MOE_MAX_E], outw[LA_MOE_MAX_E];
+        float mx = -INFINITY;
+        for (int e = 0; e < n_experts; ++e) {
+            float v = 0.f;
+            for (int w = 0; w < 8; ++w) v += shr[w][e];
+            lg[e] = bfr(v);
+            mx = fmaxf(mx, lg[e]);
+        }
+        float den = 0.f;
+        for (int e = 0; e < n_experts; ++e) { pr[e] = expf(lg[e] - mx); den += pr[e]; }
+        for (int e = 0; e < n_experts; ++e) { pr[e] = pr[e] / den; outw[e] = 0.f; }
+        unsigned taken = 0u;
+        float ksum = 0.f;
+        int pick[LA_MOE_MAX_E];
+        for (int k = 0; k < top_k; ++k) {
+            int best = -1;
+            for (int e = 0; e < n_experts; ++e)
+                if (!((taken >> e) & 1u) && (best < 0 || pr[e] > pr[best])) best = e;
+            taken |= 1u << best;
+            pick[k] = best;
+            ksum += pr[best];
+        }
+        const bool live = t < n_rows[0];
+        for (int k = 0; k < top_k; ++k) outw[pick[k]] = live ? bfr(pr[pick[k]] / ksum) : 0.f;
+        for (int e = 0; e < LA_MOE_MAX_E; ++e) route_w[t * LA_MOE_MAX_E + e] = e < n_experts ? outw[e] : 0.f;
+    }
+}
+
+template <int NS, bool MOE>
+__global__ __launch_bounds__(512) void k_row_norm(const bf16_t* __restrict__ embed, const int* __restrict__ ids,
+                                                   bf16_t* __restrict__ h, const float* __restrict__ slabs,
+                                                   const bf16_t* __restrict__ nw, int hidden, float eps,
+                                                   bf16_t* __restrict__ xp, const bf16_t* __restrict__ addend,
+                                                   const bf16_t* __restrict__ wrouter, int n_experts, int top_k,
+                                                   float* __restrict__ route_w, const int* __restrict__ n_rows,
+                                                   int cast_first) {
+    __shared__ float sh[8];
+    __shared__ float shr[MOE ? 8 : 1][LA_MOE_MAX_E];
+    row_norm_body<NS, MOE>(blockIdx.x, sh, shr, embed, ids, h, slabs, nw, hidden, eps, xp, addend, wrouter, n_experts, top_k,
+                           route_w, n_rows, cast_first);
+}
+
+// In-kernel hand-over from the 64 producer workgroups (lowest block ids, dispatched first, so a consumer never waits on a
+// workgroup that could be queued behind it) to every workgroup of the grid: producers publish their stores with an
+// agent-scope release and bump `counter`; everybody spins until it reaches `target`, then acquires.
+__device__ __forceinline__ void grid_handover(int* counter, int target, bool producer) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (producer) {
+            __threadfence();
+            __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+        __threadfence();
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -321,9 +492,17 @@ struct GemmRArgs {
     int nvl[4];     // stored rows = nv rounded up to a multiple of 4, so that a tile is a whole number of 128-B lines
     int boff[4];    // 16-byte-chunk offset of each block inside the workgroup's region
     int wg_chunks;  // 16-byte chunks per workgroup region
+    // fused producer (NSF > 0): workgroups 0..63 first run the residual + RMSNorm row kernel that produces g.xp
+    // (row = block id) while every workgroup's first weight tiles are already in flight, then hand over in-kernel
+    const float* fn_slabs;
+    bf16_t* fn_h;
+    const bf16_t* fn_nw;
+    int fn_hidden, fn_cast;
+    float fn_eps;
+    int* fn_counter;
 };
 
-template <int RB, int EPI, int D, int NW>
+template <int RB, int EPI, int D, int NW, int NSF = 0>
 __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
     extern __shared__ __attribute__((aligned(16))) float redr[];      // [NW][RB][16][64]
     const GemmArgs& a = ra.g;
@@ -337,7 +516,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
     const int ngroups = (cnt + D - 1) / D;
     const int last_valid = cnt - (ngroups - 1) * D;
     const bf16x8* __restrict__ wbase = (const bf16x8*)a.wp;
-    const bf16x8* __restrict__ xbase = (const bf16x8*)a.xp;
+    typedef const bf16x8* __restrict__ xptr_r;
+    typedef const bf16x8* xptr_n;                                       // fused producers write g.xp inside this kernel
+    typename std::conditional<(NSF > 0), xptr_n, xptr_r>::type xbase = (const bf16x8*)a.xp;
     unsigned woff[RB], wstr[RB];      // per-lane chunk offset of k-tile wb, and chunks per k-tile (2 * valid rows)
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
@@ -358,13 +539,37 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
     if (ngroups > 0) {
         bf16x8 fa[D][RB], fb[D][2];
         const int n1 = ngroups == 1 ? last_valid : D;
+        if constexpr (NSF > 0) {
+            // weights first; the activations do not exist yet
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int dd = d < n1 ? d : 0;
+            for (int d = 0; d < D; ++d) {
+                const int dd = d < n1 ? d : 0;
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wbase + woff[rb] + dd * wstr[rb]);
-            fb[d][0] = xbase[xoff + dd * 128];
-            fb[d][1] = xbase[xoff + dd * 128 + 64];
+                for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wbase + woff[rb] + dd * wstr[rb]);
+            }
+            static_assert(NW == 8, "the fused row kernel is written for 512 threads");
+            const bool producer = blockIdx.x < LA_TB;
+            if (producer)
+                row_norm_body<NSF, false>(blockIdx.x, redr, nullptr, nullptr, nullptr, ra.fn_h, ra.fn_slabs, ra.fn_nw,
+                                          ra.fn_hidden, ra.fn_eps, (bf16_t*)a.xp, nullptr, nullptr, 0, 0, nullptr, nullptr,
+                                          ra.fn_cast);
+            grid_handover(ra.fn_counter, LA_TB, producer);
+            const bf16x8* xv = (const bf16x8*)a.xp;            // not __restrict__: written by the producers above
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int dd = d < n1 ? d : 0;
+                fb[d][0] = xv[xoff + dd * 128];
+                fb[d][1] = xv[xoff + dd * 128 + 64];
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int dd = d < n1 ? d : 0;
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wbase + woff[rb] + dd * wstr[rb]);
+                fb[d][0] = xbase[xoff + dd * 128];
+                fb[d][1] = xbase[xoff + dd * 128 + 64];
+            }
         }
         for (int g = 1; g < ngroups; ++g) {
             const int nv2 = (g == ngroups - 1) ? last_valid : D;
@@ -509,147 +714,6 @@ __global__ __launch_bounds__(256) void k_argmax_finalize(const float* __restrict
         for (int w = 1; w < 4; ++w)
             if (sv[w] > best || (sv[w] == best && si[w] < bidx)) { best = sv[w]; bidx = si[w]; }
         out[t] = bidx;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Row kernels: embedding gather + RMSNorm, residual add + RMSNorm  (LlamaRMSNorm, :76-90;
-// LlamaDecoderLayer residual adds, :352-363).  One workgroup per token row.
-// ---------------------------------------------------------------------------------------------
-template <int NWAVES>
-__device__ __forceinline__ float block_sum(float v, float* sh) {
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float tot = 0.f;
-#pragma unroll
-    for (int i = 0; i < NWAVES; ++i) tot += sh[i];
-    return tot;
-}
-
-// h_new = bf16(h + bf16(sum slabs)); x = bf16(w * (h_new * rsqrt(mean(h_new^2)+eps)))  (fp32 math).
-// 512 threads, <= 2 chunks of 8 elements per thread (hidden <= 8192).  NS is a template parameter so that every
-// load of the row (h, NS slabs, norm weight) is issued before the first use: one memory round trip, not NS+2.
-template <int NS, bool MOE>
-__global__ __launch_bounds__(512) void k_row_norm(const bf16_t* __restrict__ embed, const int* __restrict__ ids,
-                                                   bf16_t* __restrict__ h, const float* __restrict__ slabs,
-                                                   const bf16_t* __restrict__ nw, int hidden, float eps,
-                                                   bf16_t* __restrict__ xp, const bf16_t* __restrict__ addend,
-                                                   const bf16_t* __restrict__ wrouter, int n_experts, int top_k,
-                                                   float* __restrict__ route_w, const int* __restrict__ n_rows,
-                                                   int cast_first) {
-    __shared__ float sh[8];
-    __shared__ float shr[MOE ? 8 : 1][LA_MOE_MAX_E];
-    const int t = blockIdx.x;
-    const int nchunk = hidden >> 3;
-    const bf16_t* src = embed ? embed + (size_t)ids[t] * hidden : h + (size_t)t * hidden;
-    bf16x8 hv[2], wv[2], av[2];
-    f32x4 sl[NS > 0 ? NS : 1][2][2];
-#pragma unroll
-    for (int ci = 0; ci < 2; ++ci) {
-        const int c = threadIdx.x + ci * 512;
-        if (c < nchunk) {
-            hv[ci] = *(const bf16x8*)(src + c * 8);
-            wv[ci] = *(const bf16x8*)(nw + c * 8);
-            if (NS == 0 && addend) av[ci] = *(const bf16x8*)(addend + (size_t)t * hidden + c * 8);
-#pragma unroll
-            for (int s2 = 0; s2 < NS; ++s2) {
-                const float* sp = slabs + ((size_t)s2 * LA_TB + t) * hidden + c * 8;
-                sl[s2][ci][0] = *(const f32x4*)sp;
-                sl[s2][ci][1] = *(const f32x4*)(sp + 4);
-            }
-        }
-    }
-    float vals[2][8];
-    float ss = 0.f;
-#pragma unroll
-    for (int ci = 0; ci < 2; ++ci) {
-        const int c = threadIdx.x + ci * 512;
-        if (c < nchunk) {
-            bf16x8 ho;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float v = bf2f((bf16_t)hv[ci][j]);
-                if (NS > 0) {
-                    float add = 0.f;
-#pragma unroll
-                    for (int s2 = 0; s2 < NS; ++s2) add += sl[s2][ci][j >> 2][j & 3];
-                    v = bfr(v + bfr(add));
-                } else if (addend) {
-                    v = bfr(v + bf2f((bf16_t)av[ci][j]));      // MoE: residual + final_hidden_states (bf16 + bf16)
-                }
-                vals[ci][j] = v;
-                ho[j] = (short)f2bf(v);
-                ss += v * v;
-            }
-            *(bf16x8*)(h + (size_t)t * hidden + c * 8) = ho;
-        }
-    }
-    const float tot = block_sum<8>(ss, sh);
-    const float rs = 1.0f / sqrtf(tot / (float)hidden + eps);
-    float rl[MOE ? LA_MOE_MAX_E : 1];
-#pragma unroll
-    for (int e = 0; e < (MOE ? LA_MOE_MAX_E : 1); ++e) rl[e] = 0.f;
-#pragma unroll
-    for (int ci = 0; ci < 2; ++ci) {
-        const int c = threadIdx.x + ci * 512;
-        if (c < nchunk) {
-            bf16x8 xo;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                // LlamaRMSNorm rounds once; Mistral/MixtralRMSNorm round the normalised value before the weight multiply
-                const float nv = cast_first ? bfr(vals[ci][j] * rs) : vals[ci][j] * rs;
-                xo[j] = (short)f2bf(bf2f((bf16_t)wv[ci][j]) * nv);
-            }
-            *(bf16x8*)(xp + xp_offset(t, c * 8)) = xo;
-            if (MOE) {
-#pragma unroll
-                for (int e = 0; e < LA_MOE_MAX_E; ++e) {
-                    if (e < n_experts) {
-                        const bf16x8 gw = *(const bf16x8*)(wrouter + (size_t)e * hidden + c * 8);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) rl[e] += bf2f((bf16_t)xo[j]) * bf2f((bf16_t)gw[j]);
-                    }
-                }
-            }
-        }
-    }
-    if (!MOE) return;
-    // Router (MixtralSparseMoeBlock.forward, mixtral/modeling_mixtral.py:723-729): logits = gate(x) in the activation
-    // dtype, softmax in fp32, top-k, renormalise, cast back.  route_w[t][e] = weight of expert e for this row or 0.
-#pragma unroll
-    for (int e = 0; e < LA_MOE_MAX_E; ++e) rl[e] = wave_sum(rl[e]);
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int e = 0; e < LA_MOE_MAX_E; ++e) shr[threadIdx.x >> 6][e] = rl[e];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float lg[LA_MOE_MAX_E], pr[LA_MOE_MAX_E], outw[LA_MOE_MAX_E];
-        float mx = -INFINITY;
-        for (int e = 0; e < n_experts; ++e) {
-            float v = 0.f;
-            for (int w = 0; w < 8; ++w) v += shr[w][e];
-            lg[e] = bfr(v);
-            mx = fmaxf(mx, lg[e]);
-        }
-        float den = 0.f;
-        for (int e = 0; e < n_experts; ++e) { pr[e] = expf(lg[e] - mx); den += pr[e]; }
-        for (int e = 0; e < n_experts; ++e) { pr[e] = pr[e] / den; outw[e] = 0.f; }
-        unsigned taken = 0u;
-        float ksum = 0.f;
-        int pick[LA_MOE_MAX_E];
-        for (int k = 0; k < top_k; ++k) {
-            int best = -1;
-            for (int e = 0; e < n_experts; ++e)
-                if (!((taken >> e) & 1u) && (best < 0 || pr[e] > pr[best])) best = e;
-            taken |= 1u << best;
-            pick[k] = best;
-            ksum += pr[best];
-        }
-        const bool live = t < n_rows[0];
-        for (int k = 0; k < top_k; ++k) outw[pick[k]] = live ? bfr(pr[pick[k]] / ksum) : 0.f;
-        for (int e = 0; e < LA_MOE_MAX_E; ++e) route_w[t * LA_MOE_MAX_E + e] = e < n_experts ? outw[e] : 0.f;
     }
 }
 
@@ -1293,13 +1357,25 @@ int lk_pack_planned(hipStream_t st, const void* w, const void* w2, const int* d_
     k_pack_planned<<<(unsigned)((total + 255) / 256), 256, 0, st>>>((const bf16_t*)w, (const bf16_t*)w2, d_plan, pa, (bf16_t*)out);
     LAUNCH_CHECK(); return 0;
 }
+static bool set_fused_norm(GemmRArgs& ra, const FusedNorm* fn, int n_wg) {
+    if (!fn || !fn->counter) return false;
+    if (n_wg < LA_TB || fn->hidden > 8192 || (fn->hidden & 7)) return false;
+    ra.fn_slabs = fn->slabs; ra.fn_h = (bf16_t*)fn->h; ra.fn_nw = (const bf16_t*)fn->nw; ra.fn_hidden = fn->hidden;
+    ra.fn_cast = fn->cast_first; ra.fn_eps = fn->eps; ra.fn_counter = fn->counter;
+    return true;
+}
 int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, int n_wg, void* act_xp,
-                      const float* route_col) {
+                      const float* route_col, const FusedNorm* fn) {
     GemmRArgs ra{}; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act_xp;
     ra.g.route_col = route_col;
     ra.R = F / n_wg; if (F % n_wg || ra.R > 64 || ra.R <= 32) return -1;
     fill_nv(ra, ra.R, 2, 2);
-    k_gemm64r<4, EPI_SWIGLU, 4, 8><<<n_wg, 512, 8 * 4 * 4096, st>>>(ra);
+    if (set_fused_norm(ra, fn, n_wg)) {
+        if (fn->n_slabs != 4 || route_col) return -1;
+        k_gemm64r<4, EPI_SWIGLU, 4, 8, 4><<<n_wg, 512, 8 * 4 * 4096, st>>>(ra);
+    } else {
+        k_gemm64r<4, EPI_SWIGLU, 4, 8><<<n_wg, 512, 8 * 4 * 4096, st>>>(ra);
+    }
     LAUNCH_CHECK(); return 0;
 }
 int lk_gemm64r_logits(hipStream_t st, const void* wp, const void* xp, int V, int K, int n_wg, void* logits, float* cv, int* ci) {
@@ -1311,7 +1387,7 @@ int lk_gemm64r_logits(hipStream_t st, const void* wp, const void* xp, int V, int
     LAUNCH_CHECK(); return 0;
 }
 int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int nkv, int K, int n_wg, const int* pos,
-                   const void* rcos, const void* rsin, void* qf, void* kfresh, void* vfresh) {
+                   const void* rcos, const void* rsin, void* qf, void* kfresh, void* vfresh, const FusedNorm* fn) {
     GemmRArgs ra{}; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = (nh + 2 * nkv) * 128;
     ra.g.pos = pos; ra.g.rcos = (const bf16_t*)rcos; ra.g.rsin = (const bf16_t*)rsin;
     ra.g.qf = (bf16_t*)qf; ra.g.kfresh = (bf16_t*)kfresh; ra.g.vfresh = (bf16_t*)vfresh; ra.g.nh = nh; ra.g.nkv = nkv;
@@ -1320,7 +1396,12 @@ int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int n
     ra.nv[0] = ra.nv[1] = ra.R;
     ra.nvl[0] = ra.nvl[1] = (ra.R + 3) & ~3;
     ra.boff[0] = 0; ra.boff[1] = ra.nvl[0] * 2 * ra.g.K16; ra.wg_chunks = 2 * ra.boff[1];
-    k_gemm64r<2, EPI_QKV, 8, 8><<<n_wg, 512, 8 * 2 * 4096, st>>>(ra);
+    if (set_fused_norm(ra, fn, n_wg)) {
+        if (fn->n_slabs != 4) return -1;
+        k_gemm64r<2, EPI_QKV, 8, 8, 4><<<n_wg, 512, 8 * 2 * 4096, st>>>(ra);
+    } else {
+        k_gemm64r<2, EPI_QKV, 8, 8><<<n_wg, 512, 8 * 2 * 4096, st>>>(ra);
+    }
     LAUNCH_CHECK(); return 0;
 }
 static bool g_attr_done = false;
@@ -1331,6 +1412,8 @@ int lk_gemm64r_init() {
     hipError_t e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_SWIGLU, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_LOGITS, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<2, EPI_QKV, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 4096);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_SWIGLU, 4, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<2, EPI_QKV, 8, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 4096);
     if (e != hipSuccess) return (int)e;
     g_attr_done = true;
     return 0;

@@ -136,7 +136,7 @@ class LlamaVerifyEngine(object):
     verify block are shared by the active slots (bstep)."""
 
     def __init__(self, shape, state_dict, max_length=2048, device='cuda:0', attn_split=0, gemm_cfg=None,
-                 consume_state_dict=False, balanced=True, n_slots=1):
+                 consume_state_dict=False, balanced=True, n_slots=1, fuse=0):
         if not torch.cuda.is_available():
             raise RuntimeError('LlamaVerifyEngine needs an MI355X: the verify step has no CPU fallback')
         self.shape = shape
@@ -267,6 +267,7 @@ class LlamaVerifyEngine(object):
         cfg.n_slots = self.n_slots
         cfg.n_experts, cfg.top_k = shape.n_experts, shape.top_k
         cfg.norm_cast_first = int(shape.norm_cast_first)
+        cfg.fuse = int(fuse)
         self._cfg = cfg
         nbytes = lib.la_llama_workspace_bytes(C.byref(cfg))
         if nbytes <= 0:

@@ -277,3 +277,27 @@ def test_sequential_processor_path_on_device():
     one = np.array([1], dtype=np.uint64)
     eng.step(nxt, one); eng2.step(nxt, one)
     assert torch.equal(eng.logits()[:1], eng2.logits()[:1])        # the committed KV rows are identical
+
+
+def test_fused_norm_gemm_launches_are_bitwise_identical_to_separate_kernels():
+    """cfg.fuse: the residual + RMSNorm row stage running inside the gate/up and QKV launches (producer workgroups +
+    in-kernel hand-over) must reproduce the separate-kernel path bit for bit: logits, accepted tokens, hidden state."""
+    from painlessinferenceacceleration_amd.llama_engine import random_weights
+    shape = LlamaShape(3, 4096, 32, 32, 11008, 32000, 1e-5)
+    rs = np.random.RandomState(5)
+    prompt = rs.randint(3, 32000, size=100).tolist()
+    _, rows = random_tree(rs, 64)
+    ids = rs.randint(3, 32000, size=64).astype(np.int32)
+    outs = []
+    for fuse in (-1, 0, 1, 2):
+        eng = LlamaVerifyEngine(shape, random_weights(shape, seed=4, std=0.02, device='cuda:0'), max_length=256, fuse=fuse,
+                                consume_state_dict=True)
+        eng.prefill(prompt)
+        toks, n = eng.step(ids, rows)
+        toks2, _ = eng.step(np.asarray(toks[-1:], dtype=np.int32), np.array([1], dtype=np.uint64))
+        outs.append((toks, n, toks2, eng.logits().clone(), eng.hidden().clone()))
+        del eng
+        torch.cuda.empty_cache()
+    for o in outs[1:]:
+        assert o[0] == outs[0][0] and o[1] == outs[0][1] and o[2] == outs[0][2]
+        assert torch.equal(o[3][:1], outs[0][3][:1]) and torch.equal(o[4][:1], outs[0][4][:1])
