@@ -125,6 +125,7 @@ def main():
     ap.add_argument('--pure-random', action='store_true', help='plain N(0,0.02) init (greedy/lookahead drift apart in bf16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-iters', type=int, default=3)
+    ap.add_argument('--fuse', type=int, default=0, help='engine cfg.fuse bits (opt-in in-kernel norm->GEMM fusion; 0 = separate kernels)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -152,7 +153,7 @@ def main():
     n_truth = (K + W) * (BL + 1) + 8
     max_length = P + n_truth + 2 * DL
     model = LlamaForCausalLM.random_init(shape, seed=0, device=dev, max_length=max_length, eos_token_id=None,
-                                         decisive=not args.pure_random)
+                                         decisive=not args.pure_random, fuse=args.fuse)
     eng = model.engine
 
     # ---- untimed set-up: prompt, ground-truth continuation (plain greedy on the same engine), trie warm-up

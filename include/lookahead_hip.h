@@ -230,8 +230,9 @@ typedef struct la_llama_config {
                                 max_keys region of the main KV cache */
     int32_t n_experts;       /* > 0: Mixtral-style sparse MoE MLP (mixtral/modeling_mixtral.py:692-759), <= LA_MOE_MAX_E */
     int32_t top_k;           /* experts per token (Mixtral: 2) */
-    int32_t fuse;            /* in-kernel norm->GEMM fusion: 0 = auto, -1 = off, else bit 0 = post-attention norm into the
-                                gate/up launch, bit 1 = input norm of layers > 0 into the QKV launch */
+    int32_t fuse;            /* in-kernel norm->GEMM fusion, opt-in (0 / -1 = off): bit 0 = post-attention norm into the
+                                gate/up launch, bit 1 = input norm of layers > 0 into the QKV launch.  Bitwise identical
+                                results; slower than separate kernels on MI355X (cross-XCD hand-over), see DESIGN.md */
     int32_t norm_cast_first; /* RMSNorm flavour: 0 = LlamaRMSNorm (llama/modeling_llama.py:86-90, one rounding), 1 = Mistral/
                                 MixtralRMSNorm (mixtral/modeling_mixtral.py:160-165, normalised value rounded first) */
 } la_llama_config;

@@ -72,10 +72,11 @@ static void resolve_cfg(la_llama* m) {
     // qkv_ks == -1 in the config selects the unfused path (plain [Wq;Wk;Wv] packing + k_qkv_post)
     m->qkv_fused = c.gemm_cfg[1] >= 0;
     if (!m->qkv_fused) m->qkv_ks = 1;
-    // in-kernel norm fusion needs the balanced (one workgroup per CU) GEMM, 4 split-K slabs in front of it, a dense MLP
+    // In-kernel norm fusion (opt-in: measured SLOWER than separate kernels on MI355X) needs the
+    // balanced (one workgroup per CU) GEMM, 4 split-K slabs in front of it and a dense MLP.
     m->fuse = 0;
-    if (c.fuse >= 0 && c.n_experts == 0) {
-        const int want = c.fuse > 0 ? c.fuse : 3;
+    if (c.fuse > 0 && c.n_experts == 0) {
+        const int want = c.fuse;
         if ((want & 1) && c.balanced_wg[1] >= LA_TREE_MAX && m->o_ks == 4) m->fuse |= 1;
         if ((want & 2) && c.balanced_wg[0] >= LA_TREE_MAX && m->down_ks == 4) m->fuse |= 2;
     }

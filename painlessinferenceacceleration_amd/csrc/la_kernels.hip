@@ -217,18 +217,17 @@ __global__ __launch_bounds__(512) void k_row_norm(const bf16_t* __restrict__ emb
 // In-kernel hand-over from the 64 producer workgroups (lowest block ids, dispatched first, so a consumer never waits on a
 // workgroup that could be queued behind it) to every workgroup of the grid: producers publish their stores with an
 // agent-scope release and bump `counter`; everybody spins until it reaches `target`, then acquires.
-__device__ __forceinline__ void grid_handover(int* counter, int target, bool producer) {
+__device__ __forceinline__ void handover_signal(int* counter) {
     __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void handover_wait(int* counter, int target) {
     if (threadIdx.x == 0) {
-        if (producer) {
-            __threadfence();
-            __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
-        __threadfence();
+        // relaxed polls (an acquire load would invalidate the caches on every iteration), one acquire at the end
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -540,20 +539,24 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
         bf16x8 fa[D][RB], fb[D][2];
         const int n1 = ngroups == 1 ? last_valid : D;
         if constexpr (NSF > 0) {
-            // weights first; the activations do not exist yet
+            // The activations do not exist yet.  Producers run the row stage BEFORE touching their weights (a wave's loads
+            // return in order: the row operands would queue behind ~16 KiB of weight tiles per wave); everybody else has
+            // its first weight tiles in flight while waiting.
+            static_assert(NW == 8, "the fused row kernel is written for 512 threads");
+            const bool producer = blockIdx.x < LA_TB;
+            if (producer) {
+                row_norm_body<NSF, false>(blockIdx.x, redr, nullptr, nullptr, nullptr, ra.fn_h, ra.fn_slabs, ra.fn_nw,
+                                          ra.fn_hidden, ra.fn_eps, (bf16_t*)a.xp, nullptr, nullptr, 0, 0, nullptr, nullptr,
+                                          ra.fn_cast);
+                handover_signal(ra.fn_counter);
+            }
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const int dd = d < n1 ? d : 0;
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wbase + woff[rb] + dd * wstr[rb]);
             }
-            static_assert(NW == 8, "the fused row kernel is written for 512 threads");
-            const bool producer = blockIdx.x < LA_TB;
-            if (producer)
-                row_norm_body<NSF, false>(blockIdx.x, redr, nullptr, nullptr, nullptr, ra.fn_h, ra.fn_slabs, ra.fn_nw,
-                                          ra.fn_hidden, ra.fn_eps, (bf16_t*)a.xp, nullptr, nullptr, 0, 0, nullptr, nullptr,
-                                          ra.fn_cast);
-            grid_handover(ra.fn_counter, LA_TB, producer);
+            handover_wait(ra.fn_counter, LA_TB);
             const bf16x8* xv = (const bf16x8*)a.xp;            // not __restrict__: written by the producers above
 #pragma unroll
             for (int d = 0; d < D; ++d) {

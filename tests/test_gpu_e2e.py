@@ -289,7 +289,7 @@ def test_fused_norm_gemm_launches_are_bitwise_identical_to_separate_kernels():
     _, rows = random_tree(rs, 64)
     ids = rs.randint(3, 32000, size=64).astype(np.int32)
     outs = []
-    for fuse in (-1, 0, 1, 2):
+    for fuse in (0, 3, 1, 2):
         eng = LlamaVerifyEngine(shape, random_weights(shape, seed=4, std=0.02, device='cuda:0'), max_length=256, fuse=fuse,
                                 consume_state_dict=True)
         eng.prefill(prompt)
