@@ -132,7 +132,8 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     dist = None
-    if world > 1:
+    dist_on = world > 1 or bool(os.environ.get('BENCH_FORCE_DIST'))    # FORCE: exercise the RCCL path with one rank
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -164,7 +165,7 @@ def main():
     t_greedy = time.time() - t0
     cache = LookaheadCache(eos_ids=[None])
     model.lookahead_cache = cache
-    if world > 1:                                # every replica is warmed with every rank's (noisy) answers
+    if dist_on:                                  # every replica is warmed with every rank's (noisy) answers
         tt = torch.tensor(truth, dtype=torch.int32, device=dev)
         allt = [torch.empty_like(tt) for _ in range(world)]
         dist.all_gather(allt, tt)
@@ -183,7 +184,7 @@ def main():
     if os.environ.get('BENCH_DEBUG'):
         print(f'[debug] prefill tok {seq[-1]} truth0 {truth[0]} nkeys {eng.n_keys}', file=sys.stderr, flush=True)
     gather_in = torch.zeros(16, dtype=torch.int32, device=dev)
-    gather_out = torch.zeros(16 * world, dtype=torch.int32, device=dev) if world > 1 else None
+    gather_out = torch.zeros(16 * world, dtype=torch.int32, device=dev) if dist_on else None
     edls, dls, qts = [], [], []
 
     def one_step():
@@ -205,7 +206,7 @@ def main():
                   f'truth {truth[k:k + 6]} prev-truth {truth[max(k - 2, 0):k]}', file=sys.stderr, flush=True)
         seq.extend(toks)
         dls.append(len(ids)); edls.append(len(toks))
-        if world > 1:
+        if dist_on:
             gather_in.zero_()
             gather_in[0] = len(toks)
             gather_in[1:1 + len(toks)] = torch.tensor(toks, dtype=torch.int32)
@@ -224,18 +225,18 @@ def main():
     for _ in range(W):
         one_step()
     n0 = len(edls)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(K):
         one_step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.time() - t0
     accepted = int(sum(edls[n0:]))
-    if world > 1:
+    if dist_on:
         v = torch.tensor([elapsed, float(accepted)], dtype=torch.float64, device=dev)
         mx = v.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = v.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
@@ -245,7 +246,7 @@ def main():
     correct = seq[P:P + len(truth)] == truth[:len(seq) - P]       # lookahead output == plain greedy output
 
     if rank != 0:
-        if world > 1:
+        if dist_on:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -299,7 +300,7 @@ def main():
         'roofline': roofline, 'cpu_baseline': cpu,
     }
     print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
