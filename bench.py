@@ -12,7 +12,9 @@ Synthetic data: the prompt is 512 phrase-bank tokens; the trie is 
 Benchmark.warm_up does (benchmarks/benchmark.py:159-169), with 12 noisy copies of the model's own greedy
 continuation (each token replaced with probability rho=0.3), so drafts are multi-branch and partially accepted.
 Multi-GPU: one independent sequence per rank (batch sharding, weak scaling); the only exchange is the
-per-step all-gather of accepted tokens over RCCL so that every rank's trie replica sees every sequence.
+per-step all-gather of accepted tokens over RCCL so that every rank's trie replica sees every sequence.  The gather is
+split-phase: started after step k, collected while the GPU runs step k+1, then applied for all ranks in global batch-index
+order (replicas stay identical; a step's tokens reach the drafts one step later; emitted tokens are unaffected).
 """
 import argparse
 import json
@@ -125,6 +127,7 @@ def main():
     ap.add_argument('--pure-random', action='store_true', help='plain N(0,0.02) init (greedy/lookahead drift apart in bf16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-iters', type=int, default=3)
+    ap.add_argument('--attn-split', type=int, default=0, help='key splits of the tree-attention kernel (0 = engine default 8)')
     ap.add_argument('--fuse', type=int, default=0, help='engine cfg.fuse bits (opt-in in-kernel norm->GEMM fusion; 0 = separate kernels)')
     args = ap.parse_args()
 
@@ -154,7 +157,7 @@ def main():
     n_truth = (K + W) * (BL + 1) + 8
     max_length = P + n_truth + 2 * DL
     model = LlamaForCausalLM.random_init(shape, seed=0, device=dev, max_length=max_length, eos_token_id=None,
-                                         decisive=not args.pure_random, fuse=args.fuse)
+                                         decisive=not args.pure_random, fuse=args.fuse, attn_split=args.attn_split)
     eng = model.engine
 
     # ---- untimed set-up: prompt, ground-truth continuation (plain greedy on the same engine), trie warm-up
@@ -183,8 +186,11 @@ def main():
     seq.append(eng.prefill(seq))
     if os.environ.get('BENCH_DEBUG'):
         print(f'[debug] prefill tok {seq[-1]} truth0 {truth[0]} nkeys {eng.n_keys}', file=sys.stderr, flush=True)
-    gather_in = torch.zeros(16, dtype=torch.int32, device=dev)
-    gather_out = torch.zeros(16 * world, dtype=torch.int32, device=dev) if dist_on else None
+    gather = None
+    if dist_on:
+        from painlessinferenceacceleration_amd.distributed import AcceptedTokenGather
+        gather = AcceptedTokenGather(dev)
+    pending = [False]
     edls, dls, qts = [], [], []
 
     def one_step():
@@ -199,7 +205,11 @@ def main():
                                   mode='mix', idx=rank)
             print(f'[debug] query {1e3 * qts[-1]:.3f} ms, repeated {1e3 * (time.time() - t1):.3f} ms, T {len(ids)} stats {cache.stats()}',
                   file=sys.stderr, flush=True)
-        toks, _ = eng.step(ids, rowmask, mode=0)
+        eng.step_async(ids, rowmask, mode=0)
+        if pending[0]:       # N > 1: the previous step's gather + every rank's trie update run while the GPU verifies
+            gather.finish_into_trie(cache, BL)
+            pending[0] = False
+        toks, _ = eng.step_finish()
         if os.environ.get('BENCH_DEBUG') and len(edls) < 6:
             k = len(seq) - P
             print(f'[debug] step {len(edls)} ctx {len(seq)} T {len(ids)} ids {ids[:5].tolist()} -> toks {toks[:6]} '
@@ -207,14 +217,11 @@ def main():
         seq.extend(toks)
         dls.append(len(ids)); edls.append(len(toks))
         if dist_on:
-            gather_in.zero_()
-            gather_in[0] = len(toks)
-            gather_in[1:1 + len(toks)] = torch.tensor(toks, dtype=torch.int32)
-            dist.all_gather_into_tensor(gather_out, gather_in)
-            allv = gather_out.cpu().view(world, 16)
-            for r in range(world):               # global batch-index order keeps every trie replica identical
-                n = int(allv[r, 0])
-                cache.stream_put(allv[r, 1:1 + n].tolist(), branch_length=BL + 1, final=False, idx=r)
+            # split-phase RCCL all-gather: started now, collected during the next verify step, then applied for ALL ranks
+            # (this one included) in global batch-index order, so every trie replica goes through the same sequence of
+            # inserts.  Tokens are unaffected (verification is lossless); drafts see a step's tokens one step later.
+            gather.begin(toks)
+            pending[0] = True
         else:
             cache.stream_put(toks, branch_length=BL + 1, final=False, idx=rank)
 
@@ -231,6 +238,9 @@ def main():
     t0 = time.time()
     for _ in range(K):
         one_step()
+    if pending[0]:
+        gather.finish_into_trie(cache, BL)
+        pending[0] = False
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()

@@ -401,6 +401,10 @@ class LlamaVerifyEngine(object):
     def step(self, ids, rowmask, mode=0, eager=False):
         """-> list of emitted tokens (accepted path + bonus), list of accepted tree rows."""
         self.step_async(ids, rowmask, mode, eager)
+        return self.step_finish()
+
+    def step_finish(self):
+        """Wait for the block enqueued by step_async and return its result (host work can run in between)."""
         self.stream.synchronize()
         o = self._out_np
         n_out = int(o[_lib.LA_ST_NOUT])

@@ -46,9 +46,21 @@ def _worker(rank, world, port, steps, q):
     g = AcceptedTokenGather('cpu')
     mine = _streams(world, steps)[rank]
     seen = []
-    for s in range(steps):
-        seen.append(g.update_trie(cache, mine[s], branch_length=12))
-    g.update_trie(cache, [], branch_length=12, final=True)
+    if os.environ.get('LA_TEST_SPLIT_PHASE'):
+        # split-phase form used by bench.py at N > 1: the gather of step s is collected during step s + 1
+        pending = False
+        for s in range(steps):
+            if pending:
+                seen.append(g.finish_into_trie(cache, branch_length=12))
+            g.begin(mine[s])
+            pending = True
+        seen.append(g.finish_into_trie(cache, branch_length=12))
+        g.begin([])
+        g.finish_into_trie(cache, branch_length=12, final=True)
+    else:
+        for s in range(steps):
+            seen.append(g.update_trie(cache, mine[s], branch_length=12))
+        g.update_trie(cache, [], branch_length=12, final=True)
     res = []
     rng = random.Random(9)
     for _ in range(200):
@@ -60,8 +72,13 @@ def _worker(rank, world, port, steps, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_trie_replicas_stay_identical():
+@pytest.mark.parametrize('split_phase', [False, True])
+def test_two_rank_trie_replicas_stay_identical(split_phase):
     world, steps = 2, 40
+    if split_phase:
+        os.environ['LA_TEST_SPLIT_PHASE'] = '1'
+    else:
+        os.environ.pop('LA_TEST_SPLIT_PHASE', None)
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
