@@ -284,6 +284,11 @@ def main():
         'achieved': round(gu_bytes / (gu_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
         'frac': round(gu_bytes / (gu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
         'bytes_per_launch': gu_bytes, 'ms_per_launch': round(gu_ms, 5),
+        # the same launch against the matrix-core roof: 64-row trees keep the kernel far below the MFMA ridge (HBM-bound by
+        # design); profiles/r01_pmc_SQ_v5.txt holds the SQ_VALU_MFMA_BUSY_CYCLES pass of rocprofv3
+        'mfma': {'flops_per_launch': 2 * 2 * shape.ffn * shape.hidden * 64,
+                 'achieved_TFLOPs': round(2 * 2 * shape.ffn * shape.hidden * 64 / (gu_ms * 1e-3) / 1e12, 1),
+                 'peak_TFLOPs': 2500.0, 'frac': round(2 * 2 * shape.ffn * shape.hidden * 64 / (gu_ms * 1e-3) / 1e12 / 2500.0, 4)},
         'verify_step': {'algorithmic_bytes': step_bytes, 'ms_graph_step': round(ms_step, 4),
                         'achieved_GBps': round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
                         'frac': round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

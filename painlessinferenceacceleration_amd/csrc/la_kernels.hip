@@ -224,7 +224,13 @@ __device__ __forceinline__ void handover_signal(int* counter) {
 __device__ __forceinline__ void handover_wait(int* counter, int target) {
     if (threadIdx.x == 0) {
         // relaxed polls (an acquire load would invalidate the caches on every iteration), one acquire at the end
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(8);
+        // bounded: the producers are the lowest block ids; should a dispatcher ever start them late enough for ~1 s of
+        // polling to pass, abort the launch (HIP error) instead of hanging the queue
+        unsigned spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 22)) __builtin_trap();
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();

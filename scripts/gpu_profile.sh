@@ -15,6 +15,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $RAW/pmc_$C -o run -- bash -c "cd $REPO && $BENCH" > $OUT/prof_pmc_$C.log 2>&1 )
   echo "pmc $C exit $?" >> $OUT/prof_pmc_$C.log
 done
+# MFMA / wave-state counters (SQ block, own pass): evidence that the GEMMs are HBM-bound, not matrix-core-bound
+( cd /tmp && timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $RAW/pmc_SQ -o run -- bash -c "cd $REPO && $BENCH" > $OUT/prof_pmc_SQ.log 2>&1 )
+echo "pmc SQ exit $?" >> $OUT/prof_pmc_SQ.log
 find $RAW -type f | head -30
 for f in $(find $RAW/stats -name "*kernel_stats*.csv" -o -name "*stats*.csv" | head -5); do cp $f $OUT/; done
 python - <<'PY'
@@ -36,6 +39,22 @@ for f in glob.glob(os.path.join(raw, 'stats', '**', '*kernel_trace*.csv'), recur
     with open(os.path.join(out, 'kernel_trace_summary.txt'), 'w') as fo:
         for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             fo.write(f'{k}\t{n}\t{t / n / 1e3:.2f}us\t{t / 1e6:.3f}ms\n')
+for f in glob.glob(os.path.join(raw, 'pmc_SQ', '**', '*counter_collection*.csv'), recursive=True):
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name'][:70]
+        a = agg[k][r.get('Counter_Name')]
+        a[0] += 1; a[1] += float(r['Counter_Value'])
+    print('== SQ', f)
+    with open(os.path.join(out, 'pmc_SQ_summary.txt'), 'w') as fo:
+        for k, cs in agg.items():
+            if not k.startswith(('k_', 'void k_')):
+                continue
+            m = {c: v[1] / max(v[0], 1) for c, v in cs.items()}
+            gui = m.get('GRBM_GUI_ACTIVE', 0.0)
+            util = 100.0 * m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui * 256 * 4) if gui else float('nan')
+            line = f"{k[:52]:54s} " + ' '.join(f'{c}={v:.0f}' for c, v in sorted(m.items())) + f' mfma_util_pct={util:.2f}'
+            fo.write(line + '\n'); print(line)
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     for f in glob.glob(os.path.join(raw, f'pmc_{c}', '**', '*counter_collection*.csv'), recursive=True):
         agg = collections.defaultdict(lambda: [0, 0.0])
