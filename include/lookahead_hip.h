@@ -233,6 +233,9 @@ typedef struct la_llama_config {
     int32_t fuse;            /* in-kernel norm->GEMM fusion, opt-in (0 / -1 = off): bit 0 = post-attention norm into the
                                 gate/up launch, bit 1 = input norm of layers > 0 into the QKV launch.  Bitwise identical
                                 results; slower than separate kernels on MI355X (cross-XCD hand-over), see DESIGN.md */
+    int32_t sliding_window;  /* > 0: sliding-window attention over the committed keys (Mistral: 4096; visible iff
+                                pos_row - pos_key <= window, the transformers mask rule).  An EXTENSION: the reference's
+                                lookahead path feeds the full mask (mistral/modeling_mistral.py:979-983) */
     int32_t norm_cast_first; /* RMSNorm flavour: 0 = LlamaRMSNorm (llama/modeling_llama.py:86-90, one rounding), 1 = Mistral/
                                 MixtralRMSNorm (mixtral/modeling_mixtral.py:160-165, normalised value rounded first) */
 } la_llama_config;

@@ -72,6 +72,14 @@ class OracleLlama(object):
         h = w['model.embed_tokens.weight'][ids][None]
         mask4 = mask[None, None]
         pos = torch.sum(mask4, dim=-1).squeeze(1) - 1                          # model hook, :586
+        win = int(getattr(s, 'sliding_window', 0) or 0)
+        if win > 0:
+            # EXTENSION (not on the reference's lookahead path): the transformers sliding-window rule
+            # (modeling_attn_mask_utils._make_causal_mask: masked iff pos_row - pos_key > window) on the committed keys
+            C = mask.shape[1] - T
+            keypos = torch.arange(C)
+            mask4 = mask4.clone()
+            mask4[0, 0, :, :C] &= ((pos[0][:, None] - keypos[None, :]) <= win).long()
         bias = (1.0 - mask4.to(dt)) * torch.finfo(dt).min                      # :587
         cos, sin = _rope_cos_sin(pos[0], hd, s.rope_theta, dt)
         cos, sin = cos[None, None], sin[None, None]

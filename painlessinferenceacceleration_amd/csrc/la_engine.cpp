@@ -257,11 +257,11 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
         if (batch)
             KCHK(lk_tree_attn_b(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
                                 kf, vf, m->rowmask, m->bstate, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, m->nsplit,
-                                m->opart, m->mpart, m->lpart, m->attn_xp));
+                                m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window));
         else
             KCHK(lk_tree_attn(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
                               kf, vf, m->rowmask, m->state, c.n_heads, c.n_kv_heads, m->total_keys, m->nsplit,
-                              m->opart, m->mpart, m->lpart, m->attn_xp));
+                              m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window));
         P(KC_O);
         KCHK(lk_gemm64_slab(st, L.wo, m->attn_xp, c.hidden, m->o_k, m->o_rb, m->o_ks, m->slabs));
         P(KC_OTHER);

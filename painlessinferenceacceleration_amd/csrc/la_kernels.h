@@ -49,10 +49,10 @@ int lk_qkv_post(hipStream_t st, const float* slabs, int n_slabs, int nh, int nkv
                 const void* rsin, void* qf, void* kfresh, void* vfresh);
 int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                  const void* vfresh, const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys,
-                 int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp);
+                 int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window = 0);
 int lk_tree_attn_b(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                    const void* vfresh, const uint64_t* rowmask, const int* bstate, int nh, int nkv, int slot_keys,
-                   int n_slots, int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp);
+                   int n_slots, int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window = 0);
 int lk_build_tree_inputs_b(hipStream_t st, const int* in, int* bstate, int* pos, uint64_t* rowmask, int* ids);
 int lk_accept_scan_b(hipStream_t st, const int* in, const int* ids, const uint64_t* rowmask, int* bstate, int n_slots,
                      int slot_keys);

@@ -894,6 +894,7 @@ struct AttnArgs {
     const int* seq;       // [64] row -> slot (-1 = unused row)
     const int* nkeys_b;   // [LA_MAX_SEQ] committed keys per slot
     int slot_tiles;       // 32-key tiles per slot region of the main cache
+    int window;           // > 0: sliding-window attention, a row at position p sees committed keys j with p - j <= window
 };
 
 #define LA_NEG (-1.0e30f)
@@ -920,7 +921,13 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
     } else {
         nkeys = a.state[LA_ST_NKEYS];
     }
-    const int NP = (nkeys + 31) >> 5, NT = NP + 2;
+    // sliding window (HF Mistral mask rule, modeling_attn_mask_utils: visible iff pos_row - j <= window): tiles wholly
+    // below the root's horizon are skipped for every row, the rest is masked per row
+    const int NPall = (nkeys + 31) >> 5;
+    const int ts = (a.window > 0 && nkeys - a.window > 0) ? ((nkeys - a.window) >> 5) : 0;
+    const int NP = NPall - ts, NT = NP + 2;
+    tile0 += ts;
+    const int key_lo = (a.window > 0) ? nkeys + __popcll(a.rowmask[tb * 32 + (lane & 31)]) - 1 - a.window : 0;
     const int i0 = (NT * sp) / a.nsplit;
     // a wave whose token block holds no row of the slot contributes nothing: skip its tiles (it still joins the merge)
     const int i1 = (__ballot(mine) == 0ull) ? i0 : (NT * (sp + 1)) / a.nsplit;
@@ -966,7 +973,8 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
         for (int i = 0; i < 16; ++i) {
             const int kk = (i & 3) + 8 * (i >> 2) + 4 * hh;
             float v = bfr(__fdiv_rn(bfr(sc[i]), 11.313708498984761f));
-            const bool ok = fresh ? ((rm >> (kb * 32 + kk)) & 1ull) != 0ull : (kb * 32 + kk) < nk_row;
+            const int kidx = (ts + kb) * 32 + kk;      // committed keys: absolute index = position
+            const bool ok = fresh ? ((rm >> (kb * 32 + kk)) & 1ull) != 0ull : (kidx < nk_row && kidx >= key_lo);
             v = ok ? v : LA_NEG;
             sc[i] = v;
             mx = fmaxf(mx, v);
@@ -1544,9 +1552,10 @@ static int tree_attn_launch(hipStream_t st, AttnArgs a, int n_slots, void* attn_
 
 int lk_tree_attn_b(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                    const void* vfresh, const uint64_t* rowmask, const int* bstate, int nh, int nkv, int slot_keys,
-                   int n_slots, int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp) {
+                   int n_slots, int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window) {
     if (n_slots < 1 || n_slots > LA_MAX_SEQ || (slot_keys & 31)) return -1;
     AttnArgs a{};
+    a.window = window;
     a.qf = (const bf16_t*)qf; a.kmain = (const bf16_t*)kmain; a.vmain = (const bf16_t*)vmain;
     a.kfresh = (const bf16_t*)kfresh; a.vfresh = (const bf16_t*)vfresh;
     a.rowmask = (const unsigned long long*)rowmask; a.state = nullptr;
@@ -1558,8 +1567,9 @@ int lk_tree_attn_b(hipStream_t st, const void* qf, const void* kmain, const void
 
 int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                  const void* vfresh, const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys,
-                 int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp) {
+                 int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window) {
     AttnArgs a{};
+    a.window = window;
     a.qf = (const bf16_t*)qf; a.kmain = (const bf16_t*)kmain; a.vmain = (const bf16_t*)vmain;
     a.kfresh = (const bf16_t*)kfresh; a.vfresh = (const bf16_t*)vfresh;
     a.rowmask = (const unsigned long long*)rowmask; a.state = state;

@@ -24,12 +24,14 @@ class LlamaShape(object):
     """The fields of LlamaConfig the path uses."""
 
     def __init__(self, n_layers=32, hidden=4096, n_heads=32, n_kv_heads=None, ffn=11008, vocab=32000,
-                 rms_eps=1e-5, rope_theta=10000.0, head_dim=None, n_experts=0, top_k=2, norm_cast_first=False):
+                 rms_eps=1e-5, rope_theta=10000.0, head_dim=None, n_experts=0, top_k=2, norm_cast_first=False, sliding_window=0):
         self.n_layers, self.hidden, self.n_heads = n_layers, hidden, n_heads
         self.n_experts, self.top_k = n_experts, top_k       # > 0: Mixtral sparse-MoE MLP
         # RMSNorm flavour: False = LlamaRMSNorm (one rounding), True = Mistral/MixtralRMSNorm (normalised value rounded
         # to the activation dtype before the weight multiply, mixtral/modeling_mixtral.py:160-165)
         self.norm_cast_first = bool(norm_cast_first)
+        # 0 = full attention (what the reference's lookahead path does for every family); > 0 = sliding window (extension)
+        self.sliding_window = int(sliding_window)
         self.n_kv_heads = n_kv_heads if n_kv_heads is not None else n_heads
         self.ffn, self.vocab, self.rms_eps, self.rope_theta = ffn, vocab, rms_eps, rope_theta
         self.head_dim = head_dim if head_dim is not None else hidden // n_heads
@@ -268,6 +270,7 @@ class LlamaVerifyEngine(object):
         cfg.n_experts, cfg.top_k = shape.n_experts, shape.top_k
         cfg.norm_cast_first = int(shape.norm_cast_first)
         cfg.fuse = int(fuse)
+        cfg.sliding_window = int(getattr(shape, 'sliding_window', 0))
         self._cfg = cfg
         nbytes = lib.la_llama_workspace_bytes(C.byref(cfg))
         if nbytes <= 0:

@@ -301,3 +301,44 @@ def test_fused_norm_gemm_launches_are_bitwise_identical_to_separate_kernels():
     for o in outs[1:]:
         assert o[0] == outs[0][0] and o[1] == outs[0][1] and o[2] == outs[0][2]
         assert torch.equal(o[3][:1], outs[0][3][:1]) and torch.equal(o[4][:1], outs[0][4][:1])
+
+
+@pytest.mark.parametrize('window', [40, 100])
+def test_sliding_window_attention_extension(window):
+    """cfg.sliding_window (extension; BASELINE config 3): rows see only committed keys within `window` positions (the
+    transformers mask rule), whole tiles below the horizon are skipped.  Engine vs the oracle with the same rule, for a
+    context longer than the window, in the bs=1 and the cursor-batch step."""
+    shape = tiny_shape()
+    shape.sliding_window = window
+    sd = _bf16_sd(0)
+    oracle = lo.OracleLlama(shape, sd)
+    rs = np.random.RandomState(window + 7)
+    prompt = rs.randint(3, shape.vocab, size=150).tolist()
+    T = 30
+    _, rows = random_tree(rs, T)
+    ids = rs.randint(3, shape.vocab, size=T).astype(np.int32)
+    # oracle: the prompt is prefilled in 64-token chains exactly like the engine (window applies inside them too)
+    past, nk = None, 0
+    for s in range(0, 150, 64):
+        blk = prompt[s:s + 64]
+        n = len(blk)
+        full = torch.cat([torch.ones((n, nk), dtype=torch.long), torch.tril(torch.ones((n, n), dtype=torch.long))], 1)
+        lgp, past = oracle.forward(torch.tensor(blk), full, past)
+        nk += n
+    full = torch.cat([torch.ones((T, nk), dtype=torch.long), torch.from_numpy(_mask_from_rows(rows, T))], 1)
+    lg, _ = oracle.forward(torch.tensor(ids.tolist()), full, past)
+    eng = LlamaVerifyEngine(shape, sd, max_length=512)
+    eng.prefill(prompt)
+    _check_rows(eng.logits()[:150 - 128], lgp, range(150 - 128), 'window prefill')
+    eng.step(ids, rows)
+    _check_rows(eng.logits()[:T], lg, range(T), 'window tree')
+    beng = LlamaVerifyEngine(shape, sd, max_length=512, n_slots=2)
+    beng.bprefill_many({1: prompt})
+    beng.bstep([(1, ids, np.asarray(rows, dtype=np.uint64), 0, 16)])
+    assert torch.equal(beng.logits()[:T], eng.logits()[:T])
+    # and the window really changes the result
+    shape0 = tiny_shape()
+    e0 = LlamaVerifyEngine(shape0, sd, max_length=512)
+    e0.prefill(prompt)
+    e0.step(ids, rows)
+    assert not torch.equal(e0.logits()[:T], eng.logits()[:T])
