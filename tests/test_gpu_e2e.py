@@ -23,10 +23,10 @@ def _bf16_sd(seed=0, cfg=None):
     return {k: v.to(torch.bfloat16) for k, v in tiny_weights(seed, torch.float32, cfg=cfg).items()}
 
 
-def _check_rows(got, ref, rows, what):
+def _check_rows(got, ref, rows, what, tol=TOL):
     got, ref = got.float().cpu(), ref.float().cpu()
     for t in rows:
-        bound = TOL * float(ref[t].abs().max())
+        bound = tol * float(ref[t].abs().max())
         err = float((got[t] - ref[t]).abs().max())
         assert err <= bound, f'{what}: row {t}: err {err:.4g} > {bound:.4g}'
         top = torch.topk(ref[t], 2).values

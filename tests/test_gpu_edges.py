@@ -1,0 +1,133 @@
+# -*- coding: utf-8 -*-
+"""-m gpu: edge cases of the device path the reference's own tests and examples touch implicitly — block boundaries of the
+prompt, minimum / maximum tree sizes, cache capacity, eos and max_length stops, the streamer interface."""
+import queue
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import llama_oracle as lo
+from painlessinferenceacceleration_amd.llama_engine import LlamaVerifyEngine, random_weights
+from painlessinferenceacceleration_amd.lookahead_cache import LookaheadCache
+from painlessinferenceacceleration_amd.modeling_llama import LlamaForCausalLM
+from tests.gpu_utils import random_tree
+from tests.test_gpu_e2e import _bf16_sd, _check_rows, _mask_from_rows
+from tests.tiny_model import tiny_shape
+
+pytestmark = pytest.mark.gpu
+# These cases are about block boundaries and bookkeeping, on random (off-distribution) ids over a 2-layer toy model whose
+# deepest rows sit at 2.0-2.1e-2 of max|logit|: they state 3e-2; the parity tolerance proper (2e-2) lives in test_gpu_e2e.py.
+EDGE_TOL = 3e-2
+
+
+@pytest.mark.parametrize('P', [1, 63, 64, 65, 128, 129])
+def test_prompt_lengths_around_block_boundaries(P):
+    shape, sd = tiny_shape(), _bf16_sd(0)
+    eng = LlamaVerifyEngine(shape, sd, max_length=320)
+    oracle = lo.OracleLlama(shape, sd)
+    rs = np.random.RandomState(P)
+    prompt = rs.randint(3, shape.vocab, size=P).tolist()
+    eng.prefill(prompt)
+    assert eng.n_keys == P
+    lg, past = oracle.forward(torch.tensor(prompt), torch.tril(torch.ones((P, P), dtype=torch.long)), None)
+    last = (P - 1) // 64 * 64
+    _check_rows(eng.logits()[:P - last], lg[last:], range(P - last), f'prefill P={P}', tol=EDGE_TOL)
+    # minimum tree (the root alone) and a full 64-row chain on top
+    tok = int(lg[-1].float().argmax())
+    toks, n = eng.step(np.asarray([tok], dtype=np.int32), np.array([1], dtype=np.uint64))
+    assert n == 1 and len(toks) == 1 and eng.n_keys == P + 1
+    full = torch.ones((1, P + 1), dtype=torch.long)
+    lg1, past = oracle.forward(torch.tensor([tok]), full, past)
+    _check_rows(eng.logits()[:1], lg1, range(1), 'T=1', tol=EDGE_TOL)
+    chain = np.array([(2 << t) - 1 for t in range(63)] + [0xFFFFFFFFFFFFFFFF], dtype=np.uint64)
+    ids = rs.randint(3, shape.vocab, size=64).astype(np.int32)
+    eng.step(ids, chain)
+    full = torch.cat([torch.ones((64, P + 1), dtype=torch.long), torch.tril(torch.ones((64, 64), dtype=torch.long))], 1)
+    lg64, _ = oracle.forward(torch.tensor(ids.tolist()), full, past)
+    _check_rows(eng.logits(), lg64, range(64), 'T=64 chain', tol=EDGE_TOL)
+
+
+def test_capacity_and_argument_guards():
+    shape, sd = tiny_shape(), _bf16_sd(0)
+    eng = LlamaVerifyEngine(shape, sd, max_length=64)          # capacity = ceil((64 + 65) / 32) * 32 = 160 keys
+    assert eng.max_keys == 160
+    rs = np.random.RandomState(0)
+    eng.prefill(rs.randint(3, shape.vocab, size=128).tolist())
+    _, rows = random_tree(rs, 33)
+    with pytest.raises(AssertionError):                          # 128 + 33 > 160
+        eng.step(rs.randint(3, shape.vocab, size=33).astype(np.int32), rows)
+    with pytest.raises(AssertionError):                          # a block holds 64 rows
+        eng.step(np.zeros(65, dtype=np.int32), np.ones(65, dtype=np.uint64))
+    with pytest.raises(AssertionError):
+        eng.step(np.zeros(0, dtype=np.int32), np.ones(0, dtype=np.uint64))
+    eng.step(rs.randint(3, shape.vocab, size=32).astype(np.int32), rows[:32])      # exactly fits
+    beng = LlamaVerifyEngine(shape, sd, max_length=64, n_slots=2)
+    with pytest.raises(AssertionError):                          # two segments of one slot
+        beng.bstep([(0, np.array([5], dtype=np.int32), np.array([1], dtype=np.uint64), 0, 4),
+                    (0, np.array([6], dtype=np.int32), np.array([1], dtype=np.uint64), 0, 4)])
+    with pytest.raises(AssertionError):                          # slot outside the engine
+        beng.bstep([(2, np.array([5], dtype=np.int32), np.array([1], dtype=np.uint64), 0, 4)])
+
+
+def _decisive_model(max_length=512):
+    shape = tiny_shape()
+    return shape, LlamaForCausalLM(shape, random_weights(shape, seed=2, device='cpu', decisive=True), max_length=max_length,
+                                   eos_token_id=None)
+
+
+def test_eos_and_max_length_stops():
+    shape, model = _decisive_model()
+    rs = np.random.RandomState(1)
+    prompt = torch.tensor([rs.randint(3, shape.vocab, size=40).tolist()])
+    dk = {'use_lookahead': True, 'decoding_length': 64, 'branch_length': 12, 'stop_words': {}}
+    gre = model.greedy_search(prompt, 40 + 120, eos_token_id=None)[0].tolist()
+    # warm the trie, then: (1) max_length is hit exactly (branch_length is clamped to the room left, :680)
+    model.lookahead_generation(prompt, stopping_criteria=160, eos_token_id=[None], decoding_kwargs=dict(dk))
+    for ml in (41, 47, 100, 160):
+        out = model.lookahead_generation(prompt, stopping_criteria=ml, eos_token_id=[None], return_dict_in_generate=True,
+                                         decoding_kwargs=dict(dk))
+        seq = out.sequences[0].tolist()
+        assert len(seq) == ml and seq == gre[:ml], ml
+    # (2) an eos inside an accepted run stops the request at the end of that step; the tokens of the step stay (:1225-1231)
+    eos = gre[40 + 30]
+    out = model.lookahead_generation(prompt, stopping_criteria=160, eos_token_id=eos, return_dict_in_generate=True,
+                                     decoding_kwargs=dict(dk))
+    seq = out.sequences[0].tolist()
+    assert seq == gre[:len(seq)] and eos in seq[40:]
+    first = seq.index(eos, 40)
+    assert first == 70 and len(seq) - first <= 13 and len(seq) < 160
+    assert sum(out.kwargs['edls']) == len(seq) - 40
+
+
+def test_streamer_and_stream_generate():
+    shape, model = _decisive_model()
+    rs = np.random.RandomState(2)
+    prompt = torch.tensor([rs.randint(3, shape.vocab, size=30).tolist()])
+
+    class Streamer(object):
+        def __init__(self):
+            self.q = queue.Queue()
+
+        def put(self, value):
+            self.q.put(np.asarray(value).reshape(-1).tolist())
+
+        def end(self):
+            self.q.put(None)
+
+        def __iter__(self):
+            return self
+
+        def __next__(self):
+            v = self.q.get(timeout=60)
+            if v is None:
+                raise StopIteration
+            return v
+
+    dk = {'use_lookahead': True, 'decoding_length': 64, 'branch_length': 12, 'stop_words': {}}
+    ref = model.generate(input_ids=prompt, max_new_tokens=60, decoding_kwargs=dict(dk), eos_token_id=[None])[0].tolist()
+    st = Streamer()
+    chunks = list(model.stream_generate(input_ids=prompt, max_new_tokens=60, decoding_kwargs=dict(dk), eos_token_id=[None],
+                                        streamer=st))
+    assert [t for c in chunks for t in c] == ref[30:]
+    assert len(chunks) >= 2
