@@ -254,6 +254,19 @@ def main():
     else:
         accepted_all = float(accepted)
     correct = seq[P:P + len(truth)] == truth[:len(seq) - P]       # lookahead output == plain greedy output
+    native = None
+    if not dist_on and len(seq) + (BL + 1) * 16 < max_length:
+        # informational: the same steps through the native loop (la_lookahead_decode, what lookahead_generation() uses when
+        # no streamer / processor is attached).  `value` stays on the interpreter loop, which is also what N > 1 runs.
+        torch.cuda.synchronize()
+        t1 = time.time()
+        new, dls_n, edls_n, _, _, _ = eng.decode_native(cache, seq, max_length - 2 * DL, eos_ids=(), decoding_length=DL,
+                                                        branch_length=BL, max_query_length=2, idx=rank, max_steps=16)
+        dt = time.time() - t1
+        seq.extend(new)
+        native = {'steps': len(edls_n), 'ms_per_step': round(1e3 * dt / max(len(edls_n), 1), 4),
+                  'accepted_tokens_per_sec': round(sum(edls_n) / dt, 2),
+                  'equals_greedy': seq[P:P + len(truth)] == truth[:len(seq) - P]}
 
     if rank != 0:
         if dist_on:
@@ -311,7 +324,8 @@ def main():
                    'mean_accept_len': round(mean_acc, 3), 'mean_draft_len': round(mean_T, 2),
                    'verify_steps_per_sec': round(K * world / elapsed, 2), 'context_at_end': ctx,
                    'trie_query_ms_mean': round(1e3 * float(np.mean(qts[n0:])), 4),
-                   'lookahead_equals_greedy': bool(correct), 'plain_greedy_tokens_per_sec': round(len(truth) / t_greedy, 2)},
+                   'lookahead_equals_greedy': bool(correct), 'plain_greedy_tokens_per_sec': round(len(truth) / t_greedy, 2),
+                   'native_loop': native},
         'roofline': roofline, 'cpu_baseline': cpu,
     }
     print(json.dumps(out))

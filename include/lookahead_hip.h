@@ -293,6 +293,26 @@ void* la_llama_buffer(la_llama* m, int which);
 int la_llama_profile(la_llama* m, void* stream, const int32_t* host_in, int iters,
                      float* out_ms /*[8]*/, int32_t* out_launches /*[7] or NULL*/);
 
+/* ---- native decode loop: the per-step host work of lookahead_generation (pretrained_model.py:1172-1240) without the
+ * interpreter: hier_get(last max_query_length tokens) -> la_llama_step -> stream_put, until max_length / eos / max_steps.
+ * Greedy, empty logits-processor list, decoding_mode hier.  The prompt must already be prefilled (seq[0..seq_len) holds
+ * prompt + first generated token, its trie `put` done).  Appends tokens to seq (capacity >= max_length + 16), fills
+ * dls/edls (capacity >= max_steps) and returns the number of steps in *n_steps; *finished = 1 when a stop condition
+ * other than max_steps ended the loop.  host_in / host_out: pinned staging blocks (LA_IN_WORDS / LA_ST_OUTTOK+64). */
+typedef struct la_decode_params {
+    int32_t decoding_length, branch_length, max_query_length;
+    int32_t mode;                 /* LA_MODE_* of the retrieval (hier_mix = LA_MODE_MIX) */
+    int32_t idx;                  /* trie request slot of this sequence */
+    int32_t max_length;           /* stop when seq_len >= max_length */
+    int32_t max_steps;
+    int32_t n_eos;
+    int32_t eos[8];
+} la_decode_params;
+int la_lookahead_decode(la_llama* m, la_cache* c, void* stream, const la_decode_params* p, int32_t* seq, int32_t* seq_len,
+                        int32_t* host_in, int32_t* host_out, int32_t* dls, int32_t* edls, int32_t* n_steps,
+                        int32_t* finished, double* fts /*[max_steps] seconds per step or NULL*/,
+                        double* qts /*[max_steps] seconds of the trie query or NULL*/);
+
 /* ---- mixture of experts (Mixtral) row stages; the expert GEMMs are the la_gemm64* kernels launched once per expert
  * with an early exit when no row routes to that expert ------------------------------------------------------- */
 /* post-attention residual + RMSNorm with the router fused: route_w[64][LA_MOE_MAX_E] fp32 (bf16-valued, 0 = not routed);

@@ -84,6 +84,11 @@ class LlamaWeightsC(C.Structure):
                 ("layers", C.POINTER(LlamaLayerWeightsC))]
 
 
+class DecodeParamsC(C.Structure):
+    _fields_ = [("decoding_length", i32), ("branch_length", i32), ("max_query_length", i32), ("mode", i32), ("idx", i32),
+                ("max_length", i32), ("max_steps", i32), ("n_eos", i32), ("eos", i32 * 8)]
+
+
 def _proto(name, restype, *argtypes):
     fn = getattr(lib, name)
     fn.restype = restype
@@ -141,6 +146,8 @@ PROTOTYPES = {
     "la_llama_step": (i32, vp, vp, vp, vp),
     "la_llama_step_eager": (i32, vp, vp, vp, vp),
     "la_llama_commit": (i32, vp, vp, pi32, i32, vp),
+    "la_lookahead_decode": (i32, vp, vp, vp, C.POINTER(DecodeParamsC), pi32, pi32, vp, vp, pi32, pi32, pi32, pi32,
+                            C.POINTER(C.c_double), C.POINTER(C.c_double)),
     "la_llama_buffer": (vp, vp, i32),
     "la_llama_profile": (i32, vp, vp, vp, i32, pf32, pi32),
     "la_resid_norm_router": (i32, vp, vp, vp, i32, vp, i32, f32, vp, vp, i32, i32, vp, vp),

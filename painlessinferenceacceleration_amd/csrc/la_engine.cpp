@@ -6,6 +6,8 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <algorithm>
+#include <chrono>
 #include "la_kernels.h"
 
 extern void la_set_error(const std::string& s);
@@ -381,6 +383,61 @@ extern "C" int la_llama_step_eager(la_llama* m, void* stream, const int32_t* hos
     if (rc != LA_OK) return rc;
     if (host_out)
         HIPCHK(hipMemcpyAsync(host_out, m->state, (LA_ST_OUTTOK + 64) * sizeof(int), hipMemcpyDeviceToHost, st));
+    return LA_OK;
+}
+
+extern "C" int la_lookahead_decode(la_llama* m, la_cache* c, void* stream, const la_decode_params* p, int32_t* seq,
+                                   int32_t* seq_len, int32_t* host_in, int32_t* host_out, int32_t* dls, int32_t* edls,
+                                   int32_t* n_steps, int32_t* finished, double* fts, double* qts) {
+    if (!m || !c || !p || !seq || !seq_len || !host_in || !host_out || !n_steps || p->decoding_length > LA_TREE_MAX ||
+        p->max_query_length < 1 || p->max_query_length > 8 || p->n_eos < 0 || p->n_eos > 8) return LA_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int32_t ids[LA_TREE_MAX], parent[LA_TREE_MAX], sizes[2], nsz = 0, T = 0;
+    uint64_t rows[LA_TREE_MAX];
+    int len = *seq_len, steps = 0, done = 0;
+    auto t_prev = std::chrono::steady_clock::now();
+    int nkeys = len - 1;                           // committed keys = context without the newest token
+    while (steps < p->max_steps) {
+        const int ubl = std::min(p->branch_length, p->max_length - len - 1);          // pretrained_model.py:680
+        if (ubl < 0) { la_set_error("decode: no room left below max_length"); return LA_E_RANGE; }
+        const int nq = std::min(p->max_query_length, len);
+        auto t0 = std::chrono::steady_clock::now();
+        int rc = la_cache_hier_get(c, seq + len - nq, nq, p->decoding_length, ubl, 0, std::max(p->decoding_length / 2, 1),
+                                   p->mode, p->idx, LA_TREE_MAX, ids, parent, rows, nullptr, sizes, &nsz, &T);
+        if (rc != LA_OK) return rc;
+        if (T == 0) { ids[0] = seq[len - 1]; rows[0] = 1ull; T = 1; }
+        if (nkeys + T > m->cfg.max_keys) { la_set_error("decode: KV cache capacity exceeded"); return LA_E_RANGE; }
+        host_in[LA_IN_T] = T;
+        host_in[LA_IN_MODE] = 0;
+        memcpy(host_in + LA_IN_IDS, ids, sizeof(int32_t) * T);
+        memcpy(host_in + LA_IN_ROWMASK, rows, sizeof(uint64_t) * T);
+        if (qts) qts[steps] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        rc = la_llama_step(m, st, host_in, host_out);
+        if (rc != LA_OK) return rc;
+        HIPCHK(hipStreamSynchronize(st));
+        const int n = host_out[LA_ST_NOUT];
+        nkeys = host_out[LA_ST_NKEYS];
+        if (n < 1 || n > 16) { la_set_error("decode: bad step output"); return LA_E_HIP; }
+        memcpy(seq + len, host_out + LA_ST_OUTTOK, sizeof(int32_t) * n);
+        rc = la_cache_stream_put(c, seq + len, n, p->branch_length + 1, 0, p->idx);
+        if (rc != LA_OK) return rc;
+        if (dls) dls[steps] = T;
+        if (edls) edls[steps] = n;
+        if (fts) {
+            auto t1 = std::chrono::steady_clock::now();
+            fts[steps] = std::chrono::duration<double>(t1 - t_prev).count();
+            t_prev = t1;
+        }
+        ++steps;
+        bool eos = false;
+        for (int i = 0; i < n && !eos; ++i)
+            for (int e = 0; e < p->n_eos; ++e) if (seq[len + i] == p->eos[e]) { eos = true; break; }
+        len += n;
+        if (len >= p->max_length || eos) { done = 1; break; }
+    }
+    *seq_len = len;
+    *n_steps = steps;
+    if (finished) *finished = done;
     return LA_OK;
 }
 

@@ -414,6 +414,38 @@ class LlamaVerifyEngine(object):
         self.n_keys = int(o[_lib.LA_ST_NKEYS])
         return o[_lib.LA_ST_OUTTOK:_lib.LA_ST_OUTTOK + n_out].tolist(), int(o[_lib.LA_ST_NCOMMIT])
 
+    def decode_native(self, cache, seq, max_length, eos_ids=(), decoding_length=64, branch_length=12, max_query_length=2,
+                      mode=_lib.LA_MODE_MIX, idx=0, max_steps=1 << 30):
+        """Run verify steps in the native loop (la_lookahead_decode: trie query -> captured graph -> trie update, no
+        interpreter in between) until max_length / eos / max_steps.  `seq` = prompt + first generated token, already
+        prefilled.  -> (new tokens, dls, edls, fts, qts, finished)."""
+        p = _lib.DecodeParamsC()
+        p.decoding_length, p.branch_length, p.max_query_length = int(decoding_length), int(branch_length), int(max_query_length)
+        p.mode, p.idx, p.max_length = int(mode), int(idx), int(max_length)
+        eos_ids = [int(e) for e in eos_ids if e is not None][:8]
+        p.n_eos = len(eos_ids)
+        for i, e in enumerate(eos_ids):
+            p.eos[i] = e
+        cap = max(1, min(int(max_steps), max(int(max_length) - len(seq), 0) + 1))
+        p.max_steps = cap
+        buf = np.zeros(max(int(max_length), len(seq)) + 32, dtype=np.int32)
+        buf[:len(seq)] = seq
+        n = C.c_int32(len(seq))
+        dls = np.zeros(cap, dtype=np.int32)
+        edls = np.zeros(cap, dtype=np.int32)
+        fts = np.zeros(cap, dtype=np.float64)
+        qts = np.zeros(cap, dtype=np.float64)
+        steps, fin = C.c_int32(0), C.c_int32(0)
+        dp = C.POINTER(C.c_double)
+        check(lib.la_lookahead_decode(self._h, cache._h, self._sp(), C.byref(p), buf.ctypes.data_as(_lib.pi32), C.byref(n),
+                                      self.host_in.data_ptr(), self.host_out.data_ptr(), dls.ctypes.data_as(_lib.pi32),
+                                      edls.ctypes.data_as(_lib.pi32), C.byref(steps), C.byref(fin),
+                                      fts.ctypes.data_as(dp), qts.ctypes.data_as(dp)), 'lookahead_decode')
+        k = steps.value
+        self.n_keys = int(self._out_np[_lib.LA_ST_NKEYS]) if k else self.n_keys
+        return (buf[len(seq):n.value].tolist(), dls[:k].tolist(), edls[:k].tolist(), fts[:k].tolist(), qts[:k].tolist(),
+                bool(fin.value))
+
     def verify_only(self, ids, rowmask, eager=False):
         """Forward of one block without the device accept walk (mode 2): logits() holds one row per tree token, nothing is
         committed until commit()."""

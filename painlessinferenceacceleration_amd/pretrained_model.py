@@ -135,6 +135,12 @@ class LookaheadPreTrainedModel(object):
         first = True
         eos_set = set(eos_token_id) if eos_token_id is not None else set()
         do_sample = bool(decoding_kwargs.get('do_sample', False))
+        dm = decoding_kwargs.get('decoding_mode', 'hier')
+        dm = dm + '_mix' if dm in ('hier', 'par', 'one') else dm
+        native_mode = {'input': 0, 'output': 1, 'mix': 2}.get(dm.split('_')[1], 2)
+        native_loop = (not sequential and streamer is None and dm.split('_')[0] == 'hier' and decoding_length <= 64
+                       and not decoding_kwargs.get('debug_lookahead', False) and decoding_kwargs.get('native_loop', True)
+                       and hasattr(eng, 'decode_native'))
 
         def pick(scores_ids, row):
             """next token from one logits row through the processor list (pretrained_model.py:833-839)"""
@@ -193,6 +199,21 @@ class LookaheadPreTrainedModel(object):
             decoding_kwargs['fts'].append(te - ts)
             ts = te
             if finished:
+                self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=0)
+                break
+            if native_loop:
+                # every remaining step runs in la_lookahead_decode: same calls in the same order (hier_get -> la_llama_step
+                # -> stream_put -> stop checks), without the interpreter between them
+                new, dls_, edls_, fts_, qts_, fin = eng.decode_native(
+                    self.lookahead_cache, seq, stop_max_length, eos_ids=eos_set, decoding_length=decoding_length,
+                    branch_length=branch_length, max_query_length=decoding_kwargs.get('max_query_length', 2),
+                    mode=native_mode, idx=0)
+                seq.extend(new)
+                decoding_kwargs['dls'].extend(dls_)
+                decoding_kwargs['edls'].extend(edls_)
+                decoding_kwargs['fts'].extend(fts_)
+                decoding_kwargs['qts'].extend(qts_)
+                assert fin
                 self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=0)
                 break
         if streamer is not None:

@@ -342,3 +342,30 @@ def test_sliding_window_attention_extension(window):
     e0.prefill(prompt)
     e0.step(ids, rows)
     assert not torch.equal(e0.logits()[:T], eng.logits()[:T])
+
+
+def test_native_decode_loop_equals_python_loop():
+    """la_lookahead_decode (trie query -> step -> trie update in C++) against the interpreter loop: same sequences, dls,
+    edls on a cold and on a warmed trie, with an eos stop and with a max_length stop."""
+    from painlessinferenceacceleration_amd.llama_engine import random_weights
+    shape = tiny_shape()
+    sd = random_weights(shape, seed=2, device='cpu', decisive=True)
+    model = LlamaForCausalLM(shape, sd, max_length=512, eos_token_id=None)
+    rs = np.random.RandomState(12)
+    prompt = torch.tensor([rs.randint(3, shape.vocab, size=45).tolist()])
+    gre = model.greedy_search(prompt, 45 + 150, eos_token_id=None)[0].tolist()
+    for eos, ml in (([None], 195), (gre[45 + 77], 195), ([None], 60)):
+        runs = {}
+        for native in (False, True):
+            model.lookahead_cache = LookaheadCache()
+            outs = []
+            for rep in range(2):
+                dk = {'use_lookahead': True, 'decoding_length': 64, 'branch_length': 12, 'stop_words': {}, 'native_loop': native}
+                out = model.lookahead_generation(prompt, stopping_criteria=ml, eos_token_id=eos, return_dict_in_generate=True,
+                                                 decoding_kwargs=dk)
+                outs.append((out.sequences[0].tolist(), out.kwargs['dls'], out.kwargs['edls'], len(out.kwargs['fts']),
+                             len(out.kwargs['qts'])))
+            runs[native] = outs
+            assert model.lookahead_cache.stats()['n_nodes'] > 0
+        assert runs[True] == runs[False], (eos, ml)
+        assert runs[True][1][0] == gre[:len(runs[True][1][0])]
