@@ -123,6 +123,7 @@ int la_trie_hier_get_dev(void* stream, const int32_t* d_tok, const double* d_fo,
 #define LA_ST_DSTBASE    4   /* out: first main-cache row written by the commit           */
 #define LA_ST_NCOMMIT    5   /* out: rows committed                                       */
 #define LA_ST_MAXKEYS    6   /* capacity of the main KV cache in keys (multiple of 32)    */
+#define LA_ST_SEQ        7   /* out: steps published so far (zero-copy completion word)   */
 #define LA_ST_OUTTOK     8   /* out: [64] emitted tokens, path order then bonus           */
 #define LA_ST_SRCIDX    72   /* out: [64] tree rows committed, in order                   */
 #define LA_ST_ARGMAX   136   /* out: [64] argmax token per tree row                       */
@@ -269,11 +270,18 @@ la_llama* la_llama_create(const la_llama_config* cfg, const la_llama_weights* w,
 void      la_llama_destroy(la_llama* m);
 /* Reset the sequence (nkeys = 0). */
 int la_llama_reset(la_llama* m, void* stream);
-/* One block: h2d of the step input (host_in: LA_IN_WORDS int32), the captured graph
+/* One block.  host_in (LA_IN_WORDS int32) and host_out (LA_ST_OUTTOK+64 int32) MUST be pinned host memory
+ * (hipHostMalloc / hipHostRegister; torch pin_memory()): the first kernel reads host_in and the last kernel writes
+ * host_out directly (zero-copy), there are no copy commands around the graph.  Call la_llama_wait before reading host_out
+ * (it polls the completion word LA_ST_SEQ; hipStreamSynchronize alone is sufficient too).  Passing other addresses than
+ * in the previous call re-captures the graph.
+ * Captured graph
  * (embed -> L x {qkv, rope+kv, tree-attn, o, norm, gate/up, down, norm} -> lm_head+argmax ->
  * accept scan -> kv commit), d2h of the first 8+64 state words into host_out.  Asynchronous on
  * `stream`; the caller synchronises before reading host_out.  host_in/host_out should be pinned. */
 int la_llama_step(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);
+/* Wait for the step launched last by la_llama_step (spins on host_out[LA_ST_SEQ], falls back to a stream sync). */
+int la_llama_wait(la_llama* m, void* stream);
 /* Sequential accept path (non-empty logits-processor list / sampling, pretrained_model.py:825-875): run a step with
  * host_in[LA_IN_MODE] = 2 (forward only: no accept walk, nothing committed), read the logits rows the walk needs
  * (la_llama_buffer(m, 0)), then commit the accepted tree rows rows[0..n) (rows[0] = 0, the root).  Synchronous. */

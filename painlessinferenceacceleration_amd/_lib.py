@@ -15,7 +15,7 @@ LA_MODE_INPUT, LA_MODE_OUTPUT, LA_MODE_MIX = 0, 1, 2
 LA_TREE_MAX = 64
 LA_MOE_MAX_E = 8
 # device step-state words (include/lookahead_hip.h)
-LA_ST_NKEYS, LA_ST_T, LA_ST_MODE, LA_ST_NOUT, LA_ST_DSTBASE, LA_ST_NCOMMIT, LA_ST_MAXKEYS = 0, 1, 2, 3, 4, 5, 6
+LA_ST_NKEYS, LA_ST_T, LA_ST_MODE, LA_ST_NOUT, LA_ST_DSTBASE, LA_ST_NCOMMIT, LA_ST_MAXKEYS, LA_ST_SEQ = 0, 1, 2, 3, 4, 5, 6, 7
 LA_ST_OUTTOK, LA_ST_SRCIDX, LA_ST_ARGMAX, LA_ST_WORDS = 8, 72, 136, 200
 LA_IN_T, LA_IN_MODE, LA_IN_IDS, LA_IN_ROWMASK, LA_IN_WORDS = 0, 1, 4, 68, 196
 # cursor-batch blocks
@@ -144,6 +144,7 @@ PROTOTYPES = {
     "la_llama_destroy": (None, vp),
     "la_llama_reset": (i32, vp, vp),
     "la_llama_step": (i32, vp, vp, vp, vp),
+    "la_llama_wait": (i32, vp, vp),
     "la_llama_step_eager": (i32, vp, vp, vp, vp),
     "la_llama_commit": (i32, vp, vp, pi32, i32, vp),
     "la_lookahead_decode": (i32, vp, vp, vp, C.POINTER(DecodeParamsC), pi32, pi32, vp, vp, pi32, pi32, pi32, pi32,

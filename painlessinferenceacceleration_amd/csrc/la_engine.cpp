@@ -8,6 +8,7 @@
 #include <vector>
 #include <algorithm>
 #include <chrono>
+#include <atomic>
 #include "la_kernels.h"
 
 extern void la_set_error(const std::string& s);
@@ -39,6 +40,9 @@ struct la_llama {
     size_t kv_layer_elems, fresh_layer_elems;
     int n_slots, total_keys;
     hipGraphExec_t graph_exec, bgraph_exec;
+    const int32_t* zc_in;      // pinned host blocks the captured single-sequence graph reads / writes (zero-copy)
+    int32_t* zc_out;
+    int seq_expected;          // value host_out[LA_ST_SEQ] takes when the last launched step has been published
     bool graph_ready, bgraph_ready;
     hipStream_t graph_stream;
 };
@@ -179,6 +183,7 @@ extern "C" la_llama* la_llama_create(const la_llama_config* cfg, const la_llama_
     m->graph_ready = m->bgraph_ready = false;
     m->graph_exec = m->bgraph_exec = nullptr;
     m->graph_stream = nullptr;
+    m->zc_in = nullptr; m->zc_out = nullptr; m->seq_expected = 0;
     return m;
 }
 
@@ -197,6 +202,8 @@ extern "C" int la_llama_reset(la_llama* m, void* stream) {
     HIPCHK(hipMemcpyAsync(m->state + LA_ST_MAXKEYS, &mk, sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(m->bstate, 0, LA_BST_WORDS * sizeof(int), st));
     HIPCHK(hipStreamSynchronize(st));
+    m->seq_expected = 0;
+    if (m->zc_out) m->zc_out[LA_ST_SEQ] = 0;
     return LA_OK;
 }
 
@@ -227,12 +234,13 @@ struct Prof {
 };
 
 // enqueue every kernel of one block on `st` (used eagerly, under graph capture, and by the profiler)
-static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = false) {
+static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = false, const int32_t* zc_in = nullptr,
+                        int32_t* zc_out = nullptr) {
     const la_llama_config& c = m->cfg;
     auto P = [&](int cls) { if (pf) pf->mark(cls); };
     P(KC_OTHER);
     if (batch) KCHK(lk_build_tree_inputs_b(st, m->bin, m->bstate, m->pos, m->rowmask, m->ids));
-    else KCHK(lk_build_tree_inputs(st, m->in, m->state, m->pos, m->rowmask, m->ids));
+    else KCHK(lk_build_tree_inputs(st, zc_in ? (const int*)zc_in : m->in, m->state, m->pos, m->rowmask, m->ids));
     const int cf = c.norm_cast_first;
     if (m->fuse) HIPCHK(hipMemsetAsync(m->fuse_cnt, 0, sizeof(int) * 2 * c.n_layers, st));
     KCHK(lk_embed_norm(st, m->w.embed, m->ids, m->layers[0].norm1, c.hidden, c.rms_eps, m->h, m->xp, cf));
@@ -322,15 +330,17 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
     } else {
         KCHK(lk_accept_scan(st, m->ids, m->rowmask, m->state));
         KCHK(lk_kv_commit(st, m->kfresh, m->vfresh, m->kmain, m->vmain, m->state, c.n_layers, c.n_kv_heads, m->total_keys));
+        if (zc_out) KCHK(lk_publish(st, m->state, (int*)zc_out));
     }
     P(KC_N);
     return LA_OK;
 }
 
-static int build_graph(la_llama* m, hipStream_t st, bool batch = false) {
+static int build_graph(la_llama* m, hipStream_t st, bool batch = false, const int32_t* zc_in = nullptr,
+                       int32_t* zc_out = nullptr) {
     hipGraph_t g = nullptr;
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    int rc = enqueue_step(m, st, nullptr, batch);
+    int rc = enqueue_step(m, st, nullptr, batch, zc_in, zc_out);
     hipError_t e = hipStreamEndCapture(st, &g);
     if (rc != LA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
     HIPCHK(e);
@@ -365,13 +375,44 @@ extern "C" int la_llama_bstep_eager(la_llama* m, void* stream, const int32_t* ho
 }
 
 extern "C" int la_llama_step(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out) {
-    if (!m || !host_in) return LA_E_ARG;
+    if (!m || !host_in || !host_out) return LA_E_ARG;
     hipStream_t st = (hipStream_t)stream;
-    HIPCHK(hipMemcpyAsync(m->in, host_in, LA_IN_WORDS * sizeof(int), hipMemcpyHostToDevice, st));
-    if (!m->graph_ready) { int rc = build_graph(m, st); if (rc != LA_OK) return rc; }
+    if (m->graph_ready && (m->zc_in != host_in || m->zc_out != host_out)) {      // other staging blocks: capture again
+        (void)hipGraphExecDestroy(m->graph_exec);
+        m->graph_exec = nullptr;
+        m->graph_ready = false;
+    }
+    if (!m->graph_ready) {
+        hipPointerAttribute_t pa;
+        if (hipPointerGetAttributes(&pa, host_in) != hipSuccess || hipPointerGetAttributes(&pa, host_out) != hipSuccess) {
+            (void)hipGetLastError();
+            la_set_error("la_llama_step: host_in / host_out must be pinned host memory (zero-copy step I/O)");
+            return LA_E_ARG;
+        }
+        int rc = build_graph(m, st, false, host_in, host_out);
+        if (rc != LA_OK) return rc;
+        m->zc_in = host_in; m->zc_out = host_out;
+    }
+    m->seq_expected += 1;
     HIPCHK(hipGraphLaunch(m->graph_exec, st));
-    if (host_out)
-        HIPCHK(hipMemcpyAsync(host_out, m->state, (LA_ST_OUTTOK + 64) * sizeof(int), hipMemcpyDeviceToHost, st));
+    return LA_OK;
+}
+
+extern "C" int la_llama_wait(la_llama* m, void* stream) {
+    if (!m) return LA_E_ARG;
+    if (m->zc_out) {
+        volatile int32_t* flag = m->zc_out + LA_ST_SEQ;
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (*flag != m->seq_expected) {
+            if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (*flag == m->seq_expected) return LA_OK;
+    }
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (m->zc_out && m->zc_out[LA_ST_SEQ] != m->seq_expected) { la_set_error("la_llama_wait: step was not published"); return LA_E_HIP; }
     return LA_OK;
 }
 
@@ -414,7 +455,8 @@ extern "C" int la_lookahead_decode(la_llama* m, la_cache* c, void* stream, const
         if (qts) qts[steps] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         rc = la_llama_step(m, st, host_in, host_out);
         if (rc != LA_OK) return rc;
-        HIPCHK(hipStreamSynchronize(st));
+        rc = la_llama_wait(m, st);
+        if (rc != LA_OK) return rc;
         const int n = host_out[LA_ST_NOUT];
         nkeys = host_out[LA_ST_NKEYS];
         if (n < 1 || n > 16) { la_set_error("decode: bad step output"); return LA_E_HIP; }

@@ -58,6 +58,7 @@ int lk_accept_scan_b(hipStream_t st, const int* in, const int* ids, const uint64
                      int slot_keys);
 int lk_kv_commit_b(hipStream_t st, const void* kfresh, const void* vfresh, void* kmain, void* vmain, const int* bstate,
                    int n_layers, int nkv, int total_keys);
+int lk_publish(hipStream_t st, int* state, int* host_out);
 int lk_accept_scan(hipStream_t st, const int* ids, const uint64_t* rowmask, int* state);
 int lk_kv_commit(hipStream_t st, const void* kfresh, const void* vfresh, void* kmain, void* vmain, const int* state,
                  int n_layers, int nkv, int max_keys);

@@ -1191,6 +1191,21 @@ __global__ __launch_bounds__(256) void k_kv_commit(const bf16_t* __restrict__ kf
     }
 }
 
+// Zero-copy result hand-over: the last kernel of the captured step copies the first LA_ST_OUTTOK+64 state words into the
+// caller's PINNED host block and then bumps the sequence word (LA_ST_SEQ) there; the host polls that word instead of
+// queueing a D2H copy kernel and sleeping on the stream (measured: 22 us graph-end -> copy gap + ~50 us wake-up).
+__global__ void k_publish(int* __restrict__ state, int* __restrict__ host_out) {
+    const int j = threadIdx.x;      // 128 threads
+    int seq = 0;
+    if (j == 0) { seq = state[LA_ST_SEQ] + 1; state[LA_ST_SEQ] = seq; }
+    if (j < LA_ST_OUTTOK + 64 && j != LA_ST_SEQ) host_out[j] = state[j];
+    __threadfence_system();
+    __syncthreads();
+    if (j == 0) {
+        __hip_atomic_store(host_out + LA_ST_SEQ, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Multi-sequence accept scan + commit plan (pretrained_model_batch.py:814-905).  One wavefront per slot: the same
 // walk as k_accept_scan over the rows the slot owns, at most LIMIT[slot] emitted tokens (the loop bound
@@ -1593,6 +1608,10 @@ static int tree_attn_launch(hipStream_t st, AttnArgs a, int n_slots, void* attn_
         default: return -1;
     }
 #undef AC
+    LAUNCH_CHECK(); return 0;
+}
+int lk_publish(hipStream_t st, int* state, int* host_out) {
+    k_publish<<<1, 128, 0, st>>>(state, host_out);
     LAUNCH_CHECK(); return 0;
 }
 int lk_accept_scan(hipStream_t st, const int* ids, const uint64_t* rowmask, int* state) {

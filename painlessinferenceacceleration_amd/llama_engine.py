@@ -399,6 +399,7 @@ class LlamaVerifyEngine(object):
         """Enqueue one block (tree of T<=64 tokens) on the current stream; results land in host_out."""
         self._fill(ids, rowmask, mode)
         fn = lib.la_llama_step_eager if eager else lib.la_llama_step
+        self._eager_pending = bool(eager)
         check(fn(self._h, self._sp(), self.host_in.data_ptr(), self.host_out.data_ptr()), 'llama_step')
 
     def step(self, ids, rowmask, mode=0, eager=False):
@@ -406,9 +407,17 @@ class LlamaVerifyEngine(object):
         self.step_async(ids, rowmask, mode, eager)
         return self.step_finish()
 
+    def _wait(self):
+        # captured step: the last kernel writes the result block into pinned host memory and bumps its sequence word, which
+        # la_llama_wait polls (no D2H copy command, no sleep on the stream); eager steps use copies + a stream sync
+        if getattr(self, '_eager_pending', False):
+            self.stream.synchronize()
+        else:
+            check(lib.la_llama_wait(self._h, self._sp()), 'llama_wait')
+
     def step_finish(self):
         """Wait for the block enqueued by step_async and return its result (host work can run in between)."""
-        self.stream.synchronize()
+        self._wait()
         o = self._out_np
         n_out = int(o[_lib.LA_ST_NOUT])
         self.n_keys = int(o[_lib.LA_ST_NKEYS])
@@ -450,7 +459,7 @@ class LlamaVerifyEngine(object):
         """Forward of one block without the device accept walk (mode 2): logits() holds one row per tree token, nothing is
         committed until commit()."""
         self.step_async(ids, rowmask, mode=2, eager=eager)
-        self.stream.synchronize()
+        self._wait()
 
     def commit(self, rows):
         """Keep the K/V of tree rows `rows` (root first) of the last verify_only block."""
