@@ -274,6 +274,24 @@ class LookaheadPreTrainedModel(object):
                  streamer=None, do_sample=False, repetition_penalty=1.0, **unused):
         """Minimal generate(): the arguments the reference's examples/benchmarks pass
         (benchmarks/benchmark.py:282-300, examples/llama_example.py:51-60)."""
+        gcfg = unused.get('generation_config', None)       # GenerationConfig / LookaheadGenerationConfig object
+        if gcfg is not None:
+            max_new_tokens = max_new_tokens if max_new_tokens is not None else getattr(gcfg, 'max_new_tokens', None)
+            if max_length is None and max_new_tokens is None:
+                max_length = getattr(gcfg, 'max_length', None)
+            eos_token_id = eos_token_id if eos_token_id is not None else getattr(gcfg, 'eos_token_id', None)
+            pad_token_id = pad_token_id if pad_token_id is not None else getattr(gcfg, 'pad_token_id', None)
+            do_sample = do_sample or bool(getattr(gcfg, 'do_sample', False))
+            if repetition_penalty == 1.0:
+                repetition_penalty = float(getattr(gcfg, 'repetition_penalty', 1.0) or 1.0)
+            if decoding_kwargs is None:                    # lookahead_generation_utils.py:19-29
+                if hasattr(gcfg, 'to_decoding_kwargs'):
+                    decoding_kwargs = gcfg.to_decoding_kwargs()
+                else:
+                    decoding_kwargs = dict(getattr(gcfg, 'decoding_kwargs', {}) or {})
+                    for k in ('use_lookahead', 'debug_lookahead', 'decoding_length', 'branch_length', 'decoding_mode'):
+                        if hasattr(gcfg, k):
+                            decoding_kwargs.setdefault(k, getattr(gcfg, k))
         if max_length is None:
             max_length = input_ids.size(1) + (max_new_tokens if max_new_tokens is not None else 20)
         dk = dict(decoding_kwargs or {})

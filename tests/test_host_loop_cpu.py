@@ -167,3 +167,25 @@ def test_loop_with_logits_processors_reproduces_reference_run():
     s = m2.generate(input_ids=torch.tensor([prompt]), max_new_tokens=8, do_sample=True, eos_token_id=2,
                     decoding_kwargs=dict(DK))
     assert s.shape[1] >= len(prompt) + 1
+
+
+def test_generate_called_like_the_reference_example():
+    """examples/llama_example.py:39-69: the [False, False, True, True] loop with a stop-word SET, position_ids / use_cache
+    keywords, and the LookaheadGenerationConfig route."""
+    from painlessinferenceacceleration_amd.lookahead_generation_utils import LookaheadGenerationConfig
+    m = Model(torch.float32)
+    g = load_golden('fp32')
+    input_ids = torch.tensor([g['prompt'].tolist()])
+    outs = []
+    for use_lookahead in [False, False, True, True]:
+        decoding_kwargs = {"use_lookahead": use_lookahead, "debug_lookahead": False, "decoding_length": 64,
+                           "branch_length": 12, "stop_words": set([5, 9, 11])}
+        outputs = m.generate(input_ids=input_ids, attention_mask=torch.ones_like(input_ids), position_ids=None,
+                             pad_token_id=2, eos_token_id=2, use_cache=True, max_new_tokens=40, repetition_penalty=1.0,
+                             do_sample=False, decoding_kwargs=decoding_kwargs)
+        outs.append(outputs[0, input_ids.size(-1):].tolist())
+    assert outs[0] == outs[1] == outs[2][:len(outs[0])] and outs[3][:len(outs[0])] == outs[0]
+    cfg = LookaheadGenerationConfig(use_lookahead=True, decoding_length=64, branch_length=12, max_new_tokens=40,
+                                    eos_token_id=2, pad_token_id=2)
+    out = m.generate(input_ids=input_ids, generation_config=cfg)
+    assert out[0, input_ids.size(-1):].tolist()[:len(outs[0])] == outs[0]
