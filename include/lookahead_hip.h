@@ -43,7 +43,8 @@ extern "C" {
 #define LA_MOE_MAX_E      8   /* experts per mixture-of-experts layer (Mixtral: 8, top-2) */
 
 /* ABI version: bumped when a signature changes. */
-int          la_abi_version(void);
+#define LA_ABI_VERSION  3    /* bumped whenever a struct layout or an entry point changes */
+int          la_abi_version(void);   /* == LA_ABI_VERSION of the header the library was built from */
 const char*  la_last_error(void);
 
 /* ------------------------------------------------------------------------

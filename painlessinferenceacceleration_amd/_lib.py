@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblookahead_hip.so")
 
 LA_OK = 0
+ABI_VERSION = 3         # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
 LA_MODE_INPUT, LA_MODE_OUTPUT, LA_MODE_MIX = 0, 1, 2
 LA_TREE_MAX = 64
 LA_MOE_MAX_E = 8
@@ -165,6 +166,9 @@ PROTOTYPES = {
 
 for _n, _sig in PROTOTYPES.items():
     _proto(_n, _sig[0], *_sig[1:])
+if lib.la_abi_version() != ABI_VERSION:
+    raise ImportError(f"{LIB_PATH} implements ABI {lib.la_abi_version()}, the bindings expect {ABI_VERSION}: rebuild it with "
+                      f"`bash {os.path.join(_HERE, 'csrc', 'build.sh')}`")
 
 
 def last_error() -> str:

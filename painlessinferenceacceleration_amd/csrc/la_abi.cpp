@@ -13,7 +13,7 @@ void la_set_error(const std::string& s) { g_err = s; }
 
 extern "C" {
 
-int la_abi_version(void) { return 2; }
+int la_abi_version(void) { return LA_ABI_VERSION; }
 const char* la_last_error(void) { return g_err.c_str(); }
 
 int la_build_tree_inputs(void* stream, const int32_t* d_in, int32_t* d_state, int32_t* d_pos, uint64_t* d_rowmask,

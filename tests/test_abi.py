@@ -26,7 +26,9 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_abi_version_and_error_channel():
-    assert _lib.lib.la_abi_version() == 2
+    assert _lib.lib.la_abi_version() == _lib.ABI_VERSION
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'lookahead_hip.h')).read()
+    assert int(re.search(r'#define LA_ABI_VERSION\s+(\d+)', hdr).group(1)) == _lib.ABI_VERSION
     c = _lib.lib.la_cache_create(10, 10)
     assert c
     rc = _lib.lib.la_cache_put(c, None, 3, 8, 0, 7, 0)      # bad mode / null tokens -> LA_E_ARG, never a crash

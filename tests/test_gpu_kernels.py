@@ -24,7 +24,7 @@ def bf(t):
 
 
 def test_library_is_the_native_one():
-    assert lib.la_abi_version() == 2
+    assert lib.la_abi_version() == _lib.ABI_VERSION
     assert torch.cuda.is_available()
     assert 'gfx950' in torch.cuda.get_device_properties(0).gcnArchName
 
