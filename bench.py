@@ -288,7 +288,8 @@ def main():
     traffic, traffic_src = None, None
     try:        # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py)
         pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')))
-        traffic = pmc['kernels']['void k_gemm64r<4, 1, 4, 8>(GemmRArgs)']['hbm_bytes_per_launch']
+        key = [k for k in pmc['kernels'] if k.startswith('void k_gemm64r<4, 1, 4, 8')][0]      # gate/up launch
+        traffic = pmc['kernels'][key]['hbm_bytes_per_launch']
         traffic_src = pmc['source']
     except Exception:
         pass

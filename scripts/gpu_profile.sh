@@ -51,9 +51,9 @@ for f in glob.glob(os.path.join(raw, 'pmc_SQ', '**', '*counter_collection*.csv')
             if not k.startswith(('k_', 'void k_')):
                 continue
             m = {c: v[1] / max(v[0], 1) for c, v in cs.items()}
-            gui = m.get('GRBM_GUI_ACTIVE', 0.0)
-            util = 100.0 * m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui * 256 * 4) if gui else float('nan')
-            line = f"{k[:52]:54s} " + ' '.join(f'{c}={v:.0f}' for c, v in sorted(m.items())) + f' mfma_util_pct={util:.2f}'
+            # raw per-dispatch means; utilisation is derived in profiles/pmc_latest.json from the kernel's duration
+            # (SQ_VALU_MFMA_BUSY_CYCLES / (duration x 2.4 GHz x 1024 SIMDs)); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+            line = f"{k[:52]:54s} " + ' '.join(f'{c}={v:.0f}' for c, v in sorted(m.items()))
             fo.write(line + '\n'); print(line)
 for c in ('FETCH_SIZE', 'WRITE_SIZE'):
     for f in glob.glob(os.path.join(raw, f'pmc_{c}', '**', '*counter_collection*.csv'), recursive=True):
