@@ -128,7 +128,6 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-iters', type=int, default=3)
     ap.add_argument('--attn-split', type=int, default=0, help='key splits of the tree-attention kernel (0 = engine default 8)')
-    ap.add_argument('--no-prearm', action='store_true', help='launch every step graph only after its input exists')
     ap.add_argument('--fuse', type=int, default=0, help='engine cfg.fuse bits (opt-in in-kernel norm->GEMM fusion; 0 = separate kernels)')
     args = ap.parse_args()
 
@@ -194,7 +193,7 @@ def main():
     pending = [False]
     edls, dls, qts = [], [], []
 
-    def one_step(arm_next=False):
+    def one_step():
         tq = time.time()
         ubl = min(BL, max_length - len(seq) - 1)
         ids, rowmask, _, _ = cache.hier_get_packed(seq[-2:], decoding_length=DL, branch_length=ubl, min_input_size=0,
@@ -206,7 +205,7 @@ def main():
                                   mode='mix', idx=rank)
             print(f'[debug] query {1e3 * qts[-1]:.3f} ms, repeated {1e3 * (time.time() - t1):.3f} ms, T {len(ids)} stats {cache.stats()}',
                   file=sys.stderr, flush=True)
-        eng.step_async(ids, rowmask, mode=0, arm_next=arm_next and not args.no_prearm)
+        eng.step_async(ids, rowmask, mode=0)
         if pending[0]:       # N > 1: the previous step's gather + every rank's trie update run while the GPU verifies
             gather.finish_into_trie(cache, BL)
             pending[0] = False
@@ -230,15 +229,15 @@ def main():
     gc.collect()
     gc.freeze()          # a generation-2 collection over torch's import graph costs tens of ms on the host thread that
                          # drives the loop; the serving loop allocates nothing that needs cycle collection
-    for i in range(W):
-        one_step(arm_next=i + 1 < W)      # the next step's graph is queued while this one runs (la_llama_arm)
+    for _ in range(W):
+        one_step()
     n0 = len(edls)
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
-    for i in range(K):
-        one_step(arm_next=i + 1 < K)
+    for _ in range(K):
+        one_step()
     if pending[0]:
         gather.finish_into_trie(cache, BL)
         pending[0] = False

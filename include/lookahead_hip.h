@@ -43,7 +43,7 @@ extern "C" {
 #define LA_MOE_MAX_E      8   /* experts per mixture-of-experts layer (Mixtral: 8, top-2) */
 
 /* ABI version: bumped when a signature changes. */
-#define LA_ABI_VERSION  4    /* bumped whenever a struct layout or an entry point changes */
+#define LA_ABI_VERSION  3    /* bumped whenever a struct layout or an entry point changes */
 int          la_abi_version(void);   /* == LA_ABI_VERSION of the header the library was built from */
 const char*  la_last_error(void);
 
@@ -133,7 +133,6 @@ int la_trie_hier_get_dev(void* stream, const int32_t* d_tok, const double* d_fo,
 /* Host->device step input block: {T, mode, pad, pad, ids[64] (int32), rowmask[64] (uint64)}. */
 #define LA_IN_T          0
 #define LA_IN_MODE       1
-#define LA_IN_SEQ        2   /* written by la_llama_step: sequence number of this input (pre-armed graphs wait for it) */
 #define LA_IN_IDS        4
 #define LA_IN_ROWMASK   68   /* int32 word offset; 8-byte aligned */
 #define LA_IN_WORDS    196
@@ -282,14 +281,6 @@ int la_llama_reset(la_llama* m, void* stream);
  * accept scan -> kv commit), d2h of the first 8+64 state words into host_out.  Asynchronous on
  * `stream`; the caller synchronises before reading host_out.  host_in/host_out should be pinned. */
 int la_llama_step(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);
-/* Pre-arm: queue the NEXT step's graph now, before its input exists (call right after la_llama_step).  Its first kernel
- * polls the pinned input block; the following la_llama_step then only publishes the input (no launch on the critical path).
- * At most one armed step.  While a step is armed NOTHING may wait for the whole stream or device (hipStreamSynchronize /
- * hipDeviceSynchronize / torch.cuda.synchronize would wait for a kernel that waits for the host): use la_llama_wait, and
- * call la_llama_disarm (feeds a forward-only null step, ~1 step of GPU time) before anything else touches the stream.
- * reset / reset_slot / step_eager / bstep / commit / profile / destroy disarm by themselves. */
-int la_llama_arm(la_llama* m, void* stream);
-int la_llama_disarm(la_llama* m, void* stream);
 /* Wait for the step launched last by la_llama_step (spins on host_out[LA_ST_SEQ], falls back to a stream sync). */
 int la_llama_wait(la_llama* m, void* stream);
 /* Sequential accept path (non-empty logits-processor list / sampling, pretrained_model.py:825-875): run a step with
@@ -323,7 +314,6 @@ typedef struct la_decode_params {
     int32_t idx;                  /* trie request slot of this sequence */
     int32_t max_length;           /* stop when seq_len >= max_length */
     int32_t max_steps;
-    int32_t prearm;               /* != 0: pre-arm the next step's graph while the current one runs (la_llama_arm) */
     int32_t n_eos;
     int32_t eos[8];
 } la_decode_params;

@@ -11,14 +11,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblookahead_hip.so")
 
 LA_OK = 0
-ABI_VERSION = 4         # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
+ABI_VERSION = 3         # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
 LA_MODE_INPUT, LA_MODE_OUTPUT, LA_MODE_MIX = 0, 1, 2
 LA_TREE_MAX = 64
 LA_MOE_MAX_E = 8
 # device step-state words (include/lookahead_hip.h)
 LA_ST_NKEYS, LA_ST_T, LA_ST_MODE, LA_ST_NOUT, LA_ST_DSTBASE, LA_ST_NCOMMIT, LA_ST_MAXKEYS, LA_ST_SEQ = 0, 1, 2, 3, 4, 5, 6, 7
 LA_ST_OUTTOK, LA_ST_SRCIDX, LA_ST_ARGMAX, LA_ST_WORDS = 8, 72, 136, 200
-LA_IN_T, LA_IN_MODE, LA_IN_SEQ, LA_IN_IDS, LA_IN_ROWMASK, LA_IN_WORDS = 0, 1, 2, 4, 68, 196
+LA_IN_T, LA_IN_MODE, LA_IN_IDS, LA_IN_ROWMASK, LA_IN_WORDS = 0, 1, 4, 68, 196
 # cursor-batch blocks
 LA_MAX_SEQ = 16
 LA_BIN_T, LA_BIN_IDS, LA_BIN_ROWMASK, LA_BIN_SEQ, LA_BIN_MODE, LA_BIN_LIMIT, LA_BIN_WORDS = 0, 4, 68, 196, 260, 276, 292
@@ -87,7 +87,7 @@ class LlamaWeightsC(C.Structure):
 
 class DecodeParamsC(C.Structure):
     _fields_ = [("decoding_length", i32), ("branch_length", i32), ("max_query_length", i32), ("mode", i32), ("idx", i32),
-                ("max_length", i32), ("max_steps", i32), ("prearm", i32), ("n_eos", i32), ("eos", i32 * 8)]
+                ("max_length", i32), ("max_steps", i32), ("n_eos", i32), ("eos", i32 * 8)]
 
 
 def _proto(name, restype, *argtypes):
@@ -146,8 +146,6 @@ PROTOTYPES = {
     "la_llama_reset": (i32, vp, vp),
     "la_llama_step": (i32, vp, vp, vp, vp),
     "la_llama_wait": (i32, vp, vp),
-    "la_llama_arm": (i32, vp, vp),
-    "la_llama_disarm": (i32, vp, vp),
     "la_llama_step_eager": (i32, vp, vp, vp, vp),
     "la_llama_commit": (i32, vp, vp, pi32, i32, vp),
     "la_lookahead_decode": (i32, vp, vp, vp, C.POINTER(DecodeParamsC), pi32, pi32, vp, vp, pi32, pi32, pi32, pi32,

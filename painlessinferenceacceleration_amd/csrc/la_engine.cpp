@@ -43,9 +43,6 @@ struct la_llama {
     const int32_t* zc_in;      // pinned host blocks the captured single-sequence graph reads / writes (zero-copy)
     int32_t* zc_out;
     int seq_expected;          // value host_out[LA_ST_SEQ] takes when the last launched step has been published
-    hipGraphExec_t agraph_exec;  // the same step with the waiting head kernel (la_llama_arm)
-    bool agraph_ready;
-    int armed;                 // 1 while an armed graph is queued and has not been fed
     bool graph_ready, bgraph_ready;
     hipStream_t graph_stream;
 };
@@ -187,22 +184,18 @@ extern "C" la_llama* la_llama_create(const la_llama_config* cfg, const la_llama_
     m->graph_exec = m->bgraph_exec = nullptr;
     m->graph_stream = nullptr;
     m->zc_in = nullptr; m->zc_out = nullptr; m->seq_expected = 0;
-    m->agraph_exec = nullptr; m->agraph_ready = false; m->armed = 0;
     return m;
 }
 
 extern "C" void la_llama_destroy(la_llama* m) {
     if (!m) return;
-    if (m->armed) (void)la_llama_disarm(m, m->graph_stream);
     if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
-    if (m->agraph_exec) (void)hipGraphExecDestroy(m->agraph_exec);
     if (m->bgraph_exec) (void)hipGraphExecDestroy(m->bgraph_exec);
     delete m;
 }
 
 extern "C" int la_llama_reset(la_llama* m, void* stream) {
     if (!m) return LA_E_ARG;
-    { int rc_ = la_llama_disarm(m, stream); if (rc_ != LA_OK) return rc_; }
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipMemsetAsync(m->state, 0, LA_ST_WORDS * sizeof(int), st));
     int mk = m->cfg.max_keys;
@@ -211,13 +204,11 @@ extern "C" int la_llama_reset(la_llama* m, void* stream) {
     HIPCHK(hipStreamSynchronize(st));
     m->seq_expected = 0;
     if (m->zc_out) m->zc_out[LA_ST_SEQ] = 0;
-    if (m->zc_in) ((int32_t*)m->zc_in)[LA_IN_SEQ] = 0;
     return LA_OK;
 }
 
 extern "C" int la_llama_reset_slot(la_llama* m, void* stream, int slot) {
     if (!m || slot >= m->n_slots) return LA_E_ARG;
-    { int rc_ = la_llama_disarm(m, stream); if (rc_ != LA_OK) return rc_; }
     hipStream_t st = (hipStream_t)stream;
     if (slot < 0) HIPCHK(hipMemsetAsync(m->bstate, 0, LA_BST_WORDS * sizeof(int), st));
     else HIPCHK(hipMemsetAsync(m->bstate + LA_BST_NKEYS + slot, 0, sizeof(int), st));
@@ -244,12 +235,11 @@ struct Prof {
 
 // enqueue every kernel of one block on `st` (used eagerly, under graph capture, and by the profiler)
 static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = false, const int32_t* zc_in = nullptr,
-                        int32_t* zc_out = nullptr, bool armed_head = false) {
+                        int32_t* zc_out = nullptr) {
     const la_llama_config& c = m->cfg;
     auto P = [&](int cls) { if (pf) pf->mark(cls); };
     P(KC_OTHER);
     if (batch) KCHK(lk_build_tree_inputs_b(st, m->bin, m->bstate, m->pos, m->rowmask, m->ids));
-    else if (armed_head) KCHK(lk_build_tree_inputs_armed(st, (const int*)zc_in, m->state, m->pos, m->rowmask, m->ids));
     else KCHK(lk_build_tree_inputs(st, zc_in ? (const int*)zc_in : m->in, m->state, m->pos, m->rowmask, m->ids));
     const int cf = c.norm_cast_first;
     if (m->fuse) HIPCHK(hipMemsetAsync(m->fuse_cnt, 0, sizeof(int) * 2 * c.n_layers, st));
@@ -347,23 +337,22 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
 }
 
 static int build_graph(la_llama* m, hipStream_t st, bool batch = false, const int32_t* zc_in = nullptr,
-                       int32_t* zc_out = nullptr, bool armed_head = false) {
+                       int32_t* zc_out = nullptr) {
     hipGraph_t g = nullptr;
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    int rc = enqueue_step(m, st, nullptr, batch, zc_in, zc_out, armed_head);
+    int rc = enqueue_step(m, st, nullptr, batch, zc_in, zc_out);
     hipError_t e = hipStreamEndCapture(st, &g);
     if (rc != LA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
     HIPCHK(e);
-    HIPCHK(hipGraphInstantiate(armed_head ? &m->agraph_exec : (batch ? &m->bgraph_exec : &m->graph_exec), g, nullptr, nullptr, 0));
+    HIPCHK(hipGraphInstantiate(batch ? &m->bgraph_exec : &m->graph_exec, g, nullptr, nullptr, 0));
     (void)hipGraphDestroy(g);
-    (armed_head ? m->agraph_ready : (batch ? m->bgraph_ready : m->graph_ready)) = true;
+    (batch ? m->bgraph_ready : m->graph_ready) = true;
     m->graph_stream = st;
     return LA_OK;
 }
 
 static int bstep(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out, bool eager) {
     if (!m || !host_in) return LA_E_ARG;
-    { int rc_ = la_llama_disarm(m, stream); if (rc_ != LA_OK) return rc_; }
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipMemcpyAsync(m->bin, host_in, LA_BIN_WORDS * sizeof(int), hipMemcpyHostToDevice, st));
     if (eager) {
@@ -388,21 +377,10 @@ extern "C" int la_llama_bstep_eager(la_llama* m, void* stream, const int32_t* ho
 extern "C" int la_llama_step(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out) {
     if (!m || !host_in || !host_out) return LA_E_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (m->armed && (m->zc_in != host_in || m->zc_out != host_out)) { int rc = la_llama_disarm(m, stream); if (rc != LA_OK) return rc; }
-    if (m->armed) {
-        // the step's graph is already queued (la_llama_arm): publishing the input's sequence number releases its head kernel
-        m->seq_expected += 1;
-        __atomic_store_n((int32_t*)host_in + LA_IN_SEQ, m->seq_expected, __ATOMIC_RELEASE);
-        m->armed = 0;
-        return LA_OK;
-    }
     if (m->graph_ready && (m->zc_in != host_in || m->zc_out != host_out)) {      // other staging blocks: capture again
         (void)hipGraphExecDestroy(m->graph_exec);
         m->graph_exec = nullptr;
         m->graph_ready = false;
-        if (m->agraph_exec) (void)hipGraphExecDestroy(m->agraph_exec);
-        m->agraph_exec = nullptr;
-        m->agraph_ready = false;
     }
     if (!m->graph_ready) {
         hipPointerAttribute_t pa;
@@ -418,32 +396,6 @@ extern "C" int la_llama_step(la_llama* m, void* stream, const int32_t* host_in, 
     m->seq_expected += 1;
     HIPCHK(hipGraphLaunch(m->graph_exec, st));
     return LA_OK;
-}
-
-extern "C" int la_llama_arm(la_llama* m, void* stream) {
-    if (!m) return LA_E_ARG;
-    if (m->armed) return LA_OK;
-    if (!m->graph_ready || !m->zc_in) { la_set_error("la_llama_arm: call la_llama_step once first"); return LA_E_ARG; }
-    hipStream_t st = (hipStream_t)stream;
-    if (!m->agraph_ready) {
-        int rc = build_graph(m, st, false, m->zc_in, m->zc_out, true);
-        if (rc != LA_OK) return rc;
-    }
-    HIPCHK(hipGraphLaunch(m->agraph_exec, st));
-    m->armed = 1;
-    return LA_OK;
-}
-
-extern "C" int la_llama_disarm(la_llama* m, void* stream) {
-    if (!m) return LA_E_ARG;
-    if (!m->armed) return LA_OK;
-    // feed a forward-only null step (root row only, nothing committed) and wait for it
-    int32_t* in = (int32_t*)m->zc_in;
-    in[LA_IN_T] = 1; in[LA_IN_MODE] = 2; in[LA_IN_IDS] = 0;
-    in[LA_IN_ROWMASK] = 1; in[LA_IN_ROWMASK + 1] = 0;
-    int rc = la_llama_step(m, stream, m->zc_in, m->zc_out);
-    if (rc != LA_OK) return rc;
-    return la_llama_wait(m, stream);
 }
 
 extern "C" int la_llama_wait(la_llama* m, void* stream) {
@@ -466,7 +418,6 @@ extern "C" int la_llama_wait(la_llama* m, void* stream) {
 
 extern "C" int la_llama_step_eager(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out) {
     if (!m || !host_in) return LA_E_ARG;
-    { int rc_ = la_llama_disarm(m, stream); if (rc_ != LA_OK) return rc_; }
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipMemcpyAsync(m->in, host_in, LA_IN_WORDS * sizeof(int), hipMemcpyHostToDevice, st));
     int rc = enqueue_step(m, st, nullptr);
@@ -504,12 +455,6 @@ extern "C" int la_lookahead_decode(la_llama* m, la_cache* c, void* stream, const
         if (qts) qts[steps] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         rc = la_llama_step(m, st, host_in, host_out);
         if (rc != LA_OK) return rc;
-        // pre-arm the next step unless this one can be the last for a reason known in advance (max_steps / max_length);
-        // an eos stop leaves one armed graph behind, which the next reset / step on this engine drains
-        if (p->prearm && steps + 1 < p->max_steps && len + p->branch_length + 1 < p->max_length) {
-            rc = la_llama_arm(m, st);
-            if (rc != LA_OK) return rc;
-        }
         rc = la_llama_wait(m, st);
         if (rc != LA_OK) return rc;
         const int n = host_out[LA_ST_NOUT];
@@ -532,7 +477,6 @@ extern "C" int la_lookahead_decode(la_llama* m, la_cache* c, void* stream, const
         len += n;
         if (len >= p->max_length || eos) { done = 1; break; }
     }
-    if (m->armed) { int rc = la_llama_disarm(m, stream); if (rc != LA_OK) return rc; }      // eos stop: drain the armed step
     *seq_len = len;
     *n_steps = steps;
     if (finished) *finished = done;
@@ -543,7 +487,6 @@ extern "C" int la_lookahead_decode(la_llama* m, la_cache* c, void* stream, const
 // nkeys..nkeys+n (the sequential accept of pretrained_model.py:825-875 with a non-empty logits-processor list).
 extern "C" int la_llama_commit(la_llama* m, void* stream, const int32_t* rows, int n, int32_t* host_out) {
     if (!m || !rows || n < 1 || n > LA_TREE_MAX) return LA_E_ARG;
-    { int rc_ = la_llama_disarm(m, stream); if (rc_ != LA_OK) return rc_; }
     hipStream_t st = (hipStream_t)stream;
     int hdr[LA_ST_WORDS];
     HIPCHK(hipMemcpyAsync(hdr, m->state, sizeof(hdr), hipMemcpyDeviceToHost, st));
@@ -587,7 +530,6 @@ extern "C" void* la_llama_buffer(la_llama* m, int which) {
 extern "C" int la_llama_profile(la_llama* m, void* stream, const int32_t* host_in, int iters,
                                 float* out_ms, int32_t* out_launches) {
     if (!m || !host_in || iters <= 0 || !out_ms) return LA_E_ARG;
-    { int rc_ = la_llama_disarm(m, stream); if (rc_ != LA_OK) return rc_; }
     hipStream_t st = (hipStream_t)stream;
     int saved[LA_ST_WORDS];
     HIPCHK(hipMemcpyAsync(m->in, host_in, LA_IN_WORDS * sizeof(int), hipMemcpyHostToDevice, st));

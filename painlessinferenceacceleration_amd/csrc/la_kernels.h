@@ -45,7 +45,6 @@ int lk_resid_norm_addend(hipStream_t st, void* h, const void* addend, const void
                          int cast_first = 0);
 int lk_moe_accum(hipStream_t st, const float* slabs, int n_slabs, const float* route_col, int hidden, void* acc, int first);
 int lk_build_tree_inputs(hipStream_t st, const int* in, int* state, int* pos, uint64_t* rowmask, int* ids);
-int lk_build_tree_inputs_armed(hipStream_t st, const int* host_in, int* state, int* pos, uint64_t* rowmask, int* ids);
 int lk_qkv_post(hipStream_t st, const float* slabs, int n_slabs, int nh, int nkv, const int* pos, const void* rcos,
                 const void* rsin, void* qf, void* kfresh, void* vfresh);
 int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,

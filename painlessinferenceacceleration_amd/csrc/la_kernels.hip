@@ -773,40 +773,6 @@ __global__ void k_build_tree_inputs(const int* __restrict__ in, int* __restrict_
     if (t == 0) { state[LA_ST_T] = T; state[LA_ST_MODE] = in[LA_IN_MODE]; }
 }
 
-// Pre-armed form: the whole step graph is queued BEFORE its input exists (right behind the previous step), and this head
-// kernel polls the pinned input block until the host publishes sequence number state[LA_ST_SEQ] + 1 there.  The graph-launch
-// latency (~0.1 ms for 260 nodes) thereby leaves the critical path between two dependent steps.  Bounded spin (~10 s).
-__global__ void k_build_tree_inputs_armed(const int* in, int* __restrict__ state, int* __restrict__ pos,
-                                          unsigned long long* __restrict__ rowmask, int* __restrict__ ids) {
-    const int t = threadIdx.x;   // 64 threads
-    if (t == 0) {
-        const int want = state[LA_ST_SEQ] + 1;
-        unsigned spins = 0;
-        while (__hip_atomic_load(in + LA_IN_SEQ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != want) {
-            __builtin_amdgcn_s_sleep(16);
-            if (++spins > 5000000u) __builtin_trap();
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    }
-    __syncthreads();
-    const int T = __hip_atomic_load(in + LA_IN_T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    unsigned long long rm = 1ull << t;
-    int id = 0;
-    if (t < T) {
-        const unsigned lo = (unsigned)__hip_atomic_load(in + LA_IN_ROWMASK + 2 * t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        const unsigned hi = (unsigned)__hip_atomic_load(in + LA_IN_ROWMASK + 2 * t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        rm = ((unsigned long long)hi << 32) | lo;
-        id = __hip_atomic_load(in + LA_IN_IDS + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    rowmask[t] = rm;
-    ids[t] = id;
-    pos[t] = state[LA_ST_NKEYS] + __popcll(rm) - 1;
-    if (t == 0) {
-        state[LA_ST_T] = T;
-        state[LA_ST_MODE] = __hip_atomic_load(in + LA_IN_MODE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
 // Multi-sequence form (pretrained_model_batch.py:706-731 + modeling_llama_batch.py:729-734): the 64 block rows are
 // shared by up to LA_MAX_SEQ sequence slots; a row's position counts its own slot's committed keys.
 __global__ void k_build_tree_inputs_b(const int* __restrict__ in, int* __restrict__ bstate, int* __restrict__ pos,
@@ -1584,10 +1550,6 @@ int lk_moe_accum(hipStream_t st, const float* slabs, int n_slabs, const float* r
 }
 int lk_build_tree_inputs(hipStream_t st, const int* in, int* state, int* pos, uint64_t* rowmask, int* ids) {
     k_build_tree_inputs<<<1, 64, 0, st>>>(in, state, pos, (unsigned long long*)rowmask, ids);
-    LAUNCH_CHECK(); return 0;
-}
-int lk_build_tree_inputs_armed(hipStream_t st, const int* host_in, int* state, int* pos, uint64_t* rowmask, int* ids) {
-    k_build_tree_inputs_armed<<<1, 64, 0, st>>>(host_in, state, pos, (unsigned long long*)rowmask, ids);
     LAUNCH_CHECK(); return 0;
 }
 int lk_qkv_post(hipStream_t st, const float* slabs, int n_slabs, int nh, int nkv, const int* pos, const void* rcos,

@@ -395,20 +395,12 @@ class LlamaVerifyEngine(object):
         a[_lib.LA_IN_IDS:_lib.LA_IN_IDS + T] = ids
         self._in_rm[:T] = rowmask
 
-    def step_async(self, ids, rowmask, mode=0, eager=False, arm_next=False):
-        """Enqueue one block (tree of T<=64 tokens) on the engine stream; results land in host_out.  arm_next: also queue the
-        NEXT step's graph now (la_llama_arm) so that its launch latency is off the critical path — only inside a loop that
-        calls nothing but step_async / step_finish on this engine until disarm() (no stream- or device-wide sync)."""
+    def step_async(self, ids, rowmask, mode=0, eager=False):
+        """Enqueue one block (tree of T<=64 tokens) on the current stream; results land in host_out."""
         self._fill(ids, rowmask, mode)
         fn = lib.la_llama_step_eager if eager else lib.la_llama_step
         self._eager_pending = bool(eager)
         check(fn(self._h, self._sp(), self.host_in.data_ptr(), self.host_out.data_ptr()), 'llama_step')
-        if arm_next and not eager:
-            check(lib.la_llama_arm(self._h, self._sp()), 'llama_arm')
-
-    def disarm(self):
-        """Drain a pre-armed step (forward-only null step); a no-op when nothing is armed."""
-        check(lib.la_llama_disarm(self._h, self._sp()), 'llama_disarm')
 
     def step(self, ids, rowmask, mode=0, eager=False):
         """-> list of emitted tokens (accepted path + bonus), list of accepted tree rows."""
@@ -432,7 +424,7 @@ class LlamaVerifyEngine(object):
         return o[_lib.LA_ST_OUTTOK:_lib.LA_ST_OUTTOK + n_out].tolist(), int(o[_lib.LA_ST_NCOMMIT])
 
     def decode_native(self, cache, seq, max_length, eos_ids=(), decoding_length=64, branch_length=12, max_query_length=2,
-                      mode=_lib.LA_MODE_MIX, idx=0, max_steps=1 << 30, prearm=True):
+                      mode=_lib.LA_MODE_MIX, idx=0, max_steps=1 << 30):
         """Run verify steps in the native loop (la_lookahead_decode: trie query -> captured graph -> trie update, no
         interpreter in between) until max_length / eos / max_steps.  `seq` = prompt + first generated token, already
         prefilled.  -> (new tokens, dls, edls, fts, qts, finished)."""
@@ -445,7 +437,6 @@ class LlamaVerifyEngine(object):
             p.eos[i] = e
         cap = max(1, min(int(max_steps), max(int(max_length) - len(seq), 0) + 1))
         p.max_steps = cap
-        p.prearm = 1 if prearm else 0
         buf = np.zeros(max(int(max_length), len(seq)) + 32, dtype=np.int32)
         buf[:len(seq)] = seq
         n = C.c_int32(len(seq))

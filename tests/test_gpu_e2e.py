@@ -369,44 +369,3 @@ def test_native_decode_loop_equals_python_loop():
             assert model.lookahead_cache.stats()['n_nodes'] > 0
         assert runs[True] == runs[False], (eos, ml)
         assert runs[True][1][0] == gre[:len(runs[True][1][0])]
-
-
-def test_prearmed_steps_are_identical_and_drain_cleanly():
-    """la_llama_arm: the next step's graph is queued before its input exists.  Same tokens / logits as plain launches,
-    disarm() drains the null step without touching the sequence, reset() and eager steps drain by themselves."""
-    shape, sd = tiny_shape(), _bf16_sd(3)
-    rs = np.random.RandomState(1)
-    prompt = rs.randint(3, shape.vocab, size=70).tolist()
-    trees = []
-    for _ in range(6):
-        n = int(rs.randint(1, 40))
-        _, rows = random_tree(rs, n)
-        trees.append((rs.randint(3, shape.vocab, size=n).astype(np.int32), rows))
-    ref_eng = LlamaVerifyEngine(shape, sd, max_length=512)
-    ref_eng.prefill(prompt)
-    ref = []
-    for ids, rows in trees:
-        ref.append((ref_eng.step(ids, rows), ref_eng.logits()[:len(ids)].clone(), ref_eng.n_keys))
-    eng = LlamaVerifyEngine(shape, sd, max_length=512)
-    eng.prefill(prompt)
-    for i, (ids, rows) in enumerate(trees):
-        eng.step_async(ids, rows, arm_next=True)              # every step leaves one armed graph behind
-        out = eng.step_finish()
-        assert out == ref[i][0] and eng.n_keys == ref[i][2]
-        assert torch.equal(eng.logits()[:len(ids)], ref[i][1])
-    eng.disarm()
-    assert eng.n_keys == ref[-1][2]
-    nxt = np.asarray([5], dtype=np.int32)
-    one = np.array([1], dtype=np.uint64)
-    a, _ = eng.step(nxt, one)
-    b, _ = ref_eng.step(nxt, one)
-    assert a == b and torch.equal(eng.logits()[:1], ref_eng.logits()[:1])
-    eng.step_async(nxt, one, arm_next=True)
-    eng.step_finish()
-    eng.reset()                                               # drains by itself
-    eng.prefill(prompt)
-    eng.step_async(trees[0][0], trees[0][1], arm_next=True)
-    out = eng.step_finish()
-    assert out == ref[0][0]
-    toks, _ = eng.step(nxt, one, eager=True)                  # eager launch drains the armed step first
-    assert len(toks) == 1
