@@ -126,6 +126,7 @@ def main():
     ap.add_argument('--layers', type=int, default=0, help='debug: override layer count (invalidates the metric)')
     ap.add_argument('--pure-random', action='store_true', help='plain N(0,0.02) init (greedy/lookahead drift apart in bf16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--model', choices=['7b', '13b'], default='7b', help='7b = the BASELINE metric; 13b = the config-4 model shape')
     ap.add_argument('--profile-iters', type=int, default=3)
     ap.add_argument('--attn-split', type=int, default=0, help='key splits of the tree-attention kernel (0 = engine default 8)')
     ap.add_argument('--fuse', type=int, default=0, help='engine cfg.fuse bits (opt-in in-kernel norm->GEMM fusion; 0 = separate kernels)')
@@ -149,7 +150,8 @@ def main():
     from painlessinferenceacceleration_amd.lookahead_cache import LookaheadCache
     from painlessinferenceacceleration_amd.modeling_llama import LlamaForCausalLM
 
-    shape = LlamaShape.llama2_7b()
+    shape = LlamaShape.llama2_13b() if args.model == '13b' else LlamaShape.llama2_7b()
+    model_name = 'Llama-2-13B' if args.model == '13b' else 'Llama-2-7B'
     if args.layers:
         shape.n_layers = args.layers
     K, W, P = args.steps, args.warmup, args.prompt_len
@@ -318,7 +320,7 @@ def main():
         'metric': 'accepted_tokens_per_sec', 'value': round(accepted_all / elapsed, 2), 'unit': 'tokens/s',
         'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': 'Llama-2-7B bf16 bs=1/GPU lookahead verify loop, 64-token draft tree / 8-12 noisy branches '
+        'config': {'workload': model_name + ' bf16 bs=1/GPU lookahead verify loop, 64-token draft tree / 8-12 noisy branches '
                                '(hier, decoding_length=64, branch_length=12), synthetic permutation-LM weights (N(0,0.02); o/down std 1e-4; '
                                'lm_head[pi(t)]=embed[t]) for decisive greedy margins, 512-token phrase-bank prompt',
                    'n_layers': shape.n_layers, 'prompt_len': P, 'rho': args.rho, 'copies': args.copies, 'parallelism': f'batch-shard x{world}',
