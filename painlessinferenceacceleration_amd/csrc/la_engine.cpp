@@ -39,7 +39,9 @@ struct la_llama {
     uint64_t* rowmask;
     size_t kv_layer_elems, fresh_layer_elems;
     int n_slots, total_keys;
-    hipGraphExec_t graph_exec, bgraph_exec;
+    hipGraphExec_t graph_exec, bgraph_exec;      // bgraph_exec: scratch slot used while capturing a batch variant
+    hipGraphExec_t bgraphs[4];                  // batch step captured per attention key-split count {8, 4, 2, 1}
+    bool bready[4];
     const int32_t* zc_in;      // pinned host blocks the captured single-sequence graph reads / writes (zero-copy)
     int32_t* zc_out;
     int seq_expected;          // value host_out[LA_ST_SEQ] takes when the last launched step has been published
@@ -184,6 +186,7 @@ extern "C" la_llama* la_llama_create(const la_llama_config* cfg, const la_llama_
     m->graph_exec = m->bgraph_exec = nullptr;
     m->graph_stream = nullptr;
     m->zc_in = nullptr; m->zc_out = nullptr; m->seq_expected = 0;
+    for (int i = 0; i < 4; ++i) { m->bgraphs[i] = nullptr; m->bready[i] = false; }
     return m;
 }
 
@@ -191,6 +194,7 @@ extern "C" void la_llama_destroy(la_llama* m) {
     if (!m) return;
     if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
     if (m->bgraph_exec) (void)hipGraphExecDestroy(m->bgraph_exec);
+    for (int i = 0; i < 4; ++i) if (m->bready[i]) (void)hipGraphExecDestroy(m->bgraphs[i]);
     delete m;
 }
 
@@ -235,7 +239,7 @@ struct Prof {
 
 // enqueue every kernel of one block on `st` (used eagerly, under graph capture, and by the profiler)
 static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = false, const int32_t* zc_in = nullptr,
-                        int32_t* zc_out = nullptr) {
+                        int32_t* zc_out = nullptr, int bsplit = 0) {
     const la_llama_config& c = m->cfg;
     auto P = [&](int cls) { if (pf) pf->mark(cls); };
     P(KC_OTHER);
@@ -266,7 +270,7 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
         P(KC_ATTN);
         if (batch)
             KCHK(lk_tree_attn_b(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
-                                kf, vf, m->rowmask, m->bstate, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, m->nsplit,
+                                kf, vf, m->rowmask, m->bstate, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, bsplit > 0 ? bsplit : m->nsplit,
                                 m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window));
         else
             KCHK(lk_tree_attn(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
@@ -337,10 +341,10 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
 }
 
 static int build_graph(la_llama* m, hipStream_t st, bool batch = false, const int32_t* zc_in = nullptr,
-                       int32_t* zc_out = nullptr) {
+                       int32_t* zc_out = nullptr, int bsplit = 0) {
     hipGraph_t g = nullptr;
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    int rc = enqueue_step(m, st, nullptr, batch, zc_in, zc_out);
+    int rc = enqueue_step(m, st, nullptr, batch, zc_in, zc_out, bsplit);
     hipError_t e = hipStreamEndCapture(st, &g);
     if (rc != LA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
     HIPCHK(e);
@@ -355,12 +359,30 @@ static int bstep(la_llama* m, void* stream, const int32_t* host_in, int32_t* hos
     if (!m || !host_in) return LA_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipMemcpyAsync(m->bin, host_in, LA_BIN_WORDS * sizeof(int), hipMemcpyHostToDevice, st));
+    // The attention grid is (heads, key splits, slots): with many active slots fewer key splits fill the chip just as well
+    // and leave fewer partials to merge.  splits = configured count / active slots, as a power of two; one captured graph
+    // per value.
+    unsigned seen = 0;
+    const int T = host_in[LA_BIN_T];
+    for (int r = 0; r < T && r < LA_TREE_MAX; ++r) {
+        const int sl = host_in[LA_BIN_SEQ + r];
+        if (sl >= 0 && sl < LA_MAX_SEQ) seen |= 1u << sl;
+    }
+    const int active = __builtin_popcount(seen) > 0 ? __builtin_popcount(seen) : 1;
+    int v = 0, bsplit = m->nsplit;
+    const int target = m->nsplit / active > 1 ? m->nsplit / active : 1;
+    while (v < 3 && bsplit > target && bsplit % 2 == 0) { bsplit /= 2; ++v; }
     if (eager) {
-        int rc = enqueue_step(m, st, nullptr, true);
+        int rc = enqueue_step(m, st, nullptr, true, nullptr, nullptr, bsplit);
         if (rc != LA_OK) return rc;
     } else {
-        if (!m->bgraph_ready) { int rc = build_graph(m, st, true); if (rc != LA_OK) return rc; }
-        HIPCHK(hipGraphLaunch(m->bgraph_exec, st));
+        if (!m->bready[v]) {
+            int rc = build_graph(m, st, true, nullptr, nullptr, bsplit);
+            if (rc != LA_OK) return rc;
+            m->bgraphs[v] = m->bgraph_exec; m->bgraph_exec = nullptr; m->bgraph_ready = false;
+            m->bready[v] = true;
+        }
+        HIPCHK(hipGraphLaunch(m->bgraphs[v], st));
     }
     if (host_out)
         HIPCHK(hipMemcpyAsync(host_out, m->bstate, LA_BST_DST * sizeof(int), hipMemcpyDeviceToHost, st));

@@ -46,6 +46,9 @@ def main():
     t0 = time.time()
     truth = model.greedy_search(ids, P + n_truth, eos_token_id=None)[:, P:].tolist()
     print(f'[setup] batch greedy of {len(prompts)} x {n_truth} tokens: {time.time() - t0:.1f}s', file=sys.stderr)
+    import gc
+    gc.collect()
+    gc.freeze()          # see bench.py: a generation-2 collection stalls the loop for tens of ms
     rows_out = []
     for B in Bs:
         cache = LookaheadCache(eos_ids=[None])
