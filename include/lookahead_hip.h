@@ -276,10 +276,9 @@ int la_llama_reset(la_llama* m, void* stream);
  * host_out directly (zero-copy), there are no copy commands around the graph.  Call la_llama_wait before reading host_out
  * (it polls the completion word LA_ST_SEQ; hipStreamSynchronize alone is sufficient too).  Passing other addresses than
  * in the previous call re-captures the graph.
- * Captured graph
- * (embed -> L x {qkv, rope+kv, tree-attn, o, norm, gate/up, down, norm} -> lm_head+argmax ->
- * accept scan -> kv commit), d2h of the first 8+64 state words into host_out.  Asynchronous on
- * `stream`; the caller synchronises before reading host_out.  host_in/host_out should be pinned. */
+ * The captured graph: build inputs -> embed -> L x {qkv (+RoPE, fresh K/V), tree attention, o, norm, gate/up, down, norm}
+ * -> lm_head + argmax -> accept scan -> kv commit -> publish (first LA_ST_OUTTOK+64 state words into host_out).
+ * Asynchronous on `stream`. */
 int la_llama_step(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);
 /* Wait for the step launched last by la_llama_step (spins on host_out[LA_ST_SEQ], falls back to a stream sync). */
 int la_llama_wait(la_llama* m, void* stream);
@@ -287,7 +286,8 @@ int la_llama_wait(la_llama* m, void* stream);
  * host_in[LA_IN_MODE] = 2 (forward only: no accept walk, nothing committed), read the logits rows the walk needs
  * (la_llama_buffer(m, 0)), then commit the accepted tree rows rows[0..n) (rows[0] = 0, the root).  Synchronous. */
 int la_llama_commit(la_llama* m, void* stream, const int32_t* rows, int n, int32_t* host_out);
-/* Same work launched kernel-by-kernel (no graph): for profiling and as a cross-check. */
+/* Same work launched kernel-by-kernel (no graph), with copy commands around it (host blocks need not be pinned; wait with
+ * hipStreamSynchronize): for profiling and as a cross-check. */
 int la_llama_step_eager(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);
 /* Device addresses of internal buffers for parity tests: 0 logits bf16 [64][vocab], 1 state,
  * 2 hidden h bf16 [64][hidden], 3 final normed x (packed), 4/5 main K/V cache, 6/7 fresh K/V tiles,
