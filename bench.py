@@ -145,9 +145,16 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
+        # test-only knobs (1-GPU box): BENCH_DIST_BACKEND=gloo + BENCH_SHARE_GPU=1 run N ranks through the same control
+        # flow on ONE device, with the collectives on host tensors; the measured configuration is always nccl (= RCCL)
+        backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    dev = f'cuda:{local_rank}'
+    dev = 'cuda:0' if os.environ.get('BENCH_SHARE_GPU') else f'cuda:{local_rank}'
+    comm_dev = dev if os.environ.get('BENCH_DIST_BACKEND', 'nccl') == 'nccl' else 'cpu'
     torch.cuda.set_device(dev)
 
     from painlessinferenceacceleration_amd.llama_engine import LlamaShape
@@ -175,7 +182,7 @@ def main():
     cache = LookaheadCache(eos_ids=[None])
     model.lookahead_cache = cache
     if dist_on:                                  # every replica is warmed with every rank's (noisy) answers
-        tt = torch.tensor(truth, dtype=torch.int32, device=dev)
+        tt = torch.tensor(truth, dtype=torch.int32, device=comm_dev)
         allt = [torch.empty_like(tt) for _ in range(world)]
         dist.all_gather(allt, tt)
         truths = [x.cpu().tolist() for x in allt]
@@ -195,7 +202,7 @@ def main():
     gather = None
     if dist_on:
         from painlessinferenceacceleration_amd.distributed import AcceptedTokenGather
-        gather = AcceptedTokenGather(dev)
+        gather = AcceptedTokenGather(comm_dev)
     pending = [False]
     edls, dls, qts = [], [], []
 
@@ -253,7 +260,7 @@ def main():
     elapsed = time.time() - t0
     accepted = int(sum(edls[n0:]))
     if dist_on:
-        v = torch.tensor([elapsed, float(accepted)], dtype=torch.float64, device=dev)
+        v = torch.tensor([elapsed, float(accepted)], dtype=torch.float64, device=comm_dev)
         mx = v.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = v.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         elapsed, accepted_all = float(mx[0]), float(sm[1])
