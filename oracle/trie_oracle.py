@@ -249,17 +249,99 @@ class TrieOracle(object):
             return token_ids[-1:], np.ones((1, 1), dtype=np.int64), [0, 0]
         return out
 
+    # ---------------------------------------------------------------- one_get / get_one_branch (:171-222, 490-517)
+    def _one_branch(self, rec, query, max_length, mode, idx):
+        """Greedy single chain below the matched prefix: at every level the live child with the largest key, first child
+        winning ties (strict '>'); keys: input/output mode = that frequency, mix = 10000 * output + input (the reference
+        names them the other way round, :188-191, the arithmetic is this)."""
+        parent, matched = self._descend(rec, query, mode, idx)
+        if parent is None or not self.kids[parent]:
+            return [query[-1] if len(query) > 0 else self.tok[rec[0]]], np.ones((1, 1), dtype=np.int64), [0, 0]
+        ids = [matched or self.tok[rec[0]]]
+        length = 0
+        while self.kids[parent] and length < max_length:
+            best, best_key = None, 0.0
+            for ch in self.kids[parent]:
+                fi, fo = self._freq(ch, idx), self._freq(ch, -1)
+                if mode == 'mix':
+                    key = 10000 * fo + fi if (fi > 0 or fo > 0) else 0.0
+                elif mode == 'input':
+                    key = fi
+                else:
+                    key = fo
+                if key > 0 and key > best_key:
+                    best, best_key = ch, key
+            if best is None:
+                break
+            ids.append(self.tok[best])
+            parent = best
+            length += 1
+        return ids, np.tril(np.ones((length + 1, length + 1), dtype=np.int64), 0), [length]
+
+    def one_get(self, token_ids, decoding_length=64, branch_length=8, min_input_size=0, min_output_size=0, mode='mix',
+                idx=0):
+        assert mode in ('input', 'output', 'mix')
+        token_ids = list(token_ids)
+        mask = np.ones((1, 1), dtype=np.int64)
+        if decoding_length <= 1 or branch_length == 0:
+            return token_ids[-1:], mask, []
+        ids, sizes = None, [0, 0]
+        for i, t in enumerate(token_ids):
+            rec = self.tree_of.get(t)
+            if rec is None:
+                continue
+            rest = token_ids[i + 1:]
+            if t in self.stop_words and len(rest) == 0:
+                continue
+            ids, mask, sizes = self._one_branch(rec, rest, branch_length, mode, idx)
+            if len(ids) >= branch_length // 2:
+                break
+        if ids is None:
+            ids = token_ids[-1:]
+        return ids, mask, sizes
+
+    # ---------------------------------------------------------------- par_get (:441-488)
+    def par_get(self, token_ids, decoding_length=16, branch_length=8, min_input_size=0, min_output_size=0, mode='mix',
+                idx=0):
+        """The hierarchical draft re-laid as independent root-to-leaf chains: walking rows from last to first, a row's
+        ancestor set is kept unless a kept set already contains it; kept paths are concatenated (cut at the draft budget)
+        under a mask in which each chain sees the root and itself."""
+        out_ids, masks, _ = self.hier_get(token_ids, decoding_length=decoding_length, branch_length=branch_length,
+                                          min_input_size=min_input_size, min_output_size=min_output_size, mode=mode, idx=idx)
+        budget = len(out_ids) - 1
+        kept = []
+        for row in range(budget, 0, -1):
+            members = set(np.nonzero(masks[row, 1:])[0].tolist())
+            if not any(len(members - other) == 0 for other in kept):
+                kept.append(members)
+        kept.reverse()
+        ids, spans, used = [out_ids[0]], [], 0
+        for members in kept:
+            cols = sorted(members)[:budget - used]
+            used += len(cols)
+            spans.append(len(cols))
+            ids.extend(out_ids[c + 1] for c in cols)
+            if used >= budget:
+                break
+        m = np.tril(np.ones((used + 1, used + 1)), 0)
+        start = 1
+        for n in spans:
+            m[start:start + n, 1:start] = 0
+            start += n
+        return ids, m, [start - 1]
+
     # ---------------------------------------------------------------- bat_get (:519-561)
     def bat_get(self, token_id_list, decoding_length=64, branch_length=8, decoding_cursors=None, mode='output',
                 indices=None, decoding_mode='hier'):
         """Per-sample hierarchical drafts with the budget `decoding_length // bs` (the caller has already divided
         once, :534 divides again), right-padded with id 0, masks laid on a [bs, W, max_cur-min_cur+W] canvas at the
         sample's cursor offset; every column up to and including the sample's own root column is forced to 1."""
-        assert decoding_mode == 'hier', 'the oracle restates the hierarchical mode only'
+        assert decoding_mode in ('hier', 'one')
+        getter = self.hier_get if decoding_mode == 'hier' else self.one_get
         bs = len(token_id_list)
         assert bs == len(decoding_cursors) == len(indices)
         per = decoding_length // bs
-        got = [self.hier_get(q, decoding_length=per, branch_length=branch_length, min_input_size=0,
+        got = [getter(q, decoding_length=per, branch_length=branch_length, min_input_size=0,
                              min_output_size=max(per // 2, 1), mode=mode, idx=indices[i])
                for i, q in enumerate(token_id_list)]
         lo, hi = min(decoding_cursors), max(decoding_cursors)

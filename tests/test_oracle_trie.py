@@ -15,7 +15,7 @@ def test_oracle_replays_reference_trace(path):
     init = trace['init']
     cache = TrieOracle(eos_ids=init['eos_ids'], stop_words={w: 1 for w in init['stop_words']},
                        max_node=init['max_node'], max_output_node=init['max_output_node'])
-    n = tr.replay(cache, trace, has_batch=True, has_par=False, has_one=False)
+    n = tr.replay(cache, trace, has_batch=True, has_par=True, has_one=True)
     assert n > 50
     assert cache.n_trees() == trace['final']['n_trees']
     assert cache.n_nodes() == trace['final']['n_nodes']
