@@ -105,112 +105,111 @@ class Benchmark(object):
             n = max(len(ans), len(output_ids), 1)
             return sum(1 for a, b in zip(output_ids, ans) if a == b) / float(n)
 
+    def _run_cell(self, queries, answers, batch_size, gen_kw):
+        """One (decoding_length, branch_length) cell: every batch of queries through chat(); returns the accumulated counters."""
+        acc = {'tok_in': 0, 'tok_out': 0, 'draft': [], 'accepted': [], 'prefill_s': [], 'step_s': [], 'match': []}
+        started = time.time()
+        for first in range(0, len(queries) - batch_size + 1, batch_size):
+            group = queries[first:first + batch_size]
+            _, in_ids, out_ids, out_texts, info = self.chat(group, **gen_kw)
+            acc['tok_in'] += sum(map(len, in_ids))
+            acc['tok_out'] += sum(map(len, out_ids))
+            n = len(group)
+            if answers is not None:
+                acc['match'] += [self._score(out_ids[i], out_texts[i], answers[first + i]) for i in range(n)]
+            # the first `n` entries of dls / edls belong to the prefill step of each sample (benchmark.py:302-305)
+            acc['draft'] += list(info.get('dls', []))[n:]
+            acc['accepted'] += list(info.get('edls', []))[n:]
+            step_times = list(info.get('fts', [0]))
+            acc['prefill_s'].append(step_times[0])
+            acc['step_s'] += step_times[1:]
+        acc['wall_s'] = time.time() - started
+        return acc
+
     def perf_check(self, queries, answers=None, warmup_ids=None, max_new_tokens=256, sizes=(32, 64), lens=(4, 8, 12),
                    decoding_mode='hier', batch_size=1, max_node_rate=16, max_query_length=2):
-        wc = len(warmup_ids) if warmup_ids is not None else 0
-        print(f'\nmode:{decoding_mode} bs:{batch_size} queries:{len(queries)} warmup:{wc} sizes:{sizes} lens:{lens}')
-        if batch_size > 1:
+        """benchmarks/benchmark.py:243-351: one log line per (decoding_length, branch_length) cell; -> {cell: tokens/s}."""
+        n_warm = 0 if warmup_ids is None else len(warmup_ids)
+        print(f'\nmode:{decoding_mode} bs:{batch_size} queries:{len(queries)} warmup:{n_warm} sizes:{sizes} lens:{lens}')
+        if batch_size > 1:                               # batches of similar length (:249-250)
             order = sorted(range(len(queries)), key=lambda i: len(queries[i]))
             queries = [queries[i] for i in order]
-            answers = [answers[i] for i in order] if answers is not None else None
-        speeds, outputs = [], {}
-        cache = self.model.lookahead_cache
-        for decoding_length in sizes:
-            for branch_length in lens:
-                if decoding_length < branch_length * batch_size:
+            answers = None if answers is None else [answers[i] for i in order]
+        trie = self.model.lookahead_cache
+        mean = lambda xs: sum(xs) / max(len(xs), 1)      # noqa: E731
+        result = {}
+        for dl in sizes:
+            for bl in lens:
+                if dl < bl * batch_size:
                     continue
-                use_lookahead = decoding_length > 1 and branch_length > 0
-                in_token = out_token = 0
-                dls, edls, pts, gts, scores, times = [], [], [], [], [], []
-                if use_lookahead:
-                    cache.fresh()
-                    cache.max_output_node = max_node_rate * decoding_length
-                    cache.max_node = 2 * max_node_rate * decoding_length
+                lookahead_on = dl > 1 and bl > 0
+                if lookahead_on:                         # fresh trie per cell, limits scaled with the draft size (:268-274)
+                    trie.fresh()
+                    trie.max_output_node = max_node_rate * dl
+                    trie.max_node = 2 * max_node_rate * dl
                     if warmup_ids is not None:
-                        self.warm_up(warmup_ids, branch_length=branch_length, eop=self.eop)
+                        self.warm_up(warmup_ids, branch_length=bl, eop=self.eop)
                 if torch.cuda.is_available():
                     torch.cuda.reset_peak_memory_stats(device=None)
-                ts = time.time()
-                for k in range(len(queries) // batch_size):
-                    qs_ = queries[k * batch_size:(k + 1) * batch_size]
-                    ts_ = time.time()
-                    _, input_id_list, output_id_list, output_texts, kwargs = self.chat(
-                        qs_, max_new_tokens=max_new_tokens, use_lookahead=use_lookahead, decoding_length=decoding_length,
-                        branch_length=branch_length, decoding_mode=decoding_mode, max_query_length=max_query_length)
-                    times.append(time.time() - ts_)
-                    in_token += sum(len(x) for x in input_id_list)
-                    out_token += sum(len(x) for x in output_id_list)
-                    bs = len(qs_)
-                    if answers is not None:
-                        for i in range(bs):
-                            scores.append(self._score(output_id_list[i], output_texts[i], answers[k * batch_size + i]))
-                    dls_, edls_ = kwargs.get('dls', []), kwargs.get('edls', [])
-                    dls.extend(dls_[bs:] if len(dls_) > bs else [])
-                    edls.extend(edls_[bs:] if len(edls_) > bs else [])
-                    pts.append(kwargs.get('fts', [0])[0])
-                    gts.extend(kwargs.get('fts', [0])[1:])
-                n_repeat = max(len(queries), 1)
-                t = (time.time() - ts) / n_repeat
-                in_token /= n_repeat
-                out_token /= n_repeat
-                speed = out_token / max(t, 1e-9)
-                speeds.append(speed)
-                outputs[(decoding_length, branch_length)] = speed
-                dl = sum(dls) / max(len(dls), 1)
-                edl = sum(edls) / max(len(edls), 1)
-                pt = sum(pts) / max(len(pts), 1)
-                gt = sum(gts) / max(len(gts), 1)
+                acc = self._run_cell(queries, answers, batch_size,
+                                     dict(max_new_tokens=max_new_tokens, use_lookahead=lookahead_on, decoding_length=dl,
+                                          branch_length=bl, decoding_mode=decoding_mode, max_query_length=max_query_length))
+                per_query = max(len(queries), 1)
+                t = acc['wall_s'] / per_query
+                tokens_out = acc['tok_out'] / per_query
+                speed = tokens_out / max(t, 1e-9)
+                result[(dl, bl)] = speed
                 mem = torch.cuda.max_memory_allocated() / 1e9 if torch.cuda.is_available() else 0.0
-                score = sum(scores) / max(len(scores), 1.0)
-                log_str = (f'mode:{decoding_mode} bs:{batch_size} decoding_length:{decoding_length} '
-                           f'branch_length:{branch_length} query:{len(queries)} warmup:{wc} input:{in_token:.1f} '
-                           f'output:{out_token:.1f} edl:{edl:.3f}/{dl:.3f}/{pt:.3f}/{gt:.3f} time:{t:.3f} '
-                           f'speed:{speed:.1f} mem:{mem:.3f} acc:{score:.4f}')
+                log_str = (f'mode:{decoding_mode} bs:{batch_size} decoding_length:{dl} branch_length:{bl} '
+                           f'query:{len(queries)} warmup:{n_warm} input:{acc["tok_in"] / per_query:.1f} output:{tokens_out:.1f} '
+                           f'edl:{mean(acc["accepted"]):.3f}/{mean(acc["draft"]):.3f}/{mean(acc["prefill_s"]):.3f}/'
+                           f'{mean(acc["step_s"]):.3f} time:{t:.3f} speed:{speed:.1f} mem:{mem:.3f} acc:{mean(acc["match"]):.4f}')
                 print(log_str)
                 if self.logger is not None:
                     self.logger.write(log_str + '\n')
                     self.logger.flush()
-        return outputs
+        return result
 
     # ------------------------------------------------------------------------------------------- perf_check_trie
     @staticmethod
     def perf_check_trie(lookahead_cache, warmup_ids, input_ids, output_ids, max_node_rate=16, decoding_length=64,
                         branch_length=24, edl=8, verbose=True):
-        """Trie-only timing loop of benchmark.py:353-395 (put per prompt, bat_get every `edl` output tokens, stream_put of
-        the output).  Works on ANY object with the LookaheadCache surface, so the native trie and the reference's Python
-        trie can be timed side by side.  -> dict of the printed numbers (seconds)."""
-        lookahead_cache.max_output_node = decoding_length * max_node_rate
-        lookahead_cache.fresh()
-        for ids_ in warmup_ids:
-            lookahead_cache.put(list(ids_), branch_length=branch_length + 1, mode='output', idx=0, final=False)
+        """Trie-only timing loop of benchmark.py:353-395: per sample one `put` of the prompt, one `bat_get` every `edl`
+        output tokens, then the output streamed in with `stream_put`.  Works on ANY object with the LookaheadCache surface,
+        so the native trie and the reference's Python trie can be timed side by side.  -> dict (seconds / counts)."""
+        trie = lookahead_cache
+        trie.max_output_node = decoding_length * max_node_rate
+        trie.fresh()
+        for seq in warmup_ids:
+            trie.put(list(seq), branch_length=branch_length + 1, mode='output', idx=0, final=False)
+        clock = {'put': 0.0, 'get': 0.0}
+        n_put = n_get = 0
+
+        def timed(kind, fn, *a, **kw):
+            t0 = time.time()
+            fn(*a, **kw)
+            clock[kind] += time.time() - t0
+
+        for prompt, reply in zip(input_ids, output_ids):
+            prompt, reply = list(prompt), list(reply)
+            n_put += len(prompt) + len(reply)
+            timed('put', trie.put, prompt, branch_length=branch_length + 1, mode='input', idx=0, final=False)
+            starts = range(0, len(reply) - 1, edl)
+            for j in starts:
+                n_get += 1
+                timed('get', trie.bat_get, [reply[j:j + 2]], decoding_length=decoding_length, branch_length=branch_length,
+                      decoding_cursors=[j], mode='mix', indices=[0], decoding_mode='hier')
+            for j in starts:
+                timed('put', trie.stream_put, reply[j:j + edl], branch_length=branch_length + 1, mode='output', idx=0,
+                      final=False)
+            timed('put', trie.stream_put, [], branch_length=branch_length + 1, mode='output', idx=0, final=True)
         count = len(input_ids)
-        put_count = get_count = 0
-        put_time = get_time = 0.0
-        for i in range(count):
-            in_ids, out_ids = list(input_ids[i]), list(output_ids[i])
-            put_count += len(in_ids)
-            ts = time.time()
-            lookahead_cache.put(in_ids, branch_length=branch_length + 1, mode='input', idx=0, final=False)
-            put_time += time.time() - ts
-            ts = time.time()
-            for j in range(0, len(out_ids) - 1, edl):
-                get_count += 1
-                lookahead_cache.bat_get([out_ids[j:j + 2]], decoding_length=decoding_length, branch_length=branch_length,
-                                        decoding_cursors=[j], mode='mix', indices=[0], decoding_mode='hier')
-            get_time += time.time() - ts
-            put_count += len(out_ids)
-            ts = time.time()
-            for j in range(0, len(out_ids) - 1, edl):
-                lookahead_cache.stream_put(out_ids[j:j + edl], branch_length=branch_length + 1, mode='output', idx=0,
-                                           final=False)
-            lookahead_cache.stream_put([], branch_length=branch_length + 1, mode='output', idx=0, final=True)
-            put_time += time.time() - ts
-        res = {'samples': count, 'put_tokens': put_count, 'put_s': put_time, 'put_us_per_token': 1e6 * put_time / max(put_count, 1),
-               'gets': get_count, 'get_s': get_time, 'get_ms_per_query': 1e3 * get_time / max(get_count, 1)}
+        res = {'samples': count, 'put_tokens': n_put, 'put_s': clock['put'], 'put_us_per_token': 1e6 * clock['put'] / max(n_put, 1),
+               'gets': n_get, 'get_s': clock['get'], 'get_ms_per_query': 1e3 * clock['get'] / max(n_get, 1)}
         if verbose:
             print(f'\nparam:{max_node_rate}/{decoding_length}/{branch_length} sample:{count} '
-                  f'put:{put_count}/{put_time:.2f}/{res["put_us_per_token"] / 1e3:.2f}/{1e3 * put_time / max(count, 1):.2f} '
-                  f'get:{get_count}/{get_time:.2f}/{res["get_ms_per_query"]:.2f}/{1e3 * get_time / max(count, 1):.2f}\n')
+                  f'put:{n_put}/{clock["put"]:.2f}/{res["put_us_per_token"] / 1e3:.2f}/{1e3 * clock["put"] / max(count, 1):.2f} '
+                  f'get:{n_get}/{clock["get"]:.2f}/{res["get_ms_per_query"]:.2f}/{1e3 * clock["get"] / max(count, 1):.2f}\n')
         return res
 
     def grid_search(self, queries, warmup_ids=None, sizes=(16, 32, 64), lens=(4, 8, 12, 16), **kw):
