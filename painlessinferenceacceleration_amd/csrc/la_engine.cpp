@@ -24,6 +24,11 @@ struct la_llama {
     std::vector<const void*> ex_gateup, ex_down;     // [n_layers][n_experts] copies of the caller's pointer arrays
     uint16_t* moe_acc;
     float* route_w;
+    // merged expert launches (all experts of a layer in one grid) when every layer's expert images are equally spaced
+    bool ex_merged;
+    std::vector<long> ex_gu_stride, ex_dn_stride;     // per layer, in bf16 elements
+    uint16_t* act_ex;       // [E][64][ffn] packed SwiGLU outputs
+    float* slabs_ex;        // [E][down_ks][64][hidden]
     int* fuse_cnt;      // [2 * n_layers] hand-over counters of the fused norm->GEMM launches (zeroed every step)
     int fuse;           // bit 0: post-attention norm -> gate/up GEMM, bit 1: input norm of layer l>0 -> QKV GEMM
     la_llama_weights w;
@@ -130,6 +135,8 @@ static size_t carve(la_llama* m, char* base) {
     m->bstate = cv.take<int>(LA_BST_WORDS);
     m->bin = cv.take<int>(LA_BIN_WORDS);
     m->moe_acc = cv.take<uint16_t>(c.n_experts > 0 ? (size_t)64 * c.hidden : 8);
+    m->act_ex = cv.take<uint16_t>(c.n_experts > 0 ? (size_t)c.n_experts * 64 * c.ffn : 8);
+    m->slabs_ex = cv.take<float>(c.n_experts > 0 ? (size_t)c.n_experts * m->down_ks * 64 * c.hidden : 8);
     m->fuse_cnt = cv.take<int>((size_t)2 * c.n_layers + 8);
     m->route_w = cv.take<float>((size_t)(c.n_experts > 0 ? c.n_layers : 1) * 64 * LA_MOE_MAX_E);   // kept per layer (parity tests)
     return align_up(cv.off, 256);
@@ -177,6 +184,21 @@ extern "C" la_llama* la_llama_create(const la_llama_config* cfg, const la_llama_
             if (!L.router || !L.ex_gateup || !L.ex_down) { la_set_error("MoE layer without router/expert weights"); delete m; return nullptr; }
             for (int e = 0; e < cfg->n_experts; ++e) { m->ex_gateup.push_back(L.ex_gateup[e]); m->ex_down.push_back(L.ex_down[e]); }
         }
+        // equally spaced expert images (the Python engine packs them into one buffer per layer) -> one launch per stage
+        m->ex_merged = true;
+        for (int l = 0; l < cfg->n_layers && m->ex_merged; ++l) {
+            const char* g0 = (const char*)m->ex_gateup[(size_t)l * cfg->n_experts];
+            const char* d0 = (const char*)m->ex_down[(size_t)l * cfg->n_experts];
+            long gs = cfg->n_experts > 1 ? (long)((const char*)m->ex_gateup[(size_t)l * cfg->n_experts + 1] - g0) : 0;
+            long ds = cfg->n_experts > 1 ? (long)((const char*)m->ex_down[(size_t)l * cfg->n_experts + 1] - d0) : 0;
+            for (int e = 0; e < cfg->n_experts; ++e) {
+                if ((const char*)m->ex_gateup[(size_t)l * cfg->n_experts + e] != g0 + (long)e * gs) m->ex_merged = false;
+                if ((const char*)m->ex_down[(size_t)l * cfg->n_experts + e] != d0 + (long)e * ds) m->ex_merged = false;
+            }
+            if (gs < 0 || ds < 0 || (gs & 15) || (ds & 15)) m->ex_merged = false;
+            m->ex_gu_stride.push_back(gs / 2);
+            m->ex_dn_stride.push_back(ds / 2);
+        }
     }
     resolve_cfg(m);
     size_t need = carve(m, (char*)ws);
@@ -186,6 +208,7 @@ extern "C" la_llama* la_llama_create(const la_llama_config* cfg, const la_llama_
     m->graph_exec = m->bgraph_exec = nullptr;
     m->graph_stream = nullptr;
     m->zc_in = nullptr; m->zc_out = nullptr; m->seq_expected = 0;
+    if (cfg->n_experts == 0) m->ex_merged = false;
     for (int i = 0; i < 4; ++i) { m->bgraphs[i] = nullptr; m->bready[i] = false; }
     return m;
 }
@@ -286,6 +309,25 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
             float* rw = m->route_w + (size_t)l * 64 * LA_MOE_MAX_E;
             KCHK(lk_resid_norm_router(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp, L.router, c.n_experts,
                                       c.top_k, rw, batch ? m->bin + LA_BIN_T : m->state + LA_ST_T, cf));
+            if (m->ex_merged) {
+                // one launch per stage for ALL experts: workgroups of experts nobody routes to return at once, the others
+                // keep the chip full across expert boundaries (no per-expert ramp / drain, no empty launches)
+                const void* wgu0 = m->ex_gateup[(size_t)l * c.n_experts];
+                const void* wdn0 = m->ex_down[(size_t)l * c.n_experts];
+                const long act_stride = (long)64 * c.ffn, slab_stride = (long)m->down_ks * 64 * c.hidden;
+                P(KC_GATEUP);
+                if (c.balanced_wg[1] > 0)
+                    KCHK(lk_gemm64r_swiglu_ex(st, wgu0, m->ex_gu_stride[l], m->xp, c.ffn, c.hidden, c.balanced_wg[1], m->act_ex,
+                                              act_stride, rw, c.n_experts));
+                else
+                    KCHK(lk_gemm64_swiglu_ex(st, wgu0, m->ex_gu_stride[l], m->xp, c.ffn, c.hidden, m->act_ex, act_stride, rw,
+                                             c.n_experts));
+                P(KC_DOWN);
+                KCHK(lk_gemm64_slab_ex(st, wdn0, m->ex_dn_stride[l], m->act_ex, act_stride, c.hidden, c.ffn, m->down_rb, m->down_ks,
+                                       m->slabs_ex, slab_stride, rw, c.n_experts));
+                P(KC_OTHER);
+                KCHK(lk_moe_accum_all(st, m->slabs_ex, slab_stride, m->down_ks, rw, c.n_experts, c.hidden, m->moe_acc));
+            } else
             for (int e = 0; e < c.n_experts; ++e) {
                 const float* col = rw + e;
                 const void* wgu = m->ex_gateup[(size_t)l * c.n_experts + e];

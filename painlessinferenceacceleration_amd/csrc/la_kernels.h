@@ -58,6 +58,13 @@ int lk_accept_scan_b(hipStream_t st, const int* in, const int* ids, const uint64
                      int slot_keys);
 int lk_kv_commit_b(hipStream_t st, const void* kfresh, const void* vfresh, void* kmain, void* vmain, const int* bstate,
                    int n_layers, int nkv, int total_keys);
+int lk_gemm64r_swiglu_ex(hipStream_t st, const void* wp0, long w_stride, const void* xp, int F, int K, int n_wg, void* act0,
+                         long act_stride, const float* route_w, int E);
+int lk_gemm64_swiglu_ex(hipStream_t st, const void* wp0, long w_stride, const void* xp, int F, int K, void* act0, long act_stride,
+                        const float* route_w, int E);
+int lk_gemm64_slab_ex(hipStream_t st, const void* wp0, long w_stride, const void* xp0, long x_stride, int N, int K, int rbv, int ksplit,
+                      float* slabs0, long slab_stride, const float* route_w, int E);
+int lk_moe_accum_all(hipStream_t st, const float* slabs0, long slab_stride, int n_slabs, const float* route_w, int E, int hidden, void* acc);
 int lk_publish(hipStream_t st, int* state, int* host_out);
 int lk_accept_scan(hipStream_t st, const int* ids, const uint64_t* rowmask, int* state);
 int lk_kv_commit(hipStream_t st, const void* kfresh, const void* vfresh, void* kmain, void* vmain, const int* state,

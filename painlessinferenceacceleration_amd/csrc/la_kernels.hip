@@ -267,6 +267,10 @@ struct GemmArgs {
     // mixture-of-experts: routing weights of this expert, one float per token row at stride LA_MOE_MAX_E; the whole
     // launch returns at once when no row routes to the expert (its weights are then never read)
     const float* route_col;
+    // merged expert launch (ex_on): one grid dimension enumerates the experts of a MoE layer, whose weight images, SwiGLU
+    // outputs and split-K slabs are equally spaced; expert e uses route_col + e and returns at once when no row routes to it
+    int ex_on;
+    long ex_w, ex_x, ex_act, ex_slab;      // element strides per expert (weights, x operand, act_xp, slabs)
 };
 
 __device__ __forceinline__ bool expert_unused(const float* route_col) {
@@ -276,7 +280,8 @@ __device__ __forceinline__ bool expert_unused(const float* route_col) {
 template <int RB, int EPI, int D, int NW>
 __global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
     __shared__ float red[NW][RB * 2 * 16 * 64];
-    if (expert_unused(a.route_col)) return;
+    const int ex = a.ex_on ? (int)blockIdx.z : 0;
+    if (expert_unused(a.route_col ? a.route_col + ex : nullptr)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nb0 = blockIdx.x * RB;
@@ -292,8 +297,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
 
     // integer offsets from the kernel-argument bases (not mutated pointers) keep the loads in the global
     // address space: a loop-carried pointer degrades to flat_load, which ties vmcnt and lgkmcnt together
-    const bf16x8* __restrict__ wbase = (const bf16x8*)a.wp;
-    const bf16x8* __restrict__ xbase = (const bf16x8*)a.xp;
+    const bf16x8* __restrict__ wbase = (const bf16x8*)(a.wp + (size_t)ex * a.ex_w);
+    const bf16x8* __restrict__ xbase = (const bf16x8*)(a.xp + (size_t)ex * a.ex_x);
     unsigned woff[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) woff[rb] = (unsigned)(((nb0 + rb) * a.K16 + wb) * 64 + lane);
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
             }
     const int tok = tb * 32 + tl;
     if constexpr (EPI == EPI_SLAB) {
-        float* o = a.slabs + (size_t)ks * LA_TB * a.N;
+        float* o = a.slabs + (size_t)ex * a.ex_slab + (size_t)ks * LA_TB * a.N;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
                 pk[j] = (short)f2bf(sv * uv);
             }
             const int f = jb * 32 + 8 * (g0 + gg) + 4 * hh;    // 4 consecutive features f..f+3
-            *(bf16x4*)(a.act_xp + xp_offset(tok, f)) = pk;
+            *(bf16x4*)(a.act_xp + (size_t)ex * a.ex_act + xp_offset(tok, f)) = pk;
         }
     } else if constexpr (EPI == EPI_QKV) {
         // Workgroup b owns head slot b>>1, half u=b&1: row-block 0 = dims 32u+[0,32), row-block 1 = the RoPE
@@ -511,7 +516,8 @@ template <int RB, int EPI, int D, int NW, int NSF = 0>
 __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
     extern __shared__ __attribute__((aligned(16))) float redr[];      // [NW][RB][16][64]
     const GemmArgs& a = ra.g;
-    if (expert_unused(a.route_col)) return;
+    const int ex = a.ex_on ? (int)blockIdx.y : 0;
+    if (expert_unused(a.route_col ? a.route_col + ex : nullptr)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nb0 = blockIdx.x * RB;
@@ -520,7 +526,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
     const int cnt = q + (wave < r ? 1 : 0);
     const int ngroups = (cnt + D - 1) / D;
     const int last_valid = cnt - (ngroups - 1) * D;
-    const bf16x8* __restrict__ wbase = (const bf16x8*)a.wp;
+    const bf16x8* __restrict__ wbase = (const bf16x8*)(a.wp + (size_t)ex * a.ex_w);
     typedef const bf16x8* __restrict__ xptr_r;
     typedef const bf16x8* xptr_n;                                       // fused producers write g.xp inside this kernel
     typename std::conditional<(NSF > 0), xptr_n, xptr_r>::type xbase = (const bf16x8*)a.xp;
@@ -641,7 +647,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
                     const float gv = bfr(total(qq, gi, j)), uv = bfr(total(qq + RB / 2, gi, j));
                     const float sv = bfr(gv / (1.0f + expf(-gv)));
                     const int feat = ra.R * blockIdx.x + 32 * qq + f;
-                    a.act_xp[xp_offset(tok, feat)] = f2bf(sv * uv);
+                    a.act_xp[(size_t)ex * a.ex_act + xp_offset(tok, feat)] = f2bf(sv * uv);
                 }
             }
         } else if constexpr (EPI == EPI_QKV) {
@@ -1282,6 +1288,42 @@ __global__ __launch_bounds__(256) void k_kv_commit_b(const bf16_t* __restrict__ 
     }
 }
 
+// all experts of a layer in one launch: same arithmetic and the same expert order as k_moe_accum called E times
+template <int NS>
+__global__ __launch_bounds__(256) void k_moe_accum_all(const float* __restrict__ slabs, long ex_slab, const float* __restrict__ route_w,
+                                                        int n_experts, int hidden, bf16_t* __restrict__ acc) {
+    const int t = blockIdx.x;
+    float w[LA_MOE_MAX_E];
+#pragma unroll
+    for (int e = 0; e < LA_MOE_MAX_E; ++e) w[e] = e < n_experts ? route_w[t * LA_MOE_MAX_E + e] : 0.f;
+    for (int c = threadIdx.x; c < (hidden >> 3); c += 256) {
+        float cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < LA_MOE_MAX_E; ++e) {
+            if (w[e] == 0.f) continue;
+            float add[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) {
+                const float* sp = slabs + (size_t)e * ex_slab + ((size_t)s2 * LA_TB + t) * hidden + c * 8;
+                const f32x4 a0 = *(const f32x4*)sp, a1 = *(const f32x4*)(sp + 4);
+                add[0] += a0[0]; add[1] += a0[1]; add[2] += a0[2]; add[3] += a0[3];
+                add[4] += a1[0]; add[5] += a1[1]; add[6] += a1[2]; add[7] += a1[3];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float contrib = bfr(bfr(add[j]) * w[e]);
+                cur[j] = any ? bfr(cur[j] + contrib) : contrib;
+            }
+            any = true;
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(cur[j]);
+        *(bf16x8*)(acc + (size_t)t * hidden + c * 8) = o;
+    }
+}
+
 // =============================================================================================
 // launchers
 // =============================================================================================
@@ -1608,6 +1650,45 @@ static int tree_attn_launch(hipStream_t st, AttnArgs a, int n_slots, void* attn_
         default: return -1;
     }
 #undef AC
+    LAUNCH_CHECK(); return 0;
+}
+// ---- merged MoE launches: E experts in one grid ----
+int lk_gemm64r_swiglu_ex(hipStream_t st, const void* wp0, long w_stride, const void* xp, int F, int K, int n_wg, void* act0,
+                         long act_stride, const float* route_w, int E) {
+    GemmRArgs ra{}; ra.g.wp = (const bf16_t*)wp0; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act0;
+    ra.g.route_col = route_w; ra.g.ex_on = 1; ra.g.ex_w = w_stride; ra.g.ex_x = 0; ra.g.ex_act = act_stride;
+    ra.R = F / n_wg; if (F % n_wg || ra.R > 64 || ra.R <= 32 || E < 1 || E > LA_MOE_MAX_E) return -1;
+    fill_nv(ra, ra.R, 2, 2);
+    k_gemm64r<4, EPI_SWIGLU, 4, 8><<<dim3(n_wg, E), 512, 8 * 4 * 4096, st>>>(ra);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_gemm64_swiglu_ex(hipStream_t st, const void* wp0, long w_stride, const void* xp, int F, int K, void* act0, long act_stride,
+                        const float* route_w, int E) {
+    GemmArgs a{}; a.wp = (const bf16_t*)wp0; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = F; a.act_xp = (bf16_t*)act0;
+    a.route_col = route_w; a.ex_on = 1; a.ex_w = w_stride; a.ex_act = act_stride;
+    if (E < 1 || E > LA_MOE_MAX_E) return -1;
+    k_gemm64<2, EPI_SWIGLU, 8, 4><<<dim3(F / 32, 1, E), 256, 0, st>>>(a);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_gemm64_slab_ex(hipStream_t st, const void* wp0, long w_stride, const void* xp0, long x_stride, int N, int K, int rbv, int ksplit,
+                      float* slabs0, long slab_stride, const float* route_w, int E) {
+    const int rb = rbv & 0xff;
+    GemmArgs a{}; a.wp = (const bf16_t*)wp0; a.xp = (const bf16_t*)xp0; a.K16 = K / 16; a.N = N; a.slabs = slabs0;
+    a.route_col = route_w; a.ex_on = 1; a.ex_w = w_stride; a.ex_x = x_stride; a.ex_slab = slab_stride;
+    if (E < 1 || E > LA_MOE_MAX_E) return -1;
+    if (rb == 2 && (N % 64) == 0) k_gemm64<2, EPI_SLAB, 8, 4><<<dim3(N / 64, ksplit, E), 256, 0, st>>>(a);
+    else k_gemm64<1, EPI_SLAB, 8, 4><<<dim3(N / 32, ksplit, E), 256, 0, st>>>(a);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_moe_accum_all(hipStream_t st, const float* slabs0, long slab_stride, int n_slabs, const float* route_w, int E, int hidden, void* acc) {
+    if (hidden & 7) return -1;
+#define MA(NS) k_moe_accum_all<NS><<<LA_TB, 256, 0, st>>>(slabs0, slab_stride, route_w, E, hidden, (bf16_t*)acc)
+    switch (n_slabs) {
+        case 1: MA(1); break; case 2: MA(2); break; case 3: MA(3); break; case 4: MA(4); break;
+        case 6: MA(6); break; case 8: MA(8); break;
+        default: return -1;
+    }
+#undef MA
     LAUNCH_CHECK(); return 0;
 }
 int lk_publish(hipStream_t st, int* state, int* host_out) {

@@ -232,11 +232,27 @@ class LlamaVerifyEngine(object):
                 layers[i].router = dev(take(p + 'block_sparse_moe.gate.weight')).data_ptr()
                 gu = (_lib.vp * shape.n_experts)()
                 dn = (_lib.vp * shape.n_experts)()
+                # the expert images of a layer are packed at equal spacing in ONE buffer per projection, which lets the
+                # engine run all experts of a stage in a single launch (la_engine.cpp: ex_merged)
+                gu_all = dn_all = None
                 for e in range(shape.n_experts):
                     q = p + f'block_sparse_moe.experts.{e}.'
-                    gu[e] = pack_gateup(take(q + 'w1.weight'), take(q + 'w3.weight'))
-                    dn[e] = pack(take(q + 'w2.weight')).data_ptr()
-                self._keep.extend([gu, dn])
+                    one_gu = pack_planned(1, [take(q + 'w1.weight'), take(q + 'w3.weight')]) if self.balanced_wg[1] \
+                        else pack(take(q + 'w1.weight'), take(q + 'w3.weight'))
+                    one_dn = pack(take(q + 'w2.weight'))
+                    if gu_all is None:
+                        gstride = (one_gu.numel() + 63) // 64 * 64
+                        dstride = (one_dn.numel() + 63) // 64 * 64
+                        gu_all = torch.zeros(shape.n_experts * gstride, dtype=torch.bfloat16, device=self.device)
+                        dn_all = torch.zeros(shape.n_experts * dstride, dtype=torch.bfloat16, device=self.device)
+                    gu_all[e * gstride:e * gstride + one_gu.numel()].copy_(one_gu)
+                    dn_all[e * dstride:e * dstride + one_dn.numel()].copy_(one_dn)
+                    gu[e] = gu_all.data_ptr() + 2 * e * gstride
+                    dn[e] = dn_all.data_ptr() + 2 * e * dstride
+                    self._keep = [t for t in self._keep if t is not one_gu and t is not one_dn]
+                    del one_gu, one_dn
+                torch.cuda.synchronize(self.device)
+                self._keep.extend([gu, dn, gu_all, dn_all])
                 layers[i].ex_gateup = C.cast(gu, C.POINTER(_lib.vp))
                 layers[i].ex_down = C.cast(dn, C.POINTER(_lib.vp))
             else:
