@@ -251,7 +251,9 @@ typedef struct la_llama_layer_weights {   /* device pointers, packed by la_pack_
     const void* norm2;       /* post_attention_layernorm weight bf16 [hidden] */
     /* n_experts > 0 (wgateup / wdown above are then unused): */
     const void* router;              /* block_sparse_moe.gate weight, bf16 [n_experts][hidden] row-major        */
-    const void* const* ex_gateup;    /* host array [n_experts]: packed interleaved w1/w3 of each expert         */
+    const void* const* ex_gateup;    /* host array [n_experts]: packed interleaved w1/w3 of each expert; when the images of a
+                                        layer are equally spaced in memory (ptr[e] = ptr[0] + e * stride, stride % 16 == 0) all
+                                        experts of a stage run in ONE launch, otherwise one launch per expert             */
     const void* const* ex_down;      /* host array [n_experts]: packed w2 of each expert                        */
 } la_llama_layer_weights;
 
