@@ -185,7 +185,7 @@ extern "C" la_llama* la_llama_create(const la_llama_config* cfg, const la_llama_
             for (int e = 0; e < cfg->n_experts; ++e) { m->ex_gateup.push_back(L.ex_gateup[e]); m->ex_down.push_back(L.ex_down[e]); }
         }
         // equally spaced expert images (the Python engine packs them into one buffer per layer) -> one launch per stage
-        m->ex_merged = true;
+        m->ex_merged = cfg->top_k <= 4;          // k_moe_accum_all gathers at most 4 routed experts per row
         for (int l = 0; l < cfg->n_layers && m->ex_merged; ++l) {
             const char* g0 = (const char*)m->ex_gateup[(size_t)l * cfg->n_experts];
             const char* d0 = (const char*)m->ex_down[(size_t)l * cfg->n_experts];

@@ -91,6 +91,7 @@ __device__ __forceinline__ void row_norm_body(const int t, float* sh, float (*sh
     const int nchunk = hidden >> 3;
     const bf16_t* src = embed ? embed + (size_t)ids[t] * hidden : h + (size_t)t * hidden;
     bf16x8 hv[2], wv[2], av[2];
+    bf16x8 gwv[MOE ? LA_MOE_MAX_E : 1][2];          // router rows: requested with everything else (one memory round trip)
     f32x4 sl[NS > 0 ? NS : 1][2][2];
 #pragma unroll
     for (int ci = 0; ci < 2; ++ci) {
@@ -98,6 +99,11 @@ __device__ __forceinline__ void row_norm_body(const int t, float* sh, float (*sh
         if (c < nchunk) {
             hv[ci] = *(const bf16x8*)(src + c * 8);
             wv[ci] = *(const bf16x8*)(nw + c * 8);
+            if (MOE) {
+#pragma unroll
+                for (int e = 0; e < LA_MOE_MAX_E; ++e)
+                    if (e < n_experts) gwv[e][ci] = *(const bf16x8*)(wrouter + (size_t)e * hidden + c * 8);
+            }
             if (NS == 0 && addend) av[ci] = *(const bf16x8*)(addend + (size_t)t * hidden + c * 8);
 #pragma unroll
             for (int s2 = 0; s2 < NS; ++s2) {
@@ -153,7 +159,7 @@ __device__ __forceinline__ void row_norm_body(const int t, float* sh, float (*sh
 #pragma unroll
                 for (int e = 0; e < LA_MOE_MAX_E; ++e) {
                     if (e < n_experts) {
-                        const bf16x8 gw = *(const bf16x8*)(wrouter + (size_t)e * hidden + c * 8);
+                        const bf16x8 gw = gwv[e][ci];
 #pragma unroll
                         for (int j = 0; j < 8; ++j) rl[e] += bf2f((bf16_t)xo[j]) * bf2f((bf16_t)gw[j]);
                     }
@@ -1293,30 +1299,40 @@ template <int NS>
 __global__ __launch_bounds__(256) void k_moe_accum_all(const float* __restrict__ slabs, long ex_slab, const float* __restrict__ route_w,
                                                         int n_experts, int hidden, bf16_t* __restrict__ acc) {
     const int t = blockIdx.x;
-    float w[LA_MOE_MAX_E];
-#pragma unroll
-    for (int e = 0; e < LA_MOE_MAX_E; ++e) w[e] = e < n_experts ? route_w[t * LA_MOE_MAX_E + e] : 0.f;
+    // the (<= 4) experts this row is routed to, in index order (block-uniform)
+    int sel[4];
+    float wsel[4];
+    int ns = 0;
+    for (int e = 0; e < n_experts && ns < 4; ++e) {
+        const float w = route_w[t * LA_MOE_MAX_E + e];
+        if (w != 0.f) { sel[ns] = e; wsel[ns] = w; ++ns; }
+    }
+    for (int k = ns; k < 4; ++k) { sel[k] = 0; wsel[k] = 0.f; }
     for (int c = threadIdx.x; c < (hidden >> 3); c += 256) {
+        f32x4 v[4][NS][2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < ns) {
+#pragma unroll
+                for (int s2 = 0; s2 < NS; ++s2) {
+                    const float* sp = slabs + (size_t)sel[k] * ex_slab + ((size_t)s2 * LA_TB + t) * hidden + c * 8;
+                    v[k][s2][0] = *(const f32x4*)sp;
+                    v[k][s2][1] = *(const f32x4*)(sp + 4);
+                }
+            }
         float cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        bool any = false;
 #pragma unroll
-        for (int e = 0; e < LA_MOE_MAX_E; ++e) {
-            if (w[e] == 0.f) continue;
-            float add[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < 4; ++k)
+            if (k < ns) {
 #pragma unroll
-            for (int s2 = 0; s2 < NS; ++s2) {
-                const float* sp = slabs + (size_t)e * ex_slab + ((size_t)s2 * LA_TB + t) * hidden + c * 8;
-                const f32x4 a0 = *(const f32x4*)sp, a1 = *(const f32x4*)(sp + 4);
-                add[0] += a0[0]; add[1] += a0[1]; add[2] += a0[2]; add[3] += a0[3];
-                add[4] += a1[0]; add[5] += a1[1]; add[6] += a1[2]; add[7] += a1[3];
+                for (int j = 0; j < 8; ++j) {
+                    float add = 0.f;
+#pragma unroll
+                    for (int s2 = 0; s2 < NS; ++s2) add += v[k][s2][j >> 2][j & 3];
+                    const float contrib = bfr(bfr(add) * wsel[k]);
+                    cur[j] = k ? bfr(cur[j] + contrib) : contrib;
+                }
             }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float contrib = bfr(bfr(add[j]) * w[e]);
-                cur[j] = any ? bfr(cur[j] + contrib) : contrib;
-            }
-            any = true;
-        }
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(cur[j]);
