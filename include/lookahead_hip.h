@@ -43,7 +43,7 @@ extern "C" {
 #define LA_MOE_MAX_E      8   /* experts per mixture-of-experts layer (Mixtral: 8, top-2) */
 
 /* ABI version: bumped when a signature changes. */
-#define LA_ABI_VERSION  3    /* bumped whenever a struct layout or an entry point changes */
+#define LA_ABI_VERSION  4    /* bumped whenever a struct layout or an entry point changes */
 int          la_abi_version(void);   /* == LA_ABI_VERSION of the header the library was built from */
 const char*  la_last_error(void);
 
@@ -85,6 +85,13 @@ int la_cache_one_get(la_cache* c, const int32_t* token_ids, int n,
                      int decoding_length, int branch_length, int mode, int idx,
                      int cap, int32_t* out_ids, int32_t out_sizes[2], int32_t* out_nsizes,
                      int32_t* out_n);
+/* bat_get() (lookahead_cache.py:519-561) in its device-path form: the per-sample drafts of a batch in one call, unpadded
+ * (no [bs,T,W] canvas).  queries: [bs][q_stride] (first nq[b] used); per-sample budget decoding_length // bs and
+ * min_output_size = max(budget // 2, 1) as in the reference; one_branch != 0 selects one_get.  Outputs: rows of `cap`
+ * (<= 64) entries: ids, 64-bit row masks, out_n[bs], out_sizes[bs][2], out_nsizes[bs]. */
+int la_cache_bat_get_packed(la_cache* c, const int32_t* queries, const int32_t* nq, int q_stride, int bs, int decoding_length,
+                            int branch_length, int mode, const int32_t* indices, int one_branch, int cap, int32_t* out_ids,
+                            uint64_t* out_rowmask, int32_t* out_n, int32_t* out_sizes, int32_t* out_nsizes);
 /* reset_input_freqs() (:566-570), squeeze_branch_counts() (:572-576). */
 int la_cache_reset_input_freqs(la_cache* c, int idx);
 int la_cache_squeeze(la_cache* c);

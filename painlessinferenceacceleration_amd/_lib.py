@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblookahead_hip.so")
 
 LA_OK = 0
-ABI_VERSION = 3         # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
+ABI_VERSION = 4         # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
 LA_MODE_INPUT, LA_MODE_OUTPUT, LA_MODE_MIX = 0, 1, 2
 LA_TREE_MAX = 64
 LA_MOE_MAX_E = 8
@@ -111,6 +111,7 @@ PROTOTYPES = {
     "la_cache_stream_put": (i32, vp, pi32, i32, i32, i32, i32),
     "la_cache_hier_get": (i32, vp, pi32, i32, i32, i32, i32, i32, i32, i32, i32, pi32, pi32, pu64, pi64, pi32, pi32, pi32),
     "la_cache_one_get": (i32, vp, pi32, i32, i32, i32, i32, i32, i32, pi32, pi32, pi32, pi32),
+    "la_cache_bat_get_packed": (i32, vp, pi32, pi32, i32, i32, i32, i32, i32, pi32, i32, i32, pi32, pu64, pi32, pi32, pi32),
     "la_cache_reset_input_freqs": (i32, vp, i32),
     "la_cache_squeeze": (i32, vp),
     "la_cache_stats": (i32, vp, pi64, pi64, pi64, pi64),

@@ -600,6 +600,35 @@ int la_cache_export(la_cache* c, int idx, int32_t cap, int32_t* tok, double* fo,
     return LA_OK;
 }
 
+// bat_get() without the padded canvas (lookahead_cache.py:519-561): the per-sample drafts of a batch in ONE call — same
+// budget rule (decoding_length // bs per sample, min_output_size = max(per // 2, 1), idx = indices[b]); hier: ids + 64-bit
+// row masks, one: ids + chain masks.  Rows b of the outputs hold out_n[b] <= cap entries.
+int la_cache_bat_get_packed(la_cache* c, const int32_t* queries, const int32_t* nq, int q_stride, int bs, int decoding_length,
+                            int branch_length, int mode, const int32_t* indices, int one_branch, int cap, int32_t* out_ids,
+                            uint64_t* out_rowmask, int32_t* out_n, int32_t* out_sizes, int32_t* out_nsizes) {
+    if (!c || !queries || !nq || !indices || !out_ids || !out_rowmask || !out_n || !out_sizes || !out_nsizes || bs < 1 ||
+        cap < 1 || cap > 64 || q_stride < 1) return LA_E_ARG;
+    const int per = decoding_length / bs;
+    const int min_out = per / 2 > 1 ? per / 2 : 1;
+    std::vector<int32_t> parent((size_t)cap);
+    for (int b = 0; b < bs; ++b) {
+        int32_t* ids = out_ids + (size_t)b * cap;
+        uint64_t* rm = out_rowmask + (size_t)b * cap;
+        int rc;
+        if (!one_branch) {
+            rc = la_cache_hier_get(c, queries + (size_t)b * q_stride, nq[b], per, branch_length, 0, min_out, mode, indices[b], cap,
+                                   ids, parent.data(), rm, nullptr, out_sizes + 2 * b, out_nsizes + b, out_n + b);
+            if (rc == LA_OK && out_n[b] == 1) rm[0] = 1ull;
+        } else {
+            rc = la_cache_one_get(c, queries + (size_t)b * q_stride, nq[b], per, branch_length, mode, indices[b], cap, ids,
+                                  out_sizes + 2 * b, out_nsizes + b, out_n + b);
+            for (int i = 0; rc == LA_OK && i < out_n[b]; ++i) rm[i] = i == 63 ? ~0ull : ((2ull << i) - 1ull);
+        }
+        if (rc != LA_OK) return rc;
+    }
+    return LA_OK;
+}
+
 // ---- persistence: "LATRIE01" | n_trees | per tree {token, max_node, max_output_node, n_node, n_output_node,
 //      n_rec} | per record (pre-order, insertion order) {token, depth, fo, n_fi, (idx, f)*}
 int la_cache_save(la_cache* c, const char* path) {

@@ -257,28 +257,32 @@ class LookaheadCache(object):
                        decoding_mode='hier'):
         """Device-path form of bat_get: the same per-sample drafts (same budget rule, :534-541) as
         [(ids int32[T_b], rowmask uint64[T_b], sizes)], unpadded and without the [bs,T,W] canvas — the batch engine
-        takes each sample's rows as they are."""
+        takes each sample's rows as they are.  One native call for the whole batch (la_cache_bat_get_packed)."""
         assert mode in ('input', 'output', 'mix')
         assert decoding_mode in ('hier', 'one')
         bs = len(token_id_list)
         assert bs == len(indices), f'{bs=} {len(indices)=}'
         per_sample = decoding_length // bs
-        out = []
-        for sub_idx, token_ids in enumerate(token_id_list):
-            if decoding_mode == 'hier':
-                ids, rowmask, _, sizes = self.hier_get_packed(token_ids, decoding_length=per_sample,
-                                                              branch_length=branch_length, min_input_size=0,
-                                                              min_output_size=max(per_sample // 2, 1), mode=mode,
-                                                              idx=indices[sub_idx])
-                out.append((ids.copy(), rowmask.copy(), sizes))
-            else:
-                lst, _, sizes = self.one_get(token_ids, decoding_length=per_sample, branch_length=branch_length,
-                                             min_input_size=0, min_output_size=max(per_sample // 2, 1), mode=mode,
-                                             idx=indices[sub_idx])
-                n = len(lst)
-                chain = ((np.uint64(2) << np.arange(n, dtype=np.uint64)) - np.uint64(1)).astype(np.uint64)
-                out.append((np.asarray(lst, dtype=np.int32), chain, sizes))
-        return out
+        assert per_sample <= _lib.LA_TREE_MAX or per_sample <= 1, 'device path handles <= 64 tree tokens per sample'
+        cap = _lib.LA_TREE_MAX
+        qmax = max(1, max(len(q) for q in token_id_list))
+        q = np.zeros((bs, qmax), dtype=np.int32)
+        nq = np.zeros(bs, dtype=np.int32)
+        for b, toks in enumerate(token_id_list):
+            nq[b] = len(toks)
+            q[b, :len(toks)] = toks
+        ids = np.zeros((bs, cap), dtype=np.int32)
+        rows = np.zeros((bs, cap), dtype=np.uint64)
+        n = np.zeros(bs, dtype=np.int32)
+        sizes = np.zeros((bs, 2), dtype=np.int32)
+        nsizes = np.zeros(bs, dtype=np.int32)
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        check(lib.la_cache_bat_get_packed(self._h, q.ctypes.data_as(_lib.pi32), nq.ctypes.data_as(_lib.pi32), qmax, bs,
+                                          int(decoding_length), int(branch_length), _MODES[mode], idx.ctypes.data_as(_lib.pi32),
+                                          1 if decoding_mode == 'one' else 0, cap, ids.ctypes.data_as(_lib.pi32),
+                                          rows.ctypes.data_as(_lib.pu64), n.ctypes.data_as(_lib.pi32),
+                                          sizes.ctypes.data_as(_lib.pi32), nsizes.ctypes.data_as(_lib.pi32)), 'bat_get_packed')
+        return [(ids[b, :n[b]], rows[b, :n[b]], sizes[b, :nsizes[b]].tolist()) for b in range(bs)]
 
     # ---- maintenance ---------------------------------------------------------------------------------
     def fresh(self):

@@ -160,3 +160,51 @@ def test_import_of_a_trie_saved_by_the_reference():
         with tempfile.NamedTemporaryFile('w', suffix='.json', delete=False) as f:
             json.dump(bad, f)
         LookaheadCache().load_reference_mem(f.name)
+
+
+def test_bat_get_packed_equals_per_sample_retrieval_and_bat_get():
+    """la_cache_bat_get_packed (one native call per batch) against hier_get_packed / one_get per sample with bat_get's budget
+    rule, and against the padded bat_get canvas of the same call."""
+    rs = np.random.RandomState(4)
+    cache = LookaheadCache(eos_ids=[None])
+    phrases = [rs.randint(3, 80, size=rs.randint(3, 9)).tolist() for _ in range(20)]
+
+    def text(n):
+        out = []
+        while len(out) < n:
+            out.extend(phrases[rs.randint(0, len(phrases))])
+        return out[:n]
+    for i in range(30):
+        cache.put(text(50), branch_length=13, mode='output', idx=-1)
+    for i in range(4):
+        cache.put(text(40), branch_length=13, mode='input', idx=i)
+    for trial in range(60):
+        bs = int(rs.choice([1, 2, 3, 4, 8]))
+        dl = int(rs.choice([64, 128, 256, 16]))
+        if dl // bs > 64:
+            continue
+        mode = ['input', 'output', 'mix'][rs.randint(0, 3)]
+        fmt = 'hier' if rs.rand() < 0.7 else 'one'
+        qs = [text(30)[-2:] for _ in range(bs)]
+        idxs = [int(rs.randint(0, 4)) for _ in range(bs)]
+        got = cache.bat_get_packed(qs, decoding_length=dl, branch_length=12, mode=mode, indices=idxs, decoding_mode=fmt)
+        per = dl // bs
+        cursors = [int(rs.randint(5, 9)) for _ in range(bs)]
+        id_list, canvas, size_list = cache.bat_get(qs, decoding_length=dl, branch_length=12, decoding_cursors=cursors, mode=mode,
+                                                   indices=idxs, decoding_mode=fmt)
+        lo = min(cursors)
+        for b in range(bs):
+            ids, rows, sizes = got[b]
+            if fmt == 'hier':
+                e_ids, e_rows, _, e_sizes = cache.hier_get_packed(qs[b], decoding_length=per, branch_length=12, min_input_size=0,
+                                                                  min_output_size=max(per // 2, 1), mode=mode, idx=idxs[b])
+                assert ids.tolist() == e_ids.tolist() and rows.tolist() == e_rows.tolist() and sizes == e_sizes
+            else:
+                e_ids, e_mask, e_sizes = cache.one_get(qs[b], decoding_length=per, branch_length=12, mode=mode, idx=idxs[b])
+                assert ids.tolist() == list(e_ids) and sizes == list(e_sizes)
+                assert rows.tolist() == [(2 << i) - 1 for i in range(len(ids))]
+            n = len(ids)
+            assert id_list[b][:n] == ids.tolist()
+            off = cursors[b] - lo
+            own = canvas[b][:n, off:off + n]
+            assert tr.rows_of(own) == [int(r) for r in rows]
