@@ -21,7 +21,7 @@ class TrieOracle(object):
     """Same public surface as the reference LookaheadCache, minus persistence."""
 
     def __init__(self, eos_ids=(2,), stop_words=None, max_node=65536, max_output_node=512):
-        self.eos_ids = list(eos_ids) if eos_ids is not None else [None]
+        self.eos_ids = eos_ids if eos_ids is not None else [None]      # the live object, as lookahead_cache.py:339
         self.stop_words = stop_words if stop_words is not None else {}
         self.max_node = max_node
         self.max_output_node = max_output_node

@@ -523,7 +523,7 @@ extern "C" int la_lookahead_decode(la_llama* m, la_cache* c, void* stream, const
         if (rc != LA_OK) return rc;
         const int n = host_out[LA_ST_NOUT];
         nkeys = host_out[LA_ST_NKEYS];
-        if (n < 1 || n > 16) { la_set_error("decode: bad step output"); return LA_E_HIP; }
+        if (n < 1 || n > LA_TREE_MAX) { la_set_error("decode: bad step output"); return LA_E_HIP; }   // a step emits <= branch_length + 1 <= T tokens
         memcpy(seq + len, host_out + LA_ST_OUTTOK, sizeof(int32_t) * n);
         rc = la_cache_stream_put(c, seq + len, n, p->branch_length + 1, 0, p->idx);
         if (rc != LA_OK) return rc;

@@ -633,8 +633,11 @@ int la_cache_bat_get_packed(la_cache* c, const int32_t* queries, const int32_t* 
 //      n_rec} | per record (pre-order, insertion order) {token, depth, fo, n_fi, (idx, f)*}
 int la_cache_save(la_cache* c, const char* path) {
     if (!c || !path) return LA_E_ARG;
-    FILE* f = fopen(path, "wb");
-    if (!f) { la_set_error(std::string("save: cannot open ") + path); return LA_E_IO; }
+    // written next to the target and renamed over it only when complete: a crash or a full disk mid-save leaves the
+    // previous snapshot intact
+    const std::string tmp_path = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp_path.c_str(), "wb");
+    if (!f) { la_set_error(std::string("save: cannot open ") + tmp_path); return LA_E_IO; }
     auto w = [&](const void* p, size_t n) { return fwrite(p, 1, n, f) == n; };
     bool ok = w("LATRIE01", 8);
     // keep dict order of mem irrelevant: trees are looked up by token only
@@ -663,19 +666,25 @@ int la_cache_save(la_cache* c, const char* path) {
             for (auto& p : nd.fi) { ok = ok && w(&p.first, 4) && w(&p.second, 8); }
         }
     }
-    fclose(f);
-    if (!ok) { la_set_error("save: short write"); return LA_E_IO; }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { remove(tmp_path.c_str()); la_set_error("save: short write"); return LA_E_IO; }
+    if (rename(tmp_path.c_str(), path) != 0) { remove(tmp_path.c_str()); la_set_error(std::string("save: cannot rename to ") + path); return LA_E_IO; }
     return LA_OK;
 }
 
-int la_cache_load(la_cache* c, const char* path) {
-    if (!c || !path) return LA_E_ARG;
+int la_cache_load(la_cache* live, const char* path) {
+    if (!live || !path) return LA_E_ARG;
     FILE* f = fopen(path, "rb");
     if (!f) { la_set_error(std::string("load: cannot open ") + path); return LA_E_IO; }
     auto r = [&](void* p, size_t n) { return fread(p, 1, n, f) == n; };
     char magic[8];
     if (!r(magic, 8) || memcmp(magic, "LATRIE01", 8) != 0) { fclose(f); la_set_error("load: bad magic"); return LA_E_IO; }
-    la_cache_fresh(c);                                      // load_mem replaces self.mem only
+    // The snapshot is parsed into a scratch cache and swapped in only when the whole file was valid: a truncated or corrupt
+    // file leaves the live forest untouched (the reference's load_mem keeps self.mem when unpickling fails,
+    // lookahead_cache.py:583-587).
+    la_cache scratch;
+    la_cache* c = &scratch;
+    c->max_node = live->max_node; c->max_output_node = live->max_output_node; c->next_uid = live->next_uid;
     int64_t nt = 0;
     bool ok = r(&nt, 8);
     for (int64_t ti = 0; ok && ti < nt; ++ti) {
@@ -690,7 +699,7 @@ int la_cache_load(la_cache* c, const char* path) {
         for (int64_t i = 0; ok && i < hdr[5]; ++i) {
             int32_t rec[3]; double fo;
             ok = r(rec, sizeof(rec)) && r(&fo, 8);
-            if (!ok || rec[1] < 1 || rec[1] > (int32_t)path_nodes.size()) { ok = false; break; }
+            if (!ok || rec[1] < 1 || rec[1] > (int32_t)path_nodes.size() || rec[2] < 0) { ok = false; break; }
             path_nodes.resize(rec[1]);
             int32_t nn = c->new_node(rec[0], path_nodes.back());
             c->link_child(path_nodes.back(), nn);
@@ -705,6 +714,11 @@ int la_cache_load(la_cache* c, const char* path) {
     }
     fclose(f);
     if (!ok) { la_set_error("load: truncated or corrupt snapshot"); return LA_E_IO; }
+    // load_mem replaces self.mem only: dirty sets, stream buffers, eos / stop words of the live cache stay
+    live->mem.swap(c->mem); live->live_by_uid.swap(c->live_by_uid);
+    live->nodes.swap(c->nodes); live->free_nodes.swap(c->free_nodes); live->child_index.swap(c->child_index);
+    live->trees.swap(c->trees); live->free_trees.swap(c->free_trees);
+    live->live_nodes = c->live_nodes; live->next_uid = c->next_uid;
     return LA_OK;
 }
 

@@ -66,7 +66,11 @@ class LookaheadCache(object):
     @eos_ids.setter
     def eos_ids(self, value):
         self._eos_ids = value if value is not None else [None]
+        self._push_eos()
+
+    def _push_eos(self):
         ids = [int(x) for x in self._eos_ids if x is not None]
+        self._eos_pushed = tuple(ids)
         arr, p, n = _as_i32(ids)
         check(lib.la_cache_set_eos(self._h, p, n), 'set_eos')
 
@@ -77,8 +81,24 @@ class LookaheadCache(object):
     @stop_words.setter
     def stop_words(self, value):
         self._stop_words = value if value is not None else {}
-        arr, p, n = _as_i32([int(x) for x in self._stop_words])
+        self._push_stop_words()
+
+    def _push_stop_words(self):
+        ids = sorted(int(x) for x in self._stop_words)
+        self._stop_pushed = tuple(ids)
+        arr, p, n = _as_i32(ids)
         check(lib.la_cache_set_stop_words(self._h, p, n), 'set_stop_words')
+
+    def _sync_live(self):
+        """The reference reads `self.stop_words` / `self.eos_ids` live on every call (lookahead_cache.py:352, 396, 422), so
+        callers may mutate the containers in place (cache.stop_words.add(x), or the dict they passed through
+        decoding_kwargs).  The native trie holds a copy: re-push it whenever the live contents differ from the last push
+        (a tuple compare of a handful of ids per call)."""
+        if len(self._stop_words) != len(self._stop_pushed) or \
+                (self._stop_pushed and tuple(sorted(int(x) for x in self._stop_words)) != self._stop_pushed):
+            self._push_stop_words()
+        if tuple(int(x) for x in self._eos_ids if x is not None) != self._eos_pushed:
+            self._push_eos()
 
     @property
     def max_node(self):
@@ -124,12 +144,14 @@ class LookaheadCache(object):
     # ---- updates -------------------------------------------------------------------------------------
     def put(self, token_ids, branch_length=8, final=False, mode='output', idx=0):
         """lookahead_cache.py:349-373."""
+        self._sync_live()
         assert mode in ('input', 'output')
         arr, p, n = _as_i32(token_ids)
         check(lib.la_cache_put(self._h, p, n, int(branch_length), int(bool(final)), _MODES[mode], int(idx)), 'put')
 
     def stream_put(self, token_ids, branch_length=8, final=False, mode='output', idx=0):
         """lookahead_cache.py:375-406."""
+        self._sync_live()
         assert mode == 'output' and idx >= 0
         arr, p, n = _as_i32(token_ids)
         check(lib.la_cache_stream_put(self._h, p, n, int(branch_length), int(bool(final)), int(idx)), 'stream_put')
@@ -138,6 +160,7 @@ class LookaheadCache(object):
     def _hier_raw(self, token_ids, decoding_length, branch_length, min_input_size, min_output_size, mode, idx,
                   want_mask):
         assert mode in ('input', 'output', 'mix')
+        self._sync_live()
         self._alloc(max(int(decoding_length), 1))
         arr, p, n = _as_i32(token_ids)
         mask_p = self._mask.ctypes.data_as(_lib.pi64) if want_mask else None
@@ -174,6 +197,7 @@ class LookaheadCache(object):
                 mode='mix', idx=0):
         """lookahead_cache.py:490-517 -> single greedy chain, lower-triangular mask."""
         assert mode in ('input', 'output', 'mix')
+        self._sync_live()
         self._alloc(max(int(branch_length) + 1, 1))
         arr, p, n = _as_i32(token_ids)
         check(lib.la_cache_one_get(self._h, p, n, int(decoding_length), int(branch_length), _MODES[mode], int(idx),
@@ -260,6 +284,7 @@ class LookaheadCache(object):
         takes each sample's rows as they are.  One native call for the whole batch (la_cache_bat_get_packed)."""
         assert mode in ('input', 'output', 'mix')
         assert decoding_mode in ('hier', 'one')
+        self._sync_live()
         bs = len(token_id_list)
         assert bs == len(indices), f'{bs=} {len(indices)=}'
         per_sample = decoding_length // bs

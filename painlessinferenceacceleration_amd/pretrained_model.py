@@ -14,6 +14,7 @@ from threading import Thread
 import numpy as np
 import torch
 
+from . import _lib
 from .lookahead_cache import LookaheadCache
 from .lookahead_generation_utils import GenerationMode, LookaheadDecoderOnlyOutput
 
@@ -116,6 +117,11 @@ class LookaheadPreTrainedModel(object):
         if stop_max_length is None:
             raise ValueError('lookahead_generation needs a MaxLengthCriteria (stopping_criteria.max_length)')
         decoding_length = decoding_kwargs.get('decoding_length', 64)
+        if not 1 <= int(decoding_length) <= _lib.LA_TREE_MAX:
+            raise ValueError(f'decoding_length={decoding_length}: the device verify block holds at most {_lib.LA_TREE_MAX} '
+                             f'tree tokens per sequence (the reference grid-searches up to 256, benchmarks/benchmark.py:358)')
+        if int(decoding_kwargs.get('max_query_length', 2)) < 1:
+            raise ValueError('max_query_length must be >= 1')
         decoding_kwargs['max_length'] = stop_max_length
         decoding_kwargs['decoding_max_length'] = stop_max_length + decoding_length + 1
         attention_mask = model_kwargs.get('attention_mask', None)
@@ -138,8 +144,10 @@ class LookaheadPreTrainedModel(object):
         dm = decoding_kwargs.get('decoding_mode', 'hier')
         dm = dm + '_mix' if dm in ('hier', 'par', 'one') else dm
         native_mode = {'input': 0, 'output': 1, 'mix': 2}.get(dm.split('_')[1], 2)
+        max_query_length = int(decoding_kwargs.get('max_query_length', 2))
         native_loop = (not sequential and streamer is None and dm.split('_')[0] == 'hier' and decoding_length <= 64
                        and not decoding_kwargs.get('debug_lookahead', False) and decoding_kwargs.get('native_loop', True)
+                       and 1 <= max_query_length <= 8          # la_lookahead_decode's query buffer; longer queries use this loop
                        and hasattr(eng, 'decode_native'))
 
         def pick(scores_ids, row):
@@ -151,71 +159,80 @@ class LookaheadPreTrainedModel(object):
                 return int(torch.multinomial(torch.softmax(scores.float(), dim=-1), num_samples=1)[0, 0])
             return int(torch.argmax(scores, dim=-1)[0])
 
-        while True:
-            if first:
-                tok = eng.prefill(seq)
-                next_tokens = [pick(seq, (len(seq) - 1) % 64)] if sequential else [tok]
-                decoding_kwargs['dls'].append(1)
-                decoding_kwargs['edls'].append(1)
-                first = False
-            else:
-                ids, rowmask = self.lookahead_prepare_inputs_for_generation(seq, decoding_kwargs, len(seq))
-                if len(ids) == 0:
-                    ids, rowmask = np.asarray(seq[-1:], dtype=np.int32), _ONE
-                if sequential:
-                    eng.verify_only(ids, rowmask)
-                    T = len(ids)
-                    parent = [-1] * T
-                    for j in range(1, T):
-                        below = int(rowmask[j]) & ((1 << j) - 1)
-                        parent[j] = below.bit_length() - 1
-                    cur, rows, next_tokens = 0, [0], []
-                    while True:
-                        t = pick(seq + next_tokens, cur)
-                        next_tokens.append(t)
-                        nxt = next((j for j in range(1, T) if parent[j] == cur and int(ids[j]) == t), None)
-                        if nxt is None:
-                            break
-                        cur = nxt
-                        rows.append(cur)
-                    eng.commit(rows)
+        flushed = False
+        try:
+            while True:
+                if first:
+                    tok = eng.prefill(seq)
+                    next_tokens = [pick(seq, (len(seq) - 1) % 64)] if sequential else [tok]
+                    decoding_kwargs['dls'].append(1)
+                    decoding_kwargs['edls'].append(1)
+                    first = False
                 else:
-                    next_tokens, _ = eng.step(ids, rowmask, mode=0)
-                decoding_kwargs['dls'].append(len(ids))
-                decoding_kwargs['edls'].append(len(next_tokens))
-                if decoding_kwargs.get('debug_lookahead', False):
-                    tok = decoding_kwargs.get('tokenizer', None)
-                    words = '' if tok is None else tok.decode(next_tokens)
-                    print(f'decoding_length:{len(ids)} accept_length:{len(next_tokens)} '
-                          f'query:{decoding_kwargs["decoding_qids"]} hits:{decoding_kwargs["sizes"]} '
-                          f'accept_token:{next_tokens} accept_word:{words}')
-            seq.extend(next_tokens)
-            if streamer is not None:
-                streamer.put(np.array([next_tokens]))
-            self.lookahead_cache.stream_put(next_tokens, branch_length=branch_length + 1, final=False,
-                                            mode='output', idx=0)
-            finished = len(seq) >= stop_max_length or any(t in eos_set for t in next_tokens)
-            te = time.time()
-            decoding_kwargs['fts'].append(te - ts)
-            ts = te
-            if finished:
+                    ids, rowmask = self.lookahead_prepare_inputs_for_generation(seq, decoding_kwargs, len(seq))
+                    if len(ids) == 0:
+                        ids, rowmask = np.asarray(seq[-1:], dtype=np.int32), _ONE
+                    if sequential:
+                        eng.verify_only(ids, rowmask)
+                        T = len(ids)
+                        parent = [-1] * T
+                        for j in range(1, T):
+                            below = int(rowmask[j]) & ((1 << j) - 1)
+                            parent[j] = below.bit_length() - 1
+                        cur, rows, next_tokens = 0, [0], []
+                        while True:
+                            t = pick(seq + next_tokens, cur)
+                            next_tokens.append(t)
+                            nxt = next((j for j in range(1, T) if parent[j] == cur and int(ids[j]) == t), None)
+                            if nxt is None:
+                                break
+                            cur = nxt
+                            rows.append(cur)
+                        eng.commit(rows)
+                    else:
+                        next_tokens, _ = eng.step(ids, rowmask, mode=0)
+                    decoding_kwargs['dls'].append(len(ids))
+                    decoding_kwargs['edls'].append(len(next_tokens))
+                    if decoding_kwargs.get('debug_lookahead', False):
+                        tok = decoding_kwargs.get('tokenizer', None)
+                        words = '' if tok is None else tok.decode(next_tokens)
+                        print(f'decoding_length:{len(ids)} accept_length:{len(next_tokens)} '
+                              f'query:{decoding_kwargs["decoding_qids"]} hits:{decoding_kwargs["sizes"]} '
+                              f'accept_token:{next_tokens} accept_word:{words}')
+                seq.extend(next_tokens)
+                if streamer is not None:
+                    streamer.put(np.array([next_tokens]))
+                self.lookahead_cache.stream_put(next_tokens, branch_length=branch_length + 1, final=False,
+                                                mode='output', idx=0)
+                finished = len(seq) >= stop_max_length or any(t in eos_set for t in next_tokens)
+                te = time.time()
+                decoding_kwargs['fts'].append(te - ts)
+                ts = te
+                if finished:
+                    self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=0)
+                    flushed = True
+                    break
+                if native_loop:
+                    # every remaining step runs in la_lookahead_decode: same calls in the same order (hier_get -> la_llama_step
+                    # -> stream_put -> stop checks), without the interpreter between them
+                    new, dls_, edls_, fts_, qts_, fin = eng.decode_native(
+                        self.lookahead_cache, seq, stop_max_length, eos_ids=eos_set, decoding_length=decoding_length,
+                        branch_length=branch_length, max_query_length=decoding_kwargs.get('max_query_length', 2),
+                        mode=native_mode, idx=0)
+                    seq.extend(new)
+                    decoding_kwargs['dls'].extend(dls_)
+                    decoding_kwargs['edls'].extend(edls_)
+                    decoding_kwargs['fts'].extend(fts_)
+                    decoding_kwargs['qts'].extend(qts_)
+                    assert fin
+                    self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=0)
+                    flushed = True
+                    break
+        finally:
+            # an exception mid-generation must not leave this request's stream buffer / input frequencies behind (they would
+            # mix into the next request); the reference flushes on the normal path only (pretrained_model.py:1236-1239)
+            if not flushed:
                 self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=0)
-                break
-            if native_loop:
-                # every remaining step runs in la_lookahead_decode: same calls in the same order (hier_get -> la_llama_step
-                # -> stream_put -> stop checks), without the interpreter between them
-                new, dls_, edls_, fts_, qts_, fin = eng.decode_native(
-                    self.lookahead_cache, seq, stop_max_length, eos_ids=eos_set, decoding_length=decoding_length,
-                    branch_length=branch_length, max_query_length=decoding_kwargs.get('max_query_length', 2),
-                    mode=native_mode, idx=0)
-                seq.extend(new)
-                decoding_kwargs['dls'].extend(dls_)
-                decoding_kwargs['edls'].extend(edls_)
-                decoding_kwargs['fts'].extend(fts_)
-                decoding_kwargs['qts'].extend(qts_)
-                assert fin
-                self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=0)
-                break
         if streamer is not None:
             streamer.end()
         sequences = torch.tensor([seq], dtype=torch.long, device=out_device)

@@ -208,3 +208,65 @@ def test_bat_get_packed_equals_per_sample_retrieval_and_bat_get():
             off = cursors[b] - lo
             own = canvas[b][:n, off:off + n]
             assert tr.rows_of(own) == [int(r) for r in rows]
+
+
+def test_corrupt_snapshot_leaves_the_live_cache_untouched_and_save_is_atomic():
+    """load_mem of a truncated file returns an error and the forest answers exactly as before (the reference keeps
+    self.mem when unpickling fails, lookahead_cache.py:583-587); save_mem goes through a temp file + rename."""
+    import tempfile
+    rs = random.Random(5)
+    cache = LookaheadCache(eos_ids=[2])
+    for _ in range(40):
+        cache.put([rs.randrange(3, 40) for _ in range(30)], branch_length=9, mode='output', idx=-1)
+    queries = [[rs.randrange(3, 40), rs.randrange(3, 40)] for _ in range(30)]
+
+    def answers(c):
+        out = []
+        for q in queries:
+            ids, mask, sizes = c.hier_get(q, decoding_length=32, branch_length=8, min_output_size=16)
+            out.append(([int(x) for x in ids], tr.rows_of(mask), list(sizes)))
+        return out
+    before, st = answers(cache), cache.stats()
+    with tempfile.TemporaryDirectory() as d:
+        good = os.path.join(d, 'snap.latrie')
+        cache.save_mem(good)
+        assert os.listdir(d) == ['snap.latrie']                      # no temp file left behind
+        blob = open(good, 'rb').read()
+        for cut in (len(blob) // 2, len(blob) - 3, 12):
+            bad = os.path.join(d, f'cut{cut}.latrie')
+            open(bad, 'wb').write(blob[:cut])
+            with pytest.raises(Exception):
+                cache.load_mem(bad)
+            assert cache.stats() == st and answers(cache) == before
+        with pytest.raises(Exception):
+            cache.save_mem(os.path.join(d, 'no_such_dir', 'x.latrie'))
+        assert open(good, 'rb').read() == blob
+        cache.load_mem(good)
+        assert answers(cache) == before
+
+
+def test_in_place_mutation_of_stop_words_and_eos_is_seen_like_the_reference():
+    """The reference consults self.stop_words / self.eos_ids live (lookahead_cache.py:352, 396, 422); callers mutate the
+    containers in place.  Checked against the oracle, which reads them per call like the reference."""
+    stop = {}
+    eos = [2]
+    native = LookaheadCache(eos_ids=eos, stop_words=stop)
+    oracle = TrieOracle(eos_ids=eos, stop_words=stop)
+    rs = random.Random(11)
+    seqs = [[rs.randrange(3, 25) for _ in range(24)] for _ in range(30)]
+    for c in (native, oracle):
+        for s in seqs[:15]:
+            c.put(s, branch_length=7, mode='output', idx=-1)
+    stop[7] = 1            # in place: no setter runs
+    stop[11] = 1
+    eos.append(5)
+    for c in (native, oracle):
+        for s in seqs[15:]:
+            c.put(s, branch_length=7, mode='output', idx=-1)
+        c.stream_put(seqs[0] + seqs[1], branch_length=7, final=False, idx=3)
+    for q in ([3, 7], [9, 11], [11, 7], [4, 5], [12, 13]):
+        a = native.hier_get(q, decoding_length=24, branch_length=6, min_output_size=12)
+        b = oracle.hier_get(q, decoding_length=24, branch_length=6, min_output_size=12)
+        assert [int(x) for x in a[0]] == [int(x) for x in b[0]] and tr.rows_of(a[1]) == tr.rows_of(b[1]) \
+            and list(a[2]) == list(b[2]), q
+    assert native.stats()['n_nodes'] == oracle.n_nodes()
