@@ -46,6 +46,12 @@ extern "C" {
 #define LA_ABI_VERSION  4    /* bumped whenever a struct layout or an entry point changes */
 int          la_abi_version(void);   /* == LA_ABI_VERSION of the header the library was built from */
 const char*  la_last_error(void);
+/* Measurement knobs for the kernel A/B scripts (scripts/gpu_ab.py); every knob is 0 in production.
+ * key 0: GEMM kernels return after the weight-streaming loop, before the cross-wave reduction and epilogue. */
+int          la_debug_set(int key, int value);
+/* key 0: device buffer int64[workgroups][waves][4] the GEMM kernels stamp with wall_clock64() at entry / end of the
+ * streaming loop / exit (NULL = off). */
+int          la_debug_set_ptr(int key, void* d_ptr);
 
 /* ------------------------------------------------------------------------
  * 1. Trie cache (host).  Replaces class LookaheadCache / Tree / Node,

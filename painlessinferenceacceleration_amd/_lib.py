@@ -101,6 +101,8 @@ def _proto(name, restype, *argtypes):
 PROTOTYPES = {
     "la_abi_version": (i32,),
     "la_last_error": (C.c_char_p,),
+    "la_debug_set": (i32, i32, i32),
+    "la_debug_set_ptr": (i32, i32, vp),
     "la_cache_create": (vp, i32, i32),
     "la_cache_destroy": (None, vp),
     "la_cache_set_limits": (i32, vp, i32, i32),

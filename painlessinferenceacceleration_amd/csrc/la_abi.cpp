@@ -15,6 +15,16 @@ extern "C" {
 
 int la_abi_version(void) { return LA_ABI_VERSION; }
 const char* la_last_error(void) { return g_err.c_str(); }
+extern int g_la_dbg_noepi;
+extern long long* g_la_dbg_times;
+int la_debug_set(int key, int value) {
+    if (key == 0) { g_la_dbg_noepi = value; return LA_OK; }
+    return LA_E_ARG;
+}
+int la_debug_set_ptr(int key, void* d_ptr) {
+    if (key == 0) { g_la_dbg_times = (long long*)d_ptr; return LA_OK; }
+    return LA_E_ARG;
+}
 
 int la_build_tree_inputs(void* stream, const int32_t* d_in, int32_t* d_state, int32_t* d_pos, uint64_t* d_rowmask,
                          int32_t* d_ids) {

@@ -277,6 +277,8 @@ struct GemmArgs {
     // outputs and split-K slabs are equally spaced; expert e uses route_col + e and returns at once when no row routes to it
     int ex_on;
     long ex_w, ex_x, ex_act, ex_slab;      // element strides per expert (weights, x operand, act_xp, slabs)
+    int dbg_noepi;      // measurement aid (scripts/gpu_ab.py): return after the streaming loop, before the reduction/epilogue
+    long long* dbg_times;   // measurement aid: [workgroup][wave][4] wall_clock64() at entry / loop end / exit (null in production)
 };
 
 __device__ __forceinline__ bool expert_unused(const float* route_col) {
@@ -285,13 +287,15 @@ __device__ __forceinline__ bool expert_unused(const float* route_col) {
 
 template <int RB, int EPI, int D, int NW>
 __global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
-    __shared__ float red[NW][RB * 2 * 16 * 64];
+    __shared__ __attribute__((aligned(16))) float red[NW][RB * 2 * 16 * 64];
     const int ex = a.ex_on ? (int)blockIdx.z : 0;
     if (expert_unused(a.route_col ? a.route_col + ex : nullptr)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nb0 = blockIdx.x * RB;
     const int ksplit = gridDim.y, ks = blockIdx.y;
+    long long* const stamp = a.dbg_times ? a.dbg_times + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 4 : nullptr;
+    if (stamp && lane == 0) stamp[0] = wall_clock64();
     const int t0 = (int)(((long)a.K16 * ks) / ksplit);
     const int t1 = (int)(((long)a.K16 * (ks + 1)) / ksplit);
     // this wave's contiguous k-tile range
@@ -365,14 +369,21 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
 
     // ---- deterministic cross-wave reduction: every wave parks its partial tile in LDS, ONE barrier, then wave w
     //      sums (fixed order p = 0..NW-1) and finishes the slice {token block w&1, register groups of w>>1} for all
-    //      row-blocks — the epilogue runs on all waves instead of serialising on wave 0.
+    //      row-blocks — the epilogue runs on all waves instead of serialising on wave 0.  The buffer is laid out in
+    //      16-byte units [wave][rb][tb][i/4][lane] so that both sides use ds_write_b128 / ds_read_b128.
+    if (stamp && lane == 0) stamp[1] = wall_clock64();
+    if (a.dbg_noepi) return;
+    f32x4* red4 = (f32x4*)&red[0][0];
     {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) red[wave][((rb * 2 + tb) * 16 + i) * 64 + lane] = acc[rb][tb][i];
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    const f32x4 v = {acc[rb][tb][4 * i4], acc[rb][tb][4 * i4 + 1], acc[rb][tb][4 * i4 + 2], acc[rb][tb][4 * i4 + 3]};
+                    red4[((wave * RB * 2 + rb * 2 + tb) * 4 + i4) * 64 + lane] = v;
+                }
     }
     constexpr int GPW = 8 / NW;                  // register groups (of 4 features) per wave: NW=4 -> 2, NW=8 -> 1
     const int tb = wave & 1, g0 = (wave >> 1) * GPW;
@@ -394,14 +405,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int gg = 0; gg < GPW; ++gg)
+        for (int gg = 0; gg < GPW; ++gg) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v = 0.f;
+            for (int p = 0; p < NW; ++p) v += red4[((p * RB * 2 + rb * 2 + tb) * 4 + (g0 + gg)) * 64 + lane];
 #pragma unroll
-                for (int p = 0; p < NW; ++p) v += red[p][((rb * 2 + tb) * 16 + (g0 + gg) * 4 + j) * 64 + lane];
-                fin[rb][gg][j] = v;
-            }
+            for (int j = 0; j < 4; ++j) fin[rb][gg][j] = v[j];
+        }
     const int tok = tb * 32 + tl;
     if constexpr (EPI == EPI_SLAB) {
         float* o = a.slabs + (size_t)ex * a.ex_slab + (size_t)ks * LA_TB * a.N;
@@ -490,6 +500,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
             a.cand_idx[slot * LA_TB + tok] = bidx;
         }
     }
+    if (stamp && lane == 0) stamp[2] = wall_clock64();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -526,7 +537,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
     if (expert_unused(a.route_col ? a.route_col + ex : nullptr)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nb0 = blockIdx.x * RB;
+    long long* const stamp = a.dbg_times ? a.dbg_times + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 4 : nullptr;
+    if (stamp && lane == 0) stamp[0] = wall_clock64();
     const int twg = a.K16, q = twg / NW, r = twg - q * NW;
     const int wb = wave * q + (wave < r ? wave : r);
     const int cnt = q + (wave < r ? 1 : 0);
@@ -621,8 +633,70 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
         }
     }
 
-    // ---- two passes (token block 0, 1): park partial tiles in LDS, barrier, each wave finishes a fixed slice ----
+    if (stamp && lane == 0) stamp[1] = wall_clock64();
+    if (a.dbg_noepi) return;
+    // ---- cross-wave reduction through LDS in 16-byte units [wave][rb][i/4][lane] (ds_write_b128 / ds_read_b128), fixed
+    //      summation order p = 0..NW-1 (deterministic), then every wave finishes a fixed slice.
     const int tl = lane & 31, hh = lane >> 5;
+    f32x4* red4 = (f32x4*)redr;
+    if constexpr (EPI == EPI_QKV) {
+        static_assert(EPI != EPI_QKV || (RB == 2 && NW == 8), "qkv layout");
+        if ((ra.R & 3) == 0) {
+            // ONE pass, both token blocks parked at once (128 KiB): wave -> (token block, register group); a lane owns 4
+            // consecutive RoPE pairs, i.e. 8-byte runs of the QF/KF fragments and of the cos/sin rows.
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int i4 = 0; i4 < 4; ++i4) {
+                        const f32x4 v = {acc[rb][tb][4 * i4], acc[rb][tb][4 * i4 + 1], acc[rb][tb][4 * i4 + 2], acc[rb][tb][4 * i4 + 3]};
+                        red4[(((tb * NW + wave) * RB + rb) * 4 + i4) * 64 + lane] = v;
+                    }
+            const int tbe = wave >> 2, gi = wave & 3;
+            const int tok = tbe * 32 + tl;
+            const int f0 = 8 * gi + 4 * hh;
+            const bool live = f0 < ra.nv[0];
+            const int pr = ra.R * blockIdx.x + f0, slot = pr >> 6, dlo = pr & 63, dhi = dlo + 64;
+            const bool rope = slot < a.nh + a.nkv;
+            bf16x4 c4 = {0, 0, 0, 0}, s4 = {0, 0, 0, 0};
+            if (live && rope) {          // dependent pos -> cos/sin loads are in flight across the barrier
+                const int ps = a.pos[tok];
+                c4 = *(const bf16x4*)(a.rcos + (size_t)ps * 64 + dlo);
+                s4 = *(const bf16x4*)(a.rsin + (size_t)ps * 64 + dlo);
+            }
+            __syncthreads();
+            if (!live) return;
+            f32x4 xl = {0.f, 0.f, 0.f, 0.f}, xh = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int p = 0; p < NW; ++p) {
+                xl += red4[(((tbe * NW + p) * RB + 0) * 4 + gi) * 64 + lane];
+                xh += red4[(((tbe * NW + p) * RB + 1) * 4 + gi) * 64 + lane];
+            }
+            if (rope) {
+                bf16_t* dst = slot < a.nh ? a.qf + (size_t)slot * 8192 : a.kfresh + (size_t)(slot - a.nh) * 8192;
+                bf16x4 olo, ohi;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float c = bf2f((bf16_t)c4[j]), sn = bf2f((bf16_t)s4[j]);
+                    const float bl = bfr(xl[j]), bh = bfr(xh[j]);
+                    olo[j] = (short)f2bf(bfr(bl * c) + bfr(-bh * sn));
+                    ohi[j] = (short)f2bf(bfr(bh * c) + bfr(bl * sn));
+                }
+                *(bf16x4*)(dst + rf_offset(tok, dlo)) = olo;
+                *(bf16x4*)(dst + rf_offset(tok, dhi)) = ohi;
+            } else {
+                bf16_t* dst = a.vfresh + (size_t)(slot - a.nh - a.nkv) * 8192;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dst[vf_offset(tok, dlo + j)] = f2bf(xl[j]);
+                    dst[vf_offset(tok, dhi + j)] = f2bf(xh[j]);
+                }
+            }
+            if (stamp && lane == 0) stamp[2] = wall_clock64();
+            return;
+        }
+    }
     constexpr int SL = RB * 4 / NW;            // (row-block, register-group) slices per wave and pass (SWIGLU/QKV pair up)
     static_assert(RB * 4 % NW == 0 || EPI == EPI_SWIGLU || EPI == EPI_QKV, "slice split");
     float best = -INFINITY;
@@ -633,50 +707,58 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) redr[((wave * RB + rb) * 16 + i) * 64 + lane] = acc[rb][tb][i];
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const f32x4 v = {acc[rb][tb][4 * i4], acc[rb][tb][4 * i4 + 1], acc[rb][tb][4 * i4 + 2], acc[rb][tb][4 * i4 + 3]};
+                red4[((wave * RB + rb) * 4 + i4) * 64 + lane] = v;
+            }
         __syncthreads();
         const int tok = tb * 32 + tl;
-        auto total = [&](int rb, int gi, int j) {
-            float v = 0.f;
+        auto total4 = [&](int rb, int gi) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int p = 0; p < NW; ++p) v += redr[((p * RB + rb) * 16 + gi * 4 + j) * 64 + lane];
+            for (int p = 0; p < NW; ++p) v += red4[((p * RB + rb) * 4 + gi) * 64 + lane];
             return v;
         };
         if constexpr (EPI == EPI_SWIGLU) {
             // wave -> (pair q, register group gi): gate block q, up block q + RB/2
             static_assert(EPI != EPI_SWIGLU || (RB == 4 && NW == 8), "swiglu layout");
             const int qq = wave >> 2, gi = wave & 3;
+            if (8 * gi + 4 * hh < ra.nv[qq]) {
+                const f32x4 g4 = total4(qq, gi), u4 = total4(qq + RB / 2, gi);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int f = 8 * gi + 4 * hh + j;
-                if (f < ra.nv[qq]) {
-                    const float gv = bfr(total(qq, gi, j)), uv = bfr(total(qq + RB / 2, gi, j));
-                    const float sv = bfr(gv / (1.0f + expf(-gv)));
-                    const int feat = ra.R * blockIdx.x + 32 * qq + f;
-                    a.act_xp[(size_t)ex * a.ex_act + xp_offset(tok, feat)] = f2bf(sv * uv);
+                for (int j = 0; j < 4; ++j) {
+                    const int f = 8 * gi + 4 * hh + j;
+                    if (f < ra.nv[qq]) {
+                        const float gv = bfr(g4[j]), uv = bfr(u4[j]);
+                        const float sv = bfr(gv / (1.0f + expf(-gv)));
+                        const int feat = ra.R * blockIdx.x + 32 * qq + f;
+                        a.act_xp[(size_t)ex * a.ex_act + xp_offset(tok, feat)] = f2bf(sv * uv);
+                    }
                 }
             }
         } else if constexpr (EPI == EPI_QKV) {
-            // wave -> register group gi (NW == 4); block 0 = dims dlo of R pairs, block 1 = their +64 partners
-            static_assert(EPI != EPI_QKV || RB == 2, "qkv layout");
+            // general R (not a multiple of 4): wave -> register group gi, scalar stores
             const int gi = wave & 3;
             const int ps = a.pos[tok];
+            if (wave < 4 && 8 * gi + 4 * hh < ra.nv[0]) {
+                const f32x4 xl4 = total4(0, gi), xh4 = total4(1, gi);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int f = 8 * gi + 4 * hh + j;
-                if (wave < 4 && f < ra.nv[0]) {
-                    const int pr = ra.R * blockIdx.x + f, slot = pr >> 6, dlo = pr & 63, dhi = dlo + 64;
-                    const float xl = total(0, gi, j), xh = total(1, gi, j);
-                    if (slot < a.nh + a.nkv) {
-                        bf16_t* dst = slot < a.nh ? a.qf + (size_t)slot * 8192 : a.kfresh + (size_t)(slot - a.nh) * 8192;
-                        const float c = bf2f(a.rcos[(size_t)ps * 64 + dlo]), sn = bf2f(a.rsin[(size_t)ps * 64 + dlo]);
-                        const float bl = bfr(xl), bh = bfr(xh);
-                        dst[rf_offset(tok, dlo)] = f2bf(bfr(bl * c) + bfr(-bh * sn));
-                        dst[rf_offset(tok, dhi)] = f2bf(bfr(bh * c) + bfr(bl * sn));
-                    } else {
-                        bf16_t* dst = a.vfresh + (size_t)(slot - a.nh - a.nkv) * 8192;
-                        dst[vf_offset(tok, dlo)] = f2bf(xl);
-                        dst[vf_offset(tok, dhi)] = f2bf(xh);
+                for (int j = 0; j < 4; ++j) {
+                    const int f = 8 * gi + 4 * hh + j;
+                    if (f < ra.nv[0]) {
+                        const int pr = ra.R * blockIdx.x + f, slot = pr >> 6, dlo = pr & 63, dhi = dlo + 64;
+                        const float xl = xl4[j], xh = xh4[j];
+                        if (slot < a.nh + a.nkv) {
+                            bf16_t* dst = slot < a.nh ? a.qf + (size_t)slot * 8192 : a.kfresh + (size_t)(slot - a.nh) * 8192;
+                            const float c = bf2f(a.rcos[(size_t)ps * 64 + dlo]), sn = bf2f(a.rsin[(size_t)ps * 64 + dlo]);
+                            const float bl = bfr(xl), bh = bfr(xh);
+                            dst[rf_offset(tok, dlo)] = f2bf(bfr(bl * c) + bfr(-bh * sn));
+                            dst[rf_offset(tok, dhi)] = f2bf(bfr(bh * c) + bfr(bl * sn));
+                        } else {
+                            bf16_t* dst = a.vfresh + (size_t)(slot - a.nh - a.nkv) * 8192;
+                            dst[vf_offset(tok, dlo)] = f2bf(xl);
+                            dst[vf_offset(tok, dhi)] = f2bf(xh);
+                        }
                     }
                 }
             }
@@ -685,15 +767,18 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
 #pragma unroll
             for (int sidx = 0; sidx < SL; ++sidx) {
                 const int sl = wave * SL + sidx, rb = sl >> 2, gi = sl & 3;
+                if (8 * gi + 4 * hh < ra.nv[rb]) {
+                    const f32x4 t4 = total4(rb, gi);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int f = 8 * gi + 4 * hh + j;
-                    if (f < ra.nv[rb]) {
-                        const bf16_t hv = f2bf(total(rb, gi, j));
-                        const int idx = ra.R * blockIdx.x + 32 * rb + f;
-                        if (a.logits) a.logits[(size_t)tok * a.N + idx] = hv;
-                        const float v = bf2f(hv);
-                        if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
+                    for (int j = 0; j < 4; ++j) {
+                        const int f = 8 * gi + 4 * hh + j;
+                        if (f < ra.nv[rb]) {
+                            const bf16_t hv = f2bf(t4[j]);
+                            const int idx = ra.R * blockIdx.x + 32 * rb + f;
+                            if (a.logits) a.logits[(size_t)tok * a.N + idx] = hv;
+                            const float v = bf2f(hv);
+                            if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
+                        }
                     }
                 }
             }
@@ -708,6 +793,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
             best = -INFINITY; bidx = 0x7fffffff;
         }
     }
+    if (stamp && lane == 0) stamp[2] = wall_clock64();
 }
 
 __global__ __launch_bounds__(256) void k_argmax_finalize(const float* __restrict__ cv, const int* __restrict__ ci,
@@ -1343,6 +1429,10 @@ __global__ __launch_bounds__(256) void k_moe_accum_all(const float* __restrict__
 // =============================================================================================
 // launchers
 // =============================================================================================
+// measurement knobs (la_debug_set, scripts/gpu_ab.py); 0 in production
+int g_la_dbg_noepi = 0;
+long long* g_la_dbg_times = nullptr;
+
 #define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 int lk_pack_weight(hipStream_t st, const void* w, const void* w2, int N, int K, int il, void* out) {
@@ -1374,21 +1464,21 @@ static int launch_gemm(hipStream_t st, const GemmArgs& a, int nblocks, int kspli
 int lk_gemm64_slab(hipStream_t st, const void* wp, const void* xp, int N, int K, int rbv, int ksplit, float* slabs,
                    const float* route_col) {
     const int rb = rbv & 0xff, variant = rbv >> 8;
-    GemmArgs a{}; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = N; a.slabs = slabs;
+    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = N; a.slabs = slabs;
     a.route_col = route_col;
     if (rb == 2 && (N % 64) == 0) return launch_gemm<2, EPI_SLAB>(st, a, N / 64, ksplit, variant);
     return launch_gemm<1, EPI_SLAB>(st, a, N / 32, ksplit, variant);
 }
 int lk_gemm64_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, void* act_xp, int variant,
                      const float* route_col) {
-    GemmArgs a{}; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = F; a.act_xp = (bf16_t*)act_xp;
+    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = F; a.act_xp = (bf16_t*)act_xp;
     a.route_col = route_col;
     return launch_gemm<2, EPI_SWIGLU>(st, a, F / 32, 1, variant);
 }
 int lk_gemm64_logits(hipStream_t st, const void* wp, const void* xp, int V, int K, int rbv, void* logits,
                      float* cv, int* ci) {
     const int rb = rbv & 0xff, variant = rbv >> 8;
-    GemmArgs a{}; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = V;
+    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = V;
     a.logits = (bf16_t*)logits; a.cand_val = cv; a.cand_idx = ci;
     if (rb == 2 && (V % 64) == 0) return launch_gemm<2, EPI_LOGITS>(st, a, V / 64, 1, variant);
     return launch_gemm<1, EPI_LOGITS>(st, a, V / 32, 1, variant);
@@ -1396,7 +1486,7 @@ int lk_gemm64_logits(hipStream_t st, const void* wp, const void* xp, int V, int 
 // QKV projection with the RoPE / fragment epilogue.  wp must be packed from the row-permuted [Wq;Wk;Wv] (lk_qkv_row_perm).
 int lk_gemm64_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int nkv, int K, const int* pos, const void* rcos,
                   const void* rsin, void* qf, void* kfresh, void* vfresh, int variant) {
-    GemmArgs a{}; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = (nh + 2 * nkv) * 128;
+    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = (nh + 2 * nkv) * 128;
     a.pos = pos; a.rcos = (const bf16_t*)rcos; a.rsin = (const bf16_t*)rsin;
     a.qf = (bf16_t*)qf; a.kfresh = (bf16_t*)kfresh; a.vfresh = (bf16_t*)vfresh; a.nh = nh; a.nkv = nkv;
     return launch_gemm<2, EPI_QKV>(st, a, a.N / 64, 1, variant);
@@ -1456,7 +1546,7 @@ static bool set_fused_norm(GemmRArgs& ra, const FusedNorm* fn, int n_wg) {
 }
 int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, int n_wg, void* act_xp,
                       const float* route_col, const FusedNorm* fn) {
-    GemmRArgs ra{}; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act_xp;
+    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act_xp;
     ra.g.route_col = route_col;
     ra.R = F / n_wg; if (F % n_wg || ra.R > 64 || ra.R <= 32) return -1;
     fill_nv(ra, ra.R, 2, 2);
@@ -1469,7 +1559,7 @@ int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int
     LAUNCH_CHECK(); return 0;
 }
 int lk_gemm64r_logits(hipStream_t st, const void* wp, const void* xp, int V, int K, int n_wg, void* logits, float* cv, int* ci) {
-    GemmRArgs ra{}; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = V;
+    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = V;
     ra.g.logits = (bf16_t*)logits; ra.g.cand_val = cv; ra.g.cand_idx = ci;
     ra.R = V / n_wg; if (V % n_wg || ra.R > 128 || ra.R <= 96) return -1;
     fill_nv(ra, ra.R, 4, 1);
@@ -1478,7 +1568,7 @@ int lk_gemm64r_logits(hipStream_t st, const void* wp, const void* xp, int V, int
 }
 int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int nkv, int K, int n_wg, const int* pos,
                    const void* rcos, const void* rsin, void* qf, void* kfresh, void* vfresh, const FusedNorm* fn) {
-    GemmRArgs ra{}; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = (nh + 2 * nkv) * 128;
+    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = (nh + 2 * nkv) * 128;
     ra.g.pos = pos; ra.g.rcos = (const bf16_t*)rcos; ra.g.rsin = (const bf16_t*)rsin;
     ra.g.qf = (bf16_t*)qf; ra.g.kfresh = (bf16_t*)kfresh; ra.g.vfresh = (bf16_t*)vfresh; ra.g.nh = nh; ra.g.nkv = nkv;
     const int pairs = (nh + 2 * nkv) * 64;
@@ -1488,9 +1578,9 @@ int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int n
     ra.boff[0] = 0; ra.boff[1] = ra.nvl[0] * 2 * ra.g.K16; ra.wg_chunks = 2 * ra.boff[1];
     if (set_fused_norm(ra, fn, n_wg)) {
         if (fn->n_slabs != 4) return -1;
-        k_gemm64r<2, EPI_QKV, 8, 8, 4><<<n_wg, 512, 8 * 2 * 4096, st>>>(ra);
+        k_gemm64r<2, EPI_QKV, 8, 8, 4><<<n_wg, 512, 2 * 8 * 2 * 4096, st>>>(ra);
     } else {
-        k_gemm64r<2, EPI_QKV, 8, 8><<<n_wg, 512, 8 * 2 * 4096, st>>>(ra);
+        k_gemm64r<2, EPI_QKV, 8, 8><<<n_wg, 512, 2 * 8 * 2 * 4096, st>>>(ra);
     }
     LAUNCH_CHECK(); return 0;
 }
@@ -1501,9 +1591,9 @@ int lk_gemm64r_init() {
                             (LA_ATT_PAR / 2) * 2 * 66 * 64 * sizeof(float)) != hipSuccess) return -1;
     hipError_t e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_SWIGLU, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_LOGITS, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<2, EPI_QKV, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 4096);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<2, EPI_QKV, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 2 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_SWIGLU, 4, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<2, EPI_QKV, 8, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 4096);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<2, EPI_QKV, 8, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 2 * 4096);
     if (e != hipSuccess) return (int)e;
     g_attr_done = true;
     return 0;
@@ -1671,7 +1761,7 @@ static int tree_attn_launch(hipStream_t st, AttnArgs a, int n_slots, void* attn_
 // ---- merged MoE launches: E experts in one grid ----
 int lk_gemm64r_swiglu_ex(hipStream_t st, const void* wp0, long w_stride, const void* xp, int F, int K, int n_wg, void* act0,
                          long act_stride, const float* route_w, int E) {
-    GemmRArgs ra{}; ra.g.wp = (const bf16_t*)wp0; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act0;
+    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp0; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act0;
     ra.g.route_col = route_w; ra.g.ex_on = 1; ra.g.ex_w = w_stride; ra.g.ex_x = 0; ra.g.ex_act = act_stride;
     ra.R = F / n_wg; if (F % n_wg || ra.R > 64 || ra.R <= 32 || E < 1 || E > LA_MOE_MAX_E) return -1;
     fill_nv(ra, ra.R, 2, 2);
@@ -1680,7 +1770,7 @@ int lk_gemm64r_swiglu_ex(hipStream_t st, const void* wp0, long w_stride, const v
 }
 int lk_gemm64_swiglu_ex(hipStream_t st, const void* wp0, long w_stride, const void* xp, int F, int K, void* act0, long act_stride,
                         const float* route_w, int E) {
-    GemmArgs a{}; a.wp = (const bf16_t*)wp0; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = F; a.act_xp = (bf16_t*)act0;
+    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp0; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = F; a.act_xp = (bf16_t*)act0;
     a.route_col = route_w; a.ex_on = 1; a.ex_w = w_stride; a.ex_act = act_stride;
     if (E < 1 || E > LA_MOE_MAX_E) return -1;
     k_gemm64<2, EPI_SWIGLU, 8, 4><<<dim3(F / 32, 1, E), 256, 0, st>>>(a);
@@ -1689,7 +1779,7 @@ int lk_gemm64_swiglu_ex(hipStream_t st, const void* wp0, long w_stride, const vo
 int lk_gemm64_slab_ex(hipStream_t st, const void* wp0, long w_stride, const void* xp0, long x_stride, int N, int K, int rbv, int ksplit,
                       float* slabs0, long slab_stride, const float* route_w, int E) {
     const int rb = rbv & 0xff;
-    GemmArgs a{}; a.wp = (const bf16_t*)wp0; a.xp = (const bf16_t*)xp0; a.K16 = K / 16; a.N = N; a.slabs = slabs0;
+    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp0; a.xp = (const bf16_t*)xp0; a.K16 = K / 16; a.N = N; a.slabs = slabs0;
     a.route_col = route_w; a.ex_on = 1; a.ex_w = w_stride; a.ex_x = x_stride; a.ex_slab = slab_stride;
     if (E < 1 || E > LA_MOE_MAX_E) return -1;
     if (rb == 2 && (N % 64) == 0) k_gemm64<2, EPI_SLAB, 8, 4><<<dim3(N / 64, ksplit, E), 256, 0, st>>>(a);
