@@ -16,9 +16,11 @@ extern "C" {
 int la_abi_version(void) { return LA_ABI_VERSION; }
 const char* la_last_error(void) { return g_err.c_str(); }
 extern int g_la_dbg_noepi;
+extern int g_la_kskew;
 extern long long* g_la_dbg_times;
 int la_debug_set(int key, int value) {
     if (key == 0) { g_la_dbg_noepi = value; return LA_OK; }
+    if (key == 1 && value >= 0 && value <= 64) { g_la_kskew = value; return LA_OK; }
     return LA_E_ARG;
 }
 int la_debug_set_ptr(int key, void* d_ptr) {

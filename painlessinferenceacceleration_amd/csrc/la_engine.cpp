@@ -76,7 +76,7 @@ static void resolve_cfg(la_llama* m) {
     // workgroups) beat everything else; see DESIGN.md section 4
     m->qkv_rb = pick(c.gemm_cfg[0], 2);
     m->qkv_ks = pick(c.gemm_cfg[1], 1);
-    m->o_rb = pick(c.gemm_cfg[2], 2);
+    m->o_rb = pick(c.gemm_cfg[2], 2 | (3 << 8));      // o_proj: 8 waves x 8 tile-sets (the whole K slice in flight at once): 10.8 -> 9.4 us
     m->o_ks = pick(c.gemm_cfg[3], 4);
     m->down_rb = pick(c.gemm_cfg[4], 2);
     m->down_ks = pick(c.gemm_cfg[5], 4);

@@ -277,12 +277,34 @@ struct GemmArgs {
     // outputs and split-K slabs are equally spaced; expert e uses route_col + e and returns at once when no row routes to it
     int ex_on;
     long ex_w, ex_x, ex_act, ex_slab;      // element strides per expert (weights, x operand, act_xp, slabs)
+    int kskew;          // 8-wave kernels: share (1/64ths) of the K range given to waves 0..3; 0 = even split (see wave_krange)
     int dbg_noepi;      // measurement aid (scripts/gpu_ab.py): return after the streaming loop, before the reduction/epilogue
     long long* dbg_times;   // measurement aid: [workgroup][wave][4] wall_clock64() at entry / loop end / exit (null in production)
 };
 
 __device__ __forceinline__ bool expert_unused(const float* route_col) {
     return route_col != nullptr && __ballot(route_col[(threadIdx.x & 63) * LA_MOE_MAX_E] != 0.f) == 0ull;
+}
+
+// K range of one wave.  Measured on MI355X (scripts/gpu_ab.py timeline): with two waves per SIMD the wave in hardware slot 0
+// (waves 0..3 of a 512-thread workgroup) is served ~2.2x faster than its SIMD partner while both are streaming, so an even
+// split leaves the partner alone for the last third of the launch with half the bytes in flight.  kskew/64 of the k-tiles go
+// to waves 0..3 so that both halves finish together; the split is static, i.e. the summation order stays deterministic.
+template <int NW>
+__device__ __forceinline__ void wave_krange(int t0, int twg, int wave, int kskew, int& wb, int& cnt) {
+    if (NW == 8 && kskew > 0) {
+        int told = (int)(((long)twg * kskew) >> 6);
+        told = told > twg ? twg : told;
+        const int grp = wave >> 2, wi = wave & 3;
+        const int tg = grp ? twg - told : told, base = grp ? told : 0;
+        const int q = tg >> 2, r = tg & 3;
+        wb = t0 + base + wi * q + (wi < r ? wi : r);
+        cnt = q + (wi < r ? 1 : 0);
+    } else {
+        const int q = twg / NW, r = twg - q * NW;
+        wb = t0 + wave * q + (wave < r ? wave : r);
+        cnt = q + (wave < r ? 1 : 0);
+    }
 }
 
 template <int RB, int EPI, int D, int NW>
@@ -294,14 +316,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nb0 = blockIdx.x * RB;
     const int ksplit = gridDim.y, ks = blockIdx.y;
-    long long* const stamp = a.dbg_times ? a.dbg_times + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 4 : nullptr;
-    if (stamp && lane == 0) stamp[0] = wall_clock64();
+    long long* const stamp = a.dbg_times ? a.dbg_times + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8 : nullptr;
+    if (stamp && lane == 0) { stamp[0] = wall_clock64(); stamp[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
     const int t0 = (int)(((long)a.K16 * ks) / ksplit);
     const int t1 = (int)(((long)a.K16 * (ks + 1)) / ksplit);
     // this wave's contiguous k-tile range
-    const int twg = t1 - t0, q = twg / NW, r = twg - q * NW;
-    const int wb = t0 + wave * q + (wave < r ? wave : r);
-    const int cnt = q + (wave < r ? 1 : 0);
+    int wb, cnt;
+    wave_krange<NW>(t0, t1 - t0, wave, a.kskew, wb, cnt);
     const int ngroups = (cnt + D - 1) / D;            // groups of D tiles; the last one may be partial
     const int last_valid = cnt - (ngroups - 1) * D;   // valid slots in the last group (1..D)
 
@@ -339,6 +360,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
             fb[d][1] = xbase[xoff + dd * 128 + 64];
         }
         for (int g = 1; g < ngroups; ++g) {
+            if (stamp && lane == 0 && g == (ngroups >> 1)) stamp[3] = wall_clock64();
             const int nv = (g == ngroups - 1) ? last_valid : D;   // valid slots of the group being fetched
 #pragma unroll
             for (int d = 0; d < D; ++d) {
@@ -537,11 +559,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
     if (expert_unused(a.route_col ? a.route_col + ex : nullptr)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    long long* const stamp = a.dbg_times ? a.dbg_times + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 4 : nullptr;
-    if (stamp && lane == 0) stamp[0] = wall_clock64();
-    const int twg = a.K16, q = twg / NW, r = twg - q * NW;
-    const int wb = wave * q + (wave < r ? wave : r);
-    const int cnt = q + (wave < r ? 1 : 0);
+    long long* const stamp = a.dbg_times ? a.dbg_times + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8 : nullptr;
+    if (stamp && lane == 0) { stamp[0] = wall_clock64(); stamp[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
+    int wb, cnt;
+    wave_krange<NW>(0, a.K16, wave, a.kskew, wb, cnt);
     const int ngroups = (cnt + D - 1) / D;
     const int last_valid = cnt - (ngroups - 1) * D;
     const bf16x8* __restrict__ wbase = (const bf16x8*)(a.wp + (size_t)ex * a.ex_w);
@@ -605,6 +626,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
             }
         }
         for (int g = 1; g < ngroups; ++g) {
+            if (stamp && lane == 0 && g == (ngroups >> 1)) stamp[3] = wall_clock64();
             const int nv2 = (g == ngroups - 1) ? last_valid : D;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
@@ -993,17 +1015,20 @@ struct AttnArgs {
     const int* nkeys_b;   // [LA_MAX_SEQ] committed keys per slot
     int slot_tiles;       // 32-key tiles per slot region of the main cache
     int window;           // > 0: sliding-window attention, a row at position p sees committed keys j with p - j <= window
+    long long* dbg_times; // measurement aid (scripts/gpu_ab.py): [workgroup][wave][8] wall-clock stamps, null in production
 };
 
 #define LA_NEG (-1.0e30f)
 
 #define LA_ATT_PAR 4      // key-tile parities per workgroup (waves = 2 token blocks x LA_ATT_PAR)
 __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float mgbuf[];   // [LA_ATT_PAR/2][2][66][64] merge buffer
+    extern __shared__ __attribute__((aligned(16))) float mgbuf[];   // [LA_ATT_PAR][2][66][64] merge buffer (132 KiB)
     const int h = blockIdx.x, sp = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tb = wave & 1, par = wave >> 1;      // par in [0, LA_ATT_PAR)
+    long long* const stamp = a.dbg_times ? a.dbg_times + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (2 * LA_ATT_PAR) + wave) * 8 : nullptr;
+    if (stamp && lane == 0) stamp[0] = wall_clock64();
     const int hk = h / (a.nh / a.nkv);
     const int KB = a.max_keys >> 5;
     int nkeys, tile0 = 0;
@@ -1107,6 +1132,7 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) kA[s] = kt[s * 64 + lane];
         }
+        if (stamp && lane == 0) stamp[1] = wall_clock64();
         while (it < i1) {
             int nx = it + LA_ATT_PAR;
             if (nx < i1) {
@@ -1115,6 +1141,7 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
                 for (int s = 0; s < 8; ++s) kB[s] = kt[s * 64 + lane];
             }
             tile(it, kA);
+            if (stamp && lane == 0 && it < i0 + LA_ATT_PAR) stamp[2] = wall_clock64();
             it = nx;
             if (it >= i1) break;
             nx = it + LA_ATT_PAR;
@@ -1128,47 +1155,55 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
         }
     }
 
-    // merge the key-parity waves of each token block: fixed-order tree (par p+half -> p), wave par==0 writes
+    // Merge the key-parity waves of each token block in ONE LDS round: every wave parks (O, m, l), one barrier, then wave
+    // (tb, par) finishes head-dim block db = par of its token block (fixed order p = 0..LA_ATT_PAR-1 -> deterministic) and
+    // stores that quarter of the split partial itself: all 8 waves take part in the merge and in the store.
+    static_assert(LA_ATT_PAR == 4, "one head-dim block (of 4) per key-parity wave");
+    if (stamp && lane == 0) stamp[3] = wall_clock64();
+    {
+        float* mg = mgbuf + (size_t)((par * 2 + tb) * 66) * 64;
 #pragma unroll
-    for (int half = LA_ATT_PAR / 2; half >= 1; half >>= 1) {
-        float* mg = mgbuf + (size_t)(((par - half) * 2 + tb) * 66) * 64;
-        if (par >= half && par < 2 * half) {
+        for (int db = 0; db < 4; ++db)
 #pragma unroll
-            for (int db = 0; db < 4; ++db)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) mg[(db * 16 + i) * 64 + lane] = o[db][i];
-            mg[64 * 64 + lane] = m;
-            mg[65 * 64 + lane] = l;
-        }
-        __syncthreads();
-        if (par < half) {
-            const float* mr = mgbuf + (size_t)((par * 2 + tb) * 66) * 64;
-            const float m1 = mr[64 * 64 + lane], l1 = mr[65 * 64 + lane];
-            const float M = fmaxf(m, m1);
-            const float a0 = __expf(m - M), a1 = __expf(m1 - M);
-            l = l * a0 + l1 * a1;
-#pragma unroll
-            for (int db = 0; db < 4; ++db)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) o[db][i] = o[db][i] * a0 + mr[(db * 16 + i) * 64 + lane] * a1;
-            m = M;
-        }
-        if (half > 1) __syncthreads();
+            for (int i = 0; i < 16; ++i) mg[(db * 16 + i) * 64 + lane] = o[db][i];
+        mg[64 * 64 + lane] = m;
+        mg[65 * 64 + lane] = l;
     }
-    if (par != 0 || !mine) return;
+    __syncthreads();
+    float mp[LA_ATT_PAR], wp[LA_ATT_PAR];
+    float M = LA_NEG, L = 0.f;
+#pragma unroll
+    for (int p = 0; p < LA_ATT_PAR; ++p) {
+        mp[p] = mgbuf[(size_t)(((p * 2 + tb) * 66) + 64) * 64 + lane];
+        M = fmaxf(M, mp[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < LA_ATT_PAR; ++p) {
+        wp[p] = __expf(mp[p] - M);
+        L += mgbuf[(size_t)(((p * 2 + tb) * 66) + 65) * 64 + lane] * wp[p];
+    }
+    float od[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float v = 0.f;
+#pragma unroll
+        for (int p = 0; p < LA_ATT_PAR; ++p) v += mgbuf[(size_t)(((p * 2 + tb) * 66) + par * 16 + i) * 64 + lane] * wp[p];
+        od[i] = v;
+    }
+    if (stamp && lane == 0) stamp[4] = wall_clock64();
+    if (!mine) return;
     const int tok = tb * 32 + (lane & 31);
     float* op = a.opart + (((size_t)h * a.nsplit + sp) * LA_TB + tok) * 128;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 v = {o[db][4 * g], o[db][4 * g + 1], o[db][4 * g + 2], o[db][4 * g + 3]};
-            *(f32x4*)(op + db * 32 + 8 * g + 4 * hh) = v;
-        }
-    if (hh == 0) {
-        a.mpart[((size_t)h * a.nsplit + sp) * LA_TB + tok] = m;
-        a.lpart[((size_t)h * a.nsplit + sp) * LA_TB + tok] = l;
+    for (int g = 0; g < 4; ++g) {
+        f32x4 v = {od[4 * g], od[4 * g + 1], od[4 * g + 2], od[4 * g + 3]};
+        *(f32x4*)(op + par * 32 + 8 * g + 4 * hh) = v;
     }
+    if (hh == 0 && par == 0) {
+        a.mpart[((size_t)h * a.nsplit + sp) * LA_TB + tok] = M;
+        a.lpart[((size_t)h * a.nsplit + sp) * LA_TB + tok] = L;
+    }
+    if (stamp && lane == 0) stamp[5] = wall_clock64();
 }
 
 // merge key splits, normalise, round to bf16 (attn_output dtype) and emit the packed operand of o_proj
@@ -1431,6 +1466,7 @@ __global__ __launch_bounds__(256) void k_moe_accum_all(const float* __restrict__
 // =============================================================================================
 // measurement knobs (la_debug_set, scripts/gpu_ab.py); 0 in production
 int g_la_dbg_noepi = 0;
+int g_la_kskew = 0;           // K share of waves 0..3 in 1/64ths (8-wave GEMMs); set before the step graph is captured
 long long* g_la_dbg_times = nullptr;
 
 #define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -1456,6 +1492,8 @@ static int launch_gemm(hipStream_t st, const GemmArgs& a, int nblocks, int kspli
     }
     switch (variant) {
         case 2: k_gemm64<RB, EPI, 6, 4><<<g, 256, 0, st>>>(a); break;
+        case 3: if constexpr (EPI == EPI_SLAB) { k_gemm64<RB, EPI, 8, 8><<<g, 512, 0, st>>>(a); break; }     // 8 waves x 8 tile-sets
+        case 4: if constexpr (EPI == EPI_SLAB) { k_gemm64<RB, EPI, 4, 8><<<g, 512, 0, st>>>(a); break; }     // 8 waves x 4 tile-sets
         default: k_gemm64<RB, EPI, 8, 4><<<g, 256, 0, st>>>(a); break;
     }
     LAUNCH_CHECK(); return 0;
@@ -1464,21 +1502,21 @@ static int launch_gemm(hipStream_t st, const GemmArgs& a, int nblocks, int kspli
 int lk_gemm64_slab(hipStream_t st, const void* wp, const void* xp, int N, int K, int rbv, int ksplit, float* slabs,
                    const float* route_col) {
     const int rb = rbv & 0xff, variant = rbv >> 8;
-    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = N; a.slabs = slabs;
+    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.kskew = g_la_kskew; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = N; a.slabs = slabs;
     a.route_col = route_col;
     if (rb == 2 && (N % 64) == 0) return launch_gemm<2, EPI_SLAB>(st, a, N / 64, ksplit, variant);
     return launch_gemm<1, EPI_SLAB>(st, a, N / 32, ksplit, variant);
 }
 int lk_gemm64_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, void* act_xp, int variant,
                      const float* route_col) {
-    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = F; a.act_xp = (bf16_t*)act_xp;
+    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.kskew = g_la_kskew; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = F; a.act_xp = (bf16_t*)act_xp;
     a.route_col = route_col;
     return launch_gemm<2, EPI_SWIGLU>(st, a, F / 32, 1, variant);
 }
 int lk_gemm64_logits(hipStream_t st, const void* wp, const void* xp, int V, int K, int rbv, void* logits,
                      float* cv, int* ci) {
     const int rb = rbv & 0xff, variant = rbv >> 8;
-    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = V;
+    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.kskew = g_la_kskew; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = V;
     a.logits = (bf16_t*)logits; a.cand_val = cv; a.cand_idx = ci;
     if (rb == 2 && (V % 64) == 0) return launch_gemm<2, EPI_LOGITS>(st, a, V / 64, 1, variant);
     return launch_gemm<1, EPI_LOGITS>(st, a, V / 32, 1, variant);
@@ -1486,7 +1524,7 @@ int lk_gemm64_logits(hipStream_t st, const void* wp, const void* xp, int V, int 
 // QKV projection with the RoPE / fragment epilogue.  wp must be packed from the row-permuted [Wq;Wk;Wv] (lk_qkv_row_perm).
 int lk_gemm64_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int nkv, int K, const int* pos, const void* rcos,
                   const void* rsin, void* qf, void* kfresh, void* vfresh, int variant) {
-    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = (nh + 2 * nkv) * 128;
+    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.kskew = g_la_kskew; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = (nh + 2 * nkv) * 128;
     a.pos = pos; a.rcos = (const bf16_t*)rcos; a.rsin = (const bf16_t*)rsin;
     a.qf = (bf16_t*)qf; a.kfresh = (bf16_t*)kfresh; a.vfresh = (bf16_t*)vfresh; a.nh = nh; a.nkv = nkv;
     return launch_gemm<2, EPI_QKV>(st, a, a.N / 64, 1, variant);
@@ -1546,7 +1584,7 @@ static bool set_fused_norm(GemmRArgs& ra, const FusedNorm* fn, int n_wg) {
 }
 int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, int n_wg, void* act_xp,
                       const float* route_col, const FusedNorm* fn) {
-    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act_xp;
+    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.kskew = g_la_kskew; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act_xp;
     ra.g.route_col = route_col;
     ra.R = F / n_wg; if (F % n_wg || ra.R > 64 || ra.R <= 32) return -1;
     fill_nv(ra, ra.R, 2, 2);
@@ -1559,7 +1597,7 @@ int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int
     LAUNCH_CHECK(); return 0;
 }
 int lk_gemm64r_logits(hipStream_t st, const void* wp, const void* xp, int V, int K, int n_wg, void* logits, float* cv, int* ci) {
-    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = V;
+    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.kskew = g_la_kskew; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = V;
     ra.g.logits = (bf16_t*)logits; ra.g.cand_val = cv; ra.g.cand_idx = ci;
     ra.R = V / n_wg; if (V % n_wg || ra.R > 128 || ra.R <= 96) return -1;
     fill_nv(ra, ra.R, 4, 1);
@@ -1568,7 +1606,7 @@ int lk_gemm64r_logits(hipStream_t st, const void* wp, const void* xp, int V, int
 }
 int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int nkv, int K, int n_wg, const int* pos,
                    const void* rcos, const void* rsin, void* qf, void* kfresh, void* vfresh, const FusedNorm* fn) {
-    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = (nh + 2 * nkv) * 128;
+    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.kskew = g_la_kskew; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = (nh + 2 * nkv) * 128;
     ra.g.pos = pos; ra.g.rcos = (const bf16_t*)rcos; ra.g.rsin = (const bf16_t*)rsin;
     ra.g.qf = (bf16_t*)qf; ra.g.kfresh = (bf16_t*)kfresh; ra.g.vfresh = (bf16_t*)vfresh; ra.g.nh = nh; ra.g.nkv = nkv;
     const int pairs = (nh + 2 * nkv) * 64;
@@ -1588,7 +1626,7 @@ static bool g_attr_done = false;
 int lk_gemm64r_init() {
     if (g_attr_done) return 0;
     if (hipFuncSetAttribute((const void*)k_tree_attn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (LA_ATT_PAR / 2) * 2 * 66 * 64 * sizeof(float)) != hipSuccess) return -1;
+                            2 * LA_ATT_PAR * 66 * 64 * sizeof(float)) != hipSuccess) return -1;
     hipError_t e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_SWIGLU, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_LOGITS, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<2, EPI_QKV, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 2 * 4096);
@@ -1718,6 +1756,7 @@ int lk_tree_attn_b(hipStream_t st, const void* qf, const void* kmain, const void
                    int n_slots, int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window) {
     if (n_slots < 1 || n_slots > LA_MAX_SEQ || (slot_keys & 31)) return -1;
     AttnArgs a{};
+    a.dbg_times = g_la_dbg_times;
     a.window = window;
     a.qf = (const bf16_t*)qf; a.kmain = (const bf16_t*)kmain; a.vmain = (const bf16_t*)vmain;
     a.kfresh = (const bf16_t*)kfresh; a.vfresh = (const bf16_t*)vfresh;
@@ -1732,6 +1771,7 @@ int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* 
                  const void* vfresh, const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys,
                  int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window) {
     AttnArgs a{};
+    a.dbg_times = g_la_dbg_times;
     a.window = window;
     a.qf = (const bf16_t*)qf; a.kmain = (const bf16_t*)kmain; a.vmain = (const bf16_t*)vmain;
     a.kfresh = (const bf16_t*)kfresh; a.vfresh = (const bf16_t*)vfresh;
@@ -1746,7 +1786,7 @@ static int tree_attn_launch(hipStream_t st, AttnArgs a, int n_slots, void* attn_
     const int nh = a.nh, nsplit = a.nsplit;
     float *opart = a.opart, *mpart = a.mpart, *lpart = a.lpart;
     if (lk_gemm64r_init() != 0) return -1;
-    k_tree_attn<<<dim3(nh, nsplit, n_slots), 2 * LA_ATT_PAR * 64, (LA_ATT_PAR / 2) * 2 * 66 * 64 * sizeof(float), st>>>(a);
+    k_tree_attn<<<dim3(nh, nsplit, n_slots), 2 * LA_ATT_PAR * 64, 2 * LA_ATT_PAR * 66 * 64 * sizeof(float), st>>>(a);
     LAUNCH_CHECK();
     int total = nh * LA_TB * 16;
 #define AC(NS) k_attn_combine<NS><<<(total + 255) / 256, 256, 0, st>>>(opart, mpart, lpart, nh, a.seq, (bf16_t*)attn_xp)
@@ -1761,7 +1801,7 @@ static int tree_attn_launch(hipStream_t st, AttnArgs a, int n_slots, void* attn_
 // ---- merged MoE launches: E experts in one grid ----
 int lk_gemm64r_swiglu_ex(hipStream_t st, const void* wp0, long w_stride, const void* xp, int F, int K, int n_wg, void* act0,
                          long act_stride, const float* route_w, int E) {
-    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp0; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act0;
+    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.kskew = g_la_kskew; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp0; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act0;
     ra.g.route_col = route_w; ra.g.ex_on = 1; ra.g.ex_w = w_stride; ra.g.ex_x = 0; ra.g.ex_act = act_stride;
     ra.R = F / n_wg; if (F % n_wg || ra.R > 64 || ra.R <= 32 || E < 1 || E > LA_MOE_MAX_E) return -1;
     fill_nv(ra, ra.R, 2, 2);
@@ -1770,7 +1810,7 @@ int lk_gemm64r_swiglu_ex(hipStream_t st, const void* wp0, long w_stride, const v
 }
 int lk_gemm64_swiglu_ex(hipStream_t st, const void* wp0, long w_stride, const void* xp, int F, int K, void* act0, long act_stride,
                         const float* route_w, int E) {
-    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp0; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = F; a.act_xp = (bf16_t*)act0;
+    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.kskew = g_la_kskew; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp0; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = F; a.act_xp = (bf16_t*)act0;
     a.route_col = route_w; a.ex_on = 1; a.ex_w = w_stride; a.ex_act = act_stride;
     if (E < 1 || E > LA_MOE_MAX_E) return -1;
     k_gemm64<2, EPI_SWIGLU, 8, 4><<<dim3(F / 32, 1, E), 256, 0, st>>>(a);
@@ -1779,7 +1819,7 @@ int lk_gemm64_swiglu_ex(hipStream_t st, const void* wp0, long w_stride, const vo
 int lk_gemm64_slab_ex(hipStream_t st, const void* wp0, long w_stride, const void* xp0, long x_stride, int N, int K, int rbv, int ksplit,
                       float* slabs0, long slab_stride, const float* route_w, int E) {
     const int rb = rbv & 0xff;
-    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp0; a.xp = (const bf16_t*)xp0; a.K16 = K / 16; a.N = N; a.slabs = slabs0;
+    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.kskew = g_la_kskew; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp0; a.xp = (const bf16_t*)xp0; a.K16 = K / 16; a.N = N; a.slabs = slabs0;
     a.route_col = route_w; a.ex_on = 1; a.ex_w = w_stride; a.ex_x = x_stride; a.ex_slab = slab_stride;
     if (E < 1 || E > LA_MOE_MAX_E) return -1;
     if (rb == 2 && (N % 64) == 0) k_gemm64<2, EPI_SLAB, 8, 4><<<dim3(N / 64, ksplit, E), 256, 0, st>>>(a);

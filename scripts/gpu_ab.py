@@ -52,13 +52,14 @@ def both(name, fn, wbytes):
 def timeline(name, fn, n_wg, n_waves, reps=6):
     """Per-wave wall-clock stamps of ONE launch (the kernels write wall_clock64() at entry / end of the streaming loop /
     exit): dispatch skew, spread of the loop ends (CU imbalance) and the length of the epilogue."""
-    buf = torch.zeros(n_wg * n_waves * 4, dtype=torch.int64, device=DEV)
+    buf = torch.zeros(n_wg * n_waves * 8, dtype=torch.int64, device=DEV)
     check(lib.la_debug_set_ptr(0, ptr(buf)), 'debug_set_ptr')
     for i in range(reps):
         fn(i)
     torch.cuda.synchronize()
     check(lib.la_debug_set_ptr(0, None), 'debug_set_ptr')
-    t = buf.cpu().numpy().reshape(n_wg, n_waves, 4).astype(np.float64)
+    raw = buf.cpu().numpy().reshape(n_wg, n_waves, 8)
+    t = raw.astype(np.float64)
     rate = 100.0          # wall_clock64 ticks per us (100 MHz constant clock)
     t0, t1, t2 = t[:, :, 0], t[:, :, 1], t[:, :, 2]
     base = t0.min()
@@ -74,6 +75,24 @@ def timeline(name, fn, n_wg, n_waves, reps=6):
     per_xcd = [dur[x::8].mean() for x in range(8)]
     print('   loop duration per wave: mean %.2f  min %.2f  max %.2f ; by XCD (wg %% 8): %s' %
           (dur.mean(), dur.min(), dur.max(), ' '.join(f'{v:.2f}' for v in per_xcd)))
+    mid = (t[:, :, 3] - t0) / rate
+    print('   by wave index: loop duration ' + ' '.join(f'{dur[:, w].mean():.2f}' for w in range(n_waves)) +
+          ' | first half ' + ' '.join(f'{mid[:, w].mean():.2f}' for w in range(n_waves)))
+    hw = raw[:, :, 4]
+    simd = (hw >> 4) & 3
+    wslot = hw & 15
+    print('   by SIMD id: ' + ' '.join(f'{s_}:{dur[simd == s_].mean():.2f}(n={int((simd == s_).sum())})' for s_ in range(4)))
+    print('   by hw wave slot: ' + ' '.join(f'{k}:{dur[wslot == k].mean():.2f}' for k in sorted(set(wslot.reshape(-1).tolist()))))
+    # within a SIMD of one WG: the wave that entered first vs second
+    first, second = [], []
+    for w_ in range(n_wg):
+        for s_ in range(4):
+            idx = [k for k in range(n_waves) if simd[w_, k] == s_]
+            if len(idx) == 2:
+                a_, b_ = sorted(idx, key=lambda k: t0[w_, k])
+                first.append(dur[w_, a_]); second.append(dur[w_, b_])
+    if first:
+        print(f'   two waves on one SIMD: earlier-entered {np.mean(first):.2f} us, later-entered {np.mean(second):.2f} us (pairs {len(first)})')
     wg_end = (t1.max(axis=1) - base) / rate
     order = np.argsort(wg_end)
     print('   slowest WGs (id:loop-end us): ' + ' '.join(f'{i}:{wg_end[i]:.2f}' for i in order[-8:]), flush=True)
@@ -124,6 +143,59 @@ def gemms(hidden=4096, ffn=11008, nh=32, nkv=32, vocab=32000):
                                                                             ptr(cv), ptr(ci)), vocab * hidden * 2)
 
 
+def sweep(hidden=4096, ffn=11008, nh=32, nkv=32, vocab=32000):
+    """K-skew of the 8-wave kernels (la_debug_set key 1) and the 8-wave variants of the split-K slab GEMMs."""
+    g = torch.Generator(device=DEV).manual_seed(1)
+
+    def rnd(n, k):
+        return (torch.randn(n, k, generator=g, device=DEV, dtype=torch.float32) * 0.05).to(torch.bfloat16)
+    xp = gu.pack_x(rnd(64, hidden))
+    wps = [gu.pack_planned(1, [rnd(ffn, hidden), rnd(ffn, hidden)], NWG) for _ in range(NBUF)]
+    act = torch.zeros(64 * ffn, dtype=torch.bfloat16, device=DEV)
+    for ks in (0, 36, 40, 42, 44, 46, 48):
+        check(lib.la_debug_set(1, ks), 'kskew')
+        us = timeit(lambda i: lib.la_gemm64r_swiglu(sp(), ptr(wps[i % NBUF]), ptr(xp), ffn, hidden, NWG, ptr(act)))
+        print(f'gate/up kskew={ks:2d}: {us:7.2f} us  {2 * ffn * hidden * 2 / us / 1e3:7.1f} GB/s', flush=True)
+    check(lib.la_debug_set(1, 44), 'kskew')
+    timeline('gate/up kskew=44', lambda i: lib.la_gemm64r_swiglu(sp(), ptr(wps[i % NBUF]), ptr(xp), ffn, hidden, NWG, ptr(act)), NWG, 8)
+    del wps
+    N = (nh + 2 * nkv) * 128
+    wps = [gu.pack_planned(2, [rnd(N, hidden)], NWG) for _ in range(NBUF)]
+    pos = torch.arange(64, device=DEV, dtype=torch.int32) + 600
+    rc, rs_ = rope_tables(128, 2048, 10000.0, DEV)
+    qf = torch.zeros(nh * 8192, dtype=torch.bfloat16, device=DEV)
+    kf = torch.zeros(nkv * 8192, dtype=torch.bfloat16, device=DEV)
+    vf = torch.zeros(nkv * 8192, dtype=torch.bfloat16, device=DEV)
+    for ks in (0, 36, 40, 42, 44, 46, 48):
+        check(lib.la_debug_set(1, ks), 'kskew')
+        us = timeit(lambda i: lib.la_gemm64r_qkv(sp(), ptr(wps[i % NBUF]), ptr(xp), nh, nkv, hidden, NWG, ptr(pos), ptr(rc), ptr(rs_), ptr(qf),
+                                                 ptr(kf), ptr(vf)))
+        print(f'qkv     kskew={ks:2d}: {us:7.2f} us  {N * hidden * 2 / us / 1e3:7.1f} GB/s', flush=True)
+    del wps
+    wps = [gu.pack_planned(0, [rnd(vocab, hidden)], NWG) for _ in range(NBUF)]
+    logits = torch.zeros(64 * vocab, dtype=torch.bfloat16, device=DEV)
+    cv = torch.zeros(NWG * 8 * 64, dtype=torch.float32, device=DEV)
+    ci = torch.zeros(NWG * 8 * 64, dtype=torch.int32, device=DEV)
+    for ks in (0, 40, 44, 48):
+        check(lib.la_debug_set(1, ks), 'kskew')
+        us = timeit(lambda i: lib.la_gemm64r_logits(sp(), ptr(wps[i % NBUF]), ptr(xp), vocab, hidden, NWG, ptr(logits), ptr(cv), ptr(ci)))
+        print(f'lm_head kskew={ks:2d}: {us:7.2f} us  {vocab * hidden * 2 / us / 1e3:7.1f} GB/s', flush=True)
+    del wps
+    slabs = torch.zeros(8 * 64 * hidden, dtype=torch.float32, device=DEV)
+    for name, n, k in (('o_proj', hidden, nh * 128), ('down', hidden, ffn)):
+        wps = [gu.pack_weight(rnd(n, k)) for _ in range(NBUF * (3 if k <= 4096 else 1))]
+        xk = gu.pack_x(rnd(64, k))
+        nb = len(wps)
+        for var, ksplit in ((0, 4), (3, 4), (4, 4), (3, 2), (3, 8)):
+            for ks in ((0,) if var == 0 else (0, 40, 44, 48)):
+                check(lib.la_debug_set(1, ks), 'kskew')
+                rbv = 2 | (var << 8)
+                us = timeit(lambda i: lib.la_gemm64_slab(sp(), ptr(wps[i % nb]), ptr(xk), n, k, rbv, ksplit, ptr(slabs)))
+                print(f'{name:6s} variant={var} ksplit={ksplit} kskew={ks:2d}: {us:7.2f} us  {n * k * 2 / us / 1e3:7.1f} GB/s', flush=True)
+        del wps
+    check(lib.la_debug_set(1, 0), 'kskew')
+
+
 def small(hidden=4096, nh=32, nkv=32):
     g = torch.Generator(device=DEV).manual_seed(2)
     h = torch.randn(64, hidden, generator=g, device=DEV).to(torch.bfloat16)
@@ -153,6 +225,30 @@ def small(hidden=4096, nh=32, nkv=32):
                                                    nh, nkv, max_keys, nsplit, ptr(opart), ptr(mpart), ptr(lpart), ptr(out)), 40)
             kvb = 2 * nkv * 128 * 2 * (nkeys + 64)
             print(f'tree_attn(+combine) nkeys={nkeys} nsplit={nsplit}: {us:.2f} us  ({kvb / us / 1e3:.0f} GB/s KV)', flush=True)
+    # phase stamps of the attention kernel at the bench context length
+    nkeys, nsplit = 640, 8
+    state = torch.zeros(_lib.LA_ST_WORDS, dtype=torch.int32, device=DEV)
+    state[0] = nkeys
+    opart = torch.zeros(nh * nsplit * 64 * 128, dtype=torch.float32, device=DEV)
+    mpart = torch.zeros(nh * nsplit * 64, dtype=torch.float32, device=DEV)
+    lpart = torch.zeros_like(mpart)
+    nwg, nwv = nh * nsplit, 8
+    buf = torch.zeros(nwg * nwv * 8, dtype=torch.int64, device=DEV)
+    check(lib.la_debug_set_ptr(0, ptr(buf)), 'debug_set_ptr')
+    for i in range(6):
+        lib.la_tree_attn(sp(), ptr(qf), ptr(km[i % NL]), ptr(vm[i % NL]), ptr(kf), ptr(vf), ptr(rm), ptr(state), nh, nkv, max_keys, nsplit,
+                         ptr(opart), ptr(mpart), ptr(lpart), ptr(out))
+    torch.cuda.synchronize()
+    check(lib.la_debug_set_ptr(0, None), 'debug_set_ptr')
+    t = buf.cpu().numpy().reshape(nwg, nwv, 8).astype(np.float64)
+    base = t[:, :, 0].min()
+    names = ['entry', 'ranges+q+K issued', 'first tile done', 'loop end', 'merge end', 'exit (par 0)']
+    print(f'-- timeline k_tree_attn nkeys={nkeys} nsplit={nsplit}: us since first wave, percentiles 0/10/50/90/100')
+    for k, nm in enumerate(names):
+        a = t[:, :, k].reshape(-1)
+        a = a[a > 0]
+        a = (a - base) / 100.0
+        print(f'   {nm:20s} ' + ' '.join(f'{np.percentile(a, q):6.2f}' for q in (0, 10, 50, 90, 100)) + f'  (n={len(a)})', flush=True)
     st = torch.zeros(_lib.LA_ST_WORDS, dtype=torch.int32, device=DEV)
     cv = torch.zeros(64 * 8, dtype=torch.float32, device=DEV)
     ci = torch.zeros(64 * 8, dtype=torch.int32, device=DEV)
@@ -167,3 +263,5 @@ if __name__ == '__main__':
         gemms()
     if 'small' in which:
         small()
+    if 'sweep' in which:
+        sweep()
