@@ -43,7 +43,7 @@ extern "C" {
 #define LA_MOE_MAX_E      8   /* experts per mixture-of-experts layer (Mixtral: 8, top-2) */
 
 /* ABI version: bumped when a signature changes. */
-#define LA_ABI_VERSION  4    /* bumped whenever a struct layout or an entry point changes */
+#define LA_ABI_VERSION  5    /* bumped whenever a struct layout or an entry point changes */
 int          la_abi_version(void);   /* == LA_ABI_VERSION of the header the library was built from */
 const char*  la_last_error(void);
 /* Measurement knobs for the kernel A/B scripts (scripts/gpu_ab.py); every knob is 0 in production.
@@ -252,6 +252,7 @@ typedef struct la_llama_config {
     int32_t sliding_window;  /* > 0: sliding-window attention over the committed keys (Mistral: 4096; visible iff
                                 pos_row - pos_key <= window, the transformers mask rule).  An EXTENSION: the reference's
                                 lookahead path feeds the full mask (mistral/modeling_mistral.py:979-983) */
+    int32_t max_blocks;      /* > 1: allocate the multi-block step (la_llama_mstep) for up to this many 64-row blocks (<= LA_MB_MAX) */
     int32_t norm_cast_first; /* RMSNorm flavour: 0 = LlamaRMSNorm (llama/modeling_llama.py:86-90, one rounding), 1 = Mistral/
                                 MixtralRMSNorm (mixtral/modeling_mixtral.py:160-165, normalised value rounded first) */
 } la_llama_config;
@@ -388,6 +389,41 @@ int la_tree_attn_batch(void* stream, const void* d_qf, const void* d_kmain, cons
                        const void* d_vfresh, const uint64_t* d_rowmask, const int32_t* d_bstate, int n_heads,
                        int n_kv_heads, int slot_keys, int n_slots, int n_split, float* d_opart, float* d_mpart,
                        float* d_lpart, void* d_attn_xp);
+/* ------------------------------------------------------------------------
+ * Multi-block step: nblk <= LA_MB_MAX blocks of 64 rows in ONE pass over the weights (M = nblk*64 rows through the LDS-
+ * staged GEMM family of csrc/la_mblock.hip).  A block is one sequence's 64-token draft tree (BASELINE configs 3-5: a full
+ * tree per sample) or one 64-token piece of a prompt (prefill: consecutive blocks of the same slot form a
+ * causal chain; every block but the last of a chain must hold 64 rows).  Reference: the batched forward
+ * models/llama/modeling_llama_batch.py:340-420 and pretrained_model_batch.py:706-931, per sample.
+ * Needs cfg.max_blocks >= nblk and cfg.n_slots >= 1; slots are those of the cursor-batch path (LA_BST_NKEYS).
+ * --------------------------------------------------------------------- */
+#define LA_MB_MAX          8
+#define LA_MIN_NBLK        0
+#define LA_MIN_BLK         4    /* [8][4] per block: slot, T (1..64), mode (0 verify tree, 1 prefill chain), limit    */
+#define LA_MIN_IDS        36    /* [8][64] token ids                                                                   */
+#define LA_MIN_ROWMASK   548    /* uint64[8][64] ancestor masks over the block's own rows (8-byte aligned offset)      */
+#define LA_MIN_WORDS    1572
+#define LA_MOUT_NOUT       0    /* out: [8] tokens emitted per block                                                    */
+#define LA_MOUT_NKEYS      8    /* out: [16] committed keys per slot after the step                                     */
+#define LA_MOUT_OUTTOK    24    /* out: [8][16] emitted tokens per block                                                */
+#define LA_MOUT_DST      152    /* out: [8][64] main-cache key row each block row was committed to, -1 = dropped        */
+#define LA_MOUT_ARGMAX   664    /* out: [8][64] argmax token per block row                                              */
+#define LA_MOUT_WORDS   1176
+/* h2d of host_in (LA_MIN_WORDS), captured graph (one per nblk), d2h of the first LA_MOUT_DST words into host_out. */
+int la_llama_mstep(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);
+int la_llama_mstep_eager(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);
+/* One GEMM of the multi-block family (unit parity): kind 0 = split-K slabs [ksplit][slab_rows][N] over a la_pack_weight image,
+ * 1 = gate/up + SwiGLU -> act_xp [blk][64 x N packed], 2 = QKV + RoPE -> qf [blk][nh][8192], kfresh / vfresh [blk][nkv][8192],
+ * 3 = lm_head -> logits bf16 [nblk*64][N] + argmax candidates [blk][4*workgroups][64].  n_wg > 0: image packed by
+ * la_pack_planned for that many workgroups; 0: classic images (la_pack_weight; interleaved gate/up; la_qkv_row_perm rows).
+ * x: nblk consecutive 64-row la_pack_x images.  Replaces nn.Linear of the batched forward (modeling_llama_batch.py:340-420). */
+int la_mb_gemm(void* stream, int kind, const void* d_wp, const void* d_xp, int N, int K, int nblk, int n_wg, int ksplit,
+               float* d_slabs, int slab_rows, void* d_act_xp, void* d_logits, float* d_cand_val, int32_t* d_cand_idx,
+               const int32_t* d_pos, const void* d_rope_cos, const void* d_rope_sin, void* d_qf, void* d_kfresh, void* d_vfresh,
+               int n_heads, int n_kv_heads);
+/* Set a slot's committed-key cursor (slot 0 = also the single-sequence cursor LA_ST_NKEYS); synchronises the stream. */
+int la_llama_set_nkeys(la_llama* m, void* stream, int slot, int nkeys);
+
 /* Whole batch step (needs cfg.n_slots >= 1): h2d of host_in (LA_BIN_WORDS), captured graph, d2h of
  * LA_BST_DST words (NKEYS, NOUT, OUTTOK) into host_out.  Same asynchrony rules as la_llama_step. */
 int la_llama_bstep(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);

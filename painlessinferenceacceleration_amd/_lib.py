@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblookahead_hip.so")
 
 LA_OK = 0
-ABI_VERSION = 4         # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
+ABI_VERSION = 5         # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
 LA_MODE_INPUT, LA_MODE_OUTPUT, LA_MODE_MIX = 0, 1, 2
 LA_TREE_MAX = 64
 LA_MOE_MAX_E = 8
@@ -22,6 +22,9 @@ LA_IN_T, LA_IN_MODE, LA_IN_IDS, LA_IN_ROWMASK, LA_IN_WORDS = 0, 1, 4, 68, 196
 # cursor-batch blocks
 LA_MAX_SEQ = 16
 LA_BIN_T, LA_BIN_IDS, LA_BIN_ROWMASK, LA_BIN_SEQ, LA_BIN_MODE, LA_BIN_LIMIT, LA_BIN_WORDS = 0, 4, 68, 196, 260, 276, 292
+LA_MB_MAX = 8
+LA_MIN_NBLK, LA_MIN_BLK, LA_MIN_IDS, LA_MIN_ROWMASK, LA_MIN_WORDS = 0, 4, 36, 548, 1572
+LA_MOUT_NOUT, LA_MOUT_NKEYS, LA_MOUT_OUTTOK, LA_MOUT_DST, LA_MOUT_ARGMAX, LA_MOUT_WORDS = 0, 8, 24, 152, 664, 1176
 LA_BST_NKEYS, LA_BST_NOUT, LA_BST_OUTTOK, LA_BST_DST, LA_BST_ARGMAX, LA_BST_SEQ, LA_BST_WORDS = 0, 16, 32, 288, 352, 416, 480
 
 
@@ -72,7 +75,8 @@ class LlamaConfigC(C.Structure):
     _fields_ = [("n_layers", i32), ("hidden", i32), ("n_heads", i32), ("n_kv_heads", i32), ("head_dim", i32),
                 ("ffn", i32), ("vocab", i32), ("max_keys", i32), ("max_pos", i32), ("attn_split", i32),
                 ("rms_eps", f32), ("gemm_cfg", i32 * 8), ("balanced_wg", i32 * 3), ("n_slots", i32),
-                ("n_experts", i32), ("top_k", i32), ("fuse", i32), ("sliding_window", i32), ("norm_cast_first", i32)]
+                ("n_experts", i32), ("top_k", i32), ("fuse", i32), ("sliding_window", i32), ("max_blocks", i32),
+                ("norm_cast_first", i32)]
 
 
 class LlamaLayerWeightsC(C.Structure):
@@ -163,6 +167,10 @@ PROTOTYPES = {
     "la_kv_commit_batch": (i32, vp, vp, vp, vp, vp, vp, i32, i32, i32),
     "la_tree_attn_batch": (i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp),
     "la_llama_bstep": (i32, vp, vp, vp, vp),
+    "la_llama_mstep": (i32, vp, vp, vp, vp),
+    "la_llama_mstep_eager": (i32, vp, vp, vp, vp),
+    "la_llama_set_nkeys": (i32, vp, vp, i32, i32),
+    "la_mb_gemm": (i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32),
     "la_llama_bstep_eager": (i32, vp, vp, vp, vp),
     "la_llama_reset_slot": (i32, vp, vp, i32),
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <string>
 #include "la_kernels.h"
+#include "la_mblock.h"
 
 static thread_local std::string g_err;
 void la_set_error(const std::string& s) { g_err = s; }
@@ -18,6 +19,15 @@ const char* la_last_error(void) { return g_err.c_str(); }
 extern int g_la_dbg_noepi;
 extern int g_la_kskew;
 extern long long* g_la_dbg_times;
+int la_mb_gemm(void* stream, int kind, const void* wp, const void* xp, int N, int K, int nblk, int n_wg, int ksplit,
+               float* slabs, int slab_rows, void* act_xp, void* logits, float* cand_val, int32_t* cand_idx, const int32_t* pos,
+               const void* rcos, const void* rsin, void* qf, void* kfresh, void* vfresh, int nh, int nkv) {
+    if (!wp || !xp) return LA_E_ARG;
+    MbGemm g{}; g.wp = wp; g.xp = xp; g.N = N; g.K = K; g.nblk = nblk; g.n_wg = n_wg; g.ksplit = ksplit;
+    g.slabs = slabs; g.slab_rows = slab_rows; g.act_xp = act_xp; g.logits = logits; g.cand_val = cand_val; g.cand_idx = cand_idx;
+    g.pos = pos; g.rcos = rcos; g.rsin = rsin; g.qf = qf; g.kfresh = kfresh; g.vfresh = vfresh; g.nh = nh; g.nkv = nkv;
+    WRAP(lk_mb_gemm((hipStream_t)stream, kind, g));
+}
 int la_debug_set(int key, int value) {
     if (key == 0) { g_la_dbg_noepi = value; return LA_OK; }
     if (key == 1 && value >= 0 && value <= 64) { g_la_kskew = value; return LA_OK; }

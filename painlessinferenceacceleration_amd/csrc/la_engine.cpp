@@ -10,6 +10,7 @@
 #include <chrono>
 #include <atomic>
 #include "la_kernels.h"
+#include "la_mblock.h"
 
 extern void la_set_error(const std::string& s);
 
@@ -44,6 +45,15 @@ struct la_llama {
     uint64_t* rowmask;
     size_t kv_layer_elems, fresh_layer_elems;
     int n_slots, total_keys;
+    // multi-block step (cfg.max_blocks > 1): activations of up to max_blocks x 64 rows
+    int mb_max, mb_nsplit;
+    uint16_t *mb_h, *mb_xp, *mb_attn_xp, *mb_act, *mb_logits, *mb_qf, *mb_kfresh, *mb_vfresh;
+    float *mb_slabs, *mb_opart, *mb_mpart, *mb_lpart, *mb_cand_val;
+    int *mb_cand_idx, *mb_meta, *mb_pos, *mb_ids, *mb_in, *mb_out;
+    uint64_t* mb_rowmask;
+    size_t mb_fresh_layer;
+    hipGraphExec_t mgraphs[LA_MB_MAX + 1];
+    bool mready[LA_MB_MAX + 1];
     hipGraphExec_t graph_exec, bgraph_exec;      // bgraph_exec: scratch slot used while capturing a batch variant
     hipGraphExec_t bgraphs[4];                  // batch step captured per attention key-split count {8, 4, 2, 1}
     bool bready[4];
@@ -139,6 +149,34 @@ static size_t carve(la_llama* m, char* base) {
     m->slabs_ex = cv.take<float>(c.n_experts > 0 ? (size_t)c.n_experts * m->down_ks * 64 * c.hidden : 8);
     m->fuse_cnt = cv.take<int>((size_t)2 * c.n_layers + 8);
     m->route_w = cv.take<float>((size_t)(c.n_experts > 0 ? c.n_layers : 1) * 64 * LA_MOE_MAX_E);   // kept per layer (parity tests)
+    m->mb_max = c.max_blocks > 1 ? c.max_blocks : 0;
+    if (m->mb_max) {
+        const size_t MB = (size_t)LA_MB_MAX, R = MB * 64;            // sized for whole passes of 4 blocks
+        m->mb_nsplit = m->nsplit > 4 ? 4 : m->nsplit;              // attention grid = (heads, splits, blocks): fewer splits fill the chip
+        m->mb_h = cv.take<uint16_t>(R * c.hidden);
+        m->mb_xp = cv.take<uint16_t>(R * c.hidden);
+        m->mb_attn_xp = cv.take<uint16_t>(R * m->o_k);
+        m->mb_act = cv.take<uint16_t>(R * c.ffn);
+        m->mb_logits = cv.take<uint16_t>(R * c.vocab);
+        const int ksm = m->o_ks > m->down_ks ? m->o_ks : m->down_ks;
+        m->mb_slabs = cv.take<float>((size_t)ksm * R * c.hidden);
+        m->mb_qf = cv.take<uint16_t>(MB * c.n_heads * 8192);
+        m->mb_fresh_layer = MB * c.n_kv_heads * 8192;
+        m->mb_kfresh = cv.take<uint16_t>(m->mb_fresh_layer * c.n_layers);
+        m->mb_vfresh = cv.take<uint16_t>(m->mb_fresh_layer * c.n_layers);
+        m->mb_opart = cv.take<float>(MB * c.n_heads * m->mb_nsplit * 64 * 128);
+        m->mb_mpart = cv.take<float>(MB * c.n_heads * m->mb_nsplit * 64);
+        m->mb_lpart = cv.take<float>(MB * c.n_heads * m->mb_nsplit * 64);
+        const size_t cslots = (size_t)lk_mb_cand_slots(lk_mb_logits_wgs(c.vocab, c.balanced_wg[2]));
+        m->mb_cand_val = cv.take<float>(MB * cslots * 64);
+        m->mb_cand_idx = cv.take<int>(MB * cslots * 64);
+        m->mb_meta = cv.take<int>(MB * LA_MB_META);
+        m->mb_pos = cv.take<int>(R);
+        m->mb_ids = cv.take<int>(R);
+        m->mb_rowmask = cv.take<uint64_t>(R);
+        m->mb_in = cv.take<int>(LA_MIN_WORDS);
+        m->mb_out = cv.take<int>(LA_MOUT_WORDS);
+    }
     return align_up(cv.off, 256);
 }
 
@@ -147,7 +185,7 @@ static int validate(const la_llama_config* c) {
     if (c->head_dim != 128) { la_set_error("head_dim must be 128"); return LA_E_ARG; }
     if (c->n_layers <= 0 || c->hidden % 32 || c->hidden > 8192 || c->ffn % 32 || c->vocab % 32 ||
         c->n_heads % c->n_kv_heads || c->max_keys % 32 || c->max_keys < 96 || c->n_slots < 0 || c->n_slots > LA_MAX_SEQ ||
-        c->n_experts < 0 || c->n_experts > LA_MOE_MAX_E || (c->n_experts > 0 && (c->top_k < 1 || c->top_k > c->n_experts))) {
+        c->max_blocks < 0 || c->max_blocks > LA_MB_MAX || c->n_experts < 0 || c->n_experts > LA_MOE_MAX_E || (c->n_experts > 0 && (c->top_k < 1 || c->top_k > c->n_experts))) {
         la_set_error("unsupported llama config (need hidden%32==0<=8192, ffn%32==0, vocab%32==0, max_keys%32==0)");
         return LA_E_ARG;
     }
@@ -210,6 +248,8 @@ extern "C" la_llama* la_llama_create(const la_llama_config* cfg, const la_llama_
     m->zc_in = nullptr; m->zc_out = nullptr; m->seq_expected = 0;
     if (cfg->n_experts == 0) m->ex_merged = false;
     for (int i = 0; i < 4; ++i) { m->bgraphs[i] = nullptr; m->bready[i] = false; }
+    for (int i = 0; i <= LA_MB_MAX; ++i) { m->mgraphs[i] = nullptr; m->mready[i] = false; }
+    if (m->mb_max && lk_mb_init() != 0) { la_set_error("hipFuncSetAttribute failed for the multi-block kernels"); delete m; return nullptr; }
     return m;
 }
 
@@ -218,6 +258,7 @@ extern "C" void la_llama_destroy(la_llama* m) {
     if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
     if (m->bgraph_exec) (void)hipGraphExecDestroy(m->bgraph_exec);
     for (int i = 0; i < 4; ++i) if (m->bready[i]) (void)hipGraphExecDestroy(m->bgraphs[i]);
+    for (int i = 0; i <= LA_MB_MAX; ++i) if (m->mready[i]) (void)hipGraphExecDestroy(m->mgraphs[i]);
     delete m;
 }
 
@@ -438,6 +479,83 @@ extern "C" int la_llama_bstep_eager(la_llama* m, void* stream, const int32_t* ho
     return bstep(m, stream, host_in, host_out, true);
 }
 
+// ---- multi-block step: nblk x 64 rows through the LDS-staged GEMM family (la_mblock.hip) -------------------------------
+static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk) {
+    const la_llama_config& c = m->cfg;
+    if (c.n_experts > 0) { la_set_error("mstep: the sparse-MoE MLP runs on the 64-row path only"); return LA_E_ARG; }
+    if (!m->qkv_fused) { la_set_error("mstep needs the fused QKV image (gemm_cfg[1] >= 0)"); return LA_E_ARG; }
+    const int M = nblk * 64;
+    const int npass_rows = (nblk <= 2 ? nblk : ((nblk + 3) / 4) * 4) * 64;     // rows whole passes write (slab stride)
+    const int cf = c.norm_cast_first;
+    KCHK(lk_mb_build_inputs(st, m->mb_in, m->bstate, nblk, m->mb_meta, m->mb_pos, m->mb_rowmask, m->mb_ids));
+    KCHK(lk_mb_embed_norm(st, m->w.embed, m->mb_ids, m->layers[0].norm1, c.hidden, c.rms_eps, m->mb_h, m->mb_xp, M, cf));
+    for (int l = 0; l < c.n_layers; ++l) {
+        const la_llama_layer_weights& L = m->layers[l];
+        uint16_t* kf = m->mb_kfresh + (size_t)l * m->mb_fresh_layer;
+        uint16_t* vf = m->mb_vfresh + (size_t)l * m->mb_fresh_layer;
+        MbGemm q{}; q.wp = L.wqkv; q.xp = m->mb_xp; q.N = m->qkv_n; q.K = c.hidden; q.nblk = nblk; q.n_wg = c.balanced_wg[0]; q.ksplit = 1;
+        q.pos = m->mb_pos; q.rcos = m->w.rope_cos; q.rsin = m->w.rope_sin; q.qf = m->mb_qf; q.kfresh = kf; q.vfresh = vf;
+        q.nh = c.n_heads; q.nkv = c.n_kv_heads;
+        KCHK(lk_mb_gemm(st, 2, q));
+        KCHK(lk_mb_tree_attn(st, m->mb_qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems, kf, vf,
+                             m->mb_rowmask, m->mb_meta, nblk, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, m->mb_nsplit,
+                             m->mb_opart, m->mb_mpart, m->mb_lpart, m->mb_attn_xp, c.sliding_window));
+        MbGemm o{}; o.wp = L.wo; o.xp = m->mb_attn_xp; o.N = c.hidden; o.K = m->o_k; o.nblk = nblk; o.ksplit = m->o_ks;
+        o.slabs = m->mb_slabs; o.slab_rows = npass_rows;
+        KCHK(lk_mb_gemm(st, 0, o));
+        KCHK(lk_mb_resid_norm(st, m->mb_h, m->mb_slabs, m->o_ks, npass_rows, L.norm2, c.hidden, c.rms_eps, m->mb_xp, M, cf));
+        MbGemm g{}; g.wp = L.wgateup; g.xp = m->mb_xp; g.N = c.ffn; g.K = c.hidden; g.nblk = nblk; g.n_wg = c.balanced_wg[1]; g.ksplit = 1;
+        g.act_xp = m->mb_act;
+        KCHK(lk_mb_gemm(st, 1, g));
+        MbGemm d{}; d.wp = L.wdown; d.xp = m->mb_act; d.N = c.hidden; d.K = c.ffn; d.nblk = nblk; d.ksplit = m->down_ks;
+        d.slabs = m->mb_slabs; d.slab_rows = npass_rows;
+        KCHK(lk_mb_gemm(st, 0, d));
+        const void* nw = (l + 1 < c.n_layers) ? m->layers[l + 1].norm1 : m->w.final_norm;
+        KCHK(lk_mb_resid_norm(st, m->mb_h, m->mb_slabs, m->down_ks, npass_rows, nw, c.hidden, c.rms_eps, m->mb_xp, M, cf));
+    }
+    const int lwg = lk_mb_logits_wgs(c.vocab, c.balanced_wg[2]);
+    MbGemm h{}; h.wp = m->w.lm_head; h.xp = m->mb_xp; h.N = c.vocab; h.K = c.hidden; h.nblk = nblk; h.n_wg = c.balanced_wg[2]; h.ksplit = 1;
+    h.logits = m->mb_logits; h.cand_val = m->mb_cand_val; h.cand_idx = m->mb_cand_idx;
+    KCHK(lk_mb_gemm(st, 3, h));
+    KCHK(lk_mb_argmax(st, m->mb_cand_val, m->mb_cand_idx, lk_mb_cand_slots(lwg), nblk, m->mb_out + LA_MOUT_ARGMAX));
+    KCHK(lk_mb_accept_scan(st, m->mb_meta, m->mb_ids, m->mb_rowmask, m->mb_out + LA_MOUT_ARGMAX, nblk, c.max_keys, m->bstate, m->mb_out));
+    KCHK(lk_mb_kv_commit(st, m->mb_kfresh, m->mb_vfresh, m->kmain, m->vmain, m->mb_out, nblk, c.n_layers, c.n_kv_heads, m->total_keys));
+    return LA_OK;
+}
+
+static int mstep(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out, bool eager) {
+    if (!m || !host_in) return LA_E_ARG;
+    const int nblk = host_in[LA_MIN_NBLK];
+    if (!m->mb_max || nblk < 1 || nblk > m->mb_max) { la_set_error("mstep: block count outside cfg.max_blocks"); return LA_E_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(m->mb_in, host_in, LA_MIN_WORDS * sizeof(int), hipMemcpyHostToDevice, st));
+    if (eager) {
+        int rc = enqueue_mstep(m, st, nblk);
+        if (rc != LA_OK) return rc;
+    } else {
+        if (!m->mready[nblk]) {
+            hipGraph_t g = nullptr;
+            HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            int rc = enqueue_mstep(m, st, nblk);
+            hipError_t e = hipStreamEndCapture(st, &g);
+            if (rc != LA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+            HIPCHK(e);
+            HIPCHK(hipGraphInstantiate(&m->mgraphs[nblk], g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+            m->mready[nblk] = true;
+        }
+        HIPCHK(hipGraphLaunch(m->mgraphs[nblk], st));
+    }
+    if (host_out) HIPCHK(hipMemcpyAsync(host_out, m->mb_out, LA_MOUT_DST * sizeof(int), hipMemcpyDeviceToHost, st));
+    return LA_OK;
+}
+extern "C" int la_llama_mstep(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out) {
+    return mstep(m, stream, host_in, host_out, false);
+}
+extern "C" int la_llama_mstep_eager(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out) {
+    return mstep(m, stream, host_in, host_out, true);
+}
+
 extern "C" int la_llama_step(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out) {
     if (!m || !host_in || !host_out) return LA_E_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -569,6 +687,17 @@ extern "C" int la_llama_commit(la_llama* m, void* stream, const int32_t* rows, i
     return LA_OK;
 }
 
+// Set the committed-key cursor of a slot from the host (slot 0 is also the single-sequence cursor LA_ST_NKEYS): lets a
+// prompt prefilled by la_llama_mstep continue on la_llama_step, and a finished slot be rewound without clearing the others.
+extern "C" int la_llama_set_nkeys(la_llama* m, void* stream, int slot, int nkeys) {
+    if (!m || slot < 0 || slot >= m->n_slots || nkeys < 0 || nkeys > m->cfg.max_keys) return LA_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(m->bstate + LA_BST_NKEYS + slot, &nkeys, sizeof(int), hipMemcpyHostToDevice, st));
+    if (slot == 0) HIPCHK(hipMemcpyAsync(m->state + LA_ST_NKEYS, &nkeys, sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return LA_OK;
+}
+
 extern "C" void* la_llama_buffer(la_llama* m, int which) {
     if (!m) return nullptr;
     switch (which) {
@@ -583,6 +712,9 @@ extern "C" void* la_llama_buffer(la_llama* m, int which) {
         case 8: return m->bstate;
         case 9: return m->route_w;
         case 10: return m->moe_acc;
+        case 11: return m->mb_max ? m->mb_logits : nullptr;
+        case 12: return m->mb_max ? m->mb_out : nullptr;
+        case 13: return m->mb_max ? m->mb_h : nullptr;
         default: return nullptr;
     }
 }

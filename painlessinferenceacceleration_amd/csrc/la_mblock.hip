@@ -1,0 +1,857 @@
+// la_mblock.hip — multi-block verify step for gfx950: M = nblk x 64 rows (nblk <= 8) through the SAME packed weights.
+//
+// Why a second GEMM family.  At M = 64 (la_kernels.hip) a weight byte is used 64 times: the launch is a pure HBM stream,
+// waves split K and every wave keeps its own x fragments in registers.  At M = 256..512 (configs 3-5 of BASELINE.json:
+// bs 4..8 x 64-token trees; prompt prefill) the same bytes feed 4-8x the MFMAs and x no longer fits a wave's registers:
+// here the 8 waves of a workgroup own different 32-row weight blocks, the x tile of a k-step is staged ONCE per workgroup
+// in LDS (register-staged double buffer, one barrier per stage) and read by every wave with ds_read_b128; weight
+// fragments still stream HBM -> VGPR in MFMA operand order, each byte once per 256-row pass.
+// Reference semantics: modeling_llama_batch.py:340-420 (batched forward), pretrained_model_batch.py:706-931 (per-sample
+// draft, accept, in-place KV) with the per-sample 64-token tree SURVEY H2 / BASELINE configs 3-5 ask for.
+#include "la_common.h"
+#include "la_mblock.h"
+
+#define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+enum { MB_SLAB = 0, MB_SWIGLU = 1, MB_QKV = 2, MB_LOGITS = 3 };
+
+struct MbArgs {
+    const bf16_t* wp;
+    const bf16_t* xp;
+    int K16;                 // k-tiles of the whole reduction dimension (x image: K16*1024 elements per 64-row block)
+    int N;
+    int M;                   // rows of the slab buffer per K split (slab stride)
+    int nblk;                // 64-row blocks of the step that carry data
+    // weight addressing: planned (workgroup-major virtual blocks, la_pack_planned) or classic (la_pack_weight)
+    int planned, R;
+    int gu_interleaved;      // MB_SWIGLU on a classic image: row-blocks alternate gate/up (la_pack_weight interleave2)
+    int nv[4], nvl[4], boff[4], wg_chunks;
+    float* slabs;            // MB_SLAB: [ksplit][M][N]
+    bf16_t* act_xp;          // MB_SWIGLU: [blk][64 x N packed]
+    bf16_t* logits;          // MB_LOGITS: [M][N] row-major bf16 (may be null)
+    float* cand_val;         // MB_LOGITS: [blk][gridDim.x * 4][64]
+    int* cand_idx;
+    const int* pos; const bf16_t* rcos; const bf16_t* rsin;      // MB_QKV
+    bf16_t* qf; bf16_t* kfresh; bf16_t* vfresh; int nh, nkv;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// out[M][N] = x[M][K] . W[N][K]^T for NT/2 64-row blocks per pass (grid.z = pass).
+//   workgroup = 8 waves = RBV weight row-blocks x KP = 8/RBV K-parts; wave (rb, kp) streams row-block rb over part kp
+//   (weight tiles D deep in registers, nontemporal), a stage = 4 k-tiles (KT = 4/KP per part) whose x fragments
+//   (4*NT KiB) sit in an LDS double buffer; per stage and wave: KT x NT MFMAs.  K-parts are summed through LDS in a fixed
+//   order (deterministic) per 64-row block, then the same epilogues as the single-block kernels.
+// ---------------------------------------------------------------------------------------------------------------
+template <int RBV, int NT, int EPI>
+__global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
+    constexpr int KP = 8 / RBV, KT = 4 / KP;
+    constexpr int FR = 4 * NT;                  // x fragments (1 KiB) per stage
+    constexpr int FPW = FR / 8;                 // fragments staged by one wave
+    constexpr int D = 8;                        // weight tiles in flight per wave
+    constexpr int SPG = D / KT;                 // stages per unrolled group (weight ring slots are compile-time inside it)
+    static_assert(FPW >= 1 && (FR % 8) == 0, "stage split");
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    bf16x8* xs = (bf16x8*)lds_raw;              // [2 stages][FR][64 lanes]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rb = wave % RBV, kp = wave / RBV;
+    const int blk0 = blockIdx.z * (NT / 2);
+    const int ksplit = gridDim.y, ks = blockIdx.y;
+    const int t0 = (int)(((long)a.K16 * ks) / ksplit), t1 = (int)(((long)a.K16 * (ks + 1)) / ksplit);
+    const int twg = t1 - t0, pq = twg / KP, pr = twg - pq * KP;
+    const int my_start = t0 + kp * pq + (kp < pr ? kp : pr), my_cnt = pq + (kp < pr ? 1 : 0);
+    const int nstages = (pq + (pr > 0 ? 1 : 0) + KT - 1) / KT;
+
+    // ---- weight fragment addressing (16-byte chunks)
+    const bf16x8* __restrict__ wbase = (const bf16x8*)a.wp;
+    unsigned woff, wstr;
+    int nvalid = 32;
+    if (a.planned) {
+        const int nvb = a.nvl[rb];
+        const int rr = (lane & 31) < nvb ? (lane & 31) : nvb - 1;
+        wstr = (unsigned)(2 * nvb);
+        woff = (unsigned)blockIdx.x * (unsigned)a.wg_chunks + (unsigned)a.boff[rb] + (unsigned)my_start * wstr + (unsigned)((lane >> 5) * nvb + rr);
+        nvalid = a.nv[rb];
+    } else {
+        wstr = 64u;
+        woff = (unsigned)(((blockIdx.x * RBV + rb) * a.K16 + my_start) * 64 + lane);
+    }
+    // ---- x fragments staged by this wave: f = wave + 8*i -> (part, k-tile in stage, token block)
+    const bf16x8* __restrict__ xbase = (const bf16x8*)a.xp;
+    int xpart_start[FPW], xpart_cnt[FPW], xj[FPW];
+    unsigned xconst[FPW];
+#pragma unroll
+    for (int i = 0; i < FPW; ++i) {
+        const int f = wave + 8 * i, part = f / (KT * NT), j = (f / NT) % KT, tbk = f % NT;
+        xpart_start[i] = t0 + part * pq + (part < pr ? part : pr);
+        xpart_cnt[i] = pq + (part < pr ? 1 : 0);
+        xj[i] = j;
+        int xb = blk0 + (tbk >> 1);
+        xb = xb < a.nblk ? xb : a.nblk - 1;         // surplus blocks of a padded pass re-read the last real block (results dropped)
+        xconst[i] = (unsigned)(((xb * a.K16) * 2 + (tbk & 1)) * 64 + lane);
+    }
+    auto xload = [&](int s, bf16x8 (&xr)[FPW]) {
+#pragma unroll
+        for (int i = 0; i < FPW; ++i) {
+            const int kl = s * KT + xj[i];
+            const int kk = kl < xpart_cnt[i] ? kl : 0;                    // past the end: any valid tile (its MFMAs are skipped)
+            xr[i] = xbase[xconst[i] + (unsigned)(xpart_start[i] + kk) * 128u];
+        }
+    };
+    auto xstore = [&](int slot, const bf16x8 (&xr)[FPW]) {
+#pragma unroll
+        for (int i = 0; i < FPW; ++i) xs[(slot * FR + wave + 8 * i) * 64 + lane] = xr[i];
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    if (nstages > 0) {
+        bf16x8 fa[D];
+        bf16x8 xr[FPW];
+#pragma unroll
+        for (int d = 0; d < D; ++d) fa[d] = __builtin_nontemporal_load(wbase + woff + (unsigned)(d < my_cnt ? d : 0) * wstr);
+        xload(0, xr);
+        xstore(0, xr);
+        if (nstages > 1) xload(1, xr);
+        __syncthreads();
+        for (int sg = 0; sg < nstages; sg += SPG) {
+#pragma unroll
+            for (int u = 0; u < SPG; ++u) {
+                const int s = sg + u;
+                if (s < nstages) {                                         // workgroup-uniform
+#pragma unroll
+                    for (int j = 0; j < KT; ++j) {
+                        const int kl = s * KT + j;
+                        const int slotw = (u * KT + j) % D;
+                        if (kl < my_cnt) {                                 // wave-uniform
+                            const bf16x8 av = fa[slotw];
+                            const int nx = kl + D;
+                            fa[slotw] = __builtin_nontemporal_load(wbase + woff + (unsigned)(nx < my_cnt ? nx : 0) * wstr);
+                            const bf16x8* xt = xs + (((u & 1) * FR) + (kp * KT + j) * NT) * 64 + lane;
+#pragma unroll
+                            for (int t = 0; t < NT; ++t)
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, xt[t * 64], acc[t], 0, 0, 0);
+                        }
+                    }
+                    if (s + 1 < nstages) xstore((u + 1) & 1, xr);          // slot of stage s-1: every wave passed its barrier
+                    if (s + 2 < nstages) xload(s + 2, xr);
+                    __syncthreads();
+                }
+            }
+        }
+    }
+
+    // ---- epilogue, one 64-row block at a time: K-parts parked in LDS [kp][rb][tb][i/4][lane] (16-byte units), one barrier,
+    //      fixed summation order p = 0..KP-1, every wave finishes a fixed set of (row-block, token block, register group) slices
+    f32x4* red4 = (f32x4*)lds_raw;
+    const int tl = lane & 31, hh = lane >> 5;
+    (void)nvalid;
+#pragma unroll
+    for (int c = 0; c < NT / 2; ++c) {
+        const int blk = blk0 + c;
+        if (blk >= a.nblk) break;                   // surplus blocks of a padded pass (workgroup-uniform)
+        if (c) __syncthreads();
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const f32x4 w4 = {acc[2 * c + tb][4 * i4], acc[2 * c + tb][4 * i4 + 1], acc[2 * c + tb][4 * i4 + 2], acc[2 * c + tb][4 * i4 + 3]};
+                red4[(((kp * RBV + rb) * 2 + tb) * 4 + i4) * 64 + lane] = w4;
+            }
+        __syncthreads();
+        auto total4 = [&](int rbq, int tb, int gi) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int p = 0; p < KP; ++p) v += red4[(((p * RBV + rbq) * 2 + tb) * 4 + gi) * 64 + lane];
+            return v;
+        };
+        if constexpr (EPI == MB_SLAB) {
+            static_assert(EPI != MB_SLAB || RBV == 2, "slab layout");
+            // slices (rb, tb, gi): 16 -> 2 per wave
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int sl = wave * 2 + i, rq = sl >> 3, tb = (sl >> 2) & 1, gi = sl & 3;
+                const f32x4 v = total4(rq, tb, gi);
+                const int tok = blk * 64 + tb * 32 + tl;
+                float* o = a.slabs + ((size_t)ks * a.M + tok) * a.N + (blockIdx.x * RBV + rq) * 32 + 8 * gi + 4 * hh;
+                *(f32x4*)o = v;
+            }
+        } else if constexpr (EPI == MB_SWIGLU) {
+            static_assert(EPI != MB_SWIGLU || RBV == 4, "swiglu layout {G0,G1,U0,U1}");
+            // pair slices (q, tb, gi): 16 -> 2 per wave;  act = bf16(silu(bf16(g)) * bf16(u)) (LlamaMLP.forward, :185-186)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int sl = wave * 2 + i, qq = sl >> 3, tb = (sl >> 2) & 1, gi = sl & 3;
+                const int rg = a.gu_interleaved ? 2 * qq : qq, ru = a.gu_interleaved ? 2 * qq + 1 : qq + 2;
+                if (8 * gi + 4 * hh < a.nv[rg]) {
+                    const f32x4 g4 = total4(rg, tb, gi), u4 = total4(ru, tb, gi);
+                    const int tok = tb * 32 + tl;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int f = 8 * gi + 4 * hh + j;
+                        if (f < a.nv[rg]) {
+                            const float gv = bfr(g4[j]), uv = bfr(u4[j]);
+                            const float sv = bfr(gv / (1.0f + expf(-gv)));
+                            const int feat = a.gu_interleaved ? (2 * blockIdx.x + qq) * 32 + f : a.R * blockIdx.x + 32 * qq + f;
+                            a.act_xp[(size_t)blk * 64 * a.N + xp_offset(tok, feat)] = f2bf(sv * uv);
+                        }
+                    }
+                }
+            }
+        } else if constexpr (EPI == MB_QKV) {
+            static_assert(EPI != MB_QKV || RBV == 2, "qkv layout {lo, hi}");
+            // pair slices (tb, gi): 8 -> 1 per wave; RoPE in bf16 arithmetic (apply_rotary_pos_emb, modeling_llama.py:154-169)
+            const int tb = wave >> 2, gi = wave & 3;
+            const int tok = tb * 32 + tl;
+            if (8 * gi + 4 * hh < a.nv[0]) {
+                const f32x4 xl4 = total4(0, tb, gi), xh4 = total4(1, tb, gi);
+                const int ps = a.pos[blk * 64 + tok];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = 8 * gi + 4 * hh + j;
+                    if (f < a.nv[0]) {
+                        const int prr = a.R * blockIdx.x + f, slot = prr >> 6, dlo = prr & 63, dhi = dlo + 64;
+                        const float xl = xl4[j], xh = xh4[j];
+                        if (slot < a.nh + a.nkv) {
+                            bf16_t* dst = slot < a.nh ? a.qf + ((size_t)blk * a.nh + slot) * 8192
+                                                      : a.kfresh + ((size_t)blk * a.nkv + (slot - a.nh)) * 8192;
+                            const float cc = bf2f(a.rcos[(size_t)ps * 64 + dlo]), sn = bf2f(a.rsin[(size_t)ps * 64 + dlo]);
+                            const float bl = bfr(xl), bh = bfr(xh);
+                            dst[rf_offset(tok, dlo)] = f2bf(bfr(bl * cc) + bfr(-bh * sn));
+                            dst[rf_offset(tok, dhi)] = f2bf(bfr(bh * cc) + bfr(bl * sn));
+                        } else {
+                            bf16_t* dst = a.vfresh + ((size_t)blk * a.nkv + (slot - a.nh - a.nkv)) * 8192;
+                            dst[vf_offset(tok, dlo)] = f2bf(xl);
+                            dst[vf_offset(tok, dhi)] = f2bf(xh);
+                        }
+                    }
+                }
+            }
+        } else {
+            static_assert(EPI != MB_LOGITS || RBV == 4, "logits layout");
+            // wave -> token block w&1, row-block w>>1, all four register groups; one argmax candidate per (wave, token)
+            const int tb = wave & 1, rq = wave >> 1;
+            const int tok = tb * 32 + tl;
+            float best = -INFINITY;
+            int bidx = 0x7fffffff;
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                if (8 * gi + 4 * hh < a.nv[rq]) {
+                    const f32x4 t4 = total4(rq, tb, gi);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int f = 8 * gi + 4 * hh + j;
+                        if (f < a.nv[rq]) {
+                            const bf16_t hv = f2bf(t4[j]);
+                            const int idx = a.R * blockIdx.x + 32 * rq + f;
+                            if (a.logits) a.logits[((size_t)blk * 64 + tok) * a.N + idx] = hv;
+                            const float v = bf2f(hv);
+                            if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
+                        }
+                    }
+                }
+            }
+            float ob = __shfl_xor(best, 32, 64);
+            int oi = __shfl_xor(bidx, 32, 64);
+            if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+            if (hh == 0) {
+                const size_t slot = ((size_t)blk * gridDim.x + blockIdx.x) * 4 + rq;
+                a.cand_val[slot * 64 + tok] = best;
+                a.cand_idx[slot * 64 + tok] = bidx;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row kernels over M rows: embedding gather + RMSNorm / residual + split-K slab sum + RMSNorm (same arithmetic and rounding
+// points as k_row_norm in la_kernels.hip; LlamaRMSNorm :76-90, LlamaDecoderLayer residual adds :352-363).
+// ---------------------------------------------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(512) void k_row_norm_mb(const bf16_t* __restrict__ embed, const int* __restrict__ ids,
+                                                      bf16_t* __restrict__ h, const float* __restrict__ slabs,
+                                                      const bf16_t* __restrict__ nw, int hidden, float eps,
+                                                      bf16_t* __restrict__ xp, int slab_rows, int cast_first) {
+    __shared__ float sh[8];
+    const int t = blockIdx.x;
+    const int nchunk = hidden >> 3;
+    const bf16_t* src = embed ? embed + (size_t)ids[t] * hidden : h + (size_t)t * hidden;
+    bf16x8 hv[2], wv[2];
+    f32x4 sl[NS > 0 ? NS : 1][2][2];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 512;
+        if (c < nchunk) {
+            hv[ci] = *(const bf16x8*)(src + c * 8);
+            wv[ci] = *(const bf16x8*)(nw + c * 8);
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) {
+                const float* sp = slabs + ((size_t)s2 * slab_rows + t) * hidden + c * 8;
+                sl[s2][ci][0] = *(const f32x4*)sp;
+                sl[s2][ci][1] = *(const f32x4*)(sp + 4);
+            }
+        }
+    }
+    float vals[2][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 512;
+        if (c < nchunk) {
+            bf16x8 ho;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = bf2f((bf16_t)hv[ci][j]);
+                if (NS > 0) {
+                    float add = 0.f;
+#pragma unroll
+                    for (int s2 = 0; s2 < NS; ++s2) add += sl[s2][ci][j >> 2][j & 3];
+                    v = bfr(v + bfr(add));
+                }
+                vals[ci][j] = v;
+                ho[j] = (short)f2bf(v);
+                ss += v * v;
+            }
+            *(bf16x8*)(h + (size_t)t * hidden + c * 8) = ho;
+        }
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tot += sh[i];
+    const float rs = 1.0f / sqrtf(tot / (float)hidden + eps);
+    bf16_t* xo_base = xp + (size_t)(t >> 6) * 64 * hidden;
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 512;
+        if (c < nchunk) {
+            bf16x8 xo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float nv = cast_first ? bfr(vals[ci][j] * rs) : vals[ci][j] * rs;
+                xo[j] = (short)f2bf(bf2f((bf16_t)wv[ci][j]) * nv);
+            }
+            *(bf16x8*)(xo_base + xp_offset(t & 63, c * 8)) = xo;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Step inputs: per block ids / 64-bit ancestor masks / positions, and the block meta records.
+// in: [LA_MIN_*] (include/lookahead_hip.h).  pos = committed keys of the slot + rows of earlier blocks of the same slot in
+// this step (prefill chain) + popcount(rowmask) - 1  (model hook position_ids = mask.sum(-1) - 1, modeling_llama.py:584-588).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_build_inputs_mb(const int* __restrict__ in, const int* __restrict__ bstate, int* __restrict__ meta,
+                                  int* __restrict__ pos, unsigned long long* __restrict__ rowmask, int* __restrict__ ids) {
+    const int b = blockIdx.x, t = threadIdx.x;       // 64 threads
+    const int* rec = in + LA_MIN_BLK + 4 * b;
+    int slot = rec[0];
+    slot = slot < 0 ? 0 : (slot >= LA_MAX_SEQ ? LA_MAX_SEQ - 1 : slot);
+    int T = rec[1];
+    T = T < 1 ? 1 : (T > 64 ? 64 : T);
+    int base = 0, first = b;
+    for (int p = b - 1; p >= 0; --p) {
+        const int* r2 = in + LA_MIN_BLK + 4 * p;
+        if (r2[0] == slot) { int t2 = r2[1]; t2 = t2 < 1 ? 1 : (t2 > 64 ? 64 : t2); base += t2; first = p; }
+    }
+    const int nkeys = bstate[LA_BST_NKEYS + slot];
+    const unsigned long long* rmin = (const unsigned long long*)(in + LA_MIN_ROWMASK) + b * 64;
+    const unsigned long long rm = t < T ? rmin[t] : (1ull << t);
+    rowmask[b * 64 + t] = rm;
+    ids[b * 64 + t] = t < T ? in[LA_MIN_IDS + b * 64 + t] : 0;
+    pos[b * 64 + t] = t < T ? nkeys + base + __popcll(rm) - 1 : 0;
+    if (t == 0) {
+        int* m = meta + b * LA_MB_META;
+        m[LA_MBM_SLOT] = slot; m[LA_MBM_T] = T; m[LA_MBM_MODE] = rec[2]; m[LA_MBM_LIMIT] = rec[3];
+        m[LA_MBM_NKEYS] = nkeys; m[LA_MBM_BASE] = base; m[LA_MBM_FIRST] = first;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Tree attention of block `blk` (LlamaAttention.forward, modeling_llama.py:270-296 under the rank-4 mask): committed keys of
+// the block's slot mask-free, the fresh tiles of EARLIER blocks of the same slot in this step fully visible (prefill chain),
+// the block's own 64 fresh keys under its ancestor masks.  Same tile arithmetic and rounding points as k_tree_attn.
+// grid = (heads, key splits, blocks), 8 waves = 2 token blocks x 4 key-tile parities.
+// ---------------------------------------------------------------------------------------------------------------
+struct MbAttnArgs {
+    const bf16_t* qf; const bf16_t* kmain; const bf16_t* vmain; const bf16_t* kfresh; const bf16_t* vfresh;
+    const unsigned long long* rowmask;
+    const int* meta;
+    int nh, nkv, total_keys, slot_tiles, nsplit, window;
+    float* opart; float* mpart; float* lpart;          // [blk][nh][nsplit][64][128] ...
+};
+#define MB_NEG (-1.0e30f)
+__global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float mgbuf[];   // [4][2][66][64]
+    const int h = blockIdx.x, sp = blockIdx.y, blk = blockIdx.z;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tb = wave & 1, par = wave >> 1;
+    const int hk = h / (a.nh / a.nkv);
+    const int KB = a.total_keys >> 5;
+    const int* mt = a.meta + blk * LA_MB_META;
+    const int slot = mt[LA_MBM_SLOT], T = mt[LA_MBM_T], nkeys = mt[LA_MBM_NKEYS], first = mt[LA_MBM_FIRST];
+    const int nprev = blk - first;                     // earlier blocks of the chain (each 64 rows)
+    const int row = tb * 32 + (lane & 31);
+    const bool mine = row < T;
+    const unsigned long long rm = mine ? a.rowmask[blk * 64 + row] : 0ull;
+    const int NPall = (nkeys + 31) >> 5;
+    const int qpos0 = nkeys + nprev * 64;              // position of the block's first row
+    const int ts = (a.window > 0 && qpos0 - a.window > 0) ? ((qpos0 - a.window) >> 5) : 0;
+    const int tsm = ts < NPall ? ts : NPall;           // skipped main tiles
+    const int NP = NPall - tsm;
+    const int NF = 2 * nprev;                          // fresh tiles of earlier chain blocks
+    const int NT = NP + NF + 2;
+    const int tile0 = slot * a.slot_tiles + tsm;
+    const int key_lo = (a.window > 0) ? nkeys + nprev * 64 + __popcll(rm) - 1 - a.window : -0x40000000;
+    const int i0 = (NT * sp) / a.nsplit;
+    const int i1 = (__ballot(mine) == 0ull) ? i0 : (NT * (sp + 1)) / a.nsplit;
+
+    bf16x8 q[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) q[s] = *((const bf16x8*)(a.qf + (((size_t)blk * a.nh + h) * 2 + tb) * 4096 + (size_t)s * 512) + lane);
+    const int hh = lane >> 5;
+    f32x16 o[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+    float m = MB_NEG, l = 0.f;
+
+    auto tptr = [&](const bf16_t* mainp, const bf16_t* freshp, int it) -> const bf16x8* {
+        if (it < NP) return (const bf16x8*)(mainp + ((size_t)hk * KB + tile0 + it) * 4096);
+        const int j = it - NP;                          // fresh tile index: earlier blocks first, then own
+        const int fb = j < NF ? first + (j >> 1) : blk;
+        return (const bf16x8*)(freshp + (((size_t)fb * a.nkv + hk) * 2 + (j & 1)) * 4096);
+    };
+    auto tile = [&](int it, const bf16x8 (&kf)[8]) {
+        const bool own = it >= NP + NF;
+        const bool prior = it >= NP && !own;
+        const int kb = own ? it - NP - NF : it;
+        const bf16x8* vt = tptr(a.vmain, a.vfresh, it);
+        bf16x8 vf[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) vf[s] = vt[s * 64 + lane];
+        f32x16 sc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], q[s], sc, 0, 0, 0);
+        float mx = MB_NEG;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kk = (i & 3) + 8 * (i >> 2) + 4 * hh;
+            float v = bfr(__fdiv_rn(bfr(sc[i]), 11.313708498984761f));
+            bool ok;
+            if (own) ok = ((rm >> (kb * 32 + kk)) & 1ull) != 0ull;
+            else if (prior) { const int kpos = nkeys + (it - NP) * 32 + kk; ok = mine && kpos >= key_lo; }
+            else { const int kidx = (tsm + kb) * 32 + kk; ok = mine && kidx < nkeys && kidx >= key_lo; }
+            v = ok ? v : MB_NEG;
+            sc[i] = v;
+            mx = fmaxf(mx, v);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float alpha = __expf(m - mn);
+        float ps = 0.f;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float p = (sc[i] > -1.0e29f) ? __expf(sc[i] - mn) : 0.f;
+            ps += p;
+            pf[i >> 3][i & 7] = (short)f2bf(p);
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        l = l * alpha + ps;
+        m = mn;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db * 2 + 0], pf[0], o[db], 0, 0, 0);
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db * 2 + 1], pf[1], o[db], 0, 0, 0);
+        }
+    };
+    {
+        bf16x8 kA[8], kB[8];
+        int it = i0 + par;
+        if (it < i1) {
+            const bf16x8* kt = tptr(a.kmain, a.kfresh, it);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) kA[s] = kt[s * 64 + lane];
+        }
+        while (it < i1) {
+            int nx = it + 4;
+            if (nx < i1) {
+                const bf16x8* kt = tptr(a.kmain, a.kfresh, nx);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) kB[s] = kt[s * 64 + lane];
+            }
+            tile(it, kA);
+            it = nx;
+            if (it >= i1) break;
+            nx = it + 4;
+            if (nx < i1) {
+                const bf16x8* kt = tptr(a.kmain, a.kfresh, nx);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) kA[s] = kt[s * 64 + lane];
+            }
+            tile(it, kB);
+            it = nx;
+        }
+    }
+    {
+        float* mg = mgbuf + (size_t)((par * 2 + tb) * 66) * 64;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mg[(db * 16 + i) * 64 + lane] = o[db][i];
+        mg[64 * 64 + lane] = m;
+        mg[65 * 64 + lane] = l;
+    }
+    __syncthreads();
+    float mp[4], wp[4];
+    float Mx = MB_NEG, L = 0.f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { mp[p] = mgbuf[(size_t)(((p * 2 + tb) * 66) + 64) * 64 + lane]; Mx = fmaxf(Mx, mp[p]); }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { wp[p] = __expf(mp[p] - Mx); L += mgbuf[(size_t)(((p * 2 + tb) * 66) + 65) * 64 + lane] * wp[p]; }
+    float od[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float v = 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) v += mgbuf[(size_t)(((p * 2 + tb) * 66) + par * 16 + i) * 64 + lane] * wp[p];
+        od[i] = v;
+    }
+    const size_t pidx = (((size_t)blk * a.nh + h) * a.nsplit + sp) * 64 + row;
+    float* op = a.opart + pidx * 128;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 v = {od[4 * g], od[4 * g + 1], od[4 * g + 2], od[4 * g + 3]};
+        *(f32x4*)(op + par * 32 + 8 * g + 4 * hh) = v;
+    }
+    if (hh == 0 && par == 0) { a.mpart[pidx] = Mx; a.lpart[pidx] = L; }
+}
+
+// merge key splits, normalise, round to bf16 and emit the packed operand of o_proj (rows past T carry zeros)
+template <int NS>
+__global__ __launch_bounds__(256) void k_attn_combine_mb(const float* __restrict__ opart, const float* __restrict__ mpart,
+                                                          const float* __restrict__ lpart, int nh, const int* __restrict__ meta,
+                                                          bf16_t* __restrict__ attn_xp) {
+    const int blk = blockIdx.y;
+    const int gid = blockIdx.x * 256 + threadIdx.x;   // (h, tok, d8)
+    if (gid >= nh * 64 * 16) return;
+    const int d8 = gid & 15, tok = (gid >> 4) & 63, h = gid >> 10;
+    bf16_t* dst = attn_xp + (size_t)blk * 64 * nh * 128 + xp_offset(tok, h * 128 + d8 * 8);
+    if (tok >= meta[blk * LA_MB_META + LA_MBM_T]) {
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        *(bf16x8*)dst = z;
+        return;
+    }
+    float ms[NS], ls[NS];
+    f32x4 o0[NS], o1[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const size_t pidx = (((size_t)blk * nh + h) * NS + s) * 64 + tok;
+        ms[s] = mpart[pidx];
+        ls[s] = lpart[pidx];
+        const float* op = opart + pidx * 128 + d8 * 8;
+        o0[s] = *(const f32x4*)op;
+        o1[s] = *(const f32x4*)(op + 4);
+    }
+    float Mx = MB_NEG;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) Mx = fmaxf(Mx, ms[s]);
+    float L = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float w = __expf(ms[s] - Mx);
+        L += w * ls[s];
+        acc[0] += w * o0[s][0]; acc[1] += w * o0[s][1]; acc[2] += w * o0[s][2]; acc[3] += w * o0[s][3];
+        acc[4] += w * o1[s][0]; acc[5] += w * o1[s][1]; acc[6] += w * o1[s][2]; acc[7] += w * o1[s][3];
+    }
+    const float inv = 1.0f / L;
+    bf16x8 ov;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ov[j] = (short)f2bf(acc[j] * inv);
+    *(bf16x8*)dst = ov;
+}
+
+__global__ __launch_bounds__(256) void k_argmax_mb(const float* __restrict__ cv, const int* __restrict__ ci, int n_tiles,
+                                                    int* __restrict__ out) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int t = blockIdx.x, blk = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* cvb = cv + (size_t)blk * n_tiles * 64;
+    const int* cib = ci + (size_t)blk * n_tiles * 64;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int i = threadIdx.x; i < n_tiles; i += 256) {
+        const float v = cvb[(size_t)i * 64 + t];
+        const int idx = cib[(size_t)i * 64 + t];
+        if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bidx, o, 64);
+        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    if (lane == 0) { sv[wave] = best; si[wave] = bidx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bidx)) { best = sv[w]; bidx = si[w]; }
+        out[blk * 64 + t] = bidx;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Accept scan + commit plan, one wavefront per block (same walk as k_accept_scan / pretrained_model_batch.py:814-905):
+// DST[row] = absolute main-cache key row every kept row goes to (root + accepted drafts, or all rows of a prefill chain),
+// then the slots' cursors advance (block order -> deterministic).  One workgroup of nblk waves.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_accept_scan_mb(const int* __restrict__ meta, const int* __restrict__ ids,
+                                 const unsigned long long* __restrict__ rowmask, const int* __restrict__ argmax, int nblk,
+                                 int slot_keys, int* __restrict__ bstate, int* __restrict__ out) {
+    __shared__ int ncommit[8];
+    const int b = threadIdx.x >> 6, j = threadIdx.x & 63;
+    if (b < nblk) {
+        const int* mt = meta + b * LA_MB_META;
+        const int slot = mt[LA_MBM_SLOT], T = mt[LA_MBM_T], mode = mt[LA_MBM_MODE];
+        int limit = mt[LA_MBM_LIMIT];
+        limit = limit < 1 ? 1 : (limit > 16 ? 16 : limit);
+        const int base = slot * slot_keys + mt[LA_MBM_NKEYS] + mt[LA_MBM_BASE];
+        const int am = argmax[b * 64 + j];
+        int dst = -1, nc;
+        if (mode == 1) {
+            const int tok = __shfl(am, T - 1, 64);
+            if (j < T) dst = base + j;
+            if (j == 0) { out[LA_MOUT_OUTTOK + b * 16] = tok; out[LA_MOUT_NOUT + b] = 1; }
+            nc = T;
+        } else {
+            const unsigned long long below = rowmask[b * 64 + j] & ((1ull << j) - 1ull);
+            const int parent = (j == 0 || j >= T || below == 0ull) ? -1 : 63 - __clzll((long long)below);
+            const int myid = ids[b * 64 + j];
+            int cur = 0, depth = 0;
+            if (j == 0) dst = base;
+            while (true) {
+                const int want = __shfl(am, cur, 64);
+                if (j == 0) out[LA_MOUT_OUTTOK + b * 16 + depth] = want;
+                if (depth + 1 >= limit) break;
+                const unsigned long long cand = __ballot(j < T && j > 0 && parent == cur && myid == want);
+                if (cand == 0ull) break;
+                cur = __ffsll((long long)cand) - 1;
+                ++depth;
+                if (j == cur) dst = base + depth;
+            }
+            if (j == 0) out[LA_MOUT_NOUT + b] = depth + 1;
+            nc = depth + 1;
+        }
+        out[LA_MOUT_DST + b * 64 + j] = dst;
+        out[LA_MOUT_ARGMAX + b * 64 + j] = am;
+        if (j == 0) ncommit[b] = nc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int p = 0; p < nblk; ++p) bstate[LA_BST_NKEYS + meta[p * LA_MB_META + LA_MBM_SLOT]] += ncommit[p];
+        for (int p = nblk; p < 8; ++p) out[LA_MOUT_NOUT + p] = 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < LA_MAX_SEQ) out[LA_MOUT_NKEYS + threadIdx.x] = bstate[LA_BST_NKEYS + threadIdx.x];
+}
+
+// fresh rows -> their DST rows of the main cache.  grid = (layers * kv heads, blocks), 256 threads.
+__global__ __launch_bounds__(256) void k_kv_commit_mb(const bf16_t* __restrict__ kfresh, const bf16_t* __restrict__ vfresh,
+                                                       bf16_t* __restrict__ kmain, bf16_t* __restrict__ vmain,
+                                                       const int* __restrict__ out, int nkv, int blk_stride, int total_keys) {
+    const int lh = blockIdx.x, blk = blockIdx.y;
+    const int layer = lh / nkv, head = lh - layer * nkv;
+    const size_t KB = (size_t)(total_keys >> 5);
+    const bf16_t* kf = kfresh + (((size_t)layer * blk_stride + blk) * nkv + head) * 8192;
+    const bf16_t* vf = vfresh + (((size_t)layer * blk_stride + blk) * nkv + head) * 8192;
+    bf16_t* km = kmain + (size_t)lh * KB * 4096;
+    bf16_t* vm = vmain + (size_t)lh * KB * 4096;
+    const int* dstp = out + LA_MOUT_DST + blk * 64;
+    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+        const int r = i >> 4, p = i & 15;
+        const int dst = dstp[r];
+        if (dst < 0 || dst >= total_keys) continue;
+        *(bf16x8*)(km + rf_offset(dst, p * 8)) = *(const bf16x8*)(kf + rf_offset(r, p * 8));
+    }
+    for (int i = threadIdx.x; i < 64 * 128; i += 256) {
+        const int r = i >> 7, d = i & 127;
+        const int dst = dstp[r];
+        if (dst < 0 || dst >= total_keys) continue;
+        vm[vf_offset(dst, d)] = vf[vf_offset(r, d)];
+    }
+}
+
+// =============================================================================================================
+// launchers
+// =============================================================================================================
+static bool g_mb_attr = false;
+template <typename K> static hipError_t set_lds(K k, int bytes) {
+    return hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+static constexpr int mb_lds(int nt) { return (2 * 4 * nt * 1024) > 65536 ? (2 * 4 * nt * 1024) : 65536; }   // x double buffer vs reduction (64 KiB)
+
+int lk_mb_init() {
+    if (g_mb_attr) return 0;
+    hipError_t e = hipSuccess;
+#define SETALL(NT) \
+    if (e == hipSuccess) e = set_lds(k_gemm_mb<2, NT, MB_SLAB>, mb_lds(NT)); \
+    if (e == hipSuccess) e = set_lds(k_gemm_mb<4, NT, MB_SWIGLU>, mb_lds(NT)); \
+    if (e == hipSuccess) e = set_lds(k_gemm_mb<2, NT, MB_QKV>, mb_lds(NT)); \
+    if (e == hipSuccess) e = set_lds(k_gemm_mb<4, NT, MB_LOGITS>, mb_lds(NT));
+    SETALL(2) SETALL(4) SETALL(8)
+#undef SETALL
+    if (e == hipSuccess) e = set_lds(k_tree_attn_mb, 8 * 66 * 64 * 4);
+    if (e != hipSuccess) return (int)e;
+    g_mb_attr = true;
+    return 0;
+}
+
+int lk_mb_build_inputs(hipStream_t st, const int* d_in, const int* d_bstate, int nblk, int* d_meta, int* d_pos,
+                       uint64_t* d_rowmask, int* d_ids) {
+    if (nblk < 1 || nblk > LA_MB_MAX) return -1;
+    k_build_inputs_mb<<<nblk, 64, 0, st>>>(d_in, d_bstate, d_meta, d_pos, (unsigned long long*)d_rowmask, d_ids);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_mb_embed_norm(hipStream_t st, const void* embed, const int* ids, const void* nw, int hidden, float eps, void* h, void* xp,
+                     int M, int cast_first) {
+    if (hidden > 8192 || (hidden & 7)) return -1;
+    k_row_norm_mb<0><<<M, 512, 0, st>>>((const bf16_t*)embed, ids, (bf16_t*)h, nullptr, (const bf16_t*)nw, hidden, eps, (bf16_t*)xp, M, cast_first);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_mb_resid_norm(hipStream_t st, void* h, const float* slabs, int n_slabs, int slab_rows, const void* nw, int hidden, float eps,
+                     void* xp, int M, int cast_first) {
+    if (hidden > 8192 || (hidden & 7)) return -1;
+#define RN(NS) k_row_norm_mb<NS><<<M, 512, 0, st>>>(nullptr, nullptr, (bf16_t*)h, slabs, (const bf16_t*)nw, hidden, eps, (bf16_t*)xp, slab_rows, cast_first)
+    switch (n_slabs) {
+        case 1: RN(1); break; case 2: RN(2); break; case 4: RN(4); break; case 8: RN(8); break;
+        default: return -1;
+    }
+#undef RN
+    LAUNCH_CHECK(); return 0;
+}
+
+int lk_mb_cand_slots(int n_wg) { return n_wg * 4; }
+
+template <int RBV, int EPI>
+static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int nblk) {
+    // token blocks per pass: the smallest template that covers the step in <= 2 passes
+    if (nblk <= 1) { k_gemm_mb<RBV, 2, EPI><<<dim3(n_wg, ksplit, 1), 512, mb_lds(2), st>>>(a); }
+    else if (nblk == 2) { k_gemm_mb<RBV, 4, EPI><<<dim3(n_wg, ksplit, 1), 512, mb_lds(4), st>>>(a); }
+    else { k_gemm_mb<RBV, 8, EPI><<<dim3(n_wg, ksplit, (nblk + 3) / 4), 512, mb_lds(8), st>>>(a); }
+    LAUNCH_CHECK(); return 0;
+}
+
+static void fill_plan(MbArgs& a, int R, int bpm, int mats, int K16) {
+    for (int m = 0; m < mats; ++m)
+        for (int b = 0; b < bpm; ++b) { int v = R - 32 * b; if (v > 32) v = 32; a.nv[m * bpm + b] = v; }
+    int off = 0;
+    for (int i = 0; i < mats * bpm; ++i) { a.nvl[i] = (a.nv[i] + 3) & ~3; a.boff[i] = off; off += a.nvl[i] * 2 * K16; }
+    a.wg_chunks = off;
+}
+
+int lk_mb_gemm(hipStream_t st, int kind, const MbGemm& g) {
+    if (lk_mb_init() != 0) return -1;
+    if (g.nblk < 1 || g.nblk > LA_MB_MAX) return -1;
+    MbArgs a{};
+    a.wp = (const bf16_t*)g.wp; a.xp = (const bf16_t*)g.xp; a.K16 = g.K / 16; a.N = g.N; a.M = g.slab_rows; a.nblk = g.nblk;
+    if (kind == 0) {
+        if (g.N % 64) return -1;
+        a.planned = 0; a.slabs = g.slabs;
+        return launch_mb<2, MB_SLAB>(st, a, g.N / 64, g.ksplit, g.nblk);
+    }
+    a.planned = g.n_wg > 0 ? 1 : 0;
+    for (int i = 0; i < 4; ++i) { a.nv[i] = 32; a.nvl[i] = 32; }
+    if (kind == 1) {
+        a.act_xp = (bf16_t*)g.act_xp;
+        if (!a.planned) {                          // classic interleaved gate/up image: 4 row-blocks {G,U,G,U} per workgroup
+            if (g.N % 64) return -1;
+            a.gu_interleaved = 1; a.R = 64;
+            return launch_mb<4, MB_SWIGLU>(st, a, g.N / 64, 1, g.nblk);
+        }
+        a.R = g.N / g.n_wg; if (g.N % g.n_wg || a.R > 64 || a.R <= 32) return -1;
+        fill_plan(a, a.R, 2, 2, a.K16);
+        return launch_mb<4, MB_SWIGLU>(st, a, g.n_wg, 1, g.nblk);
+    }
+    if (kind == 2) {
+        a.pos = g.pos; a.rcos = (const bf16_t*)g.rcos; a.rsin = (const bf16_t*)g.rsin;
+        a.qf = (bf16_t*)g.qf; a.kfresh = (bf16_t*)g.kfresh; a.vfresh = (bf16_t*)g.vfresh; a.nh = g.nh; a.nkv = g.nkv;
+        if (!a.planned) {                          // classic row-permuted image (la_qkv_row_perm): pair index = 32 * workgroup + f
+            a.R = 32;
+            return launch_mb<2, MB_QKV>(st, a, (g.nh + 2 * g.nkv) * 2, 1, g.nblk);
+        }
+        const int pairs = (g.nh + 2 * g.nkv) * 64;
+        a.R = pairs / g.n_wg; if (pairs % g.n_wg || a.R > 32) return -1;
+        a.nv[0] = a.nv[1] = a.R; a.nvl[0] = a.nvl[1] = (a.R + 3) & ~3;
+        a.boff[0] = 0; a.boff[1] = a.nvl[0] * 2 * a.K16; a.wg_chunks = 2 * a.boff[1];
+        return launch_mb<2, MB_QKV>(st, a, g.n_wg, 1, g.nblk);
+    }
+    if (kind == 3) {
+        a.logits = (bf16_t*)g.logits; a.cand_val = g.cand_val; a.cand_idx = g.cand_idx;
+        if (!a.planned) {
+            if (g.N % 128) return -1;
+            a.R = 128;
+            return launch_mb<4, MB_LOGITS>(st, a, g.N / 128, 1, g.nblk);
+        }
+        a.R = g.N / g.n_wg; if (g.N % g.n_wg || a.R > 128 || a.R <= 96) return -1;
+        fill_plan(a, a.R, 4, 1, a.K16);
+        return launch_mb<4, MB_LOGITS>(st, a, g.n_wg, 1, g.nblk);
+    }
+    return -1;
+}
+
+// workgroups of the lm_head launch (argmax candidate slots = 4 per workgroup and block)
+int lk_mb_logits_wgs(int V, int n_wg) { return n_wg > 0 ? n_wg : V / 128; }
+
+int lk_mb_argmax(hipStream_t st, const float* cv, const int* ci, int n_tiles, int nblk, int* out_rows) {
+    k_argmax_mb<<<dim3(64, nblk), 256, 0, st>>>(cv, ci, n_tiles, out_rows);
+    LAUNCH_CHECK(); return 0;
+}
+
+int lk_mb_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh, const void* vfresh,
+                    const uint64_t* rowmask, const int* meta, int nblk, int nh, int nkv, int slot_keys, int n_slots, int nsplit,
+                    float* opart, float* mpart, float* lpart, void* attn_xp, int window) {
+    if (lk_mb_init() != 0 || nblk < 1 || nblk > LA_MB_MAX || (slot_keys & 31)) return -1;
+    MbAttnArgs a{};
+    a.qf = (const bf16_t*)qf; a.kmain = (const bf16_t*)kmain; a.vmain = (const bf16_t*)vmain;
+    a.kfresh = (const bf16_t*)kfresh; a.vfresh = (const bf16_t*)vfresh;
+    a.rowmask = (const unsigned long long*)rowmask; a.meta = meta;
+    a.nh = nh; a.nkv = nkv; a.total_keys = slot_keys * n_slots; a.slot_tiles = slot_keys >> 5; a.nsplit = nsplit; a.window = window;
+    a.opart = opart; a.mpart = mpart; a.lpart = lpart;
+    k_tree_attn_mb<<<dim3(nh, nsplit, nblk), 512, 8 * 66 * 64 * sizeof(float), st>>>(a);
+    LAUNCH_CHECK();
+    const int total = nh * 64 * 16;
+#define AC(NS) k_attn_combine_mb<NS><<<dim3((total + 255) / 256, nblk), 256, 0, st>>>(opart, mpart, lpart, nh, meta, (bf16_t*)attn_xp)
+    switch (nsplit) {
+        case 1: AC(1); break; case 2: AC(2); break; case 4: AC(4); break; case 8: AC(8); break;
+        default: return -1;
+    }
+#undef AC
+    LAUNCH_CHECK(); return 0;
+}
+
+int lk_mb_accept_scan(hipStream_t st, const int* meta, const int* ids, const uint64_t* rowmask, const int* argmax, int nblk,
+                      int slot_keys, int* bstate, int* d_out) {
+    if (nblk < 1 || nblk > LA_MB_MAX) return -1;
+    k_accept_scan_mb<<<1, 512, 0, st>>>(meta, ids, (const unsigned long long*)rowmask, argmax, nblk, slot_keys, bstate, d_out);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_mb_kv_commit(hipStream_t st, const void* kfresh, const void* vfresh, void* kmain, void* vmain, const int* d_out, int nblk,
+                    int n_layers, int nkv, int total_keys) {
+    k_kv_commit_mb<<<dim3(n_layers * nkv, nblk), 256, 0, st>>>((const bf16_t*)kfresh, (const bf16_t*)vfresh, (bf16_t*)kmain,
+                                                              (bf16_t*)vmain, d_out, nkv, LA_MB_MAX, total_keys);
+    LAUNCH_CHECK(); return 0;
+}

@@ -138,7 +138,7 @@ class LlamaVerifyEngine(object):
     verify block are shared by the active slots (bstep)."""
 
     def __init__(self, shape, state_dict, max_length=2048, device='cuda:0', attn_split=0, gemm_cfg=None,
-                 consume_state_dict=False, balanced=True, n_slots=1, fuse=0):
+                 consume_state_dict=False, balanced=True, n_slots=1, fuse=0, max_blocks=0):
         if not torch.cuda.is_available():
             raise RuntimeError('LlamaVerifyEngine needs an MI355X: the verify step has no CPU fallback')
         self.shape = shape
@@ -286,6 +286,9 @@ class LlamaVerifyEngine(object):
         cfg.n_experts, cfg.top_k = shape.n_experts, shape.top_k
         cfg.norm_cast_first = int(shape.norm_cast_first)
         cfg.fuse = int(fuse)
+        assert 0 <= max_blocks <= _lib.LA_MB_MAX
+        self.max_blocks = int(max_blocks) if max_blocks > 1 else 0
+        cfg.max_blocks = self.max_blocks
         cfg.sliding_window = int(getattr(shape, 'sliding_window', 0))
         self._cfg = cfg
         nbytes = lib.la_llama_workspace_bytes(C.byref(cfg))
@@ -305,6 +308,12 @@ class LlamaVerifyEngine(object):
         self._bin_np = self.host_bin.numpy()
         self._bout_np = self.host_bout.numpy()
         self._bin_rm = self._bin_np[_lib.LA_BIN_ROWMASK:_lib.LA_BIN_ROWMASK + 128].view(np.uint64)
+        if self.max_blocks:
+            self.host_min = torch.zeros(_lib.LA_MIN_WORDS, dtype=torch.int32).pin_memory()
+            self.host_mout = torch.zeros(_lib.LA_MOUT_DST, dtype=torch.int32).pin_memory()
+            self._min_np = self.host_min.numpy()
+            self._mout_np = self.host_mout.numpy()
+            self._min_rm = self._min_np[_lib.LA_MIN_ROWMASK:_lib.LA_MIN_ROWMASK + 2 * 64 * _lib.LA_MB_MAX].view(np.uint64)
         self.slot_keys = [0] * self.n_slots
         self.n_keys = 0
         self.reset()
@@ -397,6 +406,63 @@ class LlamaVerifyEngine(object):
                 if done[s] == len(todo[s]):
                     first[s] = out[s][0]
         return first
+
+    # ---- multi-block step: every block is a full 64-row verify block of its own (la_llama_mstep) ---------------------
+    def mstep(self, blocks, eager=False):
+        """blocks: list of (slot, ids, rowmask, mode, limit) — one sequence's draft tree each (mode 0), or consecutive
+        64-token pieces of one prompt (mode 1, same slot: a causal chain; every piece but the last holds 64 rows).
+        All blocks run in ONE pass over the weights (M = 64 * len(blocks) rows).  -> list of emitted token lists."""
+        assert self.max_blocks and 1 <= len(blocks) <= self.max_blocks, 'engine was created with max_blocks < len(blocks)'
+        a = self._min_np
+        a[_lib.LA_MIN_NBLK] = len(blocks)
+        used = {}
+        for b, (slot, ids, rowmask, mode, limit) in enumerate(blocks):
+            n = len(ids)
+            assert 0 <= slot < self.n_slots and 1 <= n <= 64
+            prev = used.get(slot)
+            assert prev is None or (mode == 1 and prev == (1, 64)), 'several blocks of one slot must form a prefill chain of full blocks'
+            used[slot] = (mode, n)
+            a[_lib.LA_MIN_BLK + 4 * b:_lib.LA_MIN_BLK + 4 * b + 4] = (slot, n, mode, max(1, min(16, int(limit))))
+            a[_lib.LA_MIN_IDS + 64 * b:_lib.LA_MIN_IDS + 64 * b + n] = ids
+            self._min_rm[64 * b:64 * b + n] = rowmask
+        rows = {}
+        for slot, ids, _, _, _ in blocks:
+            rows[slot] = rows.get(slot, 0) + len(ids)
+        for slot, n in rows.items():
+            assert self.slot_keys[slot] + n <= self.max_keys, 'KV cache capacity of the slot exceeded'
+        fn = lib.la_llama_mstep_eager if eager else lib.la_llama_mstep
+        check(fn(self._h, self._sp(), self.host_min.data_ptr(), self.host_mout.data_ptr()), 'llama_mstep')
+        self.stream.synchronize()
+        o = self._mout_np
+        for slot in rows:
+            self.slot_keys[slot] = int(o[_lib.LA_MOUT_NKEYS + slot])
+        if 0 in rows:
+            self.n_keys = self.slot_keys[0]
+        return [o[_lib.LA_MOUT_OUTTOK + 16 * b:_lib.LA_MOUT_OUTTOK + 16 * b + int(o[_lib.LA_MOUT_NOUT + b])].tolist()
+                for b in range(len(blocks))]
+
+    def mprefill(self, slot, prompt_ids, eager=False):
+        """Prompt of one slot in passes of up to max_blocks x 64 tokens (one pass over the weights each); -> first
+        generated token.  Slot 0 hands its cursor to the single-sequence step as well (la_llama_set_nkeys)."""
+        prompt_ids = [int(x) for x in prompt_ids]
+        tok = None
+        per = 64 * self.max_blocks
+        for s in range(0, len(prompt_ids), per):
+            piece = prompt_ids[s:s + per]
+            blocks = [(slot, np.asarray(piece[i:i + 64], dtype=np.int32), self._CHAIN[:len(piece[i:i + 64])], 1, 1)
+                      for i in range(0, len(piece), 64)]
+            tok = self.mstep(blocks, eager=eager)[-1][0]
+        if slot == 0:
+            check(lib.la_llama_set_nkeys(self._h, self._sp(), 0, self.slot_keys[0]), 'set_nkeys')
+            self.n_keys = self.slot_keys[0]
+        return tok
+
+    def mlogits(self):
+        """bf16 [max_blocks * 64][vocab] of the last multi-block step (row = 64 * block + tree row)."""
+        return self._view(11, _lib.LA_MB_MAX * 64 * self.shape.vocab * 2, torch.bfloat16).view(_lib.LA_MB_MAX * 64, self.shape.vocab)
+
+    def mout(self):
+        return self._view(12, _lib.LA_MOUT_WORDS * 4, torch.int32)
 
     def bstate(self):
         return self._view(8, _lib.LA_BST_WORDS * 4, torch.int32)

@@ -1,0 +1,257 @@
+# -*- coding: utf-8 -*-
+"""-m gpu: the multi-block step (la_llama_mstep / la_mb_gemm, csrc/la_mblock.hip) through the C ABI.
+
+Every block of a multi-block step is one sequence's full 64-row verify block (or one 64-token piece of a prompt), so parity
+is defined per sequence: block b of an M = 64*B row step must reproduce what the bs=1 oracle computes for that
+sequence alone — logits within the tolerance of test_gpu_e2e.py (2e-2 * max|logit| per row, argmax wherever the gap is
+decisive), accept walk / commit plan / cursors bit-exact given the device's argmax rows."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import llama_oracle as lo
+from painlessinferenceacceleration_amd import _lib
+from painlessinferenceacceleration_amd._lib import check, lib
+from painlessinferenceacceleration_amd.llama_engine import LlamaShape, LlamaVerifyEngine, random_weights, rope_tables
+from tests import gpu_utils as gu
+from tests.gpu_utils import DEV, ptr, random_tree, sp
+from tests.test_gpu_e2e import TOL, _bf16_sd, _check_rows, _mask_from_rows
+from tests.tiny_model import tiny_shape
+
+pytestmark = pytest.mark.gpu
+
+# Logits tolerance on the TINY seeded model (hidden 256, weights std 0.08): measured on MI355X (scripts/gpu_mb_diag.py, 15 prompts)
+# the 64-row path and the multi-block path sit at the same distance from the bf16 CPU oracle (max 0.0211 vs 0.0221 of max|logit|
+# per row, mean 0.012 both) and within 0.013 of each other; the tails of that distribution cross 2e-2, so the tiny-model checks of
+# this file use 3e-2 and the Llama-2-7B-shape check keeps the stated 2e-2.
+TOL_TINY = 3e-2
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _pack_blocks(x):
+    """[nblk*64][K] -> nblk consecutive 64-row XP images"""
+    return torch.cat([gu.pack_x(x[b * 64:(b + 1) * 64].contiguous()) for b in range(x.shape[0] // 64)])
+
+
+def _mb(kind, wp, xp, N, K, nblk, n_wg=0, ksplit=1, slabs=None, slab_rows=0, act=None, logits=None, cv=None, ci=None, pos=None,
+        rc=None, rs_=None, qf=None, kf=None, vf=None, nh=0, nkv=0):
+    check(lib.la_mb_gemm(sp(), kind, ptr(wp), ptr(xp), N, K, nblk, n_wg, ksplit, ptr(slabs), slab_rows, ptr(act), ptr(logits), ptr(cv),
+                         ptr(ci), ptr(pos), ptr(rc), ptr(rs_), ptr(qf), ptr(kf), ptr(vf), nh, nkv), 'mb_gemm')
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('nblk', [1, 2, 3, 4, 8])
+@pytest.mark.parametrize('N,K,ks', [(256, 512, 1), (4096, 1376, 4), (512, 11008, 4)])
+def test_mb_slab_gemm(nblk, N, K, ks):
+    g = torch.Generator(device=DEV).manual_seed(N + nblk)
+    x = bf(torch.randn(nblk * 64, K, generator=g, device=DEV))
+    w = bf(torch.randn(N, K, generator=g, device=DEV) * 0.05)
+    rows = (nblk if nblk <= 2 else (nblk + 3) // 4 * 4) * 64
+    slabs = torch.full((ks, rows, N), float('nan'), dtype=torch.float32, device=DEV)
+    _mb(0, gu.pack_weight(w), _pack_blocks(x), N, K, nblk, ksplit=ks, slabs=slabs, slab_rows=rows)
+    got = slabs[:, :nblk * 64].sum(0)
+    ref = x.double() @ w.double().t()
+    assert gu.rel_err(got, ref) < 2e-3, gu.rel_err(got, ref)
+
+
+@pytest.mark.parametrize('nblk', [1, 2, 4, 5])
+@pytest.mark.parametrize('F,K,nwg', [(512, 256, 0), (11008, 512, 256), (688, 512, 16)])
+def test_mb_swiglu_gemm_planned_and_classic(nblk, F, K, nwg):
+    g = torch.Generator(device=DEV).manual_seed(F + nblk)
+    x = bf(torch.randn(nblk * 64, K, generator=g, device=DEV))
+    wg = bf(torch.randn(F, K, generator=g, device=DEV) * 0.05)
+    wu = bf(torch.randn(F, K, generator=g, device=DEV) * 0.05)
+    wp = gu.pack_planned(1, [wg, wu], nwg) if nwg else gu.pack_weight(wg, wu)
+    act = torch.zeros(8 * 64 * F, dtype=torch.bfloat16, device=DEV)
+    _mb(1, wp, _pack_blocks(x), F, K, nblk, n_wg=nwg, act=act)
+    for b in range(nblk):
+        got = gu.from_packed(act[b * 64 * F:(b + 1) * 64 * F], gu.xp_index(F)).float()
+        xb = x[b * 64:(b + 1) * 64].float()
+        gg, uu = bf(xb @ wg.float().t()), bf(xb @ wu.float().t())
+        ref = bf(bf(torch.nn.functional.silu(gg.float())).float() * uu.float()).float()
+        assert gu.rel_err(got, ref) < 2e-2, (b, gu.rel_err(got, ref))
+        assert float((got != ref).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize('nblk', [1, 3, 4, 8])
+@pytest.mark.parametrize('V,K,nwg', [(512, 256, 0), (32000, 512, 256)])
+def test_mb_logits_gemm_and_argmax(nblk, V, K, nwg):
+    g = torch.Generator(device=DEV).manual_seed(V + nblk)
+    x = bf(torch.randn(nblk * 64, K, generator=g, device=DEV))
+    w = bf(torch.randn(V, K, generator=g, device=DEV) * 0.05)
+    wp = gu.pack_planned(0, [w], nwg) if nwg else gu.pack_weight(w)
+    n_tiles = 4 * (nwg if nwg else V // 128)
+    logits = torch.zeros(8 * 64, V, dtype=torch.bfloat16, device=DEV)
+    cv = torch.zeros(8 * n_tiles * 64, dtype=torch.float32, device=DEV)
+    ci = torch.zeros(8 * n_tiles * 64, dtype=torch.int32, device=DEV)
+    _mb(3, wp, _pack_blocks(x), V, K, nblk, n_wg=nwg, logits=logits, cv=cv, ci=ci)
+    lg = logits[:nblk * 64].float()
+    assert gu.rel_err(lg, x.double() @ w.double().t()) < 1e-2
+    # argmax candidates reduce to the first maximum of the stored bf16 row (torch.argmax tie rule on CPU)
+    cvv = cv.view(8, n_tiles, 64)[:nblk].cpu()
+    cii = ci.view(8, n_tiles, 64)[:nblk].cpu()
+    lf = lg.cpu()
+    for b in range(nblk):
+        for t in range(0, 64, 7):
+            row = lf[b * 64 + t]
+            best = float(row.max())
+            exp = int((row == best).nonzero()[0])
+            cand = [(float(cvv[b, i, t]), int(cii[b, i, t])) for i in range(n_tiles)]
+            mv = max(c[0] for c in cand)
+            assert mv == best and min(c[1] for c in cand if c[0] == mv) == exp
+
+
+@pytest.mark.parametrize('nblk', [1, 2, 4, 6])
+@pytest.mark.parametrize('nh,nkv,nwg', [(2, 2, 0), (32, 32, 256), (8, 2, 32)])
+def test_mb_qkv_gemm_equals_single_block_kernel(nblk, nh, nkv, nwg):
+    """Fragments written by the multi-block QKV launch == the single-block balanced / classic kernel run per block (same
+    rounding points; the fp32 sums differ by the K split, so a small fraction of elements moves by one bf16 ulp)."""
+    K = 512
+    N = (nh + 2 * nkv) * 128
+    g = torch.Generator(device=DEV).manual_seed(nh * 7 + nkv + nblk)
+    x = bf(torch.randn(nblk * 64, K, generator=g, device=DEV))
+    w = bf(torch.randn(N, K, generator=g, device=DEV) * 0.05)
+    pos = torch.randint(0, 900, (nblk * 64,), generator=g, device=DEV, dtype=torch.int32)
+    rc, rs_ = rope_tables(128, 1024, 10000.0, DEV)
+    if nwg:
+        wp = gu.pack_planned(2, [w], nwg)
+    else:
+        perm = np.zeros(N, dtype=np.int32)
+        check(lib.la_qkv_row_perm(nh, nkv, perm.ctypes.data_as(_lib.pi32)), 'perm')
+        wp = gu.pack_weight(w[torch.from_numpy(perm.astype(np.int64)).to(DEV)].contiguous())
+    qf = torch.zeros(8 * nh * 8192, dtype=torch.bfloat16, device=DEV)
+    kf = torch.zeros(8 * nkv * 8192, dtype=torch.bfloat16, device=DEV)
+    vf = torch.zeros(8 * nkv * 8192, dtype=torch.bfloat16, device=DEV)
+    xp = _pack_blocks(x)
+    _mb(2, wp, xp, N, K, nblk, n_wg=nwg, pos=pos, rc=rc, rs_=rs_, qf=qf, kf=kf, vf=vf, nh=nh, nkv=nkv)
+    for b in range(nblk):
+        q1 = torch.zeros(nh * 8192, dtype=torch.bfloat16, device=DEV)
+        k1 = torch.zeros(nkv * 8192, dtype=torch.bfloat16, device=DEV)
+        v1 = torch.zeros(nkv * 8192, dtype=torch.bfloat16, device=DEV)
+        xb = xp[b * 64 * K:(b + 1) * 64 * K]
+        pb = pos[b * 64:(b + 1) * 64].contiguous()
+        if nwg:
+            check(lib.la_gemm64r_qkv(sp(), ptr(wp), ptr(xb), nh, nkv, K, nwg, ptr(pb), ptr(rc), ptr(rs_), ptr(q1), ptr(k1), ptr(v1)), 'qkv_r')
+        else:
+            check(lib.la_gemm64_qkv(sp(), ptr(wp), ptr(xb), nh, nkv, K, ptr(pb), ptr(rc), ptr(rs_), ptr(q1), ptr(k1), ptr(v1), 0), 'qkv')
+        torch.cuda.synchronize()
+        for a, ref, name in ((qf[b * nh * 8192:(b + 1) * nh * 8192], q1, 'q'), (kf[b * nkv * 8192:(b + 1) * nkv * 8192], k1, 'k'),
+                             (vf[b * nkv * 8192:(b + 1) * nkv * 8192], v1, 'v')):
+            assert gu.rel_err(a.float(), ref.float()) < 1e-2, (b, name)
+            assert float((a != ref).float().mean()) < 0.02, (b, name)
+
+
+def _oracle_seq(oracle, prompt):
+    P = len(prompt)
+    lg, past = oracle.forward(torch.tensor(prompt), torch.tril(torch.ones((P, P), dtype=torch.long)), None)
+    return lg, past
+
+
+@pytest.mark.parametrize('B', [2, 4, 5, 8])
+def test_mstep_every_block_matches_its_bs1_oracle_run(B):
+    """B sequences with different prompt lengths, each with its own 64-row random tree in ONE multi-block step: logits of
+    block b vs the oracle run on sequence b alone, accept walk and commit plan bit-exact given the device argmax, then a second
+    step on the committed caches (checks the KV rows the first step kept)."""
+    shape = tiny_shape()
+    sd = _bf16_sd(1)
+    eng = LlamaVerifyEngine(shape, sd, max_length=384, n_slots=B, max_blocks=B)
+    oracle = lo.OracleLlama(shape, sd)
+    rs = np.random.RandomState(B)
+    prompts = [rs.randint(3, shape.vocab, size=int(rs.randint(5, 150))).tolist() for _ in range(B)]
+    pasts, nk = [], []
+    for b, p in enumerate(prompts):
+        tok = eng.mprefill(b, p)
+        lg, past = _oracle_seq(oracle, p)
+        _check_rows(eng.mlogits()[((len(p) - 1) // 64 % eng.max_blocks) * 64:][:(len(p) - 1) % 64 + 1],
+                    lg[(len(p) - 1) // 64 * 64:], range((len(p) - 1) % 64 + 1), f'prefill {b}', tol=TOL_TINY)
+        assert eng.slot_keys[b] == len(p)
+        pasts.append(past)
+        nk.append(len(p))
+        prompts[b] = p + [tok]
+    for step in range(2):
+        blocks, trees = [], []
+        for b in range(B):
+            T = int(rs.randint(1, 65)) if b else 64
+            _, rows = random_tree(rs, T)
+            ids = np.concatenate([[prompts[b][-1]], rs.randint(3, shape.vocab, size=T - 1)]).astype(np.int32)
+            blocks.append((b, ids, rows, 0, 16))
+            trees.append((ids, rows, T))
+        outs = eng.mstep(blocks, eager=(step == 1))
+        mo = eng.mout().cpu().numpy()
+        for b in range(B):
+            ids, rows, T = trees[b]
+            mask = _mask_from_rows(rows, T)
+            full = torch.cat([torch.ones((T, nk[b]), dtype=torch.long), torch.from_numpy(mask)], 1)
+            lg, past_all = oracle.forward(torch.tensor(ids.tolist()), full, pasts[b])
+            _check_rows(eng.mlogits()[b * 64:b * 64 + T], lg, range(T), f'step {step} block {b}', tol=TOL_TINY)
+            am = mo[_lib.LA_MOUT_ARGMAX + 64 * b:_lib.LA_MOUT_ARGMAX + 64 * b + T].tolist()
+            exp_toks, exp_rows = lo.accept_scan(ids.tolist(), mask, am)
+            exp_toks, exp_rows = exp_toks[:16], exp_rows[:16]
+            assert outs[b] == exp_toks, (step, b)
+            dst = mo[_lib.LA_MOUT_DST + 64 * b:_lib.LA_MOUT_DST + 64 * b + 64]
+            want = np.full(64, -1, dtype=np.int64)
+            for d, r in enumerate(exp_rows):
+                want[r] = b * eng.max_keys + nk[b] + d
+            assert dst.tolist() == want.tolist(), (step, b)
+            keep = list(range(nk[b])) + [nk[b] + r for r in exp_rows]
+            idx = torch.tensor(keep, dtype=torch.long)
+            pasts[b] = [(k[:, idx], v[:, idx]) for k, v in past_all]
+            nk[b] += len(exp_rows)
+            assert eng.slot_keys[b] == nk[b]
+            prompts[b] = prompts[b] + exp_toks
+
+
+@pytest.mark.parametrize('P', [64, 130, 512, 700])
+def test_mprefill_chain_equals_oracle_and_feeds_the_single_sequence_step(P):
+    """A prompt as ONE chain of 64-row blocks per pass (blocks see the fresh keys of the earlier blocks of the chain), then a
+    tree step on the classic single-sequence path on top of the cache the chain committed."""
+    shape = tiny_shape()
+    sd = _bf16_sd(2)
+    eng = LlamaVerifyEngine(shape, sd, max_length=1024, n_slots=1, max_blocks=8)
+    oracle = lo.OracleLlama(shape, sd)
+    rs = np.random.RandomState(P)
+    prompt = rs.randint(3, shape.vocab, size=P).tolist()
+    tok = eng.mprefill(0, prompt)
+    lg, past = _oracle_seq(oracle, prompt)
+    last = (P - 1) // 64
+    nb_last_pass = last % 8
+    rows = (P - 1) % 64 + 1
+    _check_rows(eng.mlogits()[nb_last_pass * 64:nb_last_pass * 64 + rows], lg[last * 64:], range(rows), 'chain', tol=TOL_TINY)
+    top = torch.topk(lg[-1].float(), 2).values
+    if float(top[0] - top[1]) > 4 * TOL * float(lg[-1].float().abs().max()):
+        assert tok == int(lg[-1].float().argmax())
+    assert eng.n_keys == P
+    T = 64
+    _, trows = random_tree(rs, T)
+    ids = np.concatenate([[tok], rs.randint(3, shape.vocab, size=T - 1)]).astype(np.int32)
+    eng.step(ids, trows, mode=0)
+    full = torch.cat([torch.ones((T, P), dtype=torch.long), torch.from_numpy(_mask_from_rows(trows, T))], 1)
+    lg2, _ = oracle.forward(torch.tensor(ids.tolist()), full, past)
+    _check_rows(eng.logits(), lg2, range(T), 'tree after chain', tol=TOL_TINY)
+
+
+def test_mstep_llama7b_layer_shapes_vs_oracle():
+    """Two layers at the Llama-2-7B layer shape (balanced weight images, K = 4096 / 11008), 4 sequences x 64 rows."""
+    shape = LlamaShape(2, 4096, 32, 32, 11008, 32000, 1e-5)
+    sd = random_weights(shape, seed=5, device='cpu')
+    eng = LlamaVerifyEngine(shape, sd, max_length=256, n_slots=4, max_blocks=4)
+    assert all(eng.balanced_wg), eng.balanced_wg
+    oracle = lo.OracleLlama(shape, sd)
+    rs = np.random.RandomState(3)
+    blocks, refs = [], []
+    for b in range(4):
+        p = rs.randint(3, shape.vocab, size=int(rs.randint(20, 100))).tolist()
+        tok = eng.mprefill(b, p)
+        _, past = _oracle_seq(oracle, p)
+        T = 64 if b == 0 else int(rs.randint(8, 65))
+        _, rows = random_tree(rs, T)
+        ids = np.concatenate([[tok], rs.randint(3, shape.vocab, size=T - 1)]).astype(np.int32)
+        blocks.append((b, ids, rows, 0, 16))
+        full = torch.cat([torch.ones((T, len(p)), dtype=torch.long), torch.from_numpy(_mask_from_rows(rows, T))], 1)
+        refs.append((oracle.forward(torch.tensor(ids.tolist()), full, past)[0], T))
+    eng.mstep(blocks)
+    for b, (lg, T) in enumerate(refs):
+        _check_rows(eng.mlogits()[b * 64:b * 64 + T], lg, range(T), f'7B-shape block {b}')
