@@ -152,7 +152,7 @@ static size_t carve(la_llama* m, char* base) {
     m->mb_max = c.max_blocks > 1 ? c.max_blocks : 0;
     if (m->mb_max) {
         const size_t MB = (size_t)LA_MB_MAX, R = MB * 64;            // sized for whole passes of 4 blocks
-        m->mb_nsplit = m->nsplit > 4 ? 4 : m->nsplit;              // attention grid = (heads, splits, blocks): fewer splits fill the chip
+        m->mb_nsplit = 8;                                           // splits x blocks <= 8 (see mb_split): partial buffers hold 8 units
         m->mb_h = cv.take<uint16_t>(R * c.hidden);
         m->mb_xp = cv.take<uint16_t>(R * c.hidden);
         m->mb_attn_xp = cv.take<uint16_t>(R * m->o_k);
@@ -164,9 +164,9 @@ static size_t carve(la_llama* m, char* base) {
         m->mb_fresh_layer = MB * c.n_kv_heads * 8192;
         m->mb_kfresh = cv.take<uint16_t>(m->mb_fresh_layer * c.n_layers);
         m->mb_vfresh = cv.take<uint16_t>(m->mb_fresh_layer * c.n_layers);
-        m->mb_opart = cv.take<float>(MB * c.n_heads * m->mb_nsplit * 64 * 128);
-        m->mb_mpart = cv.take<float>(MB * c.n_heads * m->mb_nsplit * 64);
-        m->mb_lpart = cv.take<float>(MB * c.n_heads * m->mb_nsplit * 64);
+        m->mb_opart = cv.take<float>((size_t)8 * c.n_heads * 64 * 128);
+        m->mb_mpart = cv.take<float>((size_t)8 * c.n_heads * 64);
+        m->mb_lpart = cv.take<float>((size_t)8 * c.n_heads * 64);
         const size_t cslots = (size_t)lk_mb_cand_slots(lk_mb_logits_wgs(c.vocab, c.balanced_wg[2]));
         m->mb_cand_val = cv.take<float>(MB * cslots * 64);
         m->mb_cand_idx = cv.take<int>(MB * cslots * 64);
@@ -480,6 +480,9 @@ extern "C" int la_llama_bstep_eager(la_llama* m, void* stream, const int32_t* ho
 }
 
 // ---- multi-block step: nblk x 64 rows through the LDS-staged GEMM family (la_mblock.hip) -------------------------------
+// key splits of the multi-block attention: heads x splits x blocks workgroups should fill the 256 CUs about once
+static int mb_split(int nblk) { return nblk > 4 ? 1 : nblk > 2 ? 2 : nblk == 2 ? 4 : 8; }      // splits x blocks <= 8
+
 static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk) {
     const la_llama_config& c = m->cfg;
     if (c.n_experts > 0) { la_set_error("mstep: the sparse-MoE MLP runs on the 64-row path only"); return LA_E_ARG; }
@@ -498,7 +501,7 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk) {
         q.nh = c.n_heads; q.nkv = c.n_kv_heads;
         KCHK(lk_mb_gemm(st, 2, q));
         KCHK(lk_mb_tree_attn(st, m->mb_qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems, kf, vf,
-                             m->mb_rowmask, m->mb_meta, nblk, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, m->mb_nsplit,
+                             m->mb_rowmask, m->mb_meta, nblk, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, mb_split(nblk),
                              m->mb_opart, m->mb_mpart, m->mb_lpart, m->mb_attn_xp, c.sliding_window));
         MbGemm o{}; o.wp = L.wo; o.xp = m->mb_attn_xp; o.N = c.hidden; o.K = m->o_k; o.nblk = nblk; o.ksplit = m->o_ks;
         o.slabs = m->mb_slabs; o.slab_rows = npass_rows;

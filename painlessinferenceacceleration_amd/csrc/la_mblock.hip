@@ -110,15 +110,47 @@ __global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
     if (nstages > 0) {
+        // x fragments are prefetched XD stages ahead in registers.  vmcnt retires in order, so a wait on an x set also waits for
+        // every OLDER load: with the sets issued XD = D/KT stages before their ds_write, the loads younger than the awaited set
+        // are XD-1 x sets and exactly D weight tiles — the weight ring stays D deep across every stage boundary (with a 1-stage
+        // x prefetch each stage end drained the weight queue to KT tiles: 3x slower, profiles/r02_mblock_kernel_stats_v1.txt).
+        constexpr int XD = D / KT >= 4 ? 4 : D / KT;
+        static_assert(SPG % XD == 0 && (SPG % 2) == 0, "static ring indices inside an unrolled group");
         bf16x8 fa[D];
-        bf16x8 xr[FPW];
+        bf16x8 xr[XD][FPW];
+#pragma unroll
+        for (int x = 0; x < XD; ++x) xload(x, xr[x]);                      // stages 0..XD-1 (clamped past the end)
 #pragma unroll
         for (int d = 0; d < D; ++d) fa[d] = __builtin_nontemporal_load(wbase + woff + (unsigned)(d < my_cnt ? d : 0) * wstr);
-        xload(0, xr);
-        xstore(0, xr);
-        if (nstages > 1) xload(1, xr);
+        xstore(0, xr[0]);
+        xload(XD, xr[0]);
         __syncthreads();
-        for (int sg = 0; sg < nstages; sg += SPG) {
+        // Full groups: every part has all D tiles of the group -> branch-free body (tile indices past a part's end only occur in
+        // refills and x prefetches, where they are clamped to a valid tile), order pinned with sched_barrier so that hipcc
+        // keeps the ring slots in fixed registers and emits counted s_waitcnt vmcnt(n) instead of draining the queue.
+        const int gfull = pq / D;
+        for (int g = 0; g < gfull; ++g) {
+#pragma unroll
+            for (int u = 0; u < SPG; ++u) {
+#pragma unroll
+                for (int j = 0; j < KT; ++j) {
+                    const int slotw = u * KT + j;
+                    const bf16x8* xt = xs + (((u & 1) * FR) + (kp * KT + j) * NT) * 64 + lane;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slotw], xt[t * 64], acc[t], 0, 0, 0);
+                    const int nx = g * D + slotw + D;
+                    fa[slotw] = __builtin_nontemporal_load(wbase + woff + (unsigned)(nx < my_cnt ? nx : 0) * wstr);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                xstore((u + 1) & 1, xr[(u + 1) % XD]);
+                xload(g * SPG + u + 1 + XD, xr[(u + 1) % XD]);
+                __syncthreads();
+            }
+        }
+        // Tail group (< D tiles per part, parts may differ by one tile): same ring positions, every step guarded.
+        {
+            const int sg = gfull * SPG;
 #pragma unroll
             for (int u = 0; u < SPG; ++u) {
                 const int s = sg + u;
@@ -126,19 +158,16 @@ __global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
 #pragma unroll
                     for (int j = 0; j < KT; ++j) {
                         const int kl = s * KT + j;
-                        const int slotw = (u * KT + j) % D;
+                        const int slotw = u * KT + j;
                         if (kl < my_cnt) {                                 // wave-uniform
-                            const bf16x8 av = fa[slotw];
-                            const int nx = kl + D;
-                            fa[slotw] = __builtin_nontemporal_load(wbase + woff + (unsigned)(nx < my_cnt ? nx : 0) * wstr);
                             const bf16x8* xt = xs + (((u & 1) * FR) + (kp * KT + j) * NT) * 64 + lane;
 #pragma unroll
                             for (int t = 0; t < NT; ++t)
-                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, xt[t * 64], acc[t], 0, 0, 0);
+                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slotw], xt[t * 64], acc[t], 0, 0, 0);
                         }
                     }
-                    if (s + 1 < nstages) xstore((u + 1) & 1, xr);          // slot of stage s-1: every wave passed its barrier
-                    if (s + 2 < nstages) xload(s + 2, xr);
+                    xstore((u + 1) & 1, xr[(u + 1) % XD]);
+                    xload(s + 1 + XD, xr[(u + 1) % XD]);
                     __syncthreads();
                 }
             }

@@ -457,6 +457,29 @@ class LlamaVerifyEngine(object):
             self.n_keys = self.slot_keys[0]
         return tok
 
+    def mprefill_many(self, prompts, eager=False):
+        """prompts: {slot: token list}.  The 64-token pieces of all prompts are dealt, slot after slot, into passes of up to
+        max_blocks blocks (one pass over the weights each); a slot whose prompt spans several passes continues from its
+        committed keys.  -> {slot: first generated token}."""
+        todo = {s: [int(x) for x in p] for s, p in prompts.items()}
+        assert all(len(p) > 0 for p in todo.values())
+        pieces = []                                   # (slot, piece, is_last)
+        for s in sorted(todo):
+            p = todo[s]
+            for i in range(0, len(p), 64):
+                pieces.append((s, p[i:i + 64], i + 64 >= len(p)))
+        first = {}
+        for i in range(0, len(pieces), self.max_blocks):
+            group = pieces[i:i + self.max_blocks]
+            out = self.mstep([(s, np.asarray(pc, dtype=np.int32), self._CHAIN[:len(pc)], 1, 1) for s, pc, _ in group], eager=eager)
+            for (s, _, last), toks in zip(group, out):
+                if last:
+                    first[s] = toks[0]
+        if 0 in todo:
+            check(lib.la_llama_set_nkeys(self._h, self._sp(), 0, self.slot_keys[0]), 'set_nkeys')
+            self.n_keys = self.slot_keys[0]
+        return first
+
     def mlogits(self):
         """bf16 [max_blocks * 64][vocab] of the last multi-block step (row = 64 * block + tree row)."""
         return self._view(11, _lib.LA_MB_MAX * 64 * self.shape.vocab * 2, torch.bfloat16).view(_lib.LA_MB_MAX * 64, self.shape.vocab)

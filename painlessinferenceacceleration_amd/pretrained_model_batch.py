@@ -8,8 +8,11 @@ rule — decoding_length // bs per sample, halved again inside bat_get, SURVEY H
 stream through the CUs once per step for the whole batch.  Per step the host does: one native trie query per sample,
 one la_llama_bstep (forward + per-sample accept walk + KV row moves on device), one native trie update per sample.
 
-Deviation (documented, SURVEY H2): when decoding_length // active_samples exceeds 64 the per-step budget is clamped to
-the 64 rows of a block; tokens are unaffected (lookahead is lossless), only dls/edls differ from the reference there.
+Budget modes.  Default = the reference's rule: (decoding_length // bs) // bs rows per sample (SURVEY H2).  When the batch asks
+for more than 64 rows in total — or decoding_kwargs['per_sample_budget'] is set, which gives EVERY sample its own
+decoding_length-token tree as BASELINE configs 3-5 state (an extension: the reference halves the budget twice) — each sample
+gets a 64-row block of its own and the blocks of a step run in ONE pass over the weights (la_llama_mstep, M = 64 x samples
+rows through the LDS-staged GEMM family).  Tokens are unaffected by the budget (lookahead is lossless); dls/edls differ.
 """
 import time
 import warnings
@@ -41,12 +44,12 @@ class LookaheadPreTrainedModel(object):
         if decoding_mode in ('hier', 'par', 'one'):
             decoding_mode = decoding_mode + '_mix'
         fmt, mode = decoding_mode.split('_')
-        sub = max(decoding_length // len(qids), 1)
-        if sub > _lib.LA_TREE_MAX:
-            if not decoding_kwargs.get('_warned_budget'):
-                warnings.warn(f'decoding_length // batch = {sub} > 64 rows of a verify block: draft budget clamped to 64')
-                decoding_kwargs['_warned_budget'] = True
-            sub = _lib.LA_TREE_MAX
+        if decoding_kwargs.get('per_sample_budget', False):
+            # every sample gets a decoding_length-token tree (bat_get divides its argument by the batch size once)
+            sub = min(decoding_length, _lib.LA_TREE_MAX) * len(qids)
+        else:
+            sub = max(decoding_length // len(qids), 1)                 # pretrained_model_batch.py:713
+            sub = min(sub, _lib.LA_TREE_MAX * len(qids))               # a sample's tree never exceeds the 64 rows of a block
         ts = time.time()
         drafts = self.lookahead_cache.bat_get_packed(qids, decoding_length=sub, branch_length=branch_length, mode=mode,
                                                      indices=batch_indices, decoding_mode=fmt)
@@ -121,7 +124,9 @@ class LookaheadPreTrainedModel(object):
         ts = time.time()
         eng.reset_slot(-1)
         # prefill: valid prompt tokens of every sample, packed into shared 64-row chain blocks
-        first = eng.bprefill_many({i: ids0[i][am[i] == 1].tolist() for i in range(bs)})
+        prompts = {i: ids0[i][am[i] == 1].tolist() for i in range(bs)}
+        multi = bool(getattr(eng, 'max_blocks', 0))
+        first = eng.mprefill_many(prompts) if multi else eng.bprefill_many(prompts)
         next_token_list = [[first[i]] for i in range(bs)]
         decoding_kwargs['dls'].extend([1] * bs)
         decoding_kwargs['edls'].extend([1] * bs)
@@ -155,7 +160,15 @@ class LookaheadPreTrainedModel(object):
                     d_ids, d_rm = np.asarray(rows[b][-1:], dtype=np.int32), _ONE
                 cur = len(rows[b]) - 1
                 segments.append((b, d_ids, d_rm, 0, stop_max_length - cur - 1))
-            emitted = eng.bstep(segments)
+            if sum(len(sg[1]) for sg in segments) <= _lib.LA_TREE_MAX:
+                emitted = eng.bstep(segments)                          # the whole batch shares one 64-row block
+            else:
+                assert multi, 'more than 64 draft rows per step need an engine created with max_blocks > 1'
+                emitted = {}
+                for g0 in range(0, len(segments), eng.max_blocks):     # one 64-row block per sample, max_blocks per pass
+                    group = segments[g0:g0 + eng.max_blocks]
+                    for sg, toks in zip(group, eng.mstep(group)):
+                        emitted[sg[0]] = toks
             width = max(len(sg[1]) for sg in segments)
             next_token_list = [emitted[b] for b in batch_indices]
             for k in range(len(batch_indices)):
@@ -185,7 +198,8 @@ class LookaheadPreTrainedModel(object):
         eos = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
         eng = self.engine
         eng.reset_slot(-1)
-        first = eng.bprefill_many({i: ids0[i][am[i] == 1].tolist() for i in range(bs)})
+        prompts = {i: ids0[i][am[i] == 1].tolist() for i in range(bs)}
+        first = eng.mprefill_many(prompts) if getattr(eng, 'max_blocks', 0) else eng.bprefill_many(prompts)
         rows = [ids0[i].tolist() + [first[i]] for i in range(bs)]
         live = [b for b in range(bs) if len(rows[b]) < max_length and rows[b][-1] not in eos]
         while live:
