@@ -1,0 +1,111 @@
+# -*- coding: utf-8 -*-
+"""ORACLE tooling: an end-to-end golden run of the REFERENCE loop with PARTIAL accepts and multi-branch trees
+(build container only; /root/reference imported in place through the shim of oracle/gen_golden_model.py).
+
+The plain tiny random model has ~3-ulp top-2 gaps, so its golden run (llama_tiny_*.npz) cannot be compared token for token
+with a bf16 GPU run beyond a few steps, and its warm-trie request accepts every draft (edls = 13, 13, ...).  Here the tiny
+model is the decisive "permutation LM" (tests/tiny_model.py::tiny_decisive_weights) and the reference trie is warmed, as
+Benchmark.warm_up does (benchmarks/benchmark.py:159-169), with NOISY copies of the model's own greedy continuation: drafts are
+multi-branch, some branches are wrong, accepts are partial — and every token / dls / edls of the reference's
+lookahead_generation (common/pretrained_model.py:947-1268) is reproducible bit for bit by any correct implementation.
+
+Writes tests/golden/llama_tiny_noisy_{fp32,bf16}.npz: prompt, greedy continuation, warm-up copies, and per request the
+sequences, dls, edls and per-step draft ids / row masks / emitted tokens.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import gen_golden_model as gm            # noqa: E402
+from tests.tiny_model import TINY, noisy_copies, tiny_decisive_weights      # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+MAX_NEW, RHO, COPIES, BL, DL = 120, 0.3, 8, 12, 64
+
+
+def run(dtype, tag):
+    from transformers import LogitsProcessorList, MaxLengthCriteria, StoppingCriteriaList
+    LookaheadCache, LPM, LlamaForCausalLM = gm.import_reference()
+    model = gm.build_reference_model(LlamaForCausalLM, torch.float32)
+    missing, unexpected = model.load_state_dict(tiny_decisive_weights(0, torch.float32), strict=False)
+    assert not unexpected
+    model = model.to(dtype)
+    for mod in model.modules():
+        if hasattr(mod, 'inv_freq'):
+            mod.inv_freq = 1.0 / (mod.base ** (torch.arange(0, mod.dim, 2, dtype=torch.int64).float() / mod.dim))
+    prompt = gm.tiny_prompt(seed=4321, n=40)
+    # ground truth: plain greedy of the reference model
+    seq = list(prompt)
+    with torch.no_grad():
+        o = model(input_ids=torch.tensor([seq]), use_cache=True)
+        past = o.past_key_values
+        for _ in range(MAX_NEW + 40):
+            t = int(torch.argmax(o.logits[0, -1].float()))
+            seq.append(t)
+            o = model(input_ids=torch.tensor([[t]]), past_key_values=past, use_cache=True)
+            past = o.past_key_values
+    truth = seq[len(prompt):]
+    copies = noisy_copies(prompt[-2:] + truth, COPIES, RHO, TINY['vocab'], seed=99)
+    steps = []
+    orig_upd = model._lookahead_update_model_kwargs_for_generation
+
+    def rec_upd(outputs, model_kwargs, **kw):
+        mk = orig_upd(outputs, model_kwargs, **kw)
+        dk = mk['decoding_kwargs']
+        st = {'next': [int(x) for x in mk['next_token_list'][0]], 'ids': None, 'rows': None}
+        if 'decoding_masks' in dk and dk.get('dls') and dk['dls'][-1] > 1:
+            m = np.asarray(dk['decoding_masks']).astype(np.int64)
+            st['ids'] = [int(x) for x in dk['decoding_ids']]
+            st['rows'] = [int(sum(int(b) << j for j, b in enumerate(r))) for r in m]
+        steps.append(st)
+        return mk
+    model._lookahead_update_model_kwargs_for_generation = rec_upd
+    model.lookahead_cache = LookaheadCache(eos_ids=[2])
+    for c in copies:
+        model.lookahead_cache.put(c, branch_length=BL + 1, mode='output', idx=-1)
+    runs = []
+    for rep in range(2):                 # the second request also sees what the first one put into the trie
+        steps.clear()
+        ids = torch.tensor([prompt], dtype=torch.long)
+        dk = {'use_lookahead': True, 'decoding_mode': 'hier', 'decoding_length': DL, 'branch_length': BL, 'max_query_length': 2,
+              'stop_words': {}}
+        with torch.no_grad():
+            out = model.lookahead_generation(ids, logits_processor=LogitsProcessorList(),
+                                             stopping_criteria=StoppingCriteriaList([MaxLengthCriteria(max_length=len(prompt) + MAX_NEW)]),
+                                             pad_token_id=0, eos_token_id=2, return_dict_in_generate=True,
+                                             attention_mask=torch.ones_like(ids), decoding_kwargs=dk, use_cache=True)
+        runs.append({'sequences': out.sequences[0].tolist(), 'dls': list(out.kwargs['dls']), 'edls': list(out.kwargs['edls']),
+                     'steps': [dict(s) for s in steps]})
+    save = {'prompt': np.array(prompt), 'truth': np.array(truth), 'copies': np.array(copies), 'n_runs': np.array(len(runs)),
+            'max_new': np.array(MAX_NEW)}
+    for r, run_ in enumerate(runs):
+        save[f'r{r}_sequences'] = np.array(run_['sequences'])
+        save[f'r{r}_dls'] = np.array(run_['dls'])
+        save[f'r{r}_edls'] = np.array(run_['edls'])
+        save[f'r{r}_nsteps'] = np.array(len(run_['steps']))
+        for i, st in enumerate(run_['steps']):
+            save[f'r{r}_s{i}_next'] = np.array(st['next'])
+            if st['ids'] is not None:
+                save[f'r{r}_s{i}_ids'] = np.array(st['ids'])
+                save[f'r{r}_s{i}_rows'] = np.array(st['rows'], dtype=np.uint64)
+    np.savez_compressed(os.path.join(OUT, f'llama_tiny_noisy_{tag}.npz'), **save)
+    for r, run_ in enumerate(runs):
+        e = run_['edls'][1:]
+        d = run_['dls'][1:]
+        print(tag, f'run {r}: steps {len(e)} dls {d[:10]} edls {e[:10]} partial accepts {sum(1 < x < BL + 1 for x in e)} '
+                   f'full {sum(x == BL + 1 for x in e)} single {sum(x == 1 for x in e)} == greedy {run_["sequences"] == (prompt + truth)[:len(run_["sequences"])]}')
+    return runs
+
+
+if __name__ == '__main__':
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    a = run(torch.float32, 'fp32')
+    b = run(torch.bfloat16, 'bf16')
+    assert [r['sequences'] for r in a] == [r['sequences'] for r in b] and [r['edls'] for r in a] == [r['edls'] for r in b], \
+        'the decisive model must decode identically in fp32 and bf16'

@@ -54,9 +54,19 @@ class LlamaShape(object):
 
     @classmethod
     def from_hf(cls, cfg):
+        """LlamaConfig / MistralConfig / MixtralConfig of transformers 4.3x (the reference's pins) or 5.x (rope_theta moved
+        into cfg.rope_parameters)."""
+        rope_theta = getattr(cfg, 'rope_theta', None)
+        if rope_theta is None:
+            rp = getattr(cfg, 'rope_parameters', None) or {}
+            rope_theta = rp.get('rope_theta', 10000.0) if isinstance(rp, dict) else getattr(rp, 'rope_theta', 10000.0)
+        scaling = getattr(cfg, 'rope_scaling', None)
+        if scaling and (scaling.get('rope_type', scaling.get('type', 'default')) not in ('default', None)):
+            raise NotImplementedError(f'rope_scaling {scaling} is not supported by the RoPE tables of this path')
+        head_dim = getattr(cfg, 'head_dim', None) or cfg.hidden_size // cfg.num_attention_heads
         return cls(cfg.num_hidden_layers, cfg.hidden_size, cfg.num_attention_heads,
                    getattr(cfg, 'num_key_value_heads', None), cfg.intermediate_size, cfg.vocab_size,
-                   cfg.rms_norm_eps, getattr(cfg, 'rope_theta', 10000.0),
+                   cfg.rms_norm_eps, float(rope_theta), head_dim=head_dim,
                    n_experts=getattr(cfg, 'num_local_experts', 0) or 0, top_k=getattr(cfg, 'num_experts_per_tok', 2),
                    norm_cast_first=getattr(cfg, 'model_type', 'llama') in ('mistral', 'mixtral'))
 
@@ -66,6 +76,32 @@ class LlamaShape(object):
         per_layer = (self.n_heads + 2 * self.n_kv_heads) * hd * self.hidden + self.n_heads * hd * self.hidden \
             + mlp + 2 * self.hidden
         return self.n_layers * per_layer + self.hidden + self.vocab * self.hidden
+
+
+def legacy_state_dict(sd, shape):
+    """HF-named state dict -> the transformers-4.36 parameter names the engine consumes (the reference's model files:
+    block_sparse_moe.gate / experts.{e}.w1|w3|w2, mixtral/modeling_mixtral.py:668-759).  transformers 5.x stores the experts of
+    a layer fused: mlp.gate.weight [E, hidden], mlp.experts.gate_up_proj [E, 2*ffn, hidden] (gate rows first),
+    mlp.experts.down_proj [E, hidden, ffn]; tied lm_head falls back to the embedding."""
+    out = {}
+    for k, v in sd.items():
+        v = v.detach()
+        if shape.n_experts > 0 and k.endswith('.mlp.gate.weight'):
+            out[k.replace('.mlp.gate.weight', '.block_sparse_moe.gate.weight')] = v
+        elif shape.n_experts > 0 and k.endswith('.mlp.experts.gate_up_proj'):
+            p = k[:-len('mlp.experts.gate_up_proj')] + 'block_sparse_moe.experts.'
+            for e in range(shape.n_experts):
+                out[f'{p}{e}.w1.weight'] = v[e, :shape.ffn]
+                out[f'{p}{e}.w3.weight'] = v[e, shape.ffn:]
+        elif shape.n_experts > 0 and k.endswith('.mlp.experts.down_proj'):
+            p = k[:-len('mlp.experts.down_proj')] + 'block_sparse_moe.experts.'
+            for e in range(shape.n_experts):
+                out[f'{p}{e}.w2.weight'] = v[e]
+        else:
+            out[k] = v
+    if 'lm_head.weight' not in out:
+        out['lm_head.weight'] = out['model.embed_tokens.weight']
+    return out
 
 
 def rope_tables(head_dim, max_pos, theta, device):

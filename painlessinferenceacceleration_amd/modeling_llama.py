@@ -6,7 +6,7 @@ from types import SimpleNamespace
 
 import torch
 
-from .llama_engine import LlamaShape, LlamaVerifyEngine, random_weights
+from .llama_engine import LlamaShape, LlamaVerifyEngine, legacy_state_dict, random_weights
 from .lookahead_cache import LookaheadCache
 from .pretrained_model import LookaheadPreTrainedModel
 
@@ -27,7 +27,10 @@ class LlamaForCausalLM(LookaheadPreTrainedModel):
     @classmethod
     def from_hf(cls, hf_model, **kw):
         """Wrap a transformers LlamaForCausalLM (weights are repacked into HBM; the HF module is not used afterwards)."""
-        return cls(LlamaShape.from_hf(hf_model.config), {k: v.detach() for k, v in hf_model.state_dict().items()}, **kw)
+        shape = LlamaShape.from_hf(hf_model.config)
+        kw.setdefault('eos_token_id', getattr(hf_model.config, 'eos_token_id', 2))
+        kw.setdefault('pad_token_id', getattr(hf_model.config, 'pad_token_id', 0) or 0)
+        return cls(shape, legacy_state_dict(hf_model.state_dict(), shape), **kw)
 
     @classmethod
     def random_init(cls, shape, seed=0, device='cuda:0', decisive=False, **kw):

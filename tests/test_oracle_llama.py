@@ -167,3 +167,33 @@ def test_oracle_sequential_processor_path_matches_reference():
         out = lo.lookahead_generate(model, cache, prompt, len(prompt) + 64, eos_token_id=2, logits_processor=procs)
         assert out['sequences'] == g[f'r{r}_sequences'].tolist()
         assert out['dls'] == g[f'r{r}_dls'].tolist() and out['edls'] == g[f'r{r}_edls'].tolist()
+
+
+@pytest.mark.parametrize('tag,dtype', [('fp32', torch.float32), ('bf16', torch.bfloat16)])
+def test_oracle_loop_matches_reference_run_with_partial_accepts(tag, dtype):
+    """oracle/gen_golden_noisy.py: the reference loop on the decisive tiny model with a NOISY warm trie — multi-branch trees,
+    23 partially accepted steps in the first request.  Tokens, dls, edls and every step's draft ids / row masks / emitted
+    tokens of the oracle loop over the trie oracle must equal the recording."""
+    from tests.tiny_model import tiny_decisive_weights
+    g = np.load(os.path.join(GOLDEN, f'llama_tiny_noisy_{tag}.npz'))
+    torch.set_num_threads(4)
+    model = lo.OracleLlama(tiny_shape(), tiny_decisive_weights(0, dtype))
+    cache = TrieOracle(eos_ids=[2])
+    for c in g['copies'].tolist():
+        cache.put(c, branch_length=13, mode='output', idx=-1)
+    prompt = g['prompt'].tolist()
+    max_length = len(prompt) + int(g['max_new'])
+    partial = 0
+    for r in range(int(g['n_runs'])):
+        rec = []
+        out = lo.lookahead_generate(model, cache, prompt, max_length, eos_token_id=2, record=rec)
+        assert out['sequences'] == g[f'r{r}_sequences'].tolist()
+        assert out['dls'] == g[f'r{r}_dls'].tolist() and out['edls'] == g[f'r{r}_edls'].tolist()
+        assert len(rec) == int(g[f'r{r}_nsteps'])
+        for i, st in enumerate(rec):
+            assert st['next'] == g[f'r{r}_s{i}_next'].tolist(), (r, i)
+            if f'r{r}_s{i}_ids' in g.files:
+                assert st['ids'] == g[f'r{r}_s{i}_ids'].tolist(), (r, i)
+                assert [int(x) for x in st['rows']] == [int(x) for x in g[f'r{r}_s{i}_rows']], (r, i)
+        partial += sum(1 < e < 13 for e in out['edls'][1:])
+    assert partial >= 20

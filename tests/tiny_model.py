@@ -98,3 +98,39 @@ def moe_weights(cfg, seed=0, dtype=torch.float32, std=0.06, router_std=0.2):
     sd['model.norm.weight'] = nw()
     sd['lm_head.weight'] = w(cfg['vocab'], cfg['hidden'])
     return sd
+
+
+def tiny_decisive_weights(seed=0, dtype=torch.float32, cfg=None):
+    """The tiny Llama as a "permutation LM" (same recipe as llama_engine.random_weights(decisive=True), but a pure function of a
+    numpy seed): o_proj / down_proj std 1e-4 keep the residual stream on the token embedding and lm_head[pi(t)] = embed[t] for one
+    cycle pi over [3, V), so the greedy continuation has margins of ~15 sigma — identical tokens in fp32 and bf16, on the
+    reference's CPU path and on the MI355X engine.  Used by oracle/gen_golden_noisy.py and the partial-accept parity tests."""
+    sd = tiny_weights(seed, torch.float32, cfg=cfg)
+    rs = np.random.RandomState(seed + 1000)
+    c = dict(TINY)
+    if cfg:
+        c.update(cfg)
+    for i in range(c['n_layers']):
+        p = f'model.layers.{i}.'
+        for name in ('self_attn.o_proj.weight', 'mlp.down_proj.weight'):
+            sd[p + name] = sd[p + name] * (1e-4 / 0.08)
+    V = c['vocab']
+    order = 3 + rs.permutation(V - 3)
+    perm = np.arange(V)
+    perm[order] = np.roll(order, -1)
+    head = torch.empty_like(sd['model.embed_tokens.weight'])
+    head[torch.from_numpy(perm)] = sd['model.embed_tokens.weight']
+    sd['lm_head.weight'] = head
+    return {k: v.to(dtype) for k, v in sd.items()}
+
+
+def noisy_copies(truth, n_copies, rho, vocab, seed):
+    """bench.py's trie warm-up: n_copies of the continuation with each token replaced with probability rho."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(n_copies):
+        t = np.array(truth)
+        hit = rs.rand(len(t)) < rho
+        t[hit] = rs.randint(3, vocab, size=int(hit.sum()))
+        out.append(t.tolist())
+    return out
