@@ -11,10 +11,18 @@ captured verify graph (embed, 32 layers, lm_head+argmax, accept scan, KV commit)
 Synthetic data: the prompt is 512 phrase-bank tokens; the trie is warmed, as the reference's
 Benchmark.warm_up does (benchmarks/benchmark.py:159-169), with 12 noisy copies of the model's own greedy
 continuation (each token replaced with probability rho=0.3), so drafts are multi-branch and partially accepted.
-Multi-GPU: one independent sequence per rank (batch sharding, weak scaling); the only exchange is the
-per-step all-gather of accepted tokens over RCCL so that every rank's trie replica sees every sequence.  The gather is
-split-phase: started after step k, collected while the GPU runs step k+1, then applied for all ranks in global batch-index
-order (replicas stay identical; a step's tokens reach the drafts one step later; emitted tokens are unaffected).
+Multi-GPU: independent sequences per rank (batch sharding, weak scaling); the only exchange is the per-step all-gather of
+accepted tokens over RCCL (la_gather_accepted) so that every rank's trie replica sees every sequence.  Default = split-phase
+mode: started after step k, collected while the GPU runs step k+1, then applied for all sequences in global batch-index order
+(replicas stay identical; a step's tokens reach the drafts one step later; emitted tokens are unaffected).  --strict-gather
+selects the blocking mode in which the trie state at query time equals the reference's single-process order; the JSON line
+says which mode a number comes from.
+
+Other workloads (secondary lines, same JSON shape; BASELINE configs 3-4): --batch B runs B sequences per GPU, each with its OWN
+64-token tree per step, in one pass over the weights (la_llama_mstep, M = 64 B rows); --model 13b|mistral picks the shape.
+The line also carries: the 8(d) fixed "T64/B8" tree with the accept sweep a in {0,3,6,12} (`fixed_tree_sweep`), the
+reference-style speed including prefill (`speed_incl_prefill`), and `cpu_baseline`: the oracle's own lookahead loop (a port of
+the reference's transformers CPU path) run on this box's host cores on the full 32-layer model for a few real verify steps.
 """
 import argparse
 import json
@@ -61,62 +69,65 @@ def algorithmic_bytes(shape, T, ctx, logits_bytes):
     return W + kv_tok * ctx + kv_tok * T + T * (shape.hidden * 2 + 8) + logits_bytes
 
 
-def cpu_baseline(shape, T, ctx, accept_len, budget_s=20.0):
-    """The oracle's verify forward (oracle/llama_oracle.py, a port of the reference's transformers CPU path) timed
-    on this box's host cores at the full Llama-2-7B layer shape.  Bounded sample (~10-30 s of CPU work): one decoder
-    layer + lm_head are timed at T tree tokens / ctx context for each (dtype, thread count) candidate with a per-trial
-    cap, the fastest candidate is kept (generous to the CPU: bf16 falls into a slow oneDNN path on hosts without
-    AMX), and the step time is composed as t(lm_head part) + n_layers * t(layer); accepted tok/s = steps/s x the
-    mean accept-len measured on the GPU run."""
-    from oracle import llama_oracle as lo
-    from painlessinferenceacceleration_amd.llama_engine import LlamaShape, random_weights
-    # one decoder layer is timed on a model with a 64-entry vocabulary (its lm_head is negligible), the embedding + final
-    # norm + full lm_head on a 0-layer model: both terms are measured directly (no difference of two noisy timings)
-    one = LlamaShape(1, shape.hidden, shape.n_heads, shape.n_kv_heads, shape.ffn, 64, shape.rms_eps)
-    zero = LlamaShape(0, shape.hidden, shape.n_heads, shape.n_kv_heads, shape.ffn, shape.vocab, shape.rms_eps)
-    sd1_bf16 = random_weights(one, seed=0, device='cpu')
-    sd0_bf16 = random_weights(zero, seed=0, device='cpu')
-    rs = np.random.RandomState(0)
-    hd = shape.head_dim
-    ids1 = torch.tensor(rs.randint(3, 64, size=T).tolist())
-    ids0 = torch.tensor(rs.randint(3, shape.vocab, size=T).tolist())
-    mask = torch.cat([torch.ones((T, ctx), dtype=torch.long), torch.tril(torch.ones((T, T), dtype=torch.long))], 1)
-    ncpu = os.cpu_count() or 1
-    cands = []
-    for dt in (torch.bfloat16, torch.float32):
-        for nt in sorted(set([min(ncpu, 8), min(ncpu, 32), min(ncpu, 96)])):
-            cands.append((dt, nt))
-    t_start = time.time()
-    best = None
-    tried = []
-    for dt, nt in cands:
-        if time.time() - t_start > budget_s:
-            break
-        torch.set_num_threads(nt)
-        past = [(torch.randn(shape.n_kv_heads, ctx, hd).to(dt), torch.randn(shape.n_kv_heads, ctx, hd).to(dt))]
-        m1 = lo.OracleLlama(one, {k: v.to(dt) for k, v in sd1_bf16.items()})
-        m0 = lo.OracleLlama(zero, {k: v.to(dt) for k, v in sd0_bf16.items()})
+def fixed_t64b8_tree():
+    """SURVEY 8(d) "T64/B8": 63 draft nodes + root, 8 leaves all at depth 12 — a main chain of 12 plus 7 side branches forking
+    after depth 9,8,6,4,3,2,1 with lengths 3,4,6,8,9,10,11 (DFS order: main chain, then the deepest fork first).
+    -> (parent[64], depth[64], uint64 row masks[64])"""
+    parent, depth = [-1], [0]
+    for d in range(1, 13):
+        parent.append(d - 1); depth.append(d)
+    for fork, length in ((9, 3), (8, 4), (6, 6), (4, 8), (3, 9), (2, 10), (1, 11)):
+        p = fork                                   # main-chain node of that depth has index == depth
+        for k in range(length):
+            parent.append(p); depth.append(fork + 1 + k)
+            p = len(parent) - 1
+    assert len(parent) == 64 and sum(1 for i in range(64) if i not in parent) == 8 and max(depth) == 12
+    rows = []
+    for i, p in enumerate(parent):
+        rows.append((rows[p] if p >= 0 else 0) | (1 << i))
+    return parent, depth, np.array(rows, dtype=np.uint64)
 
-        def timed(model, ids, p, cap):
-            t0 = time.time(); model.forward(ids, mask, p); first = time.time() - t0       # warm-up (page-in, kernels)
-            if first > cap:
-                return first
-            n, t0 = 0, time.time()
-            while n < 5 and time.time() - t0 < cap:
-                model.forward(ids, mask, p); n += 1
-            return (time.time() - t0) / max(n, 1)
-        t_layer = timed(m1, ids1, past, 2.5)
-        t_head = timed(m0, ids0, [], 1.0)
-        step = t_head + shape.n_layers * t_layer
-        tried.append(f"{str(dt).split('.')[-1]}x{nt}t:{step * 1e3:.0f}ms")
-        if best is None or step < best[0]:
-            best = (step, dt, nt)
-    step, dt, nt = best
-    return {'value': round(accept_len / step, 3), 'unit': 'tokens/s', 'cores': nt, 'kind': 'port',
-            'ms_per_step': round(step * 1e3, 1), 'dtype': str(dt).split('.')[-1],
-            'sample': f'oracle verify forward at the benchmarked layer shape (hidden {shape.hidden}, ffn {shape.ffn}, {shape.n_layers} layers), T={T}, ctx={ctx}: 1 decoder layer and embedding+lm_head timed separately '
-                      f'(<=5 runs each, candidates {" ".join(tried)}), step = lm_head part + {shape.n_layers} x layer; '
-                      f'accepted tok/s = steps/s x GPU-run mean accept-len {accept_len:.2f}'}
+
+def cpu_model_name():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline_loop(shape, sd_cpu, prompt, copies, branch_length, decoding_length, verify_steps=5, threads=None):
+    """`cpu_baseline` (kind "port"): the oracle's OWN lookahead loop — oracle/llama_oracle.py::lookahead_generate over
+    oracle/trie_oracle.py, the restatement of the reference's transformers CPU path (pretrained_model.py:947-1268 +
+    lookahead_cache.py) — on the FULL model (all layers, bf16, the weights the GPU run uses), same prompt, same trie warm-up,
+    for `verify_steps` real verify steps after the prefill.  Accepted tok/s = its own accepted tokens / its own step times
+    (prefill excluded, like `value`).  dtype and thread count are PINNED (bf16; min(host cores, 16) threads: more threads were
+    slower on every box measured in round 1) and recorded with the CPU model, so the number does not move with a search."""
+    from oracle import llama_oracle as lo
+    from oracle.trie_oracle import TrieOracle
+    ncpu = os.cpu_count() or 1
+    nt = threads or min(ncpu, 16)
+    torch.set_num_threads(nt)
+    model = lo.OracleLlama(shape, sd_cpu)
+    cache = TrieOracle(eos_ids=[None])
+    for c in copies:
+        cache.put(c, branch_length=branch_length + 1, mode='output', idx=-1)
+    t0 = time.time()
+    out = lo.lookahead_generate(model, cache, prompt, len(prompt) + (verify_steps + 1) * (branch_length + 1) + 2, eos_token_id=None,
+                                decoding_length=decoding_length, branch_length=branch_length, max_steps=verify_steps + 1)
+    wall = time.time() - t0
+    fts, edls, dls = out['fts'], out['edls'], out['dls']
+    t_dec, n_acc = float(sum(fts[1:])), int(sum(edls[1:]))
+    return {'value': round(n_acc / max(t_dec, 1e-9), 3), 'unit': 'tokens/s', 'cores': nt, 'kind': 'port',
+            'ms_per_step': round(1e3 * t_dec / max(len(fts) - 1, 1), 1), 'dtype': 'bfloat16', 'cpu_model': cpu_model_name(),
+            'host_cores': ncpu, 'verify_steps': len(fts) - 1, 'mean_accept_len': round(n_acc / max(len(fts) - 1, 1), 3),
+            'mean_draft_len': round(float(np.mean(dls[1:])) if len(dls) > 1 else 0.0, 2),
+            'prefill_s': round(float(fts[0]), 2), 'wall_s': round(wall, 1),
+            'sample': f'oracle lookahead loop (port of the reference transformers CPU path) on the full {shape.n_layers}-layer model: prefill of '
+                      f'{len(prompt)} tokens + {len(fts) - 1} verify steps with its own drafts (same prompt and trie warm-up as the GPU run), '
+                      f'bf16, {nt} threads pinned'}
 
 
 def main():
@@ -130,7 +141,11 @@ def main():
     ap.add_argument('--layers', type=int, default=0, help='debug: override layer count (invalidates the metric)')
     ap.add_argument('--pure-random', action='store_true', help='plain N(0,0.02) init (greedy/lookahead drift apart in bf16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--model', choices=['7b', '13b'], default='7b', help='7b = the BASELINE metric; 13b = the config-4 model shape')
+    ap.add_argument('--cpu-steps', type=int, default=5, help='verify steps of the CPU baseline loop')
+    ap.add_argument('--model', choices=['7b', '13b', 'mistral'], default='7b',
+                    help='7b = the BASELINE metric; 13b / mistral = the config-4 / config-3 model shapes')
+    ap.add_argument('--batch', type=int, default=1, help='sequences per GPU; > 1: each gets its own 64-token tree per step (la_llama_mstep)')
+    ap.add_argument('--strict-gather', action='store_true', help='N > 1: blocking all-gather (reference trie order at query time)')
     ap.add_argument('--profile-iters', type=int, default=3)
     ap.add_argument('--attn-split', type=int, default=0, help='key splits of the tree-attention kernel (0 = engine default 8)')
     ap.add_argument('--fuse', type=int, default=0, help='engine cfg.fuse bits (opt-in in-kernel norm->GEMM fusion; 0 = separate kernels)')
@@ -157,86 +172,120 @@ def main():
     comm_dev = dev if os.environ.get('BENCH_DIST_BACKEND', 'nccl') == 'nccl' else 'cpu'
     torch.cuda.set_device(dev)
 
-    from painlessinferenceacceleration_amd.llama_engine import LlamaShape
+    from painlessinferenceacceleration_amd.llama_engine import LlamaShape, random_weights
     from painlessinferenceacceleration_amd.lookahead_cache import LookaheadCache
     from painlessinferenceacceleration_amd.modeling_llama import LlamaForCausalLM
+    from painlessinferenceacceleration_amd.modeling_llama_batch import LlamaForCausalLM as BatchLlama
 
-    shape = LlamaShape.llama2_13b() if args.model == '13b' else LlamaShape.llama2_7b()
-    model_name = 'Llama-2-13B' if args.model == '13b' else 'Llama-2-7B'
+    shape = {'7b': LlamaShape.llama2_7b, '13b': LlamaShape.llama2_13b, 'mistral': LlamaShape.mistral_7b}[args.model]()
+    model_name = {'7b': 'Llama-2-7B', '13b': 'Llama-2-13B', 'mistral': 'Mistral-7B'}[args.model]
     if args.layers:
         shape.n_layers = args.layers
-    K, W, P = args.steps, args.warmup, args.prompt_len
+    K, W, P, B = args.steps, args.warmup, args.prompt_len, args.batch
+    assert 1 <= B <= 8
     BL, DL = 12, 64
-    n_truth = (K + W) * (BL + 1) + 8
+    n_truth = (K + W + 56) * (BL + 1) + 8          # measured steps + native-loop leg (16 steps) + fixed-tree sweep (24 steps) + slack
     max_length = P + n_truth + 2 * DL
-    model = LlamaForCausalLM.random_init(shape, seed=0, device=dev, max_length=max_length, eos_token_id=None,
-                                         decisive=not args.pure_random, fuse=args.fuse, attn_split=args.attn_split)
+    want_cpu = not args.no_cpu_baseline and world == 1 and B == 1      # the CPU leg is timed on rank 0 at N=1 only
+    sd = random_weights(shape, seed=0, device=dev, decisive=not args.pure_random)
+    sd_cpu = {k: v.cpu() for k, v in sd.items()} if want_cpu else None
+    if B == 1:
+        model = LlamaForCausalLM(shape, sd, device=dev, max_length=max_length, eos_token_id=None, consume_state_dict=True,
+                                 fuse=args.fuse, attn_split=args.attn_split, max_blocks=8)
+    else:
+        model = BatchLlama(shape, sd, device=dev, max_length=max_length, max_batch=B, eos_token_id=None, consume_state_dict=True,
+                           attn_split=args.attn_split, max_blocks=B)
+    del sd
     eng = model.engine
+    NSEQ = world * B
+    gidx = [i * world + rank for i in range(B)]          # global batch indices of this rank's sequences (b mod world == rank)
 
-    # ---- untimed set-up: prompt, ground-truth continuation (plain greedy on the same engine), trie warm-up
-    prompts = [phrase_prompt(1234 + r, P, shape.vocab) for r in range(world)]
-    prompt = prompts[rank]
+    # ---- untimed set-up: prompts, ground-truth continuations (plain greedy on the same engine), trie warm-up
+    prompts = [phrase_prompt(1234 + b, P, shape.vocab) for b in range(NSEQ)]
     t0 = time.time()
-    truth = model.greedy_search(torch.tensor([prompt]), P + n_truth, eos_token_id=None)[0].tolist()[P:]
+    if B == 1:
+        truth_own = [model.greedy_search(torch.tensor([prompts[gidx[0]]]), P + n_truth, eos_token_id=None)[0].tolist()[P:]]
+    else:
+        truth_own = model.greedy_search(torch.tensor([prompts[b] for b in gidx]), P + n_truth, eos_token_id=None)[:, P:].tolist()
     t_greedy = time.time() - t0
     cache = LookaheadCache(eos_ids=[None])
     model.lookahead_cache = cache
-    if dist_on:                                  # every replica is warmed with every rank's (noisy) answers
-        tt = torch.tensor(truth, dtype=torch.int32, device=comm_dev)
+    truths = [None] * NSEQ
+    if dist_on:                                  # every replica is warmed with every sequence's (noisy) answers
+        tt = torch.tensor(truth_own, dtype=torch.int32, device=comm_dev)
         allt = [torch.empty_like(tt) for _ in range(world)]
         dist.all_gather(allt, tt)
-        truths = [x.cpu().tolist() for x in allt]
+        for r in range(world):
+            for i in range(B):
+                truths[i * world + r] = allt[r][i].cpu().tolist()
     else:
-        truths = [truth]
-    for r in range(world):
-        for c in noisy_copies(prompts[r][-2:] + truths[r], args.copies, args.rho, shape.vocab, seed=99 + r):
+        for i in range(B):
+            truths[gidx[i]] = truth_own[i]
+    copies0 = None
+    for b in range(NSEQ):
+        cps = noisy_copies(prompts[b][-2:] + truths[b], args.copies, args.rho, shape.vocab, seed=99 + b)
+        if b == 0:
+            copies0 = cps
+        for c in cps:
             cache.put(c, branch_length=BL + 1, mode='output', idx=-1)
 
     # ---- the measured loop ----------------------------------------------------------------------------------
-    seq = list(prompt)
-    cache.put(seq[1:], branch_length=BL + 1, mode='input', idx=rank)
+    seqs = [list(prompts[b]) for b in gidx]
+    for i, b in enumerate(gidx):
+        cache.put(seqs[i][1:], branch_length=BL + 1, mode='input', idx=b)
     eng.reset()
-    seq.append(eng.prefill(seq))
-    if os.environ.get('BENCH_DEBUG'):
-        print(f'[debug] prefill tok {seq[-1]} truth0 {truth[0]} nkeys {eng.n_keys}', file=sys.stderr, flush=True)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    if B == 1:
+        seqs[0].append(eng.prefill(seqs[0]))
+    else:
+        first = eng.mprefill_many({i: seqs[i] for i in range(B)})
+        for i in range(B):
+            seqs[i].append(first[i])
+    torch.cuda.synchronize()
+    t_prefill = time.time() - t0
     gather = None
     if dist_on:
         from painlessinferenceacceleration_amd.distributed import AcceptedTokenGather
-        gather = AcceptedTokenGather(comm_dev)
+        gather = AcceptedTokenGather(comm_dev, b_loc=B, branch_length=BL)
     pending = [False]
     edls, dls, qts = [], [], []
 
+    def drafts_for(i):
+        ubl = min(BL, max_length - len(seqs[i]) - 1)
+        ids, rowmask, _, _ = cache.hier_get_packed(seqs[i][-2:], decoding_length=DL, branch_length=ubl, min_input_size=0,
+                                                   min_output_size=DL // 2, mode='mix', idx=gidx[i])
+        if len(ids) == 0:
+            return np.asarray(seqs[i][-1:], dtype=np.int32), np.array([1], dtype=np.uint64)
+        return ids.copy(), rowmask.copy()
+
     def one_step():
         tq = time.time()
-        ubl = min(BL, max_length - len(seq) - 1)
-        ids, rowmask, _, _ = cache.hier_get_packed(seq[-2:], decoding_length=DL, branch_length=ubl, min_input_size=0,
-                                                   min_output_size=DL // 2, mode='mix', idx=rank)
+        dr = [drafts_for(i) for i in range(B)]
         qts.append(time.time() - tq)
-        if os.environ.get('BENCH_DEBUG'):
-            t1 = time.time()
-            cache.hier_get_packed(seq[-2:], decoding_length=DL, branch_length=ubl, min_input_size=0, min_output_size=DL // 2,
-                                  mode='mix', idx=rank)
-            print(f'[debug] query {1e3 * qts[-1]:.3f} ms, repeated {1e3 * (time.time() - t1):.3f} ms, T {len(ids)} stats {cache.stats()}',
-                  file=sys.stderr, flush=True)
-        eng.step_async(ids, rowmask, mode=0)
-        if pending[0]:       # N > 1: the previous step's gather + every rank's trie update run while the GPU verifies
-            gather.finish_into_trie(cache, BL)
-            pending[0] = False
-        toks, _ = eng.step_finish()
-        if os.environ.get('BENCH_DEBUG') and len(edls) < 6:
-            k = len(seq) - P
-            print(f'[debug] step {len(edls)} ctx {len(seq)} T {len(ids)} ids {ids[:5].tolist()} -> toks {toks[:6]} '
-                  f'truth {truth[k:k + 6]} prev-truth {truth[max(k - 2, 0):k]}', file=sys.stderr, flush=True)
-        seq.extend(toks)
-        dls.append(len(ids)); edls.append(len(toks))
-        if dist_on:
-            # split-phase RCCL all-gather: started now, collected during the next verify step, then applied for ALL ranks
-            # (this one included) in global batch-index order, so every trie replica goes through the same sequence of
-            # inserts.  Tokens are unaffected (verification is lossless); drafts see a step's tokens one step later.
-            gather.begin(toks)
-            pending[0] = True
+        if B == 1:
+            eng.step_async(dr[0][0], dr[0][1], mode=0)
+            if pending[0]:       # N > 1, split-phase: the previous step's gather + every trie update run while the GPU verifies
+                gather.finish_into_trie(cache, BL)
+                pending[0] = False
+            toks_all = [eng.step_finish()[0]]
         else:
-            cache.stream_put(toks, branch_length=BL + 1, final=False, idx=rank)
+            if pending[0]:
+                gather.finish_into_trie(cache, BL)
+                pending[0] = False
+            toks_all = eng.mstep([(i, dr[i][0], dr[i][1], 0, 16) for i in range(B)])
+        for i in range(B):
+            seqs[i].extend(toks_all[i])
+            dls.append(len(dr[i][0])); edls.append(len(toks_all[i]))
+        if dist_on:
+            if args.strict_gather:       # blocking: every replica holds every token of the step before the next query
+                gather.update_trie(cache, toks_all if B > 1 else toks_all[0], BL)
+            else:                        # split-phase RCCL all-gather: collected during the next verify step
+                gather.begin(toks_all if B > 1 else toks_all[0])
+                pending[0] = True
+        else:
+            for i in range(B):
+                cache.stream_put(toks_all[i], branch_length=BL + 1, final=False, idx=gidx[i])
 
     import gc
     gc.collect()
@@ -244,7 +293,7 @@ def main():
                          # drives the loop; the serving loop allocates nothing that needs cycle collection
     for _ in range(W):
         one_step()
-    n0 = len(edls)
+    n0, q0 = len(edls), len(qts)
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
@@ -266,20 +315,52 @@ def main():
         elapsed, accepted_all = float(mx[0]), float(sm[1])
     else:
         accepted_all = float(accepted)
-    correct = seq[P:P + len(truth)] == truth[:len(seq) - P]       # lookahead output == plain greedy output
+    correct = all(seqs[i][P:P + len(truths[gidx[i]])] == truths[gidx[i]][:len(seqs[i]) - P] for i in range(B))
     native = None
-    if not dist_on and len(seq) + (BL + 1) * 16 < max_length:
+    if B == 1 and not dist_on and len(seqs[0]) + (BL + 1) * (16 + 24) < max_length - 2 * DL:
         # informational: the same steps through the native loop (la_lookahead_decode, what lookahead_generation() uses when
         # no streamer / processor is attached).  `value` stays on the interpreter loop, which is also what N > 1 runs.
         torch.cuda.synchronize()
         t1 = time.time()
-        new, dls_n, edls_n, _, _, _ = eng.decode_native(cache, seq, max_length - 2 * DL, eos_ids=(), decoding_length=DL,
-                                                        branch_length=BL, max_query_length=2, idx=rank, max_steps=16)
+        new, dls_n, edls_n, _, _, _ = eng.decode_native(cache, seqs[0], max_length - 2 * DL, eos_ids=(), decoding_length=DL,
+                                                        branch_length=BL, max_query_length=2, idx=gidx[0], max_steps=16)
         dt = time.time() - t1
-        seq.extend(new)
+        seqs[0].extend(new)
         native = {'steps': len(edls_n), 'ms_per_step': round(1e3 * dt / max(len(edls_n), 1), 4),
                   'accepted_tokens_per_sec': round(sum(edls_n) / dt, 2),
-                  'equals_greedy': seq[P:P + len(truth)] == truth[:len(seq) - P]}
+                  'equals_greedy': seqs[0][P:P + len(truths[gidx[0]])] == truths[gidx[0]][:len(seqs[0]) - P]}
+
+    # ---- 8(d) fixed draft-tree shape "T64/B8" with the accept sweep: the main chain equals the greedy continuation for a tokens
+    sweep = None
+    if B == 1 and not dist_on and not args.pure_random:
+        parent, depth, rows64 = fixed_t64b8_tree()
+        truth = truths[gidx[0]]
+        sweep = {}
+        V = shape.vocab
+        for a in (0, 3, 6, 12):
+            times, ok = [], True
+            for _ in range(6):
+                k = len(seqs[0]) - P                       # truth[k] is the token after the root
+                ids = np.zeros(64, dtype=np.int32)
+                ids[0] = seqs[0][-1]
+                for j in range(1, 64):
+                    d = depth[j]
+                    right = truth[k + d - 1]
+                    on_main = j <= 12
+                    if on_main and d <= a:
+                        ids[j] = right
+                    else:                                   # a wrong token, distinct from every sibling (siblings differ in j)
+                        w = 3 + (right - 3 + 1 + j) % (V - 3)
+                        ids[j] = w
+                torch.cuda.synchronize(); t1 = time.time()
+                toks, _ = eng.step(ids, rows64, mode=0)
+                times.append(time.time() - t1)
+                ok = ok and toks == truth[k:k + a + 1]
+                seqs[0].extend(toks)
+                cache.stream_put(toks, branch_length=BL + 1, final=False, idx=gidx[0])
+            ms = 1e3 * float(np.mean(times[1:]))
+            sweep[f'a={a}'] = {'ms_per_step': round(ms, 4), 'accepted_per_step': a + 1, 'accepted_tokens_per_sec': round((a + 1) / ms * 1e3, 1),
+                               'accepted_as_designed': bool(ok)}
 
     if rank != 0:
         if dist_on:
@@ -287,59 +368,86 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (gate/up GEMM, k_gemm64r<4,SWIGLU,4,8>) from live HIP events ---------
-    ctx = eng.n_keys
-    ids, rowmask, _, _ = cache.hier_get_packed(seq[-2:], decoding_length=DL, branch_length=BL, min_output_size=DL // 2)
-    T_prof = len(ids)
-    prof = eng.profile(ids, rowmask, iters=args.profile_iters)
-    gu_ms = prof['ms']['gateup'] / max(prof['launches']['gateup'], 1)
-    gu_bytes = 2 * shape.ffn * shape.hidden * 2 + 64 * shape.hidden * 2 + 64 * shape.ffn * 2
+    # ---- roofline ---------------------------------------------------------------------------------------------------
+    ctx = eng.n_keys if B == 1 else int(np.mean(eng.slot_keys[:B]))
     ms_step = 1e3 * elapsed / K
     mean_T = float(np.mean(dls[n0:]))
-    step_bytes = algorithmic_bytes(shape, 64, ctx, 64 * shape.vocab * 2)
-    gemm_ms = sum(prof['ms'][k] for k in ('qkv', 'o', 'gateup', 'down', 'lm_head'))
-    traffic, traffic_src = None, None
-    try:        # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py)
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')))
-        key = [k for k in pmc['kernels'] if k.startswith('void k_gemm64r<4, 1, 4, 8')][0]      # gate/up launch
-        traffic = pmc['kernels'][key]['hbm_bytes_per_launch']
-        traffic_src = pmc['source']
-    except Exception:
-        pass
-    roofline = {
-        'bound': 'hbm', 'kernel': 'k_gemm64r<4,EPI_SWIGLU,4,8> (gate/up projection + fused SwiGLU, 32 launches/step)',
-        'achieved': round(gu_bytes / (gu_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-        'frac': round(gu_bytes / (gu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
-        'bytes_per_launch': gu_bytes, 'ms_per_launch': round(gu_ms, 5),
-        # the same launch against the matrix-core roof: 64-row trees keep the kernel far below the MFMA ridge (HBM-bound by
-        # design); profiles/r01_pmc_SQ_v5.txt holds the SQ_VALU_MFMA_BUSY_CYCLES pass of rocprofv3
-        'mfma': {'flops_per_launch': 2 * 2 * shape.ffn * shape.hidden * 64,
-                 'achieved_TFLOPs': round(2 * 2 * shape.ffn * shape.hidden * 64 / (gu_ms * 1e-3) / 1e12, 1),
-                 'peak_TFLOPs': 2500.0, 'frac': round(2 * 2 * shape.ffn * shape.hidden * 64 / (gu_ms * 1e-3) / 1e12 / 2500.0, 4)},
-        'verify_step': {'algorithmic_bytes': step_bytes, 'ms_graph_step': round(ms_step, 4),
-                        'achieved_GBps': round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
-                        'frac': round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        'ms_eager_step_events': round(prof['ms_step'], 4),
-                        'ms_by_class_events': {k: round(v, 4) for k, v in prof['ms'].items()},
-                        'all_gemm_GBps_events': round(2 * shape.n_params_no_embed() / (gemm_ms * 1e-3) / 1e9, 1)},
-    }
     mean_acc = float(np.mean(edls[n0:]))
+    W_bytes = 2 * shape.n_params_no_embed()
+    if B == 1:
+        # dominant kernel (gate/up GEMM, k_gemm64r<4,SWIGLU,4,8>) from live HIP events on the engine's stream
+        ids, rowmask = drafts_for(0)
+        prof = eng.profile(ids, rowmask, iters=args.profile_iters)
+        gu_ms = prof['ms']['gateup'] / max(prof['launches']['gateup'], 1)
+        gu_bytes = 2 * shape.ffn * shape.hidden * 2 + 64 * shape.hidden * 2 + 64 * shape.ffn * 2
+        step_bytes = algorithmic_bytes(shape, 64, ctx, 64 * shape.vocab * 2)
+        gemm_ms = sum(prof['ms'][k] for k in ('qkv', 'o', 'gateup', 'down', 'lm_head'))
+        traffic, traffic_src = None, None
+        try:        # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py)
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')))
+            key = [k for k in pmc['kernels'] if k.startswith('void k_gemm64r<4, 1, 4, 8')][0]      # gate/up launch
+            traffic = pmc['kernels'][key]['hbm_bytes_per_launch']
+            traffic_src = pmc['source']
+        except Exception:
+            pass
+        roofline = {
+            'bound': 'hbm', 'kernel': 'k_gemm64r<4,EPI_SWIGLU,4,8> (gate/up projection + fused SwiGLU, %d launches/step)' % shape.n_layers,
+            'achieved': round(gu_bytes / (gu_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(gu_bytes / (gu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+            'bytes_per_launch': gu_bytes, 'ms_per_launch': round(gu_ms, 5),
+            # the same launch against the matrix-core roof: 64-row trees keep the kernel far below the MFMA ridge (HBM-bound by design)
+            'mfma': {'flops_per_launch': 2 * 2 * shape.ffn * shape.hidden * 64,
+                     'achieved_TFLOPs': round(2 * 2 * shape.ffn * shape.hidden * 64 / (gu_ms * 1e-3) / 1e12, 1),
+                     'peak_TFLOPs': 2500.0, 'frac': round(2 * 2 * shape.ffn * shape.hidden * 64 / (gu_ms * 1e-3) / 1e12 / 2500.0, 4)},
+            'verify_step': {'algorithmic_bytes': step_bytes, 'ms_graph_step': round(ms_step, 4),
+                            'achieved_GBps': round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
+                            'frac': round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            'ms_eager_step_events': round(prof['ms_step'], 4),
+                            'ms_by_class_events': {k: round(v, 4) for k, v in prof['ms'].items()},
+                            'all_gemm_GBps_events': round(2 * shape.n_params_no_embed() / (gemm_ms * 1e-3) / 1e9, 1)},
+        }
+    else:
+        # M = 64 B rows per step: near / past the ridge -> the step is priced against BOTH roofs from its wall time;
+        # per-kernel durations of the same step: profiles/r02_mblock_kernel_stats_*.txt (rocprofv3 --kernel-trace --stats)
+        kv_tok = 2 * shape.n_layers * shape.n_kv_heads * shape.head_dim * 2
+        step_bytes = W_bytes + kv_tok * ctx * B + kv_tok * 64 * B + 64 * B * (shape.hidden * 2 + 8) + 64 * B * shape.vocab * 2
+        step_flops = 2.0 * shape.n_params_no_embed() * 64 * B + 4.0 * shape.n_layers * shape.n_heads * shape.head_dim * 64 * B * (ctx + 64)
+        hbm_frac = step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+        mfma_frac = step_flops / (ms_step * 1e-3) / 1e12 / 2500.0
+        bound = 'mfma' if mfma_frac >= hbm_frac else 'hbm'
+        roofline = {
+            'bound': bound, 'kernel': 'whole multi-block verify step (k_gemm_mb family + k_tree_attn_mb), M = %d rows' % (64 * B),
+            'achieved': round(step_flops / (ms_step * 1e-3) / 1e12, 1) if bound == 'mfma' else round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
+            'peak': 2500.0 if bound == 'mfma' else HBM_PEAK_GBS, 'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
+            'frac': round(max(mfma_frac, hbm_frac), 4), 'traffic': None,
+            'hbm': {'algorithmic_bytes': step_bytes, 'achieved_GBps': round(step_bytes / (ms_step * 1e-3) / 1e9, 1), 'frac': round(hbm_frac, 4)},
+            'mfma': {'flops': step_flops, 'achieved_TFLOPs': round(step_flops / (ms_step * 1e-3) / 1e12, 1), 'frac': round(mfma_frac, 4)},
+        }
     cpu = None
-    if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed on rank 0 at N=1 only
-        cpu = cpu_baseline(shape, 64, ctx, mean_acc)
+    if want_cpu:
+        cpu = cpu_baseline_loop(shape, sd_cpu, prompts[0], copies0, BL, DL, verify_steps=args.cpu_steps)
+    gen = accepted_all / max(world, 1)
     out = {
         'metric': 'accepted_tokens_per_sec', 'value': round(accepted_all / elapsed, 2), 'unit': 'tokens/s',
         'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': model_name + ' bf16 bs=1/GPU lookahead verify loop, 64-token draft tree / 8-12 noisy branches '
+        'config': {'workload': model_name + f' bf16 bs={B}/GPU lookahead verify loop, 64-token draft tree per sequence / 8-12 noisy branches '
                                '(hier, decoding_length=64, branch_length=12), synthetic permutation-LM weights (N(0,0.02); o/down std 1e-4; '
-                               'lm_head[pi(t)]=embed[t]) for decisive greedy margins, 512-token phrase-bank prompt',
-                   'n_layers': shape.n_layers, 'prompt_len': P, 'rho': args.rho, 'copies': args.copies, 'parallelism': f'batch-shard x{world}',
+                               'lm_head[pi(t)]=embed[t]) for decisive greedy margins, 512-token phrase-bank prompts',
+                   'n_layers': shape.n_layers, 'prompt_len': P, 'rho': args.rho, 'copies': args.copies,
+                   'parallelism': f'batch-shard x{world}, {B} sequence(s) per GPU', 'sequences': NSEQ,
+                   'gather_mode': None if not dist_on else ('strict' if args.strict_gather else 'split-phase'),
                    'mean_accept_len': round(mean_acc, 3), 'mean_draft_len': round(mean_T, 2),
                    'verify_steps_per_sec': round(K * world / elapsed, 2), 'context_at_end': ctx,
-                   'trie_query_ms_mean': round(1e3 * float(np.mean(qts[n0:])), 4),
-                   'lookahead_equals_greedy': bool(correct), 'plain_greedy_tokens_per_sec': round(len(truth) / t_greedy, 2),
-                   'native_loop': native},
+                   'trie_query_ms_mean': round(1e3 * float(np.mean(qts[q0:])), 4),
+                   'lookahead_equals_greedy': bool(correct), 'plain_greedy_tokens_per_sec': round(B * len(truth_own[0]) / t_greedy, 2),
+                   'native_loop': native,
+                   'speed_incl_prefill': {'prefill_ms': round(1e3 * t_prefill, 3), 'prefill_tokens': P * B,
+                                          'generated_tokens': int(gen), 'decode_s': round(elapsed, 4),
+                                          'tokens_per_sec': round(gen / (t_prefill + elapsed), 2),
+                                          'at_256_new_tokens': round(256 * B / (t_prefill + 256 * B / max(accepted_all / world / elapsed, 1e-9)), 2),
+                                          'note': 'reference headline definition: generated tokens / (prefill + decode) wall time (benchmarks/benchmark.py:277-328), per GPU'},
+                   'fixed_tree_sweep': sweep},
         'roofline': roofline, 'cpu_baseline': cpu,
     }
     print(json.dumps(out))

@@ -390,6 +390,21 @@ int la_tree_attn_batch(void* stream, const void* d_qf, const void* d_kmain, cons
                        int n_kv_heads, int slot_keys, int n_slots, int n_split, float* d_opart, float* d_mpart,
                        float* d_lpart, void* d_attn_xp);
 /* ------------------------------------------------------------------------
+ * Multi-GPU: the accepted-token all-gather (the only exchange on the path).  One process per GPU; every rank owns
+ * B_loc sequences, a model replica and a trie replica.  Per step: d_local int32[B_loc][words] = {n, tokens...} per sequence ->
+ * d_global int32[world][B_loc][words] by ONE ncclAllGather on `stream` (RCCL over xGMI); the host then applies stream_put for
+ * every sequence in global batch-index order (pretrained_model_batch.py:1254-1259), so all trie replicas equal the reference's
+ * single-process batch run.  The reference has no counterpart (single process, device_map only): its contract is the ORDER.
+ * librccl is resolved at run time; la_comm_unique_id is called on rank 0 and its 128 bytes are distributed by the launcher
+ * (bench.py / distributed.py broadcast them through torch.distributed).
+ * --------------------------------------------------------------------- */
+typedef struct la_comm la_comm;
+int      la_comm_unique_id(uint8_t* out128);
+la_comm* la_comm_create(const uint8_t* id128, int world, int rank);     /* binds to the current HIP device */
+int      la_comm_destroy(la_comm* c);
+int      la_gather_accepted(la_comm* c, void* stream, const int32_t* d_local, int b_loc, int words, int32_t* d_global);
+
+/* ------------------------------------------------------------------------
  * Multi-block step: nblk <= LA_MB_MAX blocks of 64 rows in ONE pass over the weights (M = nblk*64 rows through the LDS-
  * staged GEMM family of csrc/la_mblock.hip).  A block is one sequence's 64-token draft tree (BASELINE configs 3-5: a full
  * tree per sample) or one 64-token piece of a prompt (prefill: consecutive blocks of the same slot form a

@@ -215,7 +215,7 @@ def lookahead_generate(model, cache, prompt, max_length, eos_token_id=2, decodin
     """bs=1 lookahead_generation, greedy decoding; logits_processor: None / empty (row-parallel argmax) or a
     LogitsProcessorList (sequential walk).  -> dict(sequences, dls, edls, fts, qts).  `cache` is any object with the
     LookaheadCache surface."""
-    eos = [eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id)
+    eos = [eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id if eos_token_id is not None else [None])
     cache.eos_ids = eos
     cache.stop_words = stop_words if stop_words is not None else {}
     seq = [int(x) for x in prompt]

@@ -170,6 +170,10 @@ PROTOTYPES = {
     "la_llama_mstep": (i32, vp, vp, vp, vp),
     "la_llama_mstep_eager": (i32, vp, vp, vp, vp),
     "la_llama_set_nkeys": (i32, vp, vp, i32, i32),
+    "la_comm_unique_id": (i32, vp),
+    "la_comm_create": (vp, vp, i32, i32),
+    "la_comm_destroy": (i32, vp),
+    "la_gather_accepted": (i32, vp, vp, vp, i32, i32, vp),
     "la_mb_gemm": (i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32),
     "la_llama_bstep_eager": (i32, vp, vp, vp, vp),
     "la_llama_reset_slot": (i32, vp, vp, i32),

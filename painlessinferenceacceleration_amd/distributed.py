@@ -1,81 +1,165 @@
 # -*- coding: utf-8 -*-
 """Batch sharding across the GPUs of one node: the only exchange on the path.
 
-Sequences are independent: rank r owns sequence r, a full model replica, its KV cache and a trie
-replica.  Per verify step every rank contributes `int32[branch_length + 2]` = {n, tokens...}; one all-gather
-(RCCL over xGMI on GPU, gloo in the CPU tests) hands every rank every sequence's accepted tokens, which are then
-applied to the local trie in GLOBAL batch-index order — exactly the order in which the reference's single-process
-batch loop calls stream_put (common/pretrained_model_batch.py:1254-1259) — so all replicas stay identical.
-The message is 56 B per sequence: latency-bound, never bandwidth-bound.
+Sequences are independent: with B sequences and N ranks, rank r owns the B_loc = B / N sequences with global
+batch index b = i * N + r (b mod N == r), a full model replica, their KV caches and a trie replica.  Per verify step every
+rank contributes int32[B_loc][SLOT] = {n, tokens...} per sequence; ONE all-gather hands every rank every sequence's accepted
+tokens, which are then applied to the local trie in GLOBAL batch-index order — the order in which the reference's
+single-process batch loop calls stream_put (common/pretrained_model_batch.py:1254-1259) — so all replicas stay identical to
+that run.  The message is 64 B per sequence: latency-bound, never bandwidth-bound.
+
+Transport: on GPUs the all-gather is la_gather_accepted (C ABI, ncclAllGather of RCCL over xGMI on the engine's stream,
+communicator created from an id broadcast through torch.distributed); on CPU (gloo tests) and as a fallback it is
+torch.distributed.all_gather_into_tensor.  Two modes, label every number with the one it was measured in:
+  strict       gather(...) / update_trie(...): blocking, every rank's drafts see every token of the step — trie state at query
+               time equals the reference's single-process order (bit-exact retrieval);
+  split-phase  begin(...) after step k, finish_into_trie(...) during step k+1: the gather and the host-side trie updates
+               overlap the next verify step; drafts see a step's tokens one step later (emitted tokens are unaffected:
+               verification is lossless), replicas still identical to each other.
 """
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
-SLOT = 16      # int32 words per sequence: count + up to branch_length+1 (<= 13) tokens, padded
+from . import _lib
+from ._lib import check, lib
+
+
+def slot_words(branch_length):
+    """int32 words per sequence: count + up to branch_length + 1 tokens, rounded up to 16 words (64-byte messages)."""
+    return max(16, (int(branch_length) + 2 + 15) // 16 * 16)
 
 
 class AcceptedTokenGather(object):
-    def __init__(self, device, group=None):
+    def __init__(self, device, group=None, b_loc=1, branch_length=12, native=None):
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.local_only = not dist.is_initialized()        # a 1-rank process group still runs the collective
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = torch.device(device)
-        self._in = torch.zeros(SLOT, dtype=torch.int32, device=self.device)
-        self._out = torch.zeros(SLOT * self.world, dtype=torch.int32, device=self.device)
+        self.b_loc = int(b_loc)
+        self.slot = slot_words(branch_length)
+        self.max_tokens = self.slot - 1
+        n = self.b_loc * self.slot
+        self._in = torch.zeros(n, dtype=torch.int32, device=self.device)
+        self._out = torch.zeros(n * self.world, dtype=torch.int32, device=self.device)
+        pin = self.device.type == 'cuda'
+        self._stage = torch.zeros(n, dtype=torch.int32, pin_memory=pin)
+        self._host = torch.zeros(n * self.world, dtype=torch.int32, pin_memory=pin)
+        self._work = None
+        self._comm = None
+        self._stream = None
+        if native is None:
+            native = self.device.type == 'cuda' and not self.local_only and dist.get_backend(group) == 'nccl'
+        if native:
+            self._init_native()
 
+    # ---- native RCCL communicator (la_comm_*): id from rank 0, distributed through torch.distributed ---------------------
+    def _init_native(self):
+        idbuf = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            arr = (C.c_uint8 * 128)()
+            check(lib.la_comm_unique_id(arr), 'comm_unique_id')
+            idbuf = torch.tensor(list(arr), dtype=torch.uint8)
+        if not self.local_only:
+            t = idbuf.to(self.device) if dist.get_backend(self.group) == 'nccl' else idbuf
+            dist.broadcast(t, src=0, group=self.group)
+            idbuf = t.cpu()
+        arr = (C.c_uint8 * 128)(*idbuf.tolist())
+        torch.cuda.set_device(self.device)
+        self._comm = lib.la_comm_create(arr, self.world, self.rank)
+        if not self._comm:
+            raise _lib.LookaheadHipError(f'la_comm_create: {_lib.last_error()}')
+        self._stream = torch.cuda.Stream(self.device)
+        self._done = torch.cuda.Event()
+
+    def __del__(self):
+        if getattr(self, '_comm', None):
+            lib.la_comm_destroy(self._comm)
+            self._comm = None
+
+    # ---- packing -------------------------------------------------------------------------------------------------------
+    def _lists(self, tokens):
+        if self.b_loc == 1 and (len(tokens) == 0 or not isinstance(tokens[0], (list, tuple, np.ndarray))):
+            tokens = [tokens]                  # bs=1 per rank: a flat token list
+        assert len(tokens) == self.b_loc, f'{len(tokens)} token lists for b_loc={self.b_loc}'
+        return [list(t) for t in tokens]
+
+    def _pack(self, lists):
+        buf = self._stage
+        buf.zero_()
+        v = buf.view(self.b_loc, self.slot)
+        for i, t in enumerate(lists):
+            if len(t) > self.max_tokens:
+                raise ValueError(f'{len(t)} accepted tokens do not fit the {self.slot}-word gather slot; construct '
+                                 f'AcceptedTokenGather with branch_length >= {len(t) - 1}')
+            v[i, 0] = len(t)
+            if t:
+                v[i, 1:1 + len(t)] = torch.tensor(t, dtype=torch.int32)
+        return buf
+
+    def _unpack(self, host):
+        """-> token lists in GLOBAL batch-index order b = i * world + r."""
+        allv = host.view(self.world, self.b_loc, self.slot)
+        return [allv[r, i, 1:1 + int(allv[r, i, 0])].tolist() for i in range(self.b_loc) for r in range(self.world)]
+
+    def global_index(self, i):
+        """global batch index of this rank's i-th sequence"""
+        return i * self.world + self.rank
+
+    # ---- strict (blocking) form -------------------------------------------------------------------------------------------
     def gather(self, tokens):
-        """tokens: this rank's accepted tokens of the step -> list (per rank, in rank order) of token lists."""
-        assert len(tokens) < SLOT
-        if self.local_only:
-            return [list(tokens)]
-        buf = torch.zeros(SLOT, dtype=torch.int32)
-        buf[0] = len(tokens)
-        buf[1:1 + len(tokens)] = torch.tensor(tokens, dtype=torch.int32)
-        self._in.copy_(buf)
-        dist.all_gather_into_tensor(self._out, self._in, group=self.group)
-        allv = self._out.cpu().view(self.world, SLOT)
-        return [allv[r, 1:1 + int(allv[r, 0])].tolist() for r in range(self.world)]
+        """tokens: this rank's accepted tokens of the step (b_loc lists; a flat list when b_loc == 1)
+        -> token lists of all B sequences in global batch-index order."""
+        self.begin(tokens)
+        return self.finish()
 
-    # ---- split-phase form: the gather of step k overlaps the verify step k+1 -------------------------------------
+    # ---- split-phase form: the gather of step k overlaps the verify step k+1 ---------------------------------------------
     def begin(self, tokens):
         """Start the all-gather of this rank's accepted tokens (asynchronous; one outstanding gather at a time)."""
-        assert len(tokens) < SLOT and getattr(self, '_work', None) is None
-        self._mine = list(tokens)
+        assert self._work is None, 'one outstanding gather at a time'
+        lists = self._lists(tokens)
+        self._mine = lists
         if self.local_only:
             self._work = True
             return
-        if not hasattr(self, '_stage'):
-            pin = self.device.type == 'cuda'
-            self._stage = torch.zeros(SLOT, dtype=torch.int32, pin_memory=pin)
-            self._host = torch.zeros(SLOT * self.world, dtype=torch.int32, pin_memory=pin)
-        self._stage.zero_()
-        self._stage[0] = len(tokens)
-        if tokens:
-            self._stage[1:1 + len(tokens)] = torch.tensor(tokens, dtype=torch.int32)
-        self._in.copy_(self._stage, non_blocking=True)
-        self._work = dist.all_gather_into_tensor(self._out, self._in, group=self.group, async_op=True)
+        self._pack(lists)
+        if self._comm:
+            with torch.cuda.stream(self._stream):
+                self._in.copy_(self._stage, non_blocking=True)
+                check(lib.la_gather_accepted(self._comm, C.c_void_p(self._stream.cuda_stream), self._in.data_ptr(), self.b_loc,
+                                             self.slot, self._out.data_ptr()), 'gather_accepted')
+                self._host.copy_(self._out, non_blocking=True)
+                self._done.record(self._stream)
+            self._work = True
+        else:
+            self._in.copy_(self._stage, non_blocking=True)
+            self._work = dist.all_gather_into_tensor(self._out, self._in, group=self.group, async_op=True)
 
     def finish(self):
-        """-> per-rank token lists of the gather started by begin()."""
-        assert getattr(self, '_work', None) is not None
+        """-> token lists (global batch-index order) of the gather started by begin()."""
+        assert self._work is not None
         work, self._work = self._work, None
         if self.local_only:
-            return [self._mine]
-        work.wait()
-        self._host.copy_(self._out)
-        allv = self._host.view(self.world, SLOT)
-        return [allv[r, 1:1 + int(allv[r, 0])].tolist() for r in range(self.world)]
+            return self._mine
+        if self._comm:
+            self._done.synchronize()
+        else:
+            work.wait()
+            self._host.copy_(self._out)
+        return self._unpack(self._host)
 
     def finish_into_trie(self, cache, branch_length, final=False):
-        per_rank = self.finish()
-        for r, toks in enumerate(per_rank):
-            cache.stream_put(toks, branch_length=branch_length + 1, final=final, mode='output', idx=r)
-        return per_rank
+        per_seq = self.finish()
+        for b, toks in enumerate(per_seq):
+            cache.stream_put(toks, branch_length=branch_length + 1, final=final, mode='output', idx=b)
+        return per_seq
 
     def update_trie(self, cache, tokens, branch_length, final=False):
-        """all-gather + stream_put for every sequence (idx = global batch index) in rank order."""
-        per_rank = self.gather(tokens)
-        for r, toks in enumerate(per_rank):
-            cache.stream_put(toks, branch_length=branch_length + 1, final=final, mode='output', idx=r)
-        return per_rank
+        """strict mode: all-gather + stream_put for every sequence (idx = global batch index) in batch-index order."""
+        per_seq = self.gather(tokens)
+        for b, toks in enumerate(per_seq):
+            cache.stream_put(toks, branch_length=branch_length + 1, final=final, mode='output', idx=b)
+        return per_seq

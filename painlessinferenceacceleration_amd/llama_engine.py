@@ -612,10 +612,16 @@ class LlamaVerifyEngine(object):
 
     _CHAIN = np.array([(2 << t) - 1 for t in range(63)] + [0xFFFFFFFFFFFFFFFF], dtype=np.uint64)
 
-    def prefill(self, prompt_ids, eager=False):
-        """Process the prompt as chains of <=64 tokens (lower-triangular row masks); returns the first generated
-        token (argmax of the last prompt row, pretrained_model.py:783-798)."""
+    def prefill(self, prompt_ids, eager=False, fast=None):
+        """Process the prompt; returns the first generated token (argmax of the last prompt row,
+        pretrained_model.py:783-798).  fast (default: engines created with max_blocks > 1, prompts of more than one block):
+        chains of up to max_blocks x 64 tokens per pass over the weights (la_llama_mstep); otherwise 64-token steps, whose
+        last block's logits stay readable through logits()."""
         prompt_ids = [int(x) for x in prompt_ids]
+        if fast is None:
+            fast = bool(self.max_blocks) and len(prompt_ids) > 64
+        if fast:
+            return self.mprefill(0, prompt_ids, eager=eager)
         tok = None
         for s in range(0, len(prompt_ids), 64):
             blk = prompt_ids[s:s + 64]

@@ -163,7 +163,7 @@ class LookaheadPreTrainedModel(object):
         try:
             while True:
                 if first:
-                    tok = eng.prefill(seq)
+                    tok = eng.prefill(seq, fast=False) if sequential else eng.prefill(seq)
                     next_tokens = [pick(seq, (len(seq) - 1) % 64)] if sequential else [tok]
                     decoding_kwargs['dls'].append(1)
                     decoding_kwargs['edls'].append(1)
@@ -263,7 +263,7 @@ class LookaheadPreTrainedModel(object):
                 return int(torch.multinomial(torch.softmax(scores.float(), dim=-1), num_samples=1)[0, 0])
             return int(torch.argmax(scores, dim=-1)[0])
 
-        tok = eng.prefill(seq)
+        tok = eng.prefill(seq, fast=False) if host_pick else eng.prefill(seq)
         if host_pick:
             tok = pick((len(seq) - 1) % 64)
         seq.append(tok)

@@ -27,7 +27,7 @@ class OracleEngine(object):
         logits, past = self.model.forward(torch.tensor([int(x) for x in ids]), full, self.past)
         return logits, past, tree
 
-    def prefill(self, prompt_ids):
+    def prefill(self, prompt_ids, eager=False, fast=None):
         tok = None
         for s in range(0, len(prompt_ids), 64):
             blk = prompt_ids[s:s + 64]

@@ -37,11 +37,35 @@ def test_synthetic_workload_generators_are_deterministic():
     assert 0.6 < kept < 0.8                      # rho = 0.3 of the tokens are replaced
 
 
-def test_cpu_baseline_leg_runs_on_a_small_shape():
-    s = LlamaShape(2, 256, 2, 2, 512, 1024, 1e-5)
-    r = bench.cpu_baseline(s, 16, 64, 5.0, budget_s=3.0)
-    assert r['kind'] == 'port' and r['unit'] == 'tokens/s' and r['value'] > 0 and r['cores'] >= 1
-    assert r['ms_per_step'] > 0 and 'sample' in r
+def test_cpu_baseline_leg_runs_the_oracle_loop_on_a_small_shape():
+    """the CPU leg = the oracle's own lookahead loop (full model, own drafts, own accept-len), here on the tiny decisive model"""
+    import torch
+    from tests.tiny_model import tiny_decisive_weights, tiny_shape
+    s = tiny_shape()
+    sd = tiny_decisive_weights(0, torch.bfloat16)
+    prompt = bench.phrase_prompt(7, 40, s.vocab)
+    # greedy continuation of the permutation LM = follow lm_head[pi(t)] = embed[t]; a few noisy copies warm the trie
+    from oracle import llama_oracle as lo
+    model = lo.OracleLlama(s, sd)
+    seq = list(prompt)
+    lg, past = model.forward(torch.tensor(seq), torch.tril(torch.ones((40, 40), dtype=torch.long)), None)
+    for _ in range(60):
+        t = int(lg[-1].float().argmax())
+        seq.append(t)
+        lg, past = model.forward(torch.tensor([t]), torch.ones((1, len(seq)), dtype=torch.long), past)
+    copies = bench.noisy_copies(prompt[-2:] + seq[40:], 6, 0.3, s.vocab, seed=99)
+    r = bench.cpu_baseline_loop(s, sd, prompt, copies, 12, 64, verify_steps=4, threads=2)
+    assert r['kind'] == 'port' and r['unit'] == 'tokens/s' and r['value'] > 0 and r['cores'] == 2 and r['verify_steps'] == 4
+    assert r['ms_per_step'] > 0 and r['mean_accept_len'] > 1.0 and 'cpu_model' in r and 'sample' in r
+
+
+def test_fixed_t64b8_tree_is_the_survey_shape():
+    """T = 64, 8 leaves all at depth 12, row0 = 0x1, row12 = 0x1fff (main chain), first fork row = 0x23ff."""
+    parent, depth, rows = bench.fixed_t64b8_tree()
+    leaves = [i for i in range(64) if i not in parent]
+    assert len(parent) == 64 and len(leaves) == 8 and all(depth[i] == 12 for i in leaves)
+    assert int(rows[0]) == 0x1 and int(rows[12]) == 0x1fff and int(rows[13]) == 0x23ff
+    assert all(int(rows[i]).bit_count() == depth[i] + 1 for i in range(64))
 
 
 def test_committed_pmc_summary_is_what_bench_reads():

@@ -43,8 +43,13 @@ def _worker(rank, world, port, steps, q):
     from painlessinferenceacceleration_amd.distributed import AcceptedTokenGather
     from painlessinferenceacceleration_amd.lookahead_cache import LookaheadCache
     cache = LookaheadCache(eos_ids=[None])
-    g = AcceptedTokenGather('cpu')
-    mine = _streams(world, steps)[rank]
+    b_loc = int(os.environ.get('LA_TEST_BLOC', '1'))
+    g = AcceptedTokenGather('cpu', b_loc=b_loc)
+    allseq = _streams(world * b_loc, steps)
+    if b_loc == 1:
+        mine = allseq[rank]
+    else:      # this rank owns the global sequences b = i * world + rank; one token list per owned sequence and step
+        mine = [[allseq[g.global_index(i)][s] for i in range(b_loc)] for s in range(steps)]
     seen = []
     if os.environ.get('LA_TEST_SPLIT_PHASE'):
         # split-phase form used by bench.py at N > 1: the gather of step s is collected during step s + 1
@@ -55,12 +60,12 @@ def _worker(rank, world, port, steps, q):
             g.begin(mine[s])
             pending = True
         seen.append(g.finish_into_trie(cache, branch_length=12))
-        g.begin([])
+        g.begin([[] for _ in range(b_loc)] if b_loc > 1 else [])
         g.finish_into_trie(cache, branch_length=12, final=True)
     else:
         for s in range(steps):
             seen.append(g.update_trie(cache, mine[s], branch_length=12))
-        g.update_trie(cache, [], branch_length=12, final=True)
+        g.update_trie(cache, [[] for _ in range(b_loc)] if b_loc > 1 else [], branch_length=12, final=True)
     res = []
     rng = random.Random(9)
     for _ in range(200):
@@ -72,9 +77,13 @@ def _worker(rank, world, port, steps, q):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('b_loc', [1, 2])
 @pytest.mark.parametrize('split_phase', [False, True])
-def test_two_rank_trie_replicas_stay_identical(split_phase):
+def test_two_rank_trie_replicas_stay_identical(split_phase, b_loc):
+    """world 2 x b_loc sequences per rank (config 4's layout: 32 sequences over 8 GPUs = 4 per rank): every rank's trie replica
+    == a single-process cache fed all B sequences in global batch-index order, in the strict and in the split-phase mode."""
     world, steps = 2, 40
+    os.environ['LA_TEST_BLOC'] = str(b_loc)
     if split_phase:
         os.environ['LA_TEST_SPLIT_PHASE'] = '1'
     else:
@@ -93,19 +102,20 @@ def test_two_rank_trie_replicas_stay_identical(split_phase):
         p.join(timeout=60)
         assert p.exitcode == 0
     # every rank saw every sequence's tokens, in rank order
-    streams = _streams(world, steps)
+    B = world * b_loc
+    streams = _streams(B, steps)
     for r in range(world):
         for s in range(steps):
-            assert outs[r][0][s] == [streams[k][s] for k in range(world)]
+            assert outs[r][0][s] == [streams[k][s] for k in range(B)]
     # replicas agree with each other (queries carry idx=rank, but no input freqs exist, so drafts coincide)
     assert outs[0][1] == outs[1][1]
     # ... and with a single-process cache fed in global batch-index order
     from painlessinferenceacceleration_amd.lookahead_cache import LookaheadCache
     ref = LookaheadCache(eos_ids=[None])
     for s in range(steps):
-        for r in range(world):
+        for r in range(B):
             ref.stream_put(streams[r][s], branch_length=13, final=False, idx=r)
-    for r in range(world):
+    for r in range(B):
         ref.stream_put([], branch_length=13, final=True, idx=r)
     assert ref.stats()['n_nodes'] == outs[0][2]['n_nodes'] == outs[1][2]['n_nodes']
     rng = random.Random(9)
