@@ -145,6 +145,7 @@ def main():
     ap.add_argument('--model', choices=['7b', '13b', 'mistral'], default='7b',
                     help='7b = the BASELINE metric; 13b / mistral = the config-4 / config-3 model shapes')
     ap.add_argument('--batch', type=int, default=1, help='sequences per GPU; > 1: each gets its own 64-token tree per step (la_llama_mstep)')
+    ap.add_argument('--device-trie', action='store_true', help='--batch > 1: drafts of all sequences from ONE device launch over the incremental trie mirror')
     ap.add_argument('--strict-gather', action='store_true', help='N > 1: blocking all-gather (reference trie order at query time)')
     ap.add_argument('--profile-iters', type=int, default=3)
     ap.add_argument('--attn-split', type=int, default=0, help='key splits of the tree-attention kernel (0 = engine default 8)')
@@ -259,9 +260,21 @@ def main():
             return np.asarray(seqs[i][-1:], dtype=np.int32), np.array([1], dtype=np.uint64)
         return ids.copy(), rowmask.copy()
 
+    dev_trie = None
+    if args.device_trie and B > 1:
+        from painlessinferenceacceleration_amd.device_trie import DeviceTrie
+        dev_trie = DeviceTrie(cache, idxs=gidx, device=dev)
+
+    def drafts_dev():
+        ubl = [min(BL, max_length - len(seqs[i]) - 1) for i in range(B)]
+        got = dev_trie.hier_get([seqs[i][-2:] for i in range(B)], idxs=gidx, branch_lengths=ubl, decoding_length=DL, branch_length=BL,
+                                min_input_size=0, min_output_size=DL // 2, mode='mix')
+        return [(np.asarray(g[0], dtype=np.int32), np.asarray(g[1], dtype=np.uint64)) if len(g[0]) else
+                (np.asarray(seqs[i][-1:], dtype=np.int32), np.array([1], dtype=np.uint64)) for i, g in enumerate(got)]
+
     def one_step():
         tq = time.time()
-        dr = [drafts_for(i) for i in range(B)]
+        dr = drafts_dev() if dev_trie is not None else [drafts_for(i) for i in range(B)]
         qts.append(time.time() - tq)
         if B == 1:
             eng.step_async(dr[0][0], dr[0][1], mode=0)
@@ -437,6 +450,8 @@ def main():
                    'n_layers': shape.n_layers, 'prompt_len': P, 'rho': args.rho, 'copies': args.copies,
                    'parallelism': f'batch-shard x{world}, {B} sequence(s) per GPU', 'sequences': NSEQ,
                    'gather_mode': None if not dist_on else ('strict' if args.strict_gather else 'split-phase'),
+                   'draft_retrieval': 'device trie (incremental mirror, one launch per step)' if dev_trie is not None else 'host trie',
+                   'device_trie_stats': dev_trie.stats if dev_trie is not None else None,
                    'mean_accept_len': round(mean_acc, 3), 'mean_draft_len': round(mean_T, 2),
                    'verify_steps_per_sec': round(K * world / elapsed, 2), 'context_at_end': ctx,
                    'trie_query_ms_mean': round(1e3 * float(np.mean(qts[q0:])), 4),

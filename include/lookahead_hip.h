@@ -111,6 +111,27 @@ int la_cache_tree_counters(la_cache* c, int32_t token, int64_t* n_node, int64_t*
 int la_cache_save(la_cache* c, const char* path);
 int la_cache_load(la_cache* c, const char* path);
 
+/* Incremental device mirror of the forest (the layout la_trie_hier_get_dev reads), owned by the host trie: every put /
+ * stream_put / reset_input_freqs is logged as the handful of words it changed; squeeze / fresh / load mark the mirror for a
+ * rebuild.  idx_planes: the input-frequency slots (LookaheadCache idx values, e.g. the batch indices 0..B-1) mirrored as fi
+ * planes.  Per sync: la_cache_mirror_state -> if *full: la_cache_mirror_image into host buffers + upload, else
+ * la_cache_mirror_patch + upload + la_trie_patch_dev on the stream that runs the queries. */
+int la_cache_mirror_enable(la_cache* c, const int32_t* idx_planes, int n_planes);
+int la_cache_mirror_state(la_cache* c, int32_t* n_records, int32_t* full, int32_t* n_ipatch, int32_t* n_dpatch);
+int la_cache_mirror_image(la_cache* c, int32_t cap, int32_t* tok, double* fo, double* fi /*[planes][cap]*/, int32_t* cstart,
+                          int32_t* ccount);
+int la_cache_mirror_patch(la_cache* c, int32_t* ipatch /*[n_i][3]*/, int32_t* dkey /*[n_d][2]*/, double* dval /*[n_d]*/);
+/* Apply a patch to the device image (one thread per word; fi planes are `fi_stride` records apart). */
+int la_trie_patch_dev(void* stream, int32_t* d_tok, double* d_fo, double* d_fi, int64_t fi_stride, int32_t* d_cstart,
+                      int32_t* d_ccount, const int32_t* d_ipatch, int n_i, const int32_t* d_dkey, const double* d_dval, int n_d);
+/* la_trie_hier_get_dev with one fi plane per query (d_plane[b], planes fi_stride records apart) and the per-query branch
+ * length / stop rule of a batch step. */
+int la_trie_hier_get_dev2(void* stream, const int32_t* d_tok, const double* d_fo, const double* d_fi, int64_t fi_stride,
+                          const int32_t* d_cstart, const int32_t* d_ccount, int32_t n_records, const int32_t* d_queries /*[B][8]*/,
+                          const int32_t* d_nq, const int32_t* d_plane, const int32_t* d_branch_length /*[B] or NULL*/, int B,
+                          int decoding_length, int branch_length, int min_in, int min_out, int mode, const int32_t* d_stop,
+                          int n_stop, int32_t* d_scratch_q, double* d_scratch_v, int32_t* d_out_ids, uint64_t* d_out_rowmask,
+                          int32_t* d_out_n, int32_t* d_out_sizes, int32_t* d_out_nsizes);
 /* Device-side retrieval.  la_cache_export snapshots the forest for one input slot `idx` into host arrays (call with
  * cap = 0 to get *n_nodes): live nodes renumbered breadth-first, children of node u = ids [cstart[u], cstart[u]+ccount[u])
  * in dict insertion order, node 0 = super-root over the per-token trees.  la_trie_hier_get_dev runs hier_get

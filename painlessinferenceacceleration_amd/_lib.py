@@ -170,6 +170,12 @@ PROTOTYPES = {
     "la_llama_mstep": (i32, vp, vp, vp, vp),
     "la_llama_mstep_eager": (i32, vp, vp, vp, vp),
     "la_llama_set_nkeys": (i32, vp, vp, i32, i32),
+    "la_cache_mirror_enable": (i32, vp, pi32, i32),
+    "la_cache_mirror_state": (i32, vp, pi32, pi32, pi32, pi32),
+    "la_cache_mirror_image": (i32, vp, i32, pi32, C.POINTER(C.c_double), C.POINTER(C.c_double), pi32, pi32),
+    "la_cache_mirror_patch": (i32, vp, pi32, pi32, C.POINTER(C.c_double)),
+    "la_trie_patch_dev": (i32, vp, vp, vp, vp, i64, vp, vp, vp, i32, vp, vp, i32),
+    "la_trie_hier_get_dev2": (i32, vp, vp, vp, vp, i64, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp),
     "la_comm_unique_id": (i32, vp),
     "la_comm_create": (vp, vp, i32, i32),
     "la_comm_destroy": (i32, vp),

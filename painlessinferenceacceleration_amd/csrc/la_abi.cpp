@@ -197,4 +197,26 @@ int la_trie_hier_get_dev(void* stream, const int32_t* d_tok, const double* d_fo,
                           d_scratch_q, d_scratch_v, d_out_ids, d_out_rowmask, d_out_n, d_out_sizes, d_out_nsizes));
 }
 
+int la_trie_patch_dev(void* stream, int32_t* d_tok, double* d_fo, double* d_fi, int64_t fi_stride, int32_t* d_cstart,
+                      int32_t* d_ccount, const int32_t* d_ipatch, int n_i, const int32_t* d_dkey, const double* d_dval, int n_d) {
+    if (!d_tok || !d_fo || !d_cstart || !d_ccount || n_i < 0 || n_d < 0 || (n_i > 0 && !d_ipatch) || (n_d > 0 && (!d_dkey || !d_dval)))
+        return LA_E_ARG;
+    WRAP(lk_trie_patch((hipStream_t)stream, d_tok, d_fo, d_fi, (long)fi_stride, d_cstart, d_ccount, d_ipatch, n_i, d_dkey, d_dval, n_d));
+}
+
+int la_trie_hier_get_dev2(void* stream, const int32_t* d_tok, const double* d_fo, const double* d_fi, int64_t fi_stride,
+                          const int32_t* d_cstart, const int32_t* d_ccount, int32_t n_records, const int32_t* d_queries,
+                          const int32_t* d_nq, const int32_t* d_plane, const int32_t* d_branch_length, int B, int decoding_length,
+                          int branch_length, int min_in, int min_out, int mode, const int32_t* d_stop, int n_stop,
+                          int32_t* d_scratch_q, double* d_scratch_v, int32_t* d_out_ids, uint64_t* d_out_rowmask, int32_t* d_out_n,
+                          int32_t* d_out_sizes, int32_t* d_out_nsizes) {
+    if (!d_tok || !d_fo || !d_fi || !d_cstart || !d_ccount || n_records < 1 || !d_queries || !d_nq || B < 1 ||
+        !d_scratch_q || !d_scratch_v || !d_out_ids || !d_out_rowmask || !d_out_n || !d_out_sizes || !d_out_nsizes ||
+        mode < 0 || mode > 2 || (n_stop > 0 && !d_stop)) return LA_E_ARG;
+    if (decoding_length > LA_TREE_MAX) { la_set_error("device hier_get handles decoding_length <= 64"); return LA_E_RANGE; }
+    WRAP(lk_trie_hier_get2((hipStream_t)stream, d_tok, d_fo, d_fi, (long)fi_stride, d_cstart, d_ccount, n_records, d_queries, d_nq,
+                           d_plane, d_branch_length, B, decoding_length, branch_length, min_in, min_out, mode, d_stop, n_stop,
+                           d_scratch_q, d_scratch_v, d_out_ids, d_out_rowmask, d_out_n, d_out_sizes, d_out_nsizes));
+}
+
 }  // extern "C"

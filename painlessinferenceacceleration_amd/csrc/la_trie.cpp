@@ -40,6 +40,88 @@ static inline uint64_t key_of(int32_t parent, int32_t token) {
 
 }  // namespace
 
+// ---- incremental device mirror (consumed by la_trie_hier_get_dev, csrc/la_trie_dev.hip) --------------------------------
+// The host trie stays the single owner of all updates; the mirror is the SAME forest in the device layout — record 0 is a
+// super-root whose children are the tree roots, the children of a record are consecutive records in insertion order — kept as
+// host arrays plus a log of the words that changed since the last sync.  A node's child block grows like a vector (capacity
+// doubling at the arena end; the old block becomes garbage), so an n-gram insert (<= 13 nodes) costs a handful of record
+// writes, and a verify step's trie update reaches the device as a patch of a few hundred bytes instead of a re-export
+// (212 ms for 157 k nodes, profiles/r01_trie_host_vs_device.txt).  Deletions (squeeze, fresh, load) mark the mirror stale:
+// the next sync rebuilds and re-uploads it (they happen at request boundaries, lookahead_cache.py:572-576).
+struct Mirror {
+    std::vector<int32_t> plane_idx;                   // input-frequency slots mirrored as fi planes (e.g. 0..B-1)
+    std::vector<int32_t> tok, cstart, ccount, ccap, host_of;
+    std::vector<double> fo;
+    std::vector<std::vector<double>> fi;              // [plane][record]
+    std::vector<int32_t> dev_of;                      // host node id -> record (-1 = none)
+    bool stale = true, full = true;
+    std::unordered_map<uint64_t, size_t> ipos, dpos;  // (array, record) -> position in the log: last write wins
+    std::vector<int32_t> ilog;                        // triples {array: 0 tok, 1 cstart, 2 ccount; record; value}
+    std::vector<int32_t> dkey;                        // pairs {plane: 0 fo, 1 + k fi plane k; record}
+    std::vector<double> dval;
+
+    int plane_of(int32_t idx) const {
+        for (size_t k = 0; k < plane_idx.size(); ++k) if (plane_idx[k] == idx) return (int)k;
+        return -1;
+    }
+    void clear_log() { ipos.clear(); dpos.clear(); ilog.clear(); dkey.clear(); dval.clear(); }
+    void log_i(int arr, int32_t rec, int32_t val) {
+        const uint64_t k = ((uint64_t)arr << 32) | (uint32_t)rec;
+        auto it = ipos.find(k);
+        if (it != ipos.end()) { ilog[it->second * 3 + 2] = val; return; }
+        ipos[k] = ilog.size() / 3;
+        ilog.push_back(arr); ilog.push_back(rec); ilog.push_back(val);
+    }
+    void log_d(int plane, int32_t rec, double val) {
+        const uint64_t k = ((uint64_t)plane << 32) | (uint32_t)rec;
+        auto it = dpos.find(k);
+        if (it != dpos.end()) { dval[it->second] = val; return; }
+        dpos[k] = dval.size();
+        dkey.push_back(plane); dkey.push_back(rec); dval.push_back(val);
+    }
+    int32_t grow(int32_t n) {                          // n fresh records at the arena end
+        const int32_t start = (int32_t)tok.size();
+        tok.resize(start + n, -1); cstart.resize(start + n, 0); ccount.resize(start + n, 0); ccap.resize(start + n, 0);
+        host_of.resize(start + n, -1); fo.resize(start + n, 0.0);
+        for (auto& pl : fi) pl.resize(start + n, 0.0);
+        return start;
+    }
+    void write_record(int32_t rec) {                   // log every word of a (new or moved) record
+        log_i(0, rec, tok[rec]); log_i(1, rec, cstart[rec]); log_i(2, rec, ccount[rec]);
+        log_d(0, rec, fo[rec]);
+        for (size_t k = 0; k < fi.size(); ++k) log_d(1 + (int)k, rec, fi[k][rec]);
+    }
+    // append a child record under `prec`; returns its record id
+    int32_t add_child(int32_t prec, int32_t token, int32_t host_node) {
+        if (ccount[prec] == ccap[prec]) {              // block full: move it to the arena end with twice the room
+            const int32_t ncap = ccap[prec] < 2 ? 4 : 2 * ccap[prec];
+            const int32_t nstart = grow(ncap), ostart = cstart[prec], cnt = ccount[prec];
+            for (int32_t k = 0; k < cnt; ++k) {
+                const int32_t o = ostart + k, n = nstart + k;
+                tok[n] = tok[o]; cstart[n] = cstart[o]; ccount[n] = ccount[o]; ccap[n] = ccap[o]; host_of[n] = host_of[o];
+                fo[n] = fo[o];
+                for (auto& pl : fi) pl[n] = pl[o];
+                if (host_of[n] >= 0) dev_of[host_of[n]] = n;
+                host_of[o] = -1;
+                write_record(n);
+            }
+            cstart[prec] = nstart; ccap[prec] = ncap;
+            log_i(1, prec, nstart);
+        }
+        const int32_t rec = cstart[prec] + ccount[prec];
+        ccount[prec] += 1;
+        log_i(2, prec, ccount[prec]);
+        tok[rec] = token; cstart[rec] = 0; ccount[rec] = 0; ccap[rec] = 0; host_of[rec] = host_node; fo[rec] = 0.0;
+        for (auto& pl : fi) pl[rec] = 0.0;
+        if (host_node >= 0) {
+            if ((size_t)host_node >= dev_of.size()) dev_of.resize((size_t)host_node + 1, -1);
+            dev_of[host_node] = rec;
+        }
+        write_record(rec);
+        return rec;
+    }
+};
+
 struct la_cache {
     int64_t max_node, max_output_node;
     std::vector<int32_t> eos;            // empty <=> [None]
@@ -55,6 +137,9 @@ struct la_cache {
     std::unordered_map<int32_t, std::vector<int32_t>> output_ids;   // _output_ids[idx]
     int64_t next_uid = 1;
     int64_t live_nodes = 0;
+    Mirror* mir = nullptr;                                        // optional device mirror (la_cache_mirror_*)
+    ~la_cache() { delete mir; }
+    bool mir_live() const { return mir && !mir->stale; }
 
     // ---- arena ----
     int32_t new_node(int32_t token, int32_t parent) {
@@ -75,6 +160,10 @@ struct la_cache {
         p.last_child = child;
         child_index[key_of(parent, c.token)] = child;
         ++live_nodes;
+        if (mir_live()) {
+            const int32_t prec = (size_t)parent < mir->dev_of.size() ? mir->dev_of[parent] : -1;
+            if (prec < 0) mir->stale = true; else mir->add_child(prec, c.token, child);
+        }
     }
     int32_t find_child(int32_t parent, int32_t token) const {
         auto it = child_index.find(key_of(parent, token));
@@ -82,6 +171,7 @@ struct la_cache {
     }
     // delete `child` and its whole subtree (dict.pop of a Node drops everything below it)
     void drop_subtree(int32_t child) {
+        if (mir) mir->stale = true;
         Node& c = nodes[child];
         Node& p = nodes[c.parent];
         if (c.prev_sib >= 0) nodes[c.prev_sib].next_sib = c.next_sib; else p.first_child = c.next_sib;
@@ -116,6 +206,18 @@ struct la_cache {
         n.fi.emplace_back(idx, f);
     }
 
+    // mirror: the freq slot `idx` of `node` changed on the host
+    void mir_freq(int32_t node, int32_t idx) {
+        if (!mir_live()) return;
+        const int32_t rec = (size_t)node < mir->dev_of.size() ? mir->dev_of[node] : -1;
+        if (rec < 0) { mir->stale = true; return; }
+        if (idx == -1) { mir->fo[rec] = nodes[node].fo; mir->log_d(0, rec, nodes[node].fo); return; }
+        const int pl = mir->plane_of(idx);
+        if (pl < 0) return;                                          // this input slot is not mirrored
+        const double v = get_fi(nodes[node], idx);
+        mir->fi[pl][rec] = v; mir->log_d(1 + pl, rec, v);
+    }
+
     // ---- Tree ----
     int32_t tree_get_or_create(int32_t token, bool* created) {
         auto it = mem.find(token);
@@ -129,6 +231,7 @@ struct la_cache {
         t.n_node = 0; t.n_output_node = 0; t.uid = next_uid++;
         mem[token] = slot;
         live_by_uid[t.uid] = slot;
+        if (mir_live()) mir->add_child(0, token, t.root);            // tree roots are the super-root's children
         *created = true;
         return slot;
     }
@@ -143,6 +246,7 @@ struct la_cache {
                     int32_t nn = new_node(toks[j], cur);
                     link_child(cur, nn);
                     add_freq(nodes[nn], idx, 1.0);
+                    mir_freq(nn, idx);
                     cur = nn;
                 }
                 t.n_node += n - i;
@@ -150,6 +254,7 @@ struct la_cache {
                 return;
             }
             add_freq(nodes[ch], idx, 1.0);                          // :53
+            mir_freq(ch, idx);
             cur = ch;
         }
     }
@@ -293,6 +398,7 @@ struct la_cache {
             int32_t next = nodes[ch].next_sib;
             if (nodes[ch].fo > 1.0) {
                 nodes[ch].fo *= 0.5;
+                if (mir) mir->stale = true;
                 if (nodes[ch].first_child >= 0) squeeze_rec(ch);
             } else {
                 drop_subtree(ch);
@@ -325,6 +431,7 @@ struct la_cache {
                 double f = get_fi(nodes[ch], idx);
                 if (f == 0.0) continue;
                 set_fi(nodes[ch], idx, 0.0);
+                mir_freq(ch, idx);
                 if (nodes[ch].first_child >= 0) stack.push_back(ch);
             }
         }
@@ -385,6 +492,7 @@ int la_cache_fresh(la_cache* c) {
     c->nodes.clear(); c->free_nodes.clear(); c->child_index.clear();
     c->trees.clear(); c->free_trees.clear();
     c->live_nodes = 0;
+    if (c->mir) c->mir->stale = true;
     return LA_OK;
 }
 
@@ -600,6 +708,96 @@ int la_cache_export(la_cache* c, int idx, int32_t cap, int32_t* tok, double* fo,
     return LA_OK;
 }
 
+// ---- incremental mirror: enable / state / full image / patch ------------------------------------------------------------
+static void mirror_rebuild(la_cache* c) {
+    Mirror& m = *c->mir;
+    const size_t planes = m.plane_idx.size();
+    m.tok.clear(); m.cstart.clear(); m.ccount.clear(); m.ccap.clear(); m.host_of.clear(); m.fo.clear();
+    m.fi.assign(planes, std::vector<double>());
+    m.dev_of.assign(c->nodes.size(), -1);
+    m.clear_log();
+    m.grow(1);                                           // super root
+    std::vector<int32_t> roots;
+    for (auto& kv : c->mem) roots.push_back(c->trees[kv.second].root);
+    std::sort(roots.begin(), roots.end());               // creation order of the arena = a deterministic order
+    const int32_t r0 = m.grow((int32_t)roots.size());
+    m.cstart[0] = r0; m.ccount[0] = m.ccap[0] = (int32_t)roots.size();
+    std::vector<int32_t> order;                          // records still to expand (breadth-first)
+    for (size_t i = 0; i < roots.size(); ++i) {
+        const int32_t rec = r0 + (int32_t)i;
+        m.host_of[rec] = roots[i]; m.dev_of[roots[i]] = rec;
+        order.push_back(rec);
+    }
+    for (size_t qi = 0; qi < order.size(); ++qi) {
+        const int32_t rec = order[qi], node = m.host_of[rec];
+        const Node& nd = c->nodes[node];
+        m.tok[rec] = nd.token; m.fo[rec] = nd.fo;
+        for (size_t k = 0; k < planes; ++k) m.fi[k][rec] = la_cache::get_fi(nd, m.plane_idx[k]);
+        int32_t cnt = 0;
+        for (int32_t ch = nd.first_child; ch >= 0; ch = c->nodes[ch].next_sib) ++cnt;
+        if (cnt == 0) continue;
+        const int32_t cs = m.grow(cnt);
+        m.cstart[rec] = cs; m.ccount[rec] = m.ccap[rec] = cnt;
+        int32_t k = 0;
+        for (int32_t ch = nd.first_child; ch >= 0; ch = c->nodes[ch].next_sib, ++k) {
+            m.host_of[cs + k] = ch; m.dev_of[ch] = cs + k;
+            order.push_back(cs + k);
+        }
+    }
+    m.stale = false;
+    m.full = true;
+}
+
+int la_cache_mirror_enable(la_cache* c, const int32_t* idx_planes, int n_planes) {
+    if (!c || n_planes < 0 || n_planes > 64 || (n_planes > 0 && !idx_planes)) return LA_E_ARG;
+    delete c->mir;
+    c->mir = new Mirror();
+    c->mir->plane_idx.assign(idx_planes, idx_planes + n_planes);
+    c->mir->stale = true;
+    return LA_OK;
+}
+
+int la_cache_mirror_state(la_cache* c, int32_t* n_records, int32_t* full, int32_t* n_ipatch, int32_t* n_dpatch) {
+    if (!c || !c->mir || !n_records || !full || !n_ipatch || !n_dpatch) return LA_E_ARG;
+    if (c->mir->stale) mirror_rebuild(c);
+    const Mirror& m = *c->mir;
+    *n_records = (int32_t)m.tok.size();
+    *full = m.full ? 1 : 0;
+    *n_ipatch = (int32_t)(m.ilog.size() / 3);
+    *n_dpatch = (int32_t)m.dval.size();
+    return LA_OK;
+}
+
+// whole image into caller buffers of `cap` records (fi: [planes][cap]); clears the patch log
+int la_cache_mirror_image(la_cache* c, int32_t cap, int32_t* tok, double* fo, double* fi, int32_t* cstart, int32_t* ccount) {
+    if (!c || !c->mir || !tok || !fo || !cstart || !ccount) return LA_E_ARG;
+    if (c->mir->stale) mirror_rebuild(c);
+    Mirror& m = *c->mir;
+    const size_t n = m.tok.size();
+    if ((size_t)cap < n || (!m.fi.empty() && !fi)) return LA_E_RANGE;
+    memcpy(tok, m.tok.data(), n * 4); memcpy(cstart, m.cstart.data(), n * 4); memcpy(ccount, m.ccount.data(), n * 4);
+    memcpy(fo, m.fo.data(), n * 8);
+    for (size_t k = 0; k < m.fi.size(); ++k) memcpy(fi + k * (size_t)cap, m.fi[k].data(), n * 8);
+    m.clear_log();
+    m.full = false;
+    return LA_OK;
+}
+
+// the words that changed since the last sync: ipatch int32[n_i][3] = {array (0 tok, 1 cstart, 2 ccount), record, value},
+// dkey int32[n_d][2] = {plane (0 fo, 1 + k fi plane k), record}, dval double[n_d]; every (array, record) appears once
+int la_cache_mirror_patch(la_cache* c, int32_t* ipatch, int32_t* dkey, double* dval) {
+    if (!c || !c->mir) return LA_E_ARG;
+    Mirror& m = *c->mir;
+    if (m.stale || m.full) { la_set_error("mirror_patch: a full image is due (see la_cache_mirror_state)"); return LA_E_STATE; }
+    if (!m.ilog.empty()) { if (!ipatch) return LA_E_ARG; memcpy(ipatch, m.ilog.data(), m.ilog.size() * 4); }
+    if (!m.dval.empty()) {
+        if (!dkey || !dval) return LA_E_ARG;
+        memcpy(dkey, m.dkey.data(), m.dkey.size() * 4); memcpy(dval, m.dval.data(), m.dval.size() * 8);
+    }
+    m.clear_log();
+    return LA_OK;
+}
+
 // bat_get() without the padded canvas (lookahead_cache.py:519-561): the per-sample drafts of a batch in ONE call — same
 // budget rule (decoding_length // bs per sample, min_output_size = max(per // 2, 1), idx = indices[b]); hier: ids + 64-bit
 // row masks, one: ids + chain masks.  Rows b of the outputs hold out_n[b] <= cap entries.
@@ -719,6 +917,7 @@ int la_cache_load(la_cache* live, const char* path) {
     live->nodes.swap(c->nodes); live->free_nodes.swap(c->free_nodes); live->child_index.swap(c->child_index);
     live->trees.swap(c->trees); live->free_trees.swap(c->free_trees);
     live->live_nodes = c->live_nodes; live->next_uid = c->next_uid;
+    if (live->mir) live->mir->stale = true;
     return LA_OK;
 }
 

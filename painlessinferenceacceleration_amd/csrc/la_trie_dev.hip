@@ -27,6 +27,9 @@ struct TrieQueryArgs {
     int* out_n;           // [B]
     int* out_sizes;       // [B][2]
     int* out_nsizes;      // [B]
+    const int* plane;     // [B] fi plane of each query (null: plane 0)
+    long fi_stride;       // records between fi planes
+    const int* bl;        // [B] per-query branch length (null: branch_length)
 };
 
 #define TBIG 1e9
@@ -79,7 +82,9 @@ __global__ __launch_bounds__(64) void k_trie_hier_get(TrieQueryArgs a) {
     __shared__ int st_node[72], st_pos[72], st_pid[72], st_depth[72];
     __shared__ double st_fm[72];
     const int b = blockIdx.x, lane = threadIdx.x;
-    const TrieDev& t = a.t;
+    TrieDev t = a.t;
+    if (a.plane) t.fi += (size_t)a.plane[b] * (size_t)a.fi_stride;
+    const int branch_length = a.bl ? a.bl[b] : a.branch_length;
     const int* q = a.queries + b * 8;
     const int nq = a.nq[b];
     int* oid = a.out_ids + b * 64;
@@ -87,12 +92,12 @@ __global__ __launch_bounds__(64) void k_trie_hier_get(TrieQueryArgs a) {
     int* queue = a.scratch_q + (size_t)b * t.n_nodes;
     double* vfi = a.scratch_v + (size_t)b * 2 * t.n_nodes;
     double* vfo = vfi + t.n_nodes;
-    const int max_size = a.decoding_length, max_length = a.branch_length, mode = a.mode;
+    const int max_size = a.decoding_length, max_length = branch_length, mode = a.mode;
 
     auto finish = [&](int n, int s0, int s1, int nsizes) {
         if (lane == 0) { a.out_n[b] = n; a.out_sizes[b * 2] = s0; a.out_sizes[b * 2 + 1] = s1; a.out_nsizes[b] = nsizes; }
     };
-    if (a.decoding_length <= 1 || a.branch_length == 0) {                     // :413-414
+    if (a.decoding_length <= 1 || branch_length == 0) {                       // :413-414
         if (nq > 0 && lane == 0) { oid[0] = q[nq - 1]; orm[0] = 1ull; }
         finish(nq > 0 ? 1 : 0, 0, 0, 0);
         return;
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(64) void k_trie_hier_get(TrieQueryArgs a) {
             }
             n_out = n;
         }
-        if (n_out >= a.branch_length) break;                                  // :433-434 (else a later suffix overwrites)
+        if (n_out >= branch_length) break;                                    // :433-434 (else a later suffix overwrites)
     }
     if (!have) {                                                              // :436-437
         if (nq > 0 && lane == 0) { oid[0] = q[nq - 1]; orm[0] = 1ull; }
@@ -245,7 +250,50 @@ int lk_trie_hier_get(hipStream_t st, const int* tok, const double* fo, const dou
                      int min_in, int min_out, int mode, const int* stop, int n_stop, int* scratch_q, double* scratch_v,
                      int* out_ids, uint64_t* out_rowmask, int* out_n, int* out_sizes, int* out_nsizes) {
     TrieQueryArgs a{};
+    a.plane = nullptr; a.fi_stride = 0; a.bl = nullptr;
     a.t = TrieDev{tok, fo, fi, cstart, ccount, n_nodes};
+    a.queries = queries; a.nq = nq; a.decoding_length = decoding_length; a.branch_length = branch_length;
+    a.min_in = min_in; a.min_out = min_out; a.mode = mode; a.stop = stop; a.n_stop = n_stop;
+    a.scratch_q = scratch_q; a.scratch_v = scratch_v; a.out_ids = out_ids; a.out_rowmask = (unsigned long long*)out_rowmask;
+    a.out_n = out_n; a.out_sizes = out_sizes; a.out_nsizes = out_nsizes;
+    k_trie_hier_get<<<B, 64, 0, st>>>(a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+
+// ---- incremental mirror: apply a patch (la_cache_mirror_patch) to the device image ---------------------------------------
+__global__ void k_trie_patch(int* __restrict__ tok, double* __restrict__ fo, double* __restrict__ fi, long fi_stride,
+                             int* __restrict__ cstart, int* __restrict__ ccount, const int* __restrict__ ipatch, int n_i,
+                             const int* __restrict__ dkey, const double* __restrict__ dval, int n_d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_i) {
+        const int arr = ipatch[3 * i], rec = ipatch[3 * i + 1], val = ipatch[3 * i + 2];
+        (arr == 0 ? tok : arr == 1 ? cstart : ccount)[rec] = val;
+    } else if (i < n_i + n_d) {
+        const int k = i - n_i;
+        const int plane = dkey[2 * k], rec = dkey[2 * k + 1];
+        if (plane == 0) fo[rec] = dval[k]; else fi[(size_t)(plane - 1) * (size_t)fi_stride + rec] = dval[k];
+    }
+}
+
+int lk_trie_patch(hipStream_t st, int* tok, double* fo, double* fi, long fi_stride, int* cstart, int* ccount, const int* ipatch,
+                  int n_i, const int* dkey, const double* dval, int n_d) {
+    const int n = n_i + n_d;
+    if (n <= 0) return 0;
+    k_trie_patch<<<(n + 255) / 256, 256, 0, st>>>(tok, fo, fi, fi_stride, cstart, ccount, ipatch, n_i, dkey, dval, n_d);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int lk_trie_hier_get2(hipStream_t st, const int* tok, const double* fo, const double* fi, long fi_stride, const int* cstart,
+                      const int* ccount, int n_nodes, const int* queries, const int* nq, const int* plane, const int* bl, int B,
+                      int decoding_length, int branch_length, int min_in, int min_out, int mode, const int* stop, int n_stop,
+                      int* scratch_q, double* scratch_v, int* out_ids, uint64_t* out_rowmask, int* out_n, int* out_sizes,
+                      int* out_nsizes) {
+    TrieQueryArgs a{};
+    a.t = TrieDev{tok, fo, fi, cstart, ccount, n_nodes};
+    a.plane = plane; a.fi_stride = fi_stride; a.bl = bl;
     a.queries = queries; a.nq = nq; a.decoding_length = decoding_length; a.branch_length = branch_length;
     a.min_in = min_in; a.min_out = min_out; a.mode = mode; a.stop = stop; a.n_stop = n_stop;
     a.scratch_q = scratch_q; a.scratch_v = scratch_v; a.out_ids = out_ids; a.out_rowmask = (unsigned long long*)out_rowmask;

@@ -1,10 +1,16 @@
 # -*- coding: utf-8 -*-
-"""DeviceTrie — hier_get on the GPU over a mirrored snapshot of a LookaheadCache (la_cache_export +
-la_trie_hier_get_dev, csrc/la_trie_dev.hip).  One wavefront per query; bit-identical to LookaheadCache.hier_get.
+"""DeviceTrie — hier_get on the GPU over an INCREMENTAL mirror of a LookaheadCache (csrc/la_trie.cpp Mirror +
+csrc/la_trie_dev.hip).  One wavefront per query (ballot prefix match, wave-parallel live-subtree scan, radix-select cut-offs,
+ordered DFS); bit-identical to LookaheadCache.hier_get (lookahead_cache.py:408-439).
 
-The host trie stays the owner of all updates (put / stream_put / squeeze); a mirror is a read-only snapshot for one
-input-frequency slot `idx`.  On the bs=1 path the host query (10-40 us) is faster than any device pointer chase, so
-lookahead_generation() keeps using it; this class is the batched retrieval building block (B queries in one launch).
+The host trie stays the owner of all updates (put / stream_put / reset_input_freqs / squeeze); it logs every word an update
+changes in the device layout.  sync() ships that log — a few hundred bytes per verify step — as one pinned H2D copy plus one
+patch kernel on the query stream; only fresh / load / squeeze (request boundaries) and arena growth past the device capacity
+cost a full image upload.  Input-frequency slots (`idxs`, one per batch index) are mirrored as fi planes, so one launch serves
+every sequence of a batch step with its own input frequencies.
+
+Product use: pretrained_model_batch.lookahead_generation(decoding_kwargs={'device_trie': True}) retrieves the drafts of all
+active samples with one launch here instead of one host query per sample.
 """
 import ctypes as C
 
@@ -19,47 +25,152 @@ _pd = C.POINTER(C.c_double)
 
 
 class DeviceTrie(object):
-    def __init__(self, cache, idx=0, device='cuda:0'):
+    def __init__(self, cache, idx=None, device='cuda:0', idxs=None, max_queries=64):
         if not torch.cuda.is_available():
             raise RuntimeError('DeviceTrie needs an MI355X (no CPU fallback)')
         self.device = torch.device(device)
-        n = C.c_int32()
-        check(lib.la_cache_export(cache._h, int(idx), 0, None, None, None, None, None, C.byref(n)), 'export(size)')
-        cap = n.value
-        tok = np.zeros(cap, np.int32); fo = np.zeros(cap, np.float64); fi = np.zeros(cap, np.float64)
-        cs = np.zeros(cap, np.int32); cc = np.zeros(cap, np.int32)
-        check(lib.la_cache_export(cache._h, int(idx), cap, tok.ctypes.data_as(_lib.pi32), fo.ctypes.data_as(_pd),
-                                  fi.ctypes.data_as(_pd), cs.ctypes.data_as(_lib.pi32), cc.ctypes.data_as(_lib.pi32),
-                                  C.byref(n)), 'export')
-        self.n_nodes = n.value
-        up = lambda a: torch.from_numpy(a[:self.n_nodes].copy()).to(self.device)
-        self.tok, self.fo, self.fi, self.cstart, self.ccount = up(tok), up(fo), up(fi), up(cs), up(cc)
-        self.stop_words = [int(x) for x in cache.stop_words]
+        self.cache = cache
+        self.idxs = [int(i) for i in (idxs if idxs is not None else [0 if idx is None else idx])]
+        self.plane = {v: k for k, v in enumerate(self.idxs)}
+        arr = np.asarray(self.idxs, dtype=np.int32)
+        check(lib.la_cache_mirror_enable(cache._h, arr.ctypes.data_as(_lib.pi32), len(self.idxs)), 'mirror_enable')
+        self.cap = 0
+        self.n_records = 0
+        self.stats = {'full_uploads': 0, 'patches': 0, 'patch_words': 0}
+        self._qcap = 0
+        self._alloc_queries(max_queries)
+        self._patch_cap = 0
+        self.sync()
 
-    def hier_get(self, queries, decoding_length=64, branch_length=8, min_input_size=0, min_output_size=0, mode='mix'):
-        """queries: list of token lists (each <= 8 tokens).  -> list of (ids list, uint64 row masks, sizes list)."""
+    # ---- device image ------------------------------------------------------------------------------------------------
+    def _alloc_image(self, n):
+        self.cap = max(int(n * 1.5) + 4096, 8192)
+        P = max(len(self.idxs), 1)
+        dev = self.device
+        self.tok = torch.empty(self.cap, dtype=torch.int32, device=dev)
+        self.cstart = torch.empty(self.cap, dtype=torch.int32, device=dev)
+        self.ccount = torch.empty(self.cap, dtype=torch.int32, device=dev)
+        self.fo = torch.empty(self.cap, dtype=torch.float64, device=dev)
+        self.fi = torch.zeros(P * self.cap, dtype=torch.float64, device=dev)
+        self._h_tok = torch.empty(self.cap, dtype=torch.int32).pin_memory()
+        self._h_cstart = torch.empty(self.cap, dtype=torch.int32).pin_memory()
+        self._h_ccount = torch.empty(self.cap, dtype=torch.int32).pin_memory()
+        self._h_fo = torch.empty(self.cap, dtype=torch.float64).pin_memory()
+        self._h_fi = torch.zeros(P * self.cap, dtype=torch.float64).pin_memory()
+        self._scratch = None
+
+    def _alloc_queries(self, B):
+        if B <= self._qcap:
+            return
+        self._qcap = B
+        dev = self.device
+        self._hq = torch.zeros(B * 8 + 3 * B, dtype=torch.int32).pin_memory()      # queries [B][8], nq [B], plane [B], bl [B]
+        self._dq = torch.zeros(B * 8 + 3 * B, dtype=torch.int32, device=dev)
+        self.out_ids = torch.zeros(B * 64, dtype=torch.int32, device=dev)
+        self.out_rm = torch.zeros(B * 64, dtype=torch.int64, device=dev)
+        self.out_n = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.out_sizes = torch.zeros(B * 2, dtype=torch.int32, device=dev)
+        self.out_nsizes = torch.zeros(B, dtype=torch.int32, device=dev)
+        self._scratch = None
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def sync(self):
+        """Bring the device image up to date with the host trie (patch, or full image when due).  Enqueued on the current
+        stream; returns the kind of sync that happened."""
+        n, full, ni, nd = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib.la_cache_mirror_state(self.cache._h, C.byref(n), C.byref(full), C.byref(ni), C.byref(nd)), 'mirror_state')
+        self.stop_words = [int(x) for x in self.cache.stop_words]
+        if full.value or n.value > self.cap:
+            if n.value > self.cap:
+                self._alloc_image(n.value)
+            P = len(self.idxs)
+            check(lib.la_cache_mirror_image(self.cache._h, self.cap, C.cast(self._h_tok.data_ptr(), _lib.pi32),
+                                            C.cast(self._h_fo.data_ptr(), _pd), C.cast(self._h_fi.data_ptr(), _pd),
+                                            C.cast(self._h_cstart.data_ptr(), _lib.pi32),
+                                            C.cast(self._h_ccount.data_ptr(), _lib.pi32)), 'mirror_image')
+            k = n.value
+            self.tok[:k].copy_(self._h_tok[:k], non_blocking=True)
+            self.cstart[:k].copy_(self._h_cstart[:k], non_blocking=True)
+            self.ccount[:k].copy_(self._h_ccount[:k], non_blocking=True)
+            self.fo[:k].copy_(self._h_fo[:k], non_blocking=True)
+            for p in range(P):
+                self.fi[p * self.cap:p * self.cap + k].copy_(self._h_fi[p * self.cap:p * self.cap + k], non_blocking=True)
+            self.n_records = k
+            self.stats['full_uploads'] += 1
+            return 'full'
+        self.n_records = n.value
+        if ni.value == 0 and nd.value == 0:
+            return 'clean'
+        need = 3 * ni.value + 2 * nd.value
+        if need > self._patch_cap or nd.value > getattr(self, '_patch_dcap', 0):
+            self._patch_cap = max(2 * need, 4096)
+            self._patch_dcap = max(2 * nd.value, 2048)
+            self._h_pi = torch.zeros(self._patch_cap, dtype=torch.int32).pin_memory()
+            self._d_pi = torch.zeros(self._patch_cap, dtype=torch.int32, device=self.device)
+            self._h_pd = torch.zeros(self._patch_dcap, dtype=torch.float64).pin_memory()
+            self._d_pd = torch.zeros(self._patch_dcap, dtype=torch.float64, device=self.device)
+        ip = C.cast(self._h_pi.data_ptr(), _lib.pi32)
+        dk = C.cast(self._h_pi.data_ptr() + 4 * 3 * ni.value, _lib.pi32)
+        check(lib.la_cache_mirror_patch(self.cache._h, ip, dk, C.cast(self._h_pd.data_ptr(), _pd)), 'mirror_patch')
+        self._d_pi[:need].copy_(self._h_pi[:need], non_blocking=True)
+        if nd.value:
+            self._d_pd[:nd.value].copy_(self._h_pd[:nd.value], non_blocking=True)
+        check(lib.la_trie_patch_dev(self._stream(), self.tok.data_ptr(), self.fo.data_ptr(), self.fi.data_ptr(), self.cap,
+                                    self.cstart.data_ptr(), self.ccount.data_ptr(), self._d_pi.data_ptr(), ni.value,
+                                    self._d_pi.data_ptr() + 4 * 3 * ni.value, self._d_pd.data_ptr(), nd.value), 'trie_patch_dev')
+        self.stats['patches'] += 1
+        self.stats['patch_words'] += ni.value + nd.value
+        return 'patch'
+
+    # ---- queries -------------------------------------------------------------------------------------------------------
+    def hier_get_dev(self, queries, idxs=None, branch_lengths=None, decoding_length=64, branch_length=8, min_input_size=0,
+                     min_output_size=0, mode='mix', sync=True):
+        """One launch for all queries; results stay on the device: out_ids int32[B][64], out_rm uint64[B][64], out_n int32[B]
+        (views of buffers reused by the next call).  queries: token lists (<= 8 tokens each); idxs: the input slot of each
+        query (default: the first mirrored slot); branch_lengths: per-query branch length (default: branch_length)."""
         assert mode in _MODES and decoding_length <= _lib.LA_TREE_MAX
         B = len(queries)
-        q = np.zeros((B, 8), np.int32); nq = np.zeros(B, np.int32)
+        self._alloc_queries(B)
+        if sync:
+            self.sync()
+        h = self._hq.numpy()
+        q = h[:B * 8].reshape(B, 8)
+        q[:] = 0
         for b, toks in enumerate(queries):
             assert len(toks) <= 8
-            q[b, :len(toks)] = toks; nq[b] = len(toks)
-        dq, dnq = torch.from_numpy(q).to(self.device), torch.from_numpy(nq).to(self.device)
-        stop = torch.tensor(self.stop_words or [0], dtype=torch.int32, device=self.device)
-        sq = torch.empty(B * self.n_nodes, dtype=torch.int32, device=self.device)
-        sv = torch.empty(B * 2 * self.n_nodes, dtype=torch.float64, device=self.device)
-        ids = torch.zeros(B * 64, dtype=torch.int32, device=self.device)
-        rm = torch.zeros(B * 64, dtype=torch.int64, device=self.device)
-        on = torch.zeros(B, dtype=torch.int32, device=self.device)
-        osz = torch.zeros(B * 2, dtype=torch.int32, device=self.device)
-        ons = torch.zeros(B, dtype=torch.int32, device=self.device)
-        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        p = lambda t: C.c_void_p(t.data_ptr())
-        check(lib.la_trie_hier_get_dev(st, p(self.tok), p(self.fo), p(self.fi), p(self.cstart), p(self.ccount), self.n_nodes,
-                                       p(dq), p(dnq), B, int(decoding_length), int(branch_length), int(min_input_size),
-                                       int(min_output_size), _MODES[mode], p(stop), len(self.stop_words), p(sq), p(sv),
-                                       p(ids), p(rm), p(on), p(osz), p(ons)), 'trie_hier_get_dev')
-        torch.cuda.synchronize(self.device)
-        ids, rm, on, osz, ons = ids.cpu().numpy().reshape(B, 64), rm.cpu().numpy().view(np.uint64).reshape(B, 64), \
-            on.cpu().numpy(), osz.cpu().numpy().reshape(B, 2), ons.cpu().numpy()
+            q[b, :len(toks)] = toks
+            h[B * 8 + b] = len(toks)
+            h[B * 9 + b] = self.plane[int(idxs[b])] if idxs is not None else 0
+            h[B * 10 + b] = int(branch_lengths[b]) if branch_lengths is not None else int(branch_length)
+        self._dq[:B * 11].copy_(self._hq[:B * 11], non_blocking=True)
+        if self._scratch is None or self._scratch[0].numel() < B * self.cap:
+            self._scratch = (torch.empty(B * self.cap, dtype=torch.int32, device=self.device),
+                             torch.empty(B * 2 * self.cap, dtype=torch.float64, device=self.device))
+        stop = getattr(self, '_stop_dev', None)
+        if stop is None or self._stop_list != self.stop_words:
+            self._stop_list = list(self.stop_words)
+            self._stop_dev = stop = torch.tensor(self.stop_words or [0], dtype=torch.int32, device=self.device)
+        base = self._dq.data_ptr()
+        check(lib.la_trie_hier_get_dev2(self._stream(), self.tok.data_ptr(), self.fo.data_ptr(), self.fi.data_ptr(), self.cap,
+                                        self.cstart.data_ptr(), self.ccount.data_ptr(), self.cap, base, base + 4 * B * 8,
+                                        base + 4 * B * 9, base + 4 * B * 10, B, int(decoding_length), int(branch_length),
+                                        int(min_input_size), int(min_output_size), _MODES[mode], stop.data_ptr(),
+                                        len(self.stop_words), self._scratch[0].data_ptr(), self._scratch[1].data_ptr(),
+                                        self.out_ids.data_ptr(), self.out_rm.data_ptr(), self.out_n.data_ptr(),
+                                        self.out_sizes.data_ptr(), self.out_nsizes.data_ptr()), 'trie_hier_get_dev2')
+        return B
+
+    def hier_get(self, queries, decoding_length=64, branch_length=8, min_input_size=0, min_output_size=0, mode='mix', idxs=None,
+                 branch_lengths=None):
+        """-> list of (ids list, uint64 row masks, sizes list), like LookaheadCache.hier_get per query."""
+        B = self.hier_get_dev(queries, idxs=idxs, branch_lengths=branch_lengths, decoding_length=decoding_length,
+                              branch_length=branch_length, min_input_size=min_input_size, min_output_size=min_output_size, mode=mode)
+        torch.cuda.current_stream(self.device).synchronize()
+        ids = self.out_ids[:B * 64].cpu().numpy().reshape(B, 64)
+        rm = self.out_rm[:B * 64].cpu().numpy().view(np.uint64).reshape(B, 64)
+        on = self.out_n[:B].cpu().numpy()
+        osz = self.out_sizes[:B * 2].cpu().numpy().reshape(B, 2)
+        ons = self.out_nsizes[:B].cpu().numpy()
         return [(ids[b, :on[b]].tolist(), rm[b, :on[b]].copy(), osz[b, :ons[b]].tolist()) for b in range(B)]

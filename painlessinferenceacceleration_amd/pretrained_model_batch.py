@@ -51,12 +51,31 @@ class LookaheadPreTrainedModel(object):
             sub = max(decoding_length // len(qids), 1)                 # pretrained_model_batch.py:713
             sub = min(sub, _lib.LA_TREE_MAX * len(qids))               # a sample's tree never exceeds the 64 rows of a block
         ts = time.time()
-        drafts = self.lookahead_cache.bat_get_packed(qids, decoding_length=sub, branch_length=branch_length, mode=mode,
-                                                     indices=batch_indices, decoding_mode=fmt)
+        if decoding_kwargs.get('device_trie', False) and fmt == 'hier':
+            # the drafts of ALL active samples from one launch over the incremental device mirror of the trie (one wavefront per
+            # sample, its own input-frequency plane): no host trie query on the step's critical path.  Same budget rule as
+            # bat_get (lookahead_cache.py:534-541): per sample sub // bs rows, min_output_size = max(per // 2, 1).
+            per = sub // len(qids)
+            got = self._device_trie(decoding_kwargs['_n_samples']).hier_get(
+                qids, idxs=batch_indices, decoding_length=per, branch_length=branch_length, min_input_size=0,
+                min_output_size=max(per // 2, 1), mode=mode)
+            drafts = [(np.asarray(g[0], dtype=np.int32), np.asarray(g[1], dtype=np.uint64), g[2]) for g in got]
+        else:
+            drafts = self.lookahead_cache.bat_get_packed(qids, decoding_length=sub, branch_length=branch_length, mode=mode,
+                                                         indices=batch_indices, decoding_mode=fmt)
         decoding_kwargs['qts'].append(time.time() - ts)
         decoding_kwargs.update({'decoding_qids': qids, 'decoding_ids': [d[0] for d in drafts],
                                 'hit_sizes': [d[2] for d in drafts], 'batch_indices': batch_indices})
         return [(d[0], d[1]) for d in drafts]
+
+    def _device_trie(self, n_samples):
+        """DeviceTrie over self.lookahead_cache with one input-frequency plane per batch index (rebuilt when the cache object or
+        the batch size changes)."""
+        from .device_trie import DeviceTrie
+        dt = getattr(self, '_dev_trie', None)
+        if dt is None or dt.cache is not self.lookahead_cache or len(dt.idxs) < n_samples:
+            dt = self._dev_trie = DeviceTrie(self.lookahead_cache, idxs=list(range(n_samples)), device=self.engine.device)
+        return dt
 
     @torch.no_grad()
     def lookahead_generation(self, *args, **kwargs):
@@ -94,6 +113,7 @@ class LookaheadPreTrainedModel(object):
         self.lookahead_cache.stop_words = decoding_kwargs.get('stop_words', {})
         pad = pad_token_id if pad_token_id is not None else 2
         decoding_kwargs.update({'pad': pad, 'edls': [], 'dls': [], 'fts': [], 'qts': []})
+        decoding_kwargs['_n_samples'] = int(input_ids.shape[0])
         stop_max_length = _max_length_of(stopping_criteria, max_length)
         if stop_max_length is None:
             raise ValueError('lookahead_generation needs a MaxLengthCriteria (stopping_criteria.max_length)')

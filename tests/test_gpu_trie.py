@@ -85,3 +85,80 @@ def test_device_hier_get_batched_matches_host_on_large_forest():
             assert g[2] == sizes, (mode, qy)
             big += len(g[0]) == 64
     assert big > 20        # the budget cap (and with it the cut-off rule) was exercised
+
+
+@pytest.mark.parametrize('path', tr.trace_files(), ids=os.path.basename)
+def test_incremental_device_mirror_replays_reference_trace_with_interleaved_updates(path):
+    """ONE DeviceTrie for the whole trace: every put / stream_put / reset between the recorded hier_get calls reaches the device
+    as a patch (la_cache_mirror_patch + k_trie_patch), squeeze / fresh as a new image; every recorded hier_get (all idx slots of
+    the trace mirrored as fi planes) is answered by the device kernel and must equal the reference's output."""
+    trace = tr.load(path)
+    init = trace['init']
+    cache = LookaheadCache(eos_ids=init['eos_ids'], stop_words={w: 1 for w in init['stop_words']},
+                           max_node=init['max_node'], max_output_node=init['max_output_node'])
+    idxs = sorted({op['idx'] for op in trace['ops'] if op['op'] == 'hier_get' and op['idx'] >= 0}) or [0]
+    dev = DeviceTrie(cache, idxs=idxs)
+    checked = 0
+    for i, op in enumerate(trace['ops']):
+        name = op['op']
+        if name == 'put':
+            cache.put(list(op['tokens']), branch_length=op['branch_length'], final=op['final'], mode=op['mode'], idx=op['idx'])
+        elif name == 'stream_put':
+            cache.stream_put(list(op['tokens']), branch_length=op['branch_length'], final=op['final'], idx=op['idx'])
+        elif name == 'hier_get':
+            if op['decoding_length'] > 64 or op['idx'] < 0 or len(op['tokens']) > 8:
+                continue
+            got = dev.hier_get([list(op['tokens'])], idxs=[op['idx']], decoding_length=op['decoding_length'],
+                               branch_length=op['branch_length'], min_input_size=op['min_input_size'],
+                               min_output_size=op['min_output_size'], mode=op['mode'])[0]
+            exp = op['out']
+            ctx = f"op {i}: { {k: v for k, v in op.items() if k != 'out'} }"
+            assert got[0] == exp['ids'], ctx
+            assert _rows(got[1]) == exp['rows'][:len(exp['ids'])], ctx
+            assert got[2] == exp['sizes'], ctx
+            checked += 1
+        elif name == 'reset_input_freqs':
+            cache.reset_input_freqs(op['idx'])
+        elif name == 'squeeze_branch_counts':
+            cache.squeeze_branch_counts()
+        elif name == 'fresh':
+            cache.fresh()
+        elif name == 'limits':
+            cache.max_node, cache.max_output_node = op['max_node'], op['max_output_node']
+    assert checked >= 20 and dev.stats['patches'] >= 5, dev.stats
+    print(os.path.basename(path), 'queries', checked, dev.stats)
+
+
+def test_batch_loop_with_device_trie_equals_host_trie_loop():
+    """pretrained_model_batch.lookahead_generation with decoding_kwargs['device_trie']: the drafts of all samples come from one
+    device launch per step over the incremental mirror; sequences, dls and edls must equal the host-trie loop's, request after
+    request (the second request runs on the trie the first one grew)."""
+    import torch
+    from painlessinferenceacceleration_amd.modeling_llama_batch import LlamaForCausalLM as BatchLlama
+    from tests.tiny_model import noisy_copies, tiny_decisive_weights, tiny_shape
+    shape = tiny_shape()
+    sd = tiny_decisive_weights(0, torch.bfloat16)
+    rs = np.random.RandomState(2)
+    B, P = 4, 24
+    prompts = rs.randint(3, shape.vocab, size=(B, P))
+    outs = []
+    for use_dev in (False, True):
+        model = BatchLlama(shape, dict(sd), max_length=256, max_batch=B, eos_token_id=2)
+        truth = model.greedy_search(torch.from_numpy(prompts), P + 100, eos_token_id=None)[:, P:].tolist()
+        model.lookahead_cache = LookaheadCache(eos_ids=[2])
+        for b in range(B):
+            for c in noisy_copies(prompts[b, -2:].tolist() + truth[b], 6, 0.3, shape.vocab, seed=50 + b):
+                model.lookahead_cache.put(c, branch_length=13, mode='output', idx=-1)
+        runs = []
+        for req in range(2):
+            dk = {'use_lookahead': True, 'decoding_mode': 'hier', 'decoding_length': 64, 'branch_length': 12,
+                  'per_sample_budget': True, 'device_trie': use_dev}
+            out = model.lookahead_generation(torch.from_numpy(prompts), stopping_criteria=P + 90, eos_token_id=2, pad_token_id=0,
+                                             return_dict_in_generate=True, decoding_kwargs=dk)
+            runs.append((out.sequences.tolist(), out.kwargs['dls'], out.kwargs['edls']))
+            assert [s[P:P + 60] for s in out.sequences.tolist()] == [t[:60] for t in truth]       # lossless
+        if use_dev:
+            assert model._dev_trie.stats['patches'] > 10
+        outs.append(runs)
+    assert outs[0] == outs[1]
+    assert max(outs[0][0][1]) > 16          # per-sample budget: trees larger than the reference's (64 // 4) // 4 rows

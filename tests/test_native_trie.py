@@ -270,3 +270,102 @@ def test_in_place_mutation_of_stop_words_and_eos_is_seen_like_the_reference():
         assert [int(x) for x in a[0]] == [int(x) for x in b[0]] and tr.rows_of(a[1]) == tr.rows_of(b[1]) \
             and list(a[2]) == list(b[2]), q
     assert native.stats()['n_nodes'] == oracle.n_nodes()
+
+
+def _mirror_sync_host(cache, img):
+    """Apply la_cache_mirror_image / la_cache_mirror_patch to numpy arrays standing in for the device image (the GPU applies the
+    same patch with k_trie_patch)."""
+    import ctypes as C
+    from painlessinferenceacceleration_amd import _lib
+    from painlessinferenceacceleration_amd._lib import check, lib
+    pd = C.POINTER(C.c_double)
+    n, full, ni, nd = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    check(lib.la_cache_mirror_state(cache._h, C.byref(n), C.byref(full), C.byref(ni), C.byref(nd)))
+    if full.value or n.value > img['cap']:
+        cap = img['cap'] = max(2 * n.value, 64)
+        P = img['planes']
+        img['tok'], img['cstart'], img['ccount'] = (np.zeros(cap, np.int32) for _ in range(3))
+        img['fo'], img['fi'] = np.zeros(cap, np.float64), np.zeros(P * cap, np.float64)
+        check(lib.la_cache_mirror_image(cache._h, cap, img['tok'].ctypes.data_as(_lib.pi32), img['fo'].ctypes.data_as(pd),
+                                        img['fi'].ctypes.data_as(pd), img['cstart'].ctypes.data_as(_lib.pi32),
+                                        img['ccount'].ctypes.data_as(_lib.pi32)))
+        img['n'] = n.value
+        return 'full'
+    ip, dk, dv = np.zeros(3 * ni.value + 1, np.int32), np.zeros(2 * nd.value + 1, np.int32), np.zeros(nd.value + 1, np.float64)
+    check(lib.la_cache_mirror_patch(cache._h, ip.ctypes.data_as(_lib.pi32), dk.ctypes.data_as(_lib.pi32), dv.ctypes.data_as(pd)))
+    arrs = [img['tok'], img['cstart'], img['ccount']]
+    seen = set()
+    for k in range(ni.value):
+        a, r, v = ip[3 * k:3 * k + 3]
+        assert (int(a), int(r)) not in seen
+        seen.add((int(a), int(r)))
+        arrs[a][r] = v
+    for k in range(nd.value):
+        pl, r = dk[2 * k:2 * k + 2]
+        if pl == 0:
+            img['fo'][r] = dv[k]
+        else:
+            img['fi'][(pl - 1) * img['cap'] + r] = dv[k]
+    img['n'] = n.value
+    return 'patch'
+
+
+def _walk(tok, fo, fi, cstart, ccount):
+    """canonical form of a forest in the device layout: nested (token, fo, fi, children...) with tree roots sorted by token"""
+    def rec(u):
+        kids = [rec(cstart[u] + k) for k in range(ccount[u])]
+        return (int(tok[u]), float(fo[u]), float(fi[u]), kids)
+    roots = [rec(cstart[0] + k) for k in range(ccount[0])]
+    return sorted(roots, key=lambda r: r[0])
+
+
+def test_incremental_mirror_equals_a_fresh_export_after_every_update():
+    """The incremental device mirror (patches of changed words; child blocks that grow at the arena end) must describe the same
+    forest as a fresh la_cache_export after every put / stream_put / reset_input_freqs, for every mirrored input slot; squeeze and
+    fresh fall back to a full image."""
+    import ctypes as C
+    import sys
+    from painlessinferenceacceleration_amd import _lib
+    from painlessinferenceacceleration_amd._lib import check, lib
+    sys.setrecursionlimit(10000)
+    pd = C.POINTER(C.c_double)
+    rs = random.Random(17)
+    cache = LookaheadCache(eos_ids=[2], max_node=64, max_output_node=32)
+    planes = [0, 1, 2]
+    arr = np.asarray(planes, dtype=np.int32)
+    check(lib.la_cache_mirror_enable(cache._h, arr.ctypes.data_as(_lib.pi32), len(planes)))
+    img = {'cap': 0, 'planes': len(planes), 'n': 0}
+    kinds = {'full': 0, 'patch': 0}
+    phrases = [[rs.randrange(3, 30) for _ in range(rs.randint(3, 9))] for _ in range(12)]
+
+    def snapshot(idx):
+        n = C.c_int32()
+        check(lib.la_cache_export(cache._h, idx, 0, None, None, None, None, None, C.byref(n)))
+        cap = n.value
+        t, c1, c2 = (np.zeros(cap, np.int32) for _ in range(3))
+        f1, f2 = np.zeros(cap, np.float64), np.zeros(cap, np.float64)
+        check(lib.la_cache_export(cache._h, idx, cap, t.ctypes.data_as(_lib.pi32), f1.ctypes.data_as(pd), f2.ctypes.data_as(pd),
+                                  c1.ctypes.data_as(_lib.pi32), c2.ctypes.data_as(_lib.pi32), C.byref(n)))
+        return _walk(t, f1, f2, c1, c2)
+
+    for step in range(400):
+        r = rs.random()
+        seq = sum((phrases[rs.randrange(12)] for _ in range(rs.randint(1, 4))), [])
+        if r < 0.35:
+            cache.put(seq, branch_length=rs.choice([4, 9, 13]), mode='output', idx=-1)
+        elif r < 0.55:
+            cache.put(seq, branch_length=9, mode='input', idx=rs.choice(planes + [7]))       # slot 7 is not mirrored
+        elif r < 0.9:
+            cache.stream_put(seq[:rs.randint(1, 13)], branch_length=9, final=rs.random() < 0.1, idx=rs.choice(planes))
+        elif r < 0.96:
+            cache.reset_input_freqs(rs.choice(planes))
+        elif r < 0.98:
+            cache.squeeze_branch_counts()
+        else:
+            cache.fresh()
+        if step % 3 == 0 or r >= 0.9:
+            kinds[_mirror_sync_host(cache, img)] += 1
+            for p, idx in enumerate(planes):
+                got = _walk(img['tok'], img['fo'], img['fi'][p * img['cap']:(p + 1) * img['cap']], img['cstart'], img['ccount'])
+                assert got == snapshot(idx), (step, idx)
+    assert kinds['patch'] > 80 and kinds['full'] >= 1, kinds
