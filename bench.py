@@ -142,8 +142,8 @@ def main():
     ap.add_argument('--pure-random', action='store_true', help='plain N(0,0.02) init (greedy/lookahead drift apart in bf16)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-steps', type=int, default=5, help='verify steps of the CPU baseline loop')
-    ap.add_argument('--model', choices=['7b', '13b', 'mistral'], default='7b',
-                    help='7b = the BASELINE metric; 13b / mistral = the config-4 / config-3 model shapes')
+    ap.add_argument('--model', choices=['7b', '13b', 'mistral', 'mixtral'], default='7b',
+                    help='7b = the BASELINE metric; 13b / mistral / mixtral = the config-4 / config-3 / config-5 model shapes')
     ap.add_argument('--batch', type=int, default=1, help='sequences per GPU; > 1: each gets its own 64-token tree per step (la_llama_mstep)')
     ap.add_argument('--device-trie', action='store_true', help='--batch > 1: drafts of all sequences from ONE device launch over the incremental trie mirror')
     ap.add_argument('--strict-gather', action='store_true', help='N > 1: blocking all-gather (reference trie order at query time)')
@@ -178,8 +178,9 @@ def main():
     from painlessinferenceacceleration_amd.modeling_llama import LlamaForCausalLM
     from painlessinferenceacceleration_amd.modeling_llama_batch import LlamaForCausalLM as BatchLlama
 
-    shape = {'7b': LlamaShape.llama2_7b, '13b': LlamaShape.llama2_13b, 'mistral': LlamaShape.mistral_7b}[args.model]()
-    model_name = {'7b': 'Llama-2-7B', '13b': 'Llama-2-13B', 'mistral': 'Mistral-7B'}[args.model]
+    shape = {'7b': LlamaShape.llama2_7b, '13b': LlamaShape.llama2_13b, 'mistral': LlamaShape.mistral_7b,
+             'mixtral': LlamaShape.mixtral_8x7b}[args.model]()
+    model_name = {'7b': 'Llama-2-7B', '13b': 'Llama-2-13B', 'mistral': 'Mistral-7B', 'mixtral': 'Mixtral-8x7B'}[args.model]
     if args.layers:
         shape.n_layers = args.layers
     K, W, P, B = args.steps, args.warmup, args.prompt_len, args.batch
@@ -424,7 +425,8 @@ def main():
         # per-kernel durations of the same step: profiles/r02_mblock_kernel_stats_*.txt (rocprofv3 --kernel-trace --stats)
         kv_tok = 2 * shape.n_layers * shape.n_kv_heads * shape.head_dim * 2
         step_bytes = W_bytes + kv_tok * ctx * B + kv_tok * 64 * B + 64 * B * (shape.hidden * 2 + 8) + 64 * B * shape.vocab * 2
-        step_flops = 2.0 * shape.n_params_no_embed() * 64 * B + 4.0 * shape.n_layers * shape.n_heads * shape.head_dim * 64 * B * (ctx + 64)
+        active = shape.n_params_no_embed() - (shape.n_layers * 3 * shape.ffn * shape.hidden * max(shape.n_experts - shape.top_k, 0) if shape.n_experts else 0)
+        step_flops = 2.0 * active * 64 * B + 4.0 * shape.n_layers * shape.n_heads * shape.head_dim * 64 * B * (ctx + 64)      # MoE: the top-k experts of a row
         hbm_frac = step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS
         mfma_frac = step_flops / (ms_step * 1e-3) / 1e12 / 2500.0
         bound = 'mfma' if mfma_frac >= hbm_frac else 'hbm'

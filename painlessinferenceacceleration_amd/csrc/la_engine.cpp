@@ -50,6 +50,8 @@ struct la_llama {
     uint16_t *mb_h, *mb_xp, *mb_attn_xp, *mb_act, *mb_logits, *mb_qf, *mb_kfresh, *mb_vfresh;
     float *mb_slabs, *mb_opart, *mb_mpart, *mb_lpart, *mb_cand_val;
     int *mb_cand_idx, *mb_meta, *mb_pos, *mb_ids, *mb_in, *mb_out;
+    uint16_t *mb_moe_acc, *mb_act_ex;     // MoE: accumulated expert outputs [M][hidden], per-expert SwiGLU outputs [E][M x ffn]
+    float *mb_route_w, *mb_slabs_ex;      // routing weights [M][LA_MOE_MAX_E], per-expert down-projection slabs [E][ks][M][hidden]
     uint64_t* mb_rowmask;
     size_t mb_fresh_layer;
     hipGraphExec_t mgraphs[LA_MB_MAX + 1];
@@ -176,6 +178,11 @@ static size_t carve(la_llama* m, char* base) {
         m->mb_rowmask = cv.take<uint64_t>(R);
         m->mb_in = cv.take<int>(LA_MIN_WORDS);
         m->mb_out = cv.take<int>(LA_MOUT_WORDS);
+        const size_t E = (size_t)c.n_experts;
+        m->mb_moe_acc = cv.take<uint16_t>(E ? R * c.hidden : 8);
+        m->mb_act_ex = cv.take<uint16_t>(E ? E * R * c.ffn : 8);
+        m->mb_route_w = cv.take<float>(E ? R * LA_MOE_MAX_E : 8);
+        m->mb_slabs_ex = cv.take<float>(E ? E * m->down_ks * R * c.hidden : 8);
     }
     return align_up(cv.off, 256);
 }
@@ -485,7 +492,6 @@ static int mb_split(int nblk) { return nblk > 4 ? 1 : nblk > 2 ? 2 : nblk == 2 ?
 
 static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk) {
     const la_llama_config& c = m->cfg;
-    if (c.n_experts > 0) { la_set_error("mstep: the sparse-MoE MLP runs on the 64-row path only"); return LA_E_ARG; }
     if (!m->qkv_fused) { la_set_error("mstep needs the fused QKV image (gemm_cfg[1] >= 0)"); return LA_E_ARG; }
     const int M = nblk * 64;
     const int npass_rows = (nblk <= 2 ? nblk : ((nblk + 3) / 4) * 4) * 64;     // rows whole passes write (slab stride)
@@ -506,6 +512,27 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk) {
         MbGemm o{}; o.wp = L.wo; o.xp = m->mb_attn_xp; o.N = c.hidden; o.K = m->o_k; o.nblk = nblk; o.ksplit = m->o_ks;
         o.slabs = m->mb_slabs; o.slab_rows = npass_rows;
         KCHK(lk_mb_gemm(st, 0, o));
+        const void* nw = (l + 1 < c.n_layers) ? m->layers[l + 1].norm1 : m->w.final_norm;
+        if (c.n_experts > 0) {
+            // sparse MoE MLP over M rows: router fused into the norm; per expert {gate/up + SwiGLU, down} over ALL rows (an expert no
+            // row routes to returns at once and its weights are never read), then the weighted accumulation in expert order
+            KCHK(lk_mb_resid_norm_router(st, m->mb_h, m->mb_slabs, m->o_ks, npass_rows, L.norm2, c.hidden, c.rms_eps, m->mb_xp, M, cf,
+                                         L.router, c.n_experts, c.top_k, m->mb_route_w, m->mb_meta));
+            const size_t act_stride = (size_t)LA_MB_MAX * 64 * c.ffn, slab_stride = (size_t)m->down_ks * npass_rows * c.hidden;
+            for (int e = 0; e < c.n_experts; ++e) {
+                MbGemm g{}; g.wp = m->ex_gateup[(size_t)l * c.n_experts + e]; g.xp = m->mb_xp; g.N = c.ffn; g.K = c.hidden; g.nblk = nblk;
+                g.n_wg = c.balanced_wg[1]; g.ksplit = 1; g.act_xp = m->mb_act_ex + e * act_stride; g.route_col = m->mb_route_w + e;
+                KCHK(lk_mb_gemm(st, 1, g));
+                MbGemm d{}; d.wp = m->ex_down[(size_t)l * c.n_experts + e]; d.xp = m->mb_act_ex + e * act_stride; d.N = c.hidden; d.K = c.ffn;
+                d.nblk = nblk; d.ksplit = m->down_ks; d.slabs = m->mb_slabs_ex + e * slab_stride; d.slab_rows = npass_rows;
+                d.route_col = m->mb_route_w + e;
+                KCHK(lk_mb_gemm(st, 0, d));
+            }
+            KCHK(lk_mb_moe_accum(st, m->mb_slabs_ex, (long)slab_stride, m->down_ks, npass_rows, m->mb_route_w, c.n_experts, c.hidden,
+                                 m->mb_moe_acc, M));
+            KCHK(lk_mb_resid_norm_addend(st, m->mb_h, m->mb_moe_acc, nw, c.hidden, c.rms_eps, m->mb_xp, M, cf));
+            continue;
+        }
         KCHK(lk_mb_resid_norm(st, m->mb_h, m->mb_slabs, m->o_ks, npass_rows, L.norm2, c.hidden, c.rms_eps, m->mb_xp, M, cf));
         MbGemm g{}; g.wp = L.wgateup; g.xp = m->mb_xp; g.N = c.ffn; g.K = c.hidden; g.nblk = nblk; g.n_wg = c.balanced_wg[1]; g.ksplit = 1;
         g.act_xp = m->mb_act;
@@ -513,7 +540,6 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk) {
         MbGemm d{}; d.wp = L.wdown; d.xp = m->mb_act; d.N = c.hidden; d.K = c.ffn; d.nblk = nblk; d.ksplit = m->down_ks;
         d.slabs = m->mb_slabs; d.slab_rows = npass_rows;
         KCHK(lk_mb_gemm(st, 0, d));
-        const void* nw = (l + 1 < c.n_layers) ? m->layers[l + 1].norm1 : m->w.final_norm;
         KCHK(lk_mb_resid_norm(st, m->mb_h, m->mb_slabs, m->down_ks, npass_rows, nw, c.hidden, c.rms_eps, m->mb_xp, M, cf));
     }
     const int lwg = lk_mb_logits_wgs(c.vocab, c.balanced_wg[2]);
@@ -718,6 +744,7 @@ extern "C" void* la_llama_buffer(la_llama* m, int which) {
         case 11: return m->mb_max ? m->mb_logits : nullptr;
         case 12: return m->mb_max ? m->mb_out : nullptr;
         case 13: return m->mb_max ? m->mb_h : nullptr;
+        case 14: return m->mb_max ? m->mb_route_w : nullptr;
         default: return nullptr;
     }
 }

@@ -35,8 +35,14 @@ struct MbGemm {
     void* act_xp;
     void* logits; float* cand_val; int* cand_idx;
     const int* pos; const void* rcos; const void* rsin; void* qf; void* kfresh; void* vfresh; int nh, nkv;
+    const float* route_col;            // MoE: this expert's routing weights (stride LA_MOE_MAX_E floats per row); null = dense
 };
 int lk_mb_gemm(hipStream_t st, int kind, const MbGemm& g);
+int lk_mb_resid_norm_router(hipStream_t st, void* h, const float* slabs, int n_slabs, int slab_rows, const void* nw, int hidden, float eps,
+                            void* xp, int M, int cast_first, const void* wrouter, int n_experts, int top_k, float* route_w, const int* meta);
+int lk_mb_resid_norm_addend(hipStream_t st, void* h, const void* addend, const void* nw, int hidden, float eps, void* xp, int M, int cast_first);
+int lk_mb_moe_accum(hipStream_t st, const float* slabs0, long slab_stride, int n_slabs, int slab_rows, const float* route_w, int E, int hidden,
+                    void* acc, int M);
 int lk_mb_cand_slots(int n_wg);
 int lk_mb_logits_wgs(int V, int n_wg);
 int lk_mb_argmax(hipStream_t st, const float* cv, const int* ci, int n_tiles, int nblk, int* out_rows);

@@ -33,6 +33,9 @@ struct MbArgs {
     int* cand_idx;
     const int* pos; const bf16_t* rcos; const bf16_t* rsin;      // MB_QKV
     bf16_t* qf; bf16_t* kfresh; bf16_t* vfresh; int nh, nkv;
+    // mixture-of-experts: routing weights of THIS expert, one float per row at stride LA_MOE_MAX_E; when no row of the step routes
+    // to the expert the launch returns at once and its weights are never read
+    const float* route_col; int route_rows;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -53,6 +56,11 @@ __global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     bf16x8* xs = (bf16x8*)lds_raw;              // [2 stages][FR][64 lanes]
     const int lane = threadIdx.x & 63;
+    if (a.route_col) {                          // every wave scans all rows: a uniform decision without a barrier
+        bool any = false;
+        for (int t = lane; t < a.route_rows; t += 64) any |= a.route_col[(size_t)t * LA_MOE_MAX_E] != 0.f;
+        if (__ballot(any) == 0ull) return;
+    }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rb = wave % RBV, kp = wave / RBV;
     const int blk0 = blockIdx.z * (NT / 2);
@@ -368,6 +376,232 @@ __global__ __launch_bounds__(512) void k_row_norm_mb(const bf16_t* __restrict__ 
             }
             *(bf16x8*)(xo_base + xp_offset(t & 63, c * 8)) = xo;
         }
+    }
+}
+
+// Post-attention norm of a Mixtral layer over M rows: residual + split-K slabs + RMSNorm, then the router
+// (MixtralSparseMoeBlock.forward, mixtral/modeling_mixtral.py:723-729: logits = gate(x) in the activation dtype, softmax in fp32,
+// top-k, renormalise, cast back) -> route_w[t][e] = weight of expert e for row t, 0 if not routed (rows >= the block's T: 0).
+// Same arithmetic, summation order and rounding points as k_row_norm<NS, true> of the 64-row path.
+template <int NS>
+__global__ __launch_bounds__(512) void k_row_norm_router_mb(bf16_t* __restrict__ h, const float* __restrict__ slabs, const bf16_t* __restrict__ nw,
+                                                             int hidden, float eps, bf16_t* __restrict__ xp, int slab_rows, int cast_first,
+                                                             const bf16_t* __restrict__ wrouter, int n_experts, int top_k,
+                                                             float* __restrict__ route_w, const int* __restrict__ meta) {
+    __shared__ float sh[8];
+    __shared__ float shr[8][LA_MOE_MAX_E];
+    const int t = blockIdx.x;
+    const int nchunk = hidden >> 3;
+    bf16x8 hv[2], wv[2];
+    bf16x8 gwv[LA_MOE_MAX_E][2];
+    f32x4 sl[NS][2][2];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 512;
+        if (c < nchunk) {
+            hv[ci] = *(const bf16x8*)(h + (size_t)t * hidden + c * 8);
+            wv[ci] = *(const bf16x8*)(nw + c * 8);
+#pragma unroll
+            for (int e = 0; e < LA_MOE_MAX_E; ++e)
+                if (e < n_experts) gwv[e][ci] = *(const bf16x8*)(wrouter + (size_t)e * hidden + c * 8);
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) {
+                const float* sp = slabs + ((size_t)s2 * slab_rows + t) * hidden + c * 8;
+                sl[s2][ci][0] = *(const f32x4*)sp;
+                sl[s2][ci][1] = *(const f32x4*)(sp + 4);
+            }
+        }
+    }
+    float vals[2][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 512;
+        if (c < nchunk) {
+            bf16x8 ho;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = bf2f((bf16_t)hv[ci][j]);
+                float add = 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < NS; ++s2) add += sl[s2][ci][j >> 2][j & 3];
+                v = bfr(v + bfr(add));
+                vals[ci][j] = v;
+                ho[j] = (short)f2bf(v);
+                ss += v * v;
+            }
+            *(bf16x8*)(h + (size_t)t * hidden + c * 8) = ho;
+        }
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tot += sh[i];
+    const float rs = 1.0f / sqrtf(tot / (float)hidden + eps);
+    float rl[LA_MOE_MAX_E];
+#pragma unroll
+    for (int e = 0; e < LA_MOE_MAX_E; ++e) rl[e] = 0.f;
+    bf16_t* xo_base = xp + (size_t)(t >> 6) * 64 * hidden;
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 512;
+        if (c < nchunk) {
+            bf16x8 xo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float nv = cast_first ? bfr(vals[ci][j] * rs) : vals[ci][j] * rs;
+                xo[j] = (short)f2bf(bf2f((bf16_t)wv[ci][j]) * nv);
+            }
+            *(bf16x8*)(xo_base + xp_offset(t & 63, c * 8)) = xo;
+#pragma unroll
+            for (int e = 0; e < LA_MOE_MAX_E; ++e) {
+                if (e < n_experts) {
+                    const bf16x8 gw = gwv[e][ci];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) rl[e] += bf2f((bf16_t)xo[j]) * bf2f((bf16_t)gw[j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < LA_MOE_MAX_E; ++e) rl[e] = wave_sum(rl[e]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int e = 0; e < LA_MOE_MAX_E; ++e) shr[threadIdx.x >> 6][e] = rl[e];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float lg[LA_MOE_MAX_E], pr[LA_MOE_MAX_E], outw[LA_MOE_MAX_E];
+        float mx = -INFINITY;
+        for (int e = 0; e < n_experts; ++e) {
+            float v = 0.f;
+            for (int w = 0; w < 8; ++w) v += shr[w][e];
+            lg[e] = bfr(v);
+            mx = fmaxf(mx, lg[e]);
+        }
+        float den = 0.f;
+        for (int e = 0; e < n_experts; ++e) { pr[e] = expf(lg[e] - mx); den += pr[e]; }
+        for (int e = 0; e < n_experts; ++e) { pr[e] = pr[e] / den; outw[e] = 0.f; }
+        unsigned taken = 0u;
+        float ksum = 0.f;
+        int pick[LA_MOE_MAX_E];
+        for (int k = 0; k < top_k; ++k) {
+            int best = -1;
+            for (int e = 0; e < n_experts; ++e)
+                if (!((taken >> e) & 1u) && (best < 0 || pr[e] > pr[best])) best = e;
+            taken |= 1u << best;
+            pick[k] = best;
+            ksum += pr[best];
+        }
+        const bool live = (t & 63) < meta[(t >> 6) * LA_MB_META + LA_MBM_T];
+        for (int k = 0; k < top_k; ++k) outw[pick[k]] = live ? bfr(pr[pick[k]] / ksum) : 0.f;
+        for (int e = 0; e < LA_MOE_MAX_E; ++e) route_w[(size_t)t * LA_MOE_MAX_E + e] = e < n_experts ? outw[e] : 0.f;
+    }
+}
+
+// residual + accumulated expert outputs (bf16 + bf16) + next RMSNorm over M rows (k_row_norm<0> with an addend)
+__global__ __launch_bounds__(512) void k_row_norm_addend_mb(bf16_t* __restrict__ h, const bf16_t* __restrict__ addend,
+                                                             const bf16_t* __restrict__ nw, int hidden, float eps,
+                                                             bf16_t* __restrict__ xp, int cast_first) {
+    __shared__ float sh[8];
+    const int t = blockIdx.x;
+    const int nchunk = hidden >> 3;
+    bf16x8 hv[2], wv[2], av[2];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 512;
+        if (c < nchunk) {
+            hv[ci] = *(const bf16x8*)(h + (size_t)t * hidden + c * 8);
+            wv[ci] = *(const bf16x8*)(nw + c * 8);
+            av[ci] = *(const bf16x8*)(addend + (size_t)t * hidden + c * 8);
+        }
+    }
+    float vals[2][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 512;
+        if (c < nchunk) {
+            bf16x8 ho;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = bfr(bf2f((bf16_t)hv[ci][j]) + bf2f((bf16_t)av[ci][j]));
+                vals[ci][j] = v;
+                ho[j] = (short)f2bf(v);
+                ss += v * v;
+            }
+            *(bf16x8*)(h + (size_t)t * hidden + c * 8) = ho;
+        }
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tot += sh[i];
+    const float rs = 1.0f / sqrtf(tot / (float)hidden + eps);
+    bf16_t* xo_base = xp + (size_t)(t >> 6) * 64 * hidden;
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 512;
+        if (c < nchunk) {
+            bf16x8 xo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float nv = cast_first ? bfr(vals[ci][j] * rs) : vals[ci][j] * rs;
+                xo[j] = (short)f2bf(bf2f((bf16_t)wv[ci][j]) * nv);
+            }
+            *(bf16x8*)(xo_base + xp_offset(t & 63, c * 8)) = xo;
+        }
+    }
+}
+
+// MoE accumulation over M rows (MixtralSparseMoeBlock.forward :731-756): final[t] = sum over the experts row t is routed to, in
+// expert-index order, of bf16(bf16(expert_out[t]) * w[t][e]) (index_add_ into a bf16 buffer).  Same arithmetic as k_moe_accum_all.
+template <int NS>
+__global__ __launch_bounds__(256) void k_moe_accum_mb(const float* __restrict__ slabs, long ex_slab, int slab_rows,
+                                                       const float* __restrict__ route_w, int n_experts, int hidden,
+                                                       bf16_t* __restrict__ acc) {
+    const int t = blockIdx.x;
+    int sel[4];
+    float wsel[4];
+    int ns = 0;
+    for (int e = 0; e < n_experts && ns < 4; ++e) {
+        const float w = route_w[(size_t)t * LA_MOE_MAX_E + e];
+        if (w != 0.f) { sel[ns] = e; wsel[ns] = w; ++ns; }
+    }
+    for (int k = ns; k < 4; ++k) { sel[k] = 0; wsel[k] = 0.f; }
+    for (int c = threadIdx.x; c < (hidden >> 3); c += 256) {
+        f32x4 v[4][NS][2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < ns) {
+#pragma unroll
+                for (int s2 = 0; s2 < NS; ++s2) {
+                    const float* sp = slabs + (size_t)sel[k] * ex_slab + ((size_t)s2 * slab_rows + t) * hidden + c * 8;
+                    v[k][s2][0] = *(const f32x4*)sp;
+                    v[k][s2][1] = *(const f32x4*)(sp + 4);
+                }
+            }
+        float cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < ns) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float add = 0.f;
+#pragma unroll
+                    for (int s2 = 0; s2 < NS; ++s2) add += v[k][s2][j >> 2][j & 3];
+                    const float contrib = bfr(bfr(add) * wsel[k]);
+                    cur[j] = k ? bfr(cur[j] + contrib) : contrib;
+                }
+            }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (short)f2bf(cur[j]);
+        *(bf16x8*)(acc + (size_t)t * hidden + c * 8) = o;
     }
 }
 
@@ -773,6 +1007,35 @@ int lk_mb_resid_norm(hipStream_t st, void* h, const float* slabs, int n_slabs, i
     LAUNCH_CHECK(); return 0;
 }
 
+int lk_mb_resid_norm_router(hipStream_t st, void* h, const float* slabs, int n_slabs, int slab_rows, const void* nw, int hidden, float eps,
+                            void* xp, int M, int cast_first, const void* wrouter, int n_experts, int top_k, float* route_w, const int* meta) {
+    if (hidden > 8192 || (hidden & 7) || n_experts < 1 || n_experts > LA_MOE_MAX_E || top_k < 1 || top_k > n_experts) return -1;
+#define RN(NS) k_row_norm_router_mb<NS><<<M, 512, 0, st>>>((bf16_t*)h, slabs, (const bf16_t*)nw, hidden, eps, (bf16_t*)xp, slab_rows, cast_first, \
+                                                           (const bf16_t*)wrouter, n_experts, top_k, route_w, meta)
+    switch (n_slabs) {
+        case 1: RN(1); break; case 2: RN(2); break; case 4: RN(4); break; case 8: RN(8); break;
+        default: return -1;
+    }
+#undef RN
+    LAUNCH_CHECK(); return 0;
+}
+int lk_mb_resid_norm_addend(hipStream_t st, void* h, const void* addend, const void* nw, int hidden, float eps, void* xp, int M, int cast_first) {
+    if (hidden > 8192 || (hidden & 7) || !addend) return -1;
+    k_row_norm_addend_mb<<<M, 512, 0, st>>>((bf16_t*)h, (const bf16_t*)addend, (const bf16_t*)nw, hidden, eps, (bf16_t*)xp, cast_first);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_mb_moe_accum(hipStream_t st, const float* slabs0, long slab_stride, int n_slabs, int slab_rows, const float* route_w, int E, int hidden,
+                    void* acc, int M) {
+    if (hidden & 7) return -1;
+#define MA(NS) k_moe_accum_mb<NS><<<M, 256, 0, st>>>(slabs0, slab_stride, slab_rows, route_w, E, hidden, (bf16_t*)acc)
+    switch (n_slabs) {
+        case 1: MA(1); break; case 2: MA(2); break; case 4: MA(4); break; case 8: MA(8); break;
+        default: return -1;
+    }
+#undef MA
+    LAUNCH_CHECK(); return 0;
+}
+
 int lk_mb_cand_slots(int n_wg) { return n_wg * 4; }
 
 template <int RBV, int EPI>
@@ -797,6 +1060,7 @@ int lk_mb_gemm(hipStream_t st, int kind, const MbGemm& g) {
     if (g.nblk < 1 || g.nblk > LA_MB_MAX) return -1;
     MbArgs a{};
     a.wp = (const bf16_t*)g.wp; a.xp = (const bf16_t*)g.xp; a.K16 = g.K / 16; a.N = g.N; a.M = g.slab_rows; a.nblk = g.nblk;
+    a.route_col = g.route_col; a.route_rows = g.nblk * 64;
     if (kind == 0) {
         if (g.N % 64) return -1;
         a.planned = 0; a.slabs = g.slabs;

@@ -255,3 +255,38 @@ def test_mstep_llama7b_layer_shapes_vs_oracle():
     eng.mstep(blocks)
     for b, (lg, T) in enumerate(refs):
         _check_rows(eng.mlogits()[b * 64:b * 64 + T], lg, range(T), f'7B-shape block {b}')
+
+
+def test_mstep_mixtral_blocks_track_the_64_row_path():
+    """Sparse-MoE MLP in the multi-block step (router fused into the post-attention norm over M rows, per-expert GEMMs over all
+    rows with the skip for unused experts, weighted accumulation in expert order): every block of a 3-sequence step must track
+    the 64-row engine path run on that sequence alone.  The two paths share every rounding point but sum K in a different
+    order, so a near-tie router row may flip an expert (tests/test_gpu_moe.py): the bulk of the rows sits at bf16 noise and the
+    routing weights agree on almost all (row, layer) pairs."""
+    from tests.tiny_model import moe_shape, moe_weights, TINY_MOE
+    shape = moe_shape(TINY_MOE)
+    sd = {k: v.to(torch.bfloat16) for k, v in moe_weights(TINY_MOE, seed=3).items()}
+    B = 3
+    engm = LlamaVerifyEngine(shape, dict(sd), max_length=256, n_slots=B, max_blocks=B)
+    eng1 = LlamaVerifyEngine(shape, dict(sd), max_length=256)
+    rs = np.random.RandomState(8)
+    blocks, refs = [], []
+    for b in range(B):
+        p = rs.randint(3, shape.vocab, size=int(rs.randint(10, 90))).tolist()
+        eng1.reset()
+        tok1 = eng1.prefill(p, fast=False)
+        tokm = engm.mprefill(b, p)
+        T = int(rs.randint(20, 65))
+        _, rows = random_tree(rs, T)
+        ids = np.concatenate([[tok1], rs.randint(3, shape.vocab, size=T - 1)]).astype(np.int32)
+        eng1.step(ids, rows, mode=2)
+        refs.append((eng1.logits()[:T].float().cpu().clone(), T, tok1 == tokm))
+        blocks.append((b, ids, rows, 0, 16))
+    engm.mstep(blocks)
+    agree = []
+    for b, (ref, T, same_first) in enumerate(refs):
+        got = engm.mlogits()[b * 64:b * 64 + T].float().cpu()
+        err = (got - ref).abs().max(1).values / ref.abs().max(1).values
+        agree.append(float((err < TOL_TINY).float().mean()))
+        assert float(err.median()) < TOL_TINY, (b, err)
+    assert np.mean(agree) >= 0.8, agree
