@@ -273,6 +273,9 @@ typedef struct la_llama_config {
     int32_t sliding_window;  /* > 0: sliding-window attention over the committed keys (Mistral: 4096; visible iff
                                 pos_row - pos_key <= window, the transformers mask rule).  An EXTENSION: the reference's
                                 lookahead path feeds the full mask (mistral/modeling_mistral.py:979-983) */
+    int32_t kv_ring;         /* 1 (needs sliding_window > 0): a sequence's main KV cache is a RING of max_keys rows — position p lives
+                                in row p mod max_keys — so memory is O(window) and generation is bounded by max_pos, not by max_keys;
+                                max_keys >= sliding_window + 64 * max(max_blocks, 1) + 32 */
     int32_t max_blocks;      /* > 1: allocate the multi-block step (la_llama_mstep) for up to this many 64-row blocks (<= LA_MB_MAX) */
     int32_t norm_cast_first; /* RMSNorm flavour: 0 = LlamaRMSNorm (llama/modeling_llama.py:86-90, one rounding), 1 = Mistral/
                                 MixtralRMSNorm (mixtral/modeling_mixtral.py:160-165, normalised value rounded first) */

@@ -75,7 +75,7 @@ class LlamaConfigC(C.Structure):
     _fields_ = [("n_layers", i32), ("hidden", i32), ("n_heads", i32), ("n_kv_heads", i32), ("head_dim", i32),
                 ("ffn", i32), ("vocab", i32), ("max_keys", i32), ("max_pos", i32), ("attn_split", i32),
                 ("rms_eps", f32), ("gemm_cfg", i32 * 8), ("balanced_wg", i32 * 3), ("n_slots", i32),
-                ("n_experts", i32), ("top_k", i32), ("fuse", i32), ("sliding_window", i32), ("max_blocks", i32),
+                ("n_experts", i32), ("top_k", i32), ("fuse", i32), ("sliding_window", i32), ("kv_ring", i32), ("max_blocks", i32),
                 ("norm_cast_first", i32)]
 
 

@@ -196,6 +196,13 @@ static int validate(const la_llama_config* c) {
         la_set_error("unsupported llama config (need hidden%32==0<=8192, ffn%32==0, vocab%32==0, max_keys%32==0)");
         return LA_E_ARG;
     }
+    if (c->kv_ring) {
+        const int blocks = c->max_blocks > 1 ? c->max_blocks : 1;
+        if (c->sliding_window <= 0 || c->max_keys < c->sliding_window + 64 * blocks + 32) {
+            la_set_error("kv_ring needs sliding_window > 0 and max_keys >= sliding_window + 64 * max(max_blocks, 1) + 32");
+            return LA_E_ARG;
+        }
+    }
     return LA_OK;
 }
 
@@ -312,6 +319,7 @@ struct Prof {
 static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = false, const int32_t* zc_in = nullptr,
                         int32_t* zc_out = nullptr, int bsplit = 0) {
     const la_llama_config& c = m->cfg;
+    const int ring = c.kv_ring ? c.max_keys : 0;          // sliding-window ring: position p of a sequence lives in row p mod max_keys
     auto P = [&](int cls) { if (pf) pf->mark(cls); };
     P(KC_OTHER);
     if (batch) KCHK(lk_build_tree_inputs_b(st, m->bin, m->bstate, m->pos, m->rowmask, m->ids));
@@ -342,11 +350,11 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
         if (batch)
             KCHK(lk_tree_attn_b(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
                                 kf, vf, m->rowmask, m->bstate, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, bsplit > 0 ? bsplit : m->nsplit,
-                                m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window));
+                                m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window, ring));
         else
             KCHK(lk_tree_attn(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
                               kf, vf, m->rowmask, m->state, c.n_heads, c.n_kv_heads, m->total_keys, m->nsplit,
-                              m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window));
+                              m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window, ring));
         P(KC_O);
         KCHK(lk_gemm64_slab(st, L.wo, m->attn_xp, c.hidden, m->o_k, m->o_rb, m->o_ks, m->slabs));
         P(KC_OTHER);
@@ -419,11 +427,11 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
         KCHK(lk_argmax_finalize(st, m->cand_val, m->cand_idx, lk_logits_cand_slots(c.vocab, m->lm_rb), am_rows));
     }
     if (batch) {
-        KCHK(lk_accept_scan_b(st, m->bin, m->ids, m->rowmask, m->bstate, m->n_slots, c.max_keys));
+        KCHK(lk_accept_scan_b(st, m->bin, m->ids, m->rowmask, m->bstate, m->n_slots, c.max_keys, ring));
         KCHK(lk_kv_commit_b(st, m->kfresh, m->vfresh, m->kmain, m->vmain, m->bstate, c.n_layers, c.n_kv_heads, m->total_keys));
     } else {
         KCHK(lk_accept_scan(st, m->ids, m->rowmask, m->state));
-        KCHK(lk_kv_commit(st, m->kfresh, m->vfresh, m->kmain, m->vmain, m->state, c.n_layers, c.n_kv_heads, m->total_keys));
+        KCHK(lk_kv_commit(st, m->kfresh, m->vfresh, m->kmain, m->vmain, m->state, c.n_layers, c.n_kv_heads, m->total_keys, ring));
         if (zc_out) KCHK(lk_publish(st, m->state, (int*)zc_out));
     }
     P(KC_N);
@@ -508,7 +516,7 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk) {
         KCHK(lk_mb_gemm(st, 2, q));
         KCHK(lk_mb_tree_attn(st, m->mb_qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems, kf, vf,
                              m->mb_rowmask, m->mb_meta, nblk, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, mb_split(nblk),
-                             m->mb_opart, m->mb_mpart, m->mb_lpart, m->mb_attn_xp, c.sliding_window));
+                             m->mb_opart, m->mb_mpart, m->mb_lpart, m->mb_attn_xp, c.sliding_window, c.kv_ring ? 1 : 0));
         MbGemm o{}; o.wp = L.wo; o.xp = m->mb_attn_xp; o.N = c.hidden; o.K = m->o_k; o.nblk = nblk; o.ksplit = m->o_ks;
         o.slabs = m->mb_slabs; o.slab_rows = npass_rows;
         KCHK(lk_mb_gemm(st, 0, o));
@@ -547,7 +555,7 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk) {
     h.logits = m->mb_logits; h.cand_val = m->mb_cand_val; h.cand_idx = m->mb_cand_idx;
     KCHK(lk_mb_gemm(st, 3, h));
     KCHK(lk_mb_argmax(st, m->mb_cand_val, m->mb_cand_idx, lk_mb_cand_slots(lwg), nblk, m->mb_out + LA_MOUT_ARGMAX));
-    KCHK(lk_mb_accept_scan(st, m->mb_meta, m->mb_ids, m->mb_rowmask, m->mb_out + LA_MOUT_ARGMAX, nblk, c.max_keys, m->bstate, m->mb_out));
+    KCHK(lk_mb_accept_scan(st, m->mb_meta, m->mb_ids, m->mb_rowmask, m->mb_out + LA_MOUT_ARGMAX, nblk, c.max_keys, c.kv_ring ? 1 : 0, m->bstate, m->mb_out));
     KCHK(lk_mb_kv_commit(st, m->mb_kfresh, m->mb_vfresh, m->kmain, m->vmain, m->mb_out, nblk, c.n_layers, c.n_kv_heads, m->total_keys));
     return LA_OK;
 }
@@ -658,7 +666,8 @@ extern "C" int la_lookahead_decode(la_llama* m, la_cache* c, void* stream, const
                                    p->mode, p->idx, LA_TREE_MAX, ids, parent, rows, nullptr, sizes, &nsz, &T);
         if (rc != LA_OK) return rc;
         if (T == 0) { ids[0] = seq[len - 1]; rows[0] = 1ull; T = 1; }
-        if (nkeys + T > m->cfg.max_keys) { la_set_error("decode: KV cache capacity exceeded"); return LA_E_RANGE; }
+        if (!m->cfg.kv_ring && nkeys + T > m->cfg.max_keys) { la_set_error("decode: KV cache capacity exceeded"); return LA_E_RANGE; }
+        if (nkeys + T + 1 > m->cfg.max_pos) { la_set_error("decode: position beyond the RoPE tables"); return LA_E_RANGE; }
         host_in[LA_IN_T] = T;
         host_in[LA_IN_MODE] = 0;
         memcpy(host_in + LA_IN_IDS, ids, sizeof(int32_t) * T);
@@ -710,7 +719,8 @@ extern "C" int la_llama_commit(la_llama* m, void* stream, const int32_t* rows, i
     hdr[LA_ST_NCOMMIT] = n;
     hdr[LA_ST_NKEYS] += n;
     HIPCHK(hipMemcpyAsync(m->state, hdr, sizeof(hdr), hipMemcpyHostToDevice, st));
-    KCHK(lk_kv_commit(st, m->kfresh, m->vfresh, m->kmain, m->vmain, m->state, m->cfg.n_layers, m->cfg.n_kv_heads, m->total_keys));
+    KCHK(lk_kv_commit(st, m->kfresh, m->vfresh, m->kmain, m->vmain, m->state, m->cfg.n_layers, m->cfg.n_kv_heads, m->total_keys,
+                      m->cfg.kv_ring ? m->cfg.max_keys : 0));
     if (host_out) HIPCHK(hipMemcpyAsync(host_out, m->state, (LA_ST_OUTTOK + 64) * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));       // hdr lives on this stack frame
     return LA_OK;
@@ -719,7 +729,7 @@ extern "C" int la_llama_commit(la_llama* m, void* stream, const int32_t* rows, i
 // Set the committed-key cursor of a slot from the host (slot 0 is also the single-sequence cursor LA_ST_NKEYS): lets a
 // prompt prefilled by la_llama_mstep continue on la_llama_step, and a finished slot be rewound without clearing the others.
 extern "C" int la_llama_set_nkeys(la_llama* m, void* stream, int slot, int nkeys) {
-    if (!m || slot < 0 || slot >= m->n_slots || nkeys < 0 || nkeys > m->cfg.max_keys) return LA_E_ARG;
+    if (!m || slot < 0 || slot >= m->n_slots || nkeys < 0 || (!m->cfg.kv_ring && nkeys > m->cfg.max_keys)) return LA_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipMemcpyAsync(m->bstate + LA_BST_NKEYS + slot, &nkeys, sizeof(int), hipMemcpyHostToDevice, st));
     if (slot == 0) HIPCHK(hipMemcpyAsync(m->state + LA_ST_NKEYS, &nkeys, sizeof(int), hipMemcpyHostToDevice, st));

@@ -49,13 +49,13 @@ int lk_qkv_post(hipStream_t st, const float* slabs, int n_slabs, int nh, int nkv
                 const void* rsin, void* qf, void* kfresh, void* vfresh);
 int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                  const void* vfresh, const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys,
-                 int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window = 0);
+                 int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window = 0, int ring_keys = 0);
 int lk_tree_attn_b(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                    const void* vfresh, const uint64_t* rowmask, const int* bstate, int nh, int nkv, int slot_keys,
-                   int n_slots, int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window = 0);
+                   int n_slots, int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window = 0, int ring_keys = 0);
 int lk_build_tree_inputs_b(hipStream_t st, const int* in, int* bstate, int* pos, uint64_t* rowmask, int* ids);
 int lk_accept_scan_b(hipStream_t st, const int* in, const int* ids, const uint64_t* rowmask, int* bstate, int n_slots,
-                     int slot_keys);
+                     int slot_keys, int ring = 0);
 int lk_kv_commit_b(hipStream_t st, const void* kfresh, const void* vfresh, void* kmain, void* vmain, const int* bstate,
                    int n_layers, int nkv, int total_keys);
 int lk_gemm64r_swiglu_ex(hipStream_t st, const void* wp0, long w_stride, const void* xp, int F, int K, int n_wg, void* act0,
@@ -68,7 +68,7 @@ int lk_moe_accum_all(hipStream_t st, const float* slabs0, long slab_stride, int 
 int lk_publish(hipStream_t st, int* state, int* host_out);
 int lk_accept_scan(hipStream_t st, const int* ids, const uint64_t* rowmask, int* state);
 int lk_kv_commit(hipStream_t st, const void* kfresh, const void* vfresh, void* kmain, void* vmain, const int* state,
-                 int n_layers, int nkv, int max_keys);
+                 int n_layers, int nkv, int max_keys, int ring = 0);
 int lk_trie_hier_get(hipStream_t st, const int* tok, const double* fo, const double* fi, const int* cstart, const int* ccount,
                      int n_nodes, const int* queries, const int* nq, int B, int decoding_length, int branch_length,
                      int min_in, int min_out, int mode, const int* stop, int n_stop, int* scratch_q, double* scratch_v,

@@ -1016,6 +1016,8 @@ struct AttnArgs {
     int slot_tiles;       // 32-key tiles per slot region of the main cache
     int window;           // > 0: sliding-window attention, a row at position p sees committed keys j with p - j <= window
     long long* dbg_times; // measurement aid (scripts/gpu_ab.py): [workgroup][wave][8] wall-clock stamps, null in production
+    int ring_tiles;       // > 0: the main cache of a sequence is a RING of this many 32-key tiles (position p lives in row p mod
+                          // ring size): memory O(window) for sliding-window models; needs window + tree rows <= ring size
 };
 
 #define LA_NEG (-1.0e30f)
@@ -1049,6 +1051,7 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
     const int NPall = (nkeys + 31) >> 5;
     const int ts = (a.window > 0 && nkeys - a.window > 0) ? ((nkeys - a.window) >> 5) : 0;
     const int NP = NPall - ts, NT = NP + 2;
+    const int tbase = tile0;                  // first tile of the sequence's main-cache region
     tile0 += ts;
     const int key_lo = (a.window > 0) ? nkeys + __popcll(a.rowmask[tb * 32 + (lane & 31)]) - 1 - a.window : 0;
     const int i0 = (NT * sp) / a.nsplit;
@@ -1068,13 +1071,17 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
         for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
     float m = LA_NEG, l = 0.f;
 
+    // main-cache tile of logical (position) tile ts + it: identity, or its ring slot
+    auto mtile = [&](int it) -> size_t {
+        return (size_t)(a.ring_tiles > 0 ? tbase + (ts + it) % a.ring_tiles : tile0 + it);
+    };
     auto kptr = [&](int it) -> const bf16x8* {
         return it >= NP ? (const bf16x8*)(a.kfresh + ((size_t)hk * 2 + (it - NP)) * 4096)
-                        : (const bf16x8*)(a.kmain + ((size_t)hk * KB + tile0 + it) * 4096);
+                        : (const bf16x8*)(a.kmain + ((size_t)hk * KB + mtile(it)) * 4096);
     };
     auto vptr = [&](int it) -> const bf16x8* {
         return it >= NP ? (const bf16x8*)(a.vfresh + ((size_t)hk * 2 + (it - NP)) * 4096)
-                        : (const bf16x8*)(a.vmain + ((size_t)hk * KB + tile0 + it) * 4096);
+                        : (const bf16x8*)(a.vmain + ((size_t)hk * KB + mtile(it)) * 4096);
     };
     // one key tile: S^T = K.Q^T, mask, online softmax, O^T += V^T.P^T.  The V fragments are requested before the
     // QK^T MFMAs and consumed after the softmax; the NEXT tile's K fragments are requested by the caller first.
@@ -1302,7 +1309,7 @@ __global__ void k_accept_scan(const int* __restrict__ ids, const unsigned long l
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_kv_commit(const bf16_t* __restrict__ kfresh, const bf16_t* __restrict__ vfresh,
                                                     bf16_t* __restrict__ kmain, bf16_t* __restrict__ vmain,
-                                                    const int* __restrict__ state, int nkv, int max_keys) {
+                                                    const int* __restrict__ state, int nkv, int max_keys, int ring) {
     const int lh = blockIdx.x;               // layer * nkv + kv head
     const int n = state[LA_ST_NCOMMIT], base = state[LA_ST_DSTBASE];
     const size_t KB = (size_t)(max_keys >> 5);
@@ -1312,13 +1319,13 @@ __global__ __launch_bounds__(256) void k_kv_commit(const bf16_t* __restrict__ kf
     bf16_t* vm = vmain + (size_t)lh * KB * 4096;
     for (int i = threadIdx.x; i < n * 16; i += 256) {
         int r = i >> 4, p = i & 15;
-        int src = state[LA_ST_SRCIDX + r], dst = base + r;
+        int src = state[LA_ST_SRCIDX + r], dst = ring ? (base + r) % ring : base + r;
         if (dst >= max_keys) continue;
         *(bf16x8*)(km + rf_offset(dst, p * 8)) = *(const bf16x8*)(kf + rf_offset(src, p * 8));
     }
     for (int i = threadIdx.x; i < n * 128; i += 256) {
         int r = i >> 7, d = i & 127;
-        int src = state[LA_ST_SRCIDX + r], dst = base + r;
+        int src = state[LA_ST_SRCIDX + r], dst = ring ? (base + r) % ring : base + r;
         if (dst >= max_keys) continue;
         vm[vf_offset(dst, d)] = vf[vf_offset(src, d)];
     }
@@ -1346,7 +1353,7 @@ __global__ void k_publish(int* __restrict__ state, int* __restrict__ host_out) {
 // kept (root + accepted drafts, or all rows of a prefill chain), -1 otherwise.
 // ---------------------------------------------------------------------------------------------
 __global__ void k_accept_scan_b(const int* __restrict__ in, const int* __restrict__ ids,
-                                const unsigned long long* __restrict__ rowmask, int* __restrict__ bstate, int slot_keys) {
+                                const unsigned long long* __restrict__ rowmask, int* __restrict__ bstate, int slot_keys, int ring) {
     const int s = blockIdx.x, j = threadIdx.x;   // 64 threads
     const int sq = bstate[LA_BST_SEQ + j];
     const bool mine = sq == s;
@@ -1358,13 +1365,14 @@ __global__ void k_accept_scan_b(const int* __restrict__ in, const int* __restric
     int limit = in[LA_BIN_LIMIT + s];
     limit = limit < 1 ? 1 : (limit > 16 ? 16 : limit);
     const int nkeys = bstate[LA_BST_NKEYS + s];
-    const int base = s * slot_keys + nkeys;
+    const int sbase = s * slot_keys;
+    auto row_of = [&](int k) { return sbase + (ring ? (nkeys + k) % slot_keys : nkeys + k); };      // main-cache row of the k-th kept key
     const int am = bstate[LA_BST_ARGMAX + j];
     int dst = -1, n_commit;
     if (mode == 1) {
         const int last = 63 - __clzll((long long)own);
         const int tok = __shfl(am, last, 64);
-        if (mine) dst = base + __popcll(own & ((1ull << j) - 1ull));
+        if (mine) dst = row_of(__popcll(own & ((1ull << j) - 1ull)));
         if (j == 0) { bstate[LA_BST_OUTTOK + s * 16] = tok; bstate[LA_BST_NOUT + s] = 1; }
         n_commit = __popcll(own);
     } else {
@@ -1372,7 +1380,7 @@ __global__ void k_accept_scan_b(const int* __restrict__ in, const int* __restric
         const int parent = (!mine || j == root || below == 0ull) ? -1 : 63 - __clzll((long long)below);
         const int myid = ids[j];
         int cur = root, depth = 0;
-        if (j == root) dst = base;
+        if (j == root) dst = row_of(0);
         while (true) {
             const int want = __shfl(am, cur, 64);
             if (j == 0) bstate[LA_BST_OUTTOK + s * 16 + depth] = want;
@@ -1381,7 +1389,7 @@ __global__ void k_accept_scan_b(const int* __restrict__ in, const int* __restric
             if (cand == 0ull) break;
             cur = __ffsll((long long)cand) - 1;
             ++depth;
-            if (j == cur) dst = base + depth;
+            if (j == cur) dst = row_of(depth);
         }
         if (j == 0) bstate[LA_BST_NOUT + s] = depth + 1;
         n_commit = depth + 1;
@@ -1753,11 +1761,11 @@ static int tree_attn_launch(hipStream_t st, AttnArgs a, int n_slots, void* attn_
 
 int lk_tree_attn_b(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                    const void* vfresh, const uint64_t* rowmask, const int* bstate, int nh, int nkv, int slot_keys,
-                   int n_slots, int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window) {
+                   int n_slots, int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window, int ring_keys) {
     if (n_slots < 1 || n_slots > LA_MAX_SEQ || (slot_keys & 31)) return -1;
     AttnArgs a{};
     a.dbg_times = g_la_dbg_times;
-    a.window = window;
+    a.window = window; a.ring_tiles = ring_keys >> 5;
     a.qf = (const bf16_t*)qf; a.kmain = (const bf16_t*)kmain; a.vmain = (const bf16_t*)vmain;
     a.kfresh = (const bf16_t*)kfresh; a.vfresh = (const bf16_t*)vfresh;
     a.rowmask = (const unsigned long long*)rowmask; a.state = nullptr;
@@ -1769,10 +1777,10 @@ int lk_tree_attn_b(hipStream_t st, const void* qf, const void* kmain, const void
 
 int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                  const void* vfresh, const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys,
-                 int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window) {
+                 int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window, int ring_keys) {
     AttnArgs a{};
     a.dbg_times = g_la_dbg_times;
-    a.window = window;
+    a.window = window; a.ring_tiles = ring_keys >> 5;
     a.qf = (const bf16_t*)qf; a.kmain = (const bf16_t*)kmain; a.vmain = (const bf16_t*)vmain;
     a.kfresh = (const bf16_t*)kfresh; a.vfresh = (const bf16_t*)vfresh;
     a.rowmask = (const unsigned long long*)rowmask; a.state = state;
@@ -1850,9 +1858,9 @@ int lk_build_tree_inputs_b(hipStream_t st, const int* in, int* bstate, int* pos,
     LAUNCH_CHECK(); return 0;
 }
 int lk_accept_scan_b(hipStream_t st, const int* in, const int* ids, const uint64_t* rowmask, int* bstate, int n_slots,
-                     int slot_keys) {
+                     int slot_keys, int ring) {
     if (n_slots < 1 || n_slots > LA_MAX_SEQ) return -1;
-    k_accept_scan_b<<<n_slots, 64, 0, st>>>(in, ids, (const unsigned long long*)rowmask, bstate, slot_keys);
+    k_accept_scan_b<<<n_slots, 64, 0, st>>>(in, ids, (const unsigned long long*)rowmask, bstate, slot_keys, ring);
     LAUNCH_CHECK(); return 0;
 }
 int lk_kv_commit_b(hipStream_t st, const void* kfresh, const void* vfresh, void* kmain, void* vmain, const int* bstate,
@@ -1862,8 +1870,8 @@ int lk_kv_commit_b(hipStream_t st, const void* kfresh, const void* vfresh, void*
     LAUNCH_CHECK(); return 0;
 }
 int lk_kv_commit(hipStream_t st, const void* kfresh, const void* vfresh, void* kmain, void* vmain, const int* state,
-                 int n_layers, int nkv, int max_keys) {
+                 int n_layers, int nkv, int max_keys, int ring) {
     k_kv_commit<<<n_layers * nkv, 256, 0, st>>>((const bf16_t*)kfresh, (const bf16_t*)vfresh, (bf16_t*)kmain,
-                                                (bf16_t*)vmain, state, nkv, max_keys);
+                                                (bf16_t*)vmain, state, nkv, max_keys, ring);
     LAUNCH_CHECK(); return 0;
 }

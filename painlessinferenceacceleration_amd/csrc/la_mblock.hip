@@ -646,7 +646,7 @@ struct MbAttnArgs {
     const bf16_t* qf; const bf16_t* kmain; const bf16_t* vmain; const bf16_t* kfresh; const bf16_t* vfresh;
     const unsigned long long* rowmask;
     const int* meta;
-    int nh, nkv, total_keys, slot_tiles, nsplit, window;
+    int nh, nkv, total_keys, slot_tiles, nsplit, window, ring;      // ring: the slot's main cache is a ring of slot_tiles tiles
     float* opart; float* mpart; float* lpart;          // [blk][nh][nsplit][64][128] ...
 };
 #define MB_NEG (-1.0e30f)
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
     float m = MB_NEG, l = 0.f;
 
     auto tptr = [&](const bf16_t* mainp, const bf16_t* freshp, int it) -> const bf16x8* {
-        if (it < NP) return (const bf16x8*)(mainp + ((size_t)hk * KB + tile0 + it) * 4096);
+        if (it < NP) return (const bf16x8*)(mainp + ((size_t)hk * KB + (a.ring ? slot * a.slot_tiles + (tsm + it) % a.slot_tiles : tile0 + it)) * 4096);
         const int j = it - NP;                          // fresh tile index: earlier blocks first, then own
         const int fb = j < NF ? first + (j >> 1) : blk;
         return (const bf16x8*)(freshp + (((size_t)fb * a.nkv + hk) * 2 + (j & 1)) * 4096);
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(256) void k_argmax_mb(const float* __restrict__ cv,
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void k_accept_scan_mb(const int* __restrict__ meta, const int* __restrict__ ids,
                                  const unsigned long long* __restrict__ rowmask, const int* __restrict__ argmax, int nblk,
-                                 int slot_keys, int* __restrict__ bstate, int* __restrict__ out) {
+                                 int slot_keys, int ring, int* __restrict__ bstate, int* __restrict__ out) {
     __shared__ int ncommit[8];
     const int b = threadIdx.x >> 6, j = threadIdx.x & 63;
     if (b < nblk) {
@@ -892,12 +892,13 @@ __global__ void k_accept_scan_mb(const int* __restrict__ meta, const int* __rest
         const int slot = mt[LA_MBM_SLOT], T = mt[LA_MBM_T], mode = mt[LA_MBM_MODE];
         int limit = mt[LA_MBM_LIMIT];
         limit = limit < 1 ? 1 : (limit > 16 ? 16 : limit);
-        const int base = slot * slot_keys + mt[LA_MBM_NKEYS] + mt[LA_MBM_BASE];
+        const int pos0 = mt[LA_MBM_NKEYS] + mt[LA_MBM_BASE];
+        auto row_of = [&](int k) { return slot * slot_keys + (ring ? (pos0 + k) % slot_keys : pos0 + k); };
         const int am = argmax[b * 64 + j];
         int dst = -1, nc;
         if (mode == 1) {
             const int tok = __shfl(am, T - 1, 64);
-            if (j < T) dst = base + j;
+            if (j < T) dst = row_of(j);
             if (j == 0) { out[LA_MOUT_OUTTOK + b * 16] = tok; out[LA_MOUT_NOUT + b] = 1; }
             nc = T;
         } else {
@@ -905,7 +906,7 @@ __global__ void k_accept_scan_mb(const int* __restrict__ meta, const int* __rest
             const int parent = (j == 0 || j >= T || below == 0ull) ? -1 : 63 - __clzll((long long)below);
             const int myid = ids[b * 64 + j];
             int cur = 0, depth = 0;
-            if (j == 0) dst = base;
+            if (j == 0) dst = row_of(0);
             while (true) {
                 const int want = __shfl(am, cur, 64);
                 if (j == 0) out[LA_MOUT_OUTTOK + b * 16 + depth] = want;
@@ -914,7 +915,7 @@ __global__ void k_accept_scan_mb(const int* __restrict__ meta, const int* __rest
                 if (cand == 0ull) break;
                 cur = __ffsll((long long)cand) - 1;
                 ++depth;
-                if (j == cur) dst = base + depth;
+                if (j == cur) dst = row_of(depth);
             }
             if (j == 0) out[LA_MOUT_NOUT + b] = depth + 1;
             nc = depth + 1;
@@ -1116,13 +1117,13 @@ int lk_mb_argmax(hipStream_t st, const float* cv, const int* ci, int n_tiles, in
 
 int lk_mb_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh, const void* vfresh,
                     const uint64_t* rowmask, const int* meta, int nblk, int nh, int nkv, int slot_keys, int n_slots, int nsplit,
-                    float* opart, float* mpart, float* lpart, void* attn_xp, int window) {
+                    float* opart, float* mpart, float* lpart, void* attn_xp, int window, int ring) {
     if (lk_mb_init() != 0 || nblk < 1 || nblk > LA_MB_MAX || (slot_keys & 31)) return -1;
     MbAttnArgs a{};
     a.qf = (const bf16_t*)qf; a.kmain = (const bf16_t*)kmain; a.vmain = (const bf16_t*)vmain;
     a.kfresh = (const bf16_t*)kfresh; a.vfresh = (const bf16_t*)vfresh;
     a.rowmask = (const unsigned long long*)rowmask; a.meta = meta;
-    a.nh = nh; a.nkv = nkv; a.total_keys = slot_keys * n_slots; a.slot_tiles = slot_keys >> 5; a.nsplit = nsplit; a.window = window;
+    a.nh = nh; a.nkv = nkv; a.total_keys = slot_keys * n_slots; a.slot_tiles = slot_keys >> 5; a.nsplit = nsplit; a.window = window; a.ring = ring;
     a.opart = opart; a.mpart = mpart; a.lpart = lpart;
     k_tree_attn_mb<<<dim3(nh, nsplit, nblk), 512, 8 * 66 * 64 * sizeof(float), st>>>(a);
     LAUNCH_CHECK();
@@ -1137,9 +1138,9 @@ int lk_mb_tree_attn(hipStream_t st, const void* qf, const void* kmain, const voi
 }
 
 int lk_mb_accept_scan(hipStream_t st, const int* meta, const int* ids, const uint64_t* rowmask, const int* argmax, int nblk,
-                      int slot_keys, int* bstate, int* d_out) {
+                      int slot_keys, int ring, int* bstate, int* d_out) {
     if (nblk < 1 || nblk > LA_MB_MAX) return -1;
-    k_accept_scan_mb<<<1, 512, 0, st>>>(meta, ids, (const unsigned long long*)rowmask, argmax, nblk, slot_keys, bstate, d_out);
+    k_accept_scan_mb<<<1, 512, 0, st>>>(meta, ids, (const unsigned long long*)rowmask, argmax, nblk, slot_keys, ring, bstate, d_out);
     LAUNCH_CHECK(); return 0;
 }
 int lk_mb_kv_commit(hipStream_t st, const void* kfresh, const void* vfresh, void* kmain, void* vmain, const int* d_out, int nblk,

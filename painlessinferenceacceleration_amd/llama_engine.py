@@ -174,14 +174,22 @@ class LlamaVerifyEngine(object):
     verify block are shared by the active slots (bstep)."""
 
     def __init__(self, shape, state_dict, max_length=2048, device='cuda:0', attn_split=0, gemm_cfg=None,
-                 consume_state_dict=False, balanced=True, n_slots=1, fuse=0, max_blocks=0):
+                 consume_state_dict=False, balanced=True, n_slots=1, fuse=0, max_blocks=0, kv_ring=False):
         if not torch.cuda.is_available():
             raise RuntimeError('LlamaVerifyEngine needs an MI355X: the verify step has no CPU fallback')
         self.shape = shape
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
-        self.max_keys = int(math.ceil((max_length + 64 + 1) / 32.0)) * 32
-        self.max_pos = self.max_keys + 64
+        self.kv_ring = bool(kv_ring)
+        if self.kv_ring:
+            # sliding-window ring (extension, SURVEY H3 / BASELINE config 3): KV memory O(window) per sequence instead of O(max_length)
+            win = int(getattr(shape, 'sliding_window', 0))
+            assert win > 0, 'kv_ring needs shape.sliding_window > 0'
+            self.max_keys = int(math.ceil((win + 64 * max(int(max_blocks), 1) + 64) / 32.0)) * 32
+            self.max_pos = max_length + 64 + 64 + 1
+        else:
+            self.max_keys = int(math.ceil((max_length + 64 + 1) / 32.0)) * 32
+            self.max_pos = self.max_keys + 64
         # a dedicated non-default stream: hipStreamBeginCapture is illegal on the legacy NULL stream that
         # torch.cuda.current_stream() returns by default
         self.stream = torch.cuda.Stream(self.device)
@@ -326,6 +334,7 @@ class LlamaVerifyEngine(object):
         self.max_blocks = int(max_blocks) if max_blocks > 1 else 0
         cfg.max_blocks = self.max_blocks
         cfg.sliding_window = int(getattr(shape, 'sliding_window', 0))
+        cfg.kv_ring = int(self.kv_ring)
         self._cfg = cfg
         nbytes = lib.la_llama_workspace_bytes(C.byref(cfg))
         if nbytes <= 0:
@@ -364,6 +373,10 @@ class LlamaVerifyEngine(object):
     def _sp(self):
         return C.c_void_p(self.stream.cuda_stream)
 
+    def _capacity(self):
+        """keys a sequence may hold: the cache size, or (ring) whatever the RoPE tables cover"""
+        return self.max_pos - 65 if self.kv_ring else self.max_keys
+
     def reset(self):
         check(lib.la_llama_reset(self._h, self._sp()), 'llama_reset')
         self.n_keys = 0
@@ -392,7 +405,7 @@ class LlamaVerifyEngine(object):
             assert 0 <= slot < self.n_slots and slot not in seen and n >= 1, 'one segment per slot'
             seen.add(slot)
             assert row + n <= _lib.LA_TREE_MAX, 'a verify block holds 64 rows'
-            assert self.slot_keys[slot] + n <= self.max_keys, 'KV cache capacity of the slot exceeded'
+            assert self.slot_keys[slot] + n <= self._capacity(), 'KV cache capacity of the slot exceeded'
             a[_lib.LA_BIN_IDS + row:_lib.LA_BIN_IDS + row + n] = ids
             self._bin_rm[row:row + n] = np.asarray(rowmask, dtype=np.uint64) << np.uint64(row)
             a[_lib.LA_BIN_SEQ + row:_lib.LA_BIN_SEQ + row + n] = slot
@@ -465,7 +478,7 @@ class LlamaVerifyEngine(object):
         for slot, ids, _, _, _ in blocks:
             rows[slot] = rows.get(slot, 0) + len(ids)
         for slot, n in rows.items():
-            assert self.slot_keys[slot] + n <= self.max_keys, 'KV cache capacity of the slot exceeded'
+            assert self.slot_keys[slot] + n <= self._capacity(), 'KV cache capacity of the slot exceeded'
         fn = lib.la_llama_mstep_eager if eager else lib.la_llama_mstep
         check(fn(self._h, self._sp(), self.host_min.data_ptr(), self.host_mout.data_ptr()), 'llama_mstep')
         self.stream.synchronize()
@@ -529,7 +542,7 @@ class LlamaVerifyEngine(object):
     def _fill(self, ids, rowmask, mode):
         T = len(ids)
         assert 1 <= T <= _lib.LA_TREE_MAX
-        assert self.n_keys + T <= self.max_keys, 'KV cache capacity exceeded'
+        assert self.n_keys + T <= self._capacity(), 'KV cache capacity exceeded'
         a = self._in_np
         a[_lib.LA_IN_T] = T
         a[_lib.LA_IN_MODE] = mode
@@ -605,7 +618,7 @@ class LlamaVerifyEngine(object):
     def commit(self, rows):
         """Keep the K/V of tree rows `rows` (root first) of the last verify_only block."""
         arr = np.ascontiguousarray(rows, dtype=np.int32)
-        assert self.n_keys + len(arr) <= self.max_keys, 'KV cache capacity exceeded'
+        assert self.n_keys + len(arr) <= self._capacity(), 'KV cache capacity exceeded'
         check(lib.la_llama_commit(self._h, self._sp(), arr.ctypes.data_as(_lib.pi32), len(arr), self.host_out.data_ptr()),
               'llama_commit')
         self.n_keys = int(self._out_np[_lib.LA_ST_NKEYS])

@@ -13,12 +13,12 @@ from .pretrained_model_batch import LookaheadPreTrainedModel
 
 class LlamaForCausalLM(LookaheadPreTrainedModel):
     def __init__(self, shape, state_dict, max_length=2048, max_batch=8, device='cuda:0', eos_token_id=2, pad_token_id=0,
-                 attn_split=0, gemm_cfg=None, consume_state_dict=False, balanced=True, max_blocks=None):
+                 attn_split=0, gemm_cfg=None, consume_state_dict=False, balanced=True, max_blocks=None, kv_ring=False):
         self.shape = shape
         self.engine = LlamaVerifyEngine(shape, state_dict, max_length=max_length, device=device, attn_split=attn_split,
                                         gemm_cfg=gemm_cfg, consume_state_dict=consume_state_dict, balanced=balanced,
                                         n_slots=max_batch,
-                                        max_blocks=min(max_batch, 8) if max_blocks is None else max_blocks)
+                                        max_blocks=min(max_batch, 8) if max_blocks is None else max_blocks, kv_ring=kv_ring)
         self.generation_config = SimpleNamespace(eos_token_id=eos_token_id, pad_token_id=pad_token_id,
                                                  return_dict_in_generate=False)
         self.config = SimpleNamespace(is_encoder_decoder=False, vocab_size=shape.vocab)

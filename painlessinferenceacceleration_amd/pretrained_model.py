@@ -133,8 +133,8 @@ class LookaheadPreTrainedModel(object):
         seq = input_ids[0].tolist()
         branch_length = decoding_kwargs.get('branch_length', 12)
         eng = self.engine
-        assert stop_max_length + decoding_length + 1 <= eng.max_keys, \
-            f'engine KV capacity {eng.max_keys} < max_length + decoding_length + 1'
+        cap = eng._capacity() if hasattr(eng, '_capacity') else eng.max_keys
+        assert stop_max_length + decoding_length + 1 <= cap, f'engine KV capacity {cap} < max_length + decoding_length + 1'
         self.lookahead_cache.put(seq[1:], branch_length=branch_length + 1, mode='input', idx=0)
         ts = time.time()
         eng.reset()

@@ -134,7 +134,8 @@ class LookaheadPreTrainedModel(object):
             raise ValueError(f'unsupport attention_mask.shape:{attention_mask.shape}')
         eng = self.engine
         assert bs <= eng.n_slots, f'batch of {bs} needs an engine with n_slots >= {bs} (has {eng.n_slots})'
-        assert stop_max_length + 64 + 1 <= eng.max_keys, f'engine KV capacity {eng.max_keys} per slot is too small'
+        cap = eng._capacity() if hasattr(eng, '_capacity') else eng.max_keys
+        assert stop_max_length + 64 + 1 <= cap, f'engine KV capacity {cap} per slot is too small'
         for i in range(bs):                                                     # :1204-1207 (pads included, as there)
             self.lookahead_cache.put(ids0[i, 1:-1].tolist(), branch_length=branch_length + 1, mode='input', idx=i)
         rows = [ids0[i].tolist() for i in range(bs)]      # padded-coordinate token rows; cursor = len(row) - 1

@@ -451,3 +451,48 @@ def test_full_size_llama7b_32_layers_vs_oracle():
     am = eng.state().cpu().numpy()[136:136 + T].tolist()
     exp_toks, exp_rows = lo.accept_scan(ids.tolist(), _mask_from_rows(rows, T), am)
     assert toks == exp_toks and ncommit == len(exp_rows)
+
+
+@pytest.mark.parametrize('window', [40, 100])
+def test_sliding_window_kv_ring_is_bitwise_the_windowed_full_cache(window):
+    """cfg.kv_ring (extension, BASELINE config 3: "sliding-window KV"): the main cache of a sequence is a ring of
+    window + 64 * blocks + 64 rows (position p in row p mod ring) instead of max_length rows.  The ring engine reads exactly the
+    keys the windowed full-cache engine reads, tile by tile in the same order, so every logit must be BITWISE equal — across
+    several wrap-arounds, on the single-sequence step, the cursor-batch step and the multi-block step (prefill chains included);
+    the full-cache engine itself is pinned against the oracle's window rule by test_sliding_window_attention_extension."""
+    shape = tiny_shape()
+    shape.sliding_window = window
+    sd = _bf16_sd(4)
+    rs = np.random.RandomState(window)
+    prompt = rs.randint(3, shape.vocab, size=150).tolist()
+    full = LlamaVerifyEngine(shape, sd, max_length=1024, n_slots=2, max_blocks=2)
+    ring = LlamaVerifyEngine(shape, sd, max_length=1024, n_slots=2, max_blocks=2, kv_ring=True)
+    assert ring.max_keys < 400 < full.max_keys
+    # single-sequence path: 64-row prefill steps, then tree steps far past the ring size
+    toks = [e.prefill(prompt, fast=False) for e in (full, ring)]
+    assert toks[0] == toks[1] and torch.equal(full.logits(), ring.logits())
+    for step in range(40):
+        T = int(rs.randint(1, 65))
+        _, rows = random_tree(rs, T)
+        ids = rs.randint(3, shape.vocab, size=T).astype(np.int32)
+        mode = 1 if step % 3 == 0 else 0                      # chains commit all rows: the context grows fast
+        outs = [e.step(ids, rows if mode == 0 else e._CHAIN[:T], mode=mode) for e in (full, ring)]
+        assert outs[0] == outs[1] and torch.equal(full.logits()[:T], ring.logits()[:T]), step
+    assert ring.n_keys == full.n_keys and ring.n_keys > 2 * ring.max_keys
+    # cursor-batch and multi-block paths on slot 1 (chains of 2 blocks per pass, then trees)
+    for e in (full, ring):
+        e.reset()
+    long_prompt = rs.randint(3, shape.vocab, size=520).tolist()
+    t2 = [e.mprefill(1, long_prompt) for e in (full, ring)]
+    assert t2[0] == t2[1] and torch.equal(full.mlogits()[:128], ring.mlogits()[:128])
+    for step in range(12):
+        T = int(rs.randint(8, 65))
+        _, rows = random_tree(rs, T)
+        ids = rs.randint(3, shape.vocab, size=T).astype(np.int32)
+        if step % 2:
+            o = [e.mstep([(1, ids, rows, 0, 16)]) for e in (full, ring)]
+            assert o[0] == o[1] and torch.equal(full.mlogits()[:T], ring.mlogits()[:T]), step
+        else:
+            o = [e.bstep([(1, ids, np.asarray(rows, dtype=np.uint64), 0, 16)]) for e in (full, ring)]
+            assert o[0] == o[1] and torch.equal(full.logits()[:T], ring.logits()[:T]), step
+    assert ring.slot_keys[1] == full.slot_keys[1] > 520
