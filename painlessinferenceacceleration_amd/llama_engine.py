@@ -104,6 +104,36 @@ def legacy_state_dict(sd, shape):
     return out
 
 
+def load_hf_checkpoint(model_dir):
+    """(transformers config, HF-named state dict on CPU) of a checkpoint directory: config.json plus *.safetensors (sharded or
+    not) or pytorch_model*.bin — what LlamaForCausalLM.from_pretrained(model_dir, ...) of the reference's examples resolves
+    (examples/llama_example.py:19-24).  Tensors are read shard by shard; nothing is instantiated as an nn.Module."""
+    import glob
+    import json
+    import os
+    from transformers import AutoConfig
+    cfg = AutoConfig.from_pretrained(model_dir)
+    sd = {}
+    st_files = sorted(glob.glob(os.path.join(model_dir, '*.safetensors')))
+    idx = os.path.join(model_dir, 'model.safetensors.index.json')
+    if os.path.exists(idx):
+        names = sorted(set(json.load(open(idx))['weight_map'].values()))
+        st_files = [os.path.join(model_dir, n) for n in names]
+    if st_files:
+        from safetensors import safe_open
+        for f in st_files:
+            with safe_open(f, framework='pt', device='cpu') as fh:
+                for k in fh.keys():
+                    sd[k] = fh.get_tensor(k)
+    else:
+        bins = sorted(glob.glob(os.path.join(model_dir, 'pytorch_model*.bin')))
+        if not bins:
+            raise FileNotFoundError(f'no *.safetensors or pytorch_model*.bin under {model_dir}')
+        for f in bins:
+            sd.update(torch.load(f, map_location='cpu', weights_only=True))
+    return cfg, sd
+
+
 def rope_tables(head_dim, max_pos, theta, device):
     """cos/sin exactly as LlamaRotaryEmbedding.forward (modeling_llama.py:93-126): fp32 outer product,
     cos()/sin() in fp32, cast to the activation dtype (bf16).  Only the first head_dim/2 columns are stored

@@ -6,7 +6,7 @@ from types import SimpleNamespace
 
 import torch
 
-from .llama_engine import LlamaShape, LlamaVerifyEngine, legacy_state_dict, random_weights
+from .llama_engine import LlamaShape, LlamaVerifyEngine, legacy_state_dict, load_hf_checkpoint, random_weights
 from .lookahead_cache import LookaheadCache
 from .pretrained_model_batch import LookaheadPreTrainedModel
 
@@ -31,6 +31,47 @@ class LlamaForCausalLM(LookaheadPreTrainedModel):
         kw.setdefault('eos_token_id', getattr(hf_model.config, 'eos_token_id', 2))
         kw.setdefault('pad_token_id', getattr(hf_model.config, 'pad_token_id', 0) or 0)
         return cls(shape, legacy_state_dict(hf_model.state_dict(), shape), **kw)
+
+    @classmethod
+    def from_pretrained(cls, model_dir, *unused_args, device_map=None, torch_dtype=None, max_length=4096, **kw):
+        """The reference examples' front door (examples/llama_example.py:19-24, benchmarks/llama_benchmark.py:25-29):
+        LlamaForCausalLM.from_pretrained(model_dir, cache_dir=..., torch_dtype=..., low_cpu_mem_usage=True, device_map=...).
+        The checkpoint's tensors are repacked straight into HBM (no nn.Module is built); the engine computes in bf16 whatever
+        torch_dtype asks for (fp16 checkpoints are converted), device_map picks the GPU ({"": "cuda:0"} / "auto" / None ->
+        cuda:0).  max_length = KV capacity in tokens (prompt + generation)."""
+        for k in ('cache_dir', 'low_cpu_mem_usage', 'trust_remote_code', 'revision', 'use_safetensors', 'attn_implementation'):
+            kw.pop(k, None)
+        device = 'cuda:0'
+        if isinstance(device_map, dict) and device_map:
+            device = str(next(iter(device_map.values())))
+        elif isinstance(device_map, str) and device_map.startswith('cuda'):
+            device = device_map
+        if device.isdigit():
+            device = f'cuda:{device}'
+        cfg, sd = load_hf_checkpoint(model_dir)
+        shape = LlamaShape.from_hf(cfg)
+        kw.setdefault('eos_token_id', getattr(cfg, 'eos_token_id', 2))
+        kw.setdefault('pad_token_id', getattr(cfg, 'pad_token_id', 0) or 0)
+        model = cls(shape, legacy_state_dict(sd, shape), max_length=max_length, device=device, consume_state_dict=True, **kw)
+        model.config = cfg
+        return model
+
+    # nn.Module-style no-ops the reference scripts call on a loaded model
+    def eval(self):
+        return self
+
+    def half(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def cuda(self, *a, **k):
+        return self
+
+    @property
+    def dtype(self):
+        return torch.bfloat16
 
     @classmethod
     def random_init(cls, shape, seed=0, device='cuda:0', decisive=False, **kw):

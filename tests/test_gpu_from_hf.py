@@ -112,3 +112,41 @@ def test_from_hf_engine_matches_bf16_oracle_on_bridged_weights(kind):
                          decoding_kwargs={'use_lookahead': True, 'decoding_length': 64, 'branch_length': 12})
     assert out.shape[1] == P + 8
     assert model.generation_config.eos_token_id == 2
+
+
+@pytest.mark.gpu
+def test_from_pretrained_front_door_runs_the_reference_example_sequence(tmp_path):
+    """examples/llama_example.py:19-69 with only the import changed: from_pretrained(model_dir, cache_dir, torch_dtype,
+    low_cpu_mem_usage, device_map) on a checkpoint directory written by transformers' save_pretrained, then generate() with the
+    example's keyword arguments, lookahead off / off / on / on.  All four replies must be the HF model's own greedy continuation."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples'))
+    from generate_from_checkpoint import synthetic_checkpoint
+    from painlessinferenceacceleration_amd.modeling_llama import LlamaForCausalLM
+    from painlessinferenceacceleration_amd.modeling_llama_batch import LlamaForCausalLM as BatchLlama
+    import transformers
+    d = synthetic_checkpoint(str(tmp_path), layers=2, hidden=256, heads=2, ffn=512, vocab=512)
+    hf = transformers.LlamaForCausalLM.from_pretrained(d, torch_dtype=torch.float32).eval()
+    model = LlamaForCausalLM.from_pretrained(d, cache_dir='../', torch_dtype=torch.float16, low_cpu_mem_usage=True,
+                                             device_map={'': 'cuda:0'}, max_length=512)
+    assert model.config.vocab_size == 512 and model.eval() is model and model.dtype == torch.bfloat16
+    input_ids = torch.randint(3, 512, (1, 20), generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        ref = hf.generate(input_ids, max_new_tokens=64, do_sample=False, pad_token_id=0, eos_token_id=None)[0].tolist()
+    stop_words = set([5, 6])
+    for use_lookahead in (False, False, True, True):
+        out = model.generate(input_ids=input_ids.cuda(), attention_mask=torch.ones_like(input_ids).cuda(), position_ids=None,
+                             pad_token_id=2, eos_token_id=None, use_cache=True, max_new_tokens=64, repetition_penalty=1.0,
+                             do_sample=False, decoding_kwargs={'use_lookahead': use_lookahead, 'debug_lookahead': False,
+                                                               'decoding_length': 64, 'branch_length': 12, 'stop_words': stop_words})
+        assert out.device.type == 'cuda' and out[0].tolist() == ref, use_lookahead
+    # the batch wrapper (benchmarks/llama_benchmark.py:25-29: device_map='auto')
+    bm = BatchLlama.from_pretrained(d, cache_dir='../', torch_dtype=torch.float16, low_cpu_mem_usage=True, device_map='auto',
+                                    max_length=512, max_batch=2)
+    two = torch.cat([input_ids, input_ids.flip(1)], 0)
+    with torch.no_grad():
+        ref2 = [hf.generate(two[i:i + 1], max_new_tokens=32, do_sample=False, pad_token_id=0, eos_token_id=None)[0].tolist() for i in range(2)]
+    out2 = bm.generate(input_ids=two.cuda(), attention_mask=torch.ones_like(two).cuda(), max_new_tokens=32, pad_token_id=2,
+                       eos_token_id=None, decoding_kwargs={'use_lookahead': True, 'decoding_length': 64, 'branch_length': 12})
+    assert [o.tolist() for o in out2] == ref2
