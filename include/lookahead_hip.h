@@ -48,7 +48,9 @@ int          la_abi_version(void);   /* == LA_ABI_VERSION of the header the libr
 const char*  la_last_error(void);
 /* Measurement knobs for the kernel A/B scripts (scripts/gpu_ab.py); every knob is 0 in production.
  * key 0: GEMM kernels return after the weight-streaming loop, before the cross-wave reduction and epilogue.
- * key 1: K share (1/64ths) of waves 0..3 in the 8-wave GEMMs (0 = library default); set before la_llama_step captures. */
+ * key 1: K share (1/64ths) of waves 0..3 in the 8-wave GEMMs (0 = library default); set before la_llama_step captures.
+ * key 2: s_setprio level (0..3) of waves 4..7 in the 8-wave GEMMs.
+ * key 3: 1 = multi-block GEMMs always on the K-split kernels (no wide one-pass form); set before la_llama_mstep captures. */
 int          la_debug_set(int key, int value);
 /* key 0: device buffer int64[workgroups][waves][8] the GEMM kernels stamp with wall_clock64() at entry / end of the
  * streaming loop / exit / half of the loop, plus HW_ID in word 4 (NULL = off). */

@@ -18,6 +18,10 @@ int la_abi_version(void) { return LA_ABI_VERSION; }
 const char* la_last_error(void) { return g_err.c_str(); }
 extern int g_la_dbg_noepi;
 extern int g_la_kskew;
+extern int g_la_prio_hi;
+extern int g_la_mb_narrow;
+extern int g_la_mb_dbg;
+extern int g_la_mb_mode;
 extern long long* g_la_dbg_times;
 int la_mb_gemm(void* stream, int kind, const void* wp, const void* xp, int N, int K, int nblk, int n_wg, int ksplit,
                float* slabs, int slab_rows, void* act_xp, void* logits, float* cand_val, int32_t* cand_idx, const int32_t* pos,
@@ -31,6 +35,10 @@ int la_mb_gemm(void* stream, int kind, const void* wp, const void* xp, int N, in
 int la_debug_set(int key, int value) {
     if (key == 0) { g_la_dbg_noepi = value; return LA_OK; }
     if (key == 1 && value >= 0 && value <= 64) { g_la_kskew = value; return LA_OK; }
+    if (key == 2 && value >= 0 && value <= 3) { g_la_prio_hi = value; return LA_OK; }
+    if (key == 3 && value >= 0 && value <= 1) { g_la_mb_narrow = value; return LA_OK; }
+    if (key == 4 && value >= 0 && value <= 5) { g_la_mb_dbg = value; return LA_OK; }
+    if (key == 5 && value >= 0 && value <= 3) { g_la_mb_mode = value; return LA_OK; }
     return LA_E_ARG;
 }
 int la_debug_set_ptr(int key, void* d_ptr) {

@@ -28,11 +28,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // round-to-nearest-even, NaN preserving: same rounding torch uses for float -> bfloat16
+// (branch-free: an early return for NaN made hipcc wrap every conversion of an unrolled epilogue in its own exec-mask region)
 __device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    const uint32_t u = __float_as_uint(f);
+    const uint32_t r = u + 0x7fffu + ((u >> 16) & 1u);
+    const bool nan = (u & 0x7fffffffu) > 0x7f800000u;
+    return (bf16_t)((nan ? (u | 0x400000u) : r) >> 16);
 }
 __device__ __forceinline__ float bfr(float f) { return bf2f(f2bf(f)); }
 

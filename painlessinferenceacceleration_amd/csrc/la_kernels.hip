@@ -277,6 +277,7 @@ struct GemmArgs {
     // outputs and split-K slabs are equally spaced; expert e uses route_col + e and returns at once when no row routes to it
     int ex_on;
     long ex_w, ex_x, ex_act, ex_slab;      // element strides per expert (weights, x operand, act_xp, slabs)
+    int prio_hi;        // 8-wave kernels: s_setprio level of waves 4..7 (the SIMD partners that are served last), 0 = default
     int kskew;          // 8-wave kernels: share (1/64ths) of the K range given to waves 0..3; 0 = even split (see wave_krange)
     int dbg_noepi;      // measurement aid (scripts/gpu_ab.py): return after the streaming loop, before the reduction/epilogue
     long long* dbg_times;   // measurement aid: [workgroup][wave][4] wall_clock64() at entry / loop end / exit (null in production)
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(GemmArgs a) {
     // this wave's contiguous k-tile range
     int wb, cnt;
     wave_krange<NW>(t0, t1 - t0, wave, a.kskew, wb, cnt);
+    if (NW == 8 && a.prio_hi > 0 && wave >= 4) { if (a.prio_hi == 1) __builtin_amdgcn_s_setprio(1); else if (a.prio_hi == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
     const int ngroups = (cnt + D - 1) / D;            // groups of D tiles; the last one may be partial
     const int last_valid = cnt - (ngroups - 1) * D;   // valid slots in the last group (1..D)
 
@@ -563,6 +565,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
     if (stamp && lane == 0) { stamp[0] = wall_clock64(); stamp[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
     int wb, cnt;
     wave_krange<NW>(0, a.K16, wave, a.kskew, wb, cnt);
+    if (NW == 8 && a.prio_hi > 0 && wave >= 4) { if (a.prio_hi == 1) __builtin_amdgcn_s_setprio(1); else if (a.prio_hi == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
     const int ngroups = (cnt + D - 1) / D;
     const int last_valid = cnt - (ngroups - 1) * D;
     const bf16x8* __restrict__ wbase = (const bf16x8*)(a.wp + (size_t)ex * a.ex_w);
@@ -1474,7 +1477,8 @@ __global__ __launch_bounds__(256) void k_moe_accum_all(const float* __restrict__
 // =============================================================================================
 // measurement knobs (la_debug_set, scripts/gpu_ab.py); 0 in production
 int g_la_dbg_noepi = 0;
-int g_la_kskew = 0;           // K share of waves 0..3 in 1/64ths (8-wave GEMMs); set before the step graph is captured
+int g_la_kskew = 0;
+int g_la_prio_hi = 0;         // s_setprio level of waves 4..7 in the 8-wave GEMMs (measurement knob, key 2)           // K share of waves 0..3 in 1/64ths (8-wave GEMMs); set before the step graph is captured
 long long* g_la_dbg_times = nullptr;
 
 #define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -1510,21 +1514,21 @@ static int launch_gemm(hipStream_t st, const GemmArgs& a, int nblocks, int kspli
 int lk_gemm64_slab(hipStream_t st, const void* wp, const void* xp, int N, int K, int rbv, int ksplit, float* slabs,
                    const float* route_col) {
     const int rb = rbv & 0xff, variant = rbv >> 8;
-    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.kskew = g_la_kskew; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = N; a.slabs = slabs;
+    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.kskew = g_la_kskew; a.prio_hi = g_la_prio_hi; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = N; a.slabs = slabs;
     a.route_col = route_col;
     if (rb == 2 && (N % 64) == 0) return launch_gemm<2, EPI_SLAB>(st, a, N / 64, ksplit, variant);
     return launch_gemm<1, EPI_SLAB>(st, a, N / 32, ksplit, variant);
 }
 int lk_gemm64_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, void* act_xp, int variant,
                      const float* route_col) {
-    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.kskew = g_la_kskew; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = F; a.act_xp = (bf16_t*)act_xp;
+    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.kskew = g_la_kskew; a.prio_hi = g_la_prio_hi; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = F; a.act_xp = (bf16_t*)act_xp;
     a.route_col = route_col;
     return launch_gemm<2, EPI_SWIGLU>(st, a, F / 32, 1, variant);
 }
 int lk_gemm64_logits(hipStream_t st, const void* wp, const void* xp, int V, int K, int rbv, void* logits,
                      float* cv, int* ci) {
     const int rb = rbv & 0xff, variant = rbv >> 8;
-    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.kskew = g_la_kskew; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = V;
+    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.kskew = g_la_kskew; a.prio_hi = g_la_prio_hi; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = V;
     a.logits = (bf16_t*)logits; a.cand_val = cv; a.cand_idx = ci;
     if (rb == 2 && (V % 64) == 0) return launch_gemm<2, EPI_LOGITS>(st, a, V / 64, 1, variant);
     return launch_gemm<1, EPI_LOGITS>(st, a, V / 32, 1, variant);
@@ -1532,7 +1536,7 @@ int lk_gemm64_logits(hipStream_t st, const void* wp, const void* xp, int V, int 
 // QKV projection with the RoPE / fragment epilogue.  wp must be packed from the row-permuted [Wq;Wk;Wv] (lk_qkv_row_perm).
 int lk_gemm64_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int nkv, int K, const int* pos, const void* rcos,
                   const void* rsin, void* qf, void* kfresh, void* vfresh, int variant) {
-    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.kskew = g_la_kskew; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = (nh + 2 * nkv) * 128;
+    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.kskew = g_la_kskew; a.prio_hi = g_la_prio_hi; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = (nh + 2 * nkv) * 128;
     a.pos = pos; a.rcos = (const bf16_t*)rcos; a.rsin = (const bf16_t*)rsin;
     a.qf = (bf16_t*)qf; a.kfresh = (bf16_t*)kfresh; a.vfresh = (bf16_t*)vfresh; a.nh = nh; a.nkv = nkv;
     return launch_gemm<2, EPI_QKV>(st, a, a.N / 64, 1, variant);
@@ -1592,7 +1596,7 @@ static bool set_fused_norm(GemmRArgs& ra, const FusedNorm* fn, int n_wg) {
 }
 int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, int n_wg, void* act_xp,
                       const float* route_col, const FusedNorm* fn) {
-    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.kskew = g_la_kskew; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act_xp;
+    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.kskew = g_la_kskew; ra.g.prio_hi = g_la_prio_hi; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act_xp;
     ra.g.route_col = route_col;
     ra.R = F / n_wg; if (F % n_wg || ra.R > 64 || ra.R <= 32) return -1;
     fill_nv(ra, ra.R, 2, 2);
@@ -1605,7 +1609,7 @@ int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int
     LAUNCH_CHECK(); return 0;
 }
 int lk_gemm64r_logits(hipStream_t st, const void* wp, const void* xp, int V, int K, int n_wg, void* logits, float* cv, int* ci) {
-    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.kskew = g_la_kskew; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = V;
+    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.kskew = g_la_kskew; ra.g.prio_hi = g_la_prio_hi; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = V;
     ra.g.logits = (bf16_t*)logits; ra.g.cand_val = cv; ra.g.cand_idx = ci;
     ra.R = V / n_wg; if (V % n_wg || ra.R > 128 || ra.R <= 96) return -1;
     fill_nv(ra, ra.R, 4, 1);
@@ -1614,7 +1618,7 @@ int lk_gemm64r_logits(hipStream_t st, const void* wp, const void* xp, int V, int
 }
 int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int nkv, int K, int n_wg, const int* pos,
                    const void* rcos, const void* rsin, void* qf, void* kfresh, void* vfresh, const FusedNorm* fn) {
-    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.kskew = g_la_kskew; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = (nh + 2 * nkv) * 128;
+    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.kskew = g_la_kskew; ra.g.prio_hi = g_la_prio_hi; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = (nh + 2 * nkv) * 128;
     ra.g.pos = pos; ra.g.rcos = (const bf16_t*)rcos; ra.g.rsin = (const bf16_t*)rsin;
     ra.g.qf = (bf16_t*)qf; ra.g.kfresh = (bf16_t*)kfresh; ra.g.vfresh = (bf16_t*)vfresh; ra.g.nh = nh; ra.g.nkv = nkv;
     const int pairs = (nh + 2 * nkv) * 64;
@@ -1809,7 +1813,7 @@ static int tree_attn_launch(hipStream_t st, AttnArgs a, int n_slots, void* attn_
 // ---- merged MoE launches: E experts in one grid ----
 int lk_gemm64r_swiglu_ex(hipStream_t st, const void* wp0, long w_stride, const void* xp, int F, int K, int n_wg, void* act0,
                          long act_stride, const float* route_w, int E) {
-    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.kskew = g_la_kskew; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp0; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act0;
+    GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.kskew = g_la_kskew; ra.g.prio_hi = g_la_prio_hi; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp0; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act0;
     ra.g.route_col = route_w; ra.g.ex_on = 1; ra.g.ex_w = w_stride; ra.g.ex_x = 0; ra.g.ex_act = act_stride;
     ra.R = F / n_wg; if (F % n_wg || ra.R > 64 || ra.R <= 32 || E < 1 || E > LA_MOE_MAX_E) return -1;
     fill_nv(ra, ra.R, 2, 2);
@@ -1818,7 +1822,7 @@ int lk_gemm64r_swiglu_ex(hipStream_t st, const void* wp0, long w_stride, const v
 }
 int lk_gemm64_swiglu_ex(hipStream_t st, const void* wp0, long w_stride, const void* xp, int F, int K, void* act0, long act_stride,
                         const float* route_w, int E) {
-    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.kskew = g_la_kskew; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp0; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = F; a.act_xp = (bf16_t*)act0;
+    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.kskew = g_la_kskew; a.prio_hi = g_la_prio_hi; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp0; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = F; a.act_xp = (bf16_t*)act0;
     a.route_col = route_w; a.ex_on = 1; a.ex_w = w_stride; a.ex_act = act_stride;
     if (E < 1 || E > LA_MOE_MAX_E) return -1;
     k_gemm64<2, EPI_SWIGLU, 8, 4><<<dim3(F / 32, 1, E), 256, 0, st>>>(a);
@@ -1827,7 +1831,7 @@ int lk_gemm64_swiglu_ex(hipStream_t st, const void* wp0, long w_stride, const vo
 int lk_gemm64_slab_ex(hipStream_t st, const void* wp0, long w_stride, const void* xp0, long x_stride, int N, int K, int rbv, int ksplit,
                       float* slabs0, long slab_stride, const float* route_w, int E) {
     const int rb = rbv & 0xff;
-    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.kskew = g_la_kskew; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp0; a.xp = (const bf16_t*)xp0; a.K16 = K / 16; a.N = N; a.slabs = slabs0;
+    GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.kskew = g_la_kskew; a.prio_hi = g_la_prio_hi; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp0; a.xp = (const bf16_t*)xp0; a.K16 = K / 16; a.N = N; a.slabs = slabs0;
     a.route_col = route_w; a.ex_on = 1; a.ex_w = w_stride; a.ex_x = x_stride; a.ex_slab = slab_stride;
     if (E < 1 || E > LA_MOE_MAX_E) return -1;
     if (rb == 2 && (N % 64) == 0) k_gemm64<2, EPI_SLAB, 8, 4><<<dim3(N / 64, ksplit, E), 256, 0, st>>>(a);

@@ -8,6 +8,7 @@
 // fragments still stream HBM -> VGPR in MFMA operand order, each byte once per 256-row pass.
 // Reference semantics: modeling_llama_batch.py:340-420 (batched forward), pretrained_model_batch.py:706-931 (per-sample
 // draft, accept, in-place KV) with the per-sample 64-token tree SURVEY H2 / BASELINE configs 3-5 ask for.
+#include <type_traits>
 #include "la_common.h"
 #include "la_mblock.h"
 
@@ -37,6 +38,117 @@ struct MbArgs {
     // to the expert the launch returns at once and its weights are never read
     const float* route_col; int route_rows;
 };
+
+// ---------------------------------------------------------------------------------------------------------------
+// Epilogue of one 64-row block: the workgroup's RBV x 2 accumulator tiles sit in LDS as KP partial sums
+// red4[(((p * RBV + rb) * 2 + tb) * 4 + i/4) * 64 + lane] (16-byte units); each of the 8 waves finishes a fixed set of
+// (row-block, token block, register group) slices, parts summed in the order p = 0..KP-1 (deterministic).
+// ---------------------------------------------------------------------------------------------------------------
+template <int RBV, int EPI, int KP>
+__device__ __forceinline__ void mb_epilogue_block(const MbArgs& a, const f32x4* red4, int blk, int ks, int wave, int lane) {
+    const int tl = lane & 31, hh = lane >> 5;
+    auto total4 = [&](int rbq, int tb, int gi) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < KP; ++p) v += red4[(((p * RBV + rbq) * 2 + tb) * 4 + gi) * 64 + lane];
+        return v;
+    };
+    if constexpr (EPI == MB_SLAB) {
+        static_assert(EPI != MB_SLAB || RBV == 2, "slab layout");
+        // slices (rb, tb, gi): 16 -> 2 per wave
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int sl = wave * 2 + i, rq = sl >> 3, tb = (sl >> 2) & 1, gi = sl & 3;
+            const f32x4 v = total4(rq, tb, gi);
+            const int tok = blk * 64 + tb * 32 + tl;
+            float* o = a.slabs + ((size_t)ks * a.M + tok) * a.N + (blockIdx.x * RBV + rq) * 32 + 8 * gi + 4 * hh;
+            *(f32x4*)o = v;
+        }
+    } else if constexpr (EPI == MB_SWIGLU) {
+        static_assert(EPI != MB_SWIGLU || RBV == 4, "swiglu layout {G0,G1,U0,U1}");
+        // pair slices (q, tb, gi): 16 -> 2 per wave;  act = bf16(silu(bf16(g)) * bf16(u)) (LlamaMLP.forward, :185-186)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int sl = wave * 2 + i, qq = sl >> 3, tb = (sl >> 2) & 1, gi = sl & 3;
+            const int rg = a.gu_interleaved ? 2 * qq : qq, ru = a.gu_interleaved ? 2 * qq + 1 : qq + 2;
+            if (8 * gi + 4 * hh < a.nv[rg]) {
+                const f32x4 g4 = total4(rg, tb, gi), u4 = total4(ru, tb, gi);
+                const int tok = tb * 32 + tl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = 8 * gi + 4 * hh + j;
+                    if (f < a.nv[rg]) {
+                        const float gv = bfr(g4[j]), uv = bfr(u4[j]);
+                        const float sv = bfr(gv / (1.0f + expf(-gv)));
+                        const int feat = a.gu_interleaved ? (2 * blockIdx.x + qq) * 32 + f : a.R * blockIdx.x + 32 * qq + f;
+                        a.act_xp[(size_t)blk * 64 * a.N + xp_offset(tok, feat)] = f2bf(sv * uv);
+                    }
+                }
+            }
+        }
+    } else if constexpr (EPI == MB_QKV) {
+        static_assert(EPI != MB_QKV || RBV == 2, "qkv layout {lo, hi}");
+        // pair slices (tb, gi): 8 -> 1 per wave; RoPE in bf16 arithmetic (apply_rotary_pos_emb, modeling_llama.py:154-169)
+        const int tb = wave >> 2, gi = wave & 3;
+        const int tok = tb * 32 + tl;
+        if (8 * gi + 4 * hh < a.nv[0]) {
+            const f32x4 xl4 = total4(0, tb, gi), xh4 = total4(1, tb, gi);
+            const int ps = a.pos[blk * 64 + tok];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = 8 * gi + 4 * hh + j;
+                if (f < a.nv[0]) {
+                    const int prr = a.R * blockIdx.x + f, slot = prr >> 6, dlo = prr & 63, dhi = dlo + 64;
+                    const float xl = xl4[j], xh = xh4[j];
+                    if (slot < a.nh + a.nkv) {
+                        bf16_t* dst = slot < a.nh ? a.qf + ((size_t)blk * a.nh + slot) * 8192
+                                                  : a.kfresh + ((size_t)blk * a.nkv + (slot - a.nh)) * 8192;
+                        const float cc = bf2f(a.rcos[(size_t)ps * 64 + dlo]), sn = bf2f(a.rsin[(size_t)ps * 64 + dlo]);
+                        const float bl = bfr(xl), bh = bfr(xh);
+                        dst[rf_offset(tok, dlo)] = f2bf(bfr(bl * cc) + bfr(-bh * sn));
+                        dst[rf_offset(tok, dhi)] = f2bf(bfr(bh * cc) + bfr(bl * sn));
+                    } else {
+                        bf16_t* dst = a.vfresh + ((size_t)blk * a.nkv + (slot - a.nh - a.nkv)) * 8192;
+                        dst[vf_offset(tok, dlo)] = f2bf(xl);
+                        dst[vf_offset(tok, dhi)] = f2bf(xh);
+                    }
+                }
+            }
+        }
+    } else {
+        static_assert(EPI != MB_LOGITS || RBV == 4, "logits layout");
+        // wave -> token block w&1, row-block w>>1, all four register groups; one argmax candidate per (wave, token)
+        const int tb = wave & 1, rq = wave >> 1;
+        const int tok = tb * 32 + tl;
+        float best = -INFINITY;
+        int bidx = 0x7fffffff;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+            if (8 * gi + 4 * hh < a.nv[rq]) {
+                const f32x4 t4 = total4(rq, tb, gi);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = 8 * gi + 4 * hh + j;
+                    if (f < a.nv[rq]) {
+                        const bf16_t hv = f2bf(t4[j]);
+                        const int idx = a.R * blockIdx.x + 32 * rq + f;
+                        if (a.logits) a.logits[((size_t)blk * 64 + tok) * a.N + idx] = hv;
+                        const float v = bf2f(hv);
+                        if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
+                    }
+                }
+            }
+        }
+        float ob = __shfl_xor(best, 32, 64);
+        int oi = __shfl_xor(bidx, 32, 64);
+        if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+        if (hh == 0) {
+            const size_t slot = ((size_t)blk * gridDim.x + blockIdx.x) * 4 + rq;
+            a.cand_val[slot * 64 + tok] = best;
+            a.cand_idx[slot * 64 + tok] = bidx;
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // out[M][N] = x[M][K] . W[N][K]^T for NT/2 64-row blocks per pass (grid.z = pass).
@@ -185,7 +297,6 @@ __global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
     // ---- epilogue, one 64-row block at a time: K-parts parked in LDS [kp][rb][tb][i/4][lane] (16-byte units), one barrier,
     //      fixed summation order p = 0..KP-1, every wave finishes a fixed set of (row-block, token block, register group) slices
     f32x4* red4 = (f32x4*)lds_raw;
-    const int tl = lane & 31, hh = lane >> 5;
     (void)nvalid;
 #pragma unroll
     for (int c = 0; c < NT / 2; ++c) {
@@ -200,105 +311,354 @@ __global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
                 red4[(((kp * RBV + rb) * 2 + tb) * 4 + i4) * 64 + lane] = w4;
             }
         __syncthreads();
-        auto total4 = [&](int rbq, int tb, int gi) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        mb_epilogue_block<RBV, EPI, KP>(a, red4, blk, ks, wave, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The wide form for nblk >= 3 (192..512 rows): ALL token blocks of the step in one weight pass, both operands through LDS,
+// no K parts, no reduction, epilogues straight from the accumulators.
+//   workgroup = 8 waves = RG row groups x TQ token groups (RBV = 4: 2 x 4, RBV = 2: 1 x 8); every wave owns TWO weight
+//   row-blocks x TW token blocks (2 TW accumulator tiles) over the workgroup's whole K range.  The two row-blocks of a wave
+//   are the ones its epilogue combines — gate and up rows of the same features, the lo and hi halves of a RoPE pair — so no
+//   epilogue needs another wave's sums.
+//   Operands arrive by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no staging registers).  A stage =
+//   KS = 2 k-tiles = A_STAGE weight pieces + B_STAGE x pieces in the order the fragments are read back; wave w copies the
+//   pieces w + 8 i.  vmcnt retires in order per wave, so both operands ride ONE 3-stage ring and a wave's outstanding DMA
+//   is always "the pieces of the younger stages": s_waitcnt vmcnt(pieces per stage), never 0 inside the loop.
+//   Stage s is consumed as two k-tiles out of two register sets; the barrier that publishes stage s+1 sits BETWEEN them:
+//     read set1 <- (s, k-tile 1) | MFMAs of set0 | lgkmcnt(0): every read of stage s is complete | own DMA of s+1 landed |
+//     s_barrier | read set0 <- (s+1, k-tile 0) | MFMAs of set1, one DMA issue of stage s+3 (into the slot the barrier has
+//     just freed) after each — every ds_read latency runs under the MFMAs of the other set, every DMA issue between MFMAs.
+//   Fragment reads are ds_read_b128, lane-linear (conflict-free): (2 + TW) per k-tile for 2 TW MFMAs.
+// Measured anatomy (gate/up, 512 rows, profiles/r02_mblock_wide_parts.txt): MFMA issue floor 68 us at the 2.0 PFLOP/s the
+// chip sustains, DMA-only loop 67 us (x from L2 and weights from HBM share the CU's in-order vector-memory path).
+// ---------------------------------------------------------------------------------------------------------------
+// float -> bf16 on the gfx950 converter (v_cvt_pk_bf16_f32: round-to-nearest-even like f2bf, one instruction instead of six)
+__device__ __forceinline__ bf16_t f2bf_hw(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ float bfr_hw(float f) { return bf2f(f2bf_hw(f)); }
+
+template <int N> __device__ __forceinline__ void vm_wait() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int RBV, int TW> struct WideGeom {
+    static constexpr int KS = 2, RG = RBV / 2, TQ = 8 / RG, NTBP = TQ * TW;  // token blocks (32 rows) per workgroup
+    static constexpr int A_STAGE = KS * RBV, B_STAGE = KS * NTBP;           // 1 KiB pieces per stage
+    static constexpr int STAGE = A_STAGE + B_STAGE;
+    static constexpr int NR = 4;                                              // ring slots (stages)
+    static constexpr int NP_HI = (STAGE + 7) / 8, NP_LO = STAGE / 8;          // pieces per wave and stage
+    static constexpr int N_HI = STAGE - 8 * NP_LO;                            // waves 0..N_HI-1 carry NP_HI pieces
+    static constexpr int H = (NP_HI + 1) / 2;                                 // pieces issued in the first half of a stage
+    static constexpr int LDS = NR * STAGE * 1024;
+    static constexpr int BLOCKS = NTBP / 2;                                   // 64-row blocks per workgroup
+    static_assert(A_STAGE <= 8 && LDS <= 160 * 1024 && (RBV == 2 || RBV == 4), "ring geometry");
+};
+
+template <int RBV, int TW, int EPI, int DBG = 0>
+__global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
+    using GEO = WideGeom<RBV, TW>;
+    constexpr int KS = GEO::KS, TQ = GEO::TQ, NTBP = GEO::NTBP, A_STAGE = GEO::A_STAGE, STAGE = GEO::STAGE, NR = GEO::NR;
+    constexpr int NP_HI = GEO::NP_HI, NP_LO = GEO::NP_LO, N_HI = GEO::N_HI;
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    if (a.route_col) {
+        bool any = false;
+        for (int t = lane; t < a.route_rows; t += 64) any |= a.route_col[(size_t)t * LA_MOE_MAX_E] != 0.f;
+        if (__ballot(any) == 0ull) return;
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // row group = wave / 4: a workgroup's waves are dealt to the SIMDs cyclically, so each SIMD gets one wave of either row group
+    // (the row groups' epilogues differ in weight: a planned gate/up image has 32 valid rows in one pair of blocks, R - 32 in the other)
+    const int rg = RBV == 4 ? (wave >> 2) : 0, tq = RBV == 4 ? (wave & 3) : wave;
+    static_assert(TQ == (RBV == 4 ? 4 : 8), "wave grid");
+    // the wave's two row-blocks: planned gate/up images are {G0, G1, U0, U1} (pair = rb, rb + 2), classic interleaved images
+    // {G, U, G, U} (pair = 2 rg, 2 rg + 1); lm_head rows are independent; RBV = 2 images are {lo, hi} / two plain blocks
+    const int rb0 = RBV == 4 ? ((EPI == MB_SWIGLU && !a.gu_interleaved) ? rg : 2 * rg) : 0;
+    const int rb1 = RBV == 4 ? ((EPI == MB_SWIGLU && !a.gu_interleaved) ? rg + 2 : 2 * rg + 1) : 1;
+    const int ksplit = gridDim.y, ks = blockIdx.y;
+    const int t0 = (int)(((long)a.K16 * ks) / ksplit), t1 = (int)(((long)a.K16 * (ks + 1)) / ksplit);
+    const int nst = (t1 - t0 + KS - 1) / KS;
+    const int zb0 = blockIdx.z * GEO::BLOCKS;       // first 64-row block of this workgroup (grid.z splits the token blocks)
+
+    const bf16x8* __restrict__ wbase = (const bf16x8*)a.wp;
+    const bf16x8* __restrict__ xbase = (const bf16x8*)a.xp;
+    const bool w0 = wave < A_STAGE;                 // piece 0 of this wave is a weight piece (only i = 0 can be: A_STAGE <= 8)
+    const bool hi = wave < N_HI;                    // this wave carries NP_HI pieces
+    const bf16x8* src[NP_HI];                       // per-lane source of the piece at k-tile 0
+    unsigned gstr[NP_HI];                           // its k-tile stride (16 B units)
+    int pkk[NP_HI], pdst[NP_HI];                    // wave-uniform: k-tile inside the stage, byte offset inside the stage buffer
 #pragma unroll
-            for (int p = 0; p < KP; ++p) v += red4[(((p * RBV + rbq) * 2 + tb) * 4 + gi) * 64 + lane];
-            return v;
-        };
-        if constexpr (EPI == MB_SLAB) {
-            static_assert(EPI != MB_SLAB || RBV == 2, "slab layout");
-            // slices (rb, tb, gi): 16 -> 2 per wave
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int sl = wave * 2 + i, rq = sl >> 3, tb = (sl >> 2) & 1, gi = sl & 3;
-                const f32x4 v = total4(rq, tb, gi);
-                const int tok = blk * 64 + tb * 32 + tl;
-                float* o = a.slabs + ((size_t)ks * a.M + tok) * a.N + (blockIdx.x * RBV + rq) * 32 + 8 * gi + 4 * hh;
-                *(f32x4*)o = v;
+    for (int i = 0; i < NP_HI; ++i) {
+        const int p = wave + 8 * ((i < NP_LO || hi) ? i : 0);
+        if (i == 0 && w0) {
+            const int kk = p / RBV, rb = p % RBV;
+            if (a.planned) {
+                const int nvb = a.nvl[rb];
+                const int rr = (lane & 31) < nvb ? (lane & 31) : nvb - 1;
+                gstr[i] = (unsigned)(2 * nvb);
+                src[i] = wbase + ((size_t)blockIdx.x * (unsigned)a.wg_chunks + (unsigned)a.boff[rb] + (unsigned)((lane >> 5) * nvb + rr));
+            } else {
+                gstr[i] = 64u;
+                src[i] = wbase + ((size_t)(blockIdx.x * RBV + rb) * a.K16 * 64 + lane);
             }
+            pkk[i] = kk;
+            pdst[i] = (kk * RBV + rb) * 1024;
+        } else {
+            const int q = p - A_STAGE, kk = q / NTBP, tb = q % NTBP;
+            int xb = zb0 + (tb >> 1);
+            xb = xb < a.nblk ? xb : a.nblk - 1;     // token blocks past the step re-read the last real block (results dropped)
+            gstr[i] = 128u;
+            src[i] = xbase + ((size_t)((xb * a.K16) * 2 + (tb & 1)) * 64 + lane);
+            pkk[i] = kk;
+            pdst[i] = (A_STAGE + kk * NTBP + tb) * 1024;
+        }
+    }
+    auto issue_one = [&](int sidx, int i) {         // piece i of this wave's share of stage sidx (k-tile clamped into the range)
+        int kt = t0 + sidx * KS + pkk[i];
+        kt = kt < t1 ? kt : t1 - 1;
+        const bf16x8* g = src[i] + (size_t)kt * gstr[i];
+        char* d = lds_raw + (sidx % NR) * (STAGE * 1024) + pdst[i];
+        if (i == 0) {
+            if (w0) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 2);       // streamed weights: nt
+            else __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 0);
+        } else if (i < NP_LO || hi) {
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 0);
+        }
+    };
+    auto issue = [&](int sidx) {
+#pragma unroll
+        for (int i = 0; i < NP_HI; ++i) issue_one(sidx, i);
+    };
+
+    f32x16 acc[2][TW];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][t][i] = 0.f;
+
+    // Fragment reads are inline asm so that the LDS queue is counted by hand (lgkmcnt retires ds_reads in order): hipcc's own
+    // scoreboard gives up across the loop back-edge and waits lgkmcnt(0) before the first MFMA of a set, i.e. for the reads it
+    // has just issued for the OTHER set.
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds_raw + (unsigned)lane * 16u;
+    auto read_frags = [&](int sidx, int kk, bf16x8 (&fa)[2], bf16x8 (&fb)[TW]) {
+        const unsigned S = lds0 + (unsigned)((sidx % NR) * (STAGE * 1024));
+        const unsigned A = S + (unsigned)(kk * RBV * 1024);
+        const unsigned B = S + (unsigned)((A_STAGE + kk * NTBP + tq * TW) * 1024);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[0]) : "v"(A + rb0 * 1024u) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(fa[1]) : "v"(A + rb1 * 1024u) : "memory");
+#pragma unroll
+        for (int t = 0; t < TW; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[t]) : "v"(B + t * 1024u) : "memory");
+    };
+    auto mma = [&](int r, int t, const bf16x8 (&fa)[2], const bf16x8 (&fb)[TW]) {
+        if constexpr (DBG == 1 || DBG == 3) acc[r][t][0] += __builtin_bit_cast(float, (int)(fa[r][0] ^ fb[t][0]));
+        else acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[r], fb[t], acc[r][t], 0, 0, 0);
+    };
+
+    constexpr int H = GEO::H;
+    issue(0); issue(1); issue(2);
+    if (hi) vm_wait<2 * NP_HI>(); else vm_wait<2 * NP_LO>();
+    __builtin_amdgcn_s_barrier();
+    bf16x8 fa0[2], fb0[TW], fa1[2], fb1[TW];
+    read_frags(0, 0, fa0, fb0);
+    constexpr int NMMA = 2 * TW, NRD = 2 + TW;
+    for (int s = 0; s < nst; ++s) {
+        const bool full = (t0 + s * KS + 1) < t1;   // an odd K range ends on half a stage (workgroup-uniform)
+        if constexpr (DBG != 3) read_frags(s, 1, fa1, fb1);
+        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(DBG != 3 ? NRD : 0) : "memory");      // set0 complete, set1 in flight
+        __builtin_amdgcn_sched_barrier(0);
+        // first half: MFMAs of set0, the first H DMA pieces of stage s+3 between them (its slot was freed one barrier ago)
+#pragma unroll
+        for (int m = 0; m < (NMMA > H ? NMMA : H); ++m) {
+            if (m < NMMA) mma(m / TW, m % TW, fa0, fb0);
+            if constexpr (DBG != 2 && DBG != 5) { if (m < H) issue_one(s + 3, m); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // every read of stage s is complete
+        // own pieces of stage s+1 landed: younger are all of stage s+2 and the H pieces of s+3
+        if constexpr (DBG != 2 && DBG != 5) { if (hi) vm_wait<NP_HI + H>(); else vm_wait<NP_LO + H>(); }
+        else vm_wait<0>();
+        if constexpr (DBG != 5) __builtin_amdgcn_s_barrier();               // stage s+1 complete for everyone; the slot of stage s is free
+        if constexpr (DBG != 3) read_frags(s + 1, 0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        // second half: MFMAs of set1 and the remaining pieces of stage s+3
+        if (full) {
+#pragma unroll
+            for (int m = 0; m < (NMMA > NP_HI - H ? NMMA : NP_HI - H); ++m) {
+                if (m < NMMA) mma(m / TW, m % TW, fa1, fb1);
+                if constexpr (DBG != 2 && DBG != 5) { if (m < NP_HI - H) issue_one(s + 3, H + m); }
+            }
+        } else {
+            if constexpr (DBG != 2 && DBG != 5) {
+#pragma unroll
+                for (int m = H; m < NP_HI; ++m) issue_one(s + 3, m);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    vm_wait<0>();
+    if constexpr (DBG == 4) {                       // measurement: the launch without its epilogue
+        float sacc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int t = 0; t < TW; ++t) sacc += acc[r][t][0] + acc[r][t][15];
+        if (sacc == 1.2345e-30f) a.act_xp[0] = 0;
+        return;
+    }
+
+    // ---- epilogues from the accumulators: lane (tl, hh) of tile (row-block, token block) holds rows f = 8 (i/4) + 4 hh + i%4
+    //      of token tl; same arithmetic and rounding points as mb_epilogue_block / the single-block kernels
+    const int tl = lane & 31, hh = lane >> 5;
+    // MB_SWIGLU staging geometry: features [sw_lo, sw_lo + sw_r) of this workgroup, columns shifted by sw_sh = sw_lo % 8 so that
+    // the 16-byte chunks of the activation image are 16-byte aligned in the tile; row stride in elements, never a multiple of 64
+    const int sw_lo = a.gu_interleaved ? 64 * blockIdx.x : a.R * blockIdx.x, sw_r = a.gu_interleaved ? 64 : a.R, sw_sh = sw_lo & 7;
+    const int sw_nch = (sw_sh + sw_r + 7) >> 3;
+    const int sw_stride = (sw_nch * 8) % 64 == 0 ? sw_nch * 8 + 8 : sw_nch * 8;
+    if constexpr (EPI == MB_SWIGLU) __syncthreads();            // every wave is done with the ring
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        const int tbg = tq * TW + t, blk = zb0 + (tbg >> 1), tok = (tbg & 1) * 32 + tl;
+        if (blk >= a.nblk) continue;                // wave-uniform
+        if constexpr (EPI == MB_SLAB) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int gi = 0; gi < 4; ++gi) {
+                    const f32x4 v = {acc[r][t][4 * gi], acc[r][t][4 * gi + 1], acc[r][t][4 * gi + 2], acc[r][t][4 * gi + 3]};
+                    float* o = a.slabs + ((size_t)ks * a.M + blk * 64 + tok) * a.N + (blockIdx.x * RBV + r) * 32 + 8 * gi + 4 * hh;
+                    *(f32x4*)o = v;
+                }
         } else if constexpr (EPI == MB_SWIGLU) {
-            static_assert(EPI != MB_SWIGLU || RBV == 4, "swiglu layout {G0,G1,U0,U1}");
-            // pair slices (q, tb, gi): 16 -> 2 per wave;  act = bf16(silu(bf16(g)) * bf16(u)) (LlamaMLP.forward, :185-186)
+            // act = bf16(silu(bf16(g)) * bf16(u)) (LlamaMLP.forward, :185-186), parked as tile[token][sh + feature - lo] in the
+            // (drained) ring: the activation image keeps 8 consecutive features of a token in one 16-byte chunk, but a balanced
+            // plan starts a workgroup's features anywhere (R = 43 at the 7B shape) — 2-byte stores straight from the MFMA layout
+            // cost ~27 us per launch at 512 rows (L2 write REQUESTS, not bytes); see the store pass below
+            const int nvg = a.nv[rb0];
+            bf16_t* tile = (bf16_t*)lds_raw;
+            const int c0 = sw_sh + 32 * rg;
+            const int trow = (tbg >> 1) * 64 + tok;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int sl = wave * 2 + i, qq = sl >> 3, tb = (sl >> 2) & 1, gi = sl & 3;
-                const int rg = a.gu_interleaved ? 2 * qq : qq, ru = a.gu_interleaved ? 2 * qq + 1 : qq + 2;
-                if (8 * gi + 4 * hh < a.nv[rg]) {
-                    const f32x4 g4 = total4(rg, tb, gi), u4 = total4(ru, tb, gi);
-                    const int tok = tb * 32 + tl;
+            for (int i = 0; i < 16; ++i) {
+                if (8 * (i >> 2) >= nvg) break;                        // wave-uniform: no valid row in this register group
+                const int f = 8 * (i >> 2) + 4 * hh + (i & 3);
+                const float gv = bfr_hw(acc[0][t][i]), uv = bfr_hw(acc[1][t][i]);
+                // silu in fast fp32 (v_exp_f32 + v_rcp_f32, ~1 ulp each): the result is rounded to bf16 right away, and the
+                // libm / IEEE-division forms cost ~60 VALU instructions per element — 64 elements per lane at 512 rows
+                const float sv = bfr_hw(gv * __builtin_amdgcn_rcpf(1.0f + __expf(-gv)));
+                const bf16_t o = f2bf_hw(sv * uv);
+                if (f < nvg) tile[trow * sw_stride + c0 + f] = o;
+            }
+        } else if constexpr (EPI == MB_QKV) {
+            // RoPE in bf16 arithmetic (apply_rotary_pos_emb, modeling_llama.py:154-169); tile 0 = lo halves, tile 1 = hi halves
+            const int ps = a.pos[blk * 64 + tok];
+            if ((a.R & 1) == 0) {
+                // pairs of consecutive rows (an even R keeps them in one head and one 16-byte chunk): 4-byte table loads and stores
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int f = 8 * gi + 4 * hh + j;
-                        if (f < a.nv[rg]) {
-                            const float gv = bfr(g4[j]), uv = bfr(u4[j]);
-                            const float sv = bfr(gv / (1.0f + expf(-gv)));
-                            const int feat = a.gu_interleaved ? (2 * blockIdx.x + qq) * 32 + f : a.R * blockIdx.x + 32 * qq + f;
-                            a.act_xp[(size_t)blk * 64 * a.N + xp_offset(tok, feat)] = f2bf(sv * uv);
+                for (int i = 0; i < 16; i += 2) {
+                    if (8 * (i >> 2) >= a.nv[0]) break;                // wave-uniform
+                    const int f = 8 * (i >> 2) + 4 * hh + (i & 3);
+                    if (f < a.nv[0]) {
+                        const int prr = a.R * blockIdx.x + f, slot = prr >> 6, dlo = prr & 63, dhi = dlo + 64;
+                        if (slot < a.nh + a.nkv) {
+                            bf16_t* dst = slot < a.nh ? a.qf + ((size_t)blk * a.nh + slot) * 8192
+                                                      : a.kfresh + ((size_t)blk * a.nkv + (slot - a.nh)) * 8192;
+                            const uint32_t c2 = *(const uint32_t*)(a.rcos + (size_t)ps * 64 + dlo), s2 = *(const uint32_t*)(a.rsin + (size_t)ps * 64 + dlo);
+                            uint32_t olo = 0, ohi = 0;
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const float cc = bf2f((bf16_t)(c2 >> (16 * e))), sn = bf2f((bf16_t)(s2 >> (16 * e)));
+                                const float bl = bfr_hw(acc[0][t][i + e]), bh = bfr_hw(acc[1][t][i + e]);
+                                olo |= (uint32_t)f2bf_hw(bfr_hw(bl * cc) + bfr_hw(-bh * sn)) << (16 * e);
+                                ohi |= (uint32_t)f2bf_hw(bfr_hw(bh * cc) + bfr_hw(bl * sn)) << (16 * e);
+                            }
+                            *(uint32_t*)(dst + rf_offset(tok, dlo)) = olo;
+                            *(uint32_t*)(dst + rf_offset(tok, dhi)) = ohi;
+                        } else {
+                            bf16_t* dst = a.vfresh + ((size_t)blk * a.nkv + (slot - a.nh - a.nkv)) * 8192;
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                dst[vf_offset(tok, dlo + e)] = f2bf_hw(acc[0][t][i + e]);
+                                dst[vf_offset(tok, dhi + e)] = f2bf_hw(acc[1][t][i + e]);
+                            }
                         }
                     }
                 }
-            }
-        } else if constexpr (EPI == MB_QKV) {
-            static_assert(EPI != MB_QKV || RBV == 2, "qkv layout {lo, hi}");
-            // pair slices (tb, gi): 8 -> 1 per wave; RoPE in bf16 arithmetic (apply_rotary_pos_emb, modeling_llama.py:154-169)
-            const int tb = wave >> 2, gi = wave & 3;
-            const int tok = tb * 32 + tl;
-            if (8 * gi + 4 * hh < a.nv[0]) {
-                const f32x4 xl4 = total4(0, tb, gi), xh4 = total4(1, tb, gi);
-                const int ps = a.pos[blk * 64 + tok];
+            } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int f = 8 * gi + 4 * hh + j;
+                for (int i = 0; i < 16; ++i) {
+                    const int f = 8 * (i >> 2) + 4 * hh + (i & 3);
                     if (f < a.nv[0]) {
                         const int prr = a.R * blockIdx.x + f, slot = prr >> 6, dlo = prr & 63, dhi = dlo + 64;
-                        const float xl = xl4[j], xh = xh4[j];
+                        const float xl = acc[0][t][i], xh = acc[1][t][i];
                         if (slot < a.nh + a.nkv) {
                             bf16_t* dst = slot < a.nh ? a.qf + ((size_t)blk * a.nh + slot) * 8192
                                                       : a.kfresh + ((size_t)blk * a.nkv + (slot - a.nh)) * 8192;
                             const float cc = bf2f(a.rcos[(size_t)ps * 64 + dlo]), sn = bf2f(a.rsin[(size_t)ps * 64 + dlo]);
-                            const float bl = bfr(xl), bh = bfr(xh);
-                            dst[rf_offset(tok, dlo)] = f2bf(bfr(bl * cc) + bfr(-bh * sn));
-                            dst[rf_offset(tok, dhi)] = f2bf(bfr(bh * cc) + bfr(bl * sn));
+                            const float bl = bfr_hw(xl), bh = bfr_hw(xh);
+                            dst[rf_offset(tok, dlo)] = f2bf_hw(bfr_hw(bl * cc) + bfr_hw(-bh * sn));
+                            dst[rf_offset(tok, dhi)] = f2bf_hw(bfr_hw(bh * cc) + bfr_hw(bl * sn));
                         } else {
                             bf16_t* dst = a.vfresh + ((size_t)blk * a.nkv + (slot - a.nh - a.nkv)) * 8192;
-                            dst[vf_offset(tok, dlo)] = f2bf(xl);
-                            dst[vf_offset(tok, dhi)] = f2bf(xh);
+                            dst[vf_offset(tok, dlo)] = f2bf_hw(xl);
+                            dst[vf_offset(tok, dhi)] = f2bf_hw(xh);
                         }
                     }
                 }
             }
         } else {
-            static_assert(EPI != MB_LOGITS || RBV == 4, "logits layout");
-            // wave -> token block w&1, row-block w>>1, all four register groups; one argmax candidate per (wave, token)
-            const int tb = wave & 1, rq = wave >> 1;
-            const int tok = tb * 32 + tl;
-            float best = -INFINITY;
-            int bidx = 0x7fffffff;
+            // lm_head: bf16 logits + one argmax candidate per (row-block, token)
 #pragma unroll
-            for (int gi = 0; gi < 4; ++gi) {
-                if (8 * gi + 4 * hh < a.nv[rq]) {
-                    const f32x4 t4 = total4(rq, tb, gi);
+            for (int r = 0; r < 2; ++r) {
+                const int rq = r == 0 ? rb0 : rb1;
+                float best = -INFINITY;
+                int bidx = 0x7fffffff;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int f = 8 * gi + 4 * hh + j;
-                        if (f < a.nv[rq]) {
-                            const bf16_t hv = f2bf(t4[j]);
-                            const int idx = a.R * blockIdx.x + 32 * rq + f;
-                            if (a.logits) a.logits[((size_t)blk * 64 + tok) * a.N + idx] = hv;
-                            const float v = bf2f(hv);
-                            if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
-                        }
+                for (int i = 0; i < 16; ++i) {
+                    const int f = 8 * (i >> 2) + 4 * hh + (i & 3);
+                    if (f < a.nv[rq]) {
+                        const bf16_t hv = f2bf(acc[r][t][i]);
+                        const int idx = a.R * blockIdx.x + 32 * rq + f;
+                        if (a.logits) a.logits[((size_t)blk * 64 + tok) * a.N + idx] = hv;
+                        const float v = bf2f(hv);
+                        if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
                     }
                 }
+                float ob = __shfl_xor(best, 32, 64);
+                int oi = __shfl_xor(bidx, 32, 64);
+                if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+                if (hh == 0) {
+                    const size_t slot = ((size_t)blk * gridDim.x + blockIdx.x) * 4 + rq;
+                    a.cand_val[slot * 64 + tok] = best;
+                    a.cand_idx[slot * 64 + tok] = bidx;
+                }
             }
-            float ob = __shfl_xor(best, 32, 64);
-            int oi = __shfl_xor(bidx, 32, 64);
-            if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-            if (hh == 0) {
-                const size_t slot = ((size_t)blk * gridDim.x + blockIdx.x) * 4 + rq;
-                a.cand_val[slot * 64 + tok] = best;
-                a.cand_idx[slot * 64 + tok] = bidx;
+        }
+    }
+    if constexpr (EPI == MB_SWIGLU) {
+        // store pass: one (token, 16-byte chunk) item per lane and step — 32 consecutive tokens of a lane group are 512
+        // contiguous bytes of the activation image; the first / last chunk of a token may be shared with the neighbour workgroups
+        __syncthreads();
+        const bf16_t* tile = (const bf16_t*)lds_raw;
+        const int ntok = GEO::BLOCKS * 64;
+        for (int it = threadIdx.x; it < ntok * sw_nch; it += 512) {
+            const int trow = it % ntok, c = it / ntok, blk = zb0 + (trow >> 6);
+            if (blk >= a.nblk) continue;
+            const int fa_ = (sw_lo & ~7) + 8 * c;                        // first feature of the chunk
+            bf16_t* dst = a.act_xp + (size_t)blk * 64 * a.N + xp_offset(trow & 63, fa_);
+            const bf16_t* srcp = tile + trow * sw_stride + 8 * c;
+            if (fa_ >= sw_lo && fa_ + 8 <= sw_lo + sw_r) {
+                *(bf16x8*)dst = *(const bf16x8*)srcp;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (fa_ + e >= sw_lo && fa_ + e < sw_lo + sw_r) dst[e] = srcp[e];
             }
         }
     }
@@ -963,6 +1323,9 @@ __global__ __launch_bounds__(256) void k_kv_commit_mb(const bf16_t* __restrict__
 // launchers
 // =============================================================================================================
 static bool g_mb_attr = false;
+int g_la_mb_dbg = 0;
+int g_la_mb_mode = 0;         // la_debug_set key 5: 1 = wide kernel as two co-resident workgroups per CU (80 KiB LDS, 256 rows each)
+int g_la_mb_narrow = 0;       // la_debug_set key 3: 1 = the K-split kernels (k_gemm_mb) for every nblk (A/B measurements)
 template <typename K> static hipError_t set_lds(K k, int bytes) {
     return hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
@@ -978,6 +1341,20 @@ int lk_mb_init() {
     if (e == hipSuccess) e = set_lds(k_gemm_mb<4, NT, MB_LOGITS>, mb_lds(NT));
     SETALL(2) SETALL(4) SETALL(8)
 #undef SETALL
+#define SETW4(T) \
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_SWIGLU>, WideGeom<4, T>::LDS); \
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_LOGITS>, WideGeom<4, T>::LDS);
+#define SETW2(T) \
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<2, T, MB_SLAB>, WideGeom<2, T>::LDS); \
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<2, T, MB_QKV>, WideGeom<2, T>::LDS);
+    SETW4(2) SETW4(3) SETW4(4) SETW2(1) SETW2(2)
+#undef SETW4
+#undef SETW2
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 1>, WideGeom<4, 4>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 2>, WideGeom<4, 4>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 3>, WideGeom<4, 4>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 4>, WideGeom<4, 4>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 5>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_tree_attn_mb, 8 * 66 * 64 * 4);
     if (e != hipSuccess) return (int)e;
     g_mb_attr = true;
@@ -1041,6 +1418,31 @@ int lk_mb_cand_slots(int n_wg) { return n_wg * 4; }
 
 template <int RBV, int EPI>
 static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int nblk) {
+    // nblk >= 3: every token block in ONE weight pass (k_gemm_wide): RBV = 4 -> 4 TW token blocks per workgroup, RBV = 2 -> 8 TW
+    if (nblk >= 3 && !g_la_mb_narrow) {
+        const dim3 grid(n_wg, ksplit, 1);
+        if constexpr (RBV == 4 && EPI == MB_SWIGLU) {           // measurement builds of the 512-row gate/up launch (la_debug_set key 4)
+            if (g_la_mb_dbg && nblk >= 7) {
+                if (g_la_mb_dbg == 1) k_gemm_wide<4, 4, MB_SWIGLU, 1><<<grid, 512, WideGeom<4, 4>::LDS, st>>>(a);
+                else if (g_la_mb_dbg == 2) k_gemm_wide<4, 4, MB_SWIGLU, 2><<<grid, 512, WideGeom<4, 4>::LDS, st>>>(a);
+                else if (g_la_mb_dbg == 3) k_gemm_wide<4, 4, MB_SWIGLU, 3><<<grid, 512, WideGeom<4, 4>::LDS, st>>>(a);
+                else if (g_la_mb_dbg == 4) k_gemm_wide<4, 4, MB_SWIGLU, 4><<<grid, 512, WideGeom<4, 4>::LDS, st>>>(a);
+                else k_gemm_wide<4, 4, MB_SWIGLU, 5><<<grid, 512, WideGeom<4, 4>::LDS, st>>>(a);
+                LAUNCH_CHECK(); return 0;
+            }
+        }
+        if constexpr (RBV == 4) {
+            switch ((nblk + 1) / 2) {
+                case 2: k_gemm_wide<4, 2, EPI><<<grid, 512, WideGeom<4, 2>::LDS, st>>>(a); break;
+                case 3: k_gemm_wide<4, 3, EPI><<<grid, 512, WideGeom<4, 3>::LDS, st>>>(a); break;
+                default: k_gemm_wide<4, 4, EPI><<<grid, 512, WideGeom<4, 4>::LDS, st>>>(a); break;
+            }
+        } else {
+            if (nblk <= 4) k_gemm_wide<2, 1, EPI><<<dim3(n_wg, ksplit, (nblk + 3) / 4), 512, WideGeom<2, 1>::LDS, st>>>(a);
+            else k_gemm_wide<2, 2, EPI><<<grid, 512, WideGeom<2, 2>::LDS, st>>>(a);
+        }
+        LAUNCH_CHECK(); return 0;
+    }
     // token blocks per pass: the smallest template that covers the step in <= 2 passes
     if (nblk <= 1) { k_gemm_mb<RBV, 2, EPI><<<dim3(n_wg, ksplit, 1), 512, mb_lds(2), st>>>(a); }
     else if (nblk == 2) { k_gemm_mb<RBV, 4, EPI><<<dim3(n_wg, ksplit, 1), 512, mb_lds(4), st>>>(a); }

@@ -196,6 +196,53 @@ def sweep(hidden=4096, ffn=11008, nh=32, nkv=32, vocab=32000):
     check(lib.la_debug_set(1, 0), 'kskew')
 
 
+def prio(hidden=4096, ffn=11008, nh=32, nkv=32, vocab=32000):
+    """s_setprio for waves 4..7 of the 8-wave kernels (la_debug_set key 2): does issue priority even out the two waves of a SIMD?"""
+    g = torch.Generator(device=DEV).manual_seed(1)
+
+    def rnd(n, k):
+        return (torch.randn(n, k, generator=g, device=DEV, dtype=torch.float32) * 0.05).to(torch.bfloat16)
+    xp = gu.pack_x(rnd(64, hidden))
+    wps = [gu.pack_planned(1, [rnd(ffn, hidden), rnd(ffn, hidden)], NWG) for _ in range(NBUF)]
+    act = torch.zeros(64 * ffn, dtype=torch.bfloat16, device=DEV)
+    fn = lambda i: lib.la_gemm64r_swiglu(sp(), ptr(wps[i % NBUF]), ptr(xp), ffn, hidden, NWG, ptr(act))
+    for pr in (0, 1, 2, 3, 0):
+        check(lib.la_debug_set(2, pr), 'prio')
+        print(f'gate/up prio_hi={pr}: {timeit(fn):7.2f} us', flush=True)
+    check(lib.la_debug_set(2, 1), 'prio')
+    timeline('gate/up prio_hi=1', fn, NWG, 8)
+    del wps
+    N = (nh + 2 * nkv) * 128
+    wps = [gu.pack_planned(2, [rnd(N, hidden)], NWG) for _ in range(NBUF)]
+    pos = torch.arange(64, device=DEV, dtype=torch.int32) + 600
+    rc, rs_ = rope_tables(128, 2048, 10000.0, DEV)
+    qf = torch.zeros(nh * 8192, dtype=torch.bfloat16, device=DEV)
+    kf = torch.zeros(nkv * 8192, dtype=torch.bfloat16, device=DEV)
+    vf = torch.zeros(nkv * 8192, dtype=torch.bfloat16, device=DEV)
+    fq = lambda i: lib.la_gemm64r_qkv(sp(), ptr(wps[i % NBUF]), ptr(xp), nh, nkv, hidden, NWG, ptr(pos), ptr(rc), ptr(rs_), ptr(qf), ptr(kf), ptr(vf))
+    for pr in (0, 1, 2, 3, 0):
+        check(lib.la_debug_set(2, pr), 'prio')
+        print(f'qkv     prio_hi={pr}: {timeit(fq):7.2f} us', flush=True)
+    del wps
+    wps = [gu.pack_planned(0, [rnd(vocab, hidden)], NWG) for _ in range(NBUF)]
+    logits = torch.zeros(64 * vocab, dtype=torch.bfloat16, device=DEV)
+    cv = torch.zeros(NWG * 8 * 64, dtype=torch.float32, device=DEV)
+    ci = torch.zeros(NWG * 8 * 64, dtype=torch.int32, device=DEV)
+    fl = lambda i: lib.la_gemm64r_logits(sp(), ptr(wps[i % NBUF]), ptr(xp), vocab, hidden, NWG, ptr(logits), ptr(cv), ptr(ci))
+    for pr in (0, 1, 3, 0):
+        check(lib.la_debug_set(2, pr), 'prio')
+        print(f'lm_head prio_hi={pr}: {timeit(fl):7.2f} us', flush=True)
+    del wps
+    slabs = torch.zeros(8 * 64 * hidden, dtype=torch.float32, device=DEV)
+    wps = [gu.pack_weight(rnd(hidden, nh * 128)) for _ in range(NBUF * 3)]
+    nb = len(wps)
+    fo = lambda i: lib.la_gemm64_slab(sp(), ptr(wps[i % nb]), ptr(xp), hidden, nh * 128, 2 | (3 << 8), 4, ptr(slabs))
+    for pr in (0, 1, 3, 0):
+        check(lib.la_debug_set(2, pr), 'prio')
+        print(f'o_proj  prio_hi={pr}: {timeit(fo):7.2f} us', flush=True)
+    check(lib.la_debug_set(2, 0), 'prio')
+
+
 def small(hidden=4096, nh=32, nkv=32):
     g = torch.Generator(device=DEV).manual_seed(2)
     h = torch.randn(64, hidden, generator=g, device=DEV).to(torch.bfloat16)
@@ -265,3 +312,5 @@ if __name__ == '__main__':
         small()
     if 'sweep' in which:
         sweep()
+    if 'prio' in which:
+        prio()
