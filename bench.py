@@ -431,7 +431,7 @@ def main():
         mfma_frac = step_flops / (ms_step * 1e-3) / 1e12 / 2500.0
         bound = 'mfma' if mfma_frac >= hbm_frac else 'hbm'
         roofline = {
-            'bound': bound, 'kernel': 'whole multi-block verify step (k_gemm_mb family + k_tree_attn_mb), M = %d rows' % (64 * B),
+            'bound': bound, 'kernel': 'whole multi-block verify step (k_gemm_wide / k_gemm_mb + k_tree_attn_mb), M = %d rows' % (64 * B),
             'achieved': round(step_flops / (ms_step * 1e-3) / 1e12, 1) if bound == 'mfma' else round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
             'peak': 2500.0 if bound == 'mfma' else HBM_PEAK_GBS, 'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
             'frac': round(max(mfma_frac, hbm_frac), 4), 'traffic': None,
