@@ -28,8 +28,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // round-to-nearest-even, NaN preserving: same rounding torch uses for float -> bfloat16
-// (branch-free: an early return for NaN made hipcc wrap every conversion of an unrolled epilogue in its own exec-mask region)
-__device__ __forceinline__ bf16_t f2bf(float f) {
+// (the gfx950 converter v_cvt_pk_bf16_f32: IEEE round-to-nearest-even, quiet NaN — one instruction; the integer form
+//  u + 0x7fff + ((u >> 16) & 1) it replaces is kept as f2bf_int for the host-visible packers' reference)
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ bf16_t f2bf_int(float f) {
     const uint32_t u = __float_as_uint(f);
     const uint32_t r = u + 0x7fffu + ((u >> 16) & 1u);
     const bool nan = (u & 0x7fffffffu) > 0x7f800000u;

@@ -1070,7 +1070,9 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int kk = (i & 3) + 8 * (i >> 2) + 4 * hh;
-            float v = bfr(__fdiv_rn(bfr(sc[i]), 11.313708498984761f));
+            // bf16(x / sqrt(128)) == bf16(x * fp32(1 / sqrt(128))) for EVERY finite bf16 x (checked exhaustively over the 65536 bit
+            // patterns, tests/test_oracle_llama.py::test_attention_scale_as_multiply_is_exact): one multiply instead of an IEEE division
+            float v = bfr(bfr(sc[i]) * 0.088388346135616302490234375f);
             bool ok;
             if (own) ok = ((rm >> (kb * 32 + kk)) & 1ull) != 0ull;
             else if (prior) { const int kpos = nkeys + (it - NP) * 32 + kk; ok = mine && kpos >= key_lo; }
@@ -1093,10 +1095,14 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
         ps += __shfl_xor(ps, 32, 64);
         l = l * alpha + ps;
         m = mn;
+        if (__ballot(alpha != 1.0f) != 0ull) {          // the running maxima moved for some row: rescale (x * 1.0f is exact, so skipping is too)
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+        }
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
             o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db * 2 + 0], pf[0], o[db], 0, 0, 0);
             o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db * 2 + 1], pf[1], o[db], 0, 0, 0);
         }

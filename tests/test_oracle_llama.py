@@ -197,3 +197,16 @@ def test_oracle_loop_matches_reference_run_with_partial_accepts(tag, dtype):
                 assert [int(x) for x in st['rows']] == [int(x) for x in g[f'r{r}_s{i}_rows']], (r, i)
         partial += sum(1 < e < 13 for e in out['edls'][1:])
     assert partial >= 20
+
+
+def test_attention_scale_as_multiply_is_exact():
+    """The HIP attention kernels compute bf16(scores / sqrt(head_dim)) (modeling_llama.py:270) as bf16(x * fp32(1/sqrt(128))): the two
+    agree for every finite bf16 x, so the multiply is a bit-exact restatement (head_dim = 128 is the only one the kernels serve)."""
+    import numpy as np
+    import torch
+    bits = (np.arange(65536, dtype=np.uint32) << 16)
+    x = torch.from_numpy(bits.view(np.float32).copy())
+    fin = torch.isfinite(x)
+    div = (x / 11.313708498984761).to(torch.bfloat16).view(torch.int16)
+    mul = (x * torch.tensor(np.float32(0.088388346135616302490234375))).to(torch.bfloat16).view(torch.int16)
+    assert bool((div[fin] == mul[fin]).all())
