@@ -1008,6 +1008,7 @@ struct MbAttnArgs {
     const int* meta;
     int nh, nkv, total_keys, slot_tiles, nsplit, window, ring;      // ring: the slot's main cache is a ring of slot_tiles tiles
     float* opart; float* mpart; float* lpart;          // [blk][nh][nsplit][64][128] ...
+    bf16_t* attn_xp;                                   // nsplit == 1: the normalised output goes straight into o_proj's operand image
 };
 #define MB_NEG (-1.0e30f)
 __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
@@ -1158,6 +1159,23 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) v += mgbuf[(size_t)(((p * 2 + tb) * 66) + par * 16 + i) * 64 + lane] * wp[p];
         od[i] = v;
+    }
+    if (a.attn_xp) {
+        // one key split: what k_attn_combine_mb<1> would compute from the partial — bf16(o * (1 / L)), zeros for rows past T —
+        // written here (8 bytes = 4 head dims per lane), one launch and the fp32 partial round trip less per layer
+        const float inv = 1.0f / L;
+        bf16_t* dst = a.attn_xp + (size_t)blk * 64 * a.nh * 128;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint32_t lo = 0, hi2 = 0;
+            if (row < T) {
+                lo = (uint32_t)f2bf(od[4 * g] * inv) | ((uint32_t)f2bf(od[4 * g + 1] * inv) << 16);
+                hi2 = (uint32_t)f2bf(od[4 * g + 2] * inv) | ((uint32_t)f2bf(od[4 * g + 3] * inv) << 16);
+            }
+            uint2 v; v.x = lo; v.y = hi2;
+            *(uint2*)(dst + xp_offset(row, h * 128 + par * 32 + 8 * g + 4 * hh)) = v;
+        }
+        return;
     }
     const size_t pidx = (((size_t)blk * a.nh + h) * a.nsplit + sp) * 64 + row;
     float* op = a.opart + pidx * 128;
@@ -1533,8 +1551,10 @@ int lk_mb_tree_attn(hipStream_t st, const void* qf, const void* kmain, const voi
     a.rowmask = (const unsigned long long*)rowmask; a.meta = meta;
     a.nh = nh; a.nkv = nkv; a.total_keys = slot_keys * n_slots; a.slot_tiles = slot_keys >> 5; a.nsplit = nsplit; a.window = window; a.ring = ring;
     a.opart = opart; a.mpart = mpart; a.lpart = lpart;
+    a.attn_xp = nsplit == 1 ? (bf16_t*)attn_xp : nullptr;
     k_tree_attn_mb<<<dim3(nh, nsplit, nblk), 512, 8 * 66 * 64 * sizeof(float), st>>>(a);
     LAUNCH_CHECK();
+    if (nsplit == 1) return 0;
     const int total = nh * 64 * 16;
 #define AC(NS) k_attn_combine_mb<NS><<<dim3((total + 255) / 256, nblk), 256, 0, st>>>(opart, mpart, lpart, nh, meta, (bf16_t*)attn_xp)
     switch (nsplit) {
