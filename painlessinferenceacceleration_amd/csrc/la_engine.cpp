@@ -52,6 +52,10 @@ struct la_llama {
     int *mb_cand_idx, *mb_meta, *mb_pos, *mb_ids, *mb_in, *mb_out;
     uint16_t *mb_moe_acc, *mb_act_ex;     // MoE: accumulated expert outputs [M][hidden], per-expert SwiGLU outputs [E][M x ffn]
     float *mb_route_w, *mb_slabs_ex;      // routing weights [M][LA_MOE_MAX_E], per-expert down-projection slabs [E][ks][M][hidden]
+    // gathered MoE (nblk >= 2): rows per expert [E][512], position of a row in each expert's list [M][8], {rows, blocks} per expert,
+    // per-expert packed inputs [E][M x hidden]
+    int *mb_moe_perm, *mb_moe_pos, *mb_moe_cnt;
+    uint16_t* mb_xg;
     uint64_t* mb_rowmask;
     size_t mb_fresh_layer;
     hipGraphExec_t mgraphs[LA_MB_MAX + 1];
@@ -183,6 +187,10 @@ static size_t carve(la_llama* m, char* base) {
         m->mb_act_ex = cv.take<uint16_t>(E ? E * R * c.ffn : 8);
         m->mb_route_w = cv.take<float>(E ? R * LA_MOE_MAX_E : 8);
         m->mb_slabs_ex = cv.take<float>(E ? E * m->down_ks * R * c.hidden : 8);
+        m->mb_moe_perm = cv.take<int>(E ? E * LA_MB_MAX * 64 : 8);
+        m->mb_moe_pos = cv.take<int>(E ? R * LA_MOE_MAX_E : 8);
+        m->mb_moe_cnt = cv.take<int>(2 * LA_MOE_MAX_E);
+        m->mb_xg = cv.take<uint16_t>(E ? E * R * c.hidden : 8);
     }
     return align_up(cv.off, 256);
 }
@@ -527,17 +535,26 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk) {
             KCHK(lk_mb_resid_norm_router(st, m->mb_h, m->mb_slabs, m->o_ks, npass_rows, L.norm2, c.hidden, c.rms_eps, m->mb_xp, M, cf,
                                          L.router, c.n_experts, c.top_k, m->mb_route_w, m->mb_meta));
             const size_t act_stride = (size_t)LA_MB_MAX * 64 * c.ffn, slab_stride = (size_t)m->down_ks * npass_rows * c.hidden;
+            // M >= 128: every expert works on the rows it received, packed into their own blocks (la_mblock.hip "Gathered MoE")
+            const bool gathered = nblk >= 2;
+            const long xg_stride = (long)LA_MB_MAX * 64 * c.hidden;
+            if (gathered) {
+                KCHK(lk_mb_moe_plan(st, m->mb_route_w, M, c.n_experts, m->mb_moe_perm, m->mb_moe_pos, m->mb_moe_cnt));
+                KCHK(lk_mb_moe_gather(st, m->mb_xp, m->mb_moe_perm, m->mb_moe_cnt, c.hidden, nblk, c.n_experts, m->mb_xg, xg_stride));
+            }
             for (int e = 0; e < c.n_experts; ++e) {
-                MbGemm g{}; g.wp = m->ex_gateup[(size_t)l * c.n_experts + e]; g.xp = m->mb_xp; g.N = c.ffn; g.K = c.hidden; g.nblk = nblk;
-                g.n_wg = c.balanced_wg[1]; g.ksplit = 1; g.act_xp = m->mb_act_ex + e * act_stride; g.route_col = m->mb_route_w + e;
+                MbGemm g{}; g.wp = m->ex_gateup[(size_t)l * c.n_experts + e]; g.xp = gathered ? m->mb_xg + e * xg_stride : m->mb_xp;
+                g.N = c.ffn; g.K = c.hidden; g.nblk = nblk;
+                g.n_wg = c.balanced_wg[1]; g.ksplit = 1; g.act_xp = m->mb_act_ex + e * act_stride;
+                if (gathered) g.nblk_dev = m->mb_moe_cnt + LA_MOE_MAX_E + e; else g.route_col = m->mb_route_w + e;
                 KCHK(lk_mb_gemm(st, 1, g));
                 MbGemm d{}; d.wp = m->ex_down[(size_t)l * c.n_experts + e]; d.xp = m->mb_act_ex + e * act_stride; d.N = c.hidden; d.K = c.ffn;
                 d.nblk = nblk; d.ksplit = m->down_ks; d.slabs = m->mb_slabs_ex + e * slab_stride; d.slab_rows = npass_rows;
-                d.route_col = m->mb_route_w + e;
+                if (gathered) d.nblk_dev = m->mb_moe_cnt + LA_MOE_MAX_E + e; else d.route_col = m->mb_route_w + e;
                 KCHK(lk_mb_gemm(st, 0, d));
             }
             KCHK(lk_mb_moe_accum(st, m->mb_slabs_ex, (long)slab_stride, m->down_ks, npass_rows, m->mb_route_w, c.n_experts, c.hidden,
-                                 m->mb_moe_acc, M));
+                                 m->mb_moe_acc, M, gathered ? m->mb_moe_pos : nullptr));
             KCHK(lk_mb_resid_norm_addend(st, m->mb_h, m->mb_moe_acc, nw, c.hidden, c.rms_eps, m->mb_xp, M, cf));
             continue;
         }

@@ -36,13 +36,17 @@ struct MbGemm {
     void* logits; float* cand_val; int* cand_idx;
     const int* pos; const void* rcos; const void* rsin; void* qf; void* kfresh; void* vfresh; int nh, nkv;
     const float* route_col;            // MoE: this expert's routing weights (stride LA_MOE_MAX_E floats per row); null = dense
+    const int* nblk_dev;               // gathered MoE: the expert's block count on the device (nblk = the upper bound); null = nblk
 };
 int lk_mb_gemm(hipStream_t st, int kind, const MbGemm& g);
 int lk_mb_resid_norm_router(hipStream_t st, void* h, const float* slabs, int n_slabs, int slab_rows, const void* nw, int hidden, float eps,
                             void* xp, int M, int cast_first, const void* wrouter, int n_experts, int top_k, float* route_w, const int* meta);
 int lk_mb_resid_norm_addend(hipStream_t st, void* h, const void* addend, const void* nw, int hidden, float eps, void* xp, int M, int cast_first);
 int lk_mb_moe_accum(hipStream_t st, const float* slabs0, long slab_stride, int n_slabs, int slab_rows, const float* route_w, int E, int hidden,
-                    void* acc, int M);
+                    void* acc, int M, const int* pos);
+// gathered MoE: perm [E][LA_MB_MAX*64], pos [M][LA_MOE_MAX_E], cnt_nb [2][LA_MOE_MAX_E] = {rows, 64-row blocks} per expert
+int lk_mb_moe_plan(hipStream_t st, const float* route_w, int M, int E, int* perm, int* pos, int* cnt_nb);
+int lk_mb_moe_gather(hipStream_t st, const void* xp, const int* perm, const int* cnt_nb, int hidden, int nblk, int E, void* xg, long xg_stride);
 int lk_mb_cand_slots(int n_wg);
 int lk_mb_logits_wgs(int V, int n_wg);
 int lk_mb_argmax(hipStream_t st, const float* cv, const int* ci, int n_tiles, int nblk, int* out_rows);

@@ -37,6 +37,8 @@ struct MbArgs {
     // mixture-of-experts: routing weights of THIS expert, one float per row at stride LA_MOE_MAX_E; when no row of the step routes
     // to the expert the launch returns at once and its weights are never read
     const float* route_col; int route_rows;
+    // gathered MoE (k_moe_plan_mb): the number of 64-row blocks this expert received, decided on the device
+    const int* nblk_dev;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -176,6 +178,8 @@ __global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rb = wave % RBV, kp = wave / RBV;
     const int blk0 = blockIdx.z * (NT / 2);
+    const int nblk = a.nblk_dev ? __builtin_amdgcn_readfirstlane(*a.nblk_dev) : a.nblk;
+    if (blk0 >= nblk) return;                   // a pass with no block of this expert: its weights are never read
     const int ksplit = gridDim.y, ks = blockIdx.y;
     const int t0 = (int)(((long)a.K16 * ks) / ksplit), t1 = (int)(((long)a.K16 * (ks + 1)) / ksplit);
     const int twg = t1 - t0, pq = twg / KP, pr = twg - pq * KP;
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
         xpart_cnt[i] = pq + (part < pr ? 1 : 0);
         xj[i] = j;
         int xb = blk0 + (tbk >> 1);
-        xb = xb < a.nblk ? xb : a.nblk - 1;         // surplus blocks of a padded pass re-read the last real block (results dropped)
+        xb = xb < nblk ? xb : nblk - 1;             // surplus blocks of a padded pass re-read the last real block (results dropped)
         xconst[i] = (unsigned)(((xb * a.K16) * 2 + (tbk & 1)) * 64 + lane);
     }
     auto xload = [&](int s, bf16x8 (&xr)[FPW]) {
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
 #pragma unroll
     for (int c = 0; c < NT / 2; ++c) {
         const int blk = blk0 + c;
-        if (blk >= a.nblk) break;                   // surplus blocks of a padded pass (workgroup-uniform)
+        if (blk >= nblk) break;                     // surplus blocks of a padded pass (workgroup-uniform)
         if (c) __syncthreads();
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb)
@@ -920,19 +924,72 @@ __global__ __launch_bounds__(512) void k_row_norm_addend_mb(bf16_t* __restrict__
 
 // MoE accumulation over M rows (MixtralSparseMoeBlock.forward :731-756): final[t] = sum over the experts row t is routed to, in
 // expert-index order, of bf16(bf16(expert_out[t]) * w[t][e]) (index_add_ into a bf16 buffer).  Same arithmetic as k_moe_accum_all.
+// ---------------------------------------------------------------------------------------------------------------
+// Gathered MoE (M >= 128 rows): instead of running every expert over ALL rows (4x the MLP flops at top-2 of 8), the rows an
+// expert received are packed into their own 64-row blocks (ascending row order -> deterministic), the expert's GEMMs run over
+// ceil(count / 64) blocks (decided on the device: MbArgs.nblk_dev), and the accumulation reads row t's result at its position
+// in each selected expert's block list.  Same arithmetic per row as the dense form (MixtralSparseMoeBlock.forward:
+// index_add of routing_weight * expert(x) in expert order).
+//   k_moe_plan_mb: one workgroup; perm[e][i] = i-th row routed to e, pos[t][e] = i (or -1), cnt[e], nb[e] = ceil(cnt / 64)
+//   k_moe_gather_mb: grid (E, blocks): the packed activation image of block j of expert e, 16-byte chunks (token, 8 features)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_moe_plan_mb(const float* __restrict__ route_w, int M, int n_experts, int* __restrict__ perm,
+                                                      int* __restrict__ pos, int* __restrict__ cnt_nb) {
+    __shared__ int wsum[8];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int e = 0; e < n_experts; ++e) {
+        const bool on = t < M && route_w[(size_t)t * LA_MOE_MAX_E + e] != 0.f;
+        const unsigned long long bal = __ballot(on);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int base = 0, total = 0;
+        for (int w = 0; w < 8; ++w) { if (w < wave) base += wsum[w]; total += wsum[w]; }
+        if (t < M) pos[(size_t)t * LA_MOE_MAX_E + e] = on ? base + before : -1;
+        if (on) perm[(size_t)e * (LA_MB_MAX * 64) + base + before] = t;
+        if (t == 0) { cnt_nb[e] = total; cnt_nb[LA_MOE_MAX_E + e] = (total + 63) >> 6; }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(512) void k_moe_gather_mb(const bf16_t* __restrict__ xp, const int* __restrict__ perm, const int* __restrict__ cnt_nb,
+                                                        int hidden, bf16_t* __restrict__ xg, long xg_stride) {
+    const int e = blockIdx.x, j = blockIdx.y;
+    const int cnt = cnt_nb[e];
+    if (j * 64 >= cnt) return;
+    __shared__ int rows[64];
+    if (threadIdx.x < 64) rows[threadIdx.x] = j * 64 + threadIdx.x < cnt ? perm[(size_t)e * (LA_MB_MAX * 64) + j * 64 + threadIdx.x] : -1;
+    __syncthreads();
+    const size_t blk_elems = (size_t)64 * hidden;
+    bf16x8* dst = (bf16x8*)(xg + (size_t)e * xg_stride + (size_t)j * blk_elems);
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    // chunk index inside a block image: ((k-tile * 2 + token block) * 64 + lane'), lane' = (token & 31) + 32 * ((k >> 3) & 1)
+    for (int c = threadIdx.x; c < 64 * (hidden >> 3); c += 512) {
+        const int lp = c & 63, tbk = (c >> 6) & 1, kt = c >> 7;
+        const int tok = tbk * 32 + (lp & 31);
+        const int r = rows[tok];
+        bf16x8 v = z;
+        if (r >= 0) {
+            const int sb = r >> 6, st = r & 63;
+            v = *((const bf16x8*)(xp + (size_t)sb * blk_elems) + ((kt * 2 + (st >> 5)) * 64 + (st & 31) + 32 * (lp >> 5)));
+        }
+        dst[c] = v;
+    }
+}
+
 template <int NS>
 __global__ __launch_bounds__(256) void k_moe_accum_mb(const float* __restrict__ slabs, long ex_slab, int slab_rows,
                                                        const float* __restrict__ route_w, int n_experts, int hidden,
-                                                       bf16_t* __restrict__ acc) {
+                                                       bf16_t* __restrict__ acc, const int* __restrict__ pos) {
     const int t = blockIdx.x;
-    int sel[4];
+    int sel[4], srow[4];
     float wsel[4];
     int ns = 0;
     for (int e = 0; e < n_experts && ns < 4; ++e) {
         const float w = route_w[(size_t)t * LA_MOE_MAX_E + e];
-        if (w != 0.f) { sel[ns] = e; wsel[ns] = w; ++ns; }
+        if (w != 0.f) { sel[ns] = e; wsel[ns] = w; srow[ns] = pos ? pos[(size_t)t * LA_MOE_MAX_E + e] : t; ++ns; }
     }
-    for (int k = ns; k < 4; ++k) { sel[k] = 0; wsel[k] = 0.f; }
+    for (int k = ns; k < 4; ++k) { sel[k] = 0; wsel[k] = 0.f; srow[k] = 0; }
     for (int c = threadIdx.x; c < (hidden >> 3); c += 256) {
         f32x4 v[4][NS][2];
 #pragma unroll
@@ -940,7 +997,7 @@ __global__ __launch_bounds__(256) void k_moe_accum_mb(const float* __restrict__ 
             if (k < ns) {
 #pragma unroll
                 for (int s2 = 0; s2 < NS; ++s2) {
-                    const float* sp = slabs + (size_t)sel[k] * ex_slab + ((size_t)s2 * slab_rows + t) * hidden + c * 8;
+                    const float* sp = slabs + (size_t)sel[k] * ex_slab + ((size_t)s2 * slab_rows + srow[k]) * hidden + c * 8;
                     v[k][s2][0] = *(const f32x4*)sp;
                     v[k][s2][1] = *(const f32x4*)(sp + 4);
                 }
@@ -1426,10 +1483,20 @@ int lk_mb_resid_norm_addend(hipStream_t st, void* h, const void* addend, const v
     k_row_norm_addend_mb<<<M, 512, 0, st>>>((bf16_t*)h, (const bf16_t*)addend, (const bf16_t*)nw, hidden, eps, (bf16_t*)xp, cast_first);
     LAUNCH_CHECK(); return 0;
 }
+int lk_mb_moe_plan(hipStream_t st, const float* route_w, int M, int E, int* perm, int* pos, int* cnt_nb) {
+    if (M < 1 || M > LA_MB_MAX * 64 || E < 1 || E > LA_MOE_MAX_E) return -1;
+    k_moe_plan_mb<<<1, 512, 0, st>>>(route_w, M, E, perm, pos, cnt_nb);
+    LAUNCH_CHECK(); return 0;
+}
+int lk_mb_moe_gather(hipStream_t st, const void* xp, const int* perm, const int* cnt_nb, int hidden, int nblk, int E, void* xg, long xg_stride) {
+    if (hidden & 15) return -1;
+    k_moe_gather_mb<<<dim3(E, nblk), 512, 0, st>>>((const bf16_t*)xp, perm, cnt_nb, hidden, (bf16_t*)xg, xg_stride);
+    LAUNCH_CHECK(); return 0;
+}
 int lk_mb_moe_accum(hipStream_t st, const float* slabs0, long slab_stride, int n_slabs, int slab_rows, const float* route_w, int E, int hidden,
-                    void* acc, int M) {
+                    void* acc, int M, const int* pos) {
     if (hidden & 7) return -1;
-#define MA(NS) k_moe_accum_mb<NS><<<M, 256, 0, st>>>(slabs0, slab_stride, slab_rows, route_w, E, hidden, (bf16_t*)acc)
+#define MA(NS) k_moe_accum_mb<NS><<<M, 256, 0, st>>>(slabs0, slab_stride, slab_rows, route_w, E, hidden, (bf16_t*)acc, pos)
     switch (n_slabs) {
         case 1: MA(1); break; case 2: MA(2); break; case 4: MA(4); break; case 8: MA(8); break;
         default: return -1;
@@ -1442,6 +1509,12 @@ int lk_mb_cand_slots(int n_wg) { return n_wg * 4; }
 
 template <int RBV, int EPI>
 static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int nblk) {
+    if (a.nblk_dev) {
+        // gathered expert: the block count is a device value (typically 1-2 of the step's nblk): passes of two blocks, a pass
+        // past the expert's count returns before it touches the weights
+        k_gemm_mb<RBV, 4, EPI><<<dim3(n_wg, ksplit, (nblk + 1) / 2), 512, mb_lds(4), st>>>(a);
+        LAUNCH_CHECK(); return 0;
+    }
     // nblk >= 3: every token block in ONE weight pass (k_gemm_wide): RBV = 4 -> 4 TW token blocks per workgroup, RBV = 2 -> 8 TW
     if (nblk >= 3 && !g_la_mb_narrow) {
         const dim3 grid(n_wg, ksplit, 1);
@@ -1487,7 +1560,7 @@ int lk_mb_gemm(hipStream_t st, int kind, const MbGemm& g) {
     if (g.nblk < 1 || g.nblk > LA_MB_MAX) return -1;
     MbArgs a{};
     a.wp = (const bf16_t*)g.wp; a.xp = (const bf16_t*)g.xp; a.K16 = g.K / 16; a.N = g.N; a.M = g.slab_rows; a.nblk = g.nblk;
-    a.route_col = g.route_col; a.route_rows = g.nblk * 64;
+    a.route_col = g.route_col; a.route_rows = g.nblk * 64; a.nblk_dev = g.nblk_dev;
     if (kind == 0) {
         if (g.N % 64) return -1;
         a.planned = 0; a.slabs = g.slabs;
