@@ -290,3 +290,34 @@ def test_mstep_mixtral_blocks_track_the_64_row_path():
         agree.append(float((err < TOL_TINY).float().mean()))
         assert float(err.median()) < TOL_TINY, (b, err)
     assert np.mean(agree) >= 0.8, agree
+
+
+def test_mstep_moe_every_expert_receives_every_row():
+    """Gathered MoE worst case: 2 experts, top-2 -> each expert's list is ALL rows of the step (4 blocks = two 128-row passes of
+    the expert GEMMs, positions == rows).  No routing decision can flip here, so every block must sit at bf16 noise of the 64-row
+    engine path run on that sequence alone."""
+    from tests.tiny_model import moe_shape, moe_weights, TINY_MOE
+    cfg = dict(TINY_MOE, n_experts=2, top_k=2)
+    shape = moe_shape(cfg)
+    sd = {k: v.to(torch.bfloat16) for k, v in moe_weights(cfg, seed=5).items()}
+    B = 4
+    engm = LlamaVerifyEngine(shape, dict(sd), max_length=256, n_slots=B, max_blocks=B)
+    eng1 = LlamaVerifyEngine(shape, dict(sd), max_length=256)
+    rs = np.random.RandomState(11)
+    blocks, refs = [], []
+    for b in range(B):
+        p = rs.randint(3, shape.vocab, size=int(rs.randint(10, 90))).tolist()
+        eng1.reset()
+        tok1 = eng1.prefill(p, fast=False)
+        engm.mprefill(b, p)
+        T = 64 if b == 0 else int(rs.randint(20, 65))
+        _, rows = random_tree(rs, T)
+        ids = np.concatenate([[tok1], rs.randint(3, shape.vocab, size=T - 1)]).astype(np.int32)
+        eng1.step(ids, rows, mode=2)
+        refs.append((eng1.logits()[:T].float().cpu().clone(), T))
+        blocks.append((b, ids, rows, 0, 16))
+    engm.mstep(blocks)
+    for b, (ref, T) in enumerate(refs):
+        got = engm.mlogits()[b * 64:b * 64 + T].float().cpu()
+        err = (got - ref).abs().max(1).values / ref.abs().max(1).values
+        assert float((err < TOL_TINY).float().mean()) >= 0.95 and float(err.median()) < 0.5 * TOL_TINY, (b, err)
