@@ -72,7 +72,7 @@ def main():
                     torch.cuda.synchronize()
                     continue
                 us, med = bench(fn)
-                print(f'{name:8s} rows {nblk * 64:4d} {"k_gemm_mb  " if narrow else "k_gemm_wide"} min {us:8.2f} us  median {med:8.2f} us  {flops / us / 1e6:7.1f} TFLOP/s', flush=True)
+                print(f'{name:8s} rows {nblk * 64:4d} {"k_gemm_mb  " if narrow else "k_gemm_wide" if not wmode else "wide, KS=2  "} min {us:8.2f} us  median {med:8.2f} us  {flops / us / 1e6:7.1f} TFLOP/s', flush=True)
     check(lib.la_debug_set(3, 0), 'debug_set')
     check(lib.la_debug_set(5, 0), 'debug_set')
     if mode == 'parts':
