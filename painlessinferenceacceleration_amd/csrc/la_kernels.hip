@@ -1102,28 +1102,49 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
         for (int s = 0; s < 8; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], q[s], sc, 0, 0, 0);
         // attn_weights = bf16(QK^T) / sqrt(head_dim) -> bf16 (modeling_llama.py:270), masked keys excluded
         float mx = LA_NEG;
+        // a committed tile every row sees whole (no window, one sequence, all 32 keys below nkeys) needs no mask arithmetic:
+        // the common case — all but the last committed tile and the two fresh ones (wave-uniform)
+        const bool whole = !fresh && a.window <= 0 && !a.seq && (ts + kb) * 32 + 31 < nkeys;
+        if (whole) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int kk = (i & 3) + 8 * (i >> 2) + 4 * hh;
-            // bf16(x / sqrt(128)) == bf16(x * fp32(1 / sqrt(128))) for EVERY finite bf16 x (checked exhaustively over the 65536 bit
-            // patterns, tests/test_oracle_llama.py::test_attention_scale_as_multiply_is_exact): one multiply instead of an IEEE division
-            float v = bfr(bfr(sc[i]) * 0.088388346135616302490234375f);
-            const int kidx = (ts + kb) * 32 + kk;      // committed keys: absolute index = position
-            const bool ok = fresh ? ((rm >> (kb * 32 + kk)) & 1ull) != 0ull : (kidx < nk_row && kidx >= key_lo);
-            v = ok ? v : LA_NEG;
-            sc[i] = v;
-            mx = fmaxf(mx, v);
+            for (int i = 0; i < 16; ++i) {
+                const float v = bfr(bfr(sc[i]) * 0.088388346135616302490234375f);
+                sc[i] = v;
+                mx = fmaxf(mx, v);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int kk = (i & 3) + 8 * (i >> 2) + 4 * hh;
+                // bf16(x / sqrt(128)) == bf16(x * fp32(1 / sqrt(128))) for EVERY finite bf16 x (checked exhaustively over the 65536 bit
+                // patterns, tests/test_oracle_llama.py::test_attention_scale_as_multiply_is_exact): one multiply instead of an IEEE division
+                float v = bfr(bfr(sc[i]) * 0.088388346135616302490234375f);
+                const int kidx = (ts + kb) * 32 + kk;      // committed keys: absolute index = position
+                const bool ok = fresh ? ((rm >> (kb * 32 + kk)) & 1ull) != 0ull : (kidx < nk_row && kidx >= key_lo);
+                v = ok ? v : LA_NEG;
+                sc[i] = v;
+                mx = fmaxf(mx, v);
+            }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mn = fmaxf(m, mx);
         const float alpha = __expf(m - mn);
         float ps = 0.f;
         bf16x8 pf[2];
+        if (whole) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            float p = (sc[i] > -1.0e29f) ? __expf(sc[i] - mn) : 0.f;
-            ps += p;
-            pf[i >> 3][i & 7] = (short)f2bf(p);
+            for (int i = 0; i < 16; ++i) {
+                const float p = __expf(sc[i] - mn);
+                ps += p;
+                pf[i >> 3][i & 7] = (short)f2bf(p);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float p = (sc[i] > -1.0e29f) ? __expf(sc[i] - mn) : 0.f;
+                ps += p;
+                pf[i >> 3][i & 7] = (short)f2bf(p);
+            }
         }
         ps += __shfl_xor(ps, 32, 64);
         l = l * alpha + ps;
