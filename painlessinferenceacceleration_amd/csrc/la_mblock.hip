@@ -964,7 +964,9 @@ __global__ __launch_bounds__(512) void k_moe_gather_mb(const bf16_t* __restrict_
     bf16x8* dst = (bf16x8*)(xg + (size_t)e * xg_stride + (size_t)j * blk_elems);
     const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     // chunk index inside a block image: ((k-tile * 2 + token block) * 64 + lane'), lane' = (token & 31) + 32 * ((k >> 3) & 1)
-    for (int c = threadIdx.x; c < 64 * (hidden >> 3); c += 512) {
+    const int nchunk = 64 * (hidden >> 3), per = (nchunk + gridDim.z - 1) / gridDim.z;       // gridDim.z workgroups share a block
+    const int cend = (blockIdx.z + 1) * per < nchunk ? (blockIdx.z + 1) * per : nchunk;
+    for (int c = blockIdx.z * per + threadIdx.x; c < cend; c += 512) {
         const int lp = c & 63, tbk = (c >> 6) & 1, kt = c >> 7;
         const int tok = tbk * 32 + (lp & 31);
         const int r = rows[tok];
@@ -1490,7 +1492,7 @@ int lk_mb_moe_plan(hipStream_t st, const float* route_w, int M, int E, int* perm
 }
 int lk_mb_moe_gather(hipStream_t st, const void* xp, const int* perm, const int* cnt_nb, int hidden, int nblk, int E, void* xg, long xg_stride) {
     if (hidden & 15) return -1;
-    k_moe_gather_mb<<<dim3(E, nblk), 512, 0, st>>>((const bf16_t*)xp, perm, cnt_nb, hidden, (bf16_t*)xg, xg_stride);
+    k_moe_gather_mb<<<dim3(E, nblk, 8), 512, 0, st>>>((const bf16_t*)xp, perm, cnt_nb, hidden, (bf16_t*)xg, xg_stride);
     LAUNCH_CHECK(); return 0;
 }
 int lk_mb_moe_accum(hipStream_t st, const float* slabs0, long slab_stride, int n_slabs, int slab_rows, const float* route_w, int E, int hidden,
