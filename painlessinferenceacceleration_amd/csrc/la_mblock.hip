@@ -1,11 +1,15 @@
 // la_mblock.hip — multi-block verify step for gfx950: M = nblk x 64 rows (nblk <= 8) through the SAME packed weights.
 //
-// Why a second GEMM family.  At M = 64 (la_kernels.hip) a weight byte is used 64 times: the launch is a pure HBM stream,
-// waves split K and every wave keeps its own x fragments in registers.  At M = 256..512 (configs 3-5 of BASELINE.json:
-// bs 4..8 x 64-token trees; prompt prefill) the same bytes feed 4-8x the MFMAs and x no longer fits a wave's registers:
-// here the 8 waves of a workgroup own different 32-row weight blocks, the x tile of a k-step is staged ONCE per workgroup
-// in LDS (register-staged double buffer, one barrier per stage) and read by every wave with ds_read_b128; weight
-// fragments still stream HBM -> VGPR in MFMA operand order, each byte once per 256-row pass.
+// Why more GEMM families.  At M = 64 (la_kernels.hip) a weight byte is used 64 times: the launch is a pure HBM stream,
+// waves split K and every wave keeps its own x fragments in registers.  At M = 128..512 (configs 3-5 of BASELINE.json:
+// bs 4..8 x 64-token trees; prompt prefill) the same bytes feed 2-8x the MFMAs and x no longer fits a wave's registers.
+//   k_gemm_mb   (M <= 128, and the gathered experts of Mixtral): the 8 waves own different 32-row weight blocks x K parts, the x
+//               tile of a stage is staged once per workgroup in LDS (register-staged double buffer), weight fragments stream
+//               HBM -> VGPR in MFMA operand order; K parts reduced through LDS.
+//   k_gemm_wide (M = 192..512): one pass over the weights for ALL rows; both operands by LDS-DMA through one ring of stages,
+//               every wave two row-blocks x TW token blocks over the whole K range, epilogues from the accumulators.
+// Mixtral at M >= 128 gathers the rows of every expert into their own blocks (k_moe_plan_mb / k_moe_gather_mb) instead of
+// running every expert over all rows.
 // Reference semantics: modeling_llama_batch.py:340-420 (batched forward), pretrained_model_batch.py:706-931 (per-sample
 // draft, accept, in-place KV) with the per-sample 64-token tree SURVEY H2 / BASELINE configs 3-5 ask for.
 #include <type_traits>
