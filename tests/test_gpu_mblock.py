@@ -57,8 +57,8 @@ def test_mb_slab_gemm(nblk, N, K, ks):
     assert gu.rel_err(got, ref) < 2e-3, gu.rel_err(got, ref)
 
 
-@pytest.mark.parametrize('nblk', [1, 2, 4, 5])
-@pytest.mark.parametrize('F,K,nwg', [(512, 256, 0), (11008, 512, 256), (688, 512, 16)])
+@pytest.mark.parametrize('nblk', [1, 2, 4, 5, 8])
+@pytest.mark.parametrize('F,K,nwg', [(512, 256, 0), (11008, 512, 256), (688, 512, 16), (13824, 1024, 256)])
 def test_mb_swiglu_gemm_planned_and_classic(nblk, F, K, nwg):
     g = torch.Generator(device=DEV).manual_seed(F + nblk)
     x = bf(torch.randn(nblk * 64, K, generator=g, device=DEV))
@@ -104,8 +104,8 @@ def test_mb_logits_gemm_and_argmax(nblk, V, K, nwg):
             assert mv == best and min(c[1] for c in cand if c[0] == mv) == exp
 
 
-@pytest.mark.parametrize('nblk', [1, 2, 4, 6])
-@pytest.mark.parametrize('nh,nkv,nwg', [(2, 2, 0), (32, 32, 256), (8, 2, 32)])
+@pytest.mark.parametrize('nblk', [1, 2, 4, 6, 8])
+@pytest.mark.parametrize('nh,nkv,nwg', [(2, 2, 0), (32, 32, 256), (8, 2, 32), (40, 40, 256), (32, 8, 256)])
 def test_mb_qkv_gemm_equals_single_block_kernel(nblk, nh, nkv, nwg):
     """Fragments written by the multi-block QKV launch == the single-block balanced / classic kernel run per block (same
     rounding points; the fp32 sums differ by the K split, so a small fraction of elements moves by one bf16 ulp)."""
