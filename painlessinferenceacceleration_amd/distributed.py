@@ -51,12 +51,41 @@ class AcceptedTokenGather(object):
         self._work = None
         self._comm = None
         self._stream = None
+        native_given = native is not None
         if native is None:
             native = self.device.type == 'cuda' and not self.local_only and dist.get_backend(group) == 'nccl'
         if native:
-            self._init_native()
+            self._init_native_agreed(strict=native_given)
 
     # ---- native RCCL communicator (la_comm_*): id from rank 0, distributed through torch.distributed ---------------------
+    def _init_native_agreed(self, strict):
+        """Create the native communicator on every rank, then AGREE on it: one all-reduce(MIN) of the success flags through
+        torch.distributed.  If any rank failed, every rank drops its communicator and the gather runs through
+        torch.distributed (still RCCL on GPUs) — a mixed set of transports would deadlock in the first collective.
+        strict (native=True was asked for explicitly): a failure raises instead."""
+        err = None
+        try:
+            self._init_native()
+        except Exception as e:                      # noqa: BLE001 - any failure means "no native transport on this rank"
+            err = e
+            self._comm = None
+        if not self.local_only:
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=self.device if dist.get_backend(self.group) == 'nccl' else 'cpu')
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            all_ok = bool(int(ok.item()))
+        else:
+            all_ok = err is None
+        if all_ok:
+            return
+        if self._comm:
+            lib.la_comm_destroy(self._comm)
+            self._comm = None
+        if strict:
+            raise err if err is not None else _lib.LookaheadHipError('la_comm_create failed on another rank')
+        import warnings
+        warnings.warn(f'native RCCL communicator unavailable ({err if err else "failed on another rank"}): '
+                      'accepted-token gather falls back to torch.distributed.all_gather_into_tensor')
+
     def _init_native(self):
         idbuf = torch.zeros(128, dtype=torch.uint8)
         if self.rank == 0:

@@ -123,3 +123,41 @@ def test_two_rank_trie_replicas_stay_identical(split_phase, b_loc):
         qy = [rng.randrange(3, 60) for _ in range(2)]
         ids, mask, sizes = ref.hier_get(qy, decoding_length=64, branch_length=12, min_output_size=32, mode='mix', idx=0)
         assert (ids, mask.tolist(), sizes) == outs[0][1][i]
+
+
+def _worker_native_fails(rank, world, port, q):
+    """native transport asked for by auto-detection fails on ONE rank: all ranks must agree to fall back"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import warnings
+    from painlessinferenceacceleration_amd import distributed as D
+
+    def fake_init(self):
+        if self.rank == 1:
+            raise RuntimeError('la_comm_create: simulated failure')
+        self._comm = None          # "succeeds" on rank 0 (no real communicator on CPU)
+
+    D.AcceptedTokenGather._init_native = fake_init
+    g = D.AcceptedTokenGather('cpu', b_loc=1)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        g._init_native_agreed(strict=False)
+    out = g.gather([10 + rank, 20 + rank])
+    q.put((rank, g._comm is None, len(w) == 1, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_native_transport_failure_on_one_rank_falls_back_everywhere():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_native_fails, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, no_comm, warned, out in got:
+        assert no_comm and warned and out == [[10, 20], [11, 21]], (rank, no_comm, warned, out)
