@@ -188,6 +188,13 @@ def main():
     BL, DL = 12, 64
     n_truth = (K + W + 56) * (BL + 1) + 8          # measured steps + native-loop leg (16 steps) + fixed-tree sweep (24 steps) + slack
     max_length = P + n_truth + 2 * DL
+    # Mistral (config 2): the checkpoint's sliding window (4096, HF Mistral-7B-v0.1 config.json) with the KV cache as a ring of
+    # window + one step of rows per sequence (memory O(window), not O(max_length)); contexts of this workload stay inside the window
+    if args.model == 'mistral' and B > 1:
+        shape.sliding_window = 4096
+    kv_ring = bool(getattr(shape, 'sliding_window', 0)) and B > 1
+    if kv_ring:
+        max_length = max(max_length, shape.sliding_window + 64 * B + 64)
     want_cpu = not args.no_cpu_baseline and world == 1 and B == 1      # the CPU leg is timed on rank 0 at N=1 only
     sd = random_weights(shape, seed=0, device=dev, decisive=not args.pure_random)
     sd_cpu = {k: v.cpu() for k, v in sd.items()} if want_cpu else None
@@ -196,7 +203,7 @@ def main():
                                  fuse=args.fuse, attn_split=args.attn_split, max_blocks=8)
     else:
         model = BatchLlama(shape, sd, device=dev, max_length=max_length, max_batch=B, eos_token_id=None, consume_state_dict=True,
-                           attn_split=args.attn_split, max_blocks=B)
+                           attn_split=args.attn_split, max_blocks=B, kv_ring=kv_ring)
     del sd
     eng = model.engine
     NSEQ = world * B
@@ -451,6 +458,7 @@ def main():
                                'lm_head[pi(t)]=embed[t]) for decisive greedy margins, 512-token phrase-bank prompts',
                    'n_layers': shape.n_layers, 'prompt_len': P, 'rho': args.rho, 'copies': args.copies,
                    'parallelism': f'batch-shard x{world}, {B} sequence(s) per GPU', 'sequences': NSEQ,
+                   'kv_cache': (f'ring of {eng.shape.sliding_window} + one step of rows per sequence (sliding window)' if kv_ring else 'linear, max_length keys per sequence'),
                    'gather_mode': None if not dist_on else ('strict' if args.strict_gather else 'split-phase'),
                    'draft_retrieval': 'device trie (incremental mirror, one launch per step)' if dev_trie is not None else 'host trie',
                    'device_trie_stats': dev_trie.stats if dev_trie is not None else None,
