@@ -43,7 +43,7 @@ extern "C" {
 #define LA_MOE_MAX_E      8   /* experts per mixture-of-experts layer (Mixtral: 8, top-2) */
 
 /* ABI version: bumped when a signature changes. */
-#define LA_ABI_VERSION  5    /* bumped whenever a struct layout or an entry point changes */
+#define LA_ABI_VERSION  6    /* bumped whenever a struct layout or an entry point changes */
 int          la_abi_version(void);   /* == LA_ABI_VERSION of the header the library was built from */
 const char*  la_last_error(void);
 /* Measurement knobs for the kernel A/B scripts (scripts/gpu_ab.py); every knob is 0 in production.
@@ -393,7 +393,7 @@ int la_resid_norm_addend(void* stream, void* d_h, const void* d_addend, const vo
 #define LA_BIN_IDS        4   /* [64] token ids                                              */
 #define LA_BIN_ROWMASK   68   /* uint64[64] ancestor masks over block rows                   */
 #define LA_BIN_SEQ      196   /* [64] slot of each row, -1 = row unused                      */
-#define LA_BIN_MODE     260   /* [16] per slot: 0 = verify tree, 1 = prefill chain           */
+#define LA_BIN_MODE     260   /* [16] per slot: 0 = verify tree, 1 = prefill chain, 2 = forward only (la_llama_bcommit) */
 #define LA_BIN_LIMIT    276   /* [16] per slot: max tokens to emit (max_length - cursor - 1) */
 #define LA_BIN_WORDS    292
 /* batch device state block (int32 words) */
@@ -440,7 +440,7 @@ int      la_gather_accepted(la_comm* c, void* stream, const int32_t* d_local, in
  * --------------------------------------------------------------------- */
 #define LA_MB_MAX          8
 #define LA_MIN_NBLK        0
-#define LA_MIN_BLK         4    /* [8][4] per block: slot, T (1..64), mode (0 verify tree, 1 prefill chain), limit    */
+#define LA_MIN_BLK         4    /* [8][4] per block: slot, T (1..64), mode (0 verify tree, 1 prefill chain, 2 forward only), limit */
 #define LA_MIN_IDS        36    /* [8][64] token ids                                                                   */
 #define LA_MIN_ROWMASK   548    /* uint64[8][64] ancestor masks over the block's own rows (8-byte aligned offset)      */
 #define LA_MIN_WORDS    1572
@@ -469,6 +469,16 @@ int la_llama_set_nkeys(la_llama* m, void* stream, int slot, int nkeys);
  * LA_BST_DST words (NKEYS, NOUT, OUTTOK) into host_out.  Same asynchrony rules as la_llama_step. */
 int la_llama_bstep(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);
 int la_llama_bstep_eager(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);
+/* Sequential accept path of the batch twin (pretrained_model_batch.py:814-931 with a non-empty logits-processor list or
+ * sampling: the processors see the tokens accepted so far, so the walk runs on the host).  Run la_llama_bstep / la_llama_mstep
+ * with mode 2 for the slots / blocks concerned (forward only: logits rows in la_llama_buffer(m, 0) / (m, 11), nothing emitted,
+ * nothing committed, cursors unchanged), walk each sample's tree over its logits rows, then hand the commit plan back:
+ * keep[r] (bcommit: r = block row, 64 entries; mcommit: r = 64 * block + row, nblk * 64 entries) = k >= 0 if row r is the k-th
+ * kept key of its sequence in this step (k = 0: the root; the kept positions of a sequence must be 0..n-1), -1 if dropped.
+ * The rows move to main-cache rows cursor + k (the in-place moves of :893-904, _update_cache :982-985) and the cursors advance.
+ * Synchronous; host_out receives the header words (LA_BST_DST / LA_MOUT_DST of them) with the new cursors. */
+int la_llama_bcommit(la_llama* m, void* stream, const int32_t* keep, int32_t* host_out);
+int la_llama_mcommit(la_llama* m, void* stream, int nblk, const int32_t* keep, int32_t* host_out);
 /* Forget a slot's sequence (committed keys = 0); slot < 0 resets every slot. */
 int la_llama_reset_slot(la_llama* m, void* stream, int slot);
 

@@ -190,9 +190,10 @@ def kv_keep_positions(context_length, n_draft, logit_indices):
 
 # --------------------------------------------------------------------------------------------- loop
 @torch.no_grad()
-def accept_scan_sequential(ids, mask, logits, seq, logits_processor):
+def accept_scan_sequential(ids, mask, logits, seq, logits_processor, limit=None):
     """The accept walk with a logits-processor list (pretrained_model.py:825-864): the processors see the sequence
-    INCLUDING the tokens accepted so far in this step, so rows are evaluated one after another along the path."""
+    INCLUDING the tokens accepted so far in this step, so rows are evaluated one after another along the path.
+    limit (batch twin, pretrained_model_batch.py:862): at most this many tokens are emitted."""
     T = len(ids)
     par = parents_from_mask(np.asarray(mask))
     cur, toks, rows = 0, [], [0]
@@ -200,6 +201,8 @@ def accept_scan_sequential(ids, mask, logits, seq, logits_processor):
         ctx = torch.tensor([list(seq) + toks], dtype=torch.long)
         want = int(torch.argmax(logits_processor(ctx, logits[cur][None].clone()), dim=-1)[0])
         toks.append(want)
+        if limit is not None and len(toks) >= limit:
+            break
         nxt = next((j for j in range(1, T) if par[j] == cur and int(ids[j]) == want), None)
         if nxt is None:
             break
@@ -374,9 +377,11 @@ def accept_scan_limited(ids, mask, argmax_rows, limit):
 
 @torch.no_grad()
 def lookahead_generate_batch(model, cache, input_ids, attention_mask, max_length, eos_token_id=2, pad_token_id=0,
-                             decoding_length=64, branch_length=12, decoding_mode='hier', stop_words=None, record=None):
-    """bs>1 lookahead_generation (pretrained_model_batch.py:1002-1330) with an empty logits-processor list and greedy
-    decoding.  input_ids / attention_mask: int arrays [B,P] (left padding allowed).  -> dict(sequences [B,L] array,
+                             decoding_length=64, branch_length=12, decoding_mode='hier', stop_words=None, record=None,
+                             logits_processor=None):
+    """bs>1 lookahead_generation (pretrained_model_batch.py:1002-1330), greedy decoding; logits_processor: None / empty
+    (row-parallel argmax) or a LogitsProcessorList — then the prefill calls it batch-wise on the padded prompts (:783) and
+    every accepted token is picked along the path with the processors seeing rows[b, :cur+i+2], pads included (:814-875).  input_ids / attention_mask: int arrays [B,P] (left padding allowed).  -> dict(sequences [B,L] array,
     dls, edls).  Per step: drafts from cache.bat_get with budget decoding_length // active (:713), one batched
     forward, a per-sample accept walk, in-place KV moves, per-sample stream_put, finished samples leave the batch."""
     ids0 = np.asarray(input_ids, dtype=np.int64)
@@ -395,7 +400,9 @@ def lookahead_generate_batch(model, cache, input_ids, attention_mask, max_length
     dls, edls = [], []
     # prefill (:783-812)
     logits, past = model.forward_batch(torch.from_numpy(ids0), full[:, :, :P, :P], None, decoding_max_length=L)
-    first = torch.argmax(logits[:, -1], dim=-1).tolist()
+    sequential = logits_processor is not None and len(logits_processor) > 0
+    last = logits_processor(torch.from_numpy(ids0), logits[:, -1].clone()) if sequential else logits[:, -1]
+    first = torch.argmax(last, dim=-1).tolist()
     active = list(range(B))                     # batch_indices
     cursors = [P] * B
     for b in range(B):
@@ -443,7 +450,11 @@ def lookahead_generate_batch(model, cache, input_ids, attention_mask, max_length
             own = d_masks[k][:, off:off + W]
             T = int(sum(int(own[j, j]) for j in range(W)))      # real rows carry their own diagonal bit; pad rows do not
             limit = max_length - cur - 1                         # emitted tokens <= min(depth, input_length-cur-2)+1 (:862)
-            toks, acc = accept_scan_limited(d_ids[k][:T], own[:T, :T], am_rows[k], limit)
+            if sequential:
+                toks, acc = accept_scan_sequential(d_ids[k][:T], own[:T, :T], logits[k], rows[k, :cur + 1].tolist(),
+                                                   logits_processor, limit)
+            else:
+                toks, acc = accept_scan_limited(d_ids[k][:T], own[:T, :T], am_rows[k], limit)
             m = len(toks) - 1
             rows[k, cur + 1:cur + 1 + len(toks)] = toks
             if acc[-1] != m:                                      # accepted rows are not already contiguous (:893-904)

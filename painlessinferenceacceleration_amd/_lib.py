@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblookahead_hip.so")
 
 LA_OK = 0
-ABI_VERSION = 5         # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
+ABI_VERSION = 6         # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
 LA_MODE_INPUT, LA_MODE_OUTPUT, LA_MODE_MIX = 0, 1, 2
 LA_TREE_MAX = 64
 LA_MOE_MAX_E = 8
@@ -170,6 +170,8 @@ PROTOTYPES = {
     "la_llama_mstep": (i32, vp, vp, vp, vp),
     "la_llama_mstep_eager": (i32, vp, vp, vp, vp),
     "la_llama_set_nkeys": (i32, vp, vp, i32, i32),
+    "la_llama_bcommit": (i32, vp, vp, pi32, vp),
+    "la_llama_mcommit": (i32, vp, vp, i32, pi32, vp),
     "la_cache_mirror_enable": (i32, vp, pi32, i32),
     "la_cache_mirror_state": (i32, vp, pi32, pi32, pi32, pi32),
     "la_cache_mirror_image": (i32, vp, i32, pi32, C.POINTER(C.c_double), C.POINTER(C.c_double), pi32, pi32),

@@ -743,6 +743,83 @@ extern "C" int la_llama_commit(la_llama* m, void* stream, const int32_t* rows, i
     return LA_OK;
 }
 
+// Host-decided commit after a cursor-batch step whose slots ran in mode 2 (the batch twin of la_llama_commit: the per-sample
+// sequential accept walk of pretrained_model_batch.py:814-931 with a non-empty logits-processor list happens on the host over the
+// logits rows).  keep[r] for block row r = k >= 0: the row is the k-th kept key of its slot (k = 0: the root) and moves to main-
+// cache row cursor + k of that slot (the in-place moves of :893-904 / _update_cache :982-985); -1: dropped.  The slots' cursors
+// advance by their kept rows.  d2h of the LA_BST_DST header words into host_out, stream synchronised.
+extern "C" int la_llama_bcommit(la_llama* m, void* stream, const int32_t* keep, int32_t* host_out) {
+    if (!m || !keep || m->n_slots < 1) return LA_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const la_llama_config& c = m->cfg;
+    std::vector<int> bs(LA_BST_WORDS);
+    HIPCHK(hipMemcpyAsync(bs.data(), m->bstate, LA_BST_WORDS * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    int cnt[LA_MAX_SEQ] = {0};
+    unsigned seen[LA_MAX_SEQ] = {0};
+    for (int r = 0; r < LA_TREE_MAX; ++r) {
+        const int sl = bs[LA_BST_SEQ + r], k = keep[r];
+        bs[LA_BST_DST + r] = -1;
+        if (k < 0) continue;
+        if (sl < 0 || sl >= m->n_slots || k >= 32 || (seen[sl] >> k & 1u)) { la_set_error("bcommit: bad keep plan"); return LA_E_RANGE; }
+        seen[sl] |= 1u << k;
+        ++cnt[sl];
+        const int pos = bs[LA_BST_NKEYS + sl] + k;
+        bs[LA_BST_DST + r] = sl * c.max_keys + (c.kv_ring ? pos % c.max_keys : pos);
+    }
+    for (int sl = 0; sl < m->n_slots; ++sl) {
+        if (seen[sl] != (cnt[sl] >= 32 ? 0xffffffffu : (1u << cnt[sl]) - 1u)) { la_set_error("bcommit: kept positions of a slot are not 0..n-1"); return LA_E_RANGE; }
+        if (!c.kv_ring && bs[LA_BST_NKEYS + sl] + cnt[sl] > c.max_keys) { la_set_error("bcommit: KV capacity of the slot exceeded"); return LA_E_RANGE; }
+        bs[LA_BST_NKEYS + sl] += cnt[sl];
+        bs[LA_BST_NOUT + sl] = 0;
+    }
+    HIPCHK(hipMemcpyAsync(m->bstate, bs.data(), LA_BST_ARGMAX * sizeof(int), hipMemcpyHostToDevice, st));   // NKEYS, NOUT, OUTTOK, DST
+    KCHK(lk_kv_commit_b(st, m->kfresh, m->vfresh, m->kmain, m->vmain, m->bstate, c.n_layers, c.n_kv_heads, m->total_keys));
+    if (host_out) HIPCHK(hipMemcpyAsync(host_out, m->bstate, LA_BST_DST * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));       // bs lives on this stack frame
+    return LA_OK;
+}
+
+// The same after a multi-block step (la_llama_mstep) whose blocks ran in mode 2: keep[b * 64 + r] for row r of block b.
+extern "C" int la_llama_mcommit(la_llama* m, void* stream, int nblk, const int32_t* keep, int32_t* host_out) {
+    if (!m || !keep || !m->mb_max || nblk < 1 || nblk > m->mb_max) return LA_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const la_llama_config& c = m->cfg;
+    std::vector<int> meta(nblk * LA_MB_META), out(LA_MOUT_ARGMAX), nk(LA_MAX_SEQ);
+    HIPCHK(hipMemcpyAsync(meta.data(), m->mb_meta, meta.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(nk.data(), m->bstate + LA_BST_NKEYS, LA_MAX_SEQ * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < LA_MOUT_ARGMAX; ++i) out[i] = (i >= LA_MOUT_DST) ? -1 : 0;
+    unsigned used = 0;
+    for (int b = 0; b < nblk; ++b) {
+        const int* mt = &meta[b * LA_MB_META];
+        const int sl = mt[LA_MBM_SLOT], T = mt[LA_MBM_T];
+        if (sl < 0 || sl >= m->n_slots || (used >> sl & 1u) || mt[LA_MBM_MODE] != 2) { la_set_error("mcommit: the last step's blocks were not one mode-2 block per slot"); return LA_E_RANGE; }
+        used |= 1u << sl;
+        unsigned seen = 0;
+        int cnt = 0;
+        for (int r = 0; r < LA_TREE_MAX; ++r) {
+            const int k = keep[b * 64 + r];
+            if (k < 0) continue;
+            if (r >= T || k >= 32 || (seen >> k & 1u)) { la_set_error("mcommit: bad keep plan"); return LA_E_RANGE; }
+            seen |= 1u << k;
+            ++cnt;
+            const int pos = nk[sl] + k;
+            out[LA_MOUT_DST + b * 64 + r] = sl * c.max_keys + (c.kv_ring ? pos % c.max_keys : pos);
+        }
+        if (seen != (cnt >= 32 ? 0xffffffffu : (1u << cnt) - 1u)) { la_set_error("mcommit: kept positions of a block are not 0..n-1"); return LA_E_RANGE; }
+        if (!c.kv_ring && nk[sl] + cnt > c.max_keys) { la_set_error("mcommit: KV capacity of the slot exceeded"); return LA_E_RANGE; }
+        nk[sl] += cnt;
+    }
+    for (int i = 0; i < LA_MAX_SEQ; ++i) out[LA_MOUT_NKEYS + i] = nk[i];
+    HIPCHK(hipMemcpyAsync(m->bstate + LA_BST_NKEYS, nk.data(), LA_MAX_SEQ * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(m->mb_out, out.data(), LA_MOUT_ARGMAX * sizeof(int), hipMemcpyHostToDevice, st));    // NOUT, NKEYS, OUTTOK, DST
+    KCHK(lk_mb_kv_commit(st, m->mb_kfresh, m->mb_vfresh, m->kmain, m->vmain, m->mb_out, nblk, c.n_layers, c.n_kv_heads, m->total_keys));
+    if (host_out) HIPCHK(hipMemcpyAsync(host_out, m->mb_out, LA_MOUT_DST * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return LA_OK;
+}
+
 // Set the committed-key cursor of a slot from the host (slot 0 is also the single-sequence cursor LA_ST_NKEYS): lets a
 // prompt prefilled by la_llama_mstep continue on la_llama_step, and a finished slot be rewound without clearing the others.
 extern "C" int la_llama_set_nkeys(la_llama* m, void* stream, int slot, int nkeys) {

@@ -1399,7 +1399,12 @@ __global__ void k_accept_scan_b(const int* __restrict__ in, const int* __restric
     auto row_of = [&](int k) { return sbase + (ring ? (nkeys + k) % slot_keys : nkeys + k); };      // main-cache row of the k-th kept key
     const int am = bstate[LA_BST_ARGMAX + j];
     int dst = -1, n_commit;
-    if (mode == 1) {
+    if (mode == 2) {
+        // forward only (sequential accept path, pretrained_model_batch.py:814-875 with a non-empty processor list): the host
+        // walks the tree over the logits rows and decides the commit (la_llama_bcommit); nothing moves here
+        if (j == 0) bstate[LA_BST_NOUT + s] = 0;
+        n_commit = 0;
+    } else if (mode == 1) {
         const int last = 63 - __clzll((long long)own);
         const int tok = __shfl(am, last, 64);
         if (mine) dst = row_of(__popcll(own & ((1ull << j) - 1ull)));

@@ -1343,7 +1343,11 @@ __global__ void k_accept_scan_mb(const int* __restrict__ meta, const int* __rest
         auto row_of = [&](int k) { return slot * slot_keys + (ring ? (pos0 + k) % slot_keys : pos0 + k); };
         const int am = argmax[b * 64 + j];
         int dst = -1, nc;
-        if (mode == 1) {
+        if (mode == 2) {
+            // forward only: the host decides the commit (la_llama_mcommit), see k_accept_scan_b
+            if (j == 0) out[LA_MOUT_NOUT + b] = 0;
+            nc = 0;
+        } else if (mode == 1) {
             const int tok = __shfl(am, T - 1, 64);
             if (j < T) dst = row_of(j);
             if (j == 0) { out[LA_MOUT_OUTTOK + b * 16] = tok; out[LA_MOUT_NOUT + b] = 1; }

@@ -430,10 +430,12 @@ class LlamaVerifyEngine(object):
         a[_lib.LA_BIN_LIMIT:_lib.LA_BIN_LIMIT + 16] = 16
         row = 0
         seen = set()
+        self._bstep_first = {}
         for slot, ids, rowmask, mode, limit in segments:
             n = len(ids)
             assert 0 <= slot < self.n_slots and slot not in seen and n >= 1, 'one segment per slot'
             seen.add(slot)
+            self._bstep_first[slot] = row
             assert row + n <= _lib.LA_TREE_MAX, 'a verify block holds 64 rows'
             assert self.slot_keys[slot] + n <= self._capacity(), 'KV cache capacity of the slot exceeded'
             a[_lib.LA_BIN_IDS + row:_lib.LA_BIN_IDS + row + n] = ids
@@ -453,6 +455,39 @@ class LlamaVerifyEngine(object):
             self.slot_keys[slot] = int(o[_lib.LA_BST_NKEYS + slot])
             out[slot] = o[_lib.LA_BST_OUTTOK + 16 * slot:_lib.LA_BST_OUTTOK + 16 * slot + n_out].tolist()
         return out
+
+    def bstep_rows(self):
+        """{slot: first block row} of the last bstep (segments are laid out one after another)."""
+        return dict(self._bstep_first)
+
+    def bcommit(self, kept):
+        """After a bstep whose segments ran in mode 2 (forward only): kept = {slot: [local tree rows to keep, root first]};
+        their K/V move to the slot's cursor (la_llama_bcommit), cursors advance."""
+        keep = np.full(64, -1, dtype=np.int32)
+        for slot, rows in kept.items():
+            base = self._bstep_first[slot]
+            for k, r in enumerate(rows):
+                keep[base + int(r)] = k
+            assert self.slot_keys[slot] + len(rows) <= self._capacity(), 'KV cache capacity of the slot exceeded'
+        check(lib.la_llama_bcommit(self._h, self._sp(), keep.ctypes.data_as(_lib.pi32), self.host_bout.data_ptr()), 'llama_bcommit')
+        for slot in kept:
+            self.slot_keys[slot] = int(self._bout_np[_lib.LA_BST_NKEYS + slot])
+
+    def mcommit(self, kept):
+        """After an mstep whose blocks ran in mode 2: kept = list (one entry per block, block order) of the tree rows to keep,
+        root first (la_llama_mcommit)."""
+        slots = self._mstep_slots
+        assert len(kept) == len(slots)
+        keep = np.full(64 * len(kept), -1, dtype=np.int32)
+        for b, rows in enumerate(kept):
+            for k, r in enumerate(rows):
+                keep[64 * b + int(r)] = k
+        check(lib.la_llama_mcommit(self._h, self._sp(), len(kept), keep.ctypes.data_as(_lib.pi32), self.host_mout.data_ptr()),
+              'llama_mcommit')
+        for slot in slots:
+            self.slot_keys[slot] = int(self._mout_np[_lib.LA_MOUT_NKEYS + slot])
+        if 0 in slots:
+            self.n_keys = self.slot_keys[0]
 
     def bprefill(self, slot, prompt_ids, eager=False):
         """Prompt of one slot as chains of <= 64 rows; -> first generated token."""
@@ -505,6 +540,7 @@ class LlamaVerifyEngine(object):
             a[_lib.LA_MIN_IDS + 64 * b:_lib.LA_MIN_IDS + 64 * b + n] = ids
             self._min_rm[64 * b:64 * b + n] = rowmask
         rows = {}
+        self._mstep_slots = [blk[0] for blk in blocks]
         for slot, ids, _, _, _ in blocks:
             rows[slot] = rows.get(slot, 0) + len(ids)
         for slot, n in rows.items():

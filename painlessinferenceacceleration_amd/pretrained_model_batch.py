@@ -95,8 +95,12 @@ class LookaheadPreTrainedModel(object):
                              pad_token_id=None, eos_token_id=None, output_attentions=None,
                              output_hidden_states=None, output_scores=None, return_dict_in_generate=None,
                              synced_gpus=False, streamer=None, **model_kwargs):
-        if logits_processor is not None and len(logits_processor) > 0:
-            raise NotImplementedError('non-empty logits_processor lists need the sequential accept path (SURVEY H7)')
+        # the reference's batch loop always walks every sample's tree token by token with the processors applied to
+        # input_ids[b, :cur+i+2] (pretrained_model_batch.py:814-875).  With an empty list and greedy decoding that walk equals the
+        # device accept scan; a non-empty list or sampling takes the sequential path: forward-only step (mode 2), host walk over
+        # the logits rows, host-decided commit (la_llama_bcommit / la_llama_mcommit).
+        sequential = (logits_processor is not None and len(logits_processor) > 0) or \
+            bool(model_kwargs.get('decoding_kwargs', {}).get('do_sample', False))
         if output_scores or output_attentions or output_hidden_states:
             raise NotImplementedError('scores/attentions/hidden_states are not produced by the device path (SURVEY H8)')
         gc = self.generation_config
@@ -147,7 +151,33 @@ class LookaheadPreTrainedModel(object):
         # prefill: valid prompt tokens of every sample, packed into shared 64-row chain blocks
         prompts = {i: ids0[i][am[i] == 1].tolist() for i in range(bs)}
         multi = bool(getattr(eng, 'max_blocks', 0))
-        first = eng.mprefill_many(prompts) if multi else eng.bprefill_many(prompts)
+        do_sample = bool(decoding_kwargs.get('do_sample', False))
+
+        def pick(ctx_ids, row):
+            """next token from one logits row through the processor list (pretrained_model_batch.py:840-846)"""
+            scores = row[None]
+            if logits_processor is not None and len(logits_processor) > 0:
+                ctx = torch.tensor([ctx_ids], dtype=torch.long, device=eng.device)
+                scores = logits_processor(ctx, scores.clone())
+            if do_sample:
+                return int(torch.multinomial(torch.softmax(scores.float(), dim=-1), num_samples=1)[0, 0])
+            return int(torch.argmax(scores, dim=-1)[0])
+
+        if sequential:
+            # prompts one slot after the other: the last prompt row's logits stay readable for the processor call of :783
+            # (batch-wise there; the processors are row-wise, so one padded row at a time is the same call)
+            first = {}
+            for i in range(bs):
+                n = len(prompts[i])
+                if multi:
+                    eng.mprefill(i, prompts[i])
+                    last = (n - 1) % (64 * eng.max_blocks)
+                    first[i] = pick(ids0[i].tolist(), eng.mlogits()[last])
+                else:
+                    eng.bprefill(i, prompts[i])
+                    first[i] = pick(ids0[i].tolist(), eng.logits()[(n - 1) % 64])
+        else:
+            first = eng.mprefill_many(prompts) if multi else eng.bprefill_many(prompts)
         next_token_list = [[first[i]] for i in range(bs)]
         decoding_kwargs['dls'].extend([1] * bs)
         decoding_kwargs['edls'].extend([1] * bs)
@@ -180,15 +210,30 @@ class LookaheadPreTrainedModel(object):
                 if len(d_ids) == 0:
                     d_ids, d_rm = np.asarray(rows[b][-1:], dtype=np.int32), _ONE
                 cur = len(rows[b]) - 1
-                segments.append((b, d_ids, d_rm, 0, stop_max_length - cur - 1))
+                segments.append((b, d_ids, d_rm, 2 if sequential else 0, stop_max_length - cur - 1))
             if sum(len(sg[1]) for sg in segments) <= _lib.LA_TREE_MAX:
                 emitted = eng.bstep(segments)                          # the whole batch shares one 64-row block
+                if sequential:
+                    base, logits = eng.bstep_rows(), eng.logits()
+                    kept = {}
+                    for sg in segments:
+                        emitted[sg[0]], kept[sg[0]] = self._sequential_walk(rows[sg[0]], sg, logits, base[sg[0]], pick)
+                    eng.bcommit(kept)
             else:
                 assert multi, 'more than 64 draft rows per step need an engine created with max_blocks > 1'
                 emitted = {}
                 for g0 in range(0, len(segments), eng.max_blocks):     # one 64-row block per sample, max_blocks per pass
                     group = segments[g0:g0 + eng.max_blocks]
-                    for sg, toks in zip(group, eng.mstep(group)):
+                    out = eng.mstep(group)
+                    if sequential:
+                        logits, kept = eng.mlogits(), []
+                        for k, sg in enumerate(group):
+                            toks, keep_rows = self._sequential_walk(rows[sg[0]], sg, logits, 64 * k, pick)
+                            emitted[sg[0]] = toks
+                            kept.append(keep_rows)
+                        eng.mcommit(kept)
+                        continue
+                    for sg, toks in zip(group, out):
                         emitted[sg[0]] = toks
             width = max(len(sg[1]) for sg in segments)
             next_token_list = [emitted[b] for b in batch_indices]
@@ -210,9 +255,36 @@ class LookaheadPreTrainedModel(object):
                                               kwargs=kwargs)
         return sequences
 
+    @staticmethod
+    def _sequential_walk(row_ids, segment, logits, base, pick):
+        """pretrained_model_batch.py:829-886 for one sample: starting at the root, pick the next token from the current tree row's
+        logits with the processors seeing the padded row plus the tokens accepted so far, then follow the child carrying that
+        token (first such row in DFS order).  -> (emitted tokens, kept tree rows, root first)."""
+        _, d_ids, d_rm, _, limit = segment
+        T = len(d_ids)
+        parent = [-1] * T
+        for j in range(1, T):
+            below = int(d_rm[j]) & ((1 << j) - 1)
+            parent[j] = below.bit_length() - 1
+        limit = max(1, min(int(limit), 32))
+        cur, kept, toks = 0, [0], []
+        while True:
+            t = pick(row_ids + toks, logits[base + cur])
+            toks.append(t)
+            if len(toks) >= limit:
+                break
+            nxt = next((j for j in range(1, T) if parent[j] == cur and int(d_ids[j]) == t), None)
+            if nxt is None:
+                break
+            cur = nxt
+            kept.append(cur)
+        return toks, kept
+
     @torch.no_grad()
-    def greedy_search(self, input_ids, max_length, attention_mask=None, eos_token_id=None, pad_token_id=0):
-        """Plain greedy decoding of the whole batch through the same engine (one row per sample per block)."""
+    def greedy_search(self, input_ids, max_length, attention_mask=None, eos_token_id=None, pad_token_id=0,
+                      logits_processor=None, do_sample=False):
+        """Plain decoding of the whole batch through the same engine (one row per sample per block).  With a processor list or
+        sampling every token is picked on the host from the sample's logits row (forward-only step + la_llama_bcommit)."""
         ids0 = input_ids.cpu().numpy().astype(np.int64)
         bs, P = ids0.shape
         am = np.ones_like(ids0) if attention_mask is None else attention_mask.cpu().numpy().astype(np.int64)
@@ -220,13 +292,41 @@ class LookaheadPreTrainedModel(object):
         eng = self.engine
         eng.reset_slot(-1)
         prompts = {i: ids0[i][am[i] == 1].tolist() for i in range(bs)}
-        first = eng.mprefill_many(prompts) if getattr(eng, 'max_blocks', 0) else eng.bprefill_many(prompts)
+        host_pick = do_sample or (logits_processor is not None and len(logits_processor) > 0)
+        multi = bool(getattr(eng, 'max_blocks', 0))
+
+        def pick(ctx_ids, row):
+            scores = row[None]
+            if logits_processor is not None and len(logits_processor) > 0:
+                scores = logits_processor(torch.tensor([ctx_ids], dtype=torch.long, device=eng.device), scores.clone())
+            if do_sample:
+                return int(torch.multinomial(torch.softmax(scores.float(), dim=-1), num_samples=1)[0, 0])
+            return int(torch.argmax(scores, dim=-1)[0])
+
+        if host_pick:
+            first = {}
+            for i in range(bs):
+                n = len(prompts[i])
+                if multi:
+                    eng.mprefill(i, prompts[i])
+                    first[i] = pick(ids0[i].tolist(), eng.mlogits()[(n - 1) % (64 * eng.max_blocks)])
+                else:
+                    eng.bprefill(i, prompts[i])
+                    first[i] = pick(ids0[i].tolist(), eng.logits()[(n - 1) % 64])
+        else:
+            first = eng.mprefill_many(prompts) if multi else eng.bprefill_many(prompts)
         rows = [ids0[i].tolist() + [first[i]] for i in range(bs)]
         live = [b for b in range(bs) if len(rows[b]) < max_length and rows[b][-1] not in eos]
         while live:
-            out = eng.bstep([(b, np.asarray(rows[b][-1:], dtype=np.int32), _ONE, 0, 1) for b in live])
-            for b in live:
-                rows[b].append(out[b][0])
+            out = eng.bstep([(b, np.asarray(rows[b][-1:], dtype=np.int32), _ONE, 2 if host_pick else 0, 1) for b in live])
+            if host_pick:
+                base, logits = eng.bstep_rows(), eng.logits()
+                for b in live:
+                    rows[b].append(pick(rows[b], logits[base[b]]))
+                eng.bcommit({b: [0] for b in live})
+            else:
+                for b in live:
+                    rows[b].append(out[b][0])
             live = [b for b in live if len(rows[b]) < max_length and rows[b][-1] not in eos]
         L = max(len(r) for r in rows)
         seqs = np.full((bs, L), pad_token_id, dtype=np.int64)
@@ -237,17 +337,26 @@ class LookaheadPreTrainedModel(object):
     def generate(self, input_ids=None, attention_mask=None, max_length=None, max_new_tokens=None,
                  decoding_kwargs=None, eos_token_id=None, pad_token_id=None, return_dict_in_generate=False,
                  streamer=None, do_sample=False, repetition_penalty=1.0, **unused):
-        if do_sample or repetition_penalty != 1.0:
-            raise NotImplementedError('sampling / repetition penalty are outside the parity scope (SURVEY H7)')
+        """The keyword surface of the reference's examples.  repetition_penalty != 1 / logits_processor= / do_sample take the
+        sequential accept path (host-side token pick), everything else stays on the device."""
+        gcfg = self.generation_config
+        do_sample = do_sample or bool(getattr(gcfg, 'do_sample', False)) if gcfg is not None else do_sample
         if max_length is None:
             max_length = input_ids.size(1) + (max_new_tokens if max_new_tokens is not None else 20)
+        processors = unused.get('logits_processor', None)
+        if repetition_penalty is not None and repetition_penalty != 1.0:
+            from transformers import LogitsProcessorList, RepetitionPenaltyLogitsProcessor
+            processors = LogitsProcessorList(list(processors or []) + [RepetitionPenaltyLogitsProcessor(penalty=repetition_penalty)])
         dk = dict(decoding_kwargs or {})
         if dk.get('use_lookahead', False) and dk.get('decoding_length', 64) > 1 and dk.get('branch_length', 12) > 0:
-            return self.lookahead_generation(input_ids, stopping_criteria=int(max_length), pad_token_id=pad_token_id,
-                                             eos_token_id=eos_token_id, return_dict_in_generate=return_dict_in_generate,
+            dk['do_sample'] = bool(do_sample)
+            return self.lookahead_generation(input_ids, logits_processor=processors, stopping_criteria=int(max_length),
+                                             pad_token_id=pad_token_id, eos_token_id=eos_token_id,
+                                             return_dict_in_generate=return_dict_in_generate,
                                              streamer=streamer, attention_mask=attention_mask, decoding_kwargs=dk)
         out = self.greedy_search(input_ids, max_length, attention_mask=attention_mask,
                                  eos_token_id=eos_token_id if eos_token_id is not None
                                  else getattr(self.generation_config, 'eos_token_id', None),
-                                 pad_token_id=pad_token_id if pad_token_id is not None else 0)
+                                 pad_token_id=pad_token_id if pad_token_id is not None else 0,
+                                 logits_processor=processors, do_sample=do_sample)
         return LookaheadDecoderOnlyOutput(sequences=out, kwargs={}) if return_dict_in_generate else out

@@ -67,14 +67,17 @@ class OracleEngine(object):
 
 
 class OracleBatchEngine(object):
-    """TEST-ONLY stand-in for LlamaVerifyEngine(n_slots=N): the cursor-batch surface (reset_slot / bprefill_many /
-    bstep) on the oracle forward, one KV list per slot."""
+    """TEST-ONLY stand-in for LlamaVerifyEngine(n_slots=N[, max_blocks=M]): the cursor-batch surface (reset_slot / bprefill /
+    bprefill_many / bstep / bcommit) and the multi-block surface (mprefill / mprefill_many / mstep / mcommit) on the oracle
+    forward, one KV list per slot.  mode 2 = forward only, the host decides the commit (sequential accept path)."""
+    device = torch.device('cpu')
 
-    def __init__(self, shape, state_dict, max_length=512, n_slots=4):
+    def __init__(self, shape, state_dict, max_length=512, n_slots=4, max_blocks=0):
         self.shape = shape
         self.model = lo.OracleLlama(shape, state_dict)
         self.max_keys = ((max_length + 65 + 31) // 32) * 32
         self.n_slots = n_slots
+        self.max_blocks = max_blocks
         self.reset_slot(-1)
 
     def reset_slot(self, slot):
@@ -85,24 +88,85 @@ class OracleBatchEngine(object):
             self.past[slot] = None
             self.slot_keys[slot] = 0
 
+    def _segment(self, slot, ids, rowmask, mode, limit):
+        T, nk = len(ids), self.slot_keys[slot]
+        tree = np.array([[(int(rowmask[i]) >> j) & 1 for j in range(T)] for i in range(T)], dtype=np.int64)
+        full = torch.cat([torch.ones((T, nk), dtype=torch.long), torch.from_numpy(tree)], 1)
+        logits, past = self.model.forward(torch.tensor([int(x) for x in ids]), full, self.past[slot])
+        am = [int(x) for x in torch.argmax(logits.float(), -1)]
+        if mode == 2:
+            self._pending[slot] = past
+            return [], logits
+        if mode == 1:
+            toks, rows = [am[-1]], list(range(T))
+        else:
+            toks, rows = lo.accept_scan_limited([int(x) for x in ids], tree, am, max(1, min(16, int(limit))))
+        self._keep(slot, past, rows)
+        return toks, logits
+
+    def _keep(self, slot, past, rows):
+        nk = self.slot_keys[slot]
+        idx = torch.tensor(list(range(nk)) + [nk + int(r) for r in rows], dtype=torch.long)
+        self.past[slot] = [(k[:, idx], v[:, idx]) for k, v in past]
+        self.slot_keys[slot] = nk + len(rows)
+
     def bstep(self, segments, eager=False):
         assert sum(len(s[1]) for s in segments) <= 64
-        out = {}
+        out, self._pending, self._first, blocks, row = {}, {}, {}, [], 0
         for slot, ids, rowmask, mode, limit in segments:
-            T, nk = len(ids), self.slot_keys[slot]
-            tree = np.array([[(int(rowmask[i]) >> j) & 1 for j in range(T)] for i in range(T)], dtype=np.int64)
-            full = torch.cat([torch.ones((T, nk), dtype=torch.long), torch.from_numpy(tree)], 1)
-            logits, past = self.model.forward(torch.tensor([int(x) for x in ids]), full, self.past[slot])
-            am = [int(x) for x in torch.argmax(logits.float(), -1)]
-            if mode == 1:
-                toks, rows = [am[-1]], list(range(T))
-            else:
-                toks, rows = lo.accept_scan_limited([int(x) for x in ids], tree, am, max(1, min(16, int(limit))))
-            idx = torch.tensor(list(range(nk)) + [nk + r for r in rows], dtype=torch.long)
-            self.past[slot] = [(k[:, idx], v[:, idx]) for k, v in past]
-            self.slot_keys[slot] = nk + len(rows)
-            out[slot] = toks
+            out[slot], lg = self._segment(slot, ids, rowmask, mode, limit)
+            self._first[slot] = row
+            row += len(ids)
+            blocks.append(lg)
+        self._logits = torch.cat(blocks, 0)
         return out
 
+    def bstep_rows(self):
+        return dict(self._first)
+
+    def logits(self):
+        return self._logits
+
+    def bcommit(self, kept):
+        for slot, rows in kept.items():
+            self._keep(slot, self._pending[slot], rows)
+
+    def bprefill(self, slot, prompt_ids, eager=False):
+        tok = None
+        for s in range(0, len(prompt_ids), 64):
+            blk = prompt_ids[s:s + 64]
+            tok = self.bstep([(slot, blk, [(2 << t) - 1 for t in range(len(blk))], 1, 1)])[slot][0]
+        return tok
+
     def bprefill_many(self, prompts, eager=False):
-        return {s: self.bstep([(s, p, [(2 << t) - 1 for t in range(len(p))], 1, 1)])[s][0] for s, p in prompts.items()}
+        return {s: self.bprefill(s, p) for s, p in prompts.items()}
+
+    # ---- multi-block surface: every block a full tree of its own -----------------------------------------------
+    def mstep(self, blocks, eager=False):
+        assert self.max_blocks and len(blocks) <= self.max_blocks
+        out, self._pending, lgs, self._mslots = [], {}, [], [b[0] for b in blocks]
+        for slot, ids, rowmask, mode, limit in blocks:
+            toks, lg = self._segment(slot, ids, rowmask, mode, limit)
+            out.append(toks)
+            lgs.append(torch.cat([lg, torch.zeros((64 - lg.shape[0], lg.shape[1]), dtype=lg.dtype)], 0))
+        self._mlogits = torch.cat(lgs, 0)
+        return out
+
+    def mlogits(self):
+        return self._mlogits
+
+    def mcommit(self, kept):
+        for slot, rows in zip(self._mslots, kept):
+            self._keep(slot, self._pending[slot], rows)
+
+    def mprefill(self, slot, prompt_ids, eager=False):
+        tok, per = None, 64 * self.max_blocks
+        for s in range(0, len(prompt_ids), per):
+            piece = prompt_ids[s:s + per]
+            blocks = [(slot, piece[i:i + 64], [(2 << t) - 1 for t in range(len(piece[i:i + 64]))], 1, 1)
+                      for i in range(0, len(piece), 64)]
+            tok = self.mstep(blocks)[-1][0]
+        return tok
+
+    def mprefill_many(self, prompts, eager=False):
+        return {s: self.mprefill(s, p) for s, p in prompts.items()}

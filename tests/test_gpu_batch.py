@@ -265,3 +265,137 @@ def test_batch_lookahead_equals_per_sample_greedy_decisive():
     assert np.mean(out.kwargs['edls'][4:]) > 2.0, out.kwargs['edls']
     g2 = model.greedy_search(torch.from_numpy(ids), P + 40, attention_mask=torch.from_numpy(am), eos_token_id=None)
     assert g2[:, P:P + 40].tolist() == [x[:40] for x in greedy]
+
+
+def test_forward_only_batch_steps_and_host_commit_equal_device_accept():
+    """mode 2 (forward only) + la_llama_bcommit / la_llama_mcommit with an identity walk (argmax, no processors) must leave
+    exactly the state the device accept scan leaves: same emitted tokens, same cursors, and bitwise the same logits on the
+    next step (i.e. the same K/V rows were kept), on the shared 64-row block and on one block per sample."""
+    shape = tiny_shape()
+    sd = _bf16_sd(1)
+    rs = np.random.RandomState(21)
+    B = 3
+    prompts = [rs.randint(3, shape.vocab, size=int(n)).tolist() for n in (37, 70, 12)]
+    for multi in (False, True):
+        engs = [LlamaVerifyEngine(shape, dict(sd), max_length=384, n_slots=B, max_blocks=B if multi else 0) for _ in range(2)]
+        firsts = [e.mprefill_many({b: prompts[b] for b in range(B)}) if multi else
+                  e.bprefill_many({b: prompts[b] for b in range(B)}) for e in engs]
+        assert firsts[0] == firsts[1]
+        last = dict(firsts[0])
+        for step in range(3):
+            segs = []
+            for b in range(B):
+                T = int(rs.randint(1, 60 if multi else 20))
+                _, rows = random_tree(rs, T)
+                ids = np.concatenate([[last[b]], rs.randint(3, shape.vocab, size=T - 1)]).astype(np.int32)
+                segs.append((b, ids, np.asarray(rows, dtype=np.uint64), T))
+            dev, host = engs
+            if multi:
+                out_d = dict(zip(range(B), dev.mstep([(b, i, r, 0, 16) for b, i, r, _ in segs])))
+                host.mstep([(b, i, r, 2, 16) for b, i, r, _ in segs])
+                lg, base = host.mlogits(), {b: 64 * b for b in range(B)}
+                assert torch.equal(lg, dev.mlogits())
+            else:
+                out_d = dev.bstep([(b, i, r, 0, 16) for b, i, r, _ in segs])
+                out_h = host.bstep([(b, i, r, 2, 16) for b, i, r, _ in segs])
+                assert all(out_h[b] == [] for b in range(B))            # nothing emitted, nothing committed
+                lg, base = host.logits(), host.bstep_rows()
+                assert torch.equal(lg, dev.logits())
+            before = list(host.slot_keys)
+            kept = {}
+            for b, ids, rows, T in segs:
+                am = lg[base[b]:base[b] + T].float().argmax(-1).tolist()
+                toks, acc = lo.accept_scan(ids.tolist(), _mask_from_rows(rows, T), am)
+                assert toks[:16] == out_d[b], (multi, step, b)
+                kept[b] = acc[:16]
+                last[b] = toks[:16][-1]
+            assert host.slot_keys == before                                # cursors untouched until the commit
+            if multi:
+                host.mcommit([kept[b] for b in range(B)])
+            else:
+                host.bcommit(kept)
+            assert host.slot_keys == dev.slot_keys, (multi, step)
+        one = np.array([1], dtype=np.uint64)
+        nxt = [(b, np.asarray([last[b]], dtype=np.int32), one, 0, 1) for b in range(B)]
+        a, c = dev.bstep(nxt), host.bstep(nxt)
+        assert a == c and torch.equal(dev.logits()[:B], host.logits()[:B]), multi
+    # a malformed plan is refused (kept positions must be 0..n-1 per sequence)
+    keep = np.full(64, -1, dtype=np.int32)
+    keep[0] = 1
+    host.bstep([(0, np.asarray([5], dtype=np.int32), one, 2, 1)])
+    assert lib.la_llama_bcommit(host._h, host._sp(), keep.ctypes.data_as(_lib.pi32), host.host_bout.data_ptr()) == -2      # LA_E_RANGE
+
+
+@pytest.mark.parametrize('multi', [False, True])
+def test_batch_sequential_processor_path_on_device(multi):
+    """Batch lookahead with a repetition penalty (sequential accept path: forward-only step, host walk over the logits rows,
+    la_llama_bcommit / la_llama_mcommit) == plain batch decoding with the same penalty through the same engine (decisive
+    weights, ragged left-padded prompts; multi: every sample its own 64-row tree through la_llama_mstep), and accepts are
+    multi-token."""
+    from transformers import LogitsProcessorList, RepetitionPenaltyLogitsProcessor
+    shape = tiny_shape()
+    sd = random_weights(shape, seed=2, device='cpu', decisive=True)
+    model = BatchLlama(shape, dict(sd), max_length=512, max_batch=4, eos_token_id=None, max_blocks=4 if multi else 0)
+    rs = np.random.RandomState(13)
+    lens = [60, 47, 31, 60]
+    P = max(lens)
+    ids = np.zeros((4, P), dtype=np.int64)
+    am = np.zeros((4, P), dtype=np.int64)
+    for b, n in enumerate(lens):
+        ids[b, P - n:] = rs.randint(3, shape.vocab, size=n)
+        am[b, P - n:] = 1
+    procs = LogitsProcessorList([RepetitionPenaltyLogitsProcessor(1.05)])
+    n_new = 100
+    plain = model.greedy_search(torch.from_numpy(ids), P + n_new, attention_mask=torch.from_numpy(am), eos_token_id=None,
+                                logits_processor=procs).cpu().numpy()
+    free = model.greedy_search(torch.from_numpy(ids), P + n_new, attention_mask=torch.from_numpy(am), eos_token_id=None).cpu().numpy()
+    assert (plain != free).any()                                           # the penalty changes the text
+    dk = {'use_lookahead': True, 'decoding_length': 64, 'branch_length': 12, 'stop_words': {}, 'per_sample_budget': multi}
+    for rep in range(2):
+        out = model.lookahead_generation(torch.from_numpy(ids), logits_processor=procs, stopping_criteria=P + n_new,
+                                         eos_token_id=[None], pad_token_id=0, return_dict_in_generate=True,
+                                         attention_mask=torch.from_numpy(am), decoding_kwargs=dict(dk))
+        got = out.sequences.cpu().numpy()
+        w = min(got.shape[1], plain.shape[1], P + n_new)
+        assert got[:, :w].tolist() == plain[:, :w].tolist(), rep
+    assert np.mean(out.kwargs['edls'][4:]) > 1.5, out.kwargs['edls']
+    if multi:
+        assert max(out.kwargs['dls']) > 16                                  # trees wider than the shared-block budget
+
+
+def test_batch_processor_run_vs_reference_golden():
+    """bf16 engine against the REFERENCE batch run with RepetitionPenaltyLogitsProcessor(1.3) (fp32 golden,
+    oracle/gen_golden_batch_processors.py): per sample the tokens agree up to the first position where the penalised top-2 gap
+    of the fp32 oracle is inside the tolerance (near-tie)."""
+    from transformers import LogitsProcessorList, RepetitionPenaltyLogitsProcessor
+    from tests.tiny_model import tiny_weights
+    g = np.load(os.path.join(GOLDEN, 'llama_tiny_batch_fp32_rep.npz'))
+    shape, sd = tiny_shape(), _bf16_sd()
+    oracle = lo.OracleLlama(shape, tiny_weights(0, torch.float32))
+    procs = LogitsProcessorList([RepetitionPenaltyLogitsProcessor(float(g['penalty']))])
+    whole = 0
+    for name, max_blocks in (('b2', 0), ('b3pad', 0), ('b3pad256', 4)):
+        bs, dl, max_new = [int(x) for x in g[f'{name}_cfg']]
+        model = BatchLlama(shape, dict(sd), max_length=256, max_batch=4, max_blocks=max_blocks)
+        ids, am = torch.from_numpy(g[f'{name}_ids']), torch.from_numpy(g[f'{name}_am'])
+        P = ids.shape[1]
+        dk = {'use_lookahead': True, 'decoding_mode': 'hier', 'decoding_length': dl, 'branch_length': 12, 'stop_words': {}}
+        out = model.lookahead_generation(ids, logits_processor=procs, stopping_criteria=P + max_new, eos_token_id=2, pad_token_id=0,
+                                         return_dict_in_generate=True, attention_mask=am, decoding_kwargs=dk)
+        ref, got = g[f'{name}_r0_sequences'], out.sequences.cpu().numpy()
+        if got.shape == ref.shape and bool((got == ref).all()):
+            assert out.kwargs['dls'] == g[f'{name}_r0_dls'].tolist() and out.kwargs['edls'] == g[f'{name}_r0_edls'].tolist()
+            whole += 1
+            continue
+        for b in range(bs):
+            w = min(got.shape[1], ref.shape[1])
+            diff = np.nonzero(got[b, :w] != ref[b, :w])[0]
+            if len(diff) == 0:
+                continue
+            i = int(diff[0])
+            ctx = [int(t) for t, m in zip(ref[b, :P], am[b]) if m] + ref[b, P:i].tolist()
+            lg, _ = oracle.forward(torch.tensor(ctx), torch.tril(torch.ones((len(ctx), len(ctx)), dtype=torch.long)), None)
+            sc = procs(torch.from_numpy(ref[b:b + 1, :i]), lg[-1:].float().clone())[0]
+            top = torch.topk(sc, 2).values
+            assert float(top[0] - top[1]) <= 2 * TOL * float(lg[-1].float().abs().max()), (name, b, i)
+    print('batch processor cases identical to the reference run end to end:', whole, 'of 3')

@@ -118,6 +118,48 @@ def test_batch_loop_reproduces_reference_batch_run():
     assert gre[:, :ids.shape[1] + 20].tolist() == [r[:ids.shape[1] + 20] for r in g['b4w256_r0_sequences'].tolist()]
 
 
+def test_batch_loop_sequential_processor_path_reproduces_reference():
+    """Batch loop with RepetitionPenaltyLogitsProcessor(1.3) — the sequential accept path (forward-only step, host walk with
+    the processors over the padded row + accepted tokens, host-decided commit) — against the reference batch run with the same
+    processor (pretrained_model_batch.py:814-931): sequences / dls / edls exact, on the shared-block engine surface (bstep /
+    bcommit) and, for the 256-token budget, one block per sample (mstep / mcommit)."""
+    import os
+    from transformers import LogitsProcessorList, RepetitionPenaltyLogitsProcessor
+    from painlessinferenceacceleration_amd.pretrained_model_batch import LookaheadPreTrainedModel as BatchMixin
+    from tests.oracle_engine import OracleBatchEngine
+    from tests.tiny_model import GOLDEN
+
+    class BModel(BatchMixin):
+        def __init__(self, max_blocks):
+            self.engine = OracleBatchEngine(tiny_shape(), tiny_weights(0), max_length=256, n_slots=4, max_blocks=max_blocks)
+            self.generation_config = SimpleNamespace(eos_token_id=2, pad_token_id=0, return_dict_in_generate=False)
+            self.lookahead_cache = LookaheadCache()
+
+    g = np.load(os.path.join(GOLDEN, 'llama_tiny_batch_fp32_rep.npz'))
+    procs = LogitsProcessorList([RepetitionPenaltyLogitsProcessor(float(g['penalty']))])
+    for name, max_blocks in (('b2', 0), ('b3pad', 0), ('b3pad', 4), ('b3pad256', 4)):
+        bs, dl, max_new = [int(x) for x in g[f'{name}_cfg']]
+        ids, am = torch.from_numpy(g[f'{name}_ids']), torch.from_numpy(g[f'{name}_am'])
+        m = BModel(max_blocks)
+        for r in range(2):
+            dk = dict(DK); dk['decoding_length'] = dl
+            out = m.lookahead_generation(ids, logits_processor=procs, stopping_criteria=ids.shape[1] + max_new, eos_token_id=2,
+                                         pad_token_id=0, return_dict_in_generate=True, attention_mask=am, decoding_kwargs=dk)
+            assert out.sequences.tolist() == g[f'{name}_r{r}_sequences'].tolist(), (name, r)
+            assert out.kwargs['dls'] == g[f'{name}_r{r}_dls'].tolist(), (name, r)
+            assert out.kwargs['edls'] == g[f'{name}_r{r}_edls'].tolist(), (name, r)
+    # the generate() front door: repetition_penalty= builds the same processor; without lookahead the host-pick greedy loop
+    # emits the same tokens (lookahead is lossless under processors too)
+    m = BModel(0)
+    ids, am = torch.from_numpy(g['b3pad_ids']), torch.from_numpy(g['b3pad_am'])
+    a = m.generate(input_ids=ids, attention_mask=am, max_new_tokens=20, decoding_kwargs=dict(DK), eos_token_id=2, pad_token_id=0,
+                   repetition_penalty=float(g['penalty']))
+    b = m.generate(input_ids=ids, attention_mask=am, max_new_tokens=20, decoding_kwargs={'use_lookahead': False}, eos_token_id=2,
+                   pad_token_id=0, repetition_penalty=float(g['penalty']))
+    n = ids.shape[1] + 20
+    assert a[:, :n].tolist() == b[:, :n].tolist() == [row[:n] for row in g['b3pad_r0_sequences'].tolist()]
+
+
 def test_benchmark_harness_perf_check_and_trie_loop(capsys):
     """painlessinferenceacceleration_amd.benchmark.Benchmark (methodology of lookahead/benchmarks/benchmark.py): warm_up +
     perf_check over a (decoding_length, branch_length) grid on the oracle-backed model, and the trie-only timing loop."""

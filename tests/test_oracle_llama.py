@@ -210,3 +210,26 @@ def test_attention_scale_as_multiply_is_exact():
     div = (x / 11.313708498984761).to(torch.bfloat16).view(torch.int16)
     mul = (x * torch.tensor(np.float32(0.088388346135616302490234375))).to(torch.bfloat16).view(torch.int16)
     assert bool((div[fin] == mul[fin]).all())
+
+
+def test_oracle_batch_sequential_processor_path_matches_reference():
+    """Batch twin with RepetitionPenaltyLogitsProcessor(1.3): the per-sample sequential accept walk of
+    pretrained_model_batch.py:814-931 (processors see the padded row up to the accepted token) and the batch-wise processor
+    call of the prefill (:783); bs 2 / 3 with left padding, budgets 64 / 256, two consecutive requests each."""
+    from transformers import LogitsProcessorList, RepetitionPenaltyLogitsProcessor
+    g = np.load(os.path.join(GOLDEN, 'llama_tiny_batch_fp32_rep.npz'))
+    torch.set_num_threads(4)
+    model = lo.OracleLlamaBatch(tiny_shape(), tiny_weights(0, torch.float32))
+    procs = LogitsProcessorList([RepetitionPenaltyLogitsProcessor(float(g['penalty']))])
+    partial = 0
+    for name in g['cases'].tolist():
+        bs, dl, max_new = [int(x) for x in g[f'{name}_cfg']]
+        ids, am = g[f'{name}_ids'], g[f'{name}_am']
+        cache = TrieOracle()
+        for r in range(2):
+            out = lo.lookahead_generate_batch(model, cache, ids, am, ids.shape[1] + max_new, eos_token_id=2, pad_token_id=0,
+                                              decoding_length=dl, branch_length=12, logits_processor=procs)
+            assert out['sequences'].tolist() == g[f'{name}_r{r}_sequences'].tolist(), (name, r)
+            assert out['dls'] == g[f'{name}_r{r}_dls'].tolist() and out['edls'] == g[f'{name}_r{r}_edls'].tolist(), (name, r)
+            partial += sum(1 for d, e in zip(out['dls'], out['edls']) if 1 < e < min(d, 13))
+    assert partial > 0          # the fixture exercises partially accepted trees, not only full chains
