@@ -106,6 +106,7 @@ PROTOTYPES = {
     "la_abi_version": (i32,),
     "la_last_error": (C.c_char_p,),
     "la_debug_set": (i32, i32, i32),
+    "la_debug_get": (i32, i32),
     "la_debug_set_ptr": (i32, i32, vp),
     "la_cache_create": (vp, i32, i32),
     "la_cache_destroy": (None, vp),

@@ -11,6 +11,7 @@
 #include <atomic>
 #include "la_kernels.h"
 #include "la_mblock.h"
+extern int g_la_pf_kib, g_la_pf_delay, g_la_graph_epoch;
 
 extern void la_set_error(const std::string& s);
 
@@ -67,6 +68,7 @@ struct la_llama {
     int32_t* zc_out;
     int seq_expected;          // value host_out[LA_ST_SEQ] takes when the last launched step has been published
     bool graph_ready, bgraph_ready;
+    int graph_epoch = 0;       // g_la_graph_epoch at the time the single-sequence step graph was captured
     hipStream_t graph_stream;
 };
 
@@ -334,7 +336,17 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
     else KCHK(lk_build_tree_inputs(st, zc_in ? (const int*)zc_in : m->in, m->state, m->pos, m->rowmask, m->ids));
     const int cf = c.norm_cast_first;
     if (m->fuse) HIPCHK(hipMemsetAsync(m->fuse_cnt, 0, sizeof(int) * 2 * c.n_layers, st));
-    KCHK(lk_embed_norm(st, m->w.embed, m->ids, m->layers[0].norm1, c.hidden, c.rms_eps, m->h, m->xp, cf));
+    // Idle-window weight prefetch (la_kernels.h, PfDesc): the row kernels and the attention combine carry extra workgroups that
+    // pull the first KiB every workgroup of the NEXT GEMM will stream into the L2 of its XCD.  g_la_pf_kib = 0 switches it off.
+    const int pf_kib = m->fuse ? 0 : g_la_pf_kib, pf_dly = g_la_pf_delay;
+    auto pf_qkv = [&](int l, PfDesc* d) {
+        *d = PfDesc{};
+        if (pf_kib > 0 && l < c.n_layers && c.balanced_wg[0] > 0)
+            lk_pf_planned(d, m->layers[l].wqkv, 2, (c.n_heads + 2 * c.n_kv_heads) * 128, c.hidden, c.balanced_wg[0], pf_kib, pf_dly, nullptr);
+    };
+    PfDesc pd{};
+    pf_qkv(0, &pd);
+    KCHK(lk_embed_norm(st, m->w.embed, m->ids, m->layers[0].norm1, c.hidden, c.rms_eps, m->h, m->xp, cf, &pd));
     for (int l = 0; l < c.n_layers; ++l) {
         const la_llama_layer_weights& L = m->layers[l];
         uint16_t* kf = m->kfresh + (size_t)l * m->fresh_layer_elems;
@@ -355,14 +367,16 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
                              m->qf, kf, vf));
         }
         P(KC_ATTN);
+        pd = PfDesc{};
+        if (pf_kib > 0) lk_pf_classic(&pd, L.wo, c.hidden, m->o_k, m->o_rb, m->o_ks, pf_kib, pf_dly, nullptr);
         if (batch)
             KCHK(lk_tree_attn_b(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
                                 kf, vf, m->rowmask, m->bstate, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, bsplit > 0 ? bsplit : m->nsplit,
-                                m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window, ring));
+                                m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window, ring, &pd));
         else
             KCHK(lk_tree_attn(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
                               kf, vf, m->rowmask, m->state, c.n_heads, c.n_kv_heads, m->total_keys, m->nsplit,
-                              m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window, ring));
+                              m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window, ring, &pd));
         P(KC_O);
         KCHK(lk_gemm64_slab(st, L.wo, m->attn_xp, c.hidden, m->o_k, m->o_rb, m->o_ks, m->slabs));
         P(KC_OTHER);
@@ -412,7 +426,9 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
             P(KC_GATEUP);
             KCHK(lk_gemm64r_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, c.balanced_wg[1], m->act_xp, nullptr, &fg));
         } else {
-            KCHK(lk_resid_norm(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp, cf));
+            pd = PfDesc{};
+            if (pf_kib > 0 && c.balanced_wg[1] > 0) lk_pf_planned(&pd, L.wgateup, 1, c.ffn, c.hidden, c.balanced_wg[1], pf_kib, pf_dly, nullptr);
+            KCHK(lk_resid_norm(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp, cf, &pd));
             P(KC_GATEUP);
             if (c.balanced_wg[1] > 0) KCHK(lk_gemm64r_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, c.balanced_wg[1], m->act_xp));
             else KCHK(lk_gemm64_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, m->act_xp, m->gu_variant));
@@ -420,8 +436,14 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
         P(KC_DOWN);
         KCHK(lk_gemm64_slab(st, L.wdown, m->act_xp, c.hidden, c.ffn, m->down_rb, m->down_ks, m->slabs));
         P(KC_OTHER);
-        if (!((m->fuse & 2) && l + 1 < c.n_layers))          // otherwise fused into the next layer's QKV launch
-            KCHK(lk_resid_norm(st, m->h, m->slabs, m->down_ks, nw, c.hidden, c.rms_eps, m->xp, cf));
+        if (!((m->fuse & 2) && l + 1 < c.n_layers)) {        // otherwise fused into the next layer's QKV launch
+            if (l + 1 < c.n_layers) pf_qkv(l + 1, &pd);
+            else {
+                pd = PfDesc{};
+                if (pf_kib > 0 && c.balanced_wg[2] > 0) lk_pf_planned(&pd, m->w.lm_head, 0, c.vocab, c.hidden, c.balanced_wg[2], pf_kib, pf_dly, nullptr);
+            }
+            KCHK(lk_resid_norm(st, m->h, m->slabs, m->down_ks, nw, c.hidden, c.rms_eps, m->xp, cf, &pd));
+        }
     }
     P(KC_LMHEAD);
     int* am_rows = batch ? m->bstate + LA_BST_ARGMAX : m->state + LA_ST_ARGMAX;
@@ -613,7 +635,8 @@ extern "C" int la_llama_mstep_eager(la_llama* m, void* stream, const int32_t* ho
 extern "C" int la_llama_step(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out) {
     if (!m || !host_in || !host_out) return LA_E_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (m->graph_ready && (m->zc_in != host_in || m->zc_out != host_out)) {      // other staging blocks: capture again
+    // other staging blocks, or a capture-time knob (la_debug_set keys 7 / 8) changed since the capture: capture again
+    if (m->graph_ready && (m->zc_in != host_in || m->zc_out != host_out || m->graph_epoch != g_la_graph_epoch)) {
         (void)hipGraphExecDestroy(m->graph_exec);
         m->graph_exec = nullptr;
         m->graph_ready = false;
@@ -627,7 +650,7 @@ extern "C" int la_llama_step(la_llama* m, void* stream, const int32_t* host_in, 
         }
         int rc = build_graph(m, st, false, host_in, host_out);
         if (rc != LA_OK) return rc;
-        m->zc_in = host_in; m->zc_out = host_out;
+        m->zc_in = host_in; m->zc_out = host_out; m->graph_epoch = g_la_graph_epoch;
     }
     m->seq_expected += 1;
     HIPCHK(hipGraphLaunch(m->graph_exec, st));

@@ -13,6 +13,27 @@ struct FusedNorm {
     int* counter;                        // zeroed device int, one per fused launch and step
 };
 
+// Idle-window weight prefetch.  The row kernels (k_row_norm) and the attention combine stream almost nothing: HBM is idle while
+// they run, and the GEMM that follows starts cold.  Extra workgroups appended to those launches (block ids past the kernel's own)
+// read the first k-tiles every workgroup of the NEXT GEMM will stream — default cache policy, so the lines stay in the L2 of the
+// XCD whose CUs will ask for them (block b of a grid runs on XCD b % 8; the extra ids keep that residue) — and drop the data.
+// A descriptor names those bytes: consumer workgroup (bx, ks) / wave w / row-block rb starts at
+// base + bx*A + ks*A2 + boff[rb] + w*C[rb] and the first L[rb] bytes of that run are fetched.  Bit-identical by construction
+// (nothing is written); la_debug_set keys 7 (KiB per consumer workgroup, 0 = off) and 8 (start delay) drive it.
+struct PfDesc {
+    const char* base;         // null: no prefetch workgroups are appended
+    int n_consumers;          // workgroups of the consuming launch (= appended workgroups)
+    int nbx;                  // consumer gridDim.x (ks = b / nbx)
+    unsigned A, A2;           // bytes per bx / per ks step
+    unsigned boff[4], C[4], L[4];
+    int RB, NW;
+    int delay;                // s_sleep(32) rounds before the first load (lets the kernel's own loads go first)
+    unsigned magic;           // value the xor of the fetched data is compared with (never equal in practice): keeps the loads alive
+    int* sink;
+};
+void lk_pf_planned(PfDesc* d, const void* wp, int kind, int n_rows, int K, int n_wg, int kib, int delay, int* sink);
+void lk_pf_classic(PfDesc* d, const void* wp, int N, int K, int rbv, int ksplit, int kib, int delay, int* sink);
+
 int lk_pack_weight(hipStream_t st, const void* w, const void* w2, int N, int K, int interleave2, void* out);
 int lk_pack_x(hipStream_t st, const void* x, int K, void* out);
 int lk_gemm64_slab(hipStream_t st, const void* wp, const void* xp, int N, int K, int rb, int ksplit, float* slabs,
@@ -35,9 +56,9 @@ int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int n
                    const void* rcos, const void* rsin, void* qf, void* kfresh, void* vfresh, const FusedNorm* fn = nullptr);
 int lk_argmax_finalize(hipStream_t st, const float* cv, const int* ci, int n_tiles, int* out_rows);
 int lk_embed_norm(hipStream_t st, const void* embed, const int* ids, const void* nw, int hidden, float eps, void* h, void* xp,
-                  int cast_first = 0);
+                  int cast_first = 0, const PfDesc* pf = nullptr);
 int lk_resid_norm(hipStream_t st, void* h, const float* slabs, int n_slabs, const void* nw, int hidden, float eps, void* xp,
-                  int cast_first = 0);
+                  int cast_first = 0, const PfDesc* pf = nullptr);
 int lk_resid_norm_router(hipStream_t st, void* h, const float* slabs, int n_slabs, const void* nw, int hidden, float eps,
                          void* xp, const void* wrouter, int n_experts, int top_k, float* route_w, const int* n_rows,
                          int cast_first = 0);
@@ -49,10 +70,12 @@ int lk_qkv_post(hipStream_t st, const float* slabs, int n_slabs, int nh, int nkv
                 const void* rsin, void* qf, void* kfresh, void* vfresh);
 int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                  const void* vfresh, const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys,
-                 int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window = 0, int ring_keys = 0);
+                 int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window = 0, int ring_keys = 0,
+                 const PfDesc* pf = nullptr);
 int lk_tree_attn_b(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                    const void* vfresh, const uint64_t* rowmask, const int* bstate, int nh, int nkv, int slot_keys,
-                   int n_slots, int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window = 0, int ring_keys = 0);
+                   int n_slots, int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window = 0, int ring_keys = 0,
+                   const PfDesc* pf = nullptr);
 int lk_build_tree_inputs_b(hipStream_t st, const int* in, int* bstate, int* pos, uint64_t* rowmask, int* ids);
 int lk_accept_scan_b(hipStream_t st, const int* in, const int* ids, const uint64_t* rowmask, int* bstate, int n_slots,
                      int slot_keys, int ring = 0);

@@ -206,6 +206,47 @@ __device__ __forceinline__ void row_norm_body(const int t, float* sh, float (*sh
     }
 }
 
+// Prefetch workgroup b of an idle-window launch (see PfDesc, la_kernels.h): up to PF_MAX 16-byte loads per thread, all issued
+// before the first use, covering the first bytes each wave of consumer workgroup b will stream.  The data is xor-folded and
+// compared with a value it never has, so the loads stay in the program and the wave only retires once they have landed in L2.
+#define PF_MAX 16
+__device__ __forceinline__ void pf_body(const PfDesc& p, int b) {
+    if (b >= p.n_consumers) return;
+    for (int i = 0; i < p.delay; ++i) __builtin_amdgcn_s_sleep(32);
+    const int bx = b % p.nbx, ks = b / p.nbx;
+    const char* __restrict__ start = p.base + (size_t)bx * p.A + (size_t)ks * p.A2;
+    const unsigned n0 = p.L[0] >> 4, n1 = p.RB > 1 ? p.L[1] >> 4 : 0u, n2 = p.RB > 2 ? p.L[2] >> 4 : 0u, n3 = p.RB > 3 ? p.L[3] >> 4 : 0u;
+    const unsigned cps = n0 + n1 + n2 + n3;              // 16-byte chunks per consumer wave
+    const unsigned total = cps * (unsigned)p.NW;
+    if (total == 0u) return;
+    // Every thread issues PF_MAX loads back to back (indices past the end re-read the last chunk: an L2 hit) as asm statements —
+    // hipcc otherwise consumes each pair of loads before issuing the next — and waits once; the destination registers are
+    // operands of the wait, so nothing is allocated over a load that is still in flight.  The data itself is dropped.
+    const unsigned e1 = n0, e2 = n0 + n1, e3 = n0 + n1 + n2;
+    const unsigned bo0 = p.boff[0], bo1 = p.boff[1], bo2 = p.boff[2], bo3 = p.boff[3];      // scalars (kernel-argument loads)
+    const unsigned cw0 = p.C[0], cw1 = p.C[1], cw2 = p.C[2], cw3 = p.C[3];
+    // chunk index i = tid + j * blockDim -> (wave w, chunk r of the wave's cps): one division, then uniform steps
+    const unsigned step_w = blockDim.x / cps, step_r = blockDim.x - step_w * cps;
+    unsigned w = threadIdx.x / cps, r = threadIdx.x - w * cps, i = threadIdx.x;
+    f32x4 v[PF_MAX];
+#pragma unroll
+    for (int j = 0; j < PF_MAX; ++j) {
+        const bool in = i < total;
+        const unsigned ww = in ? w : (unsigned)p.NW - 1u, rr = in ? r : cps - 1u;
+        const bool a1 = rr >= e1, a2 = rr >= e2, a3 = rr >= e3;
+        const unsigned rb0 = a3 ? e3 : a2 ? e2 : a1 ? e1 : 0u;
+        const unsigned bo = a3 ? bo3 : a2 ? bo2 : a1 ? bo1 : bo0;
+        const unsigned cw = a3 ? cw3 : a2 ? cw2 : a1 ? cw1 : cw0;
+        const char* addr = start + (size_t)bo + (size_t)ww * cw + (size_t)(rr - rb0) * 16;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[j]) : "v"(addr));
+        i += blockDim.x; w += step_w; r += step_r;
+        if (r >= cps) { r -= cps; ++w; }
+    }
+    static_assert(PF_MAX == 16, "operand list of the wait below");
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+                 "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]) : "memory");
+}
+
 template <int NS, bool MOE>
 __global__ __launch_bounds__(512) void k_row_norm(const bf16_t* __restrict__ embed, const int* __restrict__ ids,
                                                    bf16_t* __restrict__ h, const float* __restrict__ slabs,
@@ -213,9 +254,10 @@ __global__ __launch_bounds__(512) void k_row_norm(const bf16_t* __restrict__ emb
                                                    bf16_t* __restrict__ xp, const bf16_t* __restrict__ addend,
                                                    const bf16_t* __restrict__ wrouter, int n_experts, int top_k,
                                                    float* __restrict__ route_w, const int* __restrict__ n_rows,
-                                                   int cast_first) {
+                                                   int cast_first, PfDesc pf) {
     __shared__ float sh[8];
     __shared__ float shr[MOE ? 8 : 1][LA_MOE_MAX_E];
+    if (blockIdx.x >= LA_TB) { pf_body(pf, (int)blockIdx.x - LA_TB); return; }      // appended idle-window prefetch workgroups
     row_norm_body<NS, MOE>(blockIdx.x, sh, shr, embed, ids, h, slabs, nw, hidden, eps, xp, addend, wrouter, n_experts, top_k,
                            route_w, n_rows, cast_first);
 }
@@ -1247,7 +1289,9 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
 template <int NS>
 __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ opart, const float* __restrict__ mpart,
                                                        const float* __restrict__ lpart, int nh,
-                                                       const int* __restrict__ seq, bf16_t* __restrict__ attn_xp) {
+                                                       const int* __restrict__ seq, bf16_t* __restrict__ attn_xp,
+                                                       int n_main, PfDesc pf) {
+    if ((int)blockIdx.x >= n_main) { pf_body(pf, (int)blockIdx.x - n_main); return; }   // appended idle-window prefetch workgroups
     int gid = blockIdx.x * 256 + threadIdx.x;   // (h, tok, d8)
     if (gid >= nh * LA_TB * 16) return;
     int d8 = gid & 15, tok = (gid >> 4) & 63, h = gid >> 10;
@@ -1512,6 +1556,9 @@ int g_la_dbg_noepi = 0;
 int g_la_kskew = 0;
 int g_la_prio_hi = 0;         // s_setprio level of waves 4..7 in the 8-wave GEMMs (measurement knob, key 2)           // K share of waves 0..3 in 1/64ths (8-wave GEMMs); set before the step graph is captured
 long long* g_la_dbg_times = nullptr;
+int g_la_pf_kib = 0;          // idle-window weight prefetch: KiB per consumer workgroup (la_debug_set key 7; read when a step graph is captured)
+int g_la_graph_epoch = 0;     // bumped by la_debug_set when a capture-time knob changes: la_llama_step captures its graph again
+int g_la_pf_delay = 0;        // s_sleep(32) rounds the prefetch workgroups wait before their first load (key 8)
 
 #define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
@@ -1603,6 +1650,48 @@ long lk_planned_elems(int kind, int n_rows, int K, int n_wg) {
     if (kind == 1) { ra.R = n_rows / n_wg; fill_nv(ra, ra.R, 2, 2); }
     else { ra.R = n_rows / n_wg; fill_nv(ra, ra.R, 4, 1); }
     return (long)n_wg * ra.wg_chunks * 8;
+}
+// Prefetch descriptors (PfDesc) of the first `kib` KiB each workgroup of a GEMM launch will stream.
+// planned images (k_gemm64r): kind / n_rows as lk_rowplan; 8 waves split K evenly, wave w starts at k-tile w * K16 / 8.
+void lk_pf_planned(PfDesc* d, const void* wp, int kind, int n_rows, int K, int n_wg, int kib, int delay, int* sink) {
+    *d = PfDesc{};
+    if (!wp || kib <= 0 || n_wg <= 0) return;
+    GemmRArgs ra{}; ra.g.K16 = K / 16;
+    int RB;
+    if (kind == 2) { const int pairs = n_rows / 2; ra.R = pairs / n_wg; RB = 2;
+        ra.nvl[0] = ra.nvl[1] = (ra.R + 3) & ~3;
+        ra.boff[0] = 0; ra.boff[1] = ra.nvl[0] * 2 * ra.g.K16; ra.wg_chunks = 2 * ra.boff[1]; }
+    else if (kind == 1) { ra.R = n_rows / n_wg; fill_nv(ra, ra.R, 2, 2); RB = 4; }
+    else { ra.R = n_rows / n_wg; fill_nv(ra, ra.R, 4, 1); RB = 4; }
+    const int NW = 8, q = ra.g.K16 / NW;
+    int tile_all = 0;                                   // bytes of one k-tile over all row-blocks
+    for (int rb = 0; rb < RB; ++rb) tile_all += 2 * ra.nvl[rb] * 16;
+    int P = (kib * 1024) / (NW * tile_all);             // k-tiles per wave
+    if (P > q) P = q;
+    if (P < 1) return;
+    d->base = (const char*)wp; d->n_consumers = n_wg; d->nbx = n_wg; d->A = (unsigned)ra.wg_chunks * 16u; d->A2 = 0u;
+    for (int rb = 0; rb < RB; ++rb) {
+        const unsigned wstr = 2u * (unsigned)ra.nvl[rb] * 16u;      // bytes per k-tile of this row-block
+        d->boff[rb] = (unsigned)ra.boff[rb] * 16u; d->C[rb] = (unsigned)q * wstr; d->L[rb] = (unsigned)P * wstr;
+    }
+    d->RB = RB; d->NW = NW; d->delay = delay; d->magic = 0x5bd1e995u; d->sink = sink;
+}
+// classic images (k_gemm64 over la_pack_weight, grid (N / (32 RB), ksplit)): rbv as lk_gemm64_slab
+void lk_pf_classic(PfDesc* d, const void* wp, int N, int K, int rbv, int ksplit, int kib, int delay, int* sink) {
+    *d = PfDesc{};
+    if (!wp || kib <= 0 || ksplit <= 0) return;
+    const int rb0 = rbv & 0xff, variant = rbv >> 8, K16 = K / 16;
+    const int RB = (rb0 == 2 && (N % 64) == 0) ? 2 : 1;
+    const int NW = (variant == 3 || variant == 4 || (RB == 1 && variant == 1)) ? 8 : 4;
+    const int nbx = N / (32 * RB), per = K16 / ksplit, q = per / NW;
+    if (q < 1) return;
+    int P = (kib * 1024) / (NW * RB * 1024);
+    if (P > q) P = q;
+    if (P < 1) return;
+    d->base = (const char*)wp; d->n_consumers = nbx * ksplit; d->nbx = nbx;
+    d->A = (unsigned)RB * (unsigned)K16 * 1024u; d->A2 = (unsigned)per * 1024u;
+    for (int rb = 0; rb < RB; ++rb) { d->boff[rb] = (unsigned)rb * (unsigned)K16 * 1024u; d->C[rb] = (unsigned)q * 1024u; d->L[rb] = (unsigned)P * 1024u; }
+    d->RB = RB; d->NW = NW; d->delay = delay; d->magic = 0x5bd1e995u; d->sink = sink;
 }
 // planned packing (see k_pack_planned): kind as lk_rowplan
 int lk_pack_planned(hipStream_t st, const void* w, const void* w2, const int* d_plan, int kind, int n_rows, int K, int n_wg, void* out) {
@@ -1723,18 +1812,23 @@ int lk_argmax_finalize(hipStream_t st, const float* cv, const int* ci, int n_til
     k_argmax_finalize<<<LA_TB, 256, 0, st>>>(cv, ci, n_tiles, out_rows);
     LAUNCH_CHECK(); return 0;
 }
+// appended prefetch workgroups of a launch whose own grid has n_main workgroups (n_main % 8 == 0 keeps the XCD residue)
+static inline int pf_extra(const PfDesc* pf) { return (pf && pf->base && pf->n_consumers > 0) ? pf->n_consumers : 0; }
+static inline PfDesc pf_or_none(const PfDesc* pf) { PfDesc d{}; if (pf_extra(pf)) d = *pf; return d; }
+
 int lk_embed_norm(hipStream_t st, const void* embed, const int* ids, const void* nw, int hidden, float eps, void* h, void* xp,
-                  int cast_first) {
+                  int cast_first, const PfDesc* pf) {
     if (hidden > 8192 || (hidden & 7)) return -1;
-    k_row_norm<0, false><<<LA_TB, 512, 0, st>>>((const bf16_t*)embed, ids, (bf16_t*)h, nullptr, (const bf16_t*)nw, hidden, eps,
-                                                (bf16_t*)xp, nullptr, nullptr, 0, 0, nullptr, nullptr, cast_first);
+    k_row_norm<0, false><<<LA_TB + pf_extra(pf), 512, 0, st>>>((const bf16_t*)embed, ids, (bf16_t*)h, nullptr, (const bf16_t*)nw, hidden, eps,
+                                                (bf16_t*)xp, nullptr, nullptr, 0, 0, nullptr, nullptr, cast_first, pf_or_none(pf));
     LAUNCH_CHECK(); return 0;
 }
 int lk_resid_norm(hipStream_t st, void* h, const float* slabs, int n_slabs, const void* nw, int hidden, float eps, void* xp,
-                  int cast_first) {
+                  int cast_first, const PfDesc* pf) {
     if (hidden > 8192 || (hidden & 7)) return -1;
-#define RN(NS) k_row_norm<NS, false><<<LA_TB, 512, 0, st>>>(nullptr, nullptr, (bf16_t*)h, slabs, (const bf16_t*)nw, hidden, eps, \
-                                                            (bf16_t*)xp, nullptr, nullptr, 0, 0, nullptr, nullptr, cast_first)
+    const PfDesc pfd = pf_or_none(pf);
+#define RN(NS) k_row_norm<NS, false><<<LA_TB + pf_extra(pf), 512, 0, st>>>(nullptr, nullptr, (bf16_t*)h, slabs, (const bf16_t*)nw, hidden, eps, \
+                                                            (bf16_t*)xp, nullptr, nullptr, 0, 0, nullptr, nullptr, cast_first, pfd)
     switch (n_slabs) {
         case 0: RN(0); break; case 1: RN(1); break; case 2: RN(2); break; case 3: RN(3); break;
         case 4: RN(4); break; case 6: RN(6); break; case 8: RN(8); break;
@@ -1749,7 +1843,7 @@ int lk_resid_norm_router(hipStream_t st, void* h, const float* slabs, int n_slab
                          int cast_first) {
     if (hidden > 8192 || (hidden & 7) || n_experts < 1 || n_experts > LA_MOE_MAX_E || top_k < 1 || top_k > n_experts) return -1;
 #define RN(NS) k_row_norm<NS, true><<<LA_TB, 512, 0, st>>>(nullptr, nullptr, (bf16_t*)h, slabs, (const bf16_t*)nw, hidden, eps, \
-                                                           (bf16_t*)xp, nullptr, (const bf16_t*)wrouter, n_experts, top_k, route_w, n_rows, cast_first)
+                                                           (bf16_t*)xp, nullptr, (const bf16_t*)wrouter, n_experts, top_k, route_w, n_rows, cast_first, PfDesc{})
     switch (n_slabs) {
         case 1: RN(1); break; case 2: RN(2); break; case 3: RN(3); break; case 4: RN(4); break;
         case 6: RN(6); break; case 8: RN(8); break;
@@ -1763,7 +1857,7 @@ int lk_resid_norm_addend(hipStream_t st, void* h, const void* addend, const void
                          int cast_first) {
     if (hidden > 8192 || (hidden & 7) || !addend) return -1;
     k_row_norm<0, false><<<LA_TB, 512, 0, st>>>(nullptr, nullptr, (bf16_t*)h, nullptr, (const bf16_t*)nw, hidden, eps,
-                                                (bf16_t*)xp, (const bf16_t*)addend, nullptr, 0, 0, nullptr, nullptr, cast_first);
+                                                (bf16_t*)xp, (const bf16_t*)addend, nullptr, 0, 0, nullptr, nullptr, cast_first, PfDesc{});
     LAUNCH_CHECK(); return 0;
 }
 int lk_moe_accum(hipStream_t st, const float* slabs, int n_slabs, const float* route_col, int hidden, void* acc, int first) {
@@ -1793,11 +1887,12 @@ int lk_qkv_post(hipStream_t st, const float* slabs, int n_slabs, int nh, int nkv
 #undef QP
     LAUNCH_CHECK(); return 0;
 }
-static int tree_attn_launch(hipStream_t st, AttnArgs a, int n_slots, void* attn_xp);
+static int tree_attn_launch(hipStream_t st, AttnArgs a, int n_slots, void* attn_xp, const PfDesc* pf);
 
 int lk_tree_attn_b(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                    const void* vfresh, const uint64_t* rowmask, const int* bstate, int nh, int nkv, int slot_keys,
-                   int n_slots, int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window, int ring_keys) {
+                   int n_slots, int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window, int ring_keys,
+                   const PfDesc* pf) {
     if (n_slots < 1 || n_slots > LA_MAX_SEQ || (slot_keys & 31)) return -1;
     AttnArgs a{};
     a.dbg_times = g_la_dbg_times;
@@ -1808,12 +1903,13 @@ int lk_tree_attn_b(hipStream_t st, const void* qf, const void* kmain, const void
     a.nh = nh; a.nkv = nkv; a.max_keys = slot_keys * n_slots; a.nsplit = nsplit;
     a.opart = opart; a.mpart = mpart; a.lpart = lpart;
     a.seq = bstate + LA_BST_SEQ; a.nkeys_b = bstate + LA_BST_NKEYS; a.slot_tiles = slot_keys >> 5;
-    return tree_attn_launch(st, a, n_slots, attn_xp);
+    return tree_attn_launch(st, a, n_slots, attn_xp, pf);
 }
 
 int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                  const void* vfresh, const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys,
-                 int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window, int ring_keys) {
+                 int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window, int ring_keys,
+                 const PfDesc* pf) {
     AttnArgs a{};
     a.dbg_times = g_la_dbg_times;
     a.window = window; a.ring_tiles = ring_keys >> 5;
@@ -1823,17 +1919,20 @@ int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* 
     a.nh = nh; a.nkv = nkv; a.max_keys = max_keys; a.nsplit = nsplit;
     a.opart = opart; a.mpart = mpart; a.lpart = lpart;
     a.seq = nullptr; a.nkeys_b = nullptr; a.slot_tiles = 0;
-    return tree_attn_launch(st, a, 1, attn_xp);
+    return tree_attn_launch(st, a, 1, attn_xp, pf);
 }
 
-static int tree_attn_launch(hipStream_t st, AttnArgs a, int n_slots, void* attn_xp) {
+static int tree_attn_launch(hipStream_t st, AttnArgs a, int n_slots, void* attn_xp, const PfDesc* pf) {
     const int nh = a.nh, nsplit = a.nsplit;
     float *opart = a.opart, *mpart = a.mpart, *lpart = a.lpart;
     if (lk_gemm64r_init() != 0) return -1;
     k_tree_attn<<<dim3(nh, nsplit, n_slots), 2 * LA_ATT_PAR * 64, 2 * LA_ATT_PAR * 66 * 64 * sizeof(float), st>>>(a);
     LAUNCH_CHECK();
     int total = nh * LA_TB * 16;
-#define AC(NS) k_attn_combine<NS><<<(total + 255) / 256, 256, 0, st>>>(opart, mpart, lpart, nh, a.seq, (bf16_t*)attn_xp)
+    const int n_main = (total + 255) / 256;
+    if (n_main % 8) pf = nullptr;                    // appended ids would land on other XCDs than their consumers
+    const PfDesc pfd = pf_or_none(pf);
+#define AC(NS) k_attn_combine<NS><<<n_main + pf_extra(pf), 256, 0, st>>>(opart, mpart, lpart, nh, a.seq, (bf16_t*)attn_xp, n_main, pfd)
     switch (nsplit) {
         case 1: AC(1); break; case 2: AC(2); break; case 3: AC(3); break; case 4: AC(4); break; case 6: AC(6); break;
         case 8: AC(8); break; case 12: AC(12); break; case 16: AC(16); break;

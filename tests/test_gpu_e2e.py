@@ -11,6 +11,7 @@ import torch
 
 from oracle import llama_oracle as lo
 from oracle.trie_oracle import TrieOracle
+from painlessinferenceacceleration_amd import _lib
 from painlessinferenceacceleration_amd.llama_engine import LlamaShape, LlamaVerifyEngine, random_weights
 from painlessinferenceacceleration_amd.lookahead_cache import LookaheadCache
 from painlessinferenceacceleration_amd.modeling_llama import LlamaForCausalLM
@@ -18,6 +19,7 @@ from tests.gpu_utils import random_tree
 from tests.tiny_model import GOLDEN, load_golden, tiny_shape, tiny_weights
 
 pytestmark = pytest.mark.gpu
+PF_DEFAULT = (_lib.lib.la_debug_get(7), _lib.lib.la_debug_get(8))     # the library's idle-window prefetch default
 TOL = 2e-2
 
 
@@ -303,6 +305,42 @@ def test_fused_norm_gemm_launches_are_bitwise_identical_to_separate_kernels():
     for o in outs[1:]:
         assert o[0] == outs[0][0] and o[1] == outs[0][1] and o[2] == outs[0][2]
         assert torch.equal(o[3][:1], outs[0][3][:1]) and torch.equal(o[4][:1], outs[0][4][:1])
+
+
+def test_idle_window_prefetch_is_bitwise_neutral():
+    """la_debug_set keys 7 / 8: the extra workgroups appended to the row kernels and to the attention combine only READ the next
+    GEMM's first k-tiles (planned QKV / gate-up / lm_head images, classic o_proj image).  At the Llama-2-7B layer shape and on the
+    tiny model (classic images only) every setting must leave tokens, logits and hidden state bit-identical — graph and eager —
+    and must stay inside the weight images (an out-of-bounds descriptor would fault the launch)."""
+    from painlessinferenceacceleration_amd._lib import check, lib
+    from painlessinferenceacceleration_amd.llama_engine import random_weights
+    rs = np.random.RandomState(8)
+    try:
+        for shape, vocab, seed in ((LlamaShape(3, 4096, 32, 32, 11008, 32000, 1e-5), 32000, 4), (tiny_shape(), tiny_shape().vocab, 1)):
+            eng = LlamaVerifyEngine(shape, random_weights(shape, seed=seed, std=0.02, device='cuda:0'), max_length=512,
+                                    consume_state_dict=True)
+            prompt = rs.randint(3, vocab, size=100).tolist()
+            _, rows = random_tree(rs, 64)
+            ids = rs.randint(3, vocab, size=64).astype(np.int32)
+            outs = []
+            for kib, dly in ((0, 0), (16, 0), (64, 1), (128, 0), (128, 3)):
+                check(lib.la_debug_set(7, kib), 'debug_set')
+                check(lib.la_debug_set(8, dly), 'debug_set')
+                assert lib.la_debug_get(7) == kib and lib.la_debug_get(8) == dly
+                for eager in (False, True):
+                    eng.reset()
+                    eng.prefill(prompt, fast=False)
+                    toks, n = eng.step(ids, rows, eager=eager)
+                    toks2, _ = eng.step(np.asarray(toks[-1:], dtype=np.int32), np.array([1], dtype=np.uint64), eager=eager)
+                    outs.append((toks, n, toks2, eng.logits()[:1].clone(), eng.hidden()[:1].clone()))
+            for o in outs[1:]:
+                assert o[0] == outs[0][0] and o[1] == outs[0][1] and o[2] == outs[0][2]
+                assert torch.equal(o[3], outs[0][3]) and torch.equal(o[4], outs[0][4])
+            del eng
+            torch.cuda.empty_cache()
+    finally:
+        lib.la_debug_set(7, PF_DEFAULT[0])
+        lib.la_debug_set(8, PF_DEFAULT[1])
 
 
 @pytest.mark.parametrize('window', [40, 100])
