@@ -89,9 +89,9 @@ def fixed_t64b8_tree():
 
 
 def _pf_setting():
-    """(KiB per consumer workgroup, start delay) of the idle-window weight prefetch in effect (library default or LA_PF_KIB)."""
+    """(KiB per consumer workgroup, start delay, gate/up tail KiB) of the weight prefetch in effect (library default or LA_PF_KIB)."""
     from painlessinferenceacceleration_amd._lib import lib
-    return int(lib.la_debug_get(7)), int(lib.la_debug_get(8))
+    return int(lib.la_debug_get(7)), int(lib.la_debug_get(8)), int(lib.la_debug_get(9))
 
 
 def cpu_model_name():
@@ -184,11 +184,12 @@ def main():
     from painlessinferenceacceleration_amd.modeling_llama import LlamaForCausalLM
     from painlessinferenceacceleration_amd.modeling_llama_batch import LlamaForCausalLM as BatchLlama
 
-    # measurement override of the library's idle-window prefetch default (la_debug_set keys 7 / 8, scripts/gpu_pf_ab.py)
+    # measurement override of the library's idle-window prefetch default (la_debug_set keys 7 / 8 / 9, scripts/gpu_pf_ab.py)
     if os.environ.get('LA_PF_KIB') is not None:
         from painlessinferenceacceleration_amd._lib import check as _check, lib as _lalib
         _check(_lalib.la_debug_set(7, int(os.environ['LA_PF_KIB'])), 'debug_set')
         _check(_lalib.la_debug_set(8, int(os.environ.get('LA_PF_DELAY', '0'))), 'debug_set')
+        _check(_lalib.la_debug_set(9, int(os.environ.get('LA_PF_TAIL', '0'))), 'debug_set')
 
     shape = {'7b': LlamaShape.llama2_7b, '13b': LlamaShape.llama2_13b, 'mistral': LlamaShape.mistral_7b,
              'mixtral': LlamaShape.mixtral_8x7b}[args.model]()
@@ -480,6 +481,7 @@ def main():
                    'lookahead_equals_greedy': bool(correct), 'plain_greedy_tokens_per_sec': round(B * len(truth_own[0]) / t_greedy, 2),
                    'native_loop': native,
                    'idle_window_prefetch_kib': _pf_setting()[0], 'idle_window_prefetch_delay': _pf_setting()[1],
+                   'gateup_tail_prefetch_kib': _pf_setting()[2],
                    'speed_incl_prefill': {'prefill_ms': round(1e3 * t_prefill, 3), 'prefill_tokens': P * B,
                                           'generated_tokens': int(gen), 'decode_s': round(elapsed, 4),
                                           'tokens_per_sec': round(gen / (t_prefill + elapsed), 2),

@@ -53,7 +53,8 @@ const char*  la_last_error(void);
  * key 3: 1 = multi-block GEMMs always on the K-split kernels (no wide one-pass form); set before la_llama_mstep captures.
  * key 7: idle-window weight prefetch of the 64-row step, KiB per workgroup of the next GEMM (0 = off, <= 128): the row kernels and
  *        the attention combine carry extra workgroups that pull the first k-tiles of the next GEMM into L2 (bit-identical
- *        results); key 8: start delay of those workgroups in s_sleep(32) rounds.  Both are read when a step graph is captured. */
+ *        results); key 8: start delay of those workgroups in s_sleep(32) rounds; key 9: KiB per down_proj workgroup pulled in from
+ *        the tail of the gate/up launch (<= 64).  All three are read when a step graph is captured. */
 int          la_debug_set(int key, int value);
 int          la_debug_get(int key);          /* current value of a knob (the library default unless la_debug_set changed it) */
 /* key 0: device buffer int64[workgroups][waves][8] the GEMM kernels stamp with wall_clock64() at entry / end of the

@@ -11,7 +11,7 @@
 #include <atomic>
 #include "la_kernels.h"
 #include "la_mblock.h"
-extern int g_la_pf_kib, g_la_pf_delay, g_la_graph_epoch;
+extern int g_la_pf_kib, g_la_pf_delay, g_la_pf_tail_kib, g_la_graph_epoch;
 
 extern void la_set_error(const std::string& s);
 
@@ -430,8 +430,13 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
             if (pf_kib > 0 && c.balanced_wg[1] > 0) lk_pf_planned(&pd, L.wgateup, 1, c.ffn, c.hidden, c.balanced_wg[1], pf_kib, pf_dly, nullptr);
             KCHK(lk_resid_norm(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp, cf, &pd));
             P(KC_GATEUP);
-            if (c.balanced_wg[1] > 0) KCHK(lk_gemm64r_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, c.balanced_wg[1], m->act_xp));
-            else KCHK(lk_gemm64_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, m->act_xp, m->gu_variant));
+            if (c.balanced_wg[1] > 0) {
+                // down_proj follows at once: its first k-tiles are pulled into L2 from the tail of the gate/up launch
+                pd = PfDesc{};
+                if (g_la_pf_tail_kib > 0 && !m->fuse) lk_pf_classic(&pd, L.wdown, c.hidden, c.ffn, m->down_rb, m->down_ks, g_la_pf_tail_kib, 0, nullptr);
+                if (pd.n_consumers > c.balanced_wg[1]) pd = PfDesc{};         // one prefetching workgroup per consumer workgroup
+                KCHK(lk_gemm64r_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, c.balanced_wg[1], m->act_xp, nullptr, nullptr, &pd));
+            } else KCHK(lk_gemm64_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, m->act_xp, m->gu_variant));
         }
         P(KC_DOWN);
         KCHK(lk_gemm64_slab(st, L.wdown, m->act_xp, c.hidden, c.ffn, m->down_rb, m->down_ks, m->slabs));

@@ -50,7 +50,7 @@ int lk_rowplan(int kind, int n_rows, int n_wg, int* out);
 long lk_planned_elems(int kind, int n_rows, int K, int n_wg);
 int lk_pack_planned(hipStream_t st, const void* w, const void* w2, const int* d_plan, int kind, int n_rows, int K, int n_wg, void* out);
 int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, int n_wg, void* act_xp,
-                      const float* route_col = nullptr, const FusedNorm* fn = nullptr);
+                      const float* route_col = nullptr, const FusedNorm* fn = nullptr, const PfDesc* pf = nullptr);
 int lk_gemm64r_logits(hipStream_t st, const void* wp, const void* xp, int V, int K, int n_wg, void* logits, float* cv, int* ci);
 int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int nkv, int K, int n_wg, const int* pos,
                    const void* rcos, const void* rsin, void* qf, void* kfresh, void* vfresh, const FusedNorm* fn = nullptr);

@@ -206,31 +206,30 @@ __device__ __forceinline__ void row_norm_body(const int t, float* sh, float (*sh
     }
 }
 
-// Prefetch workgroup b of an idle-window launch (see PfDesc, la_kernels.h): up to PF_MAX 16-byte loads per thread, all issued
-// before the first use, covering the first bytes each wave of consumer workgroup b will stream.  The data is xor-folded and
-// compared with a value it never has, so the loads stay in the program and the wave only retires once they have landed in L2.
-#define PF_MAX 16
-__device__ __forceinline__ void pf_body(const PfDesc& p, int b) {
-    if (b >= p.n_consumers) return;
-    for (int i = 0; i < p.delay; ++i) __builtin_amdgcn_s_sleep(32);
+// Prefetch for consumer workgroup b (see PfDesc, la_kernels.h): every thread issues NT 16-byte loads back to back over the
+// first bytes each wave of that workgroup will stream (chunk indices past the end re-read the last chunk: an L2 hit).  The loads
+// are asm statements — hipcc otherwise consumes each pair before issuing the next — with default cache policy, and their data
+// is dropped: the destination registers only become operands of the closing wait (pf_wait*), so that nothing is allocated over a
+// load that is still in flight.
+// ASM = false issues plain loads instead (tail prefetch inside a GEMM launch): the compiler then counts them in the vmcnt waits
+// of the code that follows — an asm load is invisible to it, and a later s_waitcnt vmcnt(n) meant for an older load would drain
+// the prefetch too — and pf_keep* at the end of the kernel is their only consumer.
+template <int NT, bool ASM = true>
+__device__ __forceinline__ void pf_issue(const PfDesc& p, int b, f32x4 (&v)[NT]) {
+    b = b < p.n_consumers ? b : p.n_consumers - 1;
     const int bx = b % p.nbx, ks = b / p.nbx;
     const char* __restrict__ start = p.base + (size_t)bx * p.A + (size_t)ks * p.A2;
     const unsigned n0 = p.L[0] >> 4, n1 = p.RB > 1 ? p.L[1] >> 4 : 0u, n2 = p.RB > 2 ? p.L[2] >> 4 : 0u, n3 = p.RB > 3 ? p.L[3] >> 4 : 0u;
-    const unsigned cps = n0 + n1 + n2 + n3;              // 16-byte chunks per consumer wave
+    const unsigned cps = n0 + n1 + n2 + n3;              // 16-byte chunks per consumer wave (> 0: the host builds no empty descriptor)
     const unsigned total = cps * (unsigned)p.NW;
-    if (total == 0u) return;
-    // Every thread issues PF_MAX loads back to back (indices past the end re-read the last chunk: an L2 hit) as asm statements —
-    // hipcc otherwise consumes each pair of loads before issuing the next — and waits once; the destination registers are
-    // operands of the wait, so nothing is allocated over a load that is still in flight.  The data itself is dropped.
     const unsigned e1 = n0, e2 = n0 + n1, e3 = n0 + n1 + n2;
     const unsigned bo0 = p.boff[0], bo1 = p.boff[1], bo2 = p.boff[2], bo3 = p.boff[3];      // scalars (kernel-argument loads)
     const unsigned cw0 = p.C[0], cw1 = p.C[1], cw2 = p.C[2], cw3 = p.C[3];
     // chunk index i = tid + j * blockDim -> (wave w, chunk r of the wave's cps): one division, then uniform steps
     const unsigned step_w = blockDim.x / cps, step_r = blockDim.x - step_w * cps;
     unsigned w = threadIdx.x / cps, r = threadIdx.x - w * cps, i = threadIdx.x;
-    f32x4 v[PF_MAX];
 #pragma unroll
-    for (int j = 0; j < PF_MAX; ++j) {
+    for (int j = 0; j < NT; ++j) {
         const bool in = i < total;
         const unsigned ww = in ? w : (unsigned)p.NW - 1u, rr = in ? r : cps - 1u;
         const bool a1 = rr >= e1, a2 = rr >= e2, a3 = rr >= e3;
@@ -238,13 +237,27 @@ __device__ __forceinline__ void pf_body(const PfDesc& p, int b) {
         const unsigned bo = a3 ? bo3 : a2 ? bo2 : a1 ? bo1 : bo0;
         const unsigned cw = a3 ? cw3 : a2 ? cw2 : a1 ? cw1 : cw0;
         const char* addr = start + (size_t)bo + (size_t)ww * cw + (size_t)(rr - rb0) * 16;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[j]) : "v"(addr));
+        if constexpr (ASM) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[j]) : "v"(addr));
+        else v[j] = *(const f32x4*)addr;
         i += blockDim.x; w += step_w; r += step_r;
         if (r >= cps) { r -= cps; ++w; }
     }
-    static_assert(PF_MAX == 16, "operand list of the wait below");
+}
+__device__ __forceinline__ void pf_keep8(f32x4 (&v)[8]) {        // consumer of 8 plain prefetch loads (nothing is emitted)
+    asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+}
+__device__ __forceinline__ void pf_wait16(f32x4 (&v)[16]) {
     asm volatile("s_waitcnt vmcnt(0)" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
                  "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]) : "memory");
+}
+// An appended prefetch workgroup of an idle-window launch: optional start delay (the launch's own loads go first), 16 loads per
+// thread, and the wave retires once they have landed in L2.
+__device__ __forceinline__ void pf_body(const PfDesc& p, int b) {
+    if (b >= p.n_consumers) return;
+    for (int i = 0; i < p.delay; ++i) __builtin_amdgcn_s_sleep(32);
+    f32x4 v[16];
+    pf_issue<16>(p, b, v);
+    pf_wait16(v);
 }
 
 template <int NS, bool MOE>
@@ -593,6 +606,9 @@ struct GemmRArgs {
     int fn_hidden, fn_cast;
     float fn_eps;
     int* fn_counter;
+    // tail prefetch: after its streaming loop every workgroup pulls the first k-tiles the same-numbered workgroup of the NEXT GEMM
+    // (down_proj after gate/up: no idle-window kernel sits between them) will stream into L2, under its reduction + epilogue
+    PfDesc pf;
 };
 
 template <int RB, int EPI, int D, int NW, int NSF = 0>
@@ -698,10 +714,26 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
                 }
             }
         }
+        if constexpr (EPI == EPI_SWIGLU && NSF == 0) {
+            // Tail prefetch below: make every tile slot a consumed value, so that the compiler's scoreboard is empty on BOTH sides
+            // of the pf_on branch (slots past last_valid hold re-reads nobody uses; a wait for them placed after the join would
+            // also drain the prefetch loads).  At run time everything has returned by now: no instruction is emitted but waits.
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) asm volatile("" :: "v"(fa[d][rb]));
+                asm volatile("" :: "v"(fb[d][0]), "v"(fb[d][1]));
+            }
+        }
     }
 
     if (stamp && lane == 0) stamp[1] = wall_clock64();
     if (a.dbg_noepi) return;
+    f32x4 pfv[8];
+    const bool pf_on = EPI == EPI_SWIGLU && NSF == 0 && ra.pf.base != nullptr;        // wave-uniform
+    if constexpr (EPI == EPI_SWIGLU && NSF == 0) {
+        if (pf_on) pf_issue<8, false>(ra.pf, (int)blockIdx.x, pfv);
+    }
     // ---- cross-wave reduction through LDS in 16-byte units [wave][rb][i/4][lane] (ds_write_b128 / ds_read_b128), fixed
     //      summation order p = 0..NW-1 (deterministic), then every wave finishes a fixed slice.
     const int tl = lane & 31, hh = lane >> 5;
@@ -859,6 +891,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(GemmRArgs ra) {
             }
             best = -INFINITY; bidx = 0x7fffffff;
         }
+    }
+    if constexpr (EPI == EPI_SWIGLU && NSF == 0) {
+        if (pf_on) pf_keep8(pfv);              // the prefetch loads landed under the epilogue; their registers stay reserved until here
     }
     if (stamp && lane == 0) stamp[2] = wall_clock64();
 }
@@ -1557,10 +1592,16 @@ int g_la_kskew = 0;
 int g_la_prio_hi = 0;         // s_setprio level of waves 4..7 in the 8-wave GEMMs (measurement knob, key 2)           // K share of waves 0..3 in 1/64ths (8-wave GEMMs); set before the step graph is captured
 long long* g_la_dbg_times = nullptr;
 int g_la_pf_kib = 0;          // idle-window weight prefetch: KiB per consumer workgroup (la_debug_set key 7; read when a step graph is captured)
+int g_la_pf_tail_kib = 0;     // tail prefetch of down_proj from the gate/up launch: KiB per workgroup (key 9)
 int g_la_graph_epoch = 0;     // bumped by la_debug_set when a capture-time knob changes: la_llama_step captures its graph again
 int g_la_pf_delay = 0;        // s_sleep(32) rounds the prefetch workgroups wait before their first load (key 8)
 
 #define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+// appended prefetch workgroups of a launch whose own grid has n_main workgroups (n_main % 8 == 0 keeps the XCD residue)
+static inline int pf_extra(const PfDesc* pf) { return (pf && pf->base && pf->n_consumers > 0) ? pf->n_consumers : 0; }
+static inline PfDesc pf_or_none(const PfDesc* pf) { PfDesc d{}; if (pf_extra(pf)) d = *pf; return d; }
+
 
 int lk_pack_weight(hipStream_t st, const void* w, const void* w2, int N, int K, int il, void* out) {
     size_t total = (size_t)(il ? 2 * N : N) / 32 * (K / 16) * 64;
@@ -1716,11 +1757,12 @@ static bool set_fused_norm(GemmRArgs& ra, const FusedNorm* fn, int n_wg) {
     return true;
 }
 int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, int n_wg, void* act_xp,
-                      const float* route_col, const FusedNorm* fn) {
+                      const float* route_col, const FusedNorm* fn, const PfDesc* pf) {
     GemmRArgs ra{}; ra.g.dbg_noepi = g_la_dbg_noepi; ra.g.kskew = g_la_kskew; ra.g.prio_hi = g_la_prio_hi; ra.g.dbg_times = g_la_dbg_times; ra.g.wp = (const bf16_t*)wp; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act_xp;
     ra.g.route_col = route_col;
     ra.R = F / n_wg; if (F % n_wg || ra.R > 64 || ra.R <= 32) return -1;
     fill_nv(ra, ra.R, 2, 2);
+    if (pf_extra(pf)) ra.pf = *pf;
     if (set_fused_norm(ra, fn, n_wg)) {
         if (fn->n_slabs != 4 || route_col) return -1;
         k_gemm64r<4, EPI_SWIGLU, 4, 8, 4><<<n_wg, 512, 8 * 4 * 4096, st>>>(ra);
@@ -1812,10 +1854,6 @@ int lk_argmax_finalize(hipStream_t st, const float* cv, const int* ci, int n_til
     k_argmax_finalize<<<LA_TB, 256, 0, st>>>(cv, ci, n_tiles, out_rows);
     LAUNCH_CHECK(); return 0;
 }
-// appended prefetch workgroups of a launch whose own grid has n_main workgroups (n_main % 8 == 0 keeps the XCD residue)
-static inline int pf_extra(const PfDesc* pf) { return (pf && pf->base && pf->n_consumers > 0) ? pf->n_consumers : 0; }
-static inline PfDesc pf_or_none(const PfDesc* pf) { PfDesc d{}; if (pf_extra(pf)) d = *pf; return d; }
-
 int lk_embed_norm(hipStream_t st, const void* embed, const int* ids, const void* nw, int hidden, float eps, void* h, void* xp,
                   int cast_first, const PfDesc* pf) {
     if (hidden > 8192 || (hidden & 7)) return -1;

@@ -19,7 +19,7 @@ from tests.gpu_utils import random_tree
 from tests.tiny_model import GOLDEN, load_golden, tiny_shape, tiny_weights
 
 pytestmark = pytest.mark.gpu
-PF_DEFAULT = (_lib.lib.la_debug_get(7), _lib.lib.la_debug_get(8))     # the library's idle-window prefetch default
+PF_DEFAULT = (_lib.lib.la_debug_get(7), _lib.lib.la_debug_get(8), _lib.lib.la_debug_get(9))     # the library's idle-window prefetch default
 TOL = 2e-2
 
 
@@ -308,7 +308,7 @@ def test_fused_norm_gemm_launches_are_bitwise_identical_to_separate_kernels():
 
 
 def test_idle_window_prefetch_is_bitwise_neutral():
-    """la_debug_set keys 7 / 8: the extra workgroups appended to the row kernels and to the attention combine only READ the next
+    """la_debug_set keys 7 / 8 / 9: the gate/up launch's tail loads (down_proj image) and the extra workgroups appended to the row kernels and to the attention combine only READ the next
     GEMM's first k-tiles (planned QKV / gate-up / lm_head images, classic o_proj image).  At the Llama-2-7B layer shape and on the
     tiny model (classic images only) every setting must leave tokens, logits and hidden state bit-identical — graph and eager —
     and must stay inside the weight images (an out-of-bounds descriptor would fault the launch)."""
@@ -323,10 +323,11 @@ def test_idle_window_prefetch_is_bitwise_neutral():
             _, rows = random_tree(rs, 64)
             ids = rs.randint(3, vocab, size=64).astype(np.int32)
             outs = []
-            for kib, dly in ((0, 0), (16, 0), (64, 1), (128, 0), (128, 3)):
+            for kib, dly, tail in ((0, 0, 0), (16, 0, 0), (64, 1, 16), (128, 0, 64), (128, 3, 0), (0, 0, 48)):
                 check(lib.la_debug_set(7, kib), 'debug_set')
                 check(lib.la_debug_set(8, dly), 'debug_set')
-                assert lib.la_debug_get(7) == kib and lib.la_debug_get(8) == dly
+                check(lib.la_debug_set(9, tail), 'debug_set')
+                assert lib.la_debug_get(7) == kib and lib.la_debug_get(8) == dly and lib.la_debug_get(9) == tail
                 for eager in (False, True):
                     eng.reset()
                     eng.prefill(prompt, fast=False)
@@ -339,8 +340,8 @@ def test_idle_window_prefetch_is_bitwise_neutral():
             del eng
             torch.cuda.empty_cache()
     finally:
-        lib.la_debug_set(7, PF_DEFAULT[0])
-        lib.la_debug_set(8, PF_DEFAULT[1])
+        for key, val in zip((7, 8, 9), PF_DEFAULT):
+            lib.la_debug_set(key, val)
 
 
 @pytest.mark.parametrize('window', [40, 100])
