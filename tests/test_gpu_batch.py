@@ -360,7 +360,8 @@ def test_batch_sequential_processor_path_on_device(multi):
         assert got[:, :w].tolist() == plain[:, :w].tolist(), rep
     assert np.mean(out.kwargs['edls'][4:]) > 1.5, out.kwargs['edls']
     if multi:
-        assert max(out.kwargs['dls']) > 16                                  # trees wider than the shared-block budget
+        # every sample had a block of its own (per_sample_budget): the shared-block rule gives 64 // 4 // 4 = 4 rows per sample
+        assert max(out.kwargs['dls']) > 4, out.kwargs['dls']
 
 
 def test_batch_processor_run_vs_reference_golden():
