@@ -57,7 +57,13 @@ class LookaheadPreTrainedModel(object):
             decoding_mode = decoding_mode + '_mix'
         fmt, mode = decoding_mode.split('_')
         ts = time.time()
-        if fmt == 'hier':
+        if fmt == 'hier' and decoding_kwargs.get('device_trie', False) and len(qids) <= 8:
+            # draft from the wavefront trie walk over the incremental device mirror (csrc/la_trie_dev.hip): bit-identical to the
+            # host query; opt-in here because one host query (~20 us) is faster than sync + launch + D2H at bs = 1
+            got = self._device_trie().hier_get([list(qids)], decoding_length=decoding_length, branch_length=update_branch_length,
+                                               min_input_size=0, min_output_size=max(decoding_length // 2, 1), mode=mode, idxs=[0])[0]
+            ids, rowmask, sizes = np.asarray(got[0], dtype=np.int32), np.asarray(got[1], dtype=np.uint64), got[2]
+        elif fmt == 'hier':
             ids, rowmask, _, sizes = self.lookahead_cache.hier_get_packed(
                 qids, decoding_length=decoding_length, branch_length=update_branch_length, min_input_size=0,
                 min_output_size=max(decoding_length // 2, 1), mode=mode, idx=0)
@@ -71,6 +77,14 @@ class LookaheadPreTrainedModel(object):
         decoding_kwargs['qts'].append(time.time() - ts)
         decoding_kwargs.update({'decoding_qids': qids, 'decoding_ids': ids, 'sizes': sizes})
         return ids, rowmask
+
+    def _device_trie(self):
+        """DeviceTrie over self.lookahead_cache, input-frequency plane of idx 0 (rebuilt when the cache object changes)."""
+        from .device_trie import DeviceTrie
+        dt = getattr(self, '_dev_trie', None)
+        if dt is None or dt.cache is not self.lookahead_cache:
+            dt = self._dev_trie = DeviceTrie(self.lookahead_cache, idxs=[0], device=self.engine.device)
+        return dt
 
     # ---------------------------------------------------------------------------------------------- the loop
     @torch.no_grad()
@@ -146,6 +160,7 @@ class LookaheadPreTrainedModel(object):
         native_mode = {'input': 0, 'output': 1, 'mix': 2}.get(dm.split('_')[1], 2)
         max_query_length = int(decoding_kwargs.get('max_query_length', 2))
         native_loop = (not sequential and streamer is None and dm.split('_')[0] == 'hier' and decoding_length <= 64
+                       and not decoding_kwargs.get('device_trie', False)
                        and not decoding_kwargs.get('debug_lookahead', False) and decoding_kwargs.get('native_loop', True)
                        and 1 <= max_query_length <= 8          # la_lookahead_decode's query buffer; longer queries use this loop
                        and hasattr(eng, 'decode_native'))

@@ -162,3 +162,37 @@ def test_batch_loop_with_device_trie_equals_host_trie_loop():
         outs.append(runs)
     assert outs[0] == outs[1]
     assert max(outs[0][0][1]) > 16          # per-sample budget: trees larger than the reference's (64 // 4) // 4 rows
+
+
+def test_single_sequence_loop_with_device_trie_equals_host_trie_loop():
+    """pretrained_model.lookahead_generation (bs = 1) with decoding_kwargs['device_trie']: every draft comes from the wavefront
+    trie walk over the incremental device mirror; tokens, dls and edls must equal the host-trie loop's (interpreter and native
+    loop), request after request."""
+    import torch
+    from painlessinferenceacceleration_amd.modeling_llama import LlamaForCausalLM
+    from tests.tiny_model import noisy_copies, tiny_decisive_weights, tiny_shape
+    shape = tiny_shape()
+    sd = tiny_decisive_weights(0, torch.bfloat16)
+    rs = np.random.RandomState(4)
+    P = 40
+    prompt = rs.randint(3, shape.vocab, size=(1, P))
+    outs = []
+    for use_dev, native in ((False, True), (False, False), (True, False)):
+        model = LlamaForCausalLM(shape, dict(sd), max_length=512, eos_token_id=2)
+        truth = model.greedy_search(torch.from_numpy(prompt), P + 120, eos_token_id=None)[0, P:].tolist()
+        model.lookahead_cache = LookaheadCache(eos_ids=[2])
+        for c in noisy_copies(prompt[0, -2:].tolist() + truth, 8, 0.3, shape.vocab, seed=60):
+            model.lookahead_cache.put(c, branch_length=13, mode='output', idx=-1)
+        runs = []
+        for req in range(2):
+            dk = {'use_lookahead': True, 'decoding_mode': 'hier', 'decoding_length': 64, 'branch_length': 12,
+                  'device_trie': use_dev, 'native_loop': native}
+            out = model.lookahead_generation(torch.from_numpy(prompt), stopping_criteria=P + 100, eos_token_id=2,
+                                             return_dict_in_generate=True, decoding_kwargs=dk)
+            runs.append((out.sequences.tolist(), out.kwargs['dls'], out.kwargs['edls']))
+            assert out.sequences[0, P:P + 80].tolist() == truth[:80]                                # lossless
+        if use_dev:
+            assert model._dev_trie.stats['patches'] > 5
+        outs.append(runs)
+    assert outs[0] == outs[1] == outs[2]
+    assert np.mean(outs[2][1][2][1:]) > 2.0
