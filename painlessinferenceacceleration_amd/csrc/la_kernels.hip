@@ -1103,6 +1103,15 @@ struct AttnArgs {
 #define LA_NEG (-1.0e30f)
 
 #define LA_ATT_PAR 4      // key-tile parities per workgroup (waves = 2 token blocks x LA_ATT_PAR)
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// ST = true ("staged"): the K and V tiles of a key step are copied ONCE per workgroup into LDS by LDS-DMA
+// (global_load_lds_dwordx4, no staging registers) and read by both token-block waves of a key parity; the direct form loads
+// every tile into the registers of BOTH waves, i.e. each K/V byte crosses the CU's vector-memory path twice — at long contexts
+// that path (about 22 GB/s per CU) is the bound.  Two stages of LA_ATT_PAR tiles x 16 KiB are in flight per workgroup
+// (the ring aliases the merge buffer).  Same arithmetic, same order of operations: bit-identical results.
+template <bool ST>
 __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float mgbuf[];   // [LA_ATT_PAR][2][66][64] merge buffer (132 KiB)
     const int h = blockIdx.x, sp = blockIdx.y;
@@ -1165,13 +1174,19 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
     };
     // one key tile: S^T = K.Q^T, mask, online softmax, O^T += V^T.P^T.  The V fragments are requested before the
     // QK^T MFMAs and consumed after the softmax; the NEXT tile's K fragments are requested by the caller first.
-    auto tile = [&](int it, const bf16x8 (&kf)[8]) {
+    auto tile = [&](int it, const bf16x8 (&kf)[8], unsigned vlds) {
         const bool fresh = it >= NP;
         const int kb = fresh ? it - NP : it;
-        const bf16x8* vt = vptr(it);
         bf16x8 vf[8];
+        if constexpr (ST) {
+            // V fragments of the staged tile: LDS reads issued before the QK^T MFMAs, awaited before the PV MFMAs
 #pragma unroll
-        for (int s = 0; s < 8; ++s) vf[s] = vt[s * 64 + lane];
+            for (int s = 0; s < 8; ++s) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vf[s]) : "v"(vlds), "n"(s * 1024) : "memory");
+        } else {
+            const bf16x8* vt = vptr(it);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) vf[s] = vt[s * 64 + lane];
+        }
         f32x16 sc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) sc[i] = 0.f;
@@ -1232,13 +1247,63 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
         }
+        if constexpr (ST)                                                         // the V fragments have arrived (in/out operands, see K)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]), "+v"(vf[4]), "+v"(vf[5]),
+                         "+v"(vf[6]), "+v"(vf[7]) :: "memory");
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
             o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db * 2 + 0], pf[0], o[db], 0, 0, 0);
             o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db * 2 + 1], pf[1], o[db], 0, 0, 0);
         }
     };
-    {
+    if constexpr (ST) {
+        // ---- staged K/V: stage s = the tiles i0 + 4 s + par (par = 0..3) in ring slot s & 1; wave (tb, par) copies K (tb = 0) or V
+        //      (tb = 1) of its parity's tile as 8 pieces of 1 KiB.  The tile range is the workgroup's (a wave whose token block holds
+        //      no row of the slot still copies for its partner); a tile past the range re-reads the first one and is never consumed,
+        //      so every wave issues exactly 8 pieces per stage and the vmcnt arithmetic is static.
+        char* ring = (char*)mgbuf;
+        const unsigned ring0 = (unsigned)(size_t)(lptr_t)ring;
+        const int i1_all = (NT * (sp + 1)) / a.nsplit;
+        const int nst = (i1_all - i0 + LA_ATT_PAR - 1) / LA_ATT_PAR;
+        auto issue = [&](int st) {
+            int it = i0 + st * LA_ATT_PAR + par;
+            it = it < i1_all ? it : i0;
+            const bf16x8* src = (tb == 0 ? kptr(it) : vptr(it)) + lane;
+            char* dst = ring + (st & 1) * 65536 + par * 16384 + tb * 8192;
+#pragma unroll
+            for (int pc = 0; pc < 8; ++pc)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + pc * 64), (lptr_t)(dst + pc * 1024), 16, 0, 0);
+        };
+        // Two stages are ALWAYS issued (a workgroup with fewer tiles re-reads its first one): the number of copies in flight is
+        // then static, so the compiler's own wait for q below counts them instead of draining them.
+        issue(0);
+        issue(1);
+        // q (ordinary loads, requested before the copies) becomes a consumed value here: no load of the compiler's own stays
+        // pending across the stage loop
+#pragma unroll
+        for (int s = 0; s < 8; ++s) asm volatile("" :: "v"(q[s]));
+        if (stamp && lane == 0) stamp[1] = wall_clock64();
+        for (int st = 0; st < nst; ++st) {
+            if (st == 0 || st + 1 < nst) vm_wait<8>(); else vm_wait<0>();   // own pieces of stage st have landed (stage st + 1 may fly)
+            __builtin_amdgcn_s_barrier();                                    // ... and everybody else's
+            const int it = i0 + st * LA_ATT_PAR + par;
+            if (it < i1) {
+                const unsigned kl = ring0 + (unsigned)((st & 1) * 65536 + par * 16384) + (unsigned)lane * 16u;
+                bf16x8 kf[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[s]) : "v"(kl), "n"(s * 1024) : "memory");
+                // the fragments are in/out operands of the wait: nothing that reads them can be scheduled above it
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(kf[4]), "+v"(kf[5]),
+                             "+v"(kf[6]), "+v"(kf[7]) :: "memory");
+                tile(it, kf, kl + 8192u);
+                if (stamp && lane == 0 && st == 0) stamp[2] = wall_clock64();
+            }
+            __builtin_amdgcn_s_barrier();                                    // slot st & 1 is free again
+            if (st + 2 < nst) issue(st + 2);
+        }
+        vm_wait<0>();                                                        // nst < 2: the unused copies; the ring becomes the merge buffer
+        __builtin_amdgcn_s_barrier();
+    } else {
         bf16x8 kA[8], kB[8];
         int it = i0 + par;
         if (it < i1) {
@@ -1254,7 +1319,7 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
 #pragma unroll
                 for (int s = 0; s < 8; ++s) kB[s] = kt[s * 64 + lane];
             }
-            tile(it, kA);
+            tile(it, kA, 0u);
             if (stamp && lane == 0 && it < i0 + LA_ATT_PAR) stamp[2] = wall_clock64();
             it = nx;
             if (it >= i1) break;
@@ -1264,7 +1329,7 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(AttnArgs a) {
 #pragma unroll
                 for (int s = 0; s < 8; ++s) kA[s] = kt[s * 64 + lane];
             }
-            tile(it, kB);
+            tile(it, kB, 0u);
             it = nx;
         }
     }
@@ -1593,6 +1658,7 @@ int g_la_prio_hi = 0;         // s_setprio level of waves 4..7 in the 8-wave GEM
 long long* g_la_dbg_times = nullptr;
 int g_la_pf_kib = 0;          // idle-window weight prefetch: KiB per consumer workgroup (la_debug_set key 7; read when a step graph is captured)
 int g_la_pf_tail_kib = 0;     // tail prefetch of down_proj from the gate/up launch: KiB per workgroup (key 9)
+int g_la_attn_staged = 0;     // 1: tree attention with K/V staged through LDS once per workgroup (la_debug_set key 10)
 int g_la_graph_epoch = 0;     // bumped by la_debug_set when a capture-time knob changes: la_llama_step captures its graph again
 int g_la_pf_delay = 0;        // s_sleep(32) rounds the prefetch workgroups wait before their first load (key 8)
 
@@ -1800,7 +1866,9 @@ int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int n
 static bool g_attr_done = false;
 int lk_gemm64r_init() {
     if (g_attr_done) return 0;
-    if (hipFuncSetAttribute((const void*)k_tree_attn, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)k_tree_attn<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            2 * LA_ATT_PAR * 66 * 64 * sizeof(float)) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)k_tree_attn<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             2 * LA_ATT_PAR * 66 * 64 * sizeof(float)) != hipSuccess) return -1;
     hipError_t e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_SWIGLU, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_LOGITS, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
@@ -1964,7 +2032,9 @@ static int tree_attn_launch(hipStream_t st, AttnArgs a, int n_slots, void* attn_
     const int nh = a.nh, nsplit = a.nsplit;
     float *opart = a.opart, *mpart = a.mpart, *lpart = a.lpart;
     if (lk_gemm64r_init() != 0) return -1;
-    k_tree_attn<<<dim3(nh, nsplit, n_slots), 2 * LA_ATT_PAR * 64, 2 * LA_ATT_PAR * 66 * 64 * sizeof(float), st>>>(a);
+    static_assert(2 * LA_ATT_PAR * 66 * 64 * sizeof(float) >= 2 * LA_ATT_PAR * 16384, "the K/V ring of the staged form aliases the merge buffer");
+    if (g_la_attn_staged) k_tree_attn<true><<<dim3(nh, nsplit, n_slots), 2 * LA_ATT_PAR * 64, 2 * LA_ATT_PAR * 66 * 64 * sizeof(float), st>>>(a);
+    else k_tree_attn<false><<<dim3(nh, nsplit, n_slots), 2 * LA_ATT_PAR * 64, 2 * LA_ATT_PAR * 66 * 64 * sizeof(float), st>>>(a);
     LAUNCH_CHECK();
     int total = nh * LA_TB * 16;
     const int n_main = (total + 255) / 256;

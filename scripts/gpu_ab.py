@@ -303,6 +303,39 @@ def small(hidden=4096, nh=32, nkv=32):
     print(f'launch floor (argmax_finalize, 64 blocks): {us:.2f} us', flush=True)
 
 
+def attn(nh=32, nkv=32):
+    """tree attention (+ combine) at the 7B shape: K/V tiles straight into registers vs staged once per workgroup through LDS
+    (la_debug_set key 10), by context length and key-split count; K/V rotate over 6 layers' worth of cache (> Infinity Cache)."""
+    g = torch.Generator(device=DEV).manual_seed(2)
+    qf = torch.randn(nh * 8192, generator=g, device=DEV).to(torch.bfloat16)
+    kf = torch.randn(nkv * 8192, generator=g, device=DEV).to(torch.bfloat16)
+    vf = torch.randn(nkv * 8192, generator=g, device=DEV).to(torch.bfloat16)
+    max_keys = 4096 + 64
+    NL = 6
+    km = torch.randn(NL, nkv * max_keys * 128, generator=g, device=DEV).to(torch.bfloat16)
+    vm = torch.randn(NL, nkv * max_keys * 128, generator=g, device=DEV).to(torch.bfloat16)
+    rm = torch.from_numpy(np.array([(2 << t) - 1 for t in range(63)] + [-1], dtype=np.int64)).to(DEV)
+    out = torch.zeros(64 * nh * 128, dtype=torch.bfloat16, device=DEV)
+    for nkeys in (640, 992, 1984, 4032):
+        state = torch.zeros(_lib.LA_ST_WORDS, dtype=torch.int32, device=DEV)
+        state[0] = nkeys
+        for nsplit in (4, 8):
+            opart = torch.zeros(nh * nsplit * 64 * 128, dtype=torch.float32, device=DEV)
+            mpart = torch.zeros(nh * nsplit * 64, dtype=torch.float32, device=DEV)
+            lpart = torch.zeros_like(mpart)
+            res = []
+            for staged in (0, 1, 0, 1):
+                check(lib.la_debug_set(10, staged), 'debug_set')
+                res.append(timeit(lambda i: lib.la_tree_attn(sp(), ptr(qf), ptr(km[i % NL]), ptr(vm[i % NL]), ptr(kf), ptr(vf), ptr(rm),
+                                                             ptr(state), nh, nkv, max_keys, nsplit, ptr(opart), ptr(mpart), ptr(lpart),
+                                                             ptr(out)), 60))
+            kvb = 2 * nkv * 128 * 2 * (nkeys + 64)
+            d, st = min(res[0], res[2]), min(res[1], res[3])
+            print(f'tree_attn(+combine) nkeys={nkeys:5d} nsplit={nsplit}: direct {d:6.2f} us ({kvb / d / 1e3:5.0f} GB/s KV)   '
+                  f'staged {st:6.2f} us ({kvb / st / 1e3:5.0f} GB/s KV)', flush=True)
+    check(lib.la_debug_set(10, 0), 'debug_set')
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['gemm', 'small']
     print(f'device {torch.cuda.get_device_name(0)} CUs {NWG}', flush=True)
@@ -310,6 +343,8 @@ if __name__ == '__main__':
         gemms()
     if 'small' in which:
         small()
+    if 'attn' in which:
+        attn()
     if 'sweep' in which:
         sweep()
     if 'prio' in which:

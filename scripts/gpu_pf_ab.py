@@ -26,24 +26,26 @@ def main():
     ap.add_argument('--layers', type=int, default=32)
     ap.add_argument('--steps', type=int, default=48)
     ap.add_argument('--out', default='gpurun_out/pf_ab.json')
+    ap.add_argument('--prompt-len', type=int, default=512)
     ap.add_argument('--settings', default='0:0:0,16:0:0,32:0:0,64:0:0,128:0:0,64:2:0,0:0:32,0:0:64,64:0:32,64:0:64,128:0:64,0:0:0',
-                    help='comma list of kib:delay:tail_kib (la_debug_set keys 7 / 8 / 9)')
+                    help='comma list of kib:delay:tail_kib[:attn_staged] (la_debug_set keys 7 / 8 / 9 / 10)')
     args = ap.parse_args()
     torch.cuda.set_device(0)
     shape = LlamaShape.llama2_7b()
     shape.n_layers = args.layers
     sd = random_weights(shape, seed=0, device='cuda:0', decisive=True)
-    eng = LlamaVerifyEngine(shape, sd, max_length=2048, consume_state_dict=True)
+    eng = LlamaVerifyEngine(shape, sd, max_length=max(2048, args.prompt_len + 512), consume_state_dict=True)
     rs = np.random.RandomState(0)
-    prompt = rs.randint(3, shape.vocab, size=512).tolist()
+    prompt = rs.randint(3, shape.vocab, size=args.prompt_len).tolist()
     _, _, rows = fixed_t64b8_tree()
     ids = rs.randint(3, shape.vocab, size=64).astype(np.int32)
     results, base = [], None
     for setting in args.settings.split(','):
-        kib, dly, tail = [int(x) for x in setting.split(':')]
+        kib, dly, tail, staged = ([int(x) for x in setting.split(':')] + [0])[:4]
         check(lib.la_debug_set(7, kib), 'debug_set')
         check(lib.la_debug_set(8, dly), 'debug_set')
         check(lib.la_debug_set(9, tail), 'debug_set')
+        check(lib.la_debug_set(10, staged), 'debug_set')
         eng.reset()
         tok = eng.prefill(prompt, fast=False)
         ids[0] = tok
@@ -58,7 +60,7 @@ def main():
         ms = (time.perf_counter() - t0) / args.steps * 1e3
         logits = eng.logits().clone()
         prof = eng.profile(ids, rows, iters=3)
-        rec = {'kib': kib, 'delay': dly, 'tail_kib': tail, 'ms_per_step': round(ms, 4), 'ms_by_class_events': {k: round(v, 4) for k, v in prof['ms'].items()},
+        rec = {'kib': kib, 'delay': dly, 'tail_kib': tail, 'attn_staged': staged, 'ms_per_step': round(ms, 4), 'ms_by_class_events': {k: round(v, 4) for k, v in prof['ms'].items()},
                'ms_eager_step': round(prof['ms_step'], 4)}
         if base is None:
             base = (toks, logits)
@@ -67,7 +69,7 @@ def main():
             rec['identical_to_off'] = bool(toks == base[0] and torch.equal(logits, base[1]))
         print(json.dumps(rec), flush=True)
         results.append(rec)
-    for k in (7, 8, 9):
+    for k in (7, 8, 9, 10):
         check(lib.la_debug_set(k, 0), 'debug_set')
     ok = [r for r in results if r['identical_to_off']]
     best = min(ok, key=lambda r: r['ms_per_step'])

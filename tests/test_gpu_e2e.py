@@ -344,6 +344,59 @@ def test_idle_window_prefetch_is_bitwise_neutral():
             lib.la_debug_set(key, val)
 
 
+def test_staged_attention_is_bitwise_identical_end_to_end():
+    """la_debug_set key 10 (K/V tiles staged once per workgroup through LDS instead of twice into registers): tokens, logits and
+    hidden state of whole steps must not change by a bit — long prompts (several stages per workgroup), a sliding window on the
+    KV ring (ring-slot addressing of the copies), and the cursor batch (a wave whose token block holds no row of a slot still
+    copies for its partner)."""
+    from painlessinferenceacceleration_amd._lib import check, lib
+    shape = tiny_shape()
+    sd = _bf16_sd(3)
+    rs = np.random.RandomState(12)
+    default_form = lib.la_debug_get(10)
+    try:
+        # (a) single sequence, 700-token prompt, tree step + follow-up step, graph and eager
+        for kw in ({}, {'kv_ring': True}):
+            shp = tiny_shape()
+            if kw:
+                shp.sliding_window = 100
+            eng = LlamaVerifyEngine(shp, dict(sd), max_length=1024, **kw)
+            prompt = rs.randint(3, shape.vocab, size=700).tolist()
+            _, rows = random_tree(rs, 64)
+            ids = rs.randint(3, shape.vocab, size=64).astype(np.int32)
+            outs = []
+            for staged in (0, 1):
+                check(lib.la_debug_set(10, staged), 'debug_set')
+                for eager in (False, True):
+                    eng.reset()
+                    eng.prefill(prompt, fast=False)
+                    toks, n = eng.step(ids, rows, eager=eager)
+                    toks2, _ = eng.step(np.asarray(toks[-1:], dtype=np.int32), np.array([1], dtype=np.uint64), eager=eager)
+                    outs.append((toks, n, toks2, eng.logits()[:1].clone(), eng.hidden()[:1].clone()))
+            for o in outs[1:]:
+                assert o[0] == outs[0][0] and o[1] == outs[0][1] and o[2] == outs[0][2], kw
+                assert torch.equal(o[3], outs[0][3]) and torch.equal(o[4], outs[0][4]), kw
+            del eng
+        # (b) cursor batch: three slots with different context lengths sharing one block (eager: the batch graphs are captured once)
+        eng = LlamaVerifyEngine(shape, dict(sd), max_length=512, n_slots=3)
+        prompts = {0: rs.randint(3, shape.vocab, size=300).tolist(), 1: rs.randint(3, shape.vocab, size=37).tolist(),
+                   2: rs.randint(3, shape.vocab, size=130).tolist()}
+        segs = []
+        for b, n in ((0, 20), (1, 5), (2, 30)):
+            _, rows = random_tree(rs, n)
+            segs.append((b, rs.randint(3, shape.vocab, size=n).astype(np.int32), rows, 0, 16))
+        outs = []
+        for staged in (0, 1):
+            check(lib.la_debug_set(10, staged), 'debug_set')
+            eng.reset_slot(-1)
+            eng.bprefill_many(prompts, eager=True)
+            o = eng.bstep(segs, eager=True)
+            outs.append((o, eng.logits()[:55].clone(), list(eng.slot_keys)))
+        assert outs[0][0] == outs[1][0] and outs[0][2] == outs[1][2] and torch.equal(outs[0][1], outs[1][1])
+    finally:
+        lib.la_debug_set(10, default_form)
+
+
 @pytest.mark.parametrize('window', [40, 100])
 def test_sliding_window_attention_extension(window):
     """cfg.sliding_window (extension; BASELINE config 3): rows see only committed keys within `window` positions (the

@@ -179,10 +179,13 @@ def test_qkv_post(nh, nkv):
 
 
 @pytest.mark.parametrize('nh,nkv,nkeys,nsplit,T', [(2, 2, 0, 1, 64), (2, 2, 70, 2, 64), (4, 1, 333, 4, 17), (2, 2, 640, 8, 64),
-                                                   (2, 2, 31, 3, 1), (2, 2, 1500, 8, 64)])
+                                                   (2, 2, 31, 3, 1), (2, 2, 1500, 8, 64), (2, 2, 1500, 2, 64), (4, 2, 2040, 1, 40),
+                                                   (2, 2, 5, 8, 3)])
 def test_tree_attention(nh, nkv, nkeys, nsplit, T):
     """softmax(QK^T/sqrt(d) + tree mask) V with a mask-free prefix: tolerance 2e-2 relative to max|out|
-    (bf16 P and bf16 output rounding) against an fp32 torch attention over the same bf16 inputs."""
+    (bf16 P and bf16 output rounding) against an fp32 torch attention over the same bf16 inputs.  Both forms of the kernel —
+    K/V tiles straight into registers, and staged once per workgroup through LDS (la_debug_set key 10) — must agree BITWISE
+    (partials and packed output): same arithmetic in the same order, only the way the tiles reach the MFMA operands differs."""
     rs = np.random.RandomState(nkeys + T)
     g = torch.Generator(device=DEV).manual_seed(nkeys)
     max_keys = 2048
@@ -205,9 +208,21 @@ def test_tree_attention(nh, nkv, nkeys, nsplit, T):
     mpart = torch.zeros(nh * nsplit * 64, dtype=torch.float32, device=DEV)
     lpart = torch.zeros_like(mpart)
     out = torch.zeros(64 * nh * 128, dtype=torch.bfloat16, device=DEV)
-    check(lib.la_tree_attn(sp(), ptr(qf), ptr(km), ptr(vm), ptr(kf), ptr(vf), ptr(rm), ptr(state), nh, nkv, max_keys,
-                           nsplit, ptr(opart), ptr(mpart), ptr(lpart), ptr(out)), 'tree_attn')
-    torch.cuda.synchronize()
+    default_form = lib.la_debug_get(10)
+    forms = []
+    try:
+        for staged in (0, 1):
+            check(lib.la_debug_set(10, staged), 'debug_set')
+            for t in (opart, mpart, lpart, out):
+                t.zero_()
+            check(lib.la_tree_attn(sp(), ptr(qf), ptr(km), ptr(vm), ptr(kf), ptr(vf), ptr(rm), ptr(state), nh, nkv, max_keys,
+                                   nsplit, ptr(opart), ptr(mpart), ptr(lpart), ptr(out)), 'tree_attn')
+            torch.cuda.synchronize()
+            forms.append((opart.clone(), mpart.clone(), lpart.clone(), out.clone()))
+    finally:
+        lib.la_debug_set(10, default_form)
+    for a_, b_ in zip(forms[0], forms[1]):
+        assert torch.equal(a_, b_)
     got = gu.from_packed(out, gu.xp_index(nh * 128)).float().view(64, nh, 128)
     rep = nh // nkv
     K = torch.cat([kmain[:, :nkeys], kfr], 1).float().repeat_interleave(rep, 0)       # [nh, nkeys+64, 128]
