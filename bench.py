@@ -94,6 +94,41 @@ def _pf_setting():
     return int(lib.la_debug_get(7)), int(lib.la_debug_get(8)), int(lib.la_debug_get(9))
 
 
+def secondary_legs(spec):
+    """The batch configurations (BASELINE configs 3-5) as secondary lines of the default run: each `model:batch` leg is this script
+    run again in its own process (`--model M --batch B`, 24 timed steps, no CPU leg) after the headline's timed region; the
+    fields a reader needs are kept.  A leg that fails is reported as such — it never touches the headline line."""
+    import subprocess
+    legs = []
+    for item in spec.split(','):
+        item = item.strip()
+        if not item:
+            continue
+        model, batch = item.split(':')
+        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--model', model, '--batch', batch, '--steps', '24',
+               '--warmup', '4', '--no-cpu-baseline']
+        env = dict(os.environ)
+        env['BENCH_IS_SECONDARY'] = '1'
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+            if r.returncode != 0 or not line:
+                legs.append({'model': model, 'batch': int(batch), 'error': (r.stderr or r.stdout)[-300:], 'wall_s': round(time.time() - t0, 1)})
+                continue
+            j = json.loads(line[-1])
+            c = j['config']
+            legs.append({'workload': c['workload'], 'metric': j['metric'], 'value': j['value'], 'unit': j['unit'],
+                         'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'warmup': j['warmup'], 'sequences': c['sequences'],
+                         'mean_accept_len': c['mean_accept_len'], 'mean_draft_len': c['mean_draft_len'], 'kv_cache': c['kv_cache'],
+                         'lookahead_equals_greedy': c['lookahead_equals_greedy'], 'context_at_end': c['context_at_end'],
+                         'roofline': j.get('roofline'), 'wall_s': round(time.time() - t0, 1),
+                         'command': 'python bench.py --model %s --batch %s --steps 24 --warmup 4 --no-cpu-baseline' % (model, batch)})
+        except Exception as e:           # noqa: BLE001 — a secondary leg must never take the headline line down
+            legs.append({'model': model, 'batch': int(batch), 'error': repr(e)[:300], 'wall_s': round(time.time() - t0, 1)})
+    return legs
+
+
 def cpu_model_name():
     try:
         for line in open('/proc/cpuinfo'):
@@ -156,6 +191,10 @@ def main():
     ap.add_argument('--profile-iters', type=int, default=3)
     ap.add_argument('--attn-split', type=int, default=0, help='key splits of the tree-attention kernel (0 = engine default 8)')
     ap.add_argument('--fuse', type=int, default=0, help='engine cfg.fuse bits (opt-in in-kernel norm->GEMM fusion; 0 = separate kernels)')
+    ap.add_argument('--secondary', default='mistral:8,13b:4',
+                    help='N=1 default workload only: comma list of model:batch legs (BASELINE configs 3-5: a 64-token tree per sequence '
+                         'through la_llama_mstep) run AFTER the timed region, each in its own process; their lines are embedded under '
+                         '"secondary".  "" = none; "mistral:8,13b:4,mixtral:4" = all three')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -461,6 +500,9 @@ def main():
     cpu = None
     if want_cpu:
         cpu = cpu_baseline_loop(shape, sd_cpu, prompts[0], copies0, BL, DL, verify_steps=args.cpu_steps)
+    secondary = None
+    if world == 1 and B == 1 and args.model == '7b' and not args.layers and args.secondary and not os.environ.get('BENCH_IS_SECONDARY'):
+        secondary = secondary_legs(args.secondary)
     gen = accepted_all / max(world, 1)
     out = {
         'metric': 'accepted_tokens_per_sec', 'value': round(accepted_all / elapsed, 2), 'unit': 'tokens/s',
@@ -490,6 +532,8 @@ def main():
                    'fixed_tree_sweep': sweep},
         'roofline': roofline, 'cpu_baseline': cpu,
     }
+    if secondary is not None:
+        out['secondary'] = secondary
     print(json.dumps(out))
     if dist_on:
         dist.barrier()
