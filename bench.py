@@ -191,10 +191,10 @@ def main():
     ap.add_argument('--profile-iters', type=int, default=3)
     ap.add_argument('--attn-split', type=int, default=0, help='key splits of the tree-attention kernel (0 = engine default 8)')
     ap.add_argument('--fuse', type=int, default=0, help='engine cfg.fuse bits (opt-in in-kernel norm->GEMM fusion; 0 = separate kernels)')
-    ap.add_argument('--secondary', default='mistral:8,13b:4',
+    ap.add_argument('--secondary', default='mistral:8,13b:4,mixtral:4',
                     help='N=1 default workload only: comma list of model:batch legs (BASELINE configs 3-5: a 64-token tree per sequence '
                          'through la_llama_mstep) run AFTER the timed region, each in its own process; their lines are embedded under '
-                         '"secondary".  "" = none; "mistral:8,13b:4,mixtral:4" = all three')
+                         '"secondary".  "" = none')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
