@@ -22,6 +22,7 @@ extern int g_la_prio_hi;
 extern int g_la_mb_narrow;
 extern int g_la_mb_dbg;
 extern int g_la_mb_mode;
+extern int g_la_mb_pair;
 extern int g_la_pf_kib, g_la_pf_delay, g_la_pf_tail_kib, g_la_attn_staged, g_la_graph_epoch;
 extern long long* g_la_dbg_times;
 int la_mb_gemm(void* stream, int kind, const void* wp, const void* xp, int N, int K, int nblk, int n_wg, int ksplit,
@@ -40,6 +41,7 @@ int la_debug_set(int key, int value) {
     if (key == 3 && value >= 0 && value <= 1) { g_la_mb_narrow = value; return LA_OK; }
     if (key == 4 && value >= 0 && value <= 5) { g_la_mb_dbg = value; return LA_OK; }
     if (key == 5 && value >= 0 && value <= 3) { g_la_mb_mode = value; return LA_OK; }
+    if (key == 6 && value >= 0 && value <= 1) { g_la_mb_pair = value; return LA_OK; }
     if (key == 7 && value >= 0 && value <= 128) { g_la_pf_kib = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 8 && value >= 0 && value <= 16) { g_la_pf_delay = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 9 && value >= 0 && value <= 64) { g_la_pf_tail_kib = value; ++g_la_graph_epoch; return LA_OK; }
@@ -49,7 +51,7 @@ int la_debug_set(int key, int value) {
 int la_debug_get(int key) {
     switch (key) {
         case 0: return g_la_dbg_noepi; case 1: return g_la_kskew; case 2: return g_la_prio_hi; case 3: return g_la_mb_narrow;
-        case 4: return g_la_mb_dbg; case 5: return g_la_mb_mode; case 7: return g_la_pf_kib; case 8: return g_la_pf_delay; case 9: return g_la_pf_tail_kib; case 10: return g_la_attn_staged;
+        case 4: return g_la_mb_dbg; case 5: return g_la_mb_mode; case 6: return g_la_mb_pair; case 7: return g_la_pf_kib; case 8: return g_la_pf_delay; case 9: return g_la_pf_tail_kib; case 10: return g_la_attn_staged;
         default: return LA_E_ARG;
     }
 }

@@ -43,6 +43,9 @@ struct MbArgs {
     const float* route_col; int route_rows;
     // gathered MoE (k_moe_plan_mb): the number of 64-row blocks this expert received, decided on the device
     const int* nblk_dev;
+    // paired form of the wide kernel (launch_mb): the weight rows of a workgroup are read by a second workgroup working on the other
+    // token blocks (same XCD): stream them with the default cache policy so that the second reader finds them in L2
+    int w_keep;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
         const bf16x8* g = src[i] + (size_t)kt * gstr[i];
         char* d = lds_raw + (sidx % NR) * (STAGE * 1024) + pdst[i];
         if (i == 0) {
-            if (w0) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 2);       // streamed weights: nt
+            if (w0 && !a.w_keep) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 2);       // streamed weights: nt
             else __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 0);
         } else if (i < NP_LO || hi) {
             __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 0);
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
 #pragma unroll
                 for (int gi = 0; gi < 4; ++gi) {
                     const f32x4 v = {acc[r][t][4 * gi], acc[r][t][4 * gi + 1], acc[r][t][4 * gi + 2], acc[r][t][4 * gi + 3]};
-                    float* o = a.slabs + ((size_t)ks * a.M + blk * 64 + tok) * a.N + (blockIdx.x * RBV + r) * 32 + 8 * gi + 4 * hh;
+                    float* o = a.slabs + ((size_t)ks * a.M + blk * 64 + tok) * a.N + (blockIdx.x * RBV + (r == 0 ? rb0 : rb1)) * 32 + 8 * gi + 4 * hh;
                     *(f32x4*)o = v;
                 }
         } else if constexpr (EPI == MB_SWIGLU) {
@@ -566,6 +569,7 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
         } else if constexpr (EPI == MB_QKV) {
             // RoPE in bf16 arithmetic (apply_rotary_pos_emb, modeling_llama.py:154-169); tile 0 = lo halves, tile 1 = hi halves
             const int ps = a.pos[blk * 64 + tok];
+            const int region = blockIdx.x * (RBV / 2) + rg;      // RBV = 4 (paired form): row group rg holds the {lo, hi} blocks of region 2 x + rg
             if ((a.R & 1) == 0) {
                 // pairs of consecutive rows (an even R keeps them in one head and one 16-byte chunk): 4-byte table loads and stores
 #pragma unroll
@@ -573,7 +577,7 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
                     if (8 * (i >> 2) >= a.nv[0]) break;                // wave-uniform
                     const int f = 8 * (i >> 2) + 4 * hh + (i & 3);
                     if (f < a.nv[0]) {
-                        const int prr = a.R * blockIdx.x + f, slot = prr >> 6, dlo = prr & 63, dhi = dlo + 64;
+                        const int prr = a.R * region + f, slot = prr >> 6, dlo = prr & 63, dhi = dlo + 64;
                         if (slot < a.nh + a.nkv) {
                             bf16_t* dst = slot < a.nh ? a.qf + ((size_t)blk * a.nh + slot) * 8192
                                                       : a.kfresh + ((size_t)blk * a.nkv + (slot - a.nh)) * 8192;
@@ -603,7 +607,7 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
                 for (int i = 0; i < 16; ++i) {
                     const int f = 8 * (i >> 2) + 4 * hh + (i & 3);
                     if (f < a.nv[0]) {
-                        const int prr = a.R * blockIdx.x + f, slot = prr >> 6, dlo = prr & 63, dhi = dlo + 64;
+                        const int prr = a.R * region + f, slot = prr >> 6, dlo = prr & 63, dhi = dlo + 64;
                         const float xl = acc[0][t][i], xh = acc[1][t][i];
                         if (slot < a.nh + a.nkv) {
                             bf16_t* dst = slot < a.nh ? a.qf + ((size_t)blk * a.nh + slot) * 8192
@@ -1416,6 +1420,7 @@ __global__ __launch_bounds__(256) void k_kv_commit_mb(const bf16_t* __restrict__
 static bool g_mb_attr = false;
 int g_la_mb_dbg = 0;
 int g_la_mb_mode = 0;         // la_debug_set key 5: 1 = wide kernel as two co-resident workgroups per CU (80 KiB LDS, 256 rows each)
+int g_la_mb_pair = 0;         // la_debug_set key 6: 1 = paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup)
 int g_la_mb_narrow = 0;       // la_debug_set key 3: 1 = the K-split kernels (k_gemm_mb) for every nblk (A/B measurements)
 template <typename K> static hipError_t set_lds(K k, int bytes) {
     return hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1437,7 +1442,9 @@ int lk_mb_init() {
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_LOGITS>, WideGeom<4, T>::LDS);
 #define SETW2(T) \
     if (e == hipSuccess) e = set_lds(k_gemm_wide<2, T, MB_SLAB>, WideGeom<2, T>::LDS); \
-    if (e == hipSuccess) e = set_lds(k_gemm_wide<2, T, MB_QKV>, WideGeom<2, T>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<2, T, MB_QKV>, WideGeom<2, T>::LDS); \
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_SLAB>, WideGeom<4, T>::LDS); \
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_QKV>, WideGeom<4, T>::LDS);
     SETW4(2) SETW4(3) SETW4(4) SETW2(1) SETW2(2)
 #undef SETW4
 #undef SETW2
@@ -1535,6 +1542,25 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                 else if (g_la_mb_dbg == 3) k_gemm_wide<4, 4, MB_SWIGLU, 3><<<grid, 512, WideGeom<4, 4>::LDS, st>>>(a);
                 else if (g_la_mb_dbg == 4) k_gemm_wide<4, 4, MB_SWIGLU, 4><<<grid, 512, WideGeom<4, 4>::LDS, st>>>(a);
                 else k_gemm_wide<4, 4, MB_SWIGLU, 5><<<grid, 512, WideGeom<4, 4>::LDS, st>>>(a);
+                LAUNCH_CHECK(); return 0;
+            }
+        }
+        if constexpr (RBV == 2) {
+            // Paired form (MB_SLAB, MB_QKV): TWO adjacent weight regions per workgroup and HALF the token blocks — the RBV = 4 wave
+            // grid (2 row groups x 4 token groups) over regions {2 x, 2 x + 1}, grid.z = 2 token halves.  Every workgroup re-reads the
+            // whole x operand of its token blocks from L2 (1 GB per launch at 512 rows and 256 workgroups: the dominant term of these
+            // launches); pairing halves that, and the second reader of a weight region (z = 1, 128 workgroup ids later: same XCD)
+            // finds it in L2.  Same MFMAs on the same operands in the same order per output: bit-identical results.
+            if (g_la_mb_pair && n_wg % 2 == 0 && (n_wg / 2 * ksplit) % 8 == 0) {
+                MbArgs p = a;
+                p.w_keep = 1;
+                if (p.planned) {
+                    p.boff[2] = a.wg_chunks + a.boff[0]; p.boff[3] = a.wg_chunks + a.boff[1];
+                    p.nv[2] = a.nv[0]; p.nv[3] = a.nv[1]; p.nvl[2] = a.nvl[0]; p.nvl[3] = a.nvl[1];
+                    p.wg_chunks = 2 * a.wg_chunks;
+                }
+                if (nblk <= 4) k_gemm_wide<4, 1, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 1) / 2), 512, WideGeom<4, 1>::LDS, st>>>(p);
+                else k_gemm_wide<4, 2, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 3) / 4), 512, WideGeom<4, 2>::LDS, st>>>(p);
                 LAUNCH_CHECK(); return 0;
             }
         }

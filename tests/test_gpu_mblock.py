@@ -321,3 +321,51 @@ def test_mstep_moe_every_expert_receives_every_row():
         got = engm.mlogits()[b * 64:b * 64 + T].float().cpu()
         err = (got - ref).abs().max(1).values / ref.abs().max(1).values
         assert float((err < TOL_TINY).float().mean()) >= 0.95 and float(err.median()) < 0.5 * TOL_TINY, (b, err)
+
+
+@pytest.mark.parametrize('nblk', [3, 4, 5, 7, 8])
+def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
+    """la_debug_set key 6: the slab and QKV launches of the wide family with TWO weight regions x HALF the token blocks per
+    workgroup (RBV = 4 wave grid, grid.z = token halves).  Every output element is the same chain of MFMAs over the same operands
+    in the same order, so slabs and Q / K / V fragments must equal the unpaired launch bit for bit — classic and planned images,
+    MHA and GQA shapes, K splits."""
+    rc, rs_ = rope_tables(128, 1024, 10000.0, DEV)
+    default_form = lib.la_debug_get(6)
+    try:
+        for N, K, ks in ((4096, 1376, 4), (512, 2048, 1), (5120, 512, 4)):
+            g = torch.Generator(device=DEV).manual_seed(N + nblk)
+            x = bf(torch.randn(nblk * 64, K, generator=g, device=DEV))
+            wp = gu.pack_weight(bf(torch.randn(N, K, generator=g, device=DEV) * 0.05))
+            rows = (nblk + 3) // 4 * 4 * 64
+            outs = []
+            for pair in (0, 1):
+                check(lib.la_debug_set(6, pair), 'debug_set')
+                slabs = torch.full((ks, rows, N), float('nan'), dtype=torch.float32, device=DEV)
+                _mb(0, wp, _pack_blocks(x), N, K, nblk, ksplit=ks, slabs=slabs, slab_rows=rows)
+                outs.append(slabs[:, :nblk * 64].clone())
+            assert torch.equal(outs[0], outs[1]), (N, K, ks)
+        for nh, nkv, nwg in ((32, 32, 256), (32, 8, 256), (40, 40, 256), (8, 2, 32), (2, 2, 0)):
+            K = 512
+            N = (nh + 2 * nkv) * 128
+            g = torch.Generator(device=DEV).manual_seed(nh * 7 + nkv + nblk)
+            x = bf(torch.randn(nblk * 64, K, generator=g, device=DEV))
+            w = bf(torch.randn(N, K, generator=g, device=DEV) * 0.05)
+            pos = torch.randint(0, 900, (nblk * 64,), generator=g, device=DEV, dtype=torch.int32)
+            if nwg:
+                wp = gu.pack_planned(2, [w], nwg)
+            else:
+                perm = np.zeros(N, dtype=np.int32)
+                check(lib.la_qkv_row_perm(nh, nkv, perm.ctypes.data_as(_lib.pi32)), 'perm')
+                wp = gu.pack_weight(w[torch.from_numpy(perm.astype(np.int64)).to(DEV)].contiguous())
+            outs = []
+            for pair in (0, 1):
+                check(lib.la_debug_set(6, pair), 'debug_set')
+                qf = torch.zeros(8 * nh * 8192, dtype=torch.bfloat16, device=DEV)
+                kf = torch.zeros(8 * nkv * 8192, dtype=torch.bfloat16, device=DEV)
+                vf = torch.zeros(8 * nkv * 8192, dtype=torch.bfloat16, device=DEV)
+                _mb(2, wp, _pack_blocks(x), N, K, nblk, n_wg=nwg, pos=pos, rc=rc, rs_=rs_, qf=qf, kf=kf, vf=vf, nh=nh, nkv=nkv)
+                outs.append((qf, kf, vf))
+            for a_, b_ in zip(outs[0], outs[1]):
+                assert torch.equal(a_, b_), (nh, nkv, nwg)
+    finally:
+        lib.la_debug_set(6, default_form)
