@@ -1420,7 +1420,7 @@ __global__ __launch_bounds__(256) void k_kv_commit_mb(const bf16_t* __restrict__
 static bool g_mb_attr = false;
 int g_la_mb_dbg = 0;
 int g_la_mb_mode = 0;         // la_debug_set key 5: 1 = wide kernel as two co-resident workgroups per CU (80 KiB LDS, 256 rows each)
-int g_la_mb_pair = 0;         // la_debug_set key 6: 1 = paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup)
+int g_la_mb_pair = 1;         // la_debug_set key 6: 1 = paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup)
 int g_la_mb_narrow = 0;       // la_debug_set key 3: 1 = the K-split kernels (k_gemm_mb) for every nblk (A/B measurements)
 template <typename K> static hipError_t set_lds(K k, int bytes) {
     return hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
