@@ -30,7 +30,7 @@ struct MbArgs {
     // weight addressing: planned (workgroup-major virtual blocks, la_pack_planned) or classic (la_pack_weight)
     int planned, R;
     int gu_interleaved;      // MB_SWIGLU on a classic image: row-blocks alternate gate/up (la_pack_weight interleave2)
-    int nv[4], nvl[4], boff[4], wg_chunks;
+    int nv[8], nvl[8], boff[8], wg_chunks;       // entries 4..7: second region of a paired gate/up launch (RBV = 8)
     float* slabs;            // MB_SLAB: [ksplit][M][N]
     bf16_t* act_xp;          // MB_SWIGLU: [blk][64 x N packed]
     bf16_t* logits;          // MB_LOGITS: [M][N] row-major bf16 (may be null)
@@ -358,6 +358,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int RBV, int TW> struct WideGeom {
     static constexpr int KS = 2, RG = RBV / 2, TQ = 8 / RG, NTBP = TQ * TW;  // token blocks (32 rows) per workgroup
+    // RBV = 8: the paired gate/up launch — two adjacent planned regions {G0,G1,U0,U1} x 2 per workgroup, 4 row groups x 2 token groups
     static constexpr int A_STAGE = KS * RBV, B_STAGE = KS * NTBP;           // 1 KiB pieces per stage
     static constexpr int STAGE = A_STAGE + B_STAGE;
     static constexpr int NR = 4;                                              // ring slots (stages)
@@ -366,7 +367,7 @@ template <int RBV, int TW> struct WideGeom {
     static constexpr int H = (NP_HI + 1) / 2;                                 // pieces issued in the first half of a stage
     static constexpr int LDS = NR * STAGE * 1024;
     static constexpr int BLOCKS = NTBP / 2;                                   // 64-row blocks per workgroup
-    static_assert(A_STAGE <= 8 && LDS <= 160 * 1024 && (RBV == 2 || RBV == 4), "ring geometry");
+    static_assert(A_STAGE <= 16 && LDS <= 160 * 1024 && (RBV == 2 || RBV == 4 || RBV == 8), "ring geometry");
 };
 
 template <int RBV, int TW, int EPI, int DBG = 0>
@@ -384,12 +385,13 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // row group = wave / 4: a workgroup's waves are dealt to the SIMDs cyclically, so each SIMD gets one wave of either row group
     // (the row groups' epilogues differ in weight: a planned gate/up image has 32 valid rows in one pair of blocks, R - 32 in the other)
-    const int rg = RBV == 4 ? (wave >> 2) : 0, tq = RBV == 4 ? (wave & 3) : wave;
-    static_assert(TQ == (RBV == 4 ? 4 : 8), "wave grid");
+    const int rg = wave / TQ, tq = wave % TQ;        // RBV = 2: 1 x 8, RBV = 4: 2 x 4, RBV = 8: 4 row groups x 2 token groups
+    static_assert(TQ == (RBV == 8 ? 2 : RBV == 4 ? 4 : 8) && (EPI == MB_SWIGLU || RBV != 8), "wave grid");
     // the wave's two row-blocks: planned gate/up images are {G0, G1, U0, U1} (pair = rb, rb + 2), classic interleaved images
     // {G, U, G, U} (pair = 2 rg, 2 rg + 1); lm_head rows are independent; RBV = 2 images are {lo, hi} / two plain blocks
-    const int rb0 = RBV == 4 ? ((EPI == MB_SWIGLU && !a.gu_interleaved) ? rg : 2 * rg) : 0;
-    const int rb1 = RBV == 4 ? ((EPI == MB_SWIGLU && !a.gu_interleaved) ? rg + 2 : 2 * rg + 1) : 1;
+    // RBV = 8 (planned gate/up only): row groups 0, 1 work on region 2 x, row groups 2, 3 on region 2 x + 1 (blocks 4..7)
+    const int rb0 = RBV == 8 ? 4 * (rg >> 1) + (rg & 1) : RBV == 4 ? ((EPI == MB_SWIGLU && !a.gu_interleaved) ? rg : 2 * rg) : 0;
+    const int rb1 = RBV == 8 ? rb0 + 2 : RBV == 4 ? ((EPI == MB_SWIGLU && !a.gu_interleaved) ? rg + 2 : 2 * rg + 1) : 1;
     const int ksplit = gridDim.y, ks = blockIdx.y;
     const int t0 = (int)(((long)a.K16 * ks) / ksplit), t1 = (int)(((long)a.K16 * (ks + 1)) / ksplit);
     const int nst = (t1 - t0 + KS - 1) / KS;
@@ -397,15 +399,15 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
 
     const bf16x8* __restrict__ wbase = (const bf16x8*)a.wp;
     const bf16x8* __restrict__ xbase = (const bf16x8*)a.xp;
-    const bool w0 = wave < A_STAGE;                 // piece 0 of this wave is a weight piece (only i = 0 can be: A_STAGE <= 8)
     const bool hi = wave < N_HI;                    // this wave carries NP_HI pieces
+    // piece p = wave + 8 i of a stage is a weight piece iff p < A_STAGE (i = 0 for the waves below A_STAGE; i = 0 and 1 at RBV = 8)
     const bf16x8* src[NP_HI];                       // per-lane source of the piece at k-tile 0
     unsigned gstr[NP_HI];                           // its k-tile stride (16 B units)
     int pkk[NP_HI], pdst[NP_HI];                    // wave-uniform: k-tile inside the stage, byte offset inside the stage buffer
 #pragma unroll
     for (int i = 0; i < NP_HI; ++i) {
         const int p = wave + 8 * ((i < NP_LO || hi) ? i : 0);
-        if (i == 0 && w0) {
+        if (p < A_STAGE) {
             const int kk = p / RBV, rb = p % RBV;
             if (a.planned) {
                 const int nvb = a.nvl[rb];
@@ -433,11 +435,9 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
         kt = kt < t1 ? kt : t1 - 1;
         const bf16x8* g = src[i] + (size_t)kt * gstr[i];
         char* d = lds_raw + (sidx % NR) * (STAGE * 1024) + pdst[i];
-        if (i == 0) {
-            if (w0 && !a.w_keep) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 2);       // streamed weights: nt
+        if (i < NP_LO || hi) {
+            if (wave + 8 * i < A_STAGE && !a.w_keep) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 2);   // streamed weights: nt
             else __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 0);
-        } else if (i < NP_LO || hi) {
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 0);
         }
     };
     auto issue = [&](int sidx) {
@@ -529,7 +529,8 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
     const int tl = lane & 31, hh = lane >> 5;
     // MB_SWIGLU staging geometry: features [sw_lo, sw_lo + sw_r) of this workgroup, columns shifted by sw_sh = sw_lo % 8 so that
     // the 16-byte chunks of the activation image are 16-byte aligned in the tile; row stride in elements, never a multiple of 64
-    const int sw_lo = a.gu_interleaved ? 64 * blockIdx.x : a.R * blockIdx.x, sw_r = a.gu_interleaved ? 64 : a.R, sw_sh = sw_lo & 7;
+    constexpr int REG = RBV == 8 ? 2 : 1;           // planned regions per workgroup (their features are adjacent)
+    const int sw_lo = a.gu_interleaved ? 64 * blockIdx.x : a.R * REG * blockIdx.x, sw_r = a.gu_interleaved ? 64 : REG * a.R, sw_sh = sw_lo & 7;
     const int sw_nch = (sw_sh + sw_r + 7) >> 3;
     const int sw_stride = (sw_nch * 8) % 64 == 0 ? sw_nch * 8 + 8 : sw_nch * 8;
     if constexpr (EPI == MB_SWIGLU) __syncthreads();            // every wave is done with the ring
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
             // cost ~27 us per launch at 512 rows (L2 write REQUESTS, not bytes); see the store pass below
             const int nvg = a.nv[rb0];
             bf16_t* tile = (bf16_t*)lds_raw;
-            const int c0 = sw_sh + 32 * rg;
+            const int c0 = sw_sh + (RBV == 8 ? (rg >> 1) * a.R + 32 * (rg & 1) : 32 * rg);
             const int trow = (tbg >> 1) * 64 + tok;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -1438,6 +1439,7 @@ int lk_mb_init() {
     SETALL(2) SETALL(4) SETALL(8)
 #undef SETALL
 #define SETW4(T) \
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<8, T, MB_SWIGLU>, WideGeom<8, T>::LDS); \
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_SWIGLU>, WideGeom<4, T>::LDS); \
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_LOGITS>, WideGeom<4, T>::LDS);
 #define SETW2(T) \
@@ -1561,6 +1563,22 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                 }
                 if (nblk <= 4) k_gemm_wide<4, 1, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 1) / 2), 512, WideGeom<4, 1>::LDS, st>>>(p);
                 else k_gemm_wide<4, 2, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 3) / 4), 512, WideGeom<4, 2>::LDS, st>>>(p);
+                LAUNCH_CHECK(); return 0;
+            }
+        }
+        if constexpr (RBV == 4 && EPI == MB_SWIGLU) {
+            // paired gate/up launch (planned images): regions {2 x, 2 x + 1} = row-blocks 0..7, half the token blocks per workgroup
+            if (g_la_mb_pair && a.planned && !a.gu_interleaved && n_wg % 16 == 0 && ksplit == 1) {
+                MbArgs p = a;
+                p.w_keep = 1;
+                for (int i = 0; i < 4; ++i) { p.boff[4 + i] = a.wg_chunks + a.boff[i]; p.nv[4 + i] = a.nv[i]; p.nvl[4 + i] = a.nvl[i]; }
+                p.wg_chunks = 2 * a.wg_chunks;
+                const dim3 g2(n_wg / 2, 1, 2);
+                switch ((nblk + 1) / 2) {                       // 64-row blocks per workgroup = TW
+                    case 2: k_gemm_wide<8, 2, EPI><<<g2, 512, WideGeom<8, 2>::LDS, st>>>(p); break;
+                    case 3: k_gemm_wide<8, 3, EPI><<<g2, 512, WideGeom<8, 3>::LDS, st>>>(p); break;
+                    default: k_gemm_wide<8, 4, EPI><<<g2, 512, WideGeom<8, 4>::LDS, st>>>(p); break;
+                }
                 LAUNCH_CHECK(); return 0;
             }
         }

@@ -29,6 +29,9 @@ def main():
         wq = [gu.pack_planned(2, [bf(torch.randn(Nq, hidden, generator=g, device=DEV) * 0.05)], 256) for _ in range(NBUF)]
         wo = [gu.pack_weight(bf(torch.randn(hidden, nh * 128, generator=g, device=DEV) * 0.05)) for _ in range(NBUF)]
         wd = [gu.pack_weight(bf(torch.randn(hidden, ffn, generator=g, device=DEV) * 0.05)) for _ in range(NBUF)]
+        wgu = [gu.pack_planned(1, [bf(torch.randn(ffn, hidden, generator=g, device=DEV) * 0.05), bf(torch.randn(ffn, hidden, generator=g, device=DEV) * 0.05)], 256)
+               for _ in range(NBUF)]
+        act = torch.zeros(8 * 64 * ffn, dtype=torch.bfloat16, device=DEV)
         slabs = torch.zeros(4 * 512 * hidden, dtype=torch.float32, device=DEV)
         qf = torch.zeros(8 * nh * 8192, dtype=torch.bfloat16, device=DEV)
         kf = torch.zeros(8 * nkv * 8192, dtype=torch.bfloat16, device=DEV)
@@ -53,13 +56,16 @@ def main():
             def down(i):
                 check(lib.la_mb_gemm(sp(), 0, ptr(wd[i % NBUF]), ptr(ap), hidden, ffn, nblk, 0, 4, ptr(slabs), 512, ptr(z), ptr(z), ptr(z),
                                      ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), 0, 0), 'mb_gemm')
-            for kname, fn in (('qkv', qkv), ('o_proj', oproj), ('down', down)):
+            def gateup(i):
+                check(lib.la_mb_gemm(sp(), 1, ptr(wgu[i % NBUF]), ptr(xp), ffn, hidden, nblk, 256, 1, ptr(z), 0, ptr(act), ptr(z), ptr(z), ptr(z),
+                                     ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), 0, 0), 'mb_gemm')
+            for kname, fn in (('gate/up', gateup), ('qkv', qkv), ('o_proj', oproj), ('down', down)):
                 res = []
                 for pair in (0, 1, 0, 1):
                     check(lib.la_debug_set(6, pair), 'debug_set')
                     res.append(bench(fn, trials=5, n=12)[0])
                 print(f'{name:12s} rows {nblk * 64:4d} {kname:7s} unpaired {min(res[0], res[2]):8.2f} us   paired {min(res[1], res[3]):8.2f} us', flush=True)
-        del wq, wo, wd
+        del wq, wo, wd, wgu
         torch.cuda.empty_cache()
     check(lib.la_debug_set(6, 0), 'debug_set')
 

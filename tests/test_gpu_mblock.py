@@ -367,5 +367,20 @@ def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
                 outs.append((qf, kf, vf))
             for a_, b_ in zip(outs[0], outs[1]):
                 assert torch.equal(a_, b_), (nh, nkv, nwg)
+        # gate/up + SwiGLU on planned images: two regions {G0, G1, U0, U1} x 2 per workgroup (RBV = 8 wave grid)
+        for F, K in ((11008, 512), (13824, 1024), (14336, 256)):
+            g = torch.Generator(device=DEV).manual_seed(F + nblk)
+            x = bf(torch.randn(nblk * 64, K, generator=g, device=DEV))
+            wg_ = bf(torch.randn(F, K, generator=g, device=DEV) * 0.05)
+            wu_ = bf(torch.randn(F, K, generator=g, device=DEV) * 0.05)
+            wp = gu.pack_planned(1, [wg_, wu_], 256)
+            outs = []
+            for pair in (0, 1):
+                check(lib.la_debug_set(6, pair), 'debug_set')
+                act = torch.zeros(8 * 64 * F, dtype=torch.bfloat16, device=DEV)
+                _mb(1, wp, _pack_blocks(x), F, K, nblk, n_wg=256, act=act)
+                outs.append(act)
+            assert torch.equal(outs[0], outs[1]), (F, K)
+            assert float(outs[0][:nblk * 64 * F].float().abs().sum()) > 0
     finally:
         lib.la_debug_set(6, default_form)
