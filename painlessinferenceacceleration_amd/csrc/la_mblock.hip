@@ -1421,7 +1421,7 @@ __global__ __launch_bounds__(256) void k_kv_commit_mb(const bf16_t* __restrict__
 static bool g_mb_attr = false;
 int g_la_mb_dbg = 0;
 int g_la_mb_mode = 0;         // la_debug_set key 5: 1 = wide kernel as two co-resident workgroups per CU (80 KiB LDS, 256 rows each)
-int g_la_mb_pair = 1;         // la_debug_set key 6: 1 = paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup)
+int g_la_mb_pair = 1;         // la_debug_set key 6, bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too
 int g_la_mb_narrow = 0;       // la_debug_set key 3: 1 = the K-split kernels (k_gemm_mb) for every nblk (A/B measurements)
 template <typename K> static hipError_t set_lds(K k, int bytes) {
     return hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1553,7 +1553,7 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
             // whole x operand of its token blocks from L2 (1 GB per launch at 512 rows and 256 workgroups: the dominant term of these
             // launches); pairing halves that, and the second reader of a weight region (z = 1, 128 workgroup ids later: same XCD)
             // finds it in L2.  Same MFMAs on the same operands in the same order per output: bit-identical results.
-            if (g_la_mb_pair && n_wg % 2 == 0 && (n_wg / 2 * ksplit) % 8 == 0) {
+            if ((g_la_mb_pair & 1) && n_wg % 2 == 0 && (n_wg / 2 * ksplit) % 8 == 0) {
                 MbArgs p = a;
                 p.w_keep = 1;
                 if (p.planned) {
@@ -1567,8 +1567,10 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
             }
         }
         if constexpr (RBV == 4 && EPI == MB_SWIGLU) {
-            // paired gate/up launch (planned images): regions {2 x, 2 x + 1} = row-blocks 0..7, half the token blocks per workgroup
-            if (g_la_mb_pair && a.planned && !a.gu_interleaved && n_wg % 16 == 0 && ksplit == 1) {
+            // paired gate/up launch (planned images): regions {2 x, 2 x + 1} = row-blocks 0..7, half the token blocks per workgroup.
+            // Bit-identical, but NOT faster (this launch is bound by its MFMA / ds_read side, not by the x traffic: 512 rows 116.5 vs
+            // 116.4 us, 256 rows 68.4 vs 76.6 us at the 7B shape, profiles/r02b_mblock_paired_ab.txt): opt-in (la_debug_set(6, 3)).
+            if ((g_la_mb_pair & 2) && a.planned && !a.gu_interleaved && n_wg % 16 == 0 && ksplit == 1) {
                 MbArgs p = a;
                 p.w_keep = 1;
                 for (int i = 0; i < 4; ++i) { p.boff[4 + i] = a.wg_chunks + a.boff[i]; p.nv[4 + i] = a.nv[i]; p.nvl[4 + i] = a.nvl[i]; }

@@ -61,13 +61,13 @@ def main():
                                      ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), 0, 0), 'mb_gemm')
             for kname, fn in (('gate/up', gateup), ('qkv', qkv), ('o_proj', oproj), ('down', down)):
                 res = []
-                for pair in (0, 1, 0, 1):
+                for pair in (0, 3, 0, 3):
                     check(lib.la_debug_set(6, pair), 'debug_set')
                     res.append(bench(fn, trials=5, n=12)[0])
                 print(f'{name:12s} rows {nblk * 64:4d} {kname:7s} unpaired {min(res[0], res[2]):8.2f} us   paired {min(res[1], res[3]):8.2f} us', flush=True)
         del wq, wo, wd, wgu
         torch.cuda.empty_cache()
-    check(lib.la_debug_set(6, 0), 'debug_set')
+    check(lib.la_debug_set(6, 1), 'debug_set')
 
 
 if __name__ == '__main__':

@@ -375,7 +375,7 @@ def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
             wu_ = bf(torch.randn(F, K, generator=g, device=DEV) * 0.05)
             wp = gu.pack_planned(1, [wg_, wu_], 256)
             outs = []
-            for pair in (0, 1):
+            for pair in (0, 3):
                 check(lib.la_debug_set(6, pair), 'debug_set')
                 act = torch.zeros(8 * 64 * F, dtype=torch.bfloat16, device=DEV)
                 _mb(1, wp, _pack_blocks(x), F, K, nblk, n_wg=256, act=act)
