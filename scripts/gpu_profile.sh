@@ -8,7 +8,7 @@ REPO=$PWD
 OUT=$REPO/gpurun_out
 RAW=/tmp/la_prof
 rm -rf $RAW; mkdir -p $OUT $RAW
-BENCH="python bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline --profile-iters 1"
+BENCH="python bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline --profile-iters 1 --secondary \"\""
 ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/stats -o run -- bash -c "cd $REPO && $BENCH" > $OUT/prof_stats.log 2>&1 )
 echo "stats exit $?" >> $OUT/prof_stats.log
 for C in FETCH_SIZE WRITE_SIZE; do
