@@ -451,7 +451,9 @@ def main():
         # dominant kernel (gate/up GEMM, k_gemm64r<4,SWIGLU,4,8>) from live HIP events on the engine's stream
         ids, rowmask = drafts_for(0)
         prof = eng.profile(ids, rowmask, iters=args.profile_iters)
-        gu_ms = prof['ms']['gateup'] / max(prof['launches']['gateup'], 1)
+        gu_ms_step = prof['ms']['gateup'] / max(prof['launches']['gateup'], 1)     # inside the eager step: event packets on both sides
+        # the launch duration proper: all layers' gate/up launches back to back inside ONE event pair (kernel + launch boundary)
+        gu_ms = eng.profile_gateup(iters=5)
         gu_bytes = 2 * shape.ffn * shape.hidden * 2 + 64 * shape.hidden * 2 + 64 * shape.ffn * 2
         step_bytes = algorithmic_bytes(shape, 64, ctx, 64 * shape.vocab * 2)
         gemm_ms = sum(prof['ms'][k] for k in ('qkv', 'o', 'gateup', 'down', 'lm_head'))
@@ -468,6 +470,10 @@ def main():
             'achieved': round(gu_bytes / (gu_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(gu_bytes / (gu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
             'bytes_per_launch': gu_bytes, 'ms_per_launch': round(gu_ms, 5),
+            'timing': 'HIP events on the engine stream: %d launches (one per layer, own weights) back to back per event pair, 5 passes; '
+                      'inside the eager step, with event packets between all kernels, the same launch reads %.5f ms; rocprofv3 kernel '
+                      'average: profiles/r02b_profile_raw.txt' % (shape.n_layers, gu_ms_step),
+            'ms_per_launch_in_eager_step': round(gu_ms_step, 5),
             # the same launch against the matrix-core roof: 64-row trees keep the kernel far below the MFMA ridge (HBM-bound by design)
             'mfma': {'flops_per_launch': 2 * 2 * shape.ffn * shape.hidden * 64,
                      'achieved_TFLOPs': round(2 * 2 * shape.ffn * shape.hidden * 64 / (gu_ms * 1e-3) / 1e12, 1),

@@ -353,6 +353,10 @@ void* la_llama_buffer(la_llama* m, int which);
  * steps; the sequence state is saved and restored, so the context does not advance. */
 int la_llama_profile(la_llama* m, void* stream, const int32_t* host_in, int iters,
                      float* out_ms /*[8]*/, int32_t* out_launches /*[7] or NULL*/);
+/* Mean duration (ms) of one gate/up launch — the dominant kernel of the step — measured without event packets between launches:
+ * every layer's launch back to back inside one pair of HIP events per pass (kernel + the dependent-launch boundary).  bench.py's
+ * `roofline.achieved`; the rocprofv3 kernel average under profiles/ is the cross-check. */
+int la_llama_profile_gateup(la_llama* m, void* stream, int iters, float* out_ms);
 
 /* ---- native decode loop: the per-step host work of lookahead_generation (pretrained_model.py:1172-1240) without the
  * interpreter: hier_get(last max_query_length tokens) -> la_llama_step -> stream_put, until max_length / eos / max_steps.

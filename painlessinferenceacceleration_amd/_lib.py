@@ -160,6 +160,7 @@ PROTOTYPES = {
                             C.POINTER(C.c_double), C.POINTER(C.c_double)),
     "la_llama_buffer": (vp, vp, i32),
     "la_llama_profile": (i32, vp, vp, vp, i32, pf32, pi32),
+    "la_llama_profile_gateup": (i32, vp, vp, i32, pf32),
     "la_resid_norm_router": (i32, vp, vp, vp, i32, vp, i32, f32, vp, vp, i32, i32, vp, vp),
     "la_moe_accum": (i32, vp, vp, i32, vp, i32, i32, vp, i32),
     "la_resid_norm_addend": (i32, vp, vp, vp, vp, i32, f32, vp),

@@ -885,6 +885,33 @@ extern "C" void* la_llama_buffer(la_llama* m, int which) {
 // out_ms[0..6] = per-step sum of {qkv, o, gate/up, down, lm_head, attention(+combine), other};
 // out_ms[7] = whole step; out_launches[0..6] = launches of that class per step.
 // The sequence state is saved and restored so profiling does not advance the context.
+// Duration of the dominant kernel without the event packets of la_llama_profile between launches: the gate/up launch of every
+// layer (its own weights, the activation operand left by the last step), back to back, bracketed by ONE pair of HIP events per
+// pass; out_ms = mean time per launch (kernel + the dependent-launch boundary, ~1.5 us).  Dense models with the balanced image.
+extern "C" int la_llama_profile_gateup(la_llama* m, void* stream, int iters, float* out_ms) {
+    if (!m || iters <= 0 || !out_ms) return LA_E_ARG;
+    const la_llama_config& c = m->cfg;
+    if (c.n_experts > 0 || c.balanced_wg[1] <= 0) { la_set_error("profile_gateup: dense model with the balanced gate/up image only"); return LA_E_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    double acc = 0;
+    for (int it = 0; it <= iters; ++it) {                 // pass 0 warms up
+        HIPCHK(hipEventRecord(e0, st));
+        for (int l = 0; l < c.n_layers; ++l)
+            KCHK(lk_gemm64r_swiglu(st, m->layers[l].wgateup, m->xp, c.ffn, c.hidden, c.balanced_wg[1], m->act_xp));
+        HIPCHK(hipEventRecord(e1, st));
+        HIPCHK(hipStreamSynchronize(st));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        if (it > 0) acc += ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *out_ms = (float)(acc / iters / c.n_layers);
+    return LA_OK;
+}
+
 extern "C" int la_llama_profile(la_llama* m, void* stream, const int32_t* host_in, int iters,
                                 float* out_ms, int32_t* out_launches) {
     if (!m || !host_in || iters <= 0 || !out_ms) return LA_E_ARG;

@@ -729,6 +729,12 @@ class LlamaVerifyEngine(object):
         L = self.shape.n_layers
         return self._view(9, L * 64 * _lib.LA_MOE_MAX_E * 4, torch.float32).view(L, 64, _lib.LA_MOE_MAX_E)
 
+    def profile_gateup(self, iters=5):
+        """mean ms of one gate/up launch, every layer's launch back to back inside one HIP-event pair (la_llama_profile_gateup)"""
+        ms = C.c_float(0)
+        check(lib.la_llama_profile_gateup(self._h, self._sp(), int(iters), C.byref(ms)), 'profile_gateup')
+        return float(ms.value)
+
     def profile(self, ids, rowmask, iters=3):
         """HIP-event timing per kernel class (see la_llama_profile)."""
         self._fill(ids, rowmask, 0)
