@@ -11,7 +11,7 @@
 #include <atomic>
 #include "la_kernels.h"
 #include "la_mblock.h"
-extern int g_la_pf_kib, g_la_pf_delay, g_la_pf_tail_kib, g_la_graph_epoch;
+extern int g_la_pf_kib, g_la_pf_delay, g_la_pf_tail_kib, g_la_graph_epoch, g_la_graph_reps;
 
 extern void la_set_error(const std::string& s);
 
@@ -477,7 +477,11 @@ static int build_graph(la_llama* m, hipStream_t st, bool batch = false, const in
                        int32_t* zc_out = nullptr, int bsplit = 0) {
     hipGraph_t g = nullptr;
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    int rc = enqueue_step(m, st, nullptr, batch, zc_in, zc_out, bsplit);
+    // measurement knob (la_debug_set key 11): the single-sequence graph holds the step n times (the same input block each time, only
+    // the last repetition publishes) — what a launch costs beyond its kernels shows as time per repetition vs n
+    const int reps = (!batch && g_la_graph_reps > 1) ? g_la_graph_reps : 1;
+    int rc = LA_OK;
+    for (int r = 0; r < reps && rc == LA_OK; ++r) rc = enqueue_step(m, st, nullptr, batch, zc_in, r + 1 == reps ? zc_out : nullptr, bsplit);
     hipError_t e = hipStreamEndCapture(st, &g);
     if (rc != LA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
     HIPCHK(e);

@@ -1659,6 +1659,7 @@ long long* g_la_dbg_times = nullptr;
 int g_la_pf_kib = 0;          // idle-window weight prefetch: KiB per consumer workgroup (la_debug_set key 7; read when a step graph is captured)
 int g_la_pf_tail_kib = 0;     // tail prefetch of down_proj from the gate/up launch: KiB per workgroup (key 9)
 int g_la_attn_staged = 0;     // 1: tree attention with K/V staged through LDS once per workgroup (la_debug_set key 10)
+int g_la_graph_reps = 1;      // measurement: repetitions of the step inside the single-sequence graph (key 11)
 int g_la_graph_epoch = 0;     // bumped by la_debug_set when a capture-time knob changes: la_llama_step captures its graph again
 int g_la_pf_delay = 0;        // s_sleep(32) rounds the prefetch workgroups wait before their first load (key 8)
 
