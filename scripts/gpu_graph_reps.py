@@ -32,12 +32,12 @@ def main():
         eng.reset()
         ids[0] = eng.prefill(prompt, fast=False)
         for _ in range(3):
-            eng.step(ids, rows)
+            eng.step(ids, rows, mode=2)
         torch.cuda.synchronize()
         n = 24 // reps + 2
         t0 = time.perf_counter()
         for _ in range(n):
-            eng.step(ids, rows)
+            eng.step(ids, rows, mode=2)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
         rec = {'steps_per_graph': reps, 'ms_per_launch': round(ms, 4), 'ms_per_step': round(ms / reps, 4), 'context_at_end': eng.n_keys}
