@@ -108,6 +108,9 @@ class LookaheadPreTrainedModel(object):
         # processors are applied sequentially along the accepted path (pretrained_model.py:834), so a non-empty
         # list (or sampling) takes the host-walked path: device forward only (mode 2), one logits row per accepted token,
         # host-decided commit.  The empty-list greedy default stays entirely on the device.
+        if isinstance(logits_processor, (list, tuple)) and not callable(logits_processor):
+            from transformers import LogitsProcessorList      # a plain list of processors: the reference's generate() wraps it the same way
+            logits_processor = LogitsProcessorList(list(logits_processor))
         sequential = (logits_processor is not None and len(logits_processor) > 0) or \
             bool(model_kwargs.get('decoding_kwargs', {}).get('do_sample', False))
         if output_scores or output_attentions or output_hidden_states:

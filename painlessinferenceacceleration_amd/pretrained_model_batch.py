@@ -99,6 +99,9 @@ class LookaheadPreTrainedModel(object):
         # input_ids[b, :cur+i+2] (pretrained_model_batch.py:814-875).  With an empty list and greedy decoding that walk equals the
         # device accept scan; a non-empty list or sampling takes the sequential path: forward-only step (mode 2), host walk over
         # the logits rows, host-decided commit (la_llama_bcommit / la_llama_mcommit).
+        if isinstance(logits_processor, (list, tuple)) and not callable(logits_processor):
+            from transformers import LogitsProcessorList      # a plain list of processors: the reference's generate() wraps it the same way
+            logits_processor = LogitsProcessorList(list(logits_processor))
         sequential = (logits_processor is not None and len(logits_processor) > 0) or \
             bool(model_kwargs.get('decoding_kwargs', {}).get('do_sample', False))
         if output_scores or output_attentions or output_hidden_states:

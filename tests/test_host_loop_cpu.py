@@ -160,6 +160,51 @@ def test_batch_loop_sequential_processor_path_reproduces_reference():
     assert a[:, :n].tolist() == b[:, :n].tolist() == [row[:n] for row in g['b3pad_r0_sequences'].tolist()]
 
 
+def test_batch_sequential_path_with_identity_processor_equals_default_path():
+    """A processor that returns the scores unchanged sends the batch loop down the sequential accept path (forward-only step,
+    host walk, host commit); tokens, dls and edls must equal the default path's (device-style accept) on the same prompts —
+    including eos stops in the middle of an accepted chain and the max_length limit — on both engine surfaces."""
+    import os
+    from painlessinferenceacceleration_amd.pretrained_model_batch import LookaheadPreTrainedModel as BatchMixin
+    from tests.oracle_engine import OracleBatchEngine
+    from tests.tiny_model import GOLDEN
+
+    class Identity(object):
+        calls = 0
+
+        def __call__(self, input_ids, scores):
+            Identity.calls += 1
+            assert input_ids.dim() == 2 and scores.dim() == 2 and input_ids.shape[0] == scores.shape[0] == 1
+            return scores
+
+    class BModel(BatchMixin):
+        def __init__(self, max_blocks):
+            self.engine = OracleBatchEngine(tiny_shape(), tiny_weights(0), max_length=256, n_slots=4, max_blocks=max_blocks)
+            self.generation_config = SimpleNamespace(eos_token_id=2, pad_token_id=0, return_dict_in_generate=False)
+            self.lookahead_cache = LookaheadCache()
+
+    g = np.load(os.path.join(GOLDEN, 'llama_tiny_batch_fp32.npz'))
+    ids, am = torch.from_numpy(g['b3pad_ids']), torch.from_numpy(g['b3pad_am'])
+    ref_seq = g['b3pad_r0_sequences']
+    P = ids.shape[1]
+    eos = int(ref_seq[0, P + 9])                 # a token sample 0 generates early: it stops there, the others go on
+    for max_blocks, dl in ((0, 64), (4, 256)):
+        outs = []
+        for procs in (None, [Identity()]):
+            m = BModel(max_blocks)
+            runs = []
+            for r in range(2):
+                dk = dict(DK); dk['decoding_length'] = dl
+                out = m.lookahead_generation(ids, logits_processor=procs, stopping_criteria=P + 41, eos_token_id=eos, pad_token_id=0,
+                                             return_dict_in_generate=True, attention_mask=am, decoding_kwargs=dk)
+                runs.append((out.sequences.tolist(), out.kwargs['dls'], out.kwargs['edls']))
+            outs.append(runs)
+        assert outs[0] == outs[1], (max_blocks, dl)
+        seq0 = outs[0][0][0][0]
+        assert eos in seq0[P:P + 12] and len([t for t in seq0[P:] if t != 0]) <= 12 + 13
+    assert Identity.calls > 50
+
+
 def test_benchmark_harness_perf_check_and_trie_loop(capsys):
     """painlessinferenceacceleration_amd.benchmark.Benchmark (methodology of lookahead/benchmarks/benchmark.py): warm_up +
     perf_check over a (decoding_length, branch_length) grid on the oracle-backed model, and the trie-only timing loop."""
