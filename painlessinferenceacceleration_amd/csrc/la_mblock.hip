@@ -1450,6 +1450,8 @@ int lk_mb_init() {
     SETW4(2) SETW4(3) SETW4(4) SETW2(1) SETW2(2)
 #undef SETW4
 #undef SETW2
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 2, MB_SLAB, 4>, WideGeom<4, 2>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 2, MB_QKV, 4>, WideGeom<4, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 1>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 2>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 3>, WideGeom<4, 4>::LDS);
@@ -1562,6 +1564,7 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                     p.wg_chunks = 2 * a.wg_chunks;
                 }
                 if (nblk <= 4) k_gemm_wide<4, 1, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 1) / 2), 512, WideGeom<4, 1>::LDS, st>>>(p);
+                else if (g_la_mb_dbg == 4) k_gemm_wide<4, 2, EPI, 4><<<dim3(n_wg / 2, ksplit, (nblk + 3) / 4), 512, WideGeom<4, 2>::LDS, st>>>(p);   // measurement: no epilogue
                 else k_gemm_wide<4, 2, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 3) / 4), 512, WideGeom<4, 2>::LDS, st>>>(p);
                 LAUNCH_CHECK(); return 0;
             }

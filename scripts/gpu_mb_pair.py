@@ -59,6 +59,17 @@ def main():
             def gateup(i):
                 check(lib.la_mb_gemm(sp(), 1, ptr(wgu[i % NBUF]), ptr(xp), ffn, hidden, nblk, 256, 1, ptr(z), 0, ptr(act), ptr(z), ptr(z), ptr(z),
                                      ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), 0, 0), 'mb_gemm')
+            if len(sys.argv) > 1 and sys.argv[1] == 'epi':
+                # share of the epilogue: the paired 512-row launches with and without it (la_debug_set key 4 = 4: measurement build)
+                if nblk == 8:
+                    for kname, fn in (('qkv', qkv), ('o_proj', oproj), ('down', down)):
+                        res = []
+                        for dbg in (0, 4, 0, 4):
+                            check(lib.la_debug_set(4, dbg), 'debug_set')
+                            res.append(bench(fn, trials=5, n=12)[0])
+                        check(lib.la_debug_set(4, 0), 'debug_set')
+                        print(f'{name:12s} rows {nblk * 64:4d} {kname:7s} paired: full {min(res[0], res[2]):8.2f} us   without epilogue {min(res[1], res[3]):8.2f} us', flush=True)
+                continue
             for kname, fn in (('gate/up', gateup), ('qkv', qkv), ('o_proj', oproj), ('down', down)):
                 res = []
                 for pair in (0, 3, 0, 3):
