@@ -191,6 +191,7 @@ def main():
     ap.add_argument('--profile-iters', type=int, default=3)
     ap.add_argument('--attn-split', type=int, default=0, help='key splits of the tree-attention kernel (0 = engine default 8)')
     ap.add_argument('--fuse', type=int, default=0, help='engine cfg.fuse bits (opt-in in-kernel norm->GEMM fusion; 0 = separate kernels)')
+    ap.add_argument('--gemm-cfg', default='', help='engine gemm_cfg override (comma list: qkv_rb,qkv_ks,o_rb,o_ks,down_rb,down_ks,lm_rb,gu_variant; 0 = default)')
     ap.add_argument('--secondary', default='mistral:8,13b:4,mixtral:4',
                     help='N=1 default workload only: comma list of model:batch legs (BASELINE configs 3-5: a 64-token tree per sequence '
                          'through la_llama_mstep) run AFTER the timed region, each in its own process; their lines are embedded under '
@@ -250,12 +251,13 @@ def main():
     want_cpu = not args.no_cpu_baseline and world == 1 and B == 1      # the CPU leg is timed on rank 0 at N=1 only
     sd = random_weights(shape, seed=0, device=dev, decisive=not args.pure_random)
     sd_cpu = {k: v.cpu() for k, v in sd.items()} if want_cpu else None
+    gemm_cfg = [int(x) for x in args.gemm_cfg.split(',')] if args.gemm_cfg else None
     if B == 1:
         model = LlamaForCausalLM(shape, sd, device=dev, max_length=max_length, eos_token_id=None, consume_state_dict=True,
-                                 fuse=args.fuse, attn_split=args.attn_split, max_blocks=8)
+                                 fuse=args.fuse, attn_split=args.attn_split, max_blocks=8, gemm_cfg=gemm_cfg)
     else:
         model = BatchLlama(shape, sd, device=dev, max_length=max_length, max_batch=B, eos_token_id=None, consume_state_dict=True,
-                           attn_split=args.attn_split, max_blocks=B, kv_ring=kv_ring)
+                           attn_split=args.attn_split, max_blocks=B, kv_ring=kv_ring, gemm_cfg=gemm_cfg)
     del sd
     eng = model.engine
     NSEQ = world * B

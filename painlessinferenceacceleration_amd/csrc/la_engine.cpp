@@ -94,10 +94,21 @@ static void resolve_cfg(la_llama* m) {
     // workgroups) beat everything else; see DESIGN.md section 4
     m->qkv_rb = pick(c.gemm_cfg[0], 2);
     m->qkv_ks = pick(c.gemm_cfg[1], 1);
+    // K splits of the slab GEMMs (o_proj, down_proj: N = hidden): as many as keep hidden / 64 row-blocks x splits within ONE wave of
+    // workgroups over the CUs — 4 at hidden 4096 (64 x 4 = 256), 3 at 5120 (80 x 3 = 240; 4 splits = 320 workgroups run as two waves
+    // on 256 CUs), 2 at 8192.  Dense models only: the MoE accumulate kernels are instantiated for 4 slabs.
+    int auto_ks = 4;
+    if (c.n_experts == 0 && c.hidden >= 64) {
+        const int cus = c.balanced_wg[1] > 0 ? c.balanced_wg[1] : 256;
+        const int k = cus / (c.hidden / 64);
+        auto_ks = k >= 8 ? 8 : k >= 6 ? 6 : k >= 1 ? k : 1;      // 5 and 7 have no row-kernel instantiation
+        if (auto_ks == 5) auto_ks = 4;
+        if (auto_ks == 7) auto_ks = 6;
+    }
     m->o_rb = pick(c.gemm_cfg[2], 2 | (3 << 8));      // o_proj: 8 waves x 8 tile-sets (the whole K slice in flight at once): 10.8 -> 9.4 us
-    m->o_ks = pick(c.gemm_cfg[3], 4);
+    m->o_ks = pick(c.gemm_cfg[3], auto_ks);
     m->down_rb = pick(c.gemm_cfg[4], 2);
-    m->down_ks = pick(c.gemm_cfg[5], 4);
+    m->down_ks = pick(c.gemm_cfg[5], auto_ks);
     m->lm_rb = pick(c.gemm_cfg[6], 2);
     m->gu_variant = c.gemm_cfg[7];
     // qkv_ks == -1 in the config selects the unfused path (plain [Wq;Wk;Wv] packing + k_qkv_post)

@@ -1480,7 +1480,7 @@ int lk_mb_resid_norm(hipStream_t st, void* h, const float* slabs, int n_slabs, i
     if (hidden > 8192 || (hidden & 7)) return -1;
 #define RN(NS) k_row_norm_mb<NS><<<M, 512, 0, st>>>(nullptr, nullptr, (bf16_t*)h, slabs, (const bf16_t*)nw, hidden, eps, (bf16_t*)xp, slab_rows, cast_first)
     switch (n_slabs) {
-        case 1: RN(1); break; case 2: RN(2); break; case 4: RN(4); break; case 8: RN(8); break;
+        case 1: RN(1); break; case 2: RN(2); break; case 3: RN(3); break; case 4: RN(4); break; case 6: RN(6); break; case 8: RN(8); break;
         default: return -1;
     }
 #undef RN
