@@ -101,9 +101,7 @@ static void resolve_cfg(la_llama* m) {
     if (c.n_experts == 0 && c.hidden >= 64) {
         const int cus = c.balanced_wg[1] > 0 ? c.balanced_wg[1] : 256;
         const int k = cus / (c.hidden / 64);
-        auto_ks = k >= 8 ? 8 : k >= 6 ? 6 : k >= 1 ? k : 1;      // 5 and 7 have no row-kernel instantiation
-        if (auto_ks == 5) auto_ks = 4;
-        if (auto_ks == 7) auto_ks = 6;
+        auto_ks = k >= 4 ? 4 : k >= 1 ? k : 1;                   // never more than the 4 the small shapes were tuned and tested with
     }
     m->o_rb = pick(c.gemm_cfg[2], 2 | (3 << 8));      // o_proj: 8 waves x 8 tile-sets (the whole K slice in flight at once): 10.8 -> 9.4 us
     m->o_ks = pick(c.gemm_cfg[3], auto_ks);
