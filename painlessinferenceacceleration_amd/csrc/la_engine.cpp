@@ -88,7 +88,13 @@ static void resolve_cfg(la_llama* m) {
     const la_llama_config& c = m->cfg;
     m->qkv_n = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim;
     m->o_k = c.n_heads * c.head_dim;
-    m->nsplit = c.attn_split > 0 ? c.attn_split : 8;
+    // key splits of the tree attention: heads x splits workgroups should fit ONE wave over the CUs (32 heads -> 8, 40 -> 6, 64 -> 4)
+    {
+        const int cus = c.balanced_wg[1] > 0 ? c.balanced_wg[1] : 256;
+        const int k = c.n_heads > 0 ? cus / c.n_heads : 8;
+        const int auto_split = k >= 8 ? 8 : k >= 6 ? 6 : k >= 4 ? 4 : k >= 1 ? k : 1;       // 5 and 7 have no combine instantiation
+        m->nsplit = c.attn_split > 0 ? c.attn_split : auto_split;
+    }
     auto pick = [](int v, int d) { return v > 0 ? v : d; };
     // defaults from scripts/gpu_tune.py on MI355X (Llama-2-7B shapes): per-CU balanced grids (multiples of 256
     // workgroups) beat everything else; see DESIGN.md section 4
