@@ -550,7 +550,11 @@ extern "C" int la_llama_bstep_eager(la_llama* m, void* stream, const int32_t* ho
 
 // ---- multi-block step: nblk x 64 rows through the LDS-staged GEMM family (la_mblock.hip) -------------------------------
 // key splits of the multi-block attention: heads x splits x blocks workgroups should fill the 256 CUs about once
-static int mb_split(int nblk) { return nblk > 4 ? 1 : nblk > 2 ? 2 : nblk == 2 ? 4 : 8; }      // splits x blocks <= 8
+static int mb_split(int nblk, int n_heads = 32, int cus = 256) {
+    int s = nblk > 4 ? 1 : nblk > 2 ? 2 : nblk == 2 ? 4 : 8;                                   // splits x blocks <= 8 (partial buffers)
+    while (s > 1 && n_heads * s * nblk > cus) s >>= 1;                                         // ... and one wave of workgroups (40 heads: 13B)
+    return s;
+}
 
 static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk) {
     const la_llama_config& c = m->cfg;
@@ -569,7 +573,7 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk) {
         q.nh = c.n_heads; q.nkv = c.n_kv_heads;
         KCHK(lk_mb_gemm(st, 2, q));
         KCHK(lk_mb_tree_attn(st, m->mb_qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems, kf, vf,
-                             m->mb_rowmask, m->mb_meta, nblk, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, mb_split(nblk),
+                             m->mb_rowmask, m->mb_meta, nblk, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, mb_split(nblk, c.n_heads, c.balanced_wg[1] > 0 ? c.balanced_wg[1] : 256),
                              m->mb_opart, m->mb_mpart, m->mb_lpart, m->mb_attn_xp, c.sliding_window, c.kv_ring ? 1 : 0));
         MbGemm o{}; o.wp = L.wo; o.xp = m->mb_attn_xp; o.N = c.hidden; o.K = m->o_k; o.nblk = nblk; o.ksplit = m->o_ks;
         o.slabs = m->mb_slabs; o.slab_rows = npass_rows;
