@@ -113,6 +113,15 @@ static void resolve_cfg(la_llama* m) {
     m->o_ks = pick(c.gemm_cfg[3], auto_ks);
     m->down_rb = pick(c.gemm_cfg[4], 2);
     m->down_ks = pick(c.gemm_cfg[5], auto_ks);
+    // a K split shorter than 8 k-tiles starves the pipelines of the multi-block kernels (observed: a device fault at 4-5 tiles per
+    // split on the tiny test shape with 8 splits): step an oversized request down through the supported counts
+    auto fit_ks = [](int ks, int k16) {
+        static const int ok[] = {8, 6, 4, 3, 2, 1};
+        for (int v : ok) if (v <= ks && (v == 1 || k16 / v >= 8)) return v;
+        return 1;
+    };
+    m->o_ks = fit_ks(m->o_ks, m->o_k / 16);
+    m->down_ks = fit_ks(m->down_ks, c.ffn / 16);
     m->lm_rb = pick(c.gemm_cfg[6], 2);
     m->gu_variant = c.gemm_cfg[7];
     // qkv_ks == -1 in the config selects the unfused path (plain [Wq;Wk;Wv] packing + k_qkv_post)
