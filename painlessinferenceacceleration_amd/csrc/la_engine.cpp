@@ -113,11 +113,12 @@ static void resolve_cfg(la_llama* m) {
     m->o_ks = pick(c.gemm_cfg[3], auto_ks);
     m->down_rb = pick(c.gemm_cfg[4], 2);
     m->down_ks = pick(c.gemm_cfg[5], auto_ks);
-    // a K split shorter than 8 k-tiles starves the pipelines of the multi-block kernels (observed: a device fault at 4-5 tiles per
-    // split on the tiny test shape with 8 splits): step an oversized request down through the supported counts
+    // a K split of fewer than 4 k-tiles is outside what the slab kernels were exercised with (observed: a device fault on the tiny
+    // test shape, K = 256, with 8 splits = 2 tiles per split; 4 splits = 4 tiles run in every test): step an oversized request down
+    // through the supported counts
     auto fit_ks = [](int ks, int k16) {
         static const int ok[] = {8, 6, 4, 3, 2, 1};
-        for (int v : ok) if (v <= ks && (v == 1 || k16 / v >= 8)) return v;
+        for (int v : ok) if (v <= ks && (v == 1 || k16 / v >= 4)) return v;
         return 1;
     };
     m->o_ks = fit_ks(m->o_ks, m->o_k / 16);
