@@ -16,4 +16,5 @@ bench: build
 # regenerate the golden vectors from the reference (needs /root/reference; build container only)
 golden:
 	python oracle/gen_golden.py && python oracle/gen_golden_model.py && python oracle/gen_golden_batch.py && \
-	python oracle/gen_golden_moe.py && python oracle/gen_golden_processors.py && python oracle/gen_golden_mem.py
+	python oracle/gen_golden_moe.py && python oracle/gen_golden_processors.py && python oracle/gen_golden_mem.py && \
+	python oracle/gen_golden_noisy.py && python oracle/gen_golden_batch_processors.py
