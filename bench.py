@@ -230,6 +230,9 @@ def main():
         _check(_lalib.la_debug_set(7, int(os.environ['LA_PF_KIB'])), 'debug_set')
         _check(_lalib.la_debug_set(8, int(os.environ.get('LA_PF_DELAY', '0'))), 'debug_set')
         _check(_lalib.la_debug_set(9, int(os.environ.get('LA_PF_TAIL', '0'))), 'debug_set')
+    if os.environ.get('LA_MB_KS2') is not None:          # measurement: 2 K splits for the multi-block slab GEMMs at >= 5 blocks
+        from painlessinferenceacceleration_amd._lib import check as _check, lib as _lalib
+        _check(_lalib.la_debug_set(12, int(os.environ['LA_MB_KS2'])), 'debug_set')
 
     shape = {'7b': LlamaShape.llama2_7b, '13b': LlamaShape.llama2_13b, 'mistral': LlamaShape.mistral_7b,
              'mixtral': LlamaShape.mixtral_8x7b}[args.model]()

@@ -11,7 +11,7 @@
 #include <atomic>
 #include "la_kernels.h"
 #include "la_mblock.h"
-extern int g_la_pf_kib, g_la_pf_delay, g_la_pf_tail_kib, g_la_graph_epoch, g_la_graph_reps;
+extern int g_la_pf_kib, g_la_pf_delay, g_la_pf_tail_kib, g_la_graph_epoch, g_la_graph_reps, g_la_mb_ks2;
 
 extern void la_set_error(const std::string& s);
 
@@ -571,6 +571,10 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk) {
     if (!m->qkv_fused) { la_set_error("mstep needs the fused QKV image (gemm_cfg[1] >= 0)"); return LA_E_ARG; }
     const int M = nblk * 64;
     const int npass_rows = (nblk <= 2 ? nblk : ((nblk + 3) / 4) * 4) * 64;     // rows whole passes write (slab stride)
+    // la_debug_set key 12 (measurement, off by default): at >= 5 blocks the slab GEMMs of a dense model run 2 K splits over 4 token
+    // groups instead of 4 splits over 2 — the same 256 workgroups, half the fp32 partials written and read back by the row kernels
+    const bool ks2 = g_la_mb_ks2 && nblk >= 5 && c.n_experts == 0 && m->o_ks > 2 && m->down_ks > 2 && (c.hidden / 128) * 2 * 4 <= 256;
+    const int o_ks = ks2 ? 2 : m->o_ks, down_ks = ks2 ? 2 : m->down_ks;
     const int cf = c.norm_cast_first;
     KCHK(lk_mb_build_inputs(st, m->mb_in, m->bstate, nblk, m->mb_meta, m->mb_pos, m->mb_rowmask, m->mb_ids));
     KCHK(lk_mb_embed_norm(st, m->w.embed, m->mb_ids, m->layers[0].norm1, c.hidden, c.rms_eps, m->mb_h, m->mb_xp, M, cf));
@@ -585,7 +589,7 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk) {
         KCHK(lk_mb_tree_attn(st, m->mb_qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems, kf, vf,
                              m->mb_rowmask, m->mb_meta, nblk, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, mb_split(nblk, c.n_heads, c.balanced_wg[1] > 0 ? c.balanced_wg[1] : 256),
                              m->mb_opart, m->mb_mpart, m->mb_lpart, m->mb_attn_xp, c.sliding_window, c.kv_ring ? 1 : 0));
-        MbGemm o{}; o.wp = L.wo; o.xp = m->mb_attn_xp; o.N = c.hidden; o.K = m->o_k; o.nblk = nblk; o.ksplit = m->o_ks;
+        MbGemm o{}; o.wp = L.wo; o.xp = m->mb_attn_xp; o.N = c.hidden; o.K = m->o_k; o.nblk = nblk; o.ksplit = o_ks;
         o.slabs = m->mb_slabs; o.slab_rows = npass_rows;
         KCHK(lk_mb_gemm(st, 0, o));
         const void* nw = (l + 1 < c.n_layers) ? m->layers[l + 1].norm1 : m->w.final_norm;
@@ -618,14 +622,14 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk) {
             KCHK(lk_mb_resid_norm_addend(st, m->mb_h, m->mb_moe_acc, nw, c.hidden, c.rms_eps, m->mb_xp, M, cf));
             continue;
         }
-        KCHK(lk_mb_resid_norm(st, m->mb_h, m->mb_slabs, m->o_ks, npass_rows, L.norm2, c.hidden, c.rms_eps, m->mb_xp, M, cf));
+        KCHK(lk_mb_resid_norm(st, m->mb_h, m->mb_slabs, o_ks, npass_rows, L.norm2, c.hidden, c.rms_eps, m->mb_xp, M, cf));
         MbGemm g{}; g.wp = L.wgateup; g.xp = m->mb_xp; g.N = c.ffn; g.K = c.hidden; g.nblk = nblk; g.n_wg = c.balanced_wg[1]; g.ksplit = 1;
         g.act_xp = m->mb_act;
         KCHK(lk_mb_gemm(st, 1, g));
-        MbGemm d{}; d.wp = L.wdown; d.xp = m->mb_act; d.N = c.hidden; d.K = c.ffn; d.nblk = nblk; d.ksplit = m->down_ks;
+        MbGemm d{}; d.wp = L.wdown; d.xp = m->mb_act; d.N = c.hidden; d.K = c.ffn; d.nblk = nblk; d.ksplit = down_ks;
         d.slabs = m->mb_slabs; d.slab_rows = npass_rows;
         KCHK(lk_mb_gemm(st, 0, d));
-        KCHK(lk_mb_resid_norm(st, m->mb_h, m->mb_slabs, m->down_ks, npass_rows, nw, c.hidden, c.rms_eps, m->mb_xp, M, cf));
+        KCHK(lk_mb_resid_norm(st, m->mb_h, m->mb_slabs, down_ks, npass_rows, nw, c.hidden, c.rms_eps, m->mb_xp, M, cf));
     }
     const int lwg = lk_mb_logits_wgs(c.vocab, c.balanced_wg[2]);
     MbGemm h{}; h.wp = m->w.lm_head; h.xp = m->mb_xp; h.N = c.vocab; h.K = c.hidden; h.nblk = nblk; h.n_wg = c.balanced_wg[2]; h.ksplit = 1;

@@ -1422,6 +1422,7 @@ static bool g_mb_attr = false;
 int g_la_mb_dbg = 0;
 int g_la_mb_mode = 0;         // la_debug_set key 5: 1 = wide kernel as two co-resident workgroups per CU (80 KiB LDS, 256 rows each)
 int g_la_mb_pair = 1;         // la_debug_set key 6, bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too
+int g_la_mb_ks2 = 0;          // la_debug_set key 12: slab GEMMs of the multi-block step with 2 K splits at >= 5 blocks (measurement)
 int g_la_mb_narrow = 0;       // la_debug_set key 3: 1 = the K-split kernels (k_gemm_mb) for every nblk (A/B measurements)
 template <typename K> static hipError_t set_lds(K k, int bytes) {
     return hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1563,7 +1564,8 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                     p.nv[2] = a.nv[0]; p.nv[3] = a.nv[1]; p.nvl[2] = a.nvl[0]; p.nvl[3] = a.nvl[1];
                     p.wg_chunks = 2 * a.wg_chunks;
                 }
-                if (nblk <= 4) k_gemm_wide<4, 1, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 1) / 2), 512, WideGeom<4, 1>::LDS, st>>>(p);
+                // few K splits (<= 2, la_debug_set key 12): more token groups instead — 2 blocks per workgroup at every block count
+                if (nblk <= 4 || ksplit <= 2) k_gemm_wide<4, 1, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 1) / 2), 512, WideGeom<4, 1>::LDS, st>>>(p);
                 else if (g_la_mb_dbg == 4) k_gemm_wide<4, 2, EPI, 4><<<dim3(n_wg / 2, ksplit, (nblk + 3) / 4), 512, WideGeom<4, 2>::LDS, st>>>(p);   // measurement: no epilogue
                 else k_gemm_wide<4, 2, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 3) / 4), 512, WideGeom<4, 2>::LDS, st>>>(p);
                 LAUNCH_CHECK(); return 0;

@@ -97,7 +97,7 @@ def test_debug_knobs_roundtrip_and_defaults():
     """la_debug_set / la_debug_get: every knob reads back, out-of-range values are refused, and the library defaults are the
     documented ones (everything 0 except key 6 = 1, the paired wide launches, and key 11 = 1 step per graph)."""
     lib = _lib.lib
-    defaults = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0, 5: 0, 6: 1, 7: 0, 8: 0, 9: 0, 10: 0, 11: 1}
+    defaults = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0, 5: 0, 6: 1, 7: 0, 8: 0, 9: 0, 10: 0, 11: 1, 12: 0}
     for key, d in defaults.items():
         assert lib.la_debug_get(key) == d, key
     try:
