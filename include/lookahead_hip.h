@@ -58,7 +58,9 @@ const char*  la_last_error(void);
  *        results); key 8: start delay of those workgroups in s_sleep(32) rounds; key 9: KiB per down_proj workgroup pulled in from
  *        the tail of the gate/up launch (<= 64).  key 10: form of the tree-attention kernel, 0 = K/V tiles straight into the
  *        registers of both token-block waves, 1 = staged once per workgroup through LDS (LDS-DMA ring); bit-identical results.
- *        Keys 7-10 are read when a step graph is captured (la_llama_step captures again after a change). */
+ *        Keys 7-10 are read when a step graph is captured (la_llama_step captures again after a change).
+ * key 11: the single-sequence step captured n (1..8) times into one graph (measurement of the per-launch cost: none found).
+ * key 12: multi-block slab GEMMs with 2 K splits over 4 token groups at >= 5 blocks (measured slower; read at graph capture). */
 int          la_debug_set(int key, int value);
 int          la_debug_get(int key);          /* current value of a knob (the library default unless la_debug_set changed it) */
 /* key 0: device buffer int64[workgroups][waves][8] the GEMM kernels stamp with wall_clock64() at entry / end of the
