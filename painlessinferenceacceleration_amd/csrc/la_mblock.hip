@@ -1564,8 +1564,8 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                     p.nv[2] = a.nv[0]; p.nv[3] = a.nv[1]; p.nvl[2] = a.nvl[0]; p.nvl[3] = a.nvl[1];
                     p.wg_chunks = 2 * a.wg_chunks;
                 }
-                // few K splits (<= 2, la_debug_set key 12): more token groups instead — 2 blocks per workgroup at every block count
-                if (nblk <= 4 || ksplit <= 2) k_gemm_wide<4, 1, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 1) / 2), 512, WideGeom<4, 1>::LDS, st>>>(p);
+                // la_debug_set key 12 (slab launches with <= 2 K splits): more token groups instead — 2 blocks per workgroup at every block count
+                if (nblk <= 4 || (EPI == MB_SLAB && g_la_mb_ks2 && ksplit <= 2)) k_gemm_wide<4, 1, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 1) / 2), 512, WideGeom<4, 1>::LDS, st>>>(p);
                 else if (g_la_mb_dbg == 4) k_gemm_wide<4, 2, EPI, 4><<<dim3(n_wg / 2, ksplit, (nblk + 3) / 4), 512, WideGeom<4, 2>::LDS, st>>>(p);   // measurement: no epilogue
                 else k_gemm_wide<4, 2, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 3) / 4), 512, WideGeom<4, 2>::LDS, st>>>(p);
                 LAUNCH_CHECK(); return 0;
