@@ -284,24 +284,31 @@ struct la_cache {
         return v[pos];
     }
 
+    // rows: ancestor masks, row i at rows + i * words (one flat scratch buffer per thread: a query allocates nothing)
     struct Out {
-        int cap; int32_t* ids; int32_t* parent; std::vector<std::vector<uint64_t>>* rows; int n;
+        int cap; int32_t* ids; int32_t* parent; uint64_t* rows; int words; int n;
         int32_t sizes[2];
     };
+    struct Ent { int32_t node; double fm; };
 
     // _ravel (:248-293)
     void ravel(int32_t parent_node, int pid, int max_size, int max_length, const Thresholds& th, int mode,
                int32_t idx, Out& o) const {
         if (o.n >= max_size || max_length <= 0) return;
-        struct Ent { int32_t node; double fm; };
-        std::vector<Ent> sorts;
+        // the children of this level live on a per-thread stack shared by the whole recursion: [base, end) is this call's range
+        // (entries are read by value: deeper levels may grow the stack and move it)
+        static thread_local std::vector<Ent> stk;
+        const size_t base = stk.size();
         for (int32_t ch = nodes[parent_node].first_child; ch >= 0; ch = nodes[ch].next_sib) {
             const Node& nd = nodes[ch];
             double fm = (1.0 - th.output_weight) * get_fi(nd, idx) + th.output_weight * nd.fo;   // :254
-            sorts.push_back({ch, fm});
+            stk.push_back({ch, fm});
         }
-        std::stable_sort(sorts.begin(), sorts.end(), [](const Ent& a, const Ent& b) { return a.fm > b.fm; });
-        for (const Ent& e : sorts) {
+        const size_t end = stk.size();
+        std::stable_sort(stk.begin() + base, stk.begin() + end, [](const Ent& a, const Ent& b) { return a.fm > b.fm; });
+        struct Pop { std::vector<Ent>& v; size_t n; ~Pop() { v.resize(n); } } pop{stk, base};
+        for (size_t si = base; si < end; ++si) {
+            const Ent e = stk[si];
             if (o.n >= max_size) return;                                                         // :260
             const Node& nd = nodes[e.node];
             double fi = get_fi(nd, idx), fo = nd.fo;
@@ -317,8 +324,9 @@ struct la_cache {
             int rid = o.n++;
             o.ids[rid] = nd.token;
             o.parent[rid] = pid > -1 ? pid : 0;
-            std::vector<uint64_t>& row = (*o.rows)[rid];
-            if (pid > -1) row = (*o.rows)[pid]; else { std::fill(row.begin(), row.end(), 0); row[0] = 1; }
+            uint64_t* row = o.rows + (size_t)rid * o.words;
+            if (pid > -1) std::copy(o.rows + (size_t)pid * o.words, o.rows + (size_t)(pid + 1) * o.words, row);
+            else { std::fill(row, row + o.words, 0); row[0] = 1; }
             row[rid >> 6] |= 1ull << (rid & 63);
             if (nd.first_child >= 0)
                 ravel(e.node, rid, max_size, max_length - 1, th, mode, idx, o);
@@ -353,7 +361,7 @@ struct la_cache {
         o.n = 0; o.sizes[0] = o.sizes[1] = 0;
         auto single = [&](int32_t token) {
             o.ids[0] = token; o.parent[0] = -1;
-            std::fill((*o.rows)[0].begin(), (*o.rows)[0].end(), 0); (*o.rows)[0][0] = 1;
+            std::fill(o.rows, o.rows + o.words, 0); o.rows[0] = 1;
             o.n = 1;
             return 1;
         };
@@ -553,10 +561,10 @@ int la_cache_stream_put(la_cache* c, const int32_t* toks, int n, int branch_leng
 
 static void emit(const la_cache::Out& o, int n, uint64_t* out_rowmask, int64_t* out_mask) {
     if (out_rowmask && n <= 64)
-        for (int i = 0; i < n; ++i) out_rowmask[i] = (*o.rows)[i][0];
+        for (int i = 0; i < n; ++i) out_rowmask[i] = o.rows[(size_t)i * o.words];
     if (out_mask)
         for (int i = 0; i < n; ++i)
-            for (int j = 0; j < n; ++j) out_mask[(size_t)i * n + j] = ((*o.rows)[i][j >> 6] >> (j & 63)) & 1ull;
+            for (int j = 0; j < n; ++j) out_mask[(size_t)i * n + j] = (o.rows[(size_t)i * o.words + (j >> 6)] >> (j & 63)) & 1ull;
 }
 
 int la_cache_hier_get(la_cache* c, const int32_t* q, int nq, int decoding_length, int branch_length,
@@ -566,8 +574,8 @@ int la_cache_hier_get(la_cache* c, const int32_t* q, int nq, int decoding_length
     if (!c || nq < 0 || (nq > 0 && !q) || !out_ids || !out_parent || !out_sizes || !out_nsizes || !out_n || cap < 1)
         return LA_E_ARG;
     if (mode < 0 || mode > 2) { la_set_error("hier_get: bad mode"); return LA_E_ARG; }
-    std::vector<std::vector<uint64_t>> rows;
-    la_cache::Out o{cap, out_ids, out_parent, &rows, 0, {0, 0}};
+    static thread_local std::vector<uint64_t> rows;                 // [decoding_length][words], reused by every query of the thread
+    la_cache::Out o{cap, out_ids, out_parent, nullptr, 0, 0, {0, 0}};
     auto fallback_last = [&](int nsizes) {                          // token_ids[-1:], default_mask
         *out_nsizes = nsizes; out_sizes[0] = out_sizes[1] = 0;
         if (nq == 0) { *out_n = 0; return LA_OK; }
@@ -578,7 +586,9 @@ int la_cache_hier_get(la_cache* c, const int32_t* q, int nq, int decoding_length
     };
     if (decoding_length <= 1 || branch_length == 0) return fallback_last(0);    // :413-414
     if (decoding_length > cap) { la_set_error("hier_get: decoding_length exceeds output capacity"); return LA_E_RANGE; }
-    rows.assign((size_t)decoding_length, std::vector<uint64_t>((size_t)(decoding_length + 63) / 64, 0));
+    o.words = (decoding_length + 63) / 64;
+    rows.assign((size_t)decoding_length * o.words, 0);
+    o.rows = rows.data();
     bool have = false;
     int n_out = 0;
     for (int i = 0; i < nq; ++i) {
