@@ -4,11 +4,12 @@ set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="${1:-$HERE/../liblookahead_hip.so}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
-mkdir -p "$HERE/_obj"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -amdgpu-kernarg-preload-count=16 ${LA_EXTRA_HIPCC_FLAGS:-}"
+OBJ="${LA_OBJ_DIR:-$HERE/_obj}"
+mkdir -p "$OBJ"
 pids=()
 for f in la_kernels.hip la_mblock.hip la_trie_dev.hip la_engine.cpp la_abi.cpp la_trie.cpp la_comm.cpp; do
-  o="$HERE/_obj/${f%.*}.o"
+  o="$OBJ/${f%.*}.o"
   if [ ! -f "$o" ] || [ "$HERE/$f" -nt "$o" ] || [ "$HERE/la_common.h" -nt "$o" ] || [ "$HERE/la_kernels.h" -nt "$o" ] || [ "$HERE/la_mblock.h" -nt "$o" ] \
      || [ "$HERE/../../include/lookahead_hip.h" -nt "$o" ]; then
     ( $HIPCC $FLAGS -x hip -c "$HERE/$f" -o "$o" ) &
@@ -16,5 +17,5 @@ for f in la_kernels.hip la_mblock.hip la_trie_dev.hip la_engine.cpp la_abi.cpp l
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/_obj/la_kernels.o "$HERE"/_obj/la_mblock.o "$HERE"/_obj/la_trie_dev.o "$HERE"/_obj/la_engine.o "$HERE"/_obj/la_abi.o "$HERE"/_obj/la_trie.o "$HERE"/_obj/la_comm.o -ldl
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/la_kernels.o "$OBJ"/la_mblock.o "$OBJ"/la_trie_dev.o "$OBJ"/la_engine.o "$OBJ"/la_abi.o "$OBJ"/la_trie.o "$OBJ"/la_comm.o -ldl
 echo "built $OUT"

@@ -13,6 +13,7 @@ Product use: pretrained_model_batch.lookahead_generation(decoding_kwargs={'devic
 active samples with one launch here instead of one host query per sample.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -32,6 +33,15 @@ class DeviceTrie(object):
         self.cache = cache
         self.idxs = [int(i) for i in (idxs if idxs is not None else [0 if idx is None else idx])]
         self.plane = {v: k for k, v in enumerate(self.idxs)}
+        # la_cache_mirror_enable REPLACES the cache's mirror: an older DeviceTrie on the same cache would apply its next patch
+        # to the wrong image.  One live owner per cache: the previous one is revoked and raises on its next use.
+        prev = getattr(cache, '_mirror_owner', None)
+        if prev is not None and prev() is not None:
+            prev()._revoked = True
+        self._revoked = False
+        cache._mirror_owner = weakref.ref(self)
+        self._h2d_done = torch.cuda.Event()
+        self._h2d_pending = False
         arr = np.asarray(self.idxs, dtype=np.int32)
         check(lib.la_cache_mirror_enable(cache._h, arr.ctypes.data_as(_lib.pi32), len(self.idxs)), 'mirror_enable')
         self.cap = 0
@@ -76,9 +86,26 @@ class DeviceTrie(object):
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _check_owner(self):
+        if self._revoked:
+            raise RuntimeError('this DeviceTrie was superseded by a newer mirror of the same LookaheadCache')
+
+    def _staging_free(self):
+        """The pinned staging buffers are rewritten by the host on every call: wait until the H2D copies queued from them by
+        the previous call have been executed (an event behind the last copy; microseconds, normally already signalled)."""
+        if self._h2d_pending:
+            self._h2d_done.synchronize()
+            self._h2d_pending = False
+
+    def _staging_queued(self):
+        self._h2d_done.record(torch.cuda.current_stream(self.device))
+        self._h2d_pending = True
+
     def sync(self):
         """Bring the device image up to date with the host trie (patch, or full image when due).  Enqueued on the current
         stream; returns the kind of sync that happened."""
+        self._check_owner()
+        self._staging_free()
         n, full, ni, nd = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         check(lib.la_cache_mirror_state(self.cache._h, C.byref(n), C.byref(full), C.byref(ni), C.byref(nd)), 'mirror_state')
         self.stop_words = [int(x) for x in self.cache.stop_words]
@@ -99,6 +126,7 @@ class DeviceTrie(object):
                 self.fi[p * self.cap:p * self.cap + k].copy_(self._h_fi[p * self.cap:p * self.cap + k], non_blocking=True)
             self.n_records = k
             self.stats['full_uploads'] += 1
+            self._staging_queued()
             return 'full'
         self.n_records = n.value
         if ni.value == 0 and nd.value == 0:
@@ -120,6 +148,7 @@ class DeviceTrie(object):
         check(lib.la_trie_patch_dev(self._stream(), self.tok.data_ptr(), self.fo.data_ptr(), self.fi.data_ptr(), self.cap,
                                     self.cstart.data_ptr(), self.ccount.data_ptr(), self._d_pi.data_ptr(), ni.value,
                                     self._d_pi.data_ptr() + 4 * 3 * ni.value, self._d_pd.data_ptr(), nd.value), 'trie_patch_dev')
+        self._staging_queued()
         self.stats['patches'] += 1
         self.stats['patch_words'] += ni.value + nd.value
         return 'patch'
@@ -132,9 +161,11 @@ class DeviceTrie(object):
         query (default: the first mirrored slot); branch_lengths: per-query branch length (default: branch_length)."""
         assert mode in _MODES and decoding_length <= _lib.LA_TREE_MAX
         B = len(queries)
+        self._check_owner()
         self._alloc_queries(B)
         if sync:
             self.sync()
+        self._staging_free()
         h = self._hq.numpy()
         q = h[:B * 8].reshape(B, 8)
         q[:] = 0
@@ -145,6 +176,7 @@ class DeviceTrie(object):
             h[B * 9 + b] = self.plane[int(idxs[b])] if idxs is not None else 0
             h[B * 10 + b] = int(branch_lengths[b]) if branch_lengths is not None else int(branch_length)
         self._dq[:B * 11].copy_(self._hq[:B * 11], non_blocking=True)
+        self._staging_queued()
         if self._scratch is None or self._scratch[0].numel() < B * self.cap:
             self._scratch = (torch.empty(B * self.cap, dtype=torch.int32, device=self.device),
                              torch.empty(B * 2 * self.cap, dtype=torch.float64, device=self.device))

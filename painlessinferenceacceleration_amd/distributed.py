@@ -87,22 +87,41 @@ class AcceptedTokenGather(object):
                       'accepted-token gather falls back to torch.distributed.all_gather_into_tensor')
 
     def _init_native(self):
-        idbuf = torch.zeros(128, dtype=torch.uint8)
+        # 128 id bytes + 1 "rank 0 has an id" flag.  Rank 0 ALWAYS takes part in the broadcast, also when it could not make an
+        # id (librccl missing): every rank must run the same collectives before the agreement all-reduce, or the others
+        # would sit in the broadcast while rank 0 is already in the all-reduce.
+        idbuf = torch.zeros(129, dtype=torch.uint8)
+        id_err = None
         if self.rank == 0:
-            arr = (C.c_uint8 * 128)()
-            check(lib.la_comm_unique_id(arr), 'comm_unique_id')
-            idbuf = torch.tensor(list(arr), dtype=torch.uint8)
+            try:
+                arr = (C.c_uint8 * 128)()
+                check(lib.la_comm_unique_id(arr), 'comm_unique_id')
+                idbuf[:128] = torch.tensor(list(arr), dtype=torch.uint8)
+                idbuf[128] = 1
+            except Exception as e:                  # noqa: BLE001 - reported after the broadcast
+                id_err = e
         if not self.local_only:
             t = idbuf.to(self.device) if dist.get_backend(self.group) == 'nccl' else idbuf
             dist.broadcast(t, src=0, group=self.group)
             idbuf = t.cpu()
-        arr = (C.c_uint8 * 128)(*idbuf.tolist())
+        if id_err is not None:
+            raise id_err
+        if int(idbuf[128]) != 1:
+            raise _lib.LookaheadHipError('rank 0 could not create an RCCL unique id')
+        arr = (C.c_uint8 * 128)(*idbuf[:128].tolist())
         torch.cuda.set_device(self.device)
         self._comm = lib.la_comm_create(arr, self.world, self.rank)
         if not self._comm:
             raise _lib.LookaheadHipError(f'la_comm_create: {_lib.last_error()}')
         self._stream = torch.cuda.Stream(self.device)
         self._done = torch.cuda.Event()
+
+    @property
+    def transport(self):
+        """which code path the all-gather runs through (recorded by bench.py as config.gather_transport)"""
+        if self.local_only:
+            return 'none (single process)'
+        return 'la_gather_accepted(rccl)' if self._comm else f'torch.distributed({dist.get_backend(self.group)})'
 
     def __del__(self):
         if getattr(self, '_comm', None):

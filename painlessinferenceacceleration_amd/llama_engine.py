@@ -114,7 +114,10 @@ def load_hf_checkpoint(model_dir):
     from transformers import AutoConfig
     cfg = AutoConfig.from_pretrained(model_dir)
     sd = {}
-    st_files = sorted(glob.glob(os.path.join(model_dir, '*.safetensors')))
+    # consolidated*.safetensors (Mistral / Mixtral repos ship them NEXT to the HF shards, under other key names) would double
+    # the host memory and leave keys nobody consumes
+    st_files = sorted(f for f in glob.glob(os.path.join(model_dir, '*.safetensors'))
+                      if not os.path.basename(f).startswith('consolidated'))
     idx = os.path.join(model_dir, 'model.safetensors.index.json')
     if os.path.exists(idx):
         names = sorted(set(json.load(open(idx))['weight_map'].values()))
@@ -216,7 +219,7 @@ class LlamaVerifyEngine(object):
             win = int(getattr(shape, 'sliding_window', 0))
             assert win > 0, 'kv_ring needs shape.sliding_window > 0'
             self.max_keys = int(math.ceil((win + 64 * max(int(max_blocks), 1) + 64) / 32.0)) * 32
-            self.max_pos = max_length + 64 + 64 + 1
+            self.max_pos = max_length + 64 + 64 + 2      # _capacity() = max_length + 65, as the linear cache admits
         else:
             self.max_keys = int(math.ceil((max_length + 64 + 1) / 32.0)) * 32
             self.max_pos = self.max_keys + 64
