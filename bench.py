@@ -94,7 +94,42 @@ def _pf_setting():
     return int(lib.la_debug_get(7)), int(lib.la_debug_get(8)), int(lib.la_debug_get(9))
 
 
-def secondary_legs(spec):
+_RDZV_KEYS = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'GROUP_WORLD_SIZE', 'ROLE_RANK', 'ROLE_WORLD_SIZE',
+              'ROLE_NAME', 'MASTER_ADDR', 'MASTER_PORT', 'TORCHELASTIC_RESTART_COUNT', 'TORCHELASTIC_MAX_RESTARTS',
+              'TORCHELASTIC_RUN_ID', 'TORCHELASTIC_USE_AGENT_STORE', 'TORCHELASTIC_ERROR_FILE', 'TORCH_NCCL_ASYNC_ERROR_HANDLING')
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def self_launch_cmd(argv, n, port):
+    """The command `python bench.py --gpus N ...` turns itself into when no rank environment is present: one process per GPU
+    under torch.distributed.run on this node (the shape of the driver's own N > 1 launch), rendezvous on 127.0.0.1."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={int(n)}', '--master-addr', '127.0.0.1',
+            '--master-port', str(int(port)), os.path.abspath(__file__)] + [str(a) for a in argv]
+
+
+def clean_rank_env(env=None):
+    """environment for a fresh N-rank job started from inside (or outside) another one: no inherited rank / rendezvous variables"""
+    env = dict(os.environ if env is None else env)
+    for k in _RDZV_KEYS:
+        env.pop(k, None)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return env
+
+
+def self_launch(args_gpus, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE: spawn the N ranks ourselves; rank 0's single JSON line is the child's stdout."""
+    import subprocess
+    r = subprocess.run(self_launch_cmd(argv, args_gpus, _free_port()), env=clean_rank_env())
+    sys.exit(r.returncode)
+
+
+def secondary_legs(spec, gpus=1):
     """The batch configurations (BASELINE configs 3-5) as secondary lines of the default run: each `model:batch` leg is this script
     run again in its own process (`--model M --batch B`, 24 timed steps, no CPU leg) after the headline's timed region; the
     fields a reader needs are kept.  A leg that fails is reported as such — it never touches the headline line."""
@@ -105,13 +140,13 @@ def secondary_legs(spec):
         if not item:
             continue
         model, batch = item.split(':')
-        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--model', model, '--batch', batch, '--steps', '24',
-               '--warmup', '4', '--no-cpu-baseline']
-        env = dict(os.environ)
+        leg_args = ['--gpus', str(gpus), '--model', model, '--batch', batch, '--steps', '24', '--warmup', '4', '--no-cpu-baseline']
+        cmd = [sys.executable, os.path.abspath(__file__)] + leg_args if gpus == 1 else self_launch_cmd(leg_args, gpus, _free_port())
+        env = clean_rank_env()
         env['BENCH_IS_SECONDARY'] = '1'
         t0 = time.time()
         try:
-            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420 if gpus == 1 else 900)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
             if r.returncode != 0 or not line:
                 legs.append({'model': model, 'batch': int(batch), 'error': (r.stderr or r.stdout)[-300:], 'wall_s': round(time.time() - t0, 1)})
@@ -122,8 +157,10 @@ def secondary_legs(spec):
                          'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'warmup': j['warmup'], 'sequences': c['sequences'],
                          'mean_accept_len': c['mean_accept_len'], 'mean_draft_len': c['mean_draft_len'], 'kv_cache': c['kv_cache'],
                          'lookahead_equals_greedy': c['lookahead_equals_greedy'], 'context_at_end': c['context_at_end'],
+                         'n_gpus': j['n_gpus'], 'gather_mode': c.get('gather_mode'), 'gather_transport': c.get('gather_transport'),
+                         'rccl_ranks': c.get('rccl_ranks'),
                          'roofline': j.get('roofline'), 'wall_s': round(time.time() - t0, 1),
-                         'command': 'python bench.py --model %s --batch %s --steps 24 --warmup 4 --no-cpu-baseline' % (model, batch)})
+                         'command': 'python bench.py --gpus %d --model %s --batch %s --steps 24 --warmup 4 --no-cpu-baseline' % (gpus, model, batch)})
         except Exception as e:           # noqa: BLE001 — a secondary leg must never take the headline line down
             legs.append({'model': model, 'batch': int(batch), 'error': repr(e)[:300], 'wall_s': round(time.time() - t0, 1)})
     return legs
@@ -196,7 +233,13 @@ def main():
                     help='N=1 default workload only: comma list of model:batch legs (BASELINE configs 3-5: a 64-token tree per sequence '
                          'through la_llama_mstep) run AFTER the timed region, each in its own process; their lines are embedded under '
                          '"secondary".  "" = none')
+    ap.add_argument('--secondary-multi', default=None,
+                    help='N > 1 default workload only: model:batch legs run as their own N-rank jobs after the headline (default: '
+                         '"13b:4" at --gpus 8 = BASELINE config 4, Llama-2-13B bs=32 batch-sharded over 8 GPUs; "" = none)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
+        self_launch(args.gpus, sys.argv[1:])          # does not return
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -230,6 +273,11 @@ def main():
         _check(_lalib.la_debug_set(7, int(os.environ['LA_PF_KIB'])), 'debug_set')
         _check(_lalib.la_debug_set(8, int(os.environ.get('LA_PF_DELAY', '0'))), 'debug_set')
         _check(_lalib.la_debug_set(9, int(os.environ.get('LA_PF_TAIL', '0'))), 'debug_set')
+    if os.environ.get('LA_DEBUG'):                       # measurement: any la_debug_set keys, "k=v,k=v" (scripts/gpu_knob_sweep.sh)
+        from painlessinferenceacceleration_amd._lib import lib as _lalib, check as _check
+        for kv in os.environ['LA_DEBUG'].split(','):
+            k, v = kv.split('=')
+            _check(_lalib.la_debug_set(int(k), int(v)), 'debug_set')
     if os.environ.get('LA_MB_KS2') is not None:          # measurement: 2 K splits for the multi-block slab GEMMs at >= 5 blocks
         from painlessinferenceacceleration_amd._lib import check as _check, lib as _lalib
         _check(_lalib.la_debug_set(12, int(os.environ['LA_MB_KS2'])), 'debug_set')
@@ -511,9 +559,19 @@ def main():
     cpu = None
     if want_cpu:
         cpu = cpu_baseline_loop(shape, sd_cpu, prompts[0], copies0, BL, DL, verify_steps=args.cpu_steps)
+    gather_transport = gather.transport if gather is not None else None
+    rccl_ranks = world if (gather_transport is not None and ('rccl' in gather_transport or 'nccl' in gather_transport)) else 0
+    if dist_on:                      # the job's collectives are over: leave the group before any follow-up job is started
+        dist.barrier()
+        dist.destroy_process_group()
     secondary = None
     if world == 1 and B == 1 and args.model == '7b' and not args.layers and args.secondary and not os.environ.get('BENCH_IS_SECONDARY'):
         secondary = secondary_legs(args.secondary)
+    multi = args.secondary_multi if args.secondary_multi is not None else ('13b:4' if world == 8 else '')
+    if world > 1 and B == 1 and args.model == '7b' and not args.layers and multi and not os.environ.get('BENCH_IS_SECONDARY'):
+        # BASELINE config 4 (and any other listed leg) as its own N-rank job on the same GPUs: the other ranks of this job have
+        # left the group and are exiting; 288 GB per GPU hold both models, so nothing has to be freed first
+        secondary = secondary_legs(multi, gpus=world)
     gen = accepted_all / max(world, 1)
     out = {
         'metric': 'accepted_tokens_per_sec', 'value': round(accepted_all / elapsed, 2), 'unit': 'tokens/s',
@@ -526,6 +584,7 @@ def main():
                    'parallelism': f'batch-shard x{world}, {B} sequence(s) per GPU', 'sequences': NSEQ,
                    'kv_cache': (f'ring of {eng.shape.sliding_window} + one step of rows per sequence (sliding window)' if kv_ring else 'linear, max_length keys per sequence'),
                    'gather_mode': None if not dist_on else ('strict' if args.strict_gather else 'split-phase'),
+                   'gather_transport': gather_transport, 'rccl_ranks': rccl_ranks,
                    'draft_retrieval': 'device trie (incremental mirror, one launch per step)' if dev_trie is not None else 'host trie',
                    'device_trie_stats': dev_trie.stats if dev_trie is not None else None,
                    'mean_accept_len': round(mean_acc, 3), 'mean_draft_len': round(mean_T, 2),
@@ -545,10 +604,7 @@ def main():
     }
     if secondary is not None:
         out['secondary'] = secondary
-    print(json.dumps(out))
-    if dist_on:
-        dist.barrier()
-        dist.destroy_process_group()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

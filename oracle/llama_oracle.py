@@ -159,21 +159,29 @@ def parents_from_mask(mask):
     return par
 
 
+def _live_children(ids, par, live, want):
+    """Rows whose parent is a live row and whose draft token is `want`, ascending.  The reference keeps EVERY leaf branch whose
+    token at the current depth equals the picked token (pretrained_model.py:850-860) and reads the next logits row from the
+    first of them (mask_indices[0], :831).  In a hier tree the survivors share one node per depth, so this is "the child of
+    the current row"; in a par layout (lookahead_cache.py:441-488) a shared prefix is duplicated across chains, all copies
+    stay live, and the walk may continue on a later chain when the first one stops matching."""
+    return [j for j in range(1, len(ids)) if par[j] in live and int(ids[j]) == want]
+
+
 def accept_scan(ids, mask, argmax_rows):
     """ids: list[T] (ids[0] = root), mask: [T,T] 0/1, argmax_rows[t] = greedy token after tree row t.
     -> (next_token_list, logit_indices).  Restates pretrained_model.py:806-864: starting at the root, follow
-    the child whose draft token equals the current row's argmax (first such row in DFS order) until none does;
-    the emitted tokens are the argmax of every visited row (matches + 1 bonus)."""
-    T = len(ids)
+    the rows whose draft token equals the current row's argmax (first such row in DFS order supplies the next logits) until
+    none does; the emitted tokens are the argmax of every visited row (matches + 1 bonus)."""
     par = parents_from_mask(np.asarray(mask))
-    cur, toks, rows = 0, [], [0]
+    cur, live, toks, rows = 0, {0}, [], [0]
     while True:
         want = int(argmax_rows[cur])
         toks.append(want)
-        nxt = next((j for j in range(1, T) if par[j] == cur and int(ids[j]) == want), None)
-        if nxt is None:
+        nxt = _live_children(ids, par, live, want)
+        if not nxt:
             break
-        cur = nxt
+        cur, live = nxt[0], set(nxt)
         rows.append(cur)
     return toks, rows
 
@@ -194,19 +202,18 @@ def accept_scan_sequential(ids, mask, logits, seq, logits_processor, limit=None)
     """The accept walk with a logits-processor list (pretrained_model.py:825-864): the processors see the sequence
     INCLUDING the tokens accepted so far in this step, so rows are evaluated one after another along the path.
     limit (batch twin, pretrained_model_batch.py:862): at most this many tokens are emitted."""
-    T = len(ids)
     par = parents_from_mask(np.asarray(mask))
-    cur, toks, rows = 0, [], [0]
+    cur, live, toks, rows = 0, {0}, [], [0]
     while True:
         ctx = torch.tensor([list(seq) + toks], dtype=torch.long)
         want = int(torch.argmax(logits_processor(ctx, logits[cur][None].clone()), dim=-1)[0])
         toks.append(want)
         if limit is not None and len(toks) >= limit:
             break
-        nxt = next((j for j in range(1, T) if par[j] == cur and int(ids[j]) == want), None)
-        if nxt is None:
+        nxt = _live_children(ids, par, live, want)
+        if not nxt:
             break
-        cur = nxt
+        cur, live = nxt[0], set(nxt)
         rows.append(cur)
     return toks, rows
 

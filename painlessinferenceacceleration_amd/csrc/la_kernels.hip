@@ -1475,14 +1475,20 @@ __global__ void k_accept_scan(const int* __restrict__ ids, const unsigned long l
         const unsigned long long below = rm & ((1ull << j) - 1ull);
         const int parent = (j == 0 || below == 0ull) ? -1 : 63 - __clzll(below);
         const int myid = ids[j];
+        // live = the rows whose root path spells the tokens accepted so far.  A hier tree has one such row per depth (trie
+        // children carry distinct tokens), i.e. "the child of cur"; a par layout (lookahead_cache.py:441-488) repeats a shared
+        // prefix in every chain, all copies stay live, and the lowest row — the reference's first surviving leaf branch,
+        // mask_indices[0] at pretrained_model.py:831 — supplies the next logits row and the kept K/V row.
         int cur = 0, depth = 0;
+        unsigned long long live = 1ull;
         if (j == 0) { state[LA_ST_SRCIDX] = 0; }
         while (true) {
             const int want = __shfl(am, cur, 64);
             if (j == 0) state[LA_ST_OUTTOK + depth] = want;
-            const unsigned long long cand = __ballot(j < T && j > 0 && parent == cur && myid == want);
+            const unsigned long long cand = __ballot(j < T && j > 0 && parent >= 0 && ((live >> parent) & 1ull) != 0ull && myid == want);
             if (cand == 0ull) break;
             cur = __ffsll((long long)cand) - 1;
+            live = cand;
             ++depth;
             if (j == 0) state[LA_ST_SRCIDX + depth] = cur;
         }

@@ -35,6 +35,31 @@ def _max_length_of(stopping_criteria, max_length):
     return None if ml is None else int(ml)
 
 
+def _custom_stop(stopping_criteria):
+    """The user's criteria besides MaxLengthCriteria as one predicate stop(token_row) -> bool, or None when there are none.
+    The reference evaluates `stopping_criteria(input_ids, scores)` after every verify step (pretrained_model.py:1225-1226;
+    batch: once per sample on input_ids[i:i+1, :cur+1], pretrained_model_batch.py:1284); scores is None / empty on this
+    path.  The length criterion itself is the `len(seq) >= max_length` test of the loops."""
+    if stopping_criteria is None or isinstance(stopping_criteria, int) or not callable(stopping_criteria):
+        return None
+    try:
+        crit = list(stopping_criteria)
+    except TypeError:
+        crit = [stopping_criteria]
+    crit = [c for c in crit if type(c).__name__ != 'MaxLengthCriteria']
+    if not crit:
+        return None
+
+    def stop(token_row, device='cpu'):
+        ids = torch.tensor([list(token_row)], dtype=torch.long, device=device)
+        for c in crit:
+            r = c(ids, None)
+            if bool(r.any()) if torch.is_tensor(r) else bool(r):
+                return True
+        return False
+    return stop
+
+
 class LookaheadPreTrainedModel(object):
     """Mixin over an object that owns `self.engine` (LlamaVerifyEngine) and optionally `self.lookahead_cache`."""
 
@@ -162,7 +187,9 @@ class LookaheadPreTrainedModel(object):
         dm = dm + '_mix' if dm in ('hier', 'par', 'one') else dm
         native_mode = {'input': 0, 'output': 1, 'mix': 2}.get(dm.split('_')[1], 2)
         max_query_length = int(decoding_kwargs.get('max_query_length', 2))
+        custom_stop = _custom_stop(stopping_criteria)      # user StoppingCriteria: evaluated per step, interpreter loop only
         native_loop = (not sequential and streamer is None and dm.split('_')[0] == 'hier' and decoding_length <= 64
+                       and custom_stop is None
                        and not decoding_kwargs.get('device_trie', False)
                        and not decoding_kwargs.get('debug_lookahead', False) and decoding_kwargs.get('native_loop', True)
                        and 1 <= max_query_length <= 8          # la_lookahead_decode's query buffer; longer queries use this loop
@@ -197,14 +224,17 @@ class LookaheadPreTrainedModel(object):
                         for j in range(1, T):
                             below = int(rowmask[j]) & ((1 << j) - 1)
                             parent[j] = below.bit_length() - 1
-                        cur, rows, next_tokens = 0, [0], []
+                        # every row whose parent is live and whose token was picked stays live; the first one supplies the
+                        # next logits row (the reference's surviving leaf branches, pretrained_model.py:831, 850-860: in a
+                        # par layout a shared prefix is duplicated across chains and the walk may move to a later chain)
+                        cur, live, rows, next_tokens = 0, {0}, [0], []
                         while True:
                             t = pick(seq + next_tokens, cur)
                             next_tokens.append(t)
-                            nxt = next((j for j in range(1, T) if parent[j] == cur and int(ids[j]) == t), None)
-                            if nxt is None:
+                            nxt = [j for j in range(1, T) if parent[j] in live and int(ids[j]) == t]
+                            if not nxt:
                                 break
-                            cur = nxt
+                            cur, live = nxt[0], set(nxt)
                             rows.append(cur)
                         eng.commit(rows)
                     else:
@@ -222,7 +252,8 @@ class LookaheadPreTrainedModel(object):
                     streamer.put(np.array([next_tokens]))
                 self.lookahead_cache.stream_put(next_tokens, branch_length=branch_length + 1, final=False,
                                                 mode='output', idx=0)
-                finished = len(seq) >= stop_max_length or any(t in eos_set for t in next_tokens)
+                finished = len(seq) >= stop_max_length or any(t in eos_set for t in next_tokens) or \
+                    (custom_stop is not None and custom_stop(seq, out_device))                   # :1225-1231
                 te = time.time()
                 decoding_kwargs['fts'].append(te - ts)
                 ts = te

@@ -23,7 +23,7 @@ import torch
 from . import _lib
 from .lookahead_cache import LookaheadCache
 from .lookahead_generation_utils import LookaheadDecoderOnlyOutput
-from .pretrained_model import _max_length_of
+from .pretrained_model import _custom_stop, _max_length_of
 
 _ONE = np.array([1], dtype=np.uint64)
 
@@ -124,6 +124,7 @@ class LookaheadPreTrainedModel(object):
         stop_max_length = _max_length_of(stopping_criteria, max_length)
         if stop_max_length is None:
             raise ValueError('lookahead_generation needs a MaxLengthCriteria (stopping_criteria.max_length)')
+        custom_stop = _custom_stop(stopping_criteria)
         decoding_length = decoding_kwargs.get('decoding_length', 63)
         decoding_kwargs['max_length'] = stop_max_length
         decoding_kwargs['decoding_max_length'] = stop_max_length + decoding_length + 1
@@ -196,7 +197,8 @@ class LookaheadPreTrainedModel(object):
             max_cur = max(max_cur, max(len(rows[b]) - 1 for b in batch_indices))
             keep = []
             for k, b in enumerate(batch_indices):                               # :1269-1276 + _early_stop :937-980
-                if len(rows[b]) >= stop_max_length or any(t in eos_set for t in next_token_list[k]):
+                if len(rows[b]) >= stop_max_length or any(t in eos_set for t in next_token_list[k]) or \
+                        (custom_stop is not None and custom_stop(rows[b], out_device)):                # :1284
                     finished_rows[b] = list(rows[b])
                 else:
                     keep.append(b)

@@ -76,3 +76,44 @@ def test_committed_pmc_summary_is_what_bench_reads():
     s7 = LlamaShape.llama2_7b()
     algorithmic = 2 * s7.ffn * s7.hidden * 2 + 64 * s7.hidden * 2 + 64 * s7.ffn * 2
     assert algorithmic <= e['hbm_bytes_per_launch'] <= 1.10 * algorithmic      # nothing is re-read from HBM
+
+
+def test_self_launch_command_and_clean_environment(monkeypatch):
+    """`python bench.py --gpus N` without rank variables re-executes itself under torch.distributed.run (one process per GPU,
+    rendezvous on 127.0.0.1) — the shape of the driver's own N > 1 launch; a follow-up job started from inside a rank must not
+    inherit that rank's rendezvous variables."""
+    import sys
+    import bench
+    cmd = bench.self_launch_cmd(['--gpus', '8', '--steps', '5'], 8, 29511)
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert '--nnodes=1' in cmd and '--nproc-per-node=8' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[cmd.index('--master-port') + 1] == '29511'
+    assert cmd[-4:] == ['--gpus', '8', '--steps', '5'] and cmd[-5].endswith('bench.py')
+    monkeypatch.setenv('RANK', '3'); monkeypatch.setenv('WORLD_SIZE', '8'); monkeypatch.setenv('MASTER_PORT', '1')
+    env = bench.clean_rank_env()
+    assert not any(k in env for k in ('RANK', 'WORLD_SIZE', 'MASTER_PORT', 'LOCAL_RANK'))
+    assert env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    p = bench._free_port()
+    assert 1024 < p < 65536
+
+
+def test_self_launch_runs_two_gloo_ranks_end_to_end(tmp_path):
+    """The self-launch path itself, on CPU: a stub 'bench' with the same launcher spawns 2 ranks through torch.distributed.run,
+    they form a gloo group on 127.0.0.1 and rank 0 prints ONE line."""
+    import subprocess
+    import sys
+    import bench
+    stub = tmp_path / 'stub.py'
+    stub.write_text(
+        "import os, json, torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "import torch\n"
+        "t = torch.tensor([dist.get_rank() + 1]); dist.all_reduce(t)\n"
+        "if dist.get_rank() == 0: print(json.dumps({'world': dist.get_world_size(), 'sum': int(t)}), flush=True)\n"
+        "dist.barrier(); dist.destroy_process_group()\n")
+    cmd = bench.self_launch_cmd([], 2, bench._free_port())
+    cmd[cmd.index(os.path.abspath(bench.__file__))] = str(stub)
+    r = subprocess.run(cmd, env=bench.clean_rank_env(), capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and json.loads(lines[0]) == {'world': 2, 'sum': 3}

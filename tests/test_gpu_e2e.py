@@ -465,13 +465,15 @@ def test_native_decode_loop_equals_python_loop():
         assert runs[True][1][0] == gre[:len(runs[True][1][0])]
 
 
-@pytest.mark.parametrize('native', [False, True])
-def test_partial_accept_run_equals_reference_golden(native):
+@pytest.mark.parametrize('native,suffix', [(False, ''), (True, ''), (False, '_par'), (False, '_one')])
+def test_partial_accept_run_equals_reference_golden(native, suffix):
     """oracle/gen_golden_noisy.py recorded the REFERENCE loop (pretrained_model.py:947-1268) on the decisive tiny model with a
     noisy warm trie: multi-branch trees, 23 partially accepted steps.  The engine — interpreter loop and native
-    la_lookahead_decode loop — must reproduce every token, dls and edls, and (interpreter loop) every step's draft."""
+    la_lookahead_decode loop — must reproduce every token, dls and edls.  Round 3: the same for decoding_mode 'par' and 'one'
+    (lookahead_cache.py:441-517) through the device step: a par block mask repeats shared prefixes across chains, and
+    k_accept_scan keeps every row whose path spells the accepted tokens alive, as the reference keeps its leaf branches."""
     from tests.tiny_model import tiny_decisive_weights
-    g = np.load(os.path.join(GOLDEN, 'llama_tiny_noisy_bf16.npz'))
+    g = np.load(os.path.join(GOLDEN, f'llama_tiny_noisy{suffix}_bf16.npz'))
     shape = tiny_shape()
     model = LlamaForCausalLM(shape, tiny_decisive_weights(0, torch.bfloat16), max_length=256)
     model.lookahead_cache = LookaheadCache(eos_ids=[2])
@@ -481,14 +483,42 @@ def test_partial_accept_run_equals_reference_golden(native):
     max_length = len(prompt) + int(g['max_new'])
     partial = 0
     for r in range(int(g['n_runs'])):
-        dk = {'use_lookahead': True, 'decoding_mode': 'hier', 'decoding_length': 64, 'branch_length': 12, 'max_query_length': 2,
-              'stop_words': {}, 'native_loop': native}
+        dk = {'use_lookahead': True, 'decoding_mode': str(g['decoding_mode']), 'decoding_length': 64, 'branch_length': 12,
+              'max_query_length': 2, 'stop_words': {}, 'native_loop': native}
         out = model.lookahead_generation(torch.tensor([prompt]), stopping_criteria=max_length, eos_token_id=2, pad_token_id=0,
                                          return_dict_in_generate=True, decoding_kwargs=dk)
         assert out.sequences[0].tolist() == g[f'r{r}_sequences'].tolist(), f'request {r}'
         assert out.kwargs['dls'] == g[f'r{r}_dls'].tolist() and out.kwargs['edls'] == g[f'r{r}_edls'].tolist(), f'request {r}'
         partial += sum(1 < e < 13 for e in out.kwargs['edls'][1:])
     assert partial >= 20
+
+
+def test_custom_stopping_criteria_on_the_device_loop():
+    """pretrained_model.py:1225-1226: a user StoppingCriteria is evaluated after every verify step (the native C++ loop is not
+    taken then); the request ends with the step in which it first holds and keeps that step's whole accepted chunk."""
+    from transformers import MaxLengthCriteria, StoppingCriteria, StoppingCriteriaList
+    from tests.tiny_model import tiny_decisive_weights
+    g = np.load(os.path.join(GOLDEN, 'llama_tiny_noisy_bf16.npz'))
+    prompt = g['prompt'].tolist()
+    P, max_new = len(prompt), int(g['max_new'])
+    seq, edls = g['r0_sequences'].tolist(), g['r0_edls'].tolist()
+    target = seq[P + 30]
+    first = next(i for i in range(P, len(seq)) if seq[i] == target)
+    ends = np.cumsum(edls) + P
+    want_len = int(next(e for e in ends if e > first))
+
+    class StopOnToken(StoppingCriteria):
+        def __call__(self, input_ids, scores, **kw):
+            return bool((input_ids[0, P:] == target).any())
+    model = LlamaForCausalLM(tiny_shape(), tiny_decisive_weights(0, torch.bfloat16), max_length=256)
+    model.lookahead_cache = LookaheadCache(eos_ids=[2])
+    for c in g['copies'].tolist():
+        model.lookahead_cache.put(c, branch_length=13, mode='output', idx=-1)
+    sc = StoppingCriteriaList([MaxLengthCriteria(max_length=P + max_new), StopOnToken()])
+    dk = {'use_lookahead': True, 'decoding_length': 64, 'branch_length': 12, 'stop_words': {}}
+    out = model.lookahead_generation(torch.tensor([prompt]), stopping_criteria=sc, eos_token_id=2, pad_token_id=0,
+                                     return_dict_in_generate=True, decoding_kwargs=dk)
+    assert out.sequences[0].tolist() == seq[:want_len] and want_len < len(seq)
 
 
 def test_full_size_llama7b_32_layers_vs_oracle():

@@ -276,3 +276,75 @@ def test_generate_called_like_the_reference_example():
                                     eos_token_id=2, pad_token_id=2)
     out = m.generate(input_ids=input_ids, generation_config=cfg)
     assert out[0, input_ids.size(-1):].tolist()[:len(outs[0])] == outs[0]
+
+
+class DecisiveModel(LookaheadPreTrainedModel):
+    def __init__(self, dtype=torch.float32, max_length=512):
+        from tests.tiny_model import tiny_decisive_weights
+        self.engine = OracleEngine(tiny_shape(), tiny_decisive_weights(0, dtype), max_length=max_length)
+        self.generation_config = SimpleNamespace(eos_token_id=2, pad_token_id=0, return_dict_in_generate=False)
+        self.lookahead_cache = LookaheadCache(eos_ids=[2])
+
+
+@pytest.mark.parametrize('suffix', ['', '_par', '_one'])
+def test_product_loop_draft_modes_reproduce_reference_runs(suffix):
+    """decoding_mode 'hier' / 'par' / 'one' (selected at pretrained_model.py:712-723, retrieval lookahead_cache.py:408-517)
+    through the PRODUCT host loop and the native trie against the reference's recorded runs with a noisy warm trie
+    (oracle/gen_golden_noisy.py): tokens, dls, edls.  'par' needs the surviving-branches accept walk (a shared prefix is
+    duplicated across chains): the reference accepts 5 tokens in the first tree step where a child-of-current walk stops at 4."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', f'llama_tiny_noisy{suffix}_fp32.npz'))
+    m = DecisiveModel(torch.float32)
+    for c in g['copies'].tolist():
+        m.lookahead_cache.put(c, branch_length=13, mode='output', idx=-1)
+    prompt = g['prompt'].tolist()
+    for r in range(int(g['n_runs'])):
+        dk = dict(DK, decoding_mode=str(g['decoding_mode']))
+        out = m.lookahead_generation(torch.tensor([prompt]), stopping_criteria=len(prompt) + int(g['max_new']), eos_token_id=2,
+                                     pad_token_id=0, return_dict_in_generate=True, decoding_kwargs=dk)
+        assert out.sequences[0].tolist() == g[f'r{r}_sequences'].tolist(), (suffix, r)
+        assert out.kwargs['dls'] == g[f'r{r}_dls'].tolist() and out.kwargs['edls'] == g[f'r{r}_edls'].tolist(), (suffix, r)
+
+
+def test_custom_stopping_criteria_are_evaluated_every_step():
+    """pretrained_model.py:1225-1226: `stopping_criteria(input_ids, scores)` after every verify step — a user criterion ends the
+    request at the end of the step in which it first holds (the whole accepted chunk is kept), the max-length criterion of
+    the same list still bounds it, and the request flushes the trie as a normal end does."""
+    from transformers import MaxLengthCriteria, StoppingCriteria, StoppingCriteriaList
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'llama_tiny_noisy_fp32.npz'))
+    prompt = g['prompt'].tolist()
+    P, max_new = len(prompt), int(g['max_new'])
+
+    def fresh():
+        m = DecisiveModel(torch.float32)
+        for c in g['copies'].tolist():
+            m.lookahead_cache.put(c, branch_length=13, mode='output', idx=-1)
+        return m
+    base = fresh().lookahead_generation(torch.tensor([prompt]), stopping_criteria=P + max_new, eos_token_id=2, pad_token_id=0,
+                                        return_dict_in_generate=True, decoding_kwargs=dict(DK))
+    seq, edls = base.sequences[0].tolist(), base.kwargs['edls']
+    target = seq[P + 30]
+    first = next(i for i in range(P, len(seq)) if seq[i] == target)
+    ends = np.cumsum(edls) + P                              # sequence length after every step
+    want_len = int(next(e for e in ends if e > first))
+
+    calls = []
+
+    class StopOnToken(StoppingCriteria):
+        def __call__(self, input_ids, scores, **kw):
+            calls.append(int(input_ids.shape[1]))
+            return bool((input_ids[0, P:] == target).any())
+    sc = StoppingCriteriaList([MaxLengthCriteria(max_length=P + max_new), StopOnToken()])
+    m = fresh()
+    out = m.lookahead_generation(torch.tensor([prompt]), stopping_criteria=sc, eos_token_id=2, pad_token_id=0,
+                                 return_dict_in_generate=True, decoding_kwargs=dict(DK))
+    got = out.sequences[0].tolist()
+    assert got == seq[:want_len] and len(got) < len(seq)
+    assert calls == [int(e) for e in ends if e <= want_len]          # once per step, on the sequence so far
+    assert m.lookahead_cache.stats()['n_dirty_input_trees'] == 0     # final flush ran (reset_input_freqs)
+    # a list with only the length criterion behaves as the plain integer
+    out2 = fresh().lookahead_generation(torch.tensor([prompt]), eos_token_id=2, pad_token_id=0, return_dict_in_generate=True,
+                                        stopping_criteria=StoppingCriteriaList([MaxLengthCriteria(max_length=P + max_new)]),
+                                        decoding_kwargs=dict(DK))
+    assert out2.sequences[0].tolist() == seq

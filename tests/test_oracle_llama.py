@@ -169,24 +169,29 @@ def test_oracle_sequential_processor_path_matches_reference():
         assert out['dls'] == g[f'r{r}_dls'].tolist() and out['edls'] == g[f'r{r}_edls'].tolist()
 
 
+@pytest.mark.parametrize('suffix', ['', '_par', '_one', '_dl128'])
 @pytest.mark.parametrize('tag,dtype', [('fp32', torch.float32), ('bf16', torch.bfloat16)])
-def test_oracle_loop_matches_reference_run_with_partial_accepts(tag, dtype):
+def test_oracle_loop_matches_reference_run_with_partial_accepts(tag, dtype, suffix):
     """oracle/gen_golden_noisy.py: the reference loop on the decisive tiny model with a NOISY warm trie — multi-branch trees,
     23 partially accepted steps in the first request.  Tokens, dls, edls and every step's draft ids / row masks / emitted
-    tokens of the oracle loop over the trie oracle must equal the recording."""
+    tokens of the oracle loop over the trie oracle must equal the recording.  Variants: decoding_mode 'par' / 'one'
+    (lookahead_cache.py:441-517) and the reference's best published setting decoding_length=128, branch_length=32
+    (lookahead/README.md:100: trees of up to 128 rows, up to 33 tokens accepted per step)."""
     from tests.tiny_model import tiny_decisive_weights
-    g = np.load(os.path.join(GOLDEN, f'llama_tiny_noisy_{tag}.npz'))
+    g = np.load(os.path.join(GOLDEN, f'llama_tiny_noisy{suffix}_{tag}.npz'))
+    dm, dl, bl = str(g['decoding_mode']), int(g['decoding_length']), int(g['branch_length'])
     torch.set_num_threads(4)
     model = lo.OracleLlama(tiny_shape(), tiny_decisive_weights(0, dtype))
     cache = TrieOracle(eos_ids=[2])
     for c in g['copies'].tolist():
-        cache.put(c, branch_length=13, mode='output', idx=-1)
+        cache.put(c, branch_length=bl + 1, mode='output', idx=-1)
     prompt = g['prompt'].tolist()
     max_length = len(prompt) + int(g['max_new'])
     partial = 0
     for r in range(int(g['n_runs'])):
         rec = []
-        out = lo.lookahead_generate(model, cache, prompt, max_length, eos_token_id=2, record=rec)
+        out = lo.lookahead_generate(model, cache, prompt, max_length, eos_token_id=2, record=rec, decoding_mode=dm,
+                                    decoding_length=dl, branch_length=bl)
         assert out['sequences'] == g[f'r{r}_sequences'].tolist()
         assert out['dls'] == g[f'r{r}_dls'].tolist() and out['edls'] == g[f'r{r}_edls'].tolist()
         assert len(rec) == int(g[f'r{r}_nsteps'])
@@ -194,9 +199,14 @@ def test_oracle_loop_matches_reference_run_with_partial_accepts(tag, dtype):
             assert st['next'] == g[f'r{r}_s{i}_next'].tolist(), (r, i)
             if f'r{r}_s{i}_ids' in g.files:
                 assert st['ids'] == g[f'r{r}_s{i}_ids'].tolist(), (r, i)
-                assert [int(x) for x in st['rows']] == [int(x) for x in g[f'r{r}_s{i}_rows']], (r, i)
-        partial += sum(1 < e < 13 for e in out['edls'][1:])
+                want = [int(x) for x in g[f'r{r}_s{i}_rows']]
+                if f'r{r}_s{i}_rows_hi' in g.files:
+                    want = [lo_ | (int(hi) << 64) for lo_, hi in zip(want, g[f'r{r}_s{i}_rows_hi'])]
+                assert [int(x) for x in st['rows']] == want, (r, i)
+        partial += sum(1 < e < bl + 1 for e in out['edls'][1:])
     assert partial >= 20
+    if dl > 64:
+        assert max(max(g[f'r{r}_dls'].tolist()) for r in range(int(g['n_runs']))) > 64      # the fixture really has wide trees
 
 
 def test_attention_scale_as_multiply_is_exact():
