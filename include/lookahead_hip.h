@@ -43,7 +43,7 @@ extern "C" {
 #define LA_MOE_MAX_E      8   /* experts per mixture-of-experts layer (Mixtral: 8, top-2) */
 
 /* ABI version: bumped when a signature changes. */
-#define LA_ABI_VERSION  6    /* bumped whenever a struct layout or an entry point changes */
+#define LA_ABI_VERSION  7    /* bumped whenever a struct layout or an entry point changes */
 int          la_abi_version(void);   /* == LA_ABI_VERSION of the header the library was built from */
 const char*  la_last_error(void);
 /* Measurement knobs for the kernel A/B scripts (scripts/gpu_ab.py); every knob is 0 in production.
@@ -91,7 +91,7 @@ int la_cache_stream_put(la_cache* c, const int32_t* token_ids, int n, int branch
                         int final_, int idx);
 /* hier_get() (lookahead_cache.py:408-439) -> Tree.get/_match/_dfs_get_freqs/_ravel (:65-154, 224-293).
  * Outputs (caller-owned): out_ids[cap], out_parent[cap] (index of the parent row, -1 for row 0),
- * out_rowmask[cap] (bit j of row i <=> mask[i][j]; only filled when *out_n <= 64),
+ * out_rowmask[cap * W], W = ceil(decoding_length / 64) words per row (bit j of row i <=> mask[i][j]; W = 1: one word per row),
  * out_mask (optional, row-major int64 [*out_n][*out_n], needs cap*cap entries),
  * out_sizes[2], *out_nsizes in {0,2} (the reference returns [] on the early exit, :413-414). */
 int la_cache_hier_get(la_cache* c, const int32_t* token_ids, int n,
@@ -455,16 +455,28 @@ int      la_gather_accepted(la_comm* c, void* stream, const int32_t* d_local, in
  * --------------------------------------------------------------------- */
 #define LA_MB_MAX          8
 #define LA_MIN_NBLK        0
-#define LA_MIN_BLK         4    /* [8][4] per block: slot, T (1..64), mode (0 verify tree, 1 prefill chain, 2 forward only), limit */
+#define LA_MIN_BLK         4    /* [8][4] per block: slot, T (1..64), mode (0 verify tree, 1 prefill chain, 2 forward only,
+                                   3 = next 64 rows of the WIDE tree the preceding block(s) of the same slot started), limit */
 #define LA_MIN_IDS        36    /* [8][64] token ids                                                                   */
 #define LA_MIN_ROWMASK   548    /* uint64[8][64] ancestor masks over the block's own rows (8-byte aligned offset)      */
-#define LA_MIN_WORDS    1572
+#define LA_MIN_XMASK    1572    /* uint64[8][64][3] mode-3 blocks: ancestor masks over the rows of the 1st / 2nd / 3rd block of the tree */
+#define LA_MIN_WORDS    4644
+/* Wide trees (round 3): the reference grid-searches decoding_length x branch_length freely and publishes its best numbers at
+ * decoding_length = 128, branch_length = 32 (lookahead/README.md:100, benchmarks/benchmark.py:256-288).  A tree of up to
+ * LA_TREE_WIDE_MAX rows is ceil(T / 64) consecutive blocks of one slot: block 0 in mode 0, the others in mode 3; row r of the
+ * tree lives in block r / 64; a row's ancestor mask is its LA_MIN_ROWMASK word (own block) plus the LA_MIN_XMASK words of the
+ * earlier blocks.  Positions = cursor + popcount(all words) - 1; attention sees the earlier blocks' fresh keys under those
+ * words; ONE wavefront walks the whole tree (4 rows per lane) and emits up to LA_MOUT_TOKS tokens into the first block's
+ * LA_MOUT_OUTTOK record; LA_MOUT_DST carries the kept rows of every block. */
+#define LA_TREE_WIDE_MAX 256
+#define LA_MODE_TREE_PIECE 3
+#define LA_MOUT_TOKS      40    /* tokens a block (or a wide tree through its first block) can emit per step */
 #define LA_MOUT_NOUT       0    /* out: [8] tokens emitted per block                                                    */
 #define LA_MOUT_NKEYS      8    /* out: [16] committed keys per slot after the step                                     */
-#define LA_MOUT_OUTTOK    24    /* out: [8][16] emitted tokens per block                                                */
-#define LA_MOUT_DST      152    /* out: [8][64] main-cache key row each block row was committed to, -1 = dropped        */
-#define LA_MOUT_ARGMAX   664    /* out: [8][64] argmax token per block row                                              */
-#define LA_MOUT_WORDS   1176
+#define LA_MOUT_OUTTOK    24    /* out: [8][LA_MOUT_TOKS] emitted tokens per block                                      */
+#define LA_MOUT_DST      344    /* out: [8][64] main-cache key row each block row was committed to, -1 = dropped        */
+#define LA_MOUT_ARGMAX   856    /* out: [8][64] argmax token per block row                                              */
+#define LA_MOUT_WORDS   1368
 /* h2d of host_in (LA_MIN_WORDS), captured graph (one per nblk), d2h of the first LA_MOUT_DST words into host_out. */
 int la_llama_mstep(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);
 int la_llama_mstep_eager(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);

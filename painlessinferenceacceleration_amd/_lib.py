@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblookahead_hip.so")
 
 LA_OK = 0
-ABI_VERSION = 6         # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
+ABI_VERSION = 7         # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
 LA_MODE_INPUT, LA_MODE_OUTPUT, LA_MODE_MIX = 0, 1, 2
 LA_TREE_MAX = 64
 LA_MOE_MAX_E = 8
@@ -23,8 +23,9 @@ LA_IN_T, LA_IN_MODE, LA_IN_IDS, LA_IN_ROWMASK, LA_IN_WORDS = 0, 1, 4, 68, 196
 LA_MAX_SEQ = 16
 LA_BIN_T, LA_BIN_IDS, LA_BIN_ROWMASK, LA_BIN_SEQ, LA_BIN_MODE, LA_BIN_LIMIT, LA_BIN_WORDS = 0, 4, 68, 196, 260, 276, 292
 LA_MB_MAX = 8
-LA_MIN_NBLK, LA_MIN_BLK, LA_MIN_IDS, LA_MIN_ROWMASK, LA_MIN_WORDS = 0, 4, 36, 548, 1572
-LA_MOUT_NOUT, LA_MOUT_NKEYS, LA_MOUT_OUTTOK, LA_MOUT_DST, LA_MOUT_ARGMAX, LA_MOUT_WORDS = 0, 8, 24, 152, 664, 1176
+LA_MIN_NBLK, LA_MIN_BLK, LA_MIN_IDS, LA_MIN_ROWMASK, LA_MIN_XMASK, LA_MIN_WORDS = 0, 4, 36, 548, 1572, 4644
+LA_TREE_WIDE_MAX, LA_MODE_TREE_PIECE, LA_MOUT_TOKS = 256, 3, 40
+LA_MOUT_NOUT, LA_MOUT_NKEYS, LA_MOUT_OUTTOK, LA_MOUT_DST, LA_MOUT_ARGMAX, LA_MOUT_WORDS = 0, 8, 24, 344, 856, 1368
 LA_BST_NKEYS, LA_BST_NOUT, LA_BST_OUTTOK, LA_BST_DST, LA_BST_ARGMAX, LA_BST_SEQ, LA_BST_WORDS = 0, 16, 32, 288, 352, 416, 480
 
 

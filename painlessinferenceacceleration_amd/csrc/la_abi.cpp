@@ -35,19 +35,21 @@ int la_mb_gemm(void* stream, int kind, const void* wp, const void* xp, int N, in
     g.pos = pos; g.rcos = rcos; g.rsin = rsin; g.qf = qf; g.kfresh = kfresh; g.vfresh = vfresh; g.nh = nh; g.nkv = nkv;
     WRAP(lk_mb_gemm((hipStream_t)stream, kind, g));
 }
+// Every knob is read when a step graph is CAPTURED (kernel arguments / launch shapes are baked in): each change bumps the
+// capture epoch, and la_llama_step / la_llama_bstep / la_llama_mstep re-capture a graph whose epoch is stale.
 int la_debug_set(int key, int value) {
-    if (key == 0) { g_la_dbg_noepi = value; return LA_OK; }
-    if (key == 1 && value >= 0 && value <= 64) { g_la_kskew = value; return LA_OK; }
-    if (key == 2 && value >= 0 && value <= 3) { g_la_prio_hi = value; return LA_OK; }
-    if (key == 3 && value >= 0 && value <= 1) { g_la_mb_narrow = value; return LA_OK; }
-    if (key == 4 && value >= 0 && value <= 5) { g_la_mb_dbg = value; return LA_OK; }
-    if (key == 5 && value >= 0 && value <= 3) { g_la_mb_mode = value; return LA_OK; }
-    if (key == 6 && value >= 0 && value <= 3) { g_la_mb_pair = value; return LA_OK; }
+    if (key == 0) { g_la_dbg_noepi = value; ++g_la_graph_epoch; return LA_OK; }
+    if (key == 1 && value >= 0 && value <= 64) { g_la_kskew = value; ++g_la_graph_epoch; return LA_OK; }
+    if (key == 2 && value >= 0 && value <= 3) { g_la_prio_hi = value; ++g_la_graph_epoch; return LA_OK; }
+    if (key == 3 && value >= 0 && value <= 1) { g_la_mb_narrow = value; ++g_la_graph_epoch; return LA_OK; }
+    if (key == 4 && value >= 0 && value <= 5) { g_la_mb_dbg = value; ++g_la_graph_epoch; return LA_OK; }
+    if (key == 5 && value >= 0 && value <= 3) { g_la_mb_mode = value; ++g_la_graph_epoch; return LA_OK; }
+    if (key == 6 && value >= 0 && value <= 3) { g_la_mb_pair = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 7 && value >= 0 && value <= 128) { g_la_pf_kib = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 8 && value >= 0 && value <= 16) { g_la_pf_delay = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 9 && value >= 0 && value <= 64) { g_la_pf_tail_kib = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 10 && value >= 0 && value <= 1) { g_la_attn_staged = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 12 && value >= 0 && value <= 1) { g_la_mb_ks2 = value; return LA_OK; }
+    if (key == 12 && value >= 0 && value <= 1) { g_la_mb_ks2 = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 11 && value >= 1 && value <= 8) { g_la_graph_reps = value; ++g_la_graph_epoch; return LA_OK; }
     return LA_E_ARG;
 }

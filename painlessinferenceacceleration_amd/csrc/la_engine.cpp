@@ -61,9 +61,11 @@ struct la_llama {
     size_t mb_fresh_layer;
     hipGraphExec_t mgraphs[LA_MB_MAX + 1];
     bool mready[LA_MB_MAX + 1];
+    int mepoch[LA_MB_MAX + 1];     // g_la_graph_epoch at capture time, per multi-block graph
     hipGraphExec_t graph_exec, bgraph_exec;      // bgraph_exec: scratch slot used while capturing a batch variant
     hipGraphExec_t bgraphs[4];                  // batch step captured per attention key-split count {8, 4, 2, 1}
     bool bready[4];
+    int bepoch[4];
     const int32_t* zc_in;      // pinned host blocks the captured single-sequence graph reads / writes (zero-copy)
     int32_t* zc_out;
     int seq_expected;          // value host_out[LA_ST_SEQ] takes when the last launched step has been published
@@ -538,11 +540,15 @@ static int bstep(la_llama* m, void* stream, const int32_t* host_in, int32_t* hos
         int rc = enqueue_step(m, st, nullptr, true, nullptr, nullptr, bsplit);
         if (rc != LA_OK) return rc;
     } else {
+        if (m->bready[v] && m->bepoch[v] != g_la_graph_epoch) {      // a capture-time knob changed (la_debug_set): capture again
+            (void)hipGraphExecDestroy(m->bgraphs[v]);
+            m->bgraphs[v] = nullptr; m->bready[v] = false;
+        }
         if (!m->bready[v]) {
             int rc = build_graph(m, st, true, nullptr, nullptr, bsplit);
             if (rc != LA_OK) return rc;
             m->bgraphs[v] = m->bgraph_exec; m->bgraph_exec = nullptr; m->bgraph_ready = false;
-            m->bready[v] = true;
+            m->bready[v] = true; m->bepoch[v] = g_la_graph_epoch;
         }
         HIPCHK(hipGraphLaunch(m->bgraphs[v], st));
     }
@@ -588,7 +594,8 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk) {
         KCHK(lk_mb_gemm(st, 2, q));
         KCHK(lk_mb_tree_attn(st, m->mb_qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems, kf, vf,
                              m->mb_rowmask, m->mb_meta, nblk, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, mb_split(nblk, c.n_heads, c.balanced_wg[1] > 0 ? c.balanced_wg[1] : 256),
-                             m->mb_opart, m->mb_mpart, m->mb_lpart, m->mb_attn_xp, c.sliding_window, c.kv_ring ? 1 : 0));
+                             m->mb_opart, m->mb_mpart, m->mb_lpart, m->mb_attn_xp, c.sliding_window, c.kv_ring ? 1 : 0,
+                             (const uint64_t*)(m->mb_in + LA_MIN_XMASK)));
         MbGemm o{}; o.wp = L.wo; o.xp = m->mb_attn_xp; o.N = c.hidden; o.K = m->o_k; o.nblk = nblk; o.ksplit = o_ks;
         o.slabs = m->mb_slabs; o.slab_rows = npass_rows;
         KCHK(lk_mb_gemm(st, 0, o));
@@ -636,7 +643,7 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk) {
     h.logits = m->mb_logits; h.cand_val = m->mb_cand_val; h.cand_idx = m->mb_cand_idx;
     KCHK(lk_mb_gemm(st, 3, h));
     KCHK(lk_mb_argmax(st, m->mb_cand_val, m->mb_cand_idx, lk_mb_cand_slots(lwg), nblk, m->mb_out + LA_MOUT_ARGMAX));
-    KCHK(lk_mb_accept_scan(st, m->mb_meta, m->mb_ids, m->mb_rowmask, m->mb_out + LA_MOUT_ARGMAX, nblk, c.max_keys, c.kv_ring ? 1 : 0, m->bstate, m->mb_out));
+    KCHK(lk_mb_accept_scan(st, m->mb_meta, m->mb_ids, m->mb_rowmask, (const uint64_t*)(m->mb_in + LA_MIN_XMASK), m->mb_out + LA_MOUT_ARGMAX, nblk, c.max_keys, c.kv_ring ? 1 : 0, m->bstate, m->mb_out));
     KCHK(lk_mb_kv_commit(st, m->mb_kfresh, m->mb_vfresh, m->kmain, m->vmain, m->mb_out, nblk, c.n_layers, c.n_kv_heads, m->total_keys));
     return LA_OK;
 }
@@ -651,6 +658,10 @@ static int mstep(la_llama* m, void* stream, const int32_t* host_in, int32_t* hos
         int rc = enqueue_mstep(m, st, nblk);
         if (rc != LA_OK) return rc;
     } else {
+        if (m->mready[nblk] && m->mepoch[nblk] != g_la_graph_epoch) {
+            (void)hipGraphExecDestroy(m->mgraphs[nblk]);
+            m->mgraphs[nblk] = nullptr; m->mready[nblk] = false;
+        }
         if (!m->mready[nblk]) {
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -660,7 +671,7 @@ static int mstep(la_llama* m, void* stream, const int32_t* host_in, int32_t* hos
             HIPCHK(e);
             HIPCHK(hipGraphInstantiate(&m->mgraphs[nblk], g, nullptr, nullptr, 0));
             (void)hipGraphDestroy(g);
-            m->mready[nblk] = true;
+            m->mready[nblk] = true; m->mepoch[nblk] = g_la_graph_epoch;
         }
         HIPCHK(hipGraphLaunch(m->mgraphs[nblk], st));
     }
@@ -855,26 +866,37 @@ extern "C" int la_llama_mcommit(la_llama* m, void* stream, int nblk, const int32
     HIPCHK(hipMemcpyAsync(nk.data(), m->bstate + LA_BST_NKEYS, LA_MAX_SEQ * sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     for (int i = 0; i < LA_MOUT_ARGMAX; ++i) out[i] = (i >= LA_MOUT_DST) ? -1 : 0;
+    // one mode-2 block per slot, optionally followed by the mode-3 pieces of the same wide tree: the kept positions k of a
+    // slot are 0..n-1 over all its blocks (n <= LA_MOUT_TOKS)
     unsigned used = 0;
+    unsigned long long seen[LA_MAX_SEQ] = {0};
+    int cnt[LA_MAX_SEQ] = {0}, base_nk[LA_MAX_SEQ];
+    for (int i = 0; i < LA_MAX_SEQ; ++i) base_nk[i] = nk[i];
+    int prev_slot = -1;
     for (int b = 0; b < nblk; ++b) {
         const int* mt = &meta[b * LA_MB_META];
-        const int sl = mt[LA_MBM_SLOT], T = mt[LA_MBM_T];
-        if (sl < 0 || sl >= m->n_slots || (used >> sl & 1u) || mt[LA_MBM_MODE] != 2) { la_set_error("mcommit: the last step's blocks were not one mode-2 block per slot"); return LA_E_RANGE; }
+        const int sl = mt[LA_MBM_SLOT], T = mt[LA_MBM_T], md = mt[LA_MBM_MODE];
+        const bool piece = md == LA_MODE_TREE_PIECE && sl == prev_slot;
+        if (sl < 0 || sl >= m->n_slots || (!piece && ((used >> sl & 1u) || md != 2))) {
+            la_set_error("mcommit: the last step's blocks were not one mode-2 block (+ its wide-tree pieces) per slot"); return LA_E_RANGE;
+        }
         used |= 1u << sl;
-        unsigned seen = 0;
-        int cnt = 0;
+        prev_slot = sl;
         for (int r = 0; r < LA_TREE_MAX; ++r) {
             const int k = keep[b * 64 + r];
             if (k < 0) continue;
-            if (r >= T || k >= 32 || (seen >> k & 1u)) { la_set_error("mcommit: bad keep plan"); return LA_E_RANGE; }
-            seen |= 1u << k;
-            ++cnt;
-            const int pos = nk[sl] + k;
+            if (r >= T || k >= LA_MOUT_TOKS || (seen[sl] >> k & 1ull)) { la_set_error("mcommit: bad keep plan"); return LA_E_RANGE; }
+            seen[sl] |= 1ull << k;
+            ++cnt[sl];
+            const int pos = base_nk[sl] + k;
             out[LA_MOUT_DST + b * 64 + r] = sl * c.max_keys + (c.kv_ring ? pos % c.max_keys : pos);
         }
-        if (seen != (cnt >= 32 ? 0xffffffffu : (1u << cnt) - 1u)) { la_set_error("mcommit: kept positions of a block are not 0..n-1"); return LA_E_RANGE; }
-        if (!c.kv_ring && nk[sl] + cnt > c.max_keys) { la_set_error("mcommit: KV capacity of the slot exceeded"); return LA_E_RANGE; }
-        nk[sl] += cnt;
+    }
+    for (int sl = 0; sl < LA_MAX_SEQ; ++sl) {
+        if (!(used >> sl & 1u)) continue;
+        if (seen[sl] != ((1ull << cnt[sl]) - 1ull)) { la_set_error("mcommit: kept positions of a sequence are not 0..n-1"); return LA_E_RANGE; }
+        if (!c.kv_ring && nk[sl] + cnt[sl] > c.max_keys) { la_set_error("mcommit: KV capacity of the slot exceeded"); return LA_E_RANGE; }
+        nk[sl] += cnt[sl];
     }
     for (int i = 0; i < LA_MAX_SEQ; ++i) out[LA_MOUT_NKEYS + i] = nk[i];
     HIPCHK(hipMemcpyAsync(m->bstate + LA_BST_NKEYS, nk.data(), LA_MAX_SEQ * sizeof(int), hipMemcpyHostToDevice, st));

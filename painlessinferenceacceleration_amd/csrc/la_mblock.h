@@ -14,7 +14,7 @@
 #define LA_MB_META      8
 #define LA_MBM_SLOT     0    // sequence slot (KV region) of the block
 #define LA_MBM_T        1    // valid rows
-#define LA_MBM_MODE     2    // 0 = verify tree, 1 = prefill chain (commit all rows)
+#define LA_MBM_MODE     2    // 0 = verify tree, 1 = prefill chain (commit all rows), 2 = forward only, 3 = later piece of a wide tree
 #define LA_MBM_LIMIT    3    // max tokens to emit
 #define LA_MBM_NKEYS    4    // committed keys of the slot when the step started
 #define LA_MBM_BASE     5    // rows of earlier blocks of the same slot in this step (prefill chains)
@@ -52,8 +52,8 @@ int lk_mb_logits_wgs(int V, int n_wg);
 int lk_mb_argmax(hipStream_t st, const float* cv, const int* ci, int n_tiles, int nblk, int* out_rows);
 int lk_mb_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh, const void* vfresh,
                     const uint64_t* rowmask, const int* meta, int nblk, int nh, int nkv, int slot_keys, int n_slots, int nsplit,
-                    float* opart, float* mpart, float* lpart, void* attn_xp, int window, int ring);
-int lk_mb_accept_scan(hipStream_t st, const int* meta, const int* ids, const uint64_t* rowmask, const int* argmax, int nblk,
+                    float* opart, float* mpart, float* lpart, void* attn_xp, int window, int ring, const uint64_t* xmask);
+int lk_mb_accept_scan(hipStream_t st, const int* meta, const int* ids, const uint64_t* rowmask, const uint64_t* xmask, const int* argmax, int nblk,
                       int slot_keys, int ring, int* bstate, int* d_out);
 int lk_mb_kv_commit(hipStream_t st, const void* kfresh, const void* vfresh, void* kmain, void* vmain, const int* d_out, int nblk,
                     int n_layers, int nkv, int total_keys);

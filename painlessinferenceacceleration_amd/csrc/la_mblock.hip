@@ -1056,7 +1056,17 @@ __global__ void k_build_inputs_mb(const int* __restrict__ in, const int* __restr
     const unsigned long long rm = t < T ? rmin[t] : (1ull << t);
     rowmask[b * 64 + t] = rm;
     ids[b * 64 + t] = t < T ? in[LA_MIN_IDS + b * 64 + t] : 0;
-    pos[b * 64 + t] = t < T ? nkeys + base + __popcll(rm) - 1 : 0;
+    int p0 = nkeys + base + __popcll(rm) - 1;
+    if (rec[2] == LA_MODE_TREE_PIECE) {
+        // a later 64-row piece of a wide tree: depth = ancestors in the earlier pieces + in the own block (the hook
+        // position_ids = mask.sum(-1) - 1 over the whole tree row, modeling_llama.py:584-588), not a chain offset
+        const unsigned long long* xm = (const unsigned long long*)(in + LA_MIN_XMASK) + ((size_t)b * 64 + t) * 3;
+        int anc = 0;
+        const int np = b - first;                          // earlier pieces (<= 3)
+        for (int q = 0; q < 3; ++q) if (q < np && t < T) anc += __popcll(xm[q]);
+        p0 = nkeys + anc + __popcll(rm) - 1;
+    }
+    pos[b * 64 + t] = t < T ? p0 : 0;
     if (t == 0) {
         int* m = meta + b * LA_MB_META;
         m[LA_MBM_SLOT] = slot; m[LA_MBM_T] = T; m[LA_MBM_MODE] = rec[2]; m[LA_MBM_LIMIT] = rec[3];
@@ -1073,6 +1083,7 @@ __global__ void k_build_inputs_mb(const int* __restrict__ in, const int* __restr
 struct MbAttnArgs {
     const bf16_t* qf; const bf16_t* kmain; const bf16_t* vmain; const bf16_t* kfresh; const bf16_t* vfresh;
     const unsigned long long* rowmask;
+    const unsigned long long* xmask;                   // [blk][64][3] wide-tree pieces (mode 3): masks over the earlier pieces' rows
     const int* meta;
     int nh, nkv, total_keys, slot_tiles, nsplit, window, ring;      // ring: the slot's main cache is a ring of slot_tiles tiles
     float* opart; float* mpart; float* lpart;          // [blk][nh][nsplit][64][128] ...
@@ -1093,15 +1104,23 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
     const int row = tb * 32 + (lane & 31);
     const bool mine = row < T;
     const unsigned long long rm = mine ? a.rowmask[blk * 64 + row] : 0ull;
+    // wide-tree piece: the earlier blocks of the slot are the first rows of the SAME tree, visible under this row's ancestor words
+    const bool piece = mt[LA_MBM_MODE] == LA_MODE_TREE_PIECE;
+    unsigned long long xm0 = 0ull, xm1 = 0ull, xm2 = 0ull;
+    if (piece && mine) {
+        const unsigned long long* xp_ = a.xmask + ((size_t)blk * 64 + row) * 3;
+        xm0 = xp_[0]; if (nprev > 1) xm1 = xp_[1]; if (nprev > 2) xm2 = xp_[2];
+    }
+    const int anc_prev = piece ? __popcll(xm0) + __popcll(xm1) + __popcll(xm2) : nprev * 64;
     const int NPall = (nkeys + 31) >> 5;
-    const int qpos0 = nkeys + nprev * 64;              // position of the block's first row
+    const int qpos0 = piece ? nkeys : nkeys + nprev * 64;      // lowest position a row of the block can have
     const int ts = (a.window > 0 && qpos0 - a.window > 0) ? ((qpos0 - a.window) >> 5) : 0;
     const int tsm = ts < NPall ? ts : NPall;           // skipped main tiles
     const int NP = NPall - tsm;
     const int NF = 2 * nprev;                          // fresh tiles of earlier chain blocks
     const int NT = NP + NF + 2;
     const int tile0 = slot * a.slot_tiles + tsm;
-    const int key_lo = (a.window > 0) ? nkeys + nprev * 64 + __popcll(rm) - 1 - a.window : -0x40000000;
+    const int key_lo = (a.window > 0) ? nkeys + anc_prev + __popcll(rm) - 1 - a.window : -0x40000000;
     const int i0 = (NT * sp) / a.nsplit;
     const int i1 = (__ballot(mine) == 0ull) ? i0 : (NT * (sp + 1)) / a.nsplit;
 
@@ -1144,6 +1163,11 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
             float v = bfr(bfr(sc[i]) * 0.088388346135616302490234375f);
             bool ok;
             if (own) ok = ((rm >> (kb * 32 + kk)) & 1ull) != 0ull;
+            else if (prior && piece) {
+                const int jf = it - NP;                      // fresh tile of piece jf >> 1, rows 32 * (jf & 1) ...
+                const unsigned long long xw = (jf >> 1) == 0 ? xm0 : ((jf >> 1) == 1 ? xm1 : xm2);
+                ok = ((xw >> ((jf & 1) * 32 + kk)) & 1ull) != 0ull;
+            }
             else if (prior) { const int kpos = nkeys + (it - NP) * 32 + kk; ok = mine && kpos >= key_lo; }
             else { const int kidx = (tsm + kb) * 32 + kk; ok = mine && kidx < nkeys && kidx >= key_lo; }
             v = ok ? v : MB_NEG;
@@ -1333,9 +1357,15 @@ __global__ __launch_bounds__(256) void k_argmax_mb(const float* __restrict__ cv,
 // Accept scan + commit plan, one wavefront per block (same walk as k_accept_scan / pretrained_model_batch.py:814-905):
 // DST[row] = absolute main-cache key row every kept row goes to (root + accepted drafts, or all rows of a prefill chain),
 // then the slots' cursors advance (block order -> deterministic).  One workgroup of nblk waves.
+// A wide tree (block b in mode 0 followed by mode-3 blocks of the same slot) is walked by wave b alone: lane j owns rows
+// j, 64 + j, 128 + j, 192 + j; a row's parent is the highest set bit below it over the concatenated ancestor words; the walk
+// keeps every row whose root path spells the accepted tokens alive (the reference's surviving leaf branches,
+// pretrained_model.py:831, 850-860) and continues on the lowest one.  The waves of the continuation blocks only publish
+// their argmax rows.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void k_accept_scan_mb(const int* __restrict__ meta, const int* __restrict__ ids,
-                                 const unsigned long long* __restrict__ rowmask, const int* __restrict__ argmax, int nblk,
+                                 const unsigned long long* __restrict__ rowmask, const unsigned long long* __restrict__ xmask,
+                                 const int* __restrict__ argmax, int nblk,
                                  int slot_keys, int ring, int* __restrict__ bstate, int* __restrict__ out) {
     __shared__ int ncommit[8];
     const int b = threadIdx.x >> 6, j = threadIdx.x & 63;
@@ -1343,41 +1373,83 @@ __global__ void k_accept_scan_mb(const int* __restrict__ meta, const int* __rest
         const int* mt = meta + b * LA_MB_META;
         const int slot = mt[LA_MBM_SLOT], T = mt[LA_MBM_T], mode = mt[LA_MBM_MODE];
         int limit = mt[LA_MBM_LIMIT];
-        limit = limit < 1 ? 1 : (limit > 16 ? 16 : limit);
+        limit = limit < 1 ? 1 : (limit > LA_MOUT_TOKS ? LA_MOUT_TOKS : limit);
         const int pos0 = mt[LA_MBM_NKEYS] + mt[LA_MBM_BASE];
         auto row_of = [&](int k) { return slot * slot_keys + (ring ? (pos0 + k) % slot_keys : pos0 + k); };
         const int am = argmax[b * 64 + j];
-        int dst = -1, nc;
-        if (mode == 2) {
-            // forward only: the host decides the commit (la_llama_mcommit), see k_accept_scan_b
+        out[LA_MOUT_ARGMAX + b * 64 + j] = am;
+        int nc = 0;
+        if (mode == LA_MODE_TREE_PIECE) {
+            // rows, DST and counters of this block belong to the tree's first wave
             if (j == 0) out[LA_MOUT_NOUT + b] = 0;
-            nc = 0;
+        } else if (mode == 2) {
+            // forward only: the host decides the commit (la_llama_mcommit), see k_accept_scan_b.  Nothing of this block — nor of
+            // the wide-tree pieces that follow it — may move: their DST records still hold an earlier step's plan.
+            if (j == 0) out[LA_MOUT_NOUT + b] = 0;
+            out[LA_MOUT_DST + b * 64 + j] = -1;
+            for (int q = 1; q < 4 && b + q < nblk && meta[(b + q) * LA_MB_META + LA_MBM_MODE] == LA_MODE_TREE_PIECE
+                            && meta[(b + q) * LA_MB_META + LA_MBM_SLOT] == slot; ++q)
+                out[LA_MOUT_DST + (b + q) * 64 + j] = -1;
         } else if (mode == 1) {
             const int tok = __shfl(am, T - 1, 64);
-            if (j < T) dst = row_of(j);
-            if (j == 0) { out[LA_MOUT_OUTTOK + b * 16] = tok; out[LA_MOUT_NOUT + b] = 1; }
+            out[LA_MOUT_DST + b * 64 + j] = j < T ? row_of(j) : -1;
+            if (j == 0) { out[LA_MOUT_OUTTOK + b * LA_MOUT_TOKS] = tok; out[LA_MOUT_NOUT + b] = 1; }
             nc = T;
         } else {
-            const unsigned long long below = rowmask[b * 64 + j] & ((1ull << j) - 1ull);
-            const int parent = (j == 0 || j >= T || below == 0ull) ? -1 : 63 - __clzll((long long)below);
-            const int myid = ids[b * 64 + j];
+            int np = 1;                                        // pieces of the tree (wave-uniform)
+            while (np < 4 && b + np < nblk && meta[(b + np) * LA_MB_META + LA_MBM_MODE] == LA_MODE_TREE_PIECE
+                   && meta[(b + np) * LA_MB_META + LA_MBM_SLOT] == slot) ++np;
+            int Tq[4], amq[4], idq[4], par[4], dst[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                Tq[q] = 0; amq[q] = 0; idq[q] = 0; par[q] = -1; dst[q] = -1;
+                if (q < np) {
+                    Tq[q] = q == 0 ? T : meta[(b + q) * LA_MB_META + LA_MBM_T];
+                    amq[q] = q == 0 ? am : argmax[(b + q) * 64 + j];
+                    idq[q] = ids[(b + q) * 64 + j];
+                    if (j < Tq[q] && (q > 0 || j > 0)) {
+                        const unsigned long long below = rowmask[(b + q) * 64 + j] & ((1ull << j) - 1ull);
+                        if (below != 0ull) par[q] = 64 * q + 63 - __clzll((long long)below);
+                        else {
+                            const unsigned long long* xm = xmask + ((size_t)(b + q) * 64 + j) * 3;
+                            for (int r = q - 1; r >= 0; --r) {
+                                const unsigned long long w = xm[r];
+                                if (w != 0ull) { par[q] = 64 * r + 63 - __clzll((long long)w); break; }
+                            }
+                        }
+                    }
+                }
+            }
+            unsigned long long live[4] = {1ull, 0ull, 0ull, 0ull};
             int cur = 0, depth = 0;
-            if (j == 0) dst = row_of(0);
+            if (j == 0) dst[0] = row_of(0);
             while (true) {
-                const int want = __shfl(am, cur, 64);
-                if (j == 0) out[LA_MOUT_OUTTOK + b * 16 + depth] = want;
+                const int cq = cur >> 6, cl = cur & 63;
+                const int want = __shfl(cq == 0 ? amq[0] : cq == 1 ? amq[1] : cq == 2 ? amq[2] : amq[3], cl, 64);
+                if (j == 0) out[LA_MOUT_OUTTOK + b * LA_MOUT_TOKS + depth] = want;
                 if (depth + 1 >= limit) break;
-                const unsigned long long cand = __ballot(j < T && j > 0 && parent == cur && myid == want);
-                if (cand == 0ull) break;
-                cur = __ffsll((long long)cand) - 1;
+                unsigned long long cand[4];
+                bool any = false;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int p = par[q];
+                    const unsigned long long lw = p < 0 ? 0ull : ((p >> 6) == 0 ? live[0] : (p >> 6) == 1 ? live[1] : (p >> 6) == 2 ? live[2] : live[3]);
+                    cand[q] = q < np ? __ballot(p >= 0 && ((lw >> (p & 63)) & 1ull) != 0ull && idq[q] == want) : 0ull;
+                    any = any || cand[q] != 0ull;
+                }
+                if (!any) break;
+                int nq = 0;
+                while (cand[nq] == 0ull) ++nq;
+                cur = 64 * nq + __ffsll((long long)cand[nq]) - 1;
                 ++depth;
-                if (j == cur) dst = row_of(depth);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { live[q] = cand[q]; if (cur == 64 * q + j) dst[q] = row_of(depth); }
             }
             if (j == 0) out[LA_MOUT_NOUT + b] = depth + 1;
             nc = depth + 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (q < np) out[LA_MOUT_DST + (b + q) * 64 + j] = dst[q];
         }
-        out[LA_MOUT_DST + b * 64 + j] = dst;
-        out[LA_MOUT_ARGMAX + b * 64 + j] = am;
         if (j == 0) ncommit[b] = nc;
     }
     __syncthreads();
@@ -1677,9 +1749,10 @@ int lk_mb_argmax(hipStream_t st, const float* cv, const int* ci, int n_tiles, in
 
 int lk_mb_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh, const void* vfresh,
                     const uint64_t* rowmask, const int* meta, int nblk, int nh, int nkv, int slot_keys, int n_slots, int nsplit,
-                    float* opart, float* mpart, float* lpart, void* attn_xp, int window, int ring) {
+                    float* opart, float* mpart, float* lpart, void* attn_xp, int window, int ring, const uint64_t* xmask) {
     if (lk_mb_init() != 0 || nblk < 1 || nblk > LA_MB_MAX || (slot_keys & 31)) return -1;
     MbAttnArgs a{};
+    a.xmask = (const unsigned long long*)xmask;
     a.qf = (const bf16_t*)qf; a.kmain = (const bf16_t*)kmain; a.vmain = (const bf16_t*)vmain;
     a.kfresh = (const bf16_t*)kfresh; a.vfresh = (const bf16_t*)vfresh;
     a.rowmask = (const unsigned long long*)rowmask; a.meta = meta;
@@ -1699,10 +1772,10 @@ int lk_mb_tree_attn(hipStream_t st, const void* qf, const void* kmain, const voi
     LAUNCH_CHECK(); return 0;
 }
 
-int lk_mb_accept_scan(hipStream_t st, const int* meta, const int* ids, const uint64_t* rowmask, const int* argmax, int nblk,
+int lk_mb_accept_scan(hipStream_t st, const int* meta, const int* ids, const uint64_t* rowmask, const uint64_t* xmask, const int* argmax, int nblk,
                       int slot_keys, int ring, int* bstate, int* d_out) {
     if (nblk < 1 || nblk > LA_MB_MAX) return -1;
-    k_accept_scan_mb<<<1, 512, 0, st>>>(meta, ids, (const unsigned long long*)rowmask, argmax, nblk, slot_keys, ring, bstate, d_out);
+    k_accept_scan_mb<<<1, 512, 0, st>>>(meta, ids, (const unsigned long long*)rowmask, (const unsigned long long*)xmask, argmax, nblk, slot_keys, ring, bstate, d_out);
     LAUNCH_CHECK(); return 0;
 }
 int lk_mb_kv_commit(hipStream_t st, const void* kfresh, const void* vfresh, void* kmain, void* vmain, const int* d_out, int nblk,

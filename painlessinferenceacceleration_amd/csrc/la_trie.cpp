@@ -560,8 +560,11 @@ int la_cache_stream_put(la_cache* c, const int32_t* toks, int n, int branch_leng
 }
 
 static void emit(const la_cache::Out& o, int n, uint64_t* out_rowmask, int64_t* out_mask) {
-    if (out_rowmask && n <= 64)
-        for (int i = 0; i < n; ++i) out_rowmask[i] = o.rows[(size_t)i * o.words];
+    // packed rows: W = ceil(decoding_length / 64) words per row (W = 1 for the 64-row device block: out_rowmask[i] as before;
+    // wide trees, decoding_length up to 256: row i = words [i * W, (i + 1) * W))
+    if (out_rowmask)
+        for (int i = 0; i < n; ++i)
+            for (int w = 0; w < o.words; ++w) out_rowmask[(size_t)i * o.words + w] = o.rows[(size_t)i * o.words + w];
     if (out_mask)
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < n; ++j) out_mask[(size_t)i * n + j] = (o.rows[(size_t)i * o.words + (j >> 6)] >> (j & 63)) & 1ull;

@@ -392,6 +392,7 @@ class LlamaVerifyEngine(object):
             self._min_np = self.host_min.numpy()
             self._mout_np = self.host_mout.numpy()
             self._min_rm = self._min_np[_lib.LA_MIN_ROWMASK:_lib.LA_MIN_ROWMASK + 2 * 64 * _lib.LA_MB_MAX].view(np.uint64)
+            self._min_xm = self._min_np[_lib.LA_MIN_XMASK:_lib.LA_MIN_XMASK + 2 * 3 * 64 * _lib.LA_MB_MAX].view(np.uint64).reshape(_lib.LA_MB_MAX * 64, 3)
         self.slot_keys = [0] * self.n_slots
         self.n_keys = 0
         self.reset()
@@ -539,7 +540,7 @@ class LlamaVerifyEngine(object):
             prev = used.get(slot)
             assert prev is None or (mode == 1 and prev == (1, 64)), 'several blocks of one slot must form a prefill chain of full blocks'
             used[slot] = (mode, n)
-            a[_lib.LA_MIN_BLK + 4 * b:_lib.LA_MIN_BLK + 4 * b + 4] = (slot, n, mode, max(1, min(16, int(limit))))
+            a[_lib.LA_MIN_BLK + 4 * b:_lib.LA_MIN_BLK + 4 * b + 4] = (slot, n, mode, max(1, min(_lib.LA_MOUT_TOKS, int(limit))))
             a[_lib.LA_MIN_IDS + 64 * b:_lib.LA_MIN_IDS + 64 * b + n] = ids
             self._min_rm[64 * b:64 * b + n] = rowmask
         rows = {}
@@ -556,8 +557,60 @@ class LlamaVerifyEngine(object):
             self.slot_keys[slot] = int(o[_lib.LA_MOUT_NKEYS + slot])
         if 0 in rows:
             self.n_keys = self.slot_keys[0]
-        return [o[_lib.LA_MOUT_OUTTOK + 16 * b:_lib.LA_MOUT_OUTTOK + 16 * b + int(o[_lib.LA_MOUT_NOUT + b])].tolist()
+        return [o[_lib.LA_MOUT_OUTTOK + _lib.LA_MOUT_TOKS * b:_lib.LA_MOUT_OUTTOK + _lib.LA_MOUT_TOKS * b + int(o[_lib.LA_MOUT_NOUT + b])].tolist()
                 for b in range(len(blocks))]
+
+    # ---- wide trees: one sequence's tree of up to LA_TREE_WIDE_MAX rows as consecutive blocks of one multi-block pass -------
+    def tstep(self, ids, rowmask, slot=0, mode=0, limit=None, eager=False):
+        """One verify step of ONE sequence whose draft tree may be wider than a 64-row block (the reference grid-searches
+        decoding_length up to 256 and publishes its best numbers at decoding_length=128, branch_length=32: README.md:100,
+        benchmarks/benchmark.py:256-288).  ids int32[T], rowmask uint64[T] or uint64[T][W] (word w of row i = tree columns
+        64 w ...): rows 64 p .. 64 p + 63 form block p of the pass — block 0 in `mode` (0 verify / 2 forward only), the others as
+        LA_MODE_TREE_PIECE with their ancestor words over the earlier blocks in LA_MIN_XMASK.  -> (emitted tokens, keys kept)."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        T = len(ids)
+        rm = np.asarray(rowmask, dtype=np.uint64)
+        if rm.ndim == 1:
+            rm = rm[:, None]
+        nb = (T + 63) // 64
+        assert 1 <= T <= _lib.LA_TREE_WIDE_MAX and nb <= min(self.max_blocks, 4), \
+            f'a {T}-row tree needs an engine created with max_blocks >= {nb} (has {self.max_blocks}; at most 4 blocks per tree)'
+        assert 0 <= slot < self.n_slots and mode in (0, 2)
+        assert self.slot_keys[slot] + T <= self._capacity(), 'KV cache capacity of the slot exceeded'
+        lim = _lib.LA_MOUT_TOKS if limit is None else max(1, min(_lib.LA_MOUT_TOKS, int(limit)))
+        a = self._min_np
+        a[_lib.LA_MIN_NBLK] = nb
+        for p in range(nb):
+            r0, r1 = 64 * p, min(T, 64 * p + 64)
+            n = r1 - r0
+            a[_lib.LA_MIN_BLK + 4 * p:_lib.LA_MIN_BLK + 4 * p + 4] = (slot, n, mode if p == 0 else _lib.LA_MODE_TREE_PIECE, lim)
+            a[_lib.LA_MIN_IDS + 64 * p:_lib.LA_MIN_IDS + 64 * p + n] = ids[r0:r1]
+            self._min_rm[64 * p:64 * p + n] = rm[r0:r1, p] if p < rm.shape[1] else 0
+            for q in range(p):
+                self._min_xm[64 * p:64 * p + n, q] = rm[r0:r1, q]
+        self._mstep_slots = [slot] * nb
+        fn = lib.la_llama_mstep_eager if eager else lib.la_llama_mstep
+        check(fn(self._h, self._sp(), self.host_min.data_ptr(), self.host_mout.data_ptr()), 'llama_mstep')
+        self.stream.synchronize()
+        o = self._mout_np
+        before = self.slot_keys[slot]
+        self.slot_keys[slot] = int(o[_lib.LA_MOUT_NKEYS + slot])
+        if slot == 0:
+            self.n_keys = self.slot_keys[0]
+        return o[_lib.LA_MOUT_OUTTOK:_lib.LA_MOUT_OUTTOK + int(o[_lib.LA_MOUT_NOUT])].tolist(), self.slot_keys[slot] - before
+
+    def tcommit(self, rows, n_rows):
+        """After tstep(mode=2) over an n_rows-row tree: keep the tree rows `rows` (root first, path order) — the host-walked
+        sequential accept path on a wide tree (la_llama_mcommit over the tree's blocks)."""
+        nb = (int(n_rows) + 63) // 64
+        keep = np.full(64 * nb, -1, dtype=np.int32)
+        for k, r in enumerate(rows):
+            keep[int(r)] = k
+        check(lib.la_llama_mcommit(self._h, self._sp(), nb, keep.ctypes.data_as(_lib.pi32), self.host_mout.data_ptr()), 'llama_mcommit')
+        slot = self._mstep_slots[0]
+        self.slot_keys[slot] = int(self._mout_np[_lib.LA_MOUT_NKEYS + slot])
+        if slot == 0:
+            self.n_keys = self.slot_keys[0]
 
     def mprefill(self, slot, prompt_ids, eager=False):
         """Prompt of one slot in passes of up to max_blocks x 64 tokens (one pass over the weights each); -> first

@@ -135,7 +135,7 @@ class LookaheadCache(object):
         self._cap = cap
         self._ids = np.zeros(cap, dtype=np.int32)
         self._parent = np.zeros(cap, dtype=np.int32)
-        self._rowmask = np.zeros(cap, dtype=np.uint64)
+        self._rowmask = np.zeros(cap * ((cap + 63) // 64), dtype=np.uint64)       # W = ceil(decoding_length / 64) words per row
         self._mask = np.zeros(cap * cap, dtype=np.int64)
         self._sizes = np.zeros(2, dtype=np.int32)
         self._n = C.c_int32()
@@ -186,12 +186,22 @@ class LookaheadCache(object):
 
     def hier_get_packed(self, token_ids, decoding_length=64, branch_length=8, min_input_size=0, min_output_size=0,
                         mode='mix', idx=0):
-        """Device-path form of hier_get: (ids int32[T], rowmask uint64[T], parent int32[T], sizes list).
-        rowmask[i] bit j == mask[i][j]; valid for decoding_length <= 64."""
-        assert decoding_length <= _lib.LA_TREE_MAX or decoding_length <= 1, 'device path handles <= 64 tree tokens'
+        """Device-path form of hier_get: (ids int32[T], rowmask, parent int32[T], sizes list).  decoding_length <= 64:
+        rowmask uint64[T], bit j of rowmask[i] == mask[i][j].  Wide trees (decoding_length <= 256, the reference's
+        decoding_length=128 / branch_length=32 setting, lookahead/README.md:100): rowmask uint64[T][W], W = ceil(decoding_length /
+        64), word w of row i = columns 64 w .. 64 w + 63."""
+        assert decoding_length <= _lib.LA_TREE_WIDE_MAX, 'device path handles <= 256 tree tokens'
         n, nsizes = self._hier_raw(token_ids, decoding_length, branch_length, min_input_size, min_output_size,
                                    mode, idx, False)
-        return self._ids[:n], self._rowmask[:n], self._parent[:n], self._sizes[:nsizes].tolist()
+        W = (max(int(decoding_length), 1) + 63) // 64
+        if W == 1:
+            rm = self._rowmask[:n]
+        elif n <= 1:                                   # root only / the token_ids[-1:] fallbacks: one word is written
+            rm = np.zeros((n, W), dtype=np.uint64)
+            rm[:, 0] = 1
+        else:
+            rm = self._rowmask[:n * W].reshape(n, W)
+        return self._ids[:n], rm, self._parent[:n], self._sizes[:nsizes].tolist()
 
     def one_get(self, token_ids, decoding_length=64, branch_length=8, min_input_size=0, min_output_size=0,
                 mode='mix', idx=0):

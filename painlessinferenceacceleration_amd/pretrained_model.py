@@ -21,6 +21,34 @@ from .lookahead_generation_utils import GenerationMode, LookaheadDecoderOnlyOutp
 _ONE = np.array([1], dtype=np.uint64)
 
 
+def _pack_rows(mask, W=None):
+    """0/1 mask [T][T] -> packed ancestor rows: uint64[T] (T <= 64) or uint64[T][W] (word w = columns 64 w .. 64 w + 63)."""
+    m = np.asarray(mask).astype(np.uint64)
+    T = m.shape[1]
+    W = (T + 63) // 64 if W is None else W
+    out = np.zeros((m.shape[0], W), dtype=np.uint64)
+    for w in range(W):
+        cols = m[:, 64 * w:64 * w + 64]
+        if cols.shape[1]:
+            out[:, w] = (cols << np.arange(cols.shape[1], dtype=np.uint64)[None, :]).sum(axis=1).astype(np.uint64)
+    return out[:, 0] if W == 1 else out
+
+
+def _parents_of(rowmask, T):
+    """parent row of every tree row = highest set bit below the row over the concatenated ancestor words (DFS order)"""
+    rm = np.asarray(rowmask, dtype=np.uint64)
+    if rm.ndim == 1:
+        rm = rm[:, None]
+    parent = [-1] * T
+    for j in range(1, T):
+        below = 0
+        for w in range(rm.shape[1]):
+            below |= int(rm[j, w]) << (64 * w)
+        below &= (1 << j) - 1
+        parent[j] = below.bit_length() - 1
+    return parent
+
+
 def _max_length_of(stopping_criteria, max_length):
     if max_length is not None:
         warnings.warn("`max_length` is deprecated in this function, use "
@@ -97,8 +125,7 @@ class LookaheadPreTrainedModel(object):
                 qids, decoding_length=decoding_length, branch_length=update_branch_length, min_input_size=0,
                 min_output_size=max(decoding_length // 2, 1), mode=mode, idx=0)
             ids = np.asarray(lst, dtype=np.int32)
-            m = np.asarray(mask).astype(np.uint64)
-            rowmask = (m << np.arange(m.shape[1], dtype=np.uint64)[None, :]).sum(axis=1).astype(np.uint64)
+            rowmask = _pack_rows(mask, (decoding_length + 63) // 64 if decoding_length > 64 and len(lst) > 1 else None)
         decoding_kwargs['qts'].append(time.time() - ts)
         decoding_kwargs.update({'decoding_qids': qids, 'decoding_ids': ids, 'sizes': sizes})
         return ids, rowmask
@@ -159,9 +186,17 @@ class LookaheadPreTrainedModel(object):
         if stop_max_length is None:
             raise ValueError('lookahead_generation needs a MaxLengthCriteria (stopping_criteria.max_length)')
         decoding_length = decoding_kwargs.get('decoding_length', 64)
-        if not 1 <= int(decoding_length) <= _lib.LA_TREE_MAX:
-            raise ValueError(f'decoding_length={decoding_length}: the device verify block holds at most {_lib.LA_TREE_MAX} '
-                             f'tree tokens per sequence (the reference grid-searches up to 256, benchmarks/benchmark.py:358)')
+        # trees wider than one 64-row block run as consecutive blocks of one multi-block pass (eng.tstep; the reference's best
+        # published setting is decoding_length=128, branch_length=32, lookahead/README.md:100)
+        wide = int(decoding_length) > _lib.LA_TREE_MAX
+        if not 1 <= int(decoding_length) <= _lib.LA_TREE_WIDE_MAX:
+            raise ValueError(f'decoding_length={decoding_length}: a draft tree holds at most {_lib.LA_TREE_WIDE_MAX} tokens '
+                             f'(4 blocks of 64 rows; the reference grid-searches up to 256, benchmarks/benchmark.py:358)')
+        if wide and 64 * int(getattr(self.engine, 'max_blocks', 0) or 0) < int(decoding_length):
+            raise ValueError(f'decoding_length={decoding_length} needs an engine created with max_blocks >= '
+                             f'{(int(decoding_length) + 63) // 64} (LlamaForCausalLM(..., max_blocks=...))')
+        if int(decoding_kwargs.get('branch_length', 12)) + 1 > (_lib.LA_MOUT_TOKS if wide else 64):
+            raise ValueError(f'branch_length={decoding_kwargs.get("branch_length")}: a step emits at most {_lib.LA_MOUT_TOKS} tokens')
         if int(decoding_kwargs.get('max_query_length', 2)) < 1:
             raise ValueError('max_query_length must be >= 1')
         decoding_kwargs['max_length'] = stop_max_length
@@ -188,7 +223,7 @@ class LookaheadPreTrainedModel(object):
         native_mode = {'input': 0, 'output': 1, 'mix': 2}.get(dm.split('_')[1], 2)
         max_query_length = int(decoding_kwargs.get('max_query_length', 2))
         custom_stop = _custom_stop(stopping_criteria)      # user StoppingCriteria: evaluated per step, interpreter loop only
-        native_loop = (not sequential and streamer is None and dm.split('_')[0] == 'hier' and decoding_length <= 64
+        native_loop = (not sequential and streamer is None and dm.split('_')[0] == 'hier' and not wide
                        and custom_stop is None
                        and not decoding_kwargs.get('device_trie', False)
                        and not decoding_kwargs.get('debug_lookahead', False) and decoding_kwargs.get('native_loop', True)
@@ -198,8 +233,9 @@ class LookaheadPreTrainedModel(object):
         def pick(scores_ids, row):
             """next token from one logits row through the processor list (pretrained_model.py:833-839)"""
             ctx = torch.tensor([scores_ids], dtype=torch.long, device=eng.device)
-            scores = logits_processor(ctx, eng.logits()[row][None].clone()) if logits_processor is not None and \
-                len(logits_processor) > 0 else eng.logits()[row][None]
+            lg = eng.mlogits() if wide else eng.logits()
+            scores = logits_processor(ctx, lg[row][None].clone()) if logits_processor is not None and \
+                len(logits_processor) > 0 else lg[row][None]
             if do_sample:
                 return int(torch.multinomial(torch.softmax(scores.float(), dim=-1), num_samples=1)[0, 0])
             return int(torch.argmax(scores, dim=-1)[0])
@@ -208,8 +244,12 @@ class LookaheadPreTrainedModel(object):
         try:
             while True:
                 if first:
-                    tok = eng.prefill(seq, fast=False) if sequential else eng.prefill(seq)
-                    next_tokens = [pick(seq, (len(seq) - 1) % 64)] if sequential else [tok]
+                    if wide:
+                        tok = eng.mprefill(0, seq)
+                        next_tokens = [pick(seq, (len(seq) - 1) % (64 * eng.max_blocks))] if sequential else [tok]
+                    else:
+                        tok = eng.prefill(seq, fast=False) if sequential else eng.prefill(seq)
+                        next_tokens = [pick(seq, (len(seq) - 1) % 64)] if sequential else [tok]
                     decoding_kwargs['dls'].append(1)
                     decoding_kwargs['edls'].append(1)
                     first = False
@@ -218,12 +258,12 @@ class LookaheadPreTrainedModel(object):
                     if len(ids) == 0:
                         ids, rowmask = np.asarray(seq[-1:], dtype=np.int32), _ONE
                     if sequential:
-                        eng.verify_only(ids, rowmask)
                         T = len(ids)
-                        parent = [-1] * T
-                        for j in range(1, T):
-                            below = int(rowmask[j]) & ((1 << j) - 1)
-                            parent[j] = below.bit_length() - 1
+                        if wide:
+                            eng.tstep(ids, rowmask, mode=2)
+                        else:
+                            eng.verify_only(ids, rowmask)
+                        parent = _parents_of(rowmask, T)
                         # every row whose parent is live and whose token was picked stays live; the first one supplies the
                         # next logits row (the reference's surviving leaf branches, pretrained_model.py:831, 850-860: in a
                         # par layout a shared prefix is duplicated across chains and the walk may move to a later chain)
@@ -236,7 +276,12 @@ class LookaheadPreTrainedModel(object):
                                 break
                             cur, live = nxt[0], set(nxt)
                             rows.append(cur)
-                        eng.commit(rows)
+                        if wide:
+                            eng.tcommit(rows, T)
+                        else:
+                            eng.commit(rows)
+                    elif wide:
+                        next_tokens, _ = eng.tstep(ids, rowmask, mode=0)
                     else:
                         next_tokens, _ = eng.step(ids, rowmask, mode=0)
                     decoding_kwargs['dls'].append(len(ids))

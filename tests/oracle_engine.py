@@ -22,7 +22,11 @@ class OracleEngine(object):
 
     def _forward(self, ids, mask_rows):
         T = len(ids)
-        tree = np.array([[(int(mask_rows[i]) >> j) & 1 for j in range(T)] for i in range(T)], dtype=np.int64)
+        rm = np.asarray(mask_rows, dtype=np.uint64)
+        if rm.ndim == 1:
+            rm = rm[:, None]
+        words = [sum(int(rm[i, w]) << (64 * w) for w in range(rm.shape[1])) for i in range(T)]     # wide trees: several words per row
+        tree = np.array([[(words[i] >> j) & 1 for j in range(T)] for i in range(T)], dtype=np.int64)
         full = torch.cat([torch.ones((T, self.n_keys), dtype=torch.long), torch.from_numpy(tree)], 1)
         logits, past = self.model.forward(torch.tensor([int(x) for x in ids]), full, self.past)
         return logits, past, tree
@@ -52,6 +56,26 @@ class OracleEngine(object):
         idx = torch.tensor(keep, dtype=torch.long)
         self.past = [(k[:, idx], v[:, idx]) for k, v in self._pending]
         self.n_keys += len(rows)
+
+    # wide-tree surface of LlamaVerifyEngine (max_blocks > 0): the oracle forward has no block structure, so these are aliases
+    max_blocks = 4
+
+    def mprefill(self, slot, prompt_ids, eager=False):
+        assert slot == 0
+        return self.prefill(prompt_ids)
+
+    def mlogits(self):
+        return self._logits
+
+    def tstep(self, ids, rowmask, slot=0, mode=0, limit=None, eager=False):
+        assert len(ids) <= 256
+        if mode == 2:
+            self.verify_only(ids, rowmask)
+            return [], 0
+        return self.step(ids, rowmask)
+
+    def tcommit(self, rows, n_rows):
+        self.commit(rows)
 
     def step(self, ids, rowmask, mode=0, eager=False):
         logits, past, tree = self._forward(ids, rowmask)

@@ -493,6 +493,35 @@ def test_partial_accept_run_equals_reference_golden(native, suffix):
     assert partial >= 20
 
 
+def test_wide_tree_run_equals_reference_golden_dl128():
+    """The reference's best published setting, decoding_length=128 / branch_length=32 (lookahead/README.md:100), recorded from the
+    REFERENCE loop by oracle/gen_golden_noisy.py: trees of up to 128 rows (two chained blocks of one multi-block pass, cross-block
+    ancestor masks), up to 33 tokens accepted per step — reproduced token for token (tokens, dls, edls) on the GPU."""
+    from tests.tiny_model import tiny_decisive_weights
+    g = np.load(os.path.join(GOLDEN, 'llama_tiny_noisy_dl128_bf16.npz'))
+    dl, bl = int(g['decoding_length']), int(g['branch_length'])
+    model = LlamaForCausalLM(tiny_shape(), tiny_decisive_weights(0, torch.bfloat16), max_length=512, max_blocks=2)
+    model.lookahead_cache = LookaheadCache(eos_ids=[2])
+    for c in g['copies'].tolist():
+        model.lookahead_cache.put(c, branch_length=bl + 1, mode='output', idx=-1)
+    prompt = g['prompt'].tolist()
+    max_length = len(prompt) + int(g['max_new'])
+    wide_steps = 0
+    for r in range(int(g['n_runs'])):
+        dk = {'use_lookahead': True, 'decoding_mode': 'hier', 'decoding_length': dl, 'branch_length': bl, 'max_query_length': 2,
+              'stop_words': {}}
+        out = model.lookahead_generation(torch.tensor([prompt]), stopping_criteria=max_length, eos_token_id=2, pad_token_id=0,
+                                         return_dict_in_generate=True, decoding_kwargs=dk)
+        assert out.sequences[0].tolist() == g[f'r{r}_sequences'].tolist(), f'request {r}'
+        assert out.kwargs['dls'] == g[f'r{r}_dls'].tolist() and out.kwargs['edls'] == g[f'r{r}_edls'].tolist(), f'request {r}'
+        wide_steps += sum(d > 64 for d in out.kwargs['dls'])
+    assert wide_steps >= 10 and max(g['r1_edls'].tolist()) == bl + 1
+    with pytest.raises(ValueError):         # a 64-row engine says so instead of truncating the tree
+        LlamaForCausalLM(tiny_shape(), tiny_decisive_weights(0, torch.bfloat16), max_length=512).lookahead_generation(
+            torch.tensor([prompt]), stopping_criteria=max_length, eos_token_id=2, pad_token_id=0,
+            decoding_kwargs={'use_lookahead': True, 'decoding_length': dl, 'branch_length': bl, 'stop_words': {}})
+
+
 def test_custom_stopping_criteria_on_the_device_loop():
     """pretrained_model.py:1225-1226: a user StoppingCriteria is evaluated after every verify step (the native C++ loop is not
     taken then); the request ends with the step in which it first holds and keeps that step's whole accepted chunk."""

@@ -384,3 +384,115 @@ def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
             assert float(outs[0][:nblk * 64 * F].float().abs().sum()) > 0
     finally:
         lib.la_debug_set(6, default_form)
+
+
+def _random_wide_tree(rs, T, chain_len):
+    """T rows (parent index < row index), multiword ancestor masks uint64[T][ceil(T/64)].  Rows 0, 3, 6, ... form one long chain
+    (so that it crosses the 64-row block boundaries); every other row hangs below a random earlier row."""
+    W = (T + 63) // 64
+    chain = [r for r in range(0, T, 3)][:chain_len]
+    parent = [-1] * T
+    for k in range(1, len(chain)):
+        parent[chain[k]] = chain[k - 1]
+    on_chain = set(chain)
+    for r in range(1, T):
+        if r not in on_chain:
+            parent[r] = int(rs.randint(0, r))
+    anc = [0] * T
+    for r in range(T):
+        anc[r] = (anc[parent[r]] if parent[r] >= 0 else 0) | (1 << r)
+    rm = np.zeros((T, W), dtype=np.uint64)
+    for r in range(T):
+        for w in range(W):
+            rm[r, w] = (anc[r] >> (64 * w)) & 0xFFFFFFFFFFFFFFFF
+    mask = np.array([[(anc[i] >> j) & 1 for j in range(T)] for i in range(T)], dtype=np.int64)
+    return parent, chain, rm, mask
+
+
+@pytest.mark.parametrize('T,chain_len', [(65, 20), (128, 36), (200, 45), (256, 40)])
+def test_wide_tree_step_matches_oracle(T, chain_len):
+    """Trees wider than a block (the reference's decoding_length=128 / branch_length=32 setting, README.md:100; grid search up to
+    256, benchmarks/benchmark.py:256-288): rows 64 p .. of the tree are block p of one multi-block pass, later blocks see the
+    earlier ones under their ancestor words (LA_MIN_XMASK).  Logits of EVERY tree row vs the oracle forward under the full
+    [T][ctx + T] mask (positions = ctx + depth), the cross-block accept walk / emitted tokens / kept rows bit-exact given the
+    device's argmax rows (<= LA_MOUT_TOKS tokens), and a second step on top of the cache the first one committed."""
+    shape = tiny_shape()
+    sd = _bf16_sd(5)
+    eng = LlamaVerifyEngine(shape, sd, max_length=512, n_slots=1, max_blocks=4)
+    oracle = lo.OracleLlama(shape, sd)
+    rs = np.random.RandomState(T)
+    P = 7                  # a SHORT context: the tree's own keys carry most of the attention mass, so a wrong visibility bit shows
+    prompt = rs.randint(3, shape.vocab, size=P).tolist()
+    tok = eng.mprefill(0, prompt)
+    _, past = _oracle_seq(oracle, prompt)
+    nk = P
+    for step in range(2):
+        parent, chain, rm, mask = _random_wide_tree(rs, T, chain_len)
+        ids = np.concatenate([[tok], rs.randint(3, shape.vocab, size=T - 1)]).astype(np.int32)
+        full = torch.cat([torch.ones((T, nk), dtype=torch.long), torch.from_numpy(mask)], 1)
+        # make the long chain the DEVICE's own greedy continuation: forward-only passes (mode 2: nothing committed); a row's
+        # logits depend on its ancestors only, so fixing the chain top-down converges in len(chain) passes
+        for k in range(len(chain) - 1):
+            eng.tstep(ids, rm, mode=2)
+            ids[chain[k + 1]] = int(eng.mout()[_lib.LA_MOUT_ARGMAX + chain[k]])
+        assert eng.slot_keys[0] == nk
+        lg, past_all = oracle.forward(torch.tensor(ids.tolist()), full, past)
+        toks, kept = eng.tstep(ids, rm, mode=0, eager=(step == 1))
+        got = eng.mlogits()[:T]
+        # per-row bound 4e-2 (the tiny model's tail, see TOL_TINY: deep chain rows sit at ~3e-2) AND a mean bound that a
+        # systematically wrong mask cannot meet; the later blocks are held to the same numbers as block 0
+        gf, rf = got.float().cpu(), lg.float()
+        rel = ((gf - rf).abs().amax(-1) / rf.abs().amax(-1)).numpy()
+        assert rel.max() <= 4e-2 and rel.mean() <= 1.5e-2, (T, step, float(rel.max()), float(rel.mean()), int(rel.argmax()))
+        if T > 64:
+            assert rel[64:].mean() <= 1.5e-2 and rel[64:].max() <= 4e-2, (float(rel[64:].mean()), float(rel[64:].max()))
+        mo = eng.mout().cpu().numpy()
+        am = [int(mo[_lib.LA_MOUT_ARGMAX + r]) for r in range(T)]
+        assert am == got.float().argmax(-1).cpu().tolist()
+        exp_toks, exp_rows = lo.accept_scan(ids.tolist(), mask, am)
+        exp_toks, exp_rows = exp_toks[:_lib.LA_MOUT_TOKS], exp_rows[:_lib.LA_MOUT_TOKS]
+        assert toks == exp_toks and kept == len(exp_rows), (step, len(toks), len(exp_toks))
+        if step == 0:
+            assert len(exp_rows) > 16 and (max(exp_rows) >= 64 or T == 65)     # the walk crosses blocks and the old 16-token limit
+        nb = (T + 63) // 64
+        want = np.full(64 * nb, -1, dtype=np.int64)
+        for d, r in enumerate(exp_rows):
+            want[r] = nk + d
+        assert mo[_lib.LA_MOUT_DST:_lib.LA_MOUT_DST + 64 * nb].tolist() == want.tolist()
+        idx = torch.tensor(list(range(nk)) + [nk + r for r in exp_rows], dtype=torch.long)
+        past = [(k[:, idx], v[:, idx]) for k, v in past_all]
+        nk += len(exp_rows)
+        assert eng.slot_keys[0] == nk
+        tok = exp_toks[-1]
+
+
+def test_wide_tree_host_commit_equals_device_commit():
+    """Sequential accept path on a wide tree (logits processors / sampling: tstep(mode=2) = forward only, the host walks the
+    tree over the logits rows, tcommit(rows) moves the kept K/V rows of all the tree's blocks, la_llama_mcommit): keeping the
+    rows the device walk keeps must leave the SAME cache — the next step's logits are bitwise equal."""
+    shape = tiny_shape()
+    sd = _bf16_sd(6)
+    T = 150
+    rs = np.random.RandomState(11)
+    prompt = rs.randint(3, shape.vocab, size=40).tolist()
+    parent, chain, rm, mask = _random_wide_tree(rs, T, 30)
+    engs = [LlamaVerifyEngine(shape, sd, max_length=512, n_slots=1, max_blocks=3) for _ in range(2)]
+    tok = [e.mprefill(0, prompt) for e in engs]
+    assert tok[0] == tok[1]
+    ids = np.concatenate([[tok[0]], rs.randint(3, shape.vocab, size=T - 1)]).astype(np.int32)
+    for k in range(len(chain) - 1):
+        engs[0].tstep(ids, rm, mode=2)
+        ids[chain[k + 1]] = int(engs[0].mout()[_lib.LA_MOUT_ARGMAX + chain[k]])
+    toks, kept = engs[0].tstep(ids, rm, mode=0)
+    assert kept > 16
+    engs[1].tstep(ids, rm, mode=2)
+    am = engs[1].mlogits()[:T].float().argmax(-1).cpu().tolist()
+    exp_toks, exp_rows = lo.accept_scan(ids.tolist(), mask, am)
+    assert exp_toks[:_lib.LA_MOUT_TOKS] == toks
+    engs[1].tcommit(exp_rows[:_lib.LA_MOUT_TOKS], T)
+    assert engs[1].slot_keys[0] == engs[0].slot_keys[0] == 40 + kept
+    nxt = np.concatenate([[toks[-1]], rs.randint(3, shape.vocab, size=70)]).astype(np.int32)
+    _, _, rm2, _ = _random_wide_tree(rs, 71, 5)
+    for e in engs:
+        e.tstep(nxt, rm2, mode=2)
+    assert torch.equal(engs[0].mlogits()[:71], engs[1].mlogits()[:71])

@@ -286,7 +286,7 @@ class DecisiveModel(LookaheadPreTrainedModel):
         self.lookahead_cache = LookaheadCache(eos_ids=[2])
 
 
-@pytest.mark.parametrize('suffix', ['', '_par', '_one'])
+@pytest.mark.parametrize('suffix', ['', '_par', '_one', '_dl128'])
 def test_product_loop_draft_modes_reproduce_reference_runs(suffix):
     """decoding_mode 'hier' / 'par' / 'one' (selected at pretrained_model.py:712-723, retrieval lookahead_cache.py:408-517)
     through the PRODUCT host loop and the native trie against the reference's recorded runs with a noisy warm trie
@@ -295,11 +295,12 @@ def test_product_loop_draft_modes_reproduce_reference_runs(suffix):
     import os
     g = np.load(os.path.join(os.path.dirname(__file__), 'golden', f'llama_tiny_noisy{suffix}_fp32.npz'))
     m = DecisiveModel(torch.float32)
+    dl, bl = int(g['decoding_length']), int(g['branch_length'])       # _dl128: trees of up to 128 rows, up to 33 tokens per step
     for c in g['copies'].tolist():
-        m.lookahead_cache.put(c, branch_length=13, mode='output', idx=-1)
+        m.lookahead_cache.put(c, branch_length=bl + 1, mode='output', idx=-1)
     prompt = g['prompt'].tolist()
     for r in range(int(g['n_runs'])):
-        dk = dict(DK, decoding_mode=str(g['decoding_mode']))
+        dk = dict(DK, decoding_mode=str(g['decoding_mode']), decoding_length=dl, branch_length=bl)
         out = m.lookahead_generation(torch.tensor([prompt]), stopping_criteria=len(prompt) + int(g['max_new']), eos_token_id=2,
                                      pad_token_id=0, return_dict_in_generate=True, decoding_kwargs=dk)
         assert out.sequences[0].tolist() == g[f'r{r}_sequences'].tolist(), (suffix, r)
