@@ -138,6 +138,9 @@ static void resolve_cfg(la_llama* m) {
         if ((want & 1) && c.balanced_wg[1] >= LA_TREE_MAX && m->o_ks == 4) m->fuse |= 1;
         if ((want & 2) && c.balanced_wg[0] >= LA_TREE_MAX && m->down_ks == 4) m->fuse |= 2;
     }
+    // bit 2 (value 4), bit 3 (value 8 = 8 tile-sets in flight in the down role): gate/up and down_proj as ONE role-fused launch
+    // (k_gateup_down): needs the balanced gate/up image, the 64-row classic down image and a dense MLP
+    if ((c.fuse & 4) && c.n_experts == 0 && c.balanced_wg[1] > 0 && (c.hidden % 64) == 0 && (c.ffn % 16) == 0) m->fuse |= (c.fuse & 12);
     if (m->qkv_n % 64) m->qkv_rb = (m->qkv_rb & ~0xff) | 1;
     if (c.hidden % 64) { m->o_rb = (m->o_rb & ~0xff) | 1; m->down_rb = (m->down_rb & ~0xff) | 1; }
     if (c.vocab % 64) m->lm_rb = (m->lm_rb & ~0xff) | 1;
@@ -182,7 +185,7 @@ static size_t carve(la_llama* m, char* base) {
     m->moe_acc = cv.take<uint16_t>(c.n_experts > 0 ? (size_t)64 * c.hidden : 8);
     m->act_ex = cv.take<uint16_t>(c.n_experts > 0 ? (size_t)c.n_experts * 64 * c.ffn : 8);
     m->slabs_ex = cv.take<float>(c.n_experts > 0 ? (size_t)c.n_experts * m->down_ks * 64 * c.hidden : 8);
-    m->fuse_cnt = cv.take<int>((size_t)2 * c.n_layers + 8);
+    m->fuse_cnt = cv.take<int>((size_t)3 * c.n_layers + 8);
     m->route_w = cv.take<float>((size_t)(c.n_experts > 0 ? c.n_layers : 1) * 64 * LA_MOE_MAX_E);   // kept per layer (parity tests)
     m->mb_max = c.max_blocks > 1 ? c.max_blocks : 0;
     if (m->mb_max) {
@@ -362,7 +365,7 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
     if (batch) KCHK(lk_build_tree_inputs_b(st, m->bin, m->bstate, m->pos, m->rowmask, m->ids));
     else KCHK(lk_build_tree_inputs(st, zc_in ? (const int*)zc_in : m->in, m->state, m->pos, m->rowmask, m->ids));
     const int cf = c.norm_cast_first;
-    if (m->fuse) HIPCHK(hipMemsetAsync(m->fuse_cnt, 0, sizeof(int) * 2 * c.n_layers, st));
+    if (m->fuse) HIPCHK(hipMemsetAsync(m->fuse_cnt, 0, sizeof(int) * 3 * c.n_layers, st));
     // Idle-window weight prefetch (la_kernels.h, PfDesc): the row kernels and the attention combine carry extra workgroups that
     // pull the first KiB every workgroup of the NEXT GEMM will stream into the L2 of its XCD.  g_la_pf_kib = 0 switches it off.
     const int pf_kib = m->fuse ? 0 : g_la_pf_kib, pf_dly = g_la_pf_delay;
@@ -457,6 +460,14 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
             if (pf_kib > 0 && c.balanced_wg[1] > 0) lk_pf_planned(&pd, L.wgateup, 1, c.ffn, c.hidden, c.balanced_wg[1], pf_kib, pf_dly, nullptr);
             KCHK(lk_resid_norm(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp, cf, &pd));
             P(KC_GATEUP);
+            if ((m->fuse & 4) && (m->down_rb & 0xff) == 2) {
+                // gate/up + down_proj in one launch: the down role's workgroups start as gate/up's exit, with their first weight
+                // tile-sets in flight while they wait for act (k_gateup_down)
+                KCHK(lk_gateup_down(st, L.wgateup, m->xp, c.ffn, c.hidden, c.balanced_wg[1], m->act_xp, L.wdown, c.hidden, m->down_ks,
+                                    m->slabs, m->fuse_cnt + 2 * c.n_layers + l, (m->fuse & 8) ? 8 : 4));
+                P(KC_OTHER);
+                goto after_down;
+            }
             if (c.balanced_wg[1] > 0) {
                 // down_proj follows at once: its first k-tiles are pulled into L2 from the tail of the gate/up launch
                 pd = PfDesc{};
@@ -468,6 +479,7 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
         P(KC_DOWN);
         KCHK(lk_gemm64_slab(st, L.wdown, m->act_xp, c.hidden, c.ffn, m->down_rb, m->down_ks, m->slabs));
         P(KC_OTHER);
+    after_down:
         if (!((m->fuse & 2) && l + 1 < c.n_layers)) {        // otherwise fused into the next layer's QKV launch
             if (l + 1 < c.n_layers) pf_qkv(l + 1, &pd);
             else {

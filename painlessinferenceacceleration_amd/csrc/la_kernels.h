@@ -46,6 +46,8 @@ int lk_gemm64_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int nk
                   const void* rsin, void* qf, void* kfresh, void* vfresh, int variant);
 void lk_qkv_row_perm(int nh, int nkv, int* perm);
 int lk_gemm64r_init();
+int lk_gateup_down(hipStream_t st, const void* wgu, const void* xp, int F, int K, int n_wg, void* act_xp, const void* wdown, int N,
+                   int ksplit, float* slabs, int* counter, int dd);
 int lk_rowplan(int kind, int n_rows, int n_wg, int* out);
 long lk_planned_elems(int kind, int n_rows, int K, int n_wg);
 int lk_pack_planned(hipStream_t st, const void* w, const void* w2, const int* d_plan, int kind, int n_rows, int K, int n_wg, void* out);

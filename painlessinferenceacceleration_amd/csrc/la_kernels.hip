@@ -279,8 +279,15 @@ __global__ __launch_bounds__(512) void k_row_norm(const bf16_t* __restrict__ emb
 // workgroup that could be queued behind it) to every workgroup of the grid: producers publish their stores with an
 // agent-scope release and bump `counter`; everybody spins until it reaches `target`, then acquires.
 __device__ __forceinline__ void handover_signal(int* counter) {
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();                 // every wave's stores have completed (the barrier carries vmcnt(0)) ...
+    if (threadIdx.x == 0) {
+        // ... one lane writes the XCD's dirty L2 lines back (agent-scope release), DRAINS that write-back — hipcc may drop the
+        // s_waitcnt behind buffer_wbl2 when it thinks the wave has nothing outstanding, and the flag would overtake the data —
+        // and only then bumps the counter
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 __device__ __forceinline__ void handover_wait(int* counter, int target) {
     if (threadIdx.x == 0) {
@@ -368,17 +375,21 @@ __device__ __forceinline__ void wave_krange(int t0, int twg, int wave, int kskew
 // (image bases, K, the expert switch) is therefore passed as leading scalars — the same values as the struct fields, which the
 // launchers keep filling — so that no s_load round trip stands between dispatch and the first HBM request (measured on the
 // single-wave kernels of the step: -0.2 us per launch).  kfl = ex_on | kskew << 1 | prio_hi << 8.
-template <int RB, int EPI, int D, int NW>
-__global__ __launch_bounds__(NW * 64) void k_gemm64(const bf16_t* __restrict__ wp_s, const bf16_t* __restrict__ xp_s,
-                                                     const float* __restrict__ route_col_s, int K16_s, int kfl, GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[NW][RB * 2 * 16 * 64];
-    const int ex = (kfl & 1) ? (int)blockIdx.z : 0;
+// HW = true: the x operand is produced by OTHER workgroups of the same launch (role-fused launches, k_gateup_down): the first
+// weight tile-sets are requested, then the wave waits for ho_counter == ho_target (handover_wait), then loads x.
+struct BlockPos { int bx, by, bz, gx, gy; };
+template <int RB, int EPI, int D, int NW, bool HW = false>
+__device__ __forceinline__ void gemm64_body(const bf16_t* __restrict__ wp_s, const bf16_t* xp_s,
+                                            const float* __restrict__ route_col_s, int K16_s, int kfl, const GemmArgs& a,
+                                            const BlockPos bp, float* red_, int* ho_counter, int ho_target) {
+    float (*red)[RB * 2 * 16 * 64] = (float (*)[RB * 2 * 16 * 64])red_;
+    const int ex = (kfl & 1) ? bp.bz : 0;
     if (expert_unused(route_col_s ? route_col_s + ex : nullptr)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nb0 = blockIdx.x * RB;
-    const int ksplit = gridDim.y, ks = blockIdx.y;
-    long long* const stamp = a.dbg_times ? a.dbg_times + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8 : nullptr;
+    const int nb0 = bp.bx * RB;
+    const int ksplit = bp.gy, ks = bp.by;
+    long long* const stamp = a.dbg_times ? a.dbg_times + ((size_t)(bp.by * bp.gx + bp.bx) * NW + wave) * 8 : nullptr;
     if (stamp && lane == 0) { stamp[0] = wall_clock64(); stamp[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
     const int t0 = (int)(((long)K16_s * ks) / ksplit);
     const int t1 = (int)(((long)K16_s * (ks + 1)) / ksplit);
@@ -393,7 +404,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(const bf16_t* __restrict__ w
     // integer offsets from the kernel-argument bases (not mutated pointers) keep the loads in the global
     // address space: a loop-carried pointer degrades to flat_load, which ties vmcnt and lgkmcnt together
     const bf16x8* __restrict__ wbase = (const bf16x8*)(wp_s + ((kfl & 1) ? (size_t)ex * a.ex_w : (size_t)0));
-    const bf16x8* __restrict__ xbase = (const bf16x8*)(xp_s + ((kfl & 1) ? (size_t)ex * a.ex_x : (size_t)0));
+    typedef const bf16x8* __restrict__ xptr_r;
+    typedef const bf16x8* xptr_n;                                       // HW: written by other workgroups of this launch
+    typename std::conditional<HW, xptr_n, xptr_r>::type xbase = (const bf16x8*)(xp_s + ((kfl & 1) ? (size_t)ex * a.ex_x : (size_t)0));
     unsigned woff[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) woff[rb] = (unsigned)(((nb0 + rb) * K16_s + wb) * 64 + lane);
@@ -415,13 +428,29 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(const bf16_t* __restrict__ w
         // first tile (always valid memory) and their MFMAs are skipped by a wave-uniform branch.
         bf16x8 fa[D][RB], fb[D][2];
         const int n1 = ngroups == 1 ? last_valid : D;     // valid slots of group 0
+        if constexpr (HW) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int dd = d < n1 ? d : 0;
+            for (int d = 0; d < D; ++d) {
+                const int dd = d < n1 ? d : 0;
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wbase + woff[rb] + dd * 64);
-            fb[d][0] = xbase[xoff + dd * 128];
-            fb[d][1] = xbase[xoff + dd * 128 + 64];
+                for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wbase + woff[rb] + dd * 64);
+            }
+            handover_wait(ho_counter, ho_target);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int dd = d < n1 ? d : 0;
+                fb[d][0] = xbase[xoff + dd * 128];
+                fb[d][1] = xbase[xoff + dd * 128 + 64];
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int dd = d < n1 ? d : 0;
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) fa[d][rb] = __builtin_nontemporal_load(wbase + woff[rb] + dd * 64);
+                fb[d][0] = xbase[xoff + dd * 128];
+                fb[d][1] = xbase[xoff + dd * 128 + 64];
+            }
         }
         for (int g = 1; g < ngroups; ++g) {
             if (stamp && lane == 0 && g == (ngroups >> 1)) stamp[3] = wall_clock64();
@@ -477,7 +506,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(const bf16_t* __restrict__ w
     // EPI_QKV: this lane's RoPE operands (dependent pos -> cos/sin loads) are requested before the barrier
     bf16x4 rc[GPW], rs4[GPW];
     if constexpr (EPI == EPI_QKV) {
-        const int u = blockIdx.x & 1;
+        const int u = bp.bx & 1;
         const int ps = a.pos[tb * 32 + tl];
 #pragma unroll
         for (int gg = 0; gg < GPW; ++gg) {
@@ -512,7 +541,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(const bf16_t* __restrict__ w
         // rb 0 = gate rows, rb 1 = up rows of the same 32 features (interleaved packing).
         // act = bf16(silu(bf16(g)) * bf16(u))  — LlamaMLP.forward, modeling_llama.py:185-186
         static_assert(EPI != EPI_SWIGLU || RB == 2, "swiglu needs gate/up pair");
-        const int jb = blockIdx.x;   // feature block
+        const int jb = bp.bx;   // feature block
 #pragma unroll
         for (int gg = 0; gg < GPW; ++gg) {
             bf16x4 pk;
@@ -531,7 +560,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(const bf16_t* __restrict__ w
         // partners 64+32u+[0,32) (rows permuted at pack time).  q/k: rotate-half RoPE in bf16 arithmetic
         // (apply_rotary_pos_emb, modeling_llama.py:154-169) -> QF / fresh KF fragments; v -> fresh VF fragments.
         static_assert(EPI != EPI_QKV || RB == 2, "qkv epilogue needs the (d, d+64) row-block pair");
-        const int slot = blockIdx.x >> 1, u = blockIdx.x & 1;
+        const int slot = bp.bx >> 1, u = bp.bx & 1;
 #pragma unroll
         for (int gg = 0; gg < GPW; ++gg) {
             const int dlo = 32 * u + 8 * (g0 + gg) + 4 * hh, dhi = dlo + 64;
@@ -581,12 +610,20 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64(const bf16_t* __restrict__ w
         int oi = __shfl_xor(bidx, 32, 64);
         if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
         if (hh == 0) {      // candidate slot: (workgroup, register-group owner) x token
-            const size_t slot = (size_t)blockIdx.x * (NW / 2) + (wave >> 1);
+            const size_t slot = (size_t)bp.bx * (NW / 2) + (wave >> 1);
             a.cand_val[slot * LA_TB + tok] = best;
             a.cand_idx[slot * LA_TB + tok] = bidx;
         }
     }
     if (stamp && lane == 0) stamp[2] = wall_clock64();
+}
+
+template <int RB, int EPI, int D, int NW>
+__global__ __launch_bounds__(NW * 64) void k_gemm64(const bf16_t* __restrict__ wp_s, const bf16_t* __restrict__ xp_s,
+                                                     const float* __restrict__ route_col_s, int K16_s, int kfl, GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[NW][RB * 2 * 16 * 64];
+    const BlockPos bp = {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)gridDim.x, (int)gridDim.y};
+    gemm64_body<RB, EPI, D, NW, false>(wp_s, xp_s, route_col_s, K16_s, kfl, a, bp, &red[0][0], nullptr, 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -620,16 +657,16 @@ struct GemmRArgs {
 
 // Leading scalars = the prologue's operands (kernarg preload, see k_gemm64): nvl_pk = nvl[0..3] one byte each.
 template <int RB, int EPI, int D, int NW, int NSF = 0>
-__global__ __launch_bounds__(NW * 64) void k_gemm64r(const bf16_t* __restrict__ wp_s, const bf16_t* xp_s,
-                                                      const float* __restrict__ route_col_s, int K16_s, int kfl, int wg_chunks_s,
-                                                      unsigned nvl_pk, int boff0, int boff1, int boff2, int boff3, GemmRArgs ra) {
-    extern __shared__ __attribute__((aligned(16))) float redr[];      // [NW][RB][16][64]
+__device__ __forceinline__ void gemm64r_body(const bf16_t* __restrict__ wp_s, const bf16_t* xp_s,
+                                             const float* __restrict__ route_col_s, int K16_s, int kfl, int wg_chunks_s,
+                                             unsigned nvl_pk, int boff0, int boff1, int boff2, int boff3, const GemmRArgs& ra,
+                                             const BlockPos bp, float* redr) {
     const GemmArgs& a = ra.g;
-    const int ex = (kfl & 1) ? (int)blockIdx.y : 0;
+    const int ex = (kfl & 1) ? bp.by : 0;
     if (expert_unused(route_col_s ? route_col_s + ex : nullptr)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    long long* const stamp = a.dbg_times ? a.dbg_times + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8 : nullptr;
+    long long* const stamp = a.dbg_times ? a.dbg_times + ((size_t)(bp.by * bp.gx + bp.bx) * NW + wave) * 8 : nullptr;
     if (stamp && lane == 0) { stamp[0] = wall_clock64(); stamp[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); }
     int wb, cnt;
     const int kskew = (kfl >> 1) & 127, prio_hi = kfl >> 8;
@@ -648,7 +685,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(const bf16_t* __restrict__ 
         const int nvb = (int)((nvl_pk >> (8 * rb)) & 255u);
         const int rr = (lane & 31) < nvb ? (lane & 31) : nvb - 1;     // rows past the stored ones re-read the last one
         wstr[rb] = (unsigned)(2 * nvb);
-        woff[rb] = (unsigned)blockIdx.x * (unsigned)wg_chunks_s + (unsigned)boff_s[rb] + (unsigned)wb * wstr[rb]
+        woff[rb] = (unsigned)bp.bx * (unsigned)wg_chunks_s + (unsigned)boff_s[rb] + (unsigned)wb * wstr[rb]
                    + (unsigned)((lane >> 5) * nvb + rr);
     }
     unsigned xoff = (unsigned)(wb * 128 + lane);
@@ -667,9 +704,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(const bf16_t* __restrict__ 
             // return in order: the row operands would queue behind ~16 KiB of weight tiles per wave); everybody else has
             // its first weight tiles in flight while waiting.
             static_assert(NW == 8, "the fused row kernel is written for 512 threads");
-            const bool producer = blockIdx.x < LA_TB;
+            const bool producer = bp.bx < LA_TB;
             if (producer) {
-                row_norm_body<NSF, false>(blockIdx.x, redr, nullptr, nullptr, nullptr, ra.fn_h, ra.fn_slabs, ra.fn_nw,
+                row_norm_body<NSF, false>(bp.bx, redr, nullptr, nullptr, nullptr, ra.fn_h, ra.fn_slabs, ra.fn_nw,
                                           ra.fn_hidden, ra.fn_eps, (bf16_t*)xp_s, nullptr, nullptr, 0, 0, nullptr, nullptr,
                                           ra.fn_cast);
                 handover_signal(ra.fn_counter);
@@ -744,7 +781,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(const bf16_t* __restrict__ 
     f32x4 pfv[8];
     const bool pf_on = EPI == EPI_SWIGLU && NSF == 0 && ra.pf.base != nullptr;        // wave-uniform
     if constexpr (EPI == EPI_SWIGLU && NSF == 0) {
-        if (pf_on) pf_issue<8, false>(ra.pf, (int)blockIdx.x, pfv);
+        if (pf_on) pf_issue<8, false>(ra.pf, bp.bx, pfv);
     }
     // ---- cross-wave reduction through LDS in 16-byte units [wave][rb][i/4][lane] (ds_write_b128 / ds_read_b128), fixed
     //      summation order p = 0..NW-1 (deterministic), then every wave finishes a fixed slice.
@@ -768,7 +805,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(const bf16_t* __restrict__ 
             const int tok = tbe * 32 + tl;
             const int f0 = 8 * gi + 4 * hh;
             const bool live = f0 < ra.nv[0];
-            const int pr = ra.R * blockIdx.x + f0, slot = pr >> 6, dlo = pr & 63, dhi = dlo + 64;
+            const int pr = ra.R * bp.bx + f0, slot = pr >> 6, dlo = pr & 63, dhi = dlo + 64;
             const bool rope = slot < a.nh + a.nkv;
             bf16x4 c4 = {0, 0, 0, 0}, s4 = {0, 0, 0, 0};
             if (live && rope) {          // dependent pos -> cos/sin loads are in flight across the barrier
@@ -842,7 +879,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(const bf16_t* __restrict__ 
                     if (f < ra.nv[qq]) {
                         const float gv = bfr(g4[j]), uv = bfr(u4[j]);
                         const float sv = bfr(gv / (1.0f + expf(-gv)));
-                        const int feat = ra.R * blockIdx.x + 32 * qq + f;
+                        const int feat = ra.R * bp.bx + 32 * qq + f;
                         a.act_xp[(size_t)ex * a.ex_act + xp_offset(tok, feat)] = f2bf(sv * uv);
                     }
                 }
@@ -857,7 +894,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(const bf16_t* __restrict__ 
                 for (int j = 0; j < 4; ++j) {
                     const int f = 8 * gi + 4 * hh + j;
                     if (f < ra.nv[0]) {
-                        const int pr = ra.R * blockIdx.x + f, slot = pr >> 6, dlo = pr & 63, dhi = dlo + 64;
+                        const int pr = ra.R * bp.bx + f, slot = pr >> 6, dlo = pr & 63, dhi = dlo + 64;
                         const float xl = xl4[j], xh = xh4[j];
                         if (slot < a.nh + a.nkv) {
                             bf16_t* dst = slot < a.nh ? a.qf + (size_t)slot * 8192 : a.kfresh + (size_t)(slot - a.nh) * 8192;
@@ -885,7 +922,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(const bf16_t* __restrict__ 
                         const int f = 8 * gi + 4 * hh + j;
                         if (f < ra.nv[rb]) {
                             const bf16_t hv = f2bf(t4[j]);
-                            const int idx = ra.R * blockIdx.x + 32 * rb + f;
+                            const int idx = ra.R * bp.bx + 32 * rb + f;
                             if (a.logits) a.logits[(size_t)tok * a.N + idx] = hv;
                             const float v = bf2f(hv);
                             if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
@@ -897,7 +934,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(const bf16_t* __restrict__ 
             int oi = __shfl_xor(bidx, 32, 64);
             if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
             if (hh == 0) {
-                const size_t slot = (size_t)blockIdx.x * NW + wave;
+                const size_t slot = (size_t)bp.bx * NW + wave;
                 a.cand_val[slot * LA_TB + tok] = best;
                 a.cand_idx[slot * LA_TB + tok] = bidx;
             }
@@ -908,6 +945,40 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(const bf16_t* __restrict__ 
         if (pf_on) pf_keep8(pfv);              // the prefetch loads landed under the epilogue; their registers stay reserved until here
     }
     if (stamp && lane == 0) stamp[2] = wall_clock64();
+}
+
+template <int RB, int EPI, int D, int NW, int NSF = 0>
+__global__ __launch_bounds__(NW * 64) void k_gemm64r(const bf16_t* __restrict__ wp_s, const bf16_t* xp_s,
+                                                      const float* __restrict__ route_col_s, int K16_s, int kfl, int wg_chunks_s,
+                                                      unsigned nvl_pk, int boff0, int boff1, int boff2, int boff3, GemmRArgs ra) {
+    extern __shared__ __attribute__((aligned(16))) float redr[];      // [NW][RB][16][64]
+    const BlockPos bp = {(int)blockIdx.x, (int)blockIdx.y, 0, (int)gridDim.x, (int)gridDim.y};
+    gemm64r_body<RB, EPI, D, NW, NSF>(wp_s, xp_s, route_col_s, K16_s, kfl, wg_chunks_s, nvl_pk, boff0, boff1, boff2, boff3, ra, bp, redr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Role-fused launch gate/up -> down_proj (cfg.fuse bit 2).  One grid: workgroups [0, n_gu) run the balanced gate/up + SwiGLU
+// GEMM and publish act with an agent-scope release + counter; workgroups [n_gu, n_gu + n_dn) run the split-K down_proj: they
+// are dispatched as gate/up workgroups EXIT (every workgroup of this launch fills a CU), request their first weight tile-sets
+// at once — HBM stays busy through gate/up's ragged tail, reduction and epilogue — and wait for the counter before loading
+// act.  What it replaces: a kernel boundary + the cold start of the down_proj launch; what it costs: a release / acquire
+// pair.  Deadlock-free as long as workgroups are dispatched in block-id order (the down role only ever waits on LOWER ids;
+// the spin is bounded and traps).  Same arithmetic in the same order as the two launches: bitwise identical results.
+// ---------------------------------------------------------------------------------------------
+template <int RBD, int DD>
+__global__ __launch_bounds__(512) void k_gateup_down(const bf16_t* __restrict__ wp_s, const bf16_t* xp_s, int K16_s, int kfl, int wg_chunks_s,
+                                                      unsigned nvl_pk, int boff0, int boff1, int boff2, int boff3, int n_gu,
+                                                      GemmRArgs gu, GemmArgs dn, int dn_gx, int dn_gy, int* counter) {
+    extern __shared__ __attribute__((aligned(16))) float lds_gd[];     // gate/up reduction [8][4][16][64] == down_proj reduction [8][RBD*2*16*64]
+    if ((int)blockIdx.x < n_gu) {
+        const BlockPos bp = {(int)blockIdx.x, 0, 0, n_gu, 1};
+        gemm64r_body<4, EPI_SWIGLU, 4, 8, 0>(wp_s, xp_s, nullptr, K16_s, kfl, wg_chunks_s, nvl_pk, boff0, boff1, boff2, boff3, gu, bp, lds_gd);
+        handover_signal(counter);
+    } else {
+        const int id = (int)blockIdx.x - n_gu;
+        const BlockPos bp = {id % dn_gx, id / dn_gx, 0, dn_gx, dn_gy};
+        gemm64_body<RBD, EPI_SLAB, DD, 8, true>(dn.wp, dn.xp, nullptr, dn.K16, 0, dn, bp, lds_gd, counter, n_gu);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_argmax_finalize(const float* __restrict__ cv, const int* __restrict__ ci,
@@ -1895,6 +1966,23 @@ int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int n
     }
     LAUNCH_CHECK(); return 0;
 }
+// Role-fused gate/up -> down_proj launch (k_gateup_down): the balanced gate/up image over n_wg workgroups + the classic
+// down_proj image as N/64 row-groups x ksplit.  counter: a zeroed device int per launch and step.
+int lk_gateup_down(hipStream_t st, const void* wgu, const void* xp, int F, int K, int n_wg, void* act_xp, const void* wdown, int N,
+                   int ksplit, float* slabs, int* counter, int dd) {
+    GemmRArgs ra{}; ra.g.kskew = 0; ra.g.wp = (const bf16_t*)wgu; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act_xp;
+    ra.R = F / n_wg; if (F % n_wg || ra.R > 64 || ra.R <= 32 || (N % 64) || (F % 16) || !counter) return -1;
+    fill_nv(ra, ra.R, 2, 2);
+    GemmArgs d{}; d.wp = (const bf16_t*)wdown; d.xp = (const bf16_t*)act_xp; d.K16 = F / 16; d.N = N; d.slabs = slabs;
+    const int gx = N / 64, n_dn = gx * ksplit;
+    if (lk_gemm64r_init() != 0) return -1;
+#define GD(DD) k_gateup_down<2, DD><<<n_wg + n_dn, 512, 8 * 4 * 4096, st>>>(ra.g.wp, ra.g.xp, ra.g.K16, 0, ra.wg_chunks, \
+        ((unsigned)ra.nvl[0] | ((unsigned)ra.nvl[1] << 8) | ((unsigned)ra.nvl[2] << 16) | ((unsigned)ra.nvl[3] << 24)), \
+        ra.boff[0], ra.boff[1], ra.boff[2], ra.boff[3], n_wg, ra, d, gx, ksplit, counter)
+    if (dd == 8) GD(8); else GD(4);
+#undef GD
+    LAUNCH_CHECK(); return 0;
+}
 static bool g_attr_done = false;
 int lk_gemm64r_init() {
     if (g_attr_done) return 0;
@@ -1907,6 +1995,8 @@ int lk_gemm64r_init() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<2, EPI_QKV, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 2 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_SWIGLU, 4, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<2, EPI_QKV, 8, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 2 * 4096);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gateup_down<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gateup_down<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
     if (e != hipSuccess) return (int)e;
     g_attr_done = true;
     return 0;

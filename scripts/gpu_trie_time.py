@@ -18,7 +18,7 @@ t0 = time.time()
 for q in qs: cache.hier_get_packed(q, 64, 12, 0, 32, 'mix', 0)
 th = (time.time() - t0) / 256
 t0 = time.time(); dev = DeviceTrie(cache, idx=0); torch.cuda.synchronize(); tm = time.time() - t0
-print(f'host hier_get: {th*1e6:.1f} us/query; mirror export+upload: {tm*1e3:.2f} ms for {dev.n_nodes} nodes')
+print(f'host hier_get: {th*1e6:.1f} us/query; mirror export+upload: {tm*1e3:.2f} ms for {dev.n_records} nodes')
 for B in (1, 8, 64, 256):
     dev.hier_get(qs[:B], 64, 12, 0, 32, 'mix')
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

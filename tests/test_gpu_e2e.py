@@ -307,6 +307,37 @@ def test_fused_norm_gemm_launches_are_bitwise_identical_to_separate_kernels():
         assert torch.equal(o[3][:1], outs[0][3][:1]) and torch.equal(o[4][:1], outs[0][4][:1])
 
 
+def test_role_fused_gateup_down_launch_is_bitwise_identical():
+    """cfg.fuse bits 2/3 (k_gateup_down): gate/up + SwiGLU and the split-K down_proj as ONE launch — the down role's workgroups
+    are dispatched as gate/up's exit, hold their first weight tile-sets in flight while they wait for act (agent-scope
+    release / counter / acquire), then run the same arithmetic in the same order.  Logits of ALL rows, accepted tokens and the
+    hidden state must equal the two-launch path bit for bit, graph and eager, over several steps (a stale act line or a flag
+    that overtakes its data would show here)."""
+    from painlessinferenceacceleration_amd.llama_engine import random_weights
+    shape = LlamaShape(4, 4096, 32, 32, 11008, 32000, 1e-5)
+    rs = np.random.RandomState(15)
+    prompt = rs.randint(3, 32000, size=100).tolist()
+    trees = [(random_tree(rs, 64)[1], rs.randint(3, 32000, size=64).astype(np.int32)) for _ in range(6)]
+    # the down role runs the 8-wave slab kernel (4 or 8 tile-sets in flight): the two-launch reference is the engine with that
+    # down_proj variant (gemm_cfg[4] = 2 | variant << 8), whose waves split K the same way — same summation order
+    for fuse, variant in ((4, 4), (12, 3)):
+        outs = []
+        for f in (0, fuse):
+            eng = LlamaVerifyEngine(shape, random_weights(shape, seed=4, std=0.02, device='cuda:0'), max_length=1024, fuse=f,
+                                    gemm_cfg=[0, 0, 0, 0, 2 | (variant << 8), 0, 0, 0], consume_state_dict=True)
+            eng.prefill(prompt)
+            rec = []
+            for i, (rows, ids) in enumerate(trees):
+                toks, n = eng.step(ids, rows, eager=(i % 2 == 1))
+                rec.append((toks, n, eng.logits().clone(), eng.hidden().clone()))
+            outs.append(rec)
+            del eng
+            torch.cuda.empty_cache()
+        for a, b in zip(outs[1], outs[0]):
+            assert a[0] == b[0] and a[1] == b[1]
+            assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+
+
 def test_idle_window_prefetch_is_bitwise_neutral():
     """la_debug_set keys 7 / 8 / 9: the gate/up launch's tail loads (down_proj image) and the extra workgroups appended to the row kernels and to the attention combine only READ the next
     GEMM's first k-tiles (planned QKV / gate-up / lm_head images, classic o_proj image).  At the Llama-2-7B layer shape and on the
