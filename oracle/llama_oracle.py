@@ -85,6 +85,7 @@ class OracleLlama(object):
         cos, sin = cos[None, None], sin[None, None]
         new_past = []
         self.router_trace = []
+        self.hidden_trace = []
         cf = bool(getattr(s, 'norm_cast_first', False))
         for i in range(s.n_layers):
             p = f'model.layers.{i}.'
@@ -116,6 +117,8 @@ class OracleLlama(object):
                 g = torch.nn.functional.silu(lin(x, w[p + 'mlp.gate_proj.weight']))
                 u = lin(x, w[p + 'mlp.up_proj.weight'])
                 h = h + lin(g * u, w[p + 'mlp.down_proj.weight'])
+            if getattr(self, 'trace_hidden', False):                           # tests: residual stream after every layer
+                self.hidden_trace.append(h[0].clone())
         h = _rms(h, w['model.norm.weight'], s.rms_eps, cf)
         return lin(h, w['lm_head.weight'])[0], new_past
 

@@ -12,6 +12,7 @@
 #include "la_kernels.h"
 #include "la_mblock.h"
 extern int g_la_pf_kib, g_la_pf_delay, g_la_pf_tail_kib, g_la_graph_epoch, g_la_graph_reps, g_la_mb_ks2;
+int g_la_stop_layers = 0;     // la_debug_set key 13 (parity tests): the single-sequence step runs only the first n layers, then the final norm + lm_head
 
 extern void la_set_error(const std::string& s);
 
@@ -217,7 +218,7 @@ static size_t carve(la_llama* m, char* base) {
         const size_t E = (size_t)c.n_experts;
         m->mb_moe_acc = cv.take<uint16_t>(E ? R * c.hidden : 8);
         m->mb_act_ex = cv.take<uint16_t>(E ? E * R * c.ffn : 8);
-        m->mb_route_w = cv.take<float>(E ? R * LA_MOE_MAX_E : 8);
+        m->mb_route_w = cv.take<float>(E ? (size_t)c.n_layers * R * LA_MOE_MAX_E : 8);    // [layer][M][8]: kept per layer (parity tests force the oracle's routing with them)
         m->mb_slabs_ex = cv.take<float>(E ? E * m->down_ks * R * c.hidden : 8);
         m->mb_moe_perm = cv.take<int>(E ? E * LA_MB_MAX * 64 : 8);
         m->mb_moe_pos = cv.take<int>(E ? R * LA_MOE_MAX_E : 8);
@@ -377,7 +378,10 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
     PfDesc pd{};
     pf_qkv(0, &pd);
     KCHK(lk_embed_norm(st, m->w.embed, m->ids, m->layers[0].norm1, c.hidden, c.rms_eps, m->h, m->xp, cf, &pd));
-    for (int l = 0; l < c.n_layers; ++l) {
+    // depth probe (la_debug_set key 13): the first nl layers, then the FINAL norm + lm_head — h / logits after nl layers for the
+    // per-depth parity test (tests/test_gpu_e2e.py::test_full_size_llama7b_32_layers_vs_oracle); 0 = the whole model
+    const int nl = (!batch && g_la_stop_layers > 0 && g_la_stop_layers < c.n_layers) ? g_la_stop_layers : c.n_layers;
+    for (int l = 0; l < nl; ++l) {
         const la_llama_layer_weights& L = m->layers[l];
         uint16_t* kf = m->kfresh + (size_t)l * m->fresh_layer_elems;
         uint16_t* vf = m->vfresh + (size_t)l * m->fresh_layer_elems;
@@ -410,7 +414,7 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
         P(KC_O);
         KCHK(lk_gemm64_slab(st, L.wo, m->attn_xp, c.hidden, m->o_k, m->o_rb, m->o_ks, m->slabs));
         P(KC_OTHER);
-        const void* nw = (l + 1 < c.n_layers) ? m->layers[l + 1].norm1 : m->w.final_norm;
+        const void* nw = (l + 1 < nl) ? m->layers[l + 1].norm1 : m->w.final_norm;
         if (c.n_experts > 0) {
             // sparse MoE MLP: router fused into the norm, then per expert {gate/up+SwiGLU, down, weighted accumulate};
             // an expert no row routes to costs three empty launches and no weight traffic
@@ -480,8 +484,8 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
         KCHK(lk_gemm64_slab(st, L.wdown, m->act_xp, c.hidden, c.ffn, m->down_rb, m->down_ks, m->slabs));
         P(KC_OTHER);
     after_down:
-        if (!((m->fuse & 2) && l + 1 < c.n_layers)) {        // otherwise fused into the next layer's QKV launch
-            if (l + 1 < c.n_layers) pf_qkv(l + 1, &pd);
+        if (!((m->fuse & 2) && l + 1 < nl)) {        // otherwise fused into the next layer's QKV launch
+            if (l + 1 < nl) pf_qkv(l + 1, &pd);
             else {
                 pd = PfDesc{};
                 if (pf_kib > 0 && c.balanced_wg[2] > 0) lk_pf_planned(&pd, m->w.lm_head, 0, c.vocab, c.hidden, c.balanced_wg[2], pf_kib, pf_dly, nullptr);
@@ -615,28 +619,29 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk) {
         if (c.n_experts > 0) {
             // sparse MoE MLP over M rows: router fused into the norm; per expert {gate/up + SwiGLU, down} over ALL rows (an expert no
             // row routes to returns at once and its weights are never read), then the weighted accumulation in expert order
+            float* const route_w = m->mb_route_w + (size_t)l * LA_MB_MAX * 64 * LA_MOE_MAX_E;
             KCHK(lk_mb_resid_norm_router(st, m->mb_h, m->mb_slabs, m->o_ks, npass_rows, L.norm2, c.hidden, c.rms_eps, m->mb_xp, M, cf,
-                                         L.router, c.n_experts, c.top_k, m->mb_route_w, m->mb_meta));
+                                         L.router, c.n_experts, c.top_k, route_w, m->mb_meta));
             const size_t act_stride = (size_t)LA_MB_MAX * 64 * c.ffn, slab_stride = (size_t)m->down_ks * npass_rows * c.hidden;
             // M >= 128: every expert works on the rows it received, packed into their own blocks (la_mblock.hip "Gathered MoE")
             const bool gathered = nblk >= 2;
             const long xg_stride = (long)LA_MB_MAX * 64 * c.hidden;
             if (gathered) {
-                KCHK(lk_mb_moe_plan(st, m->mb_route_w, M, c.n_experts, m->mb_moe_perm, m->mb_moe_pos, m->mb_moe_cnt));
+                KCHK(lk_mb_moe_plan(st, route_w, M, c.n_experts, m->mb_moe_perm, m->mb_moe_pos, m->mb_moe_cnt));
                 KCHK(lk_mb_moe_gather(st, m->mb_xp, m->mb_moe_perm, m->mb_moe_cnt, c.hidden, nblk, c.n_experts, m->mb_xg, xg_stride));
             }
             for (int e = 0; e < c.n_experts; ++e) {
                 MbGemm g{}; g.wp = m->ex_gateup[(size_t)l * c.n_experts + e]; g.xp = gathered ? m->mb_xg + e * xg_stride : m->mb_xp;
                 g.N = c.ffn; g.K = c.hidden; g.nblk = nblk;
                 g.n_wg = c.balanced_wg[1]; g.ksplit = 1; g.act_xp = m->mb_act_ex + e * act_stride;
-                if (gathered) g.nblk_dev = m->mb_moe_cnt + LA_MOE_MAX_E + e; else g.route_col = m->mb_route_w + e;
+                if (gathered) g.nblk_dev = m->mb_moe_cnt + LA_MOE_MAX_E + e; else g.route_col = route_w + e;
                 KCHK(lk_mb_gemm(st, 1, g));
                 MbGemm d{}; d.wp = m->ex_down[(size_t)l * c.n_experts + e]; d.xp = m->mb_act_ex + e * act_stride; d.N = c.hidden; d.K = c.ffn;
                 d.nblk = nblk; d.ksplit = m->down_ks; d.slabs = m->mb_slabs_ex + e * slab_stride; d.slab_rows = npass_rows;
-                if (gathered) d.nblk_dev = m->mb_moe_cnt + LA_MOE_MAX_E + e; else d.route_col = m->mb_route_w + e;
+                if (gathered) d.nblk_dev = m->mb_moe_cnt + LA_MOE_MAX_E + e; else d.route_col = route_w + e;
                 KCHK(lk_mb_gemm(st, 0, d));
             }
-            KCHK(lk_mb_moe_accum(st, m->mb_slabs_ex, (long)slab_stride, m->down_ks, npass_rows, m->mb_route_w, c.n_experts, c.hidden,
+            KCHK(lk_mb_moe_accum(st, m->mb_slabs_ex, (long)slab_stride, m->down_ks, npass_rows, route_w, c.n_experts, c.hidden,
                                  m->mb_moe_acc, M, gathered ? m->mb_moe_pos : nullptr));
             KCHK(lk_mb_resid_norm_addend(st, m->mb_h, m->mb_moe_acc, nw, c.hidden, c.rms_eps, m->mb_xp, M, cf));
             continue;

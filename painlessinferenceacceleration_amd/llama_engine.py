@@ -785,6 +785,11 @@ class LlamaVerifyEngine(object):
         L = self.shape.n_layers
         return self._view(9, L * 64 * _lib.LA_MOE_MAX_E * 4, torch.float32).view(L, 64, _lib.LA_MOE_MAX_E)
 
+    def mroute_weights(self):
+        """fp32 [n_layers][LA_MB_MAX * 64][8]: routing weights of the last multi-block step (row = 64 * block + block row)"""
+        L = self.shape.n_layers
+        return self._view(14, L * _lib.LA_MB_MAX * 64 * _lib.LA_MOE_MAX_E * 4, torch.float32).view(L, _lib.LA_MB_MAX * 64, _lib.LA_MOE_MAX_E)
+
     def profile_gateup(self, iters=5):
         """mean ms of one gate/up launch, every layer's launch back to back inside one HIP-event pair (la_llama_profile_gateup)"""
         ms = C.c_float(0)

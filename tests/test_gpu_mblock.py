@@ -496,3 +496,152 @@ def test_wide_tree_host_commit_equals_device_commit():
     for e in engs:
         e.tstep(nxt, rm2, mode=2)
     assert torch.equal(engs[0].mlogits()[:71], engs[1].mlogits()[:71])
+
+
+# ---- round 3: the multi-block step at the BENCHMARKED shapes against the oracle (2-layer slices, stated 2e-2) ---------------
+def _window_prefill(oracle, prompt):
+    """The prompt through the oracle in 64-token chains, as the engine's blocks: the oracle applies shape.sliding_window to the
+    COMMITTED keys of a call (positions come from the mask row sums, so the rule cannot be written into the mask itself);
+    inside a 64-token piece the window (>= 64) never bites."""
+    past, nk, lg = None, 0, None
+    for s0 in range(0, len(prompt), 64):
+        blk = prompt[s0:s0 + 64]
+        n = len(blk)
+        full = torch.cat([torch.ones((n, nk), dtype=torch.long), torch.tril(torch.ones((n, n), dtype=torch.long))], 1)
+        lg, past = oracle.forward(torch.tensor(blk), full, past)
+        nk += n
+    return lg, past
+
+
+def test_mstep_mistral_shape_b8_window_ring_paired_launches_vs_oracle():
+    """BASELINE config 3 as the driver benchmarks it, two layers deep: Mistral-7B layer shape (GQA 32 / 8 heads, ffn 14336,
+    Mistral RMSNorm flavour, models/mistral/modeling_mistral.py:236-318), B = 8 sequences -> 512 rows in one pass (wide GEMMs
+    with the paired QKV / slab launches, the default), sliding window with the KV cache as a RING (cfg.kv_ring), contexts
+    shorter than, crossing and far beyond the window, two of them long enough to wrap the ring.  Every block vs the oracle run
+    on that sequence alone (window rule included), then a second step over the caches the first one committed."""
+    torch.set_num_threads(8)
+    W = 160
+    shape = LlamaShape(2, 4096, 32, 8, 14336, 32000, 1e-5, norm_cast_first=True, sliding_window=W)
+    sd = random_weights(shape, seed=9, device='cpu')
+    B = 8
+    eng = LlamaVerifyEngine(shape, sd, max_length=1200, n_slots=B, max_blocks=B, kv_ring=True)
+    assert eng.kv_ring and eng.max_keys == 736
+    assert lib.la_debug_get(6) & 1, 'the paired wide launches are the default'
+    oracle = lo.OracleLlama(shape, sd)
+    rs = np.random.RandomState(21)
+    lens = [40, 150, 170, 300, 90, 800, 230, 1000]          # < W, ~W, > W, >> W; 800 / 1000 wrap the 736-row ring
+    pasts, nk, last = [], [], []
+    for b, P in enumerate(lens):
+        p = rs.randint(3, shape.vocab, size=P).tolist()
+        tok = eng.mprefill(b, p)
+        lg, past = _window_prefill(oracle, p)
+        top = torch.topk(lg[-1].float(), 2).values
+        if float(top[0] - top[1]) > 4 * TOL * float(lg[-1].float().abs().max()):
+            assert tok == int(lg[-1].float().argmax()), b
+        pasts.append(past); nk.append(P); last.append(tok)
+    for step in range(2):
+        blocks, trees = [], []
+        for b in range(B):
+            T = 64 if b in (0, 5) else int(rs.randint(8, 65))
+            _, rows = random_tree(rs, T)
+            ids = np.concatenate([[last[b]], rs.randint(3, shape.vocab, size=T - 1)]).astype(np.int32)
+            blocks.append((b, ids, rows, 0, 16))
+            trees.append((ids, rows, T))
+        outs = eng.mstep(blocks)
+        mo = eng.mout().cpu().numpy()
+        for b in range(B):
+            ids, rows, T = trees[b]
+            mask = _mask_from_rows(rows, T)
+            full = torch.cat([torch.ones((T, nk[b]), dtype=torch.long), torch.from_numpy(mask)], 1)
+            lg, past_all = oracle.forward(torch.tensor(ids.tolist()), full, pasts[b])
+            _check_rows(eng.mlogits()[b * 64:b * 64 + T], lg, range(T), f'Mistral-shape step {step} block {b} (ctx {nk[b]})')
+            am = mo[_lib.LA_MOUT_ARGMAX + 64 * b:_lib.LA_MOUT_ARGMAX + 64 * b + T].tolist()
+            exp_toks, exp_rows = lo.accept_scan(ids.tolist(), mask, am)
+            assert outs[b] == exp_toks[:16], (step, b)
+            idx = torch.tensor(list(range(nk[b])) + [nk[b] + r for r in exp_rows[:16]], dtype=torch.long)
+            pasts[b] = [(k[:, idx], v[:, idx]) for k, v in past_all]
+            nk[b] += len(exp_rows[:16])
+            last[b] = exp_toks[:16][-1]
+            assert eng.slot_keys[b] == nk[b]
+
+
+def test_mstep_llama13b_shape_b4_vs_oracle():
+    """BASELINE config 4's per-GPU share, two layers deep: Llama-2-13B layer shape (hidden 5120 -> 3 K splits of the slab GEMMs,
+    40 heads -> one key split and no combine launch at 4 blocks, ffn 13824), 4 sequences x 64 rows = 256 rows per pass."""
+    torch.set_num_threads(8)
+    shape = LlamaShape(2, 5120, 40, 40, 13824, 32000, 1e-5)
+    sd = random_weights(shape, seed=10, device='cpu')
+    eng = LlamaVerifyEngine(shape, sd, max_length=512, n_slots=4, max_blocks=4)
+    oracle = lo.OracleLlama(shape, sd)
+    rs = np.random.RandomState(22)
+    blocks, refs = [], []
+    for b in range(4):
+        p = rs.randint(3, shape.vocab, size=int(rs.randint(30, 330))).tolist()
+        tok = eng.mprefill(b, p)
+        _, past = _oracle_seq(oracle, p)
+        T = 64 if b == 0 else int(rs.randint(8, 65))
+        _, rows = random_tree(rs, T)
+        ids = np.concatenate([[tok], rs.randint(3, shape.vocab, size=T - 1)]).astype(np.int32)
+        blocks.append((b, ids, rows, 0, 16))
+        full = torch.cat([torch.ones((T, len(p)), dtype=torch.long), torch.from_numpy(_mask_from_rows(rows, T))], 1)
+        refs.append((oracle.forward(torch.tensor(ids.tolist()), full, past)[0], T))
+    eng.mstep(blocks)
+    for b, (lg, T) in enumerate(refs):
+        _check_rows(eng.mlogits()[b * 64:b * 64 + T], lg, range(T), f'13B-shape block {b}')
+
+
+def test_mstep_mixtral_gathered_experts_vs_oracle_with_forced_routing():
+    """BASELINE config 5's path — the multi-block Mixtral step with GATHERED experts (k_moe_plan_mb / k_moe_gather_mb, rows packed
+    per expert, MixtralSparseMoeBlock.forward, models/mixtral/modeling_mixtral.py:692-759) — against the ORACLE, not against the
+    repo's own 64-row path: top-k routing is discontinuous, so (as tests/test_gpu_moe.py does for the 64-row path) ALL rows of
+    every block are compared with the oracle re-run under the engine's own routing (forced_routing = the step's per-layer routing
+    weights), and on decisively routed rows the engine must pick the oracle's experts."""
+    from tests.tiny_model import moe_shape, moe_weights, TINY_MOE
+    shape = moe_shape(TINY_MOE)
+    sd = {k: v.to(torch.bfloat16) for k, v in moe_weights(TINY_MOE, seed=3).items()}
+    B = 4
+    eng = LlamaVerifyEngine(shape, dict(sd), max_length=256, n_slots=B, max_blocks=B)
+    oracle = lo.OracleLlama(shape, sd)
+    rs = np.random.RandomState(23)
+    blocks, seqs = [], []
+    for b in range(B):
+        p = rs.randint(3, shape.vocab, size=int(rs.randint(10, 60))).tolist()
+        tok = eng.mprefill(b, p)
+        # the prompt's routing as the engine decided it (one block): the oracle's cache is built under the SAME routing, so an
+        # expert flipped on a prompt row cannot leak into the tree rows through the K/V they attend to
+        rwp = eng.mroute_weights()[:, :len(p), :shape.n_experts].cpu().clone()
+        T = 64 if b == 0 else int(rs.randint(20, 65))
+        _, rows = random_tree(rs, T)
+        ids = np.concatenate([[tok], rs.randint(3, shape.vocab, size=T - 1)]).astype(np.int32)
+        blocks.append((b, ids, rows, 0, 16))
+        seqs.append((p, ids, rows, T, rwp))
+    eng.mstep(blocks)
+    rw = eng.mroute_weights().cpu()                                       # [L][512][8]
+    n_dec = n_all = 0
+    for b, (p, ids, rows, T, rwp) in enumerate(seqs):
+        P = len(p)
+        _, past = oracle.forward(torch.tensor(p), torch.tril(torch.ones((P, P), dtype=torch.long)), None,
+                                 forced_routing=[rwp[li] for li in range(shape.n_layers)])
+        full = torch.cat([torch.ones((T, P), dtype=torch.long), torch.from_numpy(_mask_from_rows(rows, T))], 1)
+        lg_own, _ = oracle.forward(torch.tensor(ids.tolist()), full, past)
+        trace = [rl.clone() for rl in oracle.router_trace]
+        forced = [rw[li, 64 * b:64 * b + T, :shape.n_experts] for li in range(shape.n_layers)]
+        lg_forced, _ = oracle.forward(torch.tensor(ids.tolist()), full, past, forced_routing=forced)
+        got = eng.mlogits()[64 * b:64 * b + T].float().cpu()
+        err = (got - lg_forced.float()).abs().amax(-1) / lg_forced.float().abs().amax(-1)
+        assert float(err.max()) <= TOL_TINY, (b, float(err.max()), int(err.argmax()))
+        decisive = []                                                     # rows routed with a margin in EVERY layer (oracle)
+        for t in range(T):
+            ok = True
+            for rl in trace:
+                srt = torch.sort(torch.softmax(rl[t].float(), -1), descending=True).values
+                ok = ok and float(srt[shape.top_k - 1] - srt[shape.top_k]) > 0.05
+            if ok:
+                decisive.append(t)
+        n_dec += len(decisive); n_all += T
+        for li, rl in enumerate(trace):
+            sel = torch.topk(torch.softmax(rl.float(), -1), shape.top_k, -1).indices
+            for t in decisive:
+                mine = sorted(int(e) for e in torch.nonzero(forced[li][t]).flatten())
+                assert mine == sorted(sel[t].tolist()), (b, li, t)
+    assert n_dec >= 0.25 * n_all
