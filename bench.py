@@ -233,6 +233,9 @@ def main():
                     help='N=1 default workload only: comma list of model:batch legs (BASELINE configs 3-5: a 64-token tree per sequence '
                          'through la_llama_mstep) run AFTER the timed region, each in its own process; their lines are embedded under '
                          '"secondary".  "" = none')
+    ap.add_argument('--decoding-length', type=int, default=64, help='tree tokens per sequence and step (BASELINE: 64); > 64 (the reference\'s best '
+                    'published setting is 128 with --branch-length 32, lookahead/README.md:100): wide trees through eng.tstep, --batch 1')
+    ap.add_argument('--branch-length', type=int, default=12)
     ap.add_argument('--secondary-multi', default=None,
                     help='N > 1 default workload only: model:batch legs run as their own N-rank jobs after the headline (default: '
                          '"13b:4" at --gpus 8 = BASELINE config 4, Llama-2-13B bs=32 batch-sharded over 8 GPUs; "" = none)')
@@ -289,7 +292,9 @@ def main():
         shape.n_layers = args.layers
     K, W, P, B = args.steps, args.warmup, args.prompt_len, args.batch
     assert 1 <= B <= 8
-    BL, DL = 12, 64
+    BL, DL = args.branch_length, args.decoding_length
+    wide = DL > 64                       # trees wider than one 64-row block: the tree is 2-4 chained blocks of one multi-block pass (eng.tstep)
+    assert 1 <= DL <= 256 and 1 <= BL <= 39 and (not wide or B == 1), 'wide trees: --batch 1, decoding_length <= 256, branch_length <= 39'
     n_truth = (K + W + 56) * (BL + 1) + 8          # measured steps + native-loop leg (16 steps) + fixed-tree sweep (24 steps) + slack
     max_length = P + n_truth + 2 * DL
     # Mistral (config 2): the checkpoint's sliding window (4096, HF Mistral-7B-v0.1 config.json) with the KV cache as a ring of
@@ -350,7 +355,9 @@ def main():
     eng.reset()
     torch.cuda.synchronize()
     t0 = time.time()
-    if B == 1:
+    if B == 1 and wide:
+        seqs[0].append(eng.mprefill(0, seqs[0]))
+    elif B == 1:
         seqs[0].append(eng.prefill(seqs[0]))
     else:
         first = eng.mprefill_many({i: seqs[i] for i in range(B)})
@@ -389,7 +396,9 @@ def main():
         tq = time.time()
         dr = drafts_dev() if dev_trie is not None else [drafts_for(i) for i in range(B)]
         qts.append(time.time() - tq)
-        if B == 1:
+        if B == 1 and wide:
+            toks_all = [eng.tstep(dr[0][0], dr[0][1], mode=0)[0]]
+        elif B == 1:
             eng.step_async(dr[0][0], dr[0][1], mode=0)
             if pending[0]:       # N > 1, split-phase: the previous step's gather + every trie update run while the GPU verifies
                 gather.finish_into_trie(cache, BL)
@@ -443,7 +452,7 @@ def main():
         accepted_all = float(accepted)
     correct = all(seqs[i][P:P + len(truths[gidx[i]])] == truths[gidx[i]][:len(seqs[i]) - P] for i in range(B))
     native = None
-    if B == 1 and not dist_on and len(seqs[0]) + (BL + 1) * (16 + 24) < max_length - 2 * DL:
+    if B == 1 and not wide and not dist_on and len(seqs[0]) + (BL + 1) * (16 + 24) < max_length - 2 * DL:
         # informational: the same steps through the native loop (la_lookahead_decode, what lookahead_generation() uses when
         # no streamer / processor is attached).  `value` stays on the interpreter loop, which is also what N > 1 runs.
         torch.cuda.synchronize()
@@ -458,7 +467,7 @@ def main():
 
     # ---- 8(d) fixed draft-tree shape "T64/B8" with the accept sweep: the main chain equals the greedy continuation for a tokens
     sweep = None
-    if B == 1 and not dist_on and not args.pure_random:
+    if B == 1 and not wide and not dist_on and not args.pure_random:
         parent, depth, rows64 = fixed_t64b8_tree()
         truth = truths[gidx[0]]
         sweep = {}
@@ -500,7 +509,7 @@ def main():
     mean_T = float(np.mean(dls[n0:]))
     mean_acc = float(np.mean(edls[n0:]))
     W_bytes = 2 * shape.n_params_no_embed()
-    if B == 1:
+    if B == 1 and not wide:
         # dominant kernel (gate/up GEMM, k_gemm64r<4,SWIGLU,4,8>) from live HIP events on the engine's stream
         ids, rowmask = drafts_for(0)
         prof = eng.profile(ids, rowmask, iters=args.profile_iters)
@@ -542,14 +551,15 @@ def main():
         # M = 64 B rows per step: near / past the ridge -> the step is priced against BOTH roofs from its wall time;
         # per-kernel durations of the same step: profiles/r02_mblock_kernel_stats_*.txt (rocprofv3 --kernel-trace --stats)
         kv_tok = 2 * shape.n_layers * shape.n_kv_heads * shape.head_dim * 2
-        step_bytes = W_bytes + kv_tok * ctx * B + kv_tok * 64 * B + 64 * B * (shape.hidden * 2 + 8) + 64 * B * shape.vocab * 2
+        RB_ = (DL + 63) // 64 if wide else 1        # 64-row blocks per sequence (wide trees: the mean tree occupies up to DL rows)
+        step_bytes = W_bytes + kv_tok * ctx * B + kv_tok * 64 * B * RB_ + 64 * B * RB_ * (shape.hidden * 2 + 8) + 64 * B * RB_ * shape.vocab * 2
         active = shape.n_params_no_embed() - (shape.n_layers * 3 * shape.ffn * shape.hidden * max(shape.n_experts - shape.top_k, 0) if shape.n_experts else 0)
-        step_flops = 2.0 * active * 64 * B + 4.0 * shape.n_layers * shape.n_heads * shape.head_dim * 64 * B * (ctx + 64)      # MoE: the top-k experts of a row
+        step_flops = 2.0 * active * 64 * B * RB_ + 4.0 * shape.n_layers * shape.n_heads * shape.head_dim * 64 * B * RB_ * (ctx + 64)      # MoE: the top-k experts of a row
         hbm_frac = step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS
         mfma_frac = step_flops / (ms_step * 1e-3) / 1e12 / 2500.0
         bound = 'mfma' if mfma_frac >= hbm_frac else 'hbm'
         roofline = {
-            'bound': bound, 'kernel': 'whole multi-block verify step (k_gemm_wide / k_gemm_mb + k_tree_attn_mb), M = %d rows' % (64 * B),
+            'bound': bound, 'kernel': 'whole multi-block verify step (k_gemm_wide / k_gemm_mb + k_tree_attn_mb), M = %d rows' % (64 * B * RB_),
             'achieved': round(step_flops / (ms_step * 1e-3) / 1e12, 1) if bound == 'mfma' else round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
             'peak': 2500.0 if bound == 'mfma' else HBM_PEAK_GBS, 'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
             'frac': round(max(mfma_frac, hbm_frac), 4), 'traffic': None,
@@ -577,8 +587,8 @@ def main():
         'metric': 'accepted_tokens_per_sec', 'value': round(accepted_all / elapsed, 2), 'unit': 'tokens/s',
         'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': model_name + f' bf16 bs={B}/GPU lookahead verify loop, 64-token draft tree per sequence / 8-12 noisy branches '
-                               '(hier, decoding_length=64, branch_length=12), synthetic permutation-LM weights (N(0,0.02); o/down std 1e-4; '
+        'config': {'workload': model_name + f' bf16 bs={B}/GPU lookahead verify loop, {DL}-token draft tree per sequence / 8-12 noisy branches '
+                               f'(hier, decoding_length={DL}, branch_length={BL}), synthetic permutation-LM weights (N(0,0.02); o/down std 1e-4; '
                                'lm_head[pi(t)]=embed[t]) for decisive greedy margins, 512-token phrase-bank prompts',
                    'n_layers': shape.n_layers, 'prompt_len': P, 'rho': args.rho, 'copies': args.copies,
                    'parallelism': f'batch-shard x{world}, {B} sequence(s) per GPU', 'sequences': NSEQ,

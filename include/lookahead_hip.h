@@ -238,7 +238,7 @@ int la_pack_planned(void* stream, const void* d_w, const void* d_w2, const int32
                     int n_wg, void* d_out);
 int la_gemm64r_swiglu(void* stream, const void* d_wp, const void* d_xp, int F, int K, int n_wg, void* d_act_packed);
 int la_gemm64r_logits(void* stream, const void* d_wp, const void* d_xp, int V, int K, int n_wg,
-                      void* d_logits_bf16, float* d_cand_val /*[n_wg*8][64]*/, int32_t* d_cand_idx);
+                      void* d_logits_bf16, float* d_cand_val /*[n_wg][64]: one candidate per workgroup and token*/, int32_t* d_cand_idx);
 int la_gemm64r_qkv(void* stream, const void* d_wp, const void* d_xp, int n_heads, int n_kv_heads, int K, int n_wg,
                    const int32_t* d_pos, const void* d_rope_cos, const void* d_rope_sin,
                    void* d_qf, void* d_kfresh, void* d_vfresh);

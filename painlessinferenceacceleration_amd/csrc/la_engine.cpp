@@ -12,6 +12,7 @@
 #include "la_kernels.h"
 #include "la_mblock.h"
 extern int g_la_pf_kib, g_la_pf_delay, g_la_pf_tail_kib, g_la_graph_epoch, g_la_graph_reps, g_la_mb_ks2;
+int g_la_split_head_tail = 0;   // la_debug_set key 14: 1 = separate build-inputs / embed / argmax / accept / publish kernels (A/B)
 int g_la_stop_layers = 0;     // la_debug_set key 13 (parity tests): the single-sequence step runs only the first n layers, then the final norm + lm_head
 
 extern void la_set_error(const std::string& s);
@@ -364,7 +365,7 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
     auto P = [&](int cls) { if (pf) pf->mark(cls); };
     P(KC_OTHER);
     if (batch) KCHK(lk_build_tree_inputs_b(st, m->bin, m->bstate, m->pos, m->rowmask, m->ids));
-    else KCHK(lk_build_tree_inputs(st, zc_in ? (const int*)zc_in : m->in, m->state, m->pos, m->rowmask, m->ids));
+    else if (g_la_split_head_tail) KCHK(lk_build_tree_inputs(st, zc_in ? (const int*)zc_in : m->in, m->state, m->pos, m->rowmask, m->ids));
     const int cf = c.norm_cast_first;
     if (m->fuse) HIPCHK(hipMemsetAsync(m->fuse_cnt, 0, sizeof(int) * 3 * c.n_layers, st));
     // Idle-window weight prefetch (la_kernels.h, PfDesc): the row kernels and the attention combine carry extra workgroups that
@@ -377,7 +378,13 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
     };
     PfDesc pd{};
     pf_qkv(0, &pd);
-    KCHK(lk_embed_norm(st, m->w.embed, m->ids, m->layers[0].norm1, c.hidden, c.rms_eps, m->h, m->xp, cf, &pd));
+    // single-sequence step: input expansion + embedding row kernel in ONE launch (k_step_head); la_debug_set key 14 = 1 restores
+    // the separate kernels of rounds 1-2 (A/B measurements)
+    if (!batch && !g_la_split_head_tail)
+        KCHK(lk_step_head(st, zc_in ? (const int*)zc_in : m->in, m->state, m->pos, m->rowmask, m->ids, m->w.embed, m->layers[0].norm1,
+                          c.hidden, c.rms_eps, m->h, m->xp, cf, &pd));
+    else
+        KCHK(lk_embed_norm(st, m->w.embed, m->ids, m->layers[0].norm1, c.hidden, c.rms_eps, m->h, m->xp, cf, &pd));
     // depth probe (la_debug_set key 13): the first nl layers, then the FINAL norm + lm_head — h / logits after nl layers for the
     // per-depth parity test (tests/test_gpu_e2e.py::test_full_size_llama7b_32_layers_vs_oracle); 0 = the whole model
     const int nl = (!batch && g_la_stop_layers > 0 && g_la_stop_layers < c.n_layers) ? g_la_stop_layers : c.n_layers;
@@ -498,7 +505,15 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
     if (c.balanced_wg[2] > 0) {
         KCHK(lk_gemm64r_logits(st, m->w.lm_head, m->xp, c.vocab, c.hidden, c.balanced_wg[2], m->logits, m->cand_val, m->cand_idx));
         P(KC_OTHER);
-        KCHK(lk_argmax_finalize(st, m->cand_val, m->cand_idx, c.balanced_wg[2] * 8, am_rows));
+        if (!batch && !g_la_split_head_tail) {
+            // argmax finalize + accept walk + result hand-over in ONE launch, the KV commit after it: the host reads the accepted
+            // tokens (and starts its trie update / next query) while the commit kernel still runs
+            KCHK(lk_step_tail(st, m->cand_val, m->cand_idx, c.balanced_wg[2], m->ids, m->rowmask, m->state, (int*)zc_out));
+            KCHK(lk_kv_commit(st, m->kfresh, m->vfresh, m->kmain, m->vmain, m->state, c.n_layers, c.n_kv_heads, m->total_keys, ring));
+            P(KC_N);
+            return LA_OK;
+        }
+        KCHK(lk_argmax_finalize(st, m->cand_val, m->cand_idx, c.balanced_wg[2], am_rows));
     } else {
         KCHK(lk_gemm64_logits(st, m->w.lm_head, m->xp, c.vocab, c.hidden, m->lm_rb, m->logits, m->cand_val, m->cand_idx));
         P(KC_OTHER);

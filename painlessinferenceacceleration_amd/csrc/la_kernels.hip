@@ -81,7 +81,7 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 // load of the row (h, NS slabs, norm weight) is issued before the first use: one memory round trip, not NS+2.
 template <int NS, bool MOE>
 __device__ __forceinline__ void row_norm_body(const int t, float* sh, float (*shr)[LA_MOE_MAX_E],
-                                              const bf16_t* __restrict__ embed, const int* __restrict__ ids,
+                                              const bf16_t* __restrict__ embed_row,
                                               bf16_t* __restrict__ h, const float* __restrict__ slabs,
                                               const bf16_t* __restrict__ nw, int hidden, float eps,
                                               bf16_t* __restrict__ xp, const bf16_t* __restrict__ addend,
@@ -89,7 +89,7 @@ __device__ __forceinline__ void row_norm_body(const int t, float* sh, float (*sh
                                               float* __restrict__ route_w, const int* __restrict__ n_rows,
                                               int cast_first) {
     const int nchunk = hidden >> 3;
-    const bf16_t* src = embed ? embed + (size_t)ids[t] * hidden : h + (size_t)t * hidden;
+    const bf16_t* src = embed_row ? embed_row : h + (size_t)t * hidden;         // embedding row of the token, or the residual row
     bf16x8 hv[2], wv[2], av[2];
     bf16x8 gwv[MOE ? LA_MOE_MAX_E : 1][2];          // router rows: requested with everything else (one memory round trip)
     f32x4 sl[NS > 0 ? NS : 1][2][2];
@@ -271,8 +271,33 @@ __global__ __launch_bounds__(512) void k_row_norm(const bf16_t* __restrict__ emb
     __shared__ float sh[8];
     __shared__ float shr[MOE ? 8 : 1][LA_MOE_MAX_E];
     if (blockIdx.x >= LA_TB) { pf_body(pf, (int)blockIdx.x - LA_TB); return; }      // appended idle-window prefetch workgroups
-    row_norm_body<NS, MOE>(blockIdx.x, sh, shr, embed, ids, h, slabs, nw, hidden, eps, xp, addend, wrouter, n_experts, top_k,
-                           route_w, n_rows, cast_first);
+    row_norm_body<NS, MOE>(blockIdx.x, sh, shr, embed ? embed + (size_t)ids[blockIdx.x] * hidden : nullptr, h, slabs, nw, hidden, eps,
+                           xp, addend, wrouter, n_experts, top_k, route_w, n_rows, cast_first);
+}
+
+// Step head (single-sequence step): k_build_tree_inputs + the embedding row kernel in ONE launch.  Workgroup t expands its own
+// row of the step input (ids / 64-bit ancestor mask / position = committed keys + popcount - 1, the model hook of
+// modeling_llama.py:584-588; pad rows t >= T see themselves only) straight from the caller's input block — the zero-copy pinned
+// host block of la_llama_step — and runs the embedding gather + RMSNorm of that row; workgroup 0 also latches T and the mode.
+__global__ __launch_bounds__(512) void k_step_head(const int* __restrict__ in, int* __restrict__ state, int* __restrict__ pos,
+                                                    unsigned long long* __restrict__ rowmask, int* __restrict__ ids,
+                                                    const bf16_t* __restrict__ embed, bf16_t* __restrict__ h,
+                                                    const bf16_t* __restrict__ nw, int hidden, float eps, bf16_t* __restrict__ xp,
+                                                    int cast_first, PfDesc pf) {
+    __shared__ float sh[8];
+    if (blockIdx.x >= LA_TB) { pf_body(pf, (int)blockIdx.x - LA_TB); return; }
+    const int t = blockIdx.x;
+    const int T = in[LA_IN_T];
+    const unsigned long long rm = (t < T) ? ((const unsigned long long*)(in + LA_IN_ROWMASK))[t] : (1ull << t);
+    const int id = (t < T) ? in[LA_IN_IDS + t] : 0;
+    if (threadIdx.x == 0) {
+        rowmask[t] = rm;
+        ids[t] = id;
+        pos[t] = state[LA_ST_NKEYS] + __popcll(rm) - 1;
+        if (t == 0) { state[LA_ST_T] = T; state[LA_ST_MODE] = in[LA_IN_MODE]; }
+    }
+    row_norm_body<0, false>(t, sh, nullptr, embed + (size_t)id * hidden, h, nullptr, nw, hidden, eps, xp, nullptr, nullptr, 0, 0,
+                            nullptr, nullptr, cast_first);
 }
 
 // In-kernel hand-over from the 64 producer workgroups (lowest block ids, dispatched first, so a consumer never waits on a
@@ -706,7 +731,7 @@ __device__ __forceinline__ void gemm64r_body(const bf16_t* __restrict__ wp_s, co
             static_assert(NW == 8, "the fused row kernel is written for 512 threads");
             const bool producer = bp.bx < LA_TB;
             if (producer) {
-                row_norm_body<NSF, false>(bp.bx, redr, nullptr, nullptr, nullptr, ra.fn_h, ra.fn_slabs, ra.fn_nw,
+                row_norm_body<NSF, false>(bp.bx, redr, nullptr, nullptr, ra.fn_h, ra.fn_slabs, ra.fn_nw,
                                           ra.fn_hidden, ra.fn_eps, (bf16_t*)xp_s, nullptr, nullptr, 0, 0, nullptr, nullptr,
                                           ra.fn_cast);
                 handover_signal(ra.fn_counter);
@@ -934,11 +959,28 @@ __device__ __forceinline__ void gemm64r_body(const bf16_t* __restrict__ wp_s, co
             int oi = __shfl_xor(bidx, 32, 64);
             if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
             if (hh == 0) {
-                const size_t slot = (size_t)bp.bx * NW + wave;
-                a.cand_val[slot * LA_TB + tok] = best;
-                a.cand_idx[slot * LA_TB + tok] = bidx;
+                // park the wave's candidate of this token: [wave][64] pairs behind the reduction buffer (lk_gemm64r_logits adds
+                // LA_CAND_LDS bytes of dynamic LDS); ONE candidate per (workgroup, token) leaves the kernel (round 2: one per wave)
+                float* cl = redr + NW * RB * 16 * 64;
+                cl[(wave * LA_TB + tok) * 2] = best;
+                ((int*)cl)[(wave * LA_TB + tok) * 2 + 1] = bidx;
             }
             best = -INFINITY; bidx = 0x7fffffff;
+        }
+    }
+    if constexpr (EPI == EPI_LOGITS) {
+        __syncthreads();
+        if (wave == 0) {
+            const float* cl = redr + NW * RB * 16 * 64;
+            float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float v = cl[(w * LA_TB + lane) * 2];
+                const int i = ((const int*)cl)[(w * LA_TB + lane) * 2 + 1];
+                if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+            }
+            a.cand_val[(size_t)bp.bx * LA_TB + lane] = bv;
+            a.cand_idx[(size_t)bp.bx * LA_TB + lane] = bi;
         }
     }
     if constexpr (EPI == EPI_SWIGLU && NSF == 0) {
@@ -1526,12 +1568,10 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float* __restrict__ 
 // emitted tokens = argmax along the path (matches + 1 bonus).  mode 1 (prefill chain): commit all T rows
 // and emit argmax of the last row (pretrained_model.py:783-798).
 // ---------------------------------------------------------------------------------------------
-__global__ void k_accept_scan(const int* __restrict__ ids, const unsigned long long* __restrict__ rowmask,
-                              int* __restrict__ state) {
-    const int j = threadIdx.x;   // 64 threads
+__device__ __forceinline__ void accept_walk(const int j, const int am, const int* __restrict__ ids,
+                                            const unsigned long long* __restrict__ rowmask, int* __restrict__ state) {
     const int T = state[LA_ST_T], mode = state[LA_ST_MODE];
     const int nkeys = state[LA_ST_NKEYS];
-    const int am = state[LA_ST_ARGMAX + j];
     int n_commit;
     if (mode == 2) {            // verify only: the host walks the tree (sequential logits processors) and commits later
         if (j == 0) state[LA_ST_NOUT] = 0;
@@ -1571,6 +1611,53 @@ __global__ void k_accept_scan(const int* __restrict__ ids, const unsigned long l
         state[LA_ST_NCOMMIT] = n_commit;
         state[LA_ST_NKEYS] = nkeys + n_commit;
     }
+}
+
+// Step tail (single-sequence step): k_argmax_finalize + k_accept_scan + k_publish in ONE launch of one workgroup.
+// 1024 threads = 64 tokens x 16 candidate strides; the per-token winners meet in LDS (lowest vocabulary index wins ties, as
+// torch.argmax), wave 0 walks the tree (accept_walk: the body of k_accept_scan) and the result block goes to the caller's
+// pinned host block BEFORE the KV commit kernel runs: the host's trie update / next query overlap the commit.
+__device__ __forceinline__ void accept_walk(const int j, const int am, const int* __restrict__ ids,
+                                            const unsigned long long* __restrict__ rowmask, int* __restrict__ state);
+__global__ __launch_bounds__(1024) void k_step_tail(const float* __restrict__ cv, const int* __restrict__ ci, int n_tiles,
+                                                     const int* __restrict__ ids, const unsigned long long* __restrict__ rowmask,
+                                                     int* __restrict__ state, int* __restrict__ host_out) {
+    __shared__ float sv[16][64];
+    __shared__ int si[16][64];
+    const int tok = threadIdx.x & 63, part = threadIdx.x >> 6;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int i = part; i < n_tiles; i += 16) {
+        const float v = cv[(size_t)i * LA_TB + tok];
+        const int idx = ci[(size_t)i * LA_TB + tok];
+        if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
+    }
+    sv[part][tok] = best; si[part][tok] = bidx;
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+        for (int p = 1; p < 16; ++p) {
+            const float v = sv[p][tok]; const int idx = si[p][tok];
+            if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
+        }
+        state[LA_ST_ARGMAX + tok] = bidx;
+        accept_walk(tok, bidx, ids, rowmask, state);
+    }
+    if (!host_out) return;
+    __threadfence();                    // wave 0's state words are visible to the other waves of the block after the barrier
+    __syncthreads();
+    const int j = threadIdx.x;
+    int seq = 0;
+    if (j == 0) { seq = state[LA_ST_SEQ] + 1; state[LA_ST_SEQ] = seq; }
+    if (j < LA_ST_OUTTOK + 64 && j != LA_ST_SEQ) host_out[j] = __hip_atomic_load(state + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    if (j == 0) __hip_atomic_store(host_out + LA_ST_SEQ, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void k_accept_scan(const int* __restrict__ ids, const unsigned long long* __restrict__ rowmask,
+                              int* __restrict__ state) {
+    accept_walk((int)threadIdx.x, state[LA_ST_ARGMAX + threadIdx.x], ids, rowmask, state);      // 64 threads
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1760,6 +1847,7 @@ int g_la_graph_reps = 1;      // measurement: repetitions of the step inside the
 int g_la_graph_epoch = 0;     // bumped by la_debug_set when a capture-time knob changes: la_llama_step captures its graph again
 int g_la_pf_delay = 0;        // s_sleep(32) rounds the prefetch workgroups wait before their first load (key 8)
 
+#define LA_CAND_LDS (8 * LA_TB * 8)      // lm_head: [8 waves][64 tokens] (value, index) candidates behind the reduction buffer
 // leading scalar kernel arguments of the GEMM kernels (kernarg preload, see k_gemm64 / k_gemm64r)
 #define G64_HEAD(a) (a).wp, (a).xp, (a).route_col, (a).K16, (((a).ex_on ? 1 : 0) | (((a).kskew & 127) << 1) | ((a).prio_hi << 8))
 #define G64R_HEAD(ra) G64_HEAD((ra).g), (ra).wg_chunks, \
@@ -1945,7 +2033,7 @@ int lk_gemm64r_logits(hipStream_t st, const void* wp, const void* xp, int V, int
     ra.g.logits = (bf16_t*)logits; ra.g.cand_val = cv; ra.g.cand_idx = ci;
     ra.R = V / n_wg; if (V % n_wg || ra.R > 128 || ra.R <= 96) return -1;
     fill_nv(ra, ra.R, 4, 1);
-    k_gemm64r<4, EPI_LOGITS, 4, 8><<<n_wg, 512, 8 * 4 * 4096, st>>>(G64R_HEAD(ra), ra);
+    k_gemm64r<4, EPI_LOGITS, 4, 8><<<n_wg, 512, 8 * 4 * 4096 + LA_CAND_LDS, st>>>(G64R_HEAD(ra), ra);
     LAUNCH_CHECK(); return 0;
 }
 int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int nkv, int K, int n_wg, const int* pos,
@@ -1991,7 +2079,7 @@ int lk_gemm64r_init() {
     if (hipFuncSetAttribute((const void*)k_tree_attn<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             2 * LA_ATT_PAR * 66 * 64 * sizeof(float)) != hipSuccess) return -1;
     hipError_t e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_SWIGLU, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_LOGITS, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_LOGITS, 4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096 + LA_CAND_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<2, EPI_QKV, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 2 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_SWIGLU, 4, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<2, EPI_QKV, 8, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 2 * 4096);
@@ -2210,6 +2298,19 @@ int lk_moe_accum_all(hipStream_t st, const float* slabs0, long slab_stride, int 
         default: return -1;
     }
 #undef MA
+    LAUNCH_CHECK(); return 0;
+}
+int lk_step_head(hipStream_t st, const int* in, int* state, int* pos, uint64_t* rowmask, int* ids, const void* embed, const void* nw,
+                 int hidden, float eps, void* h, void* xp, int cast_first, const PfDesc* pf) {
+    if (hidden > 8192 || (hidden & 7)) return -1;
+    k_step_head<<<LA_TB + pf_extra(pf), 512, 0, st>>>(in, state, pos, (unsigned long long*)rowmask, ids, (const bf16_t*)embed, (bf16_t*)h,
+                                                      (const bf16_t*)nw, hidden, eps, (bf16_t*)xp, cast_first, pf_or_none(pf));
+    LAUNCH_CHECK(); return 0;
+}
+// cv / ci: [n_tiles][64] candidates (one per lm_head workgroup and token); host_out: pinned result block or null
+int lk_step_tail(hipStream_t st, const float* cv, const int* ci, int n_tiles, const int* ids, const uint64_t* rowmask, int* state,
+                 int* host_out) {
+    k_step_tail<<<1, 1024, 0, st>>>(cv, ci, n_tiles, ids, (const unsigned long long*)rowmask, state, host_out);
     LAUNCH_CHECK(); return 0;
 }
 int lk_publish(hipStream_t st, int* state, int* host_out) {

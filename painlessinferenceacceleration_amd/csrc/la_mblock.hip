@@ -1473,17 +1473,27 @@ __global__ __launch_bounds__(256) void k_kv_commit_mb(const bf16_t* __restrict__
     bf16_t* km = kmain + (size_t)lh * KB * 4096;
     bf16_t* vm = vmain + (size_t)lh * KB * 4096;
     const int* dstp = out + LA_MOUT_DST + blk * 64;
-    for (int i = threadIdx.x; i < 64 * 16; i += 256) {
-        const int r = i >> 4, p = i & 15;
-        const int dst = dstp[r];
-        if (dst < 0 || dst >= total_keys) continue;
-        *(bf16x8*)(km + rf_offset(dst, p * 8)) = *(const bf16x8*)(kf + rf_offset(r, p * 8));
+    // kept rows first (a verify block keeps <= LA_MOUT_TOKS of its 64 rows; round 2 walked all 64 x 144 items and re-read DST for
+    // every one of them: 45-170 us per step at 13B bs=4): wave 0 compacts (row, dst) pairs with one ballot, everybody then copies
+    // only those rows — 16-byte chunks of the K row-fragments, 2-byte elements of the transposed V fragments
+    __shared__ int krow[64], kdst[64];
+    __shared__ int nkeep;
+    if (threadIdx.x < 64) {
+        const int d = dstp[threadIdx.x];
+        const bool keep = d >= 0 && d < total_keys;
+        const unsigned long long m = __ballot(keep);
+        if (keep) { const int k = __popcll(m & ((1ull << threadIdx.x) - 1ull)); krow[k] = threadIdx.x; kdst[k] = d; }
+        if (threadIdx.x == 0) nkeep = __popcll(m);
     }
-    for (int i = threadIdx.x; i < 64 * 128; i += 256) {
-        const int r = i >> 7, d = i & 127;
-        const int dst = dstp[r];
-        if (dst < 0 || dst >= total_keys) continue;
-        vm[vf_offset(dst, d)] = vf[vf_offset(r, d)];
+    __syncthreads();
+    const int n = nkeep;
+    for (int i = threadIdx.x; i < n * 16; i += 256) {
+        const int k = i >> 4, p = i & 15;
+        *(bf16x8*)(km + rf_offset(kdst[k], p * 8)) = *(const bf16x8*)(kf + rf_offset(krow[k], p * 8));
+    }
+    for (int i = threadIdx.x; i < n * 128; i += 256) {
+        const int k = i >> 7, d = i & 127;
+        vm[vf_offset(kdst[k], d)] = vf[vf_offset(krow[k], d)];
     }
 }
 

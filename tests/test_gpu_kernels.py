@@ -351,7 +351,7 @@ def test_gemm64r_logits_balanced(V, K, nwg):
     state = torch.zeros(_lib.LA_ST_WORDS, dtype=torch.int32, device=DEV)
     wp, xp = gu.pack_planned(0, [w], nwg), gu.pack_x(x)
     check(lib.la_gemm64r_logits(sp(), ptr(wp), ptr(xp), V, K, nwg, ptr(logits), ptr(cv), ptr(ci)), 'logits_r')
-    check(lib.la_argmax_finalize(sp(), ptr(cv), ptr(ci), nwg * 8, ptr(state)), 'argmax')
+    check(lib.la_argmax_finalize(sp(), ptr(cv), ptr(ci), nwg, ptr(state)), 'argmax')      # one candidate per (workgroup, token)
     torch.cuda.synchronize()
     assert gu.rel_err(logits.float(), x.double() @ w.double().t()) < 1e-2
     lf = logits.float().cpu()
