@@ -61,9 +61,9 @@ struct la_llama {
     uint16_t* mb_xg;
     uint64_t* mb_rowmask;
     size_t mb_fresh_layer;
-    hipGraphExec_t mgraphs[LA_MB_MAX + 1];
-    bool mready[LA_MB_MAX + 1];
-    int mepoch[LA_MB_MAX + 1];     // g_la_graph_epoch at capture time, per multi-block graph
+    hipGraphExec_t mgraphs[2 * (LA_MB_MAX + 1)];     // [wide][nblk]: passes with wide-tree pieces use the masked attention instantiation
+    bool mready[2 * (LA_MB_MAX + 1)];
+    int mepoch[2 * (LA_MB_MAX + 1)];     // g_la_graph_epoch at capture time, per multi-block graph
     hipGraphExec_t graph_exec, bgraph_exec;      // bgraph_exec: scratch slot used while capturing a batch variant
     hipGraphExec_t bgraphs[4];                  // batch step captured per attention key-split count {8, 4, 2, 1}
     bool bready[4];
@@ -304,7 +304,7 @@ extern "C" la_llama* la_llama_create(const la_llama_config* cfg, const la_llama_
     m->zc_in = nullptr; m->zc_out = nullptr; m->seq_expected = 0;
     if (cfg->n_experts == 0) m->ex_merged = false;
     for (int i = 0; i < 4; ++i) { m->bgraphs[i] = nullptr; m->bready[i] = false; }
-    for (int i = 0; i <= LA_MB_MAX; ++i) { m->mgraphs[i] = nullptr; m->mready[i] = false; }
+    for (int i = 0; i < 2 * (LA_MB_MAX + 1); ++i) { m->mgraphs[i] = nullptr; m->mready[i] = false; }
     if (m->mb_max && lk_mb_init() != 0) { la_set_error("hipFuncSetAttribute failed for the multi-block kernels"); delete m; return nullptr; }
     return m;
 }
@@ -314,7 +314,7 @@ extern "C" void la_llama_destroy(la_llama* m) {
     if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
     if (m->bgraph_exec) (void)hipGraphExecDestroy(m->bgraph_exec);
     for (int i = 0; i < 4; ++i) if (m->bready[i]) (void)hipGraphExecDestroy(m->bgraphs[i]);
-    for (int i = 0; i <= LA_MB_MAX; ++i) if (m->mready[i]) (void)hipGraphExecDestroy(m->mgraphs[i]);
+    for (int i = 0; i < 2 * (LA_MB_MAX + 1); ++i) if (m->mready[i]) (void)hipGraphExecDestroy(m->mgraphs[i]);
     delete m;
 }
 
@@ -603,7 +603,7 @@ static int mb_split(int nblk, int n_heads = 32, int cus = 256) {
     return s;
 }
 
-static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk) {
+static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk, bool wide = false) {
     const la_llama_config& c = m->cfg;
     if (!m->qkv_fused) { la_set_error("mstep needs the fused QKV image (gemm_cfg[1] >= 0)"); return LA_E_ARG; }
     const int M = nblk * 64;
@@ -626,7 +626,7 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk) {
         KCHK(lk_mb_tree_attn(st, m->mb_qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems, kf, vf,
                              m->mb_rowmask, m->mb_meta, nblk, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, mb_split(nblk, c.n_heads, c.balanced_wg[1] > 0 ? c.balanced_wg[1] : 256),
                              m->mb_opart, m->mb_mpart, m->mb_lpart, m->mb_attn_xp, c.sliding_window, c.kv_ring ? 1 : 0,
-                             (const uint64_t*)(m->mb_in + LA_MIN_XMASK)));
+                             wide ? (const uint64_t*)(m->mb_in + LA_MIN_XMASK) : nullptr));
         MbGemm o{}; o.wp = L.wo; o.xp = m->mb_attn_xp; o.N = c.hidden; o.K = m->o_k; o.nblk = nblk; o.ksplit = o_ks;
         o.slabs = m->mb_slabs; o.slab_rows = npass_rows;
         KCHK(lk_mb_gemm(st, 0, o));
@@ -684,28 +684,31 @@ static int mstep(la_llama* m, void* stream, const int32_t* host_in, int32_t* hos
     if (!m || !host_in) return LA_E_ARG;
     const int nblk = host_in[LA_MIN_NBLK];
     if (!m->mb_max || nblk < 1 || nblk > m->mb_max) { la_set_error("mstep: block count outside cfg.max_blocks"); return LA_E_ARG; }
+    bool wide = false;                                   // any wide-tree piece in this pass: the masked attention instantiation
+    for (int b = 0; b < nblk; ++b) wide = wide || host_in[LA_MIN_BLK + 4 * b + 2] == LA_MODE_TREE_PIECE;
+    const int gi = (wide ? LA_MB_MAX + 1 : 0) + nblk;
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipMemcpyAsync(m->mb_in, host_in, LA_MIN_WORDS * sizeof(int), hipMemcpyHostToDevice, st));
     if (eager) {
-        int rc = enqueue_mstep(m, st, nblk);
+        int rc = enqueue_mstep(m, st, nblk, wide);
         if (rc != LA_OK) return rc;
     } else {
-        if (m->mready[nblk] && m->mepoch[nblk] != g_la_graph_epoch) {
-            (void)hipGraphExecDestroy(m->mgraphs[nblk]);
-            m->mgraphs[nblk] = nullptr; m->mready[nblk] = false;
+        if (m->mready[gi] && m->mepoch[gi] != g_la_graph_epoch) {
+            (void)hipGraphExecDestroy(m->mgraphs[gi]);
+            m->mgraphs[gi] = nullptr; m->mready[gi] = false;
         }
-        if (!m->mready[nblk]) {
+        if (!m->mready[gi]) {
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            int rc = enqueue_mstep(m, st, nblk);
+            int rc = enqueue_mstep(m, st, nblk, wide);
             hipError_t e = hipStreamEndCapture(st, &g);
             if (rc != LA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
             HIPCHK(e);
-            HIPCHK(hipGraphInstantiate(&m->mgraphs[nblk], g, nullptr, nullptr, 0));
+            HIPCHK(hipGraphInstantiate(&m->mgraphs[gi], g, nullptr, nullptr, 0));
             (void)hipGraphDestroy(g);
-            m->mready[nblk] = true; m->mepoch[nblk] = g_la_graph_epoch;
+            m->mready[gi] = true; m->mepoch[gi] = g_la_graph_epoch;
         }
-        HIPCHK(hipGraphLaunch(m->mgraphs[nblk], st));
+        HIPCHK(hipGraphLaunch(m->mgraphs[gi], st));
     }
     if (host_out) HIPCHK(hipMemcpyAsync(host_out, m->mb_out, LA_MOUT_DST * sizeof(int), hipMemcpyDeviceToHost, st));
     return LA_OK;

@@ -1090,6 +1090,10 @@ struct MbAttnArgs {
     bf16_t* attn_xp;                                   // nsplit == 1: the normalised output goes straight into o_proj's operand image
 };
 #define MB_NEG (-1.0e30f)
+// PIECE = true: the pass holds wide-tree pieces (mode-3 blocks); the instantiation without them is the round-2 kernel unchanged —
+// the extra ancestor words cost registers the 256-VGPR budget does not have (measured: 960 B/lane of scratch and 22 -> 134 us when
+// both forms shared one body), so la_llama_mstep picks the instantiation per pass (bit 8 of the LA_MIN_NBLK word).
+template <bool PIECE>
 __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float mgbuf[];   // [4][2][66][64]
     const int h = blockIdx.x, sp = blockIdx.y, blk = blockIdx.z;
@@ -1105,13 +1109,17 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
     const bool mine = row < T;
     const unsigned long long rm = mine ? a.rowmask[blk * 64 + row] : 0ull;
     // wide-tree piece: the earlier blocks of the slot are the first rows of the SAME tree, visible under this row's ancestor words
-    const bool piece = mt[LA_MBM_MODE] == LA_MODE_TREE_PIECE;
-    unsigned long long xm0 = 0ull, xm1 = 0ull, xm2 = 0ull;
-    if (piece && mine) {
-        const unsigned long long* xp_ = a.xmask + ((size_t)blk * 64 + row) * 3;
-        xm0 = xp_[0]; if (nprev > 1) xm1 = xp_[1]; if (nprev > 2) xm2 = xp_[2];
+    const bool piece = PIECE && mt[LA_MBM_MODE] == LA_MODE_TREE_PIECE;
+    // the ancestor words over the earlier pieces are NOT kept in registers across the tile loop (the kernel sits at the 256-VGPR
+    // limit): a prior tile re-reads its word (8 bytes per lane, an L1 / L2 hit); only the window rule needs their popcount up front
+    const unsigned long long* xrow = PIECE ? a.xmask + ((size_t)blk * 64 + (mine ? row : 0)) * 3 : nullptr;
+    int anc_prev = nprev * 64;
+    if constexpr (PIECE) {
+        if (piece) {
+            anc_prev = 0;
+            if (a.window > 0 && mine) for (int q2 = 0; q2 < nprev && q2 < 3; ++q2) anc_prev += __popcll(xrow[q2]);
+        }
     }
-    const int anc_prev = piece ? __popcll(xm0) + __popcll(xm1) + __popcll(xm2) : nprev * 64;
     const int NPall = (nkeys + 31) >> 5;
     const int qpos0 = piece ? nkeys : nkeys + nprev * 64;      // lowest position a row of the block can have
     const int ts = (a.window > 0 && qpos0 - a.window > 0) ? ((qpos0 - a.window) >> 5) : 0;
@@ -1155,6 +1163,8 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], q[s], sc, 0, 0, 0);
         float mx = MB_NEG;
+        unsigned long long xw_tile = 0ull;
+        if constexpr (PIECE) { if (prior && piece) xw_tile = xrow[(it - NP) >> 1]; }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int kk = (i & 3) + 8 * (i >> 2) + 4 * hh;
@@ -1163,10 +1173,9 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
             float v = bfr(bfr(sc[i]) * 0.088388346135616302490234375f);
             bool ok;
             if (own) ok = ((rm >> (kb * 32 + kk)) & 1ull) != 0ull;
-            else if (prior && piece) {
+            else if (PIECE && prior && piece) {
                 const int jf = it - NP;                      // fresh tile of piece jf >> 1, rows 32 * (jf & 1) ...
-                const unsigned long long xw = (jf >> 1) == 0 ? xm0 : ((jf >> 1) == 1 ? xm1 : xm2);
-                ok = ((xw >> ((jf & 1) * 32 + kk)) & 1ull) != 0ull;
+                ok = mine && ((xw_tile >> ((jf & 1) * 32 + kk)) & 1ull) != 0ull;
             }
             else if (prior) { const int kpos = nkeys + (it - NP) * 32 + kk; ok = mine && kpos >= key_lo; }
             else { const int kidx = (tsm + kb) * 32 + kk; ok = mine && kidx < nkeys && kidx >= key_lo; }
@@ -1540,7 +1549,8 @@ int lk_mb_init() {
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 3>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 4>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 5>, WideGeom<4, 4>::LDS);
-    if (e == hipSuccess) e = set_lds(k_tree_attn_mb, 8 * 66 * 64 * 4);
+    if (e == hipSuccess) e = set_lds(k_tree_attn_mb<false>, 8 * 66 * 64 * 4);
+    if (e == hipSuccess) e = set_lds(k_tree_attn_mb<true>, 8 * 66 * 64 * 4);
     if (e != hipSuccess) return (int)e;
     g_mb_attr = true;
     return 0;
@@ -1769,7 +1779,8 @@ int lk_mb_tree_attn(hipStream_t st, const void* qf, const void* kmain, const voi
     a.nh = nh; a.nkv = nkv; a.total_keys = slot_keys * n_slots; a.slot_tiles = slot_keys >> 5; a.nsplit = nsplit; a.window = window; a.ring = ring;
     a.opart = opart; a.mpart = mpart; a.lpart = lpart;
     a.attn_xp = nsplit == 1 ? (bf16_t*)attn_xp : nullptr;
-    k_tree_attn_mb<<<dim3(nh, nsplit, nblk), 512, 8 * 66 * 64 * sizeof(float), st>>>(a);
+    if (xmask) k_tree_attn_mb<true><<<dim3(nh, nsplit, nblk), 512, 8 * 66 * 64 * sizeof(float), st>>>(a);
+    else k_tree_attn_mb<false><<<dim3(nh, nsplit, nblk), 512, 8 * 66 * 64 * sizeof(float), st>>>(a);
     LAUNCH_CHECK();
     if (nsplit == 1) return 0;
     const int total = nh * 64 * 16;
