@@ -224,6 +224,7 @@ def main():
                     help='7b = the BASELINE metric; 13b / mistral / mixtral = the config-4 / config-3 / config-5 model shapes')
     ap.add_argument('--batch', type=int, default=1, help='sequences per GPU; > 1: each gets its own 64-token tree per step (la_llama_mstep)')
     ap.add_argument('--device-trie', action='store_true', help='--batch > 1: drafts of all sequences from ONE device launch over the incremental trie mirror')
+    ap.add_argument('--unchained-trie', action='store_true', help='--device-trie: read the drafts back to the host and feed them through la_llama_mstep (round-2 form)')
     ap.add_argument('--strict-gather', action='store_true', help='N > 1: blocking all-gather (reference trie order at query time)')
     ap.add_argument('--profile-iters', type=int, default=3)
     ap.add_argument('--attn-split', type=int, default=0, help='key splits of the tree-attention kernel (0 = engine default 8)')
@@ -392,7 +393,35 @@ def main():
         return [(np.asarray(g[0], dtype=np.int32), np.asarray(g[1], dtype=np.uint64)) if len(g[0]) else
                 (np.asarray(seqs[i][-1:], dtype=np.int32), np.array([1], dtype=np.uint64)) for i, g in enumerate(got)]
 
+    def one_step_chained():
+        # device trie chained in front of the verify pass: patch + query kernels and la_llama_mstep_trie on the engine's stream; the
+        # drafts never leave HBM (the host reads back accepted tokens and draft lengths)
+        tq = time.time()
+        if pending[0]:
+            gather.finish_into_trie(cache, BL)
+            pending[0] = False
+        ubl = [min(BL, max_length - len(seqs[i]) - 1) for i in range(B)]
+        with torch.cuda.stream(eng.stream):
+            dev_trie.hier_get_dev([seqs[i][-2:] for i in range(B)], idxs=gidx, branch_lengths=ubl, decoding_length=DL, branch_length=BL,
+                                  min_input_size=0, min_output_size=DL // 2, mode='mix')
+            qts.append(time.time() - tq)
+            toks_all, Ts = eng.mstep_trie(dev_trie, 0, list(range(B)), [16] * B, [seqs[i][-1] for i in range(B)])
+        for i in range(B):
+            seqs[i].extend(toks_all[i])
+            dls.append(Ts[i]); edls.append(len(toks_all[i]))
+        if dist_on:
+            if args.strict_gather:
+                gather.update_trie(cache, toks_all if B > 1 else toks_all[0], BL)
+            else:
+                gather.begin(toks_all if B > 1 else toks_all[0])
+                pending[0] = True
+        else:
+            for i in range(B):
+                cache.stream_put(toks_all[i], branch_length=BL + 1, final=False, idx=gidx[i])
+
     def one_step():
+        if dev_trie is not None and not args.unchained_trie:
+            return one_step_chained()
         tq = time.time()
         dr = drafts_dev() if dev_trie is not None else [drafts_for(i) for i in range(B)]
         qts.append(time.time() - tq)
@@ -595,7 +624,7 @@ def main():
                    'kv_cache': (f'ring of {eng.shape.sliding_window} + one step of rows per sequence (sliding window)' if kv_ring else 'linear, max_length keys per sequence'),
                    'gather_mode': None if not dist_on else ('strict' if args.strict_gather else 'split-phase'),
                    'gather_transport': gather_transport, 'rccl_ranks': rccl_ranks,
-                   'draft_retrieval': 'device trie (incremental mirror, one launch per step)' if dev_trie is not None else 'host trie',
+                   'draft_retrieval': ('device trie (incremental mirror, one launch per step' + (', chained in front of the verify pass: drafts stay in HBM)' if not args.unchained_trie else ', drafts read back to the host)')) if dev_trie is not None else 'host trie',
                    'device_trie_stats': dev_trie.stats if dev_trie is not None else None,
                    'mean_accept_len': round(mean_acc, 3), 'mean_draft_len': round(mean_T, 2),
                    'verify_steps_per_sec': round(K * world / elapsed, 2), 'context_at_end': ctx,

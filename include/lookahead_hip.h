@@ -474,12 +474,22 @@ int      la_gather_accepted(la_comm* c, void* stream, const int32_t* d_local, in
 #define LA_MOUT_NOUT       0    /* out: [8] tokens emitted per block                                                    */
 #define LA_MOUT_NKEYS      8    /* out: [16] committed keys per slot after the step                                     */
 #define LA_MOUT_OUTTOK    24    /* out: [8][LA_MOUT_TOKS] emitted tokens per block                                      */
-#define LA_MOUT_DST      344    /* out: [8][64] main-cache key row each block row was committed to, -1 = dropped        */
-#define LA_MOUT_ARGMAX   856    /* out: [8][64] argmax token per block row                                              */
-#define LA_MOUT_WORDS   1368
+#define LA_MOUT_T        344    /* out: [8] valid rows of each block (the draft length when the drafts came from the device trie) */
+#define LA_MOUT_DST      352    /* out: [8][64] main-cache key row each block row was committed to, -1 = dropped        */
+#define LA_MOUT_ARGMAX   864    /* out: [8][64] argmax token per block row                                              */
+#define LA_MOUT_WORDS   1376
 /* h2d of host_in (LA_MIN_WORDS), captured graph (one per nblk), d2h of the first LA_MOUT_DST words into host_out. */
 int la_llama_mstep(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);
 int la_llama_mstep_eager(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out);
+/* The same step with the drafts taken ON THE DEVICE from the outputs of la_trie_hier_get_dev2 (one query per block, block b =
+ * query b): d_ids int32[nblk][64], d_rowmask uint64[nblk][64], d_n int32[nblk] stay where the trie kernel wrote them — no D2H
+ * of drafts, no host packing, no H2D of the step input; slots / limits / last_tok: host arrays [nblk] (slot of each block, its
+ * emit limit, and the token the block falls back to as a 1-row tree when the query returned nothing).  Everything is queued on
+ * `stream` behind the trie kernels; host_out receives the first LA_MOUT_DST words (LA_MOUT_T = the draft lengths).  This is the
+ * trie walk chained in front of the verify forward (lookahead_prepare_inputs_for_generation, pretrained_model_batch.py:706-743,
+ * without its host round trip). */
+int la_llama_mstep_trie(la_llama* m, void* stream, int nblk, const int32_t* slots, const int32_t* limits, const int32_t* last_tok,
+                        const int32_t* d_ids, const uint64_t* d_rowmask, const int32_t* d_n, int32_t* host_out);
 /* One GEMM of the multi-block family (unit parity): kind 0 = split-K slabs [ksplit][slab_rows][N] over a la_pack_weight image,
  * 1 = gate/up + SwiGLU -> act_xp [blk][64 x N packed], 2 = QKV + RoPE -> qf [blk][nh][8192], kfresh / vfresh [blk][nkv][8192],
  * 3 = lm_head -> logits bf16 [nblk*64][N] + argmax candidates [blk][4*workgroups][64].  n_wg > 0: image packed by

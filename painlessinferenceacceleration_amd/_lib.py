@@ -25,7 +25,7 @@ LA_BIN_T, LA_BIN_IDS, LA_BIN_ROWMASK, LA_BIN_SEQ, LA_BIN_MODE, LA_BIN_LIMIT, LA_
 LA_MB_MAX = 8
 LA_MIN_NBLK, LA_MIN_BLK, LA_MIN_IDS, LA_MIN_ROWMASK, LA_MIN_XMASK, LA_MIN_WORDS = 0, 4, 36, 548, 1572, 4644
 LA_TREE_WIDE_MAX, LA_MODE_TREE_PIECE, LA_MOUT_TOKS = 256, 3, 40
-LA_MOUT_NOUT, LA_MOUT_NKEYS, LA_MOUT_OUTTOK, LA_MOUT_DST, LA_MOUT_ARGMAX, LA_MOUT_WORDS = 0, 8, 24, 344, 856, 1368
+LA_MOUT_NOUT, LA_MOUT_NKEYS, LA_MOUT_OUTTOK, LA_MOUT_T, LA_MOUT_DST, LA_MOUT_ARGMAX, LA_MOUT_WORDS = 0, 8, 24, 344, 352, 864, 1376
 LA_BST_NKEYS, LA_BST_NOUT, LA_BST_OUTTOK, LA_BST_DST, LA_BST_ARGMAX, LA_BST_SEQ, LA_BST_WORDS = 0, 16, 32, 288, 352, 416, 480
 
 
@@ -172,6 +172,7 @@ PROTOTYPES = {
     "la_llama_bstep": (i32, vp, vp, vp, vp),
     "la_llama_mstep": (i32, vp, vp, vp, vp),
     "la_llama_mstep_eager": (i32, vp, vp, vp, vp),
+    "la_llama_mstep_trie": (i32, vp, vp, i32, pi32, pi32, pi32, vp, vp, vp, vp),
     "la_llama_set_nkeys": (i32, vp, vp, i32, i32),
     "la_llama_bcommit": (i32, vp, vp, pi32, vp),
     "la_llama_mcommit": (i32, vp, vp, i32, pi32, vp),

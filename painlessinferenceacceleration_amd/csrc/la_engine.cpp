@@ -713,6 +713,36 @@ static int mstep(la_llama* m, void* stream, const int32_t* host_in, int32_t* hos
     if (host_out) HIPCHK(hipMemcpyAsync(host_out, m->mb_out, LA_MOUT_DST * sizeof(int), hipMemcpyDeviceToHost, st));
     return LA_OK;
 }
+// Drafts from the device trie: the step input is assembled on the device (k_mb_fill_from_trie) from the trie kernel's outputs, then
+// the captured graph of `nblk` plain blocks runs — nothing crosses PCIe but the result header.
+extern "C" int la_llama_mstep_trie(la_llama* m, void* stream, int nblk, const int32_t* slots, const int32_t* limits, const int32_t* last_tok,
+                                   const int32_t* d_ids, const uint64_t* d_rowmask, const int32_t* d_n, int32_t* host_out) {
+    if (!m || !slots || !limits || !last_tok || !d_ids || !d_rowmask || !d_n) return LA_E_ARG;
+    if (!m->mb_max || nblk < 1 || nblk > m->mb_max) { la_set_error("mstep_trie: block count outside cfg.max_blocks"); return LA_E_ARG; }
+    for (int b = 0; b < nblk; ++b) if (slots[b] < 0 || slots[b] >= m->n_slots) return LA_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    KCHK(lk_mb_fill_from_trie(st, d_ids, d_rowmask, d_n, slots, limits, last_tok, nblk, m->mb_in));
+    const int gi = nblk;
+    if (m->mready[gi] && m->mepoch[gi] != g_la_graph_epoch) {
+        (void)hipGraphExecDestroy(m->mgraphs[gi]);
+        m->mgraphs[gi] = nullptr; m->mready[gi] = false;
+    }
+    if (!m->mready[gi]) {
+        hipGraph_t g = nullptr;
+        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue_mstep(m, st, nblk, false);
+        hipError_t e = hipStreamEndCapture(st, &g);
+        if (rc != LA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+        HIPCHK(e);
+        HIPCHK(hipGraphInstantiate(&m->mgraphs[gi], g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
+        m->mready[gi] = true; m->mepoch[gi] = g_la_graph_epoch;
+    }
+    HIPCHK(hipGraphLaunch(m->mgraphs[gi], st));
+    if (host_out) HIPCHK(hipMemcpyAsync(host_out, m->mb_out, LA_MOUT_DST * sizeof(int), hipMemcpyDeviceToHost, st));
+    return LA_OK;
+}
+
 extern "C" int la_llama_mstep(la_llama* m, void* stream, const int32_t* host_in, int32_t* host_out) {
     return mstep(m, stream, host_in, host_out, false);
 }

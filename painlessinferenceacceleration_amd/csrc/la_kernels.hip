@@ -894,8 +894,10 @@ __device__ __forceinline__ void gemm64r_body(const bf16_t* __restrict__ wp_s, co
         };
         if constexpr (EPI == EPI_SWIGLU) {
             // wave -> (pair q, register group gi): gate block q, up block q + RB/2
-            static_assert(EPI != EPI_SWIGLU || (RB == 4 && NW == 8), "swiglu layout");
-            const int qq = wave >> 2, gi = wave & 3;
+            // (NW = 4, one wave per SIMD: every wave takes both pairs of its register group)
+            static_assert(EPI != EPI_SWIGLU || (RB == 4 && (NW == 8 || NW == 4)), "swiglu layout");
+            const int gi = wave & 3;
+            for (int qq = (NW == 8 ? (wave >> 2) : 0); qq < (NW == 8 ? (wave >> 2) + 1 : 2); ++qq)
             if (8 * gi + 4 * hh < ra.nv[qq]) {
                 const f32x4 g4 = total4(qq, gi), u4 = total4(qq + RB / 2, gi);
 #pragma unroll
@@ -1845,6 +1847,7 @@ int g_la_pf_tail_kib = 0;     // tail prefetch of down_proj from the gate/up lau
 int g_la_attn_staged = 0;     // 1: tree attention with K/V staged through LDS once per workgroup (la_debug_set key 10)
 int g_la_graph_reps = 1;      // measurement: repetitions of the step inside the single-sequence graph (key 11)
 int g_la_graph_epoch = 0;     // bumped by la_debug_set when a capture-time knob changes: la_llama_step captures its graph again
+int g_la_gemm_4w = 0;         // la_debug_set key 15: bit 0 = gate/up as 4 waves x 8 tile-sets (one wave per SIMD) — measurement
 int g_la_pf_delay = 0;        // s_sleep(32) rounds the prefetch workgroups wait before their first load (key 8)
 
 #define LA_CAND_LDS (8 * LA_TB * 8)      // lm_head: [8 waves][64 tokens] (value, index) candidates behind the reduction buffer
@@ -2023,6 +2026,11 @@ int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int
     if (set_fused_norm(ra, fn, n_wg)) {
         if (fn->n_slabs != 4 || route_col) return -1;
         k_gemm64r<4, EPI_SWIGLU, 4, 8, 4><<<n_wg, 512, 8 * 4 * 4096, st>>>(G64R_HEAD(ra), ra);
+    } else if (g_la_gemm_4w & 1) {
+        // measurement (la_debug_set key 15 bit 0): ONE wave per SIMD, 8 tile-sets in flight per wave — no SIMD partner to lose the
+        // VMEM issue arbitration to (the 8-wave form's younger waves finish their K range 10 us after the older ones)
+        if (lk_gemm64r_init() != 0) return -1;
+        k_gemm64r<4, EPI_SWIGLU, 8, 4><<<n_wg, 256, 4 * 4 * 4096, st>>>(G64R_HEAD(ra), ra);
     } else {
         k_gemm64r<4, EPI_SWIGLU, 4, 8><<<n_wg, 512, 8 * 4 * 4096, st>>>(G64R_HEAD(ra), ra);
     }
@@ -2083,6 +2091,7 @@ int lk_gemm64r_init() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<2, EPI_QKV, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 2 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_SWIGLU, 4, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<2, EPI_QKV, 8, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 2 * 4096);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_SWIGLU, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gateup_down<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gateup_down<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
     if (e != hipSuccess) return (int)e;

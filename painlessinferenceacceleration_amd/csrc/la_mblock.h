@@ -21,6 +21,8 @@
 #define LA_MBM_FIRST    6    // index of the first block of the same slot in this step
 
 int lk_mb_init();
+int lk_mb_fill_from_trie(hipStream_t st, const int* t_ids, const uint64_t* t_rm, const int* t_n, const int* slots, const int* limits,
+                         const int* last, int nblk, int* d_in);
 int lk_mb_build_inputs(hipStream_t st, const int* d_in, const int* d_bstate, int nblk, int* d_meta, int* d_pos,
                        uint64_t* d_rowmask, int* d_ids);
 int lk_mb_embed_norm(hipStream_t st, const void* embed, const int* ids, const void* nw, int hidden, float eps, void* h, void* xp,

@@ -1074,6 +1074,37 @@ __global__ void k_build_inputs_mb(const int* __restrict__ in, const int* __restr
     }
 }
 
+// Step input from the DEVICE trie (la_llama_mstep_trie): block b = query b of k_trie_hier_get, whose ids / row masks / count are
+// copied into the step-input block where k_build_inputs_mb expects them; a query that returned nothing becomes the 1-row tree
+// [last token] (the host loops' fallback, pretrained_model_batch.py:706-743).
+struct MbTrieFill { int slot[LA_MB_MAX], limit[LA_MB_MAX], last[LA_MB_MAX]; };
+__global__ void k_mb_fill_from_trie(const int* __restrict__ t_ids, const unsigned long long* __restrict__ t_rm,
+                                    const int* __restrict__ t_n, MbTrieFill f, int nblk, int* __restrict__ in) {
+    const int b = blockIdx.x, t = threadIdx.x;       // 64 threads
+    int T = t_n[b];
+    T = T < 0 ? 0 : (T > 64 ? 64 : T);
+    const bool empty = T == 0;
+    if (empty) T = 1;
+    unsigned long long* rmo = (unsigned long long*)(in + LA_MIN_ROWMASK) + b * 64;
+    if (t < T) {
+        in[LA_MIN_IDS + b * 64 + t] = empty ? f.last[b] : t_ids[b * 64 + t];
+        rmo[t] = empty ? 1ull : t_rm[b * 64 + t];
+    }
+    if (t == 0) {
+        int* rec = in + LA_MIN_BLK + 4 * b;
+        rec[0] = f.slot[b]; rec[1] = T; rec[2] = 0; rec[3] = f.limit[b];
+        if (b == 0) in[LA_MIN_NBLK] = nblk;
+    }
+}
+int lk_mb_fill_from_trie(hipStream_t st, const int* t_ids, const uint64_t* t_rm, const int* t_n, const int* slots, const int* limits,
+                         const int* last, int nblk, int* d_in) {
+    if (nblk < 1 || nblk > LA_MB_MAX) return -1;
+    MbTrieFill f{};
+    for (int b = 0; b < nblk; ++b) { f.slot[b] = slots[b]; f.limit[b] = limits[b]; f.last[b] = last[b]; }
+    k_mb_fill_from_trie<<<nblk, 64, 0, st>>>(t_ids, (const unsigned long long*)t_rm, t_n, f, nblk, d_in);
+    hipError_t e_ = hipGetLastError(); return e_ == hipSuccess ? 0 : (int)e_;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Tree attention of block `blk` (LlamaAttention.forward, modeling_llama.py:270-296 under the rank-4 mask): committed keys of
 // the block's slot mask-free, the fresh tiles of EARLIER blocks of the same slot in this step fully visible (prefill chain),
@@ -1387,6 +1418,7 @@ __global__ void k_accept_scan_mb(const int* __restrict__ meta, const int* __rest
         auto row_of = [&](int k) { return slot * slot_keys + (ring ? (pos0 + k) % slot_keys : pos0 + k); };
         const int am = argmax[b * 64 + j];
         out[LA_MOUT_ARGMAX + b * 64 + j] = am;
+        if (j == 0) out[LA_MOUT_T + b] = T;
         int nc = 0;
         if (mode == LA_MODE_TREE_PIECE) {
             // rows, DST and counters of this block belong to the tree's first wave

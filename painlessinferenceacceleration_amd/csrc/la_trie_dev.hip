@@ -30,9 +30,12 @@ struct TrieQueryArgs {
     const int* plane;     // [B] fi plane of each query (null: plane 0)
     long fi_stride;       // records between fi planes
     const int* bl;        // [B] per-query branch length (null: branch_length)
+    long long* dbg;       // measurement aid (la_debug_set_ptr(0, .)): [B][8] wall_clock64 stamps {start, matched, scanned, cut-offs, emitted} + {rows, n_out}
 };
+extern long long* g_la_dbg_times;
 
 #define TBIG 1e9
+#define LA_SCAN_SMALL 6
 
 __device__ __forceinline__ int wave_first(unsigned long long m) { return m ? __ffsll((long long)m) - 1 : -1; }
 
@@ -48,8 +51,18 @@ __device__ int find_child(const TrieDev& t, int u, int token, int lane) {
     return -1;
 }
 
-// value at position r (0-based) of the DESCENDING sort of vals[0..n) (all >= 0): radix select on the bit patterns
-__device__ double select_desc(const double* vals, int n, int r, int lane, unsigned* hist /*LDS[256]*/) {
+// value at position r (0-based) of the DESCENDING sort of vals[0..n) (all >= 0): radix select on the bit patterns.
+// Round 3 (rocprof + phase stamps, profiles/r03_trie_device_profile.txt: 141 us median for ~1750 values): the values are staged ONCE
+// in LDS (n <= LA_SEL_LDS; larger sets stream from the global scratch as before) instead of being re-read from global memory in
+// each of the 8 byte passes, and the bin in which the rank falls is found by a wave-parallel suffix sum over the 256 bins
+// (4 bins per lane, 6 shuffle steps) instead of a serial walk of up to 255 dependent LDS reads per pass.
+#define LA_SEL_LDS 4096
+__device__ double select_desc(const double* vals, int n, int r, int lane, unsigned* hist /*LDS[256]*/, double* sv /*LDS[LA_SEL_LDS]*/) {
+    const bool staged = n <= LA_SEL_LDS;
+    if (staged) {
+        for (int i = lane; i < n; i += 64) sv[i] = vals[i];
+        __syncthreads();
+    }
     unsigned long long prefix = 0ull, mask = 0ull;
     int rank = r;
     for (int byte = 7; byte >= 0; --byte) {
@@ -57,19 +70,35 @@ __device__ double select_desc(const double* vals, int n, int r, int lane, unsign
         __syncthreads();
         const int sh = byte * 8;
         for (int i = lane; i < n; i += 64) {
-            const unsigned long long b = (unsigned long long)__double_as_longlong(vals[i]);
+            const unsigned long long b = (unsigned long long)__double_as_longlong(staged ? sv[i] : vals[i]);
             if ((b & mask) == prefix) atomicAdd(&hist[(unsigned)((b >> sh) & 0xffull)], 1u);
         }
         __syncthreads();
-        // walk bins from high to low: find the bin in which the rank falls (done by every lane identically)
-        int bin = 255;
-        int acc = 0;
-        for (; bin > 0; --bin) {
-            const int cnt = (int)hist[bin];
-            if (acc + cnt > rank) break;
-            acc += cnt;
+        // lane l owns bins 255 - 4l .. 252 - 4l (descending): above = values in higher bins = exclusive prefix over lanes
+        const int top = 255 - 4 * lane;
+        const int h0 = (int)hist[top], h1 = (int)hist[top - 1], h2 = (int)hist[top - 2], h3 = (int)hist[top - 3];
+        const int mine = h0 + h1 + h2 + h3;
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
         }
-        rank -= acc;
+        const int above = incl - mine;
+        const bool here = rank >= above && rank < incl;          // exactly one lane (rank < n = total)
+        int bin = 0, nrank = 0;
+        if (here) {
+            int acc = above;
+            bin = top;
+            if (acc + h0 <= rank) { acc += h0; bin = top - 1;
+                if (acc + h1 <= rank) { acc += h1; bin = top - 2;
+                    if (acc + h2 <= rank) { acc += h2; bin = top - 3; } } }
+            nrank = rank - acc;
+        }
+        const unsigned long long hm = __ballot(here);
+        const int src = hm ? __ffsll((long long)hm) - 1 : 63;     // (empty set: n == 0 is never passed)
+        bin = __shfl(bin, src, 64);
+        rank = __shfl(nrank, src, 64);
         prefix |= (unsigned long long)bin << sh;
         mask |= 0xffull << sh;
         __syncthreads();
@@ -79,8 +108,12 @@ __device__ double select_desc(const double* vals, int n, int r, int lane, unsign
 
 __global__ __launch_bounds__(64) void k_trie_hier_get(TrieQueryArgs a) {
     __shared__ unsigned hist[256];
-    __shared__ int st_node[72], st_pos[72], st_pid[72], st_depth[72];
-    __shared__ double st_fm[72];
+    __shared__ __attribute__((aligned(16))) double sel_vals[LA_SEL_LDS];
+    __shared__ int st_pid[72], st_depth[72], fr_cnt[72], fr_next[72];
+    __shared__ int fr_child[72][64];
+    __shared__ unsigned char fr_flag[72][64];
+    __shared__ double tmp_fm[64];
+    __shared__ int tmp_k[64], tmp_fl[64];
     const int b = blockIdx.x, lane = threadIdx.x;
     TrieDev t = a.t;
     if (a.plane) t.fi += (size_t)a.plane[b] * (size_t)a.fi_stride;
@@ -93,6 +126,8 @@ __global__ __launch_bounds__(64) void k_trie_hier_get(TrieQueryArgs a) {
     double* vfi = a.scratch_v + (size_t)b * 2 * t.n_nodes;
     double* vfo = vfi + t.n_nodes;
     const int max_size = a.decoding_length, max_length = branch_length, mode = a.mode;
+    long long* const stamp = a.dbg ? a.dbg + (size_t)b * 8 : nullptr;
+    if (stamp && lane == 0) { stamp[0] = wall_clock64(); stamp[1] = stamp[2] = stamp[3] = stamp[4] = 0; stamp[5] = stamp[6] = 0; }
 
     auto finish = [&](int n, int s0, int s1, int nsizes) {
         if (lane == 0) { a.out_n[b] = n; a.out_sizes[b * 2] = s0; a.out_sizes[b * 2 + 1] = s1; a.out_nsizes[b] = nsizes; }
@@ -122,6 +157,7 @@ __global__ __launch_bounds__(64) void k_trie_hier_get(TrieQueryArgs a) {
             cur = live ? ch : -1;
         }
         sz0 = sz1 = 0;
+        if (stamp && lane == 0) stamp[1] = wall_clock64();
         if (cur < 0 || t.ccount[cur] == 0) {                                  // :70-72
             if (lane == 0) { oid[0] = nrest > 0 ? q[nq - 1] : t.tok[root]; orm[0] = 1ull; }
             n_out = 1;
@@ -143,21 +179,38 @@ __global__ __launch_bounds__(64) void k_trie_hier_get(TrieQueryArgs a) {
                 const int v = head + lane < tail ? queue[head + lane] : -1;
                 int cs = 0, cc = 0;
                 if (v >= 0) { vfi[head + lane] = t.fi[v]; vfo[head + lane] = t.fo[v]; cs = t.cstart[v]; cc = t.ccount[v]; }
-                int mx = cc;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+                // children of the 64 nodes of this batch.  Low-degree nodes (the bulk of a trie): every lane walks its own node's
+                // children, at most LA_SCAN_SMALL dependent steps; a high-degree node (the matched node and its first levels carry
+                // hundreds of children) is expanded by the whole wave, 64 consecutive children per step (coalesced fi / fo reads) —
+                // round 2 ran max(children) steps for the whole batch.  The queue order only feeds counts and the cut-off select.
                 const int nproc = min(64, tail - head);
                 head += nproc;
+                const int ccs = cc <= LA_SCAN_SMALL ? cc : 0;
+                int mx = ccs;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
                 for (int k = 0; k < mx; ++k) {
                     const int c = cs + k;
-                    const bool lv = k < cc && (t.fo[c] > 0 || t.fi[c] > 0);
+                    const bool lv = k < ccs && (t.fo[c] > 0 || t.fi[c] > 0);
                     const unsigned long long m = __ballot(lv);
                     if (lv) queue[tail + __popcll(m & ((1ull << lane) - 1ull))] = c;
                     tail += __popcll(m);
                 }
+                for (unsigned long long big = __ballot(cc > LA_SCAN_SMALL); big; big &= big - 1ull) {
+                    const int j = __ffsll((long long)big) - 1;
+                    const int bcs = __shfl(cs, j, 64), bcc = __shfl(cc, j, 64);
+                    for (int base = 0; base < bcc; base += 64) {
+                        const int c = bcs + base + lane;
+                        const bool lv = base + lane < bcc && (t.fo[c] > 0 || t.fi[c] > 0);
+                        const unsigned long long m = __ballot(lv);
+                        if (lv) queue[tail + __popcll(m & ((1ull << lane) - 1ull))] = c;
+                        tail += __popcll(m);
+                    }
+                }
                 __threadfence_block();
             }
             const int rows = tail;
+            if (stamp && lane == 0) { stamp[2] = wall_clock64(); stamp[5] = rows; }
             __threadfence_block();
             __syncthreads();                                                  // vfi/vfo complete (single wave: ordering only)
             double w = 1e-4, lo_in = TBIG, lo_out = TBIG, lo_mix = TBIG;
@@ -167,73 +220,108 @@ __global__ __launch_bounds__(64) void k_trie_hier_get(TrieQueryArgs a) {
                 for (int k = lane; k < rows; k += 64) cnt += vfi[k] > 0;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-                lo_in = cnt > max_size ? select_desc(vfi, rows, a.min_in <= 0 ? rows - 1 : min(a.min_in - 1, rows - 1), lane, hist) : 0.0;
+                lo_in = cnt > max_size ? select_desc(vfi, rows, a.min_in <= 0 ? rows - 1 : min(a.min_in - 1, rows - 1), lane, hist, sel_vals) : 0.0;
             } else if (mode == LA_MODE_OUTPUT) {
                 w = 1.0;
                 int cnt = 0;
                 for (int k = lane; k < rows; k += 64) cnt += vfo[k] > 0;
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-                lo_out = cnt > max_size ? select_desc(vfo, rows, a.min_out <= 0 ? rows - 1 : min(a.min_out - 1, rows - 1), lane, hist) : 0.0;
+                lo_out = cnt > max_size ? select_desc(vfo, rows, a.min_out <= 0 ? rows - 1 : min(a.min_out - 1, rows - 1), lane, hist, sel_vals) : 0.0;
             } else if (rows > max_size) {
                 // rows carry None as their index (:152): the mix cut-off loop never fires, lo_mix stays 1e9
-                if (a.min_in > 0) lo_in = select_desc(vfi, rows, min(a.min_in - 1, rows - 1), lane, hist);
-                if (a.min_out > 0) lo_out = select_desc(vfo, rows, min(a.min_out - 1, rows - 1), lane, hist);
+                if (a.min_in > 0) lo_in = select_desc(vfi, rows, min(a.min_in - 1, rows - 1), lane, hist, sel_vals);
+                if (a.min_out > 0) lo_out = select_desc(vfo, rows, min(a.min_out - 1, rows - 1), lane, hist, sel_vals);
             } else {
                 lo_mix = 0.0;
             }
             const double w1 = 1.0 - w;
-            // ---- _ravel
+            if (stamp && lane == 0) stamp[3] = wall_clock64();
+            // ---- _ravel (lookahead_cache.py:248-293).  Round 3: a node's children are ORDERED ONCE, when the DFS first enters the
+            // node — eligible children (the cut-off rule of :262-273) ranked by (fm desc, insertion position asc) into an LDS frame
+            // of at most 64 entries (no node can contribute more rows than the budget left) — and then consumed from the frame.
+            // Round 2 re-scanned ALL children of the node (two dependent global loads each) for every row it emitted or skipped:
+            // 306 us median for ~35 rows below nodes with hundreds of children (profiles/r03_trie_device_profile.txt).
             const int last_tok = nrest > 0 ? q[nq - 1] : 0;
             if (lane == 0) { oid[0] = (nrest > 0 && last_tok != 0) ? last_tok : t.tok[root]; orm[0] = 1ull; }   // :129
             int n = 1, sp = 0;
-            if (lane == 0) { st_node[0] = cur; st_fm[0] = 1e308; st_pos[0] = -1; st_pid[0] = -1; st_depth[0] = max_length; }
+            auto better = [](double afm, int ak, double bfm, int bk) { return afm > bfm || (afm == bfm && ak < bk); };
+            // frame of node u at stack level lv: -> number of entries
+            auto build_frame = [&](int lv, int u) -> int {
+                const int cs = t.cstart[u], cc = t.ccount[u];
+                double Lfm = -1.0; int Lk = 0x7fffffff, Lfl = 0; bool Lv = false;      // lane r holds the rank-r child found so far
+                int nL = 0;
+                for (int base = 0; base < cc; base += 64) {
+                    const int k = base + lane;
+                    const bool in = k < cc;
+                    double cfi = 0.0, cfo = 0.0;
+                    if (in) { cfi = t.fi[cs + k]; cfo = t.fo[cs + k]; }
+                    const double fm = __dadd_rn(__dmul_rn(w1, cfi), __dmul_rn(w, cfo));      // :254, no FMA
+                    bool skip;
+                    if (mode == LA_MODE_MIX) skip = cfi < lo_in && cfo < lo_out && fm < lo_mix;            // :265
+                    else if (mode == LA_MODE_INPUT) skip = cfi < lo_in;
+                    else skip = cfo < lo_out;
+                    bool Nv = in && !skip;
+                    if (nL == 64) {                      // a full list: only children better than its last entry can enter
+                        const double wfm = __shfl(Lfm, 63, 64); const int wk = __shfl(Lk, 63, 64);
+                        Nv = Nv && better(fm, k, wfm, wk);
+                    }
+                    unsigned long long mN = __ballot(Nv);
+                    if (mN == 0ull) continue;
+                    const unsigned long long mL = __ballot(Lv);
+                    int rL = lane, rN = 0;               // ranks in the union of the kept list and the new candidates
+                    const int fl = (cfi > 0.0 ? 1 : 0) | (cfo > 0.0 ? 2 : 0);
+                    for (unsigned long long m2 = mN; m2; m2 &= m2 - 1ull) {
+                        const int j = __ffsll((long long)m2) - 1;
+                        const double bfm = __shfl(fm, j, 64); const int bk = __shfl(k, j, 64);
+                        if (Lv && better(bfm, bk, Lfm, Lk)) ++rL;
+                        if (Nv && j != lane && better(bfm, bk, fm, k)) ++rN;
+                    }
+                    for (unsigned long long m2 = mL; m2; m2 &= m2 - 1ull) {
+                        const int j = __ffsll((long long)m2) - 1;
+                        const double bfm = __shfl(Lfm, j, 64); const int bk = __shfl(Lk, j, 64);
+                        if (Nv && better(bfm, bk, fm, k)) ++rN;
+                    }
+                    if (Lv && rL < 64) { tmp_fm[rL] = Lfm; tmp_k[rL] = Lk; tmp_fl[rL] = Lfl; }
+                    if (Nv && rN < 64) { tmp_fm[rN] = fm; tmp_k[rN] = k; tmp_fl[rN] = fl; }
+                    nL = min(64, __popcll(mL) + __popcll(mN));
+                    __syncthreads();
+                    Lv = lane < nL;
+                    if (Lv) { Lfm = tmp_fm[lane]; Lk = tmp_k[lane]; Lfl = tmp_fl[lane]; }
+                    __syncthreads();
+                }
+                if (Lv) { fr_child[lv][lane] = cs + Lk; fr_flag[lv][lane] = (unsigned char)Lfl; }
+                return nL;
+            };
+            {
+                const int cnt = build_frame(0, cur);
+                if (lane == 0) { fr_cnt[0] = cnt; fr_next[0] = 0; st_pid[0] = -1; st_depth[0] = max_length; }
+            }
             __syncthreads();
             sp = 1;
             while (sp > 0 && n < max_size) {
-                const int u = st_node[sp - 1], pid = st_pid[sp - 1], depth = st_depth[sp - 1];
-                const double cfm = st_fm[sp - 1];
-                const int cpos = st_pos[sp - 1];
-                const int cs = t.cstart[u], cc = t.ccount[u];
-                // next child after the cursor in (fm desc, position asc) order
-                double bfm = -1.0; int bpos = 0x7fffffff;
-                for (int k = lane; k < cc; k += 64) {
-                    const int c = cs + k;
-                    const double fm = __dadd_rn(__dmul_rn(w1, t.fi[c]), __dmul_rn(w, t.fo[c]));      // :254, no FMA
-                    const bool after = fm < cfm || (fm == cfm && k > cpos);
-                    if (after && (fm > bfm || (fm == bfm && k < bpos))) { bfm = fm; bpos = k; }
+                const int lv = sp - 1;
+                const int nx = fr_next[lv];
+                if (nx >= fr_cnt[lv]) { --sp; continue; }                     // children exhausted
+                const int c = fr_child[lv][nx], fl = fr_flag[lv][nx], pid = st_pid[lv], depth = st_depth[lv];
+                __syncthreads();                                              // everybody has read the cursor before lane 0 moves it
+                if (lane == 0) fr_next[lv] = nx + 1;
+                if (fl & 1) ++sz0;
+                if (fl & 2) ++sz1;
+                const int rid = n++;
+                if (lane == 0) {
+                    oid[rid] = t.tok[c];
+                    orm[rid] = (pid > -1 ? orm[pid] : 1ull) | (1ull << rid);
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const double ofm = __shfl_xor(bfm, o, 64);
-                    const int op = __shfl_xor(bpos, o, 64);
-                    if (ofm > bfm || (ofm == bfm && op < bpos)) { bfm = ofm; bpos = op; }
-                }
-                __syncthreads();
-                if (bpos == 0x7fffffff) { --sp; continue; }                   // children exhausted
-                if (lane == 0) { st_fm[sp - 1] = bfm; st_pos[sp - 1] = bpos; }
-                const int c = cs + bpos;
-                const double cfi = t.fi[c], cfo = t.fo[c];
-                bool skip;
-                if (mode == LA_MODE_MIX) skip = cfi < lo_in && cfo < lo_out && bfm < lo_mix;            // :265
-                else if (mode == LA_MODE_INPUT) skip = cfi < lo_in;
-                else skip = cfo < lo_out;
-                if (!skip) {
-                    if (cfi > 0.0) ++sz0;
-                    if (cfo > 0.0) ++sz1;
-                    const int rid = n++;
-                    if (lane == 0) {
-                        oid[rid] = t.tok[c];
-                        orm[rid] = (pid > -1 ? orm[pid] : 1ull) | (1ull << rid);
-                    }
-                    if (t.ccount[c] > 0 && depth - 1 > 0 && n < max_size) {
-                        if (lane == 0) { st_node[sp] = c; st_fm[sp] = 1e308; st_pos[sp] = -1; st_pid[sp] = rid; st_depth[sp] = depth - 1; }
-                        ++sp;
-                    }
+                if (t.ccount[c] > 0 && depth - 1 > 0 && n < max_size && sp < 72) {
+                    const int cnt = build_frame(sp, c);
+                    if (lane == 0) { fr_cnt[sp] = cnt; fr_next[sp] = 0; st_pid[sp] = rid; st_depth[sp] = depth - 1; }
+                    ++sp;
                 }
                 __syncthreads();
             }
             n_out = n;
+            if (stamp && lane == 0) { stamp[4] = wall_clock64(); stamp[6] = n; }
         }
         if (n_out >= branch_length) break;                                    // :433-434 (else a later suffix overwrites)
     }
@@ -255,7 +343,7 @@ int lk_trie_hier_get(hipStream_t st, const int* tok, const double* fo, const dou
     a.queries = queries; a.nq = nq; a.decoding_length = decoding_length; a.branch_length = branch_length;
     a.min_in = min_in; a.min_out = min_out; a.mode = mode; a.stop = stop; a.n_stop = n_stop;
     a.scratch_q = scratch_q; a.scratch_v = scratch_v; a.out_ids = out_ids; a.out_rowmask = (unsigned long long*)out_rowmask;
-    a.out_n = out_n; a.out_sizes = out_sizes; a.out_nsizes = out_nsizes;
+    a.out_n = out_n; a.out_sizes = out_sizes; a.out_nsizes = out_nsizes; a.dbg = g_la_dbg_times;
     k_trie_hier_get<<<B, 64, 0, st>>>(a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
@@ -297,7 +385,7 @@ int lk_trie_hier_get2(hipStream_t st, const int* tok, const double* fo, const do
     a.queries = queries; a.nq = nq; a.decoding_length = decoding_length; a.branch_length = branch_length;
     a.min_in = min_in; a.min_out = min_out; a.mode = mode; a.stop = stop; a.n_stop = n_stop;
     a.scratch_q = scratch_q; a.scratch_v = scratch_v; a.out_ids = out_ids; a.out_rowmask = (unsigned long long*)out_rowmask;
-    a.out_n = out_n; a.out_sizes = out_sizes; a.out_nsizes = out_nsizes;
+    a.out_n = out_n; a.out_sizes = out_sizes; a.out_nsizes = out_nsizes; a.dbg = g_la_dbg_times;
     k_trie_hier_get<<<B, 64, 0, st>>>(a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

@@ -76,11 +76,16 @@ class DeviceTrie(object):
         dev = self.device
         self._hq = torch.zeros(B * 8 + 3 * B, dtype=torch.int32).pin_memory()      # queries [B][8], nq [B], plane [B], bl [B]
         self._dq = torch.zeros(B * 8 + 3 * B, dtype=torch.int32, device=dev)
-        self.out_ids = torch.zeros(B * 64, dtype=torch.int32, device=dev)
-        self.out_rm = torch.zeros(B * 64, dtype=torch.int64, device=dev)
-        self.out_n = torch.zeros(B, dtype=torch.int32, device=dev)
-        self.out_sizes = torch.zeros(B * 2, dtype=torch.int32, device=dev)
-        self.out_nsizes = torch.zeros(B, dtype=torch.int32, device=dev)
+        # ONE result block [row masks (8-byte aligned) | ids | n | sizes | nsizes]: hier_get reads it back with a single D2H copy
+        # (round 2: five synchronous .cpu() calls, ~130 us of the 730 us a bs=1 query cost — profiles/r03_trie_device_profile.txt)
+        words = B * (128 + 64 + 1 + 2 + 1)
+        self._out = torch.zeros(words, dtype=torch.int32, device=dev)
+        self._h_out = torch.zeros(words, dtype=torch.int32).pin_memory()
+        self.out_rm = self._out[:B * 128].view(torch.int64)
+        self.out_ids = self._out[B * 128:B * 192]
+        self.out_n = self._out[B * 192:B * 193]
+        self.out_sizes = self._out[B * 193:B * 195]
+        self.out_nsizes = self._out[B * 195:B * 196]
         self._scratch = None
 
     def _stream(self):
@@ -199,10 +204,13 @@ class DeviceTrie(object):
         """-> list of (ids list, uint64 row masks, sizes list), like LookaheadCache.hier_get per query."""
         B = self.hier_get_dev(queries, idxs=idxs, branch_lengths=branch_lengths, decoding_length=decoding_length,
                               branch_length=branch_length, min_input_size=min_input_size, min_output_size=min_output_size, mode=mode)
+        self._h_out.copy_(self._out, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
-        ids = self.out_ids[:B * 64].cpu().numpy().reshape(B, 64)
-        rm = self.out_rm[:B * 64].cpu().numpy().view(np.uint64).reshape(B, 64)
-        on = self.out_n[:B].cpu().numpy()
-        osz = self.out_sizes[:B * 2].cpu().numpy().reshape(B, 2)
-        ons = self.out_nsizes[:B].cpu().numpy()
+        Q = self._qcap
+        h = self._h_out.numpy()
+        rm = h[:Q * 128].view(np.uint64).reshape(Q, 64)
+        ids = h[Q * 128:Q * 192].reshape(Q, 64)
+        on = h[Q * 192:Q * 193]
+        osz = h[Q * 193:Q * 195].reshape(Q, 2)
+        ons = h[Q * 195:Q * 196]
         return [(ids[b, :on[b]].tolist(), rm[b, :on[b]].copy(), osz[b, :ons[b]].tolist()) for b in range(B)]

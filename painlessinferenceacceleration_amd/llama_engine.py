@@ -560,6 +560,29 @@ class LlamaVerifyEngine(object):
         return [o[_lib.LA_MOUT_OUTTOK + _lib.LA_MOUT_TOKS * b:_lib.LA_MOUT_OUTTOK + _lib.LA_MOUT_TOKS * b + int(o[_lib.LA_MOUT_NOUT + b])].tolist()
                 for b in range(len(blocks))]
 
+    def mstep_trie(self, dev_trie, q0, slots, limits, last_tokens):
+        """One multi-block verify step whose drafts are the results of the LAST dev_trie.hier_get_dev(...) launch, taken on the
+        device: block b = query q0 + b of that launch (ids / row masks / count stay in HBM; nothing but the result header crosses
+        PCIe).  The trie kernels must have been queued on this engine's stream.  slots / limits / last_tokens: per block.
+        -> (emitted token lists, draft lengths)."""
+        nb = len(slots)
+        assert self.max_blocks and 1 <= nb <= self.max_blocks
+        arr = lambda v: (C.c_int32 * nb)(*[int(x) for x in v])
+        lim = [max(1, min(_lib.LA_MOUT_TOKS, int(x))) for x in limits]
+        check(lib.la_llama_mstep_trie(self._h, self._sp(), nb, arr(slots), arr(lim), arr(last_tokens),
+                                      C.c_void_p(dev_trie.out_ids.data_ptr() + 4 * 64 * q0), C.c_void_p(dev_trie.out_rm.data_ptr() + 8 * 64 * q0),
+                                      C.c_void_p(dev_trie.out_n.data_ptr() + 4 * q0), self.host_mout.data_ptr()), 'llama_mstep_trie')
+        self.stream.synchronize()
+        o = self._mout_np
+        self._mstep_slots = list(slots)
+        for slot in slots:
+            self.slot_keys[slot] = int(o[_lib.LA_MOUT_NKEYS + slot])
+        if 0 in slots:
+            self.n_keys = self.slot_keys[0]
+        toks = [o[_lib.LA_MOUT_OUTTOK + _lib.LA_MOUT_TOKS * b:_lib.LA_MOUT_OUTTOK + _lib.LA_MOUT_TOKS * b + int(o[_lib.LA_MOUT_NOUT + b])].tolist()
+                for b in range(nb)]
+        return toks, [int(o[_lib.LA_MOUT_T + b]) for b in range(nb)]
+
     # ---- wide trees: one sequence's tree of up to LA_TREE_WIDE_MAX rows as consecutive blocks of one multi-block pass -------
     def tstep(self, ids, rowmask, slot=0, mode=0, limit=None, eager=False):
         """One verify step of ONE sequence whose draft tree may be wider than a 64-row block (the reference grid-searches

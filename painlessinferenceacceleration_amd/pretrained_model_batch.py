@@ -183,6 +183,10 @@ class LookaheadPreTrainedModel(object):
         else:
             first = eng.mprefill_many(prompts) if multi else eng.bprefill_many(prompts)
         next_token_list = [[first[i]] for i in range(bs)]
+        dmode = decoding_kwargs.get('decoding_mode', 'hier')
+        chained = bool(decoding_kwargs.get('device_trie', False)) and multi and not sequential and streamer is None and \
+            bool(decoding_kwargs.get('per_sample_budget', False)) and dmode.split('_')[0] == 'hier' and \
+            not decoding_kwargs.get('debug_lookahead', False)
         decoding_kwargs['dls'].extend([1] * bs)
         decoding_kwargs['edls'].extend([1] * bs)
         max_cur = 0
@@ -208,6 +212,36 @@ class LookaheadPreTrainedModel(object):
             ts = te
             if not batch_indices:
                 break
+            if chained:
+                # device trie chained in front of the verify pass (la_llama_mstep_trie): ONE query launch for all active samples on the
+                # engine's stream, the step input assembled on the device from its outputs, one 64-row block per sample — no draft
+                # crosses PCIe in either direction; the host reads back the accepted tokens and the draft lengths only.  Same budget
+                # rule as the host path with per_sample_budget (lookahead_cache.py:534-541).
+                ts_q = time.time()
+                qids = [rows[b][-2:] for b in batch_indices]
+                per = min(decoding_length, _lib.LA_TREE_MAX)
+                dm = decoding_kwargs.get('decoding_mode', 'hier')
+                mode_q = (dm if '_' in dm else dm + '_mix').split('_')[1]
+                dt = self._device_trie(decoding_kwargs['_n_samples'])
+                with torch.cuda.stream(eng.stream):
+                    dt.hier_get_dev(qids, idxs=batch_indices, decoding_length=per, branch_length=branch_length, min_input_size=0,
+                                    min_output_size=max(per // 2, 1), mode=mode_q)
+                    emitted, widths = {}, []
+                    for g0 in range(0, len(batch_indices), eng.max_blocks):
+                        grp = batch_indices[g0:g0 + eng.max_blocks]
+                        toks, Ts = eng.mstep_trie(dt, g0, grp, [stop_max_length - (len(rows[b]) - 1) - 1 for b in grp],
+                                                  [rows[b][-1] for b in grp])
+                        for b, tk in zip(grp, toks):
+                            emitted[b] = tk
+                        widths.extend(Ts)
+                decoding_kwargs['qts'].append(time.time() - ts_q)
+                decoding_kwargs.update({'decoding_qids': qids, 'decoding_ids': None, 'hit_sizes': None, 'batch_indices': batch_indices})
+                width = max(widths)
+                next_token_list = [emitted[b] for b in batch_indices]
+                for k in range(len(batch_indices)):
+                    decoding_kwargs['dls'].append(width)
+                    decoding_kwargs['edls'].append(len(next_token_list[k]))
+                continue
             drafts = self.lookahead_prepare_inputs_for_generation([rows[b] for b in batch_indices], batch_indices,
                                                                   decoding_kwargs)
             segments = []

@@ -27,3 +27,19 @@ for B in (1, 8, 64, 256):
     for _ in range(n): dev.hier_get(qs[:B], 64, 12, 0, 32, 'mix')
     w = (time.time() - t0) / n
     print(f'device hier_get B={B}: {w*1e6:.0f} us per call incl. transfers ({w*1e6/B:.1f} us/query)')
+
+# phase stamps of k_trie_hier_get (la_debug_set_ptr(0, buffer): wall_clock64 = 100 MHz ticks)
+import ctypes as C
+from painlessinferenceacceleration_amd._lib import lib, check
+B = 64
+stamps = torch.zeros(B * 8, dtype=torch.int64, device='cuda:0')
+check(lib.la_debug_set_ptr(0, C.c_void_p(stamps.data_ptr())), 'set_ptr')
+dev.hier_get(qs[:B], 64, 12, 0, 32, 'mix')
+check(lib.la_debug_set_ptr(0, None), 'set_ptr')
+st = stamps.cpu().numpy().reshape(B, 8)
+us = lambda a, b: (st[:, b] - st[:, a]) / 100.0
+ok = st[:, 4] > 0
+print(f'phases over {int(ok.sum())} of {B} queries that reached the DFS (us, median / max): '
+      f'match {np.median(us(0,1)[ok]):.1f}/{us(0,1)[ok].max():.1f}  live-subtree scan {np.median(us(1,2)[ok]):.1f}/{us(1,2)[ok].max():.1f}  '
+      f'cut-offs {np.median(us(2,3)[ok]):.1f}/{us(2,3)[ok].max():.1f}  ordered DFS {np.median(us(3,4)[ok]):.1f}/{us(3,4)[ok].max():.1f}  '
+      f'| live rows median {np.median(st[ok,5]):.0f} max {st[ok,5].max()}  emitted median {np.median(st[ok,6]):.0f}')
