@@ -386,12 +386,14 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
     // row group = wave / 4: a workgroup's waves are dealt to the SIMDs cyclically, so each SIMD gets one wave of either row group
     // (the row groups' epilogues differ in weight: a planned gate/up image has 32 valid rows in one pair of blocks, R - 32 in the other)
     const int rg = wave / TQ, tq = wave % TQ;        // RBV = 2: 1 x 8, RBV = 4: 2 x 4, RBV = 8: 4 row groups x 2 token groups
-    static_assert(TQ == (RBV == 8 ? 2 : RBV == 4 ? 4 : 8) && (EPI == MB_SWIGLU || RBV != 8), "wave grid");
+    static_assert(TQ == (RBV == 8 ? 2 : RBV == 4 ? 4 : 8) && (EPI == MB_SWIGLU || EPI == MB_QKV || RBV != 8), "wave grid");
     // the wave's two row-blocks: planned gate/up images are {G0, G1, U0, U1} (pair = rb, rb + 2), classic interleaved images
     // {G, U, G, U} (pair = 2 rg, 2 rg + 1); lm_head rows are independent; RBV = 2 images are {lo, hi} / two plain blocks
     // RBV = 8 (planned gate/up only): row groups 0, 1 work on region 2 x, row groups 2, 3 on region 2 x + 1 (blocks 4..7)
-    const int rb0 = RBV == 8 ? 4 * (rg >> 1) + (rg & 1) : RBV == 4 ? ((EPI == MB_SWIGLU && !a.gu_interleaved) ? rg : 2 * rg) : 0;
-    const int rb1 = RBV == 8 ? rb0 + 2 : RBV == 4 ? ((EPI == MB_SWIGLU && !a.gu_interleaved) ? rg + 2 : 2 * rg + 1) : 1;
+    // RBV = 8 with MB_QKV ("quad" form): FOUR adjacent {lo, hi} regions per workgroup, row group rg = region 4 x + rg, a quarter of
+    // the token blocks per workgroup (grid.z = 4)
+    const int rb0 = (RBV == 8 && EPI == MB_QKV) ? 2 * rg : RBV == 8 ? 4 * (rg >> 1) + (rg & 1) : RBV == 4 ? ((EPI == MB_SWIGLU && !a.gu_interleaved) ? rg : 2 * rg) : 0;
+    const int rb1 = (RBV == 8 && EPI == MB_QKV) ? 2 * rg + 1 : RBV == 8 ? rb0 + 2 : RBV == 4 ? ((EPI == MB_SWIGLU && !a.gu_interleaved) ? rg + 2 : 2 * rg + 1) : 1;
     const int ksplit = gridDim.y, ks = blockIdx.y;
     const int t0 = (int)(((long)a.K16 * ks) / ksplit), t1 = (int)(((long)a.K16 * (ks + 1)) / ksplit);
     const int nst = (t1 - t0 + KS - 1) / KS;
@@ -1544,7 +1546,7 @@ __global__ __launch_bounds__(256) void k_kv_commit_mb(const bf16_t* __restrict__
 static bool g_mb_attr = false;
 int g_la_mb_dbg = 0;
 int g_la_mb_mode = 0;         // la_debug_set key 5: 1 = wide kernel as two co-resident workgroups per CU (80 KiB LDS, 256 rows each)
-int g_la_mb_pair = 1;         // la_debug_set key 6, bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too
+int g_la_mb_pair = 1;         // la_debug_set key 6, bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
 int g_la_mb_ks2 = 0;          // la_debug_set key 12: slab GEMMs of the multi-block step with 2 K splits at >= 5 blocks (measurement)
 int g_la_mb_narrow = 0;       // la_debug_set key 3: 1 = the K-split kernels (k_gemm_mb) for every nblk (A/B measurements)
 template <typename K> static hipError_t set_lds(K k, int bytes) {
@@ -1576,6 +1578,7 @@ int lk_mb_init() {
 #undef SETW2
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 2, MB_SLAB, 4>, WideGeom<4, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 2, MB_QKV, 4>, WideGeom<4, 2>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<8, 2, MB_QKV>, WideGeom<8, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 1>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 2>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 3>, WideGeom<4, 4>::LDS);
@@ -1680,6 +1683,25 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
             // whole x operand of its token blocks from L2 (1 GB per launch at 512 rows and 256 workgroups: the dominant term of these
             // launches); pairing halves that, and the second reader of a weight region (z = 1, 128 workgroup ids later: same XCD)
             // finds it in L2.  Same MFMAs on the same operands in the same order per output: bit-identical results.
+            // Quad form (MB_QKV of a GQA model at >= 7 blocks: small N, many rows — the x re-reads dominate): FOUR adjacent regions and
+            // a QUARTER of the token blocks per workgroup.  L2 -> LDS traffic of the launch = x bytes x (workgroup columns) + W bytes x
+            // (token groups): Mistral QKV at 512 rows 512 + 100 MB paired -> 256 + 200 MB quad; not taken where W dominates
+            // (MHA / 13B shapes, <= 4 blocks).  Same MFMA chain per output element: bit-identical to the paired and unpaired forms.
+            if constexpr (EPI == MB_QKV) {
+                const double xb = (double)nblk * 64 * a.K16 * 32, wb = (double)a.N * a.K16 * 32;       // bytes of x and of W
+                const double paired = xb * (n_wg / 2) + wb * ((nblk + 3) / 4), quad = xb * (n_wg / 4) + wb * ((nblk + 1) / 2);
+                if ((g_la_mb_pair & 4) && a.planned && nblk >= 7 && n_wg % 4 == 0 && (n_wg / 4 * ksplit) % 8 == 0 && quad < 0.85 * paired) {
+                    MbArgs p = a;
+                    p.w_keep = 1;
+                    for (int r = 1; r < 4; ++r)
+                        for (int j = 0; j < 2; ++j) {
+                            p.boff[2 * r + j] = r * a.wg_chunks + a.boff[j]; p.nv[2 * r + j] = a.nv[j]; p.nvl[2 * r + j] = a.nvl[j];
+                        }
+                    p.wg_chunks = 4 * a.wg_chunks;
+                    k_gemm_wide<8, 2, EPI><<<dim3(n_wg / 4, ksplit, (nblk + 1) / 2), 512, WideGeom<8, 2>::LDS, st>>>(p);
+                    LAUNCH_CHECK(); return 0;
+                }
+            }
             if ((g_la_mb_pair & 1) && n_wg % 2 == 0 && (n_wg / 2 * ksplit) % 8 == 0) {
                 MbArgs p = a;
                 p.w_keep = 1;

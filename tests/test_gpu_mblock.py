@@ -358,15 +358,16 @@ def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
                 check(lib.la_qkv_row_perm(nh, nkv, perm.ctypes.data_as(_lib.pi32)), 'perm')
                 wp = gu.pack_weight(w[torch.from_numpy(perm.astype(np.int64)).to(DEV)].contiguous())
             outs = []
-            for pair in (0, 1):
+            for pair in (0, 1, 5):          # 5 = paired + the QUAD form of the QKV launch (taken at >= 7 blocks of a GQA shape)
                 check(lib.la_debug_set(6, pair), 'debug_set')
                 qf = torch.zeros(8 * nh * 8192, dtype=torch.bfloat16, device=DEV)
                 kf = torch.zeros(8 * nkv * 8192, dtype=torch.bfloat16, device=DEV)
                 vf = torch.zeros(8 * nkv * 8192, dtype=torch.bfloat16, device=DEV)
                 _mb(2, wp, _pack_blocks(x), N, K, nblk, n_wg=nwg, pos=pos, rc=rc, rs_=rs_, qf=qf, kf=kf, vf=vf, nh=nh, nkv=nkv)
                 outs.append((qf, kf, vf))
-            for a_, b_ in zip(outs[0], outs[1]):
-                assert torch.equal(a_, b_), (nh, nkv, nwg)
+            for o in outs[1:]:
+                for a_, b_ in zip(outs[0], o):
+                    assert torch.equal(a_, b_), (nh, nkv, nwg)
         # gate/up + SwiGLU on planned images: two regions {G0, G1, U0, U1} x 2 per workgroup (RBV = 8 wave grid)
         for F, K in ((11008, 512), (13824, 1024), (14336, 256)):
             g = torch.Generator(device=DEV).manual_seed(F + nblk)
