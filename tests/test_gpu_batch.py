@@ -400,3 +400,24 @@ def test_batch_processor_run_vs_reference_golden():
             top = torch.topk(sc, 2).values
             assert float(top[0] - top[1]) <= 2 * TOL * float(lg[-1].float().abs().max()), (name, b, i)
     print('batch processor cases identical to the reference run end to end:', whole, 'of 3')
+
+
+def test_kv_ring_engine_generates_up_to_its_max_length():
+    """An engine built with max_length = L admits stop_max_length = L with the KV cache as a ring exactly as the linear cache does
+    (round-2 review: the ring's capacity was one key short, so the same max_length behaved differently with and without
+    kv_ring); the tokens equal the windowed linear-cache run."""
+    L = 300
+    outs = []
+    for ring in (False, True):
+        shape = tiny_shape()
+        shape.sliding_window = 96
+        sd = random_weights(shape, seed=2, device='cpu', decisive=True)
+        model = BatchLlama(shape, dict(sd), max_length=L, max_batch=2, eos_token_id=None, max_blocks=2, kv_ring=ring)
+        rs = np.random.RandomState(17)
+        ids = rs.randint(3, shape.vocab, size=(2, 50)).astype(np.int64)
+        dk = {'use_lookahead': True, 'decoding_length': 64, 'branch_length': 12, 'stop_words': {}, 'per_sample_budget': True}
+        out = model.lookahead_generation(torch.from_numpy(ids), stopping_criteria=L, eos_token_id=[None], pad_token_id=0,
+                                         return_dict_in_generate=True, decoding_kwargs=dk)
+        assert out.sequences.shape[1] == L
+        outs.append(out.sequences.cpu().numpy().tolist())
+    assert outs[0] == outs[1]

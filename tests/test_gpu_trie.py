@@ -6,6 +6,7 @@ import random
 
 import numpy as np
 import pytest
+import torch
 
 from painlessinferenceacceleration_amd.device_trie import DeviceTrie
 from painlessinferenceacceleration_amd.lookahead_cache import LookaheadCache
@@ -196,3 +197,32 @@ def test_single_sequence_loop_with_device_trie_equals_host_trie_loop():
         outs.append(runs)
     assert outs[0] == outs[1] == outs[2]
     assert np.mean(outs[2][1][2][1:]) > 2.0
+
+
+def test_second_mirror_revokes_the_first_and_staging_is_reusable_back_to_back():
+    """la_cache_mirror_enable replaces a cache's mirror: an older DeviceTrie would apply its next patch to the wrong image, so it
+    must refuse to be used; and hier_get_dev(sync=True) called back to back (no stream sync in between) must not overwrite a
+    pinned staging buffer an earlier H2D copy is still reading (an event behind the copies is waited for)."""
+    cache = LookaheadCache(eos_ids=[None])
+    rs = np.random.RandomState(3)
+    seqs = [rs.randint(3, 200, size=60).tolist() for _ in range(20)]
+    for s_ in seqs:
+        cache.put(s_, branch_length=9, mode='output', idx=-1)
+    a = DeviceTrie(cache, idx=0)
+    q1, q2 = [seqs[0][5:7], seqs[1][9:11]], [seqs[2][3:5], seqs[3][1:3]]
+    want1 = []
+    for q in q1:                                      # (the packed getters return views of buffers the next call reuses)
+        w = cache.hier_get_packed(q, 64, 8, 0, 32, 'mix', 0)
+        want1.append((w[0].tolist(), w[1].copy()))
+    # back to back: second call rewrites the staging buffers right after the first one queued its copies
+    a.hier_get_dev(q1, decoding_length=64, branch_length=8, min_input_size=0, min_output_size=32, mode='mix')
+    ids1 = a.out_ids[:2 * 64].clone(); n1 = a.out_n[:2].clone(); rm1 = a.out_rm[:2 * 64].clone()
+    a.hier_get_dev(q2, decoding_length=64, branch_length=8, min_input_size=0, min_output_size=32, mode='mix')
+    torch.cuda.synchronize()
+    for b, (ids, rm) in enumerate(want1):
+        n = int(n1[b])
+        assert ids1[b * 64:b * 64 + n].cpu().tolist() == ids and rm1[b * 64:b * 64 + n].cpu().numpy().view(np.uint64).tolist() == rm.tolist()
+    b_ = DeviceTrie(cache, idx=0)
+    with pytest.raises(RuntimeError):
+        a.hier_get([seqs[0][5:7]], decoding_length=64, branch_length=8)
+    assert b_.hier_get([seqs[0][5:7]], decoding_length=64, branch_length=8, min_output_size=32)[0][0] == want1[0][0]

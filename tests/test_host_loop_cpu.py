@@ -349,3 +349,18 @@ def test_custom_stopping_criteria_are_evaluated_every_step():
                                         stopping_criteria=StoppingCriteriaList([MaxLengthCriteria(max_length=P + max_new)]),
                                         decoding_kwargs=dict(DK))
     assert out2.sequences[0].tolist() == seq
+
+
+def test_load_hf_checkpoint_skips_consolidated_safetensors(tmp_path):
+    """Mistral / Mixtral repositories ship consolidated.safetensors (other key names) NEXT to the HF-named shards: without an
+    index file only the HF files may be read — reading both doubles host memory and leaves keys nobody consumes."""
+    import transformers
+    from safetensors.torch import save_file
+    from painlessinferenceacceleration_amd.llama_engine import load_hf_checkpoint
+    cfg = transformers.LlamaConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2, vocab_size=100)
+    cfg.save_pretrained(tmp_path)
+    save_file({'model.embed_tokens.weight': torch.zeros(100, 64)}, str(tmp_path / 'model.safetensors'))
+    save_file({'tok_embeddings.weight': torch.ones(100, 64)}, str(tmp_path / 'consolidated.safetensors'))
+    save_file({'layers.0.w': torch.ones(4)}, str(tmp_path / 'consolidated.00.safetensors'))
+    _, sd = load_hf_checkpoint(str(tmp_path))
+    assert sorted(sd) == ['model.embed_tokens.weight']
