@@ -573,7 +573,43 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
             // RoPE in bf16 arithmetic (apply_rotary_pos_emb, modeling_llama.py:154-169); tile 0 = lo halves, tile 1 = hi halves
             const int ps = a.pos[blk * 64 + tok];
             const int region = blockIdx.x * (RBV / 2) + rg;      // RBV = 4 (paired form): row group rg holds the {lo, hi} blocks of region 2 x + rg
-            if ((a.R & 1) == 0) {
+            if ((a.R & 3) == 0) {
+                // groups of FOUR consecutive rows = one register group of the lane (R % 4 == 0 keeps a group inside one head slot and
+                // one 16-byte chunk of the fragment: 7B / Mistral / Mixtral shapes): 8-byte cos / sin loads and fragment stores —
+                // half the store instructions of the pair form below (the epilogue of this launch is store-issue-bound)
+#pragma unroll
+                for (int i = 0; i < 16; i += 4) {
+                    if (8 * (i >> 2) >= a.nv[0]) break;                // wave-uniform
+                    const int f = 8 * (i >> 2) + 4 * hh;
+                    if (f < a.nv[0]) {
+                        const int prr = a.R * region + f, slot = prr >> 6, dlo = prr & 63, dhi = dlo + 64;
+                        if (slot < a.nh + a.nkv) {
+                            bf16_t* dst = slot < a.nh ? a.qf + ((size_t)blk * a.nh + slot) * 8192
+                                                      : a.kfresh + ((size_t)blk * a.nkv + (slot - a.nh)) * 8192;
+                            const uint2 c4 = *(const uint2*)(a.rcos + (size_t)ps * 64 + dlo), s4 = *(const uint2*)(a.rsin + (size_t)ps * 64 + dlo);
+                            uint2 olo = {0u, 0u}, ohi = {0u, 0u};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const uint32_t cw = e < 2 ? c4.x : c4.y, sw = e < 2 ? s4.x : s4.y;
+                                const float cc = bf2f((bf16_t)(cw >> (16 * (e & 1)))), sn = bf2f((bf16_t)(sw >> (16 * (e & 1))));
+                                const float bl = bfr_hw(acc[0][t][i + e]), bh = bfr_hw(acc[1][t][i + e]);
+                                const uint32_t lo16 = (uint32_t)f2bf_hw(bfr_hw(bl * cc) + bfr_hw(-bh * sn)) << (16 * (e & 1));
+                                const uint32_t hi16 = (uint32_t)f2bf_hw(bfr_hw(bh * cc) + bfr_hw(bl * sn)) << (16 * (e & 1));
+                                if (e < 2) { olo.x |= lo16; ohi.x |= hi16; } else { olo.y |= lo16; ohi.y |= hi16; }
+                            }
+                            *(uint2*)(dst + rf_offset(tok, dlo)) = olo;
+                            *(uint2*)(dst + rf_offset(tok, dhi)) = ohi;
+                        } else {
+                            bf16_t* dst = a.vfresh + ((size_t)blk * a.nkv + (slot - a.nh - a.nkv)) * 8192;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                dst[vf_offset(tok, dlo + e)] = f2bf_hw(acc[0][t][i + e]);
+                                dst[vf_offset(tok, dhi + e)] = f2bf_hw(acc[1][t][i + e]);
+                            }
+                        }
+                    }
+                }
+            } else if ((a.R & 1) == 0) {
                 // pairs of consecutive rows (an even R keeps them in one head and one 16-byte chunk): 4-byte table loads and stores
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) {
