@@ -1249,7 +1249,8 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(const bf16_t*
     AttnArgs a = a0;
     a.qf = qf_s; a.rowmask = rowmask_s; a.state = state_s; a.seq = seq_s; a.kmain = kmain_s; a.vmain = vmain_s;
     a.max_keys = max_keys_s; a.nsplit = nsplit_s; a.nh = nh_nkv >> 16; a.nkv = nh_nkv & 0xffff; a.window = window_s;
-    const int h = blockIdx.x, sp = blockIdx.y;
+    // GQA: head id from the block id so that the query heads of one kv head share an XCD (= an L2): see k_tree_attn_mb
+    const int h = ((int)blockIdx.x % a.nkv) * (a.nh / a.nkv) + (int)blockIdx.x / a.nkv, sp = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tb = wave & 1, par = wave >> 1;      // par in [0, LA_ATT_PAR)

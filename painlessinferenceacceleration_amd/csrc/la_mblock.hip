@@ -1165,11 +1165,16 @@ struct MbAttnArgs {
 template <bool PIECE>
 __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float mgbuf[];   // [4][2][66][64]
-    const int h = blockIdx.x, sp = blockIdx.y, blk = blockIdx.z;
+    // GQA: the query heads of one kv head read the SAME K/V tiles.  Block x of a grid runs on XCD x % 8 and every XCD has its own
+    // L2, so consecutive head ids would put the 4 readers of a Mistral kv head on 4 different XCDs — 4 HBM reads of every tile.
+    // Head id from the block id so that the group of kv head g sits on one XCD (x % nkv = g: x, x + nkv, x + 2 nkv, ... share
+    // x % 8 when nkv % 8 == 0); any nkv: still a permutation of the heads.
+    const int grp_ = a.nh / a.nkv;
+    const int h = ((int)blockIdx.x % a.nkv) * grp_ + (int)blockIdx.x / a.nkv, sp = blockIdx.y, blk = blockIdx.z;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tb = wave & 1, par = wave >> 1;
-    const int hk = h / (a.nh / a.nkv);
+    const int hk = h / grp_;
     const int KB = a.total_keys >> 5;
     const int* mt = a.meta + blk * LA_MB_META;
     const int slot = mt[LA_MBM_SLOT], T = mt[LA_MBM_T], nkeys = mt[LA_MBM_NKEYS], first = mt[LA_MBM_FIRST];
