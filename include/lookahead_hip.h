@@ -43,7 +43,7 @@ extern "C" {
 #define LA_MOE_MAX_E      8   /* experts per mixture-of-experts layer (Mixtral: 8, top-2) */
 
 /* ABI version: bumped when a signature changes. */
-#define LA_ABI_VERSION  7    /* bumped whenever a struct layout or an entry point changes */
+#define LA_ABI_VERSION  8    /* bumped whenever a struct layout or an entry point changes */
 int          la_abi_version(void);   /* == LA_ABI_VERSION of the header the library was built from */
 const char*  la_last_error(void);
 /* Measurement knobs for the kernel A/B scripts (scripts/gpu_ab.py); every knob is 0 in production.
@@ -134,9 +134,41 @@ int la_cache_mirror_state(la_cache* c, int32_t* n_records, int32_t* full, int32_
 int la_cache_mirror_image(la_cache* c, int32_t cap, int32_t* tok, double* fo, double* fi /*[planes][cap]*/, int32_t* cstart,
                           int32_t* ccount);
 int la_cache_mirror_patch(la_cache* c, int32_t* ipatch /*[n_i][3]*/, int32_t* dkey /*[n_d][2]*/, double* dval /*[n_d]*/);
-/* Apply a patch to the device image (one thread per word; fi planes are `fi_stride` records apart). */
+/* Apply a patch to the device image (one thread per word; fi planes are `fi_stride` records apart).  d_ccap (block capacities,
+ * patch array 3) may be NULL when the image is only queried. */
 int la_trie_patch_dev(void* stream, int32_t* d_tok, double* d_fo, double* d_fi, int64_t fi_stride, int32_t* d_cstart,
-                      int32_t* d_ccount, const int32_t* d_ipatch, int n_i, const int32_t* d_dkey, const double* d_dval, int n_d);
+                      int32_t* d_ccount, int32_t* d_ccap, const int32_t* d_ipatch, int n_i, const int32_t* d_dkey, const double* d_dval,
+                      int n_d);
+
+/* Device-side trie UPDATE: LookaheadCache.stream_put(final=False, mode='output') (lookahead_cache.py:369-406, Tree.put/_put/_pack
+ * :33-63) applied to the device image by the device, from tokens that are already in HBM (the accepted tokens of a verify step:
+ * d_src_tok = la_llama_mstep's device output block + LA_MOUT_OUTTOK, stride LA_MOUT_TOKS, counts = the LA_MOUT_NOUT words).  The
+ * image grows by the host mirror's rule and in the host's order, so the host REPLAYS the same puts on its trie afterwards
+ * (la_cache_stream_put with the tokens it read back, then la_cache_mirror_discard) and the two stay word-for-word identical; no
+ * patch crosses PCIe for these updates.  Everything else (input-mode put, final flush, reset_input_freqs, squeeze, load) stays a
+ * host update that reaches the device as a patch or a full image, as before.
+ *   la_trie_image          the device arrays: records [0, meta[0]) of `cap`; ccap = block capacities (la_cache_mirror_ccap);
+ *                          meta int32[4] = {records in use, overflow (sticky), branches inserted, records appended};
+ *                          root_of int32[n_root_of] = token -> record of its tree root (la_trie_root_index_dev rebuilds it after
+ *                          every host image / patch).
+ *   d_obuf / d_olen        int32[n_idx][128] / [n_idx]: the hold-back buffers _output_ids[idx] (la_cache_stream_buffer = the
+ *                          host's copy, uploaded once when the device takes over).
+ *   puts                   put k appends d_src_tok[k * src_stride ..][0 .. d_src_cnt[k]) (-1 entries dropped, cut at the first
+ *                          eos id) to buffer d_put_idx[k]; indices must be distinct within a call; <= 64 puts, <= 40 tokens each.
+ * An insert that would pass `cap` records sets meta[1] and stops all further device inserts: the host's replay passes the same
+ * capacity at the same insert and uploads a larger image. */
+typedef struct la_trie_image {
+    int32_t* tok; double* fo; double* fi; int64_t fi_stride; int32_t n_planes;
+    int32_t* cstart; int32_t* ccount; int32_t* ccap; int32_t* meta; int32_t cap;
+    int32_t* root_of; int32_t n_root_of;
+} la_trie_image;
+int la_cache_mirror_ccap(la_cache* c, int32_t cap, int32_t* ccap);
+int la_cache_mirror_discard(la_cache* c, int32_t* n_records);
+int la_cache_stream_buffer(la_cache* c, int idx, int32_t cap, int32_t* out, int32_t* n);
+int la_trie_root_index_dev(void* stream, const la_trie_image* img, int n_roots_max);
+int la_trie_stream_put_dev(void* stream, const la_trie_image* img, int32_t* d_obuf, int32_t* d_olen, const int32_t* d_src_tok,
+                           int src_stride, const int32_t* d_src_cnt, const int32_t* d_put_idx, int n_put, int branch_length,
+                           const int32_t* d_stop, int n_stop, const int32_t* d_eos, int n_eos, int32_t* d_items /*[n_put][40][2]*/);
 /* la_trie_hier_get_dev with one fi plane per query (d_plane[b], planes fi_stride records apart) and the per-query branch
  * length / stop rule of a batch step. */
 int la_trie_hier_get_dev2(void* stream, const int32_t* d_tok, const double* d_fo, const double* d_fi, int64_t fi_stride,

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblookahead_hip.so")
 
 LA_OK = 0
-ABI_VERSION = 7         # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
+ABI_VERSION = 8         # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
 LA_MODE_INPUT, LA_MODE_OUTPUT, LA_MODE_MIX = 0, 1, 2
 LA_TREE_MAX = 64
 LA_MOE_MAX_E = 8
@@ -88,6 +88,16 @@ class LlamaLayerWeightsC(C.Structure):
 class LlamaWeightsC(C.Structure):
     _fields_ = [("embed", vp), ("lm_head", vp), ("final_norm", vp), ("rope_cos", vp), ("rope_sin", vp),
                 ("layers", C.POINTER(LlamaLayerWeightsC))]
+
+
+class TrieImageC(C.Structure):
+    """la_trie_image: the device arrays of the trie mirror (device pointers as integers)"""
+    _fields_ = [('tok', C.c_void_p), ('fo', C.c_void_p), ('fi', C.c_void_p), ('fi_stride', C.c_int64), ('n_planes', C.c_int32),
+                ('cstart', C.c_void_p), ('ccount', C.c_void_p), ('ccap', C.c_void_p), ('meta', C.c_void_p), ('cap', C.c_int32),
+                ('root_of', C.c_void_p), ('n_root_of', C.c_int32)]
+
+
+LA_TRIE_OBUF = 128
 
 
 class DecodeParamsC(C.Structure):
@@ -180,7 +190,12 @@ PROTOTYPES = {
     "la_cache_mirror_state": (i32, vp, pi32, pi32, pi32, pi32),
     "la_cache_mirror_image": (i32, vp, i32, pi32, C.POINTER(C.c_double), C.POINTER(C.c_double), pi32, pi32),
     "la_cache_mirror_patch": (i32, vp, pi32, pi32, C.POINTER(C.c_double)),
-    "la_trie_patch_dev": (i32, vp, vp, vp, vp, i64, vp, vp, vp, i32, vp, vp, i32),
+    "la_trie_patch_dev": (i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, vp, vp, i32),
+    "la_cache_mirror_ccap": (i32, vp, i32, pi32),
+    "la_cache_mirror_discard": (i32, vp, pi32),
+    "la_cache_stream_buffer": (i32, vp, i32, i32, pi32, pi32),
+    "la_trie_root_index_dev": (i32, vp, C.POINTER(TrieImageC), i32),
+    "la_trie_stream_put_dev": (i32, vp, C.POINTER(TrieImageC), vp, vp, vp, i32, vp, vp, i32, i32, vp, i32, vp, i32, vp),
     "la_trie_hier_get_dev2": (i32, vp, vp, vp, vp, i64, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp),
     "la_comm_unique_id": (i32, vp),
     "la_comm_create": (vp, vp, i32, i32),

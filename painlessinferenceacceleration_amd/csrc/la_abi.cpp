@@ -228,10 +228,42 @@ int la_trie_hier_get_dev(void* stream, const int32_t* d_tok, const double* d_fo,
 }
 
 int la_trie_patch_dev(void* stream, int32_t* d_tok, double* d_fo, double* d_fi, int64_t fi_stride, int32_t* d_cstart,
-                      int32_t* d_ccount, const int32_t* d_ipatch, int n_i, const int32_t* d_dkey, const double* d_dval, int n_d) {
+                      int32_t* d_ccount, int32_t* d_ccap, const int32_t* d_ipatch, int n_i, const int32_t* d_dkey, const double* d_dval,
+                      int n_d) {
     if (!d_tok || !d_fo || !d_cstart || !d_ccount || n_i < 0 || n_d < 0 || (n_i > 0 && !d_ipatch) || (n_d > 0 && (!d_dkey || !d_dval)))
         return LA_E_ARG;
-    WRAP(lk_trie_patch((hipStream_t)stream, d_tok, d_fo, d_fi, (long)fi_stride, d_cstart, d_ccount, d_ipatch, n_i, d_dkey, d_dval, n_d));
+    WRAP(lk_trie_patch((hipStream_t)stream, d_tok, d_fo, d_fi, (long)fi_stride, d_cstart, d_ccount, d_ccap, d_ipatch, n_i, d_dkey,
+                       d_dval, n_d));
+}
+
+static int trie_image_ok(const la_trie_image* g) {
+    return g && g->tok && g->fo && g->cstart && g->ccount && g->ccap && g->meta && g->cap > 0 && g->n_planes >= 0 &&
+           (g->n_planes == 0 || g->fi) && g->n_root_of >= 0 && (g->n_root_of == 0 || g->root_of);
+}
+
+int la_trie_root_index_dev(void* stream, const la_trie_image* img, int n_roots_max) {
+    if (!trie_image_ok(img) || n_roots_max < 0) return LA_E_ARG;
+    if (img->n_root_of == 0) return LA_OK;
+    WRAP(lk_trie_root_index((hipStream_t)stream, img->tok, img->cstart, img->ccount, img->root_of, img->n_root_of, n_roots_max));
+}
+
+int la_trie_stream_put_dev(void* stream, const la_trie_image* img, int32_t* d_obuf, int32_t* d_olen, const int32_t* d_src_tok,
+                           int src_stride, const int32_t* d_src_cnt, const int32_t* d_put_idx, int n_put, int branch_length,
+                           const int32_t* d_stop, int n_stop, const int32_t* d_eos, int n_eos, int32_t* d_items) {
+    if (!trie_image_ok(img) || !d_obuf || !d_olen || !d_src_tok || !d_src_cnt || !d_put_idx || !d_items || src_stride < 1 ||
+        n_put < 0 || n_stop < 0 || n_eos < 0 || (n_stop > 0 && !d_stop) || (n_eos > 0 && !d_eos)) return LA_E_ARG;
+    if (n_put > LA_TRIE_PUTS || branch_length < 1 || branch_length > 64) {
+        la_set_error("device stream_put: at most 64 puts per call, branch_length 1..64"); return LA_E_RANGE;
+    }
+    if (n_put == 0) return LA_OK;
+    TriePutArgs a{};
+    a.tok = img->tok; a.fo = img->fo; a.fi = img->fi; a.fi_stride = (long)img->fi_stride; a.n_planes = img->n_planes;
+    a.cstart = img->cstart; a.ccount = img->ccount; a.ccap = img->ccap; a.meta = img->meta; a.cap = img->cap;
+    a.root_of = img->root_of; a.n_root_of = img->n_root_of;
+    a.obuf = d_obuf; a.olen = d_olen; a.src_tok = d_src_tok; a.src_stride = src_stride; a.src_cnt = d_src_cnt;
+    a.put_idx = d_put_idx; a.n_put = n_put; a.branch_length = branch_length;
+    a.stop = d_stop; a.n_stop = n_stop; a.eos = d_eos; a.n_eos = n_eos; a.items = d_items;
+    WRAP(lk_trie_stream_put((hipStream_t)stream, a));
 }
 
 int la_trie_hier_get_dev2(void* stream, const int32_t* d_tok, const double* d_fo, const double* d_fi, int64_t fi_stride,

@@ -102,8 +102,26 @@ int lk_trie_hier_get(hipStream_t st, const int* tok, const double* fo, const dou
                      int n_nodes, const int* queries, const int* nq, int B, int decoding_length, int branch_length,
                      int min_in, int min_out, int mode, const int* stop, int n_stop, int* scratch_q, double* scratch_v,
                      int* out_ids, uint64_t* out_rowmask, int* out_n, int* out_sizes, int* out_nsizes);
-int lk_trie_patch(hipStream_t st, int* tok, double* fo, double* fi, long fi_stride, int* cstart, int* ccount, const int* ipatch,
-                  int n_i, const int* dkey, const double* dval, int n_d);
+int lk_trie_patch(hipStream_t st, int* tok, double* fo, double* fi, long fi_stride, int* cstart, int* ccount, int* ccap,
+                  const int* ipatch, int n_i, const int* dkey, const double* dval, int n_d);
+// device-side stream_put (la_trie_dev.hip)
+#define LA_TRIE_OBUF 128
+#define LA_TRIE_ITEMS 40          // start offsets one put can complete = tokens it appends (<= LA_MOUT_TOKS)
+#define LA_TRIE_PUTS 64
+struct TriePutArgs {
+    int* tok; double* fo; double* fi; long fi_stride; int n_planes;
+    int* cstart; int* ccount; int* ccap;
+    int* meta;                    // [0] records in use  [1] overflow (sticky)  [2] branches inserted  [3] records appended
+    int cap;
+    int* root_of; int n_root_of;  // token -> record of its tree root (-1: none); tokens >= n_root_of fall back to the ballot search
+    int* obuf; int* olen;         // [n_idx][LA_TRIE_OBUF], [n_idx]
+    const int* src_tok; int src_stride; const int* src_cnt;     // put k appends src_tok[k * src_stride ..][0 .. src_cnt[k])
+    const int* put_idx; int n_put, branch_length;
+    const int* stop; int n_stop; const int* eos; int n_eos;
+    int* items;                   // [n_put][LA_TRIE_ITEMS][2]
+};
+int lk_trie_root_index(hipStream_t st, const int* tok, const int* cstart, const int* ccount, int* root_of, int n_root_of, int n_roots_max);
+int lk_trie_stream_put(hipStream_t st, const TriePutArgs& a);
 int lk_trie_hier_get2(hipStream_t st, const int* tok, const double* fo, const double* fi, long fi_stride, const int* cstart,
                       const int* ccount, int n_nodes, const int* queries, const int* nq, const int* plane, const int* bl, int B,
                       int decoding_length, int branch_length, int min_in, int min_out, int mode, const int* stop, int n_stop,

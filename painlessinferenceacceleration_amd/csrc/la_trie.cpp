@@ -56,7 +56,7 @@ struct Mirror {
     std::vector<int32_t> dev_of;                      // host node id -> record (-1 = none)
     bool stale = true, full = true;
     std::unordered_map<uint64_t, size_t> ipos, dpos;  // (array, record) -> position in the log: last write wins
-    std::vector<int32_t> ilog;                        // triples {array: 0 tok, 1 cstart, 2 ccount; record; value}
+    std::vector<int32_t> ilog;                        // triples {array: 0 tok, 1 cstart, 2 ccount, 3 ccap; record; value}
     std::vector<int32_t> dkey;                        // pairs {plane: 0 fo, 1 + k fi plane k; record}
     std::vector<double> dval;
 
@@ -87,7 +87,7 @@ struct Mirror {
         return start;
     }
     void write_record(int32_t rec) {                   // log every word of a (new or moved) record
-        log_i(0, rec, tok[rec]); log_i(1, rec, cstart[rec]); log_i(2, rec, ccount[rec]);
+        log_i(0, rec, tok[rec]); log_i(1, rec, cstart[rec]); log_i(2, rec, ccount[rec]); log_i(3, rec, ccap[rec]);
         log_d(0, rec, fo[rec]);
         for (size_t k = 0; k < fi.size(); ++k) log_d(1 + (int)k, rec, fi[k][rec]);
     }
@@ -106,7 +106,7 @@ struct Mirror {
                 write_record(n);
             }
             cstart[prec] = nstart; ccap[prec] = ncap;
-            log_i(1, prec, nstart);
+            log_i(1, prec, nstart); log_i(3, prec, ncap);
         }
         const int32_t rec = cstart[prec] + ccount[prec];
         ccount[prec] += 1;
@@ -796,7 +796,41 @@ int la_cache_mirror_image(la_cache* c, int32_t cap, int32_t* tok, double* fo, do
     return LA_OK;
 }
 
-// the words that changed since the last sync: ipatch int32[n_i][3] = {array (0 tok, 1 cstart, 2 ccount), record, value},
+// block capacities of the image la_cache_mirror_image just produced (the device-side update, la_trie_stream_put_dev, grows child
+// blocks by the same rule as Mirror::add_child and needs them); call right after la_cache_mirror_image
+int la_cache_mirror_ccap(la_cache* c, int32_t cap, int32_t* ccap) {
+    if (!c || !c->mir || !ccap) return LA_E_ARG;
+    Mirror& m = *c->mir;
+    if (m.stale) { la_set_error("mirror_ccap: the mirror is stale (take la_cache_mirror_image first)"); return LA_E_STATE; }
+    if ((size_t)cap < m.ccap.size()) return LA_E_RANGE;
+    memcpy(ccap, m.ccap.data(), m.ccap.size() * 4);
+    return LA_OK;
+}
+
+// The device applied the SAME updates itself (la_trie_stream_put_dev, then the host replayed them with la_cache_stream_put in the
+// same order): the words the replay logged are already in the device image — drop them.  LA_E_STATE when the replay left the
+// mirror stale or a full image is due (then the device image is NOT the host's and the caller must upload one).
+int la_cache_mirror_discard(la_cache* c, int32_t* n_records) {
+    if (!c || !c->mir) return LA_E_ARG;
+    Mirror& m = *c->mir;
+    if (m.stale || m.full) { la_set_error("mirror_discard: a full image is due"); return LA_E_STATE; }
+    m.clear_log();
+    if (n_records) *n_records = (int32_t)m.tok.size();
+    return LA_OK;
+}
+
+// _output_ids[idx] (lookahead_cache.py:369-375): the tokens stream_put holds back until a full branch follows them
+int la_cache_stream_buffer(la_cache* c, int idx, int32_t cap, int32_t* out, int32_t* n) {
+    if (!c || !n || cap < 0 || (cap > 0 && !out)) return LA_E_ARG;
+    auto it = c->output_ids.find(idx);
+    const size_t have = it == c->output_ids.end() ? 0 : it->second.size();
+    *n = (int32_t)have;
+    if (have > (size_t)cap) return cap == 0 ? LA_OK : LA_E_RANGE;
+    if (have) memcpy(out, it->second.data(), have * 4);
+    return LA_OK;
+}
+
+// the words that changed since the last sync: ipatch int32[n_i][3] = {array (0 tok, 1 cstart, 2 ccount, 3 ccap), record, value},
 // dkey int32[n_d][2] = {plane (0 fo, 1 + k fi plane k), record}, dval double[n_d]; every (array, record) appears once
 int la_cache_mirror_patch(la_cache* c, int32_t* ipatch, int32_t* dkey, double* dval) {
     if (!c || !c->mir) return LA_E_ARG;

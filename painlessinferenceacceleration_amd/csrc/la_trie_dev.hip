@@ -352,12 +352,13 @@ int lk_trie_hier_get(hipStream_t st, const int* tok, const double* fo, const dou
 
 // ---- incremental mirror: apply a patch (la_cache_mirror_patch) to the device image ---------------------------------------
 __global__ void k_trie_patch(int* __restrict__ tok, double* __restrict__ fo, double* __restrict__ fi, long fi_stride,
-                             int* __restrict__ cstart, int* __restrict__ ccount, const int* __restrict__ ipatch, int n_i,
-                             const int* __restrict__ dkey, const double* __restrict__ dval, int n_d) {
+                             int* __restrict__ cstart, int* __restrict__ ccount, int* __restrict__ ccap, const int* __restrict__ ipatch,
+                             int n_i, const int* __restrict__ dkey, const double* __restrict__ dval, int n_d) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_i) {
         const int arr = ipatch[3 * i], rec = ipatch[3 * i + 1], val = ipatch[3 * i + 2];
-        (arr == 0 ? tok : arr == 1 ? cstart : ccount)[rec] = val;
+        if (arr == 3) { if (ccap) ccap[rec] = val; }              // block capacities: only the device-side update reads them
+        else (arr == 0 ? tok : arr == 1 ? cstart : ccount)[rec] = val;
     } else if (i < n_i + n_d) {
         const int k = i - n_i;
         const int plane = dkey[2 * k], rec = dkey[2 * k + 1];
@@ -365,11 +366,11 @@ __global__ void k_trie_patch(int* __restrict__ tok, double* __restrict__ fo, dou
     }
 }
 
-int lk_trie_patch(hipStream_t st, int* tok, double* fo, double* fi, long fi_stride, int* cstart, int* ccount, const int* ipatch,
-                  int n_i, const int* dkey, const double* dval, int n_d) {
+int lk_trie_patch(hipStream_t st, int* tok, double* fo, double* fi, long fi_stride, int* cstart, int* ccount, int* ccap,
+                  const int* ipatch, int n_i, const int* dkey, const double* dval, int n_d) {
     const int n = n_i + n_d;
     if (n <= 0) return 0;
-    k_trie_patch<<<(n + 255) / 256, 256, 0, st>>>(tok, fo, fi, fi_stride, cstart, ccount, ipatch, n_i, dkey, dval, n_d);
+    k_trie_patch<<<(n + 255) / 256, 256, 0, st>>>(tok, fo, fi, fi_stride, cstart, ccount, ccap, ipatch, n_i, dkey, dval, n_d);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -387,6 +388,194 @@ int lk_trie_hier_get2(hipStream_t st, const int* tok, const double* fo, const do
     a.scratch_q = scratch_q; a.scratch_v = scratch_v; a.out_ids = out_ids; a.out_rowmask = (unsigned long long*)out_rowmask;
     a.out_n = out_n; a.out_sizes = out_sizes; a.out_nsizes = out_nsizes; a.dbg = g_la_dbg_times;
     k_trie_hier_get<<<B, 64, 0, st>>>(a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+
+// ---- device-side stream_put (LookaheadCache.stream_put, lookahead_cache.py:369-406, with Tree.put/_put/_pack :33-63) ------------
+// The accepted tokens of a verify step never leave HBM on their way into the trie: the step's output block (or any int32 rows) is
+// appended to the per-sequence hold-back buffers (_output_ids[idx]), every start offset that now has a full branch behind it is
+// inserted — tree root by token, then branch_length nodes, output frequency + 1 each — and the buffers keep their last
+// branch_length tokens.  The image grows by the SAME rule as the host mirror (Mirror::add_child in la_trie.cpp: a full child block
+// moves to the arena end with twice the room, first block = 4 records), and the inserts run in the same order (puts in call order,
+// start offsets ascending), so after the host replays the same puts on its trie the two images agree on every record id, block
+// and capacity and on the frequencies of every live record (tests/test_gpu_trie.py; a dead copy left behind by a moved block may
+// carry a count the parallel walk added just before the move — nothing reads it again) and no patch has to cross PCIe.
+//   k_trie_put_walk : one wavefront per (put, start offset): walks the part of the branch that already exists (ballot child search,
+//                     root through a token-indexed table) and adds its frequencies (fp64 atomics: integers, order-free);
+//                     leaves {record where the path ended, levels done} per item.
+//   k_trie_put_link : ONE wavefront, items in order: continues each unfinished branch from where its walk ended — a child created
+//                     by an earlier item of the same call is found and incremented, anything else is appended (chain of fresh
+//                     records: no search below a fresh node) — then rolls the hold-back buffers.  A block that moves re-bases the
+//                     pending items' records (and the root table when it is the forest's root block).
+// Capacity: an insert that would pass `cap` records sets meta[1] (sticky) and stops ALL further device inserts; the host (whose
+// replay is the record of truth) sees its own record count pass the capacity and uploads a larger image.
+// hold-back buffer of put k with the new tokens appended (-1 entries dropped, cut at the first eos: :350-352) -> LDS buf; returns ts
+__device__ int put_window(const TriePutArgs& a, int k, int lane, int* buf, int* ol_out) {
+    const int idx = a.put_idx[k];
+    const int ol = min(max(a.olen[idx], 0), LA_TRIE_OBUF - LA_TRIE_ITEMS - 8);
+    const int n_raw = min(max(a.src_cnt[k], 0), LA_TRIE_ITEMS);
+    int t = -1;
+    if (lane < n_raw) t = a.src_tok[(size_t)k * a.src_stride + lane];
+    bool valid = lane < n_raw && t != -1;
+    bool is_eos = false;
+    for (int e = 0; e < a.n_eos; ++e) is_eos |= (valid && t == a.eos[e]);
+    const unsigned long long em = __ballot(is_eos);
+    if (em) valid = valid && lane < (__ffsll((long long)em) - 1);
+    const unsigned long long vm = __ballot(valid);
+    for (int i = lane; i < ol; i += 64) buf[i] = a.obuf[(size_t)idx * LA_TRIE_OBUF + i];
+    if (valid) buf[ol + __popcll(vm & ((1ull << lane) - 1ull))] = t;
+    __syncthreads();
+    *ol_out = ol;
+    return ol + __popcll(vm);
+}
+
+__device__ __forceinline__ int find_child_rw(const int* tok, const int* cstart, const int* ccount, int u, int token, int lane) {
+    const int cs = cstart[u], cc = ccount[u];
+    for (int base = 0; base < cc; base += 64) {
+        const int i = base + lane;
+        const bool hit = i < cc && tok[cs + i] == token;
+        const unsigned long long m = __ballot(hit);
+        if (m) return cs + base + wave_first(m);
+    }
+    return -1;
+}
+
+__device__ __forceinline__ int find_root(const TriePutArgs& a, int token, int lane) {
+    if (token >= 0 && token < a.n_root_of) return a.root_of[token];
+    return find_child_rw(a.tok, a.cstart, a.ccount, 0, token, lane);
+}
+
+__global__ __launch_bounds__(64) void k_trie_put_walk(TriePutArgs a) {
+    __shared__ int buf[LA_TRIE_OBUF + 64];
+    const int k = blockIdx.x, i = blockIdx.y, lane = threadIdx.x;
+    int ol;
+    const int ts = put_window(a, k, lane, buf, &ol);
+    const int bl = a.branch_length;
+    int* item = a.items + ((size_t)k * LA_TRIE_ITEMS + i) * 2;
+    if (i >= ts - bl) { if (lane == 0) { item[0] = -1; item[1] = 0; } return; }
+    const int root_tok = buf[i];
+    bool is_stop = false;
+    for (int s = 0; s < a.n_stop; ++s) is_stop |= (a.stop[s] == root_tok);                // :386-387
+    if (is_stop || a.meta[1] != 0) { if (lane == 0) { item[0] = -1; item[1] = 0; } return; }
+    int cur = find_root(a, root_tok, lane), lv = 0;
+    if (cur >= 0) {
+        lv = 1;
+        for (; lv <= bl; ++lv) {
+            const int ch = find_child_rw(a.tok, a.cstart, a.ccount, cur, buf[i + lv], lane);
+            if (ch < 0) break;
+            if (lane == 0) atomicAdd(&a.fo[ch], 1.0);                                     // :53 freqs[-1] += 1 (output mode)
+            cur = ch;
+        }
+    } else {
+        cur = 0;
+    }
+    if (lane == 0) { item[0] = lv > bl ? -1 : cur; item[1] = lv; }
+}
+
+__global__ __launch_bounds__(64) void k_trie_put_link(TriePutArgs a) {
+    __shared__ int buf[LA_TRIE_OBUF + 64];
+    __shared__ int it_u[LA_TRIE_PUTS * LA_TRIE_ITEMS], it_lv[LA_TRIE_PUTS * LA_TRIE_ITEMS];
+    const int lane = threadIdx.x;
+    const int bl = a.branch_length, n_items = a.n_put * LA_TRIE_ITEMS;
+    for (int q = lane; q < n_items; q += 64) { it_u[q] = a.items[2 * q]; it_lv[q] = a.items[2 * q + 1]; }
+    __syncthreads();
+    int n_rec = a.meta[0], ovf = a.meta[1], n_branch = 0, n_new = 0;
+    // append a child record under `prec` (Mirror::add_child); wave-uniform; -1 = the arena is full
+    auto add_child = [&](int prec, int token, int q_now) -> int {
+        const int cnt = a.ccount[prec], capc = a.ccap[prec];
+        int cs = a.cstart[prec];
+        if (cnt == capc) {
+            const int ncap = capc < 2 ? 4 : 2 * capc;
+            if (n_rec + ncap > a.cap) return -1;
+            const int nstart = n_rec, ostart = cs;
+            for (int r = lane; r < ncap; r += 64) {
+                const int n = nstart + r, o = ostart + r;
+                const bool cp = r < cnt;
+                a.tok[n] = cp ? a.tok[o] : -1; a.cstart[n] = cp ? a.cstart[o] : 0; a.ccount[n] = cp ? a.ccount[o] : 0;
+                a.ccap[n] = cp ? a.ccap[o] : 0; a.fo[n] = cp ? a.fo[o] : 0.0;
+                for (int p = 0; p < a.n_planes; ++p) a.fi[(size_t)p * a.fi_stride + n] = cp ? a.fi[(size_t)p * a.fi_stride + o] : 0.0;
+                if (cp && prec == 0) { const int t = a.tok[o]; if (t >= 0 && t < a.n_root_of) a.root_of[t] = n; }
+            }
+            // the records of the pending items that sat in the moved block
+            for (int q = q_now + 1 + lane; q < n_items; q += 64) {
+                const int u = it_u[q];
+                if (u >= ostart && u < ostart + cnt && u > 0) it_u[q] = u - ostart + nstart;
+            }
+            n_rec += ncap;
+            cs = nstart;
+            if (lane == 0) { a.cstart[prec] = nstart; a.ccap[prec] = ncap; }
+        }
+        const int rec = cs + cnt;
+        if (lane == 0) {
+            a.ccount[prec] = cnt + 1;
+            a.tok[rec] = token; a.cstart[rec] = 0; a.ccount[rec] = 0; a.ccap[rec] = 0; a.fo[rec] = 0.0;
+            for (int p = 0; p < a.n_planes; ++p) a.fi[(size_t)p * a.fi_stride + rec] = 0.0;
+            if (prec == 0 && token >= 0 && token < a.n_root_of) a.root_of[token] = rec;
+        }
+        __threadfence_block();
+        __syncthreads();
+        ++n_new;
+        return rec;
+    };
+    for (int k = 0; k < a.n_put; ++k) {
+        __syncthreads();
+        int ol;
+        const int ts = put_window(a, k, lane, buf, &ol);
+        const int idx = a.put_idx[k];
+        const int nit = min(max(ts - bl, 0), LA_TRIE_ITEMS);
+        for (int i = 0; i < nit && !ovf; ++i) {
+            const int q = k * LA_TRIE_ITEMS + i;
+            int cur = it_u[q];
+            if (cur < 0) continue;                                    // a stop-word root, or the whole branch existed already
+            ++n_branch;
+            bool fresh = false;
+            for (int lv = it_lv[q]; lv <= bl; ++lv) {
+                const int t = buf[i + lv];
+                int ch = -1;
+                if (!fresh) ch = lv == 0 ? find_root(a, t, lane) : find_child_rw(a.tok, a.cstart, a.ccount, cur, t, lane);
+                if (ch < 0) {
+                    ch = add_child(cur, t, q);
+                    if (ch < 0) { ovf = 1; break; }
+                    fresh = true;
+                }
+                if (lv >= 1 && lane == 0) a.fo[ch] += 1.0;            // the tree root itself carries no frequency (:365-367)
+                __threadfence_block();
+                cur = ch;
+            }
+        }
+        // roll the hold-back buffer (:399-400)
+        __syncthreads();
+        if (ts > bl) {
+            for (int j = lane; j < bl; j += 64) a.obuf[(size_t)idx * LA_TRIE_OBUF + j] = buf[ts - bl + j];
+            if (lane == 0) a.olen[idx] = bl;
+        } else {
+            for (int j = ol + lane; j < ts; j += 64) a.obuf[(size_t)idx * LA_TRIE_OBUF + j] = buf[j];
+            if (lane == 0) a.olen[idx] = ts;
+        }
+    }
+    if (lane == 0) { a.meta[0] = n_rec; a.meta[1] = ovf; a.meta[2] += n_branch; a.meta[3] += n_new; }
+}
+
+__global__ void k_trie_root_index(const int* __restrict__ tok, const int* __restrict__ cstart, const int* __restrict__ ccount,
+                                  int* __restrict__ root_of, int n_root_of) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cs = cstart[0], cc = ccount[0];
+    if (i < cc) { const int t = tok[cs + i]; if (t >= 0 && t < n_root_of) root_of[t] = cs + i; }
+}
+
+int lk_trie_root_index(hipStream_t st, const int* tok, const int* cstart, const int* ccount, int* root_of, int n_root_of, int n_roots_max) {
+    hipError_t e = hipMemsetAsync(root_of, 0xff, (size_t)n_root_of * 4, st);
+    if (e != hipSuccess) return (int)e;
+    if (n_roots_max > 0) k_trie_root_index<<<(n_roots_max + 255) / 256, 256, 0, st>>>(tok, cstart, ccount, root_of, n_root_of);
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int lk_trie_stream_put(hipStream_t st, const TriePutArgs& a) {
+    k_trie_put_walk<<<dim3(a.n_put, LA_TRIE_ITEMS), 64, 0, st>>>(a);
+    k_trie_put_link<<<1, 64, 0, st>>>(a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

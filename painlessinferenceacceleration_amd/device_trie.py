@@ -11,6 +11,11 @@ every sequence of a batch step with its own input frequencies.
 
 Product use: pretrained_model_batch.lookahead_generation(decoding_kwargs={'device_trie': True}) retrieves the drafts of all
 active samples with one launch here instead of one host query per sample.
+
+Device-side UPDATES (put_vocab=...): stream_put_dev() applies LookaheadCache.stream_put(final=False, mode='output')
+(lookahead_cache.py:369-406) to the device image on the device, from tokens that are already in HBM (a verify step's accepted
+tokens); replay() then repeats the same puts on the host trie, whose mirror grows by the same rule in the same order, and drops
+the words it logged — the two images stay identical word for word and those updates never cross PCIe.
 """
 import ctypes as C
 import weakref
@@ -26,7 +31,9 @@ _pd = C.POINTER(C.c_double)
 
 
 class DeviceTrie(object):
-    def __init__(self, cache, idx=None, device='cuda:0', idxs=None, max_queries=64):
+    def __init__(self, cache, idx=None, device='cuda:0', idxs=None, max_queries=64, put_vocab=None, cap_slack=4096):
+        """put_vocab: enable device-side updates; = the model's vocabulary size (length of the token -> tree root table).
+        cap_slack: free records behind a fresh image (the image is re-allocated 1.5x larger when an update passes it)."""
         if not torch.cuda.is_available():
             raise RuntimeError('DeviceTrie needs an MI355X (no CPU fallback)')
         self.device = torch.device(device)
@@ -42,6 +49,24 @@ class DeviceTrie(object):
         cache._mirror_owner = weakref.ref(self)
         self._h2d_done = torch.cuda.Event()
         self._h2d_pending = False
+        self.put_vocab = int(put_vocab) if put_vocab else 0
+        self.cap_slack = int(cap_slack)
+        if self.put_vocab:
+            n_idx = max(self.idxs) + 1
+            dev = self.device
+            self.n_idx = n_idx
+            self.obuf = torch.zeros(n_idx * _lib.LA_TRIE_OBUF, dtype=torch.int32, device=dev)
+            self.olen = torch.zeros(n_idx, dtype=torch.int32, device=dev)
+            self._h_obuf = torch.zeros(n_idx * (_lib.LA_TRIE_OBUF + 1), dtype=torch.int32).pin_memory()
+            self.meta = torch.zeros(4, dtype=torch.int32, device=dev)
+            self._h_meta = torch.zeros(4, dtype=torch.int32).pin_memory()
+            self.root_of = torch.full((self.put_vocab,), -1, dtype=torch.int32, device=dev)
+            self._items = torch.zeros(64 * _lib.LA_MOUT_TOKS * 2, dtype=torch.int32, device=dev)
+            self._put_idx = torch.zeros(64, dtype=torch.int32, device=dev)
+            self._h_put_idx = torch.zeros(64, dtype=torch.int32).pin_memory()
+            self._put_idx_list = None
+            self._eos_list = self._stopw_list = None
+            self.stats_put = {'calls': 0, 'replays': 0}
         arr = np.asarray(self.idxs, dtype=np.int32)
         check(lib.la_cache_mirror_enable(cache._h, arr.ctypes.data_as(_lib.pi32), len(self.idxs)), 'mirror_enable')
         self.cap = 0
@@ -54,7 +79,7 @@ class DeviceTrie(object):
 
     # ---- device image ------------------------------------------------------------------------------------------------
     def _alloc_image(self, n):
-        self.cap = max(int(n * 1.5) + 4096, 8192)
+        self.cap = max(int(n * 1.5) + self.cap_slack, 64)
         P = max(len(self.idxs), 1)
         dev = self.device
         self.tok = torch.empty(self.cap, dtype=torch.int32, device=dev)
@@ -68,6 +93,9 @@ class DeviceTrie(object):
         self._h_fo = torch.empty(self.cap, dtype=torch.float64).pin_memory()
         self._h_fi = torch.zeros(P * self.cap, dtype=torch.float64).pin_memory()
         self._scratch = None
+        if self.put_vocab:
+            self.ccap = torch.zeros(self.cap, dtype=torch.int32, device=dev)
+            self._h_ccap = torch.zeros(self.cap, dtype=torch.int32).pin_memory()
 
     def _alloc_queries(self, B):
         if B <= self._qcap:
@@ -131,6 +159,10 @@ class DeviceTrie(object):
                 self.fi[p * self.cap:p * self.cap + k].copy_(self._h_fi[p * self.cap:p * self.cap + k], non_blocking=True)
             self.n_records = k
             self.stats['full_uploads'] += 1
+            if self.put_vocab:
+                check(lib.la_cache_mirror_ccap(self.cache._h, self.cap, C.cast(self._h_ccap.data_ptr(), _lib.pi32)), 'mirror_ccap')
+                self.ccap[:k].copy_(self._h_ccap[:k], non_blocking=True)
+                self._after_host_update(k, reset=True)
             self._staging_queued()
             return 'full'
         self.n_records = n.value
@@ -151,12 +183,104 @@ class DeviceTrie(object):
         if nd.value:
             self._d_pd[:nd.value].copy_(self._h_pd[:nd.value], non_blocking=True)
         check(lib.la_trie_patch_dev(self._stream(), self.tok.data_ptr(), self.fo.data_ptr(), self.fi.data_ptr(), self.cap,
-                                    self.cstart.data_ptr(), self.ccount.data_ptr(), self._d_pi.data_ptr(), ni.value,
+                                    self.cstart.data_ptr(), self.ccount.data_ptr(), self.ccap.data_ptr() if self.put_vocab else None,
+                                    self._d_pi.data_ptr(), ni.value,
                                     self._d_pi.data_ptr() + 4 * 3 * ni.value, self._d_pd.data_ptr(), nd.value), 'trie_patch_dev')
+        if self.put_vocab:
+            self._after_host_update(n.value, reset=False)
         self._staging_queued()
         self.stats['patches'] += 1
         self.stats['patch_words'] += ni.value + nd.value
         return 'patch'
+
+    # ---- device-side updates ---------------------------------------------------------------------------------------------
+    def _image(self):
+        img = _lib.TrieImageC()
+        img.tok, img.fo, img.fi, img.fi_stride = self.tok.data_ptr(), self.fo.data_ptr(), self.fi.data_ptr(), self.cap
+        img.n_planes = len(self.idxs)
+        img.cstart, img.ccount, img.ccap = self.cstart.data_ptr(), self.ccount.data_ptr(), self.ccap.data_ptr()
+        img.meta, img.cap = self.meta.data_ptr(), self.cap
+        img.root_of, img.n_root_of = self.root_of.data_ptr(), self.put_vocab
+        return img
+
+    def _after_host_update(self, n_records, reset):
+        """A host image / patch just went to the device: the record count the device inserts continue from, and the token ->
+        root table (a patch may have added trees or moved the root block)."""
+        self._h_meta[0] = n_records
+        if reset:
+            self._h_meta[1:] = 0
+            self.meta.copy_(self._h_meta, non_blocking=True)
+        else:
+            self.meta[:1].copy_(self._h_meta[:1], non_blocking=True)
+        img = self._image()
+        check(lib.la_trie_root_index_dev(self._stream(), C.byref(img), int(n_records)), 'trie_root_index_dev')
+
+    def load_stream_buffers(self):
+        """Upload the host's hold-back buffers (_output_ids[idx], lookahead_cache.py:369) of the mirrored slots: from here on the
+        device rolls them itself (stream_put_dev) and the host's copies follow through replay()."""
+        assert self.put_vocab, 'DeviceTrie(put_vocab=...) enables device-side updates'
+        self._check_owner()
+        self._staging_free()
+        W = _lib.LA_TRIE_OBUF
+        h = self._h_obuf.numpy()
+        h[:] = 0
+        n = C.c_int32()
+        for idx in self.idxs:
+            check(lib.la_cache_stream_buffer(self.cache._h, int(idx), W, h[idx * W:].ctypes.data_as(_lib.pi32), C.byref(n)),
+                  'stream_buffer')
+            h[self.n_idx * W + idx] = n.value
+        self.obuf.copy_(self._h_obuf[:self.n_idx * W], non_blocking=True)
+        self.olen.copy_(self._h_obuf[self.n_idx * W:], non_blocking=True)
+        self._staging_queued()
+
+    def _small_dev_list(self, name, values):
+        """device copy of a short int list (eos ids, stop words), re-uploaded only when it changes"""
+        key = [int(v) for v in values]
+        if getattr(self, name + '_list', None) != key or getattr(self, name + '_dev', None) is None:
+            setattr(self, name + '_list', key)
+            setattr(self, name + '_dev', torch.tensor(key or [0], dtype=torch.int32, device=self.device))
+        return getattr(self, name + '_dev'), len(key)
+
+    def stream_put_dev(self, src_tok_ptr, src_stride, src_cnt_ptr, idxs, branch_length):
+        """Queue the device-side stream_put of len(idxs) sequences on the current stream: put k appends the src_cnt_ptr[k] int32
+        tokens at src_tok_ptr + 4 * k * src_stride (device pointers, e.g. a verify step's output block) to the hold-back buffer of
+        slot idxs[k].  The host must replay() the same puts (same order) before its next own update of the trie."""
+        assert self.put_vocab, 'DeviceTrie(put_vocab=...) enables device-side updates'
+        self._check_owner()
+        idxs = [int(i) for i in idxs]
+        assert len(set(idxs)) == len(idxs) <= 64 and all(0 <= i < self.n_idx for i in idxs)
+        if idxs != self._put_idx_list:
+            self._staging_free()
+            self._h_put_idx[:len(idxs)] = torch.tensor(idxs, dtype=torch.int32)
+            self._put_idx.copy_(self._h_put_idx, non_blocking=True)
+            self._staging_queued()
+            self._put_idx_list = idxs
+        eos = [e for e in (self.cache.eos_ids or []) if e is not None]
+        eos_dev, n_eos = self._small_dev_list('_eos', eos)
+        stop_dev, n_stop = self._small_dev_list('_stopw', sorted(self.cache.stop_words or []))
+        img = self._image()
+        check(lib.la_trie_stream_put_dev(self._stream(), C.byref(img), self.obuf.data_ptr(), self.olen.data_ptr(),
+                                         C.c_void_p(src_tok_ptr), int(src_stride), C.c_void_p(src_cnt_ptr), self._put_idx.data_ptr(),
+                                         len(idxs), int(branch_length), stop_dev.data_ptr(), n_stop, eos_dev.data_ptr(), n_eos,
+                                         self._items.data_ptr()), 'trie_stream_put_dev')
+        self.stats_put['calls'] += 1
+
+    def replay(self, puts, branch_length):
+        """Repeat on the host trie what stream_put_dev() did on the device: puts = [(idx, tokens)] in the order of that call.  The
+        words the host logs for them are already in the device image and are dropped.  -> False when the host's image left the
+        device's behind (capacity passed, or a squeeze): the next sync() uploads a full image."""
+        n_pending = C.c_int32()
+        n, full, ni, nd = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib.la_cache_mirror_state(self.cache._h, C.byref(n), C.byref(full), C.byref(ni), C.byref(nd)), 'mirror_state')
+        assert not full.value and ni.value == 0 and nd.value == 0, 'replay() needs a synced mirror (call sync() after host updates)'
+        for idx, toks in puts:
+            self.cache.stream_put([int(t) for t in toks if t != -1], branch_length=branch_length, final=False, mode='output', idx=int(idx))
+        self.stats_put['replays'] += 1
+        rc = lib.la_cache_mirror_discard(self.cache._h, C.byref(n_pending))
+        if rc != 0:
+            return False
+        self.n_records = n_pending.value
+        return n_pending.value <= self.cap
 
     # ---- queries -------------------------------------------------------------------------------------------------------
     def hier_get_dev(self, queries, idxs=None, branch_lengths=None, decoding_length=64, branch_length=8, min_input_size=0,

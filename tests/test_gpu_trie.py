@@ -226,3 +226,154 @@ def test_second_mirror_revokes_the_first_and_staging_is_reusable_back_to_back():
     with pytest.raises(RuntimeError):
         a.hier_get([seqs[0][5:7]], decoding_length=64, branch_length=8)
     assert b_.hier_get([seqs[0][5:7]], decoding_length=64, branch_length=8, min_output_size=32)[0][0] == want1[0][0]
+
+
+def _host_image(cache, n_planes):
+    """the host mirror's arrays (la_cache_mirror_image + la_cache_mirror_ccap) as numpy"""
+    import ctypes as C
+    from painlessinferenceacceleration_amd import _lib
+    lib = _lib.lib
+    n, full, ni, nd = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    assert lib.la_cache_mirror_state(cache._h, C.byref(n), C.byref(full), C.byref(ni), C.byref(nd)) == 0
+    k = n.value
+    tok, cs, cc, cap = (np.zeros(k, dtype=np.int32) for _ in range(4))
+    fo, fi = np.zeros(k, dtype=np.float64), np.zeros(max(n_planes, 1) * k, dtype=np.float64)
+    pd = C.POINTER(C.c_double)
+    assert lib.la_cache_mirror_image(cache._h, k, tok.ctypes.data_as(_lib.pi32), fo.ctypes.data_as(pd), fi.ctypes.data_as(pd),
+                                     cs.ctypes.data_as(_lib.pi32), cc.ctypes.data_as(_lib.pi32)) == 0
+    assert lib.la_cache_mirror_ccap(cache._h, k, cap.ctypes.data_as(_lib.pi32)) == 0
+    return k, tok, cs, cc, cap, fo, fi.reshape(max(n_planes, 1), k)
+
+
+def _assert_images_equal(dt, cache):
+    torch.cuda.synchronize()
+    k, tok, cs, cc, cap, fo, fi = _host_image(cache, len(dt.idxs))
+    meta = dt.meta.cpu().numpy()
+    assert meta[1] == 0, 'device arena overflowed'
+    assert meta[0] == k, (meta, k)
+    # compared: every LIVE record (reachable from the super-root) — ids, tokens, child blocks, block capacities, frequencies.
+    # Dead words are never read again and may differ: the unused tail of a block the HOST grew (its patch carries only the records
+    # it wrote), and the frequency of a copy left behind by a moved block (the device's parallel walk may have counted a branch on
+    # the old copy just before the move carried the count to the new one; the strictly serial host counts on the new copy only).
+    live = np.zeros(k, dtype=bool)
+    stack = [0]
+    live[0] = True
+    while stack:
+        u = stack.pop()
+        for c_ in range(int(cs[u]), int(cs[u]) + int(cc[u])):
+            live[c_] = True
+            stack.append(c_)
+    for name, want in (('tok', tok), ('cstart', cs), ('ccount', cc), ('ccap', cap)):
+        got = getattr(dt, name)[:k].cpu().numpy()
+        assert got[live].tolist() == want[live].tolist(), name
+    assert live.sum() > 10
+    assert dt.fo[:k].cpu().numpy()[live].tolist() == fo[live].tolist()
+    for p in range(len(dt.idxs)):
+        assert dt.fi[p * dt.cap:p * dt.cap + k].cpu().numpy()[live].tolist() == fi[p][live].tolist()
+    # the token -> root table covers every tree
+    r0, rc = int(cs[0]), int(cc[0])
+    ro = dt.root_of.cpu().numpy()
+    for j in range(rc):
+        if 0 <= tok[r0 + j] < dt.put_vocab:
+            assert ro[tok[r0 + j]] == r0 + j
+    assert (ro >= 0).sum() == sum(1 for j in range(rc) if 0 <= tok[r0 + j] < dt.put_vocab)
+
+
+@pytest.mark.parametrize('B,bl,eos,stop', [(1, 13, [None], []), (4, 9, [2], [7]), (8, 13, [2, 5], [])])
+def test_device_stream_put_keeps_the_device_image_identical_to_the_host_mirror(B, bl, eos, stop):
+    """la_trie_stream_put_dev (LookaheadCache.stream_put on the device, lookahead_cache.py:369-406): B sequences emit 1..40 tokens
+    per step (repeating motifs, so branches exist partly / fully / not at all; -1 fillers, eos ids and stop-word roots included);
+    the device inserts them from HBM, the host replays them, and after every few steps the device arrays must equal the host
+    mirror's word for word (records, block capacities, frequencies, record count) — with host-side updates (an input-mode put that
+    arrives as a patch, a reset of a slot's input frequencies) interleaved — and device queries must equal host queries."""
+    rs = np.random.RandomState(100 + B)
+    V = 300
+    cache = LookaheadCache(eos_ids=eos, stop_words=set(stop))
+    motifs = [rs.randint(8, V, size=rs.randint(5, 30)).tolist() for _ in range(12)]
+    for m in motifs[:6]:
+        cache.put(m, branch_length=bl, mode='output', idx=-1)
+    for b in range(B):
+        cache.put(rs.randint(8, V, size=40).tolist(), branch_length=bl, mode='input', idx=b)
+        cache.stream_put(rs.randint(8, V, size=rs.randint(1, 4)).tolist(), branch_length=bl, final=False, mode='output', idx=b)
+    dt = DeviceTrie(cache, idxs=list(range(B)), put_vocab=V, cap_slack=200000)
+    dt.load_stream_buffers()
+    src = torch.zeros(B * 40, dtype=torch.int32, device='cuda')
+    cnt = torch.zeros(B, dtype=torch.int32, device='cuda')
+    for step in range(40):
+        active = [b for b in range(B) if rs.rand() < 0.85] or [0]
+        puts = []
+        hs, hc = np.zeros(B * 40, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        for k, b in enumerate(active):
+            n = int(rs.randint(1, 41)) if rs.rand() < 0.3 else int(rs.randint(1, 9))
+            toks = []
+            while len(toks) < n:
+                toks.extend(motifs[rs.randint(len(motifs))][rs.randint(0, 4):] if rs.rand() < 0.7 else rs.randint(8, V, size=3).tolist())
+            toks = toks[:n]
+            if rs.rand() < 0.15:
+                toks[rs.randint(n)] = -1
+            if eos[0] is not None and rs.rand() < 0.1:
+                toks[rs.randint(n)] = eos[rs.randint(len(eos))]
+            if stop and rs.rand() < 0.3:
+                toks[rs.randint(n)] = stop[0]
+            hs[k * 40:k * 40 + n] = toks
+            hc[k] = n
+            puts.append((b, toks))
+        src.copy_(torch.from_numpy(hs)); cnt.copy_(torch.from_numpy(hc))
+        dt.stream_put_dev(src.data_ptr(), 40, cnt.data_ptr(), active, bl)
+        assert dt.replay(puts, bl)
+        if step % 7 == 3:                               # a host-side update between device updates: reaches the device as a patch
+            cache.put(rs.randint(8, V, size=25).tolist(), branch_length=bl, mode='input', idx=int(rs.randint(B)))
+            assert dt.sync() == 'patch'
+        if step % 11 == 5:
+            cache.reset_input_freqs(int(rs.randint(B)))
+            dt.sync()
+        if step % 5 == 4 or step == 39:
+            _assert_images_equal(dt, cache)
+            # hold-back buffers
+            ol = dt.olen.cpu().numpy(); ob = dt.obuf.cpu().numpy().reshape(B, -1)
+            import ctypes as C
+            from painlessinferenceacceleration_amd import _lib
+            for b in range(B):
+                buf = np.zeros(128, dtype=np.int32); n = C.c_int32()
+                assert _lib.lib.la_cache_stream_buffer(cache._h, b, 128, buf.ctypes.data_as(_lib.pi32), C.byref(n)) == 0
+                assert ol[b] == n.value and ob[b, :n.value].tolist() == buf[:n.value].tolist()
+            qs = [motifs[rs.randint(len(motifs))][1:3] for _ in range(B)]
+            got = dt.hier_get(qs, decoding_length=64, branch_length=bl - 1, min_output_size=32, mode='mix', idxs=list(range(B)))
+            for b, q in enumerate(qs):
+                w = cache.hier_get_packed(q, 64, bl - 1, 0, 32, 'mix', b)
+                assert got[b][0] == w[0].tolist() and got[b][1].tolist() == w[1].tolist()
+    assert dt.stats['full_uploads'] == 1, dt.stats        # everything after the first image went as device updates / patches
+    st = dt.meta.cpu().numpy()
+    assert st[2] > 100 and st[3] > 500, st                # branches inserted / records appended by the device
+
+
+def test_device_stream_put_overflow_falls_back_to_a_full_image():
+    """An insert that would pass the image capacity stops the device inserts (sticky flag); the host's replay passes the same
+    capacity, reports it, and the next sync uploads a larger image after which device updates continue."""
+    rs = np.random.RandomState(7)
+    V, bl = 500, 13
+    cache = LookaheadCache(eos_ids=[None])
+    cache.put(rs.randint(8, V, size=50).tolist(), branch_length=bl, mode='output', idx=-1)
+    dt = DeviceTrie(cache, idxs=[0, 1], put_vocab=V, cap_slack=300)
+    dt.load_stream_buffers()
+    cap0 = dt.cap
+    src = torch.zeros(2 * 40, dtype=torch.int32, device='cuda')
+    cnt = torch.zeros(2, dtype=torch.int32, device='cuda')
+    overflowed = False
+    for step in range(30):
+        toks = [rs.randint(8, V, size=20).tolist() for _ in range(2)]
+        hs = np.zeros(80, dtype=np.int32)
+        hs[:20], hs[40:60] = toks[0], toks[1]
+        src.copy_(torch.from_numpy(hs)); cnt.fill_(20)
+        dt.stream_put_dev(src.data_ptr(), 40, cnt.data_ptr(), [0, 1], bl)
+        ok = dt.replay([(0, toks[0]), (1, toks[1])], bl)
+        if not ok:
+            overflowed = True
+            torch.cuda.synchronize()
+            assert int(dt.meta.cpu()[1]) == 1
+            assert dt.sync() == 'full' and dt.cap > cap0
+        if step % 6 == 5:
+            dt.sync()
+            _assert_images_equal(dt, cache)
+    assert overflowed and dt.stats['full_uploads'] >= 2
+    _assert_images_equal(dt, cache)
