@@ -293,7 +293,8 @@ def _mirror_sync_host(cache, img):
         return 'full'
     ip, dk, dv = np.zeros(3 * ni.value + 1, np.int32), np.zeros(2 * nd.value + 1, np.int32), np.zeros(nd.value + 1, np.float64)
     check(lib.la_cache_mirror_patch(cache._h, ip.ctypes.data_as(_lib.pi32), dk.ctypes.data_as(_lib.pi32), dv.ctypes.data_as(pd)))
-    arrs = [img['tok'], img['cstart'], img['ccount']]
+    img.setdefault('ccap', {})
+    arrs = [img['tok'], img['cstart'], img['ccount'], img['ccap']]      # array 3: block capacities (read by device-side updates only)
     seen = set()
     for k in range(ni.value):
         a, r, v = ip[3 * k:3 * k + 3]
