@@ -224,6 +224,7 @@ def main():
                     help='7b = the BASELINE metric; 13b / mistral / mixtral = the config-4 / config-3 / config-5 model shapes')
     ap.add_argument('--batch', type=int, default=1, help='sequences per GPU; > 1: each gets its own 64-token tree per step (la_llama_mstep)')
     ap.add_argument('--device-trie', action='store_true', help='--batch > 1: drafts of all sequences from ONE device launch over the incremental trie mirror')
+    ap.add_argument('--host-trie-update', action='store_true', help='--device-trie: apply the per-step trie update on the host and ship it as a patch (round-2 form) instead of inserting the accepted tokens on the device (la_trie_stream_put_dev)')
     ap.add_argument('--unchained-trie', action='store_true', help='--device-trie: read the drafts back to the host and feed them through la_llama_mstep (round-2 form)')
     ap.add_argument('--strict-gather', action='store_true', help='N > 1: blocking all-gather (reference trie order at query time)')
     ap.add_argument('--profile-iters', type=int, default=3)
@@ -384,7 +385,10 @@ def main():
     dev_trie = None
     if args.device_trie and B > 1:
         from painlessinferenceacceleration_amd.device_trie import DeviceTrie
-        dev_trie = DeviceTrie(cache, idxs=gidx, device=dev)
+        dev_put = not args.host_trie_update and not args.unchained_trie and not dist_on
+        dev_trie = DeviceTrie(cache, idxs=gidx, device=dev, put_vocab=shape.vocab if dev_put else None)
+        if dev_put:
+            dev_trie.load_stream_buffers()
 
     def drafts_dev():
         ubl = [min(BL, max_length - len(seqs[i]) - 1) for i in range(B)]
@@ -405,11 +409,16 @@ def main():
             dev_trie.hier_get_dev([seqs[i][-2:] for i in range(B)], idxs=gidx, branch_lengths=ubl, decoding_length=DL, branch_length=BL,
                                   min_input_size=0, min_output_size=DL // 2, mode='mix')
             qts.append(time.time() - tq)
-            toks_all, Ts = eng.mstep_trie(dev_trie, 0, list(range(B)), [16] * B, [seqs[i][-1] for i in range(B)])
+            toks_all, Ts = eng.mstep_trie(dev_trie, 0, list(range(B)), [16] * B, [seqs[i][-1] for i in range(B)],
+                                          put_idxs=gidx if dev_trie.put_vocab else None, put_branch_length=BL + 1)
         for i in range(B):
             seqs[i].extend(toks_all[i])
             dls.append(Ts[i]); edls.append(len(toks_all[i]))
-        if dist_on:
+        if dev_trie.put_vocab:
+            # the device inserted the accepted tokens into its trie image itself (behind the verify pass, from the step's output
+            # block); the host trie repeats the same puts and drops the words it logged
+            dev_trie.replay([(gidx[i], toks_all[i]) for i in range(B)], BL + 1)
+        elif dist_on:
             if args.strict_gather:
                 gather.update_trie(cache, toks_all if B > 1 else toks_all[0], BL)
             else:
@@ -624,7 +633,7 @@ def main():
                    'kv_cache': (f'ring of {eng.shape.sliding_window} + one step of rows per sequence (sliding window)' if kv_ring else 'linear, max_length keys per sequence'),
                    'gather_mode': None if not dist_on else ('strict' if args.strict_gather else 'split-phase'),
                    'gather_transport': gather_transport, 'rccl_ranks': rccl_ranks,
-                   'draft_retrieval': ('device trie (incremental mirror, one launch per step' + (', chained in front of the verify pass: drafts stay in HBM)' if not args.unchained_trie else ', drafts read back to the host)')) if dev_trie is not None else 'host trie',
+                   'draft_retrieval': ('device trie (incremental mirror, one launch per step' + (', chained in front of the verify pass: drafts stay in HBM)' if not args.unchained_trie else ', drafts read back to the host)') + ('; trie update on the device (la_trie_stream_put_dev)' if dev_trie.put_vocab else '; trie update on the host, shipped as a patch')) if dev_trie is not None else 'host trie',
                    'device_trie_stats': dev_trie.stats if dev_trie is not None else None,
                    'mean_accept_len': round(mean_acc, 3), 'mean_draft_len': round(mean_T, 2),
                    'verify_steps_per_sec': round(K * world / elapsed, 2), 'context_at_end': ctx,

@@ -144,8 +144,9 @@ int la_trie_patch_dev(void* stream, int32_t* d_tok, double* d_fo, double* d_fi, 
  * :33-63) applied to the device image by the device, from tokens that are already in HBM (the accepted tokens of a verify step:
  * d_src_tok = la_llama_mstep's device output block + LA_MOUT_OUTTOK, stride LA_MOUT_TOKS, counts = the LA_MOUT_NOUT words).  The
  * image grows by the host mirror's rule and in the host's order, so the host REPLAYS the same puts on its trie afterwards
- * (la_cache_stream_put with the tokens it read back, then la_cache_mirror_discard) and the two stay word-for-word identical; no
- * patch crosses PCIe for these updates.  Everything else (input-mode put, final flush, reset_input_freqs, squeeze, load) stays a
+ * (la_cache_stream_put with the tokens it read back, then la_cache_mirror_discard) and the two agree on every live record (id,
+ * token, child block, capacity, frequencies; dead copies left behind by moved blocks are never read again); no patch crosses
+ * PCIe for these updates.  Everything else (input-mode put, final flush, reset_input_freqs, squeeze, load) stays a
  * host update that reaches the device as a patch or a full image, as before.
  *   la_trie_image          the device arrays: records [0, meta[0]) of `cap`; ccap = block capacities (la_cache_mirror_ccap);
  *                          meta int32[4] = {records in use, overflow (sticky), branches inserted, records appended};

@@ -475,50 +475,25 @@ __global__ __launch_bounds__(64) void k_trie_put_walk(TriePutArgs a) {
 }
 
 __global__ __launch_bounds__(64) void k_trie_put_link(TriePutArgs a) {
+    // First version: every level of every unfinished branch was a dependent global round trip (search, append, fence): 890 us for
+    // the 8 x 7 branches of a Mistral bs=8 step (profiles/r03_trie_device_update.txt).  Now: (1) the walk left the node where each
+    // branch ends and nothing but an EARLIER item of this call that appended under the same node can have changed that node, so
+    // an item whose end node no earlier item touched appends without searching, from fields prefetched for all items at once;
+    // (2) everything below the first appended node is a chain of fresh records whose ids follow from the record counter — the
+    // whole chain is written in one wave-parallel step (lane j = chain node j, final field values, no read-modify-write).
     __shared__ int buf[LA_TRIE_OBUF + 64];
     __shared__ int it_u[LA_TRIE_PUTS * LA_TRIE_ITEMS], it_lv[LA_TRIE_PUTS * LA_TRIE_ITEMS];
+    __shared__ int it_cs[LA_TRIE_PUTS * LA_TRIE_ITEMS], it_cc[LA_TRIE_PUTS * LA_TRIE_ITEMS], it_cp[LA_TRIE_PUTS * LA_TRIE_ITEMS];
+    __shared__ unsigned char it_dirty[LA_TRIE_PUTS * LA_TRIE_ITEMS];
     const int lane = threadIdx.x;
     const int bl = a.branch_length, n_items = a.n_put * LA_TRIE_ITEMS;
-    for (int q = lane; q < n_items; q += 64) { it_u[q] = a.items[2 * q]; it_lv[q] = a.items[2 * q + 1]; }
+    for (int q = lane; q < n_items; q += 64) {
+        const int u = a.items[2 * q];
+        it_u[q] = u; it_lv[q] = a.items[2 * q + 1]; it_dirty[q] = 0;
+        if (u >= 0) { it_cs[q] = a.cstart[u]; it_cc[q] = a.ccount[u]; it_cp[q] = a.ccap[u]; }
+    }
     __syncthreads();
     int n_rec = a.meta[0], ovf = a.meta[1], n_branch = 0, n_new = 0;
-    // append a child record under `prec` (Mirror::add_child); wave-uniform; -1 = the arena is full
-    auto add_child = [&](int prec, int token, int q_now) -> int {
-        const int cnt = a.ccount[prec], capc = a.ccap[prec];
-        int cs = a.cstart[prec];
-        if (cnt == capc) {
-            const int ncap = capc < 2 ? 4 : 2 * capc;
-            if (n_rec + ncap > a.cap) return -1;
-            const int nstart = n_rec, ostart = cs;
-            for (int r = lane; r < ncap; r += 64) {
-                const int n = nstart + r, o = ostart + r;
-                const bool cp = r < cnt;
-                a.tok[n] = cp ? a.tok[o] : -1; a.cstart[n] = cp ? a.cstart[o] : 0; a.ccount[n] = cp ? a.ccount[o] : 0;
-                a.ccap[n] = cp ? a.ccap[o] : 0; a.fo[n] = cp ? a.fo[o] : 0.0;
-                for (int p = 0; p < a.n_planes; ++p) a.fi[(size_t)p * a.fi_stride + n] = cp ? a.fi[(size_t)p * a.fi_stride + o] : 0.0;
-                if (cp && prec == 0) { const int t = a.tok[o]; if (t >= 0 && t < a.n_root_of) a.root_of[t] = n; }
-            }
-            // the records of the pending items that sat in the moved block
-            for (int q = q_now + 1 + lane; q < n_items; q += 64) {
-                const int u = it_u[q];
-                if (u >= ostart && u < ostart + cnt && u > 0) it_u[q] = u - ostart + nstart;
-            }
-            n_rec += ncap;
-            cs = nstart;
-            if (lane == 0) { a.cstart[prec] = nstart; a.ccap[prec] = ncap; }
-        }
-        const int rec = cs + cnt;
-        if (lane == 0) {
-            a.ccount[prec] = cnt + 1;
-            a.tok[rec] = token; a.cstart[rec] = 0; a.ccount[rec] = 0; a.ccap[rec] = 0; a.fo[rec] = 0.0;
-            for (int p = 0; p < a.n_planes; ++p) a.fi[(size_t)p * a.fi_stride + rec] = 0.0;
-            if (prec == 0 && token >= 0 && token < a.n_root_of) a.root_of[token] = rec;
-        }
-        __threadfence_block();
-        __syncthreads();
-        ++n_new;
-        return rec;
-    };
     for (int k = 0; k < a.n_put; ++k) {
         __syncthreads();
         int ol;
@@ -530,20 +505,72 @@ __global__ __launch_bounds__(64) void k_trie_put_link(TriePutArgs a) {
             int cur = it_u[q];
             if (cur < 0) continue;                                    // a stop-word root, or the whole branch existed already
             ++n_branch;
-            bool fresh = false;
-            for (int lv = it_lv[q]; lv <= bl; ++lv) {
-                const int t = buf[i + lv];
-                int ch = -1;
-                if (!fresh) ch = lv == 0 ? find_root(a, t, lane) : find_child_rw(a.tok, a.cstart, a.ccount, cur, t, lane);
-                if (ch < 0) {
-                    ch = add_child(cur, t, q);
-                    if (ch < 0) { ovf = 1; break; }
-                    fresh = true;
-                }
-                if (lv >= 1 && lane == 0) a.fo[ch] += 1.0;            // the tree root itself carries no frequency (:365-367)
+            int lv = it_lv[q];
+            int cs = it_cs[q], cc = it_cc[q], cp = it_cp[q];
+            if (it_dirty[q]) {
+                // an earlier item of this call appended under this node: search again from here (its child may be ours)
                 __threadfence_block();
-                cur = ch;
+                for (; lv <= bl; ++lv) {
+                    const int t = buf[i + lv];
+                    const int ch = lv == 0 ? find_root(a, t, lane) : find_child_rw(a.tok, a.cstart, a.ccount, cur, t, lane);
+                    if (ch < 0) break;
+                    if (lv >= 1 && lane == 0) atomicAdd(&a.fo[ch], 1.0);
+                    cur = ch;
+                }
+                if (lv > bl) continue;
+                cs = a.cstart[cur]; cc = a.ccount[cur]; cp = a.ccap[cur];
             }
+            // ---- append: the first new node under `cur` (Mirror::add_child), then the chain below it
+            const int m_chain = bl - lv;                              // fresh nodes below the first one
+            int moved_from = -1, moved_cnt = 0, moved_to = 0;
+            if (cc == cp) {                                           // block full: move it to the arena end with twice the room
+                const int ncap = cp < 2 ? 4 : 2 * cp;
+                if (n_rec + ncap + 4 * m_chain > a.cap) { ovf = 1; break; }
+                __threadfence_block();                                // records of the old block written earlier in this launch
+                const int nstart = n_rec, ostart = cs;
+                for (int r = lane; r < ncap; r += 64) {
+                    const int n = nstart + r, o = ostart + r;
+                    const bool cpy = r < cc;
+                    a.tok[n] = cpy ? a.tok[o] : -1; a.cstart[n] = cpy ? a.cstart[o] : 0; a.ccount[n] = cpy ? a.ccount[o] : 0;
+                    a.ccap[n] = cpy ? a.ccap[o] : 0; a.fo[n] = cpy ? a.fo[o] : 0.0;
+                    for (int p = 0; p < a.n_planes; ++p) a.fi[(size_t)p * a.fi_stride + n] = cpy ? a.fi[(size_t)p * a.fi_stride + o] : 0.0;
+                    if (cpy && cur == 0) { const int t = a.tok[o]; if (t >= 0 && t < a.n_root_of) a.root_of[t] = n; }
+                }
+                moved_from = ostart; moved_cnt = cc; moved_to = nstart;
+                n_rec += ncap;
+                cs = nstart; cp = ncap;
+                if (lane == 0) { a.cstart[cur] = nstart; a.ccap[cur] = ncap; }
+            } else if (n_rec + 4 * m_chain > a.cap) { ovf = 1; break; }
+            const int first = cs + cc;
+            const int base = n_rec;                                   // chain node j = record base + 4 j (first slot of its own block)
+            if (lane == 0) {
+                const int t = buf[i + lv];
+                a.ccount[cur] = cc + 1;
+                a.tok[first] = t;
+                a.cstart[first] = m_chain > 0 ? base : 0; a.ccount[first] = m_chain > 0 ? 1 : 0; a.ccap[first] = m_chain > 0 ? 4 : 0;
+                a.fo[first] = lv >= 1 ? 1.0 : 0.0;                    // the tree root itself carries no frequency (:365-367)
+                for (int p = 0; p < a.n_planes; ++p) a.fi[(size_t)p * a.fi_stride + first] = 0.0;
+                if (cur == 0 && t >= 0 && t < a.n_root_of) a.root_of[t] = first;
+            }
+            for (int e = lane; e < 4 * m_chain; e += 64) {            // 4 records per chain block: slot 0 = the node, 1..3 spare
+                const int j = e >> 2, slot = e & 3, rec = base + e;
+                const bool node = slot == 0, last = j == m_chain - 1;
+                a.tok[rec] = node ? buf[i + lv + 1 + j] : -1;
+                a.cstart[rec] = node && !last ? base + 4 * (j + 1) : 0;
+                a.ccount[rec] = node && !last ? 1 : 0;
+                a.ccap[rec] = node && !last ? 4 : 0;
+                a.fo[rec] = node ? 1.0 : 0.0;
+                for (int p = 0; p < a.n_planes; ++p) a.fi[(size_t)p * a.fi_stride + rec] = 0.0;
+            }
+            n_rec += 4 * m_chain;
+            n_new += 1 + m_chain;
+            // pending items: records that sat in the moved block follow it; items that end at `cur` must search again
+            for (int q2 = q + 1 + lane; q2 < n_items; q2 += 64) {
+                int u2 = it_u[q2];
+                if (u2 > 0 && u2 >= moved_from && u2 < moved_from + moved_cnt) { u2 = u2 - moved_from + moved_to; it_u[q2] = u2; }
+                if (u2 == cur) it_dirty[q2] = 1;
+            }
+            __syncthreads();
         }
         // roll the hold-back buffer (:399-400)
         __syncthreads();

@@ -560,10 +560,13 @@ class LlamaVerifyEngine(object):
         return [o[_lib.LA_MOUT_OUTTOK + _lib.LA_MOUT_TOKS * b:_lib.LA_MOUT_OUTTOK + _lib.LA_MOUT_TOKS * b + int(o[_lib.LA_MOUT_NOUT + b])].tolist()
                 for b in range(len(blocks))]
 
-    def mstep_trie(self, dev_trie, q0, slots, limits, last_tokens):
+    def mstep_trie(self, dev_trie, q0, slots, limits, last_tokens, put_idxs=None, put_branch_length=None):
         """One multi-block verify step whose drafts are the results of the LAST dev_trie.hier_get_dev(...) launch, taken on the
         device: block b = query q0 + b of that launch (ids / row masks / count stay in HBM; nothing but the result header crosses
         PCIe).  The trie kernels must have been queued on this engine's stream.  slots / limits / last_tokens: per block.
+        put_idxs: the trie slot (batch index) of each block — the step's accepted tokens are then inserted into the DEVICE trie
+        image by the device, straight from the step's output block (DeviceTrie.stream_put_dev, queued behind the step; the host
+        waits for the result header only and must dev_trie.replay() the same tokens before its next trie update).
         -> (emitted token lists, draft lengths)."""
         nb = len(slots)
         assert self.max_blocks and 1 <= nb <= self.max_blocks
@@ -572,7 +575,18 @@ class LlamaVerifyEngine(object):
         check(lib.la_llama_mstep_trie(self._h, self._sp(), nb, arr(slots), arr(lim), arr(last_tokens),
                                       C.c_void_p(dev_trie.out_ids.data_ptr() + 4 * 64 * q0), C.c_void_p(dev_trie.out_rm.data_ptr() + 8 * 64 * q0),
                                       C.c_void_p(dev_trie.out_n.data_ptr() + 4 * q0), self.host_mout.data_ptr()), 'llama_mstep_trie')
-        self.stream.synchronize()
+        if put_idxs is not None:
+            ev = getattr(self, '_hdr_event', None)
+            if ev is None:
+                ev = self._hdr_event = torch.cuda.Event()
+            ev.record(self.stream)                      # behind the D2H of the result header
+            mo = self.mout().data_ptr()
+            with torch.cuda.stream(self.stream):
+                dev_trie.stream_put_dev(mo + 4 * _lib.LA_MOUT_OUTTOK, _lib.LA_MOUT_TOKS, mo + 4 * _lib.LA_MOUT_NOUT, put_idxs,
+                                        put_branch_length)
+            ev.synchronize()
+        else:
+            self.stream.synchronize()
         o = self._mout_np
         self._mstep_slots = list(slots)
         for slot in slots:

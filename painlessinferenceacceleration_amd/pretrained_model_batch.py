@@ -73,8 +73,9 @@ class LookaheadPreTrainedModel(object):
         the batch size changes)."""
         from .device_trie import DeviceTrie
         dt = getattr(self, '_dev_trie', None)
-        if dt is None or dt.cache is not self.lookahead_cache or len(dt.idxs) < n_samples:
-            dt = self._dev_trie = DeviceTrie(self.lookahead_cache, idxs=list(range(n_samples)), device=self.engine.device)
+        if dt is None or dt.cache is not self.lookahead_cache or len(dt.idxs) < n_samples or dt._revoked:
+            dt = self._dev_trie = DeviceTrie(self.lookahead_cache, idxs=list(range(n_samples)), device=self.engine.device,
+                                             put_vocab=self.engine.shape.vocab)
         return dt
 
     @torch.no_grad()
@@ -187,6 +188,9 @@ class LookaheadPreTrainedModel(object):
         chained = bool(decoding_kwargs.get('device_trie', False)) and multi and not sequential and streamer is None and \
             bool(decoding_kwargs.get('per_sample_budget', False)) and dmode.split('_')[0] == 'hier' and \
             not decoding_kwargs.get('debug_lookahead', False)
+        # device_trie_update (default on with the chained device trie): the trie UPDATE of every step runs on the device as well
+        dev_put = chained and bool(decoding_kwargs.get('device_trie_update', True)) and branch_length + 1 <= 64
+        put_on_device, buffers_loaded = False, False
         decoding_kwargs['dls'].extend([1] * bs)
         decoding_kwargs['edls'].extend([1] * bs)
         max_cur = 0
@@ -195,9 +199,17 @@ class LookaheadPreTrainedModel(object):
                 rows[b].extend(next_token_list[k])
             if streamer is not None:
                 streamer.put(np.array(next_token_list[0]))
-            for k, b in enumerate(batch_indices):                               # :1254-1259
-                self.lookahead_cache.stream_put([x for x in next_token_list[k] if x != -1], branch_length=branch_length + 1,
-                                                final=False, mode='output', idx=b)
+            if put_on_device:
+                # the device inserted these tokens into its trie image itself, straight from the step's output block
+                # (la_trie_stream_put_dev behind the verify pass): the host trie repeats the same puts in the same order and
+                # drops the words it logged for them — nothing of the update crosses PCIe
+                self._device_trie(decoding_kwargs['_n_samples']).replay(
+                    [(b, next_token_list[k]) for k, b in enumerate(batch_indices)], branch_length + 1)
+                put_on_device = False
+            else:
+                for k, b in enumerate(batch_indices):                           # :1254-1259
+                    self.lookahead_cache.stream_put([x for x in next_token_list[k] if x != -1], branch_length=branch_length + 1,
+                                                    final=False, mode='output', idx=b)
             max_cur = max(max_cur, max(len(rows[b]) - 1 for b in batch_indices))
             keep = []
             for k, b in enumerate(batch_indices):                               # :1269-1276 + _early_stop :937-980
@@ -226,14 +238,19 @@ class LookaheadPreTrainedModel(object):
                 with torch.cuda.stream(eng.stream):
                     dt.hier_get_dev(qids, idxs=batch_indices, decoding_length=per, branch_length=branch_length, min_input_size=0,
                                     min_output_size=max(per // 2, 1), mode=mode_q)
+                    if dev_put and not buffers_loaded:
+                        dt.load_stream_buffers()        # the hold-back buffers as the host's stream_put calls left them
+                        buffers_loaded = True
                     emitted, widths = {}, []
                     for g0 in range(0, len(batch_indices), eng.max_blocks):
                         grp = batch_indices[g0:g0 + eng.max_blocks]
                         toks, Ts = eng.mstep_trie(dt, g0, grp, [stop_max_length - (len(rows[b]) - 1) - 1 for b in grp],
-                                                  [rows[b][-1] for b in grp])
+                                                  [rows[b][-1] for b in grp], put_idxs=grp if dev_put else None,
+                                                  put_branch_length=branch_length + 1)
                         for b, tk in zip(grp, toks):
                             emitted[b] = tk
                         widths.extend(Ts)
+                    put_on_device = dev_put
                 decoding_kwargs['qts'].append(time.time() - ts_q)
                 decoding_kwargs.update({'decoding_qids': qids, 'decoding_ids': None, 'hit_sizes': None, 'batch_indices': batch_indices})
                 width = max(widths)

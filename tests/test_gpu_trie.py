@@ -133,7 +133,8 @@ def test_incremental_device_mirror_replays_reference_trace_with_interleaved_upda
 def test_batch_loop_with_device_trie_equals_host_trie_loop():
     """pretrained_model_batch.lookahead_generation with decoding_kwargs['device_trie']: the drafts of all samples come from one
     device launch per step over the incremental mirror; sequences, dls and edls must equal the host-trie loop's, request after
-    request (the second request runs on the trie the first one grew)."""
+    request (the second request runs on the trie the first one grew) — with the per-step trie update shipped from the host as a
+    patch, and with the update done by the device itself (device_trie_update: la_trie_stream_put_dev + host replay)."""
     import torch
     from painlessinferenceacceleration_amd.modeling_llama_batch import LlamaForCausalLM as BatchLlama
     from tests.tiny_model import noisy_copies, tiny_decisive_weights, tiny_shape
@@ -143,7 +144,7 @@ def test_batch_loop_with_device_trie_equals_host_trie_loop():
     B, P = 4, 24
     prompts = rs.randint(3, shape.vocab, size=(B, P))
     outs = []
-    for use_dev in (False, True):
+    for use_dev, dev_update in ((False, False), (True, False), (True, True)):
         model = BatchLlama(shape, dict(sd), max_length=256, max_batch=B, eos_token_id=2)
         truth = model.greedy_search(torch.from_numpy(prompts), P + 100, eos_token_id=None)[:, P:].tolist()
         model.lookahead_cache = LookaheadCache(eos_ids=[2])
@@ -153,15 +154,22 @@ def test_batch_loop_with_device_trie_equals_host_trie_loop():
         runs = []
         for req in range(2):
             dk = {'use_lookahead': True, 'decoding_mode': 'hier', 'decoding_length': 64, 'branch_length': 12,
-                  'per_sample_budget': True, 'device_trie': use_dev}
+                  'per_sample_budget': True, 'device_trie': use_dev, 'device_trie_update': dev_update}
             out = model.lookahead_generation(torch.from_numpy(prompts), stopping_criteria=P + 90, eos_token_id=2, pad_token_id=0,
                                              return_dict_in_generate=True, decoding_kwargs=dk)
             runs.append((out.sequences.tolist(), out.kwargs['dls'], out.kwargs['edls']))
             assert [s[P:P + 60] for s in out.sequences.tolist()] == [t[:60] for t in truth]       # lossless
-        if use_dev:
+        if use_dev and not dev_update:
             assert model._dev_trie.stats['patches'] > 10
+        if dev_update:
+            # the per-step updates ran on the device (la_trie_stream_put_dev behind every verify pass, replayed on the host): what is
+            # left as patches are the host-side updates (prompt puts, first tokens, final flushes)
+            dt = model._dev_trie
+            assert dt.stats_put['calls'] > 10 and dt.stats_put['replays'] > 10 and dt.stats['patches'] < 10, (dt.stats, dt.stats_put)
+            torch.cuda.synchronize()
+            assert int(dt.meta.cpu()[1]) == 0 and int(dt.meta.cpu()[3]) > 100
         outs.append(runs)
-    assert outs[0] == outs[1]
+    assert outs[0] == outs[1] == outs[2]
     assert max(outs[0][0][1]) > 16          # per-sample budget: trees larger than the reference's (64 // 4) // 4 rows
 
 
