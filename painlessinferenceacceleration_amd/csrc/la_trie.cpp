@@ -733,8 +733,13 @@ static void mirror_rebuild(la_cache* c) {
     std::vector<int32_t> roots;
     for (auto& kv : c->mem) roots.push_back(c->trees[kv.second].root);
     std::sort(roots.begin(), roots.end());               // creation order of the arena = a deterministic order
-    const int32_t r0 = m.grow((int32_t)roots.size());
-    m.cstart[0] = r0; m.ccount[0] = m.ccap[0] = (int32_t)roots.size();
+    // A rebuilt block gets room to grow (count / 4, at least one record): with exactly-full blocks the FIRST child appended under any
+    // node after a rebuild moved that node's whole block (for the forest's root block: thousands of records per new tree) — 5 000
+    // patch words per verify step and most of the device-side link kernel's time (profiles/r03_trie_device_update.txt).
+    auto roomy = [](int32_t cnt) { return cnt + std::max<int32_t>(1, cnt / 4); };
+    const int32_t n_roots = (int32_t)roots.size();
+    const int32_t r0 = m.grow(n_roots ? roomy(n_roots) : 0);
+    m.cstart[0] = r0; m.ccount[0] = n_roots; m.ccap[0] = n_roots ? roomy(n_roots) : 0;
     std::vector<int32_t> order;                          // records still to expand (breadth-first)
     for (size_t i = 0; i < roots.size(); ++i) {
         const int32_t rec = r0 + (int32_t)i;
@@ -749,8 +754,8 @@ static void mirror_rebuild(la_cache* c) {
         int32_t cnt = 0;
         for (int32_t ch = nd.first_child; ch >= 0; ch = c->nodes[ch].next_sib) ++cnt;
         if (cnt == 0) continue;
-        const int32_t cs = m.grow(cnt);
-        m.cstart[rec] = cs; m.ccount[rec] = m.ccap[rec] = cnt;
+        const int32_t cs = m.grow(roomy(cnt));
+        m.cstart[rec] = cs; m.ccount[rec] = cnt; m.ccap[rec] = roomy(cnt);
         int32_t k = 0;
         for (int32_t ch = nd.first_child; ch >= 0; ch = c->nodes[ch].next_sib, ++k) {
             m.host_of[cs + k] = ch; m.dev_of[ch] = cs + k;
