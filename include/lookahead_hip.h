@@ -325,6 +325,11 @@ typedef struct la_llama_config {
     int32_t max_blocks;      /* > 1: allocate the multi-block step (la_llama_mstep) for up to this many 64-row blocks (<= LA_MB_MAX) */
     int32_t norm_cast_first; /* RMSNorm flavour: 0 = LlamaRMSNorm (llama/modeling_llama.py:86-90, one rounding), 1 = Mistral/
                                 MixtralRMSNorm (mixtral/modeling_mixtral.py:160-165, normalised value rounded first) */
+    int32_t qkv_mb_wg;       /* > 0: the layers carry a SECOND QKV image (la_llama_layer_weights.wqkv_mb) packed with la_rowplan for
+                                this many workgroups, read by the multi-block step only.  The 64-row step wants one workgroup per CU
+                                (HBM streaming); at 192-512 rows the launch is MFMA-bound and a GQA model's 24 rows per workgroup
+                                (12 RoPE pairs in a 32-row MFMA block) waste 5/8 of the matrix-core work: fewer, fuller workgroups
+                                (Mistral: 96 x 32 pairs) x token quarters instead */
 } la_llama_config;
 
 typedef struct la_llama_layer_weights {   /* device pointers, packed by la_pack_weight */
@@ -340,6 +345,7 @@ typedef struct la_llama_layer_weights {   /* device pointers, packed by la_pack_
                                         layer are equally spaced in memory (ptr[e] = ptr[0] + e * stride, stride % 16 == 0) all
                                         experts of a stage run in ONE launch, otherwise one launch per expert             */
     const void* const* ex_down;      /* host array [n_experts]: packed w2 of each expert                        */
+    const void* wqkv_mb;             /* cfg.qkv_mb_wg > 0: the QKV rows once more, planned for cfg.qkv_mb_wg workgroups (multi-block step) */
 } la_llama_layer_weights;
 
 typedef struct la_llama_weights {

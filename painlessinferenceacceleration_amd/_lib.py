@@ -77,12 +77,12 @@ class LlamaConfigC(C.Structure):
                 ("ffn", i32), ("vocab", i32), ("max_keys", i32), ("max_pos", i32), ("attn_split", i32),
                 ("rms_eps", f32), ("gemm_cfg", i32 * 8), ("balanced_wg", i32 * 3), ("n_slots", i32),
                 ("n_experts", i32), ("top_k", i32), ("fuse", i32), ("sliding_window", i32), ("kv_ring", i32), ("max_blocks", i32),
-                ("norm_cast_first", i32)]
+                ("norm_cast_first", i32), ("qkv_mb_wg", i32)]
 
 
 class LlamaLayerWeightsC(C.Structure):
     _fields_ = [("wqkv", vp), ("wo", vp), ("wgateup", vp), ("wdown", vp), ("norm1", vp), ("norm2", vp),
-                ("router", vp), ("ex_gateup", C.POINTER(vp)), ("ex_down", C.POINTER(vp))]
+                ("router", vp), ("ex_gateup", C.POINTER(vp)), ("ex_down", C.POINTER(vp)), ("wqkv_mb", vp)]
 
 
 class LlamaWeightsC(C.Structure):

@@ -619,7 +619,10 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk, bool wide = fals
         const la_llama_layer_weights& L = m->layers[l];
         uint16_t* kf = m->mb_kfresh + (size_t)l * m->mb_fresh_layer;
         uint16_t* vf = m->mb_vfresh + (size_t)l * m->mb_fresh_layer;
-        MbGemm q{}; q.wp = L.wqkv; q.xp = m->mb_xp; q.N = m->qkv_n; q.K = c.hidden; q.nblk = nblk; q.n_wg = c.balanced_wg[0]; q.ksplit = 1;
+        MbGemm q{}; q.xp = m->mb_xp; q.N = m->qkv_n; q.K = c.hidden; q.nblk = nblk; q.ksplit = 1;
+        // >= 3 blocks (the wide launches): the image planned for fewer, fuller workgroups when the model carries one (cfg.qkv_mb_wg)
+        const bool mbq = c.qkv_mb_wg > 0 && L.wqkv_mb && nblk >= 3;
+        q.wp = mbq ? L.wqkv_mb : L.wqkv; q.n_wg = mbq ? c.qkv_mb_wg : c.balanced_wg[0];
         q.pos = m->mb_pos; q.rcos = m->w.rope_cos; q.rsin = m->w.rope_sin; q.qf = m->mb_qf; q.kfresh = kf; q.vfresh = vf;
         q.nh = c.n_heads; q.nkv = c.n_kv_heads;
         KCHK(lk_mb_gemm(st, 2, q));

@@ -1752,7 +1752,9 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                     p.wg_chunks = 2 * a.wg_chunks;
                 }
                 // la_debug_set key 12 (slab launches with <= 2 K splits): more token groups instead — 2 blocks per workgroup at every block count
-                if (nblk <= 4 || (EPI == MB_SLAB && g_la_mb_ks2 && ksplit <= 2)) k_gemm_wide<4, 1, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 1) / 2), 512, WideGeom<4, 1>::LDS, st>>>(p);
+                // QKV over at most 128 (fuller) workgroups — the multi-block image of a GQA model, cfg.qkv_mb_wg — takes token QUARTERS at
+                // every block count: n_wg / 2 x 4 <= 256 workgroups of 4 row-blocks x 4 token tiles (la_debug_set(6, 9) forces the form)
+                if (nblk <= 4 || (EPI == MB_SLAB && g_la_mb_ks2 && ksplit <= 2) || (EPI == MB_QKV && (n_wg <= 128 || (g_la_mb_pair & 8)))) k_gemm_wide<4, 1, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 1) / 2), 512, WideGeom<4, 1>::LDS, st>>>(p);
                 else if (g_la_mb_dbg == 4) k_gemm_wide<4, 2, EPI, 4><<<dim3(n_wg / 2, ksplit, (nblk + 3) / 4), 512, WideGeom<4, 2>::LDS, st>>>(p);   // measurement: no epilogue
                 else k_gemm_wide<4, 2, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 3) / 4), 512, WideGeom<4, 2>::LDS, st>>>(p);
                 LAUNCH_CHECK(); return 0;

@@ -12,6 +12,7 @@ from lookahead_generation (common/pretrained_model.py:1176-1181).
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -259,23 +260,43 @@ class LlamaVerifyEngine(object):
         if balanced and not (gemm_cfg and len(gemm_cfg) > 1 and gemm_cfg[1] < 0):
             for slot, (kind, n_rows) in enumerate([(2, (shape.n_heads + 2 * shape.n_kv_heads) * hd), (1, shape.ffn),
                                                    (0, shape.vocab)]):
-                n = lib.la_rowplan(kind, n_rows, n_cu, None)
+                nwg = n_cu
+                n = lib.la_rowplan(kind, n_rows, nwg, None)
                 if n > 0:
                     plan = np.zeros(n, dtype=np.int32)
-                    check(min(lib.la_rowplan(kind, n_rows, n_cu, plan.ctypes.data_as(_lib.pi32)), 0), 'rowplan')
+                    check(min(lib.la_rowplan(kind, n_rows, nwg, plan.ctypes.data_as(_lib.pi32)), 0), 'rowplan')
                     plans[slot] = torch.from_numpy(plan).to(self.device)
-                    plan_kinds[slot] = (kind, n_rows)
-                    self.balanced_wg[slot] = n_cu
+                    plan_kinds[slot] = (kind, n_rows, nwg)
+                    self.balanced_wg[slot] = nwg
+
+        # Multi-block step (192-512 rows, MFMA-bound): when the one-workgroup-per-CU QKV plan leaves the 32-row MFMA blocks less
+        # than 60 % full (GQA: Mistral / Mixtral 24 rows = 12 RoPE pairs per workgroup), a SECOND image over pairs / 32 workgroups
+        # (every block full; 50 MB per layer at the Mistral shape) serves that path: Mistral bs=8 11.26 -> 10.45 ms per step
+        # (scripts/gpu_qkv_wg_ab.sh, profiles/r03_qkv_mb_plan.txt).  LA_QKV_MB_WG overrides (0 = off).
+        self.qkv_mb_wg = 0
+        pairs = (shape.n_heads + 2 * shape.n_kv_heads) * hd // 2
+        if max_blocks > 1 and self.balanced_wg[0] and hd == 128:
+            want = pairs // 32 if (pairs % 32 == 0 and (pairs // self.balanced_wg[0]) / 32.0 < 0.6) else 0
+            if os.environ.get('LA_QKV_MB_WG') is not None:
+                want = int(os.environ['LA_QKV_MB_WG'])
+            if want > 0 and want % 16 == 0 and want < self.balanced_wg[0] and pairs % want == 0 and pairs // want <= 32:
+                n = lib.la_rowplan(2, 2 * pairs, want, None)
+                if n > 0:
+                    plan = np.zeros(n, dtype=np.int32)
+                    check(min(lib.la_rowplan(2, 2 * pairs, want, plan.ctypes.data_as(_lib.pi32)), 0), 'rowplan')
+                    plans['qkv_mb'] = torch.from_numpy(plan).to(self.device)
+                    plan_kinds['qkv_mb'] = (2, 2 * pairs, want)
+                    self.qkv_mb_wg = want
 
         def pack_planned(slot, mats):
             """compact workgroup-major packing by the plan (la_pack_planned)"""
-            kind, n_rows = plan_kinds[slot]
+            kind, n_rows, nwg = plan_kinds[slot]
             mats = [m.to(device=self.device, dtype=torch.bfloat16).contiguous() for m in mats]
             K = mats[0].shape[1]
-            out = torch.empty(lib.la_planned_elems(kind, n_rows, K, n_cu), dtype=torch.bfloat16, device=self.device)
+            out = torch.empty(lib.la_planned_elems(kind, n_rows, K, nwg), dtype=torch.bfloat16, device=self.device)
             torch.cuda.synchronize(self.device)
             check(lib.la_pack_planned(sp, mats[0].data_ptr(), mats[1].data_ptr() if len(mats) > 1 else None,
-                                      plans[slot].data_ptr(), kind, n_rows, K, n_cu, out.data_ptr()), 'pack_planned')
+                                      plans[slot].data_ptr(), kind, n_rows, K, nwg, out.data_ptr()), 'pack_planned')
             self.stream.synchronize()
             self._keep.append(out)
             return out
@@ -295,6 +316,8 @@ class LlamaVerifyEngine(object):
                              take(p + 'self_attn.v_proj.weight').to(self.device)], 0)
             if self.balanced_wg[0]:
                 layers[i].wqkv = pack_planned(0, [qkv]).data_ptr()
+                if self.qkv_mb_wg:
+                    layers[i].wqkv_mb = pack_planned('qkv_mb', [qkv]).data_ptr()
             else:
                 if self.qkv_fused:
                     qkv = qkv.index_select(0, qkv_perm)
@@ -362,6 +385,7 @@ class LlamaVerifyEngine(object):
         cfg.n_slots = self.n_slots
         cfg.n_experts, cfg.top_k = shape.n_experts, shape.top_k
         cfg.norm_cast_first = int(shape.norm_cast_first)
+        cfg.qkv_mb_wg = int(self.qkv_mb_wg)
         cfg.fuse = int(fuse)
         assert 0 <= max_blocks <= _lib.LA_MB_MAX
         self.max_blocks = int(max_blocks) if max_blocks > 1 else 0
