@@ -76,6 +76,7 @@ struct la_llama {
     hipStream_t graph_stream;
 };
 
+int g_la_ex_split = 0;            // la_debug_set key 16: 1 = gathered multi-block MoE with one launch per expert and stage (A/B)
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Carver {
@@ -648,6 +649,17 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk, bool wide = fals
                 KCHK(lk_mb_moe_plan(st, route_w, M, c.n_experts, m->mb_moe_perm, m->mb_moe_pos, m->mb_moe_cnt));
                 KCHK(lk_mb_moe_gather(st, m->mb_xp, m->mb_moe_perm, m->mb_moe_cnt, c.hidden, nblk, c.n_experts, m->mb_xg, xg_stride));
             }
+            if (gathered && m->ex_merged && !g_la_ex_split) {
+                // equally spaced expert images: ONE gate/up launch and ONE down launch for all experts (grid.z = expert x pass)
+                MbGemm g{}; g.wp = m->ex_gateup[(size_t)l * c.n_experts]; g.xp = m->mb_xg; g.N = c.ffn; g.K = c.hidden; g.nblk = nblk;
+                g.n_wg = c.balanced_wg[1]; g.ksplit = 1; g.act_xp = m->mb_act_ex; g.nblk_dev = m->mb_moe_cnt + LA_MOE_MAX_E;
+                g.ex_n = c.n_experts; g.ex_w_stride = m->ex_gu_stride[l]; g.ex_x_stride = xg_stride; g.ex_o_stride = (long)act_stride;
+                KCHK(lk_mb_gemm(st, 1, g));
+                MbGemm d{}; d.wp = m->ex_down[(size_t)l * c.n_experts]; d.xp = m->mb_act_ex; d.N = c.hidden; d.K = c.ffn; d.nblk = nblk;
+                d.ksplit = m->down_ks; d.slabs = m->mb_slabs_ex; d.slab_rows = npass_rows; d.nblk_dev = m->mb_moe_cnt + LA_MOE_MAX_E;
+                d.ex_n = c.n_experts; d.ex_w_stride = m->ex_dn_stride[l]; d.ex_x_stride = (long)act_stride; d.ex_o_stride = (long)slab_stride;
+                KCHK(lk_mb_gemm(st, 0, d));
+            } else
             for (int e = 0; e < c.n_experts; ++e) {
                 MbGemm g{}; g.wp = m->ex_gateup[(size_t)l * c.n_experts + e]; g.xp = gathered ? m->mb_xg + e * xg_stride : m->mb_xp;
                 g.N = c.ffn; g.K = c.hidden; g.nblk = nblk;

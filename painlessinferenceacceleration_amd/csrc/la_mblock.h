@@ -39,6 +39,9 @@ struct MbGemm {
     const int* pos; const void* rcos; const void* rsin; void* qf; void* kfresh; void* vfresh; int nh, nkv;
     const float* route_col;            // MoE: this expert's routing weights (stride LA_MOE_MAX_E floats per row); null = dense
     const int* nblk_dev;               // gathered MoE: the expert's block count on the device (nblk = the upper bound); null = nblk
+    // gathered MoE, ALL experts of a stage in one launch (ex_n > 1, needs nblk_dev): expert e reads wp + e * ex_w_stride, xp + e *
+    // ex_x_stride (bf16 elements), writes act_xp + e * ex_o_stride (bf16 elements) / slabs + e * ex_o_stride (floats), count nblk_dev[e]
+    int ex_n; long ex_w_stride, ex_x_stride, ex_o_stride;
 };
 int lk_mb_gemm(hipStream_t st, int kind, const MbGemm& g);
 int lk_mb_resid_norm_router(hipStream_t st, void* h, const float* slabs, int n_slabs, int slab_rows, const void* nw, int hidden, float eps,

@@ -43,6 +43,8 @@ struct MbArgs {
     const float* route_col; int route_rows;
     // gathered MoE (k_moe_plan_mb): the number of 64-row blocks this expert received, decided on the device
     const int* nblk_dev;
+    // ... for ALL experts of a stage in one launch (ex_n > 1): grid.z = expert x pass; operands of expert e at e * stride
+    int ex_n; long ex_w_stride, ex_x_stride, ex_o_stride;
     // paired form of the wide kernel (launch_mb): the weight rows of a workgroup are read by a second workgroup working on the other
     // token blocks (same XCD): stream them with the default cache policy so that the second reader finds them in L2
     int w_keep;
@@ -54,7 +56,7 @@ struct MbArgs {
 // (row-block, token block, register group) slices, parts summed in the order p = 0..KP-1 (deterministic).
 // ---------------------------------------------------------------------------------------------------------------
 template <int RBV, int EPI, int KP>
-__device__ __forceinline__ void mb_epilogue_block(const MbArgs& a, const f32x4* red4, int blk, int ks, int wave, int lane) {
+__device__ __forceinline__ void mb_epilogue_block(const MbArgs& a, const f32x4* red4, int blk, int ks, int wave, int lane, size_t o_off = 0) {
     const int tl = lane & 31, hh = lane >> 5;
     auto total4 = [&](int rbq, int tb, int gi) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -70,7 +72,7 @@ __device__ __forceinline__ void mb_epilogue_block(const MbArgs& a, const f32x4* 
             const int sl = wave * 2 + i, rq = sl >> 3, tb = (sl >> 2) & 1, gi = sl & 3;
             const f32x4 v = total4(rq, tb, gi);
             const int tok = blk * 64 + tb * 32 + tl;
-            float* o = a.slabs + ((size_t)ks * a.M + tok) * a.N + (blockIdx.x * RBV + rq) * 32 + 8 * gi + 4 * hh;
+            float* o = a.slabs + o_off + ((size_t)ks * a.M + tok) * a.N + (blockIdx.x * RBV + rq) * 32 + 8 * gi + 4 * hh;
             *(f32x4*)o = v;
         }
     } else if constexpr (EPI == MB_SWIGLU) {
@@ -90,7 +92,7 @@ __device__ __forceinline__ void mb_epilogue_block(const MbArgs& a, const f32x4* 
                         const float gv = bfr(g4[j]), uv = bfr(u4[j]);
                         const float sv = bfr(gv / (1.0f + expf(-gv)));
                         const int feat = a.gu_interleaved ? (2 * blockIdx.x + qq) * 32 + f : a.R * blockIdx.x + 32 * qq + f;
-                        a.act_xp[(size_t)blk * 64 * a.N + xp_offset(tok, feat)] = f2bf(sv * uv);
+                        a.act_xp[o_off + (size_t)blk * 64 * a.N + xp_offset(tok, feat)] = f2bf(sv * uv);
                     }
                 }
             }
@@ -166,8 +168,20 @@ __device__ __forceinline__ void mb_epilogue_block(const MbArgs& a, const f32x4* 
 //   (4*NT KiB) sit in an LDS double buffer; per stage and wave: KT x NT MFMAs.  K-parts are summed through LDS in a fixed
 //   order (deterministic) per 64-row block, then the same epilogues as the single-block kernels.
 // ---------------------------------------------------------------------------------------------------------------
-template <int RBV, int NT, int EPI>
+template <int RBV, int NT, int EPI, bool EX = false>
 __global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
+    // EX: every expert of a gathered MoE stage in ONE launch (round 3; one launch per expert before — 16 launches per layer, each
+    // with its own ramp and drain): grid.z = expert x pass, the operands of expert e sit e strides further, and the workgroups of
+    // expert e + 1 start while the last ones of expert e finish.  The argument block stays untouched (a mutable copy of it cost
+    // the dense instantiations their scalar-register residency: Mixtral bs=4 24 -> 35 ms).
+    int zpass = blockIdx.z;
+    size_t w_off = 0, x_off = 0, o_off = 0;
+    const int* nbd = a.nblk_dev;
+    if constexpr (EX) {
+        const int npass = (int)gridDim.z / a.ex_n, e = (int)blockIdx.z / npass;
+        zpass = (int)blockIdx.z - e * npass;
+        w_off = (size_t)e * a.ex_w_stride; x_off = (size_t)e * a.ex_x_stride; o_off = (size_t)e * a.ex_o_stride; nbd += e;
+    }
     constexpr int KP = 8 / RBV, KT = 4 / KP;
     constexpr int FR = 4 * NT;                  // x fragments (1 KiB) per stage
     constexpr int FPW = FR / 8;                 // fragments staged by one wave
@@ -184,8 +198,8 @@ __global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
     }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rb = wave % RBV, kp = wave / RBV;
-    const int blk0 = blockIdx.z * (NT / 2);
-    const int nblk = a.nblk_dev ? __builtin_amdgcn_readfirstlane(*a.nblk_dev) : a.nblk;
+    const int blk0 = zpass * (NT / 2);
+    const int nblk = nbd ? __builtin_amdgcn_readfirstlane(*nbd) : a.nblk;
     if (blk0 >= nblk) return;                   // a pass with no block of this expert: its weights are never read
     const int ksplit = gridDim.y, ks = blockIdx.y;
     const int t0 = (int)(((long)a.K16 * ks) / ksplit), t1 = (int)(((long)a.K16 * (ks + 1)) / ksplit);
@@ -194,7 +208,7 @@ __global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
     const int nstages = (pq + (pr > 0 ? 1 : 0) + KT - 1) / KT;
 
     // ---- weight fragment addressing (16-byte chunks)
-    const bf16x8* __restrict__ wbase = (const bf16x8*)a.wp;
+    const bf16x8* __restrict__ wbase = (const bf16x8*)(a.wp + w_off);
     unsigned woff, wstr;
     int nvalid = 32;
     if (a.planned) {
@@ -208,7 +222,7 @@ __global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
         woff = (unsigned)(((blockIdx.x * RBV + rb) * a.K16 + my_start) * 64 + lane);
     }
     // ---- x fragments staged by this wave: f = wave + 8*i -> (part, k-tile in stage, token block)
-    const bf16x8* __restrict__ xbase = (const bf16x8*)a.xp;
+    const bf16x8* __restrict__ xbase = (const bf16x8*)(a.xp + x_off);
     int xpart_start[FPW], xpart_cnt[FPW], xj[FPW];
     unsigned xconst[FPW];
 #pragma unroll
@@ -322,7 +336,7 @@ __global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
                 red4[(((kp * RBV + rb) * 2 + tb) * 4 + i4) * 64 + lane] = w4;
             }
         __syncthreads();
-        mb_epilogue_block<RBV, EPI, KP>(a, red4, blk, ks, wave, lane);
+        mb_epilogue_block<RBV, EPI, KP>(a, red4, blk, ks, wave, lane, o_off);
     }
 }
 
@@ -1605,6 +1619,8 @@ int lk_mb_init() {
     if (e == hipSuccess) e = set_lds(k_gemm_mb<4, NT, MB_LOGITS>, mb_lds(NT));
     SETALL(2) SETALL(4) SETALL(8)
 #undef SETALL
+    if (e == hipSuccess) e = set_lds(k_gemm_mb<2, 4, MB_SLAB, true>, mb_lds(4));
+    if (e == hipSuccess) e = set_lds(k_gemm_mb<4, 4, MB_SWIGLU, true>, mb_lds(4));
 #define SETW4(T) \
     if (e == hipSuccess) e = set_lds(k_gemm_wide<8, T, MB_SWIGLU>, WideGeom<8, T>::LDS); \
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_SWIGLU>, WideGeom<4, T>::LDS); \
@@ -1702,6 +1718,12 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
     if (a.nblk_dev) {
         // gathered expert: the block count is a device value (typically 1-2 of the step's nblk): passes of two blocks, a pass
         // past the expert's count returns before it touches the weights
+        if constexpr (EPI == MB_SLAB || EPI == MB_SWIGLU) {
+            if (a.ex_n > 1) {
+                k_gemm_mb<RBV, 4, EPI, true><<<dim3(n_wg, ksplit, (nblk + 1) / 2 * a.ex_n), 512, mb_lds(4), st>>>(a);
+                LAUNCH_CHECK(); return 0;
+            }
+        }
         k_gemm_mb<RBV, 4, EPI><<<dim3(n_wg, ksplit, (nblk + 1) / 2), 512, mb_lds(4), st>>>(a);
         LAUNCH_CHECK(); return 0;
     }
@@ -1811,6 +1833,8 @@ int lk_mb_gemm(hipStream_t st, int kind, const MbGemm& g) {
     MbArgs a{};
     a.wp = (const bf16_t*)g.wp; a.xp = (const bf16_t*)g.xp; a.K16 = g.K / 16; a.N = g.N; a.M = g.slab_rows; a.nblk = g.nblk;
     a.route_col = g.route_col; a.route_rows = g.nblk * 64; a.nblk_dev = g.nblk_dev;
+    a.ex_n = g.ex_n; a.ex_w_stride = g.ex_w_stride; a.ex_x_stride = g.ex_x_stride; a.ex_o_stride = g.ex_o_stride;
+    if (g.ex_n > 1 && (!g.nblk_dev || (kind != 0 && kind != 1))) return -1;
     if (kind == 0) {
         if (g.N % 64) return -1;
         a.planned = 0; a.slabs = g.slabs;
