@@ -370,3 +370,83 @@ def test_incremental_mirror_equals_a_fresh_export_after_every_update():
                 got = _walk(img['tok'], img['fo'], img['fi'][p * img['cap']:(p + 1) * img['cap']], img['cstart'], img['ccount'])
                 assert got == snapshot(idx), (step, idx)
     assert kinds['patch'] > 80 and kinds['full'] >= 1, kinds
+
+
+def test_mirror_ccap_discard_and_stream_buffer_for_device_side_updates():
+    """Host side of the device-side trie update (la_trie_stream_put_dev): block capacities cover their blocks and leave room to grow
+    after a rebuild, blocks never overlap, the hold-back buffers read back as stream_put left them (== the oracle's _output_ids), and
+    la_cache_mirror_discard drops exactly the words a replayed stream_put logged (the next patch is empty, a later update patches
+    on top of the discarded ones: the numpy image that skipped the discarded patch is stale exactly at the records they touched)."""
+    import ctypes as C
+    from oracle.trie_oracle import TrieOracle
+    from painlessinferenceacceleration_amd import _lib
+    from painlessinferenceacceleration_amd._lib import check, lib
+    rs = random.Random(5)
+    native, oracle = LookaheadCache(eos_ids=[2]), TrieOracle(eos_ids=[2])
+    planes = np.asarray([0, 1], dtype=np.int32)
+    check(lib.la_cache_mirror_enable(native._h, planes.ctypes.data_as(_lib.pi32), 2))
+    for _ in range(30):
+        s = [rs.randrange(3, 40) for _ in range(rs.randint(4, 30))]
+        for c in (native, oracle):
+            c.put(s, branch_length=9, mode='output', idx=-1)
+    n, full, ni, nd = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+
+    def state():
+        check(lib.la_cache_mirror_state(native._h, C.byref(n), C.byref(full), C.byref(ni), C.byref(nd)))
+        return n.value, full.value, ni.value, nd.value
+
+    def image():
+        k = state()[0]
+        tok, cs, cc, cap = (np.zeros(k, np.int32) for _ in range(4))
+        fo, fi = np.zeros(k, np.float64), np.zeros(2 * k, np.float64)
+        pd = C.POINTER(C.c_double)
+        check(lib.la_cache_mirror_image(native._h, k, tok.ctypes.data_as(_lib.pi32), fo.ctypes.data_as(pd), fi.ctypes.data_as(pd),
+                                        cs.ctypes.data_as(_lib.pi32), cc.ctypes.data_as(_lib.pi32)))
+        check(lib.la_cache_mirror_ccap(native._h, k, cap.ctypes.data_as(_lib.pi32)))
+        return k, tok, cs, cc, cap, fo
+
+    def check_blocks(k, cs, cc, cap):
+        spans = []
+        stack = [0]
+        while stack:
+            u = stack.pop()
+            assert 0 <= cc[u] <= cap[u]
+            if cap[u]:
+                assert 0 < cs[u] and cs[u] + cap[u] <= k
+                spans.append((int(cs[u]), int(cs[u] + cap[u])))
+            stack.extend(range(cs[u], cs[u] + cc[u]))
+        spans.sort()
+        assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])), 'child blocks overlap'
+        return len(spans)
+
+    k, tok, cs, cc, cap, fo = image()
+    assert check_blocks(k, cs, cc, cap) > 50
+    assert all(cap[u] >= cc[u] + 1 for u in range(k) if cc[u] > 0)          # a rebuilt block leaves room to grow (count / 4, >= 1)
+    assert lib.la_cache_mirror_ccap(native._h, k - 1, cap.ctypes.data_as(_lib.pi32)) == -2                    # LA_E_RANGE
+    # hold-back buffers
+    for idx in (0, 1):
+        held = [rs.randrange(3, 40) for _ in range(5 + idx)]
+        for c in (native, oracle):
+            c.stream_put(held, branch_length=9, final=False, idx=idx)
+    for idx in (0, 1, 7):
+        buf, m = np.zeros(64, np.int32), C.c_int32()
+        check(lib.la_cache_stream_buffer(native._h, idx, 64, buf.ctypes.data_as(_lib.pi32), C.byref(m)))
+        assert buf[:m.value].tolist() == [int(x) for x in oracle.pending.get(idx, [])]
+    assert lib.la_cache_stream_buffer(native._h, 0, 2, buf.ctypes.data_as(_lib.pi32), C.byref(m)) == -2 and m.value == 5
+    # a replayed update: logged words are dropped, the record count follows
+    image()                                                          # sync point: log empty
+    assert state()[2:] == (0, 0)
+    toks = [rs.randrange(3, 40) for _ in range(20)]
+    native.stream_put(toks, branch_length=9, final=False, idx=0)
+    k1, _, ni1, nd1 = state()
+    assert ni1 > 0 and nd1 > 0 and k1 > k
+    nrec = C.c_int32()
+    check(lib.la_cache_mirror_discard(native._h, C.byref(nrec)))
+    assert nrec.value == k1 and state()[2:] == (0, 0)
+    native.put([rs.randrange(3, 40) for _ in range(12)], branch_length=9, mode='input', idx=1)
+    assert state()[2] > 0                                            # later host updates patch on top
+    k2, tok2, cs2, cc2, cap2, fo2 = image()
+    assert check_blocks(k2, cs2, cc2, cap2) > 50
+    # deletions (fresh / squeeze / load) make the mirror stale: discard refuses (the device image can no longer be the host's)
+    native.fresh()
+    assert lib.la_cache_mirror_discard(native._h, None) == -4        # LA_E_STATE
