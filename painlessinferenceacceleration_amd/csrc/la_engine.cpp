@@ -671,6 +671,12 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk, bool wide = fals
                 if (gathered) d.nblk_dev = m->mb_moe_cnt + LA_MOE_MAX_E + e; else d.route_col = route_w + e;
                 KCHK(lk_mb_gemm(st, 0, d));
             }
+            if (!g_la_ex_split) {
+                // accumulation in expert order + residual + next RMSNorm in one launch (the accumulated row stays in registers)
+                KCHK(lk_mb_moe_accum_norm(st, m->mb_slabs_ex, (long)slab_stride, m->down_ks, npass_rows, route_w, c.n_experts, c.hidden, M,
+                                          gathered ? m->mb_moe_pos : nullptr, m->mb_h, nw, c.rms_eps, m->mb_xp, cf));
+                continue;
+            }
             KCHK(lk_mb_moe_accum(st, m->mb_slabs_ex, (long)slab_stride, m->down_ks, npass_rows, route_w, c.n_experts, c.hidden,
                                  m->mb_moe_acc, M, gathered ? m->mb_moe_pos : nullptr));
             KCHK(lk_mb_resid_norm_addend(st, m->mb_h, m->mb_moe_acc, nw, c.hidden, c.rms_eps, m->mb_xp, M, cf));

@@ -47,6 +47,8 @@ int lk_mb_gemm(hipStream_t st, int kind, const MbGemm& g);
 int lk_mb_resid_norm_router(hipStream_t st, void* h, const float* slabs, int n_slabs, int slab_rows, const void* nw, int hidden, float eps,
                             void* xp, int M, int cast_first, const void* wrouter, int n_experts, int top_k, float* route_w, const int* meta);
 int lk_mb_resid_norm_addend(hipStream_t st, void* h, const void* addend, const void* nw, int hidden, float eps, void* xp, int M, int cast_first);
+int lk_mb_moe_accum_norm(hipStream_t st, const float* slabs0, long slab_stride, int n_slabs, int slab_rows, const float* route_w, int E,
+                         int hidden, int M, const int* pos, void* h, const void* nw, float eps, void* xp, int cast_first);
 int lk_mb_moe_accum(hipStream_t st, const float* slabs0, long slab_stride, int n_slabs, int slab_rows, const float* route_w, int E, int hidden,
                     void* acc, int M, const int* pos);
 // gathered MoE: perm [E][LA_MB_MAX*64], pos [M][LA_MOE_MAX_E], cnt_nb [2][LA_MOE_MAX_E] = {rows, 64-row blocks} per expert

@@ -1040,6 +1040,88 @@ __global__ __launch_bounds__(512) void k_moe_gather_mb(const bf16_t* __restrict_
     }
 }
 
+// k_moe_accum_mb + k_row_norm_addend_mb in ONE launch (round 3): the row's accumulated expert outputs never leave the registers
+// on their way into the residual add and the next RMSNorm.  Same values at every rounding point: the accumulator is bf16-exact
+// after every add (index_add_ into a bf16 buffer), so "store as bf16, load as bf16" between the two kernels was the identity.
+template <int NS>
+__global__ __launch_bounds__(512) void k_moe_accum_norm_mb(const float* __restrict__ slabs, long ex_slab, int slab_rows,
+                                                            const float* __restrict__ route_w, int n_experts, int hidden,
+                                                            const int* __restrict__ pos, bf16_t* __restrict__ h,
+                                                            const bf16_t* __restrict__ nw, float eps, bf16_t* __restrict__ xp, int cast_first) {
+    __shared__ float sh[8];
+    const int t = blockIdx.x;
+    const int nchunk = hidden >> 3;
+    int sel[4], srow[4];
+    float wsel[4];
+    int ns = 0;
+    for (int e = 0; e < n_experts && ns < 4; ++e) {
+        const float w = route_w[(size_t)t * LA_MOE_MAX_E + e];
+        if (w != 0.f) { sel[ns] = e; wsel[ns] = w; srow[ns] = pos ? pos[(size_t)t * LA_MOE_MAX_E + e] : t; ++ns; }
+    }
+    for (int k = ns; k < 4; ++k) { sel[k] = 0; wsel[k] = 0.f; srow[k] = 0; }
+    float vals[2][8];
+    bf16x8 wv[2];
+    float ss = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 512;
+        if (c < nchunk) {
+            const bf16x8 hv = *(const bf16x8*)(h + (size_t)t * hidden + c * 8);
+            wv[ci] = *(const bf16x8*)(nw + c * 8);
+            float cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < ns) {
+                    f32x4 v[NS][2];
+#pragma unroll
+                    for (int s2 = 0; s2 < NS; ++s2) {
+                        const float* sp = slabs + (size_t)sel[k] * ex_slab + ((size_t)s2 * slab_rows + srow[k]) * hidden + c * 8;
+                        v[s2][0] = *(const f32x4*)sp;
+                        v[s2][1] = *(const f32x4*)(sp + 4);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float add = 0.f;
+#pragma unroll
+                        for (int s2 = 0; s2 < NS; ++s2) add += v[s2][j >> 2][j & 3];
+                        const float contrib = bfr(bfr(add) * wsel[k]);
+                        cur[j] = k ? bfr(cur[j] + contrib) : contrib;
+                    }
+                }
+            bf16x8 ho;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = bfr(bf2f((bf16_t)hv[j]) + cur[j]);
+                vals[ci][j] = v;
+                ho[j] = (short)f2bf(v);
+                ss += v * v;
+            }
+            *(bf16x8*)(h + (size_t)t * hidden + c * 8) = ho;
+        }
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tot += sh[i];
+    const float rs = 1.0f / sqrtf(tot / (float)hidden + eps);
+    bf16_t* xo_base = xp + (size_t)(t >> 6) * 64 * hidden;
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 512;
+        if (c < nchunk) {
+            bf16x8 xo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float nv = cast_first ? bfr(vals[ci][j] * rs) : vals[ci][j] * rs;
+                xo[j] = (short)f2bf(bf2f((bf16_t)wv[ci][j]) * nv);
+            }
+            *(bf16x8*)(xo_base + xp_offset(t & 63, c * 8)) = xo;
+        }
+    }
+}
+
 template <int NS>
 __global__ __launch_bounds__(256) void k_moe_accum_mb(const float* __restrict__ slabs, long ex_slab, int slab_rows,
                                                        const float* __restrict__ route_w, int n_experts, int hidden,
@@ -1703,6 +1785,19 @@ int lk_mb_moe_accum(hipStream_t st, const float* slabs0, long slab_stride, int n
                     void* acc, int M, const int* pos) {
     if (hidden & 7) return -1;
 #define MA(NS) k_moe_accum_mb<NS><<<M, 256, 0, st>>>(slabs0, slab_stride, slab_rows, route_w, E, hidden, (bf16_t*)acc, pos)
+    switch (n_slabs) {
+        case 1: MA(1); break; case 2: MA(2); break; case 4: MA(4); break; case 8: MA(8); break;
+        default: return -1;
+    }
+#undef MA
+    LAUNCH_CHECK(); return 0;
+}
+
+int lk_mb_moe_accum_norm(hipStream_t st, const float* slabs0, long slab_stride, int n_slabs, int slab_rows, const float* route_w, int E,
+                         int hidden, int M, const int* pos, void* h, const void* nw, float eps, void* xp, int cast_first) {
+    if (hidden > 8192 || (hidden & 7)) return -1;
+#define MA(NS) k_moe_accum_norm_mb<NS><<<M, 512, 0, st>>>(slabs0, slab_stride, slab_rows, route_w, E, hidden, pos, (bf16_t*)h, \
+                                                           (const bf16_t*)nw, eps, (bf16_t*)xp, cast_first)
     switch (n_slabs) {
         case 1: MA(1); break; case 2: MA(2); break; case 4: MA(4); break; case 8: MA(8); break;
         default: return -1;
