@@ -62,7 +62,8 @@ const char*  la_last_error(void);
  *        Keys 7-10 are read when a step graph is captured (la_llama_step captures again after a change).
  * key 11: the single-sequence step captured n (1..8) times into one graph (measurement of the per-launch cost: none found).
  * key 16: 1 = the gathered multi-block MoE step launches every expert's GEMMs separately and accumulates / normalises in two row
- *         kernels (default 0: one launch per stage, one fused row kernel).
+ *         kernels (default 0: one launch per stage, one fused row kernel); 2 = an expert's last single block keeps the padded
+ *         two-block pass (default: the one-block body).
  * key 12: multi-block slab GEMMs with 2 K splits over 4 token groups at >= 5 blocks (measured slower; read at graph capture). */
 int          la_debug_set(int key, int value);
 int          la_debug_get(int key);          /* current value of a knob (the library default unless la_debug_set changed it) */

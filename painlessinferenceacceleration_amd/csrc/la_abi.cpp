@@ -54,7 +54,7 @@ int la_debug_set(int key, int value) {
     if (key == 13 && value >= 0) { g_la_stop_layers = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 14 && value >= 0 && value <= 1) { g_la_split_head_tail = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 15 && value >= 0 && value <= 7) { g_la_gemm_4w = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 16 && value >= 0 && value <= 1) { g_la_ex_split = value; ++g_la_graph_epoch; return LA_OK; }
+    if (key == 16 && value >= 0 && value <= 3) { g_la_ex_split = value; ++g_la_graph_epoch; return LA_OK; }
     return LA_E_ARG;
 }
 int la_debug_get(int key) {

@@ -649,7 +649,7 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk, bool wide = fals
                 KCHK(lk_mb_moe_plan(st, route_w, M, c.n_experts, m->mb_moe_perm, m->mb_moe_pos, m->mb_moe_cnt));
                 KCHK(lk_mb_moe_gather(st, m->mb_xp, m->mb_moe_perm, m->mb_moe_cnt, c.hidden, nblk, c.n_experts, m->mb_xg, xg_stride));
             }
-            if (gathered && m->ex_merged && !g_la_ex_split) {
+            if (gathered && m->ex_merged && !(g_la_ex_split & 1)) {
                 // equally spaced expert images: ONE gate/up launch and ONE down launch for all experts (grid.z = expert x pass)
                 MbGemm g{}; g.wp = m->ex_gateup[(size_t)l * c.n_experts]; g.xp = m->mb_xg; g.N = c.ffn; g.K = c.hidden; g.nblk = nblk;
                 g.n_wg = c.balanced_wg[1]; g.ksplit = 1; g.act_xp = m->mb_act_ex; g.nblk_dev = m->mb_moe_cnt + LA_MOE_MAX_E;
@@ -671,7 +671,7 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk, bool wide = fals
                 if (gathered) d.nblk_dev = m->mb_moe_cnt + LA_MOE_MAX_E + e; else d.route_col = route_w + e;
                 KCHK(lk_mb_gemm(st, 0, d));
             }
-            if (!g_la_ex_split) {
+            if (!(g_la_ex_split & 1)) {
                 // accumulation in expert order + residual + next RMSNorm in one launch (the accumulated row stays in registers)
                 KCHK(lk_mb_moe_accum_norm(st, m->mb_slabs_ex, (long)slab_stride, m->down_ks, npass_rows, route_w, c.n_experts, c.hidden, M,
                                           gathered ? m->mb_moe_pos : nullptr, m->mb_h, nw, c.rms_eps, m->mb_xp, cf));

@@ -20,6 +20,7 @@
 
 enum { MB_SLAB = 0, MB_SWIGLU = 1, MB_QKV = 2, MB_LOGITS = 3 };
 
+extern int g_la_ex_split;       // la_debug_set key 16 (la_engine.cpp)
 struct MbArgs {
     const bf16_t* wp;
     const bf16_t* xp;
@@ -45,6 +46,7 @@ struct MbArgs {
     const int* nblk_dev;
     // ... for ALL experts of a stage in one launch (ex_n > 1): grid.z = expert x pass; operands of expert e at e * stride
     int ex_n; long ex_w_stride, ex_x_stride, ex_o_stride;
+    int ex_pad;              // measurement (la_debug_set(16, 2)): keep the padded two-block pass for an expert's last single block
     // paired form of the wide kernel (launch_mb): the weight rows of a workgroup are read by a second workgroup working on the other
     // token blocks (same XCD): stream them with the default cache policy so that the second reader finds them in L2
     int w_keep;
@@ -168,20 +170,10 @@ __device__ __forceinline__ void mb_epilogue_block(const MbArgs& a, const f32x4* 
 //   (4*NT KiB) sit in an LDS double buffer; per stage and wave: KT x NT MFMAs.  K-parts are summed through LDS in a fixed
 //   order (deterministic) per 64-row block, then the same epilogues as the single-block kernels.
 // ---------------------------------------------------------------------------------------------------------------
-template <int RBV, int NT, int EPI, bool EX = false>
-__global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
-    // EX: every expert of a gathered MoE stage in ONE launch (round 3; one launch per expert before — 16 launches per layer, each
-    // with its own ramp and drain): grid.z = expert x pass, the operands of expert e sit e strides further, and the workgroups of
-    // expert e + 1 start while the last ones of expert e finish.  The argument block stays untouched (a mutable copy of it cost
-    // the dense instantiations their scalar-register residency: Mixtral bs=4 24 -> 35 ms).
-    int zpass = blockIdx.z;
-    size_t w_off = 0, x_off = 0, o_off = 0;
-    const int* nbd = a.nblk_dev;
-    if constexpr (EX) {
-        const int npass = (int)gridDim.z / a.ex_n, e = (int)blockIdx.z / npass;
-        zpass = (int)blockIdx.z - e * npass;
-        w_off = (size_t)e * a.ex_w_stride; x_off = (size_t)e * a.ex_x_stride; o_off = (size_t)e * a.ex_o_stride; nbd += e;
-    }
+// body of k_gemm_mb for the NT / 2 blocks blk0 .. of a pass (nblk = the blocks that exist; operands offset for the merged-expert form)
+template <int RBV, int NT, int EPI>
+__device__ __forceinline__ void gemm_mb_body(const MbArgs& a, const int blk0, const int nblk, const size_t w_off, const size_t x_off,
+                                             const size_t o_off) {
     constexpr int KP = 8 / RBV, KT = 4 / KP;
     constexpr int FR = 4 * NT;                  // x fragments (1 KiB) per stage
     constexpr int FPW = FR / 8;                 // fragments staged by one wave
@@ -191,16 +183,8 @@ __global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     bf16x8* xs = (bf16x8*)lds_raw;              // [2 stages][FR][64 lanes]
     const int lane = threadIdx.x & 63;
-    if (a.route_col) {                          // every wave scans all rows: a uniform decision without a barrier
-        bool any = false;
-        for (int t = lane; t < a.route_rows; t += 64) any |= a.route_col[(size_t)t * LA_MOE_MAX_E] != 0.f;
-        if (__ballot(any) == 0ull) return;
-    }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rb = wave % RBV, kp = wave / RBV;
-    const int blk0 = zpass * (NT / 2);
-    const int nblk = nbd ? __builtin_amdgcn_readfirstlane(*nbd) : a.nblk;
-    if (blk0 >= nblk) return;                   // a pass with no block of this expert: its weights are never read
     const int ksplit = gridDim.y, ks = blockIdx.y;
     const int t0 = (int)(((long)a.K16 * ks) / ksplit), t1 = (int)(((long)a.K16 * (ks + 1)) / ksplit);
     const int twg = t1 - t0, pq = twg / KP, pr = twg - pq * KP;
@@ -338,6 +322,37 @@ __global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
         __syncthreads();
         mb_epilogue_block<RBV, EPI, KP>(a, red4, blk, ks, wave, lane, o_off);
     }
+}
+
+template <int RBV, int NT, int EPI, bool EX = false>
+__global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
+    // EX: every expert of a gathered MoE stage in ONE launch (round 3; one launch per expert before — 16 launches per layer, each
+    // with its own ramp and drain): grid.z = expert x pass, the operands of expert e sit e strides further, and the workgroups of
+    // expert e + 1 start while the last ones of expert e finish.  The argument block stays untouched (a mutable copy of it cost
+    // the dense instantiations their scalar-register residency: Mixtral bs=4 24 -> 35 ms).
+    int zpass = blockIdx.z;
+    size_t w_off = 0, x_off = 0, o_off = 0;
+    const int* nbd = a.nblk_dev;
+    if constexpr (EX) {
+        const int npass = (int)gridDim.z / a.ex_n, e = (int)blockIdx.z / npass;
+        zpass = (int)blockIdx.z - e * npass;
+        w_off = (size_t)e * a.ex_w_stride; x_off = (size_t)e * a.ex_x_stride; o_off = (size_t)e * a.ex_o_stride; nbd += e;
+    }
+    if (a.route_col) {                          // every wave scans all rows: a uniform decision without a barrier
+        const int lane = threadIdx.x & 63;
+        bool any = false;
+        for (int t = lane; t < a.route_rows; t += 64) any |= a.route_col[(size_t)t * LA_MOE_MAX_E] != 0.f;
+        if (__ballot(any) == 0ull) return;
+    }
+    const int blk0 = zpass * (NT / 2);
+    const int nblk = nbd ? __builtin_amdgcn_readfirstlane(*nbd) : a.nblk;
+    if (blk0 >= nblk) return;                   // a pass with no block of this expert: its weights are never read
+    if constexpr (EX && NT == 4) {
+        // the LAST block of an expert alone in a two-block pass (about half the experts of a 256-row Mixtral step hold <= 64 rows):
+        // the one-block body — half the x traffic, LDS stores and MFMAs of the padded pass
+        if (nblk - blk0 == 1 && !a.ex_pad) { gemm_mb_body<RBV, 2, EPI>(a, blk0, nblk, w_off, x_off, o_off); return; }
+    }
+    gemm_mb_body<RBV, NT, EPI>(a, blk0, nblk, w_off, x_off, o_off);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1929,6 +1944,7 @@ int lk_mb_gemm(hipStream_t st, int kind, const MbGemm& g) {
     a.wp = (const bf16_t*)g.wp; a.xp = (const bf16_t*)g.xp; a.K16 = g.K / 16; a.N = g.N; a.M = g.slab_rows; a.nblk = g.nblk;
     a.route_col = g.route_col; a.route_rows = g.nblk * 64; a.nblk_dev = g.nblk_dev;
     a.ex_n = g.ex_n; a.ex_w_stride = g.ex_w_stride; a.ex_x_stride = g.ex_x_stride; a.ex_o_stride = g.ex_o_stride;
+    a.ex_pad = (g_la_ex_split >> 1) & 1;
     if (g.ex_n > 1 && (!g.nblk_dev || (kind != 0 && kind != 1))) return -1;
     if (kind == 0) {
         if (g.N % 64) return -1;
