@@ -67,6 +67,7 @@ class DeviceTrie(object):
             self._put_idx_list = None
             self._eos_list = self._stopw_list = None
             self.stats_put = {'calls': 0, 'replays': 0}
+        self._unreplayed = 0
         arr = np.asarray(self.idxs, dtype=np.int32)
         check(lib.la_cache_mirror_enable(cache._h, arr.ctypes.data_as(_lib.pi32), len(self.idxs)), 'mirror_enable')
         self.cap = 0
@@ -138,6 +139,10 @@ class DeviceTrie(object):
         """Bring the device image up to date with the host trie (patch, or full image when due).  Enqueued on the current
         stream; returns the kind of sync that happened."""
         self._check_owner()
+        if getattr(self, '_unreplayed', 0):
+            # the device applied updates the host trie has not repeated yet: a host image / patch computed now would number its
+            # records differently from the device's
+            raise RuntimeError('DeviceTrie.sync(): replay() the updates queued with stream_put_dev() first')
         self._staging_free()
         n, full, ni, nd = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         check(lib.la_cache_mirror_state(self.cache._h, C.byref(n), C.byref(full), C.byref(ni), C.byref(nd)), 'mirror_state')
@@ -264,6 +269,7 @@ class DeviceTrie(object):
                                          len(idxs), int(branch_length), stop_dev.data_ptr(), n_stop, eos_dev.data_ptr(), n_eos,
                                          self._items.data_ptr()), 'trie_stream_put_dev')
         self.stats_put['calls'] += 1
+        self._unreplayed += 1
 
     def replay(self, puts, branch_length):
         """Repeat on the host trie what stream_put_dev() did on the device: puts = [(idx, tokens)] in the order of that call.  The
@@ -276,6 +282,7 @@ class DeviceTrie(object):
         for idx, toks in puts:
             self.cache.stream_put([int(t) for t in toks if t != -1], branch_length=branch_length, final=False, mode='output', idx=int(idx))
         self.stats_put['replays'] += 1
+        self._unreplayed = 0
         rc = lib.la_cache_mirror_discard(self.cache._h, C.byref(n_pending))
         if rc != 0:
             return False

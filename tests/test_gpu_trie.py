@@ -144,8 +144,9 @@ def test_batch_loop_with_device_trie_equals_host_trie_loop():
     B, P = 4, 24
     prompts = rs.randint(3, shape.vocab, size=(B, P))
     outs = []
-    for use_dev, dev_update in ((False, False), (True, False), (True, True)):
-        model = BatchLlama(shape, dict(sd), max_length=256, max_batch=B, eos_token_id=2)
+    # (the last configuration runs the 4 samples as two passes of 2 blocks: two device updates per step, replayed in batch order)
+    for use_dev, dev_update, mblocks in ((False, False, None), (True, False, None), (True, True, None), (True, True, 2)):
+        model = BatchLlama(shape, dict(sd), max_length=256, max_batch=B, eos_token_id=2, max_blocks=mblocks)
         truth = model.greedy_search(torch.from_numpy(prompts), P + 100, eos_token_id=None)[:, P:].tolist()
         model.lookahead_cache = LookaheadCache(eos_ids=[2])
         for b in range(B):
@@ -169,7 +170,7 @@ def test_batch_loop_with_device_trie_equals_host_trie_loop():
             torch.cuda.synchronize()
             assert int(dt.meta.cpu()[1]) == 0 and int(dt.meta.cpu()[3]) > 100
         outs.append(runs)
-    assert outs[0] == outs[1] == outs[2]
+    assert outs[0] == outs[1] == outs[2] == outs[3]
     assert max(outs[0][0][1]) > 16          # per-sample budget: trees larger than the reference's (64 // 4) // 4 rows
 
 
