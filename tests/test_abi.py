@@ -61,7 +61,8 @@ def test_rowplan_covers_every_row_exactly_once():
     import numpy as np
     lib = _lib.lib
     for kind, n_rows, nwg in [(0, 32000, 256), (1, 11008, 256), (2, 12288, 256), (1, 13824, 256), (2, 15360, 256),
-                              (0, 1000, 8), (1, 688, 16), (2, 5 * 128, 16)]:
+                              (0, 1000, 8), (1, 688, 16), (2, 5 * 128, 16),
+                              (2, 6144, 96), (2, 6144, 128)]:      # the multi-block step's second QKV image (Mistral: 96 x 32 pairs)
         n = lib.la_rowplan(kind, n_rows, nwg, None)
         assert n > 0 and n % 32 == 0
         plan = np.zeros(n, dtype=np.int32)
