@@ -604,7 +604,9 @@ class LlamaVerifyEngine(object):
             if ev is None:
                 ev = self._hdr_event = torch.cuda.Event()
             ev.record(self.stream)                      # behind the D2H of the result header
-            mo = self.mout().data_ptr()
+            mo = getattr(self, '_mout_ptr', None)
+            if mo is None:
+                mo = self._mout_ptr = self.mout().data_ptr()
             with torch.cuda.stream(self.stream):
                 dev_trie.stream_put_dev(mo + 4 * _lib.LA_MOUT_OUTTOK, _lib.LA_MOUT_TOKS, mo + 4 * _lib.LA_MOUT_NOUT, put_idxs,
                                         put_branch_length)
