@@ -182,6 +182,15 @@ int la_trie_hier_get_dev2(void* stream, const int32_t* d_tok, const double* d_fo
                           int decoding_length, int branch_length, int min_in, int min_out, int mode, const int32_t* d_stop,
                           int n_stop, int32_t* d_scratch_q, double* d_scratch_v, int32_t* d_out_ids, uint64_t* d_out_rowmask,
                           int32_t* d_out_n, int32_t* d_out_sizes, int32_t* d_out_nsizes);
+/* one_get on the device mirror (LookaheadCache.one_get, lookahead_cache.py:490-517 with Tree.get_one_branch :171-222): one wavefront
+ * per query, the single most frequent chain (<= branch_length tokens behind the root token) with lower-triangular row masks; the
+ * same buffers and per-query plane / branch length as la_trie_hier_get_dev2 (d_out_sizes[b][0] = the chain length when
+ * d_out_nsizes[b] == 1).  Bit-identical to la_cache_one_get. */
+int la_trie_one_get_dev2(void* stream, const int32_t* d_tok, const double* d_fo, const double* d_fi, int64_t fi_stride,
+                         const int32_t* d_cstart, const int32_t* d_ccount, int32_t n_records, const int32_t* d_queries /*[B][8]*/,
+                         const int32_t* d_nq, const int32_t* d_plane, const int32_t* d_branch_length /*[B] or NULL*/, int B,
+                         int decoding_length, int branch_length, int mode, const int32_t* d_stop, int n_stop, int32_t* d_out_ids,
+                         uint64_t* d_out_rowmask, int32_t* d_out_n, int32_t* d_out_sizes, int32_t* d_out_nsizes);
 /* Device-side retrieval.  la_cache_export snapshots the forest for one input slot `idx` into host arrays (call with
  * cap = 0 to get *n_nodes): live nodes renumbered breadth-first, children of node u = ids [cstart[u], cstart[u]+ccount[u])
  * in dict insertion order, node 0 = super-root over the per-token trees.  la_trie_hier_get_dev runs hier_get

@@ -191,6 +191,7 @@ PROTOTYPES = {
     "la_cache_mirror_image": (i32, vp, i32, pi32, C.POINTER(C.c_double), C.POINTER(C.c_double), pi32, pi32),
     "la_cache_mirror_patch": (i32, vp, pi32, pi32, C.POINTER(C.c_double)),
     "la_trie_patch_dev": (i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, vp, vp, i32),
+    "la_trie_one_get_dev2": (i32, vp, vp, vp, vp, i64, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp),
     "la_cache_mirror_ccap": (i32, vp, i32, pi32),
     "la_cache_mirror_discard": (i32, vp, pi32),
     "la_cache_stream_buffer": (i32, vp, i32, i32, pi32, pi32),

@@ -237,6 +237,19 @@ int la_trie_patch_dev(void* stream, int32_t* d_tok, double* d_fo, double* d_fi, 
                        d_dval, n_d));
 }
 
+int la_trie_one_get_dev2(void* stream, const int32_t* d_tok, const double* d_fo, const double* d_fi, int64_t fi_stride,
+                         const int32_t* d_cstart, const int32_t* d_ccount, int32_t n_records, const int32_t* d_queries,
+                         const int32_t* d_nq, const int32_t* d_plane, const int32_t* d_branch_length, int B, int decoding_length,
+                         int branch_length, int mode, const int32_t* d_stop, int n_stop, int32_t* d_out_ids, uint64_t* d_out_rowmask,
+                         int32_t* d_out_n, int32_t* d_out_sizes, int32_t* d_out_nsizes) {
+    if (!d_tok || !d_fo || !d_fi || !d_cstart || !d_ccount || n_records < 1 || !d_queries || !d_nq || B < 1 || !d_out_ids ||
+        !d_out_rowmask || !d_out_n || !d_out_sizes || !d_out_nsizes || mode < 0 || mode > 2 || (n_stop > 0 && !d_stop)) return LA_E_ARG;
+    if (branch_length + 1 > LA_TREE_MAX) { la_set_error("device one_get: branch_length + 1 <= 64"); return LA_E_RANGE; }
+    WRAP(lk_trie_one_get2((hipStream_t)stream, d_tok, d_fo, d_fi, (long)fi_stride, d_cstart, d_ccount, n_records, d_queries, d_nq,
+                          d_plane, d_branch_length, B, decoding_length, branch_length, mode, d_stop, n_stop, d_out_ids,
+                          d_out_rowmask, d_out_n, d_out_sizes, d_out_nsizes));
+}
+
 static int trie_image_ok(const la_trie_image* g) {
     return g && g->tok && g->fo && g->cstart && g->ccount && g->ccap && g->meta && g->cap > 0 && g->n_planes >= 0 &&
            (g->n_planes == 0 || g->fi) && g->n_root_of >= 0 && (g->n_root_of == 0 || g->root_of);

@@ -104,6 +104,10 @@ int lk_trie_hier_get(hipStream_t st, const int* tok, const double* fo, const dou
                      int* out_ids, uint64_t* out_rowmask, int* out_n, int* out_sizes, int* out_nsizes);
 int lk_trie_patch(hipStream_t st, int* tok, double* fo, double* fi, long fi_stride, int* cstart, int* ccount, int* ccap,
                   const int* ipatch, int n_i, const int* dkey, const double* dval, int n_d);
+int lk_trie_one_get2(hipStream_t st, const int* tok, const double* fo, const double* fi, long fi_stride, const int* cstart,
+                     const int* ccount, int n_nodes, const int* queries, const int* nq, const int* plane, const int* bl, int B,
+                     int decoding_length, int branch_length, int mode, const int* stop, int n_stop, int* out_ids,
+                     uint64_t* out_rowmask, int* out_n, int* out_sizes, int* out_nsizes);
 // device-side stream_put (la_trie_dev.hip)
 #define LA_TRIE_OBUF 128
 #define LA_TRIE_ITEMS 40          // start offsets one put can complete = tokens it appends (<= LA_MOUT_TOKS)

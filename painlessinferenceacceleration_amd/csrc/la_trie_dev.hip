@@ -350,6 +350,109 @@ int lk_trie_hier_get(hipStream_t st, const int* tok, const double* fo, const dou
 }
 
 
+// ---- one_get on the device (LookaheadCache.one_get, lookahead_cache.py:490-517, Tree.get_one_branch :171-222): one wavefront per query;
+// prefix match as in hier_get, then per level the child of highest frequency (wave max + lowest lane = the reference's strict
+// "freq > max_freq" scan in insertion order), a single chain of at most branch_length tokens with lower-triangular row masks.
+__global__ __launch_bounds__(64) void k_trie_one_get(TrieQueryArgs a) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    TrieDev t = a.t;
+    if (a.plane) t.fi += (size_t)a.plane[b] * (size_t)a.fi_stride;
+    const int branch_length = a.bl ? a.bl[b] : a.branch_length;
+    const int* q = a.queries + b * 8;
+    const int nq = a.nq[b];
+    int* oid = a.out_ids + b * 64;
+    unsigned long long* orm = a.out_rowmask + b * 64;
+    const int mode = a.mode;
+    auto finish = [&](int n, int s0, int s1, int nsizes) {
+        if (lane < n) orm[lane] = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+        if (lane == 0) { a.out_n[b] = n; a.out_sizes[b * 2] = s0; a.out_sizes[b * 2 + 1] = s1; a.out_nsizes[b] = nsizes; }
+    };
+    if (a.decoding_length <= 1 || branch_length == 0) {                       // :491-492
+        if (nq > 0 && lane == 0) oid[0] = q[nq - 1];
+        finish(nq > 0 ? 1 : 0, 0, 0, 0);
+        return;
+    }
+    bool have = false;
+    int n_out = 0, nsz = 2, len_out = 0;
+    for (int i = 0; i < nq; ++i) {
+        const int root = find_child(t, 0, q[i], lane);
+        if (root < 0) continue;
+        const int nrest = nq - (i + 1);
+        bool is_stop = false;
+        for (int k = 0; k < a.n_stop; ++k) is_stop |= (a.stop[k] == q[i]);
+        if (is_stop && nrest == 0) continue;                                  // :500-501
+        have = true;
+        int cur = root;                                                       // Tree._match (:224-246)
+        for (int k = 0; k < nrest && cur >= 0; ++k) {
+            const int ch = find_child(t, cur, q[i + 1 + k], lane);
+            if (ch < 0) { cur = -1; break; }
+            const double cfi = t.fi[ch], cfo = t.fo[ch];
+            const bool live = mode == LA_MODE_INPUT ? cfi > 0 : mode == LA_MODE_OUTPUT ? cfo > 0 : (cfi > 0 || cfo > 0);
+            cur = live ? ch : -1;
+        }
+        if (cur < 0 || t.ccount[cur] == 0) {                                  // :175-177
+            if (lane == 0) oid[0] = nrest > 0 ? q[nq - 1] : t.tok[root];
+            n_out = 1; nsz = 2; len_out = 0;
+        } else {
+            const int last_tok = nrest > 0 ? q[nq - 1] : 0;
+            if (lane == 0) oid[0] = (nrest > 0 && last_tok != 0) ? last_tok : t.tok[root];
+            n_out = 1;
+            int length = 0;
+            while (length < branch_length) {
+                const int cs = t.cstart[cur], cc = t.ccount[cur];
+                if (cc == 0) break;
+                double best = 0.0;                                            // max_freq = 0.0: a child needs freq > 0 (:186-201)
+                int best_rec = -1;
+                for (int base = 0; base < cc; base += 64) {
+                    const int k = base + lane;
+                    double v = -1.0;
+                    if (k < cc) {
+                        const double cfi = t.fi[cs + k], cfo = t.fo[cs + k];
+                        if (mode == LA_MODE_MIX) {                            // :190-193 (names swapped there): freq = 10000 * freqs[-1] + freqs[idx]
+                            if (cfi > 0 || cfo > 0) v = __dadd_rn(__dmul_rn(10000.0, cfo), cfi);
+                        } else if (mode == LA_MODE_INPUT) { if (cfi > 0) v = cfi; }
+                        else { if (cfo > 0) v = cfo; }
+                    }
+                    double wm = v;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) wm = fmax(wm, __shfl_xor(wm, o, 64));
+                    if (wm > best) {                                          // strict: an equal later child never replaces an earlier one
+                        const unsigned long long m = __ballot(v == wm);
+                        best = wm; best_rec = cs + base + wave_first(m);
+                    }
+                }
+                if (best_rec < 0) break;
+                if (lane == 0) oid[n_out] = t.tok[best_rec];
+                ++n_out; cur = best_rec; ++length;
+            }
+            nsz = 1; len_out = length;
+        }
+        if (n_out >= branch_length / 2) break;                                // :512
+    }
+    if (!have) {
+        if (nq > 0 && lane == 0) oid[0] = q[nq - 1];
+        finish(nq > 0 ? 1 : 0, 0, 0, 2);
+        return;
+    }
+    finish(n_out, len_out, 0, nsz);
+}
+
+int lk_trie_one_get2(hipStream_t st, const int* tok, const double* fo, const double* fi, long fi_stride, const int* cstart,
+                     const int* ccount, int n_nodes, const int* queries, const int* nq, const int* plane, const int* bl, int B,
+                     int decoding_length, int branch_length, int mode, const int* stop, int n_stop, int* out_ids,
+                     uint64_t* out_rowmask, int* out_n, int* out_sizes, int* out_nsizes) {
+    TrieQueryArgs a{};
+    a.t = TrieDev{tok, fo, fi, cstart, ccount, n_nodes};
+    a.plane = plane; a.fi_stride = fi_stride; a.bl = bl;
+    a.queries = queries; a.nq = nq; a.decoding_length = decoding_length; a.branch_length = branch_length;
+    a.mode = mode; a.stop = stop; a.n_stop = n_stop;
+    a.out_ids = out_ids; a.out_rowmask = (unsigned long long*)out_rowmask;
+    a.out_n = out_n; a.out_sizes = out_sizes; a.out_nsizes = out_nsizes;
+    k_trie_one_get<<<B, 64, 0, st>>>(a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 // ---- incremental mirror: apply a patch (la_cache_mirror_patch) to the device image ---------------------------------------
 __global__ void k_trie_patch(int* __restrict__ tok, double* __restrict__ fo, double* __restrict__ fi, long fi_stride,
                              int* __restrict__ cstart, int* __restrict__ ccount, int* __restrict__ ccap, const int* __restrict__ ipatch,

@@ -330,11 +330,48 @@ class DeviceTrie(object):
                                         self.out_sizes.data_ptr(), self.out_nsizes.data_ptr()), 'trie_hier_get_dev2')
         return B
 
-    def hier_get(self, queries, decoding_length=64, branch_length=8, min_input_size=0, min_output_size=0, mode='mix', idxs=None,
-                 branch_lengths=None):
-        """-> list of (ids list, uint64 row masks, sizes list), like LookaheadCache.hier_get per query."""
-        B = self.hier_get_dev(queries, idxs=idxs, branch_lengths=branch_lengths, decoding_length=decoding_length,
-                              branch_length=branch_length, min_input_size=min_input_size, min_output_size=min_output_size, mode=mode)
+    def one_get_dev(self, queries, idxs=None, branch_lengths=None, decoding_length=64, branch_length=8, mode='mix', sync=True):
+        """LookaheadCache.one_get (lookahead_cache.py:490-517) for all queries in one launch: per query the single most frequent
+        chain; results in the same device buffers as hier_get_dev (row masks lower-triangular), so a chained verify step
+        (LlamaVerifyEngine.mstep_trie) can take them as they are."""
+        assert mode in _MODES and int(branch_length) + 1 <= _lib.LA_TREE_MAX
+        B = len(queries)
+        self._check_owner()
+        self._alloc_queries(B)
+        if sync:
+            self.sync()
+        self._staging_free()
+        h = self._hq.numpy()
+        q = h[:B * 8].reshape(B, 8)
+        q[:] = 0
+        for b, toks in enumerate(queries):
+            assert len(toks) <= 8
+            q[b, :len(toks)] = toks
+            h[B * 8 + b] = len(toks)
+            h[B * 9 + b] = self.plane[int(idxs[b])] if idxs is not None else 0
+            h[B * 10 + b] = int(branch_lengths[b]) if branch_lengths is not None else int(branch_length)
+        self._dq[:B * 11].copy_(self._hq[:B * 11], non_blocking=True)
+        self._staging_queued()
+        stop = getattr(self, '_stop_dev', None)
+        if stop is None or self._stop_list != self.stop_words:
+            self._stop_list = list(self.stop_words)
+            self._stop_dev = stop = torch.tensor(self.stop_words or [0], dtype=torch.int32, device=self.device)
+        base = self._dq.data_ptr()
+        check(lib.la_trie_one_get_dev2(self._stream(), self.tok.data_ptr(), self.fo.data_ptr(), self.fi.data_ptr(), self.cap,
+                                       self.cstart.data_ptr(), self.ccount.data_ptr(), self.cap, base, base + 4 * B * 8,
+                                       base + 4 * B * 9, base + 4 * B * 10, B, int(decoding_length), int(branch_length),
+                                       _MODES[mode], stop.data_ptr(), len(self.stop_words), self.out_ids.data_ptr(),
+                                       self.out_rm.data_ptr(), self.out_n.data_ptr(), self.out_sizes.data_ptr(),
+                                       self.out_nsizes.data_ptr()), 'trie_one_get_dev2')
+        return B
+
+    def one_get(self, queries, decoding_length=64, branch_length=8, mode='mix', idxs=None, branch_lengths=None):
+        """-> list of (ids list, uint64 row masks, sizes list), like LookaheadCache.one_get per query (masks packed)."""
+        B = self.one_get_dev(queries, idxs=idxs, branch_lengths=branch_lengths, decoding_length=decoding_length,
+                             branch_length=branch_length, mode=mode)
+        return self._read_results(B)
+
+    def _read_results(self, B):
         self._h_out.copy_(self._out, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
         Q = self._qcap
@@ -345,3 +382,10 @@ class DeviceTrie(object):
         osz = h[Q * 193:Q * 195].reshape(Q, 2)
         ons = h[Q * 195:Q * 196]
         return [(ids[b, :on[b]].tolist(), rm[b, :on[b]].copy(), osz[b, :ons[b]].tolist()) for b in range(B)]
+
+    def hier_get(self, queries, decoding_length=64, branch_length=8, min_input_size=0, min_output_size=0, mode='mix', idxs=None,
+                 branch_lengths=None):
+        """-> list of (ids list, uint64 row masks, sizes list), like LookaheadCache.hier_get per query."""
+        B = self.hier_get_dev(queries, idxs=idxs, branch_lengths=branch_lengths, decoding_length=decoding_length,
+                              branch_length=branch_length, min_input_size=min_input_size, min_output_size=min_output_size, mode=mode)
+        return self._read_results(B)

@@ -51,7 +51,13 @@ class LookaheadPreTrainedModel(object):
             sub = max(decoding_length // len(qids), 1)                 # pretrained_model_batch.py:713
             sub = min(sub, _lib.LA_TREE_MAX * len(qids))               # a sample's tree never exceeds the 64 rows of a block
         ts = time.time()
-        if decoding_kwargs.get('device_trie', False) and fmt == 'hier':
+        if decoding_kwargs.get('device_trie', False) and fmt == 'one':
+            # one greedy chain per sample from one launch (la_trie_one_get_dev2); budget rule of bat_get (:534-541)
+            per = sub // len(qids)
+            got = self._device_trie(decoding_kwargs['_n_samples']).one_get(
+                qids, idxs=batch_indices, decoding_length=per, branch_length=branch_length, mode=mode)
+            drafts = [(np.asarray(g[0], dtype=np.int32), np.asarray(g[1], dtype=np.uint64), g[2]) for g in got]
+        elif decoding_kwargs.get('device_trie', False) and fmt == 'hier':
             # the drafts of ALL active samples from one launch over the incremental device mirror of the trie (one wavefront per
             # sample, its own input-frequency plane): no host trie query on the step's critical path.  Same budget rule as
             # bat_get (lookahead_cache.py:534-541): per sample sub // bs rows, min_output_size = max(per // 2, 1).
@@ -186,7 +192,7 @@ class LookaheadPreTrainedModel(object):
         next_token_list = [[first[i]] for i in range(bs)]
         dmode = decoding_kwargs.get('decoding_mode', 'hier')
         chained = bool(decoding_kwargs.get('device_trie', False)) and multi and not sequential and streamer is None and \
-            bool(decoding_kwargs.get('per_sample_budget', False)) and dmode.split('_')[0] == 'hier' and \
+            bool(decoding_kwargs.get('per_sample_budget', False)) and dmode.split('_')[0] in ('hier', 'one') and \
             not decoding_kwargs.get('debug_lookahead', False)
         # device_trie_update (default on with the chained device trie): the trie UPDATE of every step runs on the device as well
         dev_put = chained and bool(decoding_kwargs.get('device_trie_update', True)) and branch_length + 1 <= 64
@@ -236,8 +242,11 @@ class LookaheadPreTrainedModel(object):
                 mode_q = (dm if '_' in dm else dm + '_mix').split('_')[1]
                 dt = self._device_trie(decoding_kwargs['_n_samples'])
                 with torch.cuda.stream(eng.stream):
-                    dt.hier_get_dev(qids, idxs=batch_indices, decoding_length=per, branch_length=branch_length, min_input_size=0,
-                                    min_output_size=max(per // 2, 1), mode=mode_q)
+                    if dm.split('_')[0] == 'one':
+                        dt.one_get_dev(qids, idxs=batch_indices, decoding_length=per, branch_length=branch_length, mode=mode_q)
+                    else:
+                        dt.hier_get_dev(qids, idxs=batch_indices, decoding_length=per, branch_length=branch_length, min_input_size=0,
+                                        min_output_size=max(per // 2, 1), mode=mode_q)
                     if dev_put and not buffers_loaded:
                         dt.load_stream_buffers()        # the hold-back buffers as the host's stream_put calls left them
                         buffers_loaded = True

@@ -130,7 +130,8 @@ def test_incremental_device_mirror_replays_reference_trace_with_interleaved_upda
     print(os.path.basename(path), 'queries', checked, dev.stats)
 
 
-def test_batch_loop_with_device_trie_equals_host_trie_loop():
+@pytest.mark.parametrize('dmode', ['hier', 'one'])
+def test_batch_loop_with_device_trie_equals_host_trie_loop(dmode):
     """pretrained_model_batch.lookahead_generation with decoding_kwargs['device_trie']: the drafts of all samples come from one
     device launch per step over the incremental mirror; sequences, dls and edls must equal the host-trie loop's, request after
     request (the second request runs on the trie the first one grew) — with the per-step trie update shipped from the host as a
@@ -154,7 +155,7 @@ def test_batch_loop_with_device_trie_equals_host_trie_loop():
                 model.lookahead_cache.put(c, branch_length=13, mode='output', idx=-1)
         runs = []
         for req in range(2):
-            dk = {'use_lookahead': True, 'decoding_mode': 'hier', 'decoding_length': 64, 'branch_length': 12,
+            dk = {'use_lookahead': True, 'decoding_mode': dmode, 'decoding_length': 64, 'branch_length': 12,
                   'per_sample_budget': True, 'device_trie': use_dev, 'device_trie_update': dev_update}
             out = model.lookahead_generation(torch.from_numpy(prompts), stopping_criteria=P + 90, eos_token_id=2, pad_token_id=0,
                                              return_dict_in_generate=True, decoding_kwargs=dk)
@@ -171,7 +172,10 @@ def test_batch_loop_with_device_trie_equals_host_trie_loop():
             assert int(dt.meta.cpu()[1]) == 0 and int(dt.meta.cpu()[3]) > 100
         outs.append(runs)
     assert outs[0] == outs[1] == outs[2] == outs[3]
-    assert max(outs[0][0][1]) > 16          # per-sample budget: trees larger than the reference's (64 // 4) // 4 rows
+    if dmode == 'hier':
+        assert max(outs[0][0][1]) > 16      # per-sample budget: trees larger than the reference's (64 // 4) // 4 rows
+    else:
+        assert 4 < max(outs[0][0][1]) <= 13  # 'one': a single chain of at most branch_length + 1 rows per sample (la_trie_one_get_dev2)
 
 
 def test_single_sequence_loop_with_device_trie_equals_host_trie_loop():
@@ -386,3 +390,47 @@ def test_device_stream_put_overflow_falls_back_to_a_full_image():
             _assert_images_equal(dt, cache)
     assert overflowed and dt.stats['full_uploads'] >= 2
     _assert_images_equal(dt, cache)
+
+
+@pytest.mark.parametrize('mode', ['mix', 'output', 'input'])
+def test_device_one_get_equals_host_one_get(mode):
+    """la_trie_one_get_dev2 (LookaheadCache.one_get on the device mirror: greedy most-frequent chain, lower-triangular masks) vs the
+    host trie (bit-exact on the reference's traces, tests/test_native_trie.py) on a forest with ties, dead branches, stop words,
+    prompts in two input slots, queries that match fully / partly / not at all, and every branch length."""
+    rs = np.random.RandomState(31)
+    V = 60
+    cache = LookaheadCache(eos_ids=[None], stop_words={11: 1})
+    seqs = [rs.randint(3, V, size=rs.randint(6, 40)).tolist() for _ in range(120)]
+    for s_ in seqs[:80]:
+        cache.put(s_, branch_length=9, mode='output', idx=-1)
+    for s_ in seqs[80:100]:
+        cache.put(s_, branch_length=9, mode='input', idx=0)
+    for s_ in seqs[100:]:
+        cache.put(s_, branch_length=9, mode='input', idx=1)
+    dt = DeviceTrie(cache, idxs=[0, 1])
+    checked = chains = 0
+    for bl in (1, 2, 5, 8, 13):
+        queries, idxs = [], []
+        for _ in range(48):
+            src = seqs[rs.randint(len(seqs))]
+            p = rs.randint(1, len(src))
+            q = src[max(0, p - rs.randint(1, 4)):p]
+            if rs.rand() < 0.2:
+                q = q[:-1] + [int(rs.randint(3, V))]
+            if rs.rand() < 0.1:
+                q = q + [11]
+            queries.append(q)
+            idxs.append(int(rs.randint(2)))
+        got = dt.one_get(queries, decoding_length=64, branch_length=bl, mode=mode, idxs=idxs)
+        for q, ix, g in zip(queries, idxs, got):
+            ids, mask, sizes = cache.one_get(q, decoding_length=64, branch_length=bl, mode=mode, idx=ix)
+            assert g[0] == [int(x) for x in ids], (q, ix, bl)
+            assert g[2] == [int(x) for x in sizes], (q, ix, bl)
+            n = len(ids)
+            assert g[1].tolist() == [(2 << i) - 1 for i in range(n)]
+            checked += 1
+            chains += n > 2
+    assert checked == 240 and chains > 40
+    # the degenerate settings (:491-492)
+    got = dt.one_get([seqs[0][:2]], decoding_length=1, branch_length=8, mode=mode, idxs=[0])
+    assert got[0][0] == [seqs[0][1]] and got[0][2] == []
