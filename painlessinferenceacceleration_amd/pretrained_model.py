@@ -116,6 +116,10 @@ class LookaheadPreTrainedModel(object):
             got = self._device_trie().hier_get([list(qids)], decoding_length=decoding_length, branch_length=update_branch_length,
                                                min_input_size=0, min_output_size=max(decoding_length // 2, 1), mode=mode, idxs=[0])[0]
             ids, rowmask, sizes = np.asarray(got[0], dtype=np.int32), np.asarray(got[1], dtype=np.uint64), got[2]
+        elif fmt == 'one' and decoding_kwargs.get('device_trie', False) and len(qids) <= 8 and update_branch_length < 64:
+            got = self._device_trie().one_get([list(qids)], decoding_length=decoding_length, branch_length=update_branch_length,
+                                              mode=mode, idxs=[0])[0]
+            ids, rowmask, sizes = np.asarray(got[0], dtype=np.int32), np.asarray(got[1], dtype=np.uint64), got[2]
         elif fmt == 'hier':
             ids, rowmask, _, sizes = self.lookahead_cache.hier_get_packed(
                 qids, decoding_length=decoding_length, branch_length=update_branch_length, min_input_size=0,

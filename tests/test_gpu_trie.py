@@ -178,7 +178,8 @@ def test_batch_loop_with_device_trie_equals_host_trie_loop(dmode):
         assert 4 < max(outs[0][0][1]) <= 13  # 'one': a single chain of at most branch_length + 1 rows per sample (la_trie_one_get_dev2)
 
 
-def test_single_sequence_loop_with_device_trie_equals_host_trie_loop():
+@pytest.mark.parametrize('dmode', ['hier', 'one'])
+def test_single_sequence_loop_with_device_trie_equals_host_trie_loop(dmode):
     """pretrained_model.lookahead_generation (bs = 1) with decoding_kwargs['device_trie']: every draft comes from the wavefront
     trie walk over the incremental device mirror; tokens, dls and edls must equal the host-trie loop's (interpreter and native
     loop), request after request."""
@@ -199,7 +200,7 @@ def test_single_sequence_loop_with_device_trie_equals_host_trie_loop():
             model.lookahead_cache.put(c, branch_length=13, mode='output', idx=-1)
         runs = []
         for req in range(2):
-            dk = {'use_lookahead': True, 'decoding_mode': 'hier', 'decoding_length': 64, 'branch_length': 12,
+            dk = {'use_lookahead': True, 'decoding_mode': dmode, 'decoding_length': 64, 'branch_length': 12,
                   'device_trie': use_dev, 'native_loop': native}
             out = model.lookahead_generation(torch.from_numpy(prompt), stopping_criteria=P + 100, eos_token_id=2,
                                              return_dict_in_generate=True, decoding_kwargs=dk)
