@@ -233,6 +233,12 @@ class LookaheadCache(object):
         output_ids, decoding_masks, _ = self.hier_get(token_ids, decoding_length=decoding_length,
                                                       branch_length=branch_length, min_input_size=min_input_size,
                                                       min_output_size=min_output_size, mode=mode, idx=idx)
+        return self.par_layout(output_ids, decoding_masks)
+
+    @staticmethod
+    def par_layout(output_ids, decoding_masks):
+        """The re-layout step of par_get (lookahead_cache.py:449-488) on a hierarchical draft (ids, 0/1 mask [T][T]) — also applied
+        to a draft the DEVICE trie retrieved (pretrained_model.lookahead_prepare_inputs_for_generation)."""
         budget = len(output_ids) - 1
         kept = []
         for row in range(budget, 0, -1):

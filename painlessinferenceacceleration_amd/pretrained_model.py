@@ -120,6 +120,16 @@ class LookaheadPreTrainedModel(object):
             got = self._device_trie().one_get([list(qids)], decoding_length=decoding_length, branch_length=update_branch_length,
                                               mode=mode, idxs=[0])[0]
             ids, rowmask, sizes = np.asarray(got[0], dtype=np.int32), np.asarray(got[1], dtype=np.uint64), got[2]
+        elif fmt == 'par' and decoding_kwargs.get('device_trie', False) and len(qids) <= 8 and decoding_length <= 64:
+            # par = the hierarchical draft re-laid as independent chains (lookahead_cache.py:441-488): the device retrieves, the
+            # re-layout (a handful of set operations on <= 64 rows) stays on the host
+            got = self._device_trie().hier_get([list(qids)], decoding_length=decoding_length, branch_length=update_branch_length,
+                                               min_input_size=0, min_output_size=max(decoding_length // 2, 1), mode=mode, idxs=[0])[0]
+            T0 = len(got[0])
+            dense = np.array([[(int(got[1][i]) >> j) & 1 for j in range(T0)] for i in range(T0)], dtype=np.int64).reshape(T0, T0)
+            lst, mask, sizes = self.lookahead_cache.par_layout(got[0], dense)
+            ids = np.asarray(lst, dtype=np.int32)
+            rowmask = _pack_rows(mask, None)
         elif fmt == 'hier':
             ids, rowmask, _, sizes = self.lookahead_cache.hier_get_packed(
                 qids, decoding_length=decoding_length, branch_length=update_branch_length, min_input_size=0,

@@ -178,7 +178,7 @@ def test_batch_loop_with_device_trie_equals_host_trie_loop(dmode):
         assert 4 < max(outs[0][0][1]) <= 13  # 'one': a single chain of at most branch_length + 1 rows per sample (la_trie_one_get_dev2)
 
 
-@pytest.mark.parametrize('dmode', ['hier', 'one'])
+@pytest.mark.parametrize('dmode', ['hier', 'one', 'par'])
 def test_single_sequence_loop_with_device_trie_equals_host_trie_loop(dmode):
     """pretrained_model.lookahead_generation (bs = 1) with decoding_kwargs['device_trie']: every draft comes from the wavefront
     trie walk over the incremental device mirror; tokens, dls and edls must equal the host-trie loop's (interpreter and native
