@@ -572,7 +572,7 @@ def main():
             'bytes_per_launch': gu_bytes, 'ms_per_launch': round(gu_ms, 5),
             'timing': 'HIP events on the engine stream: %d launches (one per layer, own weights) back to back per event pair, 5 passes; '
                       'inside the eager step, with event packets between all kernels, the same launch reads %.5f ms; rocprofv3 kernel '
-                      'average: profiles/r02b_profile_raw.txt' % (shape.n_layers, gu_ms_step),
+                      'average: profiles/r03b_profile_raw.txt (35.3 us)' % (shape.n_layers, gu_ms_step),
             'ms_per_launch_in_eager_step': round(gu_ms_step, 5),
             # the same launch against the matrix-core roof: 64-row trees keep the kernel far below the MFMA ridge (HBM-bound by design)
             'mfma': {'flops_per_launch': 2 * 2 * shape.ffn * shape.hidden * 64,
