@@ -117,3 +117,44 @@ def test_self_launch_runs_two_gloo_ranks_end_to_end(tmp_path):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1 and json.loads(lines[0]) == {'world': 2, 'sum': 3}
+
+
+def test_host_batch_drafts_equals_per_sample_queries():
+    """bench.host_batch_drafts: the one-call batch form (la_cache_bat_get_packed) returns exactly the per-sample hier_get_packed drafts
+    the timed loop used before (same budget, same min_output_size, per-sequence input slot), falls back to per-sample calls when a
+    sequence's branch length is clamped, and substitutes the last token for an empty draft."""
+    import numpy as np
+    import bench
+    from painlessinferenceacceleration_amd.lookahead_cache import LookaheadCache
+    rs = np.random.RandomState(8)
+    V = 400
+    cache = LookaheadCache(eos_ids=[None])
+    seqs = [rs.randint(3, V, size=120).tolist() for _ in range(6)]
+    for b, s_ in enumerate(seqs):
+        for _ in range(4):
+            cache.put([t if rs.rand() > 0.15 else int(rs.randint(3, V)) for t in s_], branch_length=13, mode='output', idx=-1)
+        cache.put(s_[:60], branch_length=13, mode='input', idx=10 + b)
+    idxs = [10 + b for b in range(6)]
+
+    def per_sample(tails, ubls):
+        out = []
+        for t, ix, u in zip(tails, idxs, ubls):
+            ids, rm, _, _ = cache.hier_get_packed(t, decoding_length=64, branch_length=u, min_input_size=0, min_output_size=32,
+                                                  mode='mix', idx=ix)
+            out.append((ids.copy(), rm.copy()) if len(ids) else (np.asarray(t[-1:], dtype=np.int32), np.array([1], dtype=np.uint64)))
+        return out
+
+    hits = 0
+    for trial in range(40):
+        p = int(rs.randint(2, 100))
+        tails = [s_[p - 2:p] for s_ in seqs]
+        if trial % 5 == 0:
+            tails[0] = [V + 5, V + 6]                     # unknown tokens: no tree -> the last token alone
+        ubls = [12] * 6 if trial % 3 else [12, 12, 7, 12, 3, 12]
+        got = bench.host_batch_drafts(cache, tails, idxs, 64, 12, ubls)
+        want = per_sample(tails, ubls)
+        for g, w in zip(got, want):
+            assert g[0].tolist() == w[0].tolist() and g[1].tolist() == w[1].tolist()
+            hits += len(g[0]) > 8
+    assert hits > 60
+    assert bench.host_batch_drafts(cache, [[V + 5, V + 6]], [10], 64, 12, [12])[0][0].tolist() == [V + 6]
