@@ -480,9 +480,10 @@ def main():
             else:                        # split-phase RCCL all-gather: collected during the next verify step
                 gather.begin(toks_all if B > 1 else toks_all[0])
                 pending[0] = True
+        elif B > 1:
+            cache.stream_put_many([(gidx[i], toks_all[i]) for i in range(B)], branch_length=BL + 1, final=False)
         else:
-            for i in range(B):
-                cache.stream_put(toks_all[i], branch_length=BL + 1, final=False, idx=gidx[i])
+            cache.stream_put(toks_all[0], branch_length=BL + 1, final=False, idx=gidx[0])
 
     import gc
     gc.collect()

@@ -93,6 +93,10 @@ int la_cache_put(la_cache* c, const int32_t* token_ids, int n, int branch_length
 /* stream_put() (lookahead_cache.py:375-406). */
 int la_cache_stream_put(la_cache* c, const int32_t* token_ids, int n, int branch_length,
                         int final_, int idx);
+/* n stream_put calls in one (a batch step's accepted tokens, pretrained_model_batch.py:1254-1259): put k appends
+ * toks[offsets[k] .. offsets[k + 1]) to slot idxs[k], in order. */
+int la_cache_stream_put_many(la_cache* c, const int32_t* toks, const int32_t* offsets /*[n + 1]*/, const int32_t* idxs /*[n]*/, int n,
+                             int branch_length, int final_);
 /* hier_get() (lookahead_cache.py:408-439) -> Tree.get/_match/_dfs_get_freqs/_ravel (:65-154, 224-293).
  * Outputs (caller-owned): out_ids[cap], out_parent[cap] (index of the parent row, -1 for row 0),
  * out_rowmask[cap * W], W = ceil(decoding_length / 64) words per row (bit j of row i <=> mask[i][j]; W = 1: one word per row),

@@ -127,6 +127,7 @@ PROTOTYPES = {
     "la_cache_fresh": (i32, vp),
     "la_cache_put": (i32, vp, pi32, i32, i32, i32, i32, i32),
     "la_cache_stream_put": (i32, vp, pi32, i32, i32, i32, i32),
+    "la_cache_stream_put_many": (i32, vp, pi32, pi32, pi32, i32, i32, i32),
     "la_cache_hier_get": (i32, vp, pi32, i32, i32, i32, i32, i32, i32, i32, i32, pi32, pi32, pu64, pi64, pi32, pi32, pi32),
     "la_cache_one_get": (i32, vp, pi32, i32, i32, i32, i32, i32, i32, pi32, pi32, pi32, pi32),
     "la_cache_bat_get_packed": (i32, vp, pi32, pi32, i32, i32, i32, i32, i32, pi32, i32, i32, pi32, pu64, pi32, pi32, pi32),

@@ -38,6 +38,67 @@ static inline uint64_t key_of(int32_t parent, int32_t token) {
     return ((uint64_t)(uint32_t)parent << 32) | (uint32_t)token;
 }
 
+// (parent node, token) -> child node: open addressing with linear probing over two flat arrays (values >= 0; -1 = empty slot),
+// backward-shift deletion.  Round 3: std::unordered_map allocated one heap node per trie node — the largest single cost of an
+// n-gram insert (scripts/host_trie_put_bench.py: 8 stream_puts of ~7 new tokens 380 -> 250 us on the build container).
+struct FlatIndex {
+    std::vector<uint64_t> keys;
+    std::vector<int32_t> vals;
+    size_t count = 0;
+    int bits = 0;
+    static inline size_t slot_of(uint64_t k, int b) { return (size_t)((k * 0x9E3779B97F4A7C15ull) >> (64 - b)); }
+    void rehash(int nb) {
+        std::vector<uint64_t> ok; std::vector<int32_t> ov;
+        ok.swap(keys); ov.swap(vals);
+        bits = nb;
+        keys.assign((size_t)1 << bits, 0); vals.assign((size_t)1 << bits, -1);
+        const size_t m = ((size_t)1 << bits) - 1;
+        for (size_t i = 0; i < ov.size(); ++i)
+            if (ov[i] >= 0) {
+                size_t j = slot_of(ok[i], bits);
+                while (vals[j] >= 0) j = (j + 1) & m;
+                keys[j] = ok[i]; vals[j] = ov[i];
+            }
+    }
+    int32_t find(uint64_t k) const {
+        if (!bits) return -1;
+        const size_t m = ((size_t)1 << bits) - 1;
+        for (size_t i = slot_of(k, bits); vals[i] >= 0; i = (i + 1) & m)
+            if (keys[i] == k) return vals[i];
+        return -1;
+    }
+    void set(uint64_t k, int32_t v) {
+        if (!bits) rehash(10);
+        else if ((count + 1) * 4 > ((size_t)3 << bits)) rehash(bits + 1);       // load factor <= 0.75
+        const size_t m = ((size_t)1 << bits) - 1;
+        size_t i = slot_of(k, bits);
+        for (; vals[i] >= 0; i = (i + 1) & m)
+            if (keys[i] == k) { vals[i] = v; return; }
+        keys[i] = k; vals[i] = v; ++count;
+    }
+    void erase(uint64_t k) {
+        if (!bits) return;
+        const size_t m = ((size_t)1 << bits) - 1;
+        size_t i = slot_of(k, bits);
+        for (; vals[i] >= 0; i = (i + 1) & m)
+            if (keys[i] == k) break;
+        if (vals[i] < 0) return;
+        for (size_t j = i;;) {                              // close the gap: move back every entry the hole would cut off from its home slot
+            j = (j + 1) & m;
+            if (vals[j] < 0) break;
+            const size_t home = slot_of(keys[j], bits);
+            const bool between = i <= j ? (i < home && home <= j) : (i < home || home <= j);
+            if (between) continue;
+            keys[i] = keys[j]; vals[i] = vals[j];
+            i = j;
+        }
+        vals[i] = -1;
+        --count;
+    }
+    void clear() { keys.clear(); vals.clear(); count = 0; bits = 0; }
+    void swap(FlatIndex& o) { keys.swap(o.keys); vals.swap(o.vals); std::swap(count, o.count); std::swap(bits, o.bits); }
+};
+
 }  // namespace
 
 // ---- incremental device mirror (consumed by la_trie_hier_get_dev, csrc/la_trie_dev.hip) --------------------------------
@@ -128,7 +189,7 @@ struct la_cache {
     std::unordered_set<int32_t> stop_words;
     std::vector<Node> nodes;
     std::vector<int32_t> free_nodes;
-    std::unordered_map<uint64_t, int32_t> child_index;
+    FlatIndex child_index;
     std::unordered_map<int32_t, int32_t> mem;          // token -> tree slot
     std::vector<Tree> trees;
     std::vector<int32_t> free_trees;
@@ -158,7 +219,7 @@ struct la_cache {
         c.prev_sib = p.last_child; c.next_sib = -1;
         if (p.last_child >= 0) nodes[p.last_child].next_sib = child; else p.first_child = child;
         p.last_child = child;
-        child_index[key_of(parent, c.token)] = child;
+        child_index.set(key_of(parent, c.token), child);
         ++live_nodes;
         if (mir_live()) {
             const int32_t prec = (size_t)parent < mir->dev_of.size() ? mir->dev_of[parent] : -1;
@@ -166,8 +227,7 @@ struct la_cache {
         }
     }
     int32_t find_child(int32_t parent, int32_t token) const {
-        auto it = child_index.find(key_of(parent, token));
-        return it == child_index.end() ? -1 : it->second;
+        return child_index.find(key_of(parent, token));
     }
     // delete `child` and its whole subtree (dict.pop of a Node drops everything below it)
     void drop_subtree(int32_t child) {
@@ -555,6 +615,20 @@ int la_cache_stream_put(la_cache* c, const int32_t* toks, int n, int branch_leng
         buf.clear();
         c->reset_input_freqs(idx);
         c->squeeze_branch_counts();
+    }
+    return LA_OK;
+}
+
+// stream_put for several sequences in ONE call (a batch step's accepted tokens, pretrained_model_batch.py:1254-1259): put k appends
+// toks[offsets[k] .. offsets[k + 1]) to slot idxs[k], in order — exactly n la_cache_stream_put calls without n trips through the binding
+int la_cache_stream_put_many(la_cache* c, const int32_t* toks, const int32_t* offsets, const int32_t* idxs, int n, int branch_length,
+                             int final_) {
+    if (!c || n < 0 || (n > 0 && (!offsets || !idxs))) return LA_E_ARG;
+    for (int k = 0; k < n; ++k) {
+        const int len = offsets[k + 1] - offsets[k];
+        if (len < 0 || (len > 0 && !toks)) return LA_E_ARG;
+        const int rc = la_cache_stream_put(c, toks ? toks + offsets[k] : nullptr, len, branch_length, final_, idxs[k]);
+        if (rc != LA_OK) return rc;
     }
     return LA_OK;
 }

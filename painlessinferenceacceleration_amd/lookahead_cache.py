@@ -156,6 +156,24 @@ class LookaheadCache(object):
         arr, p, n = _as_i32(token_ids)
         check(lib.la_cache_stream_put(self._h, p, n, int(branch_length), int(bool(final)), int(idx)), 'stream_put')
 
+    def stream_put_many(self, puts, branch_length=8, final=False):
+        """stream_put for several sequences in one native call: puts = [(idx, token list)], applied in order (the batch loop's
+        per-step update, pretrained_model_batch.py:1254-1259)."""
+        self._sync_live()
+        n = len(puts)
+        if n == 0:
+            return
+        offs = np.zeros(n + 1, dtype=np.int32)
+        for k, (_, toks) in enumerate(puts):
+            offs[k + 1] = offs[k] + len(toks)
+        flat = np.zeros(max(int(offs[-1]), 1), dtype=np.int32)
+        for k, (_, toks) in enumerate(puts):
+            flat[offs[k]:offs[k + 1]] = toks
+        idxs = np.asarray([int(i) for i, _ in puts], dtype=np.int32)
+        assert (idxs >= 0).all()
+        check(lib.la_cache_stream_put_many(self._h, flat.ctypes.data_as(_lib.pi32), offs.ctypes.data_as(_lib.pi32),
+                                           idxs.ctypes.data_as(_lib.pi32), n, int(branch_length), int(bool(final))), 'stream_put_many')
+
     # ---- retrieval -----------------------------------------------------------------------------------
     def _hier_raw(self, token_ids, decoding_length, branch_length, min_input_size, min_output_size, mode, idx,
                   want_mask):

@@ -212,10 +212,9 @@ class LookaheadPreTrainedModel(object):
                 self._device_trie(decoding_kwargs['_n_samples']).replay(
                     [(b, next_token_list[k]) for k, b in enumerate(batch_indices)], branch_length + 1)
                 put_on_device = False
-            else:
-                for k, b in enumerate(batch_indices):                           # :1254-1259
-                    self.lookahead_cache.stream_put([x for x in next_token_list[k] if x != -1], branch_length=branch_length + 1,
-                                                    final=False, mode='output', idx=b)
+            else:                                                               # :1254-1259, one native call for the batch
+                self.lookahead_cache.stream_put_many([(b, [x for x in next_token_list[k] if x != -1])
+                                                      for k, b in enumerate(batch_indices)], branch_length=branch_length + 1, final=False)
             max_cur = max(max_cur, max(len(rows[b]) - 1 for b in batch_indices))
             keep = []
             for k, b in enumerate(batch_indices):                               # :1269-1276 + _early_stop :937-980

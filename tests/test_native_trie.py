@@ -450,3 +450,28 @@ def test_mirror_ccap_discard_and_stream_buffer_for_device_side_updates():
     # deletions (fresh / squeeze / load) make the mirror stale: discard refuses (the device image can no longer be the host's)
     native.fresh()
     assert lib.la_cache_mirror_discard(native._h, None) == -4        # LA_E_STATE
+
+
+def test_stream_put_many_equals_sequential_stream_puts():
+    """la_cache_stream_put_many (a batch step's accepted tokens in one native call) == the same stream_put calls one by one: same
+    forest, same hold-back buffers, same answers (incl. eos cut, empty lists, a repeated slot, the final flush)."""
+    rs = random.Random(11)
+    a, b = LookaheadCache(eos_ids=[2]), LookaheadCache(eos_ids=[2])
+    hist = [rs.randrange(3, 60) for _ in range(40)]
+    for step in range(300):
+        puts = []
+        for idx in rs.sample(range(6), rs.randint(1, 6)):
+            toks = [rs.choice(hist) if rs.random() < 0.6 else rs.randrange(2, 60) for _ in range(rs.randint(0, 14))]
+            puts.append((idx, toks))
+        if step % 17 == 0:
+            puts.append(puts[0])                                  # the same slot twice in one call: applied in order
+        final = step % 50 == 49
+        a.stream_put_many(puts, branch_length=9, final=final)
+        for idx, toks in puts:
+            b.stream_put(toks, branch_length=9, final=final, idx=idx)
+        if step % 10 == 0:
+            q = [rs.choice(hist), rs.choice(hist)]
+            ra, rb = a.hier_get(q, 32, 8, 0, 16, 'mix', 0), b.hier_get(q, 32, 8, 0, 16, 'mix', 0)
+            assert ra[0] == rb[0] and np.array_equal(ra[1], rb[1]) and ra[2] == rb[2]
+    assert a.stats() == b.stats()
+    a.stream_put_many([], branch_length=9)
