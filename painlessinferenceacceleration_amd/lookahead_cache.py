@@ -140,6 +140,15 @@ class LookaheadCache(object):
         self._sizes = np.zeros(2, dtype=np.int32)
         self._n = C.c_int32()
         self._nsizes = C.c_int32()
+        # the ctypes views of the result buffers are built once per allocation, not once per query (a query on the bs=1 critical
+        # path spent more time in these conversions than in the trie walk)
+        self._p_ids, self._p_parent = self._ids.ctypes.data_as(_lib.pi32), self._parent.ctypes.data_as(_lib.pi32)
+        self._p_rowmask, self._p_mask = self._rowmask.ctypes.data_as(_lib.pu64), self._mask.ctypes.data_as(_lib.pi64)
+        self._p_sizes = self._sizes.ctypes.data_as(_lib.pi32)
+        self._r_n, self._r_nsizes = C.byref(self._n), C.byref(self._nsizes)
+        if not hasattr(self, '_q'):
+            self._q = np.zeros(64, dtype=np.int32)
+            self._p_q = self._q.ctypes.data_as(_lib.pi32)
 
     # ---- updates -------------------------------------------------------------------------------------
     def put(self, token_ids, branch_length=8, final=False, mode='output', idx=0):
@@ -153,8 +162,15 @@ class LookaheadCache(object):
         """lookahead_cache.py:375-406."""
         self._sync_live()
         assert mode == 'output' and idx >= 0
-        arr, p, n = _as_i32(token_ids)
-        check(lib.la_cache_stream_put(self._h, p, n, int(branch_length), int(bool(final)), int(idx)), 'stream_put')
+        if isinstance(token_ids, (list, tuple)) and len(token_ids) <= 64:     # the per-step update: no array / pointer objects per call
+            n = len(token_ids)
+            self._q[:n] = token_ids
+            p = self._p_q
+        else:
+            arr, p, n = _as_i32(token_ids)
+        rc = lib.la_cache_stream_put(self._h, p, n, int(branch_length), int(bool(final)), int(idx))
+        if rc:
+            check(rc, 'stream_put')
 
     def stream_put_many(self, puts, branch_length=8, final=False):
         """stream_put for several sequences in one native call: puts = [(idx, token list)], applied in order (the batch loop's
@@ -180,14 +196,17 @@ class LookaheadCache(object):
         assert mode in ('input', 'output', 'mix')
         self._sync_live()
         self._alloc(max(int(decoding_length), 1))
-        arr, p, n = _as_i32(token_ids)
-        mask_p = self._mask.ctypes.data_as(_lib.pi64) if want_mask else None
-        check(lib.la_cache_hier_get(self._h, p, n, int(decoding_length), int(branch_length), int(min_input_size),
-                                    int(min_output_size), _MODES[mode], int(idx), self._cap,
-                                    self._ids.ctypes.data_as(_lib.pi32), self._parent.ctypes.data_as(_lib.pi32),
-                                    self._rowmask.ctypes.data_as(_lib.pu64), mask_p,
-                                    self._sizes.ctypes.data_as(_lib.pi32), C.byref(self._nsizes), C.byref(self._n)),
-              'hier_get')
+        if isinstance(token_ids, (list, tuple)) and len(token_ids) <= 64:
+            n = len(token_ids)
+            self._q[:n] = token_ids
+            p = self._p_q
+        else:
+            arr, p, n = _as_i32(token_ids)
+        rc = lib.la_cache_hier_get(self._h, p, n, int(decoding_length), int(branch_length), int(min_input_size),
+                                   int(min_output_size), _MODES[mode], int(idx), self._cap, self._p_ids, self._p_parent,
+                                   self._p_rowmask, self._p_mask if want_mask else None, self._p_sizes, self._r_nsizes, self._r_n)
+        if rc:
+            check(rc, 'hier_get')
         return self._n.value, self._nsizes.value
 
     def hier_get(self, token_ids, decoding_length=64, branch_length=8, min_input_size=0, min_output_size=0,
