@@ -99,7 +99,9 @@ int la_cache_stream_put_many(la_cache* c, const int32_t* toks, const int32_t* of
                              int branch_length, int final_);
 /* hier_get() (lookahead_cache.py:408-439) -> Tree.get/_match/_dfs_get_freqs/_ravel (:65-154, 224-293).
  * Outputs (caller-owned): out_ids[cap], out_parent[cap] (index of the parent row, -1 for row 0),
- * out_rowmask[cap * W], W = ceil(decoding_length / 64) words per row (bit j of row i <=> mask[i][j]; W = 1: one word per row),
+ * out_rowmask: REQUIRED size cap * W words, W = ceil(decoding_length / 64) — every path writes whole rows of W words (bit j of
+ *   row i <=> mask[i][j]; W = 1, i.e. decoding_length <= 64: one word per row, the layout of ABI <= 7); a caller that sized the
+ *   buffer as out_rowmask[cap] must pass decoding_length <= 64 or grow it (the token_ids[-1:] fallbacks write row 0 = {1, 0, ...}),
  * out_mask (optional, row-major int64 [*out_n][*out_n], needs cap*cap entries),
  * out_sizes[2], *out_nsizes in {0,2} (the reference returns [] on the early exit, :413-414). */
 int la_cache_hier_get(la_cache* c, const int32_t* token_ids, int n,

@@ -657,7 +657,12 @@ int la_cache_hier_get(la_cache* c, const int32_t* q, int nq, int decoding_length
         *out_nsizes = nsizes; out_sizes[0] = out_sizes[1] = 0;
         if (nq == 0) { *out_n = 0; return LA_OK; }
         out_ids[0] = q[nq - 1]; out_parent[0] = -1; *out_n = 1;
-        if (out_rowmask) out_rowmask[0] = 1;
+        // the same packed layout as emit(): row 0 = W words, W = ceil(decoding_length / 64) (W = 1 when decoding_length <= 64)
+        if (out_rowmask) {
+            const int W = decoding_length > 64 && decoding_length <= cap ? (decoding_length + 63) / 64 : 1;
+            out_rowmask[0] = 1;
+            for (int w = 1; w < W; ++w) out_rowmask[w] = 0;
+        }
         if (out_mask) out_mask[0] = 1;
         return LA_OK;
     };

@@ -110,7 +110,8 @@ class LookaheadPreTrainedModel(object):
             decoding_mode = decoding_mode + '_mix'
         fmt, mode = decoding_mode.split('_')
         ts = time.time()
-        if fmt == 'hier' and decoding_kwargs.get('device_trie', False) and len(qids) <= 8:
+        if fmt == 'hier' and decoding_kwargs.get('device_trie', False) and len(qids) <= 8 and decoding_length <= _lib.LA_TREE_MAX:
+            # (trees wider than one 64-row block come from the host trie: the device walk emits uint64[T] row masks)
             # draft from the wavefront trie walk over the incremental device mirror (csrc/la_trie_dev.hip): bit-identical to the
             # host query; opt-in here because one host query (~20 us) is faster than sync + launch + D2H at bs = 1
             got = self._device_trie().hier_get([list(qids)], decoding_length=decoding_length, branch_length=update_branch_length,
@@ -148,7 +149,7 @@ class LookaheadPreTrainedModel(object):
         """DeviceTrie over self.lookahead_cache, input-frequency plane of idx 0 (rebuilt when the cache object changes)."""
         from .device_trie import DeviceTrie
         dt = getattr(self, '_dev_trie', None)
-        if dt is None or dt.cache is not self.lookahead_cache:
+        if dt is None or dt.cache is not self.lookahead_cache or dt._revoked:        # another DeviceTrie took the cache's mirror
             dt = self._dev_trie = DeviceTrie(self.lookahead_cache, idxs=[0], device=self.engine.device)
         return dt
 

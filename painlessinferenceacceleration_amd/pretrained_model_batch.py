@@ -74,14 +74,16 @@ class LookaheadPreTrainedModel(object):
                                 'hit_sizes': [d[2] for d in drafts], 'batch_indices': batch_indices})
         return [(d[0], d[1]) for d in drafts]
 
-    def _device_trie(self, n_samples):
+    def _device_trie(self, n_samples, updates=False):
         """DeviceTrie over self.lookahead_cache with one input-frequency plane per batch index (rebuilt when the cache object or
-        the batch size changes)."""
+        the batch size changes).  updates=True (the chained loop with device-side stream_put) adds the token -> root table and the
+        block capacities; without it a sync() patch carries no root-index pass (vocab-sized memset + kernel + meta copy)."""
         from .device_trie import DeviceTrie
         dt = getattr(self, '_dev_trie', None)
-        if dt is None or dt.cache is not self.lookahead_cache or len(dt.idxs) < n_samples or dt._revoked:
+        if dt is None or dt.cache is not self.lookahead_cache or len(dt.idxs) < n_samples or dt._revoked or \
+                (updates and not dt.put_vocab):
             dt = self._dev_trie = DeviceTrie(self.lookahead_cache, idxs=list(range(n_samples)), device=self.engine.device,
-                                             put_vocab=self.engine.shape.vocab)
+                                             put_vocab=self.engine.shape.vocab if updates else None)
         return dt
 
     @torch.no_grad()
@@ -94,6 +96,11 @@ class LookaheadPreTrainedModel(object):
         gc.disable()
         try:
             return self._lookahead_generation(*args, **kwargs)
+        except BaseException:
+            # an abnormal exit (KeyboardInterrupt, a raising StoppingCriteria, a failed assert) may leave device-side trie inserts
+            # the host never replayed: drop the mirror owner, the next generation builds a fresh image from the host trie
+            self._dev_trie = None
+            raise
         finally:
             if was_enabled:
                 gc.enable()
@@ -209,7 +216,7 @@ class LookaheadPreTrainedModel(object):
                 # the device inserted these tokens into its trie image itself, straight from the step's output block
                 # (la_trie_stream_put_dev behind the verify pass): the host trie repeats the same puts in the same order and
                 # drops the words it logged for them — nothing of the update crosses PCIe
-                self._device_trie(decoding_kwargs['_n_samples']).replay(
+                self._device_trie(decoding_kwargs['_n_samples'], dev_put).replay(
                     [(b, next_token_list[k]) for k, b in enumerate(batch_indices)], branch_length + 1)
                 put_on_device = False
             else:                                                               # :1254-1259, one native call for the batch
@@ -239,7 +246,7 @@ class LookaheadPreTrainedModel(object):
                 per = min(decoding_length, _lib.LA_TREE_MAX)
                 dm = decoding_kwargs.get('decoding_mode', 'hier')
                 mode_q = (dm if '_' in dm else dm + '_mix').split('_')[1]
-                dt = self._device_trie(decoding_kwargs['_n_samples'])
+                dt = self._device_trie(decoding_kwargs['_n_samples'], dev_put)
                 with torch.cuda.stream(eng.stream):
                     if dm.split('_')[0] == 'one':
                         dt.one_get_dev(qids, idxs=batch_indices, decoding_length=per, branch_length=branch_length, mode=mode_q)

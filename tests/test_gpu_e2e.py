@@ -596,8 +596,9 @@ def test_full_size_llama7b_32_layers_vs_oracle():
     own distance, as max-norm relative error over the 64 tree rows: at EVERY depth the engine may not be further from fp32 than
     the reference's bf16 arithmetic (x 1.5 + 2e-3), i.e. the ~8 % at the logits is bf16 rounding compounding through 32 residual
     blocks — the same curve for both implementations — not a kernel.  (2) The argmax clause is anchored on quantities the engine
-    does not influence: a row is "decisive" when the fp32 oracle's top-2 gap exceeds twice the BF16 ORACLE's error on that row
-    (the reference's own arithmetic keeps the fp32 argmax there); on those rows the engine must produce the fp32 argmax."""
+    does not influence and is asserted unconditionally (round 4): rows whose fp32 top-2 gap exceeds twice the BF16 ORACLE's error
+    on that row — misses counted and bounded by max(1, 10 %) — and rows whose gap exceeds twice the bf16 oracle's worst row
+    error, where the engine must produce the fp32 argmax without exception."""
     from painlessinferenceacceleration_amd._lib import check, lib
     shape = LlamaShape.llama2_7b()
     sd = random_weights(shape, seed=11, device='cuda:0')
@@ -642,7 +643,7 @@ def test_full_size_llama7b_32_layers_vs_oracle():
         check(lib.la_debug_set(13, 0), 'debug_set')
     toks, ncommit = eng.step(ids, rows, mode=0)
     got_t = eng.logits().float().cpu()
-    n_dec = 0
+    n_dec = n_dec_b = n_miss = 0
     for name, got, r16, r32 in (('prefill', got_p, lg16[64:], lg32[64:]), ('tree step', got_t, t16, t32)):
         e_eng, e_o16, e_pair = rel(got, r32), rel(r16, r32), rel(got, r16)
         print(f'[7B x 32 layers, {name}] engine vs fp32 oracle: median {float(e_eng.median()):.4f} max {float(e_eng.max()):.4f} | '
@@ -651,14 +652,29 @@ def test_full_size_llama7b_32_layers_vs_oracle():
         assert float(e_eng.median()) <= 1.25 * float(e_o16.median()) + 0.005, name
         assert float(e_eng.max()) <= 1.5 * float(e_o16.max()) + 0.01, name
         assert float(e_pair.max()) <= 1.5 * (float(e_eng.max()) + float(e_o16.max())), name
-        for t in range(got.shape[0]):                          # (2) decisive rows are defined WITHOUT the engine
+        # (2) argmax, asserted UNCONDITIONALLY on rows defined without the engine.  Set A: the fp32 top-2 gap exceeds twice the
+        # bf16 oracle's error ON THAT ROW (the reference's own arithmetic keeps the fp32 argmax there; the engine's error on the
+        # row may be larger than the oracle's, so a miss is possible — it is counted and bounded, never skipped).  Set B: the gap
+        # exceeds twice the bf16 oracle's WORST row error of this pass: no exemption, every row must carry the fp32 argmax.
+        mx32 = r32.float().abs().max(1).values
+        worst16 = float(e_o16.max())
+        miss_a = []
+        for t in range(got.shape[0]):
             top = torch.topk(r32[t].float(), 2).values
-            if float(top[0] - top[1]) > 2 * float(e_o16[t]) * float(r32[t].float().abs().max()) + 1e-6:
+            gap = float(top[0] - top[1])
+            am32 = int(r32[t].float().argmax())
+            if gap > 2 * float(e_o16[t]) * float(mx32[t]) + 1e-6:
                 n_dec += 1
-                assert int(r16[t].float().argmax()) == int(r32[t].float().argmax())
-                if float(e_eng[t]) <= float(e_o16[t]):         # the engine is at least as close as the bf16 oracle: same argmax follows
-                    assert int(got[t].argmax()) == int(r32[t].float().argmax()), (name, t)
-    print(f'[7B x 32 layers] rows decisive at the bf16 oracle\'s own error: {n_dec}')
+                assert int(r16[t].float().argmax()) == am32
+                if int(got[t].argmax()) != am32:
+                    miss_a.append((t, round(float(e_eng[t]), 4), round(float(e_o16[t]), 4)))
+            if gap > 2 * worst16 * float(mx32[t]) + 1e-6:
+                n_dec_b += 1
+                assert int(got[t].argmax()) == am32, (name, t, float(e_eng[t]), worst16)
+        n_miss += len(miss_a)
+        print(f'[7B x 32 layers, {name}] argmax on rows decisive at the bf16 oracle\'s own row error: {len(miss_a)} misses {miss_a}')
+    print(f'[7B x 32 layers] rows decisive at the bf16 oracle\'s own row error: {n_dec} (engine misses {n_miss}); at its worst row error: {n_dec_b} (no miss allowed)')
+    assert n_miss <= max(1, n_dec // 10), (n_miss, n_dec)
     am = eng.state().cpu().numpy()[136:136 + T].tolist()
     exp_toks, exp_rows = lo.accept_scan(ids.tolist(), _mask_from_rows(rows, T), am)
     assert toks == exp_toks and ncommit == len(exp_rows)

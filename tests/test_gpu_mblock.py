@@ -5,6 +5,8 @@ Every block of a multi-block step is one sequence's full 64-row verify block (or
 is defined per sequence: block b of an M = 64*B row step must reproduce what the bs=1 oracle computes for that
 sequence alone — logits within the tolerance of test_gpu_e2e.py (2e-2 * max|logit| per row, argmax wherever the gap is
 decisive), accept walk / commit plan / cursors bit-exact given the device's argmax rows."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -646,3 +648,70 @@ def test_mstep_mixtral_gathered_experts_vs_oracle_with_forced_routing():
                 mine = sorted(int(e) for e in torch.nonzero(forced[li][t]).flatten())
                 assert mine == sorted(sel[t].tolist()), (b, li, t)
     assert n_dec >= 0.25 * n_all
+
+
+def test_mstep_mixtral8x7b_layer_shape_gathered_experts_vs_oracle_with_forced_routing():
+    """BASELINE config 5 at its REAL layer shape, two layers deep: hidden 4096, GQA 32 / 8 heads, ffn 14336, 8 experts top-2
+    (MixtralSparseMoeBlock.forward, models/mixtral/modeling_mixtral.py:692-759), B = 4 sequences x 64 rows = 256 rows per pass —
+    the gathered-expert launches the driver times (k_moe_plan_mb / k_moe_gather_mb, merged per-stage expert launches
+    k_gemm_mb<..., EX = true>, k_moe_accum_norm_mb).  Same method as the tiny-shape test above, at the STATED tolerance (2e-2):
+    every row of every block vs the oracle re-run under the engine's own per-layer routing (prompt and tree), and on rows the
+    oracle routes decisively the engine must pick the oracle's experts.  Weights: plain random init (std 0.02, every projection),
+    NOT the permutation LM — an expert's output carries its full weight here, so a wrong row list / weight / expert shows."""
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    shape = LlamaShape(2, 4096, 32, 8, 14336, 32000, 1e-5, rope_theta=1e6, n_experts=8, top_k=2, norm_cast_first=True)
+    sd = random_weights(shape, seed=12, device='cpu')
+    B = 4
+    eng = LlamaVerifyEngine(shape, dict(sd), max_length=256, n_slots=B, max_blocks=B)
+    oracle = lo.OracleLlama(shape, sd)
+    rs = np.random.RandomState(24)
+    blocks, seqs = [], []
+    for b in range(B):
+        p = rs.randint(3, shape.vocab, size=int(rs.randint(20, 64))).tolist()       # one prefill block per prompt
+        tok = eng.mprefill(b, p)
+        rwp = eng.mroute_weights()[:, :len(p), :shape.n_experts].cpu().clone()
+        T = 64 if b < 2 else int(rs.randint(30, 65))
+        _, rows = random_tree(rs, T)
+        ids = np.concatenate([[tok], rs.randint(3, shape.vocab, size=T - 1)]).astype(np.int32)
+        blocks.append((b, ids, rows, 0, 16))
+        seqs.append((p, ids, rows, T, rwp))
+    eng.mstep(blocks)
+    rw = eng.mroute_weights().cpu()
+    n_dec = n_all = 0
+    worst = 0.0
+    hit = torch.zeros(shape.n_layers, shape.n_experts)
+    for b, (p, ids, rows, T, rwp) in enumerate(seqs):
+        P = len(p)
+        _, past = oracle.forward(torch.tensor(p), torch.tril(torch.ones((P, P), dtype=torch.long)), None,
+                                 forced_routing=[rwp[li] for li in range(shape.n_layers)])
+        full = torch.cat([torch.ones((T, P), dtype=torch.long), torch.from_numpy(_mask_from_rows(rows, T))], 1)
+        oracle.forward(torch.tensor(ids.tolist()), full, past)
+        trace = [rl.clone() for rl in oracle.router_trace]
+        forced = [rw[li, 64 * b:64 * b + T, :shape.n_experts] for li in range(shape.n_layers)]
+        lg_forced, _ = oracle.forward(torch.tensor(ids.tolist()), full, past, forced_routing=forced)
+        got = eng.mlogits()[64 * b:64 * b + T].float().cpu()
+        err = (got - lg_forced.float()).abs().amax(-1) / lg_forced.float().abs().amax(-1)
+        worst = max(worst, float(err.max()))
+        assert float(err.max()) <= TOL, (b, float(err.max()), int(err.argmax()))
+        for li in range(shape.n_layers):
+            w = forced[li]
+            assert bool(((w != 0).sum(-1) == shape.top_k).all()), (b, li)              # every live row: exactly top_k experts
+            assert float((w.sum(-1) - 1).abs().max()) < 2e-2, (b, li)                  # renormalised weights (bf16)
+            hit[li] += (w != 0).sum(0).float()
+        for t in range(T):
+            ok = True
+            for rl in trace:
+                srt = torch.sort(torch.softmax(rl[t].float(), -1), descending=True).values
+                ok = ok and float(srt[shape.top_k - 1] - srt[shape.top_k]) > 0.02
+            if not ok:
+                continue
+            n_dec += 1
+            for li, rl in enumerate(trace):
+                sel = torch.topk(torch.softmax(rl[t].float(), -1), shape.top_k, -1).indices
+                mine = sorted(int(e) for e in torch.nonzero(forced[li][t]).flatten())
+                assert mine == sorted(sel.tolist()), (b, li, t)
+        n_all += T
+    print(f'[Mixtral-8x7B layer shape, 256 rows] max rel err vs oracle (forced routing) {worst:.4f}; decisively routed rows '
+          f'{n_dec}/{n_all}; rows per expert, layer 0: {hit[0].int().tolist()}')
+    assert n_dec >= 0.25 * n_all
+    assert bool((hit > 0).all()), 'every expert of every layer received rows (the gathered path ran for all of them)'
