@@ -333,8 +333,9 @@ typedef struct la_llama_config {
     int32_t n_experts;       /* > 0: Mixtral-style sparse MoE MLP (mixtral/modeling_mixtral.py:692-759), <= LA_MOE_MAX_E */
     int32_t top_k;           /* experts per token (Mixtral: 2) */
     int32_t fuse;            /* in-kernel norm->GEMM fusion, opt-in (0 / -1 = off): bit 0 = post-attention norm into the
-                                gate/up launch, bit 1 = input norm of layers > 0 into the QKV launch.  Bitwise identical
-                                results; slower than separate kernels on MI355X (cross-XCD hand-over), see DESIGN.md */
+                                gate/up launch, bit 1 = input norm of layers > 0 into the QKV launch; bits 2 / 3 = gate/up + down_proj
+                                as one role-fused launch; bit 4 (16) = the fused producers publish WRITE-THROUGH (sc1 stores + drained
+                                flag, no release fence).  Bitwise identical results; see DESIGN.md for the measurements */
     int32_t sliding_window;  /* > 0: sliding-window attention over the committed keys (Mistral: 4096; visible iff
                                 pos_row - pos_key <= window, the transformers mask rule).  An EXTENSION: the reference's
                                 lookahead path feeds the full mask (mistral/modeling_mistral.py:979-983) */

@@ -140,6 +140,9 @@ static void resolve_cfg(la_llama* m) {
         const int want = c.fuse;
         if ((want & 1) && c.balanced_wg[1] >= LA_TREE_MAX && m->o_ks == 4) m->fuse |= 1;
         if ((want & 2) && c.balanced_wg[0] >= LA_TREE_MAX && m->down_ks == 4) m->fuse |= 2;
+        // bit 4 (value 16, round 4): the fused producers publish write-through (sc1 stores + drained flag) instead of plain
+        // stores + release fence — the cheap publish form of MI355X_MICROARCH.md (publish-large: 3.0 vs 8.2 us)
+        if ((want & 16) && (m->fuse & 3)) m->fuse |= 16;
     }
     // bit 2 (value 4), bit 3 (value 8 = 8 tile-sets in flight in the down role): gate/up and down_proj as ONE role-fused launch
     // (k_gateup_down): needs the balanced gate/up image, the 64-row classic down image and a dense MLP
@@ -396,7 +399,7 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
         P(KC_QKV);
         if (c.balanced_wg[0] > 0) {
             // layers > 0: the input norm (residual + down-projection slabs of the previous layer) runs inside this launch
-            FusedNorm fq{m->slabs, m->down_ks, m->h, L.norm1, c.hidden, c.rms_eps, cf, m->fuse_cnt + 2 * l};
+            FusedNorm fq{m->slabs, m->down_ks, m->h, L.norm1, c.hidden, c.rms_eps, cf, m->fuse_cnt + 2 * l, (m->fuse & 16) ? 1 : 0};
             KCHK(lk_gemm64r_qkv(st, L.wqkv, m->xp, c.n_heads, c.n_kv_heads, c.hidden, c.balanced_wg[0], m->pos,
                                 m->w.rope_cos, m->w.rope_sin, m->qf, kf, vf, ((m->fuse & 2) && l > 0) ? &fq : nullptr));
         } else if (m->qkv_fused) {
@@ -464,7 +467,7 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
             continue;
         }
         if (m->fuse & 1) {
-            FusedNorm fg{m->slabs, m->o_ks, m->h, L.norm2, c.hidden, c.rms_eps, cf, m->fuse_cnt + 2 * l + 1};
+            FusedNorm fg{m->slabs, m->o_ks, m->h, L.norm2, c.hidden, c.rms_eps, cf, m->fuse_cnt + 2 * l + 1, (m->fuse & 16) ? 1 : 0};
             P(KC_GATEUP);
             KCHK(lk_gemm64r_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, c.balanced_wg[1], m->act_xp, nullptr, &fg));
         } else {

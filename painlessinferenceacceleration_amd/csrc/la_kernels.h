@@ -11,6 +11,7 @@ struct FusedNorm {
     void* h; const void* nw;             // residual stream (updated in place), norm weight
     int hidden; float eps; int cast_first;
     int* counter;                        // zeroed device int, one per fused launch and step
+    int write_through;                   // 1: producers publish with sc1 (write-through) stores + drained flag instead of a release fence
 };
 
 // Idle-window weight prefetch.  The row kernels (k_row_norm) and the attention combine stream almost nothing: HBM is idle while
@@ -78,6 +79,10 @@ int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* 
                  const void* vfresh, const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys,
                  int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window = 0, int ring_keys = 0,
                  const PfDesc* pf = nullptr);
+int lk_attn1_init();
+// single-sequence step, ONE launch (la_attn1.hip): no key-split partials, no combine kernel
+int lk_tree_attn1(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh, const void* vfresh,
+                  const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys, void* attn_xp, int window, int ring_keys);
 int lk_tree_attn_b(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                    const void* vfresh, const uint64_t* rowmask, const int* bstate, int nh, int nkv, int slot_keys,
                    int n_slots, int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window = 0, int ring_keys = 0,

@@ -79,7 +79,10 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 // h_new = bf16(h + bf16(sum slabs)); x = bf16(w * (h_new * rsqrt(mean(h_new^2)+eps)))  (fp32 math).
 // 512 threads, <= 2 chunks of 8 elements per thread (hidden <= 8192).  NS is a template parameter so that every
 // load of the row (h, NS slabs, norm weight) is issued before the first use: one memory round trip, not NS+2.
-template <int NS, bool MOE>
+// WT = true (fused producers of a norm->GEMM launch, cfg.fuse bit 4): the packed operand leaves as WRITE-THROUGH 16-byte stores (sc1:
+// straight to memory, no dirty line stays in this XCD's L2), so the hand-over needs no release fence (buffer_wbl2) — the cheap
+// publish form of MI355X_MICROARCH.md (publish-large: 3.0 vs 8.2 us), cdna_hip_programming.md Guideline 16 R1.
+template <int NS, bool MOE, bool WT = false>
 __device__ __forceinline__ void row_norm_body(const int t, float* sh, float (*shr)[LA_MOE_MAX_E],
                                               const bf16_t* __restrict__ embed_row,
                                               bf16_t* __restrict__ h, const float* __restrict__ slabs,
@@ -154,7 +157,12 @@ __device__ __forceinline__ void row_norm_body(const int t, float* sh, float (*sh
                 const float nv = cast_first ? bfr(vals[ci][j] * rs) : vals[ci][j] * rs;
                 xo[j] = (short)f2bf(bf2f((bf16_t)wv[ci][j]) * nv);
             }
-            *(bf16x8*)(xp + xp_offset(t, c * 8)) = xo;
+            if constexpr (WT) {
+                const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)xp, 0, LA_TB * hidden * 2, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xo), xr, (int)(xp_offset(t, c * 8) * 2), 0, 16);     // aux 16 = sc1
+            } else {
+                *(bf16x8*)(xp + xp_offset(t, c * 8)) = xo;
+            }
             if (MOE) {
 #pragma unroll
                 for (int e = 0; e < LA_MOE_MAX_E; ++e) {
@@ -303,7 +311,15 @@ __global__ __launch_bounds__(512) void k_step_head(const int* __restrict__ in, i
 // In-kernel hand-over from the 64 producer workgroups (lowest block ids, dispatched first, so a consumer never waits on a
 // workgroup that could be queued behind it) to every workgroup of the grid: producers publish their stores with an
 // agent-scope release and bump `counter`; everybody spins until it reaches `target`, then acquires.
-__device__ __forceinline__ void handover_signal(int* counter) {
+__device__ __forceinline__ void handover_signal(int* counter, bool wt = false) {
+    if (wt) {
+        // write-through payload (sc1 stores): EVERY storing wave drains its own stores, the barrier collects the waves, one lane
+        // bumps the counter — no L2 write-back (Guideline 16 R1; pitfall 14: draining lane 0 alone is not enough)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     __syncthreads();                 // every wave's stores have completed (the barrier carries vmcnt(0)) ...
     if (threadIdx.x == 0) {
         // ... one lane writes the XCD's dirty L2 lines back (agent-scope release), DRAINS that write-back — hipcc may drop the
@@ -672,7 +688,7 @@ struct GemmRArgs {
     const float* fn_slabs;
     bf16_t* fn_h;
     const bf16_t* fn_nw;
-    int fn_hidden, fn_cast;
+    int fn_hidden, fn_cast, fn_wt;
     float fn_eps;
     int* fn_counter;
     // tail prefetch: after its streaming loop every workgroup pulls the first k-tiles the same-numbered workgroup of the NEXT GEMM
@@ -731,10 +747,15 @@ __device__ __forceinline__ void gemm64r_body(const bf16_t* __restrict__ wp_s, co
             static_assert(NW == 8, "the fused row kernel is written for 512 threads");
             const bool producer = bp.bx < LA_TB;
             if (producer) {
-                row_norm_body<NSF, false>(bp.bx, redr, nullptr, nullptr, ra.fn_h, ra.fn_slabs, ra.fn_nw,
-                                          ra.fn_hidden, ra.fn_eps, (bf16_t*)xp_s, nullptr, nullptr, 0, 0, nullptr, nullptr,
-                                          ra.fn_cast);
-                handover_signal(ra.fn_counter);
+                if (ra.fn_wt)
+                    row_norm_body<NSF, false, true>(bp.bx, redr, nullptr, nullptr, ra.fn_h, ra.fn_slabs, ra.fn_nw,
+                                                    ra.fn_hidden, ra.fn_eps, (bf16_t*)xp_s, nullptr, nullptr, 0, 0, nullptr, nullptr,
+                                                    ra.fn_cast);
+                else
+                    row_norm_body<NSF, false>(bp.bx, redr, nullptr, nullptr, ra.fn_h, ra.fn_slabs, ra.fn_nw,
+                                              ra.fn_hidden, ra.fn_eps, (bf16_t*)xp_s, nullptr, nullptr, 0, 0, nullptr, nullptr,
+                                              ra.fn_cast);
+                handover_signal(ra.fn_counter, ra.fn_wt != 0);
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) {
@@ -1848,6 +1869,7 @@ int g_la_pf_tail_kib = 0;     // tail prefetch of down_proj from the gate/up lau
 int g_la_attn_staged = 0;     // 1: tree attention with K/V staged through LDS once per workgroup (la_debug_set key 10)
 int g_la_graph_reps = 1;      // measurement: repetitions of the step inside the single-sequence graph (key 11)
 int g_la_graph_epoch = 0;     // bumped by la_debug_set when a capture-time knob changes: la_llama_step captures its graph again
+extern int g_la_attn_one;
 int g_la_gemm_4w = 0;         // la_debug_set key 15: bit 0 = gate/up as 4 waves x 8 tile-sets (one wave per SIMD) — measurement
 int g_la_pf_delay = 0;        // s_sleep(32) rounds the prefetch workgroups wait before their first load (key 8)
 
@@ -2014,7 +2036,7 @@ static bool set_fused_norm(GemmRArgs& ra, const FusedNorm* fn, int n_wg) {
     if (!fn || !fn->counter) return false;
     if (n_wg < LA_TB || fn->hidden > 8192 || (fn->hidden & 7)) return false;
     ra.fn_slabs = fn->slabs; ra.fn_h = (bf16_t*)fn->h; ra.fn_nw = (const bf16_t*)fn->nw; ra.fn_hidden = fn->hidden;
-    ra.fn_cast = fn->cast_first; ra.fn_eps = fn->eps; ra.fn_counter = fn->counter;
+    ra.fn_cast = fn->cast_first; ra.fn_eps = fn->eps; ra.fn_counter = fn->counter; ra.fn_wt = fn->write_through;
     return true;
 }
 int lk_gemm64r_swiglu(hipStream_t st, const void* wp, const void* xp, int F, int K, int n_wg, void* act_xp,
@@ -2096,6 +2118,7 @@ int lk_gemm64r_init() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gateup_down<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gateup_down<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
     if (e != hipSuccess) return (int)e;
+    if (lk_attn1_init() != 0) return -1;
     g_attr_done = true;
     return 0;
 }
@@ -2245,6 +2268,10 @@ int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* 
     a.nh = nh; a.nkv = nkv; a.max_keys = max_keys; a.nsplit = nsplit;
     a.opart = opart; a.mpart = mpart; a.lpart = lpart;
     a.seq = nullptr; a.nkeys_b = nullptr; a.slot_tiles = 0;
+    // default: the single-launch form (la_attn1.hip); la_debug_set(17, 0) = key splits + combine (the A/B switch, and the carrier of
+    // the idle-window prefetch workgroups)
+    if (g_la_attn_one && !pf_extra(pf) && !g_la_attn_staged)
+        return lk_tree_attn1(st, qf, kmain, vmain, kfresh, vfresh, rowmask, state, nh, nkv, max_keys, attn_xp, window, ring_keys);
     return tree_attn_launch(st, a, 1, attn_xp, pf);
 }
 

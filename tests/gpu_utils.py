@@ -1,5 +1,6 @@
 # -*- coding: utf-8 -*-
 """Helpers for the -m gpu tests: HBM layout index maps (mirrors of csrc/la_common.h) and ctypes plumbing."""
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -103,3 +104,21 @@ def pack_planned(kind, mats, n_wg):
                               n_wg, ptr(out)), 'pack_planned')
     torch.cuda.synchronize()
     return out
+
+
+@contextlib.contextmanager
+def debug_knob(key, value):
+    """la_debug_set(key, value) for the duration of a block (capture-time knobs re-capture the step graphs on both edges)."""
+    old = lib.la_debug_get(key)
+    check(lib.la_debug_set(key, value), 'debug_set')
+    try:
+        yield
+    finally:
+        lib.la_debug_set(key, old)
+
+
+def split_attention():
+    """The single-sequence step with the key-split attention + combine launches (la_debug_set key 17 = 0) — the kernels the
+    cursor-batch step runs — for tests that compare the two paths BITWISE; the default single-launch form sums the keys in
+    another tile order."""
+    return debug_knob(17, 0)

@@ -14,6 +14,7 @@ from painlessinferenceacceleration_amd._lib import check, lib
 from painlessinferenceacceleration_amd.llama_engine import LlamaShape, LlamaVerifyEngine, random_weights
 from painlessinferenceacceleration_amd.lookahead_cache import LookaheadCache
 from painlessinferenceacceleration_amd.modeling_llama_batch import LlamaForCausalLM as BatchLlama
+from tests import gpu_utils as gu
 from tests.gpu_utils import DEV, ptr, random_tree, sp
 from tests.test_gpu_e2e import TOL, _bf16_sd, _check_rows, _mask_from_rows
 from tests.tiny_model import GOLDEN, tiny_shape
@@ -179,9 +180,14 @@ def test_bstep_graph_equals_eager_and_single_sequence_path():
     _, rows = random_tree(rs, 30)
     ids = rs.randint(3, shape.vocab, size=30).astype(np.int32)
     single = LlamaVerifyEngine(shape, sd, max_length=256)
-    single.prefill(prompt)
-    toks1, _ = single.step(ids, rows)
-    ref = single.logits()[:30].clone()
+    with gu.split_attention():                   # the cursor batch runs the key-split attention kernels: compare like with like
+        single.prefill(prompt)
+        toks1, _ = single.step(ids, rows)
+        ref = single.logits()[:30].clone()
+    single.reset()
+    single.prefill(prompt)                       # default (single-launch attention): same tokens, logits a few bf16 ulps apart
+    toks1b, _ = single.step(ids, rows)
+    assert toks1b == toks1 and gu.rel_err(single.logits()[:30].float(), ref.float()) < 1e-2
     outs = []
     for eager in (False, True):
         eng = LlamaVerifyEngine(shape, sd, max_length=256, n_slots=3)

@@ -293,7 +293,7 @@ def test_fused_norm_gemm_launches_are_bitwise_identical_to_separate_kernels():
     _, rows = random_tree(rs, 64)
     ids = rs.randint(3, 32000, size=64).astype(np.int32)
     outs = []
-    for fuse in (0, 3, 1, 2):
+    for fuse in (0, 3, 1, 2, 19, 17, 18):           # bit 4 (16): write-through publish (sc1 stores + drained flag, no release fence)
         eng = LlamaVerifyEngine(shape, random_weights(shape, seed=4, std=0.02, device='cuda:0'), max_length=256, fuse=fuse,
                                 consume_state_dict=True)
         eng.prefill(prompt)
@@ -339,6 +339,12 @@ def test_role_fused_gateup_down_launch_is_bitwise_identical():
 
 
 def test_idle_window_prefetch_is_bitwise_neutral():
+    from tests.gpu_utils import split_attention
+    with split_attention():                      # the prefetch workgroups ride on the combine launch of the key-split form
+        _idle_window_prefetch_is_bitwise_neutral()
+
+
+def _idle_window_prefetch_is_bitwise_neutral():
     """la_debug_set keys 7 / 8 / 9: the gate/up launch's tail loads (down_proj image) and the extra workgroups appended to the row kernels and to the attention combine only READ the next
     GEMM's first k-tiles (planned QKV / gate-up / lm_head images, classic o_proj image).  At the Llama-2-7B layer shape and on the
     tiny model (classic images only) every setting must leave tokens, logits and hidden state bit-identical — graph and eager —
@@ -376,6 +382,12 @@ def test_idle_window_prefetch_is_bitwise_neutral():
 
 
 def test_staged_attention_is_bitwise_identical_end_to_end():
+    from tests.gpu_utils import split_attention
+    with split_attention():                      # key 10 selects between the two key-split forms
+        _staged_attention_is_bitwise_identical_end_to_end()
+
+
+def _staged_attention_is_bitwise_identical_end_to_end():
     """la_debug_set key 10 (K/V tiles staged once per workgroup through LDS instead of twice into registers): tokens, logits and
     hidden state of whole steps must not change by a bit — long prompts (several stages per workgroup), a sliding window on the
     KV ring (ring-slot addressing of the copies), and the cursor batch (a wave whose token block holds no row of a slot still
@@ -460,7 +472,17 @@ def test_sliding_window_attention_extension(window):
     beng = LlamaVerifyEngine(shape, sd, max_length=512, n_slots=2)
     beng.bprefill_many({1: prompt})
     beng.bstep([(1, ids, np.asarray(rows, dtype=np.uint64), 0, 16)])
-    assert torch.equal(beng.logits()[:T], eng.logits()[:T])
+    # the cursor batch runs the key-split attention: bitwise vs the single-sequence step in that form, a few ulps vs the default
+    _check_rows(beng.logits()[:T], eng.logits()[:T], range(T), 'window: cursor batch vs single-launch attention', tol=1e-2)
+    from tests.gpu_utils import split_attention
+    with split_attention():
+        eng.reset()
+        eng.prefill(prompt)
+        eng.step(ids, rows)
+        assert torch.equal(beng.logits()[:T], eng.logits()[:T])
+    eng.reset()
+    eng.prefill(prompt)
+    eng.step(ids, rows)
     # and the window really changes the result
     shape0 = tiny_shape()
     e0 = LlamaVerifyEngine(shape0, sd, max_length=512)

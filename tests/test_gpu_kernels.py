@@ -183,8 +183,9 @@ def test_qkv_post(nh, nkv):
                                                    (2, 2, 5, 8, 3)])
 def test_tree_attention(nh, nkv, nkeys, nsplit, T):
     """softmax(QK^T/sqrt(d) + tree mask) V with a mask-free prefix: tolerance 2e-2 relative to max|out|
-    (bf16 P and bf16 output rounding) against an fp32 torch attention over the same bf16 inputs.  Both forms of the kernel —
-    K/V tiles straight into registers, and staged once per workgroup through LDS (la_debug_set key 10) — must agree BITWISE
+    (bf16 P and bf16 output rounding) against an fp32 torch attention over the same bf16 inputs.  Checked form: the single-launch
+    kernel (la_attn1.hip, the default of the single-sequence step; la_debug_set key 17).  The two key-split forms behind it —
+    K/V tiles straight into registers, and staged once per workgroup through LDS (key 10) — must agree BITWISE with each other
     (partials and packed output): same arithmetic in the same order, only the way the tiles reach the MFMA operands differs."""
     rs = np.random.RandomState(nkeys + T)
     g = torch.Generator(device=DEV).manual_seed(nkeys)
@@ -208,10 +209,12 @@ def test_tree_attention(nh, nkv, nkeys, nsplit, T):
     mpart = torch.zeros(nh * nsplit * 64, dtype=torch.float32, device=DEV)
     lpart = torch.zeros_like(mpart)
     out = torch.zeros(64 * nh * 128, dtype=torch.bfloat16, device=DEV)
-    default_form = lib.la_debug_get(10)
+    default_form, default_one = lib.la_debug_get(10), lib.la_debug_get(17)
     forms = []
     try:
-        for staged in (0, 1):
+        # (single launch, -), (key splits + combine, direct), (key splits + combine, staged through LDS)
+        for one, staged in ((1, 0), (0, 0), (0, 1)):
+            check(lib.la_debug_set(17, one), 'debug_set')
             check(lib.la_debug_set(10, staged), 'debug_set')
             for t in (opart, mpart, lpart, out):
                 t.zero_()
@@ -221,8 +224,14 @@ def test_tree_attention(nh, nkv, nkeys, nsplit, T):
             forms.append((opart.clone(), mpart.clone(), lpart.clone(), out.clone()))
     finally:
         lib.la_debug_set(10, default_form)
-    for a_, b_ in zip(forms[0], forms[1]):
+        lib.la_debug_set(17, default_one)
+    for a_, b_ in zip(forms[1], forms[2]):
         assert torch.equal(a_, b_)
+    assert float(forms[0][0].abs().max()) == 0.0, 'the single-launch form writes no split partials'
+    # single launch vs key splits: the same per-(row, key) arithmetic summed in another tile order -> a few bf16 ulps apart
+    one_, split_ = (gu.from_packed(f[3], gu.xp_index(nh * 128)).float().view(64, nh, 128)[:T] for f in (forms[0], forms[1]))
+    assert gu.rel_err(one_, split_) < 1e-2, gu.rel_err(one_, split_)
+    out = forms[0][3]
     got = gu.from_packed(out, gu.xp_index(nh * 128)).float().view(64, nh, 128)
     rep = nh // nkv
     K = torch.cat([kmain[:, :nkeys], kfr], 1).float().repeat_interleave(rep, 0)       # [nh, nkeys+64, 128]
