@@ -38,7 +38,8 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
                                                      int sl_ring, Attn1Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds1[];      // [Q fragments: 8 KiB][merge buffer]
     const int nh = nh_nkv >> 16, nkv = nh_nkv & 0xffff, G = nh / nkv;
-    const int SL = sl_ring & 255, ring_tiles = sl_ring >> 8;
+    const int SL = sl_ring & 127, ring_tiles = sl_ring >> 8;
+    const bool norot = (sl_ring & 128) != 0;                            // measurement (la_debug_set key 18 bit 0): every sharer starts at tile 0
     const int W = 32 / SL;                                            // token rows this workgroup stores
     const int NS = G * 2 * SL;                                        // workgroups that read the same kv head
     const int b = blockIdx.x;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
     const int key_lo = (window > 0) ? nkeys + __popcll(rm) - 1 - window : 0;
     // this wave's tiles: par, par + 8, ...; the sharers start at different offsets of that list (see the header)
     const int cnt = NT > par ? (NT - par + 7) >> 3 : 0;
-    int idx = cnt > 0 ? (r * cnt) / NS : 0;
+    int idx = (cnt > 0 && !norot) ? (r * cnt) / NS : 0;
 
     auto mtile = [&](int it) -> size_t { return (size_t)(ring_tiles > 0 ? (ts + it) % ring_tiles : ts + it); };
     auto kptr = [&](int it) -> const bf16x8* {
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
         ps += __shfl_xor(ps, 32, 64);
         l = l * alpha + ps;
         m = mn;
+        if (stamp && lane == 0 && stamp[5] == 0) stamp[5] = wall_clock64();      // first tile: scores done, V not yet awaited
         if (__ballot(alpha != 1.0f) != 0ull) {          // a running maximum moved for some row: rescale (x * 1.0f is exact, so skipping is too)
 #pragma unroll
             for (int db = 0; db < 4; ++db)
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
 }
 
 extern long long* g_la_dbg_times;
+int g_la_attn1_var = 0;       // la_debug_set key 18 (measurement): bit 0 = no start rotation, bits 1-2 = force SL (1 -> 1, 2 -> 2, 3 -> 4)
 int g_la_attn_one = 1;        // la_debug_set key 17: 1 = single-launch attention on the single-sequence step (default), 0 = split + combine
 
 static int g_attn1_cus = 0;
@@ -253,12 +256,13 @@ int lk_tree_attn1(hipStream_t st, const void* qf, const void* kmain, const void*
     // token slices per 32-row block: as many workgroups as fit one per CU (nh * 2 * SL <= CUs)
     int SL = 4;
     while (SL > 1 && nh * 2 * SL > g_attn1_cus) SL >>= 1;
+    if ((g_la_attn1_var >> 1) & 3) SL = 1 << (((g_la_attn1_var >> 1) & 3) - 1);
     const int W = 32 / SL;
     Attn1Args a{};
     a.kfresh = (const bf16_t*)kfresh; a.vfresh = (const bf16_t*)vfresh; a.attn_xp = (bf16_t*)attn_xp; a.dbg_times = g_la_dbg_times;
     const size_t lds = 8192 + (size_t)8 * 16 * 2 * W * 16 + (size_t)8 * W * 8;
     k_tree_attn1<<<nh * 2 * SL, 512, lds, st>>>((const bf16_t*)qf, (const unsigned long long*)rowmask, state, (const bf16_t*)kmain,
-                                                (const bf16_t*)vmain, max_keys, (nh << 16) | nkv, window, SL | ((ring_keys >> 5) << 8), a);
+                                                (const bf16_t*)vmain, max_keys, (nh << 16) | nkv, window, SL | ((g_la_attn1_var & 1) << 7) | ((ring_keys >> 5) << 8), a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

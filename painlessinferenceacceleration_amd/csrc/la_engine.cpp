@@ -12,6 +12,7 @@
 #include "la_kernels.h"
 #include "la_mblock.h"
 extern int g_la_pf_kib, g_la_pf_delay, g_la_pf_tail_kib, g_la_graph_epoch, g_la_graph_reps, g_la_mb_ks2;
+int g_la_norm4 = 1;            // la_debug_set key 19: 1 = residual + RMSNorm with four workgroups per row (k_row_norm4) on the single-sequence step
 int g_la_split_head_tail = 0;   // la_debug_set key 14: 1 = separate build-inputs / embed / argmax / accept / publish kernels (A/B)
 int g_la_stop_layers = 0;     // la_debug_set key 13 (parity tests): the single-sequence step runs only the first n layers, then the final norm + lm_head
 
@@ -33,6 +34,7 @@ struct la_llama {
     std::vector<long> ex_gu_stride, ex_dn_stride;     // per layer, in bf16 elements
     uint16_t* act_ex;       // [E][64][ffn] packed SwiGLU outputs
     float* slabs_ex;        // [E][down_ks][64][hidden]
+    uint64_t* norm_gran;  // [2 * n_layers][64 rows][4] {tag, partial sum of squares} granules of the k_row_norm4 launches of one step
     int* fuse_cnt;      // [2 * n_layers] hand-over counters of the fused norm->GEMM launches (zeroed every step)
     int fuse;           // bit 0: post-attention norm -> gate/up GEMM, bit 1: input norm of layer l>0 -> QKV GEMM
     la_llama_weights w;
@@ -192,6 +194,7 @@ static size_t carve(la_llama* m, char* base) {
     m->act_ex = cv.take<uint16_t>(c.n_experts > 0 ? (size_t)c.n_experts * 64 * c.ffn : 8);
     m->slabs_ex = cv.take<float>(c.n_experts > 0 ? (size_t)c.n_experts * m->down_ks * 64 * c.hidden : 8);
     m->fuse_cnt = cv.take<int>((size_t)3 * c.n_layers + 8);
+    m->norm_gran = cv.take<uint64_t>((size_t)2 * c.n_layers * 256);
     m->route_w = cv.take<float>((size_t)(c.n_experts > 0 ? c.n_layers : 1) * 64 * LA_MOE_MAX_E);   // kept per layer (parity tests)
     m->mb_max = c.max_blocks > 1 ? c.max_blocks : 0;
     if (m->mb_max) {
@@ -375,6 +378,9 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
     // Idle-window weight prefetch (la_kernels.h, PfDesc): the row kernels and the attention combine carry extra workgroups that
     // pull the first KiB every workgroup of the NEXT GEMM will stream into the L2 of its XCD.  g_la_pf_kib = 0 switches it off.
     const int pf_kib = m->fuse ? 0 : g_la_pf_kib, pf_dly = g_la_pf_delay;
+    // four workgroups per norm row (k_row_norm4): single-sequence step with the fused head kernel (it zeroes the granule words); the
+    // idle-window prefetch workgroups ride on k_row_norm, so the knob (key 7) keeps the one-workgroup form
+    const bool norm4 = g_la_norm4 && !batch && !g_la_split_head_tail && pf_kib == 0 && (c.hidden & 15) == 0;
     auto pf_qkv = [&](int l, PfDesc* d) {
         *d = PfDesc{};
         if (pf_kib > 0 && l < c.n_layers && c.balanced_wg[0] > 0)
@@ -386,7 +392,7 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
     // the separate kernels of rounds 1-2 (A/B measurements)
     if (!batch && !g_la_split_head_tail)
         KCHK(lk_step_head(st, zc_in ? (const int*)zc_in : m->in, m->state, m->pos, m->rowmask, m->ids, m->w.embed, m->layers[0].norm1,
-                          c.hidden, c.rms_eps, m->h, m->xp, cf, &pd));
+                          c.hidden, c.rms_eps, m->h, m->xp, cf, &pd, m->norm_gran, 2 * c.n_layers * 256));
     else
         KCHK(lk_embed_norm(st, m->w.embed, m->ids, m->layers[0].norm1, c.hidden, c.rms_eps, m->h, m->xp, cf, &pd));
     // depth probe (la_debug_set key 13): the first nl layers, then the FINAL norm + lm_head — h / logits after nl layers for the
@@ -473,7 +479,8 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
         } else {
             pd = PfDesc{};
             if (pf_kib > 0 && c.balanced_wg[1] > 0) lk_pf_planned(&pd, L.wgateup, 1, c.ffn, c.hidden, c.balanced_wg[1], pf_kib, pf_dly, nullptr);
-            KCHK(lk_resid_norm(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp, cf, &pd));
+            if (norm4) KCHK(lk_resid_norm4(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp, cf, m->norm_gran + (size_t)(2 * l) * 256));
+            else KCHK(lk_resid_norm(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp, cf, &pd));
             P(KC_GATEUP);
             if ((m->fuse & 4) && (m->down_rb & 0xff) == 2) {
                 // gate/up + down_proj in one launch: the down role's workgroups start as gate/up's exit, with their first weight
@@ -501,7 +508,8 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
                 pd = PfDesc{};
                 if (pf_kib > 0 && c.balanced_wg[2] > 0) lk_pf_planned(&pd, m->w.lm_head, 0, c.vocab, c.hidden, c.balanced_wg[2], pf_kib, pf_dly, nullptr);
             }
-            KCHK(lk_resid_norm(st, m->h, m->slabs, m->down_ks, nw, c.hidden, c.rms_eps, m->xp, cf, &pd));
+            if (norm4) KCHK(lk_resid_norm4(st, m->h, m->slabs, m->down_ks, nw, c.hidden, c.rms_eps, m->xp, cf, m->norm_gran + (size_t)(2 * l + 1) * 256));
+            else KCHK(lk_resid_norm(st, m->h, m->slabs, m->down_ks, nw, c.hidden, c.rms_eps, m->xp, cf, &pd));
         }
     }
     P(KC_LMHEAD);

@@ -48,7 +48,9 @@ int lk_gemm64_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int nk
 void lk_qkv_row_perm(int nh, int nkv, int* perm);
 int lk_gemm64r_init();
 int lk_step_head(hipStream_t st, const int* in, int* state, int* pos, uint64_t* rowmask, int* ids, const void* embed, const void* nw,
-                 int hidden, float eps, void* h, void* xp, int cast_first, const PfDesc* pf);
+                 int hidden, float eps, void* h, void* xp, int cast_first, const PfDesc* pf, uint64_t* gran = nullptr, int n_gran = 0);
+int lk_resid_norm4(hipStream_t st, void* h, const float* slabs, int n_slabs, const void* nw, int hidden, float eps, void* xp,
+                   int cast_first, uint64_t* gran);
 int lk_step_tail(hipStream_t st, const float* cv, const int* ci, int n_tiles, const int* ids, const uint64_t* rowmask, int* state,
                  int* host_out);
 int lk_gateup_down(hipStream_t st, const void* wgu, const void* xp, int F, int K, int n_wg, void* act_xp, const void* wdown, int N,

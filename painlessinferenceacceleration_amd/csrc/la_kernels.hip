@@ -283,6 +283,97 @@ __global__ __launch_bounds__(512) void k_row_norm(const bf16_t* __restrict__ emb
                            xp, addend, wrouter, n_experts, top_k, route_w, n_rows, cast_first);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Residual add + RMSNorm with FOUR workgroups per token row (round 4).  k_row_norm gives a row to one workgroup: 64 CUs each
+// pull 80 KiB (4 fp32 slabs + residual + weight) through a memory path that holds ~16 KiB in flight — five round trips while
+// 192 CUs idle (5.3 us per launch, twice per layer).  Here workgroup (t, q) owns a QUARTER of row t: one round trip, then the four
+// quarter sums of squares meet through 8-byte {tag, value} granules (one sc1 store each, polled by one wave with sc1 loads:
+// MI355X_MICROARCH.md handoff-1to1 / Guideline 16 R2 — the data is the flag, no fence on either side) and every workgroup
+// normalises its own quarter.  The four partials are added in the fixed order q = 0..3: deterministic, but a different summation
+// order than k_row_norm's (the rsqrt argument may differ in its last bit).  Granule words are used ONCE per step (one slot per
+// norm of the step, zeroed by k_step_head), so the tag is a constant 1.
+//   LlamaRMSNorm (modeling_llama.py:76-90) + the residual adds of LlamaDecoderLayer (:352-363).
+// ---------------------------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(256) void k_row_norm4(bf16_t* __restrict__ h, const float* __restrict__ slabs, const bf16_t* __restrict__ nw,
+                                                    int hidden, float eps, bf16_t* __restrict__ xp, unsigned long long* gran, int cast_first) {
+    __shared__ float sh[4];
+    __shared__ float tot_s;
+    const int t = blockIdx.x >> 2, q = blockIdx.x & 3;
+    const int quarter = hidden >> 2, nchunk = quarter >> 2;           // 4-element chunks of this quarter (<= 512: hidden <= 8192)
+    const int e0 = q * quarter;
+    bf16x4 hv[2], wv[2];
+    f32x4 sl[NS][2];
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 256;
+        if (c < nchunk) {
+            const int e = e0 + c * 4;
+            hv[ci] = *(const bf16x4*)(h + (size_t)t * hidden + e);
+            wv[ci] = *(const bf16x4*)(nw + e);
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) sl[s2][ci] = *(const f32x4*)(slabs + ((size_t)s2 * LA_TB + t) * hidden + e);
+        }
+    }
+    float vals[2][4];
+    float ss = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 256;
+        if (c < nchunk) {
+            bf16x4 ho;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float add = 0.f;
+#pragma unroll
+                for (int s2 = 0; s2 < NS; ++s2) add += sl[s2][ci][j];
+                const float v = bfr(bf2f((bf16_t)hv[ci][j]) + bfr(add));
+                vals[ci][j] = v;
+                ho[j] = (short)f2bf(v);
+                ss += v * v;
+            }
+            *(bf16x4*)(h + (size_t)t * hidden + e0 + c * 4) = ho;
+        }
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        unsigned long long* g = gran + (size_t)t * 4;
+        if (threadIdx.x == 0) {
+            const float part = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+            __hip_atomic_store(g + q, (1ull << 32) | (unsigned long long)__float_as_uint(part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // lanes 0..3 poll the four granules of the row (the other lanes idle); bounded: ~1 s of polling aborts the launch
+        unsigned long long x = 0ull;
+        unsigned spins = 0;
+        while (true) {
+            if (threadIdx.x < 4) x = __hip_atomic_load(g + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot(threadIdx.x < 4 && (x >> 32) != 1ull) == 0ull) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 22)) __builtin_trap();
+        }
+        const float p = __uint_as_float((unsigned)x);
+        const float p0 = __shfl(p, 0, 64), p1 = __shfl(p, 1, 64), p2 = __shfl(p, 2, 64), p3 = __shfl(p, 3, 64);
+        if (threadIdx.x == 0) tot_s = ((p0 + p1) + p2) + p3;
+    }
+    __syncthreads();
+    const float rs = 1.0f / sqrtf(tot_s / (float)hidden + eps);
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci) {
+        const int c = threadIdx.x + ci * 256;
+        if (c < nchunk) {
+            bf16x4 xo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float nv = cast_first ? bfr(vals[ci][j] * rs) : vals[ci][j] * rs;
+                xo[j] = (short)f2bf(bf2f((bf16_t)wv[ci][j]) * nv);
+            }
+            *(bf16x4*)(xp + xp_offset(t, e0 + c * 4)) = xo;
+        }
+    }
+}
+
 // Step head (single-sequence step): k_build_tree_inputs + the embedding row kernel in ONE launch.  Workgroup t expands its own
 // row of the step input (ids / 64-bit ancestor mask / position = committed keys + popcount - 1, the model hook of
 // modeling_llama.py:584-588; pad rows t >= T see themselves only) straight from the caller's input block — the zero-copy pinned
@@ -291,10 +382,12 @@ __global__ __launch_bounds__(512) void k_step_head(const int* __restrict__ in, i
                                                     unsigned long long* __restrict__ rowmask, int* __restrict__ ids,
                                                     const bf16_t* __restrict__ embed, bf16_t* __restrict__ h,
                                                     const bf16_t* __restrict__ nw, int hidden, float eps, bf16_t* __restrict__ xp,
-                                                    int cast_first, PfDesc pf) {
+                                                    int cast_first, PfDesc pf, unsigned long long* gran, int n_gran) {
     __shared__ float sh[8];
     if (blockIdx.x >= LA_TB) { pf_body(pf, (int)blockIdx.x - LA_TB); return; }
     const int t = blockIdx.x;
+    // the granule words of this step's k_row_norm4 launches (each used once per step): zeroed here, a kernel boundary ahead of their first use
+    for (int i = t * 512 + (int)threadIdx.x; i < n_gran; i += LA_TB * 512) gran[i] = 0ull;
     const int T = in[LA_IN_T];
     const unsigned long long rm = (t < T) ? ((const unsigned long long*)(in + LA_IN_ROWMASK))[t] : (1ull << t);
     const int id = (t < T) ? in[LA_IN_IDS + t] : 0;
@@ -1651,10 +1744,21 @@ __global__ __launch_bounds__(1024) void k_step_tail(const float* __restrict__ cv
     const int tok = threadIdx.x & 63, part = threadIdx.x >> 6;
     float best = -INFINITY;
     int bidx = 0x7fffffff;
-    for (int i = part; i < n_tiles; i += 16) {
-        const float v = cv[(size_t)i * LA_TB + tok];
-        const int idx = ci[(size_t)i * LA_TB + tok];
-        if (v > best || (v == best && idx < bidx)) { best = v; bidx = idx; }
+    // 16 candidates per thread and round, ALL requested before the first compare: one memory round trip for the 256 lm_head
+    // workgroups' candidates instead of one per candidate (a rolled loop waits for each pair: 16 dependent round trips, ~10 us)
+    for (int base = 0; base < n_tiles; base += 256) {
+        float vv[16];
+        int ii[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = base + part + 16 * k;
+            const int ic = i < n_tiles ? i : n_tiles - 1;                 // clamped re-read of the last tile: never wins a strict compare
+            vv[k] = cv[(size_t)ic * LA_TB + tok];
+            ii[k] = ci[(size_t)ic * LA_TB + tok];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (vv[k] > best || (vv[k] == best && ii[k] < bidx)) { best = vv[k]; bidx = ii[k]; }
     }
     sv[part][tok] = best; si[part][tok] = bidx;
     __syncthreads();
@@ -2338,10 +2442,23 @@ int lk_moe_accum_all(hipStream_t st, const float* slabs0, long slab_stride, int 
     LAUNCH_CHECK(); return 0;
 }
 int lk_step_head(hipStream_t st, const int* in, int* state, int* pos, uint64_t* rowmask, int* ids, const void* embed, const void* nw,
-                 int hidden, float eps, void* h, void* xp, int cast_first, const PfDesc* pf) {
+                 int hidden, float eps, void* h, void* xp, int cast_first, const PfDesc* pf, uint64_t* gran, int n_gran) {
     if (hidden > 8192 || (hidden & 7)) return -1;
     k_step_head<<<LA_TB + pf_extra(pf), 512, 0, st>>>(in, state, pos, (unsigned long long*)rowmask, ids, (const bf16_t*)embed, (bf16_t*)h,
-                                                      (const bf16_t*)nw, hidden, eps, (bf16_t*)xp, cast_first, pf_or_none(pf));
+                                                      (const bf16_t*)nw, hidden, eps, (bf16_t*)xp, cast_first, pf_or_none(pf),
+                                                      (unsigned long long*)gran, gran ? n_gran : 0);
+    LAUNCH_CHECK(); return 0;
+}
+// residual + RMSNorm, four workgroups per row (k_row_norm4): gran = 256 zeroed granule words owned by THIS launch of the step
+int lk_resid_norm4(hipStream_t st, void* h, const float* slabs, int n_slabs, const void* nw, int hidden, float eps, void* xp,
+                   int cast_first, uint64_t* gran) {
+    if (hidden > 8192 || (hidden & 15) || !gran) return -1;
+#define RN4(NS) k_row_norm4<NS><<<LA_TB * 4, 256, 0, st>>>((bf16_t*)h, slabs, (const bf16_t*)nw, hidden, eps, (bf16_t*)xp, (unsigned long long*)gran, cast_first)
+    switch (n_slabs) {
+        case 1: RN4(1); break; case 2: RN4(2); break; case 3: RN4(3); break; case 4: RN4(4); break; case 6: RN4(6); break; case 8: RN4(8); break;
+        default: return -1;
+    }
+#undef RN4
     LAUNCH_CHECK(); return 0;
 }
 // cv / ci: [n_tiles][64] candidates (one per lm_head workgroup and token); host_out: pinned result block or null

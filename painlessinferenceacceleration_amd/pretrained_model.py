@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from .lookahead_cache import LookaheadCache
-from .lookahead_generation_utils import GenerationMode, LookaheadDecoderOnlyOutput
+from .lookahead_generation_utils import GenerationMode, LookaheadDecoderOnlyOutput, resolve_generate_args
 
 _ONE = np.array([1], dtype=np.uint64)
 
@@ -353,7 +353,8 @@ class LookaheadPreTrainedModel(object):
 
     # ---------------------------------------------------------------------------------- plain greedy (mode off)
     @torch.no_grad()
-    def greedy_search(self, input_ids, max_length, eos_token_id=None, logits_processor=None, do_sample=False):
+    def greedy_search(self, input_ids, max_length, eos_token_id=None, logits_processor=None, do_sample=False,
+                      stopping_criteria=None):
         """Plain decoding through the same engine (T=1 blocks): the `use_lookahead=False` leg of the reference's
         examples (examples/llama_example.py:39-69).  With a processor list or sampling each token is picked on the host
         from the block's logits row (forward-only step + commit)."""
@@ -362,6 +363,7 @@ class LookaheadPreTrainedModel(object):
         eng = self.engine
         eng.reset()
         host_pick = do_sample or (logits_processor is not None and len(logits_processor) > 0)
+        custom_stop = _custom_stop(stopping_criteria)        # the caller's criteria besides the length bound, once per token
 
         def pick(row):
             ctx = torch.tensor([seq], dtype=torch.long, device=eng.device)
@@ -376,7 +378,7 @@ class LookaheadPreTrainedModel(object):
         if host_pick:
             tok = pick((len(seq) - 1) % 64)
         seq.append(tok)
-        while len(seq) < max_length and tok not in eos:
+        while len(seq) < max_length and tok not in eos and not (custom_stop is not None and custom_stop(seq, input_ids.device)):
             if host_pick:
                 eng.verify_only(np.asarray([tok], dtype=np.int32), _ONE)
                 tok = pick(0)
@@ -395,47 +397,44 @@ class LookaheadPreTrainedModel(object):
             return GenerationMode.LOOKAHEAD_GENERATION
         return GenerationMode.GREEDY_SEARCH
 
-    def generate(self, input_ids=None, attention_mask=None, max_length=None, max_new_tokens=None,
-                 decoding_kwargs=None, eos_token_id=None, pad_token_id=None, return_dict_in_generate=False,
-                 streamer=None, do_sample=False, repetition_penalty=1.0, **unused):
-        """Minimal generate(): the arguments the reference's examples/benchmarks pass
-        (benchmarks/benchmark.py:282-300, examples/llama_example.py:51-60)."""
-        gcfg = unused.get('generation_config', None)       # GenerationConfig / LookaheadGenerationConfig object
-        if gcfg is not None:
-            max_new_tokens = max_new_tokens if max_new_tokens is not None else getattr(gcfg, 'max_new_tokens', None)
-            if max_length is None and max_new_tokens is None:
-                max_length = getattr(gcfg, 'max_length', None)
-            eos_token_id = eos_token_id if eos_token_id is not None else getattr(gcfg, 'eos_token_id', None)
-            pad_token_id = pad_token_id if pad_token_id is not None else getattr(gcfg, 'pad_token_id', None)
-            do_sample = do_sample or bool(getattr(gcfg, 'do_sample', False))
-            if repetition_penalty == 1.0:
-                repetition_penalty = float(getattr(gcfg, 'repetition_penalty', 1.0) or 1.0)
-            if decoding_kwargs is None:                    # lookahead_generation_utils.py:19-29
-                if hasattr(gcfg, 'to_decoding_kwargs'):
-                    decoding_kwargs = gcfg.to_decoding_kwargs()
-                else:
-                    decoding_kwargs = dict(getattr(gcfg, 'decoding_kwargs', {}) or {})
-                    for k in ('use_lookahead', 'debug_lookahead', 'decoding_length', 'branch_length', 'decoding_mode'):
-                        if hasattr(gcfg, k):
-                            decoding_kwargs.setdefault(k, getattr(gcfg, k))
-        if max_length is None:
-            max_length = input_ids.size(1) + (max_new_tokens if max_new_tokens is not None else 20)
-        dk = dict(decoding_kwargs or {})
-        processors = unused.get('logits_processor', None)
-        if repetition_penalty != 1.0:                      # what generate() builds from repetition_penalty
-            from transformers import LogitsProcessorList, RepetitionPenaltyLogitsProcessor
-            processors = LogitsProcessorList(list(processors or []) + [RepetitionPenaltyLogitsProcessor(penalty=repetition_penalty)])
+    def generate(self, inputs=None, generation_config=None, logits_processor=None, stopping_criteria=None,
+                 prefix_allowed_tokens_fn=None, synced_gpus=None, assistant_model=None, streamer=None, **kwargs):
+        """generate() with the reference's signature (common/pretrained_model.py:110-121) for the two modes this package serves —
+        lookahead and plain greedy / sampling through the same engine.  Everything the reference derives before it dispatches is
+        derived the same way (lookahead_generation_utils.resolve_generate_args): keyword > generation_config > model defaults,
+        config-derived logits processors (repetition_penalty, no_repeat_ngram_size, bad_words_ids, min_length, min_new_tokens)
+        with the caller's `logits_processor` merged behind them, MaxLengthCriteria / MaxTimeCriteria with the caller's
+        `stopping_criteria` merged behind them; the lookahead branch receives processors + criteria and no warper, exactly as
+        :428-441; temperature / top_k / top_p act in the sampling mode (`do_sample` without lookahead, :465-479).
+        Call shapes of the reference's own callers work unchanged: examples/llama_example.py:51-60,
+        benchmarks/benchmark.py:282-300."""
+        if prefix_allowed_tokens_fn is not None or assistant_model is not None:
+            raise NotImplementedError('prefix_allowed_tokens_fn / assistant_model: outside the lookahead path (SURVEY section 2, out of scope)')
+        input_ids = inputs if inputs is not None else kwargs.pop('input_ids', None)
+        kwargs.pop('input_ids', None)
+        if input_ids is None:
+            raise ValueError('generate() needs input_ids')
+        ga, model_kwargs = resolve_generate_args(self.generation_config, input_ids.size(1), generation_config=generation_config,
+                                                 logits_processor=logits_processor, stopping_criteria=stopping_criteria, **kwargs)
+        attention_mask = model_kwargs.pop('attention_mask', None)
+        dk = ga.decoding_kwargs
+        if streamer is not None:
+            pass                                             # the loops feed the streamer themselves (prompt first, :318-319)
         if self._get_generation_mode(dk) == GenerationMode.LOOKAHEAD_GENERATION:
             dk['generation_mode'] = GenerationMode.LOOKAHEAD_GENERATION
-            dk['do_sample'] = bool(do_sample)
-            return self.lookahead_generation(input_ids, logits_processor=processors, stopping_criteria=int(max_length),
-                                             pad_token_id=pad_token_id,
-                                             eos_token_id=eos_token_id, return_dict_in_generate=return_dict_in_generate,
+            dk['do_sample'] = ga.do_sample
+            return self.lookahead_generation(input_ids, logits_processor=ga.logits_processor if len(ga.logits_processor) else None,
+                                             stopping_criteria=ga.stopping_criteria, pad_token_id=ga.pad_token_id,
+                                             eos_token_id=ga.eos_token_id, output_scores=ga.output_scores or None,
+                                             return_dict_in_generate=ga.return_dict_in_generate,
                                              streamer=streamer, attention_mask=attention_mask, decoding_kwargs=dk)
-        out = self.greedy_search(input_ids, max_length, eos_token_id if eos_token_id is not None
+        from transformers import LogitsProcessorList
+        procs = LogitsProcessorList(list(ga.logits_processor) + list(ga.logits_warper))
+        out = self.greedy_search(input_ids, ga.max_length, ga.eos_token_id if ga.eos_token_id is not None
                                  else getattr(self.generation_config, 'eos_token_id', None),
-                                 logits_processor=processors, do_sample=do_sample)
-        return LookaheadDecoderOnlyOutput(sequences=out, kwargs={}) if return_dict_in_generate else out
+                                 logits_processor=procs if len(procs) else None, do_sample=ga.do_sample,
+                                 stopping_criteria=ga.stopping_criteria)
+        return LookaheadDecoderOnlyOutput(sequences=out, kwargs={}) if ga.return_dict_in_generate else out
 
     def stream_generate(self, *args, **kwargs):
         """pretrained_model.py:1323-1350: run generate() on a worker thread, yield from the streamer."""

@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from .lookahead_cache import LookaheadCache
-from .lookahead_generation_utils import LookaheadDecoderOnlyOutput
+from .lookahead_generation_utils import LookaheadDecoderOnlyOutput, resolve_generate_args
 from .pretrained_model import _custom_stop, _max_length_of
 
 _ONE = np.array([1], dtype=np.uint64)
@@ -405,29 +405,33 @@ class LookaheadPreTrainedModel(object):
             seqs[b, :len(rows[b])] = rows[b]
         return torch.from_numpy(seqs).to(input_ids.device)
 
-    def generate(self, input_ids=None, attention_mask=None, max_length=None, max_new_tokens=None,
-                 decoding_kwargs=None, eos_token_id=None, pad_token_id=None, return_dict_in_generate=False,
-                 streamer=None, do_sample=False, repetition_penalty=1.0, **unused):
-        """The keyword surface of the reference's examples.  repetition_penalty != 1 / logits_processor= / do_sample take the
+    def generate(self, inputs=None, generation_config=None, logits_processor=None, stopping_criteria=None,
+                 prefix_allowed_tokens_fn=None, synced_gpus=None, assistant_model=None, streamer=None, **kwargs):
+        """generate() with the reference's signature (common/pretrained_model_batch.py generate, same front half as
+        pretrained_model.py:110-372): see LookaheadPreTrainedModel.generate of pretrained_model.py here — one resolver
+        (lookahead_generation_utils.resolve_generate_args) serves both.  A non-empty processor list / do_sample take the
         sequential accept path (host-side token pick), everything else stays on the device."""
-        gcfg = self.generation_config
-        do_sample = do_sample or bool(getattr(gcfg, 'do_sample', False)) if gcfg is not None else do_sample
-        if max_length is None:
-            max_length = input_ids.size(1) + (max_new_tokens if max_new_tokens is not None else 20)
-        processors = unused.get('logits_processor', None)
-        if repetition_penalty is not None and repetition_penalty != 1.0:
-            from transformers import LogitsProcessorList, RepetitionPenaltyLogitsProcessor
-            processors = LogitsProcessorList(list(processors or []) + [RepetitionPenaltyLogitsProcessor(penalty=repetition_penalty)])
-        dk = dict(decoding_kwargs or {})
+        if prefix_allowed_tokens_fn is not None or assistant_model is not None:
+            raise NotImplementedError('prefix_allowed_tokens_fn / assistant_model: outside the lookahead path (SURVEY section 2, out of scope)')
+        input_ids = inputs if inputs is not None else kwargs.pop('input_ids', None)
+        kwargs.pop('input_ids', None)
+        if input_ids is None:
+            raise ValueError('generate() needs input_ids')
+        ga, model_kwargs = resolve_generate_args(self.generation_config, input_ids.size(1), generation_config=generation_config,
+                                                 logits_processor=logits_processor, stopping_criteria=stopping_criteria, **kwargs)
+        attention_mask = model_kwargs.pop('attention_mask', None)
+        dk = ga.decoding_kwargs
         if dk.get('use_lookahead', False) and dk.get('decoding_length', 64) > 1 and dk.get('branch_length', 12) > 0:
-            dk['do_sample'] = bool(do_sample)
-            return self.lookahead_generation(input_ids, logits_processor=processors, stopping_criteria=int(max_length),
-                                             pad_token_id=pad_token_id, eos_token_id=eos_token_id,
-                                             return_dict_in_generate=return_dict_in_generate,
+            dk['do_sample'] = ga.do_sample
+            return self.lookahead_generation(input_ids, logits_processor=ga.logits_processor if len(ga.logits_processor) else None,
+                                             stopping_criteria=ga.stopping_criteria, pad_token_id=ga.pad_token_id,
+                                             eos_token_id=ga.eos_token_id, return_dict_in_generate=ga.return_dict_in_generate,
                                              streamer=streamer, attention_mask=attention_mask, decoding_kwargs=dk)
-        out = self.greedy_search(input_ids, max_length, attention_mask=attention_mask,
-                                 eos_token_id=eos_token_id if eos_token_id is not None
+        from transformers import LogitsProcessorList
+        procs = LogitsProcessorList(list(ga.logits_processor) + list(ga.logits_warper))
+        out = self.greedy_search(input_ids, ga.max_length, attention_mask=attention_mask,
+                                 eos_token_id=ga.eos_token_id if ga.eos_token_id is not None
                                  else getattr(self.generation_config, 'eos_token_id', None),
-                                 pad_token_id=pad_token_id if pad_token_id is not None else 0,
-                                 logits_processor=processors, do_sample=do_sample)
-        return LookaheadDecoderOnlyOutput(sequences=out, kwargs={}) if return_dict_in_generate else out
+                                 pad_token_id=ga.pad_token_id if ga.pad_token_id is not None else 0,
+                                 logits_processor=procs if len(procs) else None, do_sample=ga.do_sample)
+        return LookaheadDecoderOnlyOutput(sequences=out, kwargs={}) if ga.return_dict_in_generate else out

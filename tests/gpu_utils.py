@@ -117,8 +117,10 @@ def debug_knob(key, value):
         lib.la_debug_set(key, old)
 
 
+@contextlib.contextmanager
 def split_attention():
-    """The single-sequence step with the key-split attention + combine launches (la_debug_set key 17 = 0) — the kernels the
-    cursor-batch step runs — for tests that compare the two paths BITWISE; the default single-launch form sums the keys in
-    another tile order."""
-    return debug_knob(17, 0)
+    """The single-sequence step on the kernels the cursor-batch step runs — key-split attention + combine launches (la_debug_set
+    key 17 = 0) and one workgroup per norm row (key 19 = 0) — for tests that compare two paths BITWISE; the defaults (single-launch
+    attention, four workgroups per norm row) sum keys / squares in another order."""
+    with debug_knob(17, 0), debug_knob(19, 0):
+        yield

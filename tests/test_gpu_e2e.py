@@ -284,6 +284,12 @@ def test_sequential_processor_path_on_device():
 
 
 def test_fused_norm_gemm_launches_are_bitwise_identical_to_separate_kernels():
+    from tests.gpu_utils import debug_knob
+    with debug_knob(19, 0):                      # the fused producers run the one-workgroup row stage: compare with that form
+        _fused_norm_gemm_launches_are_bitwise_identical_to_separate_kernels()
+
+
+def _fused_norm_gemm_launches_are_bitwise_identical_to_separate_kernels():
     """cfg.fuse: the residual + RMSNorm row stage running inside the gate/up and QKV launches (producer workgroups +
     in-kernel hand-over) must reproduce the separate-kernel path bit for bit: logits, accepted tokens, hidden state."""
     from painlessinferenceacceleration_amd.llama_engine import random_weights

@@ -1,6 +1,7 @@
 # -*- coding: utf-8 -*-
 """CPU: host logic of pretrained_model.lookahead_generation / greedy_search / generate on an oracle-backed engine,
 against the reference's golden run (fp32: token-exact) and against plain greedy."""
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -276,6 +277,78 @@ def test_generate_called_like_the_reference_example():
                                     eos_token_id=2, pad_token_id=2)
     out = m.generate(input_ids=input_ids, generation_config=cfg)
     assert out[0, input_ids.size(-1):].tolist()[:len(outs[0])] == outs[0]
+
+
+def test_generate_forwards_what_the_reference_generate_builds():
+    """generate() front door == the reference's (common/pretrained_model.py:349-372, 403, 428-441): config-derived processors +
+    the caller's logits_processor list, MaxLengthCriteria + the caller's stopping_criteria, both handed to the lookahead loop;
+    warpers (temperature / top_k / top_p) only in the sampling mode.  Called the way examples/llama_example.py:51-60 and
+    benchmarks/benchmark.py:282-300 call it, plus the two list arguments."""
+    from transformers import (LogitsProcessorList, MaxLengthCriteria, NoRepeatNGramLogitsProcessor, RepetitionPenaltyLogitsProcessor,
+                              StoppingCriteria, StoppingCriteriaList)
+    from painlessinferenceacceleration_amd.lookahead_generation_utils import resolve_generate_args
+    g = load_golden('fp32')
+    prompt = g['prompt'].tolist()
+    input_ids = torch.tensor([prompt])
+    ref_seq = g['r0_sequences'].tolist()
+    stop_tok = ref_seq[len(prompt) + 17]                     # a token the plain run emits: generation must end right there
+
+    class StopOnToken(StoppingCriteria):
+        def __init__(self):
+            self.calls = 0
+
+        def __call__(self, input_ids, scores, **kw):
+            self.calls += 1
+            return bool((input_ids[0, len(prompt):] == stop_tok).any())
+
+    # (1) user stopping_criteria reaches the lookahead loop through generate(), merged behind the length criterion
+    m = Model(torch.float32)
+    crit = StopOnToken()
+    out = m.generate(input_ids=input_ids, attention_mask=torch.ones_like(input_ids), max_new_tokens=96, eos_token_id=2, pad_token_id=0,
+                     stopping_criteria=StoppingCriteriaList([crit]), decoding_kwargs=dict(DK), return_dict_in_generate=True)
+    seq = out.sequences[0].tolist()
+    first = ref_seq.index(stop_tok, len(prompt))
+    assert crit.calls >= 1 and stop_tok in seq[len(prompt):] and seq[:first + 1] == ref_seq[:first + 1]
+    assert len(seq) <= first + 1 + 13                        # stopped at the verify step that emitted it (<= branch_length + 1 tokens later)
+    direct = Model(torch.float32).lookahead_generation(input_ids, stopping_criteria=StoppingCriteriaList(
+        [MaxLengthCriteria(max_length=len(prompt) + 96), StopOnToken()]), eos_token_id=2, pad_token_id=0,
+        return_dict_in_generate=True, decoding_kwargs=dict(DK))
+    assert direct.sequences[0].tolist() == seq and direct.kwargs['dls'] == out.kwargs['dls']
+    # ... and the plain mode honours it too
+    plain = Model(torch.float32).generate(input_ids=input_ids, max_new_tokens=96, eos_token_id=2, stopping_criteria=StoppingCriteriaList([StopOnToken()]),
+                                          decoding_kwargs={'use_lookahead': False})
+    assert plain[0].tolist() == ref_seq[:first + 1]
+    # (2) repetition_penalty + no_repeat_ngram_size (config-derived) + a user processor list: the same processors, in transformers'
+    # order, as a direct lookahead_generation call; a duplicate type is refused as transformers refuses it
+    class Bias(torch.nn.Module):
+        def forward(self, ids, scores):
+            scores = scores.clone(); scores[:, 7] += 0.25
+            return scores
+
+    bias = Bias()
+    a = Model(torch.float32).generate(input_ids=input_ids, max_new_tokens=48, eos_token_id=2, repetition_penalty=1.3, no_repeat_ngram_size=3,
+                                      logits_processor=LogitsProcessorList([bias]), decoding_kwargs=dict(DK))
+    procs = LogitsProcessorList([RepetitionPenaltyLogitsProcessor(1.3), NoRepeatNGramLogitsProcessor(3), bias])
+    b = Model(torch.float32).lookahead_generation(input_ids, logits_processor=procs, stopping_criteria=len(prompt) + 48, eos_token_id=2,
+                                                  decoding_kwargs=dict(DK))
+    assert a[0].tolist() == b[0].tolist()
+    with pytest.raises(ValueError):
+        Model(torch.float32).generate(input_ids=input_ids, max_new_tokens=8, repetition_penalty=1.3,
+                                      logits_processor=LogitsProcessorList([RepetitionPenaltyLogitsProcessor(1.1)]), decoding_kwargs=dict(DK))
+    # (3) resolver: precedence keyword > generation_config > model defaults; warpers only for do_sample; pad defaults to eos
+    cfg = SimpleNamespace(max_new_tokens=5, temperature=0.7, top_k=50, top_p=0.9, do_sample=True, eos_token_id=[2, 9])
+    ga, rest = resolve_generate_args(SimpleNamespace(eos_token_id=2, pad_token_id=None, repetition_penalty=1.1), 10, generation_config=cfg,
+                                     max_new_tokens=7, attention_mask='am', use_cache=True)
+    assert ga.max_length == 17 and ga.eos_token_id == [2, 9] and ga.pad_token_id == 2 and ga.do_sample
+    assert [type(w).__name__ for w in ga.logits_warper] == ['TemperatureLogitsWarper', 'TopKLogitsWarper', 'TopPLogitsWarper']
+    assert [type(w).__name__ for w in ga.logits_processor] == ['RepetitionPenaltyLogitsProcessor']
+    assert [type(c).__name__ for c in ga.stopping_criteria] == ['MaxLengthCriteria'] and rest == {'attention_mask': 'am', 'use_cache': True}
+    ga, _ = resolve_generate_args(None, 10, temperature=0.5, top_k=3)
+    assert len(ga.logits_warper) == 0 and ga.max_length == 30
+    # (4) sampling mode with top_k = 1 is greedy: the warpers act on the plain path
+    s = Model(torch.float32).generate(input_ids=input_ids, max_new_tokens=24, eos_token_id=2, do_sample=True, top_k=1, temperature=0.7,
+                                      decoding_kwargs={'use_lookahead': False})
+    assert s[0].tolist() == ref_seq[:len(prompt) + 24] or s[0].tolist() == g['greedy'].tolist()[:len(prompt) + 24]
 
 
 class DecisiveModel(LookaheadPreTrainedModel):
