@@ -109,7 +109,7 @@ def host_batch_drafts(cache, tails, idxs, DL, BL, ubls):
 def _pf_setting():
     """(KiB per consumer workgroup, start delay, gate/up tail KiB) of the weight prefetch in effect (library default or LA_PF_KIB)."""
     from painlessinferenceacceleration_amd._lib import lib
-    return int(lib.la_debug_get(7)), int(lib.la_debug_get(8)), int(lib.la_debug_get(9))
+    return int(lib.la_lab_get(7)), int(lib.la_lab_get(8)), int(lib.la_lab_get(9))
 
 
 _RDZV_KEYS = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'GROUP_WORLD_SIZE', 'ROLE_RANK', 'ROLE_WORLD_SIZE',
@@ -147,7 +147,7 @@ def self_launch(args_gpus, argv):
     sys.exit(r.returncode)
 
 
-def secondary_legs(spec, gpus=1):
+def secondary_legs(spec, gpus=1, layers=0):
     """The batch configurations (BASELINE configs 3-5) as secondary lines of the default run: each `model:batch` leg is this script
     run again in its own process (`--model M --batch B`, 24 timed steps, no CPU leg) after the headline's timed region; the
     fields a reader needs are kept.  A leg that fails is reported as such — it never touches the headline line."""
@@ -159,6 +159,8 @@ def secondary_legs(spec, gpus=1):
             continue
         model, batch = item.split(':')
         leg_args = ['--gpus', str(gpus), '--model', model, '--batch', batch, '--steps', '24', '--warmup', '4', '--no-cpu-baseline']
+        if layers:                       # launch-path tests only (tests/test_gpu_bench_launch.py): a truncated model, flagged in the leg
+            leg_args += ['--layers', str(int(layers)), '--steps', '6', '--warmup', '2']
         cmd = [sys.executable, os.path.abspath(__file__)] + leg_args if gpus == 1 else self_launch_cmd(leg_args, gpus, _free_port())
         env = clean_rank_env()
         env['BENCH_IS_SECONDARY'] = '1'
@@ -177,7 +179,7 @@ def secondary_legs(spec, gpus=1):
                          'lookahead_equals_greedy': c['lookahead_equals_greedy'], 'context_at_end': c['context_at_end'],
                          'n_gpus': j['n_gpus'], 'gather_mode': c.get('gather_mode'), 'gather_transport': c.get('gather_transport'),
                          'rccl_ranks': c.get('rccl_ranks'),
-                         'roofline': j.get('roofline'), 'wall_s': round(time.time() - t0, 1),
+                         'roofline': j.get('roofline'), 'wall_s': round(time.time() - t0, 1), 'n_layers': c.get('n_layers'),
                          'command': 'python bench.py --gpus %d --model %s --batch %s --steps 24 --warmup 4 --no-cpu-baseline' % (gpus, model, batch)})
         except Exception as e:           # noqa: BLE001 — a secondary leg must never take the headline line down
             legs.append({'model': model, 'batch': int(batch), 'error': repr(e)[:300], 'wall_s': round(time.time() - t0, 1)})
@@ -256,6 +258,9 @@ def main():
     ap.add_argument('--decoding-length', type=int, default=64, help='tree tokens per sequence and step (BASELINE: 64); > 64 (the reference\'s best '
                     'published setting is 128 with --branch-length 32, lookahead/README.md:100): wide trees through eng.tstep, --batch 1')
     ap.add_argument('--branch-length', type=int, default=12)
+    ap.add_argument('--secondary-layers', type=int, default=0,
+                    help='launch-path tests only: run the secondary legs too although --layers truncates the model, each with this many '
+                         'layers (their lines carry n_layers; such numbers are NOT the metric)')
     ap.add_argument('--secondary-multi', default=None,
                     help='N > 1 default workload only: model:batch legs run as their own N-rank jobs after the headline (default: '
                          '"13b:4" at --gpus 8 = BASELINE config 4, Llama-2-13B bs=32 batch-sharded over 8 GPUs; "" = none)')
@@ -293,17 +298,17 @@ def main():
     # measurement override of the library's idle-window prefetch default (la_debug_set keys 7 / 8 / 9, scripts/gpu_pf_ab.py)
     if os.environ.get('LA_PF_KIB') is not None:
         from painlessinferenceacceleration_amd._lib import check as _check, lib as _lalib
-        _check(_lalib.la_debug_set(7, int(os.environ['LA_PF_KIB'])), 'debug_set')
-        _check(_lalib.la_debug_set(8, int(os.environ.get('LA_PF_DELAY', '0'))), 'debug_set')
-        _check(_lalib.la_debug_set(9, int(os.environ.get('LA_PF_TAIL', '0'))), 'debug_set')
+        _check(_lalib.la_lab_set(7, int(os.environ['LA_PF_KIB'])), 'debug_set')
+        _check(_lalib.la_lab_set(8, int(os.environ.get('LA_PF_DELAY', '0'))), 'debug_set')
+        _check(_lalib.la_lab_set(9, int(os.environ.get('LA_PF_TAIL', '0'))), 'debug_set')
     if os.environ.get('LA_DEBUG'):                       # measurement: any la_debug_set keys, "k=v,k=v" (scripts/gpu_knob_sweep.sh)
         from painlessinferenceacceleration_amd._lib import lib as _lalib, check as _check
         for kv in os.environ['LA_DEBUG'].split(','):
             k, v = kv.split('=')
-            _check(_lalib.la_debug_set(int(k), int(v)), 'debug_set')
+            _check(_lalib.la_lab_set(int(k), int(v)), 'debug_set')
     if os.environ.get('LA_MB_KS2') is not None:          # measurement: 2 K splits for the multi-block slab GEMMs at >= 5 blocks
         from painlessinferenceacceleration_amd._lib import check as _check, lib as _lalib
-        _check(_lalib.la_debug_set(12, int(os.environ['LA_MB_KS2'])), 'debug_set')
+        _check(_lalib.la_lab_set(12, int(os.environ['LA_MB_KS2'])), 'debug_set')
 
     shape = {'7b': LlamaShape.llama2_7b, '13b': LlamaShape.llama2_13b, 'mistral': LlamaShape.mistral_7b,
              'mixtral': LlamaShape.mixtral_8x7b}[args.model]()
@@ -638,13 +643,14 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     secondary = None
-    if world == 1 and B == 1 and args.model == '7b' and not args.layers and args.secondary and not os.environ.get('BENCH_IS_SECONDARY'):
-        secondary = secondary_legs(args.secondary)
+    sec_ok = (not args.layers) or args.secondary_layers > 0
+    if world == 1 and B == 1 and args.model == '7b' and sec_ok and args.secondary and not os.environ.get('BENCH_IS_SECONDARY'):
+        secondary = secondary_legs(args.secondary, layers=args.secondary_layers)
     multi = args.secondary_multi if args.secondary_multi is not None else ('13b:4' if world == 8 else '')
-    if world > 1 and B == 1 and args.model == '7b' and not args.layers and multi and not os.environ.get('BENCH_IS_SECONDARY'):
+    if world > 1 and B == 1 and args.model == '7b' and sec_ok and multi and not os.environ.get('BENCH_IS_SECONDARY'):
         # BASELINE config 4 (and any other listed leg) as its own N-rank job on the same GPUs: the other ranks of this job have
         # left the group and are exiting; 288 GB per GPU hold both models, so nothing has to be freed first
-        secondary = secondary_legs(multi, gpus=world)
+        secondary = secondary_legs(multi, gpus=world, layers=args.secondary_layers)
     gen = accepted_all / max(world, 1)
     out = {
         'metric': 'accepted_tokens_per_sec', 'value': round(accepted_all / elapsed, 2), 'unit': 'tokens/s',

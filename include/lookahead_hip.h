@@ -43,33 +43,14 @@ extern "C" {
 #define LA_MOE_MAX_E      8   /* experts per mixture-of-experts layer (Mixtral: 8, top-2) */
 
 /* ABI version: bumped when a signature changes. */
-#define LA_ABI_VERSION  8    /* bumped whenever a struct layout or an entry point changes */
+#define LA_ABI_VERSION  9    /* bumped whenever a struct layout or an entry point changes */
 int          la_abi_version(void);   /* == LA_ABI_VERSION of the header the library was built from */
 const char*  la_last_error(void);
-/* Measurement knobs for the kernel A/B scripts (scripts/gpu_ab.py); every knob is 0 in production.
- * key 0: GEMM kernels return after the weight-streaming loop, before the cross-wave reduction and epilogue.
- * key 1: K share (1/64ths) of waves 0..3 in the 8-wave GEMMs (0 = library default); set before la_llama_step captures.
- * key 2: s_setprio level (0..3) of waves 4..7 in the 8-wave GEMMs.
- * key 3: 1 = multi-block GEMMs always on the K-split kernels (no wide one-pass form); set before la_llama_mstep captures.
- * key 6: paired form of the wide multi-block launches (two weight regions x half the token blocks per workgroup): bit 0 = slab and
- *        QKV launches (library default: on), bit 1 = gate/up too, bit 2 = quad QKV form, bit 3 = QKV with token quarters at every
- *        block count (what the second QKV image, cfg.qkv_mb_wg, takes by default); bit-identical results; read at launch / capture.
- * key 7: idle-window weight prefetch of the 64-row step, KiB per workgroup of the next GEMM (0 = off, <= 128): the row kernels and
- *        the attention combine carry extra workgroups that pull the first k-tiles of the next GEMM into L2 (bit-identical
- *        results); key 8: start delay of those workgroups in s_sleep(32) rounds; key 9: KiB per down_proj workgroup pulled in from
- *        the tail of the gate/up launch (<= 64).  key 10: form of the tree-attention kernel, 0 = K/V tiles straight into the
- *        registers of both token-block waves, 1 = staged once per workgroup through LDS (LDS-DMA ring); bit-identical results.
- *        Keys 7-10 are read when a step graph is captured (la_llama_step captures again after a change).
- * key 11: the single-sequence step captured n (1..8) times into one graph (measurement of the per-launch cost: none found).
- * key 16: 1 = the gathered multi-block MoE step launches every expert's GEMMs separately and accumulates / normalises in two row
- *         kernels (default 0: one launch per stage, one fused row kernel); 2 = an expert's last single block keeps the padded
- *         two-block pass (default: the one-block body).
- * key 12: multi-block slab GEMMs with 2 K splits over 4 token groups at >= 5 blocks (measured slower; read at graph capture). */
+/* Parity aid (tests/test_gpu_e2e.py, per-depth residual probe): key 13 = n > 0: the single-sequence step runs the first n layers,
+ * then the final norm + lm_head (0 = the whole model).  No other key is accepted here: the measurement knobs and A/B switches of
+ * the kernel lab live behind la_lab_* (include/lookahead_hip_lab.h), which this header does not declare. */
 int          la_debug_set(int key, int value);
-int          la_debug_get(int key);          /* current value of a knob (the library default unless la_debug_set changed it) */
-/* key 0: device buffer int64[workgroups][waves][8] the GEMM kernels stamp with wall_clock64() at entry / end of the
- * streaming loop / exit / half of the loop, plus HW_ID in word 4 (NULL = off). */
-int          la_debug_set_ptr(int key, void* d_ptr);
+int          la_debug_get(int key);
 
 /* ------------------------------------------------------------------------
  * 1. Trie cache (host).  Replaces class LookaheadCache / Tree / Node,

@@ -1,0 +1,47 @@
+/* lookahead_hip_lab.h — the kernel LAB of liblookahead_hip.so: measurement knobs and A/B switches for the scripts under scripts/
+ * and the bitwise-identity tests.  NOT part of the product boundary (include/lookahead_hip.h): nothing a reference maintainer
+ * binds, no stability promise.  Every knob has a library default (la_lab_get reports the value in effect); the step entry points
+ * capture their graphs again after a change.
+ *
+ * Defaults: everything 0 except key 6 = 1 (paired wide launches), key 11 = 1 (one step per graph), key 17 = 1 (single-launch tree
+ * attention), key 19 = 1 (four workgroups per norm row).
+ */
+#ifndef LOOKAHEAD_HIP_LAB_H
+#define LOOKAHEAD_HIP_LAB_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* Measurement knobs for the kernel A/B scripts (scripts/gpu_ab.py); every knob is 0 in production.
+ * key 0: GEMM kernels return after the weight-streaming loop, before the cross-wave reduction and epilogue.
+ * key 1: K share (1/64ths) of waves 0..3 in the 8-wave GEMMs (0 = library default); set before la_llama_step captures.
+ * key 2: s_setprio level (0..3) of waves 4..7 in the 8-wave GEMMs.
+ * key 3: 1 = multi-block GEMMs always on the K-split kernels (no wide one-pass form); set before la_llama_mstep captures.
+ * key 6: paired form of the wide multi-block launches (two weight regions x half the token blocks per workgroup): bit 0 = slab and
+ *        QKV launches (library default: on), bit 1 = gate/up too, bit 2 = quad QKV form, bit 3 = QKV with token quarters at every
+ *        block count (what the second QKV image, cfg.qkv_mb_wg, takes by default); bit-identical results; read at launch / capture.
+ * key 7: idle-window weight prefetch of the 64-row step, KiB per workgroup of the next GEMM (0 = off, <= 128): the row kernels and
+ *        the attention combine carry extra workgroups that pull the first k-tiles of the next GEMM into L2 (bit-identical
+ *        results); key 8: start delay of those workgroups in s_sleep(32) rounds; key 9: KiB per down_proj workgroup pulled in from
+ *        the tail of the gate/up launch (<= 64).  key 10: form of the tree-attention kernel, 0 = K/V tiles straight into the
+ *        registers of both token-block waves, 1 = staged once per workgroup through LDS (LDS-DMA ring); bit-identical results.
+ *        Keys 7-10 are read when a step graph is captured (la_llama_step captures again after a change).
+ * key 11: the single-sequence step captured n (1..8) times into one graph (measurement of the per-launch cost: none found).
+ * key 16: 1 = the gathered multi-block MoE step launches every expert's GEMMs separately and accumulates / normalises in two row
+ *         kernels (default 0: one launch per stage, one fused row kernel); 2 = an expert's last single block keeps the padded
+ *         two-block pass (default: the one-block body).
+ * key 12: multi-block slab GEMMs with 2 K splits over 4 token groups at >= 5 blocks (measured slower; read at graph capture).
+ * key 13: depth probe (also reachable through la_debug_set of the product header).  key 14: 1 = separate build-inputs / embed /
+ *         argmax / accept / publish kernels instead of the fused step head / tail.  key 15: bit 0 = gate/up as 4 waves x 8 tile-sets.
+ * key 17: tree attention of the single-sequence step, 1 = ONE launch (la_attn1.hip, default), 0 = key splits + combine.
+ * key 18: variants of the single-launch attention (measurement): bit 0 = no start rotation, bits 1-2 = forced slice count.
+ * key 19: residual + RMSNorm of the single-sequence step, 1 = four workgroups per row with a granule exchange (k_row_norm4,
+ *         default), 0 = one workgroup per row (k_row_norm). */
+int          la_lab_set(int key, int value);
+int          la_lab_get(int key);          /* current value of a knob (the library default unless la_lab_set changed it) */
+/* key 0: device buffer int64[workgroups][waves][8] the GEMM kernels stamp with wall_clock64() at entry / end of the
+ * streaming loop / exit / half of the loop, plus HW_ID in word 4 (NULL = off). */
+int          la_lab_set_ptr(int key, void* d_ptr);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblookahead_hip.so")
 
 LA_OK = 0
-ABI_VERSION = 8         # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
+ABI_VERSION = 9         # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
 LA_MODE_INPUT, LA_MODE_OUTPUT, LA_MODE_MIX = 0, 1, 2
 LA_TREE_MAX = 64
 LA_MOE_MAX_E = 8
@@ -118,7 +118,6 @@ PROTOTYPES = {
     "la_last_error": (C.c_char_p,),
     "la_debug_set": (i32, i32, i32),
     "la_debug_get": (i32, i32),
-    "la_debug_set_ptr": (i32, i32, vp),
     "la_cache_create": (vp, i32, i32),
     "la_cache_destroy": (None, vp),
     "la_cache_set_limits": (i32, vp, i32, i32),
@@ -208,7 +207,15 @@ PROTOTYPES = {
     "la_llama_reset_slot": (i32, vp, vp, i32),
 }
 
-for _n, _sig in PROTOTYPES.items():
+# the kernel lab (include/lookahead_hip_lab.h): measurement knobs / A/B switches for scripts/ and the bitwise-identity tests — not part
+# of the product boundary
+LAB_PROTOTYPES = {
+    "la_lab_set": (i32, i32, i32),
+    "la_lab_get": (i32, i32),
+    "la_lab_set_ptr": (i32, i32, vp),
+}
+
+for _n, _sig in list(PROTOTYPES.items()) + list(LAB_PROTOTYPES.items()):
     _proto(_n, _sig[0], *_sig[1:])
 if lib.la_abi_version() != ABI_VERSION:
     raise ImportError(f"{LIB_PATH} implements ABI {lib.la_abi_version()}, the bindings expect {ABI_VERSION}: rebuild it with "

@@ -16,16 +16,7 @@ extern "C" {
 
 int la_abi_version(void) { return LA_ABI_VERSION; }
 const char* la_last_error(void) { return g_err.c_str(); }
-extern int g_la_dbg_noepi;
-extern int g_la_kskew;
-extern int g_la_prio_hi;
-extern int g_la_mb_narrow;
-extern int g_la_mb_dbg;
-extern int g_la_mb_mode;
-extern int g_la_mb_pair;
-extern int g_la_mb_ks2;
-extern int g_la_pf_kib, g_la_pf_delay, g_la_pf_tail_kib, g_la_attn_staged, g_la_graph_epoch, g_la_graph_reps, g_la_stop_layers, g_la_split_head_tail, g_la_gemm_4w, g_la_ex_split, g_la_attn_one, g_la_attn1_var, g_la_norm4;
-extern long long* g_la_dbg_times;
+extern int g_la_stop_layers, g_la_graph_epoch;
 int la_mb_gemm(void* stream, int kind, const void* wp, const void* xp, int N, int K, int nblk, int n_wg, int ksplit,
                float* slabs, int slab_rows, void* act_xp, void* logits, float* cand_val, int32_t* cand_idx, const int32_t* pos,
                const void* rcos, const void* rsin, void* qf, void* kfresh, void* vfresh, int nh, int nkv) {
@@ -35,42 +26,13 @@ int la_mb_gemm(void* stream, int kind, const void* wp, const void* xp, int N, in
     g.pos = pos; g.rcos = rcos; g.rsin = rsin; g.qf = qf; g.kfresh = kfresh; g.vfresh = vfresh; g.nh = nh; g.nkv = nkv;
     WRAP(lk_mb_gemm((hipStream_t)stream, kind, g));
 }
-// Every knob is read when a step graph is CAPTURED (kernel arguments / launch shapes are baked in): each change bumps the
-// capture epoch, and la_llama_step / la_llama_bstep / la_llama_mstep re-capture a graph whose epoch is stale.
+// The product header keeps ONE debug key: 13 = depth probe of the parity tests (the step runs the first n layers, then the final
+// norm + lm_head).  The measurement knobs / A/B switches are la_lab_* (la_lab.cpp, include/lookahead_hip_lab.h).
 int la_debug_set(int key, int value) {
-    if (key == 0) { g_la_dbg_noepi = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 1 && value >= 0 && value <= 64) { g_la_kskew = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 2 && value >= 0 && value <= 3) { g_la_prio_hi = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 3 && value >= 0 && value <= 1) { g_la_mb_narrow = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 4 && value >= 0 && value <= 5) { g_la_mb_dbg = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 5 && value >= 0 && value <= 3) { g_la_mb_mode = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 6 && value >= 0 && value <= 15) { g_la_mb_pair = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 7 && value >= 0 && value <= 128) { g_la_pf_kib = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 8 && value >= 0 && value <= 16) { g_la_pf_delay = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 9 && value >= 0 && value <= 64) { g_la_pf_tail_kib = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 10 && value >= 0 && value <= 1) { g_la_attn_staged = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 12 && value >= 0 && value <= 1) { g_la_mb_ks2 = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 11 && value >= 1 && value <= 8) { g_la_graph_reps = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 13 && value >= 0) { g_la_stop_layers = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 14 && value >= 0 && value <= 1) { g_la_split_head_tail = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 15 && value >= 0 && value <= 7) { g_la_gemm_4w = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 16 && value >= 0 && value <= 3) { g_la_ex_split = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 17 && value >= 0 && value <= 1) { g_la_attn_one = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 18 && value >= 0 && value <= 7) { g_la_attn1_var = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 19 && value >= 0 && value <= 1) { g_la_norm4 = value; ++g_la_graph_epoch; return LA_OK; }
     return LA_E_ARG;
 }
-int la_debug_get(int key) {
-    switch (key) {
-        case 0: return g_la_dbg_noepi; case 1: return g_la_kskew; case 2: return g_la_prio_hi; case 3: return g_la_mb_narrow;
-        case 4: return g_la_mb_dbg; case 5: return g_la_mb_mode; case 6: return g_la_mb_pair; case 7: return g_la_pf_kib; case 8: return g_la_pf_delay; case 9: return g_la_pf_tail_kib; case 10: return g_la_attn_staged; case 11: return g_la_graph_reps; case 12: return g_la_mb_ks2; case 13: return g_la_stop_layers; case 14: return g_la_split_head_tail; case 15: return g_la_gemm_4w; case 16: return g_la_ex_split; case 17: return g_la_attn_one; case 18: return g_la_attn1_var; case 19: return g_la_norm4;
-        default: return LA_E_ARG;
-    }
-}
-int la_debug_set_ptr(int key, void* d_ptr) {
-    if (key == 0) { g_la_dbg_times = (long long*)d_ptr; return LA_OK; }
-    return LA_E_ARG;
-}
+int la_debug_get(int key) { return key == 13 ? g_la_stop_layers : LA_E_ARG; }
 
 int la_build_tree_inputs(void* stream, const int32_t* d_in, int32_t* d_state, int32_t* d_pos, uint64_t* d_rowmask,
                          int32_t* d_ids) {

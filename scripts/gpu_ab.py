@@ -1,7 +1,7 @@
 # -*- coding: utf-8 -*-
 """Kernel-level A/B on one MI355X: HIP-event time of every kernel class of the verify step at the Llama-2-7B layer
 shape (weights rotated over > 256 MB so the Infinity Cache cannot hold them), each GEMM also with the epilogue switched
-off (la_debug_set(0, 1)) so that the streaming loop and the reduction/epilogue tail are separable.
+off (la_lab_set(0, 1)) so that the streaming loop and the reduction/epilogue tail are separable.
 
     python scripts/gpu_ab.py [gemm] [small]
 """
@@ -40,9 +40,9 @@ def both(name, fn, wbytes):
     """time fn normally and with the epilogue disabled"""
     out = []
     for noepi in (0, 1):
-        check(lib.la_debug_set(0, noepi), 'debug_set')
+        check(lib.la_lab_set(0, noepi), 'debug_set')
         out.append(timeit(fn))
-    check(lib.la_debug_set(0, 0), 'debug_set')
+    check(lib.la_lab_set(0, 0), 'debug_set')
     full, loop = out
     print(f'{name:34s} full {full:7.2f} us ({wbytes / full / 1e3:7.1f} GB/s)   loop only {loop:7.2f} us '
           f'({wbytes / loop / 1e3:7.1f} GB/s)   tail {full - loop:5.2f} us', flush=True)
@@ -53,11 +53,11 @@ def timeline(name, fn, n_wg, n_waves, reps=6):
     """Per-wave wall-clock stamps of ONE launch (the kernels write wall_clock64() at entry / end of the streaming loop /
     exit): dispatch skew, spread of the loop ends (CU imbalance) and the length of the epilogue."""
     buf = torch.zeros(n_wg * n_waves * 8, dtype=torch.int64, device=DEV)
-    check(lib.la_debug_set_ptr(0, ptr(buf)), 'debug_set_ptr')
+    check(lib.la_lab_set_ptr(0, ptr(buf)), 'debug_set_ptr')
     for i in range(reps):
         fn(i)
     torch.cuda.synchronize()
-    check(lib.la_debug_set_ptr(0, None), 'debug_set_ptr')
+    check(lib.la_lab_set_ptr(0, None), 'debug_set_ptr')
     raw = buf.cpu().numpy().reshape(n_wg, n_waves, 8)
     t = raw.astype(np.float64)
     rate = 100.0          # wall_clock64 ticks per us (100 MHz constant clock)
@@ -153,10 +153,10 @@ def sweep(hidden=4096, ffn=11008, nh=32, nkv=32, vocab=32000):
     wps = [gu.pack_planned(1, [rnd(ffn, hidden), rnd(ffn, hidden)], NWG) for _ in range(NBUF)]
     act = torch.zeros(64 * ffn, dtype=torch.bfloat16, device=DEV)
     for ks in (0, 36, 40, 42, 44, 46, 48):
-        check(lib.la_debug_set(1, ks), 'kskew')
+        check(lib.la_lab_set(1, ks), 'kskew')
         us = timeit(lambda i: lib.la_gemm64r_swiglu(sp(), ptr(wps[i % NBUF]), ptr(xp), ffn, hidden, NWG, ptr(act)))
         print(f'gate/up kskew={ks:2d}: {us:7.2f} us  {2 * ffn * hidden * 2 / us / 1e3:7.1f} GB/s', flush=True)
-    check(lib.la_debug_set(1, 44), 'kskew')
+    check(lib.la_lab_set(1, 44), 'kskew')
     timeline('gate/up kskew=44', lambda i: lib.la_gemm64r_swiglu(sp(), ptr(wps[i % NBUF]), ptr(xp), ffn, hidden, NWG, ptr(act)), NWG, 8)
     del wps
     N = (nh + 2 * nkv) * 128
@@ -167,7 +167,7 @@ def sweep(hidden=4096, ffn=11008, nh=32, nkv=32, vocab=32000):
     kf = torch.zeros(nkv * 8192, dtype=torch.bfloat16, device=DEV)
     vf = torch.zeros(nkv * 8192, dtype=torch.bfloat16, device=DEV)
     for ks in (0, 36, 40, 42, 44, 46, 48):
-        check(lib.la_debug_set(1, ks), 'kskew')
+        check(lib.la_lab_set(1, ks), 'kskew')
         us = timeit(lambda i: lib.la_gemm64r_qkv(sp(), ptr(wps[i % NBUF]), ptr(xp), nh, nkv, hidden, NWG, ptr(pos), ptr(rc), ptr(rs_), ptr(qf),
                                                  ptr(kf), ptr(vf)))
         print(f'qkv     kskew={ks:2d}: {us:7.2f} us  {N * hidden * 2 / us / 1e3:7.1f} GB/s', flush=True)
@@ -177,7 +177,7 @@ def sweep(hidden=4096, ffn=11008, nh=32, nkv=32, vocab=32000):
     cv = torch.zeros(NWG * 8 * 64, dtype=torch.float32, device=DEV)
     ci = torch.zeros(NWG * 8 * 64, dtype=torch.int32, device=DEV)
     for ks in (0, 40, 44, 48):
-        check(lib.la_debug_set(1, ks), 'kskew')
+        check(lib.la_lab_set(1, ks), 'kskew')
         us = timeit(lambda i: lib.la_gemm64r_logits(sp(), ptr(wps[i % NBUF]), ptr(xp), vocab, hidden, NWG, ptr(logits), ptr(cv), ptr(ci)))
         print(f'lm_head kskew={ks:2d}: {us:7.2f} us  {vocab * hidden * 2 / us / 1e3:7.1f} GB/s', flush=True)
     del wps
@@ -188,12 +188,12 @@ def sweep(hidden=4096, ffn=11008, nh=32, nkv=32, vocab=32000):
         nb = len(wps)
         for var, ksplit in ((0, 4), (3, 4), (4, 4), (3, 2), (3, 8)):
             for ks in ((0,) if var == 0 else (0, 40, 44, 48)):
-                check(lib.la_debug_set(1, ks), 'kskew')
+                check(lib.la_lab_set(1, ks), 'kskew')
                 rbv = 2 | (var << 8)
                 us = timeit(lambda i: lib.la_gemm64_slab(sp(), ptr(wps[i % nb]), ptr(xk), n, k, rbv, ksplit, ptr(slabs)))
                 print(f'{name:6s} variant={var} ksplit={ksplit} kskew={ks:2d}: {us:7.2f} us  {n * k * 2 / us / 1e3:7.1f} GB/s', flush=True)
         del wps
-    check(lib.la_debug_set(1, 0), 'kskew')
+    check(lib.la_lab_set(1, 0), 'kskew')
 
 
 def prio(hidden=4096, ffn=11008, nh=32, nkv=32, vocab=32000):
@@ -207,9 +207,9 @@ def prio(hidden=4096, ffn=11008, nh=32, nkv=32, vocab=32000):
     act = torch.zeros(64 * ffn, dtype=torch.bfloat16, device=DEV)
     fn = lambda i: lib.la_gemm64r_swiglu(sp(), ptr(wps[i % NBUF]), ptr(xp), ffn, hidden, NWG, ptr(act))
     for pr in (0, 1, 2, 3, 0):
-        check(lib.la_debug_set(2, pr), 'prio')
+        check(lib.la_lab_set(2, pr), 'prio')
         print(f'gate/up prio_hi={pr}: {timeit(fn):7.2f} us', flush=True)
-    check(lib.la_debug_set(2, 1), 'prio')
+    check(lib.la_lab_set(2, 1), 'prio')
     timeline('gate/up prio_hi=1', fn, NWG, 8)
     del wps
     N = (nh + 2 * nkv) * 128
@@ -221,7 +221,7 @@ def prio(hidden=4096, ffn=11008, nh=32, nkv=32, vocab=32000):
     vf = torch.zeros(nkv * 8192, dtype=torch.bfloat16, device=DEV)
     fq = lambda i: lib.la_gemm64r_qkv(sp(), ptr(wps[i % NBUF]), ptr(xp), nh, nkv, hidden, NWG, ptr(pos), ptr(rc), ptr(rs_), ptr(qf), ptr(kf), ptr(vf))
     for pr in (0, 1, 2, 3, 0):
-        check(lib.la_debug_set(2, pr), 'prio')
+        check(lib.la_lab_set(2, pr), 'prio')
         print(f'qkv     prio_hi={pr}: {timeit(fq):7.2f} us', flush=True)
     del wps
     wps = [gu.pack_planned(0, [rnd(vocab, hidden)], NWG) for _ in range(NBUF)]
@@ -230,7 +230,7 @@ def prio(hidden=4096, ffn=11008, nh=32, nkv=32, vocab=32000):
     ci = torch.zeros(NWG * 8 * 64, dtype=torch.int32, device=DEV)
     fl = lambda i: lib.la_gemm64r_logits(sp(), ptr(wps[i % NBUF]), ptr(xp), vocab, hidden, NWG, ptr(logits), ptr(cv), ptr(ci))
     for pr in (0, 1, 3, 0):
-        check(lib.la_debug_set(2, pr), 'prio')
+        check(lib.la_lab_set(2, pr), 'prio')
         print(f'lm_head prio_hi={pr}: {timeit(fl):7.2f} us', flush=True)
     del wps
     slabs = torch.zeros(8 * 64 * hidden, dtype=torch.float32, device=DEV)
@@ -238,9 +238,9 @@ def prio(hidden=4096, ffn=11008, nh=32, nkv=32, vocab=32000):
     nb = len(wps)
     fo = lambda i: lib.la_gemm64_slab(sp(), ptr(wps[i % nb]), ptr(xp), hidden, nh * 128, 2 | (3 << 8), 4, ptr(slabs))
     for pr in (0, 1, 3, 0):
-        check(lib.la_debug_set(2, pr), 'prio')
+        check(lib.la_lab_set(2, pr), 'prio')
         print(f'o_proj  prio_hi={pr}: {timeit(fo):7.2f} us', flush=True)
-    check(lib.la_debug_set(2, 0), 'prio')
+    check(lib.la_lab_set(2, 0), 'prio')
 
 
 def small(hidden=4096, nh=32, nkv=32):
@@ -281,12 +281,12 @@ def small(hidden=4096, nh=32, nkv=32):
     lpart = torch.zeros_like(mpart)
     nwg, nwv = nh * nsplit, 8
     buf = torch.zeros(nwg * nwv * 8, dtype=torch.int64, device=DEV)
-    check(lib.la_debug_set_ptr(0, ptr(buf)), 'debug_set_ptr')
+    check(lib.la_lab_set_ptr(0, ptr(buf)), 'debug_set_ptr')
     for i in range(6):
         lib.la_tree_attn(sp(), ptr(qf), ptr(km[i % NL]), ptr(vm[i % NL]), ptr(kf), ptr(vf), ptr(rm), ptr(state), nh, nkv, max_keys, nsplit,
                          ptr(opart), ptr(mpart), ptr(lpart), ptr(out))
     torch.cuda.synchronize()
-    check(lib.la_debug_set_ptr(0, None), 'debug_set_ptr')
+    check(lib.la_lab_set_ptr(0, None), 'debug_set_ptr')
     t = buf.cpu().numpy().reshape(nwg, nwv, 8).astype(np.float64)
     base = t[:, :, 0].min()
     names = ['entry', 'ranges+q+K issued', 'first tile done', 'loop end', 'merge end', 'exit (par 0)']
@@ -325,7 +325,7 @@ def attn(nh=32, nkv=32):
             lpart = torch.zeros_like(mpart)
             res = []
             for staged in (0, 1, 0, 1):
-                check(lib.la_debug_set(10, staged), 'debug_set')
+                check(lib.la_lab_set(10, staged), 'debug_set')
                 res.append(timeit(lambda i: lib.la_tree_attn(sp(), ptr(qf), ptr(km[i % NL]), ptr(vm[i % NL]), ptr(kf), ptr(vf), ptr(rm),
                                                              ptr(state), nh, nkv, max_keys, nsplit, ptr(opart), ptr(mpart), ptr(lpart),
                                                              ptr(out)), 60))
@@ -333,7 +333,7 @@ def attn(nh=32, nkv=32):
             d, st = min(res[0], res[2]), min(res[1], res[3])
             print(f'tree_attn(+combine) nkeys={nkeys:5d} nsplit={nsplit}: direct {d:6.2f} us ({kvb / d / 1e3:5.0f} GB/s KV)   '
                   f'staged {st:6.2f} us ({kvb / st / 1e3:5.0f} GB/s KV)', flush=True)
-    check(lib.la_debug_set(10, 0), 'debug_set')
+    check(lib.la_lab_set(10, 0), 'debug_set')
 
 
 if __name__ == '__main__':

@@ -55,15 +55,15 @@ def main(nh=32, nkv=32):
         kvb = 2 * nkv * 128 * 2 * (nkeys + 64)
         line = []
         for name, one, var in variants:
-            check(lib.la_debug_set(17, one), 'debug_set')
-            check(lib.la_debug_set(18, var), 'debug_set')
+            check(lib.la_lab_set(17, one), 'debug_set')
+            check(lib.la_lab_set(18, var), 'debug_set')
             us = min(timeit(run(state), 60), timeit(run(state), 60))
             line.append(f'{name.strip()} {us:6.2f}')
         print(f'nkeys={nkeys:5d} ({kvb / 1e6:5.1f} MB K/V): ' + ' | '.join(line), flush=True)
-    check(lib.la_debug_set(17, 1), 'debug_set')
+    check(lib.la_lab_set(17, 1), 'debug_set')
     # phase stamps of the single-launch kernel (us since the first wave of the launch started; percentiles over 256 WGs x 8 waves)
     for nkeys, var in ((768, 0), (768, 1), (1984, 0)):
-        check(lib.la_debug_set(18, var), 'debug_set')
+        check(lib.la_lab_set(18, var), 'debug_set')
         state = torch.zeros(_lib.LA_ST_WORDS, dtype=torch.int32, device=DEV)
         state[0] = nkeys
         buf = torch.zeros(nh * 8 * 8 * 8, dtype=torch.int64, device=DEV)
@@ -71,11 +71,11 @@ def main(nh=32, nkv=32):
         for i in range(4):
             fn(i)
         torch.cuda.synchronize()
-        check(lib.la_debug_set_ptr(0, ptr(buf)), 'debug_set_ptr')
+        check(lib.la_lab_set_ptr(0, ptr(buf)), 'debug_set_ptr')
         buf.zero_()
         fn(5)
         torch.cuda.synchronize()
-        check(lib.la_debug_set_ptr(0, None), 'debug_set_ptr')
+        check(lib.la_lab_set_ptr(0, None), 'debug_set_ptr')
         t = buf.cpu().numpy().reshape(nh * 8, 8, 8).astype(np.float64)
         base = t[:, :, 0].min()
         names = ['entry', 'Q parked, K0 issued', 'first tile done', 'loop end', 'exit', 'first tile: scores done']
@@ -87,7 +87,7 @@ def main(nh=32, nkv=32):
         per_wave_tiles = (nkeys // 32 + 2 + 7) // 8
         loop = (t[:, :, 3] - t[:, :, 2]) / 100.0
         print(f'   loop after the first tile: median {np.median(loop):.2f} us for ~{per_wave_tiles - 1} more tiles per wave', flush=True)
-    check(lib.la_debug_set(18, 0), 'debug_set')
+    check(lib.la_lab_set(18, 0), 'debug_set')
 
 
 if __name__ == '__main__':

@@ -28,10 +28,10 @@ def main():
     ids = rs.randint(3, shape.vocab, size=64).astype(np.int32)
     out = []
     for reps in (1, 2, 4, 8, 1):
-        check(lib.la_debug_set(11, 1), 'debug_set')
+        check(lib.la_lab_set(11, 1), 'debug_set')
         eng.reset()
         ids[0] = eng.prefill(prompt, fast=False)
-        check(lib.la_debug_set(11, reps), 'debug_set')        # the prompt went through the plain graph: same context for every n
+        check(lib.la_lab_set(11, reps), 'debug_set')        # the prompt went through the plain graph: same context for every n
         for _ in range(3):
             eng.step(ids, rows, mode=2)
         torch.cuda.synchronize()
@@ -44,7 +44,7 @@ def main():
         rec = {'steps_per_graph': reps, 'ms_per_launch': round(ms, 4), 'ms_per_step': round(ms / reps, 4), 'context_at_end': eng.n_keys}
         print(json.dumps(rec), flush=True)
         out.append(rec)
-    check(lib.la_debug_set(11, 1), 'debug_set')
+    check(lib.la_lab_set(11, 1), 'debug_set')
 
 
 if __name__ == '__main__':

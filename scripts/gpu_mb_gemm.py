@@ -56,8 +56,8 @@ def main():
         ap = torch.cat([gu.pack_x(a[b * 64:(b + 1) * 64].contiguous()) for b in range(nblk)])
         z = None
         for narrow, wmode in ((1, 0), (0, 0)):
-            check(lib.la_debug_set(3, narrow), 'debug_set')
-            check(lib.la_debug_set(5, wmode), 'debug_set')
+            check(lib.la_lab_set(3, narrow), 'debug_set')
+            check(lib.la_lab_set(5, wmode), 'debug_set')
 
             def gateup(i):
                 check(lib.la_mb_gemm(sp(), 1, ptr(wps[i % NBUF]), ptr(xp), F, K, nblk, NWG, 1, ptr(z), 0, ptr(act), ptr(z), ptr(z), ptr(z),
@@ -73,8 +73,8 @@ def main():
                     continue
                 us, med = bench(fn)
                 print(f'{name:8s} rows {nblk * 64:4d} {"k_gemm_mb  " if narrow else "k_gemm_wide" if not wmode else "wide, KS=2  "} min {us:8.2f} us  median {med:8.2f} us  {flops / us / 1e6:7.1f} TFLOP/s', flush=True)
-    check(lib.la_debug_set(3, 0), 'debug_set')
-    check(lib.la_debug_set(5, 0), 'debug_set')
+    check(lib.la_lab_set(3, 0), 'debug_set')
+    check(lib.la_lab_set(5, 0), 'debug_set')
     if mode == 'parts':
         # what bounds a stage of the wide kernel: the same launch without MFMAs (1), without the in-loop DMA (2), DMA + barriers only (3)
         nblk = 8
@@ -82,14 +82,14 @@ def main():
         xp = torch.cat([gu.pack_x(x[b * 64:(b + 1) * 64].contiguous()) for b in range(nblk)])
         z = None
         for dbg in (0, 1, 2, 3, 4, 5, 0):
-            check(lib.la_debug_set(4, dbg), 'debug_set')
+            check(lib.la_lab_set(4, dbg), 'debug_set')
 
             def gateup(i):
                 check(lib.la_mb_gemm(sp(), 1, ptr(wps[i % NBUF]), ptr(xp), F, K, nblk, NWG, 1, ptr(z), 0, ptr(act), ptr(z), ptr(z), ptr(z),
                                      ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), 0, 0), 'mb_gemm')
             us, med = bench(gateup)
             print(f'gate/up 512 rows wide, dbg {dbg}: min {us:8.2f} us  median {med:8.2f} us', flush=True)
-        check(lib.la_debug_set(4, 0), 'debug_set')
+        check(lib.la_lab_set(4, 0), 'debug_set')
 
 
 if __name__ == '__main__':

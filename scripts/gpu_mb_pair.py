@@ -65,20 +65,20 @@ def main():
                     for kname, fn in (('qkv', qkv), ('o_proj', oproj), ('down', down)):
                         res = []
                         for dbg in (0, 4, 0, 4):
-                            check(lib.la_debug_set(4, dbg), 'debug_set')
+                            check(lib.la_lab_set(4, dbg), 'debug_set')
                             res.append(bench(fn, trials=5, n=12)[0])
-                        check(lib.la_debug_set(4, 0), 'debug_set')
+                        check(lib.la_lab_set(4, 0), 'debug_set')
                         print(f'{name:12s} rows {nblk * 64:4d} {kname:7s} paired: full {min(res[0], res[2]):8.2f} us   without epilogue {min(res[1], res[3]):8.2f} us', flush=True)
                 continue
             for kname, fn in (('gate/up', gateup), ('qkv', qkv), ('o_proj', oproj), ('down', down)):
                 res = []
                 for pair in (0, 3, 0, 3):
-                    check(lib.la_debug_set(6, pair), 'debug_set')
+                    check(lib.la_lab_set(6, pair), 'debug_set')
                     res.append(bench(fn, trials=5, n=12)[0])
                 print(f'{name:12s} rows {nblk * 64:4d} {kname:7s} unpaired {min(res[0], res[2]):8.2f} us   paired {min(res[1], res[3]):8.2f} us', flush=True)
         del wq, wo, wd, wgu
         torch.cuda.empty_cache()
-    check(lib.la_debug_set(6, 1), 'debug_set')
+    check(lib.la_lab_set(6, 1), 'debug_set')
 
 
 if __name__ == '__main__':

@@ -1,6 +1,6 @@
 #!/bin/bash
 # gathered multi-block MoE: one launch per stage for all experts + fused accumulate/norm (default) vs one launch per expert and
-# separate accumulate / norm kernels (la_debug_set(16, 1))
+# separate accumulate / norm kernels (la_lab_set(16, 1))
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 export TMPDIR=/tmp
 if [ -z "$SKIP_TESTS" ]; then timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3; fi

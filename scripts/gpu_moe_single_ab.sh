@@ -1,5 +1,5 @@
 #!/bin/bash
-# gathered MoE: an expert's last single block through the one-block body (default) vs the padded two-block pass (la_debug_set(16, 2))
+# gathered MoE: an expert's last single block through the one-block body (default) vs the padded two-block pass (la_lab_set(16, 2))
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_mblock.py tests/test_gpu_moe.py -x -q -m gpu 2>&1 | tail -3

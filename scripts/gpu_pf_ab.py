@@ -42,10 +42,10 @@ def main():
     results, base = [], None
     for setting in args.settings.split(','):
         kib, dly, tail, staged = ([int(x) for x in setting.split(':')] + [0])[:4]
-        check(lib.la_debug_set(7, kib), 'debug_set')
-        check(lib.la_debug_set(8, dly), 'debug_set')
-        check(lib.la_debug_set(9, tail), 'debug_set')
-        check(lib.la_debug_set(10, staged), 'debug_set')
+        check(lib.la_lab_set(7, kib), 'debug_set')
+        check(lib.la_lab_set(8, dly), 'debug_set')
+        check(lib.la_lab_set(9, tail), 'debug_set')
+        check(lib.la_lab_set(10, staged), 'debug_set')
         eng.reset()
         tok = eng.prefill(prompt, fast=False)
         ids[0] = tok
@@ -70,7 +70,7 @@ def main():
         print(json.dumps(rec), flush=True)
         results.append(rec)
     for k in (7, 8, 9, 10):
-        check(lib.la_debug_set(k, 0), 'debug_set')
+        check(lib.la_lab_set(k, 0), 'debug_set')
     ok = [r for r in results if r['identical_to_off']]
     best = min(ok, key=lambda r: r['ms_per_step'])
     off = [r['ms_per_step'] for r in results if r['kib'] == 0 and r['tail_kib'] == 0]

@@ -28,14 +28,14 @@ for B in (1, 8, 64, 256):
     w = (time.time() - t0) / n
     print(f'device hier_get B={B}: {w*1e6:.0f} us per call incl. transfers ({w*1e6/B:.1f} us/query)')
 
-# phase stamps of k_trie_hier_get (la_debug_set_ptr(0, buffer): wall_clock64 = 100 MHz ticks)
+# phase stamps of k_trie_hier_get (la_lab_set_ptr(0, buffer): wall_clock64 = 100 MHz ticks)
 import ctypes as C
 from painlessinferenceacceleration_amd._lib import lib, check
 B = 64
 stamps = torch.zeros(B * 8, dtype=torch.int64, device='cuda:0')
-check(lib.la_debug_set_ptr(0, C.c_void_p(stamps.data_ptr())), 'set_ptr')
+check(lib.la_lab_set_ptr(0, C.c_void_p(stamps.data_ptr())), 'set_ptr')
 dev.hier_get(qs[:B], 64, 12, 0, 32, 'mix')
-check(lib.la_debug_set_ptr(0, None), 'set_ptr')
+check(lib.la_lab_set_ptr(0, None), 'set_ptr')
 st = stamps.cpu().numpy().reshape(B, 8)
 us = lambda a, b: (st[:, b] - st[:, a]) / 100.0
 ok = st[:, 4] > 0

@@ -108,13 +108,13 @@ def pack_planned(kind, mats, n_wg):
 
 @contextlib.contextmanager
 def debug_knob(key, value):
-    """la_debug_set(key, value) for the duration of a block (capture-time knobs re-capture the step graphs on both edges)."""
-    old = lib.la_debug_get(key)
-    check(lib.la_debug_set(key, value), 'debug_set')
+    """la_lab_set(key, value) for the duration of a block (capture-time knobs re-capture the step graphs on both edges)."""
+    old = lib.la_lab_get(key)
+    check(lib.la_lab_set(key, value), 'debug_set')
     try:
         yield
     finally:
-        lib.la_debug_set(key, old)
+        lib.la_lab_set(key, old)
 
 
 @contextlib.contextmanager

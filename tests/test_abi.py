@@ -9,13 +9,21 @@ from painlessinferenceacceleration_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    src = open(os.path.join(ROOT, 'include', 'lookahead_hip.h')).read()
+def header_symbols(name='lookahead_hip.h'):
+    src = open(os.path.join(ROOT, 'include', name)).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     return sorted(set(re.findall(r'\b(la_[a-z0-9_]+)\s*\(', src)))
 
 
+def exported_symbols():
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    return sorted(ln.split()[-1] for ln in out.splitlines() if ' T la_' in ln)
+
+
 def test_every_declared_symbol_is_exported_and_bound():
+    """The product header == the bindings == the library's exports, symbol for symbol; the kernel lab (la_lab_*: measurement knobs
+    and A/B switches) is a separate, undeclared-by-the-product-header set of its own."""
     syms = header_symbols()
     assert len(syms) >= 35
     dll = ctypes.CDLL(_lib.LIB_PATH)
@@ -23,6 +31,18 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(dll, s), f'{s} declared in the header but not exported'
         assert s in _lib.PROTOTYPES, f'{s} has no ctypes prototype in _lib.py'
     assert sorted(_lib.PROTOTYPES) == syms
+    lab = header_symbols('lookahead_hip_lab.h')
+    assert lab == sorted(_lib.LAB_PROTOTYPES) == ['la_lab_get', 'la_lab_set', 'la_lab_set_ptr']
+    assert not any(s.startswith('la_lab_') for s in syms), 'the product header does not declare the lab'
+    assert exported_symbols() == sorted(syms + lab)          # nothing exported that no header declares
+
+
+def test_product_debug_key_is_the_depth_probe_only():
+    lib = _lib.lib
+    assert lib.la_debug_get(13) == 0 and lib.la_debug_set(13, 5) == 0 and lib.la_debug_get(13) == 5 and lib.la_lab_get(13) == 5
+    assert lib.la_debug_set(13, 0) == 0
+    for key in (0, 6, 7, 10, 17, 19, 99):
+        assert lib.la_debug_set(key, 0) == -1 and lib.la_debug_get(key) == -1      # LA_E_ARG: lab knobs are not reachable here
 
 
 def test_abi_version_and_error_channel():
@@ -95,18 +115,18 @@ def test_qkv_row_perm_is_a_permutation_of_rope_pairs():
 
 
 def test_debug_knobs_roundtrip_and_defaults():
-    """la_debug_set / la_debug_get: every knob reads back, out-of-range values are refused, and the library defaults are the
+    """la_lab_set / la_lab_get: every knob reads back, out-of-range values are refused, and the library defaults are the
     documented ones (everything 0 except key 6 = 1, the paired wide launches, and key 11 = 1 step per graph; round 3: 13 = depth probe,
     14 = split head / tail kernels, 15 = 4-wave GEMM variants; round 4: 17 = single-launch tree attention, default ON)."""
     lib = _lib.lib
     defaults = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0, 5: 0, 6: 1, 7: 0, 8: 0, 9: 0, 10: 0, 11: 1, 12: 0, 13: 0, 14: 0, 15: 0, 16: 0, 17: 1, 18: 0, 19: 1}
     for key, d in defaults.items():
-        assert lib.la_debug_get(key) == d, key
+        assert lib.la_lab_get(key) == d, key
     try:
         for key, ok, bad in ((6, 15, 16), (16, 3, 4), (14, 1, 2), (15, 7, 8), (7, 128, 129), (8, 16, 17), (9, 64, 65), (10, 1, 2), (11, 8, 9), (17, 0, 2)):
-            assert lib.la_debug_set(key, ok) == 0 and lib.la_debug_get(key) == ok
-            assert lib.la_debug_set(key, bad) == -1 and lib.la_debug_get(key) == ok          # LA_E_ARG, value kept
-        assert lib.la_debug_get(99) == -1 and lib.la_debug_set(99, 0) == -1
+            assert lib.la_lab_set(key, ok) == 0 and lib.la_lab_get(key) == ok
+            assert lib.la_lab_set(key, bad) == -1 and lib.la_lab_get(key) == ok          # LA_E_ARG, value kept
+        assert lib.la_lab_get(99) == -1 and lib.la_lab_set(99, 0) == -1
     finally:
         for key, d in defaults.items():
-            lib.la_debug_set(key, d)
+            lib.la_lab_set(key, d)

@@ -77,12 +77,7 @@ def _worker(rank, world, port, steps, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('b_loc', [1, 2])
-@pytest.mark.parametrize('split_phase', [False, True])
-def test_two_rank_trie_replicas_stay_identical(split_phase, b_loc):
-    """world 2 x b_loc sequences per rank (config 4's layout: 32 sequences over 8 GPUs = 4 per rank): every rank's trie replica
-    == a single-process cache fed all B sequences in global batch-index order, in the strict and in the split-phase mode."""
-    world, steps = 2, 40
+def _replicas_vs_single_process(world, b_loc, split_phase, steps):
     os.environ['LA_TEST_BLOC'] = str(b_loc)
     if split_phase:
         os.environ['LA_TEST_SPLIT_PHASE'] = '1'
@@ -96,19 +91,20 @@ def test_two_rank_trie_replicas_stay_identical(split_phase, b_loc):
         p.start()
     outs = {}
     for _ in range(world):
-        rank, seen, res, stats = q.get(timeout=180)
+        rank, seen, res, stats = q.get(timeout=600)
         outs[rank] = (seen, res, stats)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
-    # every rank saw every sequence's tokens, in rank order
+    # every rank saw every sequence's tokens, in global batch-index order
     B = world * b_loc
     streams = _streams(B, steps)
     for r in range(world):
         for s in range(steps):
             assert outs[r][0][s] == [streams[k][s] for k in range(B)]
     # replicas agree with each other (queries carry idx=rank, but no input freqs exist, so drafts coincide)
-    assert outs[0][1] == outs[1][1]
+    for r in range(1, world):
+        assert outs[0][1] == outs[r][1], r
     # ... and with a single-process cache fed in global batch-index order
     from painlessinferenceacceleration_amd.lookahead_cache import LookaheadCache
     ref = LookaheadCache(eos_ids=[None])
@@ -117,12 +113,27 @@ def test_two_rank_trie_replicas_stay_identical(split_phase, b_loc):
             ref.stream_put(streams[r][s], branch_length=13, final=False, idx=r)
     for r in range(B):
         ref.stream_put([], branch_length=13, final=True, idx=r)
-    assert ref.stats()['n_nodes'] == outs[0][2]['n_nodes'] == outs[1][2]['n_nodes']
+    assert all(ref.stats()['n_nodes'] == outs[r][2]['n_nodes'] for r in range(world))
     rng = random.Random(9)
     for i in range(200):
         qy = [rng.randrange(3, 60) for _ in range(2)]
         ids, mask, sizes = ref.hier_get(qy, decoding_length=64, branch_length=12, min_output_size=32, mode='mix', idx=0)
         assert (ids, mask.tolist(), sizes) == outs[0][1][i]
+
+
+@pytest.mark.parametrize('b_loc', [1, 2])
+@pytest.mark.parametrize('split_phase', [False, True])
+def test_two_rank_trie_replicas_stay_identical(split_phase, b_loc):
+    """world 2 x b_loc sequences per rank: every rank's trie replica == a single-process cache fed all B sequences in global
+    batch-index order, in the strict and in the split-phase mode."""
+    _replicas_vs_single_process(2, b_loc, split_phase, 40)
+
+
+def test_eight_ranks_four_sequences_each_is_config4s_layout_in_single_process_order():
+    """BASELINE config 4's exact layout — world 8, B_loc = 4: bs 32 batch-sharded over 8 ranks, rank r owning the global batch
+    indices b = i * 8 + r — in strict mode: all 8 replicas == the single-process cache fed in batch-index order (the order of the
+    reference's batch loop, pretrained_model_batch.py:1254-1259)."""
+    _replicas_vs_single_process(8, 4, False, 10)
 
 
 def _worker_native_fails(rank, world, port, q):

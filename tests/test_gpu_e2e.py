@@ -19,7 +19,7 @@ from tests.gpu_utils import random_tree
 from tests.tiny_model import GOLDEN, load_golden, tiny_shape, tiny_weights
 
 pytestmark = pytest.mark.gpu
-PF_DEFAULT = (_lib.lib.la_debug_get(7), _lib.lib.la_debug_get(8), _lib.lib.la_debug_get(9))     # the library's idle-window prefetch default
+PF_DEFAULT = (_lib.lib.la_lab_get(7), _lib.lib.la_lab_get(8), _lib.lib.la_lab_get(9))     # the library's idle-window prefetch default
 TOL = 2e-2
 
 
@@ -351,7 +351,7 @@ def test_idle_window_prefetch_is_bitwise_neutral():
 
 
 def _idle_window_prefetch_is_bitwise_neutral():
-    """la_debug_set keys 7 / 8 / 9: the gate/up launch's tail loads (down_proj image) and the extra workgroups appended to the row kernels and to the attention combine only READ the next
+    """la_lab_set keys 7 / 8 / 9: the gate/up launch's tail loads (down_proj image) and the extra workgroups appended to the row kernels and to the attention combine only READ the next
     GEMM's first k-tiles (planned QKV / gate-up / lm_head images, classic o_proj image).  At the Llama-2-7B layer shape and on the
     tiny model (classic images only) every setting must leave tokens, logits and hidden state bit-identical — graph and eager —
     and must stay inside the weight images (an out-of-bounds descriptor would fault the launch)."""
@@ -367,10 +367,10 @@ def _idle_window_prefetch_is_bitwise_neutral():
             ids = rs.randint(3, vocab, size=64).astype(np.int32)
             outs = []
             for kib, dly, tail in ((0, 0, 0), (16, 0, 0), (64, 1, 16), (128, 0, 64), (128, 3, 0), (0, 0, 48)):
-                check(lib.la_debug_set(7, kib), 'debug_set')
-                check(lib.la_debug_set(8, dly), 'debug_set')
-                check(lib.la_debug_set(9, tail), 'debug_set')
-                assert lib.la_debug_get(7) == kib and lib.la_debug_get(8) == dly and lib.la_debug_get(9) == tail
+                check(lib.la_lab_set(7, kib), 'debug_set')
+                check(lib.la_lab_set(8, dly), 'debug_set')
+                check(lib.la_lab_set(9, tail), 'debug_set')
+                assert lib.la_lab_get(7) == kib and lib.la_lab_get(8) == dly and lib.la_lab_get(9) == tail
                 for eager in (False, True):
                     eng.reset()
                     eng.prefill(prompt, fast=False)
@@ -384,7 +384,7 @@ def _idle_window_prefetch_is_bitwise_neutral():
             torch.cuda.empty_cache()
     finally:
         for key, val in zip((7, 8, 9), PF_DEFAULT):
-            lib.la_debug_set(key, val)
+            lib.la_lab_set(key, val)
 
 
 def test_staged_attention_is_bitwise_identical_end_to_end():
@@ -394,7 +394,7 @@ def test_staged_attention_is_bitwise_identical_end_to_end():
 
 
 def _staged_attention_is_bitwise_identical_end_to_end():
-    """la_debug_set key 10 (K/V tiles staged once per workgroup through LDS instead of twice into registers): tokens, logits and
+    """la_lab_set key 10 (K/V tiles staged once per workgroup through LDS instead of twice into registers): tokens, logits and
     hidden state of whole steps must not change by a bit — long prompts (several stages per workgroup), a sliding window on the
     KV ring (ring-slot addressing of the copies), and the cursor batch (a wave whose token block holds no row of a slot still
     copies for its partner)."""
@@ -402,7 +402,7 @@ def _staged_attention_is_bitwise_identical_end_to_end():
     shape = tiny_shape()
     sd = _bf16_sd(3)
     rs = np.random.RandomState(12)
-    default_form = lib.la_debug_get(10)
+    default_form = lib.la_lab_get(10)
     try:
         # (a) single sequence, 700-token prompt, tree step + follow-up step, graph and eager
         for kw in ({}, {'kv_ring': True}):
@@ -415,7 +415,7 @@ def _staged_attention_is_bitwise_identical_end_to_end():
             ids = rs.randint(3, shape.vocab, size=64).astype(np.int32)
             outs = []
             for staged in (0, 1):
-                check(lib.la_debug_set(10, staged), 'debug_set')
+                check(lib.la_lab_set(10, staged), 'debug_set')
                 for eager in (False, True):
                     eng.reset()
                     eng.prefill(prompt, fast=False)
@@ -436,14 +436,14 @@ def _staged_attention_is_bitwise_identical_end_to_end():
             segs.append((b, rs.randint(3, shape.vocab, size=n).astype(np.int32), rows, 0, 16))
         outs = []
         for staged in (0, 1):
-            check(lib.la_debug_set(10, staged), 'debug_set')
+            check(lib.la_lab_set(10, staged), 'debug_set')
             eng.reset_slot(-1)
             eng.bprefill_many(prompts, eager=True)
             o = eng.bstep(segs, eager=True)
             outs.append((o, eng.logits()[:55].clone(), list(eng.slot_keys)))
         assert outs[0][0] == outs[1][0] and outs[0][2] == outs[1][2] and torch.equal(outs[0][1], outs[1][1])
     finally:
-        lib.la_debug_set(10, default_form)
+        lib.la_lab_set(10, default_form)
 
 
 @pytest.mark.parametrize('window', [40, 100])
@@ -659,7 +659,7 @@ def test_full_size_llama7b_32_layers_vs_oracle():
     # (1) depth probe: forward-only steps (nothing is committed; layers < n write the same fresh K/V whatever n is)
     try:
         for n in (1, 2, 4, 8, 16, 24, 32):
-            check(lib.la_debug_set(13, n if n < shape.n_layers else 0), 'debug_set')
+            check(lib.la_debug_set(13, n if n < shape.n_layers else 0), 'debug_set')      # the one debug key of the product header
             eng.verify_only(ids, rows, eager=True)
             hg = eng.hidden().float().cpu()
             e_eng, e_o16 = rel(hg, h32[n - 1]), rel(h16[n - 1], h32[n - 1])

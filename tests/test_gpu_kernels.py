@@ -209,13 +209,13 @@ def test_tree_attention(nh, nkv, nkeys, nsplit, T):
     mpart = torch.zeros(nh * nsplit * 64, dtype=torch.float32, device=DEV)
     lpart = torch.zeros_like(mpart)
     out = torch.zeros(64 * nh * 128, dtype=torch.bfloat16, device=DEV)
-    default_form, default_one = lib.la_debug_get(10), lib.la_debug_get(17)
+    default_form, default_one = lib.la_lab_get(10), lib.la_lab_get(17)
     forms = []
     try:
         # (single launch, -), (key splits + combine, direct), (key splits + combine, staged through LDS)
         for one, staged in ((1, 0), (0, 0), (0, 1)):
-            check(lib.la_debug_set(17, one), 'debug_set')
-            check(lib.la_debug_set(10, staged), 'debug_set')
+            check(lib.la_lab_set(17, one), 'debug_set')
+            check(lib.la_lab_set(10, staged), 'debug_set')
             for t in (opart, mpart, lpart, out):
                 t.zero_()
             check(lib.la_tree_attn(sp(), ptr(qf), ptr(km), ptr(vm), ptr(kf), ptr(vf), ptr(rm), ptr(state), nh, nkv, max_keys,
@@ -223,8 +223,8 @@ def test_tree_attention(nh, nkv, nkeys, nsplit, T):
             torch.cuda.synchronize()
             forms.append((opart.clone(), mpart.clone(), lpart.clone(), out.clone()))
     finally:
-        lib.la_debug_set(10, default_form)
-        lib.la_debug_set(17, default_one)
+        lib.la_lab_set(10, default_form)
+        lib.la_lab_set(17, default_one)
     for a_, b_ in zip(forms[1], forms[2]):
         assert torch.equal(a_, b_)
     assert float(forms[0][0].abs().max()) == 0.0, 'the single-launch form writes no split partials'

@@ -332,7 +332,7 @@ def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
     in the same order, so slabs and Q / K / V fragments must equal the unpaired launch bit for bit — classic and planned images,
     MHA and GQA shapes, K splits."""
     rc, rs_ = rope_tables(128, 1024, 10000.0, DEV)
-    default_form = lib.la_debug_get(6)
+    default_form = lib.la_lab_get(6)
     try:
         for N, K, ks in ((4096, 1376, 4), (512, 2048, 1), (5120, 512, 4)):
             g = torch.Generator(device=DEV).manual_seed(N + nblk)
@@ -341,7 +341,7 @@ def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
             rows = (nblk + 3) // 4 * 4 * 64
             outs = []
             for pair in (0, 1):
-                check(lib.la_debug_set(6, pair), 'debug_set')
+                check(lib.la_lab_set(6, pair), 'debug_set')
                 slabs = torch.full((ks, rows, N), float('nan'), dtype=torch.float32, device=DEV)
                 _mb(0, wp, _pack_blocks(x), N, K, nblk, ksplit=ks, slabs=slabs, slab_rows=rows)
                 outs.append(slabs[:, :nblk * 64].clone())
@@ -361,7 +361,7 @@ def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
                 wp = gu.pack_weight(w[torch.from_numpy(perm.astype(np.int64)).to(DEV)].contiguous())
             outs = []
             for pair in (0, 1, 5):          # 5 = paired + the QUAD form of the QKV launch (taken at >= 7 blocks of a GQA shape)
-                check(lib.la_debug_set(6, pair), 'debug_set')
+                check(lib.la_lab_set(6, pair), 'debug_set')
                 qf = torch.zeros(8 * nh * 8192, dtype=torch.bfloat16, device=DEV)
                 kf = torch.zeros(8 * nkv * 8192, dtype=torch.bfloat16, device=DEV)
                 vf = torch.zeros(8 * nkv * 8192, dtype=torch.bfloat16, device=DEV)
@@ -379,14 +379,14 @@ def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
             wp = gu.pack_planned(1, [wg_, wu_], 256)
             outs = []
             for pair in (0, 3):
-                check(lib.la_debug_set(6, pair), 'debug_set')
+                check(lib.la_lab_set(6, pair), 'debug_set')
                 act = torch.zeros(8 * 64 * F, dtype=torch.bfloat16, device=DEV)
                 _mb(1, wp, _pack_blocks(x), F, K, nblk, n_wg=256, act=act)
                 outs.append(act)
             assert torch.equal(outs[0], outs[1]), (F, K)
             assert float(outs[0][:nblk * 64 * F].float().abs().sum()) > 0
     finally:
-        lib.la_debug_set(6, default_form)
+        lib.la_lab_set(6, default_form)
 
 
 def _random_wide_tree(rs, T, chain_len):
@@ -529,7 +529,7 @@ def test_mstep_mistral_shape_b8_window_ring_paired_launches_vs_oracle():
     B = 8
     eng = LlamaVerifyEngine(shape, sd, max_length=1200, n_slots=B, max_blocks=B, kv_ring=True)
     assert eng.kv_ring and eng.max_keys == 736
-    assert lib.la_debug_get(6) & 1, 'the paired wide launches are the default'
+    assert lib.la_lab_get(6) & 1, 'the paired wide launches are the default'
     oracle = lo.OracleLlama(shape, sd)
     rs = np.random.RandomState(21)
     lens = [40, 150, 170, 300, 90, 800, 230, 1000]          # < W, ~W, > W, >> W; 800 / 1000 wrap the 736-row ring
