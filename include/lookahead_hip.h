@@ -211,9 +211,12 @@ int la_trie_hier_get_dev(void* stream, const int32_t* d_tok, const double* d_fo,
 #define LA_ST_ARGMAX   136   /* out: [64] argmax token per tree row                       */
 #define LA_ST_WORDS    200
 
-/* Host->device step input block: {T, mode, pad, pad, ids[64] (int32), rowmask[64] (uint64)}. */
+/* Host->device step input block: {T, mode, nkeys hint, pad, ids[64] (int32), rowmask[64] (uint64)}. */
 #define LA_IN_T          0
 #define LA_IN_MODE       1
+#define LA_IN_NKEYS_HINT 2   /* the caller's count of committed keys before this block (la_llama_step reads it ON THE HOST to pick the
+                                tree-attention form: one launch while a head group's K/V fits its XCD's L2, key splits + combine beyond;
+                                a hint only — both forms are exact at any context, 0 / stale values cost time, never correctness) */
 #define LA_IN_IDS        4
 #define LA_IN_ROWMASK   68   /* int32 word offset; 8-byte aligned */
 #define LA_IN_WORDS    196

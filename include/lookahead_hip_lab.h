@@ -4,7 +4,7 @@
  * capture their graphs again after a change.
  *
  * Defaults: everything 0 except key 6 = 1 (paired wide launches), key 11 = 1 (one step per graph), key 17 = 1 (single-launch tree
- * attention), key 19 = 1 (four workgroups per norm row).
+ * attention).
  */
 #ifndef LOOKAHEAD_HIP_LAB_H
 #define LOOKAHEAD_HIP_LAB_H
@@ -34,8 +34,8 @@ extern "C" {
  *         argmax / accept / publish kernels instead of the fused step head / tail.  key 15: bit 0 = gate/up as 4 waves x 8 tile-sets.
  * key 17: tree attention of the single-sequence step, 1 = ONE launch (la_attn1.hip, default), 0 = key splits + combine.
  * key 18: variants of the single-launch attention (measurement): bit 0 = no start rotation, bits 1-2 = forced slice count.
- * key 19: residual + RMSNorm of the single-sequence step, 1 = four workgroups per row with a granule exchange (k_row_norm4,
- *         default), 0 = one workgroup per row (k_row_norm). */
+ * key 19: residual + RMSNorm of the single-sequence step, 1 = four workgroups per row with a granule exchange (k_row_norm4:
+ *         measured neutral, 5.30 vs 5.37 us per launch), 0 = one workgroup per row (k_row_norm, default). */
 int          la_lab_set(int key, int value);
 int          la_lab_get(int key);          /* current value of a knob (the library default unless la_lab_set changed it) */
 /* key 0: device buffer int64[workgroups][waves][8] the GEMM kernels stamp with wall_clock64() at entry / end of the

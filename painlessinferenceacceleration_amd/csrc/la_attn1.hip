@@ -253,8 +253,10 @@ int lk_tree_attn1(hipStream_t st, const void* qf, const void* kmain, const void*
                   const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys, void* attn_xp, int window, int ring_keys) {
     if (nh <= 0 || nkv <= 0 || nh % nkv || nh > 0x7fff || (ring_keys >> 5) >= (1 << 22)) return -1;
     if (lk_gemm64r_init() != 0) return -1;
-    // token slices per 32-row block: as many workgroups as fit one per CU (nh * 2 * SL <= CUs)
-    int SL = 4;
+    // token slices per 32-row block: 2 (measured: every slice count streams the same bytes per CU — all of the head's K/V — and
+    // two slices leave the least redundant L2 traffic at equal or better time, profiles/r04_attention_one_launch.txt); fewer when
+    // nh * 2 * SL workgroups would not fit one per CU
+    int SL = 2;
     while (SL > 1 && nh * 2 * SL > g_attn1_cus) SL >>= 1;
     if ((g_la_attn1_var >> 1) & 3) SL = 1 << (((g_la_attn1_var >> 1) & 3) - 1);
     const int W = 32 / SL;

@@ -12,7 +12,7 @@
 #include "la_kernels.h"
 #include "la_mblock.h"
 extern int g_la_pf_kib, g_la_pf_delay, g_la_pf_tail_kib, g_la_graph_epoch, g_la_graph_reps, g_la_mb_ks2;
-int g_la_norm4 = 1;            // la_debug_set key 19: 1 = residual + RMSNorm with four workgroups per row (k_row_norm4) on the single-sequence step
+int g_la_norm4 = 0;            // la_lab_set key 19 (measured neutral: 5.30 vs 5.37 us per launch, profiles/r04_*): 1 = residual + RMSNorm with four workgroups per row (k_row_norm4) on the single-sequence step
 int g_la_split_head_tail = 0;   // la_debug_set key 14: 1 = separate build-inputs / embed / argmax / accept / publish kernels (A/B)
 int g_la_stop_layers = 0;     // la_debug_set key 13 (parity tests): the single-sequence step runs only the first n layers, then the final norm + lm_head
 
@@ -67,6 +67,9 @@ struct la_llama {
     bool mready[2 * (LA_MB_MAX + 1)];
     int mepoch[2 * (LA_MB_MAX + 1)];     // g_la_graph_epoch at capture time, per multi-block graph
     hipGraphExec_t graph_exec, bgraph_exec;      // bgraph_exec: scratch slot used while capturing a batch variant
+    hipGraphExec_t graph_long = nullptr;         // the single-sequence step with the key-split attention (contexts past attn_thr)
+    bool graph_long_ready = false;
+    int attn_thr = 0;                            // committed keys + 64 up to which the single-launch attention is used (see resolve_cfg)
     hipGraphExec_t bgraphs[4];                  // batch step captured per attention key-split count {8, 4, 2, 1}
     bool bready[4];
     int bepoch[4];
@@ -149,6 +152,12 @@ static void resolve_cfg(la_llama* m) {
     // bit 2 (value 4), bit 3 (value 8 = 8 tile-sets in flight in the down role): gate/up and down_proj as ONE role-fused launch
     // (k_gateup_down): needs the balanced gate/up image, the 64-row classic down image and a dense MLP
     if ((c.fuse & 4) && c.n_experts == 0 && c.balanced_wg[1] > 0 && (c.hidden % 64) == 0 && (c.ffn % 16) == 0) m->fuse |= (c.fuse & 12);
+    // single-launch attention while the K/V one XCD's heads read fits its 4 MiB L2 with room to spare: kv heads per XCD x 512 B per key
+    // (measured at 4 kv heads per XCD: ahead of the key-split pair up to ~1500 keys, behind from ~2000, profiles/r04_attention_one_launch.txt)
+    {
+        const int kvx = c.n_kv_heads >= 8 ? (c.n_kv_heads + 7) / 8 : 1;
+        m->attn_thr = (int)(2800000 / ((long)kvx * 512));
+    }
     if (m->qkv_n % 64) m->qkv_rb = (m->qkv_rb & ~0xff) | 1;
     if (c.hidden % 64) { m->o_rb = (m->o_rb & ~0xff) | 1; m->down_rb = (m->down_rb & ~0xff) | 1; }
     if (c.vocab % 64) m->lm_rb = (m->lm_rb & ~0xff) | 1;
@@ -319,6 +328,7 @@ extern "C" la_llama* la_llama_create(const la_llama_config* cfg, const la_llama_
 extern "C" void la_llama_destroy(la_llama* m) {
     if (!m) return;
     if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    if (m->graph_long) (void)hipGraphExecDestroy(m->graph_long);
     if (m->bgraph_exec) (void)hipGraphExecDestroy(m->bgraph_exec);
     for (int i = 0; i < 4; ++i) if (m->bready[i]) (void)hipGraphExecDestroy(m->bgraphs[i]);
     for (int i = 0; i < 2 * (LA_MB_MAX + 1); ++i) if (m->mready[i]) (void)hipGraphExecDestroy(m->mgraphs[i]);
@@ -366,7 +376,7 @@ struct Prof {
 
 // enqueue every kernel of one block on `st` (used eagerly, under graph capture, and by the profiler)
 static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = false, const int32_t* zc_in = nullptr,
-                        int32_t* zc_out = nullptr, int bsplit = 0) {
+                        int32_t* zc_out = nullptr, int bsplit = 0, bool long_ctx = false) {
     const la_llama_config& c = m->cfg;
     const int ring = c.kv_ring ? c.max_keys : 0;          // sliding-window ring: position p of a sequence lives in row p mod max_keys
     auto P = [&](int cls) { if (pf) pf->mark(cls); };
@@ -427,7 +437,7 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
         else
             KCHK(lk_tree_attn(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
                               kf, vf, m->rowmask, m->state, c.n_heads, c.n_kv_heads, m->total_keys, m->nsplit,
-                              m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window, ring, &pd));
+                              m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window, ring, &pd, long_ctx ? 0 : -1));
         P(KC_O);
         KCHK(lk_gemm64_slab(st, L.wo, m->attn_xp, c.hidden, m->o_k, m->o_rb, m->o_ks, m->slabs));
         P(KC_OTHER);
@@ -544,20 +554,20 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
 }
 
 static int build_graph(la_llama* m, hipStream_t st, bool batch = false, const int32_t* zc_in = nullptr,
-                       int32_t* zc_out = nullptr, int bsplit = 0) {
+                       int32_t* zc_out = nullptr, int bsplit = 0, bool long_ctx = false) {
     hipGraph_t g = nullptr;
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     // measurement knob (la_debug_set key 11): the single-sequence graph holds the step n times (the same input block each time, only
     // the last repetition publishes) — what a launch costs beyond its kernels shows as time per repetition vs n
     const int reps = (!batch && g_la_graph_reps > 1) ? g_la_graph_reps : 1;
     int rc = LA_OK;
-    for (int r = 0; r < reps && rc == LA_OK; ++r) rc = enqueue_step(m, st, nullptr, batch, zc_in, r + 1 == reps ? zc_out : nullptr, bsplit);
+    for (int r = 0; r < reps && rc == LA_OK; ++r) rc = enqueue_step(m, st, nullptr, batch, zc_in, r + 1 == reps ? zc_out : nullptr, bsplit, long_ctx);
     hipError_t e = hipStreamEndCapture(st, &g);
     if (rc != LA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
     HIPCHK(e);
-    HIPCHK(hipGraphInstantiate(batch ? &m->bgraph_exec : &m->graph_exec, g, nullptr, nullptr, 0));
+    HIPCHK(hipGraphInstantiate(batch ? &m->bgraph_exec : (long_ctx ? &m->graph_long : &m->graph_exec), g, nullptr, nullptr, 0));
     (void)hipGraphDestroy(g);
-    (batch ? m->bgraph_ready : m->graph_ready) = true;
+    (batch ? m->bgraph_ready : (long_ctx ? m->graph_long_ready : m->graph_ready)) = true;
     m->graph_stream = st;
     return LA_OK;
 }
@@ -786,24 +796,29 @@ extern "C" int la_llama_step(la_llama* m, void* stream, const int32_t* host_in, 
     if (!m || !host_in || !host_out) return LA_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     // other staging blocks, or a capture-time knob (la_debug_set keys 7 / 8) changed since the capture: capture again
-    if (m->graph_ready && (m->zc_in != host_in || m->zc_out != host_out || m->graph_epoch != g_la_graph_epoch)) {
-        (void)hipGraphExecDestroy(m->graph_exec);
-        m->graph_exec = nullptr;
-        m->graph_ready = false;
+    if ((m->graph_ready || m->graph_long_ready) && (m->zc_in != host_in || m->zc_out != host_out || m->graph_epoch != g_la_graph_epoch)) {
+        if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+        if (m->graph_long) (void)hipGraphExecDestroy(m->graph_long);
+        m->graph_exec = m->graph_long = nullptr;
+        m->graph_ready = m->graph_long_ready = false;
     }
-    if (!m->graph_ready) {
+    // two captured forms of the step: the tree attention as ONE launch while the K/V of the kv heads of an XCD fit its L2 (every
+    // workgroup of a head streams the head's whole K/V, the sharers find it in L2), key splits + combine beyond (distinct bytes per
+    // CU).  The caller's hint word picks; both are exact at any context.
+    const bool long_ctx = host_in[LA_IN_NKEYS_HINT] + LA_TREE_MAX > m->attn_thr;
+    if (!(long_ctx ? m->graph_long_ready : m->graph_ready)) {
         hipPointerAttribute_t pa;
         if (hipPointerGetAttributes(&pa, host_in) != hipSuccess || hipPointerGetAttributes(&pa, host_out) != hipSuccess) {
             (void)hipGetLastError();
             la_set_error("la_llama_step: host_in / host_out must be pinned host memory (zero-copy step I/O)");
             return LA_E_ARG;
         }
-        int rc = build_graph(m, st, false, host_in, host_out);
+        int rc = build_graph(m, st, false, host_in, host_out, 0, long_ctx);
         if (rc != LA_OK) return rc;
         m->zc_in = host_in; m->zc_out = host_out; m->graph_epoch = g_la_graph_epoch;
     }
     m->seq_expected += 1;
-    HIPCHK(hipGraphLaunch(m->graph_exec, st));
+    HIPCHK(hipGraphLaunch(long_ctx ? m->graph_long : m->graph_exec, st));
     return LA_OK;
 }
 
@@ -829,7 +844,7 @@ extern "C" int la_llama_step_eager(la_llama* m, void* stream, const int32_t* hos
     if (!m || !host_in) return LA_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(hipMemcpyAsync(m->in, host_in, LA_IN_WORDS * sizeof(int), hipMemcpyHostToDevice, st));
-    int rc = enqueue_step(m, st, nullptr);
+    int rc = enqueue_step(m, st, nullptr, false, nullptr, nullptr, 0, host_in[LA_IN_NKEYS_HINT] + LA_TREE_MAX > m->attn_thr);
     if (rc != LA_OK) return rc;
     if (host_out)
         HIPCHK(hipMemcpyAsync(host_out, m->state, (LA_ST_OUTTOK + 64) * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -860,6 +875,7 @@ extern "C" int la_lookahead_decode(la_llama* m, la_cache* c, void* stream, const
         if (nkeys + T + 1 > m->cfg.max_pos) { la_set_error("decode: position beyond the RoPE tables"); return LA_E_RANGE; }
         host_in[LA_IN_T] = T;
         host_in[LA_IN_MODE] = 0;
+        host_in[LA_IN_NKEYS_HINT] = nkeys;
         memcpy(host_in + LA_IN_IDS, ids, sizeof(int32_t) * T);
         memcpy(host_in + LA_IN_ROWMASK, rows, sizeof(uint64_t) * T);
         if (qts) qts[steps] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

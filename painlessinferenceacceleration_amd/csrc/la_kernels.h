@@ -80,7 +80,7 @@ int lk_qkv_post(hipStream_t st, const float* slabs, int n_slabs, int nh, int nkv
 int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                  const void* vfresh, const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys,
                  int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window = 0, int ring_keys = 0,
-                 const PfDesc* pf = nullptr);
+                 const PfDesc* pf = nullptr, int form = -1);      // form: 0 = key splits + combine, -1 = the default (one launch, la_attn1.hip) unless a lab knob says otherwise
 int lk_attn1_init();
 // single-sequence step, ONE launch (la_attn1.hip): no key-split partials, no combine kernel
 int lk_tree_attn1(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh, const void* vfresh,

@@ -2362,7 +2362,7 @@ int lk_tree_attn_b(hipStream_t st, const void* qf, const void* kmain, const void
 int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                  const void* vfresh, const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys,
                  int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window, int ring_keys,
-                 const PfDesc* pf) {
+                 const PfDesc* pf, int form) {
     AttnArgs a{};
     a.dbg_times = g_la_dbg_times;
     a.window = window; a.ring_tiles = ring_keys >> 5;
@@ -2374,7 +2374,7 @@ int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* 
     a.seq = nullptr; a.nkeys_b = nullptr; a.slot_tiles = 0;
     // default: the single-launch form (la_attn1.hip); la_debug_set(17, 0) = key splits + combine (the A/B switch, and the carrier of
     // the idle-window prefetch workgroups)
-    if (g_la_attn_one && !pf_extra(pf) && !g_la_attn_staged)
+    if (g_la_attn_one && form != 0 && !pf_extra(pf) && !g_la_attn_staged)
         return lk_tree_attn1(st, qf, kmain, vmain, kfresh, vfresh, rowmask, state, nh, nkv, max_keys, attn_xp, window, ring_keys);
     return tree_attn_launch(st, a, 1, attn_xp, pf);
 }

@@ -731,6 +731,7 @@ class LlamaVerifyEngine(object):
         a = self._in_np
         a[_lib.LA_IN_T] = T
         a[_lib.LA_IN_MODE] = mode
+        a[_lib.LA_IN_NKEYS_HINT] = self.n_keys               # host-side hint: which tree-attention form the step graph uses
         a[_lib.LA_IN_IDS:_lib.LA_IN_IDS + T] = ids
         self._in_rm[:T] = rowmask
 
