@@ -258,6 +258,9 @@ def main():
     ap.add_argument('--decoding-length', type=int, default=64, help='tree tokens per sequence and step (BASELINE: 64); > 64 (the reference\'s best '
                     'published setting is 128 with --branch-length 32, lookahead/README.md:100): wide trees through eng.tstep, --batch 1')
     ap.add_argument('--branch-length', type=int, default=12)
+    ap.add_argument('--dtype', choices=['bf16', 'fp16'], default='bf16',
+                    help='16-bit type of weights / activations / KV cache: bf16 = BASELINE (liblookahead_hip.so), fp16 = the reference\'s own dtype '
+                         '(liblookahead_hip_f16.so); the line reports it in "dtype"')
     ap.add_argument('--secondary-layers', type=int, default=0,
                     help='launch-path tests only: run the secondary legs too although --layers truncates the model, each with this many '
                          'layers (their lines carry n_layers; such numbers are NOT the metric)')
@@ -330,7 +333,8 @@ def main():
     if kv_ring:
         max_length = max(max_length, shape.sliding_window + 64 * B + 64)
     want_cpu = not args.no_cpu_baseline and world == 1 and B == 1      # the CPU leg is timed on rank 0 at N=1 only
-    sd = random_weights(shape, seed=0, device=dev, decisive=not args.pure_random)
+    tdtype = torch.float16 if args.dtype == 'fp16' else torch.bfloat16
+    sd = random_weights(shape, seed=0, device=dev, decisive=not args.pure_random, dtype=tdtype)
     sd_cpu = {k: v.cpu() for k, v in sd.items()} if want_cpu else None
     gemm_cfg = [int(x) for x in args.gemm_cfg.split(',')] if args.gemm_cfg else None
     if B == 1:
@@ -655,7 +659,7 @@ def main():
     out = {
         'metric': 'accepted_tokens_per_sec', 'value': round(accepted_all / elapsed, 2), 'unit': 'tokens/s',
         'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
         'config': {'workload': model_name + f' bf16 bs={B}/GPU lookahead verify loop, {DL}-token draft tree per sequence / 8-12 noisy branches '
                                f'(hier, decoding_length={DL}, branch_length={BL}), synthetic permutation-LM weights (N(0,0.02); o/down std 1e-4; '
                                'lm_head[pi(t)]=embed[t]) for decisive greedy margins, 512-token phrase-bank prompts',

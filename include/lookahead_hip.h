@@ -45,6 +45,12 @@ extern "C" {
 /* ABI version: bumped when a signature changes. */
 #define LA_ABI_VERSION  9    /* bumped whenever a struct layout or an entry point changes */
 int          la_abi_version(void);   /* == LA_ABI_VERSION of the header the library was built from */
+/* Storage / MFMA-input type of the loaded library: 0 = bfloat16 (liblookahead_hip.so), 1 = float16 (liblookahead_hip_f16.so, the
+ * dtype the reference's examples and benchmarks run, lookahead/benchmarks/llama_benchmark.py:27).  The two libraries are the same
+ * sources compiled twice and export this same ABI; every `bf16` buffer below holds the library's 16-bit type. */
+#define LA_DTYPE_BF16    0
+#define LA_DTYPE_F16     1
+int          la_abi_dtype(void);
 const char*  la_last_error(void);
 /* Parity aid (tests/test_gpu_e2e.py, per-depth residual probe): key 13 = n > 0: the single-sequence step runs the first n layers,
  * then the final norm + lm_head (0 = the whole model).  No other key is accepted here: the measurement knobs and A/B switches of

@@ -250,3 +250,4 @@ if __name__ == '__main__':
     accept_scan_vectors()
     run_reference_generation(torch.float32, 'fp32')
     run_reference_generation(torch.bfloat16, 'bf16')
+    run_reference_generation(torch.float16, 'fp16')      # round 4: the dtype the reference's examples / benchmarks load

@@ -135,3 +135,7 @@ if __name__ == '__main__':
         b = run(torch.bfloat16, 'bf16', suffix, dm, dl, bl, mn)
         assert [r['sequences'] for r in a] == [r['sequences'] for r in b] and [r['edls'] for r in a] == [r['edls'] for r in b], \
             'the decisive model must decode identically in fp32 and bf16'
+        if suffix == '':         # round 4: the reference's own dtype (benchmarks/llama_benchmark.py:27, examples/llama_example.py:19)
+            h = run(torch.float16, 'fp16', suffix, dm, dl, bl, mn)
+            assert [r['sequences'] for r in a] == [r['sequences'] for r in h] and [r['edls'] for r in a] == [r['edls'] for r in h], \
+                'the decisive model must decode identically in fp32 and fp16'

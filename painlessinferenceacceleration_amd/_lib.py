@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblookahead_hip.so")
+LIB_PATH = os.path.join(_HERE, "liblookahead_hip.so")              # bfloat16 build (BASELINE's dtype; also serves the dtype-free trie calls)
+LIB_PATH_F16 = os.path.join(_HERE, "liblookahead_hip_f16.so")      # float16 build: the same sources compiled with -DLA_DTYPE=1
+LA_DTYPE_BF16, LA_DTYPE_F16 = 0, 1
 
 LA_OK = 0
 ABI_VERSION = 9         # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
@@ -57,14 +59,14 @@ def _preload_torch_hip_runtime():
     return libdir
 
 
-def _load():
+def _load(path=LIB_PATH):
     _preload_torch_hip_runtime()
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} not found: build it with "
+            f"{path} not found: build it with "
             f"`bash {os.path.join(_HERE, 'csrc', 'build.sh')}` (hipcc --offload-arch=gfx950) or "
             f"`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback.")
-    return C.CDLL(LIB_PATH)
+    return C.CDLL(path)
 
 
 lib = _load()
@@ -106,8 +108,8 @@ class DecodeParamsC(C.Structure):
                 ("max_length", i32), ("max_steps", i32), ("n_eos", i32), ("eos", i32 * 8)]
 
 
-def _proto(name, restype, *argtypes):
-    fn = getattr(lib, name)
+def _proto(name, restype, *argtypes, dll=None):
+    fn = getattr(lib if dll is None else dll, name)
     fn.restype = restype
     fn.argtypes = list(argtypes)
     return fn
@@ -116,6 +118,7 @@ def _proto(name, restype, *argtypes):
 # every symbol declared in include/lookahead_hip.h (tests/test_abi.py checks this list against the header)
 PROTOTYPES = {
     "la_abi_version": (i32,),
+    "la_abi_dtype": (i32,),
     "la_last_error": (C.c_char_p,),
     "la_debug_set": (i32, i32, i32),
     "la_debug_get": (i32, i32),
@@ -216,16 +219,43 @@ LAB_PROTOTYPES = {
     "la_lab_set_ptr": (i32, i32, vp),
 }
 
-for _n, _sig in list(PROTOTYPES.items()) + list(LAB_PROTOTYPES.items()):
-    _proto(_n, _sig[0], *_sig[1:])
-if lib.la_abi_version() != ABI_VERSION:
-    raise ImportError(f"{LIB_PATH} implements ABI {lib.la_abi_version()}, the bindings expect {ABI_VERSION}: rebuild it with "
-                      f"`bash {os.path.join(_HERE, 'csrc', 'build.sh')}`")
+def _bind(dll, path, want_dtype):
+    for _n, _sig in list(PROTOTYPES.items()) + list(LAB_PROTOTYPES.items()):
+        _proto(_n, _sig[0], *_sig[1:], dll=dll)
+    if dll.la_abi_version() != ABI_VERSION or dll.la_abi_dtype() != want_dtype:
+        raise ImportError(f"{path} implements ABI {dll.la_abi_version()} / dtype {dll.la_abi_dtype()}, the bindings expect {ABI_VERSION} / "
+                          f"{want_dtype}: rebuild it with `bash {os.path.join(_HERE, 'csrc', 'build.sh')}`")
+    return dll
+
+
+_bind(lib, LIB_PATH, LA_DTYPE_BF16)
+_lib_f16 = None
+
+
+def lib_for(dtype):
+    """The library instantiated for a torch dtype: bfloat16 -> liblookahead_hip.so, float16 -> liblookahead_hip_f16.so (loaded on
+    first use; same ABI, same sources, v_mfma_f32_32x32x16_f16 and fp16 rounding points).  Anything else is refused: the engine
+    computes in the checkpoint's 16-bit type, never in a silently converted one."""
+    global _lib_f16
+    name = str(dtype).replace('torch.', '')
+    if name == 'bfloat16':
+        return lib
+    if name == 'float16':
+        if _lib_f16 is None:
+            _lib_f16 = _bind(_load(LIB_PATH_F16), LIB_PATH_F16, LA_DTYPE_F16)
+        return _lib_f16
+    raise ValueError(f'no liblookahead_hip build for dtype {dtype}: bfloat16 and float16 exist')
 
 
 def last_error() -> str:
-    s = lib.la_last_error()
-    return s.decode("utf-8", "replace") if s else ""
+    """Text of the last error on this thread (each loaded library keeps its own; the non-empty one is reported)."""
+    out = []
+    for dll in (lib, _lib_f16):
+        if dll is not None:
+            s = dll.la_last_error()
+            if s:
+                out.append(s.decode("utf-8", "replace"))
+    return " | ".join(out)
 
 
 def check(rc: int, what: str = ""):

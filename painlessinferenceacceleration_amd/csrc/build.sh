@@ -1,21 +1,34 @@
 #!/bin/bash
-# Build liblookahead_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+# Build liblookahead_hip.so (bf16) and liblookahead_hip_f16.so (fp16: the same sources with -DLA_DTYPE=1) for gfx950 (MI355X) in-tree.
+# hipcc cross-compiles without a GPU.  build.sh [out.so] builds the bf16 library only when an output path is given.
 set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
-OUT="${1:-$HERE/../liblookahead_hip.so}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -amdgpu-kernarg-preload-count=16 ${LA_EXTRA_HIPCC_FLAGS:-}"
-OBJ="${LA_OBJ_DIR:-$HERE/_obj}"
-mkdir -p "$OBJ"
-pids=()
-for f in la_kernels.hip la_attn1.hip la_mblock.hip la_trie_dev.hip la_engine.cpp la_abi.cpp la_lab.cpp la_trie.cpp la_comm.cpp; do
-  o="$OBJ/${f%.*}.o"
-  if [ ! -f "$o" ] || [ "$HERE/$f" -nt "$o" ] || [ "$HERE/la_common.h" -nt "$o" ] || [ "$HERE/la_kernels.h" -nt "$o" ] || [ "$HERE/la_mblock.h" -nt "$o" ] \
-     || [ "$HERE/../../include/lookahead_hip.h" -nt "$o" ] || [ "$HERE/../../include/lookahead_hip_lab.h" -nt "$o" ]; then
-    ( $HIPCC $FLAGS -x hip -c "$HERE/$f" -o "$o" ) &
-    pids+=($!)
-  fi
-done
-for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$OBJ"/la_kernels.o "$OBJ"/la_attn1.o "$OBJ"/la_mblock.o "$OBJ"/la_trie_dev.o "$OBJ"/la_engine.o "$OBJ"/la_abi.o "$OBJ"/la_lab.o "$OBJ"/la_trie.o "$OBJ"/la_comm.o -ldl
-echo "built $OUT"
+BASEFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -amdgpu-kernarg-preload-count=16 ${LA_EXTRA_HIPCC_FLAGS:-}"
+SRCS="la_kernels.hip la_attn1.hip la_mblock.hip la_trie_dev.hip la_engine.cpp la_abi.cpp la_lab.cpp la_trie.cpp la_comm.cpp"
+build_one() {     # out.so, object dir, extra flags
+  local OUT="$1" OBJ="$2" FLAGS="$BASEFLAGS $3"
+  mkdir -p "$OBJ"
+  local pids=() objs=()
+  for f in $SRCS; do
+    local o="$OBJ/${f%.*}.o"
+    objs+=("$o")
+    if [ ! -f "$o" ] || [ "$HERE/$f" -nt "$o" ] || [ "$HERE/la_common.h" -nt "$o" ] || [ "$HERE/la_kernels.h" -nt "$o" ] || [ "$HERE/la_mblock.h" -nt "$o" ] \
+       || [ "$HERE/../../include/lookahead_hip.h" -nt "$o" ] || [ "$HERE/../../include/lookahead_hip_lab.h" -nt "$o" ] || [ "$HERE/build.sh" -nt "$o" ]; then
+      ( $HIPCC $FLAGS -x hip -c "$HERE/$f" -o "$o" ) &
+      pids+=($!)
+    fi
+  done
+  for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o "$OUT" "${objs[@]}" -ldl
+  echo "built $OUT"
+}
+if [ $# -ge 1 ]; then
+  build_one "$1" "${LA_OBJ_DIR:-$HERE/_obj}" ""
+else
+  build_one "$HERE/../liblookahead_hip.so" "${LA_OBJ_DIR:-$HERE/_obj}" "" &
+  b1=$!
+  build_one "$HERE/../liblookahead_hip_f16.so" "${LA_OBJ_DIR_F16:-$HERE/_obj_f16}" "-DLA_DTYPE=1" &
+  b2=$!
+  wait $b1; wait $b2
+fi

@@ -2,6 +2,7 @@
 // launchers for the single-kernel entry points declared in include/lookahead_hip.h.
 #include <hip/hip_runtime.h>
 #include <string>
+#include "la_common.h"
 #include "la_kernels.h"
 #include "la_mblock.h"
 
@@ -15,6 +16,7 @@ void la_set_error(const std::string& s) { g_err = s; }
 extern "C" {
 
 int la_abi_version(void) { return LA_ABI_VERSION; }
+int la_abi_dtype(void) { return LA_DTYPE; }
 const char* la_last_error(void) { return g_err.c_str(); }
 extern int g_la_stop_layers, g_la_graph_epoch;
 int la_mb_gemm(void* stream, int kind, const void* wp, const void* xp, int N, int K, int nblk, int n_wg, int ksplit,

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
 #pragma unroll
         for (int i = 0; i < 16; ++i) sc[i] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qs[s * 64 + lane], sc, 0, 0, 0);
+        for (int s = 0; s < 8; ++s) sc = LA_MFMA(kf[s], qs[s * 64 + lane], sc, 0, 0, 0);
         float mx = LA_NEG;
         // committed tile every row sees whole (no window, all 32 keys below nkeys): no mask arithmetic (wave-uniform)
         const bool whole = !fresh && window <= 0 && (ts + kb) * 32 + 31 < nkeys;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
             for (int i = 0; i < 16; ++i) {
                 // attn_weights = bf16(QK^T) / sqrt(head_dim) -> bf16 (modeling_llama.py:270); bf16(x / sqrt(128)) == bf16(x * fp32(1 / sqrt(128)))
                 // for every finite bf16 x (tests/test_oracle_llama.py::test_attention_scale_as_multiply_is_exact)
-                const float v = bfr(bfr(sc[i]) * 0.088388346135616302490234375f);
+                const float v = attn_scale(sc[i]);
                 sc[i] = v;
                 mx = fmaxf(mx, v);
             }
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int kk = (i & 3) + 8 * (i >> 2) + 4 * hh;
-                float v = bfr(bfr(sc[i]) * 0.088388346135616302490234375f);
+                float v = attn_scale(sc[i]);
                 const int kidx = (ts + kb) * 32 + kk;                  // committed keys: absolute index = position
                 const bool ok = fresh ? ((rm >> (kb * 32 + kk)) & 1ull) != 0ull : (kidx < nkeys && kidx >= key_lo);
                 v = ok ? v : LA_NEG;
@@ -156,8 +156,8 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
         }
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db * 2 + 0], pf[0], o[db], 0, 0, 0);
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db * 2 + 1], pf[1], o[db], 0, 0, 0);
+            o[db] = LA_MFMA(vf[db * 2 + 0], pf[0], o[db], 0, 0, 0);
+            o[db] = LA_MFMA(vf[db * 2 + 1], pf[1], o[db], 0, 0, 0);
         }
     };
 

@@ -18,6 +18,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Storage / MFMA-input type of THIS build of the library.  Every kernel is written once; the build compiles the sources twice:
+//   LA_DTYPE 0 -> liblookahead_hip.so      bfloat16, v_mfma_f32_32x32x16_bf16 (BASELINE's dtype)
+//   LA_DTYPE 1 -> liblookahead_hip_f16.so  float16,  v_mfma_f32_32x32x16_f16  (what the reference's own examples and benchmarks run:
+//                 lookahead/benchmarks/llama_benchmark.py:27, examples/llama_example.py:19)
+// Same fragment layouts, same rounding POINTS (every nn.Linear output, RoPE product / sum, residual add, SiLU, softmax P and attention
+// output are rounded to the storage type exactly where the reference's eager graph rounds); `bf16_t` / bf2f / f2bf / bfr name "the
+// 16-bit storage element" and its conversions in both builds.  la_abi_dtype() reports which build a process loaded.
+#ifndef LA_DTYPE
+#define LA_DTYPE 0
+#endif
 typedef uint16_t bf16_t;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
@@ -27,11 +37,17 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 #define LA_TB 64          // tokens per block (rows of every activation matrix)
 
-__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ float bf2f(bf16_t v) {
+    if constexpr (LA_DTYPE == 1) return (float)__builtin_bit_cast(_Float16, v);
+    else return __uint_as_float(((uint32_t)v) << 16);
+}
 // round-to-nearest-even, NaN preserving: same rounding torch uses for float -> bfloat16
 // (the gfx950 converter v_cvt_pk_bf16_f32: IEEE round-to-nearest-even, quiet NaN — one instruction; the integer form
 //  u + 0x7fff + ((u >> 16) & 1) it replaces is kept as f2bf_int for the host-visible packers' reference)
-__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    if constexpr (LA_DTYPE == 1) return __builtin_bit_cast(unsigned short, (_Float16)f);       // v_cvt_f16_f32: round-to-nearest-even, inf on overflow (as torch)
+    else return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
 __device__ __forceinline__ bf16_t f2bf_int(float f) {
     const uint32_t u = __float_as_uint(f);
     const uint32_t r = u + 0x7fffu + ((u >> 16) & 1u);
@@ -39,6 +55,21 @@ __device__ __forceinline__ bf16_t f2bf_int(float f) {
     return (bf16_t)((nan ? (u | 0x400000u) : r) >> 16);
 }
 __device__ __forceinline__ float bfr(float f) { return bf2f(f2bf(f)); }
+// the 32x32x16 MFMA of the build's storage type (identical operand layouts): LA_MFMA(a, b, c, 0, 0, 0)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+#if LA_DTYPE == 1
+#define LA_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), (x), (y), (z))
+#else
+#define LA_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), (x), (y), (z))
+#endif
+// attn_weights = (q @ k^T in the storage type) / sqrt(head_dim = 128), rounded to the storage type (modeling_llama.py:270).
+// bf16: x / sqrt(128) == x * fp32(1 / sqrt(128)) after rounding for EVERY finite bf16 x (exhaustive check,
+// tests/test_oracle_llama.py::test_attention_scale_as_multiply_is_exact) — one multiply; fp16: 52 of the 65536 patterns differ, so the
+// fp16 build divides (torch: fp32 division of the upcast value, then one rounding).
+__device__ __forceinline__ float attn_scale(float s) {
+    if constexpr (LA_DTYPE == 1) return bfr(bfr(s) / 11.313708498984761f);
+    else return bfr(bfr(s) * 0.088388346135616302490234375f);
+}
 
 // accumulator register r of a 32x32 MFMA tile -> row inside the tile (col = lane&31)
 __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }

@@ -593,8 +593,8 @@ __device__ __forceinline__ void gemm64_body(const bf16_t* __restrict__ wp_s, con
             for (int d = 0; d < D; ++d) {
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
-                    acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][0], acc[rb][0], 0, 0, 0);
-                    acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][1], acc[rb][1], 0, 0, 0);
+                    acc[rb][0] = LA_MFMA(fa[d][rb], fb[d][0], acc[rb][0], 0, 0, 0);
+                    acc[rb][1] = LA_MFMA(fa[d][rb], fb[d][1], acc[rb][1], 0, 0, 0);
                 }
                 const int dd = (d < nv ? g * D + d : 0);
 #pragma unroll
@@ -609,8 +609,8 @@ __device__ __forceinline__ void gemm64_body(const bf16_t* __restrict__ wp_s, con
             if (d < last_valid) {
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
-                    acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][0], acc[rb][0], 0, 0, 0);
-                    acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][1], acc[rb][1], 0, 0, 0);
+                    acc[rb][0] = LA_MFMA(fa[d][rb], fb[d][0], acc[rb][0], 0, 0, 0);
+                    acc[rb][1] = LA_MFMA(fa[d][rb], fb[d][1], acc[rb][1], 0, 0, 0);
                 }
             }
         }
@@ -881,8 +881,8 @@ __device__ __forceinline__ void gemm64r_body(const bf16_t* __restrict__ wp_s, co
             for (int d = 0; d < D; ++d) {
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
-                    acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][0], acc[rb][0], 0, 0, 0);
-                    acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][1], acc[rb][1], 0, 0, 0);
+                    acc[rb][0] = LA_MFMA(fa[d][rb], fb[d][0], acc[rb][0], 0, 0, 0);
+                    acc[rb][1] = LA_MFMA(fa[d][rb], fb[d][1], acc[rb][1], 0, 0, 0);
                 }
                 const int dd = (d < nv2 ? g * D + d : 0);
 #pragma unroll
@@ -897,8 +897,8 @@ __device__ __forceinline__ void gemm64r_body(const bf16_t* __restrict__ wp_s, co
             if (d < last_valid) {
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb) {
-                    acc[rb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][0], acc[rb][0], 0, 0, 0);
-                    acc[rb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[d][rb], fb[d][1], acc[rb][1], 0, 0, 0);
+                    acc[rb][0] = LA_MFMA(fa[d][rb], fb[d][0], acc[rb][0], 0, 0, 0);
+                    acc[rb][1] = LA_MFMA(fa[d][rb], fb[d][1], acc[rb][1], 0, 0, 0);
                 }
             }
         }
@@ -1441,7 +1441,7 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(const bf16_t*
 #pragma unroll
         for (int i = 0; i < 16; ++i) sc[i] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], q[s], sc, 0, 0, 0);
+        for (int s = 0; s < 8; ++s) sc = LA_MFMA(kf[s], q[s], sc, 0, 0, 0);
         // attn_weights = bf16(QK^T) / sqrt(head_dim) -> bf16 (modeling_llama.py:270), masked keys excluded
         float mx = LA_NEG;
         // a committed tile every row sees whole (no window, one sequence, all 32 keys below nkeys) needs no mask arithmetic:
@@ -1450,7 +1450,7 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(const bf16_t*
         if (whole) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float v = bfr(bfr(sc[i]) * 0.088388346135616302490234375f);
+                const float v = attn_scale(sc[i]);
                 sc[i] = v;
                 mx = fmaxf(mx, v);
             }
@@ -1460,7 +1460,7 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(const bf16_t*
                 const int kk = (i & 3) + 8 * (i >> 2) + 4 * hh;
                 // bf16(x / sqrt(128)) == bf16(x * fp32(1 / sqrt(128))) for EVERY finite bf16 x (checked exhaustively over the 65536 bit
                 // patterns, tests/test_oracle_llama.py::test_attention_scale_as_multiply_is_exact): one multiply instead of an IEEE division
-                float v = bfr(bfr(sc[i]) * 0.088388346135616302490234375f);
+                float v = attn_scale(sc[i]);
                 const int kidx = (ts + kb) * 32 + kk;      // committed keys: absolute index = position
                 const bool ok = fresh ? ((rm >> (kb * 32 + kk)) & 1ull) != 0ull : (kidx < nk_row && kidx >= key_lo);
                 v = ok ? v : LA_NEG;
@@ -1502,8 +1502,8 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(const bf16_t*
                          "+v"(vf[6]), "+v"(vf[7]) :: "memory");
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db * 2 + 0], pf[0], o[db], 0, 0, 0);
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db * 2 + 1], pf[1], o[db], 0, 0, 0);
+            o[db] = LA_MFMA(vf[db * 2 + 0], pf[0], o[db], 0, 0, 0);
+            o[db] = LA_MFMA(vf[db * 2 + 1], pf[1], o[db], 0, 0, 0);
         }
     };
     if constexpr (ST) {

@@ -267,7 +267,7 @@ __device__ __forceinline__ void gemm_mb_body(const MbArgs& a, const int blk0, co
                     const bf16x8* xt = xs + (((u & 1) * FR) + (kp * KT + j) * NT) * 64 + lane;
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slotw], xt[t * 64], acc[t], 0, 0, 0);
+                        acc[t] = LA_MFMA(fa[slotw], xt[t * 64], acc[t], 0, 0, 0);
                     const int nx = g * D + slotw + D;
                     fa[slotw] = __builtin_nontemporal_load(wbase + woff + (unsigned)(nx < my_cnt ? nx : 0) * wstr);
                     __builtin_amdgcn_sched_barrier(0);
@@ -292,7 +292,7 @@ __device__ __forceinline__ void gemm_mb_body(const MbArgs& a, const int blk0, co
                             const bf16x8* xt = xs + (((u & 1) * FR) + (kp * KT + j) * NT) * 64 + lane;
 #pragma unroll
                             for (int t = 0; t < NT; ++t)
-                                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slotw], xt[t * 64], acc[t], 0, 0, 0);
+                                acc[t] = LA_MFMA(fa[slotw], xt[t * 64], acc[t], 0, 0, 0);
                         }
                     }
                     xstore((u + 1) & 1, xr[(u + 1) % XD]);
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
 // chip sustains, DMA-only loop 67 us (x from L2 and weights from HBM share the CU's in-order vector-memory path).
 // ---------------------------------------------------------------------------------------------------------------
 // float -> bf16 on the gfx950 converter (v_cvt_pk_bf16_f32: round-to-nearest-even like f2bf, one instruction instead of six)
-__device__ __forceinline__ bf16_t f2bf_hw(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ bf16_t f2bf_hw(float f) { return f2bf(f); }
 __device__ __forceinline__ float bfr_hw(float f) { return bf2f(f2bf_hw(f)); }
 
 template <int N> __device__ __forceinline__ void vm_wait() {
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
     };
     auto mma = [&](int r, int t, const bf16x8 (&fa)[2], const bf16x8 (&fb)[TW]) {
         if constexpr (DBG == 1 || DBG == 3) acc[r][t][0] += __builtin_bit_cast(float, (int)(fa[r][0] ^ fb[t][0]));
-        else acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[r], fb[t], acc[r][t], 0, 0, 0);
+        else acc[r][t] = LA_MFMA(fa[r], fb[t], acc[r][t], 0, 0, 0);
     };
 
     constexpr int H = GEO::H;
@@ -1346,7 +1346,7 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) sc[i] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], q[s], sc, 0, 0, 0);
+        for (int s = 0; s < 8; ++s) sc = LA_MFMA(kf[s], q[s], sc, 0, 0, 0);
         float mx = MB_NEG;
         unsigned long long xw_tile = 0ull;
         if constexpr (PIECE) { if (prior && piece) xw_tile = xrow[(it - NP) >> 1]; }
@@ -1355,7 +1355,7 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
             const int kk = (i & 3) + 8 * (i >> 2) + 4 * hh;
             // bf16(x / sqrt(128)) == bf16(x * fp32(1 / sqrt(128))) for EVERY finite bf16 x (checked exhaustively over the 65536 bit
             // patterns, tests/test_oracle_llama.py::test_attention_scale_as_multiply_is_exact): one multiply instead of an IEEE division
-            float v = bfr(bfr(sc[i]) * 0.088388346135616302490234375f);
+            float v = attn_scale(sc[i]);
             bool ok;
             if (own) ok = ((rm >> (kb * 32 + kk)) & 1ull) != 0ull;
             else if (PIECE && prior && piece) {
@@ -1390,8 +1390,8 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
         }
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db * 2 + 0], pf[0], o[db], 0, 0, 0);
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db * 2 + 1], pf[1], o[db], 0, 0, 0);
+            o[db] = LA_MFMA(vf[db * 2 + 0], pf[0], o[db], 0, 0, 0);
+            o[db] = LA_MFMA(vf[db * 2 + 1], pf[1], o[db], 0, 0, 0);
         }
     };
     {

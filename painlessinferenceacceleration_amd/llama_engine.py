@@ -138,14 +138,14 @@ def load_hf_checkpoint(model_dir):
     return cfg, sd
 
 
-def rope_tables(head_dim, max_pos, theta, device):
+def rope_tables(head_dim, max_pos, theta, device, dtype=torch.bfloat16):
     """cos/sin exactly as LlamaRotaryEmbedding.forward (modeling_llama.py:93-126): fp32 outer product,
-    cos()/sin() in fp32, cast to the activation dtype (bf16).  Only the first head_dim/2 columns are stored
+    cos()/sin() in fp32, cast to the activation dtype (bfloat16 or float16).  Only the first head_dim/2 columns are stored
     (emb = cat(freqs, freqs))."""
     inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
     pos = torch.arange(max_pos, dtype=torch.int64).float()
     freqs = (inv_freq[:, None].float() @ pos[None, :].float()).transpose(0, 1)      # [max_pos, hd/2]
-    return freqs.cos().to(torch.bfloat16).to(device).contiguous(), freqs.sin().to(torch.bfloat16).to(device).contiguous()
+    return freqs.cos().to(dtype).to(device).contiguous(), freqs.sin().to(dtype).to(device).contiguous()
 
 
 def random_weights(shape, seed=0, std=0.02, device='cpu', dtype=torch.bfloat16, decisive=False):
@@ -208,9 +208,18 @@ class LlamaVerifyEngine(object):
     verify block are shared by the active slots (bstep)."""
 
     def __init__(self, shape, state_dict, max_length=2048, device='cuda:0', attn_split=0, gemm_cfg=None,
-                 consume_state_dict=False, balanced=True, n_slots=1, fuse=0, max_blocks=0, kv_ring=False):
+                 consume_state_dict=False, balanced=True, n_slots=1, fuse=0, max_blocks=0, kv_ring=False, dtype=None):
         if not torch.cuda.is_available():
             raise RuntimeError('LlamaVerifyEngine needs an MI355X: the verify step has no CPU fallback')
+        # The engine computes in the checkpoint's own 16-bit type: bfloat16 (BASELINE) or float16 (what the reference's examples and
+        # benchmarks load, benchmarks/llama_benchmark.py:27) — one library build per type (_lib.lib_for), never a silent conversion.
+        # dtype=None: the dtype of the state dict's lm_head (fp32 state dicts run as bfloat16, as before).
+        if dtype is None:
+            dtype = state_dict['lm_head.weight'].dtype if state_dict and 'lm_head.weight' in state_dict else torch.bfloat16
+            if dtype not in (torch.bfloat16, torch.float16):
+                dtype = torch.bfloat16
+        self.dtype = dtype
+        self._lib = _lib.lib_for(dtype)
         self.shape = shape
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
@@ -232,18 +241,18 @@ class LlamaVerifyEngine(object):
         self._keep = []
 
         def dev(t):
-            t = t.to(device=self.device, dtype=torch.bfloat16).contiguous()
+            t = t.to(device=self.device, dtype=self.dtype).contiguous()
             self._keep.append(t)
             return t
 
         def pack(w, w2=None):
-            w = w.to(device=self.device, dtype=torch.bfloat16).contiguous()
+            w = w.to(device=self.device, dtype=self.dtype).contiguous()
             n, k = w.shape
             if w2 is not None:
-                w2 = w2.to(device=self.device, dtype=torch.bfloat16).contiguous()
-            out = torch.empty((2 if w2 is not None else 1) * n * k, dtype=torch.bfloat16, device=self.device)
+                w2 = w2.to(device=self.device, dtype=self.dtype).contiguous()
+            out = torch.empty((2 if w2 is not None else 1) * n * k, dtype=self.dtype, device=self.device)
             torch.cuda.synchronize(self.device)          # w was produced on torch's stream
-            check(lib.la_pack_weight(sp, w.data_ptr(), w2.data_ptr() if w2 is not None else None, n, k,
+            check(self._lib.la_pack_weight(sp, w.data_ptr(), w2.data_ptr() if w2 is not None else None, n, k,
                                      1 if w2 is not None else 0, out.data_ptr()), 'pack_weight')
             self.stream.synchronize()                    # w / w2 may be freed by the caller right after
             self._keep.append(out)
@@ -261,10 +270,10 @@ class LlamaVerifyEngine(object):
             for slot, (kind, n_rows) in enumerate([(2, (shape.n_heads + 2 * shape.n_kv_heads) * hd), (1, shape.ffn),
                                                    (0, shape.vocab)]):
                 nwg = n_cu
-                n = lib.la_rowplan(kind, n_rows, nwg, None)
+                n = self._lib.la_rowplan(kind, n_rows, nwg, None)
                 if n > 0:
                     plan = np.zeros(n, dtype=np.int32)
-                    check(min(lib.la_rowplan(kind, n_rows, nwg, plan.ctypes.data_as(_lib.pi32)), 0), 'rowplan')
+                    check(min(self._lib.la_rowplan(kind, n_rows, nwg, plan.ctypes.data_as(_lib.pi32)), 0), 'rowplan')
                     plans[slot] = torch.from_numpy(plan).to(self.device)
                     plan_kinds[slot] = (kind, n_rows, nwg)
                     self.balanced_wg[slot] = nwg
@@ -280,10 +289,10 @@ class LlamaVerifyEngine(object):
             if os.environ.get('LA_QKV_MB_WG') is not None:
                 want = int(os.environ['LA_QKV_MB_WG'])
             if want > 0 and want % 16 == 0 and want < self.balanced_wg[0] and pairs % want == 0 and pairs // want <= 32:
-                n = lib.la_rowplan(2, 2 * pairs, want, None)
+                n = self._lib.la_rowplan(2, 2 * pairs, want, None)
                 if n > 0:
                     plan = np.zeros(n, dtype=np.int32)
-                    check(min(lib.la_rowplan(2, 2 * pairs, want, plan.ctypes.data_as(_lib.pi32)), 0), 'rowplan')
+                    check(min(self._lib.la_rowplan(2, 2 * pairs, want, plan.ctypes.data_as(_lib.pi32)), 0), 'rowplan')
                     plans['qkv_mb'] = torch.from_numpy(plan).to(self.device)
                     plan_kinds['qkv_mb'] = (2, 2 * pairs, want)
                     self.qkv_mb_wg = want
@@ -291,11 +300,11 @@ class LlamaVerifyEngine(object):
         def pack_planned(slot, mats):
             """compact workgroup-major packing by the plan (la_pack_planned)"""
             kind, n_rows, nwg = plan_kinds[slot]
-            mats = [m.to(device=self.device, dtype=torch.bfloat16).contiguous() for m in mats]
+            mats = [m.to(device=self.device, dtype=self.dtype).contiguous() for m in mats]
             K = mats[0].shape[1]
-            out = torch.empty(lib.la_planned_elems(kind, n_rows, K, nwg), dtype=torch.bfloat16, device=self.device)
+            out = torch.empty(self._lib.la_planned_elems(kind, n_rows, K, nwg), dtype=self.dtype, device=self.device)
             torch.cuda.synchronize(self.device)
-            check(lib.la_pack_planned(sp, mats[0].data_ptr(), mats[1].data_ptr() if len(mats) > 1 else None,
+            check(self._lib.la_pack_planned(sp, mats[0].data_ptr(), mats[1].data_ptr() if len(mats) > 1 else None,
                                       plans[slot].data_ptr(), kind, n_rows, K, nwg, out.data_ptr()), 'pack_planned')
             self.stream.synchronize()
             self._keep.append(out)
@@ -306,7 +315,7 @@ class LlamaVerifyEngine(object):
         self.qkv_fused = not (gemm_cfg and len(gemm_cfg) > 1 and gemm_cfg[1] < 0)
         n_qkv = (shape.n_heads + 2 * shape.n_kv_heads) * hd
         perm_np = np.zeros(n_qkv, dtype=np.int32)
-        check(lib.la_qkv_row_perm(shape.n_heads, shape.n_kv_heads, perm_np.ctypes.data_as(_lib.pi32)), 'qkv_row_perm')
+        check(self._lib.la_qkv_row_perm(shape.n_heads, shape.n_kv_heads, perm_np.ctypes.data_as(_lib.pi32)), 'qkv_row_perm')
         qkv_perm = torch.from_numpy(perm_np.astype(np.int64)).to(self.device)
         layers = (_lib.LlamaLayerWeightsC * shape.n_layers)()
         for i in range(shape.n_layers):
@@ -343,8 +352,8 @@ class LlamaVerifyEngine(object):
                     if gu_all is None:
                         gstride = (one_gu.numel() + 63) // 64 * 64
                         dstride = (one_dn.numel() + 63) // 64 * 64
-                        gu_all = torch.zeros(shape.n_experts * gstride, dtype=torch.bfloat16, device=self.device)
-                        dn_all = torch.zeros(shape.n_experts * dstride, dtype=torch.bfloat16, device=self.device)
+                        gu_all = torch.zeros(shape.n_experts * gstride, dtype=self.dtype, device=self.device)
+                        dn_all = torch.zeros(shape.n_experts * dstride, dtype=self.dtype, device=self.device)
                     gu_all[e * gstride:e * gstride + one_gu.numel()].copy_(one_gu)
                     dn_all[e * dstride:e * dstride + one_dn.numel()].copy_(one_dn)
                     gu[e] = gu_all.data_ptr() + 2 * e * gstride
@@ -363,7 +372,7 @@ class LlamaVerifyEngine(object):
             torch.cuda.synchronize(self.device)
         self._layers = layers
         self.embed = dev(take('model.embed_tokens.weight'))
-        self.rope_cos, self.rope_sin = rope_tables(hd, self.max_pos, shape.rope_theta, self.device)
+        self.rope_cos, self.rope_sin = rope_tables(hd, self.max_pos, shape.rope_theta, self.device, self.dtype)
         w = _lib.LlamaWeightsC()
         w.embed = self.embed.data_ptr()
         w.lm_head = (pack_planned(2, [take('lm_head.weight')]) if self.balanced_wg[2] else pack(take('lm_head.weight'))).data_ptr()
@@ -393,11 +402,11 @@ class LlamaVerifyEngine(object):
         cfg.sliding_window = int(getattr(shape, 'sliding_window', 0))
         cfg.kv_ring = int(self.kv_ring)
         self._cfg = cfg
-        nbytes = lib.la_llama_workspace_bytes(C.byref(cfg))
+        nbytes = self._lib.la_llama_workspace_bytes(C.byref(cfg))
         if nbytes <= 0:
             raise _lib.LookaheadHipError(f'la_llama_workspace_bytes: {_lib.last_error()}')
         self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
-        self._h = lib.la_llama_create(C.byref(cfg), C.byref(w), self.workspace.data_ptr(), nbytes)
+        self._h = self._lib.la_llama_create(C.byref(cfg), C.byref(w), self.workspace.data_ptr(), nbytes)
         if not self._h:
             raise _lib.LookaheadHipError(f'la_llama_create: {_lib.last_error()}')
         self.host_in = torch.zeros(_lib.LA_IN_WORDS, dtype=torch.int32).pin_memory()
@@ -424,7 +433,7 @@ class LlamaVerifyEngine(object):
     def __del__(self):
         h = getattr(self, '_h', None)
         if h:
-            lib.la_llama_destroy(h)
+            self._lib.la_llama_destroy(h)
             self._h = None
 
     # ------------------------------------------------------------------------------------------------
@@ -436,13 +445,13 @@ class LlamaVerifyEngine(object):
         return self.max_pos - 65 if self.kv_ring else self.max_keys
 
     def reset(self):
-        check(lib.la_llama_reset(self._h, self._sp()), 'llama_reset')
+        check(self._lib.la_llama_reset(self._h, self._sp()), 'llama_reset')
         self.n_keys = 0
         self.slot_keys = [0] * self.n_slots
 
     # ---- cursor batch ------------------------------------------------------------------------------------
     def reset_slot(self, slot):
-        check(lib.la_llama_reset_slot(self._h, self._sp(), int(slot)), 'reset_slot')
+        check(self._lib.la_llama_reset_slot(self._h, self._sp(), int(slot)), 'reset_slot')
         if slot < 0:
             self.slot_keys = [0] * self.n_slots
         else:
@@ -473,7 +482,7 @@ class LlamaVerifyEngine(object):
             a[_lib.LA_BIN_LIMIT + slot] = max(1, min(16, int(limit)))
             row += n
         a[_lib.LA_BIN_T] = row
-        fn = lib.la_llama_bstep_eager if eager else lib.la_llama_bstep
+        fn = self._lib.la_llama_bstep_eager if eager else self._lib.la_llama_bstep
         check(fn(self._h, self._sp(), self.host_bin.data_ptr(), self.host_bout.data_ptr()), 'llama_bstep')
         self.stream.synchronize()
         o = self._bout_np
@@ -497,7 +506,7 @@ class LlamaVerifyEngine(object):
             for k, r in enumerate(rows):
                 keep[base + int(r)] = k
             assert self.slot_keys[slot] + len(rows) <= self._capacity(), 'KV cache capacity of the slot exceeded'
-        check(lib.la_llama_bcommit(self._h, self._sp(), keep.ctypes.data_as(_lib.pi32), self.host_bout.data_ptr()), 'llama_bcommit')
+        check(self._lib.la_llama_bcommit(self._h, self._sp(), keep.ctypes.data_as(_lib.pi32), self.host_bout.data_ptr()), 'llama_bcommit')
         for slot in kept:
             self.slot_keys[slot] = int(self._bout_np[_lib.LA_BST_NKEYS + slot])
 
@@ -510,7 +519,7 @@ class LlamaVerifyEngine(object):
         for b, rows in enumerate(kept):
             for k, r in enumerate(rows):
                 keep[64 * b + int(r)] = k
-        check(lib.la_llama_mcommit(self._h, self._sp(), len(kept), keep.ctypes.data_as(_lib.pi32), self.host_mout.data_ptr()),
+        check(self._lib.la_llama_mcommit(self._h, self._sp(), len(kept), keep.ctypes.data_as(_lib.pi32), self.host_mout.data_ptr()),
               'llama_mcommit')
         for slot in slots:
             self.slot_keys[slot] = int(self._mout_np[_lib.LA_MOUT_NKEYS + slot])
@@ -573,7 +582,7 @@ class LlamaVerifyEngine(object):
             rows[slot] = rows.get(slot, 0) + len(ids)
         for slot, n in rows.items():
             assert self.slot_keys[slot] + n <= self._capacity(), 'KV cache capacity of the slot exceeded'
-        fn = lib.la_llama_mstep_eager if eager else lib.la_llama_mstep
+        fn = self._lib.la_llama_mstep_eager if eager else self._lib.la_llama_mstep
         check(fn(self._h, self._sp(), self.host_min.data_ptr(), self.host_mout.data_ptr()), 'llama_mstep')
         self.stream.synchronize()
         o = self._mout_np
@@ -596,7 +605,7 @@ class LlamaVerifyEngine(object):
         assert self.max_blocks and 1 <= nb <= self.max_blocks
         arr = lambda v: (C.c_int32 * nb)(*[int(x) for x in v])
         lim = [max(1, min(_lib.LA_MOUT_TOKS, int(x))) for x in limits]
-        check(lib.la_llama_mstep_trie(self._h, self._sp(), nb, arr(slots), arr(lim), arr(last_tokens),
+        check(self._lib.la_llama_mstep_trie(self._h, self._sp(), nb, arr(slots), arr(lim), arr(last_tokens),
                                       C.c_void_p(dev_trie.out_ids.data_ptr() + 4 * 64 * q0), C.c_void_p(dev_trie.out_rm.data_ptr() + 8 * 64 * q0),
                                       C.c_void_p(dev_trie.out_n.data_ptr() + 4 * q0), self.host_mout.data_ptr()), 'llama_mstep_trie')
         if put_idxs is not None:
@@ -652,7 +661,7 @@ class LlamaVerifyEngine(object):
             for q in range(p):
                 self._min_xm[64 * p:64 * p + n, q] = rm[r0:r1, q]
         self._mstep_slots = [slot] * nb
-        fn = lib.la_llama_mstep_eager if eager else lib.la_llama_mstep
+        fn = self._lib.la_llama_mstep_eager if eager else self._lib.la_llama_mstep
         check(fn(self._h, self._sp(), self.host_min.data_ptr(), self.host_mout.data_ptr()), 'llama_mstep')
         self.stream.synchronize()
         o = self._mout_np
@@ -669,7 +678,7 @@ class LlamaVerifyEngine(object):
         keep = np.full(64 * nb, -1, dtype=np.int32)
         for k, r in enumerate(rows):
             keep[int(r)] = k
-        check(lib.la_llama_mcommit(self._h, self._sp(), nb, keep.ctypes.data_as(_lib.pi32), self.host_mout.data_ptr()), 'llama_mcommit')
+        check(self._lib.la_llama_mcommit(self._h, self._sp(), nb, keep.ctypes.data_as(_lib.pi32), self.host_mout.data_ptr()), 'llama_mcommit')
         slot = self._mstep_slots[0]
         self.slot_keys[slot] = int(self._mout_np[_lib.LA_MOUT_NKEYS + slot])
         if slot == 0:
@@ -687,7 +696,7 @@ class LlamaVerifyEngine(object):
                       for i in range(0, len(piece), 64)]
             tok = self.mstep(blocks, eager=eager)[-1][0]
         if slot == 0:
-            check(lib.la_llama_set_nkeys(self._h, self._sp(), 0, self.slot_keys[0]), 'set_nkeys')
+            check(self._lib.la_llama_set_nkeys(self._h, self._sp(), 0, self.slot_keys[0]), 'set_nkeys')
             self.n_keys = self.slot_keys[0]
         return tok
 
@@ -710,13 +719,13 @@ class LlamaVerifyEngine(object):
                 if last:
                     first[s] = toks[0]
         if 0 in todo:
-            check(lib.la_llama_set_nkeys(self._h, self._sp(), 0, self.slot_keys[0]), 'set_nkeys')
+            check(self._lib.la_llama_set_nkeys(self._h, self._sp(), 0, self.slot_keys[0]), 'set_nkeys')
             self.n_keys = self.slot_keys[0]
         return first
 
     def mlogits(self):
         """bf16 [max_blocks * 64][vocab] of the last multi-block step (row = 64 * block + tree row)."""
-        return self._view(11, _lib.LA_MB_MAX * 64 * self.shape.vocab * 2, torch.bfloat16).view(_lib.LA_MB_MAX * 64, self.shape.vocab)
+        return self._view(11, _lib.LA_MB_MAX * 64 * self.shape.vocab * 2, self.dtype).view(_lib.LA_MB_MAX * 64, self.shape.vocab)
 
     def mout(self):
         return self._view(12, _lib.LA_MOUT_WORDS * 4, torch.int32)
@@ -738,7 +747,7 @@ class LlamaVerifyEngine(object):
     def step_async(self, ids, rowmask, mode=0, eager=False):
         """Enqueue one block (tree of T<=64 tokens) on the current stream; results land in host_out."""
         self._fill(ids, rowmask, mode)
-        fn = lib.la_llama_step_eager if eager else lib.la_llama_step
+        fn = self._lib.la_llama_step_eager if eager else self._lib.la_llama_step
         self._eager_pending = bool(eager)
         check(fn(self._h, self._sp(), self.host_in.data_ptr(), self.host_out.data_ptr()), 'llama_step')
 
@@ -753,7 +762,7 @@ class LlamaVerifyEngine(object):
         if getattr(self, '_eager_pending', False):
             self.stream.synchronize()
         else:
-            check(lib.la_llama_wait(self._h, self._sp()), 'llama_wait')
+            check(self._lib.la_llama_wait(self._h, self._sp()), 'llama_wait')
 
     def step_finish(self):
         """Wait for the block enqueued by step_async and return its result (host work can run in between)."""
@@ -786,7 +795,7 @@ class LlamaVerifyEngine(object):
         qts = np.zeros(cap, dtype=np.float64)
         steps, fin = C.c_int32(0), C.c_int32(0)
         dp = C.POINTER(C.c_double)
-        check(lib.la_lookahead_decode(self._h, cache._h, self._sp(), C.byref(p), buf.ctypes.data_as(_lib.pi32), C.byref(n),
+        check(self._lib.la_lookahead_decode(self._h, cache._h, self._sp(), C.byref(p), buf.ctypes.data_as(_lib.pi32), C.byref(n),
                                       self.host_in.data_ptr(), self.host_out.data_ptr(), dls.ctypes.data_as(_lib.pi32),
                                       edls.ctypes.data_as(_lib.pi32), C.byref(steps), C.byref(fin),
                                       fts.ctypes.data_as(dp), qts.ctypes.data_as(dp)), 'lookahead_decode')
@@ -805,7 +814,7 @@ class LlamaVerifyEngine(object):
         """Keep the K/V of tree rows `rows` (root first) of the last verify_only block."""
         arr = np.ascontiguousarray(rows, dtype=np.int32)
         assert self.n_keys + len(arr) <= self._capacity(), 'KV cache capacity exceeded'
-        check(lib.la_llama_commit(self._h, self._sp(), arr.ctypes.data_as(_lib.pi32), len(arr), self.host_out.data_ptr()),
+        check(self._lib.la_llama_commit(self._h, self._sp(), arr.ctypes.data_as(_lib.pi32), len(arr), self.host_out.data_ptr()),
               'llama_commit')
         self.n_keys = int(self._out_np[_lib.LA_ST_NKEYS])
 
@@ -830,19 +839,19 @@ class LlamaVerifyEngine(object):
 
     # ---- introspection for parity tests ----------------------------------------------------------------
     def _view(self, which, nbytes, dtype):
-        ptr = lib.la_llama_buffer(self._h, which)
+        ptr = self._lib.la_llama_buffer(self._h, which)
         off = ptr - self.workspace.data_ptr()
         return self.workspace[off:off + nbytes].view(dtype)
 
     def logits(self):
         """bf16 [64][vocab] of the last block (row t = tree token t)."""
-        return self._view(0, 64 * self.shape.vocab * 2, torch.bfloat16).view(64, self.shape.vocab)
+        return self._view(0, 64 * self.shape.vocab * 2, self.dtype).view(64, self.shape.vocab)
 
     def state(self):
         return self._view(1, _lib.LA_ST_WORDS * 4, torch.int32)
 
     def hidden(self):
-        return self._view(2, 64 * self.shape.hidden * 2, torch.bfloat16).view(64, self.shape.hidden)
+        return self._view(2, 64 * self.shape.hidden * 2, self.dtype).view(64, self.shape.hidden)
 
     def route_weights(self):
         """fp32 [n_layers][64][8]: routing weight of every (layer, block row, expert) of the last block (0 = not routed)."""
@@ -857,7 +866,7 @@ class LlamaVerifyEngine(object):
     def profile_gateup(self, iters=5):
         """mean ms of one gate/up launch, every layer's launch back to back inside one HIP-event pair (la_llama_profile_gateup)"""
         ms = C.c_float(0)
-        check(lib.la_llama_profile_gateup(self._h, self._sp(), int(iters), C.byref(ms)), 'profile_gateup')
+        check(self._lib.la_llama_profile_gateup(self._h, self._sp(), int(iters), C.byref(ms)), 'profile_gateup')
         return float(ms.value)
 
     def profile(self, ids, rowmask, iters=3):
@@ -865,7 +874,7 @@ class LlamaVerifyEngine(object):
         self._fill(ids, rowmask, 0)
         ms = (C.c_float * 8)()
         launches = (C.c_int32 * 7)()
-        check(lib.la_llama_profile(self._h, self._sp(), self.host_in.data_ptr(), int(iters), ms, launches), 'profile')
+        check(self._lib.la_llama_profile(self._h, self._sp(), self.host_in.data_ptr(), int(iters), ms, launches), 'profile')
         names = ['qkv', 'o', 'gateup', 'down', 'lm_head', 'attn', 'other']
         return {'ms': {n: ms[i] for i, n in enumerate(names)}, 'ms_step': ms[7],
                 'launches': {n: launches[i] for i, n in enumerate(names)}}

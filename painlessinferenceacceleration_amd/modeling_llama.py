@@ -13,12 +13,12 @@ from .pretrained_model import LookaheadPreTrainedModel
 
 class LlamaForCausalLM(LookaheadPreTrainedModel):
     def __init__(self, shape, state_dict, max_length=2048, device='cuda:0', eos_token_id=2, pad_token_id=0,
-                 attn_split=0, gemm_cfg=None, consume_state_dict=False, balanced=True, fuse=0, max_blocks=0, kv_ring=False):
+                 attn_split=0, gemm_cfg=None, consume_state_dict=False, balanced=True, fuse=0, max_blocks=0, kv_ring=False, dtype=None):
         self.shape = shape
         self.engine = LlamaVerifyEngine(shape, state_dict, max_length=max_length, device=device,
                                         attn_split=attn_split, gemm_cfg=gemm_cfg,
                                         consume_state_dict=consume_state_dict, balanced=balanced, fuse=fuse,
-                                        max_blocks=max_blocks, kv_ring=kv_ring)
+                                        max_blocks=max_blocks, kv_ring=kv_ring, dtype=dtype)
         self.generation_config = SimpleNamespace(eos_token_id=eos_token_id, pad_token_id=pad_token_id,
                                                  return_dict_in_generate=False)
         self.config = SimpleNamespace(is_encoder_decoder=False, vocab_size=shape.vocab)
@@ -37,8 +37,9 @@ class LlamaForCausalLM(LookaheadPreTrainedModel):
     def from_pretrained(cls, model_dir, *unused_args, device_map=None, torch_dtype=None, max_length=4096, **kw):
         """The reference examples' front door (examples/llama_example.py:19-24, benchmarks/llama_benchmark.py:25-29):
         LlamaForCausalLM.from_pretrained(model_dir, cache_dir=..., torch_dtype=..., low_cpu_mem_usage=True, device_map=...).
-        The checkpoint's tensors are repacked straight into HBM (no nn.Module is built); the engine computes in bf16 whatever
-        torch_dtype asks for (fp16 checkpoints are converted), device_map picks the GPU ({"": "cuda:0"} / "auto" / None ->
+        The checkpoint's tensors are repacked straight into HBM (no nn.Module is built); the engine computes in `torch_dtype` —
+        torch.float16 (the reference's own setting) or torch.bfloat16, each its own build of the library; None = the checkpoint's
+        dtype (fp32 checkpoints run as bfloat16).  device_map picks the GPU ({"": "cuda:0"} / "auto" / None ->
         cuda:0).  max_length = KV capacity in tokens (prompt + generation)."""
         for k in ('cache_dir', 'low_cpu_mem_usage', 'trust_remote_code', 'revision', 'use_safetensors', 'attn_implementation'):
             kw.pop(k, None)
@@ -53,7 +54,8 @@ class LlamaForCausalLM(LookaheadPreTrainedModel):
         shape = LlamaShape.from_hf(cfg)
         kw.setdefault('eos_token_id', getattr(cfg, 'eos_token_id', 2))
         kw.setdefault('pad_token_id', getattr(cfg, 'pad_token_id', 0) or 0)
-        model = cls(shape, legacy_state_dict(sd, shape), max_length=max_length, device=device, consume_state_dict=True, **kw)
+        model = cls(shape, legacy_state_dict(sd, shape), max_length=max_length, device=device, consume_state_dict=True,
+                    dtype=torch_dtype if torch_dtype in (torch.float16, torch.bfloat16) else None, **kw)
         model.config = cfg
         return model
 
@@ -72,7 +74,7 @@ class LlamaForCausalLM(LookaheadPreTrainedModel):
 
     @property
     def dtype(self):
-        return torch.bfloat16
+        return self.engine.dtype
 
     @classmethod
     def random_init(cls, shape, seed=0, device='cuda:0', decisive=False, **kw):

@@ -15,9 +15,9 @@ def header_symbols(name='lookahead_hip.h'):
     return sorted(set(re.findall(r'\b(la_[a-z0-9_]+)\s*\(', src)))
 
 
-def exported_symbols():
+def exported_symbols(path=None):
     import subprocess
-    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    out = subprocess.run(['nm', '-D', '--defined-only', path or _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     return sorted(ln.split()[-1] for ln in out.splitlines() if ' T la_' in ln)
 
 
@@ -35,6 +35,11 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert lab == sorted(_lib.LAB_PROTOTYPES) == ['la_lab_get', 'la_lab_set', 'la_lab_set_ptr']
     assert not any(s.startswith('la_lab_') for s in syms), 'the product header does not declare the lab'
     assert exported_symbols() == sorted(syms + lab)          # nothing exported that no header declares
+    # the float16 build (the same sources with -DLA_DTYPE=1) exports the same ABI and reports its dtype
+    assert exported_symbols(_lib.LIB_PATH_F16) == sorted(syms + lab)
+    import torch
+    lib16 = _lib.lib_for(torch.float16)
+    assert (lib16.la_abi_dtype(), _lib.lib.la_abi_dtype()) == (_lib.LA_DTYPE_F16, _lib.LA_DTYPE_BF16) and lib16.la_abi_version() == _lib.ABI_VERSION
 
 
 def test_product_debug_key_is_the_depth_probe_only():

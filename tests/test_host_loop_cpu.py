@@ -26,7 +26,7 @@ DK = {'use_lookahead': True, 'decoding_mode': 'hier', 'decoding_length': 64, 'br
       'max_query_length': 2, 'stop_words': {}}
 
 
-@pytest.mark.parametrize('tag,dtype', [('fp32', torch.float32), ('bf16', torch.bfloat16)])
+@pytest.mark.parametrize('tag,dtype', [('fp32', torch.float32), ('bf16', torch.bfloat16), ('fp16', torch.float16)])
 def test_loop_reproduces_reference_run(tag, dtype):
     g = load_golden(tag)
     m = Model(dtype)

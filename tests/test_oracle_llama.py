@@ -40,7 +40,7 @@ def test_survey_worked_example():
     assert lo.kv_keep_positions(5, 3, rows) == [0, 1, 2, 3, 4, 5, 7]
 
 
-@pytest.mark.parametrize('tag,dtype', [('fp32', torch.float32), ('bf16', torch.bfloat16)])
+@pytest.mark.parametrize('tag,dtype', [('fp32', torch.float32), ('bf16', torch.bfloat16), ('fp16', torch.float16)])
 def test_oracle_loop_matches_reference_generation(tag, dtype):
     g = load_golden(tag)
     torch.set_num_threads(4)
@@ -169,8 +169,8 @@ def test_oracle_sequential_processor_path_matches_reference():
         assert out['dls'] == g[f'r{r}_dls'].tolist() and out['edls'] == g[f'r{r}_edls'].tolist()
 
 
-@pytest.mark.parametrize('suffix', ['', '_par', '_one', '_dl128'])
-@pytest.mark.parametrize('tag,dtype', [('fp32', torch.float32), ('bf16', torch.bfloat16)])
+@pytest.mark.parametrize('tag,dtype,suffix', [(t, d, sfx) for sfx in ('', '_par', '_one', '_dl128') for t, d in (('fp32', torch.float32), ('bf16', torch.bfloat16))] +
+                         [('fp16', torch.float16, '')])          # round 4: the reference's own dtype, hier 64 / 12
 def test_oracle_loop_matches_reference_run_with_partial_accepts(tag, dtype, suffix):
     """oracle/gen_golden_noisy.py: the reference loop on the decisive tiny model with a NOISY warm trie — multi-branch trees,
     23 partially accepted steps in the first request.  Tokens, dls, edls and every step's draft ids / row masks / emitted
@@ -207,6 +207,23 @@ def test_oracle_loop_matches_reference_run_with_partial_accepts(tag, dtype, suff
     assert partial >= 20
     if dl > 64:
         assert max(max(g[f'r{r}_dls'].tolist()) for r in range(int(g['n_runs']))) > 64      # the fixture really has wide trees
+
+
+def test_attention_scale_in_fp16_needs_the_division():
+    """fp16 build (LA_DTYPE 1): fp16(x / sqrt(128)) and fp16(x * fp32(1 / sqrt(128))) differ on 52 of the 65536 bit patterns, so
+    attn_scale() of csrc/la_common.h divides in that build — fp32 division of the upcast value, one rounding, which is what torch
+    does for `half_tensor / python_float`."""
+    import math
+    bits = np.arange(65536, dtype=np.uint16)
+    x = bits.view(np.float16)
+    fin = np.isfinite(x)
+    with np.errstate(invalid='ignore'):
+        x32 = x.astype(np.float32)
+        div = (x32 / np.float32(math.sqrt(128))).astype(np.float16)
+        mul = (x32 * np.float32(0.088388346135616302490234375)).astype(np.float16)
+    assert int(((div.view(np.uint16) != mul.view(np.uint16)) & fin).sum()) == 52
+    t = (torch.from_numpy(x.copy()) / math.sqrt(128)).numpy()
+    assert int(((t.view(np.uint16) != div.view(np.uint16)) & fin).sum()) == 0          # torch == the fp32 division
 
 
 def test_attention_scale_as_multiply_is_exact():
