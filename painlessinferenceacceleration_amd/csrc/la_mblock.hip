@@ -1273,9 +1273,13 @@ struct MbAttnArgs {
 // PIECE = true: the pass holds wide-tree pieces (mode-3 blocks); the instantiation without them is the round-2 kernel unchanged —
 // the extra ancestor words cost registers the 256-VGPR budget does not have (measured: 960 B/lane of scratch and 22 -> 134 us when
 // both forms shared one body), so la_llama_mstep picks the instantiation per pass (bit 8 of the LA_MIN_NBLK word).
-template <bool PIECE>
+// VR = true (round 4, default): the V tile of the NEXT key tile is already on its way while a tile is computed — LDS-DMA into a
+// per-wave ring of two 8 KiB slots that aliases the merge buffer (no registers: K double-buffered + V + 64 accumulators fill the
+// budget).  Before, V was requested when its tile began and awaited after the softmax: with a slot's K/V coming from HBM that is one
+// exposed round trip per tile (~3.5 us x 6 tiles per wave at the 13B bs=4 / Mistral bs=8 shapes).  Same values into the same MFMAs.
+template <bool PIECE, bool VR>
 __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float mgbuf[];   // [4][2][66][64]
+    extern __shared__ __attribute__((aligned(16))) float mgbuf[];   // [4][2][66][64] merge buffer + [2][8] Q fragments (16 KiB)
     // GQA: the query heads of one kv head read the SAME K/V tiles.  Block x of a grid runs on XCD x % 8 and every XCD has its own
     // L2, so consecutive head ids would put the 4 readers of a Mistral kv head on 4 different XCDs — 4 HBM reads of every tile.
     // Head id from the block id so that the group of kv head g sits on one XCD (x % nkv = g: x, x + nkv, x + 2 nkv, ... share
@@ -1317,9 +1321,17 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
     const int i0 = (NT * sp) / a.nsplit;
     const int i1 = (__ballot(mine) == 0ull) ? i0 : (NT * (sp + 1)) / a.nsplit;
 
-    bf16x8 q[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) q[s] = *((const bf16x8*)(a.qf + (((size_t)blk * a.nh + h) * 2 + tb) * 4096 + (size_t)s * 512) + lane);
+    // Q fragments of both token blocks live in LDS (16 KiB behind the merge buffer), not in 32 registers per lane: wave (tb, par)
+    // brings fragments 2 par and 2 par + 1 of its token block, every wave reads the 8 fragments of its block back per tile.  With
+    // K double-buffered, V and the 64 accumulators the kernel otherwise sits past the 256-VGPR budget (round 3: 56 / 72 B per lane
+    // of scratch); same operands in the same MFMA order, bit-identical results.
+    bf16x8* const qs = (bf16x8*)(mgbuf + 4 * 2 * 66 * 64);
+    {
+        const bf16x8* qsrc = (const bf16x8*)(a.qf + (((size_t)blk * a.nh + h) * 2 + tb) * 4096) + lane;
+        qs[(tb * 8 + 2 * par) * 64 + lane] = qsrc[(2 * par) * 64];
+        qs[(tb * 8 + 2 * par + 1) * 64 + lane] = qsrc[(2 * par + 1) * 64];
+    }
+    const unsigned qbase = (unsigned)(tb * 8 * 64 + lane);      // fragment s of this wave's token block: qs[qbase + s * 64]
     const int hh = lane >> 5;
     f32x16 o[4];
 #pragma unroll
@@ -1334,19 +1346,30 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
         const int fb = j < NF ? first + (j >> 1) : blk;
         return (const bf16x8*)(freshp + (((size_t)fb * a.nkv + hk) * 2 + (j & 1)) * 4096);
     };
-    auto tile = [&](int it, const bf16x8 (&kf)[8]) {
+    char* const vring = (char*)mgbuf + wave * 16384;           // VR: this wave's two V slots (aliases the merge buffer until the loop ends)
+    auto issue_v = [&](int it, int slot) {
+        const bf16x8* vt = tptr(a.vmain, a.vfresh, it) + lane;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            __builtin_amdgcn_global_load_lds((gptr_t)(vt + s * 64), (lptr_t)(vring + slot * 8192 + s * 1024), 16, 0, 0);
+    };
+    auto tile = [&](int it, const bf16x8 (&kf)[8], int vslot, bool more) {
         const bool own = it >= NP + NF;
         const bool prior = it >= NP && !own;
         const int kb = own ? it - NP - NF : it;
-        const bf16x8* vt = tptr(a.vmain, a.vfresh, it);
         bf16x8 vf[8];
+        if constexpr (!VR) {
+            const bf16x8* vt = tptr(a.vmain, a.vfresh, it);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) vf[s] = vt[s * 64 + lane];
+            for (int s = 0; s < 8; ++s) vf[s] = vt[s * 64 + lane];
+        }
         f32x16 sc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) sc[i] = 0.f;
+        unsigned qo = qbase;
+        asm volatile("" : "+v"(qo));                        // opaque per tile: the compiler must not hoist the 8 fragment reads out of the tile loop (32 VGPRs)
 #pragma unroll
-        for (int s = 0; s < 8; ++s) sc = LA_MFMA(kf[s], q[s], sc, 0, 0, 0);
+        for (int s = 0; s < 8; ++s) sc = LA_MFMA(kf[s], qs[qo + s * 64], sc, 0, 0, 0);
         float mx = MB_NEG;
         unsigned long long xw_tile = 0ull;
         if constexpr (PIECE) { if (prior && piece) xw_tile = xrow[(it - NP) >> 1]; }
@@ -1388,6 +1411,14 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
         }
+        if constexpr (VR) {
+            // this tile's V copies have landed when at most the next tile's 8 K loads + 8 V copies (issued after them) are pending;
+            // the ancestor word of a wide-tree piece (PIECE) is one more, younger load — waiting for it too is harmless
+            if (more) vm_wait<16>(); else vm_wait<0>();
+            const bf16x8* vl = (const bf16x8*)(vring + vslot * 8192) + lane;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) vf[s] = vl[s * 64];
+        }
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
             o[db] = LA_MFMA(vf[db * 2 + 0], pf[0], o[db], 0, 0, 0);
@@ -1401,15 +1432,18 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
             const bf16x8* kt = tptr(a.kmain, a.kfresh, it);
 #pragma unroll
             for (int s = 0; s < 8; ++s) kA[s] = kt[s * 64 + lane];
+            if constexpr (VR) issue_v(it, 0);
         }
+        __syncthreads();                                    // the Q fragments are in LDS
         while (it < i1) {
             int nx = it + 4;
             if (nx < i1) {
                 const bf16x8* kt = tptr(a.kmain, a.kfresh, nx);
 #pragma unroll
                 for (int s = 0; s < 8; ++s) kB[s] = kt[s * 64 + lane];
+                if constexpr (VR) issue_v(nx, 1);
             }
-            tile(it, kA);
+            tile(it, kA, 0, nx < i1);
             it = nx;
             if (it >= i1) break;
             nx = it + 4;
@@ -1417,10 +1451,15 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
                 const bf16x8* kt = tptr(a.kmain, a.kfresh, nx);
 #pragma unroll
                 for (int s = 0; s < 8; ++s) kA[s] = kt[s * 64 + lane];
+                if constexpr (VR) issue_v(nx, 0);
             }
-            tile(it, kB);
+            tile(it, kB, 1, nx < i1);
             it = nx;
         }
+    }
+    if constexpr (VR) {                                     // every wave is done with its V slots: the region becomes the merge buffer
+        vm_wait<0>();
+        __syncthreads();
     }
     {
         float* mg = mgbuf + (size_t)((par * 2 + tb) * 66) * 64;
@@ -1696,6 +1735,7 @@ __global__ __launch_bounds__(256) void k_kv_commit_mb(const bf16_t* __restrict__
 // launchers
 // =============================================================================================================
 static bool g_mb_attr = false;
+int g_la_mb_attn_vring = 1;   // la_lab_set key 20: 1 = multi-block attention with the next tile's V in flight through a per-wave LDS ring (default), 0 = V requested per tile
 int g_la_mb_dbg = 0;
 int g_la_mb_mode = 0;         // la_debug_set key 5: 1 = wide kernel as two co-resident workgroups per CU (80 KiB LDS, 256 rows each)
 int g_la_mb_pair = 1;         // la_debug_set key 6, bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
@@ -1738,8 +1778,10 @@ int lk_mb_init() {
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 3>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 4>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 5>, WideGeom<4, 4>::LDS);
-    if (e == hipSuccess) e = set_lds(k_tree_attn_mb<false>, 8 * 66 * 64 * 4);
-    if (e == hipSuccess) e = set_lds(k_tree_attn_mb<true>, 8 * 66 * 64 * 4);
+    if (e == hipSuccess) e = set_lds(k_tree_attn_mb<false, true>, 8 * 66 * 64 * 4 + 16384);
+    if (e == hipSuccess) e = set_lds(k_tree_attn_mb<false, false>, 8 * 66 * 64 * 4 + 16384);
+    if (e == hipSuccess) e = set_lds(k_tree_attn_mb<true, true>, 8 * 66 * 64 * 4 + 16384);
+    if (e == hipSuccess) e = set_lds(k_tree_attn_mb<true, false>, 8 * 66 * 64 * 4 + 16384);
     if (e != hipSuccess) return (int)e;
     g_mb_attr = true;
     return 0;
@@ -2011,8 +2053,14 @@ int lk_mb_tree_attn(hipStream_t st, const void* qf, const void* kmain, const voi
     a.nh = nh; a.nkv = nkv; a.total_keys = slot_keys * n_slots; a.slot_tiles = slot_keys >> 5; a.nsplit = nsplit; a.window = window; a.ring = ring;
     a.opart = opart; a.mpart = mpart; a.lpart = lpart;
     a.attn_xp = nsplit == 1 ? (bf16_t*)attn_xp : nullptr;
-    if (xmask) k_tree_attn_mb<true><<<dim3(nh, nsplit, nblk), 512, 8 * 66 * 64 * sizeof(float), st>>>(a);
-    else k_tree_attn_mb<false><<<dim3(nh, nsplit, nblk), 512, 8 * 66 * 64 * sizeof(float), st>>>(a);
+    const size_t lds = 8 * 66 * 64 * sizeof(float) + 16384;
+    if (g_la_mb_attn_vring) {
+        if (xmask) k_tree_attn_mb<true, true><<<dim3(nh, nsplit, nblk), 512, lds, st>>>(a);
+        else k_tree_attn_mb<false, true><<<dim3(nh, nsplit, nblk), 512, lds, st>>>(a);
+    } else {
+        if (xmask) k_tree_attn_mb<true, false><<<dim3(nh, nsplit, nblk), 512, lds, st>>>(a);
+        else k_tree_attn_mb<false, false><<<dim3(nh, nsplit, nblk), 512, lds, st>>>(a);
+    }
     LAUNCH_CHECK();
     if (nsplit == 1) return 0;
     const int total = nh * 64 * 16;
