@@ -424,6 +424,8 @@ def main():
         return [(np.asarray(g[0], dtype=np.int32), np.asarray(g[1], dtype=np.uint64)) if len(g[0]) else
                 (np.asarray(seqs[i][-1:], dtype=np.int32), np.array([1], dtype=np.uint64)) for i, g in enumerate(got)]
 
+    replay_q = [None, False]          # [puts of the last chained step not yet replayed on the host trie, full image due]
+
     def one_step_chained():
         # device trie chained in front of the verify pass: patch + query kernels and la_llama_mstep_trie on the engine's stream; the
         # drafts never leave HBM (the host reads back accepted tokens and draft lengths)
@@ -433,18 +435,29 @@ def main():
             pending[0] = False
         ubl = [min(BL, max_length - len(seqs[i]) - 1) for i in range(B)]
         with torch.cuda.stream(eng.stream):
+            # round 4: with device-side updates the device image already holds step N's inserts when step N + 1 is queued, so the
+            # host's REPLAY of step N (25-50 us per sequence) moves behind the launches and runs while the GPU verifies
             dev_trie.hier_get_dev([seqs[i][-2:] for i in range(B)], idxs=gidx, branch_lengths=ubl, decoding_length=DL, branch_length=BL,
-                                  min_input_size=0, min_output_size=DL // 2, mode='mix')
+                                  min_input_size=0, min_output_size=DL // 2, mode='mix', sync=replay_q[0] is None)
             qts.append(time.time() - tq)
-            toks_all, Ts = eng.mstep_trie(dev_trie, 0, list(range(B)), [16] * B, [seqs[i][-1] for i in range(B)],
-                                          put_idxs=gidx if dev_trie.put_vocab else None, put_branch_length=BL + 1)
+            eng.mstep_trie_async(dev_trie, 0, list(range(B)), [16] * B, [seqs[i][-1] for i in range(B)],
+                                 put_idxs=gidx if dev_trie.put_vocab else None, put_branch_length=BL + 1)
+        if replay_q[0] is not None:
+            ok = dev_trie.replay(replay_q[0], BL + 1)
+            replay_q[0] = None
+            if not ok:
+                replay_q[1] = True                   # the host image outgrew the device's: finish this step, then a full image
+        toks_all, Ts = eng.mstep_trie_finish()
         for i in range(B):
             seqs[i].extend(toks_all[i])
             dls.append(Ts[i]); edls.append(len(toks_all[i]))
         if dev_trie.put_vocab:
             # the device inserted the accepted tokens into its trie image itself (behind the verify pass, from the step's output
-            # block); the host trie repeats the same puts and drops the words it logged
-            dev_trie.replay([(gidx[i], toks_all[i]) for i in range(B)], BL + 1)
+            # block); the host trie repeats the same puts — during the NEXT step — and drops the words it logged
+            replay_q[0] = [(gidx[i], toks_all[i]) for i in range(B)]
+            if replay_q[1]:                          # rare: capacity passed / squeeze — replay now, the next query syncs a full image
+                dev_trie.replay(replay_q[0], BL + 1)
+                replay_q[0], replay_q[1] = None, False
         elif dist_on:
             if args.strict_gather:
                 gather.update_trie(cache, toks_all if B > 1 else toks_all[0], BL)
@@ -510,6 +523,9 @@ def main():
     if pending[0]:
         gather.finish_into_trie(cache, BL)
         pending[0] = False
+    if replay_q[0] is not None:          # the last chained step's trie update, replayed inside the timed region
+        dev_trie.replay(replay_q[0], BL + 1)
+        replay_q[0] = None
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()

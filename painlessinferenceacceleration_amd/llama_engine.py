@@ -600,7 +600,13 @@ class LlamaVerifyEngine(object):
         put_idxs: the trie slot (batch index) of each block — the step's accepted tokens are then inserted into the DEVICE trie
         image by the device, straight from the step's output block (DeviceTrie.stream_put_dev, queued behind the step; the host
         waits for the result header only and must dev_trie.replay() the same tokens before its next trie update).
-        -> (emitted token lists, draft lengths)."""
+        -> (emitted token lists, draft lengths).  = mstep_trie_async + mstep_trie_finish."""
+        self.mstep_trie_async(dev_trie, q0, slots, limits, last_tokens, put_idxs, put_branch_length)
+        return self.mstep_trie_finish()
+
+    def mstep_trie_async(self, dev_trie, q0, slots, limits, last_tokens, put_idxs=None, put_branch_length=None):
+        """Queue the chained step (and the device-side trie update behind it) and return at once: the host is free — e.g. to
+        replay the PREVIOUS step's trie update on its own trie (DeviceTrie.replay) — until mstep_trie_finish()."""
         nb = len(slots)
         assert self.max_blocks and 1 <= nb <= self.max_blocks
         arr = lambda v: (C.c_int32 * nb)(*[int(x) for x in v])
@@ -608,6 +614,7 @@ class LlamaVerifyEngine(object):
         check(self._lib.la_llama_mstep_trie(self._h, self._sp(), nb, arr(slots), arr(lim), arr(last_tokens),
                                       C.c_void_p(dev_trie.out_ids.data_ptr() + 4 * 64 * q0), C.c_void_p(dev_trie.out_rm.data_ptr() + 8 * 64 * q0),
                                       C.c_void_p(dev_trie.out_n.data_ptr() + 4 * q0), self.host_mout.data_ptr()), 'llama_mstep_trie')
+        self._trie_wait = None
         if put_idxs is not None:
             ev = getattr(self, '_hdr_event', None)
             if ev is None:
@@ -619,9 +626,17 @@ class LlamaVerifyEngine(object):
             with torch.cuda.stream(self.stream):
                 dev_trie.stream_put_dev(mo + 4 * _lib.LA_MOUT_OUTTOK, _lib.LA_MOUT_TOKS, mo + 4 * _lib.LA_MOUT_NOUT, put_idxs,
                                         put_branch_length)
-            ev.synchronize()
+            self._trie_wait = ev
+        self._trie_slots = list(slots)
+
+    def mstep_trie_finish(self):
+        """Wait for the result header of the step queued by mstep_trie_async -> (emitted token lists, draft lengths)."""
+        if self._trie_wait is not None:
+            self._trie_wait.synchronize()
         else:
             self.stream.synchronize()
+        slots = self._trie_slots
+        nb = len(slots)
         o = self._mout_np
         self._mstep_slots = list(slots)
         for slot in slots:

@@ -204,6 +204,7 @@ class LookaheadPreTrainedModel(object):
         # device_trie_update (default on with the chained device trie): the trie UPDATE of every step runs on the device as well
         dev_put = chained and bool(decoding_kwargs.get('device_trie_update', True)) and branch_length + 1 <= 64
         put_on_device, buffers_loaded = False, False
+        replay_due, full_image_due = None, False      # puts of the last chained step the host trie has not repeated yet
         decoding_kwargs['dls'].extend([1] * bs)
         decoding_kwargs['edls'].extend([1] * bs)
         max_cur = 0
@@ -215,9 +216,9 @@ class LookaheadPreTrainedModel(object):
             if put_on_device:
                 # the device inserted these tokens into its trie image itself, straight from the step's output block
                 # (la_trie_stream_put_dev behind the verify pass): the host trie repeats the same puts in the same order and
-                # drops the words it logged for them — nothing of the update crosses PCIe
-                self._device_trie(decoding_kwargs['_n_samples'], dev_put).replay(
-                    [(b, next_token_list[k]) for k, b in enumerate(batch_indices)], branch_length + 1)
+                # drops the words it logged for them — nothing of the update crosses PCIe.  Round 4: the replay is deferred until
+                # the NEXT step's kernels are queued (the device image needs nothing from the host), so it overlaps the GPU step
+                replay_due = [(b, next_token_list[k]) for k, b in enumerate(batch_indices)]
                 put_on_device = False
             else:                                                               # :1254-1259, one native call for the batch
                 self.lookahead_cache.stream_put_many([(b, [x for x in next_token_list[k] if x != -1])
@@ -237,6 +238,11 @@ class LookaheadPreTrainedModel(object):
             if not batch_indices:
                 break
             if chained:
+                dt0 = self._device_trie(decoding_kwargs['_n_samples'], dev_put)
+                if replay_due is not None and (len(batch_indices) > eng.max_blocks or full_image_due):
+                    # several engine passes per step, or the host image outgrew the device's: replay first, then a synced query
+                    dt0.replay(replay_due, branch_length + 1)
+                    replay_due, full_image_due = None, False
                 # device trie chained in front of the verify pass (la_llama_mstep_trie): ONE query launch for all active samples on the
                 # engine's stream, the step input assembled on the device from its outputs, one 64-row block per sample — no draft
                 # crosses PCIe in either direction; the host reads back the accepted tokens and the draft lengths only.  Same budget
@@ -249,19 +255,24 @@ class LookaheadPreTrainedModel(object):
                 dt = self._device_trie(decoding_kwargs['_n_samples'], dev_put)
                 with torch.cuda.stream(eng.stream):
                     if dm.split('_')[0] == 'one':
-                        dt.one_get_dev(qids, idxs=batch_indices, decoding_length=per, branch_length=branch_length, mode=mode_q)
+                        dt.one_get_dev(qids, idxs=batch_indices, decoding_length=per, branch_length=branch_length, mode=mode_q,
+                                       sync=replay_due is None)
                     else:
                         dt.hier_get_dev(qids, idxs=batch_indices, decoding_length=per, branch_length=branch_length, min_input_size=0,
-                                        min_output_size=max(per // 2, 1), mode=mode_q)
+                                        min_output_size=max(per // 2, 1), mode=mode_q, sync=replay_due is None)
                     if dev_put and not buffers_loaded:
                         dt.load_stream_buffers()        # the hold-back buffers as the host's stream_put calls left them
                         buffers_loaded = True
                     emitted, widths = {}, []
                     for g0 in range(0, len(batch_indices), eng.max_blocks):
                         grp = batch_indices[g0:g0 + eng.max_blocks]
-                        toks, Ts = eng.mstep_trie(dt, g0, grp, [stop_max_length - (len(rows[b]) - 1) - 1 for b in grp],
-                                                  [rows[b][-1] for b in grp], put_idxs=grp if dev_put else None,
-                                                  put_branch_length=branch_length + 1)
+                        eng.mstep_trie_async(dt, g0, grp, [stop_max_length - (len(rows[b]) - 1) - 1 for b in grp],
+                                             [rows[b][-1] for b in grp], put_idxs=grp if dev_put else None,
+                                             put_branch_length=branch_length + 1)
+                        if replay_due is not None:         # the previous step's update, on the host trie, while the GPU verifies
+                            full_image_due = not dt.replay(replay_due, branch_length + 1)
+                            replay_due = None
+                        toks, Ts = eng.mstep_trie_finish()
                         for b, tk in zip(grp, toks):
                             emitted[b] = tk
                         widths.extend(Ts)
@@ -311,6 +322,9 @@ class LookaheadPreTrainedModel(object):
             for k in range(len(batch_indices)):
                 decoding_kwargs['dls'].append(width)
                 decoding_kwargs['edls'].append(len(next_token_list[k]))
+        if replay_due is not None:                                              # the last step's update (the loop ended before another launch)
+            self._device_trie(decoding_kwargs['_n_samples'], dev_put).replay(replay_due, branch_length + 1)
+            replay_due = None
         for i in range(bs):                                                     # :1288-1290
             self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=i)
         if streamer is not None:
