@@ -36,8 +36,10 @@ extern "C" {
  * key 18: variants of the single-launch attention (measurement): bit 0 = no start rotation, bits 1-2 = forced slice count.
  * key 19: residual + RMSNorm of the single-sequence step, 1 = four workgroups per row with a granule exchange (k_row_norm4:
  *         measured neutral, 5.30 vs 5.37 us per launch), 0 = one workgroup per row (k_row_norm, default).
- * key 20: multi-block tree attention, 1 = the next tile's V in flight through a per-wave LDS ring (LDS-DMA, default), 0 = V requested
- *         when its tile begins (round 3 form); bit-identical results. */
+ * key 20: multi-block tree attention, 1 = the next tile's V in flight through a per-wave LDS ring (LDS-DMA; measured slower), 0 = V
+ *         requested when its tile begins (default); bit-identical results.
+ * key 21: multi-block tree attention of GQA models, 1 = the query heads of a kv head start their key-tile lists at different offsets
+ *         (default; changes the order of the online-softmax updates), 0 = all start at the first tile. */
 int          la_lab_set(int key, int value);
 int          la_lab_get(int key);          /* current value of a knob (the library default unless la_lab_set changed it) */
 /* key 0: device buffer int64[workgroups][waves][8] the GEMM kernels stamp with wall_clock64() at entry / end of the

@@ -1266,6 +1266,7 @@ struct MbAttnArgs {
     const unsigned long long* xmask;                   // [blk][64][3] wide-tree pieces (mode 3): masks over the earlier pieces' rows
     const int* meta;
     int nh, nkv, total_keys, slot_tiles, nsplit, window, ring;      // ring: the slot's main cache is a ring of slot_tiles tiles
+    int rot;                                           // 1: the query heads of a kv head start their tile lists at different offsets (GQA)
     float* opart; float* mpart; float* lpart;          // [blk][nh][nsplit][64][128] ...
     bf16_t* attn_xp;                                   // nsplit == 1: the normalised output goes straight into o_proj's operand image
 };
@@ -1273,10 +1274,11 @@ struct MbAttnArgs {
 // PIECE = true: the pass holds wide-tree pieces (mode-3 blocks); the instantiation without them is the round-2 kernel unchanged —
 // the extra ancestor words cost registers the 256-VGPR budget does not have (measured: 960 B/lane of scratch and 22 -> 134 us when
 // both forms shared one body), so la_llama_mstep picks the instantiation per pass (bit 8 of the LA_MIN_NBLK word).
-// VR = true (round 4, default): the V tile of the NEXT key tile is already on its way while a tile is computed — LDS-DMA into a
-// per-wave ring of two 8 KiB slots that aliases the merge buffer (no registers: K double-buffered + V + 64 accumulators fill the
-// budget).  Before, V was requested when its tile began and awaited after the softmax: with a slot's K/V coming from HBM that is one
-// exposed round trip per tile (~3.5 us x 6 tiles per wave at the 13B bs=4 / Mistral bs=8 shapes).  Same values into the same MFMAs.
+// VR = true (round 4, la_lab_set(20, 1)): the V tile of the NEXT key tile is already on its way while a tile is computed — LDS-DMA
+// into a per-wave ring of two 8 KiB slots that aliases the merge buffer (no registers).  Built on the reading that the launch pays
+// one exposed V round trip per tile; measured slightly SLOWER (Mistral bs=8 10.07 vs 10.00 ms, 13B bs=4 11.05 vs 10.97, Mixtral bs=4
+// 22.8 vs 21.6): the launch is bound by the bytes each CU pulls (a workgroup streams its slot's whole K/V: 352 KiB at ~700 keys, at
+// the HBM-class rate of one CU), not by the order in which a wave requests them.  Off by default; same values into the same MFMAs.
 template <bool PIECE, bool VR>
 __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float mgbuf[];   // [4][2][66][64] merge buffer + [2][8] Q fragments (16 KiB)
@@ -1290,6 +1292,7 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tb = wave & 1, par = wave >> 1;
     const int hk = h / grp_;
+    const bool g_rot = a.rot != 0 && grp_ > 1;
     const int KB = a.total_keys >> 5;
     const int* mt = a.meta + blk * LA_MB_META;
     const int slot = mt[LA_MBM_SLOT], T = mt[LA_MBM_T], nkeys = mt[LA_MBM_NKEYS], first = mt[LA_MBM_FIRST];
@@ -1426,35 +1429,46 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
         }
     };
     {
+        // This wave's tiles: i0 + par + 4 k, k = 0 .. cnt - 1.  GQA: the grp_ query heads of a kv head stream the SAME tiles (their
+        // workgroups share an XCD, see the head map above); started together they all miss on the same lines and each pulls the
+        // whole K/V at the HBM-class rate of one CU.  Query head g of the group starts its list at k = g * cnt / grp_ and wraps
+        // (round 4, as k_tree_attn1): every part of the K/V is first touched by one of them and found in L2 by the others.  The
+        // order of the online-softmax updates changes with it (deterministic per head; grp_ = 1: unchanged).
+        const int cnt = i1 > i0 + par ? (i1 - i0 - par + 3) >> 2 : 0;
+        int kx = (cnt > 0 && g_rot) ? ((h % grp_) * cnt) / grp_ : 0;
+        auto next_k = [&]() { kx = kx + 1 == cnt ? 0 : kx + 1; return i0 + par + 4 * kx; };
         bf16x8 kA[8], kB[8];
-        int it = i0 + par;
-        if (it < i1) {
+        int it = i0 + par + 4 * kx;
+        if (cnt > 0) {
             const bf16x8* kt = tptr(a.kmain, a.kfresh, it);
 #pragma unroll
             for (int s = 0; s < 8; ++s) kA[s] = kt[s * 64 + lane];
             if constexpr (VR) issue_v(it, 0);
         }
         __syncthreads();                                    // the Q fragments are in LDS
-        while (it < i1) {
-            int nx = it + 4;
-            if (nx < i1) {
+        int left = cnt;                                     // tiles still to compute, `it` included
+        while (left > 0) {
+            int nx = it;
+            if (left > 1) {
+                nx = next_k();
                 const bf16x8* kt = tptr(a.kmain, a.kfresh, nx);
 #pragma unroll
                 for (int s = 0; s < 8; ++s) kB[s] = kt[s * 64 + lane];
                 if constexpr (VR) issue_v(nx, 1);
             }
-            tile(it, kA, 0, nx < i1);
+            tile(it, kA, 0, left > 1);
             it = nx;
-            if (it >= i1) break;
-            nx = it + 4;
-            if (nx < i1) {
+            if (--left == 0) break;
+            if (left > 1) {
+                nx = next_k();
                 const bf16x8* kt = tptr(a.kmain, a.kfresh, nx);
 #pragma unroll
                 for (int s = 0; s < 8; ++s) kA[s] = kt[s * 64 + lane];
                 if constexpr (VR) issue_v(nx, 0);
             }
-            tile(it, kB, 1, nx < i1);
+            tile(it, kB, 1, left > 1);
             it = nx;
+            --left;
         }
     }
     if constexpr (VR) {                                     // every wave is done with its V slots: the region becomes the merge buffer
@@ -1735,7 +1749,8 @@ __global__ __launch_bounds__(256) void k_kv_commit_mb(const bf16_t* __restrict__
 // launchers
 // =============================================================================================================
 static bool g_mb_attr = false;
-int g_la_mb_attn_vring = 1;   // la_lab_set key 20: 1 = multi-block attention with the next tile's V in flight through a per-wave LDS ring (default), 0 = V requested per tile
+int g_la_mb_attn_rot = 1;     // la_lab_set key 21: 1 = the query heads of a kv head start their key-tile lists at different offsets (GQA models; default)
+int g_la_mb_attn_vring = 0;   // la_lab_set key 20: 1 = multi-block attention with the next tile's V in flight through a per-wave LDS ring (measured 0.5-5 % SLOWER per step, profiles/r04_mb_attention_vring_ab.txt), 0 = V requested per tile (default)
 int g_la_mb_dbg = 0;
 int g_la_mb_mode = 0;         // la_debug_set key 5: 1 = wide kernel as two co-resident workgroups per CU (80 KiB LDS, 256 rows each)
 int g_la_mb_pair = 1;         // la_debug_set key 6, bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
@@ -2050,7 +2065,7 @@ int lk_mb_tree_attn(hipStream_t st, const void* qf, const void* kmain, const voi
     a.qf = (const bf16_t*)qf; a.kmain = (const bf16_t*)kmain; a.vmain = (const bf16_t*)vmain;
     a.kfresh = (const bf16_t*)kfresh; a.vfresh = (const bf16_t*)vfresh;
     a.rowmask = (const unsigned long long*)rowmask; a.meta = meta;
-    a.nh = nh; a.nkv = nkv; a.total_keys = slot_keys * n_slots; a.slot_tiles = slot_keys >> 5; a.nsplit = nsplit; a.window = window; a.ring = ring;
+    a.nh = nh; a.nkv = nkv; a.total_keys = slot_keys * n_slots; a.slot_tiles = slot_keys >> 5; a.nsplit = nsplit; a.window = window; a.ring = ring; a.rot = g_la_mb_attn_rot;
     a.opart = opart; a.mpart = mpart; a.lpart = lpart;
     a.attn_xp = nsplit == 1 ? (bf16_t*)attn_xp : nullptr;
     const size_t lds = 8 * 66 * 64 * sizeof(float) + 16384;
