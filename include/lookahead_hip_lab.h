@@ -39,7 +39,7 @@ extern "C" {
  * key 20: multi-block tree attention, 1 = the next tile's V in flight through a per-wave LDS ring (LDS-DMA; measured slower), 0 = V
  *         requested when its tile begins (default); bit-identical results.
  * key 21: multi-block tree attention of GQA models, 1 = the query heads of a kv head start their key-tile lists at different offsets
- *         (default; changes the order of the online-softmax updates), 0 = all start at the first tile. */
+ *         (changes the order of the online-softmax updates; measured neutral), 0 = all start at the first tile (default). */
 int          la_lab_set(int key, int value);
 int          la_lab_get(int key);          /* current value of a knob (the library default unless la_lab_set changed it) */
 /* key 0: device buffer int64[workgroups][waves][8] the GEMM kernels stamp with wall_clock64() at entry / end of the

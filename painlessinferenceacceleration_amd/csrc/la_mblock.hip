@@ -1749,7 +1749,7 @@ __global__ __launch_bounds__(256) void k_kv_commit_mb(const bf16_t* __restrict__
 // launchers
 // =============================================================================================================
 static bool g_mb_attr = false;
-int g_la_mb_attn_rot = 1;     // la_lab_set key 21: 1 = the query heads of a kv head start their key-tile lists at different offsets (GQA models; default)
+int g_la_mb_attn_rot = 0;     // la_lab_set key 21: 1 = the query heads of a kv head start their key-tile lists at different offsets (GQA models; measured neutral at Mistral bs=8 / Mixtral bs=4, profiles/r04_batch_ab2.txt: off)
 int g_la_mb_attn_vring = 0;   // la_lab_set key 20: 1 = multi-block attention with the next tile's V in flight through a per-wave LDS ring (measured 0.5-5 % SLOWER per step, profiles/r04_mb_attention_vring_ab.txt), 0 = V requested per tile (default)
 int g_la_mb_dbg = 0;
 int g_la_mb_mode = 0;         // la_debug_set key 5: 1 = wide kernel as two co-resident workgroups per CU (80 KiB LDS, 256 rows each)

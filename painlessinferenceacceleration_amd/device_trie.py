@@ -271,8 +271,8 @@ class DeviceTrie(object):
         self.stats_put['calls'] += 1
         self._unreplayed += 1
 
-    def replay(self, puts, branch_length):
-        """Repeat on the host trie what ONE stream_put_dev() call did on the device: puts = [(idx, tokens)] in the order of that call
+    def replay(self, puts, branch_length, calls=1):
+        """Repeat on the host trie what `calls` consecutive stream_put_dev() calls did on the device: puts = [(idx, tokens)] in their order
         (calls are replayed in the order they were queued; the next call may already be queued on the device — round 4: the loops
         replay step N while the GPU runs step N + 1).  The words the host logs for them are already in the device image and are dropped.  -> False when the host's image left the
         device's behind (capacity passed, or a squeeze): the next sync() uploads a full image."""
@@ -283,7 +283,7 @@ class DeviceTrie(object):
         for idx, toks in puts:
             self.cache.stream_put([int(t) for t in toks if t != -1], branch_length=branch_length, final=False, mode='output', idx=int(idx))
         self.stats_put['replays'] += 1
-        self._unreplayed = max(0, self._unreplayed - 1)       # one stream_put_dev call per replay; a newer one may already be queued
+        self._unreplayed = max(0, self._unreplayed - int(calls))       # `calls` stream_put_dev calls are covered by these puts; newer ones may already be queued
         rc = lib.la_cache_mirror_discard(self.cache._h, C.byref(n_pending))
         if rc != 0:
             return False

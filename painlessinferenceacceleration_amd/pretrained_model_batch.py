@@ -204,7 +204,7 @@ class LookaheadPreTrainedModel(object):
         # device_trie_update (default on with the chained device trie): the trie UPDATE of every step runs on the device as well
         dev_put = chained and bool(decoding_kwargs.get('device_trie_update', True)) and branch_length + 1 <= 64
         put_on_device, buffers_loaded = False, False
-        replay_due, full_image_due = None, False      # puts of the last chained step the host trie has not repeated yet
+        replay_due, full_image_due, replay_calls = None, False, 1      # puts of the last chained step the host trie has not repeated yet
         decoding_kwargs['dls'].extend([1] * bs)
         decoding_kwargs['edls'].extend([1] * bs)
         max_cur = 0
@@ -241,7 +241,7 @@ class LookaheadPreTrainedModel(object):
                 dt0 = self._device_trie(decoding_kwargs['_n_samples'], dev_put)
                 if replay_due is not None and (len(batch_indices) > eng.max_blocks or full_image_due):
                     # several engine passes per step, or the host image outgrew the device's: replay first, then a synced query
-                    dt0.replay(replay_due, branch_length + 1)
+                    dt0.replay(replay_due, branch_length + 1, calls=replay_calls)
                     replay_due, full_image_due = None, False
                 # device trie chained in front of the verify pass (la_llama_mstep_trie): ONE query launch for all active samples on the
                 # engine's stream, the step input assembled on the device from its outputs, one 64-row block per sample — no draft
@@ -270,13 +270,14 @@ class LookaheadPreTrainedModel(object):
                                              [rows[b][-1] for b in grp], put_idxs=grp if dev_put else None,
                                              put_branch_length=branch_length + 1)
                         if replay_due is not None:         # the previous step's update, on the host trie, while the GPU verifies
-                            full_image_due = not dt.replay(replay_due, branch_length + 1)
+                            full_image_due = not dt.replay(replay_due, branch_length + 1, calls=replay_calls)
                             replay_due = None
                         toks, Ts = eng.mstep_trie_finish()
                         for b, tk in zip(grp, toks):
                             emitted[b] = tk
                         widths.extend(Ts)
                     put_on_device = dev_put
+                    replay_calls = (len(batch_indices) + eng.max_blocks - 1) // eng.max_blocks       # stream_put_dev calls of this step
                 decoding_kwargs['qts'].append(time.time() - ts_q)
                 decoding_kwargs.update({'decoding_qids': qids, 'decoding_ids': None, 'hit_sizes': None, 'batch_indices': batch_indices})
                 width = max(widths)
@@ -323,7 +324,7 @@ class LookaheadPreTrainedModel(object):
                 decoding_kwargs['dls'].append(width)
                 decoding_kwargs['edls'].append(len(next_token_list[k]))
         if replay_due is not None:                                              # the last step's update (the loop ended before another launch)
-            self._device_trie(decoding_kwargs['_n_samples'], dev_put).replay(replay_due, branch_length + 1)
+            self._device_trie(decoding_kwargs['_n_samples'], dev_put).replay(replay_due, branch_length + 1, calls=replay_calls)
             replay_due = None
         for i in range(bs):                                                     # :1288-1290
             self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=i)
