@@ -12,6 +12,7 @@
 #include "la_kernels.h"
 #include "la_mblock.h"
 extern int g_la_pf_kib, g_la_pf_delay, g_la_pf_tail_kib, g_la_graph_epoch, g_la_graph_reps, g_la_mb_ks2;
+int g_la_ex_down_ks = 0;       // la_lab_set key 22: K splits of the experts' down projection in the gathered multi-block MoE step (0 = library default)
 int g_la_norm4 = 0;            // la_lab_set key 19 (measured neutral: 5.30 vs 5.37 us per launch, profiles/r04_*): 1 = residual + RMSNorm with four workgroups per row (k_row_norm4) on the single-sequence step
 int g_la_split_head_tail = 0;   // la_debug_set key 14: 1 = separate build-inputs / embed / argmax / accept / publish kernels (A/B)
 int g_la_stop_layers = 0;     // la_debug_set key 13 (parity tests): the single-sequence step runs only the first n layers, then the final norm + lm_head
@@ -70,6 +71,7 @@ struct la_llama {
     hipGraphExec_t graph_long = nullptr;         // the single-sequence step with the key-split attention (contexts past attn_thr)
     bool graph_long_ready = false;
     int attn_thr = 0;                            // committed keys + 64 up to which the single-launch attention is used (see resolve_cfg)
+    int ex_down_ks = 4;                          // K splits of the gathered experts' down projection (multi-block MoE step)
     hipGraphExec_t bgraphs[4];                  // batch step captured per attention key-split count {8, 4, 2, 1}
     bool bready[4];
     int bepoch[4];
@@ -158,6 +160,7 @@ static void resolve_cfg(la_llama* m) {
         const int kvx = c.n_kv_heads >= 8 ? (c.n_kv_heads + 7) / 8 : 1;
         m->attn_thr = (int)(2800000 / ((long)kvx * 512));
     }
+    m->ex_down_ks = m->down_ks;
     if (m->qkv_n % 64) m->qkv_rb = (m->qkv_rb & ~0xff) | 1;
     if (c.hidden % 64) { m->o_rb = (m->o_rb & ~0xff) | 1; m->down_rb = (m->down_rb & ~0xff) | 1; }
     if (c.vocab % 64) m->lm_rb = (m->lm_rb & ~0xff) | 1;
@@ -662,7 +665,11 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk, bool wide = fals
             float* const route_w = m->mb_route_w + (size_t)l * LA_MB_MAX * 64 * LA_MOE_MAX_E;
             KCHK(lk_mb_resid_norm_router(st, m->mb_h, m->mb_slabs, m->o_ks, npass_rows, L.norm2, c.hidden, c.rms_eps, m->mb_xp, M, cf,
                                          L.router, c.n_experts, c.top_k, route_w, m->mb_meta));
-            const size_t act_stride = (size_t)LA_MB_MAX * 64 * c.ffn, slab_stride = (size_t)m->down_ks * npass_rows * c.hidden;
+            // K splits of the experts' down projection in the gathered multi-block form: grid.z already carries experts x passes (>= 8
+            // workgroup layers), so the launch fills the chip without split-K — and every split less is 1/4 of the fp32 slab round trip
+            // (4 splits: 67 MB written + read per layer at 256 rows).  la_lab_set(22, n) overrides (0 = the library's choice).
+            const int ex_ks = (nblk >= 2 && m->ex_merged && !(g_la_ex_split & 1)) ? (g_la_ex_down_ks > 0 ? g_la_ex_down_ks : m->ex_down_ks) : m->down_ks;
+            const size_t act_stride = (size_t)LA_MB_MAX * 64 * c.ffn, slab_stride = (size_t)ex_ks * npass_rows * c.hidden;
             // M >= 128: every expert works on the rows it received, packed into their own blocks (la_mblock.hip "Gathered MoE")
             const bool gathered = nblk >= 2;
             const long xg_stride = (long)LA_MB_MAX * 64 * c.hidden;
@@ -677,7 +684,7 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk, bool wide = fals
                 g.ex_n = c.n_experts; g.ex_w_stride = m->ex_gu_stride[l]; g.ex_x_stride = xg_stride; g.ex_o_stride = (long)act_stride;
                 KCHK(lk_mb_gemm(st, 1, g));
                 MbGemm d{}; d.wp = m->ex_down[(size_t)l * c.n_experts]; d.xp = m->mb_act_ex; d.N = c.hidden; d.K = c.ffn; d.nblk = nblk;
-                d.ksplit = m->down_ks; d.slabs = m->mb_slabs_ex; d.slab_rows = npass_rows; d.nblk_dev = m->mb_moe_cnt + LA_MOE_MAX_E;
+                d.ksplit = ex_ks; d.slabs = m->mb_slabs_ex; d.slab_rows = npass_rows; d.nblk_dev = m->mb_moe_cnt + LA_MOE_MAX_E;
                 d.ex_n = c.n_experts; d.ex_w_stride = m->ex_dn_stride[l]; d.ex_x_stride = (long)act_stride; d.ex_o_stride = (long)slab_stride;
                 KCHK(lk_mb_gemm(st, 0, d));
             } else
@@ -694,7 +701,7 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk, bool wide = fals
             }
             if (!(g_la_ex_split & 1)) {
                 // accumulation in expert order + residual + next RMSNorm in one launch (the accumulated row stays in registers)
-                KCHK(lk_mb_moe_accum_norm(st, m->mb_slabs_ex, (long)slab_stride, m->down_ks, npass_rows, route_w, c.n_experts, c.hidden, M,
+                KCHK(lk_mb_moe_accum_norm(st, m->mb_slabs_ex, (long)slab_stride, ex_ks, npass_rows, route_w, c.n_experts, c.hidden, M,
                                           gathered ? m->mb_moe_pos : nullptr, m->mb_h, nw, c.rms_eps, m->mb_xp, cf));
                 continue;
             }

@@ -21,3 +21,16 @@ def _built_library():
         import __graft_entry__
         __graft_entry__.build()
     yield
+
+
+def pytest_sessionstart(session):
+    """LA_LAB_SET="k=v,k=v": apply kernel-lab knobs (include/lookahead_hip_lab.h) for the whole session — how scripts/ re-run a
+    suite under a variant (e.g. another K-split count) before it becomes a default."""
+    import os
+    spec = os.environ.get('LA_LAB_SET')
+    if not spec:
+        return
+    from painlessinferenceacceleration_amd._lib import check, lib
+    for kv in spec.split(','):
+        k, v = kv.split('=')
+        check(lib.la_lab_set(int(k), int(v)), 'la_lab_set')

@@ -130,7 +130,10 @@ def test_from_pretrained_front_door_runs_the_reference_example_sequence(tmp_path
     hf = transformers.LlamaForCausalLM.from_pretrained(d, torch_dtype=torch.float32).eval()
     model = LlamaForCausalLM.from_pretrained(d, cache_dir='../', torch_dtype=torch.float16, low_cpu_mem_usage=True,
                                              device_map={'': 'cuda:0'}, max_length=512)
-    assert model.config.vocab_size == 512 and model.eval() is model and model.dtype == torch.bfloat16
+    # torch_dtype=torch.float16 — the reference example's own setting — now runs the float16 build of the library (round 4; before, fp16
+    # checkpoints were silently computed in bfloat16)
+    assert model.config.vocab_size == 512 and model.eval() is model and model.dtype == torch.float16
+    assert LlamaForCausalLM.from_pretrained(d, torch_dtype=torch.bfloat16, max_length=128).dtype == torch.bfloat16
     input_ids = torch.randint(3, 512, (1, 20), generator=torch.Generator().manual_seed(1))
     with torch.no_grad():
         ref = hf.generate(input_ids, max_new_tokens=64, do_sample=False, pad_token_id=0, eos_token_id=None)[0].tolist()
