@@ -475,6 +475,7 @@ struct GemmArgs {
     long ex_w, ex_x, ex_act, ex_slab;      // element strides per expert (weights, x operand, act_xp, slabs)
     int prio_hi;        // 8-wave kernels: s_setprio level of waves 4..7 (the SIMD partners that are served last), 0 = default
     int kskew;          // 8-wave kernels: share (1/64ths) of the K range given to waves 0..3; 0 = even split (see wave_krange)
+    int slab_wt;        // EPI_SLAB: 1 = store the split-K partials write-through (sc1)
     int dbg_noepi;      // measurement aid (scripts/gpu_ab.py): return after the streaming loop, before the reduction/epilogue
     long long* dbg_times;   // measurement aid: [workgroup][wave][4] wall_clock64() at entry / loop end / exit (null in production)
 };
@@ -669,7 +670,15 @@ __device__ __forceinline__ void gemm64_body(const bf16_t* __restrict__ wp_s, con
 #pragma unroll
             for (int gg = 0; gg < GPW; ++gg) {
                 f32x4 v = {fin[rb][gg][0], fin[rb][gg][1], fin[rb][gg][2], fin[rb][gg][3]};
-                *(f32x4*)(o + (size_t)tok * a.N + (nb0 + rb) * 32 + 8 * (g0 + gg) + 4 * hh) = v;
+                float* dstp = o + (size_t)tok * a.N + (nb0 + rb) * 32 + 8 * (g0 + gg) + 4 * hh;
+                if (a.slab_wt) {
+                    // write-through (sc1): the partials go straight to memory, where the row kernel of the NEXT launch reads them from any
+                    // XCD — nothing is left dirty in this XCD's L2 for the kernel boundary to write back (la_lab_set key 23)
+                    const __amdgpu_buffer_rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)dstp, 0, 16, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), sr, 0, 0, 16);
+                } else {
+                    *(f32x4*)dstp = v;
+                }
             }
     } else if constexpr (EPI == EPI_SWIGLU) {
         // rb 0 = gate rows, rb 1 = up rows of the same 32 features (interleaved packing).
@@ -1974,6 +1983,7 @@ int g_la_attn_staged = 0;     // 1: tree attention with K/V staged through LDS o
 int g_la_graph_reps = 1;      // measurement: repetitions of the step inside the single-sequence graph (key 11)
 int g_la_graph_epoch = 0;     // bumped by la_debug_set when a capture-time knob changes: la_llama_step captures its graph again
 extern int g_la_attn_one;
+int g_la_slab_wt = 0;         // la_lab_set key 23: split-K slabs of the 64-row o_proj / down_proj stored write-through (sc1)
 int g_la_gemm_4w = 0;         // la_debug_set key 15: bit 0 = gate/up as 4 waves x 8 tile-sets (one wave per SIMD) — measurement
 int g_la_pf_delay = 0;        // s_sleep(32) rounds the prefetch workgroups wait before their first load (key 8)
 
@@ -2022,7 +2032,7 @@ int lk_gemm64_slab(hipStream_t st, const void* wp, const void* xp, int N, int K,
                    const float* route_col) {
     const int rb = rbv & 0xff, variant = rbv >> 8;
     GemmArgs a{}; a.dbg_noepi = g_la_dbg_noepi; a.kskew = g_la_kskew; a.prio_hi = g_la_prio_hi; a.dbg_times = g_la_dbg_times; a.wp = (const bf16_t*)wp; a.xp = (const bf16_t*)xp; a.K16 = K / 16; a.N = N; a.slabs = slabs;
-    a.route_col = route_col;
+    a.route_col = route_col; a.slab_wt = g_la_slab_wt;
     if (rb == 2 && (N % 64) == 0) return launch_gemm<2, EPI_SLAB>(st, a, N / 64, ksplit, variant);
     return launch_gemm<1, EPI_SLAB>(st, a, N / 32, ksplit, variant);
 }

@@ -39,6 +39,21 @@ for f in glob.glob(os.path.join(raw, 'stats', '**', '*kernel_trace*.csv'), recur
     with open(os.path.join(out, 'kernel_trace_summary.txt'), 'w') as fo:
         for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             fo.write(f'{k}\t{n}\t{t / n / 1e3:.2f}us\t{t / 1e6:.3f}ms\n')
+# the two norm launches and the two slab GEMMs of a layer carry the same kernel name: split them by their position in the step
+for f in glob.glob(os.path.join(raw, 'stats', '**', '*kernel_trace*.csv'), recursive=True):
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
+    prev, agg2 = None, collections.defaultdict(lambda: [0, 0])
+    for r in rows:
+        k = r['Kernel_Name'][:40]
+        if k.startswith(('void k_row_norm<', 'void k_gemm64<2, 0')):
+            key = (k, (prev or '')[:34])
+            agg2[key][0] += 1; agg2[key][1] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+        prev = r['Kernel_Name']
+    with open(os.path.join(out, 'kernel_by_predecessor.txt'), 'w') as fo:
+        for (k, pv), (n, t) in sorted(agg2.items(), key=lambda kv: -kv[1][1]):
+            if n >= 50:
+                line = f'{k:42s} after {pv:36s} n={n:6d} avg {t / n / 1e3:6.2f} us'
+                fo.write(line + '\n'); print(line)
 for f in glob.glob(os.path.join(raw, 'pmc_SQ', '**', '*counter_collection*.csv'), recursive=True):
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     for r in csv.DictReader(open(f)):
