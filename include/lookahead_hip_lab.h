@@ -39,7 +39,10 @@ extern "C" {
  * key 20: multi-block tree attention, 1 = the next tile's V in flight through a per-wave LDS ring (LDS-DMA; measured slower), 0 = V
  *         requested when its tile begins (default); bit-identical results.
  * key 21: multi-block tree attention of GQA models, 1 = the query heads of a kv head start their key-tile lists at different offsets
- *         (changes the order of the online-softmax updates; measured neutral), 0 = all start at the first tile (default). */
+ *         (changes the order of the online-softmax updates; measured neutral), 0 = all start at the first tile (default).
+ * key 22: K splits of the gathered experts' down GEMM (0 = the engine's choice).  key 23: 1 = the slab GEMMs of the single-sequence
+ *         step publish their partial sums write-through (measured slower: 4.23 vs 3.68 ms per step), 0 = plain stores (default).
+ * key 24: wide multi-block GEMMs, 1 = four loader waves (one per SIMD) issue all LDS-DMA of a stage, 0 = all eight waves. */
 int          la_lab_set(int key, int value);
 int          la_lab_get(int key);          /* current value of a knob (the library default unless la_lab_set changed it) */
 /* key 0: device buffer int64[workgroups][waves][8] the GEMM kernels stamp with wall_clock64() at entry / end of the

@@ -40,7 +40,6 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
     const int nh = nh_nkv >> 16, nkv = nh_nkv & 0xffff, G = nh / nkv;
     const int SL = sl_ring & 63, ring_tiles = sl_ring >> 8;
     const bool norot = (sl_ring & 128) != 0;                            // measurement (la_lab_set key 18 bit 0): every sharer starts at tile 0
-    const bool spec = (sl_ring & 64) == 0;                              // key 18 bit 3 set: no speculative touch
     const int W = 32 / SL;                                            // token rows this workgroup stores
     const int NS = G * 2 * SL;                                        // workgroups that read the same kv head
     const int b = blockIdx.x;
@@ -56,21 +55,6 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
     if (stamp && lane == 0) stamp[0] = wall_clock64();
 
     const int KB = max_keys >> 5;
-    // Speculative touch (spec: la_lab_set key 18 bit 3 clear): the tile list below hangs on nkeys, a scalar load from the device state
-    // block (~1 us behind dispatch).  Until it arrives, every lane pulls one dword of a different 128-byte line of the K and V tiles
-    // this wave will most likely start with (main tile par + 8 r: exact once the context holds (par + 8 r + 1) * 32 keys and r < the
-    // wave's tile count) — two load instructions per wave whose data is dropped; the real tile loads then find the lines in L2.
-    // Nothing depends on it: a wrong guess costs 16 KiB of extra reads.
-    unsigned sp0 = 0u, sp1 = 0u;
-    if (spec && window <= 0 && ring_tiles == 0) {
-        const int pt = par + 8 * r < KB ? par + 8 * r : KB - 1;
-        const unsigned* kp = (const unsigned*)(kmain + ((size_t)hk * KB + pt) * 4096) + lane * 32;
-        const unsigned* vp = (const unsigned*)(vmain + ((size_t)hk * KB + pt) * 4096) + lane * 32;
-        // asm loads: invisible to the compiler's vmcnt bookkeeping.  They are the OLDEST loads of the wave, so every later wait of the
-        // compiler for its own loads covers them (in-order return); their registers stay reserved until the explicit wait behind the
-        // tile loop (sp0 / sp1 are its operands), so nothing is allocated over a load still in flight
-        asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(sp0), "=&v"(sp1) : "v"(kp), "v"(vp) : "memory");
-    }
     // Q fragments of (h, tb): wave `par` brings fragment `par` (1 KiB); all waves read the 8 fragments back per tile
     bf16x8* const qs = (bf16x8*)lds1;
     const bf16x8 qmine = *((const bf16x8*)(qf + ((size_t)(h * 2 + tb) * 8 + par) * 512) + lane);
@@ -83,7 +67,7 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
     const int key_lo = (window > 0) ? nkeys + __popcll(rm) - 1 - window : 0;
     // this wave's tiles: par, par + 8, ...; the sharers start at different offsets of that list (see the header)
     const int cnt = NT > par ? (NT - par + 7) >> 3 : 0;
-    int idx = (cnt > 0 && !norot) ? r % cnt : 0;                        // sharer r starts at its r-th tile (what the speculative touch aimed at)
+    int idx = (cnt > 0 && !norot) ? r % cnt : 0;                        // sharer r starts at its r-th tile
 
     auto mtile = [&](int it) -> size_t { return (size_t)(ring_tiles > 0 ? (ts + it) % ring_tiles : ts + it); };
     auto kptr = [&](int it) -> const bf16x8* {
@@ -209,7 +193,6 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
         tile(it, kB);
         it = nx;
     }
-    asm volatile("s_waitcnt vmcnt(0)" :: "v"(sp0), "v"(sp1) : "memory");      // the speculative touch has landed (long ago): its registers are free
     if (stamp && lane == 0) stamp[3] = wall_clock64();
 
     // ---- the 8 key parities meet once: the lanes of the slice's token columns park (O, m, l); then every (head-dim group of 4,
@@ -281,7 +264,7 @@ int lk_tree_attn1(hipStream_t st, const void* qf, const void* kmain, const void*
     a.kfresh = (const bf16_t*)kfresh; a.vfresh = (const bf16_t*)vfresh; a.attn_xp = (bf16_t*)attn_xp; a.dbg_times = g_la_dbg_times;
     const size_t lds = 8192 + (size_t)8 * 16 * 2 * W * 16 + (size_t)8 * W * 8;
     k_tree_attn1<<<nh * 2 * SL, 512, lds, st>>>((const bf16_t*)qf, (const unsigned long long*)rowmask, state, (const bf16_t*)kmain,
-                                                (const bf16_t*)vmain, max_keys, (nh << 16) | nkv, window, SL | ((g_la_attn1_var & 1) << 7) | (((g_la_attn1_var >> 3) & 1) << 6) | ((ring_keys >> 5) << 8), a);
+                                                (const bf16_t*)vmain, max_keys, (nh << 16) | nkv, window, SL | ((g_la_attn1_var & 1) << 7) | ((ring_keys >> 5) << 8), a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }

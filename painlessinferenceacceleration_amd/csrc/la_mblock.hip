@@ -399,11 +399,16 @@ template <int RBV, int TW> struct WideGeom {
     static_assert(A_STAGE <= 16 && LDS <= 160 * 1024 && (RBV == 2 || RBV == 4 || RBV == 8), "ring geometry");
 };
 
-template <int RBV, int TW, int EPI, int DBG = 0>
+// NW = loader waves: 8 = every wave copies its share of a stage (pieces w + 8 i); 4 = only waves 4..7 copy (pieces (w - 4) + 4 i),
+// one loader per SIMD (a workgroup's waves w and w + 4 share a SIMD): an LDS-DMA issue blocks its wave while the CU's vector-memory
+// queue is full, and when both waves of a SIMD block at the same points of the same schedule the matrix pipe has nothing to issue.
+template <int RBV, int TW, int EPI, int DBG = 0, int NW = 8>
 __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
     using GEO = WideGeom<RBV, TW>;
     constexpr int KS = GEO::KS, TQ = GEO::TQ, NTBP = GEO::NTBP, A_STAGE = GEO::A_STAGE, STAGE = GEO::STAGE, NR = GEO::NR;
-    constexpr int NP_HI = GEO::NP_HI, NP_LO = GEO::NP_LO, N_HI = GEO::N_HI;
+    static_assert(NW == 8 || NW == 4, "loader waves");
+    constexpr int NP_HI = (STAGE + NW - 1) / NW, NP_LO = STAGE / NW, N_HI = STAGE - NW * NP_LO;      // pieces per loader wave and stage
+    static_assert(3 * NP_HI <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = threadIdx.x & 63;
     if (a.route_col) {
@@ -430,14 +435,17 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
 
     const bf16x8* __restrict__ wbase = (const bf16x8*)a.wp;
     const bf16x8* __restrict__ xbase = (const bf16x8*)a.xp;
-    const bool hi = wave < N_HI;                    // this wave carries NP_HI pieces
-    // piece p = wave + 8 i of a stage is a weight piece iff p < A_STAGE (i = 0 for the waves below A_STAGE; i = 0 and 1 at RBV = 8)
+    const int lw = wave - (8 - NW);                 // loader index (negative: this wave copies nothing)
+    const bool loader = lw >= 0;
+    const int lwc = loader ? lw : 0;
+    const bool hi = loader && lw < N_HI;            // this wave carries NP_HI pieces
+    // piece p = lw + NW i of a stage is a weight piece iff p < A_STAGE
     const bf16x8* src[NP_HI];                       // per-lane source of the piece at k-tile 0
     unsigned gstr[NP_HI];                           // its k-tile stride (16 B units)
     int pkk[NP_HI], pdst[NP_HI];                    // wave-uniform: k-tile inside the stage, byte offset inside the stage buffer
 #pragma unroll
     for (int i = 0; i < NP_HI; ++i) {
-        const int p = wave + 8 * ((i < NP_LO || hi) ? i : 0);
+        const int p = lwc + NW * ((i < NP_LO || hi) ? i : 0);
         if (p < A_STAGE) {
             const int kk = p / RBV, rb = p % RBV;
             if (a.planned) {
@@ -466,8 +474,8 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
         kt = kt < t1 ? kt : t1 - 1;
         const bf16x8* g = src[i] + (size_t)kt * gstr[i];
         char* d = lds_raw + (sidx % NR) * (STAGE * 1024) + pdst[i];
-        if (i < NP_LO || hi) {
-            if (wave + 8 * i < A_STAGE && !a.w_keep) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 2);   // streamed weights: nt
+        if (loader && (i < NP_LO || hi)) {
+            if (lw + NW * i < A_STAGE && !a.w_keep) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 2);   // streamed weights: nt
             else __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 0);
         }
     };
@@ -502,7 +510,7 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
         else acc[r][t] = LA_MFMA(fa[r], fb[t], acc[r][t], 0, 0, 0);
     };
 
-    constexpr int H = GEO::H;
+    constexpr int H = (NP_HI + 1) / 2;              // pieces issued in the first half of a stage
     issue(0); issue(1); issue(2);
     if (hi) vm_wait<2 * NP_HI>(); else vm_wait<2 * NP_LO>();
     __builtin_amdgcn_s_barrier();
@@ -1756,6 +1764,12 @@ int g_la_mb_mode = 0;         // la_debug_set key 5: 1 = wide kernel as two co-r
 int g_la_mb_pair = 1;         // la_debug_set key 6, bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
 int g_la_mb_ks2 = 0;          // la_debug_set key 12: slab GEMMs of the multi-block step with 2 K splits at >= 5 blocks (measurement)
 int g_la_mb_narrow = 0;       // la_debug_set key 3: 1 = the K-split kernels (k_gemm_mb) for every nblk (A/B measurements)
+int g_la_mb_dw = 0;           // la_lab_set key 24: 1 = wide GEMMs with 4 loader waves (one per SIMD) instead of 8
+template <int RBV, int TW, int EPI>
+static void wide_launch(dim3 grid, hipStream_t st, const MbArgs& a) {
+    if (g_la_mb_dw) k_gemm_wide<RBV, TW, EPI, 0, 4><<<grid, 512, WideGeom<RBV, TW>::LDS, st>>>(a);
+    else k_gemm_wide<RBV, TW, EPI, 0, 8><<<grid, 512, WideGeom<RBV, TW>::LDS, st>>>(a);
+}
 template <typename K> static hipError_t set_lds(K k, int bytes) {
     return hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
@@ -1776,18 +1790,26 @@ int lk_mb_init() {
 #define SETW4(T) \
     if (e == hipSuccess) e = set_lds(k_gemm_wide<8, T, MB_SWIGLU>, WideGeom<8, T>::LDS); \
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_SWIGLU>, WideGeom<4, T>::LDS); \
-    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_LOGITS>, WideGeom<4, T>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_LOGITS>, WideGeom<4, T>::LDS); \
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<8, T, MB_SWIGLU, 0, 4>, WideGeom<8, T>::LDS); \
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_SWIGLU, 0, 4>, WideGeom<4, T>::LDS); \
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_LOGITS, 0, 4>, WideGeom<4, T>::LDS);
 #define SETW2(T) \
     if (e == hipSuccess) e = set_lds(k_gemm_wide<2, T, MB_SLAB>, WideGeom<2, T>::LDS); \
     if (e == hipSuccess) e = set_lds(k_gemm_wide<2, T, MB_QKV>, WideGeom<2, T>::LDS); \
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_SLAB>, WideGeom<4, T>::LDS); \
-    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_QKV>, WideGeom<4, T>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_QKV>, WideGeom<4, T>::LDS); \
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<2, T, MB_SLAB, 0, 4>, WideGeom<2, T>::LDS); \
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<2, T, MB_QKV, 0, 4>, WideGeom<2, T>::LDS); \
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_SLAB, 0, 4>, WideGeom<4, T>::LDS); \
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_QKV, 0, 4>, WideGeom<4, T>::LDS);
     SETW4(2) SETW4(3) SETW4(4) SETW2(1) SETW2(2)
 #undef SETW4
 #undef SETW2
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 2, MB_SLAB, 4>, WideGeom<4, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 2, MB_QKV, 4>, WideGeom<4, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<8, 2, MB_QKV>, WideGeom<8, 2>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<8, 2, MB_QKV, 0, 4>, WideGeom<8, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 1>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 2>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 3>, WideGeom<4, 4>::LDS);
@@ -1928,7 +1950,7 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                             p.boff[2 * r + j] = r * a.wg_chunks + a.boff[j]; p.nv[2 * r + j] = a.nv[j]; p.nvl[2 * r + j] = a.nvl[j];
                         }
                     p.wg_chunks = 4 * a.wg_chunks;
-                    k_gemm_wide<8, 2, EPI><<<dim3(n_wg / 4, ksplit, (nblk + 1) / 2), 512, WideGeom<8, 2>::LDS, st>>>(p);
+                    wide_launch<8, 2, EPI>(dim3(n_wg / 4, ksplit, (nblk + 1) / 2), st, p);
                     LAUNCH_CHECK(); return 0;
                 }
             }
@@ -1943,9 +1965,9 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                 // la_debug_set key 12 (slab launches with <= 2 K splits): more token groups instead — 2 blocks per workgroup at every block count
                 // QKV over at most 128 (fuller) workgroups — the multi-block image of a GQA model, cfg.qkv_mb_wg — takes token QUARTERS at
                 // every block count: n_wg / 2 x 4 <= 256 workgroups of 4 row-blocks x 4 token tiles (la_debug_set(6, 9) forces the form)
-                if (nblk <= 4 || (EPI == MB_SLAB && g_la_mb_ks2 && ksplit <= 2) || (EPI == MB_QKV && (n_wg <= 128 || (g_la_mb_pair & 8)))) k_gemm_wide<4, 1, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 1) / 2), 512, WideGeom<4, 1>::LDS, st>>>(p);
+                if (nblk <= 4 || (EPI == MB_SLAB && g_la_mb_ks2 && ksplit <= 2) || (EPI == MB_QKV && (n_wg <= 128 || (g_la_mb_pair & 8)))) wide_launch<4, 1, EPI>(dim3(n_wg / 2, ksplit, (nblk + 1) / 2), st, p);
                 else if (g_la_mb_dbg == 4) k_gemm_wide<4, 2, EPI, 4><<<dim3(n_wg / 2, ksplit, (nblk + 3) / 4), 512, WideGeom<4, 2>::LDS, st>>>(p);   // measurement: no epilogue
-                else k_gemm_wide<4, 2, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 3) / 4), 512, WideGeom<4, 2>::LDS, st>>>(p);
+                else wide_launch<4, 2, EPI>(dim3(n_wg / 2, ksplit, (nblk + 3) / 4), st, p);
                 LAUNCH_CHECK(); return 0;
             }
         }
@@ -1960,22 +1982,22 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                 p.wg_chunks = 2 * a.wg_chunks;
                 const dim3 g2(n_wg / 2, 1, 2);
                 switch ((nblk + 1) / 2) {                       // 64-row blocks per workgroup = TW
-                    case 2: k_gemm_wide<8, 2, EPI><<<g2, 512, WideGeom<8, 2>::LDS, st>>>(p); break;
-                    case 3: k_gemm_wide<8, 3, EPI><<<g2, 512, WideGeom<8, 3>::LDS, st>>>(p); break;
-                    default: k_gemm_wide<8, 4, EPI><<<g2, 512, WideGeom<8, 4>::LDS, st>>>(p); break;
+                    case 2: wide_launch<8, 2, EPI>(g2, st, p); break;
+                    case 3: wide_launch<8, 3, EPI>(g2, st, p); break;
+                    default: wide_launch<8, 4, EPI>(g2, st, p); break;
                 }
                 LAUNCH_CHECK(); return 0;
             }
         }
         if constexpr (RBV == 4) {
             switch ((nblk + 1) / 2) {
-                case 2: k_gemm_wide<4, 2, EPI><<<grid, 512, WideGeom<4, 2>::LDS, st>>>(a); break;
-                case 3: k_gemm_wide<4, 3, EPI><<<grid, 512, WideGeom<4, 3>::LDS, st>>>(a); break;
-                default: k_gemm_wide<4, 4, EPI><<<grid, 512, WideGeom<4, 4>::LDS, st>>>(a); break;
+                case 2: wide_launch<4, 2, EPI>(grid, st, a); break;
+                case 3: wide_launch<4, 3, EPI>(grid, st, a); break;
+                default: wide_launch<4, 4, EPI>(grid, st, a); break;
             }
         } else {
-            if (nblk <= 4) k_gemm_wide<2, 1, EPI><<<dim3(n_wg, ksplit, (nblk + 3) / 4), 512, WideGeom<2, 1>::LDS, st>>>(a);
-            else k_gemm_wide<2, 2, EPI><<<grid, 512, WideGeom<2, 2>::LDS, st>>>(a);
+            if (nblk <= 4) wide_launch<2, 1, EPI>(dim3(n_wg, ksplit, (nblk + 3) / 4), st, a);
+            else wide_launch<2, 2, EPI>(grid, st, a);
         }
         LAUNCH_CHECK(); return 0;
     }

@@ -48,7 +48,7 @@ def main(nh=32, nkv=32):
     def run(state):
         return lambda i: lib.la_tree_attn(sp(), ptr(qf), ptr(km[i % NL]), ptr(vm[i % NL]), ptr(kf), ptr(vf), ptr(rm), ptr(state), nh, nkv,
                                           max_keys, nsplit, ptr(opart), ptr(mpart), ptr(lpart), ptr(out))
-    variants = [('split+combine', 0, 0), ('one launch (SL=2, spec touch)', 1, 0), ('  no spec touch', 1, 8), ('  no rotation', 1, 1), ('  SL=4', 1, 6), ('  SL=1', 1, 2)]
+    variants = [('split+combine', 0, 0), ('one launch (SL=2)', 1, 0), ('  no rotation', 1, 1), ('  SL=4', 1, 6), ('  SL=1', 1, 2)]
     for nkeys in (512, 640, 768, 992, 1500, 1984, 4032):
         state = torch.zeros(_lib.LA_ST_WORDS, dtype=torch.int32, device=DEV)
         state[0] = nkeys
@@ -62,7 +62,7 @@ def main(nh=32, nkv=32):
         print(f'nkeys={nkeys:5d} ({kvb / 1e6:5.1f} MB K/V): ' + ' | '.join(line), flush=True)
     check(lib.la_lab_set(17, 1), 'debug_set')
     # phase stamps of the single-launch kernel (us since the first wave of the launch started; percentiles over 256 WGs x 8 waves)
-    for nkeys, var in ((768, 0), (768, 8), (1984, 0)):
+    for nkeys, var in ((768, 0), (1984, 0)):
         check(lib.la_lab_set(18, var), 'debug_set')
         state = torch.zeros(_lib.LA_ST_WORDS, dtype=torch.int32, device=DEV)
         state[0] = nkeys
