@@ -385,6 +385,15 @@ template <int N> __device__ __forceinline__ void vm_wait() {
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// one LDS-DMA piece through a buffer resource: 16 B per lane at (voffset + soffset) of the buffer -> LDS at d + 16 lane
+template <int AUX>
+__device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rs, char* d, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)d, 16, voff, soff, 0, AUX);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7ffffff0, 0x00020000);
+}
+
 template <int RBV, int TW> struct WideGeom {
     static constexpr int KS = 2, RG = RBV / 2, TQ = 8 / RG, NTBP = TQ * TW;  // token blocks (32 rows) per workgroup
     // RBV = 8: the paired gate/up launch — two adjacent planned regions {G0,G1,U0,U1} x 2 per workgroup, 4 row groups x 2 token groups
@@ -399,16 +408,21 @@ template <int RBV, int TW> struct WideGeom {
     static_assert(A_STAGE <= 16 && LDS <= 160 * 1024 && (RBV == 2 || RBV == 4 || RBV == 8), "ring geometry");
 };
 
-// NW = loader waves: 8 = every wave copies its share of a stage (pieces w + 8 i); 4 = only waves 4..7 copy (pieces (w - 4) + 4 i),
-// one loader per SIMD (a workgroup's waves w and w + 4 share a SIMD): an LDS-DMA issue blocks its wave while the CU's vector-memory
-// queue is full, and when both waves of a SIMD block at the same points of the same schedule the matrix pipe has nothing to issue.
-template <int RBV, int TW, int EPI, int DBG = 0, int NW = 8>
+// SCH = schedule of a stage (bit 0: reads interleaved, bit 1: buffer-addressed pieces).  0: the six fragment reads of a k-tile are issued together, then its MFMAs; the pieces are addressed
+// by 64-bit per-lane pointers (global_load_lds).  Bit 0: ONE fragment read after each MFMA (the matrix pipe restarts right behind every
+// barrier instead of behind six ds_read issues and their address adds).  Bit 1: the pieces are addressed through two buffer resources
+// (weights of this workgroup, x) with a per-lane 32-bit offset and a scalar k-tile offset: buffer_load_dwordx4 ... offen lds, ~5 SALU
+// and no VALU per piece instead of ~9 SALU + a 64-bit VALU add.  Same MFMAs on the same operands in the same order: bit-identical.
+// (Measured and dropped: four loader waves — one per SIMD — issuing all pieces of a stage: 5-12 % SLOWER,
+// profiles/r04_wide_gemm_schedule.txt: a wave's own issue chain is the cost, not the queueing of the eight waves.)
+template <int RBV, int TW, int EPI, int DBG = 0, int SCH = 0>
 __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
     using GEO = WideGeom<RBV, TW>;
     constexpr int KS = GEO::KS, TQ = GEO::TQ, NTBP = GEO::NTBP, A_STAGE = GEO::A_STAGE, STAGE = GEO::STAGE, NR = GEO::NR;
-    static_assert(NW == 8 || NW == 4, "loader waves");
-    constexpr int NP_HI = (STAGE + NW - 1) / NW, NP_LO = STAGE / NW, N_HI = STAGE - NW * NP_LO;      // pieces per loader wave and stage
-    static_assert(3 * NP_HI <= 63, "vmcnt is a 6-bit counter");
+    constexpr int NP_HI = GEO::NP_HI, NP_LO = GEO::NP_LO, N_HI = GEO::N_HI;
+    static_assert(SCH == 0 || ((SCH == 2 || SCH == 3) && (DBG == 0 || DBG == 4)), "measurement builds 1, 2, 3, 5 exist for schedule 0 only");
+    constexpr bool BUF = (SCH & 2) != 0;            // pieces addressed through buffer resources
+    constexpr bool ILV = (SCH & 1) != 0;            // one fragment read after each MFMA
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = threadIdx.x & 63;
     if (a.route_col) {
@@ -435,26 +449,29 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
 
     const bf16x8* __restrict__ wbase = (const bf16x8*)a.wp;
     const bf16x8* __restrict__ xbase = (const bf16x8*)a.xp;
-    const int lw = wave - (8 - NW);                 // loader index (negative: this wave copies nothing)
-    const bool loader = lw >= 0;
-    const int lwc = loader ? lw : 0;
-    const bool hi = loader && lw < N_HI;            // this wave carries NP_HI pieces
-    // piece p = lw + NW i of a stage is a weight piece iff p < A_STAGE
-    const bf16x8* src[NP_HI];                       // per-lane source of the piece at k-tile 0
-    unsigned gstr[NP_HI];                           // its k-tile stride (16 B units)
+    const bool hi = wave < N_HI;                    // this wave carries NP_HI pieces
+    // piece p = wave + 8 i of a stage is a weight piece iff p < A_STAGE (i = 0 for the waves below A_STAGE; i = 0 and 1 at RBV = 8)
+    const bf16x8* src[NP_HI];                       // SCH 0: per-lane source of the piece at k-tile 0
+    unsigned gstr[NP_HI];                           // its k-tile stride (16 B units); SCH 1: in bytes, wave-uniform
+    unsigned voff[NP_HI];                           // SCH 1: per-lane byte offset of the piece inside its buffer (k-tile 0)
     int pkk[NP_HI], pdst[NP_HI];                    // wave-uniform: k-tile inside the stage, byte offset inside the stage buffer
+    // SCH 1 buffers: the weights of this workgroup (planned: its chunk range; classic: its RBV row-blocks) and the x image
+    const bf16x8* wg_w = a.planned ? wbase + (size_t)blockIdx.x * (unsigned)a.wg_chunks : wbase + (size_t)blockIdx.x * RBV * a.K16 * 64;
+    const __amdgpu_buffer_rsrc_t rs_w = dma_rsrc(wg_w), rs_x = dma_rsrc(xbase);
 #pragma unroll
     for (int i = 0; i < NP_HI; ++i) {
-        const int p = lwc + NW * ((i < NP_LO || hi) ? i : 0);
+        const int p = wave + 8 * ((i < NP_LO || hi) ? i : 0);
         if (p < A_STAGE) {
             const int kk = p / RBV, rb = p % RBV;
             if (a.planned) {
                 const int nvb = a.nvl[rb];
                 const int rr = (lane & 31) < nvb ? (lane & 31) : nvb - 1;
-                gstr[i] = (unsigned)(2 * nvb);
+                gstr[i] = BUF ? (unsigned)(32 * nvb) : (unsigned)(2 * nvb);
+                voff[i] = ((unsigned)a.boff[rb] + (unsigned)((lane >> 5) * nvb + rr)) * 16u;
                 src[i] = wbase + ((size_t)blockIdx.x * (unsigned)a.wg_chunks + (unsigned)a.boff[rb] + (unsigned)((lane >> 5) * nvb + rr));
             } else {
-                gstr[i] = 64u;
+                gstr[i] = BUF ? 1024u : 64u;
+                voff[i] = ((unsigned)(rb * a.K16 * 64) + (unsigned)lane) * 16u;
                 src[i] = wbase + ((size_t)(blockIdx.x * RBV + rb) * a.K16 * 64 + lane);
             }
             pkk[i] = kk;
@@ -463,7 +480,8 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
             const int q = p - A_STAGE, kk = q / NTBP, tb = q % NTBP;
             int xb = zb0 + (tb >> 1);
             xb = xb < a.nblk ? xb : a.nblk - 1;     // token blocks past the step re-read the last real block (results dropped)
-            gstr[i] = 128u;
+            gstr[i] = BUF ? 2048u : 128u;
+            voff[i] = ((unsigned)(((xb * a.K16) * 2 + (tb & 1)) * 64) + (unsigned)lane) * 16u;
             src[i] = xbase + ((size_t)((xb * a.K16) * 2 + (tb & 1)) * 64 + lane);
             pkk[i] = kk;
             pdst[i] = (A_STAGE + kk * NTBP + tb) * 1024;
@@ -472,11 +490,19 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
     auto issue_one = [&](int sidx, int i) {         // piece i of this wave's share of stage sidx (k-tile clamped into the range)
         int kt = t0 + sidx * KS + pkk[i];
         kt = kt < t1 ? kt : t1 - 1;
-        const bf16x8* g = src[i] + (size_t)kt * gstr[i];
         char* d = lds_raw + (sidx % NR) * (STAGE * 1024) + pdst[i];
-        if (loader && (i < NP_LO || hi)) {
-            if (lw + NW * i < A_STAGE && !a.w_keep) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 2);   // streamed weights: nt
-            else __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 0);
+        if (i < NP_LO || hi) {
+            if constexpr (BUF) {
+                const unsigned so = (unsigned)kt * gstr[i];
+                if (8 * i < A_STAGE && wave + 8 * i < A_STAGE) {        // (the first test is a compile-time one: later pieces are x pieces)
+                    if (!a.w_keep) dma_piece<2>(rs_w, d, voff[i], so);   // streamed weights: nt
+                    else dma_piece<0>(rs_w, d, voff[i], so);
+                } else dma_piece<0>(rs_x, d, voff[i], so);
+            } else {
+                const bf16x8* g = src[i] + (size_t)kt * gstr[i];
+                if (wave + 8 * i < A_STAGE && !a.w_keep) __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 2);   // streamed weights: nt
+                else __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)d, 16, 0, 0);
+            }
         }
     };
     auto issue = [&](int sidx) {
@@ -496,6 +522,15 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
     // scoreboard gives up across the loop back-edge and waits lgkmcnt(0) before the first MFMA of a set, i.e. for the reads it
     // has just issued for the OTHER set.
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds_raw + (unsigned)lane * 16u;
+    // fragment j of k-tile (sidx, kk) in the order the MFMAs want them: weights of row-block 0, the TW x tiles, weights of row-block 1
+    auto read_one = [&](int sidx, int kk, int j, bf16x8 (&fa)[2], bf16x8 (&fb)[TW]) {
+        const unsigned S = lds0 + (unsigned)((sidx % NR) * (STAGE * 1024));
+        const unsigned A = S + (unsigned)(kk * RBV * 1024);
+        const unsigned B = S + (unsigned)((A_STAGE + kk * NTBP + tq * TW) * 1024);
+        if (j == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[0]) : "v"(A + rb0 * 1024u) : "memory");
+        else if (j == TW + 1) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[1]) : "v"(A + rb1 * 1024u) : "memory");
+        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[j - 1]) : "v"(B), "n"((j - 1) * 1024) : "memory");
+    };
     auto read_frags = [&](int sidx, int kk, bf16x8 (&fa)[2], bf16x8 (&fb)[TW]) {
         const unsigned S = lds0 + (unsigned)((sidx % NR) * (STAGE * 1024));
         const unsigned A = S + (unsigned)(kk * RBV * 1024);
@@ -510,13 +545,52 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
         else acc[r][t] = LA_MFMA(fa[r], fb[t], acc[r][t], 0, 0, 0);
     };
 
-    constexpr int H = (NP_HI + 1) / 2;              // pieces issued in the first half of a stage
+    constexpr int H = GEO::H;
     issue(0); issue(1); issue(2);
     if (hi) vm_wait<2 * NP_HI>(); else vm_wait<2 * NP_LO>();
     __builtin_amdgcn_s_barrier();
     bf16x8 fa0[2], fb0[TW], fa1[2], fb1[TW];
     read_frags(0, 0, fa0, fb0);
     constexpr int NMMA = 2 * TW, NRD = 2 + TW;
+    if constexpr (ILV) {
+        constexpr int NG1 = NMMA > H ? (NMMA > NRD ? NMMA : NRD) : (H > NRD ? H : NRD);
+        constexpr int H2 = NP_HI - H;
+        constexpr int NG2 = NMMA > H2 ? (NMMA > NRD ? NMMA : NRD) : (H2 > NRD ? H2 : NRD);
+        for (int s = 0; s < nst; ++s) {
+            const bool full = (t0 + s * KS + 1) < t1;   // an odd K range ends on half a stage (workgroup-uniform)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // set0 (read during the previous half) is complete
+            __builtin_amdgcn_sched_barrier(0);
+            // first half: MFMA of set0 | one fragment read of set1 (stage s, k-tile 1) | one DMA piece of stage s+3, group after group
+#pragma unroll
+            for (int m = 0; m < NG1; ++m) {
+                if (m < NMMA) mma(m / TW, m % TW, fa0, fb0);
+                if (m < NRD) read_one(s, 1, m, fa1, fb1);
+                if (m < H) issue_one(s + 3, m);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // every read of stage s is complete
+            if (hi) vm_wait<NP_HI + H>(); else vm_wait<NP_LO + H>();   // own pieces of stage s+1 landed
+            __builtin_amdgcn_s_barrier();                                // stage s+1 complete for everyone; the slot of stage s is free
+            __builtin_amdgcn_sched_barrier(0);
+            // second half: MFMA of set1 | one fragment read of set0 (stage s+1, k-tile 0) | the remaining pieces of stage s+3
+            if (full) {
+#pragma unroll
+                for (int m = 0; m < NG2; ++m) {
+                    if (m < NMMA) mma(m / TW, m % TW, fa1, fb1);
+                    if (m < NRD) read_one(s + 1, 0, m, fa0, fb0);
+                    if (m < H2) issue_one(s + 3, H + m);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < (NRD > H2 ? NRD : H2); ++m) {
+                    if (m < NRD) read_one(s + 1, 0, m, fa0, fb0);
+                    if (m < H2) issue_one(s + 3, H + m);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
     for (int s = 0; s < nst; ++s) {
         const bool full = (t0 + s * KS + 1) < t1;   // an odd K range ends on half a stage (workgroup-uniform)
         if constexpr (DBG != 3) read_frags(s, 1, fa1, fb1);
@@ -550,6 +624,7 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     vm_wait<0>();
@@ -1764,11 +1839,15 @@ int g_la_mb_mode = 0;         // la_debug_set key 5: 1 = wide kernel as two co-r
 int g_la_mb_pair = 1;         // la_debug_set key 6, bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
 int g_la_mb_ks2 = 0;          // la_debug_set key 12: slab GEMMs of the multi-block step with 2 K splits at >= 5 blocks (measurement)
 int g_la_mb_narrow = 0;       // la_debug_set key 3: 1 = the K-split kernels (k_gemm_mb) for every nblk (A/B measurements)
-int g_la_mb_dw = 0;           // la_lab_set key 24: 1 = wide GEMMs with 4 loader waves (one per SIMD) instead of 8
+int g_la_mb_sch = 1;          // la_lab_set key 24: 1 = round-4 schedule of the wide GEMMs (default), 0 = the round-2 schedule (A/B reference)
 template <int RBV, int TW, int EPI>
 static void wide_launch(dim3 grid, hipStream_t st, const MbArgs& a) {
-    if (g_la_mb_dw) k_gemm_wide<RBV, TW, EPI, 0, 4><<<grid, 512, WideGeom<RBV, TW>::LDS, st>>>(a);
-    else k_gemm_wide<RBV, TW, EPI, 0, 8><<<grid, 512, WideGeom<RBV, TW>::LDS, st>>>(a);
+    // schedule (k_gemm_wide SCH): buffer-addressed pieces everywhere; a fragment read after every MFMA where a wave has >= 3 token tiles
+    // (6+ MFMAs per half stage to cover a read; with 1-2 tiles the reads-together form covers them better).  Mistral bs=8 9.88-9.97 ->
+    // 9.70-9.72 ms, 13B bs=4 10.68-10.73 -> 10.59-10.63 ms per step (profiles/r04_wide_gemm_schedule.txt); la_lab_set(24, 0) = schedule 0
+    constexpr int SCH = TW >= 3 ? 3 : 2;
+    if (g_la_mb_sch) k_gemm_wide<RBV, TW, EPI, 0, SCH><<<grid, 512, WideGeom<RBV, TW>::LDS, st>>>(a);
+    else k_gemm_wide<RBV, TW, EPI, 0, 0><<<grid, 512, WideGeom<RBV, TW>::LDS, st>>>(a);
 }
 template <typename K> static hipError_t set_lds(K k, int bytes) {
     return hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1791,25 +1870,25 @@ int lk_mb_init() {
     if (e == hipSuccess) e = set_lds(k_gemm_wide<8, T, MB_SWIGLU>, WideGeom<8, T>::LDS); \
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_SWIGLU>, WideGeom<4, T>::LDS); \
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_LOGITS>, WideGeom<4, T>::LDS); \
-    if (e == hipSuccess) e = set_lds(k_gemm_wide<8, T, MB_SWIGLU, 0, 4>, WideGeom<8, T>::LDS); \
-    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_SWIGLU, 0, 4>, WideGeom<4, T>::LDS); \
-    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_LOGITS, 0, 4>, WideGeom<4, T>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<8, T, MB_SWIGLU, 0, (T >= 3 ? 3 : 2)>, WideGeom<8, T>::LDS); \
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_SWIGLU, 0, (T >= 3 ? 3 : 2)>, WideGeom<4, T>::LDS); \
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_LOGITS, 0, (T >= 3 ? 3 : 2)>, WideGeom<4, T>::LDS);
 #define SETW2(T) \
     if (e == hipSuccess) e = set_lds(k_gemm_wide<2, T, MB_SLAB>, WideGeom<2, T>::LDS); \
     if (e == hipSuccess) e = set_lds(k_gemm_wide<2, T, MB_QKV>, WideGeom<2, T>::LDS); \
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_SLAB>, WideGeom<4, T>::LDS); \
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_QKV>, WideGeom<4, T>::LDS); \
-    if (e == hipSuccess) e = set_lds(k_gemm_wide<2, T, MB_SLAB, 0, 4>, WideGeom<2, T>::LDS); \
-    if (e == hipSuccess) e = set_lds(k_gemm_wide<2, T, MB_QKV, 0, 4>, WideGeom<2, T>::LDS); \
-    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_SLAB, 0, 4>, WideGeom<4, T>::LDS); \
-    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_QKV, 0, 4>, WideGeom<4, T>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<2, T, MB_SLAB, 0, (T >= 3 ? 3 : 2)>, WideGeom<2, T>::LDS); \
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<2, T, MB_QKV, 0, (T >= 3 ? 3 : 2)>, WideGeom<2, T>::LDS); \
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_SLAB, 0, (T >= 3 ? 3 : 2)>, WideGeom<4, T>::LDS); \
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_QKV, 0, (T >= 3 ? 3 : 2)>, WideGeom<4, T>::LDS);
     SETW4(2) SETW4(3) SETW4(4) SETW2(1) SETW2(2)
 #undef SETW4
 #undef SETW2
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 2, MB_SLAB, 4>, WideGeom<4, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 2, MB_QKV, 4>, WideGeom<4, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<8, 2, MB_QKV>, WideGeom<8, 2>::LDS);
-    if (e == hipSuccess) e = set_lds(k_gemm_wide<8, 2, MB_QKV, 0, 4>, WideGeom<8, 2>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<8, 2, MB_QKV, 0, 2>, WideGeom<8, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 1>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 2>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 3>, WideGeom<4, 4>::LDS);

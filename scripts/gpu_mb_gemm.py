@@ -49,16 +49,16 @@ def main():
     wd = [gu.pack_weight(bf(torch.randn(K, F, generator=g, device=DEV) * 0.05)) for _ in range(NBUF)]
     act = torch.zeros(8 * 64 * F, dtype=torch.bfloat16, device=DEV)
     slabs = torch.zeros(4 * 512 * K, dtype=torch.float32, device=DEV)
-    for nblk in (() if mode == 'parts' else (4, 8)):
+    for nblk in (() if mode in ('parts', 'onceparts') else (4, 8)):
         x = bf(torch.randn(nblk * 64, K, generator=g, device=DEV))
         xp = torch.cat([gu.pack_x(x[b * 64:(b + 1) * 64].contiguous()) for b in range(nblk)])
         a = bf(torch.randn(nblk * 64, F, generator=g, device=DEV))
         ap = torch.cat([gu.pack_x(a[b * 64:(b + 1) * 64].contiguous()) for b in range(nblk)])
         z = None
-        for narrow, wmode, dw in ((1, 0, 0), (0, 0, 0), (0, 0, 1)):
+        for narrow, wmode, dw in ((0, 0, 0), (0, 0, 2), (0, 0, 3)):
             check(lib.la_lab_set(3, narrow), 'debug_set')
             check(lib.la_lab_set(5, wmode), 'debug_set')
-            check(lib.la_lab_set(24, dw), 'debug_set')          # 1 = four loader waves
+            check(lib.la_lab_set(24, dw), 'debug_set')          # schedule: 2 = buffer-addressed pieces, 3 = + a fragment read after every MFMA
 
             def gateup(i):
                 check(lib.la_mb_gemm(sp(), 1, ptr(wps[i % NBUF]), ptr(xp), F, K, nblk, NWG, 1, ptr(z), 0, ptr(act), ptr(z), ptr(z), ptr(z),
@@ -73,11 +73,11 @@ def main():
                     torch.cuda.synchronize()
                     continue
                 us, med = bench(fn)
-                print(f'{name:8s} rows {nblk * 64:4d} {"k_gemm_mb  " if narrow else "wide, 4 loaders" if dw else "k_gemm_wide" if not wmode else "wide, KS=2  "} min {us:8.2f} us  median {med:8.2f} us  {flops / us / 1e6:7.1f} TFLOP/s', flush=True)
+                print(f'{name:8s} rows {nblk * 64:4d} {"k_gemm_mb  " if narrow else f"wide, sched {dw}   " if dw else "k_gemm_wide" if not wmode else "wide, KS=2  "} min {us:8.2f} us  median {med:8.2f} us  {flops / us / 1e6:7.1f} TFLOP/s', flush=True)
     check(lib.la_lab_set(3, 0), 'debug_set')
     check(lib.la_lab_set(5, 0), 'debug_set')
     check(lib.la_lab_set(24, 0), 'debug_set')
-    if mode == 'parts':
+    if mode in ('parts', 'onceparts'):
         # what bounds a stage of the wide kernel: the same launch without MFMAs (1), without the in-loop DMA (2), DMA + barriers only (3)
         nblk = 8
         x = bf(torch.randn(nblk * 64, K, generator=g, device=DEV))
@@ -89,6 +89,10 @@ def main():
             def gateup(i):
                 check(lib.la_mb_gemm(sp(), 1, ptr(wps[i % NBUF]), ptr(xp), F, K, nblk, NWG, 1, ptr(z), 0, ptr(act), ptr(z), ptr(z), ptr(z),
                                      ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), 0, 0), 'mb_gemm')
+            if mode == 'onceparts':           # one launch per build, for counter collection (dispatch order = dbg 0, 1, 2, 3, 4, 5, 0)
+                gateup(0)
+                torch.cuda.synchronize()
+                continue
             us, med = bench(gateup)
             print(f'gate/up 512 rows wide, dbg {dbg}: min {us:8.2f} us  median {med:8.2f} us', flush=True)
         check(lib.la_lab_set(4, 0), 'debug_set')
