@@ -21,6 +21,7 @@
 enum { MB_SLAB = 0, MB_SWIGLU = 1, MB_QKV = 2, MB_LOGITS = 3 };
 
 extern int g_la_ex_split;       // la_debug_set key 16 (la_engine.cpp)
+extern long long* g_la_dbg_times;
 struct MbArgs {
     const bf16_t* wp;
     const bf16_t* xp;
@@ -50,6 +51,7 @@ struct MbArgs {
     // paired form of the wide kernel (launch_mb): the weight rows of a workgroup are read by a second workgroup working on the other
     // token blocks (same XCD): stream them with the default cache policy so that the second reader finds them in L2
     int w_keep;
+    long long* dbg_times;    // measurement build DBG = 6: [workgroup][wave][8] accumulated shader cycles per loop segment
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -394,12 +396,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7ffffff0, 0x00020000);
 }
 
-template <int RBV, int TW> struct WideGeom {
+template <int RBV, int TW, int NRG = 4> struct WideGeom {
     static constexpr int KS = 2, RG = RBV / 2, TQ = 8 / RG, NTBP = TQ * TW;  // token blocks (32 rows) per workgroup
     // RBV = 8: the paired gate/up launch — two adjacent planned regions {G0,G1,U0,U1} x 2 per workgroup, 4 row groups x 2 token groups
     static constexpr int A_STAGE = KS * RBV, B_STAGE = KS * NTBP;           // 1 KiB pieces per stage
     static constexpr int STAGE = A_STAGE + B_STAGE;
-    static constexpr int NR = 4;                                              // ring slots (stages)
+    static constexpr int NR = NRG;                                            // ring slots (stages): NR - 1 stages in flight ahead of the one consumed
     static constexpr int NP_HI = (STAGE + 7) / 8, NP_LO = STAGE / 8;          // pieces per wave and stage
     static constexpr int N_HI = STAGE - 8 * NP_LO;                            // waves 0..N_HI-1 carry NP_HI pieces
     static constexpr int H = (NP_HI + 1) / 2;                                 // pieces issued in the first half of a stage
@@ -415,12 +417,13 @@ template <int RBV, int TW> struct WideGeom {
 // and no VALU per piece instead of ~9 SALU + a 64-bit VALU add.  Same MFMAs on the same operands in the same order: bit-identical.
 // (Measured and dropped: four loader waves — one per SIMD — issuing all pieces of a stage: 5-12 % SLOWER,
 // profiles/r04_wide_gemm_schedule.txt: a wave's own issue chain is the cost, not the queueing of the eight waves.)
-template <int RBV, int TW, int EPI, int DBG = 0, int SCH = 0>
+template <int RBV, int TW, int EPI, int DBG = 0, int SCH = 0, int NRG = 4>
 __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
-    using GEO = WideGeom<RBV, TW>;
+    using GEO = WideGeom<RBV, TW, NRG>;
+    static_assert(NRG == 4 || NRG == 3, "ring depth");
     constexpr int KS = GEO::KS, TQ = GEO::TQ, NTBP = GEO::NTBP, A_STAGE = GEO::A_STAGE, STAGE = GEO::STAGE, NR = GEO::NR;
     constexpr int NP_HI = GEO::NP_HI, NP_LO = GEO::NP_LO, N_HI = GEO::N_HI;
-    static_assert(SCH == 0 || ((SCH == 2 || SCH == 3) && (DBG == 0 || DBG == 4)), "measurement builds 1, 2, 3, 5 exist for schedule 0 only");
+    static_assert(SCH == 0 || ((SCH == 2 || SCH == 3) && (DBG == 0 || DBG == 4 || DBG == 6)), "measurement builds 1, 2, 3, 5 exist for schedule 0 only");
     constexpr bool BUF = (SCH & 2) != 0;            // pieces addressed through buffer resources
     constexpr bool ILV = (SCH & 1) != 0;            // one fragment read after each MFMA
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -546,8 +549,9 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
     };
 
     constexpr int H = GEO::H;
-    issue(0); issue(1); issue(2);
-    if (hi) vm_wait<2 * NP_HI>(); else vm_wait<2 * NP_LO>();
+#pragma unroll
+    for (int i = 0; i < NR - 1; ++i) issue(i);
+    if (hi) vm_wait<(NR - 2) * NP_HI>(); else vm_wait<(NR - 2) * NP_LO>();
     __builtin_amdgcn_s_barrier();
     bf16x8 fa0[2], fb0[TW], fa1[2], fb1[TW];
     read_frags(0, 0, fa0, fb0);
@@ -556,38 +560,56 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
         constexpr int NG1 = NMMA > H ? (NMMA > NRD ? NMMA : NRD) : (H > NRD ? H : NRD);
         constexpr int H2 = NP_HI - H;
         constexpr int NG2 = NMMA > H2 ? (NMMA > NRD ? NMMA : NRD) : (H2 > NRD ? H2 : NRD);
+        // DBG = 6: shader cycles per wave summed over the stages: [0] first half incl. the wait for its reads, [1] wait for the own DMA
+        // pieces, [2] barrier, [3] second half incl. the wait for its reads (each s_memtime costs its own round trip: read proportions)
+        // (Measured with this build, profiles/r04_wide_gemm_schedule.txt part 4: issue arbitration between the two waves of a SIMD — w and
+        // w + 4 — is oldest-first: waves 0..3 run a stage in ~940 cycles and wait ~470 at the barrier for waves 4..7.  s_setprio schedules
+        // that make the two classes take turns remove the barrier wait and lengthen both halves by as much: the SIMD's combined issue
+        // stream, not the sharing, sets the stage time.  Not kept.)
+        unsigned long long tacc[4] = {0ull, 0ull, 0ull, 0ull}, tprev = 0ull;
+        if constexpr (DBG == 6) tprev = __builtin_readcyclecounter();
         for (int s = 0; s < nst; ++s) {
             const bool full = (t0 + s * KS + 1) < t1;   // an odd K range ends on half a stage (workgroup-uniform)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // set0 (read during the previous half) is complete
+            if constexpr (DBG == 6) { const unsigned long long t = __builtin_readcyclecounter(); if (s > 0) tacc[3] += t - tprev; tprev = t; }
             __builtin_amdgcn_sched_barrier(0);
             // first half: MFMA of set0 | one fragment read of set1 (stage s, k-tile 1) | one DMA piece of stage s+3, group after group
 #pragma unroll
             for (int m = 0; m < NG1; ++m) {
                 if (m < NMMA) mma(m / TW, m % TW, fa0, fb0);
                 if (m < NRD) read_one(s, 1, m, fa1, fb1);
-                if (m < H) issue_one(s + 3, m);
+                if (m < H) issue_one(s + NR - 1, m);
                 __builtin_amdgcn_sched_barrier(0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // every read of stage s is complete
-            if (hi) vm_wait<NP_HI + H>(); else vm_wait<NP_LO + H>();   // own pieces of stage s+1 landed
+            if constexpr (DBG == 6) { const unsigned long long t = __builtin_readcyclecounter(); tacc[0] += t - tprev; tprev = t; __builtin_amdgcn_sched_barrier(0); }
+            if (hi) vm_wait<(NR - 3) * NP_HI + H>(); else vm_wait<(NR - 3) * NP_LO + H>();   // own pieces of stage s+1 landed
+            if constexpr (DBG == 6) { const unsigned long long t = __builtin_readcyclecounter(); tacc[1] += t - tprev; tprev = t; __builtin_amdgcn_sched_barrier(0); }
             __builtin_amdgcn_s_barrier();                                // stage s+1 complete for everyone; the slot of stage s is free
+            if constexpr (DBG == 6) { const unsigned long long t = __builtin_readcyclecounter(); tacc[2] += t - tprev; tprev = t; }
             __builtin_amdgcn_sched_barrier(0);
             // second half: MFMA of set1 | one fragment read of set0 (stage s+1, k-tile 0) | the remaining pieces of stage s+3
             if (full) {
 #pragma unroll
                 for (int m = 0; m < NG2; ++m) {
-                    if (m < NMMA) mma(m / TW, m % TW, fa1, fb1);
+                        if (m < NMMA) mma(m / TW, m % TW, fa1, fb1);
                     if (m < NRD) read_one(s + 1, 0, m, fa0, fb0);
-                    if (m < H2) issue_one(s + 3, H + m);
+                    if (m < H2) issue_one(s + NR - 1, H + m);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
 #pragma unroll
                 for (int m = 0; m < (NRD > H2 ? NRD : H2); ++m) {
                     if (m < NRD) read_one(s + 1, 0, m, fa0, fb0);
-                    if (m < H2) issue_one(s + 3, H + m);
+                    if (m < H2) issue_one(s + NR - 1, H + m);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (DBG == 6) {
+            if (a.dbg_times && lane == 0) {
+                long long* o = a.dbg_times + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 8 + wave) * 8;
+                o[0] = (long long)tacc[0]; o[1] = (long long)tacc[1]; o[2] = (long long)tacc[2]; o[3] = (long long)tacc[3]; o[4] = nst;
             }
         }
     } else {
@@ -600,12 +622,12 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
 #pragma unroll
         for (int m = 0; m < (NMMA > H ? NMMA : H); ++m) {
             if (m < NMMA) mma(m / TW, m % TW, fa0, fb0);
-            if constexpr (DBG != 2 && DBG != 5) { if (m < H) issue_one(s + 3, m); }
+            if constexpr (DBG != 2 && DBG != 5) { if (m < H) issue_one(s + NR - 1, m); }
         }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // every read of stage s is complete
         // own pieces of stage s+1 landed: younger are all of stage s+2 and the H pieces of s+3
-        if constexpr (DBG != 2 && DBG != 5) { if (hi) vm_wait<NP_HI + H>(); else vm_wait<NP_LO + H>(); }
+        if constexpr (DBG != 2 && DBG != 5) { if (hi) vm_wait<(NR - 3) * NP_HI + H>(); else vm_wait<(NR - 3) * NP_LO + H>(); }
         else vm_wait<0>();
         if constexpr (DBG != 5) __builtin_amdgcn_s_barrier();               // stage s+1 complete for everyone; the slot of stage s is free
         if constexpr (DBG != 3) read_frags(s + 1, 0, fa0, fb0);
@@ -615,12 +637,12 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
 #pragma unroll
             for (int m = 0; m < (NMMA > NP_HI - H ? NMMA : NP_HI - H); ++m) {
                 if (m < NMMA) mma(m / TW, m % TW, fa1, fb1);
-                if constexpr (DBG != 2 && DBG != 5) { if (m < NP_HI - H) issue_one(s + 3, H + m); }
+                if constexpr (DBG != 2 && DBG != 5) { if (m < NP_HI - H) issue_one(s + NR - 1, H + m); }
             }
         } else {
             if constexpr (DBG != 2 && DBG != 5) {
 #pragma unroll
-                for (int m = H; m < NP_HI; ++m) issue_one(s + 3, m);
+                for (int m = H; m < NP_HI; ++m) issue_one(s + NR - 1, m);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1835,7 +1857,7 @@ static bool g_mb_attr = false;
 int g_la_mb_attn_rot = 0;     // la_lab_set key 21: 1 = the query heads of a kv head start their key-tile lists at different offsets (GQA models; measured neutral at Mistral bs=8 / Mixtral bs=4, profiles/r04_batch_ab2.txt: off)
 int g_la_mb_attn_vring = 0;   // la_lab_set key 20: 1 = multi-block attention with the next tile's V in flight through a per-wave LDS ring (measured 0.5-5 % SLOWER per step, profiles/r04_mb_attention_vring_ab.txt), 0 = V requested per tile (default)
 int g_la_mb_dbg = 0;
-int g_la_mb_mode = 0;         // la_debug_set key 5: 1 = wide kernel as two co-resident workgroups per CU (80 KiB LDS, 256 rows each)
+int g_la_mb_mode = 0;         // la_lab_set key 5: unused (was: the wide gate/up launch as two co-resident 256-row workgroups per CU on a 3-slot ring — four waves per SIMD; measured 7 % slower at 512 rows, profiles/r04_wide_gemm_schedule.txt part 5)
 int g_la_mb_pair = 1;         // la_debug_set key 6, bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
 int g_la_mb_ks2 = 0;          // la_debug_set key 12: slab GEMMs of the multi-block step with 2 K splits at >= 5 blocks (measurement)
 int g_la_mb_narrow = 0;       // la_debug_set key 3: 1 = the K-split kernels (k_gemm_mb) for every nblk (A/B measurements)
@@ -1894,6 +1916,7 @@ int lk_mb_init() {
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 3>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 4>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 5>, WideGeom<4, 4>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 6, 3>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_tree_attn_mb<false, true>, 8 * 66 * 64 * 4 + 16384);
     if (e == hipSuccess) e = set_lds(k_tree_attn_mb<false, false>, 8 * 66 * 64 * 4 + 16384);
     if (e == hipSuccess) e = set_lds(k_tree_attn_mb<true, true>, 8 * 66 * 64 * 4 + 16384);
@@ -1999,6 +2022,11 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
     if (nblk >= 3 && !g_la_mb_narrow) {
         const dim3 grid(n_wg, ksplit, 1);
         if constexpr (RBV == 4 && EPI == MB_SWIGLU) {           // measurement builds of the 512-row gate/up launch (la_debug_set key 4)
+            if (g_la_mb_dbg == 6 && nblk >= 7) {
+                MbArgs p = a; p.dbg_times = g_la_dbg_times;
+                k_gemm_wide<4, 4, MB_SWIGLU, 6, 3><<<grid, 512, WideGeom<4, 4>::LDS, st>>>(p);
+                LAUNCH_CHECK(); return 0;
+            }
             if (g_la_mb_dbg && nblk >= 7) {
                 if (g_la_mb_dbg == 1) k_gemm_wide<4, 4, MB_SWIGLU, 1><<<grid, 512, WideGeom<4, 4>::LDS, st>>>(a);
                 else if (g_la_mb_dbg == 2) k_gemm_wide<4, 4, MB_SWIGLU, 2><<<grid, 512, WideGeom<4, 4>::LDS, st>>>(a);

@@ -55,10 +55,10 @@ def main():
         a = bf(torch.randn(nblk * 64, F, generator=g, device=DEV))
         ap = torch.cat([gu.pack_x(a[b * 64:(b + 1) * 64].contiguous()) for b in range(nblk)])
         z = None
-        for narrow, wmode, dw in ((0, 0, 0), (0, 0, 2), (0, 0, 3)):
+        for narrow, wmode, dw in ((1, 0, 1), (0, 0, 1), (0, 0, 0)):
             check(lib.la_lab_set(3, narrow), 'debug_set')
             check(lib.la_lab_set(5, wmode), 'debug_set')
-            check(lib.la_lab_set(24, dw), 'debug_set')          # schedule: 2 = buffer-addressed pieces, 3 = + a fragment read after every MFMA
+            check(lib.la_lab_set(24, dw), 'debug_set')          # 1 = round-4 schedule (default), 0 = round-2 schedule
 
             def gateup(i):
                 check(lib.la_mb_gemm(sp(), 1, ptr(wps[i % NBUF]), ptr(xp), F, K, nblk, NWG, 1, ptr(z), 0, ptr(act), ptr(z), ptr(z), ptr(z),
@@ -73,10 +73,10 @@ def main():
                     torch.cuda.synchronize()
                     continue
                 us, med = bench(fn)
-                print(f'{name:8s} rows {nblk * 64:4d} {"k_gemm_mb  " if narrow else f"wide, sched {dw}   " if dw else "k_gemm_wide" if not wmode else "wide, KS=2  "} min {us:8.2f} us  median {med:8.2f} us  {flops / us / 1e6:7.1f} TFLOP/s', flush=True)
+                print(f'{name:8s} rows {nblk * 64:4d} {"k_gemm_mb  " if narrow else "wide, 2 WGs / CU " if wmode else "wide (default)   " if dw else "wide, schedule 0 "} min {us:8.2f} us  median {med:8.2f} us  {flops / us / 1e6:7.1f} TFLOP/s', flush=True)
     check(lib.la_lab_set(3, 0), 'debug_set')
     check(lib.la_lab_set(5, 0), 'debug_set')
-    check(lib.la_lab_set(24, 0), 'debug_set')
+    check(lib.la_lab_set(24, 1), 'debug_set')
     if mode in ('parts', 'onceparts'):
         # what bounds a stage of the wide kernel: the same launch without MFMAs (1), without the in-loop DMA (2), DMA + barriers only (3)
         nblk = 8
