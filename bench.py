@@ -646,11 +646,20 @@ def main():
         hbm_frac = step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS
         mfma_frac = step_flops / (ms_step * 1e-3) / 1e12 / 2500.0
         bound = 'mfma' if mfma_frac >= hbm_frac else 'hbm'
+        traffic, traffic_src = None, None
+        try:        # HBM bytes of one steady verify step of this configuration from the committed PMC passes (scripts/gpu_prof_secondary.sh)
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_secondary.json')))
+            if not args.layers and not wide:
+                traffic = pmc['configs']['%s_b%d' % (args.model, B)]['hbm_bytes_per_step']
+                traffic_src = pmc['source']
+        except Exception:
+            pass
         roofline = {
             'bound': bound, 'kernel': 'whole multi-block verify step (k_gemm_wide / k_gemm_mb + k_tree_attn_mb), M = %d rows' % (64 * B * RB_),
             'achieved': round(step_flops / (ms_step * 1e-3) / 1e12, 1) if bound == 'mfma' else round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
             'peak': 2500.0 if bound == 'mfma' else HBM_PEAK_GBS, 'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
-            'frac': round(max(mfma_frac, hbm_frac), 4), 'traffic': None,
+            'frac': round(max(mfma_frac, hbm_frac), 4), 'traffic': traffic, 'traffic_source': traffic_src,
+            'traffic_note': 'HBM bytes of ONE verify step (FETCH_SIZE / WRITE_SIZE passes, all kernels from one k_build_inputs_mb to the next)',
             'hbm': {'algorithmic_bytes': step_bytes, 'achieved_GBps': round(step_bytes / (ms_step * 1e-3) / 1e9, 1), 'frac': round(hbm_frac, 4)},
             'mfma': {'flops': step_flops, 'achieved_TFLOPs': round(step_flops / (ms_step * 1e-3) / 1e12, 1), 'frac': round(mfma_frac, 4)},
         }
