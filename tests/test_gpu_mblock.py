@@ -389,6 +389,67 @@ def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
         lib.la_lab_set(6, default_form)
 
 
+@pytest.mark.parametrize('nblk', [3, 4, 6, 8])
+def test_mb_wide_schedules_are_bitwise_identical(nblk):
+    """la_lab_set key 24: the round-4 schedule of k_gemm_wide (buffer-addressed LDS-DMA pieces; one fragment read after every MFMA at
+    >= 3 token tiles per wave) runs the same MFMAs on the same operands in the same order as the round-2 schedule: slabs, Q / K / V
+    fragments and SwiGLU activations must be equal bit for bit — classic and planned images, odd K ranges (half stages), K splits."""
+    rc, rs_ = rope_tables(128, 1024, 10000.0, DEV)
+    default_sched = lib.la_lab_get(24)
+    assert default_sched == 1
+    try:
+        for N, K, ks in ((4096, 1376, 4), (512, 2048, 1), (5120, 528, 3)):        # 1376 / 4 and 528 / 3 k-tiles: odd ranges
+            g = torch.Generator(device=DEV).manual_seed(N + nblk)
+            x = bf(torch.randn(nblk * 64, K, generator=g, device=DEV))
+            wp = gu.pack_weight(bf(torch.randn(N, K, generator=g, device=DEV) * 0.05))
+            rows = (nblk + 3) // 4 * 4 * 64
+            outs = []
+            for sch in (0, 1):
+                check(lib.la_lab_set(24, sch), 'lab_set')
+                slabs = torch.full((ks, rows, N), float('nan'), dtype=torch.float32, device=DEV)
+                _mb(0, wp, _pack_blocks(x), N, K, nblk, ksplit=ks, slabs=slabs, slab_rows=rows)
+                outs.append(slabs[:, :nblk * 64].clone())
+            assert torch.equal(outs[0], outs[1]), (N, K, ks)
+            assert bool(torch.isfinite(outs[0]).all())
+        for nh, nkv, nwg in ((32, 32, 256), (32, 8, 256), (8, 2, 32), (2, 2, 0)):
+            K = 528
+            N = (nh + 2 * nkv) * 128
+            g = torch.Generator(device=DEV).manual_seed(nh * 7 + nkv + nblk)
+            x = bf(torch.randn(nblk * 64, K, generator=g, device=DEV))
+            w = bf(torch.randn(N, K, generator=g, device=DEV) * 0.05)
+            pos = torch.randint(0, 900, (nblk * 64,), generator=g, device=DEV, dtype=torch.int32)
+            if nwg:
+                wp = gu.pack_planned(2, [w], nwg)
+            else:
+                perm = np.zeros(N, dtype=np.int32)
+                check(lib.la_qkv_row_perm(nh, nkv, perm.ctypes.data_as(_lib.pi32)), 'perm')
+                wp = gu.pack_weight(w[torch.from_numpy(perm.astype(np.int64)).to(DEV)].contiguous())
+            outs = []
+            for sch in (0, 1):
+                check(lib.la_lab_set(24, sch), 'lab_set')
+                qf = torch.zeros(8 * nh * 8192, dtype=torch.bfloat16, device=DEV)
+                kf = torch.zeros(8 * nkv * 8192, dtype=torch.bfloat16, device=DEV)
+                vf = torch.zeros(8 * nkv * 8192, dtype=torch.bfloat16, device=DEV)
+                _mb(2, wp, _pack_blocks(x), N, K, nblk, n_wg=nwg, pos=pos, rc=rc, rs_=rs_, qf=qf, kf=kf, vf=vf, nh=nh, nkv=nkv)
+                outs.append((qf, kf, vf))
+            for a_, b_ in zip(outs[0], outs[1]):
+                assert torch.equal(a_, b_), (nh, nkv, nwg)
+        for F, K in ((11008, 528), (14336, 256)):
+            g = torch.Generator(device=DEV).manual_seed(F + nblk)
+            x = bf(torch.randn(nblk * 64, K, generator=g, device=DEV))
+            wp = gu.pack_planned(1, [bf(torch.randn(F, K, generator=g, device=DEV) * 0.05), bf(torch.randn(F, K, generator=g, device=DEV) * 0.05)], 256)
+            outs = []
+            for sch in (0, 1):
+                check(lib.la_lab_set(24, sch), 'lab_set')
+                act = torch.zeros(8 * 64 * F, dtype=torch.bfloat16, device=DEV)
+                _mb(1, wp, _pack_blocks(x), F, K, nblk, n_wg=256, act=act)
+                outs.append(act)
+            assert torch.equal(outs[0], outs[1]), (F, K)
+            assert float(outs[0][:nblk * 64 * F].float().abs().sum()) > 0
+    finally:
+        lib.la_lab_set(24, default_sched)
+
+
 def _random_wide_tree(rs, T, chain_len):
     """T rows (parent index < row index), multiword ancestor masks uint64[T][ceil(T/64)].  Rows 0, 3, 6, ... form one long chain
     (so that it crosses the 64-row block boundaries); every other row hangs below a random earlier row."""
