@@ -322,7 +322,10 @@ def main():
     assert 1 <= B <= 8
     BL, DL = args.branch_length, args.decoding_length
     wide = DL > 64                       # trees wider than one 64-row block: the tree is 2-4 chained blocks of one multi-block pass (eng.tstep)
-    assert 1 <= DL <= 256 and 1 <= BL <= 39 and (not wide or B == 1), 'wide trees: --batch 1, decoding_length <= 256, branch_length <= 39'
+    assert 1 <= DL <= 256 and 1 <= BL <= 39, 'decoding_length <= 256, branch_length <= 39'
+    # wide trees in a batch: every sequence's tree is ceil(DL / 64) blocks of the pass (eng.mstep_trees), all of them within the 8-block pass
+    assert not wide or B == 1 or (B * ((DL + 63) // 64) <= 8 and not args.device_trie and world == 1), \
+        'wide trees with --batch B: B x ceil(decoding_length / 64) <= 8 blocks, host trie, one GPU'
     n_truth = (K + W + 56) * (BL + 1) + 8          # measured steps + native-loop leg (16 steps) + fixed-tree sweep (24 steps) + slack
     max_length = P + n_truth + 2 * DL
     # Mistral (config 2): the checkpoint's sliding window (4096, HF Mistral-7B-v0.1 config.json) with the KV cache as a ring of
@@ -331,7 +334,7 @@ def main():
         shape.sliding_window = 4096
     kv_ring = bool(getattr(shape, 'sliding_window', 0)) and B > 1
     if kv_ring:
-        max_length = max(max_length, shape.sliding_window + 64 * B + 64)
+        max_length = max(max_length, shape.sliding_window + 64 * B * ((DL + 63) // 64) + 64)
     want_cpu = not args.no_cpu_baseline and world == 1 and B == 1      # the CPU leg is timed on rank 0 at N=1 only
     tdtype = torch.float16 if args.dtype == 'fp16' else torch.bfloat16
     sd = random_weights(shape, seed=0, device=dev, decisive=not args.pure_random, dtype=tdtype)
@@ -342,7 +345,7 @@ def main():
                                  fuse=args.fuse, attn_split=args.attn_split, max_blocks=8, gemm_cfg=gemm_cfg)
     else:
         model = BatchLlama(shape, sd, device=dev, max_length=max_length, max_batch=B, eos_token_id=None, consume_state_dict=True,
-                           attn_split=args.attn_split, max_blocks=B, kv_ring=kv_ring, gemm_cfg=gemm_cfg)
+                           attn_split=args.attn_split, max_blocks=B * ((DL + 63) // 64), kv_ring=kv_ring, gemm_cfg=gemm_cfg)
     del sd
     eng = model.engine
     NSEQ = world * B
@@ -492,7 +495,10 @@ def main():
             if pending[0]:
                 gather.finish_into_trie(cache, BL)
                 pending[0] = False
-            toks_all = eng.mstep([(i, dr[i][0], dr[i][1], 0, 16) for i in range(B)])
+            if wide:
+                toks_all = eng.mstep_trees([(i, dr[i][0], dr[i][1], 0, 40) for i in range(B)])
+            else:
+                toks_all = eng.mstep([(i, dr[i][0], dr[i][1], 0, 16) for i in range(B)])
         for i in range(B):
             seqs[i].extend(toks_all[i])
             dls.append(len(dr[i][0])); edls.append(len(toks_all[i]))

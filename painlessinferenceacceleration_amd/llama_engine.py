@@ -686,6 +686,69 @@ class LlamaVerifyEngine(object):
             self.n_keys = self.slot_keys[0]
         return o[_lib.LA_MOUT_OUTTOK:_lib.LA_MOUT_OUTTOK + int(o[_lib.LA_MOUT_NOUT])].tolist(), self.slot_keys[slot] - before
 
+    def mstep_trees(self, trees, eager=False):
+        """Several sequences' draft trees in ONE pass, each tree of up to LA_TREE_WIDE_MAX rows (a batch whose per-sample budget
+        exceeds a 64-row block: the reference's bat_get hands every sample (decoding_length // bs) // bs rows, any size,
+        lookahead_cache.py:534-541).  trees: list of (slot, ids int32[T], rowmask uint64[T] or uint64[T][W], mode 0 / 2, limit):
+        a tree occupies ceil(T / 64) consecutive blocks of the pass (block 0 in `mode`, the others LA_MODE_TREE_PIECE), one tree
+        per slot, all blocks together <= max_blocks.  -> list of emitted token lists (tree order)."""
+        a = self._min_np
+        b0s, slots, b = [], set(), 0
+        for slot, ids, rowmask, mode, limit in trees:
+            ids = np.ascontiguousarray(ids, dtype=np.int32)
+            T = len(ids)
+            rm = np.asarray(rowmask, dtype=np.uint64)
+            if rm.ndim == 1:
+                rm = rm[:, None]
+            nb = (T + 63) // 64
+            assert 1 <= T <= _lib.LA_TREE_WIDE_MAX and nb <= 4, f'a tree holds 1..{_lib.LA_TREE_WIDE_MAX} rows (got {T})'
+            assert 0 <= slot < self.n_slots and slot not in slots and mode in (0, 2), 'one tree per slot, mode 0 or 2'
+            assert self.slot_keys[slot] + T <= self._capacity(), 'KV cache capacity of the slot exceeded'
+            slots.add(slot)
+            lim = max(1, min(_lib.LA_MOUT_TOKS, int(limit)))
+            b0s.append((b, slot))
+            for p_ in range(nb):
+                r0, r1 = 64 * p_, min(T, 64 * p_ + 64)
+                n = r1 - r0
+                a[_lib.LA_MIN_BLK + 4 * b:_lib.LA_MIN_BLK + 4 * b + 4] = (slot, n, mode if p_ == 0 else _lib.LA_MODE_TREE_PIECE, lim)
+                a[_lib.LA_MIN_IDS + 64 * b:_lib.LA_MIN_IDS + 64 * b + n] = ids[r0:r1]
+                self._min_rm[64 * b:64 * b + n] = rm[r0:r1, p_] if p_ < rm.shape[1] else 0
+                for q in range(p_):
+                    self._min_xm[64 * b:64 * b + n, q] = rm[r0:r1, q] if q < rm.shape[1] else 0
+                b += 1
+        assert self.max_blocks and 1 <= b <= self.max_blocks, f'{b} blocks in one pass need an engine created with max_blocks >= {b}'
+        a[_lib.LA_MIN_NBLK] = b
+        self._mstep_slots = []
+        for (b0, slot), (_, ids, _, _, _) in zip(b0s, trees):
+            self._mstep_slots.extend([slot] * ((len(ids) + 63) // 64))
+        fn = self._lib.la_llama_mstep_eager if eager else self._lib.la_llama_mstep
+        check(fn(self._h, self._sp(), self.host_min.data_ptr(), self.host_mout.data_ptr()), 'llama_mstep')
+        self.stream.synchronize()
+        o = self._mout_np
+        for slot in slots:
+            self.slot_keys[slot] = int(o[_lib.LA_MOUT_NKEYS + slot])
+        if 0 in slots:
+            self.n_keys = self.slot_keys[0]
+        return [o[_lib.LA_MOUT_OUTTOK + _lib.LA_MOUT_TOKS * b0:_lib.LA_MOUT_OUTTOK + _lib.LA_MOUT_TOKS * b0 + int(o[_lib.LA_MOUT_NOUT + b0])].tolist()
+                for b0, _ in b0s]
+
+    def mcommit_trees(self, kept, n_rows):
+        """After mstep_trees(mode 2): kept[i] = the tree rows of tree i to keep (root first, path order), n_rows[i] = its row count
+        — the host-walked sequential accept path for several (possibly wide) trees of one pass (la_llama_mcommit)."""
+        nbs = [(int(n) + 63) // 64 for n in n_rows]
+        keep = np.full(64 * sum(nbs), -1, dtype=np.int32)
+        b0 = 0
+        for rows, nb in zip(kept, nbs):
+            for k, r in enumerate(rows):
+                keep[64 * b0 + int(r)] = k
+            b0 += nb
+        check(self._lib.la_llama_mcommit(self._h, self._sp(), sum(nbs), keep.ctypes.data_as(_lib.pi32), self.host_mout.data_ptr()),
+              'llama_mcommit')
+        for slot in set(self._mstep_slots):
+            self.slot_keys[slot] = int(self._mout_np[_lib.LA_MOUT_NKEYS + slot])
+        if 0 in self._mstep_slots:
+            self.n_keys = self.slot_keys[0]
+
     def tcommit(self, rows, n_rows):
         """After tstep(mode=2) over an n_rows-row tree: keep the tree rows `rows` (root first, path order) — the host-walked
         sequential accept path on a wide tree (la_llama_mcommit over the tree's blocks)."""

@@ -44,14 +44,28 @@ class LookaheadPreTrainedModel(object):
         if decoding_mode in ('hier', 'par', 'one'):
             decoding_mode = decoding_mode + '_mix'
         fmt, mode = decoding_mode.split('_')
+        # trees wider than a 64-row block (<= LA_TREE_WIDE_MAX rows = up to 4 blocks of the pass) come from the host trie's hier walk;
+        # the device trie and the one-branch walk keep the 64-row cap
+        wide_ok = fmt == 'hier' and not decoding_kwargs.get('device_trie', False) and bool(getattr(self.engine, 'max_blocks', 0))
+        cap_rows = _lib.LA_TREE_WIDE_MAX if wide_ok else _lib.LA_TREE_MAX
         if decoding_kwargs.get('per_sample_budget', False):
             # every sample gets a decoding_length-token tree (bat_get divides its argument by the batch size once)
-            sub = min(decoding_length, _lib.LA_TREE_MAX) * len(qids)
+            sub = min(decoding_length, cap_rows) * len(qids)
         else:
             sub = max(decoding_length // len(qids), 1)                 # pretrained_model_batch.py:713
-            sub = min(sub, _lib.LA_TREE_MAX * len(qids))               # a sample's tree never exceeds the 64 rows of a block
+            sub = min(sub, cap_rows * len(qids))                       # a sample's tree never exceeds the rows one pass can give it
         ts = time.time()
-        if decoding_kwargs.get('device_trie', False) and fmt == 'one':
+        per_wide = min(sub // len(qids), _lib.LA_TREE_WIDE_MAX)
+        if per_wide > _lib.LA_TREE_MAX and fmt == 'hier' and not decoding_kwargs.get('device_trie', False):
+            # a per-sample budget wider than a 64-row block: bat_get's own rule sample by sample (lookahead_cache.py:534-541:
+            # hier_get(decoding_length = budget, min_input_size = 0, min_output_size = max(budget // 2, 1))), multi-word row masks
+            drafts = []
+            for q_, i_ in zip(qids, batch_indices):
+                ids_, rm_, _, sizes_ = self.lookahead_cache.hier_get_packed(q_, decoding_length=per_wide, branch_length=branch_length,
+                                                                          min_input_size=0, min_output_size=max(per_wide // 2, 1),
+                                                                          mode=mode, idx=i_)
+                drafts.append((np.array(ids_, dtype=np.int32), np.array(rm_, dtype=np.uint64), list(sizes_)))
+        elif decoding_kwargs.get('device_trie', False) and fmt == 'one':
             # one greedy chain per sample from one launch (la_trie_one_get_dev2); budget rule of bat_get (:534-541)
             per = sub // len(qids)
             got = self._device_trie(decoding_kwargs['_n_samples']).one_get(
@@ -157,7 +171,7 @@ class LookaheadPreTrainedModel(object):
         eng = self.engine
         assert bs <= eng.n_slots, f'batch of {bs} needs an engine with n_slots >= {bs} (has {eng.n_slots})'
         cap = eng._capacity() if hasattr(eng, '_capacity') else eng.max_keys
-        assert stop_max_length + 64 + 1 <= cap, f'engine KV capacity {cap} per slot is too small'
+        assert stop_max_length + min(max(int(decoding_length), 64), _lib.LA_TREE_WIDE_MAX) + 1 <= cap, f'engine KV capacity {cap} per slot is too small'
         for i in range(bs):                                                     # :1204-1207 (pads included, as there)
             self.lookahead_cache.put(ids0[i, 1:-1].tolist(), branch_length=branch_length + 1, mode='input', idx=i)
         rows = [ids0[i].tolist() for i in range(bs)]      # padded-coordinate token rows; cursor = len(row) - 1
@@ -294,7 +308,7 @@ class LookaheadPreTrainedModel(object):
                     d_ids, d_rm = np.asarray(rows[b][-1:], dtype=np.int32), _ONE
                 cur = len(rows[b]) - 1
                 segments.append((b, d_ids, d_rm, 2 if sequential else 0, stop_max_length - cur - 1))
-            if sum(len(sg[1]) for sg in segments) <= _lib.LA_TREE_MAX:
+            if sum(len(sg[1]) for sg in segments) <= _lib.LA_TREE_MAX and all(np.ndim(sg[2]) == 1 for sg in segments):
                 emitted = eng.bstep(segments)                          # the whole batch shares one 64-row block
                 if sequential:
                     base, logits = eng.bstep_rows(), eng.logits()
@@ -305,16 +319,31 @@ class LookaheadPreTrainedModel(object):
             else:
                 assert multi, 'more than 64 draft rows per step need an engine created with max_blocks > 1'
                 emitted = {}
-                for g0 in range(0, len(segments), eng.max_blocks):     # one 64-row block per sample, max_blocks per pass
-                    group = segments[g0:g0 + eng.max_blocks]
-                    out = eng.mstep(group)
+                # ceil(T / 64) blocks per sample (1 for the usual 64-row trees), as many samples per pass as max_blocks holds
+                groups, cur_g, cur_b = [], [], 0
+                for sg in segments:
+                    nb_ = (len(sg[1]) + 63) // 64
+                    assert nb_ <= eng.max_blocks, f'a {len(sg[1])}-row tree needs an engine created with max_blocks >= {nb_}'
+                    if cur_b + nb_ > eng.max_blocks:
+                        groups.append(cur_g)
+                        cur_g, cur_b = [], 0
+                    cur_g.append(sg)
+                    cur_b += nb_
+                groups.append(cur_g)
+                for group in groups:
+                    wide_pass = any(len(sg[1]) > 64 or np.ndim(sg[2]) == 2 for sg in group)
+                    out = eng.mstep_trees(group) if wide_pass else eng.mstep(group)
                     if sequential:
-                        logits, kept = eng.mlogits(), []
-                        for k, sg in enumerate(group):
-                            toks, keep_rows = self._sequential_walk(rows[sg[0]], sg, logits, 64 * k, pick)
+                        logits, kept, base = eng.mlogits(), [], 0
+                        for sg in group:
+                            toks, keep_rows = self._sequential_walk(rows[sg[0]], sg, logits, base, pick)
                             emitted[sg[0]] = toks
                             kept.append(keep_rows)
-                        eng.mcommit(kept)
+                            base += 64 * ((len(sg[1]) + 63) // 64)
+                        if wide_pass:
+                            eng.mcommit_trees(kept, [len(sg[1]) for sg in group])
+                        else:
+                            eng.mcommit(kept)
                         continue
                     for sg, toks in zip(group, out):
                         emitted[sg[0]] = toks
@@ -349,8 +378,15 @@ class LookaheadPreTrainedModel(object):
         _, d_ids, d_rm, _, limit = segment
         T = len(d_ids)
         parent = [-1] * T
+        wide = np.ndim(d_rm) == 2
         for j in range(1, T):
-            below = int(d_rm[j]) & ((1 << j) - 1)
+            if wide:                                   # multi-word row mask: word w = tree columns 64 w .. 64 w + 63
+                full = 0
+                for w in range(d_rm.shape[1]):
+                    full |= int(d_rm[j][w]) << (64 * w)
+            else:
+                full = int(d_rm[j])
+            below = full & ((1 << j) - 1)
             parent[j] = below.bit_length() - 1
         limit = max(1, min(int(limit), 32))
         cur, kept, toks = 0, [0], []

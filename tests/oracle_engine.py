@@ -112,8 +112,10 @@ class OracleBatchEngine(object):
             self.past[slot] = None
             self.slot_keys[slot] = 0
 
-    def _segment(self, slot, ids, rowmask, mode, limit):
+    def _segment(self, slot, ids, rowmask, mode, limit, tok_cap=16):
         T, nk = len(ids), self.slot_keys[slot]
+        if np.ndim(rowmask) == 2:              # multi-word row masks of a wide tree: word w = tree columns 64 w .. 64 w + 63
+            rowmask = [sum(int(rowmask[i][w]) << (64 * w) for w in range(len(rowmask[i]))) for i in range(T)]
         tree = np.array([[(int(rowmask[i]) >> j) & 1 for j in range(T)] for i in range(T)], dtype=np.int64)
         full = torch.cat([torch.ones((T, nk), dtype=torch.long), torch.from_numpy(tree)], 1)
         logits, past = self.model.forward(torch.tensor([int(x) for x in ids]), full, self.past[slot])
@@ -124,7 +126,7 @@ class OracleBatchEngine(object):
         if mode == 1:
             toks, rows = [am[-1]], list(range(T))
         else:
-            toks, rows = lo.accept_scan_limited([int(x) for x in ids], tree, am, max(1, min(16, int(limit))))
+            toks, rows = lo.accept_scan_limited([int(x) for x in ids], tree, am, max(1, min(tok_cap, int(limit))))
         self._keep(slot, past, rows)
         return toks, logits
 
@@ -175,6 +177,22 @@ class OracleBatchEngine(object):
             lgs.append(torch.cat([lg, torch.zeros((64 - lg.shape[0], lg.shape[1]), dtype=lg.dtype)], 0))
         self._mlogits = torch.cat(lgs, 0)
         return out
+
+    def mstep_trees(self, trees, eager=False):
+        """several sequences' trees of up to 256 rows, ceil(T / 64) blocks each, one pass (LlamaVerifyEngine.mstep_trees)"""
+        assert self.max_blocks and sum((len(t[1]) + 63) // 64 for t in trees) <= self.max_blocks
+        out, self._pending, lgs, self._mslots = [], {}, [], [t[0] for t in trees]
+        for slot, ids, rowmask, mode, limit in trees:
+            toks, lg = self._segment(slot, ids, rowmask, mode, limit, tok_cap=40)
+            out.append(toks)
+            pad = (-lg.shape[0]) % 64
+            lgs.append(torch.cat([lg, torch.zeros((pad, lg.shape[1]), dtype=lg.dtype)], 0))
+        self._mlogits = torch.cat(lgs, 0)
+        return out
+
+    def mcommit_trees(self, kept, n_rows):
+        for slot, rows in zip(self._mslots, kept):
+            self._keep(slot, self._pending[slot], rows)
 
     def mlogits(self):
         return self._mlogits

@@ -273,6 +273,43 @@ def test_batch_lookahead_equals_per_sample_greedy_decisive():
     assert g2[:, P:P + 40].tolist() == [x[:40] for x in greedy]
 
 
+@pytest.mark.parametrize('sequential', [False, True])
+def test_batch_lookahead_with_wide_per_sample_trees_equals_greedy(sequential):
+    """Per-sample trees wider than a 64-row block in a batch (the reference's bat_get gives a sample (decoding_length // bs) // bs
+    rows of any size, lookahead_cache.py:534-541; its best published setting is decoding_length=128, README.md:100): drafts from
+    the host trie's hier walk with multi-word row masks, every sample's tree as ceil(T / 64) blocks of one multi-block pass
+    (LlamaVerifyEngine.mstep_trees).  Decisive weights: the output equals plain greedy decoding, the second request (run on the
+    trie the first one grew) drafts trees of more than 64 rows, and the accept lengths exceed what a 64-row tree gives at
+    branch_length 40.  sequential: the same through a processor list (forward-only pass, host walk, la_llama_mcommit)."""
+    shape = tiny_shape()
+    sd = random_weights(shape, seed=2, device='cpu', decisive=True)
+    B, P, n_new = 3, 40, 150
+    model = BatchLlama(shape, dict(sd), max_length=512, max_batch=B, eos_token_id=None, max_blocks=6)
+    rs = np.random.RandomState(23)
+    ids = rs.randint(3, shape.vocab, size=(B, P)).astype(np.int64)
+    truth = model.greedy_search(torch.from_numpy(ids), P + n_new, eos_token_id=None)[:, P:].tolist()
+    model.lookahead_cache = LookaheadCache(eos_ids=[])
+    procs = None
+    if sequential:
+        from transformers import LogitsProcessorList, MinLengthLogitsProcessor
+        procs = LogitsProcessorList([MinLengthLogitsProcessor(1, eos_token_id=1, device=str(DEV))])      # a no-op list: takes the sequential path
+    dk = {'use_lookahead': True, 'decoding_length': 128, 'branch_length': 40, 'stop_words': {}, 'per_sample_budget': True}
+    from tests.tiny_model import noisy_copies
+    for b in range(B):                  # bench.py's warm-up: noisy copies of the continuation -> many branches below every prefix
+        for c in noisy_copies(ids[b, -2:].tolist() + truth[b], 10, 0.3, shape.vocab, seed=70 + b):
+            model.lookahead_cache.put(c, branch_length=41, mode='output', idx=-1)
+    widths = []
+    for rep in range(2):
+        out = model.lookahead_generation(torch.from_numpy(ids), stopping_criteria=P + n_new, eos_token_id=[None], pad_token_id=0,
+                                         return_dict_in_generate=True, decoding_kwargs=dict(dk), logits_processor=procs)
+        got = out.sequences.cpu().numpy()
+        for b in range(B):
+            assert got[b, P:P + n_new].tolist() == truth[b][:n_new], (rep, b)
+        widths.append(max(out.kwargs['dls']))
+    assert max(widths) > 64, widths                    # trees wider than a block were drafted and verified
+    assert np.mean(out.kwargs['edls'][B:]) > 8.0, np.mean(out.kwargs['edls'][B:])
+
+
 def test_forward_only_batch_steps_and_host_commit_equal_device_accept():
     """mode 2 (forward only) + la_llama_bcommit / la_llama_mcommit with an identity walk (argmax, no processors) must leave
     exactly the state the device accept scan leaves: same emitted tokens, same cursors, and bitwise the same logits on the

@@ -530,6 +530,74 @@ def test_wide_tree_step_matches_oracle(T, chain_len):
         tok = exp_toks[-1]
 
 
+@pytest.mark.parametrize('Ts', [(100, 150), (65, 64, 130), (256, 200)])
+def test_several_wide_trees_in_one_pass_match_oracle(Ts):
+    """A batch whose per-sample trees are wider than a block (bat_get gives every sample (decoding_length // bs) // bs rows, any
+    size: lookahead_cache.py:534-541): LlamaVerifyEngine.mstep_trees packs several sequences' trees — ceil(T / 64) consecutive
+    blocks each, mode 0 + LA_MODE_TREE_PIECE — into ONE pass.  Per sequence: logits of every tree row vs the oracle forward under
+    that sequence's own past and full mask, the cross-block accept walk / emitted tokens / commit plan bit-exact given the device's
+    argmax rows, cursors; a second step on top of what the first one committed."""
+    shape = tiny_shape()
+    sd = _bf16_sd(9)
+    n = len(Ts)
+    nblk = sum((T + 63) // 64 for T in Ts)
+    eng = LlamaVerifyEngine(shape, sd, max_length=768, n_slots=n, max_blocks=nblk)
+    oracle = lo.OracleLlama(shape, sd)
+    rs = np.random.RandomState(sum(Ts))
+    pasts, nks, toks0 = [], [], []
+    for i in range(n):
+        prompt = rs.randint(3, shape.vocab, size=7 + 3 * i).tolist()
+        toks0.append(eng.mprefill(i, prompt))
+        pasts.append(_oracle_seq(oracle, prompt)[1])
+        nks.append(len(prompt))
+    for step in range(2):
+        trees, meta = [], []
+        for i, T in enumerate(Ts):
+            parent, chain, rm, mask = _random_wide_tree(rs, T, min(30, T // 3))
+            ids = np.concatenate([[toks0[i]], rs.randint(3, shape.vocab, size=T - 1)]).astype(np.int32)
+            trees.append([i, ids, rm, 0, _lib.LA_MOUT_TOKS])
+            meta.append((chain, mask))
+        # make every tree's long chain the device's own greedy continuation (forward-only passes of the whole batch, nothing committed)
+        for k in range(max(len(m[0]) for m in meta) - 1):
+            eng.mstep_trees([(t[0], t[1], t[2], 2, t[4]) for t in trees])
+            mo = eng.mout().cpu().numpy()
+            b0 = 0
+            for t, (chain, _) in zip(trees, meta):
+                if k + 1 < len(chain):
+                    t[1][chain[k + 1]] = int(mo[_lib.LA_MOUT_ARGMAX + 64 * b0 + chain[k]])
+                b0 += (len(t[1]) + 63) // 64
+        assert [eng.slot_keys[i] for i in range(n)] == nks
+        out = eng.mstep_trees([tuple(t) for t in trees], eager=(step == 1))
+        got_all = eng.mlogits()
+        mo = eng.mout().cpu().numpy()
+        b0 = 0
+        for i, (t, (chain, mask)) in enumerate(zip(trees, meta)):
+            ids, T = t[1], len(t[1])
+            nb = (T + 63) // 64
+            full = torch.cat([torch.ones((T, nks[i]), dtype=torch.long), torch.from_numpy(mask)], 1)
+            lg, past_all = oracle.forward(torch.tensor(ids.tolist()), full, pasts[i])
+            gf, rf = got_all[64 * b0:64 * b0 + T].float().cpu(), lg.float()
+            rel = ((gf - rf).abs().amax(-1) / rf.abs().amax(-1)).numpy()
+            assert rel.max() <= 4e-2 and rel.mean() <= 1.5e-2, (Ts, i, step, float(rel.max()), float(rel.mean()))
+            am = [int(mo[_lib.LA_MOUT_ARGMAX + 64 * b0 + r]) for r in range(T)]
+            assert am == gf.argmax(-1).tolist()
+            exp_toks, exp_rows = lo.accept_scan(ids.tolist(), mask, am)
+            exp_toks, exp_rows = exp_toks[:_lib.LA_MOUT_TOKS], exp_rows[:_lib.LA_MOUT_TOKS]
+            assert out[i] == exp_toks, (Ts, i, step, len(out[i]), len(exp_toks))
+            if step == 0 and T > 64:
+                assert len(exp_rows) > 8
+            want = np.full(64 * nb, -1, dtype=np.int64)
+            for d, r in enumerate(exp_rows):
+                want[r] = i * eng._capacity() + nks[i] + d             # main-cache key rows are slot-major
+            assert mo[_lib.LA_MOUT_DST + 64 * b0:_lib.LA_MOUT_DST + 64 * (b0 + nb)].tolist() == want.tolist(), (Ts, i, step)
+            idx = torch.tensor(list(range(nks[i])) + [nks[i] + r for r in exp_rows], dtype=torch.long)
+            pasts[i] = [(k[:, idx], v[:, idx]) for k, v in past_all]
+            nks[i] += len(exp_rows)
+            assert eng.slot_keys[i] == nks[i]
+            toks0[i] = exp_toks[-1]
+            b0 += nb
+
+
 def test_wide_tree_host_commit_equals_device_commit():
     """Sequential accept path on a wide tree (logits processors / sampling: tstep(mode=2) = forward only, the host walks the
     tree over the logits rows, tcommit(rows) moves the kept K/V rows of all the tree's blocks, la_llama_mcommit): keeping the

@@ -118,6 +118,28 @@ def test_batch_loop_reproduces_reference_batch_run():
     gre = m.greedy_search(ids, ids.shape[1] + 20, attention_mask=am, eos_token_id=2)
     assert gre[:, :ids.shape[1] + 20].tolist() == [r[:ids.shape[1] + 20] for r in g['b4w256_r0_sequences'].tolist()]
 
+    # round 4: with a multi-block engine the budget is NOT clamped (a sample's tree may span up to 4 blocks of the pass,
+    # mstep_trees), and the same two cases reproduce the reference run exactly — sequences, dls, edls, request after request
+    class BModel4(BatchMixin):
+        def __init__(self):
+            self.engine = OracleBatchEngine(tiny_shape(), tiny_weights(0), max_length=256, n_slots=4, max_blocks=4)
+            self.generation_config = SimpleNamespace(eos_token_id=2, pad_token_id=0, return_dict_in_generate=False)
+            self.lookahead_cache = LookaheadCache()
+
+    for name in ('b3pad128', 'b4w256'):
+        bs, dl, max_new = [int(x) for x in g[f'{name}_cfg']]
+        ids, am = torch.from_numpy(g[f'{name}_ids']), torch.from_numpy(g[f'{name}_am'])
+        m = BModel4()
+        for r in range(2):
+            dk = dict(DK); dk['decoding_length'] = dl
+            with warnings.catch_warnings():
+                warnings.simplefilter('error')                 # no clamp warning on this path
+                out = m.lookahead_generation(ids, stopping_criteria=ids.shape[1] + max_new, eos_token_id=2, pad_token_id=0,
+                                             return_dict_in_generate=True, attention_mask=am, decoding_kwargs=dk)
+            assert out.sequences.tolist() == g[f'{name}_r{r}_sequences'].tolist(), (name, r)
+            assert out.kwargs['dls'] == g[f'{name}_r{r}_dls'].tolist(), (name, r)
+            assert out.kwargs['edls'] == g[f'{name}_r{r}_edls'].tolist(), (name, r)
+
 
 def test_batch_loop_sequential_processor_path_reproduces_reference():
     """Batch loop with RepetitionPenaltyLogitsProcessor(1.3) — the sequential accept path (forward-only step, host walk with
@@ -204,6 +226,50 @@ def test_batch_sequential_path_with_identity_processor_equals_default_path():
         seq0 = outs[0][0][0][0]
         assert eos in seq0[P:P + 12] and len([t for t in seq0[P:] if t != 0]) <= 12 + 13
     assert Identity.calls > 50
+
+
+@pytest.mark.parametrize('sequential', [False, True])
+def test_batch_loop_with_wide_per_sample_trees_equals_greedy(sequential):
+    """Per-sample budgets wider than a 64-row block (bat_get's rule gives a sample (decoding_length // bs) // bs rows of any size,
+    lookahead_cache.py:534-541): the drafts come from the host trie's hier walk with multi-word row masks, the step packs every
+    sample's tree as ceil(T / 64) blocks of one pass (mstep_trees) and groups the samples by the engine's block budget.  On the
+    oracle engine: the output equals plain greedy decoding, trees of more than 64 rows are drafted, and the reference's own
+    budget rule (no per_sample_budget) reaches the same path at decoding_length = 65 bs^2."""
+    from painlessinferenceacceleration_amd.pretrained_model_batch import LookaheadPreTrainedModel as BatchMixin
+    from tests.oracle_engine import OracleBatchEngine
+    from tests.tiny_model import noisy_copies, tiny_decisive_weights
+
+    class BModel(BatchMixin):
+        def __init__(self, max_blocks):
+            self.engine = OracleBatchEngine(tiny_shape(), tiny_decisive_weights(0, torch.float32), max_length=256, n_slots=2, max_blocks=max_blocks)
+            self.generation_config = type('G', (), {'pad_token_id': 0, 'eos_token_id': None, 'return_dict_in_generate': True})()
+            self.lookahead_cache = LookaheadCache(eos_ids=[])
+
+    shape = tiny_shape()
+    rs = np.random.RandomState(5)
+    B, P, n_new = 2, 12, 70
+    ids = rs.randint(3, shape.vocab, size=(B, P)).astype(np.int64)
+    m = BModel(4)
+    truth = m.greedy_search(torch.from_numpy(ids), P + n_new, eos_token_id=None)[:, P:].tolist()
+    procs = None
+    if sequential:
+        from transformers import LogitsProcessorList, MinLengthLogitsProcessor
+        procs = LogitsProcessorList([MinLengthLogitsProcessor(1, eos_token_id=1)])
+    for dk in ({'use_lookahead': True, 'decoding_length': 100, 'branch_length': 30, 'stop_words': {}, 'per_sample_budget': True},
+               {'use_lookahead': True, 'decoding_length': 100 * B * B, 'branch_length': 30, 'stop_words': {}}):
+        m = BModel(4)
+        for b in range(B):              # bench.py's warm-up: noisy copies of the continuation -> many branches below every prefix
+            for c in noisy_copies(ids[b, -2:].tolist() + truth[b], 10, 0.3, shape.vocab, seed=70 + b):
+                m.lookahead_cache.put(c, branch_length=31, mode='output', idx=-1)
+        widths = []
+        for rep in range(2):
+            out = m.lookahead_generation(torch.from_numpy(ids), stopping_criteria=P + n_new, eos_token_id=[None], pad_token_id=0,
+                                         return_dict_in_generate=True, decoding_kwargs=dict(dk), logits_processor=procs)
+            got = out.sequences.cpu().numpy()
+            for b in range(B):
+                assert got[b, P:P + n_new].tolist() == truth[b][:n_new], (rep, b)
+            widths.append(max(out.kwargs['dls']))
+        assert max(widths) > 64, widths
 
 
 def test_benchmark_harness_perf_check_and_trie_loop(capsys):
