@@ -47,7 +47,7 @@ class LookaheadPreTrainedModel(object):
         # trees wider than a 64-row block (<= LA_TREE_WIDE_MAX rows = up to 4 blocks of the pass) come from the host trie's hier walk;
         # the device trie and the one-branch walk keep the 64-row cap
         wide_ok = fmt == 'hier' and not decoding_kwargs.get('device_trie', False) and bool(getattr(self.engine, 'max_blocks', 0))
-        cap_rows = _lib.LA_TREE_WIDE_MAX if wide_ok else _lib.LA_TREE_MAX
+        cap_rows = min(_lib.LA_TREE_WIDE_MAX, 64 * int(self.engine.max_blocks)) if wide_ok else _lib.LA_TREE_MAX      # a tree fits one pass
         if decoding_kwargs.get('per_sample_budget', False):
             # every sample gets a decoding_length-token tree (bat_get divides its argument by the batch size once)
             sub = min(decoding_length, cap_rows) * len(qids)
