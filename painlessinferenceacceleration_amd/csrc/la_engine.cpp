@@ -490,6 +490,14 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
         if (m->fuse & 1) {
             FusedNorm fg{m->slabs, m->o_ks, m->h, L.norm2, c.hidden, c.rms_eps, cf, m->fuse_cnt + 2 * l + 1, (m->fuse & 16) ? 1 : 0};
             P(KC_GATEUP);
+            if ((m->fuse & 4) && (m->down_rb & 0xff) == 2) {
+                // bits 0 + 2: norm -> gate/up + SwiGLU -> down_proj as ONE launch (k_gateup_down<.., NSF = 4>): the MLP half of the layer
+                // with two in-launch hand-overs instead of two kernel boundaries
+                KCHK(lk_gateup_down(st, L.wgateup, m->xp, c.ffn, c.hidden, c.balanced_wg[1], m->act_xp, L.wdown, c.hidden, m->down_ks,
+                                    m->slabs, m->fuse_cnt + 2 * c.n_layers + l, (m->fuse & 8) ? 8 : 4, &fg));
+                P(KC_OTHER);
+                goto after_down;
+            }
             KCHK(lk_gemm64r_swiglu(st, L.wgateup, m->xp, c.ffn, c.hidden, c.balanced_wg[1], m->act_xp, nullptr, &fg));
         } else {
             pd = PfDesc{};

@@ -54,7 +54,7 @@ int lk_resid_norm4(hipStream_t st, void* h, const float* slabs, int n_slabs, con
 int lk_step_tail(hipStream_t st, const float* cv, const int* ci, int n_tiles, const int* ids, const uint64_t* rowmask, int* state,
                  int* host_out);
 int lk_gateup_down(hipStream_t st, const void* wgu, const void* xp, int F, int K, int n_wg, void* act_xp, const void* wdown, int N,
-                   int ksplit, float* slabs, int* counter, int dd);
+                   int ksplit, float* slabs, int* counter, int dd, const FusedNorm* fn = nullptr);
 int lk_rowplan(int kind, int n_rows, int n_wg, int* out);
 long lk_planned_elems(int kind, int n_rows, int K, int n_wg);
 int lk_pack_planned(hipStream_t st, const void* w, const void* w2, const int* d_plan, int kind, int n_rows, int K, int n_wg, void* out);

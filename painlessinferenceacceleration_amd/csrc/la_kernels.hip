@@ -1132,14 +1132,18 @@ __global__ __launch_bounds__(NW * 64) void k_gemm64r(const bf16_t* __restrict__ 
 // pair.  Deadlock-free as long as workgroups are dispatched in block-id order (the down role only ever waits on LOWER ids;
 // the spin is bounded and traps).  Same arithmetic in the same order as the two launches: bitwise identical results.
 // ---------------------------------------------------------------------------------------------
-template <int RBD, int DD>
+// NSF = 4 (round 4, cfg.fuse bits 0 + 2 together): the post-attention RMSNorm runs inside the same launch as well — the first 64
+// gate/up workgroups first sum o_proj's split-K slabs, add the residual, normalise their row and publish it (FusedNorm) — so the
+// whole MLP half of a layer (norm -> gate/up + SwiGLU -> down_proj) is ONE launch with two in-launch hand-overs: the persistent-layer
+// prototype the round-3 review asked for, built from the kernels of the step (same arithmetic and order: bitwise identical).
+template <int RBD, int DD, int NSF = 0>
 __global__ __launch_bounds__(512) void k_gateup_down(const bf16_t* __restrict__ wp_s, const bf16_t* xp_s, int K16_s, int kfl, int wg_chunks_s,
                                                       unsigned nvl_pk, int boff0, int boff1, int boff2, int boff3, int n_gu,
                                                       GemmRArgs gu, GemmArgs dn, int dn_gx, int dn_gy, int* counter) {
     extern __shared__ __attribute__((aligned(16))) float lds_gd[];     // gate/up reduction [8][4][16][64] == down_proj reduction [8][RBD*2*16*64]
     if ((int)blockIdx.x < n_gu) {
         const BlockPos bp = {(int)blockIdx.x, 0, 0, n_gu, 1};
-        gemm64r_body<4, EPI_SWIGLU, 4, 8, 0>(wp_s, xp_s, nullptr, K16_s, kfl, wg_chunks_s, nvl_pk, boff0, boff1, boff2, boff3, gu, bp, lds_gd);
+        gemm64r_body<4, EPI_SWIGLU, 4, 8, NSF>(wp_s, xp_s, nullptr, K16_s, kfl, wg_chunks_s, nvl_pk, boff0, boff1, boff2, boff3, gu, bp, lds_gd);
         handover_signal(counter);
     } else {
         const int id = (int)blockIdx.x - n_gu;
@@ -2202,7 +2206,7 @@ int lk_gemm64r_qkv(hipStream_t st, const void* wp, const void* xp, int nh, int n
 // Role-fused gate/up -> down_proj launch (k_gateup_down): the balanced gate/up image over n_wg workgroups + the classic
 // down_proj image as N/64 row-groups x ksplit.  counter: a zeroed device int per launch and step.
 int lk_gateup_down(hipStream_t st, const void* wgu, const void* xp, int F, int K, int n_wg, void* act_xp, const void* wdown, int N,
-                   int ksplit, float* slabs, int* counter, int dd) {
+                   int ksplit, float* slabs, int* counter, int dd, const FusedNorm* fn) {
     GemmRArgs ra{}; ra.g.kskew = 0; ra.g.wp = (const bf16_t*)wgu; ra.g.xp = (const bf16_t*)xp; ra.g.K16 = K / 16; ra.g.N = F; ra.g.act_xp = (bf16_t*)act_xp;
     ra.R = F / n_wg; if (F % n_wg || ra.R > 64 || ra.R <= 32 || (N % 64) || (F % 16) || !counter) return -1;
     fill_nv(ra, ra.R, 2, 2);
@@ -2212,7 +2216,14 @@ int lk_gateup_down(hipStream_t st, const void* wgu, const void* xp, int F, int K
 #define GD(DD) k_gateup_down<2, DD><<<n_wg + n_dn, 512, 8 * 4 * 4096, st>>>(ra.g.wp, ra.g.xp, ra.g.K16, 0, ra.wg_chunks, \
         ((unsigned)ra.nvl[0] | ((unsigned)ra.nvl[1] << 8) | ((unsigned)ra.nvl[2] << 16) | ((unsigned)ra.nvl[3] << 24)), \
         ra.boff[0], ra.boff[1], ra.boff[2], ra.boff[3], n_wg, ra, d, gx, ksplit, counter)
-    if (dd == 8) GD(8); else GD(4);
+#define GDN(DD) k_gateup_down<2, DD, 4><<<n_wg + n_dn, 512, 8 * 4 * 4096, st>>>(ra.g.wp, ra.g.xp, ra.g.K16, 0, ra.wg_chunks, \
+        ((unsigned)ra.nvl[0] | ((unsigned)ra.nvl[1] << 8) | ((unsigned)ra.nvl[2] << 16) | ((unsigned)ra.nvl[3] << 24)), \
+        ra.boff[0], ra.boff[1], ra.boff[2], ra.boff[3], n_wg, ra, d, gx, ksplit, counter)
+    if (set_fused_norm(ra, fn, n_wg)) {
+        if (fn->n_slabs != 4) return -1;
+        if (dd == 8) GDN(8); else GDN(4);
+    } else if (dd == 8) GD(8); else GD(4);
+#undef GDN
 #undef GD
     LAUNCH_CHECK(); return 0;
 }
@@ -2231,6 +2242,8 @@ int lk_gemm64r_init() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gemm64r<4, EPI_SWIGLU, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 4 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gateup_down<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gateup_down<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gateup_down<2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_gateup_down<2, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 4 * 4096);
     if (e != hipSuccess) return (int)e;
     if (lk_attn1_init() != 0) return -1;
     g_attr_done = true;

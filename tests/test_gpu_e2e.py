@@ -326,7 +326,9 @@ def test_role_fused_gateup_down_launch_is_bitwise_identical():
     trees = [(random_tree(rs, 64)[1], rs.randint(3, 32000, size=64).astype(np.int32)) for _ in range(6)]
     # the down role runs the 8-wave slab kernel (4 or 8 tile-sets in flight): the two-launch reference is the engine with that
     # down_proj variant (gemm_cfg[4] = 2 | variant << 8), whose waves split K the same way — same summation order
-    for fuse, variant in ((4, 4), (12, 3)):
+    # 5 / 21 / 23 (round 4): bit 0 on top — the post-attention norm inside the same launch (k_gateup_down<.., NSF = 4>: norm -> gate/up ->
+    # down_proj = the MLP half of a layer as ONE launch), with the release-fence / write-through publish, and with the input norm in QKV
+    for fuse, variant in ((4, 4), (12, 3), (5, 4), (21, 4), (23, 4)):
         outs = []
         for f in (0, fuse):
             eng = LlamaVerifyEngine(shape, random_weights(shape, seed=4, std=0.02, device='cuda:0'), max_length=1024, fuse=f,
