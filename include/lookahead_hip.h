@@ -324,8 +324,10 @@ typedef struct la_llama_config {
     int32_t top_k;           /* experts per token (Mixtral: 2) */
     int32_t fuse;            /* in-kernel norm->GEMM fusion, opt-in (0 / -1 = off): bit 0 = post-attention norm into the
                                 gate/up launch, bit 1 = input norm of layers > 0 into the QKV launch; bits 2 / 3 = gate/up + down_proj
-                                as one role-fused launch; bit 4 (16) = the fused producers publish WRITE-THROUGH (sc1 stores + drained
-                                flag, no release fence).  Bitwise identical results; see DESIGN.md for the measurements */
+                                as one role-fused launch (bits 0 + 2 together: norm -> gate/up -> down_proj in ONE launch, with bit 1
+                                four launches per layer); bit 4 (16) = the fused producers publish WRITE-THROUGH (sc1 stores + drained
+                                flag, no release fence).  Bitwise identical results, all measured slower than the separate kernels
+                                 */
     int32_t sliding_window;  /* > 0: sliding-window attention over the committed keys (Mistral: 4096; visible iff
                                 pos_row - pos_key <= window, the transformers mask rule).  An EXTENSION: the reference's
                                 lookahead path feeds the full mask (mistral/modeling_mistral.py:979-983) */
