@@ -43,7 +43,9 @@ extern "C" {
  * key 22: K splits of the gathered experts' down GEMM (0 = the engine's choice).  key 23: 1 = the slab GEMMs of the single-sequence
  *         step publish their partial sums write-through (measured slower: 4.23 vs 3.68 ms per step), 0 = plain stores (default).
  * key 24: schedule of the wide multi-block GEMMs, 1 = buffer-addressed LDS-DMA pieces and (>= 3 token tiles per wave) a fragment read
- *         after every MFMA (default), 0 = 64-bit per-lane piece pointers and the six reads of a k-tile together; bit-identical. */
+ *         after every MFMA (default), 0 = 64-bit per-lane piece pointers and the six reads of a k-tile together; bit-identical. 
+ * key 25: merged-expert launches of the gathered MoE step as TWO workgroups per CU (4 instead of 8 weight tiles in flight per wave,
+ *         <= 128 VGPRs): bit 0 = gate/up (default on), bit 1 = down_proj. */
 int          la_lab_set(int key, int value);
 int          la_lab_get(int key);          /* current value of a knob (the library default unless la_lab_set changed it) */
 /* key 0: device buffer int64[workgroups][waves][8] the GEMM kernels stamp with wall_clock64() at entry / end of the

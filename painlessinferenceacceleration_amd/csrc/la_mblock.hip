@@ -173,13 +173,15 @@ __device__ __forceinline__ void mb_epilogue_block(const MbArgs& a, const f32x4* 
 //   order (deterministic) per 64-row block, then the same epilogues as the single-block kernels.
 // ---------------------------------------------------------------------------------------------------------------
 // body of k_gemm_mb for the NT / 2 blocks blk0 .. of a pass (nblk = the blocks that exist; operands offset for the merged-expert form)
-template <int RBV, int NT, int EPI>
+// D = weight tiles in flight per wave: 8 for the dense launches (one workgroup per CU); 4 for the merged-expert launches, whose
+// register footprint then admits TWO workgroups per CU (<= 128 VGPRs): the same 64 KiB of weights in flight per CU, and the ramp / drain
+// of one workgroup (x sets + first tiles; K-part reduction + epilogue: ~3 of its ~23 us) runs under the other one's stream.
+template <int RBV, int NT, int EPI, int D = 8>
 __device__ __forceinline__ void gemm_mb_body(const MbArgs& a, const int blk0, const int nblk, const size_t w_off, const size_t x_off,
                                              const size_t o_off) {
     constexpr int KP = 8 / RBV, KT = 4 / KP;
     constexpr int FR = 4 * NT;                  // x fragments (1 KiB) per stage
     constexpr int FPW = FR / 8;                 // fragments staged by one wave
-    constexpr int D = 8;                        // weight tiles in flight per wave
     constexpr int SPG = D / KT;                 // stages per unrolled group (weight ring slots are compile-time inside it)
     static_assert(FPW >= 1 && (FR % 8) == 0, "stage split");
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -245,7 +247,8 @@ __device__ __forceinline__ void gemm_mb_body(const MbArgs& a, const int blk0, co
         // every OLDER load: with the sets issued XD = D/KT stages before their ds_write, the loads younger than the awaited set
         // are XD-1 x sets and exactly D weight tiles — the weight ring stays D deep across every stage boundary (with a 1-stage
         // x prefetch each stage end drained the weight queue to KT tiles: 3x slower, profiles/r02_mblock_kernel_stats_v1.txt).
-        constexpr int XD = D / KT >= 4 ? 4 : D / KT;
+        // (D = 4 with one tile per stage and part — the two-per-CU down launch — prefetches 2 sets: 4 would put it past 128 VGPRs)
+        constexpr int XD = (D == 4 && KT == 1) ? 2 : (D / KT >= 4 ? 4 : D / KT);
         static_assert(SPG % XD == 0 && (SPG % 2) == 0, "static ring indices inside an unrolled group");
         bf16x8 fa[D];
         bf16x8 xr[XD][FPW];
@@ -326,8 +329,9 @@ __device__ __forceinline__ void gemm_mb_body(const MbArgs& a, const int blk0, co
     }
 }
 
-template <int RBV, int NT, int EPI, bool EX = false>
-__global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
+// DW = weight tiles in flight per wave (see gemm_mb_body): 4 = the two-workgroups-per-CU form of the merged-expert launches
+template <int RBV, int NT, int EPI, bool EX = false, int DW = 8>
+__global__ __launch_bounds__(512, (DW == 4 ? 4 : 1)) void k_gemm_mb(MbArgs a) {
     // EX: every expert of a gathered MoE stage in ONE launch (round 3; one launch per expert before — 16 launches per layer, each
     // with its own ramp and drain): grid.z = expert x pass, the operands of expert e sit e strides further, and the workgroups of
     // expert e + 1 start while the last ones of expert e finish.  The argument block stays untouched (a mutable copy of it cost
@@ -352,9 +356,9 @@ __global__ __launch_bounds__(512) void k_gemm_mb(MbArgs a) {
     if constexpr (EX && NT == 4) {
         // the LAST block of an expert alone in a two-block pass (about half the experts of a 256-row Mixtral step hold <= 64 rows):
         // the one-block body — half the x traffic, LDS stores and MFMAs of the padded pass
-        if (nblk - blk0 == 1 && !a.ex_pad) { gemm_mb_body<RBV, 2, EPI>(a, blk0, nblk, w_off, x_off, o_off); return; }
+        if (nblk - blk0 == 1 && !a.ex_pad) { gemm_mb_body<RBV, 2, EPI, DW>(a, blk0, nblk, w_off, x_off, o_off); return; }
     }
-    gemm_mb_body<RBV, NT, EPI>(a, blk0, nblk, w_off, x_off, o_off);
+    gemm_mb_body<RBV, NT, EPI, DW>(a, blk0, nblk, w_off, x_off, o_off);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1861,6 +1865,7 @@ int g_la_mb_mode = 0;         // la_lab_set key 5: unused (was: the wide gate/up
 int g_la_mb_pair = 1;         // la_debug_set key 6, bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
 int g_la_mb_ks2 = 0;          // la_debug_set key 12: slab GEMMs of the multi-block step with 2 K splits at >= 5 blocks (measurement)
 int g_la_mb_narrow = 0;       // la_debug_set key 3: 1 = the K-split kernels (k_gemm_mb) for every nblk (A/B measurements)
+int g_la_ex_d4 = 1;           // la_lab_set key 25: merged-expert launches as two workgroups per CU (bit 0 gate/up, bit 1 down)
 int g_la_mb_sch = 1;          // la_lab_set key 24: 1 = round-4 schedule of the wide GEMMs (default), 0 = the round-2 schedule (A/B reference)
 template <int RBV, int TW, int EPI>
 static void wide_launch(dim3 grid, hipStream_t st, const MbArgs& a) {
@@ -1888,6 +1893,8 @@ int lk_mb_init() {
 #undef SETALL
     if (e == hipSuccess) e = set_lds(k_gemm_mb<2, 4, MB_SLAB, true>, mb_lds(4));
     if (e == hipSuccess) e = set_lds(k_gemm_mb<4, 4, MB_SWIGLU, true>, mb_lds(4));
+    if (e == hipSuccess) e = set_lds(k_gemm_mb<2, 4, MB_SLAB, true, 4>, mb_lds(4));
+    if (e == hipSuccess) e = set_lds(k_gemm_mb<4, 4, MB_SWIGLU, true, 4>, mb_lds(4));
 #define SETW4(T) \
     if (e == hipSuccess) e = set_lds(k_gemm_wide<8, T, MB_SWIGLU>, WideGeom<8, T>::LDS); \
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, T, MB_SWIGLU>, WideGeom<4, T>::LDS); \
@@ -2011,7 +2018,10 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
         // past the expert's count returns before it touches the weights
         if constexpr (EPI == MB_SLAB || EPI == MB_SWIGLU) {
             if (a.ex_n > 1) {
-                k_gemm_mb<RBV, 4, EPI, true><<<dim3(n_wg, ksplit, (nblk + 1) / 2 * a.ex_n), 512, mb_lds(4), st>>>(a);
+                // two workgroups per CU (D = 4, <= 128 VGPRs): la_lab_set key 25 bit 0 = the gate/up launch (default on: Mixtral bs=4
+                // 21.0-21.5 -> 20.1-20.2 ms per step), bit 1 = the down launch (RBV = 2: 44 B per lane of scratch at that bound)
+                if (g_la_ex_d4 & (RBV == 4 ? 1 : 2)) k_gemm_mb<RBV, 4, EPI, true, 4><<<dim3(n_wg, ksplit, (nblk + 1) / 2 * a.ex_n), 512, mb_lds(4), st>>>(a);
+                else k_gemm_mb<RBV, 4, EPI, true><<<dim3(n_wg, ksplit, (nblk + 1) / 2 * a.ex_n), 512, mb_lds(4), st>>>(a);
                 LAUNCH_CHECK(); return 0;
             }
         }
