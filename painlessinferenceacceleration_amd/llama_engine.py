@@ -858,7 +858,9 @@ class LlamaVerifyEngine(object):
         p = _lib.DecodeParamsC()
         p.decoding_length, p.branch_length, p.max_query_length = int(decoding_length), int(branch_length), int(max_query_length)
         p.mode, p.idx, p.max_length = int(mode), int(idx), int(max_length)
-        eos_ids = [int(e) for e in eos_ids if e is not None][:8]
+        eos_ids = [int(e) for e in eos_ids if e is not None]
+        if len(eos_ids) > 8:
+            raise ValueError('decode_native: la_decode_params holds at most 8 eos ids (the interpreter loop has no such limit)')
         p.n_eos = len(eos_ids)
         for i, e in enumerate(eos_ids):
             p.eos[i] = e

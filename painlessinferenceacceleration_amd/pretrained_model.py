@@ -243,6 +243,7 @@ class LookaheadPreTrainedModel(object):
                        and not decoding_kwargs.get('device_trie', False)
                        and not decoding_kwargs.get('debug_lookahead', False) and decoding_kwargs.get('native_loop', True)
                        and 1 <= max_query_length <= 8          # la_lookahead_decode's query buffer; longer queries use this loop
+                       and len([e for e in (eos_token_id or []) if e is not None]) <= 8      # ... and its eos list (la_decode_params.eos[8])
                        and hasattr(eng, 'decode_native'))
 
         def pick(scores_ids, row):

@@ -98,6 +98,15 @@ def test_eos_and_max_length_stops():
     first = seq.index(eos, 40)
     assert first == 70 and len(seq) - first <= 13 and len(seq) < 160
     assert sum(out.kwargs['edls']) == len(seq) - 40
+    # (3) more eos ids than the native loop's parameter block holds (la_decode_params.eos[8]): the request takes the interpreter loop
+    # and still stops on the LAST id of the list (a silent truncation to 8 ids would run to max_length)
+    absent = [t for t in range(3, shape.vocab) if t not in gre][:9]
+    out = model.lookahead_generation(prompt, stopping_criteria=160, eos_token_id=absent + [eos], return_dict_in_generate=True,
+                                     decoding_kwargs=dict(dk))
+    seq = out.sequences[0].tolist()
+    assert seq == gre[:len(seq)] and seq.index(eos, 40) == 70 and len(seq) < 160
+    with pytest.raises(ValueError):
+        model.engine.decode_native(model.lookahead_cache, gre[:41], 160, eos_ids=absent + [eos])
 
 
 def test_streamer_and_stream_generate():
