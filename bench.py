@@ -69,6 +69,31 @@ def algorithmic_bytes(shape, T, ctx, logits_bytes):
     return W + kv_tok * ctx + kv_tok * T + T * (shape.hidden * 2 + 8) + logits_bytes
 
 
+HBM_ACHIEVABLE_GBS = 6290.0   # MI355X_MICROARCH.md: 6.29 TB/s measured (float4 copy), the rate a streaming kernel can reach
+
+
+def floor_model(shape, n_cus=256):
+    """DESIGN.md section 4 (round 4): what the launch-per-GEMM design of the 64-row step can reach.  Every GEMM launch obeys
+    T = fixed + W_bytes / stream + x_bytes_per_CU / l2_rate  (fixed ~3.5 us of pipeline fill + reduction / epilogue; weights stream from
+    HBM at ~6.4 TB/s chip-wide = 25 GB/s per CU; the activation operand every workgroup re-reads comes from its XCD's L2 at ~130 GB/s
+    per CU, and a CU's vector-memory path returns in order, so the two times ADD).  -> the terms, the GEMM floor of one step and the
+    fraction of the 8 TB/s roof a step made of these launches alone would reach (non-GEMM kernels at zero)."""
+    fixed_us, stream, l2 = 3.5, 6.4e12, 130e9
+    H, F, V, hd = shape.hidden, shape.ffn, shape.vocab, shape.head_dim
+    qkv_n = (shape.n_heads + 2 * shape.n_kv_heads) * hd
+    ks = max(1, n_cus // max(H // 64, 1))                 # K splits of the slab GEMMs: row-blocks x splits fit one wave of workgroups
+    launches = [('qkv', qkv_n * H * 2, 64 * H * 2), ('o_proj', H * shape.n_heads * hd * 2, 64 * shape.n_heads * hd * 2 // ks),
+                ('gate_up', 2 * F * H * 2, 64 * H * 2), ('down', H * F * 2, 64 * F * 2 // ks)]
+    per_layer = {n: fixed_us + 1e6 * w / stream + 1e6 * x / l2 for n, w, x in launches}
+    lm = fixed_us + 1e6 * V * H * 2 / stream + 1e6 * 64 * H * 2 / l2
+    n_exp = max(shape.n_experts, 1)
+    mlp = (per_layer['gate_up'] + per_layer['down']) * n_exp
+    gemm_us = shape.n_layers * (per_layer['qkv'] + per_layer['o_proj'] + mlp) + lm
+    return {'form': 'T_launch = fixed + W / stream + x_per_CU / l2', 'fixed_us': fixed_us, 'stream_TBps': stream / 1e12, 'l2_per_cu_GBps': l2 / 1e9,
+            'per_layer_us': {k: round(v, 2) for k, v in per_layer.items()}, 'lm_head_us': round(lm, 2),
+            'gemm_floor_ms_per_step': round(gemm_us / 1e3, 4)}
+
+
 def fixed_t64b8_tree():
     """SURVEY 8(d) "T64/B8": 63 draft nodes + root, 8 leaves all at depth 12 — a main chain of 12 plus 7 side branches forking
     after depth 9,8,6,4,3,2,1 with lengths 3,4,6,8,9,10,11 (DFS order: main chain, then the deepest fork first).
@@ -108,8 +133,8 @@ def host_batch_drafts(cache, tails, idxs, DL, BL, ubls):
 
 def _pf_setting():
     """(KiB per consumer workgroup, start delay, gate/up tail KiB) of the weight prefetch in effect (library default or LA_PF_KIB)."""
-    from painlessinferenceacceleration_amd._lib import lib
-    return int(lib.la_lab_get(7)), int(lib.la_lab_get(8)), int(lib.la_lab_get(9))
+    from painlessinferenceacceleration_amd._lib import lab_get
+    return lab_get(7), lab_get(8), lab_get(9)
 
 
 _RDZV_KEYS = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'GROUP_WORLD_SIZE', 'ROLE_RANK', 'ROLE_WORLD_SIZE',
@@ -247,14 +272,18 @@ def main():
     ap.add_argument('--host-trie-update', action='store_true', help='--device-trie: apply the per-step trie update on the host and ship it as a patch (round-2 form) instead of inserting the accepted tokens on the device (la_trie_stream_put_dev)')
     ap.add_argument('--unchained-trie', action='store_true', help='--device-trie: read the drafts back to the host and feed them through la_llama_mstep (round-2 form)')
     ap.add_argument('--strict-gather', action='store_true', help='N > 1: blocking all-gather (reference trie order at query time)')
+    ap.add_argument('--strict-trie-order', action='store_true',
+                    help='--batch > 1, host trie: apply the trie update of step k BEFORE the drafts of step k + 1 are retrieved (the reference\'s order, GPU '
+                         'idle meanwhile).  Default: the update runs on the host after the verify pass of step k + 1 has been queued (mstep_async), '
+                         'i.e. drafts see a step\'s tokens one step later — the split-phase order the N > 1 job uses; emitted tokens are unaffected')
     ap.add_argument('--profile-iters', type=int, default=3)
     ap.add_argument('--attn-split', type=int, default=0, help='key splits of the tree-attention kernel (0 = engine default 8)')
     ap.add_argument('--fuse', type=int, default=0, help='engine cfg.fuse bits (opt-in in-kernel norm->GEMM fusion; 0 = separate kernels)')
     ap.add_argument('--gemm-cfg', default='', help='engine gemm_cfg override (comma list: qkv_rb,qkv_ks,o_rb,o_ks,down_rb,down_ks,lm_rb,gu_variant; 0 = default)')
-    ap.add_argument('--secondary', default='mistral:8,13b:4,mixtral:4',
+    ap.add_argument('--secondary', default='mistral:8,13b:4,mixtral:4,13b:1',
                     help='N=1 default workload only: comma list of model:batch legs (BASELINE configs 3-5: a 64-token tree per sequence '
                          'through la_llama_mstep) run AFTER the timed region, each in its own process; their lines are embedded under '
-                         '"secondary".  "" = none')
+                         '"secondary"; 13b:1 = the 64-row step at a larger launch size (the HBM fraction rises with bytes per launch).  "" = none')
     ap.add_argument('--decoding-length', type=int, default=64, help='tree tokens per sequence and step (BASELINE: 64); > 64 (the reference\'s best '
                     'published setting is 128 with --branch-length 32, lookahead/README.md:100): wide trees through eng.tstep, --batch 1')
     ap.add_argument('--branch-length', type=int, default=12)
@@ -300,18 +329,18 @@ def main():
 
     # measurement override of the library's idle-window prefetch default (la_debug_set keys 7 / 8 / 9, scripts/gpu_pf_ab.py)
     if os.environ.get('LA_PF_KIB') is not None:
-        from painlessinferenceacceleration_amd._lib import check as _check, lib as _lalib
-        _check(_lalib.la_lab_set(7, int(os.environ['LA_PF_KIB'])), 'debug_set')
-        _check(_lalib.la_lab_set(8, int(os.environ.get('LA_PF_DELAY', '0'))), 'debug_set')
-        _check(_lalib.la_lab_set(9, int(os.environ.get('LA_PF_TAIL', '0'))), 'debug_set')
+        from painlessinferenceacceleration_amd._lib import check as _check, lab_set as _lab_set      # every loaded build (bf16 / fp16)
+        _check(_lab_set(7, int(os.environ['LA_PF_KIB'])), 'debug_set')
+        _check(_lab_set(8, int(os.environ.get('LA_PF_DELAY', '0'))), 'debug_set')
+        _check(_lab_set(9, int(os.environ.get('LA_PF_TAIL', '0'))), 'debug_set')
     if os.environ.get('LA_DEBUG'):                       # measurement: any la_debug_set keys, "k=v,k=v" (scripts/gpu_knob_sweep.sh)
-        from painlessinferenceacceleration_amd._lib import lib as _lalib, check as _check
+        from painlessinferenceacceleration_amd._lib import lab_set as _lab_set, check as _check
         for kv in os.environ['LA_DEBUG'].split(','):
             k, v = kv.split('=')
-            _check(_lalib.la_lab_set(int(k), int(v)), 'debug_set')
+            _check(_lab_set(int(k), int(v)), 'debug_set')
     if os.environ.get('LA_MB_KS2') is not None:          # measurement: 2 K splits for the multi-block slab GEMMs at >= 5 blocks
-        from painlessinferenceacceleration_amd._lib import check as _check, lib as _lalib
-        _check(_lalib.la_lab_set(12, int(os.environ['LA_MB_KS2'])), 'debug_set')
+        from painlessinferenceacceleration_amd._lib import check as _check, lab_set as _lab_set
+        _check(_lab_set(12, int(os.environ['LA_MB_KS2'])), 'debug_set')
 
     shape = {'7b': LlamaShape.llama2_7b, '13b': LlamaShape.llama2_13b, 'mistral': LlamaShape.mistral_7b,
              'mixtral': LlamaShape.mixtral_8x7b}[args.model]()
@@ -400,9 +429,12 @@ def main():
     gather = None
     if dist_on:
         from painlessinferenceacceleration_amd.distributed import AcceptedTokenGather
-        gather = AcceptedTokenGather(comm_dev, b_loc=B, branch_length=BL)
-    pending = [False]
-    edls, dls, qts = [], [], []
+        # the N-rank logic (strict / split-phase, batch-index order) lives in the package: step_update() after a step, overlap() once the
+        # next pass is queued — the same calls lookahead_generation() makes under decoding_kwargs['gather']
+        gather = AcceptedTokenGather(comm_dev, b_loc=B, branch_length=BL, mode='strict' if args.strict_gather else 'split-phase')
+    put_q = [None]                    # B > 1, one GPU: the trie update of the last step, applied under the next verify pass
+    overlap_put = B > 1 and not args.strict_trie_order
+    edls, dls, qts, ctxs = [], [], [], []          # ctxs: committed keys per sequence at the start of every step
 
     def drafts_for(i):
         ubl = min(BL, max_length - len(seqs[i]) - 1)
@@ -433,9 +465,8 @@ def main():
         # device trie chained in front of the verify pass: patch + query kernels and la_llama_mstep_trie on the engine's stream; the
         # drafts never leave HBM (the host reads back accepted tokens and draft lengths)
         tq = time.time()
-        if pending[0]:
-            gather.finish_into_trie(cache, BL)
-            pending[0] = False
+        if gather is not None:
+            gather.overlap(cache, BL)
         ubl = [min(BL, max_length - len(seqs[i]) - 1) for i in range(B)]
         with torch.cuda.stream(eng.stream):
             # round 4: with device-side updates the device image already holds step N's inserts when step N + 1 is queued, so the
@@ -462,16 +493,13 @@ def main():
                 dev_trie.replay(replay_q[0], BL + 1)
                 replay_q[0], replay_q[1] = None, False
         elif dist_on:
-            if args.strict_gather:
-                gather.update_trie(cache, toks_all if B > 1 else toks_all[0], BL)
-            else:
-                gather.begin(toks_all if B > 1 else toks_all[0])
-                pending[0] = True
+            gather.step_update(cache, toks_all if B > 1 else toks_all[0], BL)
         else:
             for i in range(B):
                 cache.stream_put(toks_all[i], branch_length=BL + 1, final=False, idx=gidx[i])
 
     def one_step():
+        ctxs.append(eng.n_keys if B == 1 else float(np.mean(eng.slot_keys[:B])))
         if dev_trie is not None and not args.unchained_trie:
             return one_step_chained()
         tq = time.time()
@@ -487,27 +515,30 @@ def main():
             toks_all = [eng.tstep(dr[0][0], dr[0][1], mode=0)[0]]
         elif B == 1:
             eng.step_async(dr[0][0], dr[0][1], mode=0)
-            if pending[0]:       # N > 1, split-phase: the previous step's gather + every trie update run while the GPU verifies
-                gather.finish_into_trie(cache, BL)
-                pending[0] = False
+            if gather is not None:       # N > 1, split-phase: the previous step's gather + every trie update run while the GPU verifies
+                gather.overlap(cache, BL)
             toks_all = [eng.step_finish()[0]]
+        elif wide:
+            if gather is not None:
+                gather.overlap(cache, BL)
+            toks_all = eng.mstep_trees([(i, dr[i][0], dr[i][1], 0, 40) for i in range(B)])
         else:
-            if pending[0]:
-                gather.finish_into_trie(cache, BL)
-                pending[0] = False
-            if wide:
-                toks_all = eng.mstep_trees([(i, dr[i][0], dr[i][1], 0, 40) for i in range(B)])
-            else:
-                toks_all = eng.mstep([(i, dr[i][0], dr[i][1], 0, 16) for i in range(B)])
+            # queue the multi-block pass, then do the host work nothing on the device waits for while the GPU verifies: the previous
+            # step's gather + puts (N > 1, split-phase) or its trie update (one GPU, unless --strict-trie-order)
+            eng.mstep_async([(i, dr[i][0], dr[i][1], 0, 16) for i in range(B)])
+            if gather is not None:
+                gather.overlap(cache, BL)
+            if put_q[0] is not None:
+                cache.stream_put_many(put_q[0], branch_length=BL + 1, final=False)
+                put_q[0] = None
+            toks_all = eng.mstep_finish()
         for i in range(B):
             seqs[i].extend(toks_all[i])
             dls.append(len(dr[i][0])); edls.append(len(toks_all[i]))
-        if dist_on:
-            if args.strict_gather:       # blocking: every replica holds every token of the step before the next query
-                gather.update_trie(cache, toks_all if B > 1 else toks_all[0], BL)
-            else:                        # split-phase RCCL all-gather: collected during the next verify step
-                gather.begin(toks_all if B > 1 else toks_all[0])
-                pending[0] = True
+        if dist_on:                      # strict: every replica holds every token of the step before the next query; split-phase: collected
+            gather.step_update(cache, toks_all if B > 1 else toks_all[0], BL)      # during the next verify step (overlap above)
+        elif B > 1 and overlap_put and not wide:
+            put_q[0] = [(gidx[i], toks_all[i]) for i in range(B)]
         elif B > 1:
             cache.stream_put_many([(gidx[i], toks_all[i]) for i in range(B)], branch_length=BL + 1, final=False)
         else:
@@ -519,16 +550,18 @@ def main():
                          # drives the loop; the serving loop allocates nothing that needs cycle collection
     for _ in range(W):
         one_step()
-    n0, q0 = len(edls), len(qts)
+    n0, q0, c0 = len(edls), len(qts), len(ctxs)
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(K):
         one_step()
-    if pending[0]:
-        gather.finish_into_trie(cache, BL)
-        pending[0] = False
+    if gather is not None:               # the last step's gather and puts, inside the timed region
+        gather.overlap(cache, BL)
+    if put_q[0] is not None:             # ... and the last deferred trie update
+        cache.stream_put_many(put_q[0], branch_length=BL + 1, final=False)
+        put_q[0] = None
     if replay_q[0] is not None:          # the last chained step's trie update, replayed inside the timed region
         dev_trie.replay(replay_q[0], BL + 1)
         replay_q[0] = None
@@ -545,6 +578,8 @@ def main():
     else:
         accepted_all = float(accepted)
     correct = all(seqs[i][P:P + len(truths[gidx[i]])] == truths[gidx[i]][:len(seqs[i]) - P] for i in range(B))
+    ctx_timed = float(np.mean(ctxs[c0:c0 + K]))      # mean context of the TIMED steps (the legs below keep extending the sequence)
+    ctx_end_timed = eng.n_keys if B == 1 else int(np.mean(eng.slot_keys[:B]))
     native = None
     if B == 1 and not wide and not dist_on and len(seqs[0]) + (BL + 1) * (16 + 24) < max_length - 2 * DL:
         # informational: the same steps through the native loop (la_lookahead_decode, what lookahead_generation() uses when
@@ -598,7 +633,7 @@ def main():
         return
 
     # ---- roofline ---------------------------------------------------------------------------------------------------
-    ctx = eng.n_keys if B == 1 else int(np.mean(eng.slot_keys[:B]))
+    ctx = ctx_timed                  # the step is priced at the mean context of the timed window, not at where later legs left the cache
     ms_step = 1e3 * elapsed / K
     mean_T = float(np.mean(dls[n0:]))
     mean_acc = float(np.mean(edls[n0:]))
@@ -611,7 +646,7 @@ def main():
         # the launch duration proper: all layers' gate/up launches back to back inside ONE event pair (kernel + launch boundary)
         gu_ms = eng.profile_gateup(iters=5)
         gu_bytes = 2 * shape.ffn * shape.hidden * 2 + 64 * shape.hidden * 2 + 64 * shape.ffn * 2
-        step_bytes = algorithmic_bytes(shape, 64, ctx, 64 * shape.vocab * 2)
+        step_bytes = int(algorithmic_bytes(shape, 64, ctx, 64 * shape.vocab * 2))
         gemm_ms = sum(prof['ms'][k] for k in ('qkv', 'o', 'gateup', 'down', 'lm_head'))
         traffic, traffic_src = None, None
         try:        # HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside bench.py)
@@ -621,22 +656,31 @@ def main():
             traffic_src = pmc['source']
         except Exception:
             pass
+        fm = floor_model(shape)
+        nongemm_ms = max(prof['ms_step'] - gemm_ms, 0.0)
+        fm['nongemm_ms_per_step_events'] = round(nongemm_ms, 4)
+        fm['frac_of_peak_if_nongemm_were_free'] = round(step_bytes / (fm['gemm_floor_ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        fm['frac_of_peak_at_floor'] = round(step_bytes / ((fm['gemm_floor_ms_per_step'] + nongemm_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         roofline = {
             'bound': 'hbm', 'kernel': 'k_gemm64r<4,EPI_SWIGLU,4,8> (gate/up projection + fused SwiGLU, %d launches/step)' % shape.n_layers,
             'achieved': round(gu_bytes / (gu_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(gu_bytes / (gu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+            'frac_of_achievable': round(gu_bytes / (gu_ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS, 4),
             'bytes_per_launch': gu_bytes, 'ms_per_launch': round(gu_ms, 5),
             'timing': 'HIP events on the engine stream: %d launches (one per layer, own weights) back to back per event pair, 5 passes; '
                       'inside the eager step, with event packets between all kernels, the same launch reads %.5f ms; rocprofv3 kernel '
-                      'average: profiles/r03b_profile_raw.txt (35.3 us)' % (shape.n_layers, gu_ms_step),
+                      'average of the same command: the newest profiles/r*_profile_raw.txt' % (shape.n_layers, gu_ms_step),
             'ms_per_launch_in_eager_step': round(gu_ms_step, 5),
             # the same launch against the matrix-core roof: 64-row trees keep the kernel far below the MFMA ridge (HBM-bound by design)
             'mfma': {'flops_per_launch': 2 * 2 * shape.ffn * shape.hidden * 64,
                      'achieved_TFLOPs': round(2 * 2 * shape.ffn * shape.hidden * 64 / (gu_ms * 1e-3) / 1e12, 1),
                      'peak_TFLOPs': 2500.0, 'frac': round(2 * 2 * shape.ffn * shape.hidden * 64 / (gu_ms * 1e-3) / 1e12 / 2500.0, 4)},
-            'verify_step': {'algorithmic_bytes': step_bytes, 'ms_graph_step': round(ms_step, 4),
+            'verify_step': {'algorithmic_bytes': step_bytes, 'context_keys_mean_of_timed_steps': round(ctx, 1),
+                            'ms_graph_step': round(ms_step, 4),
                             'achieved_GBps': round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
                             'frac': round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            'frac_of_achievable': round(step_bytes / (ms_step * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS, 4),
+                            'floor_model': fm,
                             'ms_eager_step_events': round(prof['ms_step'], 4),
                             'ms_by_class_events': {k: round(v, 4) for k, v in prof['ms'].items()},
                             'all_gemm_GBps_events': round(2 * shape.n_params_no_embed() / (gemm_ms * 1e-3) / 1e9, 1)},
@@ -646,7 +690,7 @@ def main():
         # per-kernel durations of the same step: profiles/r02_mblock_kernel_stats_*.txt (rocprofv3 --kernel-trace --stats)
         kv_tok = 2 * shape.n_layers * shape.n_kv_heads * shape.head_dim * 2
         RB_ = (DL + 63) // 64 if wide else 1        # 64-row blocks per sequence (wide trees: the mean tree occupies up to DL rows)
-        step_bytes = W_bytes + kv_tok * ctx * B + kv_tok * 64 * B * RB_ + 64 * B * RB_ * (shape.hidden * 2 + 8) + 64 * B * RB_ * shape.vocab * 2
+        step_bytes = int(W_bytes + kv_tok * ctx * B + kv_tok * 64 * B * RB_ + 64 * B * RB_ * (shape.hidden * 2 + 8) + 64 * B * RB_ * shape.vocab * 2)
         active = shape.n_params_no_embed() - (shape.n_layers * 3 * shape.ffn * shape.hidden * max(shape.n_experts - shape.top_k, 0) if shape.n_experts else 0)
         step_flops = 2.0 * active * 64 * B * RB_ + 4.0 * shape.n_layers * shape.n_heads * shape.head_dim * 64 * B * RB_ * (ctx + 64)      # MoE: the top-k experts of a row
         hbm_frac = step_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -691,7 +735,7 @@ def main():
         'metric': 'accepted_tokens_per_sec', 'value': round(accepted_all / elapsed, 2), 'unit': 'tokens/s',
         'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-        'config': {'workload': model_name + f' bf16 bs={B}/GPU lookahead verify loop, {DL}-token draft tree per sequence / 8-12 noisy branches '
+        'config': {'workload': model_name + f' {args.dtype} bs={B}/GPU lookahead verify loop, {DL}-token draft tree per sequence / 8-12 noisy branches '
                                f'(hier, decoding_length={DL}, branch_length={BL}), synthetic permutation-LM weights (N(0,0.02); o/down std 1e-4; '
                                'lm_head[pi(t)]=embed[t]) for decisive greedy margins, 512-token phrase-bank prompts',
                    'n_layers': shape.n_layers, 'prompt_len': P, 'rho': args.rho, 'copies': args.copies,
@@ -699,10 +743,15 @@ def main():
                    'kv_cache': (f'ring of {eng.shape.sliding_window} + one step of rows per sequence (sliding window)' if kv_ring else 'linear, max_length keys per sequence'),
                    'gather_mode': None if not dist_on else ('strict' if args.strict_gather else 'split-phase'),
                    'gather_transport': gather_transport, 'rccl_ranks': rccl_ranks,
+                   'trie_update': ('device' if (dev_trie is not None and dev_trie.put_vocab) else
+                                   ('gathered over all ranks, ' + gather.mode) if dist_on else
+                                   'host, under the next verify pass (mstep_async; drafts see a step one step later)' if (B > 1 and overlap_put and not wide and dev_trie is None) else
+                                   'host, before the next query (reference order)'),
                    'draft_retrieval': ('device trie (incremental mirror, one launch per step' + (', chained in front of the verify pass: drafts stay in HBM)' if not args.unchained_trie else ', drafts read back to the host)') + ('; trie update on the device (la_trie_stream_put_dev)' if dev_trie.put_vocab else '; trie update on the host, shipped as a patch')) if dev_trie is not None else 'host trie',
                    'device_trie_stats': dev_trie.stats if dev_trie is not None else None,
                    'mean_accept_len': round(mean_acc, 3), 'mean_draft_len': round(mean_T, 2),
-                   'verify_steps_per_sec': round(K * world / elapsed, 2), 'context_at_end': ctx,
+                   'verify_steps_per_sec': round(K * world / elapsed, 2), 'context_at_end': ctx_end_timed,
+                   'context_mean_timed': round(ctx_timed, 1),
                    'trie_query_ms_mean': round(1e3 * float(np.mean(qts[q0:])), 4),
                    'lookahead_equals_greedy': bool(correct), 'plain_greedy_tokens_per_sec': round(B * len(truth_own[0]) / t_greedy, 2),
                    'native_loop': native,

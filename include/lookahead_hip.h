@@ -222,7 +222,9 @@ int la_trie_hier_get_dev(void* stream, const int32_t* d_tok, const double* d_fo,
 #define LA_IN_MODE       1
 #define LA_IN_NKEYS_HINT 2   /* the caller's count of committed keys before this block (la_llama_step reads it ON THE HOST to pick the
                                 tree-attention form: one launch while a head group's K/V fits its XCD's L2, key splits + combine beyond;
-                                a hint only — both forms are exact at any context, 0 / stale values cost time, never correctness) */
+                                a hint only — both forms are exact at any context, 0 / stale values cost time, never correctness: a caller
+                                that leaves the word 0 always runs the one-launch form, which is slower past ~2000 committed keys, so
+                                fill it on long contexts.  Both forms are captured on the first call, not on the first crossing) */
 #define LA_IN_IDS        4
 #define LA_IN_ROWMASK   68   /* int32 word offset; 8-byte aligned */
 #define LA_IN_WORDS    196

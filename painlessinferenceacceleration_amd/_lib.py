@@ -230,6 +230,40 @@ def _bind(dll, path, want_dtype):
 
 _bind(lib, LIB_PATH, LA_DTYPE_BF16)
 _lib_f16 = None
+_knobs = {}          # (entry point, key) -> value: every knob set through lab_set / debug_set, replayed into a library loaded later
+
+
+def loaded_libs():
+    """every liblookahead_hip build this process has loaded (bf16 always; fp16 once an fp16 engine exists)"""
+    return [d for d in (lib, _lib_f16) if d is not None]
+
+
+def lab_set(key, value):
+    """la_lab_set on EVERY loaded build (each .so has its own knob globals and graph epoch) and on builds loaded later — a knob
+    set before an fp16 engine exists must not be silently ignored by it.  -> the status of the first library that refuses."""
+    rc = LA_OK
+    for d in loaded_libs():
+        r = d.la_lab_set(int(key), int(value))
+        rc = r if (rc == LA_OK and r != LA_OK) else rc
+    if rc == LA_OK:
+        _knobs[('la_lab_set', int(key))] = int(value)
+    return rc
+
+
+def debug_set(key, value):
+    """la_debug_set (the product header's depth probe) on every loaded build, replayed like lab_set"""
+    rc = LA_OK
+    for d in loaded_libs():
+        r = d.la_debug_set(int(key), int(value))
+        rc = r if (rc == LA_OK and r != LA_OK) else rc
+    if rc == LA_OK:
+        _knobs[('la_debug_set', int(key))] = int(value)
+    return rc
+
+
+def lab_get(key, dtype=None):
+    """la_lab_get of the build serving `dtype` (default: bf16)"""
+    return int((lib if dtype is None else lib_for(dtype)).la_lab_get(int(key)))
 
 
 def lib_for(dtype):
@@ -242,7 +276,10 @@ def lib_for(dtype):
         return lib
     if name == 'float16':
         if _lib_f16 is None:
-            _lib_f16 = _bind(_load(LIB_PATH_F16), LIB_PATH_F16, LA_DTYPE_F16)
+            dll = _bind(_load(LIB_PATH_F16), LIB_PATH_F16, LA_DTYPE_F16)
+            for (fn, key), value in _knobs.items():          # knobs set while only the bf16 build was loaded
+                getattr(dll, fn)(key, value)
+            _lib_f16 = dll
         return _lib_f16
     raise ValueError(f'no liblookahead_hip build for dtype {dtype}: bfloat16 and float16 exist')
 

@@ -11,10 +11,11 @@
 //   * its 8 waves are the 8 key-tile parities (tile = 32 keys); each wave runs the online softmax over its tiles, the waves meet
 //     ONCE in LDS, and the workgroup normalises and stores its slice of the o_proj operand (bf16, packed XP layout) itself —
 //     no partials in HBM, no second launch, nothing another workgroup has to wait for;
-//   * the nh/nkv * 2 * SL workgroups that read the same K/V (one kv head) sit on one XCD (block id mod 8) and start their tile
-//     lists at DIFFERENT offsets: each first touches another part of the head's K/V (that part comes from HBM, spread over all
-//     CUs as the key split did), and finds the rest in that XCD's L2, where a CU reads ~6x faster than from HBM (per-CU rate =
-//     bytes in flight / latency).  This is a performance assumption only: a tile nobody has fetched yet is simply a miss.
+//   * the nh/nkv * 2 * SL workgroups that read the same K/V (one kv head) sit on one XCD (block id mod 8): the head's K/V is
+//     fetched from HBM once per XCD (concurrent misses on a line merge in L2) and re-read from that XCD's L2, where a CU reads ~6x
+//     faster than from HBM (per-CU rate = bytes in flight / latency).  A performance assumption only: a tile nobody has fetched
+//     yet is simply a miss.  (Round 4 rotated the sharers' start offsets — worth 0.01 ms per step; round 5 trades that for the
+//     first K tile requested before the cursor arrives, see `spec`.)
 //   * MFMA tiles are 32 tokens wide whatever the slice, so the 32 / SL-row slice costs SL x redundant matrix work — free here
 //     (the launch is bound by memory latency; the matrix pipe is idle), and it buys SL x more workgroups in flight.
 // Same arithmetic per (row, key) as k_tree_attn (bf16(QK^T) * 1/sqrt(d) -> bf16, fp32 softmax, bf16 P, fp32 PV accumulation,
@@ -39,7 +40,6 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
     extern __shared__ __attribute__((aligned(16))) float lds1[];      // [Q fragments: 8 KiB][merge buffer]
     const int nh = nh_nkv >> 16, nkv = nh_nkv & 0xffff, G = nh / nkv;
     const int SL = sl_ring & 63, ring_tiles = sl_ring >> 8;
-    const bool norot = (sl_ring & 128) != 0;                            // measurement (la_lab_set key 18 bit 0): every sharer starts at tile 0
     const int W = 32 / SL;                                            // token rows this workgroup stores
     const int NS = G * 2 * SL;                                        // workgroups that read the same kv head
     const int b = blockIdx.x;
@@ -55,6 +55,21 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
     if (stamp && lane == 0) stamp[0] = wall_clock64();
 
     const int KB = max_keys >> 5;
+    // First K tile BEFORE the cursor is known (round 5).  The tile list hangs on `nkeys`, a scalar load of a line another XCD wrote:
+    // ~1.8 us behind dispatch (stamps, profiles/r04_attention_one_launch.txt).  Wave `par` starts at tile `par`, and with a linear,
+    // unwindowed cache that tile's address depends on kernel arguments only (preloaded scalars), so its 8 fragments are requested
+    // at once and KEPT — unlike round 4's speculative touch, which dropped its data and queued the real request behind it.  The
+    // tile is committed (valid) whenever par < NP, i.e. from 225 + 1 committed keys on for every wave; below that, or with a
+    // window / ring, the wave simply requests its real first tile once nkeys has arrived (the early data is never used then; the
+    // addresses read are inside the layer's cache: KB >= 8).  Price: the start rotation of the sharers (worth 0.01 ms per step).
+    // (bit 7 of sl_ring = la_lab_set key 18 bit 0: the early request off — the A/B switch; results are bit-identical either way)
+    const bool spec = window <= 0 && ring_tiles == 0 && KB >= 8 && (sl_ring & 128) == 0;
+    bf16x8 kA[8], kB[8];
+    if (spec) {
+        const bf16x8* kt = (const bf16x8*)(kmain + ((size_t)hk * KB + par) * 4096);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) kA[s] = kt[s * 64 + lane];
+    }
     // Q fragments of (h, tb): wave `par` brings fragment `par` (1 KiB); all waves read the 8 fragments back per tile
     bf16x8* const qs = (bf16x8*)lds1;
     const bf16x8 qmine = *((const bf16x8*)(qf + ((size_t)(h * 2 + tb) * 8 + par) * 512) + lane);
@@ -65,9 +80,9 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
     const int ts = (window > 0 && nkeys - window > 0) ? ((nkeys - window) >> 5) : 0;
     const int NP = NPall - ts, NT = NP + 2;                           // committed tiles + the 2 fresh tiles of the tree
     const int key_lo = (window > 0) ? nkeys + __popcll(rm) - 1 - window : 0;
-    // this wave's tiles: par, par + 8, ...; the sharers start at different offsets of that list (see the header)
+    // this wave's tiles: par, par + 8, ... in list order (every sharer of the head starts at the head of its list: see `spec` above)
     const int cnt = NT > par ? (NT - par + 7) >> 3 : 0;
-    int idx = (cnt > 0 && !norot) ? r % cnt : 0;                        // sharer r starts at its r-th tile
+    int idx = 0;
 
     auto mtile = [&](int it) -> size_t { return (size_t)(ring_tiles > 0 ? (ts + it) % ring_tiles : ts + it); };
     auto kptr = [&](int it) -> const bf16x8* {
@@ -161,9 +176,8 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
         }
     };
 
-    bf16x8 kA[8], kB[8];
-    int it = par + 8 * idx;
-    if (cnt > 0) {
+    int it = par;
+    if (cnt > 0 && !(spec && par < NP)) {           // wave-uniform: the early request did not fetch this wave's first tile
         const bf16x8* kt = kptr(it);
 #pragma unroll
         for (int s = 0; s < 8; ++s) kA[s] = kt[s * 64 + lane];
@@ -237,7 +251,7 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
 }
 
 extern long long* g_la_dbg_times;
-int g_la_attn1_var = 0;       // la_debug_set key 18 (measurement): bit 0 = no start rotation, bits 1-2 = force SL (1 -> 1, 2 -> 2, 3 -> 4)
+int g_la_attn1_var = 0;       // la_lab_set key 18 (measurement): bit 0 = first K tile requested only after the cursor has arrived (round-4 order), bits 1-2 = force SL (1 -> 1, 2 -> 2, 3 -> 4)
 int g_la_attn_one = 1;        // la_debug_set key 17: 1 = single-launch attention on the single-sequence step (default), 0 = split + combine
 
 static int g_attn1_cus = 0;

@@ -833,6 +833,14 @@ extern "C" int la_llama_step(la_llama* m, void* stream, const int32_t* host_in, 
         int rc = build_graph(m, st, false, host_in, host_out, 0, long_ctx);
         if (rc != LA_OK) return rc;
         m->zc_in = host_in; m->zc_out = host_out; m->graph_epoch = g_la_graph_epoch;
+        // the OTHER form too, now (first call = set-up / prefill time) rather than on the first step that crosses attn_thr: capture +
+        // instantiate of the whole model is a multi-ms stall that would otherwise land inside a decode loop (and inside
+        // la_lookahead_decode).  Only when the cache can reach the other side of the threshold at all.
+        const bool other_reachable = long_ctx ? true : (m->cfg.max_keys > m->attn_thr);
+        if (other_reachable && !(long_ctx ? m->graph_ready : m->graph_long_ready)) {
+            rc = build_graph(m, st, false, host_in, host_out, 0, !long_ctx);
+            if (rc != LA_OK) return rc;
+        }
     }
     m->seq_expected += 1;
     HIPCHK(hipGraphLaunch(long_ctx ? m->graph_long : m->graph_exec, st));

@@ -16,6 +16,13 @@ torch.distributed.all_gather_into_tensor.  Two modes, label every number with th
   split-phase  begin(...) after step k, finish_into_trie(...) during step k+1: the gather and the host-side trie updates
                overlap the next verify step; drafts see a step's tokens one step later (emitted tokens are unaffected:
                verification is lossless), replicas still identical to each other.
+
+Product entry point (round 5): both decoding loops honour `decoding_kwargs['gather'] = AcceptedTokenGather(..., mode=...)` —
+`lookahead_generation()` of pretrained_model.py (one sequence per rank) and of pretrained_model_batch.py (B_loc sequences per
+rank) then key every trie call with the GLOBAL batch index, replace their per-step stream_put by step_update() / overlap(), keep
+serving the collective after their own sequences have finished (drain(): every rank makes the same number of collective calls; a
+DONE bit rides in the count word) and flush all B sequences in batch-index order at the end (flush()).  bench.py --gpus N drives
+the same four calls from its timed loop.
 """
 import ctypes as C
 
@@ -32,8 +39,16 @@ def slot_words(branch_length):
     return max(16, (int(branch_length) + 2 + 15) // 16 * 16)
 
 
+DONE_BIT = 1 << 30          # count word: this rank has finished all its sequences (it keeps contributing empty lists)
+
+
 class AcceptedTokenGather(object):
-    def __init__(self, device, group=None, b_loc=1, branch_length=12, native=None):
+    def __init__(self, device, group=None, b_loc=1, branch_length=12, native=None, mode='split-phase'):
+        assert mode in ('strict', 'split-phase')
+        self.mode = mode
+        self.branch_length = int(branch_length)
+        self.all_done = False                              # every rank's DONE bit was set in the last collected gather
+        self._pending = False
         self.group = group
         self.local_only = not dist.is_initialized()        # a 1-rank process group still runs the collective
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -135,7 +150,7 @@ class AcceptedTokenGather(object):
         assert len(tokens) == self.b_loc, f'{len(tokens)} token lists for b_loc={self.b_loc}'
         return [list(t) for t in tokens]
 
-    def _pack(self, lists):
+    def _pack(self, lists, done=False):
         buf = self._stage
         buf.zero_()
         v = buf.view(self.b_loc, self.slot)
@@ -143,37 +158,40 @@ class AcceptedTokenGather(object):
             if len(t) > self.max_tokens:
                 raise ValueError(f'{len(t)} accepted tokens do not fit the {self.slot}-word gather slot; construct '
                                  f'AcceptedTokenGather with branch_length >= {len(t) - 1}')
-            v[i, 0] = len(t)
+            v[i, 0] = len(t) | (DONE_BIT if done else 0)
             if t:
                 v[i, 1:1 + len(t)] = torch.tensor(t, dtype=torch.int32)
         return buf
 
     def _unpack(self, host):
-        """-> token lists in GLOBAL batch-index order b = i * world + r."""
+        """-> token lists in GLOBAL batch-index order b = i * world + r (and self.all_done: every rank flagged DONE)."""
         allv = host.view(self.world, self.b_loc, self.slot)
-        return [allv[r, i, 1:1 + int(allv[r, i, 0])].tolist() for i in range(self.b_loc) for r in range(self.world)]
+        self.all_done = all((int(allv[r, 0, 0]) & DONE_BIT) != 0 for r in range(self.world))
+        return [allv[r, i, 1:1 + (int(allv[r, i, 0]) & (DONE_BIT - 1))].tolist() for i in range(self.b_loc) for r in range(self.world)]
 
     def global_index(self, i):
         """global batch index of this rank's i-th sequence"""
         return i * self.world + self.rank
 
     # ---- strict (blocking) form -------------------------------------------------------------------------------------------
-    def gather(self, tokens):
+    def gather(self, tokens, done=False):
         """tokens: this rank's accepted tokens of the step (b_loc lists; a flat list when b_loc == 1)
         -> token lists of all B sequences in global batch-index order."""
-        self.begin(tokens)
+        self.begin(tokens, done=done)
         return self.finish()
 
     # ---- split-phase form: the gather of step k overlaps the verify step k+1 ---------------------------------------------
-    def begin(self, tokens):
-        """Start the all-gather of this rank's accepted tokens (asynchronous; one outstanding gather at a time)."""
+    def begin(self, tokens, done=False):
+        """Start the all-gather of this rank's accepted tokens (asynchronous; one outstanding gather at a time).  done: this rank
+        has no live sequence left (it keeps calling with empty lists until all_done, see drain())."""
         assert self._work is None, 'one outstanding gather at a time'
         lists = self._lists(tokens)
         self._mine = lists
         if self.local_only:
             self._work = True
+            self._mine_done = bool(done)
             return
-        self._pack(lists)
+        self._pack(lists, done)
         if self._comm:
             with torch.cuda.stream(self._stream):
                 self._in.copy_(self._stage, non_blocking=True)
@@ -191,6 +209,7 @@ class AcceptedTokenGather(object):
         assert self._work is not None
         work, self._work = self._work, None
         if self.local_only:
+            self.all_done = self._mine_done
             return self._mine
         if self._comm:
             self._done.synchronize()
@@ -205,9 +224,62 @@ class AcceptedTokenGather(object):
             cache.stream_put(toks, branch_length=branch_length + 1, final=final, mode='output', idx=b)
         return per_seq
 
-    def update_trie(self, cache, tokens, branch_length, final=False):
+    def update_trie(self, cache, tokens, branch_length, final=False, done=False):
         """strict mode: all-gather + stream_put for every sequence (idx = global batch index) in batch-index order."""
-        per_seq = self.gather(tokens)
+        per_seq = self.gather(tokens, done=done)
         for b, toks in enumerate(per_seq):
             cache.stream_put(toks, branch_length=branch_length + 1, final=final, mode='output', idx=b)
         return per_seq
+
+    # ---- what a decoding loop calls (lookahead_generation of both loops, bench.py): mode-independent call sites ---------------
+    @property
+    def n_sequences(self):
+        return self.world * self.b_loc
+
+    def exchange_prompts(self, local_prompts):
+        """Once per request, off the hot path: every rank's prompt token lists -> all B lists in global batch-index order, so that
+        each replica holds every sequence's input frequencies (the reference's single-process loop puts all prompts,
+        pretrained_model_batch.py:1204-1207) and node counts / squeeze decisions agree across replicas."""
+        local_prompts = [list(map(int, p)) for p in local_prompts]
+        assert len(local_prompts) == self.b_loc
+        if self.local_only:
+            return local_prompts
+        got = [None] * self.world
+        dist.all_gather_object(got, local_prompts, group=self.group)
+        return [got[r][i] for i in range(self.b_loc) for r in range(self.world)]
+
+    def step_update(self, cache, tokens, branch_length=None, done=False):
+        """After a verify step: this rank's accepted tokens (b_loc lists; [] for a sequence that emitted nothing or has retired).
+        strict: blocking all-gather + every sequence's stream_put in global batch-index order, now.  split-phase: start the
+        all-gather; overlap() — called once the NEXT verify pass is queued — collects it and runs the puts while the GPU works."""
+        bl = self.branch_length if branch_length is None else branch_length
+        if self.mode == 'strict':
+            self.update_trie(cache, tokens, bl, done=done)
+        else:
+            if self._pending:                  # a step that had no overlap point (e.g. it finished the sequence): collect now
+                self.overlap(cache, bl)
+            self.begin(tokens, done=done)
+            self._pending = True
+
+    def overlap(self, cache, branch_length=None):
+        """split-phase: collect the gather begun after the previous step and apply it (call right after queueing a verify pass)."""
+        if self._pending:
+            self._pending = False
+            self.finish_into_trie(cache, self.branch_length if branch_length is None else branch_length)
+
+    def drain(self, cache, branch_length=None):
+        """This rank's sequences are finished (its last step_update carried done=True): keep taking part in the per-step
+        collective with empty contributions, applying the other ranks' tokens, until every rank has flagged DONE — all ranks
+        make the same number of collective calls and leave together."""
+        bl = self.branch_length if branch_length is None else branch_length
+        self.overlap(cache, bl)
+        empty = [[] for _ in range(self.b_loc)] if self.b_loc > 1 else []
+        while not self.all_done:
+            self.update_trie(cache, empty, bl, done=True)
+
+    def flush(self, cache, branch_length=None):
+        """End of the request on every rank: the final flush of all B sequences in batch-index order
+        (pretrained_model_batch.py:1288-1290)."""
+        bl = self.branch_length if branch_length is None else branch_length
+        for b in range(self.n_sequences):
+            cache.stream_put([], branch_length=bl + 1, final=True, mode='output', idx=b)

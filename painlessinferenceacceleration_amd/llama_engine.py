@@ -562,7 +562,15 @@ class LlamaVerifyEngine(object):
     def mstep(self, blocks, eager=False):
         """blocks: list of (slot, ids, rowmask, mode, limit) — one sequence's draft tree each (mode 0), or consecutive
         64-token pieces of one prompt (mode 1, same slot: a causal chain; every piece but the last holds 64 rows).
-        All blocks run in ONE pass over the weights (M = 64 * len(blocks) rows).  -> list of emitted token lists."""
+        All blocks run in ONE pass over the weights (M = 64 * len(blocks) rows).  -> list of emitted token lists.
+        = mstep_async + mstep_finish."""
+        self.mstep_async(blocks, eager=eager)
+        return self.mstep_finish()
+
+    def mstep_async(self, blocks, eager=False):
+        """Queue the multi-block pass (input block H2D, captured graph, result header D2H) and return at once: the host is free —
+        the previous step's trie update (LookaheadCache.stream_put_many), the accepted-token gather of an N-rank job
+        (AcceptedTokenGather.finish_into_trie), bookkeeping — until mstep_finish()."""
         assert self.max_blocks and 1 <= len(blocks) <= self.max_blocks, 'engine was created with max_blocks < len(blocks)'
         a = self._min_np
         a[_lib.LA_MIN_NBLK] = len(blocks)
@@ -584,14 +592,20 @@ class LlamaVerifyEngine(object):
             assert self.slot_keys[slot] + n <= self._capacity(), 'KV cache capacity of the slot exceeded'
         fn = self._lib.la_llama_mstep_eager if eager else self._lib.la_llama_mstep
         check(fn(self._h, self._sp(), self.host_min.data_ptr(), self.host_mout.data_ptr()), 'llama_mstep')
+        self._mstep_pending = (len(blocks), list(rows))
+
+    def mstep_finish(self):
+        """Wait for the pass queued by mstep_async -> list of emitted token lists (block order)."""
+        nb, slots = self._mstep_pending
+        self._mstep_pending = None
         self.stream.synchronize()
         o = self._mout_np
-        for slot in rows:
+        for slot in slots:
             self.slot_keys[slot] = int(o[_lib.LA_MOUT_NKEYS + slot])
-        if 0 in rows:
+        if 0 in slots:
             self.n_keys = self.slot_keys[0]
         return [o[_lib.LA_MOUT_OUTTOK + _lib.LA_MOUT_TOKS * b:_lib.LA_MOUT_OUTTOK + _lib.LA_MOUT_TOKS * b + int(o[_lib.LA_MOUT_NOUT + b])].tolist()
-                for b in range(len(blocks))]
+                for b in range(nb)]
 
     def mstep_trie(self, dev_trie, q0, slots, limits, last_tokens, put_idxs=None, put_branch_length=None):
         """One multi-block verify step whose drafts are the results of the LAST dev_trie.hier_get_dev(...) launch, taken on the

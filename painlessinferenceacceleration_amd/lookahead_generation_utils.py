@@ -84,8 +84,20 @@ def _merge_lists(default_list, custom_list, what):
     return default_list
 
 
+def _on_device(cls, *args, device=None):
+    """transformers >= 4.4x: the eos-aware processors keep their eos ids as a tensor created on `device` (default 'cpu') and compare
+    it with the scores' vocabulary index — HF's _get_logits_processor passes device=input_ids.device; older releases take no such
+    argument."""
+    if device is not None:
+        try:
+            return cls(*args, device=device)
+        except TypeError:
+            pass
+    return cls(*args)
+
+
 def resolve_generate_args(model_generation_config, input_length, generation_config=None, logits_processor=None,
-                          stopping_criteria=None, **kwargs):
+                          stopping_criteria=None, device=None, **kwargs):
     """The front half of the reference's generate() (common/pretrained_model.py:213-372) for the two modes this package serves.
 
     Precedence of every generation field: explicit keyword > `generation_config=` argument > the model's own generation_config
@@ -97,6 +109,8 @@ def resolve_generate_args(model_generation_config, input_length, generation_conf
       * `_get_stopping_criteria` (:359-361): MaxLengthCriteria, MaxTimeCriteria, then the caller's `stopping_criteria`;
       * warpers (temperature, top_k, top_p) are built for do_sample — the reference hands them to `sample()` only (:465-479); its
         LOOKAHEAD branch passes processors and criteria and NO warper (:428-441), and so does generate() here.
+    `device`: where the logits rows handed to the processors live (the engine's device) — the eos-aware processors build their
+    eos tensor there.
     Returns (GenerateArgs, leftover kwargs = model kwargs such as attention_mask)."""
     from transformers import (LogitsProcessorList, MaxLengthCriteria, MaxTimeCriteria, MinLengthLogitsProcessor,
                               MinNewTokensLengthLogitsProcessor, NoBadWordsLogitsProcessor, NoRepeatNGramLogitsProcessor,
@@ -143,9 +157,9 @@ def resolve_generate_args(model_generation_config, input_length, generation_conf
     if val['bad_words_ids'] is not None:
         procs.append(NoBadWordsLogitsProcessor(val['bad_words_ids'], eos_list))
     if val['min_length'] is not None and eos_list is not None and int(val['min_length']) > 0:
-        procs.append(MinLengthLogitsProcessor(int(val['min_length']), eos_list))
+        procs.append(_on_device(MinLengthLogitsProcessor, int(val['min_length']), eos_list, device=device))
     if val['min_new_tokens'] is not None and eos_list is not None and int(val['min_new_tokens']) > 0:
-        procs.append(MinNewTokensLengthLogitsProcessor(int(input_length), int(val['min_new_tokens']), eos_list))
+        procs.append(_on_device(MinNewTokensLengthLogitsProcessor, int(input_length), int(val['min_new_tokens']), eos_list, device=device))
     procs = _merge_lists(procs, list(logits_processor) if logits_processor is not None else None, 'logits processor')
     warpers = LogitsProcessorList()
     if bool(val['do_sample']):

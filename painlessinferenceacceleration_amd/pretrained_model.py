@@ -109,6 +109,7 @@ class LookaheadPreTrainedModel(object):
         if decoding_mode in ('hier', 'par', 'one'):
             decoding_mode = decoding_mode + '_mix'
         fmt, mode = decoding_mode.split('_')
+        tidx = int(decoding_kwargs.get('_trie_idx', 0))      # input-frequency plane: 0, or the global batch index of a sharded job
         ts = time.time()
         if fmt == 'hier' and decoding_kwargs.get('device_trie', False) and len(qids) <= 8 and decoding_length <= _lib.LA_TREE_MAX:
             # (trees wider than one 64-row block come from the host trie: the device walk emits uint64[T] row masks)
@@ -134,11 +135,11 @@ class LookaheadPreTrainedModel(object):
         elif fmt == 'hier':
             ids, rowmask, _, sizes = self.lookahead_cache.hier_get_packed(
                 qids, decoding_length=decoding_length, branch_length=update_branch_length, min_input_size=0,
-                min_output_size=max(decoding_length // 2, 1), mode=mode, idx=0)
+                min_output_size=max(decoding_length // 2, 1), mode=mode, idx=tidx)
         else:
             lst, mask, sizes = getattr(self.lookahead_cache, fmt + '_get')(
                 qids, decoding_length=decoding_length, branch_length=update_branch_length, min_input_size=0,
-                min_output_size=max(decoding_length // 2, 1), mode=mode, idx=0)
+                min_output_size=max(decoding_length // 2, 1), mode=mode, idx=tidx)
             ids = np.asarray(lst, dtype=np.int32)
             rowmask = _pack_rows(mask, (decoding_length + 63) // 64 if decoding_length > 64 and len(lst) > 1 else None)
         decoding_kwargs['qts'].append(time.time() - ts)
@@ -227,7 +228,21 @@ class LookaheadPreTrainedModel(object):
         eng = self.engine
         cap = eng._capacity() if hasattr(eng, '_capacity') else eng.max_keys
         assert stop_max_length + decoding_length + 1 <= cap, f'engine KV capacity {cap} < max_length + decoding_length + 1'
-        self.lookahead_cache.put(seq[1:], branch_length=branch_length + 1, mode='input', idx=0)
+        # Sharded job (distributed.py): decoding_kwargs['gather'] = AcceptedTokenGather(..., b_loc=1, mode='strict' | 'split-phase').
+        # This rank decodes ITS sequence; every trie call is keyed by the sequence's GLOBAL batch index, the per-step stream_put
+        # becomes the all-gather of all ranks' accepted tokens applied in batch-index order (pretrained_model_batch.py:1254-1259),
+        # and the rank keeps serving the collective after its own sequence has finished.
+        gather = decoding_kwargs.get('gather', None)
+        if gather is not None:
+            assert gather.b_loc == 1, 'one sequence per rank on this loop (pretrained_model_batch.py takes B_loc > 1)'
+            assert not decoding_kwargs.get('device_trie', False), 'sharded decoding keeps the trie replicas on the host'
+        tidx = gather.global_index(0) if gather is not None else 0
+        decoding_kwargs['_trie_idx'] = tidx
+        if gather is not None:            # every replica holds every sequence's input frequencies, put in batch-index order
+            for b_, p_ in enumerate(gather.exchange_prompts([seq[1:]])):
+                self.lookahead_cache.put(p_, branch_length=branch_length + 1, mode='input', idx=b_)
+        else:
+            self.lookahead_cache.put(seq[1:], branch_length=branch_length + 1, mode='input', idx=0)
         ts = time.time()
         eng.reset()
         first = True
@@ -239,7 +254,7 @@ class LookaheadPreTrainedModel(object):
         max_query_length = int(decoding_kwargs.get('max_query_length', 2))
         custom_stop = _custom_stop(stopping_criteria)      # user StoppingCriteria: evaluated per step, interpreter loop only
         native_loop = (not sequential and streamer is None and dm.split('_')[0] == 'hier' and not wide
-                       and custom_stop is None
+                       and custom_stop is None and gather is None
                        and not decoding_kwargs.get('device_trie', False)
                        and not decoding_kwargs.get('debug_lookahead', False) and decoding_kwargs.get('native_loop', True)
                        and 1 <= max_query_length <= 8          # la_lookahead_decode's query buffer; longer queries use this loop
@@ -298,6 +313,10 @@ class LookaheadPreTrainedModel(object):
                             eng.commit(rows)
                     elif wide:
                         next_tokens, _ = eng.tstep(ids, rowmask, mode=0)
+                    elif gather is not None and hasattr(eng, 'step_async'):
+                        eng.step_async(ids, rowmask, mode=0)
+                        gather.overlap(self.lookahead_cache, branch_length)      # split-phase: the previous step's gather + puts, under this pass
+                        next_tokens, _ = eng.step_finish()
                     else:
                         next_tokens, _ = eng.step(ids, rowmask, mode=0)
                     decoding_kwargs['dls'].append(len(ids))
@@ -311,15 +330,22 @@ class LookaheadPreTrainedModel(object):
                 seq.extend(next_tokens)
                 if streamer is not None:
                     streamer.put(np.array([next_tokens]))
-                self.lookahead_cache.stream_put(next_tokens, branch_length=branch_length + 1, final=False,
-                                                mode='output', idx=0)
                 finished = len(seq) >= stop_max_length or any(t in eos_set for t in next_tokens) or \
                     (custom_stop is not None and custom_stop(seq, out_device))                   # :1225-1231
+                if gather is not None:
+                    gather.step_update(self.lookahead_cache, next_tokens, branch_length, done=finished)
+                else:
+                    self.lookahead_cache.stream_put(next_tokens, branch_length=branch_length + 1, final=False,
+                                                    mode='output', idx=0)
                 te = time.time()
                 decoding_kwargs['fts'].append(te - ts)
                 ts = te
                 if finished:
-                    self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=0)
+                    if gather is not None:
+                        gather.drain(self.lookahead_cache, branch_length)          # until every rank's sequence has finished
+                        gather.flush(self.lookahead_cache, branch_length)
+                    else:
+                        self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=0)
                     flushed = True
                     break
                 if native_loop:
@@ -342,7 +368,7 @@ class LookaheadPreTrainedModel(object):
             # an exception mid-generation must not leave this request's stream buffer / input frequencies behind (they would
             # mix into the next request); the reference flushes on the normal path only (pretrained_model.py:1236-1239)
             if not flushed:
-                self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=0)
+                self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=tidx)
         if streamer is not None:
             streamer.end()
         sequences = torch.tensor([seq], dtype=torch.long, device=out_device)
@@ -416,7 +442,8 @@ class LookaheadPreTrainedModel(object):
         if input_ids is None:
             raise ValueError('generate() needs input_ids')
         ga, model_kwargs = resolve_generate_args(self.generation_config, input_ids.size(1), generation_config=generation_config,
-                                                 logits_processor=logits_processor, stopping_criteria=stopping_criteria, **kwargs)
+                                                 logits_processor=logits_processor, stopping_criteria=stopping_criteria,
+                                                 device=getattr(getattr(self, 'engine', None), 'device', None), **kwargs)
         attention_mask = model_kwargs.pop('attention_mask', None)
         dk = ga.decoding_kwargs
         if streamer is not None:

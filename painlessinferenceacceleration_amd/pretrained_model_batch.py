@@ -171,9 +171,40 @@ class LookaheadPreTrainedModel(object):
         eng = self.engine
         assert bs <= eng.n_slots, f'batch of {bs} needs an engine with n_slots >= {bs} (has {eng.n_slots})'
         cap = eng._capacity() if hasattr(eng, '_capacity') else eng.max_keys
-        assert stop_max_length + min(max(int(decoding_length), 64), _lib.LA_TREE_WIDE_MAX) + 1 <= cap, f'engine KV capacity {cap} per slot is too small'
-        for i in range(bs):                                                     # :1204-1207 (pads included, as there)
-            self.lookahead_cache.put(ids0[i, 1:-1].tolist(), branch_length=branch_length + 1, mode='input', idx=i)
+        # rows one sample's tree can take in a step: at most decoding_length (the whole budget once the other samples have retired,
+        # :713), never more than one pass can give it (lookahead_prepare_inputs_for_generation: 64 rows unless the host trie's hier
+        # walk feeds a multi-block engine); a verify block is reserved whole
+        _fmt = str(decoding_kwargs.get('decoding_mode', 'hier')).split('_')[0]
+        _wide_ok = _fmt == 'hier' and not decoding_kwargs.get('device_trie', False) and bool(getattr(eng, 'max_blocks', 0))
+        _cap_rows = min(_lib.LA_TREE_WIDE_MAX, 64 * int(eng.max_blocks)) if _wide_ok else _lib.LA_TREE_MAX
+        _per = max(min(int(decoding_length), _cap_rows), _lib.LA_TREE_MAX)
+        assert stop_max_length + _per + 1 <= cap, f'engine KV capacity {cap} per slot is too small'
+        # Sharded job (distributed.py): decoding_kwargs['gather'] = AcceptedTokenGather(..., b_loc=bs, mode=...).  This rank decodes ITS
+        # bs sequences; local row i is global batch index gather.global_index(i) in every trie call, the per-step stream_put_many
+        # becomes the all-gather of all ranks' accepted tokens applied in batch-index order (:1254-1259), and the rank keeps serving
+        # the collective until every rank has finished.
+        gather = decoding_kwargs.get('gather', None)
+        if gather is not None:
+            assert gather.b_loc == bs, f'AcceptedTokenGather(b_loc={gather.b_loc}) vs a local batch of {bs}'
+            assert not decoding_kwargs.get('device_trie', False), 'sharded decoding keeps the trie replicas on the host'
+        gi = (lambda b_: gather.global_index(b_)) if gather is not None else (lambda b_: b_)
+        # decoding_kwargs['overlap_trie_update'] (extension, off by default: the reference updates before it queries): the trie update
+        # of step k runs on the host AFTER the verify pass of step k + 1 has been queued — drafts see a step's tokens one step later
+        # (the split-phase order of the sharded job), emitted tokens are unaffected
+        overlap_put = bool(decoding_kwargs.get('overlap_trie_update', False)) and gather is None
+        deferred_put = [None]
+
+        def run_deferred_put():
+            if deferred_put[0] is not None:
+                self.lookahead_cache.stream_put_many(deferred_put[0], branch_length=branch_length + 1, final=False)
+                deferred_put[0] = None
+
+        if gather is not None:            # every replica holds every sequence's input frequencies, put in batch-index order
+            for b_, p_ in enumerate(gather.exchange_prompts([ids0[i, 1:-1].tolist() for i in range(bs)])):
+                self.lookahead_cache.put(p_, branch_length=branch_length + 1, mode='input', idx=b_)
+        else:
+            for i in range(bs):                                                 # :1204-1207 (pads included, as there)
+                self.lookahead_cache.put(ids0[i, 1:-1].tolist(), branch_length=branch_length + 1, mode='input', idx=i)
         rows = [ids0[i].tolist() for i in range(bs)]      # padded-coordinate token rows; cursor = len(row) - 1
         finished_rows = [None] * bs
         batch_indices = list(range(bs))
@@ -234,9 +265,13 @@ class LookaheadPreTrainedModel(object):
                 # the NEXT step's kernels are queued (the device image needs nothing from the host), so it overlaps the GPU step
                 replay_due = [(b, next_token_list[k]) for k, b in enumerate(batch_indices)]
                 put_on_device = False
-            else:                                                               # :1254-1259, one native call for the batch
-                self.lookahead_cache.stream_put_many([(b, [x for x in next_token_list[k] if x != -1])
-                                                      for k, b in enumerate(batch_indices)], branch_length=branch_length + 1, final=False)
+            elif gather is None:                                                # :1254-1259, one native call for the batch
+                puts = [(b, [x for x in next_token_list[k] if x != -1]) for k, b in enumerate(batch_indices)]
+                if overlap_put:
+                    run_deferred_put()                                          # (a step that found no overlap point)
+                    deferred_put[0] = puts
+                else:
+                    self.lookahead_cache.stream_put_many(puts, branch_length=branch_length + 1, final=False)
             max_cur = max(max_cur, max(len(rows[b]) - 1 for b in batch_indices))
             keep = []
             for k, b in enumerate(batch_indices):                               # :1269-1276 + _early_stop :937-980
@@ -245,6 +280,13 @@ class LookaheadPreTrainedModel(object):
                     finished_rows[b] = list(rows[b])
                 else:
                     keep.append(b)
+            if gather is not None:
+                # one collective per loop iteration on every rank: this rank's lists in local row order ([] for retired rows), DONE once
+                # no row is left; strict = gathered and applied now, split-phase = applied under the next verify pass (overlap below)
+                mine = [[] for _ in range(bs)]
+                for k, b in enumerate(batch_indices):
+                    mine[b] = [x for x in next_token_list[k] if x != -1]
+                gather.step_update(self.lookahead_cache, mine, branch_length, done=not keep)
             batch_indices = keep
             te = time.time()
             decoding_kwargs['fts'].append(te - ts)
@@ -300,7 +342,7 @@ class LookaheadPreTrainedModel(object):
                     decoding_kwargs['dls'].append(width)
                     decoding_kwargs['edls'].append(len(next_token_list[k]))
                 continue
-            drafts = self.lookahead_prepare_inputs_for_generation([rows[b] for b in batch_indices], batch_indices,
+            drafts = self.lookahead_prepare_inputs_for_generation([rows[b] for b in batch_indices], [gi(b) for b in batch_indices],
                                                                   decoding_kwargs)
             segments = []
             for b, (d_ids, d_rm) in zip(batch_indices, drafts):
@@ -309,6 +351,9 @@ class LookaheadPreTrainedModel(object):
                 cur = len(rows[b]) - 1
                 segments.append((b, d_ids, d_rm, 2 if sequential else 0, stop_max_length - cur - 1))
             if sum(len(sg[1]) for sg in segments) <= _lib.LA_TREE_MAX and all(np.ndim(sg[2]) == 1 for sg in segments):
+                run_deferred_put()                                     # (bstep has no asynchronous form: same order, no overlap)
+                if gather is not None:
+                    gather.overlap(self.lookahead_cache, branch_length)
                 emitted = eng.bstep(segments)                          # the whole batch shares one 64-row block
                 if sequential:
                     base, logits = eng.bstep_rows(), eng.logits()
@@ -332,7 +377,19 @@ class LookaheadPreTrainedModel(object):
                 groups.append(cur_g)
                 for group in groups:
                     wide_pass = any(len(sg[1]) > 64 or np.ndim(sg[2]) == 2 for sg in group)
-                    out = eng.mstep_trees(group) if wide_pass else eng.mstep(group)
+                    if wide_pass or not hasattr(eng, 'mstep_async'):
+                        run_deferred_put()
+                        if gather is not None:
+                            gather.overlap(self.lookahead_cache, branch_length)
+                        out = eng.mstep_trees(group) if wide_pass else eng.mstep(group)
+                    else:
+                        # queue the pass, then do the host work nothing on the device waits for — the deferred trie update / the
+                        # previous step's gather and its puts — while the GPU verifies
+                        eng.mstep_async(group)
+                        run_deferred_put()
+                        if gather is not None:
+                            gather.overlap(self.lookahead_cache, branch_length)
+                        out = eng.mstep_finish()
                     if sequential:
                         logits, kept, base = eng.mlogits(), [], 0
                         for sg in group:
@@ -355,8 +412,13 @@ class LookaheadPreTrainedModel(object):
         if replay_due is not None:                                              # the last step's update (the loop ended before another launch)
             self._device_trie(decoding_kwargs['_n_samples'], dev_put).replay(replay_due, branch_length + 1, calls=replay_calls)
             replay_due = None
-        for i in range(bs):                                                     # :1288-1290
-            self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=i)
+        run_deferred_put()
+        if gather is not None:
+            gather.drain(self.lookahead_cache, branch_length)                   # until every rank has finished its sequences
+            gather.flush(self.lookahead_cache, branch_length)                   # :1288-1290 for all B sequences, batch-index order
+        else:
+            for i in range(bs):                                                 # :1288-1290
+                self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=i)
         if streamer is not None:
             streamer.end()
         seqs = np.full((bs, max_cur + 1), pad, dtype=np.int64)
@@ -404,9 +466,11 @@ class LookaheadPreTrainedModel(object):
 
     @torch.no_grad()
     def greedy_search(self, input_ids, max_length, attention_mask=None, eos_token_id=None, pad_token_id=0,
-                      logits_processor=None, do_sample=False):
+                      logits_processor=None, do_sample=False, stopping_criteria=None):
         """Plain decoding of the whole batch through the same engine (one row per sample per block).  With a processor list or
-        sampling every token is picked on the host from the sample's logits row (forward-only step + la_llama_bcommit)."""
+        sampling every token is picked on the host from the sample's logits row (forward-only step + la_llama_bcommit).
+        `stopping_criteria`: the caller's criteria besides the length bound (MaxTimeCriteria, custom ones) are evaluated per
+        row after every token, on the row's own tokens — a row they stop is retired like one that met eos."""
         ids0 = input_ids.cpu().numpy().astype(np.int64)
         bs, P = ids0.shape
         am = np.ones_like(ids0) if attention_mask is None else attention_mask.cpu().numpy().astype(np.int64)
@@ -438,7 +502,13 @@ class LookaheadPreTrainedModel(object):
         else:
             first = eng.mprefill_many(prompts) if multi else eng.bprefill_many(prompts)
         rows = [ids0[i].tolist() + [first[i]] for i in range(bs)]
-        live = [b for b in range(bs) if len(rows[b]) < max_length and rows[b][-1] not in eos]
+        custom_stop = _custom_stop(stopping_criteria)
+
+        def alive(b):
+            return len(rows[b]) < max_length and rows[b][-1] not in eos and \
+                not (custom_stop is not None and custom_stop(rows[b], input_ids.device))
+
+        live = [b for b in range(bs) if alive(b)]
         while live:
             out = eng.bstep([(b, np.asarray(rows[b][-1:], dtype=np.int32), _ONE, 2 if host_pick else 0, 1) for b in live])
             if host_pick:
@@ -449,7 +519,7 @@ class LookaheadPreTrainedModel(object):
             else:
                 for b in live:
                     rows[b].append(out[b][0])
-            live = [b for b in live if len(rows[b]) < max_length and rows[b][-1] not in eos]
+            live = [b for b in live if alive(b)]
         L = max(len(r) for r in rows)
         seqs = np.full((bs, L), pad_token_id, dtype=np.int64)
         for b in range(bs):
@@ -469,7 +539,8 @@ class LookaheadPreTrainedModel(object):
         if input_ids is None:
             raise ValueError('generate() needs input_ids')
         ga, model_kwargs = resolve_generate_args(self.generation_config, input_ids.size(1), generation_config=generation_config,
-                                                 logits_processor=logits_processor, stopping_criteria=stopping_criteria, **kwargs)
+                                                 logits_processor=logits_processor, stopping_criteria=stopping_criteria,
+                                                 device=getattr(getattr(self, 'engine', None), 'device', None), **kwargs)
         attention_mask = model_kwargs.pop('attention_mask', None)
         dk = ga.decoding_kwargs
         if dk.get('use_lookahead', False) and dk.get('decoding_length', 64) > 1 and dk.get('branch_length', 12) > 0:
@@ -484,5 +555,6 @@ class LookaheadPreTrainedModel(object):
                                  eos_token_id=ga.eos_token_id if ga.eos_token_id is not None
                                  else getattr(self.generation_config, 'eos_token_id', None),
                                  pad_token_id=ga.pad_token_id if ga.pad_token_id is not None else 0,
-                                 logits_processor=procs if len(procs) else None, do_sample=ga.do_sample)
+                                 logits_processor=procs if len(procs) else None, do_sample=ga.do_sample,
+                                 stopping_criteria=ga.stopping_criteria)
         return LookaheadDecoderOnlyOutput(sequences=out, kwargs={}) if ga.return_dict_in_generate else out

@@ -30,7 +30,7 @@ def pytest_sessionstart(session):
     spec = os.environ.get('LA_LAB_SET')
     if not spec:
         return
-    from painlessinferenceacceleration_amd._lib import check, lib
+    from painlessinferenceacceleration_amd._lib import check, lab_set
     for kv in spec.split(','):
         k, v = kv.split('=')
-        check(lib.la_lab_set(int(k), int(v)), 'la_lab_set')
+        check(lab_set(int(k), int(v)), 'la_lab_set')          # every loaded build, and the fp16 build when it loads later

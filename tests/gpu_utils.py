@@ -110,11 +110,11 @@ def pack_planned(kind, mats, n_wg):
 def debug_knob(key, value):
     """la_lab_set(key, value) for the duration of a block (capture-time knobs re-capture the step graphs on both edges)."""
     old = lib.la_lab_get(key)
-    check(lib.la_lab_set(key, value), 'debug_set')
+    check(_lib.lab_set(key, value), 'debug_set')          # every loaded build: an fp16 engine reads its own library's knobs
     try:
         yield
     finally:
-        lib.la_lab_set(key, old)
+        _lib.lab_set(key, old)
 
 
 @contextlib.contextmanager

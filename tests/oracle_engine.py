@@ -89,6 +89,14 @@ class OracleEngine(object):
         self.n_keys += len(rows)
         return toks, len(rows)
 
+    # asynchronous surface (LlamaVerifyEngine.step_async / step_finish): the stand-in computes at once, the result waits
+    def step_async(self, ids, rowmask, mode=0, eager=False):
+        self._async = self.step(ids, rowmask, mode)
+
+    def step_finish(self):
+        out, self._async = self._async, None
+        return out
+
 
 class OracleBatchEngine(object):
     """TEST-ONLY stand-in for LlamaVerifyEngine(n_slots=N[, max_blocks=M]): the cursor-batch surface (reset_slot / bprefill /
@@ -176,6 +184,13 @@ class OracleBatchEngine(object):
             out.append(toks)
             lgs.append(torch.cat([lg, torch.zeros((64 - lg.shape[0], lg.shape[1]), dtype=lg.dtype)], 0))
         self._mlogits = torch.cat(lgs, 0)
+        return out
+
+    def mstep_async(self, blocks, eager=False):
+        self._masync = self.mstep(blocks)
+
+    def mstep_finish(self):
+        out, self._masync = self._masync, None
         return out
 
     def mstep_trees(self, trees, eager=False):

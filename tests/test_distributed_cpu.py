@@ -172,3 +172,137 @@ def test_native_transport_failure_on_one_rank_falls_back_everywhere():
         assert p.exitcode == 0
     for rank, no_comm, warned, out in got:
         assert no_comm and warned and out == [[10, 20], [11, 21]], (rank, no_comm, warned, out)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Product-level sharded decoding (round 5): lookahead_generation() of both loops under decoding_kwargs['gather'].
+# ---------------------------------------------------------------------------------------------------------------------------
+def _sharded_setup(world, b_loc):
+    """prompts + greedy truths of all B = world * b_loc sequences on the tiny decisive model (every rank computes the same)"""
+    from types import SimpleNamespace
+    from painlessinferenceacceleration_amd.lookahead_cache import LookaheadCache
+    from tests.oracle_engine import OracleBatchEngine, OracleEngine
+    from tests.tiny_model import tiny_decisive_weights, tiny_shape
+    shape = tiny_shape()
+    B, P, n_new = world * b_loc, 20, 60
+    rs = np.random.RandomState(17)
+    prompts = rs.randint(3, shape.vocab, size=(B, P)).astype(np.int64)
+    gen = SimpleNamespace(eos_token_id=None, pad_token_id=0, return_dict_in_generate=True)
+    if b_loc == 1:
+        from painlessinferenceacceleration_amd.pretrained_model import LookaheadPreTrainedModel as Mixin
+
+        class M(Mixin):
+            def __init__(self):
+                self.engine = OracleEngine(shape, tiny_decisive_weights(0, torch.float32), max_length=256)
+                self.generation_config = gen
+                self.lookahead_cache = LookaheadCache(eos_ids=[None])
+        m = M()
+        truths = [m.greedy_search(torch.from_numpy(prompts[b:b + 1]), P + n_new, eos_token_id=None)[0].tolist()[P:] for b in range(B)]
+    else:
+        from painlessinferenceacceleration_amd.pretrained_model_batch import LookaheadPreTrainedModel as Mixin
+
+        class M(Mixin):
+            def __init__(self):
+                self.engine = OracleBatchEngine(shape, tiny_decisive_weights(0, torch.float32), max_length=256, n_slots=max(b_loc, B), max_blocks=max(b_loc, 2))
+                self.generation_config = gen
+                self.lookahead_cache = LookaheadCache(eos_ids=[None])
+        m = M()
+        truths = m.greedy_search(torch.from_numpy(prompts), P + n_new, eos_token_id=None)[:, P:].tolist()
+    return shape, prompts, truths, M, P, n_new
+
+
+def _warm(cache, prompts, truths, vocab):
+    from tests.tiny_model import noisy_copies
+    for b in range(len(truths)):                  # bench.py's warm-up: different noise per sequence -> different accept lengths per rank
+        for c in noisy_copies(prompts[b, -2:].tolist() + truths[b], 6, 0.25 + 0.1 * (b % 2), vocab, seed=40 + b):
+            cache.put(c, branch_length=13, mode='output', idx=-1)
+
+
+def _queries(cache, B, vocab):
+    rng = random.Random(5)
+    res = []
+    for _ in range(150):
+        qy = [rng.randrange(3, vocab) for _ in range(2)]
+        ids, mask, sizes = cache.hier_get(qy, decoding_length=64, branch_length=12, min_output_size=32, mode='mix', idx=rng.randrange(B))
+        res.append((list(ids), mask.tolist(), list(sizes)))
+    return res
+
+
+def _worker_sharded(rank, world, port, b_loc, mode, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from painlessinferenceacceleration_amd.distributed import AcceptedTokenGather
+    shape, prompts, truths, M, P, n_new = _sharded_setup(world, b_loc)
+    m = M()
+    _warm(m.lookahead_cache, prompts, truths, shape.vocab)
+    g = AcceptedTokenGather('cpu', b_loc=b_loc, branch_length=12, mode=mode)
+    record, inner = [], g.finish
+
+    def finish():
+        per = inner()
+        record.append([list(t) for t in per])
+        return per
+    g.finish = finish
+    mine = [g.global_index(i) for i in range(b_loc)]
+    dk = {'use_lookahead': True, 'decoding_mode': 'hier', 'decoding_length': 64, 'branch_length': 12, 'max_query_length': 2,
+          'stop_words': {}, 'gather': g}
+    if b_loc > 1:
+        dk['per_sample_budget'] = True
+    out = m.lookahead_generation(torch.from_numpy(prompts[mine]), stopping_criteria=P + n_new, eos_token_id=[None], pad_token_id=0,
+                                 return_dict_in_generate=True, decoding_kwargs=dk)
+    q.put((rank, out.sequences.cpu().numpy().tolist(), out.kwargs['edls'], record, _queries(m.lookahead_cache, world * b_loc, shape.vocab),
+           m.lookahead_cache.stats()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('b_loc,mode', [(1, 'strict'), (1, 'split-phase'), (2, 'strict'), (2, 'split-phase')])
+def test_lookahead_generation_sharded_over_two_ranks(b_loc, mode):
+    """decoding_kwargs['gather'] in BOTH product loops (bs=1: pretrained_model.py, B_loc=2: pretrained_model_batch.py), 2 gloo ranks:
+    (1) every rank's output == plain greedy decoding of its own prompts (lookahead is lossless, sharded or not);
+    (2) the ranks finish at different steps and still leave together: same number of collectives on both, the last one all-DONE;
+    (3) the trie replicas are identical (150 queries over every input-frequency plane, node counts);
+    (4) they equal a single-process cache that received the same prompts and the same per-step token lists in global batch-index
+        order (the order of pretrained_model_batch.py:1254-1259) and the final flush of all B sequences."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, world, port, b_loc, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = {}
+    for _ in range(world):
+        got = q.get(timeout=900)
+        outs[got[0]] = got[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    shape, prompts, truths, M, P, n_new = _sharded_setup(world, b_loc)
+    B = world * b_loc
+    for r in range(world):
+        seqs = outs[r][0]
+        for i in range(b_loc):
+            b = i * world + r
+            assert seqs[i][:P] == prompts[b].tolist() and seqs[i][P:P + n_new] == truths[b][:n_new], (r, i)
+        assert np.mean(outs[r][1][b_loc:]) > 2.0                  # drafts were accepted: the steps carried real trees
+    rec0, rec1 = outs[0][2], outs[1][2]
+    assert rec0 == rec1 and len(rec0) >= 3                        # same collectives, same contents, on both ranks
+    # a rank that had finished kept serving the collective with empty lists while the other one still emitted tokens (drain)
+    assert any(any(len(t) == 0 for t in per) and any(len(t) > 0 for t in per) for per in rec0)
+    assert outs[0][3] == outs[1][3] and outs[0][4]['n_nodes'] == outs[1][4]['n_nodes']
+    # (4) single-process cache, global batch-index order
+    from painlessinferenceacceleration_amd.lookahead_cache import LookaheadCache
+    ref = LookaheadCache(eos_ids=[None])
+    _warm(ref, prompts, truths, shape.vocab)
+    for b in range(B):
+        ref.put(prompts[b, 1:].tolist() if b_loc == 1 else prompts[b, 1:-1].tolist(), branch_length=13, mode='input', idx=b)
+    for per in rec0:
+        assert len(per) == B
+        for b, toks in enumerate(per):
+            ref.stream_put(toks, branch_length=13, final=False, mode='output', idx=b)
+    for b in range(B):
+        ref.stream_put([], branch_length=13, final=True, mode='output', idx=b)
+    assert ref.stats()['n_nodes'] == outs[0][4]['n_nodes']
+    assert _queries(ref, B, shape.vocab) == outs[0][3]

@@ -503,3 +503,50 @@ def test_load_hf_checkpoint_skips_consolidated_safetensors(tmp_path):
     save_file({'layers.0.w': torch.ones(4)}, str(tmp_path / 'consolidated.00.safetensors'))
     _, sd = load_hf_checkpoint(str(tmp_path))
     assert sorted(sd) == ['model.embed_tokens.weight']
+
+
+def test_batch_loop_overlapped_trie_update_is_lossless_and_flushes():
+    """decoding_kwargs['overlap_trie_update'] (extension): the trie update of step k runs after the verify pass of step k + 1 has
+    been queued (LlamaVerifyEngine.mstep_async / mstep_finish) — drafts see a step's tokens one step later.  Tokens stay exactly the
+    greedy ones, the trie ends up with the same n-grams as the in-order run (every deferred put is applied before the final flush),
+    and a second request on the warmed cache reproduces the first."""
+    from painlessinferenceacceleration_amd.pretrained_model_batch import LookaheadPreTrainedModel as BatchMixin
+    from tests.oracle_engine import OracleBatchEngine
+    from tests.tiny_model import noisy_copies, tiny_decisive_weights
+
+    class BModel(BatchMixin):
+        def __init__(self):
+            self.engine = OracleBatchEngine(tiny_shape(), tiny_decisive_weights(0, torch.float32), max_length=256, n_slots=3, max_blocks=3)
+            self.generation_config = type('G', (), {'pad_token_id': 0, 'eos_token_id': None, 'return_dict_in_generate': True})()
+            self.lookahead_cache = LookaheadCache(eos_ids=[])
+
+    shape = tiny_shape()
+    rs = np.random.RandomState(8)
+    B, P, n_new = 3, 14, 50
+    ids = rs.randint(3, shape.vocab, size=(B, P)).astype(np.int64)
+    truth = BModel().greedy_search(torch.from_numpy(ids), P + n_new, eos_token_id=None)[:, P:].tolist()
+    stats = {}
+    for overlap in (False, True):
+        m = BModel()
+        calls = []
+        inner_async, inner_put = m.engine.mstep_async, m.lookahead_cache.stream_put_many
+        m.engine.mstep_async = lambda blocks, eager=False: (calls.append('async'), inner_async(blocks))[1]
+        m.lookahead_cache.stream_put_many = lambda *a, **k: (calls.append('put'), inner_put(*a, **k))[1]
+        for b in range(B):
+            for c in noisy_copies(ids[b, -2:].tolist() + truth[b], 6, 0.3, shape.vocab, seed=20 + b):
+                m.lookahead_cache.put(c, branch_length=13, mode='output', idx=-1)
+        dk = {'use_lookahead': True, 'decoding_length': 64, 'branch_length': 12, 'stop_words': {}, 'per_sample_budget': True,
+              'overlap_trie_update': overlap}
+        for rep in range(2):
+            out = m.lookahead_generation(torch.from_numpy(ids), stopping_criteria=P + n_new, eos_token_id=[None], pad_token_id=0,
+                                         return_dict_in_generate=True, decoding_kwargs=dict(dk))
+            got = out.sequences.cpu().numpy()
+            for b in range(B):
+                assert got[b, P:P + n_new].tolist() == truth[b][:n_new], (overlap, rep, b)
+            assert np.mean(out.kwargs['edls'][B:]) > 2
+        stats[overlap] = m.lookahead_cache.stats()['n_nodes']
+        # in-order: the update of the first tokens precedes the first pass; overlapped: every put follows the pass it hides under (and
+        # the last one is applied before the final flush)
+        assert calls[0] == ('async' if overlap else 'put') and 'async' in calls, calls[:6]
+        stats[('puts', overlap)] = calls.count('put')
+    assert stats[False] == stats[True] and stats[('puts', False)] == stats[('puts', True)]
