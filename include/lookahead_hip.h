@@ -43,7 +43,7 @@ extern "C" {
 #define LA_MOE_MAX_E      8   /* experts per mixture-of-experts layer (Mixtral: 8, top-2) */
 
 /* ABI version: bumped when a signature changes. */
-#define LA_ABI_VERSION  9    /* bumped whenever a struct layout or an entry point changes */
+#define LA_ABI_VERSION  10   /* bumped whenever a struct layout or an entry point changes */
 int          la_abi_version(void);   /* == LA_ABI_VERSION of the header the library was built from */
 /* Storage / MFMA-input type of the loaded library: 0 = bfloat16 (liblookahead_hip.so), 1 = float16 (liblookahead_hip_f16.so, the
  * dtype the reference's examples and benchmarks run, lookahead/benchmarks/llama_benchmark.py:27).  The two libraries are the same
@@ -102,6 +102,16 @@ int la_cache_one_get(la_cache* c, const int32_t* token_ids, int n,
                      int decoding_length, int branch_length, int mode, int idx,
                      int cap, int32_t* out_ids, int32_t out_sizes[2], int32_t* out_nsizes,
                      int32_t* out_n);
+/* par_get() (lookahead_cache.py:441-488): hier_get's draft re-laid as independent root-to-leaf chains (maximal ancestor sets only,
+ * draft order, truncated to len(hier draft) - 1 rows) under a block mask in which a row sees the root and the rows of its own chain
+ * up to itself.  Same buffers as la_cache_hier_get: out_ids[cap]; out_rowmask (optional) cap * W words, W = ceil(decoding_length / 64);
+ * out_mask (optional) row-major int64 [*out_n][*out_n]; out_sizes[0] = rows behind the root, *out_nsizes = 1.  An empty query yields
+ * *out_n = 0 (the reference raises IndexError there). */
+int la_cache_par_get(la_cache* c, const int32_t* token_ids, int n,
+                     int decoding_length, int branch_length,
+                     int min_input_size, int min_output_size, int mode, int idx,
+                     int cap, int32_t* out_ids, uint64_t* out_rowmask,
+                     int64_t* out_mask, int32_t out_sizes[2], int32_t* out_nsizes, int32_t* out_n);
 /* bat_get() (lookahead_cache.py:519-561) in its device-path form: the per-sample drafts of a batch in one call, unpadded
  * (no [bs,T,W] canvas).  queries: [bs][q_stride] (first nq[b] used); per-sample budget decoding_length // bs and
  * min_output_size = max(budget // 2, 1) as in the reference; one_branch != 0 selects one_get.  Outputs: rows of `cap`

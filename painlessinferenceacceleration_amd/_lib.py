@@ -13,7 +13,7 @@ LIB_PATH_F16 = os.path.join(_HERE, "liblookahead_hip_f16.so")      # float16 bui
 LA_DTYPE_BF16, LA_DTYPE_F16 = 0, 1
 
 LA_OK = 0
-ABI_VERSION = 9         # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
+ABI_VERSION = 10        # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
 LA_MODE_INPUT, LA_MODE_OUTPUT, LA_MODE_MIX = 0, 1, 2
 LA_TREE_MAX = 64
 LA_MOE_MAX_E = 8
@@ -133,6 +133,7 @@ PROTOTYPES = {
     "la_cache_stream_put_many": (i32, vp, pi32, pi32, pi32, i32, i32, i32),
     "la_cache_hier_get": (i32, vp, pi32, i32, i32, i32, i32, i32, i32, i32, i32, pi32, pi32, pu64, pi64, pi32, pi32, pi32),
     "la_cache_one_get": (i32, vp, pi32, i32, i32, i32, i32, i32, i32, pi32, pi32, pi32, pi32),
+    "la_cache_par_get": (i32, vp, pi32, i32, i32, i32, i32, i32, i32, i32, i32, pi32, pu64, pi64, pi32, pi32, pi32),
     "la_cache_bat_get_packed": (i32, vp, pi32, pi32, i32, i32, i32, i32, i32, pi32, i32, i32, pi32, pu64, pi32, pi32, pi32),
     "la_cache_reset_input_freqs": (i32, vp, i32),
     "la_cache_squeeze": (i32, vp),

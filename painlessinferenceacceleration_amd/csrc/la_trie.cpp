@@ -690,6 +690,89 @@ int la_cache_hier_get(la_cache* c, const int32_t* q, int nq, int decoding_length
     return LA_OK;
 }
 
+// par_get (:441-488): the hierarchical draft re-laid as independent root-to-leaf chains under a block mask.
+//   rows are walked from last to first; a row's ancestor set (columns 1.. of its mask row, :454-455) is kept unless an already kept
+//   set covers it (:457-462: only maximal paths survive); the kept paths, in draft order (:464), are laid out one after another,
+//   each truncated to what is left of the budget true_decoding_length = len(hier ids) - 1 (:466-477); mask = lower-triangular ones
+//   with masks[start : start + len, 1 : start] = 0 per chain (:479-486): row r of a chain starting at `start` sees the root and
+//   rows start..r.  sizes = [rows behind the root] (:488).
+int la_cache_par_get(la_cache* c, const int32_t* q, int nq, int decoding_length, int branch_length, int min_input_size,
+                     int min_output_size, int mode, int idx, int cap, int32_t* out_ids, uint64_t* out_rowmask, int64_t* out_mask,
+                     int32_t out_sizes[2], int32_t* out_nsizes, int32_t* out_n) {
+    if (!c || nq < 0 || (nq > 0 && !q) || !out_ids || !out_sizes || !out_nsizes || !out_n || cap < 1) return LA_E_ARG;
+    static thread_local std::vector<int32_t> hids, hpar;
+    static thread_local std::vector<uint64_t> hrows;
+    const int W = decoding_length > 64 && decoding_length <= cap ? (decoding_length + 63) / 64 : 1;
+    hids.assign((size_t)cap, 0); hpar.assign((size_t)cap, 0); hrows.assign((size_t)cap * W, 0);
+    int32_t hs[2] = {0, 0}, hns = 0, T = 0;
+    const int rc = la_cache_hier_get(c, q, nq, decoding_length, branch_length, min_input_size, min_output_size, mode, idx, cap,
+                                     hids.data(), hpar.data(), hrows.data(), nullptr, hs, &hns, &T);
+    if (rc != LA_OK) return rc;
+    out_sizes[0] = out_sizes[1] = 0; *out_nsizes = 1;
+    if (T == 0) { *out_n = 0; return LA_OK; }            // (the reference raises IndexError on an empty query: nothing to lay out)
+    const int budget = T - 1;
+    // member set of row i = its mask row without column 0, as a bitset over columns 1..T-1 (bit j-1 <=> column j)
+    auto members = [&](int row, uint64_t* m) {
+        for (int w = 0; w < W; ++w) {
+            uint64_t lo = hrows[(size_t)row * W + w] >> 1;
+            if (w + 1 < W) lo |= hrows[(size_t)row * W + w + 1] << 63;
+            m[w] = lo;
+        }
+    };
+    std::vector<uint64_t> kept;                            // kept sets, W words each, in discovery order (last row first)
+    std::vector<uint64_t> m((size_t)W);
+    for (int row = budget; row >= 1; --row) {
+        members(row, m.data());
+        bool covered = false;
+        for (size_t k = 0; k < kept.size() / (size_t)W && !covered; ++k) {
+            bool sub = true;
+            for (int w = 0; w < W; ++w) sub = sub && (m[w] & ~kept[k * W + w]) == 0ull;
+            covered = sub;
+        }
+        if (!covered) kept.insert(kept.end(), m.begin(), m.end());
+    }
+    const int nk = (int)(kept.size() / (size_t)W);
+    int used = 0, n = 1;
+    out_ids[0] = hids[0];
+    if (out_rowmask) { out_rowmask[0] = 1ull; for (int w = 1; w < W; ++w) out_rowmask[w] = 0ull; }
+    for (int k = nk - 1; k >= 0 && used < budget; --k) {  // reversed: draft order
+        const int start = n;
+        for (int col = 0; col < budget && used < budget; ++col) {
+            if (!((kept[(size_t)k * W + (col >> 6)] >> (col & 63)) & 1ull)) continue;
+            out_ids[n] = hids[col + 1];
+            if (out_rowmask) {
+                uint64_t* r = out_rowmask + (size_t)n * W;
+                for (int w = 0; w < W; ++w) r[w] = 0ull;
+                r[0] = 1ull;
+                for (int j = start; j <= n; ++j) r[j >> 6] |= 1ull << (j & 63);
+            }
+            ++n; ++used;
+        }
+    }
+    if (out_mask)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) out_mask[(size_t)i * n + j] = 0;
+    if (out_mask) {
+        int i = 0;
+        out_mask[0] = 1;
+        // rebuild from the chain structure: a row sees the root and the rows of its own chain up to itself
+        int start = 1;
+        for (int k = nk - 1, u = 0; k >= 0 && u < budget; --k) {
+            int len = 0;
+            for (int col = 0; col < budget && u + len < budget; ++col)
+                if ((kept[(size_t)k * W + (col >> 6)] >> (col & 63)) & 1ull) ++len;
+            for (i = start; i < start + len; ++i) {
+                out_mask[(size_t)i * n] = 1;
+                for (int j = start; j <= i; ++j) out_mask[(size_t)i * n + j] = 1;
+            }
+            start += len; u += len;
+        }
+    }
+    out_sizes[0] = n - 1;
+    *out_n = n;
+    return LA_OK;
+}
+
 // Tree.get_one_branch (:171-222) + one_get (:490-517)
 int la_cache_one_get(la_cache* c, const int32_t* q, int nq, int decoding_length, int branch_length, int mode,
                      int idx, int cap, int32_t* out_ids, int32_t out_sizes[2], int32_t* out_nsizes, int32_t* out_n) {

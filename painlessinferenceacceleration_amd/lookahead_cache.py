@@ -267,10 +267,20 @@ class LookaheadCache(object):
         Walk rows from last to first, keep a row's ancestor set unless an already kept set covers it (so only
         maximal paths survive), lay the kept paths out one after another (truncated to the draft budget) under
         a block mask in which every chain sees the root and itself only."""
-        output_ids, decoding_masks, _ = self.hier_get(token_ids, decoding_length=decoding_length,
-                                                      branch_length=branch_length, min_input_size=min_input_size,
-                                                      min_output_size=min_output_size, mode=mode, idx=idx)
-        return self.par_layout(output_ids, decoding_masks)
+        assert mode in ('input', 'output', 'mix')
+        self._sync_live()
+        self._alloc(max(int(decoding_length), 1))
+        arr, p, n = _as_i32(token_ids)
+        # retrieval + re-layout in one native call (la_cache_par_get); par_layout() below is the same re-layout for a draft that
+        # came from somewhere else (the device trie)
+        check(lib.la_cache_par_get(self._h, p, n, int(decoding_length), int(branch_length), int(min_input_size), int(min_output_size),
+                                   _MODES[mode], int(idx), self._cap, self._p_ids, self._p_rowmask, self._p_mask, self._p_sizes,
+                                   self._r_nsizes, self._r_n), 'par_get')
+        n_out = self._n.value
+        if n_out == 0:
+            return [], np.tril(np.ones((1, 1)), 0), [0]
+        return (self._ids[:n_out].tolist(), self._mask[:n_out * n_out].reshape(n_out, n_out).astype(np.float64),      # float64, as :480
+                self._sizes[:1].tolist())
 
     @staticmethod
     def par_layout(output_ids, decoding_masks):

@@ -475,3 +475,49 @@ def test_stream_put_many_equals_sequential_stream_puts():
             assert ra[0] == rb[0] and np.array_equal(ra[1], rb[1]) and ra[2] == rb[2]
     assert a.stats() == b.stats()
     a.stream_put_many([], branch_length=9)
+
+
+def test_par_get_c_abi_equals_python_layout_and_oracle():
+    """la_cache_par_get (round 5: the re-layout of lookahead_cache.py:441-488 behind the C ABI) against (a) the Python
+    re-layout of the native hier draft (LookaheadCache.par_layout, what round 4 shipped), (b) the oracle's par_get — ids, float64
+    mask, sizes — on random tries at budgets below and above one 64-row word, and the packed row masks against the dense mask."""
+    import ctypes as C
+    from oracle.trie_oracle import TrieOracle
+    from painlessinferenceacceleration_amd import _lib
+    rng = random.Random(21)
+    nat, ora = LookaheadCache(eos_ids=[None]), TrieOracle(eos_ids=[None])
+    phrases = [[rng.randrange(3, 40) for _ in range(rng.randint(3, 30))] for _ in range(40)]
+    for _ in range(300):
+        seq = []
+        while len(seq) < 60:
+            seq.extend(phrases[rng.randrange(40)])
+        bl_put = rng.choice([8, 13, 33])
+        for c in (nat, ora):
+            c.put(seq, branch_length=bl_put, mode='output', idx=-1)
+    n_multi = 0
+    for dl, bl in ((16, 8), (64, 12), (100, 20), (200, 32)):
+        rngq = random.Random(dl)
+        for _ in range(120):
+            q = [rngq.randrange(3, 40) for _ in range(rngq.randint(1, 2))]
+            ids, mask, sizes = nat.par_get(q, decoding_length=dl, branch_length=bl, min_output_size=dl // 2, mode='mix', idx=0)
+            h_ids, h_mask, _ = nat.hier_get(q, decoding_length=dl, branch_length=bl, min_output_size=dl // 2, mode='mix', idx=0)
+            p_ids, p_mask, p_sizes = LookaheadCache.par_layout(h_ids, h_mask)
+            assert ids == p_ids and sizes == p_sizes and mask.dtype == np.float64 and np.array_equal(mask, p_mask), (dl, q)
+            o_ids, o_mask, o_sizes = ora.par_get(q, decoding_length=dl, branch_length=bl, min_output_size=dl // 2, mode='mix', idx=0)
+            assert ids == list(o_ids) and sizes == list(o_sizes) and np.array_equal(mask, np.asarray(o_mask)), (dl, q)
+            # packed rows of the same call
+            n = len(ids)
+            W = (dl + 63) // 64
+            rm = np.zeros(max(dl, 1) * W, dtype=np.uint64)
+            out_ids = np.zeros(max(dl, 1), dtype=np.int32)
+            sz, nsz, nn = (C.c_int32 * 2)(), C.c_int32(), C.c_int32()
+            qa = (C.c_int32 * len(q))(*q)
+            assert _lib.lib.la_cache_par_get(nat._h, qa, len(q), dl, bl, 0, dl // 2, 2, 0, max(dl, 1), out_ids.ctypes.data_as(_lib.pi32),
+                                             rm.ctypes.data_as(_lib.pu64), None, sz, C.byref(nsz), C.byref(nn)) == 0
+            assert nn.value == n and nsz.value == 1 and sz[0] == sizes[0] and out_ids[:n].tolist() == ids
+            dense = np.array([[(int(rm[i * W + (j >> 6)]) >> (j & 63)) & 1 for j in range(n)] for i in range(n)], dtype=np.float64)
+            assert np.array_equal(dense, mask), (dl, q)
+            n_multi += int(n > 2 and mask[-1, 1] == 0)
+    assert n_multi > 20           # several chains were laid out (block mask, not one lower triangle)
+    # empty query: nothing to lay out
+    assert nat.par_get([], decoding_length=16, branch_length=8)[0] == []
