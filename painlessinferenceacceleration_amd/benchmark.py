@@ -13,6 +13,10 @@ Prompts are token-id lists (no tokenizer or dataset ships with this repo); pass 
 text.  The Rouge-L `acc` column needs the optional rouge_score package; without it the column reports exact token-match
 rate against the given answers.
 """
+import cProfile
+import io
+import json
+import pstats
 import time
 
 import torch
@@ -30,6 +34,48 @@ class Benchmark(object):
         self.warmup_prompts, self.warmup_answers, self.warmup_ids = [], [], []
 
     # ------------------------------------------------------------------------------------------------ data
+    def load_prompts(self, prompt_dir=None, warmup_prompt_dir=None, max_length=1024):
+        """benchmark.py:79-100: jsonl files with one {"prompt": ..., "answer": ..., "ids": ...} object per line.  `prompt` is text
+        (needs a tokenizer) or, in this repo's synthetic corpora, a token-id list; prompts longer than max_length (characters for
+        text as in the reference's first test, tokens otherwise) are dropped.  Fills .prompts / .answers and, from
+        warmup_prompt_dir, .warmup_prompts / .warmup_answers / .warmup_ids (the ids of the model's own answers: what warm_up() puts)."""
+        def fits(x):
+            if isinstance(x, str):
+                return len(x) <= max_length or (self.tokenizer is not None and len(self.tokenizer.encode(x)) <= max_length)
+            return len(x) <= max_length
+
+        def read(path):
+            prompts, answers, ids = [], [], []
+            with open(path, 'r') as f:
+                for line in f:
+                    if not line.strip():
+                        continue
+                    d = json.loads(line)
+                    prompts.append(d['prompt'])
+                    answers.append(d.get('answer', None))
+                    ids.append(d.get('ids', None))
+            return prompts, answers, ids
+
+        prompts, answers, _ = read(prompt_dir)
+        self.prompts = [x for x in prompts if fits(x)]
+        self.answers = answers                               # (unfiltered, as in the reference, :88)
+        if warmup_prompt_dir is not None:
+            prompts, answers, ids = read(warmup_prompt_dir)
+            self.warmup_prompts = [x for x in prompts if fits(x)]
+            self.warmup_answers = answers
+            self.warmup_ids = ids
+
+    def save_prompts(self, path, prompts, answers=None, ids=None):
+        """Write a jsonl corpus load_prompts() reads (the counterpart of the reference's save_answers file format, :57-77)."""
+        with open(path, 'w') as f:
+            for i, p in enumerate(prompts):
+                d = {'prompt': p if isinstance(p, str) else [int(t) for t in p]}
+                if answers is not None:
+                    d['answer'] = answers[i] if isinstance(answers[i], str) or answers[i] is None else [int(t) for t in answers[i]]
+                if ids is not None:
+                    d['ids'] = None if ids[i] is None else [int(t) for t in ids[i]]
+                f.write(json.dumps(d) + '\n')
+
     def tokenize(self, prompt, max_length=256):
         """-> list of token-id lists (benchmark.py:102-113); token-id inputs pass through, truncated."""
         if isinstance(prompt, (list, tuple)) and len(prompt) > 0 and isinstance(prompt[0], int):
@@ -93,6 +139,89 @@ class Benchmark(object):
                                                    use_lookahead=False)
             out.extend(output_id_list)
         return out
+
+    # ---------------------------------------------------------------------------------------------- batch_chat
+    def batch_chat(self, qs, max_new_tokens=256, decoding_length=64, branch_length=8, decoding_mode='hier', debug_lookahead=False,
+                   erase=True, batch_size=1, max_query_length=2, verbose=True):
+        """benchmark.py:188-241: every batch of queries twice — lookahead off, then on — on a trie that learns as it goes (erase =
+        fresh trie first); per batch the reference's line (input / output sizes, edl/dl/pt/gt, time, speed, speedup), at the end
+        `speed:off->on speedup`.  -> {'speed_off', 'speed_on', 'speedup', 'identical': outputs of the two legs equal on every batch}."""
+        total_out, total_t = [0, 0], [0.0, 0.0]
+        if erase:
+            self.model.lookahead_cache.fresh()
+        identical = True
+        for i in range(len(qs) // batch_size):
+            query = qs[i * batch_size:(i + 1) * batch_size]
+            speeds, outs = [], []
+            for j, use_lookahead in enumerate([False, True]):
+                ts = time.time()
+                in_texts, in_ids, out_ids, out_texts, kw = self.chat(query, max_new_tokens=max_new_tokens, use_lookahead=use_lookahead,
+                                                                     decoding_length=decoding_length, branch_length=branch_length,
+                                                                     decoding_mode=decoding_mode, debug_lookahead=debug_lookahead,
+                                                                     max_query_length=max_query_length)
+                t = time.time() - ts
+                in_char, in_token = sum(len(x) for x in in_texts), sum(len(x) for x in in_ids)
+                out_char, out_token = sum(len(x) for x in out_texts), sum(len(x) for x in out_ids)
+                speeds.append(out_token / max(t, 1e-9))
+                outs.append(out_ids)
+                total_out[j] += out_token
+                total_t[j] += t
+                bs = len(query)
+                dls, edls, fts = kw.get('dls', []), kw.get('edls', []), kw.get('fts', [0])
+                dl = sum(dls[bs:]) / len(dls[bs:]) if len(dls) > bs else 0.0
+                edl = sum(edls[bs:]) / len(edls[bs:]) if len(edls) > bs else 0.0
+                pt, gts = fts[0] if fts else 0.0, fts[1:]
+                gt = sum(gts) / max(len(gts), 1)
+                if verbose:
+                    print(f'1/{bs} Robot:{out_texts[0]}')
+                    prefix = 'lookahead:' + ('On ' if use_lookahead else 'Off')
+                    speedup = speeds[-1] / speeds[0] if use_lookahead else 0.0
+                    print(f'{prefix} mode:{decoding_mode} idx:{i} input:{in_char:.1f}/{in_token:.1f} output:{out_char:.1f}/{out_token:.1f} '
+                          f'edl:{edl:.3f}/{dl:.3f}/{pt:.3f}/{gt:.3f} time:{t:.3f} speed:{speeds[-1]:.1f} speedup:{speedup:.3f}\n')
+            identical = identical and outs[0] == outs[1]
+        org, opt = total_out[0] / max(total_t[0], 1e-9), total_out[1] / max(total_t[1], 1e-9)
+        print(f'speed:{org:.2f}->{opt:.2f} speedup:{opt / max(org, 1e-9):.3f}')
+        return {'speed_off': org, 'speed_on': opt, 'speedup': opt / max(org, 1e-9), 'identical': identical}
+
+    # ---------------------------------------------------------------------------------------------- profile hooks
+    def naive_profile(self, qs, use_lookahead=False, count=64, sortby=0, **chat_kw):
+        """benchmark.py:397-409: cProfile over chat() of every query; prints (and returns) the top `count` rows by time / cumulative."""
+        pr = cProfile.Profile()
+        pr.enable()
+        for q in qs:
+            self.chat(q, use_lookahead=use_lookahead, **chat_kw)
+        pr.disable()
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats(pstats.SortKey.TIME if sortby == 0 else pstats.SortKey.CUMULATIVE).print_stats(count)
+        print(buf.getvalue())
+        return buf.getvalue()
+
+    def naive_profile_trie(self, lookahead_cache, warmup_ids, input_ids, output_ids, max_node_rate=16, decoding_length=64,
+                           branch_length=24, edl=8, count=64, sortby=0):
+        """benchmark.py:411-426: cProfile over the trie-only loop (perf_check_trie)."""
+        pr = cProfile.Profile()
+        pr.enable()
+        self.perf_check_trie(lookahead_cache, warmup_ids, input_ids, output_ids, max_node_rate=max_node_rate,
+                             decoding_length=decoding_length, branch_length=branch_length, edl=edl, verbose=False)
+        pr.disable()
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats(pstats.SortKey.TIME if sortby == 0 else pstats.SortKey.CUMULATIVE).print_stats(count)
+        print(buf.getvalue())
+        return buf.getvalue()
+
+    def torch_profile(self, use_lookahead=False, trace_dir='./prof', prompts=None, **chat_kw):
+        """benchmark.py:428-441: torch.profiler (wait 1 / warmup 1 / active 3) over chat() of the loaded prompts, traces for
+        tensorboard in trace_dir.  The verify step itself is a captured hipGraph of hand-written kernels — per-kernel numbers come
+        from rocprofv3 (scripts/gpu_profile.sh); this hook shows the host side of the loop, as the reference's does."""
+        prof = torch.profiler.profile(schedule=torch.profiler.schedule(wait=1, warmup=1, active=3, repeat=1),
+                                      on_trace_ready=torch.profiler.tensorboard_trace_handler(trace_dir),
+                                      record_shapes=True, with_stack=True)
+        prof.start()
+        for p in (self.prompts if prompts is None else prompts):
+            prof.step()
+            self.chat(p, use_lookahead=use_lookahead, **chat_kw)
+        prof.stop()
+        return prof
 
     # ---------------------------------------------------------------------------------------------- perf_check
     def _score(self, output_ids, output_text, answer):

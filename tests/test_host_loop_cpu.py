@@ -550,3 +550,34 @@ def test_batch_loop_overlapped_trie_update_is_lossless_and_flushes():
         assert calls[0] == ('async' if overlap else 'put') and 'async' in calls, calls[:6]
         stats[('puts', overlap)] = calls.count('put')
     assert stats[False] == stats[True] and stats[('puts', False)] == stats[('puts', True)]
+
+
+def test_benchmark_harness_load_prompts_batch_chat_and_profile_hooks(tmp_path, capsys):
+    """The rest of the reference harness (benchmarks/benchmark.py:79-100 load_prompts, :188-241 batch_chat, :397-441 profile hooks)
+    on the oracle-backed model: a jsonl corpus round trip (token-id prompts, answers, warm-up ids, the max_length filter), batch_chat's
+    off/on legs with identical outputs and the reference's log lines, cProfile over chat() and over the trie loop, torch.profiler."""
+    from painlessinferenceacceleration_amd.benchmark import Benchmark
+    m = DecisiveModel(torch.float32, max_length=400)
+    rs = np.random.RandomState(12)
+    prompts = [rs.randint(3, 512, size=n).tolist() for n in (30, 41, 36, 300)]
+    b = Benchmark(model=m, eos=None)
+    answers = b.save_answers(prompts[:3], max_new_tokens=40)
+    b.save_prompts(str(tmp_path / 'q.jsonl'), prompts, answers=answers + [None])
+    b.save_prompts(str(tmp_path / 'w.jsonl'), prompts[:3], answers=answers, ids=answers)
+    b2 = Benchmark(model=m, eos=None)
+    b2.load_prompts(str(tmp_path / 'q.jsonl'), str(tmp_path / 'w.jsonl'), max_length=100)
+    assert b2.prompts == prompts[:3] and len(b2.answers) == 4 and b2.warmup_ids == answers and b2.warmup_prompts == prompts[:3]
+    b2.warm_up(b2.warmup_ids, branch_length=12)
+    r = b2.batch_chat(b2.prompts, max_new_tokens=40, decoding_length=32, branch_length=12, erase=False, batch_size=1)
+    out = capsys.readouterr().out
+    assert r['identical'] and r['speed_on'] > 0 and r['speed_off'] > 0
+    on = [ln for ln in out.splitlines() if ln.startswith('lookahead:On ')]
+    assert len(on) == 3 and all('edl:' in ln and 'speedup:' in ln for ln in on) and 'speed:' in out.splitlines()[-1]
+    assert np.mean([float(ln.split('edl:')[1].split('/')[0]) for ln in on]) > 2.0          # the warmed trie's drafts were accepted
+    txt = b2.naive_profile(b2.prompts[:1], use_lookahead=True, count=8, max_new_tokens=16, decoding_length=32, branch_length=12)
+    assert 'function calls' in txt
+    txt = b2.naive_profile_trie(LookaheadCache(), answers, prompts[:3], answers, decoding_length=32, branch_length=12, edl=4, count=8)
+    assert 'function calls' in txt
+    prof = b2.torch_profile(use_lookahead=True, trace_dir=str(tmp_path / 'prof'), prompts=b2.prompts * 2, max_new_tokens=8,
+                            decoding_length=32, branch_length=12)
+    assert prof is not None and os.path.isdir(str(tmp_path / 'prof'))
