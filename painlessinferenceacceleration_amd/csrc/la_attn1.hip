@@ -20,6 +20,7 @@
 //     (the launch is bound by memory latency; the matrix pipe is idle), and it buys SL x more workgroups in flight.
 // Same arithmetic per (row, key) as k_tree_attn (bf16(QK^T) * 1/sqrt(d) -> bf16, fp32 softmax, bf16 P, fp32 PV accumulation,
 // bf16 output); the summation order over keys differs (tile order per wave, one merge level instead of two).
+#include <type_traits>
 #include "la_common.h"
 #include "la_kernels.h"
 
@@ -64,11 +65,16 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
     // addresses read are inside the layer's cache: KB >= 8).  Price: the start rotation of the sharers (worth 0.01 ms per step).
     // (bit 7 of sl_ring = la_lab_set key 18 bit 0: the early request off — the A/B switch; results are bit-identical either way)
     const bool spec = window <= 0 && ring_tiles == 0 && KB >= 8 && (sl_ring & 128) == 0;
-    bf16x8 kA[8], kB[8];
+    bf16x8 kA[8], kB[8], vE[8];
     if (spec) {
         const bf16x8* kt = (const bf16x8*)(kmain + ((size_t)hk * KB + par) * 4096);
 #pragma unroll
         for (int s = 0; s < 8; ++s) kA[s] = kt[s * 64 + lane];
+        // ... and its V tile behind it: with K early, the first tile's V (requested inside tile(), i.e. after the cursor) became the
+        // load the first PV MFMA waits for (GPU call 1 of round 5: the K-only form gained 0.4 of the 1.8 us per layer)
+        const bf16x8* vt0 = (const bf16x8*)(vmain + ((size_t)hk * KB + par) * 4096);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) vE[s] = vt0[s * 64 + lane];
     }
     // Q fragments of (h, tb): wave `par` brings fragment `par` (1 KiB); all waves read the 8 fragments back per tile
     bf16x8* const qs = (bf16x8*)lds1;
@@ -103,13 +109,18 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
 
     // one key tile: S^T = K.Q^T (a lane owns one token column), mask, online softmax, O^T += V^T.P^T; V is requested before the
     // QK^T MFMAs and consumed after the softmax, the NEXT tile's K fragments are requested by the caller first
-    auto tile = [&](int it, const bf16x8 (&kf)[8]) {
+    auto tile = [&](int it, const bf16x8 (&kf)[8], auto v_early) {
         const bool fresh = it >= NP;
         const int kb = fresh ? it - NP : it;
         bf16x8 vf[8];
-        const bf16x8* vt = vptr(it);
+        if constexpr (decltype(v_early)::value) {       // the wave's FIRST tile: its V is in flight already (vE)
 #pragma unroll
-        for (int s = 0; s < 8; ++s) vf[s] = vt[s * 64 + lane];
+            for (int s = 0; s < 8; ++s) vf[s] = vE[s];
+        } else {
+            const bf16x8* vt = vptr(it);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) vf[s] = vt[s * 64 + lane];
+        }
         f32x16 sc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) sc[i] = 0.f;
@@ -177,35 +188,50 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
     };
 
     int it = par;
-    if (cnt > 0 && !(spec && par < NP)) {           // wave-uniform: the early request did not fetch this wave's first tile
+    const bool early_ok = spec && par < NP;
+    if (cnt > 0 && !early_ok) {                     // wave-uniform: the early request did not fetch this wave's first tile (K and V)
         const bf16x8* kt = kptr(it);
 #pragma unroll
         for (int s = 0; s < 8; ++s) kA[s] = kt[s * 64 + lane];
+        const bf16x8* vt0 = vptr(it);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) vE[s] = vt0[s * 64 + lane];
     }
     qs[par * 64 + lane] = qmine;
     __syncthreads();
     if (stamp && lane == 0) stamp[1] = wall_clock64();
     auto next_tile = [&]() { idx = idx + 1 == cnt ? 0 : idx + 1; return par + 8 * idx; };
-    for (int k = 0; k < cnt; k += 2) {
+    if (cnt > 0) {
+        // the first tile is peeled: its V comes from vE (a compile-time choice inside tile(): no merge of two V sources)
         int nx = 0;
-        if (k + 1 < cnt) {
+        if (1 < cnt) {
             nx = next_tile();
             const bf16x8* kt = kptr(nx);
 #pragma unroll
             for (int s = 0; s < 8; ++s) kB[s] = kt[s * 64 + lane];
         }
-        tile(it, kA);
-        if (stamp && lane == 0 && k == 0) stamp[2] = wall_clock64();
-        if (k + 1 >= cnt) break;
+        tile(it, kA, std::true_type{});
+        if (stamp && lane == 0) stamp[2] = wall_clock64();
         it = nx;
-        if (k + 2 < cnt) {
-            nx = next_tile();
-            const bf16x8* kt = kptr(nx);
+        for (int k = 1; k < cnt; k += 2) {
+            if (k + 1 < cnt) {
+                nx = next_tile();
+                const bf16x8* kt = kptr(nx);
 #pragma unroll
-            for (int s = 0; s < 8; ++s) kA[s] = kt[s * 64 + lane];
+                for (int s = 0; s < 8; ++s) kA[s] = kt[s * 64 + lane];
+            }
+            tile(it, kB, std::false_type{});
+            if (k + 1 >= cnt) break;
+            it = nx;
+            if (k + 2 < cnt) {
+                nx = next_tile();
+                const bf16x8* kt = kptr(nx);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) kB[s] = kt[s * 64 + lane];
+            }
+            tile(it, kA, std::false_type{});
+            it = nx;
         }
-        tile(it, kB);
-        it = nx;
     }
     if (stamp && lane == 0) stamp[3] = wall_clock64();
 

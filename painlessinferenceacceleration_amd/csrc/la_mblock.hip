@@ -854,6 +854,186 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_gemm_fat (round 5): the paired gate/up launch (two adjacent planned regions {G0,G1,U0,U1} x 2 = 8 weight row-blocks, TW 64-row
+// blocks of tokens per workgroup, grid.z = the two token halves) with FOUR waves of a 4 x TW tile each instead of eight waves of 2 x TW:
+//   wave (rg, tq) = region rg x token group tq owns ALL four row-blocks of its region x TW token blocks: 4 TW accumulator tiles
+//   (256 registers at TW = 4: the kernel runs one wave per SIMD on the 512-entry unified file, accumulators in AGPRs).
+// Why: the stage time of k_gemm_wide is the SIMD's in-order instruction stream, not its data (profiles/r04_wide_gemm_schedule.txt:
+// 32 MFMAs + 10 LDS-DMA issues + 24 fragment reads + ~60 SALU per SIMD and stage, matrix pipe busy 62 %).  Per MFMA the fat wave
+// issues (4 + TW) / (4 TW) fragment reads (0.5 at TW = 4, was 0.75) and the same DMA pieces with half the address bookkeeping
+// (one wave's worth instead of two), and its 16 MFMAs per k-tile leave every read 15 gaps to land in.  What it gives up: the second
+// wave of a SIMD that covers a wait (MI355X_MICROARCH.md prices that at <= 5 hidden issues per MFMA gap for one wave per SIMD —
+// this stream has ~1.5).  Same ring, same stage anatomy and the same MFMA chain per output element as k_gemm_wide<8, TW, MB_SWIGLU>
+// (k-tiles in ascending order into one accumulator): bit-identical activations.  Planned gate/up images only.
+// ---------------------------------------------------------------------------------------------------------------
+template <int TW> struct FatGeom {
+    static constexpr int KS = 2, RBV = 8, RPW = 4, NW = 4, RG = 2, TQ = 2, NTBP = TQ * TW;
+    static constexpr int A_STAGE = KS * RBV, B_STAGE = KS * NTBP, STAGE = A_STAGE + B_STAGE, NR = 4;
+    static constexpr int NP = STAGE / NW;                                    // pieces per wave and stage (STAGE = 16 + 4 TW: a multiple of 4)
+    static constexpr int NPA = A_STAGE / NW;                                 // ... of which weight pieces (the first NPA)
+    static constexpr int H = (NP + 1) / 2;
+    static constexpr int LDS = NR * STAGE * 1024;
+    static constexpr int BLOCKS = NTBP / 2;
+    static_assert(STAGE % NW == 0 && LDS <= 160 * 1024, "ring geometry");
+};
+
+template <int TW>
+__global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
+    using GEO = FatGeom<TW>;
+    constexpr int KS = GEO::KS, RBV = GEO::RBV, RPW = GEO::RPW, NW = GEO::NW, TQ = GEO::TQ, NTBP = GEO::NTBP;
+    constexpr int A_STAGE = GEO::A_STAGE, STAGE = GEO::STAGE, NR = GEO::NR, NP = GEO::NP, NPA = GEO::NPA, H = GEO::H;
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rg = wave / TQ, tq = wave % TQ;          // region of the pair, token group
+    const int t0 = 0, t1 = a.K16;
+    const int nst = (t1 - t0 + KS - 1) / KS;
+    const int zb0 = blockIdx.z * GEO::BLOCKS;
+
+    // ---- DMA pieces of this wave: p = wave + NW i; i < NPA: weight piece (k-tile p / RBV, row-block p % RBV), else an x piece
+    const bf16x8* wg_w = (const bf16x8*)a.wp + (size_t)blockIdx.x * (unsigned)a.wg_chunks;
+    const __amdgpu_buffer_rsrc_t rs_w = dma_rsrc(wg_w), rs_x = dma_rsrc(a.xp);
+    unsigned gstr[NP], voff[NP];
+    int pkk[NP], pdst[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int p = wave + NW * i;
+        if (i < NPA) {
+            const int kk = p / RBV, rb = p % RBV;
+            const int nvb = a.nvl[rb];
+            const int rr = (lane & 31) < nvb ? (lane & 31) : nvb - 1;
+            gstr[i] = (unsigned)(32 * nvb);
+            voff[i] = ((unsigned)a.boff[rb] + (unsigned)((lane >> 5) * nvb + rr)) * 16u;
+            pkk[i] = kk;
+            pdst[i] = (kk * RBV + rb) * 1024;
+        } else {
+            const int q = p - A_STAGE, kk = q / NTBP, tb = q % NTBP;
+            int xb = zb0 + (tb >> 1);
+            xb = xb < a.nblk ? xb : a.nblk - 1;
+            gstr[i] = 2048u;
+            voff[i] = ((unsigned)(((xb * a.K16) * 2 + (tb & 1)) * 64) + (unsigned)lane) * 16u;
+            pkk[i] = kk;
+            pdst[i] = (A_STAGE + kk * NTBP + tb) * 1024;
+        }
+    }
+    auto issue_one = [&](int sidx, int i) {
+        int kt = t0 + sidx * KS + pkk[i];
+        kt = kt < t1 ? kt : t1 - 1;
+        char* d = lds_raw + (sidx % NR) * (STAGE * 1024) + pdst[i];
+        const unsigned so = (unsigned)kt * gstr[i];
+        if (i < NPA) dma_piece<0>(rs_w, d, voff[i], so);      // (paired form: the other token half reads the same rows, default policy)
+        else dma_piece<0>(rs_x, d, voff[i], so);
+    };
+
+    f32x16 acc[RPW][TW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][t][i] = 0.f;
+
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds_raw + (unsigned)lane * 16u;
+    constexpr int NRD = RPW + TW, NMMA = RPW * TW;
+    // fragment j of k-tile (sidx, kk): the RPW weight fragments of the region, then the TW x fragments of the token group
+    auto read_one = [&](int sidx, int kk, int j, bf16x8 (&fa)[RPW], bf16x8 (&fb)[TW]) {
+        const unsigned S = lds0 + (unsigned)((sidx % NR) * (STAGE * 1024));
+        const unsigned A = S + (unsigned)((kk * RBV + RPW * rg) * 1024);
+        const unsigned B = S + (unsigned)((A_STAGE + kk * NTBP + tq * TW) * 1024);
+        if (j < RPW) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[j]) : "v"(A), "n"(j * 1024) : "memory");
+        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[j - RPW]) : "v"(B), "n"((j - RPW) * 1024) : "memory");
+    };
+    // MFMA m of a k-tile: x-major order, so that consecutive MFMAs write different accumulators and fragment j is first needed late
+    auto mma = [&](int m, const bf16x8 (&fa)[RPW], const bf16x8 (&fb)[TW]) {
+        const int r = m % RPW, t = m / RPW;
+        acc[r][t] = LA_MFMA(fa[r], fb[t], acc[r][t], 0, 0, 0);
+    };
+
+#pragma unroll
+    for (int i = 0; i < NR - 1; ++i)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) issue_one(i, q);
+    vm_wait<(NR - 2) * NP>();
+    __builtin_amdgcn_s_barrier();
+    bf16x8 fa0[RPW], fb0[TW], fa1[RPW], fb1[TW];
+#pragma unroll
+    for (int j = 0; j < NRD; ++j) read_one(0, 0, j, fa0, fb0);
+    constexpr int H2 = NP - H;
+    // (K16 is even here — the launcher sends odd K to k_gemm_wide: a branch around half a stage's MFMAs would make every one of the
+    //  4 TW accumulator tiles a loop-carried phi with two sources, and hipcc then spills accumulators inside the loop)
+    for (int s = 0; s < nst; ++s) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // set0 (read during the previous half) is complete
+        __builtin_amdgcn_sched_barrier(0);
+        // first half: MFMAs of set0 | one fragment read of set1 (stage s, k-tile 1) | one DMA piece of stage s + 3 after each
+#pragma unroll
+        for (int m = 0; m < NMMA; ++m) {
+            mma(m, fa0, fb0);
+            if (m < NRD) read_one(s, 1, m, fa1, fb1);
+            if (m < H) issue_one(s + NR - 1, m);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        vm_wait<(NR - 3) * NP + H>();                                // own pieces of stage s + 1 landed
+        __builtin_amdgcn_s_barrier();                                // stage s + 1 complete for everyone; the slot of stage s is free
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < NMMA; ++m) {
+            mma(m, fa1, fb1);
+            if (m < NRD) read_one(s + 1, 0, m, fa0, fb0);
+            if (m < H2) issue_one(s + NR - 1, H + m);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    vm_wait<0>();
+
+    // ---- SwiGLU epilogue, as k_gemm_wide<8, TW, MB_SWIGLU>: act = bf16(silu(bf16(g)) * bf16(u)) parked as tile[token][sh + feature - lo]
+    //      in the drained ring, then 16-byte chunks of the activation image
+    const int tl = lane & 31, hh = lane >> 5;
+    const int sw_lo = a.R * 2 * blockIdx.x, sw_r = 2 * a.R, sw_sh = sw_lo & 7;
+    const int sw_nch = (sw_sh + sw_r + 7) >> 3;
+    const int sw_stride = (sw_nch * 8) % 64 == 0 ? sw_nch * 8 + 8 : sw_nch * 8;
+    __syncthreads();
+    bf16_t* tile = (bf16_t*)lds_raw;
+#pragma unroll
+    for (int t = 0; t < TW; ++t) {
+        const int tbg = tq * TW + t, blk = zb0 + (tbg >> 1), tok = (tbg & 1) * 32 + tl;
+        if (blk >= a.nblk) continue;
+        const int trow = (tbg >> 1) * 64 + tok;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                    // {G_q, U_q} = row-blocks q and q + 2 of the region
+            const int nvg = a.nv[RPW * rg + q];
+            const int c0 = sw_sh + rg * a.R + 32 * q;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (8 * (i >> 2) >= nvg) break;
+                const int f = 8 * (i >> 2) + 4 * hh + (i & 3);
+                const float gv = bfr_hw(acc[q][t][i]), uv = bfr_hw(acc[q + 2][t][i]);
+                const float sv = bfr_hw(gv * __builtin_amdgcn_rcpf(1.0f + __expf(-gv)));
+                const bf16_t o = f2bf_hw(sv * uv);
+                if (f < nvg) tile[trow * sw_stride + c0 + f] = o;
+            }
+        }
+    }
+    __syncthreads();
+    const int ntok = GEO::BLOCKS * 64;
+    for (int it = threadIdx.x; it < ntok * sw_nch; it += NW * 64) {
+        const int trow = it % ntok, c = it / ntok, blk = zb0 + (trow >> 6);
+        if (blk >= a.nblk) continue;
+        const int fa_ = (sw_lo & ~7) + 8 * c;
+        bf16_t* dst = a.act_xp + (size_t)blk * 64 * a.N + xp_offset(trow & 63, fa_);
+        const bf16_t* srcp = tile + trow * sw_stride + 8 * c;
+        if (fa_ >= sw_lo && fa_ + 8 <= sw_lo + sw_r) {
+            *(bf16x8*)dst = *(const bf16x8*)srcp;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (fa_ + e >= sw_lo && fa_ + e < sw_lo + sw_r) dst[e] = srcp[e];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Row kernels over M rows: embedding gather + RMSNorm / residual + split-K slab sum + RMSNorm (same arithmetic and rounding
 // points as k_row_norm in la_kernels.hip; LlamaRMSNorm :76-90, LlamaDecoderLayer residual adds :352-363).
 // ---------------------------------------------------------------------------------------------------------------
@@ -1862,7 +2042,7 @@ int g_la_mb_attn_rot = 0;     // la_lab_set key 21: 1 = the query heads of a kv 
 int g_la_mb_attn_vring = 0;   // la_lab_set key 20: 1 = multi-block attention with the next tile's V in flight through a per-wave LDS ring (measured 0.5-5 % SLOWER per step, profiles/r04_mb_attention_vring_ab.txt), 0 = V requested per tile (default)
 int g_la_mb_dbg = 0;
 int g_la_mb_mode = 0;         // la_lab_set key 5: unused (was: the wide gate/up launch as two co-resident 256-row workgroups per CU on a 3-slot ring — four waves per SIMD; measured 7 % slower at 512 rows, profiles/r04_wide_gemm_schedule.txt part 5)
-int g_la_mb_pair = 1;         // la_debug_set key 6, bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
+int g_la_mb_pair = 1;         // la_debug_set key 6, bit 4 (round 5): gate/up at >= 3 blocks as four fat waves per workgroup (k_gemm_fat: the paired geometry, 4 x TW tiles per wave); bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
 int g_la_mb_ks2 = 0;          // la_debug_set key 12: slab GEMMs of the multi-block step with 2 K splits at >= 5 blocks (measurement)
 int g_la_mb_narrow = 0;       // la_debug_set key 3: 1 = the K-split kernels (k_gemm_mb) for every nblk (A/B measurements)
 int g_la_ex_d4 = 1;           // la_lab_set key 25: merged-expert launches as two workgroups per CU (bit 0 gate/up, bit 1 down)
@@ -1924,6 +2104,9 @@ int lk_mb_init() {
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 4>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 5>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 6, 3>, WideGeom<4, 4>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<2>, FatGeom<2>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<3>, FatGeom<3>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<4>, FatGeom<4>::LDS);
     if (e == hipSuccess) e = set_lds(k_tree_attn_mb<false, true>, 8 * 66 * 64 * 4 + 16384);
     if (e == hipSuccess) e = set_lds(k_tree_attn_mb<false, false>, 8 * 66 * 64 * 4 + 16384);
     if (e == hipSuccess) e = set_lds(k_tree_attn_mb<true, true>, 8 * 66 * 64 * 4 + 16384);
@@ -2092,12 +2275,22 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
             // paired gate/up launch (planned images): regions {2 x, 2 x + 1} = row-blocks 0..7, half the token blocks per workgroup.
             // Bit-identical, but NOT faster (this launch is bound by its MFMA / ds_read side, not by the x traffic: 512 rows 116.5 vs
             // 116.4 us, 256 rows 68.4 vs 76.6 us at the 7B shape, profiles/r02b_mblock_paired_ab.txt): opt-in (la_debug_set(6, 3)).
-            if ((g_la_mb_pair & 2) && a.planned && !a.gu_interleaved && n_wg % 16 == 0 && ksplit == 1) {
+            if ((g_la_mb_pair & (2 | 16)) && a.planned && !a.gu_interleaved && n_wg % 16 == 0 && ksplit == 1) {
+                const bool fat = (g_la_mb_pair & 16) && (a.K16 % 2) == 0;
                 MbArgs p = a;
                 p.w_keep = 1;
                 for (int i = 0; i < 4; ++i) { p.boff[4 + i] = a.wg_chunks + a.boff[i]; p.nv[4 + i] = a.nv[i]; p.nvl[4 + i] = a.nvl[i]; }
                 p.wg_chunks = 2 * a.wg_chunks;
                 const dim3 g2(n_wg / 2, 1, 2);
+                if (fat) {
+                    // round 5: the same pair of regions as FOUR fat waves (4 x TW accumulator tiles each, one wave per SIMD): k_gemm_fat
+                    switch ((nblk + 1) / 2) {
+                        case 2: k_gemm_fat<2><<<g2, 256, FatGeom<2>::LDS, st>>>(p); break;
+                        case 3: k_gemm_fat<3><<<g2, 256, FatGeom<3>::LDS, st>>>(p); break;
+                        default: k_gemm_fat<4><<<g2, 256, FatGeom<4>::LDS, st>>>(p); break;
+                    }
+                    LAUNCH_CHECK(); return 0;
+                }
                 switch ((nblk + 1) / 2) {                       // 64-row blocks per workgroup = TW
                     case 2: wide_launch<8, 2, EPI>(g2, st, p); break;
                     case 3: wide_launch<8, 3, EPI>(g2, st, p); break;

@@ -16,7 +16,7 @@ from painlessinferenceacceleration_amd._lib import check, lib      # noqa: E402
 from tests import gpu_utils as gu                                    # noqa: E402
 from tests.gpu_utils import DEV, ptr, sp                             # noqa: E402
 
-F, K, NWG, NBUF = 11008, 4096, 256, 3
+F, K, NWG, NBUF = int(os.environ.get('MB_F', '11008')), int(os.environ.get('MB_K', '4096')), 256, 3      # MB_F=14336: Mistral / Mixtral, MB_F=13824 MB_K=5120: 13B
 
 
 def bf(t):
@@ -55,9 +55,9 @@ def main():
         a = bf(torch.randn(nblk * 64, F, generator=g, device=DEV))
         ap = torch.cat([gu.pack_x(a[b * 64:(b + 1) * 64].contiguous()) for b in range(nblk)])
         z = None
-        for narrow, wmode, dw in ((1, 0, 1), (0, 0, 1), (0, 0, 0)):
+        for narrow, wmode, dw in ((1, 0, 1), (0, 0, 1), (0, 0, 0), (0, 3, 1), (0, 17, 1)):
             check(lib.la_lab_set(3, narrow), 'debug_set')
-            check(lib.la_lab_set(5, wmode), 'debug_set')
+            check(lib.la_lab_set(6, wmode if wmode else 1), 'debug_set')      # 3 = paired gate/up (8 waves), 17 = fat waves (k_gemm_fat, round 5)
             check(lib.la_lab_set(24, dw), 'debug_set')          # 1 = round-4 schedule (default), 0 = round-2 schedule
 
             def gateup(i):
@@ -73,9 +73,9 @@ def main():
                     torch.cuda.synchronize()
                     continue
                 us, med = bench(fn)
-                print(f'{name:8s} rows {nblk * 64:4d} {"k_gemm_mb  " if narrow else "wide, 2 WGs / CU " if wmode else "wide (default)   " if dw else "wide, schedule 0 "} min {us:8.2f} us  median {med:8.2f} us  {flops / us / 1e6:7.1f} TFLOP/s', flush=True)
+                print(f'{name:8s} rows {nblk * 64:4d} {"k_gemm_mb  " if narrow else "paired, 8 waves  " if wmode == 3 else "FAT 4 waves      " if wmode == 17 else "wide (default)   " if dw else "wide, schedule 0 "} min {us:8.2f} us  median {med:8.2f} us  {flops / us / 1e6:7.1f} TFLOP/s', flush=True)
     check(lib.la_lab_set(3, 0), 'debug_set')
-    check(lib.la_lab_set(5, 0), 'debug_set')
+    check(lib.la_lab_set(6, 1), 'debug_set')
     check(lib.la_lab_set(24, 1), 'debug_set')
     if mode in ('parts', 'onceparts'):
         # what bounds a stage of the wide kernel: the same launch without MFMAs (1), without the in-loop DMA (2), DMA + barriers only (3)
