@@ -3,8 +3,8 @@
  * binds, no stability promise.  Every knob has a library default (la_lab_get reports the value in effect); the step entry points
  * capture their graphs again after a change.
  *
- * Defaults: everything 0 except key 6 = 1 (paired wide launches), key 11 = 1 (one step per graph), key 17 = 1 (single-launch tree
- * attention).
+ * Defaults: everything 0 except key 6 = 17 (paired wide launches + fat-wave gate/up), key 11 = 1 (one step per graph), key 17 = 1
+ * (single-launch tree attention), key 24 = 1, key 25 = 1.
  */
 #ifndef LOOKAHEAD_HIP_LAB_H
 #define LOOKAHEAD_HIP_LAB_H
@@ -19,8 +19,8 @@ extern "C" {
  * key 6: paired form of the wide multi-block launches (two weight regions x half the token blocks per workgroup): bit 0 = slab and
  *        QKV launches (library default: on), bit 1 = gate/up too, bit 2 = quad QKV form, bit 3 = QKV with token quarters at every
  *        block count (what the second QKV image, cfg.qkv_mb_wg, takes by default), bit 4 (round 5) = gate/up as four fat waves per
- *        workgroup (k_gemm_fat: the paired geometry with 4 x TW accumulator tiles per wave, one wave per SIMD); bit-identical results;
- *        read at launch / capture.
+ *        workgroup (k_gemm_fat: the paired geometry with 4 x TW accumulator tiles per wave, one wave per SIMD; library default: on),
+ *        bit 5 = the paired slab / QKV launches as fat waves too; bit-identical results; read at launch / capture.
  * key 7: idle-window weight prefetch of the 64-row step, KiB per workgroup of the next GEMM (0 = off, <= 128): the row kernels and
  *        the attention combine carry extra workgroups that pull the first k-tiles of the next GEMM into L2 (bit-identical
  *        results); key 8: start delay of those workgroups in s_sleep(32) rounds; key 9: KiB per down_proj workgroup pulled in from

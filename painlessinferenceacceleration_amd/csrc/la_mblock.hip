@@ -854,44 +854,146 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_gemm_fat (round 5): the paired gate/up launch (two adjacent planned regions {G0,G1,U0,U1} x 2 = 8 weight row-blocks, TW 64-row
-// blocks of tokens per workgroup, grid.z = the two token halves) with FOUR waves of a 4 x TW tile each instead of eight waves of 2 x TW:
-//   wave (rg, tq) = region rg x token group tq owns ALL four row-blocks of its region x TW token blocks: 4 TW accumulator tiles
-//   (256 registers at TW = 4: the kernel runs one wave per SIMD on the 512-entry unified file, accumulators in AGPRs).
+// k_gemm_fat (round 5): the PAIRED wide launches with FOUR waves of a 4 x TW tile each instead of eight waves of 2 x TW.
+//   gate/up (RBV = 8): two adjacent planned regions {G0,G1,U0,U1} x 2, wave (rg, tq) = region rg x token group tq (2 x 2), TW = 2..4;
+//   slab / QKV (RBV = 4): the two paired regions' {lo, hi} or plain row-blocks 0..3, wave tq = token group (1 x 4), TW = 1..2.
+//   A wave owns ALL four row-blocks of its row group x TW token blocks: 4 TW accumulator tiles (256 registers at TW = 4: one wave
+//   per SIMD on the 512-entry unified file, accumulators in AGPRs).
 // Why: the stage time of k_gemm_wide is the SIMD's in-order instruction stream, not its data (profiles/r04_wide_gemm_schedule.txt:
 // 32 MFMAs + 10 LDS-DMA issues + 24 fragment reads + ~60 SALU per SIMD and stage, matrix pipe busy 62 %).  Per MFMA the fat wave
 // issues (4 + TW) / (4 TW) fragment reads (0.5 at TW = 4, was 0.75) and the same DMA pieces with half the address bookkeeping
-// (one wave's worth instead of two), and its 16 MFMAs per k-tile leave every read 15 gaps to land in.  What it gives up: the second
-// wave of a SIMD that covers a wait (MI355X_MICROARCH.md prices that at <= 5 hidden issues per MFMA gap for one wave per SIMD —
-// this stream has ~1.5).  Same ring, same stage anatomy and the same MFMA chain per output element as k_gemm_wide<8, TW, MB_SWIGLU>
-// (k-tiles in ascending order into one accumulator): bit-identical activations.  Planned gate/up images only.
+// (one wave's worth instead of two), and its 4 TW MFMAs per k-tile leave every read a dozen gaps to land in.  What it gives up: the
+// second wave of a SIMD that covers a wait (MI355X_MICROARCH.md prices that at <= 5 hidden issues per MFMA gap for one wave per
+// SIMD — this stream has ~1.5).  Same ring, same stage anatomy and the same MFMA chain per output element as k_gemm_wide (k-tiles
+// in ascending order into one accumulator): bit-identical outputs.  Measured per launch (profiles/r05_fat_waves.txt): gate/up
+// 7B 512 rows 113.8 -> 102.9 us, 256 rows 72.0 -> 65.8; Mistral 119.4 -> 113.3 / 77.5 -> 71.3; 13B 145.9 -> 138.7 / 96.1 -> 84.6.
+// The K range of a workgroup must hold an even number of k-tiles (a branch around half a stage's MFMAs makes every accumulator
+// tile a loop-carried phi with two sources, and hipcc then spills accumulators INSIDE the loop): the launcher sends other shapes
+// to k_gemm_wide.
 // ---------------------------------------------------------------------------------------------------------------
-template <int TW> struct FatGeom {
-    static constexpr int KS = 2, RBV = 8, RPW = 4, NW = 4, RG = 2, TQ = 2, NTBP = TQ * TW;
+template <int RBV, int TW> struct FatGeom {
+    static constexpr int KS = 2, RPW = 4, NW = 4, RG = RBV / RPW, TQ = NW / RG, NTBP = TQ * TW;
     static constexpr int A_STAGE = KS * RBV, B_STAGE = KS * NTBP, STAGE = A_STAGE + B_STAGE, NR = 4;
-    static constexpr int NP = STAGE / NW;                                    // pieces per wave and stage (STAGE = 16 + 4 TW: a multiple of 4)
+    static constexpr int NP = STAGE / NW;                                    // pieces per wave and stage
     static constexpr int NPA = A_STAGE / NW;                                 // ... of which weight pieces (the first NPA)
     static constexpr int H = (NP + 1) / 2;
     static constexpr int LDS = NR * STAGE * 1024;
     static constexpr int BLOCKS = NTBP / 2;
-    static_assert(STAGE % NW == 0 && LDS <= 160 * 1024, "ring geometry");
+    static_assert((RBV == 8 || RBV == 4) && STAGE % NW == 0 && A_STAGE % NW == 0 && NTBP % 2 == 0 && LDS <= 160 * 1024, "ring geometry");
 };
 
-template <int TW>
+// RoPE + fragment stores of one {lo, hi} accumulator pair (the QKV epilogue of k_gemm_wide, same arithmetic and rounding points:
+// apply_rotary_pos_emb, modeling_llama.py:154-169, in bf16 arithmetic; V rows pass through)
+// RV = rows a lane handles per store: 4 (R % 4 == 0: 8-byte table loads and fragment stores), 2 (R even: 4-byte), 1 (any R)
+template <int RV>
+__device__ __forceinline__ void fat_qkv_tile(const MbArgs& a, const f32x16& lo, const f32x16& hi, int region, int blk, int tok, int hh) {
+    const int ps = a.pos[blk * 64 + tok];
+    if constexpr (RV == 4) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) {
+            if (8 * (i >> 2) >= a.nv[0]) break;
+            const int f = 8 * (i >> 2) + 4 * hh;
+            if (f < a.nv[0]) {
+                const int prr = a.R * region + f, slot = prr >> 6, dlo = prr & 63, dhi = dlo + 64;
+                if (slot < a.nh + a.nkv) {
+                    bf16_t* dst = slot < a.nh ? a.qf + ((size_t)blk * a.nh + slot) * 8192
+                                              : a.kfresh + ((size_t)blk * a.nkv + (slot - a.nh)) * 8192;
+                    const uint2 c4 = *(const uint2*)(a.rcos + (size_t)ps * 64 + dlo), s4 = *(const uint2*)(a.rsin + (size_t)ps * 64 + dlo);
+                    uint2 olo = {0u, 0u}, ohi = {0u, 0u};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t cw = e < 2 ? c4.x : c4.y, sw = e < 2 ? s4.x : s4.y;
+                        const float cc = bf2f((bf16_t)(cw >> (16 * (e & 1)))), sn = bf2f((bf16_t)(sw >> (16 * (e & 1))));
+                        const float bl = bfr_hw(lo[i + e]), bh = bfr_hw(hi[i + e]);
+                        const uint32_t lo16 = (uint32_t)f2bf_hw(bfr_hw(bl * cc) + bfr_hw(-bh * sn)) << (16 * (e & 1));
+                        const uint32_t hi16 = (uint32_t)f2bf_hw(bfr_hw(bh * cc) + bfr_hw(bl * sn)) << (16 * (e & 1));
+                        if (e < 2) { olo.x |= lo16; ohi.x |= hi16; } else { olo.y |= lo16; ohi.y |= hi16; }
+                    }
+                    *(uint2*)(dst + rf_offset(tok, dlo)) = olo;
+                    *(uint2*)(dst + rf_offset(tok, dhi)) = ohi;
+                } else {
+                    bf16_t* dst = a.vfresh + ((size_t)blk * a.nkv + (slot - a.nh - a.nkv)) * 8192;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        dst[vf_offset(tok, dlo + e)] = f2bf_hw(lo[i + e]);
+                        dst[vf_offset(tok, dhi + e)] = f2bf_hw(hi[i + e]);
+                    }
+                }
+            }
+        }
+    } else if constexpr (RV == 2) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            if (8 * (i >> 2) >= a.nv[0]) break;
+            const int f = 8 * (i >> 2) + 4 * hh + (i & 3);
+            if (f < a.nv[0]) {
+                const int prr = a.R * region + f, slot = prr >> 6, dlo = prr & 63, dhi = dlo + 64;
+                if (slot < a.nh + a.nkv) {
+                    bf16_t* dst = slot < a.nh ? a.qf + ((size_t)blk * a.nh + slot) * 8192
+                                              : a.kfresh + ((size_t)blk * a.nkv + (slot - a.nh)) * 8192;
+                    const uint32_t c2 = *(const uint32_t*)(a.rcos + (size_t)ps * 64 + dlo), s2 = *(const uint32_t*)(a.rsin + (size_t)ps * 64 + dlo);
+                    uint32_t olo = 0, ohi = 0;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float cc = bf2f((bf16_t)(c2 >> (16 * e))), sn = bf2f((bf16_t)(s2 >> (16 * e)));
+                        const float bl = bfr_hw(lo[i + e]), bh = bfr_hw(hi[i + e]);
+                        olo |= (uint32_t)f2bf_hw(bfr_hw(bl * cc) + bfr_hw(-bh * sn)) << (16 * e);
+                        ohi |= (uint32_t)f2bf_hw(bfr_hw(bh * cc) + bfr_hw(bl * sn)) << (16 * e);
+                    }
+                    *(uint32_t*)(dst + rf_offset(tok, dlo)) = olo;
+                    *(uint32_t*)(dst + rf_offset(tok, dhi)) = ohi;
+                } else {
+                    bf16_t* dst = a.vfresh + ((size_t)blk * a.nkv + (slot - a.nh - a.nkv)) * 8192;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        dst[vf_offset(tok, dlo + e)] = f2bf_hw(lo[i + e]);
+                        dst[vf_offset(tok, dhi + e)] = f2bf_hw(hi[i + e]);
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int f = 8 * (i >> 2) + 4 * hh + (i & 3);
+            if (f < a.nv[0]) {
+                const int prr = a.R * region + f, slot = prr >> 6, dlo = prr & 63, dhi = dlo + 64;
+                const float xl = lo[i], xh = hi[i];
+                if (slot < a.nh + a.nkv) {
+                    bf16_t* dst = slot < a.nh ? a.qf + ((size_t)blk * a.nh + slot) * 8192
+                                              : a.kfresh + ((size_t)blk * a.nkv + (slot - a.nh)) * 8192;
+                    const float cc = bf2f(a.rcos[(size_t)ps * 64 + dlo]), sn = bf2f(a.rsin[(size_t)ps * 64 + dlo]);
+                    const float bl = bfr_hw(xl), bh = bfr_hw(xh);
+                    dst[rf_offset(tok, dlo)] = f2bf_hw(bfr_hw(bl * cc) + bfr_hw(-bh * sn));
+                    dst[rf_offset(tok, dhi)] = f2bf_hw(bfr_hw(bh * cc) + bfr_hw(bl * sn));
+                } else {
+                    bf16_t* dst = a.vfresh + ((size_t)blk * a.nkv + (slot - a.nh - a.nkv)) * 8192;
+                    dst[vf_offset(tok, dlo)] = f2bf_hw(xl);
+                    dst[vf_offset(tok, dhi)] = f2bf_hw(xh);
+                }
+            }
+        }
+    }
+}
+
+template <int RBV, int TW, int EPI, int RV = 4>
 __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
-    using GEO = FatGeom<TW>;
-    constexpr int KS = GEO::KS, RBV = GEO::RBV, RPW = GEO::RPW, NW = GEO::NW, TQ = GEO::TQ, NTBP = GEO::NTBP;
+    using GEO = FatGeom<RBV, TW>;
+    constexpr int KS = GEO::KS, RPW = GEO::RPW, NW = GEO::NW, TQ = GEO::TQ, NTBP = GEO::NTBP;
     constexpr int A_STAGE = GEO::A_STAGE, STAGE = GEO::STAGE, NR = GEO::NR, NP = GEO::NP, NPA = GEO::NPA, H = GEO::H;
+    static_assert((EPI == MB_SWIGLU && RBV == 8) || ((EPI == MB_SLAB || EPI == MB_QKV) && RBV == 4), "gate/up pairs two planned regions; slab / QKV pair two {lo, hi} regions");
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int rg = wave / TQ, tq = wave % TQ;          // region of the pair, token group
-    const int t0 = 0, t1 = a.K16;
-    const int nst = (t1 - t0 + KS - 1) / KS;
+    const int rg = wave / TQ, tq = wave % TQ;          // row group (4 row-blocks), token group
+    const int ksplit = gridDim.y, ks = blockIdx.y;
+    const int t0 = (int)(((long)a.K16 * ks) / ksplit), t1 = (int)(((long)a.K16 * (ks + 1)) / ksplit);
+    const int nst = (t1 - t0) / KS;                    // an even range (launcher)
     const int zb0 = blockIdx.z * GEO::BLOCKS;
 
     // ---- DMA pieces of this wave: p = wave + NW i; i < NPA: weight piece (k-tile p / RBV, row-block p % RBV), else an x piece
-    const bf16x8* wg_w = (const bf16x8*)a.wp + (size_t)blockIdx.x * (unsigned)a.wg_chunks;
+    const bf16x8* wg_w = a.planned ? (const bf16x8*)a.wp + (size_t)blockIdx.x * (unsigned)a.wg_chunks
+                                   : (const bf16x8*)a.wp + (size_t)blockIdx.x * RBV * a.K16 * 64;
     const __amdgpu_buffer_rsrc_t rs_w = dma_rsrc(wg_w), rs_x = dma_rsrc(a.xp);
     unsigned gstr[NP], voff[NP];
     int pkk[NP], pdst[NP];
@@ -900,10 +1002,15 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
         const int p = wave + NW * i;
         if (i < NPA) {
             const int kk = p / RBV, rb = p % RBV;
-            const int nvb = a.nvl[rb];
-            const int rr = (lane & 31) < nvb ? (lane & 31) : nvb - 1;
-            gstr[i] = (unsigned)(32 * nvb);
-            voff[i] = ((unsigned)a.boff[rb] + (unsigned)((lane >> 5) * nvb + rr)) * 16u;
+            if (a.planned) {
+                const int nvb = a.nvl[rb];
+                const int rr = (lane & 31) < nvb ? (lane & 31) : nvb - 1;
+                gstr[i] = (unsigned)(32 * nvb);
+                voff[i] = ((unsigned)a.boff[rb] + (unsigned)((lane >> 5) * nvb + rr)) * 16u;
+            } else {
+                gstr[i] = 1024u;
+                voff[i] = ((unsigned)(rb * a.K16 * 64) + (unsigned)lane) * 16u;
+            }
             pkk[i] = kk;
             pdst[i] = (kk * RBV + rb) * 1024;
         } else {
@@ -921,7 +1028,7 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
         kt = kt < t1 ? kt : t1 - 1;
         char* d = lds_raw + (sidx % NR) * (STAGE * 1024) + pdst[i];
         const unsigned so = (unsigned)kt * gstr[i];
-        if (i < NPA) dma_piece<0>(rs_w, d, voff[i], so);      // (paired form: the other token half reads the same rows, default policy)
+        if (i < NPA) dma_piece<0>(rs_w, d, voff[i], so);      // (paired form: the other token group reads the same rows, default policy)
         else dma_piece<0>(rs_x, d, voff[i], so);
     };
 
@@ -935,7 +1042,8 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
 
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds_raw + (unsigned)lane * 16u;
     constexpr int NRD = RPW + TW, NMMA = RPW * TW;
-    // fragment j of k-tile (sidx, kk): the RPW weight fragments of the region, then the TW x fragments of the token group
+    constexpr int NG = NMMA > NRD ? NMMA : NRD;          // issue groups per half stage (TW = 1: 5 reads behind 4 MFMAs)
+    // fragment j of k-tile (sidx, kk): the RPW weight fragments of the row group, then the TW x fragments of the token group
     auto read_one = [&](int sidx, int kk, int j, bf16x8 (&fa)[RPW], bf16x8 (&fb)[TW]) {
         const unsigned S = lds0 + (unsigned)((sidx % NR) * (STAGE * 1024));
         const unsigned A = S + (unsigned)((kk * RBV + RPW * rg) * 1024);
@@ -943,7 +1051,7 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
         if (j < RPW) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[j]) : "v"(A), "n"(j * 1024) : "memory");
         else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[j - RPW]) : "v"(B), "n"((j - RPW) * 1024) : "memory");
     };
-    // MFMA m of a k-tile: x-major order, so that consecutive MFMAs write different accumulators and fragment j is first needed late
+    // MFMA m of a k-tile: row-block fastest, so that consecutive MFMAs write different accumulators
     auto mma = [&](int m, const bf16x8 (&fa)[RPW], const bf16x8 (&fb)[TW]) {
         const int r = m % RPW, t = m / RPW;
         acc[r][t] = LA_MFMA(fa[r], fb[t], acc[r][t], 0, 0, 0);
@@ -959,15 +1067,13 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
 #pragma unroll
     for (int j = 0; j < NRD; ++j) read_one(0, 0, j, fa0, fb0);
     constexpr int H2 = NP - H;
-    // (K16 is even here — the launcher sends odd K to k_gemm_wide: a branch around half a stage's MFMAs would make every one of the
-    //  4 TW accumulator tiles a loop-carried phi with two sources, and hipcc then spills accumulators inside the loop)
     for (int s = 0; s < nst; ++s) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // set0 (read during the previous half) is complete
         __builtin_amdgcn_sched_barrier(0);
         // first half: MFMAs of set0 | one fragment read of set1 (stage s, k-tile 1) | one DMA piece of stage s + 3 after each
 #pragma unroll
-        for (int m = 0; m < NMMA; ++m) {
-            mma(m, fa0, fb0);
+        for (int m = 0; m < NG; ++m) {
+            if (m < NMMA) mma(m, fa0, fb0);
             if (m < NRD) read_one(s, 1, m, fa1, fb1);
             if (m < H) issue_one(s + NR - 1, m);
             __builtin_amdgcn_sched_barrier(0);
@@ -977,8 +1083,8 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
         __builtin_amdgcn_s_barrier();                                // stage s + 1 complete for everyone; the slot of stage s is free
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < NMMA; ++m) {
-            mma(m, fa1, fb1);
+        for (int m = 0; m < NG; ++m) {
+            if (m < NMMA) mma(m, fa1, fb1);
             if (m < NRD) read_one(s + 1, 0, m, fa0, fb0);
             if (m < H2) issue_one(s + NR - 1, H + m);
             __builtin_amdgcn_sched_barrier(0);
@@ -987,48 +1093,74 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     vm_wait<0>();
 
-    // ---- SwiGLU epilogue, as k_gemm_wide<8, TW, MB_SWIGLU>: act = bf16(silu(bf16(g)) * bf16(u)) parked as tile[token][sh + feature - lo]
-    //      in the drained ring, then 16-byte chunks of the activation image
     const int tl = lane & 31, hh = lane >> 5;
-    const int sw_lo = a.R * 2 * blockIdx.x, sw_r = 2 * a.R, sw_sh = sw_lo & 7;
-    const int sw_nch = (sw_sh + sw_r + 7) >> 3;
-    const int sw_stride = (sw_nch * 8) % 64 == 0 ? sw_nch * 8 + 8 : sw_nch * 8;
-    __syncthreads();
-    bf16_t* tile = (bf16_t*)lds_raw;
+    if constexpr (EPI == MB_SLAB) {
+        // split-K partial sums straight from the accumulators (the layout k_row_norm_mb sums: [ks][row][N])
 #pragma unroll
-    for (int t = 0; t < TW; ++t) {
-        const int tbg = tq * TW + t, blk = zb0 + (tbg >> 1), tok = (tbg & 1) * 32 + tl;
-        if (blk >= a.nblk) continue;
-        const int trow = (tbg >> 1) * 64 + tok;
+        for (int t = 0; t < TW; ++t) {
+            const int tbg = tq * TW + t, blk = zb0 + (tbg >> 1), tok = (tbg & 1) * 32 + tl;
+            if (blk >= a.nblk) continue;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {                    // {G_q, U_q} = row-blocks q and q + 2 of the region
-            const int nvg = a.nv[RPW * rg + q];
-            const int c0 = sw_sh + rg * a.R + 32 * q;
+            for (int r = 0; r < RPW; ++r)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (8 * (i >> 2) >= nvg) break;
-                const int f = 8 * (i >> 2) + 4 * hh + (i & 3);
-                const float gv = bfr_hw(acc[q][t][i]), uv = bfr_hw(acc[q + 2][t][i]);
-                const float sv = bfr_hw(gv * __builtin_amdgcn_rcpf(1.0f + __expf(-gv)));
-                const bf16_t o = f2bf_hw(sv * uv);
-                if (f < nvg) tile[trow * sw_stride + c0 + f] = o;
+                for (int gi = 0; gi < 4; ++gi) {
+                    const f32x4 v = {acc[r][t][4 * gi], acc[r][t][4 * gi + 1], acc[r][t][4 * gi + 2], acc[r][t][4 * gi + 3]};
+                    float* o = a.slabs + ((size_t)ks * a.M + blk * 64 + tok) * a.N + (blockIdx.x * RBV + RPW * rg + r) * 32 + 8 * gi + 4 * hh;
+                    *(f32x4*)o = v;
+                }
+        }
+    } else if constexpr (EPI == MB_QKV) {
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            const int tbg = tq * TW + t, blk = zb0 + (tbg >> 1), tok = (tbg & 1) * 32 + tl;
+            if (blk >= a.nblk) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)                  // region 2 x + j = row-blocks {2 j, 2 j + 1} = its {lo, hi} halves
+                fat_qkv_tile<RV>(a, acc[2 * j][t], acc[2 * j + 1][t], blockIdx.x * 2 + j, blk, tok, hh);
+        }
+    } else {
+        // ---- SwiGLU epilogue, as k_gemm_wide<8, TW, MB_SWIGLU>: act = bf16(silu(bf16(g)) * bf16(u)) parked as tile[token][sh + feature -
+        //      lo] in the drained ring, then 16-byte chunks of the activation image
+        const int sw_lo = a.R * 2 * blockIdx.x, sw_r = 2 * a.R, sw_sh = sw_lo & 7;
+        const int sw_nch = (sw_sh + sw_r + 7) >> 3;
+        const int sw_stride = (sw_nch * 8) % 64 == 0 ? sw_nch * 8 + 8 : sw_nch * 8;
+        __syncthreads();
+        bf16_t* tile = (bf16_t*)lds_raw;
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            const int tbg = tq * TW + t, blk = zb0 + (tbg >> 1), tok = (tbg & 1) * 32 + tl;
+            if (blk >= a.nblk) continue;
+            const int trow = (tbg >> 1) * 64 + tok;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {                    // {G_q, U_q} = row-blocks q and q + 2 of the region
+                const int nvg = a.nv[RPW * rg + q];
+                const int c0 = sw_sh + rg * a.R + 32 * q;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (8 * (i >> 2) >= nvg) break;
+                    const int f = 8 * (i >> 2) + 4 * hh + (i & 3);
+                    const float gv = bfr_hw(acc[q][t][i]), uv = bfr_hw(acc[q + 2][t][i]);
+                    const float sv = bfr_hw(gv * __builtin_amdgcn_rcpf(1.0f + __expf(-gv)));
+                    const bf16_t o = f2bf_hw(sv * uv);
+                    if (f < nvg) tile[trow * sw_stride + c0 + f] = o;
+                }
             }
         }
-    }
-    __syncthreads();
-    const int ntok = GEO::BLOCKS * 64;
-    for (int it = threadIdx.x; it < ntok * sw_nch; it += NW * 64) {
-        const int trow = it % ntok, c = it / ntok, blk = zb0 + (trow >> 6);
-        if (blk >= a.nblk) continue;
-        const int fa_ = (sw_lo & ~7) + 8 * c;
-        bf16_t* dst = a.act_xp + (size_t)blk * 64 * a.N + xp_offset(trow & 63, fa_);
-        const bf16_t* srcp = tile + trow * sw_stride + 8 * c;
-        if (fa_ >= sw_lo && fa_ + 8 <= sw_lo + sw_r) {
-            *(bf16x8*)dst = *(const bf16x8*)srcp;
-        } else {
+        __syncthreads();
+        const int ntok = GEO::BLOCKS * 64;
+        for (int it = threadIdx.x; it < ntok * sw_nch; it += NW * 64) {
+            const int trow = it % ntok, c = it / ntok, blk = zb0 + (trow >> 6);
+            if (blk >= a.nblk) continue;
+            const int fa_ = (sw_lo & ~7) + 8 * c;
+            bf16_t* dst = a.act_xp + (size_t)blk * 64 * a.N + xp_offset(trow & 63, fa_);
+            const bf16_t* srcp = tile + trow * sw_stride + 8 * c;
+            if (fa_ >= sw_lo && fa_ + 8 <= sw_lo + sw_r) {
+                *(bf16x8*)dst = *(const bf16x8*)srcp;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (fa_ + e >= sw_lo && fa_ + e < sw_lo + sw_r) dst[e] = srcp[e];
+                for (int e = 0; e < 8; ++e)
+                    if (fa_ + e >= sw_lo && fa_ + e < sw_lo + sw_r) dst[e] = srcp[e];
+            }
         }
     }
 }
@@ -2042,7 +2174,7 @@ int g_la_mb_attn_rot = 0;     // la_lab_set key 21: 1 = the query heads of a kv 
 int g_la_mb_attn_vring = 0;   // la_lab_set key 20: 1 = multi-block attention with the next tile's V in flight through a per-wave LDS ring (measured 0.5-5 % SLOWER per step, profiles/r04_mb_attention_vring_ab.txt), 0 = V requested per tile (default)
 int g_la_mb_dbg = 0;
 int g_la_mb_mode = 0;         // la_lab_set key 5: unused (was: the wide gate/up launch as two co-resident 256-row workgroups per CU on a 3-slot ring — four waves per SIMD; measured 7 % slower at 512 rows, profiles/r04_wide_gemm_schedule.txt part 5)
-int g_la_mb_pair = 1;         // la_debug_set key 6, bit 4 (round 5): gate/up at >= 3 blocks as four fat waves per workgroup (k_gemm_fat: the paired geometry, 4 x TW tiles per wave); bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
+int g_la_mb_pair = 1 | 16;    // la_debug_set key 6, bit 5 (round 5): the paired slab / QKV launches as fat waves too; bit 4 (round 5, default on): gate/up at >= 3 blocks as four fat waves per workgroup (k_gemm_fat: the paired geometry, 4 x TW tiles per wave); bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
 int g_la_mb_ks2 = 0;          // la_debug_set key 12: slab GEMMs of the multi-block step with 2 K splits at >= 5 blocks (measurement)
 int g_la_mb_narrow = 0;       // la_debug_set key 3: 1 = the K-split kernels (k_gemm_mb) for every nblk (A/B measurements)
 int g_la_ex_d4 = 1;           // la_lab_set key 25: merged-expert launches as two workgroups per CU (bit 0 gate/up, bit 1 down)
@@ -2104,9 +2236,15 @@ int lk_mb_init() {
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 4>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 5>, WideGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_wide<4, 4, MB_SWIGLU, 6, 3>, WideGeom<4, 4>::LDS);
-    if (e == hipSuccess) e = set_lds(k_gemm_fat<2>, FatGeom<2>::LDS);
-    if (e == hipSuccess) e = set_lds(k_gemm_fat<3>, FatGeom<3>::LDS);
-    if (e == hipSuccess) e = set_lds(k_gemm_fat<4>, FatGeom<4>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 2, MB_SWIGLU>, FatGeom<8, 2>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 3, MB_SWIGLU>, FatGeom<8, 3>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 4, MB_SWIGLU>, FatGeom<8, 4>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 1, MB_SLAB>, FatGeom<4, 1>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 2, MB_SLAB>, FatGeom<4, 2>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 1, MB_QKV, 4>, FatGeom<4, 1>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 2, MB_QKV, 4>, FatGeom<4, 2>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 1, MB_QKV, 2>, FatGeom<4, 1>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 2, MB_QKV, 2>, FatGeom<4, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_tree_attn_mb<false, true>, 8 * 66 * 64 * 4 + 16384);
     if (e == hipSuccess) e = set_lds(k_tree_attn_mb<false, false>, 8 * 66 * 64 * 4 + 16384);
     if (e == hipSuccess) e = set_lds(k_tree_attn_mb<true, true>, 8 * 66 * 64 * 4 + 16384);
@@ -2265,7 +2403,31 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                 // la_debug_set key 12 (slab launches with <= 2 K splits): more token groups instead — 2 blocks per workgroup at every block count
                 // QKV over at most 128 (fuller) workgroups — the multi-block image of a GQA model, cfg.qkv_mb_wg — takes token QUARTERS at
                 // every block count: n_wg / 2 x 4 <= 256 workgroups of 4 row-blocks x 4 token tiles (la_debug_set(6, 9) forces the form)
-                if (nblk <= 4 || (EPI == MB_SLAB && g_la_mb_ks2 && ksplit <= 2) || (EPI == MB_QKV && (n_wg <= 128 || (g_la_mb_pair & 8)))) wide_launch<4, 1, EPI>(dim3(n_wg / 2, ksplit, (nblk + 1) / 2), st, p);
+                // round 5 (bit 5 of key 6): the paired slab / QKV launches as four fat waves of 4 row-blocks x TW token blocks (k_gemm_fat);
+                // every K split must hold an even number of k-tiles
+                const bool fat = (g_la_mb_pair & 32) && a.K16 % (2 * ksplit) == 0 && g_la_mb_dbg == 0;
+                const bool quarters = nblk <= 4 || (EPI == MB_SLAB && g_la_mb_ks2 && ksplit <= 2) || (EPI == MB_QKV && (n_wg <= 128 || (g_la_mb_pair & 8)));
+                if constexpr (EPI == MB_SLAB) {
+                    if (fat) {
+                        if (quarters) k_gemm_fat<4, 1, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 1) / 2), 256, FatGeom<4, 1>::LDS, st>>>(p);
+                        else k_gemm_fat<4, 2, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 3) / 4), 256, FatGeom<4, 2>::LDS, st>>>(p);
+                        LAUNCH_CHECK(); return 0;
+                    }
+                }
+                if constexpr (EPI == MB_QKV) {
+                    if (fat && (a.R & 1) == 0) {              // RoPE pairs per workgroup: groups of 4 (7B, Mistral, Mixtral) or 2 (13B) rows per store
+                        const dim3 gq(n_wg / 2, ksplit, quarters ? (nblk + 1) / 2 : (nblk + 3) / 4);
+                        if ((a.R & 3) == 0) {
+                            if (quarters) k_gemm_fat<4, 1, EPI, 4><<<gq, 256, FatGeom<4, 1>::LDS, st>>>(p);
+                            else k_gemm_fat<4, 2, EPI, 4><<<gq, 256, FatGeom<4, 2>::LDS, st>>>(p);
+                        } else {
+                            if (quarters) k_gemm_fat<4, 1, EPI, 2><<<gq, 256, FatGeom<4, 1>::LDS, st>>>(p);
+                            else k_gemm_fat<4, 2, EPI, 2><<<gq, 256, FatGeom<4, 2>::LDS, st>>>(p);
+                        }
+                        LAUNCH_CHECK(); return 0;
+                    }
+                }
+                if (quarters) wide_launch<4, 1, EPI>(dim3(n_wg / 2, ksplit, (nblk + 1) / 2), st, p);
                 else if (g_la_mb_dbg == 4) k_gemm_wide<4, 2, EPI, 4><<<dim3(n_wg / 2, ksplit, (nblk + 3) / 4), 512, WideGeom<4, 2>::LDS, st>>>(p);   // measurement: no epilogue
                 else wide_launch<4, 2, EPI>(dim3(n_wg / 2, ksplit, (nblk + 3) / 4), st, p);
                 LAUNCH_CHECK(); return 0;
@@ -2285,9 +2447,9 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                 if (fat) {
                     // round 5: the same pair of regions as FOUR fat waves (4 x TW accumulator tiles each, one wave per SIMD): k_gemm_fat
                     switch ((nblk + 1) / 2) {
-                        case 2: k_gemm_fat<2><<<g2, 256, FatGeom<2>::LDS, st>>>(p); break;
-                        case 3: k_gemm_fat<3><<<g2, 256, FatGeom<3>::LDS, st>>>(p); break;
-                        default: k_gemm_fat<4><<<g2, 256, FatGeom<4>::LDS, st>>>(p); break;
+                        case 2: k_gemm_fat<8, 2, MB_SWIGLU><<<g2, 256, FatGeom<8, 2>::LDS, st>>>(p); break;
+                        case 3: k_gemm_fat<8, 3, MB_SWIGLU><<<g2, 256, FatGeom<8, 3>::LDS, st>>>(p); break;
+                        default: k_gemm_fat<8, 4, MB_SWIGLU><<<g2, 256, FatGeom<8, 4>::LDS, st>>>(p); break;
                     }
                     LAUNCH_CHECK(); return 0;
                 }
