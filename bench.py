@@ -182,8 +182,12 @@ def secondary_legs(spec, gpus=1, layers=0):
         item = item.strip()
         if not item:
             continue
-        model, batch = item.split(':')
+        parts = item.split(':')
+        model, batch = parts[0], parts[1]
+        dev_trie_leg = len(parts) > 2 and parts[2] == 'dev'      # model:batch:dev = the same leg with the drafts from the ON-GPU trie
         leg_args = ['--gpus', str(gpus), '--model', model, '--batch', batch, '--steps', '24', '--warmup', '4', '--no-cpu-baseline']
+        if dev_trie_leg:
+            leg_args.append('--device-trie')
         if layers:                       # launch-path tests only (tests/test_gpu_bench_launch.py): a truncated model, flagged in the leg
             leg_args += ['--layers', str(int(layers)), '--steps', '6', '--warmup', '2']
         cmd = [sys.executable, os.path.abspath(__file__)] + leg_args if gpus == 1 else self_launch_cmd(leg_args, gpus, _free_port())
@@ -202,10 +206,11 @@ def secondary_legs(spec, gpus=1, layers=0):
                          'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'warmup': j['warmup'], 'sequences': c['sequences'],
                          'mean_accept_len': c['mean_accept_len'], 'mean_draft_len': c['mean_draft_len'], 'kv_cache': c['kv_cache'],
                          'lookahead_equals_greedy': c['lookahead_equals_greedy'], 'context_at_end': c['context_at_end'],
+                         'draft_retrieval': c.get('draft_retrieval'), 'trie_update': c.get('trie_update'),
                          'n_gpus': j['n_gpus'], 'gather_mode': c.get('gather_mode'), 'gather_transport': c.get('gather_transport'),
                          'rccl_ranks': c.get('rccl_ranks'),
                          'roofline': j.get('roofline'), 'wall_s': round(time.time() - t0, 1), 'n_layers': c.get('n_layers'),
-                         'command': 'python bench.py --gpus %d --model %s --batch %s --steps 24 --warmup 4 --no-cpu-baseline' % (gpus, model, batch)})
+                         'command': 'python bench.py --gpus %d --model %s --batch %s --steps 24 --warmup 4 --no-cpu-baseline%s' % (gpus, model, batch, ' --device-trie' if dev_trie_leg else '')})
         except Exception as e:           # noqa: BLE001 — a secondary leg must never take the headline line down
             legs.append({'model': model, 'batch': int(batch), 'error': repr(e)[:300], 'wall_s': round(time.time() - t0, 1)})
     return legs
@@ -280,10 +285,11 @@ def main():
     ap.add_argument('--attn-split', type=int, default=0, help='key splits of the tree-attention kernel (0 = engine default 8)')
     ap.add_argument('--fuse', type=int, default=0, help='engine cfg.fuse bits (opt-in in-kernel norm->GEMM fusion; 0 = separate kernels)')
     ap.add_argument('--gemm-cfg', default='', help='engine gemm_cfg override (comma list: qkv_rb,qkv_ks,o_rb,o_ks,down_rb,down_ks,lm_rb,gu_variant; 0 = default)')
-    ap.add_argument('--secondary', default='mistral:8,13b:4,mixtral:4,13b:1',
+    ap.add_argument('--secondary', default='mistral:8,mistral:8:dev,13b:4,mixtral:4,13b:1',
                     help='N=1 default workload only: comma list of model:batch legs (BASELINE configs 3-5: a 64-token tree per sequence '
                          'through la_llama_mstep) run AFTER the timed region, each in its own process; their lines are embedded under '
-                         '"secondary"; 13b:1 = the 64-row step at a larger launch size (the HBM fraction rises with bytes per launch).  "" = none')
+                         '"secondary"; model:batch:dev = the same leg with the drafts from the on-GPU trie (BASELINE config 3 as stated: the host-trie line '
+                         'stands beside it); 13b:1 = the 64-row step at a larger launch size (the HBM fraction rises with bytes per launch).  "" = none')
     ap.add_argument('--decoding-length', type=int, default=64, help='tree tokens per sequence and step (BASELINE: 64); > 64 (the reference\'s best '
                     'published setting is 128 with --branch-length 32, lookahead/README.md:100): wide trees through eng.tstep, --batch 1')
     ap.add_argument('--branch-length', type=int, default=12)

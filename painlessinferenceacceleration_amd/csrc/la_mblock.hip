@@ -1023,6 +1023,14 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
             pdst[i] = (A_STAGE + kk * NTBP + tb) * 1024;
         }
     }
+    // the per-piece scalars are wave-uniform by construction; say so, or hipcc keeps the k-tile stride of the planned / classic select in
+    // a VGPR and wraps every weight piece in a v_readfirstlane waterfall loop (GPU call 3 of round 5: +8 us on the 512-row gate/up launch)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        gstr[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)gstr[i]);
+        pkk[i] = __builtin_amdgcn_readfirstlane(pkk[i]);
+        pdst[i] = __builtin_amdgcn_readfirstlane(pdst[i]);
+    }
     auto issue_one = [&](int sidx, int i) {
         int kt = t0 + sidx * KS + pkk[i];
         kt = kt < t1 ? kt : t1 - 1;
