@@ -20,6 +20,18 @@
 
 enum { MB_SLAB = 0, MB_SWIGLU = 1, MB_QKV = 2, MB_LOGITS = 3 };
 
+// k-tile range [t0, t1) of K split ks.  An even K16 is cut on EVEN k-tiles (round 5): every multi-block GEMM family uses the same
+// boundaries (so their split-K slabs stay bit-identical to each other), and the fat-wave kernels, which consume whole 2-k-tile stages,
+// take every shape with an even K16 — e.g. Llama-2-13B's o_proj, 320 k-tiles in 3 splits: 106 / 108 / 106 instead of 106 / 107 / 107.
+__device__ __forceinline__ void mb_k_range(int K16, int ks, int ksplit, int& t0, int& t1) {
+    if ((K16 & 1) == 0) {
+        const long h = K16 >> 1;
+        t0 = 2 * (int)((h * ks) / ksplit); t1 = 2 * (int)((h * (ks + 1)) / ksplit);
+    } else {
+        t0 = (int)(((long)K16 * ks) / ksplit); t1 = (int)(((long)K16 * (ks + 1)) / ksplit);
+    }
+}
+
 extern int g_la_ex_split;       // la_debug_set key 16 (la_engine.cpp)
 extern long long* g_la_dbg_times;
 struct MbArgs {
@@ -190,7 +202,8 @@ __device__ __forceinline__ void gemm_mb_body(const MbArgs& a, const int blk0, co
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rb = wave % RBV, kp = wave / RBV;
     const int ksplit = gridDim.y, ks = blockIdx.y;
-    const int t0 = (int)(((long)a.K16 * ks) / ksplit), t1 = (int)(((long)a.K16 * (ks + 1)) / ksplit);
+    int t0, t1;
+    mb_k_range(a.K16, ks, ksplit, t0, t1);
     const int twg = t1 - t0, pq = twg / KP, pr = twg - pq * KP;
     const int my_start = t0 + kp * pq + (kp < pr ? kp : pr), my_cnt = pq + (kp < pr ? 1 : 0);
     const int nstages = (pq + (pr > 0 ? 1 : 0) + KT - 1) / KT;
@@ -450,7 +463,8 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
     const int rb0 = (RBV == 8 && EPI == MB_QKV) ? 2 * rg : RBV == 8 ? 4 * (rg >> 1) + (rg & 1) : RBV == 4 ? ((EPI == MB_SWIGLU && !a.gu_interleaved) ? rg : 2 * rg) : 0;
     const int rb1 = (RBV == 8 && EPI == MB_QKV) ? 2 * rg + 1 : RBV == 8 ? rb0 + 2 : RBV == 4 ? ((EPI == MB_SWIGLU && !a.gu_interleaved) ? rg + 2 : 2 * rg + 1) : 1;
     const int ksplit = gridDim.y, ks = blockIdx.y;
-    const int t0 = (int)(((long)a.K16 * ks) / ksplit), t1 = (int)(((long)a.K16 * (ks + 1)) / ksplit);
+    int t0, t1;
+    mb_k_range(a.K16, ks, ksplit, t0, t1);
     const int nst = (t1 - t0 + KS - 1) / KS;
     const int zb0 = blockIdx.z * GEO::BLOCKS;       // first 64-row block of this workgroup (grid.z splits the token blocks)
 
@@ -987,7 +1001,8 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rg = wave / TQ, tq = wave % TQ;          // row group (4 row-blocks), token group
     const int ksplit = gridDim.y, ks = blockIdx.y;
-    const int t0 = (int)(((long)a.K16 * ks) / ksplit), t1 = (int)(((long)a.K16 * (ks + 1)) / ksplit);
+    int t0, t1;
+    mb_k_range(a.K16, ks, ksplit, t0, t1);
     const int nst = (t1 - t0) / KS;                    // an even range (launcher)
     const int zb0 = blockIdx.z * GEO::BLOCKS;
 
@@ -2182,7 +2197,7 @@ int g_la_mb_attn_rot = 0;     // la_lab_set key 21: 1 = the query heads of a kv 
 int g_la_mb_attn_vring = 0;   // la_lab_set key 20: 1 = multi-block attention with the next tile's V in flight through a per-wave LDS ring (measured 0.5-5 % SLOWER per step, profiles/r04_mb_attention_vring_ab.txt), 0 = V requested per tile (default)
 int g_la_mb_dbg = 0;
 int g_la_mb_mode = 0;         // la_lab_set key 5: unused (was: the wide gate/up launch as two co-resident 256-row workgroups per CU on a 3-slot ring — four waves per SIMD; measured 7 % slower at 512 rows, profiles/r04_wide_gemm_schedule.txt part 5)
-int g_la_mb_pair = 1 | 16;    // la_debug_set key 6, bit 5 (round 5): the paired slab / QKV launches as fat waves too; bit 4 (round 5, default on): gate/up at >= 3 blocks as four fat waves per workgroup (k_gemm_fat: the paired geometry, 4 x TW tiles per wave); bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
+int g_la_mb_pair = 1 | 16 | 32;   // la_debug_set key 6, bit 5 (round 5, default on: Mistral bs=8 9.91 -> 9.53 ms per step, profiles/r05_fat_waves.txt): the paired slab / QKV launches as fat waves too; bit 4 (round 5, default on): gate/up at >= 3 blocks as four fat waves per workgroup (k_gemm_fat: the paired geometry, 4 x TW tiles per wave); bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
 int g_la_mb_ks2 = 0;          // la_debug_set key 12: slab GEMMs of the multi-block step with 2 K splits at >= 5 blocks (measurement)
 int g_la_mb_narrow = 0;       // la_debug_set key 3: 1 = the K-split kernels (k_gemm_mb) for every nblk (A/B measurements)
 int g_la_ex_d4 = 1;           // la_lab_set key 25: merged-expert launches as two workgroups per CU (bit 0 gate/up, bit 1 down)
@@ -2413,7 +2428,7 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                 // every block count: n_wg / 2 x 4 <= 256 workgroups of 4 row-blocks x 4 token tiles (la_debug_set(6, 9) forces the form)
                 // round 5 (bit 5 of key 6): the paired slab / QKV launches as four fat waves of 4 row-blocks x TW token blocks (k_gemm_fat);
                 // every K split must hold an even number of k-tiles
-                const bool fat = (g_la_mb_pair & 32) && a.K16 % (2 * ksplit) == 0 && g_la_mb_dbg == 0;
+                const bool fat = (g_la_mb_pair & 32) && (a.K16 & 1) == 0 && a.K16 >= 2 * ksplit && g_la_mb_dbg == 0;
                 const bool quarters = nblk <= 4 || (EPI == MB_SLAB && g_la_mb_ks2 && ksplit <= 2) || (EPI == MB_QKV && (n_wg <= 128 || (g_la_mb_pair & 8)));
                 if constexpr (EPI == MB_SLAB) {
                     if (fat) {
