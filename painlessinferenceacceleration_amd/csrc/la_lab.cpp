@@ -40,7 +40,7 @@ int la_lab_set(int key, int value) {
     if (key == 16 && value >= 0 && value <= 3) { g_la_ex_split = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 17 && value >= 0 && value <= 1) { g_la_attn_one = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 24 && value >= 0 && value <= 1) { g_la_mb_sch = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 25 && value >= 0 && value <= 3) { g_la_ex_d4 = value; ++g_la_graph_epoch; return LA_OK; }
+    if (key == 25 && value >= 0 && value <= 15) { g_la_ex_d4 = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 18 && value >= 0 && value <= 7) { g_la_attn1_var = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 19 && value >= 0 && value <= 1) { g_la_norm4 = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 20 && value >= 0 && value <= 1) { g_la_mb_attn_vring = value; ++g_la_graph_epoch; return LA_OK; }

@@ -81,23 +81,25 @@ __device__ __forceinline__ void mb_epilogue_block(const MbArgs& a, const f32x4* 
         return v;
     };
     if constexpr (EPI == MB_SLAB) {
-        static_assert(EPI != MB_SLAB || RBV == 2, "slab layout");
-        // slices (rb, tb, gi): 16 -> 2 per wave
+        static_assert(EPI != MB_SLAB || RBV == 2 || RBV == 4, "slab layout");
+        // slices (rb, tb, gi): 8 RBV -> RBV per wave (RBV = 4: the paired form of the merged-expert launch, two 64-row regions per workgroup)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int sl = wave * 2 + i, rq = sl >> 3, tb = (sl >> 2) & 1, gi = sl & 3;
+        for (int i = 0; i < RBV; ++i) {
+            const int sl = wave * RBV + i, rq = sl >> 3, tb = (sl >> 2) & 1, gi = sl & 3;
             const f32x4 v = total4(rq, tb, gi);
             const int tok = blk * 64 + tb * 32 + tl;
             float* o = a.slabs + o_off + ((size_t)ks * a.M + tok) * a.N + (blockIdx.x * RBV + rq) * 32 + 8 * gi + 4 * hh;
             *(f32x4*)o = v;
         }
     } else if constexpr (EPI == MB_SWIGLU) {
-        static_assert(EPI != MB_SWIGLU || RBV == 4, "swiglu layout {G0,G1,U0,U1}");
-        // pair slices (q, tb, gi): 16 -> 2 per wave;  act = bf16(silu(bf16(g)) * bf16(u)) (LlamaMLP.forward, :185-186)
+        static_assert(EPI != MB_SWIGLU || RBV == 4 || RBV == 8, "swiglu layout {G0,G1,U0,U1} (x 2 regions: the paired merged-expert launch)");
+        // pair slices (region, q, tb, gi): 4 RBV -> RBV / 2 per wave;  act = bf16(silu(bf16(g)) * bf16(u)) (LlamaMLP.forward, :185-186)
+        constexpr int NREG = RBV / 4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int sl = wave * 2 + i, qq = sl >> 3, tb = (sl >> 2) & 1, gi = sl & 3;
-            const int rg = a.gu_interleaved ? 2 * qq : qq, ru = a.gu_interleaved ? 2 * qq + 1 : qq + 2;
+        for (int i = 0; i < RBV / 2; ++i) {
+            const int sl = wave * (RBV / 2) + i, qa = sl >> 3, tb = (sl >> 2) & 1, gi = sl & 3;
+            const int region = qa >> 1, qq = NREG == 1 ? qa : (qa & 1);
+            const int rg = (NREG == 1 && a.gu_interleaved) ? 2 * qq : 4 * region + qq, ru = (NREG == 1 && a.gu_interleaved) ? 2 * qq + 1 : rg + 2;
             if (8 * gi + 4 * hh < a.nv[rg]) {
                 const f32x4 g4 = total4(rg, tb, gi), u4 = total4(ru, tb, gi);
                 const int tok = tb * 32 + tl;
@@ -107,7 +109,7 @@ __device__ __forceinline__ void mb_epilogue_block(const MbArgs& a, const f32x4* 
                     if (f < a.nv[rg]) {
                         const float gv = bfr(g4[j]), uv = bfr(u4[j]);
                         const float sv = bfr(gv / (1.0f + expf(-gv)));
-                        const int feat = a.gu_interleaved ? (2 * blockIdx.x + qq) * 32 + f : a.R * blockIdx.x + 32 * qq + f;
+                        const int feat = (NREG == 1 && a.gu_interleaved) ? (2 * blockIdx.x + qq) * 32 + f : a.R * (NREG * blockIdx.x + region) + 32 * qq + f;
                         a.act_xp[o_off + (size_t)blk * 64 * a.N + xp_offset(tok, feat)] = f2bf(sv * uv);
                     }
                 }
@@ -2200,7 +2202,7 @@ int g_la_mb_mode = 0;         // la_lab_set key 5: unused (was: the wide gate/up
 int g_la_mb_pair = 1 | 16 | 32;   // la_debug_set key 6, bit 5 (round 5, default on: Mistral bs=8 9.91 -> 9.53 ms per step, profiles/r05_fat_waves.txt): the paired slab / QKV launches as fat waves too; bit 4 (round 5, default on): gate/up at >= 3 blocks as four fat waves per workgroup (k_gemm_fat: the paired geometry, 4 x TW tiles per wave); bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
 int g_la_mb_ks2 = 0;          // la_debug_set key 12: slab GEMMs of the multi-block step with 2 K splits at >= 5 blocks (measurement)
 int g_la_mb_narrow = 0;       // la_debug_set key 3: 1 = the K-split kernels (k_gemm_mb) for every nblk (A/B measurements)
-int g_la_ex_d4 = 1;           // la_lab_set key 25: merged-expert launches as two workgroups per CU (bit 0 gate/up, bit 1 down)
+int g_la_ex_d4 = 1;           // la_lab_set key 25: merged-expert launches as two workgroups per CU (bit 0 gate/up, bit 1 down); round 5: two weight regions per workgroup (bit 2 gate/up, bit 3 down) — takes precedence over bits 0 / 1
 int g_la_mb_sch = 1;          // la_lab_set key 24: 1 = round-4 schedule of the wide GEMMs (default), 0 = the round-2 schedule (A/B reference)
 template <int RBV, int TW, int EPI>
 static void wide_launch(dim3 grid, hipStream_t st, const MbArgs& a) {
@@ -2226,6 +2228,8 @@ int lk_mb_init() {
     if (e == hipSuccess) e = set_lds(k_gemm_mb<4, NT, MB_LOGITS>, mb_lds(NT));
     SETALL(2) SETALL(4) SETALL(8)
 #undef SETALL
+    if (e == hipSuccess) e = set_lds(k_gemm_mb<4, 4, MB_SLAB, true>, mb_lds(4));
+    if (e == hipSuccess) e = set_lds(k_gemm_mb<8, 4, MB_SWIGLU, true>, mb_lds(4));
     if (e == hipSuccess) e = set_lds(k_gemm_mb<2, 4, MB_SLAB, true>, mb_lds(4));
     if (e == hipSuccess) e = set_lds(k_gemm_mb<4, 4, MB_SWIGLU, true>, mb_lds(4));
     if (e == hipSuccess) e = set_lds(k_gemm_mb<2, 4, MB_SLAB, true, 4>, mb_lds(4));
@@ -2361,6 +2365,21 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
         // gathered expert: the block count is a device value (typically 1-2 of the step's nblk): passes of two blocks, a pass
         // past the expert's count returns before it touches the weights
         if constexpr (EPI == MB_SLAB || EPI == MB_SWIGLU) {
+            if (a.ex_n > 1 && (g_la_ex_d4 & (RBV == 4 ? 4 : 8)) && n_wg % 2 == 0 && (!a.planned || !a.gu_interleaved)) {
+                // round 5 (la_lab_set key 25, bit 2 = gate/up, bit 3 = down): TWO adjacent weight regions per workgroup.  Every workgroup of an
+                // expert stages the expert's whole x through LDS: 0.5-1.8 MB from L2 per 0.9 MB of weights from HBM, and the per-CU times of
+                // the two ADD (T = W / 25 GB/s + x / 130 GB/s) — the gap between these launches (4.6-5.2 TB/s of weights) and the
+                // dense 64-row kernels (5.9).  With two regions per workgroup the x traffic and the LDS reads per weight byte halve: the 8 waves
+                // are 2 RBV row-blocks x 4 / RBV K parts (gate/up: one row-block per wave over the whole K range).  Same MFMA chain per output
+                // element and the same fixed summation order of the K parts: bit-identical slabs / activations.
+                MbArgs p = a;
+                if (p.planned) {
+                    for (int i = 0; i < 4; ++i) { p.boff[4 + i] = a.wg_chunks + a.boff[i]; p.nv[4 + i] = a.nv[i]; p.nvl[4 + i] = a.nvl[i]; }
+                    p.wg_chunks = 2 * a.wg_chunks;
+                }
+                k_gemm_mb<2 * RBV, 4, EPI, true><<<dim3(n_wg / 2, ksplit, (nblk + 1) / 2 * a.ex_n), 512, mb_lds(4), st>>>(p);
+                LAUNCH_CHECK(); return 0;
+            }
             if (a.ex_n > 1) {
                 // two workgroups per CU (D = 4, <= 128 VGPRs): la_lab_set key 25 bit 0 = the gate/up launch (default on: Mixtral bs=4
                 // 21.0-21.5 -> 20.1-20.2 ms per step), bit 1 = the down launch (RBV = 2: 44 B per lane of scratch at that bound)

@@ -844,3 +844,44 @@ def test_mstep_mixtral8x7b_layer_shape_gathered_experts_vs_oracle_with_forced_ro
           f'{n_dec}/{n_all}; rows per expert, layer 0: {hit[0].int().tolist()}')
     assert n_dec >= 0.25 * n_all
     assert bool((hit > 0).all()), 'every expert of every layer received rows (the gathered path ran for all of them)'
+
+
+def test_merged_expert_launch_forms_agree():
+    """la_lab_set key 25: the merged-expert launches of the gathered MoE step.  One workgroup per CU (0) and two per CU with 4 weight tiles
+    in flight (bits 0 / 1) run the same MFMA chain per output element and sum the K parts in the same fixed order: bit-identical logits.
+    The round-5 forms with TWO adjacent weight regions per workgroup (bits 2 / 3: half the x traffic and LDS reads per weight byte) give a
+    wave a longer K range (gate/up: the whole K in one accumulator chain instead of two K parts; down: two parts instead of four), i.e.
+    another — equally valid, deterministic — fp32 summation order: same routing (the router runs before the experts), logits within bf16 noise of the other forms (1e-2 of max|logit| per row; the stated tolerance vs the oracle is 2e-2 and is asserted for
+    whatever form is the default by test_mstep_mixtral8x7b_layer_shape_gathered_experts_vs_oracle_with_forced_routing)."""
+    shape = LlamaShape(1, 4096, 32, 8, 14336, 32000, 1e-5, rope_theta=1e6, n_experts=8, top_k=2, norm_cast_first=True)
+    sd = random_weights(shape, seed=13, device='cpu')
+    B = 4
+    default_form = lib.la_lab_get(25)
+    outs = {}
+    try:
+        for form in (0, 1, 3, 4, 8, 12):
+            check(_lib.lab_set(25, form), 'lab_set')
+            eng = LlamaVerifyEngine(shape, dict(sd), max_length=256, n_slots=B, max_blocks=B)
+            rs = np.random.RandomState(31)
+            blocks = []
+            for b in range(B):
+                p = rs.randint(3, shape.vocab, size=int(rs.randint(20, 64))).tolist()
+                tok = eng.mprefill(b, p)
+                T = 64 if b < 2 else int(rs.randint(30, 65))
+                _, rows = random_tree(rs, T)
+                ids = np.concatenate([[tok], rs.randint(3, shape.vocab, size=T - 1)]).astype(np.int32)
+                blocks.append((b, ids, rows, 0, 16))
+            toks = eng.mstep(blocks)
+            outs[form] = (eng.mlogits()[:B * 64].clone(), eng.mroute_weights().clone(), toks)
+            del eng
+    finally:
+        _lib.lab_set(25, default_form)
+    ref = outs[0]
+    assert bool(torch.isfinite(ref[0].float()).all()) and float(ref[0].float().abs().max()) > 0
+    for form in (1, 3):
+        assert torch.equal(outs[form][0], ref[0]) and torch.equal(outs[form][1], ref[1]) and outs[form][2] == ref[2], form
+    for form in (4, 8, 12):
+        lg = outs[form][0].float()
+        err = (lg - ref[0].float()).abs().amax(-1) / ref[0].float().abs().amax(-1).clamp_min(1e-6)
+        assert torch.equal(outs[form][1], ref[1]), form                      # routing weights: identical (the router precedes the experts)
+        assert float(err.max()) <= 1e-2, (form, float(err.max()))
