@@ -4,7 +4,7 @@
  * capture their graphs again after a change.
  *
  * Defaults: everything 0 except key 6 = 49 (paired wide launches + their fat-wave forms), key 11 = 1 (one step per graph), key 17 = 1
- * (single-launch tree attention), key 24 = 1, key 25 = 1.
+ * (single-launch tree attention), key 24 = 1, key 25 = 13.
  */
 #ifndef LOOKAHEAD_HIP_LAB_H
 #define LOOKAHEAD_HIP_LAB_H
@@ -47,7 +47,9 @@ extern "C" {
  * key 24: schedule of the wide multi-block GEMMs, 1 = buffer-addressed LDS-DMA pieces and (>= 3 token tiles per wave) a fragment read
  *         after every MFMA (default), 0 = 64-bit per-lane piece pointers and the six reads of a k-tile together; bit-identical. 
  * key 25: merged-expert launches of the gathered MoE step as TWO workgroups per CU (4 instead of 8 weight tiles in flight per wave,
- *         <= 128 VGPRs): bit 0 = gate/up (default on), bit 1 = down_proj. */
+ *         <= 128 VGPRs): bit 0 = gate/up (default on), bit 1 = down_proj; round 5: TWO adjacent weight regions per workgroup (half the x
+ *         traffic and LDS reads per weight byte; another fp32 summation order), bit 2 = gate/up (planned images), bit 3 = down_proj — both on
+ *         by default (key 25 = 13), they take precedence over bits 0 / 1. */
 int          la_lab_set(int key, int value);
 int          la_lab_get(int key);          /* current value of a knob (the library default unless la_lab_set changed it) */
 /* key 0: device buffer int64[workgroups][waves][8] the GEMM kernels stamp with wall_clock64() at entry / end of the

@@ -2202,7 +2202,7 @@ int g_la_mb_mode = 0;         // la_lab_set key 5: unused (was: the wide gate/up
 int g_la_mb_pair = 1 | 16 | 32;   // la_debug_set key 6, bit 5 (round 5, default on: Mistral bs=8 9.91 -> 9.53 ms per step, profiles/r05_fat_waves.txt): the paired slab / QKV launches as fat waves too; bit 4 (round 5, default on): gate/up at >= 3 blocks as four fat waves per workgroup (k_gemm_fat: the paired geometry, 4 x TW tiles per wave); bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
 int g_la_mb_ks2 = 0;          // la_debug_set key 12: slab GEMMs of the multi-block step with 2 K splits at >= 5 blocks (measurement)
 int g_la_mb_narrow = 0;       // la_debug_set key 3: 1 = the K-split kernels (k_gemm_mb) for every nblk (A/B measurements)
-int g_la_ex_d4 = 1;           // la_lab_set key 25: merged-expert launches as two workgroups per CU (bit 0 gate/up, bit 1 down); round 5: two weight regions per workgroup (bit 2 gate/up, bit 3 down) — takes precedence over bits 0 / 1
+int g_la_ex_d4 = 13;          // la_lab_set key 25 (default 13 = bits 0 + 2 + 3: Mixtral bs=4 19.75 -> 18.96 ms per step, profiles/r05_moe_paired_experts.txt): merged-expert launches as two workgroups per CU (bit 0 gate/up, bit 1 down); round 5: two weight regions per workgroup (bit 2 gate/up, bit 3 down) — takes precedence over bits 0 / 1
 int g_la_mb_sch = 1;          // la_lab_set key 24: 1 = round-4 schedule of the wide GEMMs (default), 0 = the round-2 schedule (A/B reference)
 template <int RBV, int TW, int EPI>
 static void wide_launch(dim3 grid, hipStream_t st, const MbArgs& a) {
@@ -2365,7 +2365,7 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
         // gathered expert: the block count is a device value (typically 1-2 of the step's nblk): passes of two blocks, a pass
         // past the expert's count returns before it touches the weights
         if constexpr (EPI == MB_SLAB || EPI == MB_SWIGLU) {
-            if (a.ex_n > 1 && (g_la_ex_d4 & (RBV == 4 ? 4 : 8)) && n_wg % 2 == 0 && (!a.planned || !a.gu_interleaved)) {
+            if (a.ex_n > 1 && (g_la_ex_d4 & (RBV == 4 ? 4 : 8)) && n_wg % 2 == 0 && (EPI == MB_SLAB || (a.planned && !a.gu_interleaved))) {
                 // round 5 (la_lab_set key 25, bit 2 = gate/up, bit 3 = down): TWO adjacent weight regions per workgroup.  Every workgroup of an
                 // expert stages the expert's whole x through LDS: 0.5-1.8 MB from L2 per 0.9 MB of weights from HBM, and the per-CU times of
                 // the two ADD (T = W / 25 GB/s + x / 130 GB/s) — the gap between these launches (4.6-5.2 TB/s of weights) and the

@@ -124,7 +124,7 @@ def test_debug_knobs_roundtrip_and_defaults():
     documented ones (everything 0 except key 6 = 49: the paired wide launches + (round 5) the fat-wave forms of gate/up and of the paired slab / QKV launches, and key 11 = 1 step per graph; round 3: 13 = depth probe,
     14 = split head / tail kernels, 15 = 4-wave GEMM variants; round 4: 17 = single-launch tree attention, default ON)."""
     lib = _lib.lib
-    defaults = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0, 5: 0, 6: 49, 7: 0, 8: 0, 9: 0, 10: 0, 11: 1, 12: 0, 13: 0, 14: 0, 15: 0, 16: 0, 17: 1, 18: 0, 19: 0, 20: 0, 21: 0, 22: 0, 23: 0, 24: 1, 25: 1}
+    defaults = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0, 5: 0, 6: 49, 7: 0, 8: 0, 9: 0, 10: 0, 11: 1, 12: 0, 13: 0, 14: 0, 15: 0, 16: 0, 17: 1, 18: 0, 19: 0, 20: 0, 21: 0, 22: 0, 23: 0, 24: 1, 25: 13}
     for key, d in defaults.items():
         assert lib.la_lab_get(key) == d, key
     try:
