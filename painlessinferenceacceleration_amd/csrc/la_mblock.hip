@@ -889,7 +889,8 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
 // ---------------------------------------------------------------------------------------------------------------
 template <int RBV, int TW> struct FatGeom {
     static constexpr int KS = 2, RPW = 4, NW = 4, RG = RBV / RPW, TQ = NW / RG, NTBP = TQ * TW;
-    static constexpr int A_STAGE = KS * RBV, B_STAGE = KS * NTBP, STAGE = A_STAGE + B_STAGE, NR = 4;
+    static constexpr int A_STAGE = KS * RBV, B_STAGE = KS * NTBP, STAGE = A_STAGE + B_STAGE;
+    static constexpr int NR = 4 * STAGE * 1024 <= 144 * 1024 ? 4 : 3;          // ring slots (one region x 512 rows: 40 KiB per stage -> 3)
     static constexpr int NP = STAGE / NW;                                    // pieces per wave and stage
     static constexpr int NPA = A_STAGE / NW;                                 // ... of which weight pieces (the first NPA)
     static constexpr int H = (NP + 1) / 2;
@@ -992,12 +993,12 @@ __device__ __forceinline__ void fat_qkv_tile(const MbArgs& a, const f32x16& lo, 
     }
 }
 
-template <int RBV, int TW, int EPI, int RV = 4>
+template <int RBV, int TW, int EPI, int RV = 4, int WPOL = 0>
 __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
     using GEO = FatGeom<RBV, TW>;
     constexpr int KS = GEO::KS, RPW = GEO::RPW, NW = GEO::NW, TQ = GEO::TQ, NTBP = GEO::NTBP;
     constexpr int A_STAGE = GEO::A_STAGE, STAGE = GEO::STAGE, NR = GEO::NR, NP = GEO::NP, NPA = GEO::NPA, H = GEO::H;
-    static_assert((EPI == MB_SWIGLU && RBV == 8) || ((EPI == MB_SLAB || EPI == MB_QKV) && RBV == 4), "gate/up pairs two planned regions; slab / QKV pair two {lo, hi} regions");
+    static_assert((EPI == MB_SWIGLU && (RBV == 8 || RBV == 4)) || ((EPI == MB_SLAB || EPI == MB_QKV) && RBV == 4), "gate/up: one planned region {G0,G1,U0,U1} x all token blocks, or two regions x half of them; slab / QKV: two {lo, hi} regions");
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1053,7 +1054,9 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
         kt = kt < t1 ? kt : t1 - 1;
         char* d = lds_raw + (sidx % NR) * (STAGE * 1024) + pdst[i];
         const unsigned so = (unsigned)kt * gstr[i];
-        if (i < NPA) dma_piece<0>(rs_w, d, voff[i], so);      // (paired form: the other token group reads the same rows, default policy)
+        // WPOL (compile-time: no branch in the loop): 0 = default cache policy — the paired forms, where the other token group reads the same
+        // rows; 2 = nt — one region x all token blocks, every weight byte is read once
+        if (i < NPA) dma_piece<WPOL>(rs_w, d, voff[i], so);
         else dma_piece<0>(rs_x, d, voff[i], so);
     };
 
@@ -1146,7 +1149,8 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
     } else {
         // ---- SwiGLU epilogue, as k_gemm_wide<8, TW, MB_SWIGLU>: act = bf16(silu(bf16(g)) * bf16(u)) parked as tile[token][sh + feature -
         //      lo] in the drained ring, then 16-byte chunks of the activation image
-        const int sw_lo = a.R * 2 * blockIdx.x, sw_r = 2 * a.R, sw_sh = sw_lo & 7;
+        constexpr int NREG = RBV / 4;                          // planned regions per workgroup
+        const int sw_lo = a.R * NREG * blockIdx.x, sw_r = NREG * a.R, sw_sh = sw_lo & 7;
         const int sw_nch = (sw_sh + sw_r + 7) >> 3;
         const int sw_stride = (sw_nch * 8) % 64 == 0 ? sw_nch * 8 + 8 : sw_nch * 8;
         __syncthreads();
@@ -2266,6 +2270,9 @@ int lk_mb_init() {
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 2, MB_SWIGLU>, FatGeom<8, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 3, MB_SWIGLU>, FatGeom<8, 3>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 4, MB_SWIGLU>, FatGeom<8, 4>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 2, MB_SWIGLU, 4, 2>, FatGeom<4, 2>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 3, MB_SWIGLU, 4, 2>, FatGeom<4, 3>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 4, MB_SWIGLU, 4, 2>, FatGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 1, MB_SLAB>, FatGeom<4, 1>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 2, MB_SLAB>, FatGeom<4, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 1, MB_QKV, 4>, FatGeom<4, 1>::LDS);
@@ -2476,6 +2483,19 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
             }
         }
         if constexpr (RBV == 4 && EPI == MB_SWIGLU) {
+            // round 5 (bit 6 of key 6): ONE planned region x ALL token blocks per workgroup as four fat waves (4 row-blocks x TW token blocks each,
+            // 1 x 4 wave grid).  The paired fat form makes every CU pull TWO regions' weights, and since the two token halves run in lockstep
+            // both wait for the same HBM miss: 1.83 MB per CU at the HBM-class per-CU rate (~25 GB/s) = 73 us of the 103-113 us launch at the
+            // Mistral shape, 512 rows.  One region per workgroup: 0.92 MB of weights (nt) + 4 MB of x from L2 (~130 GB/s) per CU.
+            if ((g_la_mb_pair & 64) && a.planned && !a.gu_interleaved && ksplit == 1 && (a.K16 & 1) == 0 && nblk <= 8) {
+                const dim3 g1(n_wg, 1, 1);
+                switch ((nblk + 1) / 2) {
+                    case 2: k_gemm_fat<4, 2, MB_SWIGLU, 4, 2><<<g1, 256, FatGeom<4, 2>::LDS, st>>>(a); break;
+                    case 3: k_gemm_fat<4, 3, MB_SWIGLU, 4, 2><<<g1, 256, FatGeom<4, 3>::LDS, st>>>(a); break;
+                    default: k_gemm_fat<4, 4, MB_SWIGLU, 4, 2><<<g1, 256, FatGeom<4, 4>::LDS, st>>>(a); break;
+                }
+                LAUNCH_CHECK(); return 0;
+            }
             // paired gate/up launch (planned images): regions {2 x, 2 x + 1} = row-blocks 0..7, half the token blocks per workgroup.
             // Bit-identical, but NOT faster (this launch is bound by its MFMA / ds_read side, not by the x traffic: 512 rows 116.5 vs
             // 116.4 us, 256 rows 68.4 vs 76.6 us at the 7B shape, profiles/r02b_mblock_paired_ab.txt): opt-in (la_debug_set(6, 3)).

@@ -378,12 +378,12 @@ def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
             wu_ = bf(torch.randn(F, K, generator=g, device=DEV) * 0.05)
             wp = gu.pack_planned(1, [wg_, wu_], 256)
             outs = []
-            for pair in (0, 3, 17):         # 17 = round 5: the pair of regions as FOUR fat waves (k_gemm_fat, 4 x TW accumulator tiles per wave)
+            for pair in (0, 3, 17, 65):     # 17 = round 5: the pair of regions as FOUR fat waves (k_gemm_fat, 4 x TW accumulator tiles per wave); 65 = ONE region x all token blocks as four fat waves
                 check(lib.la_lab_set(6, pair), 'debug_set')
                 act = torch.zeros(8 * 64 * F, dtype=torch.bfloat16, device=DEV)
                 _mb(1, wp, _pack_blocks(x), F, K, nblk, n_wg=256, act=act)
                 outs.append(act)
-            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (F, K)
+            assert all(torch.equal(outs[0], o) for o in outs[1:]), (F, K)
             assert float(outs[0][:nblk * 64 * F].float().abs().sum()) > 0
     finally:
         lib.la_lab_set(6, default_form)
