@@ -2203,7 +2203,7 @@ int g_la_mb_attn_rot = 0;     // la_lab_set key 21: 1 = the query heads of a kv 
 int g_la_mb_attn_vring = 0;   // la_lab_set key 20: 1 = multi-block attention with the next tile's V in flight through a per-wave LDS ring (measured 0.5-5 % SLOWER per step, profiles/r04_mb_attention_vring_ab.txt), 0 = V requested per tile (default)
 int g_la_mb_dbg = 0;
 int g_la_mb_mode = 0;         // la_lab_set key 5: unused (was: the wide gate/up launch as two co-resident 256-row workgroups per CU on a 3-slot ring — four waves per SIMD; measured 7 % slower at 512 rows, profiles/r04_wide_gemm_schedule.txt part 5)
-int g_la_mb_pair = 1 | 16 | 32;   // la_debug_set key 6, bit 5 (round 5, default on: Mistral bs=8 9.91 -> 9.53 ms per step, profiles/r05_fat_waves.txt): the paired slab / QKV launches as fat waves too; bit 4 (round 5, default on): gate/up at >= 3 blocks as four fat waves per workgroup (k_gemm_fat: the paired geometry, 4 x TW tiles per wave); bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
+int g_la_mb_pair = 1 | 16 | 32 | 64;   // la_debug_set key 6, bit 6 (round 5, default on): gate/up at <= 4 blocks as ONE region x all token blocks per workgroup (fat waves; bit 7: at every block count), bit 5 (round 5, default on: Mistral bs=8 9.91 -> 9.53 ms per step, profiles/r05_fat_waves.txt): the paired slab / QKV launches as fat waves too; bit 4 (round 5, default on): gate/up at >= 3 blocks as four fat waves per workgroup (k_gemm_fat: the paired geometry, 4 x TW tiles per wave); bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
 int g_la_mb_ks2 = 0;          // la_debug_set key 12: slab GEMMs of the multi-block step with 2 K splits at >= 5 blocks (measurement)
 int g_la_mb_narrow = 0;       // la_debug_set key 3: 1 = the K-split kernels (k_gemm_mb) for every nblk (A/B measurements)
 int g_la_ex_d4 = 13;          // la_lab_set key 25 (default 13 = bits 0 + 2 + 3: Mixtral bs=4 19.75 -> 18.96 ms per step, profiles/r05_moe_paired_experts.txt): merged-expert launches as two workgroups per CU (bit 0 gate/up, bit 1 down); round 5: two weight regions per workgroup (bit 2 gate/up, bit 3 down) — takes precedence over bits 0 / 1
@@ -2487,7 +2487,10 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
             // 1 x 4 wave grid).  The paired fat form makes every CU pull TWO regions' weights, and since the two token halves run in lockstep
             // both wait for the same HBM miss: 1.83 MB per CU at the HBM-class per-CU rate (~25 GB/s) = 73 us of the 103-113 us launch at the
             // Mistral shape, 512 rows.  One region per workgroup: 0.92 MB of weights (nt) + 4 MB of x from L2 (~130 GB/s) per CU.
-            if ((g_la_mb_pair & 64) && a.planned && !a.gu_interleaved && ksplit == 1 && (a.K16 & 1) == 0 && nblk <= 8) {
+            // Measured (profiles/r05_fat_waves.txt, call 6): it wins at <= 4 blocks (13B 256 rows 90.3 -> 84.6 us, 13B bs=4 10.77 -> 10.63 ms per
+            // step) and LOSES at 512 rows (Mistral 115.8 -> 121.2 us: 4 MB of x per CU instead of 2) — so it is taken at <= 4 blocks only;
+            // bit 7 forces it at every block count (measurement).
+            if ((g_la_mb_pair & 64) && a.planned && !a.gu_interleaved && ksplit == 1 && (a.K16 & 1) == 0 && (nblk <= 4 || ((g_la_mb_pair & 128) && nblk <= 8))) {
                 const dim3 g1(n_wg, 1, 1);
                 switch ((nblk + 1) / 2) {
                     case 2: k_gemm_fat<4, 2, MB_SWIGLU, 4, 2><<<g1, 256, FatGeom<4, 2>::LDS, st>>>(a); break;

@@ -378,7 +378,7 @@ def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
             wu_ = bf(torch.randn(F, K, generator=g, device=DEV) * 0.05)
             wp = gu.pack_planned(1, [wg_, wu_], 256)
             outs = []
-            for pair in (0, 3, 17, 65):     # 17 = round 5: the pair of regions as FOUR fat waves (k_gemm_fat, 4 x TW accumulator tiles per wave); 65 = ONE region x all token blocks as four fat waves
+            for pair in (0, 3, 17, 65 + 128):     # 17 = round 5: the pair of regions as FOUR fat waves (k_gemm_fat, 4 x TW accumulator tiles per wave); 193 = ONE region x all token blocks as four fat waves (bit 6; bit 7: at every block count)
                 check(lib.la_lab_set(6, pair), 'debug_set')
                 act = torch.zeros(8 * 64 * F, dtype=torch.bfloat16, device=DEV)
                 _mb(1, wp, _pack_blocks(x), F, K, nblk, n_wg=256, act=act)
