@@ -887,8 +887,8 @@ __global__ __launch_bounds__(512) void k_gemm_wide(MbArgs a) {
 // tile a loop-carried phi with two sources, and hipcc then spills accumulators INSIDE the loop): the launcher sends other shapes
 // to k_gemm_wide.
 // ---------------------------------------------------------------------------------------------------------------
-template <int RBV, int TW> struct FatGeom {
-    static constexpr int KS = 2, RPW = 4, NW = 4, RG = RBV / RPW, TQ = NW / RG, NTBP = TQ * TW;
+template <int RBV, int TW, int RPW_ = 4> struct FatGeom {
+    static constexpr int KS = 2, RPW = RPW_, NW = 4, RG = RBV / RPW, TQ = NW / RG, NTBP = TQ * TW;
     static constexpr int A_STAGE = KS * RBV, B_STAGE = KS * NTBP, STAGE = A_STAGE + B_STAGE;
     static constexpr int NR = 4 * STAGE * 1024 <= 144 * 1024 ? 4 : 3;          // ring slots (one region x 512 rows: 40 KiB per stage -> 3)
     static constexpr int NP = STAGE / NW;                                    // pieces per wave and stage
@@ -896,7 +896,7 @@ template <int RBV, int TW> struct FatGeom {
     static constexpr int H = (NP + 1) / 2;
     static constexpr int LDS = NR * STAGE * 1024;
     static constexpr int BLOCKS = NTBP / 2;
-    static_assert((RBV == 8 || RBV == 4) && STAGE % NW == 0 && A_STAGE % NW == 0 && NTBP % 2 == 0 && LDS <= 160 * 1024, "ring geometry");
+    static_assert((RBV == 8 || RBV == 4 || RBV == 2) && RBV % RPW == 0 && STAGE % NW == 0 && A_STAGE % NW == 0 && NTBP % 2 == 0 && LDS <= 160 * 1024, "ring geometry");
 };
 
 // RoPE + fragment stores of one {lo, hi} accumulator pair (the QKV epilogue of k_gemm_wide, same arithmetic and rounding points:
@@ -993,12 +993,12 @@ __device__ __forceinline__ void fat_qkv_tile(const MbArgs& a, const f32x16& lo, 
     }
 }
 
-template <int RBV, int TW, int EPI, int RV = 4, int WPOL = 0>
+template <int RBV, int TW, int EPI, int RV = 4, int WPOL = 0, int RPW_ = 4>
 __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
-    using GEO = FatGeom<RBV, TW>;
+    using GEO = FatGeom<RBV, TW, RPW_>;
     constexpr int KS = GEO::KS, RPW = GEO::RPW, NW = GEO::NW, TQ = GEO::TQ, NTBP = GEO::NTBP;
     constexpr int A_STAGE = GEO::A_STAGE, STAGE = GEO::STAGE, NR = GEO::NR, NP = GEO::NP, NPA = GEO::NPA, H = GEO::H;
-    static_assert((EPI == MB_SWIGLU && (RBV == 8 || RBV == 4)) || ((EPI == MB_SLAB || EPI == MB_QKV) && RBV == 4), "gate/up: one planned region {G0,G1,U0,U1} x all token blocks, or two regions x half of them; slab / QKV: two {lo, hi} regions");
+    static_assert((EPI == MB_SWIGLU && (RBV == 8 || RBV == 4) && RPW_ == 4) || ((EPI == MB_SLAB || EPI == MB_QKV) && RBV == 4 && RPW_ == 4) || (EPI == MB_QKV && RBV == 2 && RPW_ == 2), "gate/up: one planned region {G0,G1,U0,U1} x all token blocks, or two regions x half of them; slab / QKV: two {lo, hi} regions");
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1143,8 +1143,8 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
             const int tbg = tq * TW + t, blk = zb0 + (tbg >> 1), tok = (tbg & 1) * 32 + tl;
             if (blk >= a.nblk) continue;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)                  // region 2 x + j = row-blocks {2 j, 2 j + 1} = its {lo, hi} halves
-                fat_qkv_tile<RV>(a, acc[2 * j][t], acc[2 * j + 1][t], blockIdx.x * 2 + j, blk, tok, hh);
+            for (int j = 0; j < RPW / 2; ++j)            // region (RBV / 2) x + j = row-blocks {2 j, 2 j + 1} = its {lo, hi} halves
+                fat_qkv_tile<RV>(a, acc[2 * j][t], acc[2 * j + 1][t], blockIdx.x * (RBV / 2) + (RPW / 2) * rg + j, blk, tok, hh);
         }
     } else {
         // ---- SwiGLU epilogue, as k_gemm_wide<8, TW, MB_SWIGLU>: act = bf16(silu(bf16(g)) * bf16(u)) parked as tile[token][sh + feature -
@@ -2275,6 +2275,10 @@ int lk_mb_init() {
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 4, MB_SWIGLU, 4, 2>, FatGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 1, MB_SLAB>, FatGeom<4, 1>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 2, MB_SLAB>, FatGeom<4, 2>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<2, 2, MB_QKV, 4, 2, 2>, FatGeom<2, 2, 2>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<2, 2, MB_QKV, 2, 2, 2>, FatGeom<2, 2, 2>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<2, 2, MB_QKV, 4, 0, 2>, FatGeom<2, 2, 2>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<2, 2, MB_QKV, 2, 0, 2>, FatGeom<2, 2, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 1, MB_QKV, 4>, FatGeom<4, 1>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 2, MB_QKV, 4>, FatGeom<4, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 1, MB_QKV, 2>, FatGeom<4, 1>::LDS);
@@ -2438,6 +2442,25 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                         }
                     p.wg_chunks = 4 * a.wg_chunks;
                     wide_launch<8, 2, EPI>(dim3(n_wg / 4, ksplit, (nblk + 1) / 2), st, p);
+                    LAUNCH_CHECK(); return 0;
+                }
+            }
+            if constexpr (EPI == MB_QKV) {
+                // round 5 (bit 8 of key 6): ONE {lo, hi} region x 256 rows per workgroup as four fat waves of 2 row-blocks x 2 token blocks.
+                // The paired quarters give a CU TWO regions' weights for 128 rows, and the token groups run in lockstep, so every CU waits for
+                // its weights at the HBM-class rate: 1.05 MB per CU at the Mistral shape (512 rows) = the 42 of the launch's 45 us.  One
+                // region x 256 rows: half the weight bytes per CU, twice the x (which comes from L2).  Taken at <= 4 blocks, and at 5-8
+                // blocks when the two token halves still fit one wave of workgroups (the fuller QKV image of a GQA model: 96 x 2).
+                const int zq = (nblk + 3) / 4;
+                if ((g_la_mb_pair & 256) && ksplit == 1 && (a.K16 & 1) == 0 && (a.R & 1) == 0 && g_la_mb_dbg == 0 && (zq == 1 || n_wg * zq <= 256)) {
+                    const dim3 gq(n_wg, 1, zq);
+                    if (zq == 1) {
+                        if ((a.R & 3) == 0) k_gemm_fat<2, 2, MB_QKV, 4, 2, 2><<<gq, 256, FatGeom<2, 2, 2>::LDS, st>>>(a);
+                        else k_gemm_fat<2, 2, MB_QKV, 2, 2, 2><<<gq, 256, FatGeom<2, 2, 2>::LDS, st>>>(a);
+                    } else {
+                        if ((a.R & 3) == 0) k_gemm_fat<2, 2, MB_QKV, 4, 0, 2><<<gq, 256, FatGeom<2, 2, 2>::LDS, st>>>(a);
+                        else k_gemm_fat<2, 2, MB_QKV, 2, 0, 2><<<gq, 256, FatGeom<2, 2, 2>::LDS, st>>>(a);
+                    }
                     LAUNCH_CHECK(); return 0;
                 }
             }
