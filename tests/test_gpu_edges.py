@@ -140,3 +140,42 @@ def test_streamer_and_stream_generate():
                                         streamer=st))
     assert [t for c in chunks for t in c] == ref[30:]
     assert len(chunks) >= 2
+
+
+def test_generate_min_new_tokens_and_min_length_run_on_the_engine_device():
+    """generate(min_new_tokens=..., min_length=...): the eos-aware processors HF builds compare their eos tensor with the scores' vocabulary
+    index, and the engine's logits rows are CUDA tensors — the processors must be built on the engine's device (HF's _get_logits_processor
+    passes device=input_ids.device; round-4 advisor finding: they defaulted to 'cpu' and the first step raised).  Both branches: plain
+    decoding and lookahead (sequential accept path), single-sequence and batch wrapper; the lookahead output must equal the plain one."""
+    from painlessinferenceacceleration_amd.modeling_llama_batch import LlamaForCausalLM as BatchLlama
+    from tests.tiny_model import noisy_copies, tiny_decisive_weights
+    shape = tiny_shape()
+    rs = np.random.RandomState(77)
+    P, n_new = 30, 24
+    prompt = torch.from_numpy(rs.randint(3, shape.vocab, size=(1, P)).astype(np.int64))
+    model = LlamaForCausalLM(shape, tiny_decisive_weights(0, torch.bfloat16), max_length=256, eos_token_id=None)
+    free = model.generate(input_ids=prompt, max_new_tokens=n_new, eos_token_id=None)[0].tolist()[P:]
+    eos = free[3]                                              # the 4th generated token: an unconstrained run stops there
+    assert free.index(eos) == 3
+    short = model.generate(input_ids=prompt, max_new_tokens=n_new, eos_token_id=eos)[0].tolist()[P:]
+    assert short == free[:4]
+    plain = model.generate(input_ids=prompt, max_new_tokens=n_new, eos_token_id=eos, min_new_tokens=10)[0].tolist()[P:]
+    assert len(plain) >= 10 and eos not in plain[:10] and plain[:3] == free[:3]
+    model.lookahead_cache = LookaheadCache(eos_ids=[eos])
+    for c in noisy_copies(prompt[0, -2:].tolist() + plain, 6, 0.2, shape.vocab, seed=5):
+        model.lookahead_cache.put(c, branch_length=13, mode='output', idx=-1)
+    dk = {'use_lookahead': True, 'decoding_mode': 'hier', 'decoding_length': 64, 'branch_length': 12, 'max_query_length': 2, 'stop_words': {}}
+    look = model.generate(input_ids=prompt, max_new_tokens=n_new, eos_token_id=eos, min_new_tokens=10, decoding_kwargs=dict(dk),
+                          return_dict_in_generate=True)
+    assert look.sequences[0].tolist()[P:] == plain and max(look.kwargs['edls']) > 1
+    # min_length counts the prompt too (MinLengthLogitsProcessor): P + 12 tokens before eos may appear
+    ml = model.generate(input_ids=prompt, max_new_tokens=n_new, eos_token_id=eos, min_length=P + 12)[0].tolist()[P:]
+    assert len(ml) >= 12 and eos not in ml[:12]
+    # batch wrapper, both branches
+    bm = BatchLlama(shape, tiny_decisive_weights(0, torch.bfloat16), max_length=256, max_batch=2, eos_token_id=None, max_blocks=2)
+    two = torch.cat([prompt, prompt], 0)
+    bplain = bm.generate(input_ids=two, max_new_tokens=n_new, eos_token_id=eos, min_new_tokens=10)
+    assert bplain[0].tolist()[P:P + len(plain)] == plain and bplain[1].tolist()[P:P + len(plain)] == plain
+    bm.lookahead_cache = LookaheadCache(eos_ids=[eos])
+    blook = bm.generate(input_ids=two, max_new_tokens=n_new, eos_token_id=eos, min_new_tokens=10, decoding_kwargs=dict(dk))
+    assert blook[0].tolist()[P:P + len(plain)] == plain and blook[1].tolist()[P:P + len(plain)] == plain
