@@ -2203,7 +2203,7 @@ int g_la_mb_attn_rot = 0;     // la_lab_set key 21: 1 = the query heads of a kv 
 int g_la_mb_attn_vring = 0;   // la_lab_set key 20: 1 = multi-block attention with the next tile's V in flight through a per-wave LDS ring (measured 0.5-5 % SLOWER per step, profiles/r04_mb_attention_vring_ab.txt), 0 = V requested per tile (default)
 int g_la_mb_dbg = 0;
 int g_la_mb_mode = 0;         // la_lab_set key 5: unused (was: the wide gate/up launch as two co-resident 256-row workgroups per CU on a 3-slot ring — four waves per SIMD; measured 7 % slower at 512 rows, profiles/r04_wide_gemm_schedule.txt part 5)
-int g_la_mb_pair = 1 | 16 | 32 | 64;   // la_debug_set key 6, bit 6 (round 5, default on): gate/up at <= 4 blocks as ONE region x all token blocks per workgroup (fat waves; bit 7: at every block count), bit 5 (round 5, default on: Mistral bs=8 9.91 -> 9.53 ms per step, profiles/r05_fat_waves.txt): the paired slab / QKV launches as fat waves too; bit 4 (round 5, default on): gate/up at >= 3 blocks as four fat waves per workgroup (k_gemm_fat: the paired geometry, 4 x TW tiles per wave); bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
+int g_la_mb_pair = 1 | 16 | 32 | 64 | 256;   // la_debug_set key 6, bit 8 (round 5, default on): QKV at <= 4 blocks as ONE {lo, hi} region x 256 rows per workgroup (fat waves of 2 x 2 tiles; bit 9: at 5-8 blocks too), bit 6 (round 5, default on): gate/up at <= 4 blocks as ONE region x all token blocks per workgroup (fat waves; bit 7: at every block count), bit 5 (round 5, default on: Mistral bs=8 9.91 -> 9.53 ms per step, profiles/r05_fat_waves.txt): the paired slab / QKV launches as fat waves too; bit 4 (round 5, default on): gate/up at >= 3 blocks as four fat waves per workgroup (k_gemm_fat: the paired geometry, 4 x TW tiles per wave); bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
 int g_la_mb_ks2 = 0;          // la_debug_set key 12: slab GEMMs of the multi-block step with 2 K splits at >= 5 blocks (measurement)
 int g_la_mb_narrow = 0;       // la_debug_set key 3: 1 = the K-split kernels (k_gemm_mb) for every nblk (A/B measurements)
 int g_la_ex_d4 = 13;          // la_lab_set key 25 (default 13 = bits 0 + 2 + 3: Mixtral bs=4 19.75 -> 18.96 ms per step, profiles/r05_moe_paired_experts.txt): merged-expert launches as two workgroups per CU (bit 0 gate/up, bit 1 down); round 5: two weight regions per workgroup (bit 2 gate/up, bit 3 down) — takes precedence over bits 0 / 1
@@ -2452,7 +2452,9 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                 // region x 256 rows: half the weight bytes per CU, twice the x (which comes from L2).  Taken at <= 4 blocks, and at 5-8
                 // blocks when the two token halves still fit one wave of workgroups (the fuller QKV image of a GQA model: 96 x 2).
                 const int zq = (nblk + 3) / 4;
-                if ((g_la_mb_pair & 256) && ksplit == 1 && (a.K16 & 1) == 0 && (a.R & 1) == 0 && g_la_mb_dbg == 0 && (zq == 1 || n_wg * zq <= 256)) {
+                // Measured (profiles/r05_fat_waves.txt, call 7): 13B bs=4 10.64 -> 10.59 ms, Mixtral bs=4 19.65 -> 19.41 at 4 blocks; Mistral bs=8
+                // (8 blocks, two token halves) 9.465 -> 9.489: taken at <= 4 blocks only (bit 9 forces the 5-8 block form: measurement).
+                if ((g_la_mb_pair & 256) && ksplit == 1 && (a.K16 & 1) == 0 && (a.R & 1) == 0 && g_la_mb_dbg == 0 && (zq == 1 || ((g_la_mb_pair & 512) && n_wg * zq <= 256))) {
                     const dim3 gq(n_wg, 1, zq);
                     if (zq == 1) {
                         if ((a.R & 3) == 0) k_gemm_fat<2, 2, MB_QKV, 4, 2, 2><<<gq, 256, FatGeom<2, 2, 2>::LDS, st>>>(a);

@@ -360,7 +360,7 @@ def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
                 check(lib.la_qkv_row_perm(nh, nkv, perm.ctypes.data_as(_lib.pi32)), 'perm')
                 wp = gu.pack_weight(w[torch.from_numpy(perm.astype(np.int64)).to(DEV)].contiguous())
             outs = []
-            for pair in (0, 1, 5, 33, 257):      # 257 = round 5: ONE region x 256 rows per workgroup as fat waves of 2 x 2 tiles; 5 = paired + the QUAD form of the QKV launch (taken at >= 7 blocks of a GQA shape); 33 = fat waves (round 5)
+            for pair in (0, 1, 5, 33, 257 + 512):      # 769 = round 5: ONE region x 256 rows per workgroup as fat waves of 2 x 2 tiles; 5 = paired + the QUAD form of the QKV launch (taken at >= 7 blocks of a GQA shape); 33 = fat waves (round 5)
                 check(lib.la_lab_set(6, pair), 'debug_set')
                 qf = torch.zeros(8 * nh * 8192, dtype=torch.bfloat16, device=DEV)
                 kf = torch.zeros(8 * nkv * 8192, dtype=torch.bfloat16, device=DEV)
