@@ -998,7 +998,7 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
     using GEO = FatGeom<RBV, TW, RPW_>;
     constexpr int KS = GEO::KS, RPW = GEO::RPW, NW = GEO::NW, TQ = GEO::TQ, NTBP = GEO::NTBP;
     constexpr int A_STAGE = GEO::A_STAGE, STAGE = GEO::STAGE, NR = GEO::NR, NP = GEO::NP, NPA = GEO::NPA, H = GEO::H;
-    static_assert((EPI == MB_SWIGLU && (RBV == 8 || RBV == 4) && RPW_ == 4) || ((EPI == MB_SLAB || EPI == MB_QKV) && RBV == 4 && RPW_ == 4) || (EPI == MB_QKV && RBV == 2 && RPW_ == 2), "gate/up: one planned region {G0,G1,U0,U1} x all token blocks, or two regions x half of them; slab / QKV: two {lo, hi} regions");
+    static_assert((EPI == MB_SWIGLU && (RBV == 8 || RBV == 4) && RPW_ == 4) || ((EPI == MB_SLAB || EPI == MB_QKV) && RBV == 4 && RPW_ == 4) || ((EPI == MB_QKV || EPI == MB_SLAB) && RBV == 2 && RPW_ == 2), "gate/up: one planned region {G0,G1,U0,U1} x all token blocks, or two regions x half of them; slab / QKV: two {lo, hi} regions");
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2275,6 +2275,7 @@ int lk_mb_init() {
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 4, MB_SWIGLU, 4, 2>, FatGeom<4, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 1, MB_SLAB>, FatGeom<4, 1>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 2, MB_SLAB>, FatGeom<4, 2>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<2, 2, MB_SLAB, 4, 2, 2>, FatGeom<2, 2, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<2, 2, MB_QKV, 4, 2, 2>, FatGeom<2, 2, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<2, 2, MB_QKV, 2, 2, 2>, FatGeom<2, 2, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<2, 2, MB_QKV, 4, 0, 2>, FatGeom<2, 2, 2>::LDS);
@@ -2463,6 +2464,15 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                         if ((a.R & 3) == 0) k_gemm_fat<2, 2, MB_QKV, 4, 0, 2><<<gq, 256, FatGeom<2, 2, 2>::LDS, st>>>(a);
                         else k_gemm_fat<2, 2, MB_QKV, 2, 0, 2><<<gq, 256, FatGeom<2, 2, 2>::LDS, st>>>(a);
                     }
+                    LAUNCH_CHECK(); return 0;
+                }
+            }
+            if constexpr (EPI == MB_SLAB) {
+                // round 5 (bit 10 of key 6): the slab launches (o_proj / down) at <= 4 blocks as ONE 64-row weight region x 256 rows per workgroup
+                // (four fat waves of 2 row-blocks x 2 token blocks) instead of two regions x 128 rows: half the weight bytes per CU at the
+                // HBM-class rate, twice the x from L2 — the trade that paid for gate/up and QKV at 256 rows
+                if ((g_la_mb_pair & 1024) && nblk <= 4 && (a.K16 & 1) == 0 && a.K16 >= 2 * ksplit && g_la_mb_dbg == 0 && !a.planned) {
+                    k_gemm_fat<2, 2, MB_SLAB, 4, 2, 2><<<dim3(n_wg, ksplit, 1), 256, FatGeom<2, 2, 2>::LDS, st>>>(a);
                     LAUNCH_CHECK(); return 0;
                 }
             }
