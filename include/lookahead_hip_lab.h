@@ -22,7 +22,8 @@ extern "C" {
  *        workgroup (k_gemm_fat: the paired geometry with 4 x TW accumulator tiles per wave, one wave per SIMD; library default: on),
  *        bit 5 = the paired slab / QKV launches as fat waves too (library default: on), bit 6 = gate/up at <= 4 blocks as ONE region x all token
  *        blocks per workgroup (fat waves, nt weights; default on), bit 7 = that form at every block count (measurement), bit 8 = QKV at <= 4 blocks as ONE {lo, hi} region x 256 rows per workgroup (fat waves
- *        of 2 x 2 tiles; default on), bit 9 = at 5-8 blocks too (measurement); bit-identical results; read at launch / capture.
+ *        of 2 x 2 tiles; default on), bit 9 = at 5-8 blocks too (measurement), bit 10 = the slab launches at <= 4 blocks in that one-region form (measured slower: opt-in);
+ *        bit-identical results; read at launch / capture.
  * key 7: idle-window weight prefetch of the 64-row step, KiB per workgroup of the next GEMM (0 = off, <= 128): the row kernels and
  *        the attention combine carry extra workgroups that pull the first k-tiles of the next GEMM into L2 (bit-identical
  *        results); key 8: start delay of those workgroups in s_sleep(32) rounds; key 9: KiB per down_proj workgroup pulled in from

@@ -2470,7 +2470,8 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
             if constexpr (EPI == MB_SLAB) {
                 // round 5 (bit 10 of key 6): the slab launches (o_proj / down) at <= 4 blocks as ONE 64-row weight region x 256 rows per workgroup
                 // (four fat waves of 2 row-blocks x 2 token blocks) instead of two regions x 128 rows: half the weight bytes per CU at the
-                // HBM-class rate, twice the x from L2 — the trade that paid for gate/up and QKV at 256 rows
+                // HBM-class rate, twice the x from L2 — the trade that paid for gate/up and QKV at 256 rows.  Measured SLOWER here (13B bs=4 10.50 ->
+                // 10.63 ms, Mixtral bs=4 19.15 -> 19.45, profiles/r05_fat_waves.txt call 8): opt-in, bit-identical.
                 if ((g_la_mb_pair & 1024) && nblk <= 4 && (a.K16 & 1) == 0 && a.K16 >= 2 * ksplit && g_la_mb_dbg == 0 && !a.planned) {
                     k_gemm_fat<2, 2, MB_SLAB, 4, 2, 2><<<dim3(n_wg, ksplit, 1), 256, FatGeom<2, 2, 2>::LDS, st>>>(a);
                     LAUNCH_CHECK(); return 0;
