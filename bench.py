@@ -354,7 +354,8 @@ def main():
     if args.layers:
         shape.n_layers = args.layers
     K, W, P, B = args.steps, args.warmup, args.prompt_len, args.batch
-    assert 1 <= B <= 8
+    assert 1 <= B <= 16, 'sequences per GPU: <= 16 KV slots; more than 8 run as two passes of <= 8 blocks per step'
+    assert B <= 8 or (not args.device_trie and args.decoding_length <= 64), '--batch above 8: host trie, 64-token trees'
     BL, DL = args.branch_length, args.decoding_length
     wide = DL > 64                       # trees wider than one 64-row block: the tree is 2-4 chained blocks of one multi-block pass (eng.tstep)
     assert 1 <= DL <= 256 and 1 <= BL <= 39, 'decoding_length <= 256, branch_length <= 39'
@@ -380,7 +381,7 @@ def main():
                                  fuse=args.fuse, attn_split=args.attn_split, max_blocks=8, gemm_cfg=gemm_cfg)
     else:
         model = BatchLlama(shape, sd, device=dev, max_length=max_length, max_batch=B, eos_token_id=None, consume_state_dict=True,
-                           attn_split=args.attn_split, max_blocks=B * ((DL + 63) // 64), kv_ring=kv_ring, gemm_cfg=gemm_cfg)
+                           attn_split=args.attn_split, max_blocks=min(B * ((DL + 63) // 64), 8), kv_ring=kv_ring, gemm_cfg=gemm_cfg)
     del sd
     eng = model.engine
     NSEQ = world * B
@@ -531,13 +532,15 @@ def main():
         else:
             # queue the multi-block pass, then do the host work nothing on the device waits for while the GPU verifies: the previous
             # step's gather + puts (N > 1, split-phase) or its trie update (one GPU, unless --strict-trie-order)
-            eng.mstep_async([(i, dr[i][0], dr[i][1], 0, 16) for i in range(B)])
-            if gather is not None:
-                gather.overlap(cache, BL)
-            if put_q[0] is not None:
-                cache.stream_put_many(put_q[0], branch_length=BL + 1, final=False)
-                put_q[0] = None
-            toks_all = eng.mstep_finish()
+            toks_all = []
+            for g0 in range(0, B, 8):            # more than 8 sequences: one pass over the weights per group of 8 blocks
+                eng.mstep_async([(i, dr[i][0], dr[i][1], 0, 16) for i in range(g0, min(B, g0 + 8))])
+                if gather is not None:
+                    gather.overlap(cache, BL)
+                if put_q[0] is not None:
+                    cache.stream_put_many(put_q[0], branch_length=BL + 1, final=False)
+                    put_q[0] = None
+                toks_all.extend(eng.mstep_finish())
         for i in range(B):
             seqs[i].extend(toks_all[i])
             dls.append(len(dr[i][0])); edls.append(len(toks_all[i]))
@@ -714,7 +717,7 @@ def main():
         except Exception:
             pass
         roofline = {
-            'bound': bound, 'kernel': 'whole multi-block verify step (k_gemm_wide / k_gemm_mb + k_tree_attn_mb), M = %d rows' % (64 * B * RB_),
+            'bound': bound, 'kernel': 'whole multi-block verify step (k_gemm_fat / k_gemm_wide / k_gemm_mb + k_tree_attn_mb), M = %d rows%s' % (64 * B * RB_, '' if B <= 8 else ' in %d passes over the weights (priced as ONE)' % ((B + 7) // 8)),
             'achieved': round(step_flops / (ms_step * 1e-3) / 1e12, 1) if bound == 'mfma' else round(step_bytes / (ms_step * 1e-3) / 1e9, 1),
             'peak': 2500.0 if bound == 'mfma' else HBM_PEAK_GBS, 'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
             'frac': round(max(mfma_frac, hbm_frac), 4), 'traffic': traffic, 'traffic_source': traffic_src,
