@@ -993,11 +993,19 @@ __device__ __forceinline__ void fat_qkv_tile(const MbArgs& a, const f32x16& lo, 
     }
 }
 
-template <int RBV, int TW, int EPI, int RV = 4, int WPOL = 0, int RPW_ = 4>
+// STG = 1 (round 5, second form): the operands reach LDS through REGISTERS (buffer_load_dwordx4 -> VGPR -> ds_write_b128) instead of LDS-DMA.
+//   What the DMA form pays: an LDS-DMA piece blocks its wave's issue for ~60-185 cycles (MI355X_MICROARCH.md price list), and with one wave per
+//   SIMD nothing else issues meanwhile — 8 pieces per wave and stage idle the matrix pipe for roughly half a stage (the 512-row gate/up launch:
+//   128 stages x ~1560 cycles at 2.03 GHz = the measured 103-113 us, where 1024 cycles per stage would be the MFMA time).  A plain buffer load
+//   issues in a few cycles and the fat kernels have the registers to hold two stages in flight (gate/up: 135 + 256 of 512).  Pipeline: the
+//   pieces of stage s + 3 are requested in the second half of stage s (one per MFMA gap) into the register set of stage s + 1's parity — which
+//   the first half of stage s has just emptied into LDS slot (s + 1) % 2 (one ds_write per gap) — and the barrier in the middle of stage s
+//   publishes stage s + 1 as before.  Two LDS slots instead of four.  Same MFMAs on the same operands in the same order: bit-identical.
+template <int RBV, int TW, int EPI, int RV = 4, int WPOL = 0, int RPW_ = 4, int STG = 0>
 __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
     using GEO = FatGeom<RBV, TW, RPW_>;
     constexpr int KS = GEO::KS, RPW = GEO::RPW, NW = GEO::NW, TQ = GEO::TQ, NTBP = GEO::NTBP;
-    constexpr int A_STAGE = GEO::A_STAGE, STAGE = GEO::STAGE, NR = GEO::NR, NP = GEO::NP, NPA = GEO::NPA, H = GEO::H;
+    constexpr int A_STAGE = GEO::A_STAGE, STAGE = GEO::STAGE, NR = STG ? 2 : GEO::NR, NP = GEO::NP, NPA = GEO::NPA, H = GEO::H;
     static_assert((EPI == MB_SWIGLU && (RBV == 8 || RBV == 4) && RPW_ == 4) || ((EPI == MB_SLAB || EPI == MB_QKV) && RBV == 4 && RPW_ == 4) || ((EPI == MB_QKV || EPI == MB_SLAB) && RBV == 2 && RPW_ == 2), "gate/up: one planned region {G0,G1,U0,U1} x all token blocks, or two regions x half of them; slab / QKV: two {lo, hi} regions");
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = threadIdx.x & 63;
@@ -1059,6 +1067,18 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
         if (i < NPA) dma_piece<WPOL>(rs_w, d, voff[i], so);
         else dma_piece<0>(rs_x, d, voff[i], so);
     };
+    // STG: piece i of stage sidx -> registers (the same addresses and cache policies as the DMA form), and registers -> its LDS slot
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    auto load_piece = [&](int sidx, int i) -> u32x4_t {
+        int kt = t0 + sidx * KS + pkk[i];
+        kt = kt < t1 ? kt : t1 - 1;
+        const unsigned so = (unsigned)kt * gstr[i];
+        if (i < NPA) return __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)voff[i], (int)so, WPOL);
+        return __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff[i], (int)so, 0);
+    };
+    auto store_piece = [&](int sidx, int i, const u32x4_t& v) {
+        *(u32x4_t*)(lds_raw + (sidx & 1) * (STAGE * 1024) + pdst[i] + lane * 16) = v;
+    };
 
     f32x16 acc[RPW][TW];
 #pragma unroll
@@ -1085,38 +1105,89 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
         acc[r][t] = LA_MFMA(fa[r], fb[t], acc[r][t], 0, 0, 0);
     };
 
-#pragma unroll
-    for (int i = 0; i < NR - 1; ++i)
-#pragma unroll
-        for (int q = 0; q < NP; ++q) issue_one(i, q);
-    vm_wait<(NR - 2) * NP>();
-    __builtin_amdgcn_s_barrier();
     bf16x8 fa0[RPW], fb0[TW], fa1[RPW], fb1[TW];
-#pragma unroll
-    for (int j = 0; j < NRD; ++j) read_one(0, 0, j, fa0, fb0);
     constexpr int H2 = NP - H;
-    for (int s = 0; s < nst; ++s) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // set0 (read during the previous half) is complete
-        __builtin_amdgcn_sched_barrier(0);
-        // first half: MFMAs of set0 | one fragment read of set1 (stage s, k-tile 1) | one DMA piece of stage s + 3 after each
-#pragma unroll
-        for (int m = 0; m < NG; ++m) {
-            if (m < NMMA) mma(m, fa0, fb0);
-            if (m < NRD) read_one(s, 1, m, fa1, fb1);
-            if (m < H) issue_one(s + NR - 1, m);
+    if constexpr (STG == 0) {
+    #pragma unroll
+        for (int i = 0; i < NR - 1; ++i)
+    #pragma unroll
+            for (int q = 0; q < NP; ++q) issue_one(i, q);
+        vm_wait<(NR - 2) * NP>();
+        __builtin_amdgcn_s_barrier();
+    #pragma unroll
+        for (int j = 0; j < NRD; ++j) read_one(0, 0, j, fa0, fb0);
+        for (int s = 0; s < nst; ++s) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // set0 (read during the previous half) is complete
             __builtin_amdgcn_sched_barrier(0);
+            // first half: MFMAs of set0 | one fragment read of set1 (stage s, k-tile 1) | one DMA piece of stage s + 3 after each
+    #pragma unroll
+            for (int m = 0; m < NG; ++m) {
+                if (m < NMMA) mma(m, fa0, fb0);
+                if (m < NRD) read_one(s, 1, m, fa1, fb1);
+                if (m < H) issue_one(s + NR - 1, m);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            vm_wait<(NR - 3) * NP + H>();                                // own pieces of stage s + 1 landed
+            __builtin_amdgcn_s_barrier();                                // stage s + 1 complete for everyone; the slot of stage s is free
+            __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+            for (int m = 0; m < NG; ++m) {
+                if (m < NMMA) mma(m, fa1, fb1);
+                if (m < NRD) read_one(s + 1, 0, m, fa0, fb0);
+                if (m < H2) issue_one(s + NR - 1, H + m);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+
+    } else {
+        // ---- register-staged pipeline (see the kernel header): sets sA / sB hold the stages of even / odd parity that are in flight
+        u32x4_t sA[NP], sB[NP];
+        // (the loads stay in piece order, here as in the loop: hipcc merges the vmcnt bookkeeping of the two loop entries, and a prologue it
+        //  had reordered made the loop wait for loads half a stage old — vmcnt(1) where vmcnt(8) is exact)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { sA[q] = load_piece(0, q); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { sB[q] = load_piece(1, q); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) store_piece(0, q, sA[q]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) { sA[q] = load_piece(2, q); __builtin_amdgcn_sched_barrier(0); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        vm_wait<(NR - 3) * NP + H>();                                // own pieces of stage s + 1 landed
-        __builtin_amdgcn_s_barrier();                                // stage s + 1 complete for everyone; the slot of stage s is free
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int m = 0; m < NG; ++m) {
-            if (m < NMMA) mma(m, fa1, fb1);
-            if (m < NRD) read_one(s + 1, 0, m, fa0, fb0);
-            if (m < H2) issue_one(s + NR - 1, H + m);
+        for (int j = 0; j < NRD; ++j) read_one(0, 0, j, fa0, fb0);
+        // one stage: `cur` = the register set of stage s + 1 (written to LDS in the first half, refilled with stage s + 3 in the second)
+        auto stage = [&](int s, auto parity, u32x4_t (&cur)[NP]) {
+            constexpr int P = decltype(parity)::value;               // s % 2, compile-time: the LDS slots are immediates
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // set0 (read during the previous half) is complete
             __builtin_amdgcn_sched_barrier(0);
+            constexpr int NG1 = NG > NP ? NG : NP;
+#pragma unroll
+            for (int m = 0; m < NG1; ++m) {
+                if (m < NMMA) mma(m, fa0, fb0);
+                if (m < NRD) read_one(P, 1, m, fa1, fb1);
+                if (m < NP) store_piece(1 - P, m, cur[m]);           // (the compiler waits for exactly this load: vmcnt counts the younger ones)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the reads of stage s and the writes of stage s + 1 are complete
+            __builtin_amdgcn_s_barrier();                            // stage s + 1 is visible to everyone
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < NG1; ++m) {
+                if (m < NMMA) mma(m, fa1, fb1);
+                if (m < NRD) read_one(1 - P, 0, m, fa0, fb0);
+                if (m < NP) cur[m] = load_piece(s + 3, m);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        int s = 0;
+        for (; s + 1 < nst; s += 2) {
+            stage(s, std::integral_constant<int, 0>{}, sB);
+            stage(s + 1, std::integral_constant<int, 1>{}, sA);
         }
+        if (s < nst) stage(s, std::integral_constant<int, 0>{}, sB);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     vm_wait<0>();
@@ -2203,7 +2274,7 @@ int g_la_mb_attn_rot = 0;     // la_lab_set key 21: 1 = the query heads of a kv 
 int g_la_mb_attn_vring = 0;   // la_lab_set key 20: 1 = multi-block attention with the next tile's V in flight through a per-wave LDS ring (measured 0.5-5 % SLOWER per step, profiles/r04_mb_attention_vring_ab.txt), 0 = V requested per tile (default)
 int g_la_mb_dbg = 0;
 int g_la_mb_mode = 0;         // la_lab_set key 5: unused (was: the wide gate/up launch as two co-resident 256-row workgroups per CU on a 3-slot ring — four waves per SIMD; measured 7 % slower at 512 rows, profiles/r04_wide_gemm_schedule.txt part 5)
-int g_la_mb_pair = 1 | 16 | 32 | 64 | 256;   // la_debug_set key 6, bit 8 (round 5, default on): QKV at <= 4 blocks as ONE {lo, hi} region x 256 rows per workgroup (fat waves of 2 x 2 tiles; bit 9: at 5-8 blocks too), bit 6 (round 5, default on): gate/up at <= 4 blocks as ONE region x all token blocks per workgroup (fat waves; bit 7: at every block count), bit 5 (round 5, default on: Mistral bs=8 9.91 -> 9.53 ms per step, profiles/r05_fat_waves.txt): the paired slab / QKV launches as fat waves too; bit 4 (round 5, default on): gate/up at >= 3 blocks as four fat waves per workgroup (k_gemm_fat: the paired geometry, 4 x TW tiles per wave); bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
+int g_la_mb_pair = 1 | 16 | 32 | 64 | 256 | 4096;   // la_debug_set key 6, bit 12 (round 5, default on: Mistral bs=4 6.76 -> 6.50 ms per step): QKV at <= 4 blocks over <= 128 regions as one region x 128 rows per workgroup; bit 11: the paired gate/up fat launch staged through registers (measured slower: opt-in); bit 8 (round 5, default on): QKV at <= 4 blocks as ONE {lo, hi} region x 256 rows per workgroup (fat waves of 2 x 2 tiles; bit 9: at 5-8 blocks too), bit 6 (round 5, default on): gate/up at <= 4 blocks as ONE region x all token blocks per workgroup (fat waves; bit 7: at every block count), bit 5 (round 5, default on: Mistral bs=8 9.91 -> 9.53 ms per step, profiles/r05_fat_waves.txt): the paired slab / QKV launches as fat waves too; bit 4 (round 5, default on): gate/up at >= 3 blocks as four fat waves per workgroup (k_gemm_fat: the paired geometry, 4 x TW tiles per wave); bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
 int g_la_mb_ks2 = 0;          // la_debug_set key 12: slab GEMMs of the multi-block step with 2 K splits at >= 5 blocks (measurement)
 int g_la_mb_narrow = 0;       // la_debug_set key 3: 1 = the K-split kernels (k_gemm_mb) for every nblk (A/B measurements)
 int g_la_ex_d4 = 13;          // la_lab_set key 25 (default 13 = bits 0 + 2 + 3: Mixtral bs=4 19.75 -> 18.96 ms per step, profiles/r05_moe_paired_experts.txt): merged-expert launches as two workgroups per CU (bit 0 gate/up, bit 1 down); round 5: two weight regions per workgroup (bit 2 gate/up, bit 3 down) — takes precedence over bits 0 / 1
@@ -2270,6 +2341,9 @@ int lk_mb_init() {
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 2, MB_SWIGLU>, FatGeom<8, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 3, MB_SWIGLU>, FatGeom<8, 3>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 4, MB_SWIGLU>, FatGeom<8, 4>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 2, MB_SWIGLU, 4, 0, 4, 1>, FatGeom<8, 2>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 3, MB_SWIGLU, 4, 0, 4, 1>, FatGeom<8, 3>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 4, MB_SWIGLU, 4, 0, 4, 1>, FatGeom<8, 4>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 2, MB_SWIGLU, 4, 2>, FatGeom<4, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 3, MB_SWIGLU, 4, 2>, FatGeom<4, 3>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 4, MB_SWIGLU, 4, 2>, FatGeom<4, 4>::LDS);
@@ -2280,6 +2354,8 @@ int lk_mb_init() {
     if (e == hipSuccess) e = set_lds(k_gemm_fat<2, 2, MB_QKV, 2, 2, 2>, FatGeom<2, 2, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<2, 2, MB_QKV, 4, 0, 2>, FatGeom<2, 2, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<2, 2, MB_QKV, 2, 0, 2>, FatGeom<2, 2, 2>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<2, 1, MB_QKV, 4, 0, 2>, FatGeom<2, 1, 2>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<2, 1, MB_QKV, 2, 0, 2>, FatGeom<2, 1, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 1, MB_QKV, 4>, FatGeom<4, 1>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 2, MB_QKV, 4>, FatGeom<4, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 1, MB_QKV, 2>, FatGeom<4, 1>::LDS);
@@ -2452,6 +2528,16 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                 // its weights at the HBM-class rate: 1.05 MB per CU at the Mistral shape (512 rows) = the 42 of the launch's 45 us.  One
                 // region x 256 rows: half the weight bytes per CU, twice the x (which comes from L2).  Taken at <= 4 blocks, and at 5-8
                 // blocks when the two token halves still fit one wave of workgroups (the fuller QKV image of a GQA model: 96 x 2).
+                // bit 12 of key 6: the same one-region form with ONE token tile per wave (128 rows per workgroup, grid.z = pairs of blocks) where 256
+                // rows per workgroup leave most of the chip idle — the fuller GQA image (Mistral / Mixtral: 96 regions) at 3-4 blocks is 96
+                // workgroups on 256 CUs, each waiting for 0.5 MB of weights at the HBM-class per-CU rate; two token groups = 192 workgroups
+                // (the second reader of a region finds it in L2).  <= 2 blocks: the 2 x 2 form would run MFMAs on absent blocks.
+                if ((g_la_mb_pair & 4096) && (g_la_mb_pair & 256) && ksplit == 1 && (a.K16 & 1) == 0 && (a.R & 1) == 0 && g_la_mb_dbg == 0 && nblk <= 4 && (nblk <= 2 || n_wg <= 128)) {
+                    const dim3 gq(n_wg, 1, (nblk + 1) / 2);
+                    if ((a.R & 3) == 0) k_gemm_fat<2, 1, MB_QKV, 4, 0, 2><<<gq, 256, FatGeom<2, 1, 2>::LDS, st>>>(a);
+                    else k_gemm_fat<2, 1, MB_QKV, 2, 0, 2><<<gq, 256, FatGeom<2, 1, 2>::LDS, st>>>(a);
+                    LAUNCH_CHECK(); return 0;
+                }
                 const int zq = (nblk + 3) / 4;
                 // Measured (profiles/r05_fat_waves.txt, call 7): 13B bs=4 10.64 -> 10.59 ms, Mixtral bs=4 19.65 -> 19.41 at 4 blocks; Mistral bs=8
                 // (8 blocks, two token halves) 9.465 -> 9.489: taken at <= 4 blocks only (bit 9 forces the 5-8 block form: measurement).
@@ -2547,6 +2633,14 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                 const dim3 g2(n_wg / 2, 1, 2);
                 if (fat) {
                     // round 5: the same pair of regions as FOUR fat waves (4 x TW accumulator tiles each, one wave per SIMD): k_gemm_fat
+                    if (g_la_mb_pair & 2048) {                  // bit 11: the register-staged form (k_gemm_fat, STG = 1)
+                        switch ((nblk + 1) / 2) {
+                            case 2: k_gemm_fat<8, 2, MB_SWIGLU, 4, 0, 4, 1><<<g2, 256, FatGeom<8, 2>::LDS, st>>>(p); break;
+                            case 3: k_gemm_fat<8, 3, MB_SWIGLU, 4, 0, 4, 1><<<g2, 256, FatGeom<8, 3>::LDS, st>>>(p); break;
+                            default: k_gemm_fat<8, 4, MB_SWIGLU, 4, 0, 4, 1><<<g2, 256, FatGeom<8, 4>::LDS, st>>>(p); break;
+                        }
+                        LAUNCH_CHECK(); return 0;
+                    }
                     switch ((nblk + 1) / 2) {
                         case 2: k_gemm_fat<8, 2, MB_SWIGLU><<<g2, 256, FatGeom<8, 2>::LDS, st>>>(p); break;
                         case 3: k_gemm_fat<8, 3, MB_SWIGLU><<<g2, 256, FatGeom<8, 3>::LDS, st>>>(p); break;

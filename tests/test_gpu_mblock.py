@@ -325,7 +325,7 @@ def test_mstep_moe_every_expert_receives_every_row():
         assert float((err < TOL_TINY).float().mean()) >= 0.95 and float(err.median()) < 0.5 * TOL_TINY, (b, err)
 
 
-@pytest.mark.parametrize('nblk', [3, 4, 5, 7, 8])
+@pytest.mark.parametrize('nblk', [2, 3, 4, 5, 7, 8])
 def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
     """la_debug_set key 6: the slab and QKV launches of the wide family with TWO weight regions x HALF the token blocks per
     workgroup (RBV = 4 wave grid, grid.z = token halves).  Every output element is the same chain of MFMAs over the same operands
@@ -360,7 +360,7 @@ def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
                 check(lib.la_qkv_row_perm(nh, nkv, perm.ctypes.data_as(_lib.pi32)), 'perm')
                 wp = gu.pack_weight(w[torch.from_numpy(perm.astype(np.int64)).to(DEV)].contiguous())
             outs = []
-            for pair in (0, 1, 5, 33, 257 + 512):      # 769 = round 5: ONE region x 256 rows per workgroup as fat waves of 2 x 2 tiles; 5 = paired + the QUAD form of the QKV launch (taken at >= 7 blocks of a GQA shape); 33 = fat waves (round 5)
+            for pair in (0, 1, 5, 33, 257 + 512, 257 + 4096):      # 4353 = one region x 128 rows per workgroup at <= 4 blocks (n_wg <= 128: the GQA / classic images here); 769 = round 5: ONE region x 256 rows per workgroup as fat waves of 2 x 2 tiles; 5 = paired + the QUAD form of the QKV launch (taken at >= 7 blocks of a GQA shape); 33 = fat waves (round 5)
                 check(lib.la_lab_set(6, pair), 'debug_set')
                 qf = torch.zeros(8 * nh * 8192, dtype=torch.bfloat16, device=DEV)
                 kf = torch.zeros(8 * nkv * 8192, dtype=torch.bfloat16, device=DEV)
@@ -378,7 +378,7 @@ def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
             wu_ = bf(torch.randn(F, K, generator=g, device=DEV) * 0.05)
             wp = gu.pack_planned(1, [wg_, wu_], 256)
             outs = []
-            for pair in (0, 3, 17, 65 + 128):     # 17 = round 5: the pair of regions as FOUR fat waves (k_gemm_fat, 4 x TW accumulator tiles per wave); 193 = ONE region x all token blocks as four fat waves (bit 6; bit 7: at every block count)
+            for pair in (0, 3, 17, 17 + 2048, 65 + 128):     # 2065 = the fat pair staged through registers (STG form); 17 = round 5: the pair of regions as FOUR fat waves (k_gemm_fat, 4 x TW accumulator tiles per wave); 193 = ONE region x all token blocks as four fat waves (bit 6; bit 7: at every block count)
                 check(lib.la_lab_set(6, pair), 'debug_set')
                 act = torch.zeros(8 * 64 * F, dtype=torch.bfloat16, device=DEV)
                 _mb(1, wp, _pack_blocks(x), F, K, nblk, n_wg=256, act=act)
