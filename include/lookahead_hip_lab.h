@@ -35,7 +35,7 @@ extern "C" {
  * key 11: the single-sequence step captured n (1..8) times into one graph (measurement of the per-launch cost: none found).
  * key 16: 1 = the gathered multi-block MoE step launches every expert's GEMMs separately and accumulates / normalises in two row
  *         kernels (default 0: one launch per stage, one fused row kernel); 2 = an expert's last single block keeps the padded
- *         two-block pass (default: the one-block body).
+ *         two-block pass (default: the one-block body); 4 = the expert plan and the gather as two launches (round-3 form; default: one launch).
  * key 12: multi-block slab GEMMs with 2 K splits over 4 token groups at >= 5 blocks (measured slower; read at graph capture).
  * key 13: depth probe (also reachable through la_debug_set of the product header).  key 14: 1 = separate build-inputs / embed /
  *         argmax / accept / publish kernels instead of the fused step head / tail.  key 15: bit 0 = gate/up as 4 waves x 8 tile-sets.

@@ -83,7 +83,7 @@ struct la_llama {
     hipStream_t graph_stream;
 };
 
-int g_la_ex_split = 0;            // la_debug_set key 16: 1 = gathered multi-block MoE with one launch per expert and stage (A/B)
+int g_la_ex_split = 0;            // la_debug_set key 16: 1 = gathered multi-block MoE with one launch per expert and stage (A/B); 4 = plan and gather as two launches (round-3 form)
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Carver {
@@ -684,8 +684,13 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk, bool wide = fals
             const bool gathered = nblk >= 2;
             const long xg_stride = (long)LA_MB_MAX * 64 * c.hidden;
             if (gathered) {
-                KCHK(lk_mb_moe_plan(st, route_w, M, c.n_experts, m->mb_moe_perm, m->mb_moe_pos, m->mb_moe_cnt));
-                KCHK(lk_mb_moe_gather(st, m->mb_xp, m->mb_moe_perm, m->mb_moe_cnt, c.hidden, nblk, c.n_experts, m->mb_xg, xg_stride));
+                if (!(g_la_ex_split & 4)) {              // round 5: plan + gather in one launch (la_lab_set(16, 4) = the two launches of round 3)
+                    KCHK(lk_mb_moe_plan_gather(st, route_w, M, m->mb_xp, c.hidden, nblk, c.n_experts, m->mb_xg, xg_stride, m->mb_moe_perm,
+                                               m->mb_moe_pos, m->mb_moe_cnt));
+                } else {
+                    KCHK(lk_mb_moe_plan(st, route_w, M, c.n_experts, m->mb_moe_perm, m->mb_moe_pos, m->mb_moe_cnt));
+                    KCHK(lk_mb_moe_gather(st, m->mb_xp, m->mb_moe_perm, m->mb_moe_cnt, c.hidden, nblk, c.n_experts, m->mb_xg, xg_stride));
+                }
             }
             if (gathered && m->ex_merged && !(g_la_ex_split & 1)) {
                 // equally spaced expert images: ONE gate/up launch and ONE down launch for all experts (grid.z = expert x pass)

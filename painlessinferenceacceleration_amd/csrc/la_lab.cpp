@@ -37,7 +37,7 @@ int la_lab_set(int key, int value) {
     if (key == 13 && value >= 0) { g_la_stop_layers = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 14 && value >= 0 && value <= 1) { g_la_split_head_tail = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 15 && value >= 0 && value <= 7) { g_la_gemm_4w = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 16 && value >= 0 && value <= 3) { g_la_ex_split = value; ++g_la_graph_epoch; return LA_OK; }
+    if (key == 16 && value >= 0 && value <= 7) { g_la_ex_split = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 17 && value >= 0 && value <= 1) { g_la_attn_one = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 24 && value >= 0 && value <= 1) { g_la_mb_sch = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 25 && value >= 0 && value <= 15) { g_la_ex_d4 = value; ++g_la_graph_epoch; return LA_OK; }

@@ -54,6 +54,8 @@ int lk_mb_moe_accum(hipStream_t st, const float* slabs0, long slab_stride, int n
 // gathered MoE: perm [E][LA_MB_MAX*64], pos [M][LA_MOE_MAX_E], cnt_nb [2][LA_MOE_MAX_E] = {rows, 64-row blocks} per expert
 int lk_mb_moe_plan(hipStream_t st, const float* route_w, int M, int E, int* perm, int* pos, int* cnt_nb);
 int lk_mb_moe_gather(hipStream_t st, const void* xp, const int* perm, const int* cnt_nb, int hidden, int nblk, int E, void* xg, long xg_stride);
+int lk_mb_moe_plan_gather(hipStream_t st, const float* route_w, int M, const void* xp, int hidden, int nblk, int E, void* xg, long xg_stride,
+                          int* perm, int* pos, int* cnt_nb);
 int lk_mb_cand_slots(int n_wg);
 int lk_mb_logits_wgs(int V, int n_wg);
 int lk_mb_argmax(hipStream_t st, const float* cv, const int* ci, int n_tiles, int nblk, int* out_rows);

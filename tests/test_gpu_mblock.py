@@ -885,3 +885,35 @@ def test_merged_expert_launch_forms_agree():
         err = (lg - ref[0].float()).abs().amax(-1) / ref[0].float().abs().amax(-1).clamp_min(1e-6)
         assert torch.equal(outs[form][1], ref[1]), form                      # routing weights: identical (the router precedes the experts)
         assert float(err.max()) <= 1e-2, (form, float(err.max()))
+
+
+def test_moe_plan_gather_one_launch_is_bitwise_the_two_launch_form():
+    """la_lab_set key 16 bit 2: the expert plan (rows per expert, ascending) and the gather of each expert's packed activation blocks as ONE
+    launch (round 5 default: every workgroup derives its expert's row list itself) vs the round-3 pair of launches.  Integer work in front
+    of the same GEMMs: logits, routing weights and emitted tokens must be equal bit for bit — full blocks, ragged last blocks, 2-4 blocks."""
+    shape = LlamaShape(1, 4096, 32, 8, 14336, 32000, 1e-5, rope_theta=1e6, n_experts=8, top_k=2, norm_cast_first=True)
+    sd = random_weights(shape, seed=17, device='cpu')
+    default_form = lib.la_lab_get(16)
+    assert default_form == 0
+    try:
+        for B in (2, 3, 4):
+            outs = {}
+            for form in (0, 4):
+                check(_lib.lab_set(16, form), 'lab_set')
+                eng = LlamaVerifyEngine(shape, dict(sd), max_length=256, n_slots=B, max_blocks=B)
+                rs = np.random.RandomState(37 + B)
+                blocks = []
+                for b in range(B):
+                    p = rs.randint(3, shape.vocab, size=int(rs.randint(20, 64))).tolist()
+                    tok = eng.mprefill(b, p)
+                    T = 64 if b == 0 else int(rs.randint(5, 65))
+                    _, rows = random_tree(rs, T)
+                    ids = np.concatenate([[tok], rs.randint(3, shape.vocab, size=T - 1)]).astype(np.int32)
+                    blocks.append((b, ids, rows, 0, 16))
+                toks = eng.mstep(blocks)
+                outs[form] = (eng.mlogits()[:B * 64].clone(), eng.mroute_weights().clone(), toks)
+                del eng
+            assert bool(torch.isfinite(outs[0][0].float()).all()) and float(outs[0][0].float().abs().max()) > 0
+            assert torch.equal(outs[0][0], outs[4][0]) and torch.equal(outs[0][1], outs[4][1]) and outs[0][2] == outs[4][2], B
+    finally:
+        _lib.lab_set(16, default_form)
