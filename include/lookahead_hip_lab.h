@@ -24,7 +24,8 @@ extern "C" {
  *        blocks per workgroup (fat waves, nt weights; default on), bit 7 = that form at every block count (measurement), bit 8 = QKV at <= 4 blocks as ONE {lo, hi} region x 256 rows per workgroup (fat waves
  *        of 2 x 2 tiles; default on), bit 9 = at 5-8 blocks too (measurement), bit 10 = the slab launches at <= 4 blocks in that one-region form (measured slower: opt-in),
  *        bit 11 = the paired gate/up fat launch stages its operands through registers (buffer_load -> VGPR -> ds_write) instead of LDS-DMA (measured slower: opt-in),
- *        bit 12 = QKV at <= 4 blocks over at most 128 regions (the fuller GQA image) as one region x 128 rows per workgroup (twice the workgroups of bit 8's form; default on);
+ *        bit 12 = QKV at <= 4 blocks over at most 128 regions (the fuller GQA image) as one region x 128 rows per workgroup (twice the workgroups of bit 8's form; default on),
+ *        bit 13 = the fat slab launches (o_proj / down) with 2 / 4 / 8 K splits map ONE K split to an XCD (x per L2 = 1 / splits of it; same tiles, other workgroup ids);
  *        bit-identical results; read at launch / capture.
  * key 7: idle-window weight prefetch of the 64-row step, KiB per workgroup of the next GEMM (0 = off, <= 128): the row kernels and
  *        the attention combine carry extra workgroups that pull the first k-tiles of the next GEMM into L2 (bit-identical

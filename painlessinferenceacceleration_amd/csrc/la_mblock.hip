@@ -63,6 +63,9 @@ struct MbArgs {
     // paired form of the wide kernel (launch_mb): the weight rows of a workgroup are read by a second workgroup working on the other
     // token blocks (same XCD): stream them with the default cache policy so that the second reader finds them in L2
     int w_keep;
+    // k_gemm_fat slab launches with 2 / 4 / 8 K splits (round 5, launch_mb): workgroup -> tile mapping that gives every XCD ONE K split (8 / ksplit
+    // XCDs per split), so an XCD's L2 holds a 1 / ksplit slice of x instead of all of it
+    int xcd_map;
     long long* dbg_times;    // measurement build DBG = 6: [workgroup][wave][8] accumulated shader cycles per loop segment
 };
 
@@ -1011,15 +1014,32 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rg = wave / TQ, tq = wave % TQ;          // row group (4 row-blocks), token group
-    const int ksplit = gridDim.y, ks = blockIdx.y;
+    // workgroup -> (weight regions bx, K split ks, token group bz).  Slab launches may re-map (MbArgs.xcd_map): workgroups go to the XCDs round-robin
+    // by their linear id, and with the plain grid order every XCD sees every K split — all of x (512 rows x K) lands in each of the 8 L2s: for
+    // down at the Mistral shape that is 8 x 14.7 MB = as many fabric bytes as the weights (counters: 268 MB per launch for 117 MB of W).  Re-mapped,
+    // XCD c works on K split c / (8 / ksplit) only: x per L2 = 1 / ksplit of it, the weights as before (each region's K slice is read in one XCD).
+    int bx = blockIdx.x, ks = blockIdx.y, bz = blockIdx.z;
+    const int ksplit = gridDim.y;
+    if constexpr (EPI == MB_SLAB) {
+        if (a.xcd_map) {
+            const int gx = gridDim.x, gz = gridDim.z;
+            const int lin = bx + gx * (ks + ksplit * bz);
+            const int per = (gx * ksplit * gz) >> 3;           // workgroups per XCD (launcher: a multiple of 8 in total)
+            const int xcd = lin & 7, slot = lin >> 3, g = 8 / ksplit;
+            const int j = (xcd % g) * per + slot;              // 0 .. gx * gz: the tiles of this K split, both token groups of a region in one XCD
+            ks = xcd / g;
+            bx = j / gz;
+            bz = j - bx * gz;
+        }
+    }
     int t0, t1;
     mb_k_range(a.K16, ks, ksplit, t0, t1);
     const int nst = (t1 - t0) / KS;                    // an even range (launcher)
-    const int zb0 = blockIdx.z * GEO::BLOCKS;
+    const int zb0 = bz * GEO::BLOCKS;
 
     // ---- DMA pieces of this wave: p = wave + NW i; i < NPA: weight piece (k-tile p / RBV, row-block p % RBV), else an x piece
-    const bf16x8* wg_w = a.planned ? (const bf16x8*)a.wp + (size_t)blockIdx.x * (unsigned)a.wg_chunks
-                                   : (const bf16x8*)a.wp + (size_t)blockIdx.x * RBV * a.K16 * 64;
+    const bf16x8* wg_w = a.planned ? (const bf16x8*)a.wp + (size_t)bx * (unsigned)a.wg_chunks
+                                   : (const bf16x8*)a.wp + (size_t)bx * RBV * a.K16 * 64;
     const __amdgpu_buffer_rsrc_t rs_w = dma_rsrc(wg_w), rs_x = dma_rsrc(a.xp);
     unsigned gstr[NP], voff[NP];
     int pkk[NP], pdst[NP];
@@ -1204,7 +1224,7 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
 #pragma unroll
                 for (int gi = 0; gi < 4; ++gi) {
                     const f32x4 v = {acc[r][t][4 * gi], acc[r][t][4 * gi + 1], acc[r][t][4 * gi + 2], acc[r][t][4 * gi + 3]};
-                    float* o = a.slabs + ((size_t)ks * a.M + blk * 64 + tok) * a.N + (blockIdx.x * RBV + RPW * rg + r) * 32 + 8 * gi + 4 * hh;
+                    float* o = a.slabs + ((size_t)ks * a.M + blk * 64 + tok) * a.N + (bx * RBV + RPW * rg + r) * 32 + 8 * gi + 4 * hh;
                     *(f32x4*)o = v;
                 }
         }
@@ -1215,13 +1235,13 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
             if (blk >= a.nblk) continue;
 #pragma unroll
             for (int j = 0; j < RPW / 2; ++j)            // region (RBV / 2) x + j = row-blocks {2 j, 2 j + 1} = its {lo, hi} halves
-                fat_qkv_tile<RV>(a, acc[2 * j][t], acc[2 * j + 1][t], blockIdx.x * (RBV / 2) + (RPW / 2) * rg + j, blk, tok, hh);
+                fat_qkv_tile<RV>(a, acc[2 * j][t], acc[2 * j + 1][t], bx * (RBV / 2) + (RPW / 2) * rg + j, blk, tok, hh);
         }
     } else {
         // ---- SwiGLU epilogue, as k_gemm_wide<8, TW, MB_SWIGLU>: act = bf16(silu(bf16(g)) * bf16(u)) parked as tile[token][sh + feature -
         //      lo] in the drained ring, then 16-byte chunks of the activation image
         constexpr int NREG = RBV / 4;                          // planned regions per workgroup
-        const int sw_lo = a.R * NREG * blockIdx.x, sw_r = NREG * a.R, sw_sh = sw_lo & 7;
+        const int sw_lo = a.R * NREG * bx, sw_r = NREG * a.R, sw_sh = sw_lo & 7;
         const int sw_nch = (sw_sh + sw_r + 7) >> 3;
         const int sw_stride = (sw_nch * 8) % 64 == 0 ? sw_nch * 8 + 8 : sw_nch * 8;
         __syncthreads();
@@ -2630,8 +2650,11 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                 const bool quarters = nblk <= 4 || (EPI == MB_SLAB && g_la_mb_ks2 && ksplit <= 2) || (EPI == MB_QKV && (n_wg <= 128 || (g_la_mb_pair & 8)));
                 if constexpr (EPI == MB_SLAB) {
                     if (fat) {
-                        if (quarters) k_gemm_fat<4, 1, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 1) / 2), 256, FatGeom<4, 1>::LDS, st>>>(p);
-                        else k_gemm_fat<4, 2, EPI><<<dim3(n_wg / 2, ksplit, (nblk + 3) / 4), 256, FatGeom<4, 2>::LDS, st>>>(p);
+                        const dim3 gs(n_wg / 2, ksplit, quarters ? (nblk + 1) / 2 : (nblk + 3) / 4);
+                        // bit 13 of key 6: one K split per XCD (k_gemm_fat, MbArgs.xcd_map) — 2 / 4 / 8 splits over a grid of a multiple of 8 workgroups
+                        p.xcd_map = ((g_la_mb_pair & 8192) && (ksplit == 2 || ksplit == 4 || ksplit == 8) && (gs.x * gs.y * gs.z) % 8 == 0) ? 1 : 0;
+                        if (quarters) k_gemm_fat<4, 1, EPI><<<gs, 256, FatGeom<4, 1>::LDS, st>>>(p);
+                        else k_gemm_fat<4, 2, EPI><<<gs, 256, FatGeom<4, 2>::LDS, st>>>(p);
                         LAUNCH_CHECK(); return 0;
                     }
                 }

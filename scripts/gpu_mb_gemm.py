@@ -55,7 +55,7 @@ def main():
         a = bf(torch.randn(nblk * 64, F, generator=g, device=DEV))
         ap = torch.cat([gu.pack_x(a[b * 64:(b + 1) * 64].contiguous()) for b in range(nblk)])
         z = None
-        for narrow, wmode, dw in ((0, 0, 1), (0, 49, 1), (0, 49 + 2048, 1), (0, 113, 1)):
+        for narrow, wmode, dw in ((0, 0, 1), (0, 49, 1), (0, 49 + 8192, 1)):
             check(lib.la_lab_set(3, narrow), 'debug_set')
             check(lib.la_lab_set(6, wmode if wmode else 1), 'debug_set')      # 3 = paired gate/up (8 waves), 17 = fat-wave gate/up (k_gemm_fat, round 5), 49 = fat-wave slab launches too
             check(lib.la_lab_set(24, dw), 'debug_set')          # 1 = round-4 schedule (default), 0 = round-2 schedule
@@ -73,7 +73,7 @@ def main():
                     torch.cuda.synchronize()
                     continue
                 us, med = bench(fn)
-                print(f'{name:8s} rows {nblk * 64:4d} {"k_gemm_mb  " if narrow else "paired, 8 waves  " if wmode == 3 else "FAT gate/up      " if wmode == 17 else "FAT gate/up+slab " if wmode == 49 else "FAT g/u REG-STAGED" if wmode == 49 + 2048 else "FAT, g/u UNPAIRED" if wmode == 113 else "wide (default)   " if dw else "wide, schedule 0 "} min {us:8.2f} us  median {med:8.2f} us  {flops / us / 1e6:7.1f} TFLOP/s', flush=True)
+                print(f'{name:8s} rows {nblk * 64:4d} {"k_gemm_mb  " if narrow else "paired, 8 waves  " if wmode == 3 else "FAT gate/up      " if wmode == 17 else "FAT gate/up+slab " if wmode == 49 else "FAT g/u REG-STAGED" if wmode == 49 + 2048 else "FAT + XCD K map  " if wmode == 49 + 8192 else "FAT, g/u UNPAIRED" if wmode == 113 else "wide (default)   " if dw else "wide, schedule 0 "} min {us:8.2f} us  median {med:8.2f} us  {flops / us / 1e6:7.1f} TFLOP/s', flush=True)
     check(lib.la_lab_set(3, 0), 'debug_set')
     check(lib.la_lab_set(6, 1), 'debug_set')
     check(lib.la_lab_set(24, 1), 'debug_set')

@@ -128,7 +128,7 @@ def test_debug_knobs_roundtrip_and_defaults():
     for key, d in defaults.items():
         assert lib.la_lab_get(key) == d, key
     try:
-        for key, ok, bad in ((6, 8191, 8192), (16, 7, 8), (14, 1, 2), (15, 7, 8), (7, 128, 129), (8, 16, 17), (9, 64, 65), (10, 1, 2), (11, 8, 9), (17, 0, 2)):
+        for key, ok, bad in ((6, 16383, 16384), (16, 7, 8), (14, 1, 2), (15, 7, 8), (7, 128, 129), (8, 16, 17), (9, 64, 65), (10, 1, 2), (11, 8, 9), (17, 0, 2)):
             assert lib.la_lab_set(key, ok) == 0 and lib.la_lab_get(key) == ok
             assert lib.la_lab_set(key, bad) == -1 and lib.la_lab_get(key) == ok          # LA_E_ARG, value kept
         assert lib.la_lab_get(99) == -1 and lib.la_lab_set(99, 0) == -1
