@@ -3,7 +3,7 @@
  * binds, no stability promise.  Every knob has a library default (la_lab_get reports the value in effect); the step entry points
  * capture their graphs again after a change.
  *
- * Defaults: everything 0 except key 6 = 4465 (paired wide launches + their fat-wave forms; gate/up and QKV unpaired at <= 4 blocks, QKV over <= 128 regions in two token groups), key 11 = 1 (one step per graph), key 17 = 1
+ * Defaults: everything 0 except key 6 = 12657 (paired wide launches + their fat-wave forms; gate/up and QKV unpaired at <= 4 blocks, QKV over <= 128 regions in two token groups), key 11 = 1 (one step per graph), key 17 = 1
  * (single-launch tree attention), key 24 = 1, key 25 = 13.
  */
 #ifndef LOOKAHEAD_HIP_LAB_H
@@ -25,7 +25,7 @@ extern "C" {
  *        of 2 x 2 tiles; default on), bit 9 = at 5-8 blocks too (measurement), bit 10 = the slab launches at <= 4 blocks in that one-region form (measured slower: opt-in),
  *        bit 11 = the paired gate/up fat launch stages its operands through registers (buffer_load -> VGPR -> ds_write) instead of LDS-DMA (measured slower: opt-in),
  *        bit 12 = QKV at <= 4 blocks over at most 128 regions (the fuller GQA image) as one region x 128 rows per workgroup (twice the workgroups of bit 8's form; default on),
- *        bit 13 = the fat slab launches (o_proj / down) with 2 / 4 / 8 K splits map ONE K split to an XCD (x per L2 = 1 / splits of it; same tiles, other workgroup ids);
+ *        bit 13 = the fat slab launches (o_proj / down) with 2 / 4 / 8 K splits map ONE K split to an XCD (x per L2 = 1 / splits of it; same tiles, other workgroup ids; default on for grids of whole multiples of 256 workgroups, bit 14 = on any grid: measurement);
  *        bit-identical results; read at launch / capture.
  * key 7: idle-window weight prefetch of the 64-row step, KiB per workgroup of the next GEMM (0 = off, <= 128): the row kernels and
  *        the attention combine carry extra workgroups that pull the first k-tiles of the next GEMM into L2 (bit-identical

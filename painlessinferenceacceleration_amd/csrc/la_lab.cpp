@@ -27,7 +27,7 @@ int la_lab_set(int key, int value) {
     if (key == 3 && value >= 0 && value <= 1) { g_la_mb_narrow = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 4 && value >= 0 && value <= 6) { g_la_mb_dbg = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 5 && value >= 0 && value <= 3) { g_la_mb_mode = value; ++g_la_graph_epoch; return LA_OK; }
-    if (key == 6 && value >= 0 && value <= 16383) { g_la_mb_pair = value; ++g_la_graph_epoch; return LA_OK; }
+    if (key == 6 && value >= 0 && value <= 32767) { g_la_mb_pair = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 7 && value >= 0 && value <= 128) { g_la_pf_kib = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 8 && value >= 0 && value <= 16) { g_la_pf_delay = value; ++g_la_graph_epoch; return LA_OK; }
     if (key == 9 && value >= 0 && value <= 64) { g_la_pf_tail_kib = value; ++g_la_graph_epoch; return LA_OK; }

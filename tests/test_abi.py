@@ -121,14 +121,14 @@ def test_qkv_row_perm_is_a_permutation_of_rope_pairs():
 
 def test_debug_knobs_roundtrip_and_defaults():
     """la_lab_set / la_lab_get: every knob reads back, out-of-range values are refused, and the library defaults are the
-    documented ones (everything 0 except key 6 = 4465: the paired wide launches + (round 5) the fat-wave forms of gate/up and of the paired slab / QKV launches, and key 11 = 1 step per graph; round 3: 13 = depth probe,
+    documented ones (everything 0 except key 6 = 12657: the paired wide launches + (round 5) the fat-wave forms of gate/up and of the paired slab / QKV launches, and key 11 = 1 step per graph; round 3: 13 = depth probe,
     14 = split head / tail kernels, 15 = 4-wave GEMM variants; round 4: 17 = single-launch tree attention, default ON)."""
     lib = _lib.lib
-    defaults = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0, 5: 0, 6: 4465, 7: 0, 8: 0, 9: 0, 10: 0, 11: 1, 12: 0, 13: 0, 14: 0, 15: 0, 16: 0, 17: 1, 18: 0, 19: 0, 20: 0, 21: 0, 22: 0, 23: 0, 24: 1, 25: 13}
+    defaults = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0, 5: 0, 6: 12657, 7: 0, 8: 0, 9: 0, 10: 0, 11: 1, 12: 0, 13: 0, 14: 0, 15: 0, 16: 0, 17: 1, 18: 0, 19: 0, 20: 0, 21: 0, 22: 0, 23: 0, 24: 1, 25: 13}
     for key, d in defaults.items():
         assert lib.la_lab_get(key) == d, key
     try:
-        for key, ok, bad in ((6, 16383, 16384), (16, 7, 8), (14, 1, 2), (15, 7, 8), (7, 128, 129), (8, 16, 17), (9, 64, 65), (10, 1, 2), (11, 8, 9), (17, 0, 2)):
+        for key, ok, bad in ((6, 32767, 32768), (16, 7, 8), (14, 1, 2), (15, 7, 8), (7, 128, 129), (8, 16, 17), (9, 64, 65), (10, 1, 2), (11, 8, 9), (17, 0, 2)):
             assert lib.la_lab_set(key, ok) == 0 and lib.la_lab_get(key) == ok
             assert lib.la_lab_set(key, bad) == -1 and lib.la_lab_get(key) == ok          # LA_E_ARG, value kept
         assert lib.la_lab_get(99) == -1 and lib.la_lab_set(99, 0) == -1

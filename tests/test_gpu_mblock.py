@@ -340,7 +340,7 @@ def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
             wp = gu.pack_weight(bf(torch.randn(N, K, generator=g, device=DEV) * 0.05))
             rows = (nblk + 3) // 4 * 4 * 64
             outs = []
-            for pair in (0, 1, 33, 33 + 8192, 1025):   # 8225 = the fat slab launch with one K split per XCD (xcd_map: the same tiles under other workgroup ids); 1025 = one region x 256 rows per workgroup at <= 4 blocks (fat waves of 2 x 2 tiles); 33 = round 5: the paired launch as four fat waves (k_gemm_fat; 1376 / 4 = 86 k-tiles per split: even)
+            for pair in (0, 1, 33, 33 + 8192 + 16384, 1025):   # 24609 = the fat slab launch with one K split per XCD on any grid (xcd_map: the same tiles under other workgroup ids); 1025 = one region x 256 rows per workgroup at <= 4 blocks (fat waves of 2 x 2 tiles); 33 = round 5: the paired launch as four fat waves (k_gemm_fat; 1376 / 4 = 86 k-tiles per split: even)
                 check(lib.la_lab_set(6, pair), 'debug_set')
                 slabs = torch.full((ks, rows, N), float('nan'), dtype=torch.float32, device=DEV)
                 _mb(0, wp, _pack_blocks(x), N, K, nblk, ksplit=ks, slabs=slabs, slab_rows=rows)
