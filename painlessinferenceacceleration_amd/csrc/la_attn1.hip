@@ -31,14 +31,21 @@ struct Attn1Args {
     const bf16_t* vfresh;
     bf16_t* attn_xp;
     long long* dbg_times;     // measurement aid: [workgroup][wave][8] wall-clock stamps, null in production
+    int n_main;               // workgroups of the attention proper; block ids past it are weight-prefetch riders (round 6, see pf)
+    PfDesc pf;                // riders: the first KiB every o_proj workgroup will stream, pulled into its XCD's L2 by the CUs this launch leaves idle
 };
 
+__device__ __forceinline__ void attn1_rider(const PfDesc& p, int b);
+
 // Leading scalars (kernel-argument preload, build.sh): everything between dispatch and the first K-tile request.
+// RIDE = the instantiation whose grid carries weight-prefetch rider workgroups behind the attention's own (lab knob 31).
+template <bool RIDE>
 __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ qf, const unsigned long long* __restrict__ rowmask,
                                                      const int* __restrict__ state, const bf16_t* __restrict__ kmain,
                                                      const bf16_t* __restrict__ vmain, int max_keys, int nh_nkv, int window,
                                                      int sl_ring, Attn1Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds1[];      // [Q fragments: 8 KiB][merge buffer]
+    if constexpr (RIDE) { if ((int)blockIdx.x >= a.n_main) { attn1_rider(a.pf, (int)blockIdx.x - a.n_main); return; } }
     const int nh = nh_nkv >> 16, nkv = nh_nkv & 0xffff, G = nh / nkv;
     const int SL = sl_ring & 63, ring_tiles = sl_ring >> 8;
     const int W = 32 / SL;                                            // token rows this workgroup stores
@@ -276,6 +283,29 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
     if (stamp && lane == 0) stamp[4] = wall_clock64();
 }
 
+// Rider workgroup b: 16 x 16-byte loads per thread over the first bytes consumer workgroup b of the NEXT launch (o_proj) streams
+// (PfDesc, la_kernels.h); default cache policy, data dropped; the wave retires when they have landed in this XCD's L2.
+__device__ __forceinline__ void attn1_rider(const PfDesc& p, int b) {
+    if (b >= p.n_consumers) return;
+    for (int i = 0; i < p.delay; ++i) __builtin_amdgcn_s_sleep(32);        // lab knob 32: let the attention's own first (HBM) tiles go first
+    const int bx = b % p.nbx, ks = b / p.nbx;
+    const char* start = p.base + (size_t)bx * p.A + (size_t)ks * p.A2;
+    const unsigned n0 = p.L[0] >> 4, n1 = p.RB > 1 ? p.L[1] >> 4 : 0u;          // classic images: RB <= 2
+    const unsigned cps = n0 + n1, total = cps * (unsigned)p.NW;
+    f32x4 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        unsigned i = threadIdx.x + (unsigned)j * 512u;
+        i = i < total ? i : total - 1u;
+        const unsigned w = i / cps, r = i - w * cps;
+        const bool second = r >= n0;
+        const char* addr = start + (second ? p.boff[1] : p.boff[0]) + (size_t)w * (second ? p.C[1] : p.C[0]) + (size_t)(second ? r - n0 : r) * 16;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[j]) : "v"(addr));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+                 "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]) : "memory");
+}
+
 extern long long* g_la_dbg_times;
 int g_la_attn1_var = 0;       // la_lab_set key 18 (measurement): bit 0 = first K tile requested only after the cursor has arrived (round-4 order), bits 1-2 = force SL (1 -> 1, 2 -> 2, 3 -> 4)
 int g_la_attn_one = 1;        // la_debug_set key 17: 1 = single-launch attention on the single-sequence step (default), 0 = split + combine
@@ -284,13 +314,15 @@ static int g_attn1_cus = 0;
 // one-off set-up, called from lk_gemm64r_init (never inside a stream capture): dynamic-LDS limit of the SL = 1 form, CU count
 int lk_attn1_init() {
     if (g_attn1_cus) return 0;
-    if (hipFuncSetAttribute((const void*)k_tree_attn1, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 + 8 * 16 * 64 * 16 + 8 * 32 * 8) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)k_tree_attn1<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 + 8 * 16 * 64 * 16 + 8 * 32 * 8) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)k_tree_attn1<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 + 8 * 16 * 64 * 16 + 8 * 32 * 8) != hipSuccess) return -1;
     hipDeviceProp_t p; int dev = 0;
     g_attn1_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
     return 0;
 }
 int lk_tree_attn1(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh, const void* vfresh,
-                  const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys, void* attn_xp, int window, int ring_keys) {
+                  const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys, void* attn_xp, int window, int ring_keys,
+                  const PfDesc* pf) {
     if (nh <= 0 || nkv <= 0 || nh % nkv || nh > 0x7fff || (ring_keys >> 5) >= (1 << 22)) return -1;
     if (lk_gemm64r_init() != 0) return -1;
     // token slices per 32-row block: 2 (measured: every slice count streams the same bytes per CU — all of the head's K/V — and
@@ -303,7 +335,14 @@ int lk_tree_attn1(hipStream_t st, const void* qf, const void* kmain, const void*
     Attn1Args a{};
     a.kfresh = (const bf16_t*)kfresh; a.vfresh = (const bf16_t*)vfresh; a.attn_xp = (bf16_t*)attn_xp; a.dbg_times = g_la_dbg_times;
     const size_t lds = 8192 + (size_t)8 * 16 * 2 * W * 16 + (size_t)8 * W * 8;
-    k_tree_attn1<<<nh * 2 * SL, 512, lds, st>>>((const bf16_t*)qf, (const unsigned long long*)rowmask, state, (const bf16_t*)kmain,
+    a.n_main = nh * 2 * SL;
+    int riders = 0;
+    if (pf && pf->base && pf->n_consumers > 0 && pf->RB <= 2 && (a.n_main & 7) == 0) { a.pf = *pf; riders = pf->n_consumers; }
+    if (riders)
+        k_tree_attn1<true><<<a.n_main + riders, 512, lds, st>>>((const bf16_t*)qf, (const unsigned long long*)rowmask, state, (const bf16_t*)kmain,
+                                                (const bf16_t*)vmain, max_keys, (nh << 16) | nkv, window, SL | ((g_la_attn1_var & 1) << 7) | ((ring_keys >> 5) << 8), a);
+    else
+        k_tree_attn1<false><<<a.n_main, 512, lds, st>>>((const bf16_t*)qf, (const unsigned long long*)rowmask, state, (const bf16_t*)kmain,
                                                 (const bf16_t*)vmain, max_keys, (nh << 16) | nkv, window, SL | ((g_la_attn1_var & 1) << 7) | ((ring_keys >> 5) << 8), a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;

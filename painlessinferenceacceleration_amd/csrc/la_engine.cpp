@@ -12,6 +12,7 @@
 #include "la_kernels.h"
 #include "la_mblock.h"
 extern int g_la_pf_kib, g_la_pf_delay, g_la_pf_tail_kib, g_la_graph_epoch, g_la_graph_reps, g_la_mb_ks2;
+extern int g_la_fork_pf[5], g_la_attn_ride_kib, g_la_attn_ride_delay;
 int g_la_ex_down_ks = 0;       // la_lab_set key 22: K splits of the experts' down projection in the gathered multi-block MoE step (0 = library default)
 int g_la_norm4 = 0;            // la_lab_set key 19 (measured neutral: 5.30 vs 5.37 us per launch, profiles/r04_*): 1 = residual + RMSNorm with four workgroups per row (k_row_norm4) on the single-sequence step
 int g_la_split_head_tail = 0;   // la_debug_set key 14: 1 = separate build-inputs / embed / argmax / accept / publish kernels (A/B)
@@ -81,6 +82,10 @@ struct la_llama {
     bool graph_ready, bgraph_ready;
     int graph_epoch = 0;       // g_la_graph_epoch at the time the single-sequence step graph was captured
     hipStream_t graph_stream;
+    // forked weight prefetch (round 6): a low-priority side stream that becomes a parallel branch of the captured single-sequence
+    // step (k_pf_only launches under the latency-bound kernels), and the two events that fork / join it
+    hipStream_t pf_stream = nullptr;
+    hipEvent_t pf_fork = nullptr, pf_join = nullptr;
 };
 
 int g_la_ex_split = 0;            // la_debug_set key 16: 1 = gathered multi-block MoE with one launch per expert and stage (A/B); 4 = plan and gather as two launches (round-3 form)
@@ -337,6 +342,9 @@ extern "C" void la_llama_destroy(la_llama* m) {
     if (m->bgraph_exec) (void)hipGraphExecDestroy(m->bgraph_exec);
     for (int i = 0; i < 4; ++i) if (m->bready[i]) (void)hipGraphExecDestroy(m->bgraphs[i]);
     for (int i = 0; i < 2 * (LA_MB_MAX + 1); ++i) if (m->mready[i]) (void)hipGraphExecDestroy(m->mgraphs[i]);
+    if (m->pf_fork) (void)hipEventDestroy(m->pf_fork);
+    if (m->pf_join) (void)hipEventDestroy(m->pf_join);
+    if (m->pf_stream) (void)hipStreamDestroy(m->pf_stream);
     delete m;
 }
 
@@ -381,8 +389,30 @@ struct Prof {
 
 // enqueue every kernel of one block on `st` (used eagerly, under graph capture, and by the profiler)
 static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = false, const int32_t* zc_in = nullptr,
-                        int32_t* zc_out = nullptr, int bsplit = 0, bool long_ctx = false) {
+                        int32_t* zc_out = nullptr, int bsplit = 0, bool long_ctx = false, bool fork = false) {
     const la_llama_config& c = m->cfg;
+    // Forked weight prefetch: `fork_pf(d)` makes the side stream wait for everything queued on `st` so far and launches the
+    // prefetch workgroups of descriptor d there — under stream capture a parallel branch of the graph that starts when the step
+    // reaches this point and is joined at the end of the step only (nothing waits for a prefetch: it writes nothing).
+    bool forked = false;
+    auto fork_pf = [&](const PfDesc& d, bool wait_here) -> int {
+        if (!fork || !m->pf_stream || !d.base) return LA_OK;
+        if (wait_here) {
+            HIPCHK(hipEventRecord(m->pf_fork, st));
+            HIPCHK(hipStreamWaitEvent(m->pf_stream, m->pf_fork, 0));
+        }
+        KCHK(lk_pf_only(m->pf_stream, &d));
+        forked = true;
+        return LA_OK;
+    };
+    auto join_pf = [&]() -> int {
+        if (!forked) return LA_OK;
+        HIPCHK(hipEventRecord(m->pf_join, m->pf_stream));
+        HIPCHK(hipStreamWaitEvent(st, m->pf_join, 0));
+        forked = false;
+        return LA_OK;
+    };
+    const int* fk = g_la_fork_pf;
     const int ring = c.kv_ring ? c.max_keys : 0;          // sliding-window ring: position p of a sequence lives in row p mod max_keys
     auto P = [&](int cls) { if (pf) pf->mark(cls); };
     P(KC_OTHER);
@@ -433,19 +463,35 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
                              m->qf, kf, vf));
         }
         P(KC_ATTN);
+        if (fork && c.n_experts == 0) {
+            PfDesc fd{};
+            bool first = true;
+            if (fk[0] > 0) { lk_pf_classic(&fd, L.wo, c.hidden, m->o_k, m->o_rb, m->o_ks, fk[0], 0, nullptr); if (fd.base) { int rc = fork_pf(fd, first); if (rc != LA_OK) return rc; first = false; } }
+            if (fk[1] > 0 && c.balanced_wg[1] > 0) { lk_pf_planned(&fd, L.wgateup, 1, c.ffn, c.hidden, c.balanced_wg[1], fk[1], 0, nullptr); if (fd.base) { int rc = fork_pf(fd, first); if (rc != LA_OK) return rc; first = false; } }
+        }
         pd = PfDesc{};
         if (pf_kib > 0) lk_pf_classic(&pd, L.wo, c.hidden, m->o_k, m->o_rb, m->o_ks, pf_kib, pf_dly, nullptr);
         if (batch)
             KCHK(lk_tree_attn_b(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
                                 kf, vf, m->rowmask, m->bstate, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, bsplit > 0 ? bsplit : m->nsplit,
                                 m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window, ring, &pd));
-        else
+        else {
+            // riders (la_lab_set key 31): the single-launch attention occupies nh * 4 CUs; the others pull o_proj's first KiB into L2
+            PfDesc rd{};
+            if (g_la_attn_ride_kib > 0 && !long_ctx) lk_pf_classic(&rd, L.wo, c.hidden, m->o_k, m->o_rb, m->o_ks, g_la_attn_ride_kib, g_la_attn_ride_delay, nullptr);
             KCHK(lk_tree_attn(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
                               kf, vf, m->rowmask, m->state, c.n_heads, c.n_kv_heads, m->total_keys, m->nsplit,
-                              m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window, ring, &pd, long_ctx ? 0 : -1));
+                              m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window, ring, &pd, long_ctx ? 0 : -1, &rd));
+        }
         P(KC_O);
         KCHK(lk_gemm64_slab(st, L.wo, m->attn_xp, c.hidden, m->o_k, m->o_rb, m->o_ks, m->slabs));
         P(KC_OTHER);
+        if (fork && c.n_experts == 0) {
+            PfDesc fd{};
+            bool first = true;
+            if (fk[2] > 0 && c.balanced_wg[1] > 0) { lk_pf_planned(&fd, L.wgateup, 1, c.ffn, c.hidden, c.balanced_wg[1], fk[2], 0, nullptr); if (fd.base) { int rc = fork_pf(fd, first); if (rc != LA_OK) return rc; first = false; } }
+            if (fk[4] > 0) { lk_pf_classic(&fd, L.wdown, c.hidden, c.ffn, m->down_rb, m->down_ks, fk[4], 0, nullptr); if (fd.base) { int rc = fork_pf(fd, first); if (rc != LA_OK) return rc; first = false; } }
+        }
         const void* nw = (l + 1 < nl) ? m->layers[l + 1].norm1 : m->w.final_norm;
         if (c.n_experts > 0) {
             // sparse MoE MLP: router fused into the norm, then per expert {gate/up+SwiGLU, down, weighted accumulate};
@@ -524,6 +570,12 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
         P(KC_DOWN);
         KCHK(lk_gemm64_slab(st, L.wdown, m->act_xp, c.hidden, c.ffn, m->down_rb, m->down_ks, m->slabs));
         P(KC_OTHER);
+        if (fork && fk[3] > 0) {
+            PfDesc fd{};
+            if (l + 1 < nl) { if (c.balanced_wg[0] > 0) lk_pf_planned(&fd, m->layers[l + 1].wqkv, 2, (c.n_heads + 2 * c.n_kv_heads) * 128, c.hidden, c.balanced_wg[0], fk[3], 0, nullptr); }
+            else if (c.balanced_wg[2] > 0) lk_pf_planned(&fd, m->w.lm_head, 0, c.vocab, c.hidden, c.balanced_wg[2], fk[3], 0, nullptr);
+            if (fd.base) { int rc = fork_pf(fd, true); if (rc != LA_OK) return rc; }
+        }
     after_down:
         if (!((m->fuse & 2) && l + 1 < nl)) {        // otherwise fused into the next layer's QKV launch
             if (l + 1 < nl) pf_qkv(l + 1, &pd);
@@ -546,7 +598,7 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
             KCHK(lk_step_tail(st, m->cand_val, m->cand_idx, c.balanced_wg[2], m->ids, m->rowmask, m->state, (int*)zc_out));
             KCHK(lk_kv_commit(st, m->kfresh, m->vfresh, m->kmain, m->vmain, m->state, c.n_layers, c.n_kv_heads, m->total_keys, ring));
             P(KC_N);
-            return LA_OK;
+            return join_pf();
         }
         KCHK(lk_argmax_finalize(st, m->cand_val, m->cand_idx, c.balanced_wg[2], am_rows));
     } else {
@@ -563,18 +615,27 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
         if (zc_out) KCHK(lk_publish(st, m->state, (int*)zc_out));
     }
     P(KC_N);
-    return LA_OK;
+    return join_pf();
 }
 
 static int build_graph(la_llama* m, hipStream_t st, bool batch = false, const int32_t* zc_in = nullptr,
                        int32_t* zc_out = nullptr, int bsplit = 0, bool long_ctx = false) {
     hipGraph_t g = nullptr;
+    bool fork = false;
+    if (!batch) for (int i = 0; i < 5; ++i) fork = fork || g_la_fork_pf[i] > 0;
+    if (fork && !m->pf_stream) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = the numerically largest value = the LOWEST priority
+        HIPCHK(hipStreamCreateWithPriority(&m->pf_stream, hipStreamNonBlocking, lo));
+        HIPCHK(hipEventCreateWithFlags(&m->pf_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&m->pf_join, hipEventDisableTiming));
+    }
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     // measurement knob (la_debug_set key 11): the single-sequence graph holds the step n times (the same input block each time, only
     // the last repetition publishes) — what a launch costs beyond its kernels shows as time per repetition vs n
     const int reps = (!batch && g_la_graph_reps > 1) ? g_la_graph_reps : 1;
     int rc = LA_OK;
-    for (int r = 0; r < reps && rc == LA_OK; ++r) rc = enqueue_step(m, st, nullptr, batch, zc_in, r + 1 == reps ? zc_out : nullptr, bsplit, long_ctx);
+    for (int r = 0; r < reps && rc == LA_OK; ++r) rc = enqueue_step(m, st, nullptr, batch, zc_in, r + 1 == reps ? zc_out : nullptr, bsplit, long_ctx, fork);
     hipError_t e = hipStreamEndCapture(st, &g);
     if (rc != LA_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
     HIPCHK(e);

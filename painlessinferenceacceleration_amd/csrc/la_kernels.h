@@ -34,6 +34,7 @@ struct PfDesc {
 };
 void lk_pf_planned(PfDesc* d, const void* wp, int kind, int n_rows, int K, int n_wg, int kib, int delay, int* sink);
 void lk_pf_classic(PfDesc* d, const void* wp, int N, int K, int rbv, int ksplit, int kib, int delay, int* sink);
+int lk_pf_only(hipStream_t st, const PfDesc* pf);     // the prefetch workgroups of a descriptor as their own launch (forked graph branch)
 
 int lk_pack_weight(hipStream_t st, const void* w, const void* w2, int N, int K, int interleave2, void* out);
 int lk_pack_x(hipStream_t st, const void* x, int K, void* out);
@@ -80,11 +81,12 @@ int lk_qkv_post(hipStream_t st, const float* slabs, int n_slabs, int nh, int nkv
 int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                  const void* vfresh, const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys,
                  int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window = 0, int ring_keys = 0,
-                 const PfDesc* pf = nullptr, int form = -1);      // form: 0 = key splits + combine, -1 = the default (one launch, la_attn1.hip) unless a lab knob says otherwise
+                 const PfDesc* pf = nullptr, int form = -1, const PfDesc* ride = nullptr);      // form: 0 = key splits + combine, -1 = the default (one launch, la_attn1.hip) unless a lab knob says otherwise
 int lk_attn1_init();
 // single-sequence step, ONE launch (la_attn1.hip): no key-split partials, no combine kernel
 int lk_tree_attn1(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh, const void* vfresh,
-                  const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys, void* attn_xp, int window, int ring_keys);
+                  const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys, void* attn_xp, int window, int ring_keys,
+                  const PfDesc* pf = nullptr);      // pf: weight-prefetch riders for the next launch (o_proj) on the CUs this one leaves idle
 int lk_tree_attn_b(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                    const void* vfresh, const uint64_t* rowmask, const int* bstate, int nh, int nkv, int slot_keys,
                    int n_slots, int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window = 0, int ring_keys = 0,

@@ -268,6 +268,12 @@ __device__ __forceinline__ void pf_body(const PfDesc& p, int b) {
     pf_wait16(v);
 }
 
+// The same prefetch as its OWN launch (round 6): queued on a second, low-priority stream that forks off the step's stream — a
+// parallel branch of the captured graph — so that it runs UNDER a latency-bound launch of the step (the tree attention leaves
+// half the CUs and nearly all of HBM idle for ~13 us) instead of riding inside it.  One workgroup per consumer workgroup, block
+// id = consumer id (same XCD residue).  Nothing is written: the step's results cannot depend on it.
+__global__ __launch_bounds__(512) void k_pf_only(PfDesc pf) { pf_body(pf, (int)blockIdx.x); }
+
 template <int NS, bool MOE>
 __global__ __launch_bounds__(512) void k_row_norm(const bf16_t* __restrict__ embed, const int* __restrict__ ids,
                                                    bf16_t* __restrict__ h, const float* __restrict__ slabs,
@@ -1990,6 +1996,12 @@ extern int g_la_attn_one;
 int g_la_slab_wt = 0;         // la_lab_set key 23: split-K slabs of the 64-row o_proj / down_proj stored write-through (sc1)
 int g_la_gemm_4w = 0;         // la_debug_set key 15: bit 0 = gate/up as 4 waves x 8 tile-sets (one wave per SIMD) — measurement
 int g_la_pf_delay = 0;        // s_sleep(32) rounds the prefetch workgroups wait before their first load (key 8)
+// forked weight prefetch (round 6; la_lab_set keys 26-30, KiB per consumer workgroup, 0 = off): [0] o_proj under the attention launch,
+// [1] gate/up queued behind it (runs under attention / o_proj / norm), [2] gate/up forked after o_proj (under the post-attention norm),
+// [3] next QKV / lm_head forked after down_proj (under the input norm), [4] down_proj forked after o_proj
+int g_la_fork_pf[5] = {0, 0, 0, 0, 0};
+int g_la_attn_ride_delay = 0; // la_lab_set key 32: s_sleep(32) rounds (~0.85 us each) the riders wait before their first load
+int g_la_attn_ride_kib = 0;   // la_lab_set key 31: KiB per o_proj workgroup pulled into L2 by rider workgroups of the single-launch attention (0 = off)
 
 #define LA_CAND_LDS (8 * LA_TB * 8)      // lm_head: [8 waves][64 tokens] (value, index) candidates behind the reduction buffer
 // leading scalar kernel arguments of the GEMM kernels (kernarg preload, see k_gemm64 / k_gemm64r)
@@ -2003,6 +2015,12 @@ int g_la_pf_delay = 0;        // s_sleep(32) rounds the prefetch workgroups wait
 static inline int pf_extra(const PfDesc* pf) { return (pf && pf->base && pf->n_consumers > 0) ? pf->n_consumers : 0; }
 static inline PfDesc pf_or_none(const PfDesc* pf) { PfDesc d{}; if (pf_extra(pf)) d = *pf; return d; }
 
+
+int lk_pf_only(hipStream_t st, const PfDesc* pf) {
+    if (!pf_extra(pf)) return 0;
+    k_pf_only<<<pf->n_consumers, 512, 0, st>>>(*pf);
+    LAUNCH_CHECK(); return 0;
+}
 
 int lk_pack_weight(hipStream_t st, const void* w, const void* w2, int N, int K, int il, void* out) {
     size_t total = (size_t)(il ? 2 * N : N) / 32 * (K / 16) * 64;
@@ -2385,7 +2403,7 @@ int lk_tree_attn_b(hipStream_t st, const void* qf, const void* kmain, const void
 int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                  const void* vfresh, const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys,
                  int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window, int ring_keys,
-                 const PfDesc* pf, int form) {
+                 const PfDesc* pf, int form, const PfDesc* ride) {
     AttnArgs a{};
     a.dbg_times = g_la_dbg_times;
     a.window = window; a.ring_tiles = ring_keys >> 5;
@@ -2398,7 +2416,7 @@ int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* 
     // default: the single-launch form (la_attn1.hip); la_debug_set(17, 0) = key splits + combine (the A/B switch, and the carrier of
     // the idle-window prefetch workgroups)
     if (g_la_attn_one && form != 0 && !pf_extra(pf) && !g_la_attn_staged)
-        return lk_tree_attn1(st, qf, kmain, vmain, kfresh, vfresh, rowmask, state, nh, nkv, max_keys, attn_xp, window, ring_keys);
+        return lk_tree_attn1(st, qf, kmain, vmain, kfresh, vfresh, rowmask, state, nh, nkv, max_keys, attn_xp, window, ring_keys, ride);
     return tree_attn_launch(st, a, 1, attn_xp, pf);
 }
 
