@@ -12,7 +12,7 @@
 #include "la_kernels.h"
 #include "la_mblock.h"
 extern int g_la_pf_kib, g_la_pf_delay, g_la_pf_tail_kib, g_la_graph_epoch, g_la_graph_reps, g_la_mb_ks2;
-extern int g_la_fork_pf[5], g_la_attn_ride_kib, g_la_attn_ride_delay;
+extern int g_la_fork_pf[5], g_la_attn_ride_kib, g_la_attn_ride_delay, g_la_attn_merge_ns, g_la_oproj_probe;
 int g_la_ex_down_ks = 0;       // la_lab_set key 22: K splits of the experts' down projection in the gathered multi-block MoE step (0 = library default)
 int g_la_norm4 = 0;            // la_lab_set key 19 (measured neutral: 5.30 vs 5.37 us per launch, profiles/r04_*): 1 = residual + RMSNorm with four workgroups per row (k_row_norm4) on the single-sequence step
 int g_la_split_head_tail = 0;   // la_debug_set key 14: 1 = separate build-inputs / embed / argmax / accept / publish kernels (A/B)
@@ -475,7 +475,16 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
             KCHK(lk_tree_attn_b(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
                                 kf, vf, m->rowmask, m->bstate, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, bsplit > 0 ? bsplit : m->nsplit,
                                 m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window, ring, &pd));
-        else {
+        else if (g_la_attn_merge_ns > 0 && !long_ctx && c.n_experts == 0 && c.sliding_window <= 0 && (m->o_k / 16) / m->o_ks == 64 &&
+                 g_la_attn_merge_ns <= m->nsplit && c.hidden % 64 == 0) {
+            // lab knob 33 (review item 1b): key-split attention over NS splits, NO combine launch — o_proj merges the partials on load
+            KCHK(lk_tree_attn(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
+                              kf, vf, m->rowmask, m->state, c.n_heads, c.n_kv_heads, m->total_keys, g_la_attn_merge_ns,
+                              m->opart, m->mpart, m->lpart, nullptr, c.sliding_window, ring, nullptr, 0));
+            P(KC_O);
+            KCHK(lk_oproj_merge(st, L.wo, c.hidden, m->o_k, m->o_ks, g_la_attn_merge_ns, m->opart, m->mpart, m->lpart, m->slabs));
+            goto after_oproj;
+        } else {
             // riders (la_lab_set key 31): the single-launch attention occupies nh * 4 CUs; the others pull o_proj's first KiB into L2
             PfDesc rd{};
             if (g_la_attn_ride_kib > 0 && !long_ctx) lk_pf_classic(&rd, L.wo, c.hidden, m->o_k, m->o_rb, m->o_ks, g_la_attn_ride_kib, g_la_attn_ride_delay, nullptr);
@@ -484,7 +493,12 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
                               m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window, ring, &pd, long_ctx ? 0 : -1, &rd));
         }
         P(KC_O);
+        if (g_la_oproj_probe && !batch)            // timing probe (lab knob 34): another o_proj geometry; numerics are NOT preserved
+            KCHK(lk_gemm64_slab(st, L.wo, m->attn_xp, c.hidden, m->o_k, (g_la_oproj_probe & 16) ? (1 | (1 << 8)) : m->o_rb,
+                                (g_la_oproj_probe & 15) ? (g_la_oproj_probe & 15) : m->o_ks, m->slabs));
+        else
         KCHK(lk_gemm64_slab(st, L.wo, m->attn_xp, c.hidden, m->o_k, m->o_rb, m->o_ks, m->slabs));
+    after_oproj:
         P(KC_OTHER);
         if (fork && c.n_experts == 0) {
             PfDesc fd{};
@@ -548,7 +562,8 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
         } else {
             pd = PfDesc{};
             if (pf_kib > 0 && c.balanced_wg[1] > 0) lk_pf_planned(&pd, L.wgateup, 1, c.ffn, c.hidden, c.balanced_wg[1], pf_kib, pf_dly, nullptr);
-            if (norm4) KCHK(lk_resid_norm4(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp, cf, m->norm_gran + (size_t)(2 * l) * 256));
+            if ((g_la_oproj_probe & 32) && !batch) {}          // timing probe: the post-attention norm launch is skipped (x is stale)
+            else if (norm4) KCHK(lk_resid_norm4(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp, cf, m->norm_gran + (size_t)(2 * l) * 256));
             else KCHK(lk_resid_norm(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp, cf, &pd));
             P(KC_GATEUP);
             if ((m->fuse & 4) && (m->down_rb & 0xff) == 2) {

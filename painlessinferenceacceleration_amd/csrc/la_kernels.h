@@ -83,6 +83,9 @@ int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* 
                  int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window = 0, int ring_keys = 0,
                  const PfDesc* pf = nullptr, int form = -1, const PfDesc* ride = nullptr);      // form: 0 = key splits + combine, -1 = the default (one launch, la_attn1.hip) unless a lab knob says otherwise
 int lk_attn1_init();
+// lab (round 6, knob 33): o_proj that merges the key-split attention partials while it builds its x operand (la_oproj_merge.hip)
+int lk_oproj_merge(hipStream_t st, const void* wp, int N, int K, int ksplit, int nsplit, const float* opart, const float* mpart,
+                   const float* lpart, float* slabs);
 // single-sequence step, ONE launch (la_attn1.hip): no key-split partials, no combine kernel
 int lk_tree_attn1(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh, const void* vfresh,
                   const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys, void* attn_xp, int window, int ring_keys,

@@ -2000,6 +2000,8 @@ int g_la_pf_delay = 0;        // s_sleep(32) rounds the prefetch workgroups wait
 // [1] gate/up queued behind it (runs under attention / o_proj / norm), [2] gate/up forked after o_proj (under the post-attention norm),
 // [3] next QKV / lm_head forked after down_proj (under the input norm), [4] down_proj forked after o_proj
 int g_la_fork_pf[5] = {0, 0, 0, 0, 0};
+int g_la_oproj_probe = 0;     // la_lab_set key 34 (TIMING PROBE, results are garbage): bits 0-3 = K splits of o_proj (0 = default), bit 4 = one row-block per workgroup x 8 waves, bit 5 = skip the post-attention norm launch — prices a full-K o_proj with the norm folded into gate/up (review item 1c)
+int g_la_attn_merge_ns = 0;   // la_lab_set key 33: 2 | 4 = key-split attention WITHOUT the combine launch, merged on load by o_proj (k_oproj_merge)
 int g_la_attn_ride_delay = 0; // la_lab_set key 32: s_sleep(32) rounds (~0.85 us each) the riders wait before their first load
 int g_la_attn_ride_kib = 0;   // la_lab_set key 31: KiB per o_proj workgroup pulled into L2 by rider workgroups of the single-launch attention (0 = off)
 
@@ -2430,6 +2432,7 @@ static int tree_attn_launch(hipStream_t st, AttnArgs a, int n_slots, void* attn_
     else k_tree_attn<false><<<dim3(nh, nsplit, n_slots), 2 * LA_ATT_PAR * 64, 2 * LA_ATT_PAR * 66 * 64 * sizeof(float), st>>>(ATT_HEAD(a), a);
 #undef ATT_HEAD
     LAUNCH_CHECK();
+    if (!attn_xp) return 0;                          // lab knob 33: the consumer (k_oproj_merge) reads the partials itself
     int total = nh * LA_TB * 16;
     const int n_main = (total + 255) / 256;
     if (n_main % 8) pf = nullptr;                    // appended ids would land on other XCDs than their consumers

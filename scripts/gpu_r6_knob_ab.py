@@ -60,6 +60,8 @@ def main():
     defaults = {k: lib.la_lab_get(k) for k in keys}
     times = {name: [] for name, _ in settings}
     ident = {name: True for name, _ in settings}
+    tok_eq = {name: True for name, _ in settings}
+    rel = {name: 0.0 for name, _ in settings}
     base = None
     for rep in range(args.reps):
         order = settings if rep % 2 == 0 else settings[::-1]
@@ -83,8 +85,12 @@ def main():
             logits = eng.logits().clone()
             if base is None:
                 base = (toks, logits)
-            elif not (toks == base[0] and torch.equal(logits, base[1])):
-                ident[name] = False
+            else:
+                if not (toks == base[0] and torch.equal(logits, base[1])):
+                    ident[name] = False
+                if toks != base[0]:
+                    tok_eq[name] = False
+                rel[name] = max(rel[name], float((logits.float() - base[1].float()).abs().max() / base[1].float().abs().max()))
             times[name].append(round(ms, 4))
             print(json.dumps({'rep': rep, 'setting': name, 'ms_per_step': round(ms, 4)}), flush=True)
     for k in keys:
@@ -94,7 +100,8 @@ def main():
     for name, pairs in settings:
         t = times[name]
         summary.append({'setting': name, 'knobs': {str(k): v for k, v in pairs}, 'ms_min': min(t), 'ms_median': float(np.median(t)), 'ms_all': t,
-                        'vs_first_min_pct': round((min(t) / ref - 1) * 100, 2), 'bitwise_identical_to_first': ident[name]})
+                        'vs_first_min_pct': round((min(t) / ref - 1) * 100, 2), 'bitwise_identical_to_first': ident[name], 'tokens_equal_first': tok_eq[name],
+                        'max_logit_rel_diff_vs_first': round(rel[name], 6)})
     out = {'model': args.model, 'layers': args.layers, 'steps': args.steps, 'reps': args.reps, 'prompt_len': args.prompt_len, 'summary': summary}
     os.makedirs(os.path.dirname(args.out) or '.', exist_ok=True)
     with open(args.out, 'w') as f:
