@@ -188,6 +188,8 @@ def secondary_legs(spec, gpus=1, layers=0):
         leg_args = ['--gpus', str(gpus), '--model', model, '--batch', batch, '--steps', '24', '--warmup', '4', '--no-cpu-baseline']
         if dev_trie_leg:
             leg_args.append('--device-trie')
+        if len(parts) > 2 and parts[2] == 'deferred':            # model:batch:deferred = the host-trie leg with the trie update under the next pass
+            leg_args.append('--deferred-trie-update')
         if layers:                       # launch-path tests only (tests/test_gpu_bench_launch.py): a truncated model, flagged in the leg
             leg_args += ['--layers', str(int(layers)), '--steps', '6', '--warmup', '2']
         cmd = [sys.executable, os.path.abspath(__file__)] + leg_args if gpus == 1 else self_launch_cmd(leg_args, gpus, _free_port())
@@ -200,20 +202,96 @@ def secondary_legs(spec, gpus=1, layers=0):
             if r.returncode != 0 or not line:
                 legs.append({'model': model, 'batch': int(batch), 'error': (r.stderr or r.stdout)[-300:], 'wall_s': round(time.time() - t0, 1)})
                 continue
-            j = json.loads(line[-1])
-            c = j['config']
-            legs.append({'workload': c['workload'], 'metric': j['metric'], 'value': j['value'], 'unit': j['unit'],
-                         'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'warmup': j['warmup'], 'sequences': c['sequences'],
-                         'mean_accept_len': c['mean_accept_len'], 'mean_draft_len': c['mean_draft_len'], 'kv_cache': c['kv_cache'],
-                         'lookahead_equals_greedy': c['lookahead_equals_greedy'], 'context_at_end': c['context_at_end'],
-                         'draft_retrieval': c.get('draft_retrieval'), 'trie_update': c.get('trie_update'),
-                         'n_gpus': j['n_gpus'], 'gather_mode': c.get('gather_mode'), 'gather_transport': c.get('gather_transport'),
-                         'rccl_ranks': c.get('rccl_ranks'),
-                         'roofline': j.get('roofline'), 'wall_s': round(time.time() - t0, 1), 'n_layers': c.get('n_layers'),
-                         'command': 'python bench.py --gpus %d --model %s --batch %s --steps 24 --warmup 4 --no-cpu-baseline%s' % (gpus, model, batch, ' --device-trie' if dev_trie_leg else '')})
+            legs.append(compact_leg(json.loads(line[-1]), item, round(time.time() - t0, 1)))
         except Exception as e:           # noqa: BLE001 — a secondary leg must never take the headline line down
             legs.append({'model': model, 'batch': int(batch), 'error': repr(e)[:300], 'wall_s': round(time.time() - t0, 1)})
     return legs
+
+
+def compact_leg(j, name, wall_s=None):
+    """One secondary leg as ~300 bytes: what a reader of the driver's captured tail needs to judge the leg; the prose that is the same for
+    every leg lives once in the headline's `notes` table, the leg's full record in its own BENCH_DETAIL line / detail file."""
+    c, r = j['config'], (j.get('roofline') or {})
+    alg = (r.get('hbm') or {}).get('algorithmic_bytes') or (r.get('verify_step') or {}).get('algorithmic_bytes')
+    leg = {'name': name, 'model': c.get('model'), 'sequences': c.get('sequences'), 'n_gpus': j.get('n_gpus'), 'ms_per_step': j['ms_per_step'], 'value': j['value'],
+           'accept_len': c.get('mean_accept_len'), 'draft_len': c.get('mean_draft_len'), 'bound': r.get('bound'), 'frac': r.get('frac'),
+           'hbm_frac': (r.get('hbm') or r.get('verify_step') or {}).get('frac'), 'mfma_frac': (r.get('mfma') or {}).get('frac'),
+           'traffic_ratio': round(r['traffic'] / alg, 3) if (r.get('traffic') and alg) else None,
+           'draft_retrieval': c.get('draft_retrieval'), 'trie_update': c.get('trie_update'), 'equals_greedy': c.get('lookahead_equals_greedy'),
+           'steps': j.get('steps')}
+    if c.get('n_layers_truncated'):
+        leg['n_layers'] = c.get('n_layers')
+    if j.get('n_gpus', 1) > 1:
+        leg.update({'gather_mode': c.get('gather_mode'), 'gather_transport': c.get('gather_transport'), 'rccl_ranks': c.get('rccl_ranks'),
+                    'gather_us_per_step': c.get('gather_us_per_step'), 'slowest_rank_wait_us': c.get('slowest_rank_wait_us')})
+    if wall_s is not None:
+        leg['wall_s'] = wall_s
+    return leg
+
+
+NOTES = {
+    'workload': 'lookahead verify loop (hier drafts): per sequence a 64-token draft tree over 8-12 noisy branches of its greedy continuation, '
+                'synthetic permutation-LM weights (N(0,0.02); o/down std 1e-4; lm_head[pi(t)] = embed[t]) for decisive greedy margins, 512-token phrase-bank prompts',
+    'value': 'accepted tokens / s over the timed verify steps, inputs resident in HBM; prefill excluded (speed_incl_prefill = the reference headline definition)',
+    'roofline.timing': 'dominant kernel from live HIP events on the engine stream (all layers\' launches back to back per event pair); rocprofv3 averages of the same command: newest profiles/r*_profile_raw.txt',
+    'roofline.traffic': 'HBM bytes per launch (bs=1) / per verify step (batch legs) from committed FETCH_SIZE / WRITE_SIZE passes (profiles/pmc_latest.json, pmc_secondary.json); traffic_ratio = traffic / algorithmic bytes',
+    'draft_retrieval': 'host = native C++ trie (la_cache_*); device = on-GPU trie (la_trie_dev.hip), drafts chained in front of the verify pass, trie update on the device',
+    'trie_update': 'ref-order = before the next query (reference order); deferred = under the next verify pass (drafts see a step one step later); device = la_trie_stream_put_dev',
+    'secondary': 'each leg = this script in its own process after the headline\'s timed region (24 steps, 4 warm-up): BASELINE config 3 (mistral:8 host trie in the reference update order, :deferred = update under the next pass, :dev = on-GPU trie), config 4 per-GPU share (13b:4), config 5 (mixtral:4), and 13b:1',
+    'detail': 'the full record (every field of earlier rounds) is the BENCH_DETAIL line above this one and gpurun_out/bench_detail_*.json',
+}
+
+
+def compact_record(out):
+    """The driver keeps the last 8 KB of stdout: the final JSON line carries the contract fields and one compact object per secondary leg;
+    prose and bulky diagnostics stay in the BENCH_DETAIL line printed before it."""
+    c, r, cpu = out['config'], out.get('roofline') or {}, out.get('cpu_baseline')
+    sip = c.get('speed_incl_prefill') or {}
+    cfg = {k: c.get(k) for k in ('workload', 'model', 'n_layers', 'n_layers_truncated', 'prompt_len', 'parallelism', 'sequences', 'kv_cache', 'gather_mode', 'gather_transport',
+                                 'rccl_ranks', 'gather_us_per_step', 'slowest_rank_wait_us', 'trie_update', 'draft_retrieval', 'mean_accept_len', 'mean_draft_len',
+                                 'verify_steps_per_sec', 'context_mean_timed', 'context_at_end', 'trie_query_ms_mean', 'lookahead_equals_greedy',
+                                 'plain_greedy_tokens_per_sec', 'device_trie_stats') if c.get(k) is not None}
+    cfg['speed_incl_prefill'] = {k: sip.get(k) for k in ('prefill_ms', 'tokens_per_sec', 'at_256_new_tokens')}
+    if c.get('native_loop'):
+        cfg['native_loop'] = {k: c['native_loop'].get(k) for k in ('ms_per_step', 'equals_greedy')}
+    roof = {k: r.get(k) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'frac_of_achievable', 'bytes_per_launch', 'ms_per_launch') if k in r}
+    if 'verify_step' in r:
+        v = r['verify_step']
+        fm = v.get('floor_model') or {}
+        roof['verify_step'] = {'algorithmic_bytes': v.get('algorithmic_bytes'), 'ms_graph_step': v.get('ms_graph_step'), 'achieved_GBps': v.get('achieved_GBps'),
+                               'frac': v.get('frac'), 'frac_of_achievable': v.get('frac_of_achievable'), 'ms_by_class_events': v.get('ms_by_class_events'),
+                               'floor_model': {k: fm.get(k) for k in ('gemm_floor_ms_per_step', 'nongemm_ms_per_step', 'frac_of_peak_if_nongemm_were_free', 'frac_of_peak_at_floor') if k in fm}}
+    if 'hbm' in r:
+        roof['hbm'] = {k: r['hbm'].get(k) for k in ('algorithmic_bytes', 'achieved_GBps', 'frac')}
+    if 'mfma' in r:
+        roof['mfma'] = {k: r['mfma'].get(k) for k in ('achieved_TFLOPs', 'frac')}
+    comp = {k: out[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')}
+    comp['config'] = cfg
+    comp['roofline'] = roof
+    comp['cpu_baseline'] = None if cpu is None else {k: cpu.get(k) for k in ('value', 'unit', 'cores', 'kind', 'sample', 'ms_per_step', 'mean_accept_len', 'cpu_model', 'verify_steps', 'fallback_reason') if cpu.get(k) is not None}
+    if 'secondary' in out:
+        comp['secondary'] = out['secondary']
+    comp['notes'] = NOTES
+    return comp
+
+
+def cpu_baseline_leg(shape, sd_cpu, prompt, copies, branch_length, decoding_length, verify_steps=5, threads=None):
+    """`cpu_baseline`: the REFERENCE ITSELF (kind "reference", oracle/reference_cpu.py) where /root/reference is importable — the build container —
+    and the port of it (kind "port", cpu_baseline_loop below: the oracle loop, pinned token for token to the reference) everywhere else (the GPU box)."""
+    why = None
+    try:
+        from oracle import reference_cpu
+        if reference_cpu.reference_available() and shape.n_experts == 0 and not os.environ.get('BENCH_CPU_PORT'):
+            r = reference_cpu.reference_lookahead_loop(shape, sd_cpu, prompt, copies, branch_length, decoding_length, verify_steps=verify_steps, threads=threads,
+                                                       dtype=next(iter(sd_cpu.values())).dtype)
+            r.pop('tokens', None)
+            return r
+    except Exception as e:                   # noqa: BLE001 — fall back to the port and say why
+        why = repr(e)[:200]
+    r = cpu_baseline_loop(shape, sd_cpu, prompt, copies, branch_length, decoding_length, verify_steps=verify_steps, threads=threads)
+    if why:
+        r['fallback_reason'] = why
+    return r
 
 
 def cpu_model_name():
@@ -258,6 +336,37 @@ def cpu_baseline_loop(shape, sd_cpu, prompt, copies, branch_length, decoding_len
                       f'bf16, {nt} threads pinned'}
 
 
+def cpu_only(args):
+    """bench.py --cpu-baseline-only: the CPU leg alone, on host cores, no HIP device touched.  The greedy continuation the noisy trie copies are
+    drawn from comes from the oracle (plain greedy with a KV cache) instead of the GPU engine; everything else is the leg of the default run."""
+    from oracle import llama_oracle as lo
+    from painlessinferenceacceleration_amd.llama_engine import LlamaShape, random_weights
+    shape = {'7b': LlamaShape.llama2_7b, '13b': LlamaShape.llama2_13b}[args.model]()
+    if args.layers:
+        shape.n_layers = args.layers
+    P, BL, DL = args.prompt_len, args.branch_length, args.decoding_length
+    tdtype = torch.float16 if args.dtype == 'fp16' else torch.bfloat16
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    sd = random_weights(shape, seed=0, device='cpu', decisive=True, dtype=tdtype)
+    prompt = phrase_prompt(1234, P, shape.vocab)
+    n_truth = (args.cpu_steps + 2) * (BL + 1) + 8
+    model = lo.OracleLlama(shape, sd)
+    t0 = time.time()
+    seq = list(prompt)
+    lg, past = model.forward(torch.tensor(seq), torch.tril(torch.ones((P, P), dtype=torch.long)), None)
+    for _ in range(n_truth):
+        t = int(lg[-1].float().argmax())
+        seq.append(t)
+        lg, past = model.forward(torch.tensor([t]), torch.ones((1, len(seq)), dtype=torch.long), past)
+    t_truth = time.time() - t0
+    del model, past
+    copies = noisy_copies(prompt[-2:] + seq[P:], args.copies, args.rho, shape.vocab, seed=99)
+    cpu = cpu_baseline_leg(shape, sd, prompt, copies, BL, DL, verify_steps=args.cpu_steps)
+    print(json.dumps({'metric': 'accepted_tokens_per_sec', 'cpu_baseline': cpu, 'n_layers': shape.n_layers, 'model': args.model,
+                      'plain_greedy_s_per_token_cpu': round(t_truth / max(n_truth, 1), 3),
+                      'note': 'CPU leg only (bench.py --cpu-baseline-only): no GPU was used; value = accepted tokens / s of the CPU loop'}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -278,14 +387,18 @@ def main():
     ap.add_argument('--unchained-trie', action='store_true', help='--device-trie: read the drafts back to the host and feed them through la_llama_mstep (round-2 form)')
     ap.add_argument('--strict-gather', action='store_true', help='N > 1: blocking all-gather (reference trie order at query time)')
     ap.add_argument('--strict-trie-order', action='store_true',
-                    help='--batch > 1, host trie: apply the trie update of step k BEFORE the drafts of step k + 1 are retrieved (the reference\'s order, GPU '
-                         'idle meanwhile).  Default: the update runs on the host after the verify pass of step k + 1 has been queued (mstep_async), '
-                         'i.e. drafts see a step\'s tokens one step later — the split-phase order the N > 1 job uses; emitted tokens are unaffected')
+                    help='(the default since round 6; kept for old command lines) --batch > 1, host trie: the trie update of step k is applied BEFORE the '
+                         'drafts of step k + 1 are retrieved — the reference\'s order and the product loop\'s default')
+    ap.add_argument('--deferred-trie-update', action='store_true',
+                    help='--batch > 1, host trie: the update of step k runs on the host after the verify pass of step k + 1 has been queued (mstep_async = '
+                         'decoding_kwargs[\'overlap_trie_update\'] of the product loop), i.e. drafts see a step\'s tokens one step later — the split-phase '
+                         'order the N > 1 job uses; emitted tokens are unaffected.  The round-5 records measured THIS order by default; the default '
+                         'secondary legs carry it as mistral:8:deferred beside the reference-order line')
     ap.add_argument('--profile-iters', type=int, default=3)
     ap.add_argument('--attn-split', type=int, default=0, help='key splits of the tree-attention kernel (0 = engine default 8)')
     ap.add_argument('--fuse', type=int, default=0, help='engine cfg.fuse bits (opt-in in-kernel norm->GEMM fusion; 0 = separate kernels)')
     ap.add_argument('--gemm-cfg', default='', help='engine gemm_cfg override (comma list: qkv_rb,qkv_ks,o_rb,o_ks,down_rb,down_ks,lm_rb,gu_variant; 0 = default)')
-    ap.add_argument('--secondary', default='mistral:8,mistral:8:dev,13b:4,mixtral:4,13b:1',
+    ap.add_argument('--secondary', default='mistral:8,mistral:8:deferred,mistral:8:dev,13b:4,mixtral:4,13b:1',
                     help='N=1 default workload only: comma list of model:batch legs (BASELINE configs 3-5: a 64-token tree per sequence '
                          'through la_llama_mstep) run AFTER the timed region, each in its own process; their lines are embedded under '
                          '"secondary"; model:batch:dev = the same leg with the drafts from the on-GPU trie (BASELINE config 3 as stated: the host-trie line '
@@ -302,7 +415,12 @@ def main():
     ap.add_argument('--secondary-multi', default=None,
                     help='N > 1 default workload only: model:batch legs run as their own N-rank jobs after the headline (default: '
                          '"13b:4" at --gpus 8 = BASELINE config 4, Llama-2-13B bs=32 batch-sharded over 8 GPUs; "" = none)')
+    ap.add_argument('--cpu-baseline-only', action='store_true',
+                    help='no GPU: time only the cpu_baseline leg (the reference itself where /root/reference is importable, else the port) on the '
+                         'same model shape / prompt / trie warm-up rule and print it — how the "reference" kind is measured in the build container')
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        return cpu_only(args)
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and 'RANK' not in os.environ:
         self_launch(args.gpus, sys.argv[1:])          # does not return
@@ -440,7 +558,7 @@ def main():
         # next pass is queued — the same calls lookahead_generation() makes under decoding_kwargs['gather']
         gather = AcceptedTokenGather(comm_dev, b_loc=B, branch_length=BL, mode='strict' if args.strict_gather else 'split-phase')
     put_q = [None]                    # B > 1, one GPU: the trie update of the last step, applied under the next verify pass
-    overlap_put = B > 1 and not args.strict_trie_order
+    overlap_put = B > 1 and args.deferred_trie_update and not args.strict_trie_order
     edls, dls, qts, ctxs = [], [], [], []          # ctxs: committed keys per sequence at the start of every step
 
     def drafts_for(i):
@@ -562,6 +680,8 @@ def main():
     n0, q0, c0 = len(edls), len(qts), len(ctxs)
     if dist_on:
         dist.barrier()
+    if gather is not None:               # the gather's wait statistics cover the timed steps only
+        gather.stats = {'collectives': 0, 'wait_s': 0.0, 'wait_s_max': 0.0}
     torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(K):
@@ -579,11 +699,18 @@ def main():
         dist.barrier()
     elapsed = time.time() - t0
     accepted = int(sum(edls[n0:]))
+    gather_us_per_step = slowest_rank_wait_us = None
     if dist_on:
-        v = torch.tensor([elapsed, float(accepted)], dtype=torch.float64, device=comm_dev)
+        # what the first real N-GPU run needs to explain its own curve: host time per step spent WAITING for the accepted-token gather
+        # (mean over this job's ranks; split-phase: the wait runs under the next verify pass), and the largest single wait any rank saw
+        # (a rank waits for the slowest rank of the step: ragged accept lengths / a slow GPU show up here, not in bandwidth)
+        gs = gather.stats if gather is not None else {'collectives': 0, 'wait_s': 0.0, 'wait_s_max': 0.0}
+        own_mean_us = 1e6 * gs['wait_s'] / max(gs['collectives'], 1)
+        v = torch.tensor([elapsed, float(accepted), own_mean_us, 1e6 * gs['wait_s_max']], dtype=torch.float64, device=comm_dev)
         mx = v.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = v.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         elapsed, accepted_all = float(mx[0]), float(sm[1])
+        gather_us_per_step, slowest_rank_wait_us = round(float(sm[2]) / world, 1), round(float(mx[3]), 1)
     else:
         accepted_all = float(accepted)
     correct = all(seqs[i][P:P + len(truths[gidx[i]])] == truths[gidx[i]][:len(seqs[i]) - P] for i in range(B))
@@ -727,7 +854,7 @@ def main():
         }
     cpu = None
     if want_cpu:
-        cpu = cpu_baseline_loop(shape, sd_cpu, prompts[0], copies0, BL, DL, verify_steps=args.cpu_steps)
+        cpu = cpu_baseline_leg(shape, sd_cpu, prompts[0], copies0, BL, DL, verify_steps=args.cpu_steps)
     gather_transport = gather.transport if gather is not None else None
     rccl_ranks = world if (gather_transport is not None and ('rccl' in gather_transport or 'nccl' in gather_transport)) else 0
     if dist_on:                      # the job's collectives are over: leave the group before any follow-up job is started
@@ -747,19 +874,18 @@ def main():
         'metric': 'accepted_tokens_per_sec', 'value': round(accepted_all / elapsed, 2), 'unit': 'tokens/s',
         'n_gpus': world, 'steps': K, 'warmup': W, 'ms_per_step': round(ms_step, 4), 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-        'config': {'workload': model_name + f' {args.dtype} bs={B}/GPU lookahead verify loop, {DL}-token draft tree per sequence / 8-12 noisy branches '
-                               f'(hier, decoding_length={DL}, branch_length={BL}), synthetic permutation-LM weights (N(0,0.02); o/down std 1e-4; '
-                               'lm_head[pi(t)]=embed[t]) for decisive greedy margins, 512-token phrase-bank prompts',
-                   'n_layers': shape.n_layers, 'prompt_len': P, 'rho': args.rho, 'copies': args.copies,
+        'config': {'workload': model_name + f' {args.dtype} bs={B}/GPU lookahead verify loop, {DL}-token draft tree per sequence (hier, decoding_length={DL}, '
+                               f'branch_length={BL}), synthetic weights, {P}-token prompts (notes.workload)',
+                   'model': model_name, 'n_layers': shape.n_layers, 'n_layers_truncated': bool(args.layers), 'prompt_len': P, 'rho': args.rho, 'copies': args.copies,
                    'parallelism': f'batch-shard x{world}, {B} sequence(s) per GPU', 'sequences': NSEQ,
                    'kv_cache': (f'ring of {eng.shape.sliding_window} + one step of rows per sequence (sliding window)' if kv_ring else 'linear, max_length keys per sequence'),
                    'gather_mode': None if not dist_on else ('strict' if args.strict_gather else 'split-phase'),
                    'gather_transport': gather_transport, 'rccl_ranks': rccl_ranks,
+                   'gather_us_per_step': gather_us_per_step, 'slowest_rank_wait_us': slowest_rank_wait_us,
                    'trie_update': ('device' if (dev_trie is not None and dev_trie.put_vocab) else
-                                   ('gathered over all ranks, ' + gather.mode) if dist_on else
-                                   'host, under the next verify pass (mstep_async; drafts see a step one step later)' if (B > 1 and overlap_put and not wide and dev_trie is None) else
-                                   'host, before the next query (reference order)'),
-                   'draft_retrieval': ('device trie (incremental mirror, one launch per step' + (', chained in front of the verify pass: drafts stay in HBM)' if not args.unchained_trie else ', drafts read back to the host)') + ('; trie update on the device (la_trie_stream_put_dev)' if dev_trie.put_vocab else '; trie update on the host, shipped as a patch')) if dev_trie is not None else 'host trie',
+                                   ('gathered, ' + gather.mode) if dist_on else
+                                   'deferred' if (B > 1 and overlap_put and not wide and dev_trie is None) else 'ref-order'),
+                   'draft_retrieval': (('device' + ('' if not args.unchained_trie else ', unchained') + ('' if dev_trie.put_vocab else ', host patches')) if dev_trie is not None else 'host'),
                    'device_trie_stats': dev_trie.stats if dev_trie is not None else None,
                    'mean_accept_len': round(mean_acc, 3), 'mean_draft_len': round(mean_T, 2),
                    'verify_steps_per_sec': round(K * world / elapsed, 2), 'context_at_end': ctx_end_timed,
@@ -779,7 +905,17 @@ def main():
     }
     if secondary is not None:
         out['secondary'] = secondary
-    print(json.dumps(out), flush=True)
+    # the full record first (not the last line), then the compact contract line the driver parses and whose tail it keeps
+    detail = json.dumps(out)
+    print('BENCH_DETAIL ' + detail, flush=True)
+    try:
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        tag = '%s_b%d_n%d%s' % (args.model, B, world, '_dev' if dev_trie is not None else '')
+        with open(os.path.join(ROOT, 'gpurun_out', 'bench_detail_%s.json' % tag), 'w') as f:
+            f.write(detail + '\n')
+    except OSError:
+        pass
+    print(json.dumps(compact_record(out)), flush=True)
 
 
 if __name__ == '__main__':

@@ -18,8 +18,7 @@ sys.dont_write_bytecode = True
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle.gen_golden_model import OUT, import_reference  # noqa: E402
-from tests.tiny_model import TINY_GQA, TINY_MOE, moe_weights  # noqa: E402
-from tests.gpu_utils import random_tree  # noqa: E402
+from oracle.tiny import TINY_GQA, TINY_MOE, moe_weights, random_tree  # noqa: E402  (build-free: no product import)
 
 
 def build(kind, cfgd, dtype):

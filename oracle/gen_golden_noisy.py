@@ -27,7 +27,7 @@ sys.dont_write_bytecode = True
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import gen_golden_model as gm            # noqa: E402
-from tests.tiny_model import TINY, noisy_copies, tiny_decisive_weights      # noqa: E402
+from oracle.tiny import TINY, noisy_copies, tiny_decisive_weights      # noqa: E402  (build-free: no product import)
 
 OUT = os.path.join(ROOT, 'tests', 'golden')
 MAX_NEW, RHO, COPIES, BL, DL = 120, 0.3, 8, 12, 64

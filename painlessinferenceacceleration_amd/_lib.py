@@ -239,27 +239,34 @@ def loaded_libs():
     return [d for d in (lib, _lib_f16) if d is not None]
 
 
+def _set_everywhere(fn, getter, key, value):
+    """One knob on EVERY loaded build, all or nothing: a build that refuses the value must not leave the builds before it on the new value
+    (bf16 and fp16 engines of one process would then run different kernels).  The libraries already set are rolled back to the value they
+    reported before (la_lab_get; la_debug_set has no getter: its only key is replayed from the recorded value, default 0)."""
+    key, value = int(key), int(value)
+    done = []
+    for d in loaded_libs():
+        before = getattr(d, getter)(key) if getter else _knobs.get((fn, key), 0)
+        r = getattr(d, fn)(key, value)
+        if r != LA_OK:
+            for dd, old in done:
+                getattr(dd, fn)(key, int(old))
+            return r
+        done.append((d, before))
+    _knobs[(fn, key)] = value
+    return LA_OK
+
+
 def lab_set(key, value):
     """la_lab_set on EVERY loaded build (each .so has its own knob globals and graph epoch) and on builds loaded later — a knob
-    set before an fp16 engine exists must not be silently ignored by it.  -> the status of the first library that refuses."""
-    rc = LA_OK
-    for d in loaded_libs():
-        r = d.la_lab_set(int(key), int(value))
-        rc = r if (rc == LA_OK and r != LA_OK) else rc
-    if rc == LA_OK:
-        _knobs[('la_lab_set', int(key))] = int(value)
-    return rc
+    set before an fp16 engine exists must not be silently ignored by it.  All or nothing: -> the status of the library that refused
+    (the others are rolled back)."""
+    return _set_everywhere('la_lab_set', 'la_lab_get', key, value)
 
 
 def debug_set(key, value):
     """la_debug_set (the product header's depth probe) on every loaded build, replayed like lab_set"""
-    rc = LA_OK
-    for d in loaded_libs():
-        r = d.la_debug_set(int(key), int(value))
-        rc = r if (rc == LA_OK and r != LA_OK) else rc
-    if rc == LA_OK:
-        _knobs[('la_debug_set', int(key))] = int(value)
-    return rc
+    return _set_everywhere('la_debug_set', None, key, value)
 
 
 def lab_get(key, dtype=None):
@@ -279,7 +286,9 @@ def lib_for(dtype):
         if _lib_f16 is None:
             dll = _bind(_load(LIB_PATH_F16), LIB_PATH_F16, LA_DTYPE_F16)
             for (fn, key), value in _knobs.items():          # knobs set while only the bf16 build was loaded
-                getattr(dll, fn)(key, value)
+                rc = getattr(dll, fn)(key, value)
+                if rc != LA_OK:                                # a knob the bf16 build runs under must not be dropped silently by this one
+                    raise LookaheadHipError(f'{LIB_PATH_F16}: {fn}({key}, {value}) replayed from the bf16 build was refused (status {rc})')
             _lib_f16 = dll
         return _lib_f16
     raise ValueError(f'no liblookahead_hip build for dtype {dtype}: bfloat16 and float16 exist')

@@ -917,10 +917,18 @@ extern "C" int la_llama_step(la_llama* m, void* stream, const int32_t* host_in, 
         // the OTHER form too, now (first call = set-up / prefill time) rather than on the first step that crosses attn_thr: capture +
         // instantiate of the whole model is a multi-ms stall that would otherwise land inside a decode loop (and inside
         // la_lookahead_decode).  Only when the cache can reach the other side of the threshold at all.
+        // The speculative capture is an optimisation, never a condition of THIS step: a failure is dropped (the form is captured lazily by the
+        // step that first needs it, which then reports its own error), and a recapture in the middle of a sequence (a lab knob / epoch change)
+        // takes the other form only when the context is within two steps' worth of rows of the threshold.
         const bool other_reachable = long_ctx ? true : (m->cfg.max_keys > m->attn_thr);
-        if (other_reachable && !(long_ctx ? m->graph_ready : m->graph_long_ready)) {
-            rc = build_graph(m, st, false, host_in, host_out, 0, !long_ctx);
-            if (rc != LA_OK) return rc;
+        const int dist_thr = host_in[LA_IN_NKEYS_HINT] + LA_TREE_MAX - m->attn_thr;
+        const bool mid_sequence = host_in[LA_IN_NKEYS_HINT] > 0 && m->seq_expected > 0;
+        const bool worth_it = !mid_sequence || (dist_thr > -2 * LA_TREE_MAX && dist_thr < 2 * LA_TREE_MAX);
+        if (other_reachable && worth_it && !(long_ctx ? m->graph_ready : m->graph_long_ready)) {
+            if (build_graph(m, st, false, host_in, host_out, 0, !long_ctx) != LA_OK) {
+                (void)hipGetLastError();                 // clear the sticky error of the failed capture; the required graph is ready
+                la_set_error("");
+            }
         }
     }
     m->seq_expected += 1;

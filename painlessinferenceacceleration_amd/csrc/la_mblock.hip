@@ -2519,6 +2519,10 @@ int lk_mb_cand_slots(int n_wg) { return n_wg * 4; }
 
 template <int RBV, int EPI>
 static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int nblk) {
+    // mb_k_range cuts an even K16 on even k-tiles: with fewer than two k-tiles per split a split would be EMPTY (t0 == t1), which only the
+    // fat launches guard against — k_gemm_wide's DMA clamp (t1 - 1) would read below its range.  No engine shape gets here (resolve_cfg keeps
+    // >= 4 k-tiles per split); refuse instead of computing garbage.
+    if (ksplit < 1 || (ksplit > 1 && a.K16 < 2 * ksplit)) return -1;
     if (a.nblk_dev) {
         // gathered expert: the block count is a device value (typically 1-2 of the step's nblk): passes of two blocks, a pass
         // past the expert's count returns before it touches the weights
@@ -2528,8 +2532,10 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                 // expert stages the expert's whole x through LDS: 0.5-1.8 MB from L2 per 0.9 MB of weights from HBM, and the per-CU times of
                 // the two ADD (T = W / 25 GB/s + x / 130 GB/s) — the gap between these launches (4.6-5.2 TB/s of weights) and the
                 // dense 64-row kernels (5.9).  With two regions per workgroup the x traffic and the LDS reads per weight byte halve: the 8 waves
-                // are 2 RBV row-blocks x 4 / RBV K parts (gate/up: one row-block per wave over the whole K range).  Same MFMA chain per output
-                // element and the same fixed summation order of the K parts: bit-identical slabs / activations.
+                // are 2 RBV row-blocks x 4 / RBV K parts (gate/up: one row-block per wave over the whole K range; down: 2 K parts instead of 4).
+                // FEWER K parts = ANOTHER fp32 summation order than the one-region launch: results agree to tolerance, not bitwise
+                // (include/lookahead_hip_lab.h key 25; tests/test_gpu_mblock.py::test_merged_expert_launch_forms_agree asserts 1e-2) —
+                // so Mixtral's default numerics moved by that much when this form became the default in round 5.
                 MbArgs p = a;
                 if (p.planned) {
                     for (int i = 0; i < 4; ++i) { p.boff[4 + i] = a.wg_chunks + a.boff[i]; p.nv[4 + i] = a.nv[i]; p.nvl[4 + i] = a.nvl[i]; }

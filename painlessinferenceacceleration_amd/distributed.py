@@ -25,6 +25,9 @@ DONE bit rides in the count word) and flush all B sequences in batch-index order
 the same four calls from its timed loop.
 """
 import ctypes as C
+import datetime
+import os
+import time
 
 import numpy as np
 import torch
@@ -40,12 +43,23 @@ def slot_words(branch_length):
 
 
 DONE_BIT = 1 << 30          # count word: this rank has finished all its sequences (it keeps contributing empty lists)
+FAILED_BIT = 1 << 29        # count word: this rank's request FAILED (it is draining like a finished rank; the others learn which rank it was)
+
+
+class GatherTimeout(RuntimeError):
+    """A per-step collective did not complete within the gather's timeout: a peer is gone.  The gather is marked broken — no
+    further collective is attempted, the loops flush their local trie state and re-raise."""
 
 
 class AcceptedTokenGather(object):
-    def __init__(self, device, group=None, b_loc=1, branch_length=12, native=None, mode='split-phase'):
+    def __init__(self, device, group=None, b_loc=1, branch_length=12, native=None, mode='split-phase', timeout_s=None):
         assert mode in ('strict', 'split-phase')
         self.mode = mode
+        # every wait on a collective is bounded (a rank that died mid-request must not park the others forever in drain())
+        self.timeout_s = float(timeout_s if timeout_s is not None else os.environ.get('LA_GATHER_TIMEOUT_S', '300'))
+        self.broken = False                                # a collective timed out / failed: no further collective is attempted
+        self.failed_ranks = []                             # ranks whose FAILED bit was seen during this request
+        self.stats = {'collectives': 0, 'wait_s': 0.0, 'wait_s_max': 0.0}     # host time spent waiting for collectives (finish())
         self.branch_length = int(branch_length)
         self.all_done = False                              # every rank's DONE bit was set in the last collected gather
         self._pending = False
@@ -150,15 +164,16 @@ class AcceptedTokenGather(object):
         assert len(tokens) == self.b_loc, f'{len(tokens)} token lists for b_loc={self.b_loc}'
         return [list(t) for t in tokens]
 
-    def _pack(self, lists, done=False):
+    def _pack(self, lists, done=False, failed=False):
         buf = self._stage
-        buf.zero_()
-        v = buf.view(self.b_loc, self.slot)
-        for i, t in enumerate(lists):
+        for t in lists:                        # validated BEFORE anything is staged: a refusal leaves no half-written message behind
             if len(t) > self.max_tokens:
                 raise ValueError(f'{len(t)} accepted tokens do not fit the {self.slot}-word gather slot; construct '
                                  f'AcceptedTokenGather with branch_length >= {len(t) - 1}')
-            v[i, 0] = len(t) | (DONE_BIT if done else 0)
+        buf.zero_()
+        v = buf.view(self.b_loc, self.slot)
+        for i, t in enumerate(lists):
+            v[i, 0] = len(t) | (DONE_BIT if done else 0) | (FAILED_BIT if failed else 0)
             if t:
                 v[i, 1:1 + len(t)] = torch.tensor(t, dtype=torch.int32)
         return buf
@@ -167,31 +182,37 @@ class AcceptedTokenGather(object):
         """-> token lists in GLOBAL batch-index order b = i * world + r (and self.all_done: every rank flagged DONE)."""
         allv = host.view(self.world, self.b_loc, self.slot)
         self.all_done = all((int(allv[r, 0, 0]) & DONE_BIT) != 0 for r in range(self.world))
-        return [allv[r, i, 1:1 + (int(allv[r, i, 0]) & (DONE_BIT - 1))].tolist() for i in range(self.b_loc) for r in range(self.world)]
+        for r in range(self.world):
+            if (int(allv[r, 0, 0]) & FAILED_BIT) and r not in self.failed_ranks:
+                self.failed_ranks.append(r)
+        return [allv[r, i, 1:1 + (int(allv[r, i, 0]) & (FAILED_BIT - 1))].tolist() for i in range(self.b_loc) for r in range(self.world)]
 
     def global_index(self, i):
         """global batch index of this rank's i-th sequence"""
         return i * self.world + self.rank
 
     # ---- strict (blocking) form -------------------------------------------------------------------------------------------
-    def gather(self, tokens, done=False):
+    def gather(self, tokens, done=False, failed=False):
         """tokens: this rank's accepted tokens of the step (b_loc lists; a flat list when b_loc == 1)
         -> token lists of all B sequences in global batch-index order."""
-        self.begin(tokens, done=done)
+        self.begin(tokens, done=done, failed=failed)
         return self.finish()
 
     # ---- split-phase form: the gather of step k overlaps the verify step k+1 ---------------------------------------------
-    def begin(self, tokens, done=False):
+    def begin(self, tokens, done=False, failed=False):
         """Start the all-gather of this rank's accepted tokens (asynchronous; one outstanding gather at a time).  done: this rank
         has no live sequence left (it keeps calling with empty lists until all_done, see drain())."""
         assert self._work is None, 'one outstanding gather at a time'
+        if self.broken:
+            raise GatherTimeout('the accepted-token gather is broken (an earlier collective timed out)')
         lists = self._lists(tokens)
-        self._mine = lists
         if self.local_only:
+            self._mine = lists
             self._work = True
             self._mine_done = bool(done)
             return
-        self._pack(lists, done)
+        self._pack(lists, done, failed)        # raises before any state changes when a list does not fit its slot
+        self._mine = lists
         if self._comm:
             with torch.cuda.stream(self._stream):
                 self._in.copy_(self._stage, non_blocking=True)
@@ -211,11 +232,29 @@ class AcceptedTokenGather(object):
         if self.local_only:
             self.all_done = self._mine_done
             return self._mine
-        if self._comm:
-            self._done.synchronize()
-        else:
-            work.wait()
-            self._host.copy_(self._out)
+        t0 = time.perf_counter()
+        try:
+            if self._comm:
+                deadline = t0 + self.timeout_s
+                while not self._done.query():              # bounded wait: a dead peer must not hang this rank
+                    if time.perf_counter() > deadline:
+                        raise GatherTimeout(f'la_gather_accepted did not complete within {self.timeout_s:.0f} s')
+                    time.sleep(0) if time.perf_counter() - t0 < 1e-3 else time.sleep(2e-4)
+            else:
+                ok = work.wait(datetime.timedelta(seconds=self.timeout_s))
+                if ok is False:
+                    raise GatherTimeout(f'all_gather_into_tensor did not complete within {self.timeout_s:.0f} s')
+                self._host.copy_(self._out)
+        except Exception as e:
+            self.broken = True
+            self._pending = False
+            if isinstance(e, GatherTimeout):
+                raise
+            raise GatherTimeout(f'accepted-token gather failed: {e!r}') from e
+        dt = time.perf_counter() - t0
+        self.stats['collectives'] += 1
+        self.stats['wait_s'] += dt
+        self.stats['wait_s_max'] = max(self.stats['wait_s_max'], dt)
         return self._unpack(self._host)
 
     def finish_into_trie(self, cache, branch_length, final=False):
@@ -224,9 +263,9 @@ class AcceptedTokenGather(object):
             cache.stream_put(toks, branch_length=branch_length + 1, final=final, mode='output', idx=b)
         return per_seq
 
-    def update_trie(self, cache, tokens, branch_length, final=False, done=False):
+    def update_trie(self, cache, tokens, branch_length, final=False, done=False, failed=False):
         """strict mode: all-gather + stream_put for every sequence (idx = global batch index) in batch-index order."""
-        per_seq = self.gather(tokens, done=done)
+        per_seq = self.gather(tokens, done=done, failed=failed)
         for b, toks in enumerate(per_seq):
             cache.stream_put(toks, branch_length=branch_length + 1, final=final, mode='output', idx=b)
         return per_seq
@@ -235,6 +274,46 @@ class AcceptedTokenGather(object):
     @property
     def n_sequences(self):
         return self.world * self.b_loc
+
+    def begin_request(self):
+        """Start of a request (both decoding loops call it before anything else): a gather object that is reused must not carry the
+        previous request's state into this one — an un-collected split-phase gather, a stale all_done, the failed-rank list."""
+        if self.broken:
+            raise GatherTimeout('the accepted-token gather is broken (an earlier collective timed out): build a new one')
+        if self._work is not None:             # a gather nobody collected (the previous request ended abnormally): collect and drop it
+            try:
+                self.finish()
+            except GatherTimeout:
+                raise
+        self._pending = False
+        self.all_done = False
+        self.failed_ranks = []
+        self.stats = {'collectives': 0, 'wait_s': 0.0, 'wait_s_max': 0.0}
+
+    def abort_request(self, cache, branch_length=None):
+        """The failure path of a sharded request (called from the loops' exception handlers, then the exception is re-raised): this
+        rank stops decoding but keeps its side of the protocol — it flags DONE | FAILED with empty contributions, keeps serving the
+        per-step collective until every rank has finished (drain), and runs the final flush for all B sequences — so the other ranks
+        finish their sequences normally, every replica ends the request in the same state, and nobody waits for a rank that left.
+        If the collective itself is what failed (timeout: a peer is gone) only the local flush runs."""
+        bl = self.branch_length if branch_length is None else branch_length
+        try:
+            if not self.broken:
+                if self._pending or self._work is not None:
+                    self._pending = False
+                    if self._work is not None:
+                        self.finish_into_trie(cache, bl)
+                if not self.all_done:
+                    empty = [[] for _ in range(self.b_loc)] if self.b_loc > 1 else []
+                    self.update_trie(cache, empty, bl, done=True, failed=True)
+                    while not self.all_done:
+                        self.update_trie(cache, empty, bl, done=True, failed=True)
+        except GatherTimeout:
+            pass
+        finally:
+            self._pending = False
+            self._work = None
+            self.flush(cache, bl)
 
     def exchange_prompts(self, local_prompts):
         """Once per request, off the hot path: every rank's prompt token lists -> all B lists in global batch-index order, so that

@@ -238,6 +238,8 @@ class LookaheadPreTrainedModel(object):
             assert not decoding_kwargs.get('device_trie', False), 'sharded decoding keeps the trie replicas on the host'
         tidx = gather.global_index(0) if gather is not None else 0
         decoding_kwargs['_trie_idx'] = tidx
+        if gather is not None:
+            gather.begin_request()         # no state of an earlier request (un-collected gather, all_done) leaks into this one
         if gather is not None:            # every replica holds every sequence's input frequencies, put in batch-index order
             for b_, p_ in enumerate(gather.exchange_prompts([seq[1:]])):
                 self.lookahead_cache.put(p_, branch_length=branch_length + 1, mode='input', idx=b_)
@@ -368,7 +370,13 @@ class LookaheadPreTrainedModel(object):
             # an exception mid-generation must not leave this request's stream buffer / input frequencies behind (they would
             # mix into the next request); the reference flushes on the normal path only (pretrained_model.py:1236-1239)
             if not flushed:
-                self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=tidx)
+                if gather is not None:
+                    # sharded request: this rank failed (or was interrupted) mid-request — it must still serve the per-step collective
+                    # until every rank has finished, and flush ALL B sequences, or the other ranks would block in drain() / finish() and
+                    # this replica would keep un-flushed stream buffers of the other sequences (AcceptedTokenGather.abort_request)
+                    gather.abort_request(self.lookahead_cache, branch_length)
+                else:
+                    self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=tidx)
         if streamer is not None:
             streamer.end()
         sequences = torch.tensor([seq], dtype=torch.long, device=out_device)

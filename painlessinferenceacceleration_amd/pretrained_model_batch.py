@@ -200,6 +200,7 @@ class LookaheadPreTrainedModel(object):
                 deferred_put[0] = None
 
         if gather is not None:            # every replica holds every sequence's input frequencies, put in batch-index order
+            gather.begin_request()        # no state of an earlier request (un-collected gather, all_done, failed ranks) leaks into this one
             for b_, p_ in enumerate(gather.exchange_prompts([ids0[i, 1:-1].tolist() for i in range(bs)])):
                 self.lookahead_cache.put(p_, branch_length=branch_length + 1, mode='input', idx=b_)
         else:
@@ -209,216 +210,232 @@ class LookaheadPreTrainedModel(object):
         finished_rows = [None] * bs
         batch_indices = list(range(bs))
         eos_set = set(eos_token_id) if eos_token_id is not None else set()
-        ts = time.time()
-        eng.reset_slot(-1)
-        # prefill: valid prompt tokens of every sample, packed into shared 64-row chain blocks
-        prompts = {i: ids0[i][am[i] == 1].tolist() for i in range(bs)}
-        multi = bool(getattr(eng, 'max_blocks', 0))
-        do_sample = bool(decoding_kwargs.get('do_sample', False))
+        try:
+            ts = time.time()
+            eng.reset_slot(-1)
+            # prefill: valid prompt tokens of every sample, packed into shared 64-row chain blocks
+            prompts = {i: ids0[i][am[i] == 1].tolist() for i in range(bs)}
+            multi = bool(getattr(eng, 'max_blocks', 0))
+            do_sample = bool(decoding_kwargs.get('do_sample', False))
 
-        def pick(ctx_ids, row):
-            """next token from one logits row through the processor list (pretrained_model_batch.py:840-846)"""
-            scores = row[None]
-            if logits_processor is not None and len(logits_processor) > 0:
-                ctx = torch.tensor([ctx_ids], dtype=torch.long, device=eng.device)
-                scores = logits_processor(ctx, scores.clone())
-            if do_sample:
-                return int(torch.multinomial(torch.softmax(scores.float(), dim=-1), num_samples=1)[0, 0])
-            return int(torch.argmax(scores, dim=-1)[0])
+            def pick(ctx_ids, row):
+                """next token from one logits row through the processor list (pretrained_model_batch.py:840-846)"""
+                scores = row[None]
+                if logits_processor is not None and len(logits_processor) > 0:
+                    ctx = torch.tensor([ctx_ids], dtype=torch.long, device=eng.device)
+                    scores = logits_processor(ctx, scores.clone())
+                if do_sample:
+                    return int(torch.multinomial(torch.softmax(scores.float(), dim=-1), num_samples=1)[0, 0])
+                return int(torch.argmax(scores, dim=-1)[0])
 
-        if sequential:
-            # prompts one slot after the other: the last prompt row's logits stay readable for the processor call of :783
-            # (batch-wise there; the processors are row-wise, so one padded row at a time is the same call)
-            first = {}
-            for i in range(bs):
-                n = len(prompts[i])
-                if multi:
-                    eng.mprefill(i, prompts[i])
-                    last = (n - 1) % (64 * eng.max_blocks)
-                    first[i] = pick(ids0[i].tolist(), eng.mlogits()[last])
-                else:
-                    eng.bprefill(i, prompts[i])
-                    first[i] = pick(ids0[i].tolist(), eng.logits()[(n - 1) % 64])
-        else:
-            first = eng.mprefill_many(prompts) if multi else eng.bprefill_many(prompts)
-        next_token_list = [[first[i]] for i in range(bs)]
-        dmode = decoding_kwargs.get('decoding_mode', 'hier')
-        chained = bool(decoding_kwargs.get('device_trie', False)) and multi and not sequential and streamer is None and \
-            bool(decoding_kwargs.get('per_sample_budget', False)) and dmode.split('_')[0] in ('hier', 'one') and \
-            not decoding_kwargs.get('debug_lookahead', False)
-        # device_trie_update (default on with the chained device trie): the trie UPDATE of every step runs on the device as well
-        dev_put = chained and bool(decoding_kwargs.get('device_trie_update', True)) and branch_length + 1 <= 64
-        put_on_device, buffers_loaded = False, False
-        replay_due, full_image_due, replay_calls = None, False, 1      # puts of the last chained step the host trie has not repeated yet
-        decoding_kwargs['dls'].extend([1] * bs)
-        decoding_kwargs['edls'].extend([1] * bs)
-        max_cur = 0
-        while True:
-            for k, b in enumerate(batch_indices):
-                rows[b].extend(next_token_list[k])
-            if streamer is not None:
-                streamer.put(np.array(next_token_list[0]))
-            if put_on_device:
-                # the device inserted these tokens into its trie image itself, straight from the step's output block
-                # (la_trie_stream_put_dev behind the verify pass): the host trie repeats the same puts in the same order and
-                # drops the words it logged for them — nothing of the update crosses PCIe.  Round 4: the replay is deferred until
-                # the NEXT step's kernels are queued (the device image needs nothing from the host), so it overlaps the GPU step
-                replay_due = [(b, next_token_list[k]) for k, b in enumerate(batch_indices)]
-                put_on_device = False
-            elif gather is None:                                                # :1254-1259, one native call for the batch
-                puts = [(b, [x for x in next_token_list[k] if x != -1]) for k, b in enumerate(batch_indices)]
-                if overlap_put:
-                    run_deferred_put()                                          # (a step that found no overlap point)
-                    deferred_put[0] = puts
-                else:
-                    self.lookahead_cache.stream_put_many(puts, branch_length=branch_length + 1, final=False)
-            max_cur = max(max_cur, max(len(rows[b]) - 1 for b in batch_indices))
-            keep = []
-            for k, b in enumerate(batch_indices):                               # :1269-1276 + _early_stop :937-980
-                if len(rows[b]) >= stop_max_length or any(t in eos_set for t in next_token_list[k]) or \
-                        (custom_stop is not None and custom_stop(rows[b], out_device)):                # :1284
-                    finished_rows[b] = list(rows[b])
-                else:
-                    keep.append(b)
-            if gather is not None:
-                # one collective per loop iteration on every rank: this rank's lists in local row order ([] for retired rows), DONE once
-                # no row is left; strict = gathered and applied now, split-phase = applied under the next verify pass (overlap below)
-                mine = [[] for _ in range(bs)]
-                for k, b in enumerate(batch_indices):
-                    mine[b] = [x for x in next_token_list[k] if x != -1]
-                gather.step_update(self.lookahead_cache, mine, branch_length, done=not keep)
-            batch_indices = keep
-            te = time.time()
-            decoding_kwargs['fts'].append(te - ts)
-            ts = te
-            if not batch_indices:
-                break
-            if chained:
-                dt0 = self._device_trie(decoding_kwargs['_n_samples'], dev_put)
-                if replay_due is not None and (len(batch_indices) > eng.max_blocks or full_image_due):
-                    # several engine passes per step, or the host image outgrew the device's: replay first, then a synced query
-                    dt0.replay(replay_due, branch_length + 1, calls=replay_calls)
-                    replay_due, full_image_due = None, False
-                # device trie chained in front of the verify pass (la_llama_mstep_trie): ONE query launch for all active samples on the
-                # engine's stream, the step input assembled on the device from its outputs, one 64-row block per sample — no draft
-                # crosses PCIe in either direction; the host reads back the accepted tokens and the draft lengths only.  Same budget
-                # rule as the host path with per_sample_budget (lookahead_cache.py:534-541).
-                ts_q = time.time()
-                qids = [rows[b][-2:] for b in batch_indices]
-                per = min(decoding_length, _lib.LA_TREE_MAX)
-                dm = decoding_kwargs.get('decoding_mode', 'hier')
-                mode_q = (dm if '_' in dm else dm + '_mix').split('_')[1]
-                dt = self._device_trie(decoding_kwargs['_n_samples'], dev_put)
-                with torch.cuda.stream(eng.stream):
-                    if dm.split('_')[0] == 'one':
-                        dt.one_get_dev(qids, idxs=batch_indices, decoding_length=per, branch_length=branch_length, mode=mode_q,
-                                       sync=replay_due is None)
+            if sequential:
+                # prompts one slot after the other: the last prompt row's logits stay readable for the processor call of :783
+                # (batch-wise there; the processors are row-wise, so one padded row at a time is the same call)
+                first = {}
+                for i in range(bs):
+                    n = len(prompts[i])
+                    if multi:
+                        eng.mprefill(i, prompts[i])
+                        last = (n - 1) % (64 * eng.max_blocks)
+                        first[i] = pick(ids0[i].tolist(), eng.mlogits()[last])
                     else:
-                        dt.hier_get_dev(qids, idxs=batch_indices, decoding_length=per, branch_length=branch_length, min_input_size=0,
-                                        min_output_size=max(per // 2, 1), mode=mode_q, sync=replay_due is None)
-                    if dev_put and not buffers_loaded:
-                        dt.load_stream_buffers()        # the hold-back buffers as the host's stream_put calls left them
-                        buffers_loaded = True
-                    emitted, widths = {}, []
-                    for g0 in range(0, len(batch_indices), eng.max_blocks):
-                        grp = batch_indices[g0:g0 + eng.max_blocks]
-                        eng.mstep_trie_async(dt, g0, grp, [stop_max_length - (len(rows[b]) - 1) - 1 for b in grp],
-                                             [rows[b][-1] for b in grp], put_idxs=grp if dev_put else None,
-                                             put_branch_length=branch_length + 1)
-                        if replay_due is not None:         # the previous step's update, on the host trie, while the GPU verifies
-                            full_image_due = not dt.replay(replay_due, branch_length + 1, calls=replay_calls)
-                            replay_due = None
-                        toks, Ts = eng.mstep_trie_finish()
-                        for b, tk in zip(grp, toks):
-                            emitted[b] = tk
-                        widths.extend(Ts)
-                    put_on_device = dev_put
-                    replay_calls = (len(batch_indices) + eng.max_blocks - 1) // eng.max_blocks       # stream_put_dev calls of this step
-                decoding_kwargs['qts'].append(time.time() - ts_q)
-                decoding_kwargs.update({'decoding_qids': qids, 'decoding_ids': None, 'hit_sizes': None, 'batch_indices': batch_indices})
-                width = max(widths)
+                        eng.bprefill(i, prompts[i])
+                        first[i] = pick(ids0[i].tolist(), eng.logits()[(n - 1) % 64])
+            else:
+                first = eng.mprefill_many(prompts) if multi else eng.bprefill_many(prompts)
+            next_token_list = [[first[i]] for i in range(bs)]
+            dmode = decoding_kwargs.get('decoding_mode', 'hier')
+            chained = bool(decoding_kwargs.get('device_trie', False)) and multi and not sequential and streamer is None and \
+                bool(decoding_kwargs.get('per_sample_budget', False)) and dmode.split('_')[0] in ('hier', 'one') and \
+                not decoding_kwargs.get('debug_lookahead', False)
+            # device_trie_update (default on with the chained device trie): the trie UPDATE of every step runs on the device as well
+            dev_put = chained and bool(decoding_kwargs.get('device_trie_update', True)) and branch_length + 1 <= 64
+            put_on_device, buffers_loaded = False, False
+            replay_due, full_image_due, replay_calls = None, False, 1      # puts of the last chained step the host trie has not repeated yet
+            decoding_kwargs['dls'].extend([1] * bs)
+            decoding_kwargs['edls'].extend([1] * bs)
+            max_cur = 0
+            while True:
+                for k, b in enumerate(batch_indices):
+                    rows[b].extend(next_token_list[k])
+                if streamer is not None:
+                    streamer.put(np.array(next_token_list[0]))
+                if put_on_device:
+                    # the device inserted these tokens into its trie image itself, straight from the step's output block
+                    # (la_trie_stream_put_dev behind the verify pass): the host trie repeats the same puts in the same order and
+                    # drops the words it logged for them — nothing of the update crosses PCIe.  Round 4: the replay is deferred until
+                    # the NEXT step's kernels are queued (the device image needs nothing from the host), so it overlaps the GPU step
+                    replay_due = [(b, next_token_list[k]) for k, b in enumerate(batch_indices)]
+                    put_on_device = False
+                elif gather is None:                                                # :1254-1259, one native call for the batch
+                    puts = [(b, [x for x in next_token_list[k] if x != -1]) for k, b in enumerate(batch_indices)]
+                    if overlap_put:
+                        run_deferred_put()                                          # (a step that found no overlap point)
+                        deferred_put[0] = puts
+                    else:
+                        self.lookahead_cache.stream_put_many(puts, branch_length=branch_length + 1, final=False)
+                max_cur = max(max_cur, max(len(rows[b]) - 1 for b in batch_indices))
+                keep = []
+                for k, b in enumerate(batch_indices):                               # :1269-1276 + _early_stop :937-980
+                    if len(rows[b]) >= stop_max_length or any(t in eos_set for t in next_token_list[k]) or \
+                            (custom_stop is not None and custom_stop(rows[b], out_device)):                # :1284
+                        finished_rows[b] = list(rows[b])
+                    else:
+                        keep.append(b)
+                if gather is not None:
+                    # one collective per loop iteration on every rank: this rank's lists in local row order ([] for retired rows), DONE once
+                    # no row is left; strict = gathered and applied now, split-phase = applied under the next verify pass (overlap below)
+                    mine = [[] for _ in range(bs)]
+                    for k, b in enumerate(batch_indices):
+                        mine[b] = [x for x in next_token_list[k] if x != -1]
+                    gather.step_update(self.lookahead_cache, mine, branch_length, done=not keep)
+                batch_indices = keep
+                te = time.time()
+                decoding_kwargs['fts'].append(te - ts)
+                ts = te
+                if not batch_indices:
+                    break
+                if chained:
+                    dt0 = self._device_trie(decoding_kwargs['_n_samples'], dev_put)
+                    if replay_due is not None and (len(batch_indices) > eng.max_blocks or full_image_due):
+                        # several engine passes per step, or the host image outgrew the device's: replay first, then a synced query
+                        dt0.replay(replay_due, branch_length + 1, calls=replay_calls)
+                        replay_due, full_image_due = None, False
+                    # device trie chained in front of the verify pass (la_llama_mstep_trie): ONE query launch for all active samples on the
+                    # engine's stream, the step input assembled on the device from its outputs, one 64-row block per sample — no draft
+                    # crosses PCIe in either direction; the host reads back the accepted tokens and the draft lengths only.  Same budget
+                    # rule as the host path with per_sample_budget (lookahead_cache.py:534-541).
+                    ts_q = time.time()
+                    qids = [rows[b][-2:] for b in batch_indices]
+                    per = min(decoding_length, _lib.LA_TREE_MAX)
+                    dm = decoding_kwargs.get('decoding_mode', 'hier')
+                    mode_q = (dm if '_' in dm else dm + '_mix').split('_')[1]
+                    dt = self._device_trie(decoding_kwargs['_n_samples'], dev_put)
+                    with torch.cuda.stream(eng.stream):
+                        if dm.split('_')[0] == 'one':
+                            dt.one_get_dev(qids, idxs=batch_indices, decoding_length=per, branch_length=branch_length, mode=mode_q,
+                                           sync=replay_due is None)
+                        else:
+                            dt.hier_get_dev(qids, idxs=batch_indices, decoding_length=per, branch_length=branch_length, min_input_size=0,
+                                            min_output_size=max(per // 2, 1), mode=mode_q, sync=replay_due is None)
+                        if dev_put and not buffers_loaded:
+                            dt.load_stream_buffers()        # the hold-back buffers as the host's stream_put calls left them
+                            buffers_loaded = True
+                        emitted, widths = {}, []
+                        for g0 in range(0, len(batch_indices), eng.max_blocks):
+                            grp = batch_indices[g0:g0 + eng.max_blocks]
+                            eng.mstep_trie_async(dt, g0, grp, [stop_max_length - (len(rows[b]) - 1) - 1 for b in grp],
+                                                 [rows[b][-1] for b in grp], put_idxs=grp if dev_put else None,
+                                                 put_branch_length=branch_length + 1)
+                            if replay_due is not None:         # the previous step's update, on the host trie, while the GPU verifies
+                                full_image_due = not dt.replay(replay_due, branch_length + 1, calls=replay_calls)
+                                replay_due = None
+                            toks, Ts = eng.mstep_trie_finish()
+                            for b, tk in zip(grp, toks):
+                                emitted[b] = tk
+                            widths.extend(Ts)
+                        put_on_device = dev_put
+                        replay_calls = (len(batch_indices) + eng.max_blocks - 1) // eng.max_blocks       # stream_put_dev calls of this step
+                    decoding_kwargs['qts'].append(time.time() - ts_q)
+                    decoding_kwargs.update({'decoding_qids': qids, 'decoding_ids': None, 'hit_sizes': None, 'batch_indices': batch_indices})
+                    width = max(widths)
+                    next_token_list = [emitted[b] for b in batch_indices]
+                    for k in range(len(batch_indices)):
+                        decoding_kwargs['dls'].append(width)
+                        decoding_kwargs['edls'].append(len(next_token_list[k]))
+                    continue
+                drafts = self.lookahead_prepare_inputs_for_generation([rows[b] for b in batch_indices], [gi(b) for b in batch_indices],
+                                                                      decoding_kwargs)
+                segments = []
+                for b, (d_ids, d_rm) in zip(batch_indices, drafts):
+                    if len(d_ids) == 0:
+                        d_ids, d_rm = np.asarray(rows[b][-1:], dtype=np.int32), _ONE
+                    cur = len(rows[b]) - 1
+                    segments.append((b, d_ids, d_rm, 2 if sequential else 0, stop_max_length - cur - 1))
+                if sum(len(sg[1]) for sg in segments) <= _lib.LA_TREE_MAX and all(np.ndim(sg[2]) == 1 for sg in segments):
+                    run_deferred_put()                                     # (bstep has no asynchronous form: same order, no overlap)
+                    if gather is not None:
+                        gather.overlap(self.lookahead_cache, branch_length)
+                    emitted = eng.bstep(segments)                          # the whole batch shares one 64-row block
+                    if sequential:
+                        base, logits = eng.bstep_rows(), eng.logits()
+                        kept = {}
+                        for sg in segments:
+                            emitted[sg[0]], kept[sg[0]] = self._sequential_walk(rows[sg[0]], sg, logits, base[sg[0]], pick)
+                        eng.bcommit(kept)
+                else:
+                    assert multi, 'more than 64 draft rows per step need an engine created with max_blocks > 1'
+                    emitted = {}
+                    # ceil(T / 64) blocks per sample (1 for the usual 64-row trees), as many samples per pass as max_blocks holds
+                    groups, cur_g, cur_b = [], [], 0
+                    for sg in segments:
+                        nb_ = (len(sg[1]) + 63) // 64
+                        assert nb_ <= eng.max_blocks, f'a {len(sg[1])}-row tree needs an engine created with max_blocks >= {nb_}'
+                        if cur_b + nb_ > eng.max_blocks:
+                            groups.append(cur_g)
+                            cur_g, cur_b = [], 0
+                        cur_g.append(sg)
+                        cur_b += nb_
+                    groups.append(cur_g)
+                    for group in groups:
+                        wide_pass = any(len(sg[1]) > 64 or np.ndim(sg[2]) == 2 for sg in group)
+                        if wide_pass or not hasattr(eng, 'mstep_async'):
+                            run_deferred_put()
+                            if gather is not None:
+                                gather.overlap(self.lookahead_cache, branch_length)
+                            out = eng.mstep_trees(group) if wide_pass else eng.mstep(group)
+                        else:
+                            # queue the pass, then do the host work nothing on the device waits for — the deferred trie update / the
+                            # previous step's gather and its puts — while the GPU verifies
+                            eng.mstep_async(group)
+                            run_deferred_put()
+                            if gather is not None:
+                                gather.overlap(self.lookahead_cache, branch_length)
+                            out = eng.mstep_finish()
+                        if sequential:
+                            logits, kept, base = eng.mlogits(), [], 0
+                            for sg in group:
+                                toks, keep_rows = self._sequential_walk(rows[sg[0]], sg, logits, base, pick)
+                                emitted[sg[0]] = toks
+                                kept.append(keep_rows)
+                                base += 64 * ((len(sg[1]) + 63) // 64)
+                            if wide_pass:
+                                eng.mcommit_trees(kept, [len(sg[1]) for sg in group])
+                            else:
+                                eng.mcommit(kept)
+                            continue
+                        for sg, toks in zip(group, out):
+                            emitted[sg[0]] = toks
+                width = max(len(sg[1]) for sg in segments)
                 next_token_list = [emitted[b] for b in batch_indices]
                 for k in range(len(batch_indices)):
                     decoding_kwargs['dls'].append(width)
                     decoding_kwargs['edls'].append(len(next_token_list[k]))
-                continue
-            drafts = self.lookahead_prepare_inputs_for_generation([rows[b] for b in batch_indices], [gi(b) for b in batch_indices],
-                                                                  decoding_kwargs)
-            segments = []
-            for b, (d_ids, d_rm) in zip(batch_indices, drafts):
-                if len(d_ids) == 0:
-                    d_ids, d_rm = np.asarray(rows[b][-1:], dtype=np.int32), _ONE
-                cur = len(rows[b]) - 1
-                segments.append((b, d_ids, d_rm, 2 if sequential else 0, stop_max_length - cur - 1))
-            if sum(len(sg[1]) for sg in segments) <= _lib.LA_TREE_MAX and all(np.ndim(sg[2]) == 1 for sg in segments):
-                run_deferred_put()                                     # (bstep has no asynchronous form: same order, no overlap)
-                if gather is not None:
-                    gather.overlap(self.lookahead_cache, branch_length)
-                emitted = eng.bstep(segments)                          # the whole batch shares one 64-row block
-                if sequential:
-                    base, logits = eng.bstep_rows(), eng.logits()
-                    kept = {}
-                    for sg in segments:
-                        emitted[sg[0]], kept[sg[0]] = self._sequential_walk(rows[sg[0]], sg, logits, base[sg[0]], pick)
-                    eng.bcommit(kept)
+            if replay_due is not None:                                              # the last step's update (the loop ended before another launch)
+                self._device_trie(decoding_kwargs['_n_samples'], dev_put).replay(replay_due, branch_length + 1, calls=replay_calls)
+                replay_due = None
+            run_deferred_put()
+            if gather is not None:
+                gather.drain(self.lookahead_cache, branch_length)                   # until every rank has finished its sequences
+                gather.flush(self.lookahead_cache, branch_length)                   # :1288-1290 for all B sequences, batch-index order
             else:
-                assert multi, 'more than 64 draft rows per step need an engine created with max_blocks > 1'
-                emitted = {}
-                # ceil(T / 64) blocks per sample (1 for the usual 64-row trees), as many samples per pass as max_blocks holds
-                groups, cur_g, cur_b = [], [], 0
-                for sg in segments:
-                    nb_ = (len(sg[1]) + 63) // 64
-                    assert nb_ <= eng.max_blocks, f'a {len(sg[1])}-row tree needs an engine created with max_blocks >= {nb_}'
-                    if cur_b + nb_ > eng.max_blocks:
-                        groups.append(cur_g)
-                        cur_g, cur_b = [], 0
-                    cur_g.append(sg)
-                    cur_b += nb_
-                groups.append(cur_g)
-                for group in groups:
-                    wide_pass = any(len(sg[1]) > 64 or np.ndim(sg[2]) == 2 for sg in group)
-                    if wide_pass or not hasattr(eng, 'mstep_async'):
-                        run_deferred_put()
-                        if gather is not None:
-                            gather.overlap(self.lookahead_cache, branch_length)
-                        out = eng.mstep_trees(group) if wide_pass else eng.mstep(group)
-                    else:
-                        # queue the pass, then do the host work nothing on the device waits for — the deferred trie update / the
-                        # previous step's gather and its puts — while the GPU verifies
-                        eng.mstep_async(group)
-                        run_deferred_put()
-                        if gather is not None:
-                            gather.overlap(self.lookahead_cache, branch_length)
-                        out = eng.mstep_finish()
-                    if sequential:
-                        logits, kept, base = eng.mlogits(), [], 0
-                        for sg in group:
-                            toks, keep_rows = self._sequential_walk(rows[sg[0]], sg, logits, base, pick)
-                            emitted[sg[0]] = toks
-                            kept.append(keep_rows)
-                            base += 64 * ((len(sg[1]) + 63) // 64)
-                        if wide_pass:
-                            eng.mcommit_trees(kept, [len(sg[1]) for sg in group])
-                        else:
-                            eng.mcommit(kept)
-                        continue
-                    for sg, toks in zip(group, out):
-                        emitted[sg[0]] = toks
-            width = max(len(sg[1]) for sg in segments)
-            next_token_list = [emitted[b] for b in batch_indices]
-            for k in range(len(batch_indices)):
-                decoding_kwargs['dls'].append(width)
-                decoding_kwargs['edls'].append(len(next_token_list[k]))
-        if replay_due is not None:                                              # the last step's update (the loop ended before another launch)
-            self._device_trie(decoding_kwargs['_n_samples'], dev_put).replay(replay_due, branch_length + 1, calls=replay_calls)
-            replay_due = None
-        run_deferred_put()
-        if gather is not None:
-            gather.drain(self.lookahead_cache, branch_length)                   # until every rank has finished its sequences
-            gather.flush(self.lookahead_cache, branch_length)                   # :1288-1290 for all B sequences, batch-index order
-        else:
-            for i in range(bs):                                                 # :1288-1290
-                self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=i)
+                for i in range(bs):                                                 # :1288-1290
+                    self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=i)
+        except BaseException:
+            # A failure (or an interrupt) mid-request must not leave the trie with this request's stream buffers / input frequencies, and in a
+            # sharded job must not strand the other ranks: they are (or will be) waiting in the per-step collective.  The failing rank keeps
+            # its side of the protocol — DONE | FAILED contributions until every rank has finished, then the flush of all B sequences
+            # (AcceptedTokenGather.abort_request) — and only then re-raises.
+            try:
+                run_deferred_put()
+            except Exception:       # noqa: BLE001 — the original exception is the one to report
+                pass
+            if gather is not None:
+                gather.abort_request(self.lookahead_cache, branch_length)
+            else:
+                for i in range(bs):
+                    self.lookahead_cache.stream_put([], branch_length=branch_length + 1, final=True, mode='output', idx=i)
+            raise
         if streamer is not None:
             streamer.end()
         seqs = np.full((bs, max_cur + 1), pad, dtype=np.int64)

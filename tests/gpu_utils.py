@@ -6,6 +6,7 @@ import ctypes as C
 import numpy as np
 import torch
 
+from oracle.tiny import random_tree  # noqa: F401  (build-free recipe shared with the golden generators)
 from painlessinferenceacceleration_amd import _lib
 from painlessinferenceacceleration_amd._lib import lib, check
 
@@ -72,21 +73,6 @@ def pack_x(x):
 def rel_err(a, b):
     a, b = a.double(), b.double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
-
-
-def random_tree(rs, T, branch=0.35):
-    """Random DFS-ordered tree of T rows -> (parent list, uint64 row masks)."""
-    parent = [-1]
-    rows = [1]
-    stack = [0]
-    for i in range(1, T):
-        while len(stack) > 1 and rs.rand() < branch:
-            stack.pop()
-        p = stack[-1]
-        parent.append(p)
-        rows.append(rows[p] | (1 << i))
-        stack.append(i)
-    return parent, np.array(rows, dtype=np.uint64)
 
 
 def pack_planned(kind, mats, n_wg):

@@ -158,3 +158,81 @@ def test_host_batch_drafts_equals_per_sample_queries():
             hits += len(g[0]) > 8
     assert hits > 60
     assert bench.host_batch_drafts(cache, [[V + 5, V + 6]], [10], 64, 12, [12])[0][0].tolist() == [V + 6]
+
+
+def test_cpu_baseline_reference_leg_equals_the_port_when_the_reference_is_importable():
+    """`cpu_baseline.kind = "reference"` (oracle/reference_cpu.py): the reference's own lookahead_generation + LookaheadCache + LlamaForCausalLM,
+    imported in place, must emit the tokens and the per-step draft / accept lengths of the port (oracle loop) on the same model, prompt and trie warm-up —
+    the two legs are interchangeable as the reported baseline.  Skipped where /root/reference is absent (the GPU box)."""
+    import pytest
+    import torch
+    from oracle import reference_cpu
+    if not reference_cpu.reference_available():
+        pytest.skip('/root/reference not present')
+    from oracle import llama_oracle as lo
+    from oracle.trie_oracle import TrieOracle
+    from tests.tiny_model import tiny_decisive_weights, tiny_shape
+    s = tiny_shape()
+    sd = tiny_decisive_weights(0, torch.float32)
+    prompt = bench.phrase_prompt(7, 40, s.vocab)
+    model = lo.OracleLlama(s, sd)
+    seq = list(prompt)
+    lg, past = model.forward(torch.tensor(seq), torch.tril(torch.ones((40, 40), dtype=torch.long)), None)
+    for _ in range(60):
+        t = int(lg[-1].float().argmax())
+        seq.append(t)
+        lg, past = model.forward(torch.tensor([t]), torch.ones((1, len(seq)), dtype=torch.long), past)
+    copies = bench.noisy_copies(prompt[-2:] + seq[40:], 6, 0.3, s.vocab, seed=99)
+    ref = reference_cpu.reference_lookahead_loop(s, sd, prompt, copies, 12, 64, verify_steps=4, threads=2, dtype=torch.float32)
+    assert ref['kind'] == 'reference' and ref['verify_steps'] == 4 and ref['value'] > 0 and ref['cores'] == 2
+    cache = TrieOracle(eos_ids=[None])
+    for c in copies:
+        cache.put(c, branch_length=13, mode='output', idx=-1)
+    port = lo.lookahead_generate(model, cache, prompt, len(prompt) + 5 * 13 + 2, eos_token_id=None, decoding_length=64, branch_length=12, max_steps=5)
+    n = len(ref['tokens'])
+    assert n > 4 and port['sequences'][40:40 + n] == ref['tokens'] == seq[40:40 + n]
+    assert ref['mean_accept_len'] == round(sum(port['edls'][1:]) / 4, 3) and ref['mean_draft_len'] == round(sum(port['dls'][1:]) / 4, 2)
+
+
+def test_compact_record_keeps_the_contract_fields_and_fits_the_drivers_captured_tail():
+    """The driver keeps the last 8 KB of stdout: the final JSON line (bench.compact_record) must carry the contract fields, `roofline`,
+    `cpu_baseline` and ALL secondary legs in compact form within that budget; the prose lives once in `notes`, the full record in the
+    BENCH_DETAIL line before it."""
+    import json
+    roof1 = {'bound': 'hbm', 'kernel': 'k_gemm64r<4,EPI_SWIGLU,4,8> (gate/up projection + fused SwiGLU, 32 launches/step)', 'achieved': 4982.4, 'peak': 8000.0, 'unit': 'GB/s',
+             'frac': 0.6228, 'traffic': 190512345, 'traffic_source': 'x' * 300, 'frac_of_achievable': 0.79, 'bytes_per_launch': 182288384, 'ms_per_launch': 0.03658,
+             'timing': 'y' * 400, 'mfma': {'flops_per_launch': 1, 'achieved_TFLOPs': 300.0, 'peak_TFLOPs': 2500.0, 'frac': 0.12},
+             'verify_step': {'algorithmic_bytes': 13567000000, 'ms_graph_step': 3.66, 'achieved_GBps': 3707.0, 'frac': 0.463, 'frac_of_achievable': 0.59,
+                             'floor_model': {'gemm_floor_ms_per_step': 2.9, 'nongemm_ms_per_step': 0.95, 'frac_of_peak_if_nongemm_were_free': 0.58, 'frac_of_peak_at_floor': 0.44, 'model': 'z' * 300},
+                             'ms_eager_step_events': 4.0, 'ms_by_class_events': {'qkv': 0.74, 'o': 0.33, 'gateup': 1.17, 'down': 0.75, 'lm_head': 0.05, 'attn': 0.4, 'other': 0.5},
+                             'all_gemm_GBps_events': 4400.0}}
+    cfg = {'workload': 'Llama-2-7B bf16 bs=1/GPU lookahead verify loop, 64-token draft tree per sequence (hier, decoding_length=64, branch_length=12), synthetic weights, 512-token prompts (notes.workload)',
+           'model': 'Llama-2-7B', 'n_layers': 32, 'n_layers_truncated': False, 'prompt_len': 512, 'rho': 0.3, 'copies': 8, 'parallelism': 'batch-shard x1, 1 sequence(s) per GPU', 'sequences': 1,
+           'kv_cache': 'linear, max_length keys per sequence', 'gather_mode': None, 'gather_transport': None, 'rccl_ranks': 0, 'gather_us_per_step': None, 'slowest_rank_wait_us': None,
+           'trie_update': 'ref-order', 'draft_retrieval': 'host', 'device_trie_stats': None, 'mean_accept_len': 6.45, 'mean_draft_len': 60.1, 'verify_steps_per_sec': 273.0,
+           'context_at_end': 770, 'context_mean_timed': 700.0, 'trie_query_ms_mean': 0.02, 'lookahead_equals_greedy': True, 'plain_greedy_tokens_per_sec': 280.0,
+           'native_loop': {'steps': 16, 'ms_per_step': 3.7, 'accepted_tokens_per_sec': 1700.0, 'equals_greedy': True}, 'idle_window_prefetch_kib': 0,
+           'speed_incl_prefill': {'prefill_ms': 10.9, 'prefill_tokens': 512, 'generated_tokens': 130, 'decode_s': 0.07, 'tokens_per_sec': 1500.0, 'at_256_new_tokens': 1600.0, 'note': 'n' * 200},
+           'fixed_tree_sweep': {'a=%d' % a: {'ms_per_step': 3.7, 'accepted_per_step': a + 1, 'accepted_tokens_per_sec': 500.0, 'accepted_as_designed': True} for a in (0, 3, 6, 12)}}
+    cpu = {'value': 25.2, 'unit': 'tokens/s', 'cores': 16, 'kind': 'port', 'ms_per_step': 262.0, 'dtype': 'bfloat16', 'cpu_model': 'AMD EPYC 9575F 64-Core Processor', 'host_cores': 128,
+           'verify_steps': 5, 'mean_accept_len': 6.6, 'mean_draft_len': 58.0, 'prefill_s': 3.0, 'wall_s': 20.0, 'sample': 's' * 330}
+    legs = []
+    for name, model, dr in (('mistral:8', 'Mistral-7B', 'host'), ('mistral:8:dev', 'Mistral-7B', 'device'), ('13b:4', 'Llama-2-13B', 'host'), ('mixtral:4', 'Mixtral-8x7B', 'host'), ('13b:1', 'Llama-2-13B', 'host'),
+                            ('7b:16', 'Llama-2-7B', 'host')):
+        leg_full = {'metric': 'accepted_tokens_per_sec', 'value': 5400.12, 'unit': 'tokens/s', 'n_gpus': 1, 'steps': 24, 'warmup': 4, 'ms_per_step': 9.6234,
+                    'config': dict(cfg, model=model, sequences=8, draft_retrieval=dr, trie_update='deferred'),
+                    'roofline': {'bound': 'mfma', 'kernel': 'k' * 120, 'achieved': 776.1, 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': 0.3104, 'traffic': 28400000000, 'traffic_note': 't' * 150,
+                                 'hbm': {'algorithmic_bytes': 14970000000, 'achieved_GBps': 1555.0, 'frac': 0.194}, 'mfma': {'flops': 7.46e12, 'achieved_TFLOPs': 776.1, 'frac': 0.3104}}}
+        legs.append(bench.compact_leg(bench.compact_record(dict(leg_full, higher_is_better=True, scaling='weak', vs_baseline=None, dtype='bf16', data='synthetic', cpu_baseline=None)), name, 12.3))
+    out = {'metric': 'accepted_tokens_per_sec', 'value': 1762.5, 'unit': 'tokens/s', 'n_gpus': 1, 'steps': 20, 'warmup': 5, 'ms_per_step': 3.6596, 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic', 'config': cfg, 'roofline': roof1, 'cpu_baseline': cpu, 'secondary': legs}
+    comp = bench.compact_record(out)
+    line = json.dumps(comp)
+    assert len(line) < 8000, len(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in comp
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(comp['roofline']) and comp['roofline']['verify_step']['frac'] == 0.463
+    assert {'value', 'unit', 'cores', 'kind', 'sample'} <= set(comp['cpu_baseline'])
+    assert len(comp['secondary']) == 6 and all(leg['traffic_ratio'] == round(28400000000 / 14970000000, 3) and leg['equals_greedy'] is True for leg in comp['secondary'])
+    assert [leg['draft_retrieval'] for leg in comp['secondary'][:2]] == ['host', 'device'] and comp['secondary'][0]['model'] == 'Mistral-7B'
+    assert comp['config']['workload'].startswith('Llama-2-7B') and 'workload' in comp['notes']

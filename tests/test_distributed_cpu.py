@@ -306,3 +306,91 @@ def test_lookahead_generation_sharded_over_two_ranks(b_loc, mode):
         ref.stream_put([], branch_length=13, final=True, mode='output', idx=b)
     assert ref.stats()['n_nodes'] == outs[0][4]['n_nodes']
     assert _queries(ref, B, shape.vocab) == outs[0][3]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Failure path of a sharded request (round 6, advisor finding): one rank raises mid-request.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _worker_sharded_failure(rank, world, port, b_loc, mode, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from painlessinferenceacceleration_amd.distributed import AcceptedTokenGather
+    shape, prompts, truths, M, P, n_new = _sharded_setup(world, b_loc)
+    m = M()
+    _warm(m.lookahead_cache, prompts, truths, shape.vocab)
+    g = AcceptedTokenGather('cpu', b_loc=b_loc, branch_length=12, mode=mode, timeout_s=120)
+    mine = [g.global_index(i) for i in range(b_loc)]
+    dk = {'use_lookahead': True, 'decoding_mode': 'hier', 'decoding_length': 64, 'branch_length': 12, 'max_query_length': 2,
+          'stop_words': {}, 'gather': g}
+    if b_loc > 1:
+        dk['per_sample_budget'] = True
+    calls = {'n': 0}
+    if rank == 1:                                   # rank 1's engine fails on its third verify step
+        eng = m.engine
+        name = 'step' if b_loc == 1 else 'mstep'
+        if b_loc > 1 and hasattr(eng, 'mstep_async'):
+            name = 'mstep_async'
+        inner = getattr(eng, name)
+
+        def failing(*a, **kw):
+            calls['n'] += 1
+            if calls['n'] == 3:
+                raise RuntimeError('simulated engine failure on rank 1')
+            return inner(*a, **kw)
+        setattr(eng, name, failing)
+    err, seqs = None, None
+    try:
+        out = m.lookahead_generation(torch.from_numpy(prompts[mine]), stopping_criteria=P + n_new, eos_token_id=[None], pad_token_id=0,
+                                     return_dict_in_generate=True, decoding_kwargs=dk)
+        seqs = out.sequences.cpu().numpy().tolist()
+    except RuntimeError as e:
+        err = str(e)
+    failed_seen = list(g.failed_ranks)
+    # the SAME gather object serves a second request on both ranks: nothing of the failed one may leak into it
+    for name in ('step', 'mstep', 'mstep_async'):
+        if rank == 1 and calls['n'] and hasattr(m.engine, name) and getattr(m.engine, name).__name__ == 'failing':
+            delattr(m.engine, name)
+    out2 = m.lookahead_generation(torch.from_numpy(prompts[mine]), stopping_criteria=P + n_new, eos_token_id=[None], pad_token_id=0,
+                                  return_dict_in_generate=True, decoding_kwargs=dict(dk))
+    q.put((rank, err, seqs, out2.sequences.cpu().numpy().tolist(), (failed_seen, list(g.failed_ranks)), _queries(m.lookahead_cache, world * b_loc, shape.vocab),
+           m.lookahead_cache.stats()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('b_loc,mode', [(1, 'strict'), (1, 'split-phase'), (2, 'strict'), (2, 'split-phase')])
+def test_sharded_request_survives_a_rank_that_raises_mid_request(b_loc, mode):
+    """One rank's engine raises on its third verify step (both product loops, both gather modes).  The failing rank must keep its side of
+    the per-step collective (DONE | FAILED contributions until every rank has finished, then the flush of all B sequences) before it
+    re-raises, so that (1) the healthy rank finishes its sequences == plain greedy instead of blocking in the collective, (2) it learns
+    which rank failed, (3) both processes exit, (4) a SECOND request through the same gather object runs cleanly on both ranks
+    (no stale pending gather / all_done), == plain greedy on both, and (5) the replicas still answer identically afterwards."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded_failure, args=(r, world, port, b_loc, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = {}
+    for _ in range(world):
+        got = q.get(timeout=900)
+        outs[got[0]] = got[1:]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    shape, prompts, truths, M, P, n_new = _sharded_setup(world, b_loc)
+    err0, seqs0, second0, failed0, res0, st0 = outs[0]
+    err1, seqs1, second1, failed1, res1, st1 = outs[1]
+    assert err0 is None and err1 is not None and 'simulated engine failure' in err1
+    for i in range(b_loc):
+        b = i * world
+        assert seqs0[i][:P] == prompts[b].tolist() and seqs0[i][P:P + n_new] == truths[b][:n_new]
+    for r, second in ((0, second0), (1, second1)):
+        for i in range(b_loc):
+            b = i * world + r
+            assert second[i][:P] == prompts[b].tolist() and second[i][P:P + n_new] == truths[b][:n_new], (r, i)
+    assert failed0[0] == [1] and failed1[0] == [1]         # every rank learnt which rank failed (FAILED bit of its count words) ...
+    assert failed0[1] == [] and failed1[1] == []           # ... and the second request's begin_request() cleared it
+    assert res0 == res1 and st0['n_nodes'] == st1['n_nodes']

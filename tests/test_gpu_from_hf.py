@@ -14,7 +14,7 @@ import torch
 from oracle import llama_oracle as lo
 from painlessinferenceacceleration_amd.llama_engine import LlamaShape, legacy_state_dict
 
-TOL_TINY = 3e-2          # tiny-model bf16 noise, see tests/test_gpu_mblock.py
+TOL, TOL_TAIL, TAIL_FRAC = 2e-2, 3e-2, 0.10          # the stated 2e-2 (TOL) per row + the tiny seeded model's documented tail, see tests/test_gpu_mblock.py
 
 
 def _hf(kind):
@@ -105,9 +105,9 @@ def test_from_hf_engine_matches_bf16_oracle_on_bridged_weights(kind):
         # an expert flip on a near-tie router row moves that row and the rows attending to it (tests/test_gpu_moe.py): the bulk of
         # the rows must sit at bf16 noise
         err = (got - ref.float()).abs().max(1).values / ref.float().abs().max(1).values
-        assert float(err.median()) < TOL_TINY and float((err < 2 * TOL_TINY).float().mean()) >= 0.7, err
+        assert float(err.median()) < TOL and float((err < 2 * TOL_TAIL).float().mean()) >= 0.7, err
     else:
-        _check_rows(got, ref, range(P), f'from_hf {kind}', tol=TOL_TINY)
+        _check_rows(got, ref, range(P), f'from_hf {kind}', tol=TOL, tail_tol=TOL_TAIL, tail_frac=TAIL_FRAC)
     out = model.generate(input_ids=torch.tensor([prompt]), max_new_tokens=8,
                          decoding_kwargs={'use_lookahead': True, 'decoding_length': 64, 'branch_length': 12})
     assert out.shape[1] == P + 8

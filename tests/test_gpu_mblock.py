@@ -22,11 +22,15 @@ from tests.tiny_model import tiny_shape
 
 pytestmark = pytest.mark.gpu
 
-# Logits tolerance on the TINY seeded model (hidden 256, weights std 0.08): measured on MI355X (scripts/gpu_mb_diag.py, 15 prompts)
-# the 64-row path and the multi-block path sit at the same distance from the bf16 CPU oracle (max 0.0211 vs 0.0221 of max|logit|
-# per row, mean 0.012 both) and within 0.013 of each other; the tails of that distribution cross 2e-2, so the tiny-model checks of
-# this file use 3e-2 and the Llama-2-7B-shape check keeps the stated 2e-2.
-TOL_TINY = 3e-2
+# ONE tolerance: the stated 2e-2 of max|logit| per row (TOL, tests/test_gpu_e2e.py), asserted for every row of every layer-shape test
+# (7B / 13B / Mistral / Mixtral slices).  On the TINY seeded model (hidden 256, weights std 0.08, ~3-ulp top-2 gaps) two CORRECT bf16
+# summation orders are themselves 0.021-0.022 apart in the tail: measured on MI355X over 15 prompts (scripts/gpu_mb_diag.py) the 64-row path
+# AND the multi-block path sit at max 0.0211 / 0.0221 of max|logit| from the bf16 CPU oracle (mean 0.012 both, < 2 % of rows above 2e-2) and
+# within 0.013 of each other.  So the tiny-model checks of this file keep TOL per row and allow a TAIL: at most TAIL_FRAC of a check's rows
+# between TOL and TOL_TAIL, none beyond — instead of a second, looser tolerance.
+TOL_TAIL = 3e-2
+TAIL_FRAC = 0.10
+TINY = dict(tol=TOL, tail_tol=TOL_TAIL, tail_frac=TAIL_FRAC)
 
 
 def bf(t):
@@ -168,7 +172,7 @@ def test_mstep_every_block_matches_its_bs1_oracle_run(B):
         tok = eng.mprefill(b, p)
         lg, past = _oracle_seq(oracle, p)
         _check_rows(eng.mlogits()[((len(p) - 1) // 64 % eng.max_blocks) * 64:][:(len(p) - 1) % 64 + 1],
-                    lg[(len(p) - 1) // 64 * 64:], range((len(p) - 1) % 64 + 1), f'prefill {b}', tol=TOL_TINY)
+                    lg[(len(p) - 1) // 64 * 64:], range((len(p) - 1) % 64 + 1), f'prefill {b}', **TINY)
         assert eng.slot_keys[b] == len(p)
         pasts.append(past)
         nk.append(len(p))
@@ -188,7 +192,7 @@ def test_mstep_every_block_matches_its_bs1_oracle_run(B):
             mask = _mask_from_rows(rows, T)
             full = torch.cat([torch.ones((T, nk[b]), dtype=torch.long), torch.from_numpy(mask)], 1)
             lg, past_all = oracle.forward(torch.tensor(ids.tolist()), full, pasts[b])
-            _check_rows(eng.mlogits()[b * 64:b * 64 + T], lg, range(T), f'step {step} block {b}', tol=TOL_TINY)
+            _check_rows(eng.mlogits()[b * 64:b * 64 + T], lg, range(T), f'step {step} block {b}', **TINY)
             am = mo[_lib.LA_MOUT_ARGMAX + 64 * b:_lib.LA_MOUT_ARGMAX + 64 * b + T].tolist()
             exp_toks, exp_rows = lo.accept_scan(ids.tolist(), mask, am)
             exp_toks, exp_rows = exp_toks[:16], exp_rows[:16]
@@ -221,7 +225,7 @@ def test_mprefill_chain_equals_oracle_and_feeds_the_single_sequence_step(P):
     last = (P - 1) // 64
     nb_last_pass = last % 8
     rows = (P - 1) % 64 + 1
-    _check_rows(eng.mlogits()[nb_last_pass * 64:nb_last_pass * 64 + rows], lg[last * 64:], range(rows), 'chain', tol=TOL_TINY)
+    _check_rows(eng.mlogits()[nb_last_pass * 64:nb_last_pass * 64 + rows], lg[last * 64:], range(rows), 'chain', **TINY)
     top = torch.topk(lg[-1].float(), 2).values
     if float(top[0] - top[1]) > 4 * TOL * float(lg[-1].float().abs().max()):
         assert tok == int(lg[-1].float().argmax())
@@ -232,7 +236,7 @@ def test_mprefill_chain_equals_oracle_and_feeds_the_single_sequence_step(P):
     eng.step(ids, trows, mode=0)
     full = torch.cat([torch.ones((T, P), dtype=torch.long), torch.from_numpy(_mask_from_rows(trows, T))], 1)
     lg2, _ = oracle.forward(torch.tensor(ids.tolist()), full, past)
-    _check_rows(eng.logits(), lg2, range(T), 'tree after chain', tol=TOL_TINY)
+    _check_rows(eng.logits(), lg2, range(T), 'tree after chain', **TINY)
 
 
 def test_mstep_llama7b_layer_shapes_vs_oracle():
@@ -289,8 +293,8 @@ def test_mstep_mixtral_blocks_track_the_64_row_path():
     for b, (ref, T, same_first) in enumerate(refs):
         got = engm.mlogits()[b * 64:b * 64 + T].float().cpu()
         err = (got - ref).abs().max(1).values / ref.abs().max(1).values
-        agree.append(float((err < TOL_TINY).float().mean()))
-        assert float(err.median()) < TOL_TINY, (b, err)
+        agree.append(float((err < TOL).float().mean()))
+        assert float(err.median()) < TOL, (b, err)
     assert np.mean(agree) >= 0.8, agree
 
 
@@ -322,7 +326,7 @@ def test_mstep_moe_every_expert_receives_every_row():
     for b, (ref, T) in enumerate(refs):
         got = engm.mlogits()[b * 64:b * 64 + T].float().cpu()
         err = (got - ref).abs().max(1).values / ref.abs().max(1).values
-        assert float((err < TOL_TINY).float().mean()) >= 0.95 and float(err.median()) < 0.5 * TOL_TINY, (b, err)
+        assert float((err < TOL).float().mean()) >= 1.0 - TAIL_FRAC and float(err.max()) < TOL_TAIL and float(err.median()) < 0.75 * TOL, (b, err)
 
 
 @pytest.mark.parametrize('nblk', [2, 3, 4, 5, 7, 8])
@@ -503,7 +507,7 @@ def test_wide_tree_step_matches_oracle(T, chain_len):
         lg, past_all = oracle.forward(torch.tensor(ids.tolist()), full, past)
         toks, kept = eng.tstep(ids, rm, mode=0, eager=(step == 1))
         got = eng.mlogits()[:T]
-        # per-row bound 4e-2 (the tiny model's tail, see TOL_TINY: deep chain rows sit at ~3e-2) AND a mean bound that a
+        # per-row bound 4e-2 (SHORT context on purpose: the tree's own handful of bf16 keys carry the softmax mass, DESIGN 4 'One tolerance' (2); deep chain rows sit at ~3e-2) AND a mean bound that a
         # systematically wrong mask cannot meet; the later blocks are held to the same numbers as block 0
         gf, rf = got.float().cpu(), lg.float()
         rel = ((gf - rf).abs().amax(-1) / rf.abs().amax(-1)).numpy()
@@ -761,7 +765,7 @@ def test_mstep_mixtral_gathered_experts_vs_oracle_with_forced_routing():
         lg_forced, _ = oracle.forward(torch.tensor(ids.tolist()), full, past, forced_routing=forced)
         got = eng.mlogits()[64 * b:64 * b + T].float().cpu()
         err = (got - lg_forced.float()).abs().amax(-1) / lg_forced.float().abs().amax(-1)
-        assert float(err.max()) <= TOL_TINY, (b, float(err.max()), int(err.argmax()))
+        assert float(err.max()) <= TOL_TAIL and float((err <= TOL).float().mean()) >= 1.0 - TAIL_FRAC, (b, float(err.max()), int(err.argmax()))
         decisive = []                                                     # rows routed with a margin in EVERY layer (oracle)
         for t in range(T):
             ok = True
