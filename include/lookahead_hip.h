@@ -43,7 +43,7 @@ extern "C" {
 #define LA_MOE_MAX_E      8   /* experts per mixture-of-experts layer (Mixtral: 8, top-2) */
 
 /* ABI version: bumped when a signature changes. */
-#define LA_ABI_VERSION  10   /* bumped whenever a struct layout or an entry point changes */
+#define LA_ABI_VERSION  11   /* bumped whenever a struct layout or an entry point changes */
 int          la_abi_version(void);   /* == LA_ABI_VERSION of the header the library was built from */
 /* Storage / MFMA-input type of the loaded library: 0 = bfloat16 (liblookahead_hip.so), 1 = float16 (liblookahead_hip_f16.so, the
  * dtype the reference's examples and benchmarks run, lookahead/benchmarks/llama_benchmark.py:27).  The two libraries are the same
@@ -185,6 +185,30 @@ int la_trie_hier_get_dev2(void* stream, const int32_t* d_tok, const double* d_fo
                           int decoding_length, int branch_length, int min_in, int min_out, int mode, const int32_t* d_stop,
                           int n_stop, int32_t* d_scratch_q, double* d_scratch_v, int32_t* d_out_ids, uint64_t* d_out_rowmask,
                           int32_t* d_out_n, int32_t* d_out_sizes, int32_t* d_out_nsizes);
+/* The same retrieval with ONE WORKGROUP PER QUERY (csrc/la_trie_wg.hip; round 6): level-synchronous passes of 256 threads instead of an
+ * ordered DFS by one wavefront, draft trees of up to LA_TREE_WIDE_MAX rows (the reference's best published setting is decoding_length = 128,
+ * branch_length = 32: lookahead/README.md:100) with multi-word row masks.  Semantics: lookahead_cache.py:65-144 (Tree.get), :224-246
+ * (_match), :146-154 (_dfs_get_freqs), :248-293 (_ravel), :408-439 (hier_get); bit-identical to la_cache_hier_get.
+ *   image                tok / fo / fi (planes fi_stride records apart) / cstart / ccount of `n_records` records, as la_trie_hier_get_dev2;
+ *                        root_of (optional) = token -> tree root table of la_trie_image.
+ *   queries              rows of 8 int32 (first nq[b] used), per-query fi plane and branch length (NULL: plane 0 / branch_length).
+ *   scratch              int32 [B][16][n_records], double [B][3][n_records].
+ *   results              out_ids int32 [B][row_stride]; out_rowmask uint64 [B][row_stride][mask_words] (word w of a row = tree columns
+ *                        64 w ..); row_stride >= decoding_length, mask_words >= ceil(decoding_length / 64), <= 4.  row_stride = 64,
+ *                        mask_words = 1 is the layout of la_trie_hier_get_dev2 / la_llama_mstep_trie.  out_nsizes[b] = -1: the subtree is
+ *                        deeper than 128 levels (the 1-row answer is returned). */
+typedef struct la_trie_query {
+    const int32_t* tok; const double* fo; const double* fi; int64_t fi_stride; const int32_t* cstart; const int32_t* ccount;
+    int32_t n_records;
+    const int32_t* root_of; int32_t n_root_of;
+    const int32_t* queries; const int32_t* nq; const int32_t* plane; const int32_t* branch_lengths; int32_t B;
+    int32_t decoding_length, branch_length, min_in, min_out, mode;
+    const int32_t* stop; int32_t n_stop;
+    int32_t* scratch_i; double* scratch_v;
+    int32_t* out_ids; uint64_t* out_rowmask; int32_t row_stride, mask_words;
+    int32_t* out_n; int32_t* out_sizes; int32_t* out_nsizes;
+} la_trie_query;
+int la_trie_hier_get_wg(void* stream, const la_trie_query* q);
 /* one_get on the device mirror (LookaheadCache.one_get, lookahead_cache.py:490-517 with Tree.get_one_branch :171-222): one wavefront
  * per query, the single most frequent chain (<= branch_length tokens behind the root token) with lower-triangular row masks; the
  * same buffers and per-query plane / branch length as la_trie_hier_get_dev2 (d_out_sizes[b][0] = the chain length when

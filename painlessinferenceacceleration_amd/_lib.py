@@ -13,7 +13,7 @@ LIB_PATH_F16 = os.path.join(_HERE, "liblookahead_hip_f16.so")      # float16 bui
 LA_DTYPE_BF16, LA_DTYPE_F16 = 0, 1
 
 LA_OK = 0
-ABI_VERSION = 10        # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
+ABI_VERSION = 11        # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
 LA_MODE_INPUT, LA_MODE_OUTPUT, LA_MODE_MIX = 0, 1, 2
 LA_TREE_MAX = 64
 LA_MOE_MAX_E = 8
@@ -98,6 +98,17 @@ class TrieImageC(C.Structure):
     _fields_ = [('tok', C.c_void_p), ('fo', C.c_void_p), ('fi', C.c_void_p), ('fi_stride', C.c_int64), ('n_planes', C.c_int32),
                 ('cstart', C.c_void_p), ('ccount', C.c_void_p), ('ccap', C.c_void_p), ('meta', C.c_void_p), ('cap', C.c_int32),
                 ('root_of', C.c_void_p), ('n_root_of', C.c_int32)]
+
+
+class TrieQueryC(C.Structure):
+    """la_trie_query: one launch of the workgroup-per-query retrieval (la_trie_hier_get_wg)"""
+    _fields_ = [('tok', C.c_void_p), ('fo', C.c_void_p), ('fi', C.c_void_p), ('fi_stride', C.c_int64), ('cstart', C.c_void_p),
+                ('ccount', C.c_void_p), ('n_records', C.c_int32), ('root_of', C.c_void_p), ('n_root_of', C.c_int32),
+                ('queries', C.c_void_p), ('nq', C.c_void_p), ('plane', C.c_void_p), ('branch_lengths', C.c_void_p), ('B', C.c_int32),
+                ('decoding_length', C.c_int32), ('branch_length', C.c_int32), ('min_in', C.c_int32), ('min_out', C.c_int32),
+                ('mode', C.c_int32), ('stop', C.c_void_p), ('n_stop', C.c_int32), ('scratch_i', C.c_void_p), ('scratch_v', C.c_void_p),
+                ('out_ids', C.c_void_p), ('out_rowmask', C.c_void_p), ('row_stride', C.c_int32), ('mask_words', C.c_int32),
+                ('out_n', C.c_void_p), ('out_sizes', C.c_void_p), ('out_nsizes', C.c_void_p)]
 
 
 LA_TRIE_OBUF = 128
@@ -202,6 +213,7 @@ PROTOTYPES = {
     "la_cache_stream_buffer": (i32, vp, i32, i32, pi32, pi32),
     "la_trie_root_index_dev": (i32, vp, C.POINTER(TrieImageC), i32),
     "la_trie_stream_put_dev": (i32, vp, C.POINTER(TrieImageC), vp, vp, vp, i32, vp, vp, i32, i32, vp, i32, vp, i32, vp),
+    "la_trie_hier_get_wg": (i32, vp, C.POINTER(TrieQueryC)),
     "la_trie_hier_get_dev2": (i32, vp, vp, vp, vp, i64, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp),
     "la_comm_unique_id": (i32, vp),
     "la_comm_create": (vp, vp, i32, i32),

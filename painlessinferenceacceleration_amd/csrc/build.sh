@@ -5,7 +5,7 @@ set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 BASEFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -amdgpu-kernarg-preload-count=16 ${LA_EXTRA_HIPCC_FLAGS:-}"
-SRCS="la_kernels.hip la_attn1.hip la_oproj_merge.hip la_mblock.hip la_trie_dev.hip la_engine.cpp la_abi.cpp la_lab.cpp la_trie.cpp la_comm.cpp"
+SRCS="la_kernels.hip la_attn1.hip la_oproj_merge.hip la_mblock.hip la_trie_dev.hip la_trie_wg.hip la_engine.cpp la_abi.cpp la_lab.cpp la_trie.cpp la_comm.cpp"
 build_one() {     # out.so, object dir, extra flags
   local OUT="$1" OBJ="$2" FLAGS="$BASEFLAGS $3"
   mkdir -p "$OBJ"
@@ -13,7 +13,7 @@ build_one() {     # out.so, object dir, extra flags
   for f in $SRCS; do
     local o="$OBJ/${f%.*}.o"
     objs+=("$o")
-    if [ ! -f "$o" ] || [ "$HERE/$f" -nt "$o" ] || [ "$HERE/la_common.h" -nt "$o" ] || [ "$HERE/la_kernels.h" -nt "$o" ] || [ "$HERE/la_mblock.h" -nt "$o" ] \
+    if [ ! -f "$o" ] || [ "$HERE/$f" -nt "$o" ] || [ "$HERE/la_common.h" -nt "$o" ] || [ "$HERE/la_kernels.h" -nt "$o" ] || [ "$HERE/la_mblock.h" -nt "$o" ] || [ "$HERE/la_trie_dev.h" -nt "$o" ] \
        || [ "$HERE/../../include/lookahead_hip.h" -nt "$o" ] || [ "$HERE/../../include/lookahead_hip_lab.h" -nt "$o" ] || [ "$HERE/build.sh" -nt "$o" ]; then
       ( $HIPCC $FLAGS -x hip -c "$HERE/$f" -o "$o" ) &
       pids+=($!)

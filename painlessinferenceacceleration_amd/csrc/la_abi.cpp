@@ -5,6 +5,7 @@
 #include "la_common.h"
 #include "la_kernels.h"
 #include "la_mblock.h"
+#include "la_trie_dev.h"
 
 static thread_local std::string g_err;
 void la_set_error(const std::string& s) { g_err = s; }
@@ -260,6 +261,27 @@ int la_trie_hier_get_dev2(void* stream, const int32_t* d_tok, const double* d_fo
     WRAP(lk_trie_hier_get2((hipStream_t)stream, d_tok, d_fo, d_fi, (long)fi_stride, d_cstart, d_ccount, n_records, d_queries, d_nq,
                            d_plane, d_branch_length, B, decoding_length, branch_length, min_in, min_out, mode, d_stop, n_stop,
                            d_scratch_q, d_scratch_v, d_out_ids, d_out_rowmask, d_out_n, d_out_sizes, d_out_nsizes));
+}
+
+int la_trie_hier_get_wg(void* stream, const la_trie_query* q) {
+    if (!q || !q->tok || !q->fo || !q->fi || !q->cstart || !q->ccount || q->n_records < 1 || !q->queries || !q->nq || q->B < 1 ||
+        !q->scratch_i || !q->scratch_v || !q->out_ids || !q->out_rowmask || !q->out_n || !q->out_sizes || !q->out_nsizes ||
+        q->mode < 0 || q->mode > 2 || (q->n_stop > 0 && !q->stop) || (q->root_of && q->n_root_of < 1)) return LA_E_ARG;
+    if (q->decoding_length > LA_TREE_WIDE_MAX || q->mask_words < 1 || q->mask_words > 4 || q->row_stride < 1 ||
+        q->decoding_length > q->row_stride || q->decoding_length > 64 * q->mask_words) {
+        la_set_error("la_trie_hier_get_wg: decoding_length <= min(256, row_stride, 64 * mask_words), mask_words <= 4");
+        return LA_E_RANGE;
+    }
+    TrieWgArgs a{};
+    a.q.t = TrieDev{q->tok, q->fo, q->fi, q->cstart, q->ccount, q->n_records};
+    a.q.plane = q->plane; a.q.fi_stride = (long)q->fi_stride; a.q.bl = q->branch_lengths;
+    a.q.queries = q->queries; a.q.nq = q->nq; a.q.decoding_length = q->decoding_length; a.q.branch_length = q->branch_length;
+    a.q.min_in = q->min_in; a.q.min_out = q->min_out; a.q.mode = q->mode; a.q.stop = q->stop; a.q.n_stop = q->n_stop;
+    a.q.out_ids = q->out_ids; a.q.out_rowmask = (unsigned long long*)q->out_rowmask; a.q.out_n = q->out_n; a.q.out_sizes = q->out_sizes;
+    a.q.out_nsizes = q->out_nsizes;
+    a.root_of = q->root_of; a.n_root_of = q->n_root_of; a.scr_i = q->scratch_i; a.scr_v = q->scratch_v;
+    a.row_stride = q->row_stride; a.mask_words = q->mask_words;
+    WRAP(lk_trie_hier_get_wg((hipStream_t)stream, a, q->B));
 }
 
 }  // extern "C"

@@ -25,3 +25,12 @@ struct TrieQueryArgs {
     const int* bl;        // [B] per-query branch length (null: branch_length)
     long long* dbg;       // measurement aid (la_debug_set_ptr(0, .)): [B][8] wall_clock64 stamps {start, matched, scanned, cut-offs, emitted} + {rows, n_out}
 };
+// one workgroup per query (la_trie_wg.hip): rows of `row_stride` ids / `row_stride` x `mask_words` mask words per query
+struct TrieWgArgs {
+    TrieQueryArgs q;
+    const int* root_of; int n_root_of;   // token -> record of its tree root (null: the root block is searched)
+    int* scr_i;                          // [B][16][n_nodes]
+    double* scr_v;                       // [B][3][n_nodes]
+    int row_stride, mask_words;
+};
+int lk_trie_hier_get_wg(hipStream_t st, const TrieWgArgs& a, int B);

@@ -1,7 +1,9 @@
 # -*- coding: utf-8 -*-
 """DeviceTrie — hier_get on the GPU over an INCREMENTAL mirror of a LookaheadCache (csrc/la_trie.cpp Mirror +
-csrc/la_trie_dev.hip).  One wavefront per query (ballot prefix match, wave-parallel live-subtree scan, radix-select cut-offs,
-ordered DFS); bit-identical to LookaheadCache.hier_get (lookahead_cache.py:408-439).
+csrc/la_trie_wg.hip / la_trie_dev.hip).  One WORKGROUP per query (round 6, the default: level-synchronous expansion, radix-select
+cut-offs, per-level rank / size / position passes in LDS; draft trees of up to 256 rows with multi-word row masks) or one wavefront
+per query (`algo='wave'`, rounds 1-5: ordered DFS, <= 64 rows); both bit-identical to LookaheadCache.hier_get
+(lookahead_cache.py:408-439).
 
 The host trie stays the owner of all updates (put / stream_put / reset_input_freqs / squeeze); it logs every word an update
 changes in the device layout.  sync() ships that log — a few hundred bytes per verify step — as one pinned H2D copy plus one
@@ -31,9 +33,15 @@ _pd = C.POINTER(C.c_double)
 
 
 class DeviceTrie(object):
-    def __init__(self, cache, idx=None, device='cuda:0', idxs=None, max_queries=64, put_vocab=None, cap_slack=4096):
+    def __init__(self, cache, idx=None, device='cuda:0', idxs=None, max_queries=64, put_vocab=None, cap_slack=4096, algo='wg',
+                 max_rows=64):
         """put_vocab: enable device-side updates; = the model's vocabulary size (length of the token -> tree root table).
-        cap_slack: free records behind a fresh image (the image is re-allocated 1.5x larger when an update passes it)."""
+        cap_slack: free records behind a fresh image (the image is re-allocated 1.5x larger when an update passes it).
+        algo: 'wg' (one workgroup per query, trees up to 256 rows) | 'wave' (one wavefront per query, <= 64 rows).
+        max_rows: rows per query of the result block (64: the layout la_llama_mstep_trie chains; grows to 256 on the first wider query)."""
+        assert algo in ('wg', 'wave')
+        self.algo = algo
+        self.rows = 64 if int(max_rows) <= 64 else _lib.LA_TREE_WIDE_MAX
         if not torch.cuda.is_available():
             raise RuntimeError('DeviceTrie needs an MI355X (no CPU fallback)')
         self.device = torch.device(device)
@@ -98,23 +106,29 @@ class DeviceTrie(object):
             self.ccap = torch.zeros(self.cap, dtype=torch.int32, device=dev)
             self._h_ccap = torch.zeros(self.cap, dtype=torch.int32).pin_memory()
 
-    def _alloc_queries(self, B):
-        if B <= self._qcap:
+    def _alloc_queries(self, B, rows=None):
+        rows = self.rows if rows is None else max(self.rows, 64 if rows <= 64 else _lib.LA_TREE_WIDE_MAX)
+        if B <= self._qcap and rows == self.rows:
             return
-        self._qcap = B
+        B = max(B, self._qcap)
+        self._qcap, self.rows = B, rows
+        R, W = rows, rows // 64
+        self.mask_words = W
         dev = self.device
         self._hq = torch.zeros(B * 8 + 3 * B, dtype=torch.int32).pin_memory()      # queries [B][8], nq [B], plane [B], bl [B]
         self._dq = torch.zeros(B * 8 + 3 * B, dtype=torch.int32, device=dev)
         # ONE result block [row masks (8-byte aligned) | ids | n | sizes | nsizes]: hier_get reads it back with a single D2H copy
-        # (round 2: five synchronous .cpu() calls, ~130 us of the 730 us a bs=1 query cost — profiles/r03_trie_device_profile.txt)
-        words = B * (128 + 64 + 1 + 2 + 1)
+        # (round 2: five synchronous .cpu() calls, ~130 us of the 730 us a bs=1 query cost — profiles/r03_trie_device_profile.txt).
+        # R rows per query, W = R / 64 mask words per row (R = 64: the layout the chained verify step reads, la_llama_mstep_trie)
+        nm = 2 * R * W
+        words = B * (nm + R + 1 + 2 + 1)
         self._out = torch.zeros(words, dtype=torch.int32, device=dev)
         self._h_out = torch.zeros(words, dtype=torch.int32).pin_memory()
-        self.out_rm = self._out[:B * 128].view(torch.int64)
-        self.out_ids = self._out[B * 128:B * 192]
-        self.out_n = self._out[B * 192:B * 193]
-        self.out_sizes = self._out[B * 193:B * 195]
-        self.out_nsizes = self._out[B * 195:B * 196]
+        self.out_rm = self._out[:B * nm].view(torch.int64)
+        self.out_ids = self._out[B * nm:B * (nm + R)]
+        self.out_n = self._out[B * (nm + R):B * (nm + R + 1)]
+        self.out_sizes = self._out[B * (nm + R + 1):B * (nm + R + 3)]
+        self.out_nsizes = self._out[B * (nm + R + 3):B * (nm + R + 4)]
         self._scratch = None
 
     def _stream(self):
@@ -296,10 +310,11 @@ class DeviceTrie(object):
         """One launch for all queries; results stay on the device: out_ids int32[B][64], out_rm uint64[B][64], out_n int32[B]
         (views of buffers reused by the next call).  queries: token lists (<= 8 tokens each); idxs: the input slot of each
         query (default: the first mirrored slot); branch_lengths: per-query branch length (default: branch_length)."""
-        assert mode in _MODES and decoding_length <= _lib.LA_TREE_MAX
+        assert mode in _MODES and decoding_length <= (_lib.LA_TREE_WIDE_MAX if self.algo == 'wg' else _lib.LA_TREE_MAX), \
+            'the device retrieval emits <= 256 rows per query (one workgroup per query) / <= 64 (one wavefront per query)'
         B = len(queries)
         self._check_owner()
-        self._alloc_queries(B)
+        self._alloc_queries(B, int(decoding_length))
         if sync:
             self.sync()
         self._staging_free()
@@ -314,14 +329,28 @@ class DeviceTrie(object):
             h[B * 10 + b] = int(branch_lengths[b]) if branch_lengths is not None else int(branch_length)
         self._dq[:B * 11].copy_(self._hq[:B * 11], non_blocking=True)
         self._staging_queued()
-        if self._scratch is None or self._scratch[0].numel() < B * self.cap:
-            self._scratch = (torch.empty(B * self.cap, dtype=torch.int32, device=self.device),
-                             torch.empty(B * 2 * self.cap, dtype=torch.float64, device=self.device))
+        if self._scratch is None or self._scratch[0].numel() < B * 16 * self.cap:
+            self._scratch = (torch.empty(B * 16 * self.cap, dtype=torch.int32, device=self.device),
+                             torch.empty(B * 3 * self.cap, dtype=torch.float64, device=self.device))
         stop = getattr(self, '_stop_dev', None)
         if stop is None or self._stop_list != self.stop_words:
             self._stop_list = list(self.stop_words)
             self._stop_dev = stop = torch.tensor(self.stop_words or [0], dtype=torch.int32, device=self.device)
         base = self._dq.data_ptr()
+        if self.algo == 'wg':
+            q = _lib.TrieQueryC()
+            q.tok, q.fo, q.fi, q.fi_stride = self.tok.data_ptr(), self.fo.data_ptr(), self.fi.data_ptr(), self.cap
+            q.cstart, q.ccount, q.n_records = self.cstart.data_ptr(), self.ccount.data_ptr(), self.cap
+            q.root_of, q.n_root_of = (self.root_of.data_ptr(), self.put_vocab) if self.put_vocab else (None, 0)
+            q.queries, q.nq, q.plane, q.branch_lengths, q.B = base, base + 4 * B * 8, base + 4 * B * 9, base + 4 * B * 10, B
+            q.decoding_length, q.branch_length, q.min_in, q.min_out = int(decoding_length), int(branch_length), int(min_input_size), int(min_output_size)
+            q.mode, q.stop, q.n_stop = _MODES[mode], stop.data_ptr(), len(self.stop_words)
+            q.scratch_i, q.scratch_v = self._scratch[0].data_ptr(), self._scratch[1].data_ptr()
+            q.out_ids, q.out_rowmask, q.row_stride, q.mask_words = self.out_ids.data_ptr(), self.out_rm.data_ptr(), self.rows, self.mask_words
+            q.out_n, q.out_sizes, q.out_nsizes = self.out_n.data_ptr(), self.out_sizes.data_ptr(), self.out_nsizes.data_ptr()
+            check(lib.la_trie_hier_get_wg(self._stream(), C.byref(q)), 'trie_hier_get_wg')
+            return B
+        assert self.rows == 64, 'the one-wavefront kernel writes 64-row result blocks'
         check(lib.la_trie_hier_get_dev2(self._stream(), self.tok.data_ptr(), self.fo.data_ptr(), self.fi.data_ptr(), self.cap,
                                         self.cstart.data_ptr(), self.ccount.data_ptr(), self.cap, base, base + 4 * B * 8,
                                         base + 4 * B * 9, base + 4 * B * 10, B, int(decoding_length), int(branch_length),
@@ -336,6 +365,7 @@ class DeviceTrie(object):
         chain; results in the same device buffers as hier_get_dev (row masks lower-triangular), so a chained verify step
         (LlamaVerifyEngine.mstep_trie) can take them as they are."""
         assert mode in _MODES and int(branch_length) + 1 <= _lib.LA_TREE_MAX
+        assert self.rows == 64, 'one_get_dev writes 64-row result blocks (a DeviceTrie that served wide hier_get queries keeps 256-row blocks)'
         B = len(queries)
         self._check_owner()
         self._alloc_queries(B)
@@ -375,18 +405,22 @@ class DeviceTrie(object):
     def _read_results(self, B):
         self._h_out.copy_(self._out, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
-        Q = self._qcap
+        Q, R, W = self._qcap, self.rows, self.mask_words
+        nm = 2 * R * W
         h = self._h_out.numpy()
-        rm = h[:Q * 128].view(np.uint64).reshape(Q, 64)
-        ids = h[Q * 128:Q * 192].reshape(Q, 64)
-        on = h[Q * 192:Q * 193]
-        osz = h[Q * 193:Q * 195].reshape(Q, 2)
-        ons = h[Q * 195:Q * 196]
-        return [(ids[b, :on[b]].tolist(), rm[b, :on[b]].copy(), osz[b, :ons[b]].tolist()) for b in range(B)]
+        rm = h[:Q * nm].view(np.uint64).reshape(Q, R, W)
+        ids = h[Q * nm:Q * (nm + R)].reshape(Q, R)
+        on = h[Q * (nm + R):Q * (nm + R + 1)]
+        osz = h[Q * (nm + R + 1):Q * (nm + R + 3)].reshape(Q, 2)
+        ons = h[Q * (nm + R + 3):Q * (nm + R + 4)]
+        if (ons[:B] < 0).any():
+            raise RuntimeError('device trie: a queried subtree is deeper than the 128 levels the workgroup kernel follows')
+        return [(ids[b, :on[b]].tolist(), (rm[b, :on[b], 0] if W == 1 else rm[b, :on[b]]).copy(), osz[b, :ons[b]].tolist()) for b in range(B)]
 
     def hier_get(self, queries, decoding_length=64, branch_length=8, min_input_size=0, min_output_size=0, mode='mix', idxs=None,
                  branch_lengths=None):
-        """-> list of (ids list, uint64 row masks, sizes list), like LookaheadCache.hier_get per query."""
+        """-> list of (ids list, uint64 row masks, sizes list), like LookaheadCache.hier_get per query; the masks are uint64[T] while the
+        result block holds 64 rows per query and uint64[T][4] (word w = tree columns 64 w ..) once a query asked for more."""
         B = self.hier_get_dev(queries, idxs=idxs, branch_lengths=branch_lengths, decoding_length=decoding_length,
                               branch_length=branch_length, min_input_size=min_input_size, min_output_size=min_output_size, mode=mode)
         return self._read_results(B)

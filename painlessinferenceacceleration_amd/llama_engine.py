@@ -623,6 +623,7 @@ class LlamaVerifyEngine(object):
         replay the PREVIOUS step's trie update on its own trie (DeviceTrie.replay) — until mstep_trie_finish()."""
         nb = len(slots)
         assert self.max_blocks and 1 <= nb <= self.max_blocks
+        assert getattr(dev_trie, 'rows', 64) == 64, 'the chained step reads 64-row result blocks (DeviceTrie(max_rows=64), decoding_length <= 64)'
         arr = lambda v: (C.c_int32 * nb)(*[int(x) for x in v])
         lim = [max(1, min(_lib.LA_MOUT_TOKS, int(x))) for x in limits]
         check(self._lib.la_llama_mstep_trie(self._h, self._sp(), nb, arr(slots), arr(lim), arr(last_tokens),

@@ -1,6 +1,7 @@
 # -*- coding: utf-8 -*-
-"""-m gpu: device-side hier_get (csrc/la_trie_dev.hip) must be bit-identical to the reference's golden traces
-(recorded from lookahead_cache.py by oracle/gen_golden.py) and to the host trie on larger forests."""
+"""-m gpu: device-side hier_get (csrc/la_trie_wg.hip: one workgroup per query, trees up to 256 rows; csrc/la_trie_dev.hip: one
+wavefront per query, <= 64 rows) must be bit-identical to the reference's golden traces (recorded from lookahead_cache.py by
+oracle/gen_golden.py) and to the host trie on larger forests."""
 import os
 import random
 
@@ -16,11 +17,17 @@ pytestmark = pytest.mark.gpu
 
 
 def _rows(mask_rows):
-    return [int(x) for x in mask_rows]
+    m = np.asarray(mask_rows, dtype=np.uint64)
+    if m.ndim == 1:
+        return [int(x) for x in m]
+    return [sum(int(x) << (64 * w) for w, x in enumerate(row)) for row in m]
 
 
+@pytest.mark.parametrize('algo', ['wg', 'wave'])
 @pytest.mark.parametrize('path', tr.trace_files(), ids=os.path.basename)
-def test_device_hier_get_replays_reference_trace(path):
+def test_device_hier_get_replays_reference_trace(path, algo):
+    """every recorded hier_get of the reference traces (the first 60 per trace, and with the workgroup kernel EVERY query wider than 64
+    rows on top: decoding_length 128 / 256 of the benchmark-size traces) answered by the device kernel"""
     trace = tr.load(path)
     init = trace['init']
     cache = LookaheadCache(eos_ids=init['eos_ids'], stop_words={w: 1 for w in init['stop_words']},
@@ -33,9 +40,10 @@ def test_device_hier_get_replays_reference_trace(path):
         elif name == 'stream_put':
             cache.stream_put(list(op['tokens']), branch_length=op['branch_length'], final=op['final'], idx=op['idx'])
         elif name == 'hier_get':
-            if op['decoding_length'] > 64 or checked >= 60:
+            wide = op['decoding_length'] > 64
+            if (wide and (algo == 'wave' or len(op['tokens']) > 8)) or (checked >= 60 and not wide):
                 continue
-            dev = DeviceTrie(cache, idx=op['idx'])
+            dev = DeviceTrie(cache, idx=op['idx'], algo=algo, max_rows=op['decoding_length'])
             got = dev.hier_get([list(op['tokens'])], decoding_length=op['decoding_length'], branch_length=op['branch_length'],
                                min_input_size=op['min_input_size'], min_output_size=op['min_output_size'], mode=op['mode'])[0]
             exp = op['out']
@@ -55,7 +63,47 @@ def test_device_hier_get_replays_reference_trace(path):
     assert checked >= 20
 
 
-def test_device_hier_get_batched_matches_host_on_large_forest():
+def test_workgroup_hier_get_wide_trees_match_host_on_large_forest_with_dead_nodes():
+    """the forest of tests/test_trie_wg_model.py (100 x 256-token warm-up, a prompt whose input frequencies were reset = dead nodes, a
+    live prompt): 120 queries x 4 mode settings x budgets {16, 64, 128, 256} in batched launches against the host trie, multi-word
+    row masks included; the 1-token queries walk subtrees of thousands of entries (global-scratch levels / candidate sets)."""
+    rng = random.Random(1)
+    nr = np.random.RandomState(1)
+    cache = LookaheadCache(eos_ids=[None])
+    phrases = [nr.randint(3, 2000, size=nr.randint(3, 10)).tolist() for _ in range(200)]
+    for _ in range(100):
+        seq = []
+        while len(seq) < 256:
+            seq.extend(phrases[min(int(nr.zipf(1.3)) - 1, 199)])
+        cache.put(seq[:256], branch_length=13, mode='output', idx=-1)
+    dead = sum((phrases[rng.randrange(200)] + [rng.randrange(3, 2000)] for _ in range(40)), [])
+    cache.put(dead, branch_length=13, mode='input', idx=0)
+    cache.reset_input_freqs(0)
+    prompt = sum((phrases[rng.randrange(200)] for _ in range(60)), [])
+    cache.put(prompt, branch_length=13, mode='input', idx=0)
+    queries = []
+    for _ in range(120):
+        ph = phrases[rng.randrange(200)]
+        k = rng.randrange(1, len(ph))
+        queries.append(ph[max(0, k - 2):k] if rng.random() < 0.6 else ph[k - 1:k] if rng.random() < 0.5 else [rng.randrange(3, 2000), rng.randrange(3, 2000)])
+    dev = DeviceTrie(cache, idx=0, max_rows=256)
+    n_wide = 0
+    for mode, mi, mo in [('mix', 0, 32), ('mix', 2, 8), ('output', 0, 16), ('input', 1, 0)]:
+        for dl, bl in [(16, 6), (64, 12), (128, 32), (256, 20)]:
+            mo_ = mo if dl <= 64 else dl // 2
+            got = dev.hier_get(queries, decoding_length=dl, branch_length=bl, min_input_size=mi, min_output_size=mo_, mode=mode)
+            for qy, g in zip(queries, got):
+                ids, rowmask, parent, sizes = cache.hier_get_packed(qy, decoding_length=dl, branch_length=bl, min_input_size=mi,
+                                                                   min_output_size=mo_, mode=mode, idx=0)
+                assert g[0] == ids.tolist(), (mode, dl, qy)
+                assert _rows(g[1])[:len(g[0])] == _rows(rowmask), (mode, dl, qy)
+                assert g[2] == sizes, (mode, dl, qy)
+                n_wide += len(g[0]) > 64
+    assert n_wide > 20
+
+
+@pytest.mark.parametrize('algo', ['wg', 'wave'])
+def test_device_hier_get_batched_matches_host_on_large_forest(algo):
     """100 x 256-token warm-up (the reference benchmark's recipe) + an input-mode prompt; 256 queries in one launch,
     all three modes, oversize subtrees (thresholds) included."""
     rng = random.Random(0)
@@ -74,7 +122,7 @@ def test_device_hier_get_batched_matches_host_on_large_forest():
         ph = phrases[rng.randrange(300)]
         k = rng.randrange(1, len(ph))
         queries.append(ph[max(0, k - 2):k] if rng.random() < 0.8 else [rng.randrange(3, 3000), rng.randrange(3, 3000)])
-    dev = DeviceTrie(cache, idx=0)
+    dev = DeviceTrie(cache, idx=0, algo=algo)
     big = 0
     for mode, mi, mo in [('mix', 0, 32), ('mix', 2, 8), ('output', 0, 16), ('input', 1, 0)]:
         got = dev.hier_get(queries, decoding_length=64, branch_length=12, min_input_size=mi, min_output_size=mo, mode=mode)
