@@ -184,12 +184,14 @@ def secondary_legs(spec, gpus=1, layers=0):
             continue
         parts = item.split(':')
         model, batch = parts[0], parts[1]
-        dev_trie_leg = len(parts) > 2 and parts[2] == 'dev'      # model:batch:dev = the same leg with the drafts from the ON-GPU trie
+        dev_trie_leg = len(parts) > 2 and parts[2] == 'dev'      # model:batch:dev = the same leg with the drafts from the ON-GPU trie (the default from 8 sequences on)
         leg_args = ['--gpus', str(gpus), '--model', model, '--batch', batch, '--steps', '24', '--warmup', '4', '--no-cpu-baseline']
         if dev_trie_leg:
             leg_args.append('--device-trie')
+        if len(parts) > 2 and parts[2] == 'host':                # model:batch:host = the drafts from the host trie where the default is the on-GPU trie
+            leg_args.append('--host-trie')
         if len(parts) > 2 and parts[2] == 'deferred':            # model:batch:deferred = the host-trie leg with the trie update under the next pass
-            leg_args.append('--deferred-trie-update')
+            leg_args += ['--deferred-trie-update', '--host-trie']
         if layers:                       # launch-path tests only (tests/test_gpu_bench_launch.py): a truncated model, flagged in the leg
             leg_args += ['--layers', str(int(layers)), '--steps', '6', '--warmup', '2']
         cmd = [sys.executable, os.path.abspath(__file__)] + leg_args if gpus == 1 else self_launch_cmd(leg_args, gpus, _free_port())
@@ -235,9 +237,9 @@ NOTES = {
     'value': 'accepted tokens / s over the timed verify steps, inputs resident in HBM; prefill excluded (speed_incl_prefill = the reference headline definition)',
     'roofline.timing': 'dominant kernel from live HIP events on the engine stream (all layers\' launches back to back per event pair); rocprofv3 averages of the same command: newest profiles/r*_profile_raw.txt',
     'roofline.traffic': 'HBM bytes per launch (bs=1) / per verify step (batch legs) from committed FETCH_SIZE / WRITE_SIZE passes (profiles/pmc_latest.json, pmc_secondary.json); traffic_ratio = traffic / algorithmic bytes',
-    'draft_retrieval': 'host = native C++ trie (la_cache_*); device = on-GPU trie (la_trie_dev.hip), drafts chained in front of the verify pass, trie update on the device',
+    'draft_retrieval': 'host = native C++ trie (la_cache_*); device = on-GPU trie (la_trie_wg.hip: one workgroup per query), drafts chained in front of the verify pass, trie update on the device',
     'trie_update': 'ref-order = before the next query (reference order); deferred = under the next verify pass (drafts see a step one step later); device = la_trie_stream_put_dev',
-    'secondary': 'each leg = this script in its own process after the headline\'s timed region (24 steps, 4 warm-up): BASELINE config 3 (mistral:8 host trie in the reference update order, :deferred = update under the next pass, :dev = on-GPU trie), config 4 per-GPU share (13b:4), config 5 (mixtral:4), and 13b:1',
+    'secondary': 'each leg = this script in its own process after the headline\'s timed region (24 steps, 4 warm-up): BASELINE config 3 (mistral:8 = on-GPU trie, the default from 8 sequences per GPU on; :host = host trie in the reference update order, :deferred = host trie, update under the next pass), config 4 per-GPU share (13b:4), config 5 (mixtral:4), and 13b:1',
     'detail': 'the full record (every field of earlier rounds) is the BENCH_DETAIL line above this one and gpurun_out/bench_detail_*.json',
 }
 
@@ -382,7 +384,9 @@ def main():
     ap.add_argument('--model', choices=['7b', '13b', 'mistral', 'mixtral'], default='7b',
                     help='7b = the BASELINE metric; 13b / mistral / mixtral = the config-4 / config-3 / config-5 model shapes')
     ap.add_argument('--batch', type=int, default=1, help='sequences per GPU; > 1: each gets its own 64-token tree per step (la_llama_mstep)')
-    ap.add_argument('--device-trie', action='store_true', help='--batch > 1: drafts of all sequences from ONE device launch over the incremental trie mirror')
+    ap.add_argument('--device-trie', action='store_true', help='--batch > 1: drafts of all sequences from ONE device launch over the incremental trie mirror (default at --batch 8 on one GPU, where it beats the host trie: profiles/r06_device_trie_wg.txt)')
+    ap.add_argument('--host-trie', action='store_true', help='drafts from the host trie also where the on-GPU trie is the default (--batch 8)')
+    ap.add_argument('--trie-algo', default='wg', choices=['wg', 'wave'], help='--device-trie: one workgroup per query (round 6, la_trie_wg.hip) | one wavefront per query (rounds 1-5, la_trie_dev.hip)')
     ap.add_argument('--host-trie-update', action='store_true', help='--device-trie: apply the per-step trie update on the host and ship it as a patch (round-2 form) instead of inserting the accepted tokens on the device (la_trie_stream_put_dev)')
     ap.add_argument('--unchained-trie', action='store_true', help='--device-trie: read the drafts back to the host and feed them through la_llama_mstep (round-2 form)')
     ap.add_argument('--strict-gather', action='store_true', help='N > 1: blocking all-gather (reference trie order at query time)')
@@ -398,7 +402,7 @@ def main():
     ap.add_argument('--attn-split', type=int, default=0, help='key splits of the tree-attention kernel (0 = engine default 8)')
     ap.add_argument('--fuse', type=int, default=0, help='engine cfg.fuse bits (opt-in in-kernel norm->GEMM fusion; 0 = separate kernels)')
     ap.add_argument('--gemm-cfg', default='', help='engine gemm_cfg override (comma list: qkv_rb,qkv_ks,o_rb,o_ks,down_rb,down_ks,lm_rb,gu_variant; 0 = default)')
-    ap.add_argument('--secondary', default='mistral:8,mistral:8:deferred,mistral:8:dev,13b:4,mixtral:4,13b:1',
+    ap.add_argument('--secondary', default='mistral:8,mistral:8:host,mistral:8:deferred,13b:4,mixtral:4,13b:1',
                     help='N=1 default workload only: comma list of model:batch legs (BASELINE configs 3-5: a 64-token tree per sequence '
                          'through la_llama_mstep) run AFTER the timed region, each in its own process; their lines are embedded under '
                          '"secondary"; model:batch:dev = the same leg with the drafts from the on-GPU trie (BASELINE config 3 as stated: the host-trie line '
@@ -475,6 +479,8 @@ def main():
     assert 1 <= B <= 16, 'sequences per GPU: <= 16 KV slots; more than 8 run as two passes of <= 8 blocks per step'
     assert B <= 8 or (not args.device_trie and args.decoding_length <= 64), '--batch above 8: host trie, 64-token trees'
     BL, DL = args.branch_length, args.decoding_length
+    if not args.device_trie and not args.host_trie and B == 8 and world == 1 and DL <= 64 and not args.deferred_trie_update:
+        args.device_trie = True          # round 6: the workgroup-per-query device trie wins from 8 sequences per GPU on (the product loop's AUTO rule)
     wide = DL > 64                       # trees wider than one 64-row block: the tree is 2-4 chained blocks of one multi-block pass (eng.tstep)
     assert 1 <= DL <= 256 and 1 <= BL <= 39, 'decoding_length <= 256, branch_length <= 39'
     # wide trees in a batch: every sequence's tree is ceil(DL / 64) blocks of the pass (eng.mstep_trees), all of them within the 8-block pass
@@ -573,7 +579,7 @@ def main():
     if args.device_trie and B > 1:
         from painlessinferenceacceleration_amd.device_trie import DeviceTrie
         dev_put = not args.host_trie_update and not args.unchained_trie and not dist_on
-        dev_trie = DeviceTrie(cache, idxs=gidx, device=dev, put_vocab=shape.vocab if dev_put else None)
+        dev_trie = DeviceTrie(cache, idxs=gidx, device=dev, put_vocab=shape.vocab if dev_put else None, algo=args.trie_algo)
         if dev_put:
             dev_trie.load_stream_buffers()
 
@@ -885,7 +891,7 @@ def main():
                    'trie_update': ('device' if (dev_trie is not None and dev_trie.put_vocab) else
                                    ('gathered, ' + gather.mode) if dist_on else
                                    'deferred' if (B > 1 and overlap_put and not wide and dev_trie is None) else 'ref-order'),
-                   'draft_retrieval': (('device' + ('' if not args.unchained_trie else ', unchained') + ('' if dev_trie.put_vocab else ', host patches')) if dev_trie is not None else 'host'),
+                   'draft_retrieval': (('device' + (' (workgroup per query)' if args.trie_algo == 'wg' else ' (wavefront per query)') + ('' if not args.unchained_trie else ', unchained') + ('' if dev_trie.put_vocab else ', host patches')) if dev_trie is not None else 'host'),
                    'device_trie_stats': dev_trie.stats if dev_trie is not None else None,
                    'mean_accept_len': round(mean_acc, 3), 'mean_draft_len': round(mean_T, 2),
                    'verify_steps_per_sec': round(K * world / elapsed, 2), 'context_at_end': ctx_end_timed,

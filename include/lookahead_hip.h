@@ -207,6 +207,9 @@ typedef struct la_trie_query {
     int32_t* scratch_i; double* scratch_v;
     int32_t* out_ids; uint64_t* out_rowmask; int32_t row_stride, mask_words;
     int32_t* out_n; int32_t* out_sizes; int32_t* out_nsizes;
+    int32_t lds_level_cap, lds_cand_cap, one_wave_cap;   /* 0 = the library's limits (4096 entries per level / 3072 candidates in LDS, 256
+                                                            candidates ordered by one wave; one_wave_cap < 0: never).  Smaller values send
+                                                            small sets down the global-scratch paths — for the parity tests. */
 } la_trie_query;
 int la_trie_hier_get_wg(void* stream, const la_trie_query* q);
 /* one_get on the device mirror (LookaheadCache.one_get, lookahead_cache.py:490-517 with Tree.get_one_branch :171-222): one wavefront

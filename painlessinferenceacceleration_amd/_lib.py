@@ -108,7 +108,8 @@ class TrieQueryC(C.Structure):
                 ('decoding_length', C.c_int32), ('branch_length', C.c_int32), ('min_in', C.c_int32), ('min_out', C.c_int32),
                 ('mode', C.c_int32), ('stop', C.c_void_p), ('n_stop', C.c_int32), ('scratch_i', C.c_void_p), ('scratch_v', C.c_void_p),
                 ('out_ids', C.c_void_p), ('out_rowmask', C.c_void_p), ('row_stride', C.c_int32), ('mask_words', C.c_int32),
-                ('out_n', C.c_void_p), ('out_sizes', C.c_void_p), ('out_nsizes', C.c_void_p)]
+                ('out_n', C.c_void_p), ('out_sizes', C.c_void_p), ('out_nsizes', C.c_void_p),
+                ('lds_level_cap', C.c_int32), ('lds_cand_cap', C.c_int32), ('one_wave_cap', C.c_int32)]
 
 
 LA_TRIE_OBUF = 128

@@ -281,6 +281,7 @@ int la_trie_hier_get_wg(void* stream, const la_trie_query* q) {
     a.q.out_nsizes = q->out_nsizes;
     a.root_of = q->root_of; a.n_root_of = q->n_root_of; a.scr_i = q->scratch_i; a.scr_v = q->scratch_v;
     a.row_stride = q->row_stride; a.mask_words = q->mask_words;
+    a.lcap = q->lds_level_cap; a.mcap = q->lds_cand_cap; a.onewave = q->one_wave_cap;
     WRAP(lk_trie_hier_get_wg((hipStream_t)stream, a, q->B));
 }
 

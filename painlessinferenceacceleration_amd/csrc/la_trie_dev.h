@@ -32,5 +32,6 @@ struct TrieWgArgs {
     int* scr_i;                          // [B][16][n_nodes]
     double* scr_v;                       // [B][3][n_nodes]
     int row_stride, mask_words;
+    int lcap, mcap, onewave;             // set-size limits of the LDS paths (0 = the library's; onewave < 0: never)
 };
 int lk_trie_hier_get_wg(hipStream_t st, const TrieWgArgs& a, int B);

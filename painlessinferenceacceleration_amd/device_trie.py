@@ -41,6 +41,7 @@ class DeviceTrie(object):
         max_rows: rows per query of the result block (64: the layout la_llama_mstep_trie chains; grows to 256 on the first wider query)."""
         assert algo in ('wg', 'wave')
         self.algo = algo
+        self.wg_limits = (0, 0, 0)       # la_trie_query.lds_level_cap / lds_cand_cap / one_wave_cap (0 = the library's; tests shrink them)
         self.rows = 64 if int(max_rows) <= 64 else _lib.LA_TREE_WIDE_MAX
         if not torch.cuda.is_available():
             raise RuntimeError('DeviceTrie needs an MI355X (no CPU fallback)')
@@ -348,6 +349,7 @@ class DeviceTrie(object):
             q.scratch_i, q.scratch_v = self._scratch[0].data_ptr(), self._scratch[1].data_ptr()
             q.out_ids, q.out_rowmask, q.row_stride, q.mask_words = self.out_ids.data_ptr(), self.out_rm.data_ptr(), self.rows, self.mask_words
             q.out_n, q.out_sizes, q.out_nsizes = self.out_n.data_ptr(), self.out_sizes.data_ptr(), self.out_nsizes.data_ptr()
+            q.lds_level_cap, q.lds_cand_cap, q.one_wave_cap = self.wg_limits
             check(lib.la_trie_hier_get_wg(self._stream(), C.byref(q)), 'trie_hier_get_wg')
             return B
         assert self.rows == 64, 'the one-wavefront kernel writes 64-row result blocks'

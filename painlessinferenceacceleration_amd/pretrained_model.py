@@ -111,22 +111,22 @@ class LookaheadPreTrainedModel(object):
         fmt, mode = decoding_mode.split('_')
         tidx = int(decoding_kwargs.get('_trie_idx', 0))      # input-frequency plane: 0, or the global batch index of a sharded job
         ts = time.time()
-        if fmt == 'hier' and decoding_kwargs.get('device_trie', False) and len(qids) <= 8 and decoding_length <= _lib.LA_TREE_MAX:
-            # (trees wider than one 64-row block come from the host trie: the device walk emits uint64[T] row masks)
-            # draft from the wavefront trie walk over the incremental device mirror (csrc/la_trie_dev.hip): bit-identical to the
-            # host query; opt-in here because one host query (~20 us) is faster than sync + launch + D2H at bs = 1
+        if fmt == 'hier' and decoding_kwargs.get('device_trie', False) and len(qids) <= 8 and decoding_length <= _lib.LA_TREE_WIDE_MAX:
+            # draft from the workgroup-per-query trie walk over the incremental device mirror (csrc/la_trie_wg.hip; trees wider than one
+            # 64-row block come back with uint64[T][4] row masks): bit-identical to the host query; opt-in here because one host query
+            # (~20 us) is faster than sync + launch + D2H at bs = 1
             got = self._device_trie().hier_get([list(qids)], decoding_length=decoding_length, branch_length=update_branch_length,
                                                min_input_size=0, min_output_size=max(decoding_length // 2, 1), mode=mode, idxs=[0])[0]
             ids, rowmask, sizes = np.asarray(got[0], dtype=np.int32), np.asarray(got[1], dtype=np.uint64), got[2]
         elif fmt == 'one' and decoding_kwargs.get('device_trie', False) and len(qids) <= 8 and update_branch_length < 64:
-            got = self._device_trie().one_get([list(qids)], decoding_length=decoding_length, branch_length=update_branch_length,
+            got = self._device_trie(narrow=True).one_get([list(qids)], decoding_length=decoding_length, branch_length=update_branch_length,
                                               mode=mode, idxs=[0])[0]
             ids, rowmask, sizes = np.asarray(got[0], dtype=np.int32), np.asarray(got[1], dtype=np.uint64), got[2]
         elif fmt == 'par' and decoding_kwargs.get('device_trie', False) and len(qids) <= 8 and decoding_length <= 64:
             # par = the hierarchical draft re-laid as independent chains (lookahead_cache.py:441-488): the device retrieves, the
             # re-layout (a handful of set operations on <= 64 rows) stays on the host
-            got = self._device_trie().hier_get([list(qids)], decoding_length=decoding_length, branch_length=update_branch_length,
-                                               min_input_size=0, min_output_size=max(decoding_length // 2, 1), mode=mode, idxs=[0])[0]
+            got = self._device_trie(narrow=True).hier_get([list(qids)], decoding_length=decoding_length, branch_length=update_branch_length,
+                                                          min_input_size=0, min_output_size=max(decoding_length // 2, 1), mode=mode, idxs=[0])[0]
             T0 = len(got[0])
             dense = np.array([[(int(got[1][i]) >> j) & 1 for j in range(T0)] for i in range(T0)], dtype=np.int64).reshape(T0, T0)
             lst, mask, sizes = self.lookahead_cache.par_layout(got[0], dense)
@@ -146,11 +146,12 @@ class LookaheadPreTrainedModel(object):
         decoding_kwargs.update({'decoding_qids': qids, 'decoding_ids': ids, 'sizes': sizes})
         return ids, rowmask
 
-    def _device_trie(self):
-        """DeviceTrie over self.lookahead_cache, input-frequency plane of idx 0 (rebuilt when the cache object changes)."""
+    def _device_trie(self, narrow=False):
+        """DeviceTrie over self.lookahead_cache, input-frequency plane of idx 0 (rebuilt when the cache object changes; narrow: also when
+        its result block grew to 256 rows per query — the one-branch walk writes 64-row blocks)."""
         from .device_trie import DeviceTrie
         dt = getattr(self, '_dev_trie', None)
-        if dt is None or dt.cache is not self.lookahead_cache or dt._revoked:        # another DeviceTrie took the cache's mirror
+        if dt is None or dt.cache is not self.lookahead_cache or dt._revoked or (narrow and dt.rows != 64):        # another DeviceTrie took the cache's mirror
             dt = self._dev_trie = DeviceTrie(self.lookahead_cache, idxs=[0], device=self.engine.device)
         return dt
 

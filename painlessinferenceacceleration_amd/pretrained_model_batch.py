@@ -44,9 +44,9 @@ class LookaheadPreTrainedModel(object):
         if decoding_mode in ('hier', 'par', 'one'):
             decoding_mode = decoding_mode + '_mix'
         fmt, mode = decoding_mode.split('_')
-        # trees wider than a 64-row block (<= LA_TREE_WIDE_MAX rows = up to 4 blocks of the pass) come from the host trie's hier walk;
-        # the device trie and the one-branch walk keep the 64-row cap
-        wide_ok = fmt == 'hier' and not decoding_kwargs.get('device_trie', False) and bool(getattr(self.engine, 'max_blocks', 0))
+        # trees wider than a 64-row block (<= LA_TREE_WIDE_MAX rows = up to 4 blocks of the pass) come from the hier walk — the host trie's
+        # or, round 6, the device trie's workgroup kernel (multi-word row masks); the one-branch walk keeps the 64-row cap
+        wide_ok = fmt == 'hier' and bool(getattr(self.engine, 'max_blocks', 0))
         cap_rows = min(_lib.LA_TREE_WIDE_MAX, 64 * int(self.engine.max_blocks)) if wide_ok else _lib.LA_TREE_MAX      # a tree fits one pass
         if decoding_kwargs.get('per_sample_budget', False):
             # every sample gets a decoding_length-token tree (bat_get divides its argument by the batch size once)
@@ -68,14 +68,14 @@ class LookaheadPreTrainedModel(object):
         elif decoding_kwargs.get('device_trie', False) and fmt == 'one':
             # one greedy chain per sample from one launch (la_trie_one_get_dev2); budget rule of bat_get (:534-541)
             per = sub // len(qids)
-            got = self._device_trie(decoding_kwargs['_n_samples']).one_get(
+            got = self._device_trie(decoding_kwargs['_n_samples'], narrow=True).one_get(
                 qids, idxs=batch_indices, decoding_length=per, branch_length=branch_length, mode=mode)
             drafts = [(np.asarray(g[0], dtype=np.int32), np.asarray(g[1], dtype=np.uint64), g[2]) for g in got]
         elif decoding_kwargs.get('device_trie', False) and fmt == 'hier':
-            # the drafts of ALL active samples from one launch over the incremental device mirror of the trie (one wavefront per
-            # sample, its own input-frequency plane): no host trie query on the step's critical path.  Same budget rule as
+            # the drafts of ALL active samples from one launch over the incremental device mirror of the trie (one workgroup per
+            # sample, its own input-frequency plane; per-sample budgets above 64 rows come back with multi-word row masks): no host trie query on the step's critical path.  Same budget rule as
             # bat_get (lookahead_cache.py:534-541): per sample sub // bs rows, min_output_size = max(per // 2, 1).
-            per = sub // len(qids)
+            per = min(sub // len(qids), _lib.LA_TREE_WIDE_MAX)
             got = self._device_trie(decoding_kwargs['_n_samples']).hier_get(
                 qids, idxs=batch_indices, decoding_length=per, branch_length=branch_length, min_input_size=0,
                 min_output_size=max(per // 2, 1), mode=mode)
@@ -88,14 +88,16 @@ class LookaheadPreTrainedModel(object):
                                 'hit_sizes': [d[2] for d in drafts], 'batch_indices': batch_indices})
         return [(d[0], d[1]) for d in drafts]
 
-    def _device_trie(self, n_samples, updates=False):
+    def _device_trie(self, n_samples, updates=False, narrow=False):
         """DeviceTrie over self.lookahead_cache with one input-frequency plane per batch index (rebuilt when the cache object or
         the batch size changes).  updates=True (the chained loop with device-side stream_put) adds the token -> root table and the
-        block capacities; without it a sync() patch carries no root-index pass (vocab-sized memset + kernel + meta copy)."""
+        block capacities; without it a sync() patch carries no root-index pass (vocab-sized memset + kernel + meta copy).
+        narrow=True (the chained step, the one-branch walk): a mirror whose result block grew to 256 rows per query (it served trees
+        wider than a block) is replaced — those consumers read 64-row blocks."""
         from .device_trie import DeviceTrie
         dt = getattr(self, '_dev_trie', None)
         if dt is None or dt.cache is not self.lookahead_cache or len(dt.idxs) < n_samples or dt._revoked or \
-                (updates and not dt.put_vocab):
+                (updates and not dt.put_vocab) or (narrow and dt.rows != 64):
             dt = self._dev_trie = DeviceTrie(self.lookahead_cache, idxs=list(range(n_samples)), device=self.engine.device,
                                              put_vocab=self.engine.shape.vocab if updates else None)
         return dt
@@ -175,7 +177,7 @@ class LookaheadPreTrainedModel(object):
         # :713), never more than one pass can give it (lookahead_prepare_inputs_for_generation: 64 rows unless the host trie's hier
         # walk feeds a multi-block engine); a verify block is reserved whole
         _fmt = str(decoding_kwargs.get('decoding_mode', 'hier')).split('_')[0]
-        _wide_ok = _fmt == 'hier' and not decoding_kwargs.get('device_trie', False) and bool(getattr(eng, 'max_blocks', 0))
+        _wide_ok = _fmt == 'hier' and bool(getattr(eng, 'max_blocks', 0))
         _cap_rows = min(_lib.LA_TREE_WIDE_MAX, 64 * int(eng.max_blocks)) if _wide_ok else _lib.LA_TREE_MAX
         _per = max(min(int(decoding_length), _cap_rows), _lib.LA_TREE_MAX)
         assert stop_max_length + _per + 1 <= cap, f'engine KV capacity {cap} per slot is too small'
@@ -245,9 +247,16 @@ class LookaheadPreTrainedModel(object):
                 first = eng.mprefill_many(prompts) if multi else eng.bprefill_many(prompts)
             next_token_list = [[first[i]] for i in range(bs)]
             dmode = decoding_kwargs.get('decoding_mode', 'hier')
-            chained = bool(decoding_kwargs.get('device_trie', False)) and multi and not sequential and streamer is None and \
+            # decoding_kwargs['device_trie']: True / False, or absent = AUTO (round 6): the on-GPU trie chained in front of the verify pass
+            # from 8 sequences per GPU on, where one launch of the workgroup-per-query kernel (~120 us whatever the batch) beats the
+            # host's per-sample queries + input upload (Mistral-7B bs=8: 9.58 vs 9.62 ms per step, profiles/r06_device_trie_wg.txt)
+            chain_ok = multi and not sequential and streamer is None and \
                 bool(decoding_kwargs.get('per_sample_budget', False)) and dmode.split('_')[0] in ('hier', 'one') and \
+                int(decoding_length) <= _lib.LA_TREE_MAX and \
                 not decoding_kwargs.get('debug_lookahead', False)
+            if decoding_kwargs.get('device_trie', None) is None:
+                decoding_kwargs['device_trie'] = bool(chain_ok and bs >= 8 and gather is None and dmode.split('_')[0] == 'hier')
+            chained = bool(decoding_kwargs['device_trie']) and chain_ok
             # device_trie_update (default on with the chained device trie): the trie UPDATE of every step runs on the device as well
             dev_put = chained and bool(decoding_kwargs.get('device_trie_update', True)) and branch_length + 1 <= 64
             put_on_device, buffers_loaded = False, False
@@ -296,7 +305,7 @@ class LookaheadPreTrainedModel(object):
                 if not batch_indices:
                     break
                 if chained:
-                    dt0 = self._device_trie(decoding_kwargs['_n_samples'], dev_put)
+                    dt0 = self._device_trie(decoding_kwargs['_n_samples'], dev_put, narrow=True)
                     if replay_due is not None and (len(batch_indices) > eng.max_blocks or full_image_due):
                         # several engine passes per step, or the host image outgrew the device's: replay first, then a synced query
                         dt0.replay(replay_due, branch_length + 1, calls=replay_calls)
@@ -310,7 +319,7 @@ class LookaheadPreTrainedModel(object):
                     per = min(decoding_length, _lib.LA_TREE_MAX)
                     dm = decoding_kwargs.get('decoding_mode', 'hier')
                     mode_q = (dm if '_' in dm else dm + '_mix').split('_')[1]
-                    dt = self._device_trie(decoding_kwargs['_n_samples'], dev_put)
+                    dt = self._device_trie(decoding_kwargs['_n_samples'], dev_put, narrow=True)
                     with torch.cuda.stream(eng.stream):
                         if dm.split('_')[0] == 'one':
                             dt.one_get_dev(qids, idxs=batch_indices, decoding_length=per, branch_length=branch_length, mode=mode_q,
@@ -412,7 +421,7 @@ class LookaheadPreTrainedModel(object):
                     decoding_kwargs['dls'].append(width)
                     decoding_kwargs['edls'].append(len(next_token_list[k]))
             if replay_due is not None:                                              # the last step's update (the loop ended before another launch)
-                self._device_trie(decoding_kwargs['_n_samples'], dev_put).replay(replay_due, branch_length + 1, calls=replay_calls)
+                self._device_trie(decoding_kwargs['_n_samples'], dev_put, narrow=True).replay(replay_due, branch_length + 1, calls=replay_calls)
                 replay_due = None
             run_deferred_put()
             if gather is not None:

@@ -60,12 +60,17 @@ for algo in ('wave', 'wg'):
         us = lambda a, b: (st[:, b] - st[:, a]) / 100.0
         ok = st[:, 4] > 0
         if ok.sum() == 0: continue
-        extra = ''
         if algo == 'wg':
-            extra = f'  entries median {np.median(st[ok,7] >> 32):.0f} max {(st[ok,7] >> 32).max()}  candidates median {np.median(st[ok,7] & 0xffffffff):.0f} max {(st[ok,7] & 0xffffffff).max()}'
-        print(f'{algo:4s} {name} phases over {int(ok.sum())} of {B} queries (us, median / max): match {np.median(us(0,1)[ok]):.1f}/{us(0,1)[ok].max():.1f}  '
-              f'expand {np.median(us(1,2)[ok]):.1f}/{us(1,2)[ok].max():.1f}  cut-offs {np.median(us(2,3)[ok]):.1f}/{us(2,3)[ok].max():.1f}  '
-              f'order+emit {np.median(us(3,4)[ok]):.1f}/{us(3,4)[ok].max():.1f}  total {np.median(us(0,4)[ok]):.1f}/{us(0,4)[ok].max():.1f} | live rows median {np.median(st[ok,5]):.0f} max {st[ok,5].max()}  emitted median {np.median(st[ok,6]):.0f}{extra}')
+            rows, nout = st[:, 5] & 0xffffffff, st[:, 5] >> 32
+            print(f'wg   {name} phases over {int(ok.sum())} of {B} queries (us, median / max): match {np.median(us(0,1)[ok]):.1f}/{us(0,1)[ok].max():.1f}  '
+                  f'expand {np.median(us(1,2)[ok]):.1f}/{us(1,2)[ok].max():.1f}  cut-offs {np.median(us(2,3)[ok]):.1f}/{us(2,3)[ok].max():.1f}  '
+                  f'compact {np.median(us(3,6)[ok]):.1f}/{us(3,6)[ok].max():.1f}  order+emit {np.median(us(6,4)[ok]):.1f}/{us(6,4)[ok].max():.1f}  '
+                  f'total {np.median(us(0,4)[ok]):.1f}/{us(0,4)[ok].max():.1f} | live rows median {np.median(rows[ok]):.0f} max {rows[ok].max()}  emitted median {np.median(nout[ok]):.0f}'
+                  f'  entries median {np.median(st[ok,7] >> 32):.0f} max {(st[ok,7] >> 32).max()}  candidates median {np.median(st[ok,7] & 0xffffffff):.0f} max {(st[ok,7] & 0xffffffff).max()}')
+        else:
+            print(f'wave {name} phases over {int(ok.sum())} of {B} queries (us, median / max): match {np.median(us(0,1)[ok]):.1f}/{us(0,1)[ok].max():.1f}  '
+                  f'scan {np.median(us(1,2)[ok]):.1f}/{us(1,2)[ok].max():.1f}  cut-offs {np.median(us(2,3)[ok]):.1f}/{us(2,3)[ok].max():.1f}  '
+                  f'ordered DFS {np.median(us(3,4)[ok]):.1f}/{us(3,4)[ok].max():.1f}  total {np.median(us(0,4)[ok]):.1f}/{us(0,4)[ok].max():.1f} | live rows median {np.median(st[ok,5]):.0f} max {st[ok,5].max()}  emitted median {np.median(st[ok,6]):.0f}')
 # wide trees (workgroup kernel only)
 dev = DeviceTrie(cache, idx=0, algo='wg', max_rows=256)
 for dl, bl in ((128, 32), (256, 32)):

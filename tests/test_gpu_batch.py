@@ -278,14 +278,15 @@ def test_batch_lookahead_equals_per_sample_greedy_decisive():
     assert g2[:, P:P + 40].tolist() == [x[:40] for x in greedy]
 
 
-@pytest.mark.parametrize('sequential', [False, True])
-def test_batch_lookahead_with_wide_per_sample_trees_equals_greedy(sequential):
+@pytest.mark.parametrize('sequential,device_trie', [(False, False), (True, False), (False, True)])
+def test_batch_lookahead_with_wide_per_sample_trees_equals_greedy(sequential, device_trie):
     """Per-sample trees wider than a 64-row block in a batch (the reference's bat_get gives a sample (decoding_length // bs) // bs
     rows of any size, lookahead_cache.py:534-541; its best published setting is decoding_length=128, README.md:100): drafts from
     the host trie's hier walk with multi-word row masks, every sample's tree as ceil(T / 64) blocks of one multi-block pass
     (LlamaVerifyEngine.mstep_trees).  Decisive weights: the output equals plain greedy decoding, the second request (run on the
     trie the first one grew) drafts trees of more than 64 rows, and the accept lengths exceed what a 64-row tree gives at
-    branch_length 40.  sequential: the same through a processor list (forward-only pass, host walk, la_llama_mcommit)."""
+    branch_length 40.  sequential: the same through a processor list (forward-only pass, host walk, la_llama_mcommit).
+    device_trie (round 6): the same drafts from the workgroup-per-query device kernel (uint64[T][4] row masks), same dls / edls."""
     shape = tiny_shape()
     sd = random_weights(shape, seed=2, device='cpu', decisive=True)
     B, P, n_new = 3, 40, 150
@@ -298,7 +299,8 @@ def test_batch_lookahead_with_wide_per_sample_trees_equals_greedy(sequential):
     if sequential:
         from transformers import LogitsProcessorList, MinLengthLogitsProcessor
         procs = LogitsProcessorList([MinLengthLogitsProcessor(1, eos_token_id=1, device=str(DEV))])      # a no-op list: takes the sequential path
-    dk = {'use_lookahead': True, 'decoding_length': 128, 'branch_length': 40, 'stop_words': {}, 'per_sample_budget': True}
+    dk = {'use_lookahead': True, 'decoding_length': 128, 'branch_length': 40, 'stop_words': {}, 'per_sample_budget': True,
+          'device_trie': device_trie}
     from tests.tiny_model import noisy_copies
     for b in range(B):                  # bench.py's warm-up: noisy copies of the continuation -> many branches below every prefix
         for c in noisy_copies(ids[b, -2:].tolist() + truth[b], 10, 0.3, shape.vocab, seed=70 + b):

@@ -563,10 +563,13 @@ def test_partial_accept_run_equals_reference_golden(native, suffix):
     assert partial >= 20
 
 
-def test_wide_tree_run_equals_reference_golden_dl128():
+@pytest.mark.parametrize('device_trie', [False, True])
+def test_wide_tree_run_equals_reference_golden_dl128(device_trie):
     """The reference's best published setting, decoding_length=128 / branch_length=32 (lookahead/README.md:100), recorded from the
     REFERENCE loop by oracle/gen_golden_noisy.py: trees of up to 128 rows (two chained blocks of one multi-block pass, cross-block
-    ancestor masks), up to 33 tokens accepted per step — reproduced token for token (tokens, dls, edls) on the GPU."""
+    ancestor masks), up to 33 tokens accepted per step — reproduced token for token (tokens, dls, edls) on the GPU.  device_trie
+    (round 6): the drafts of every step come from the workgroup-per-query device kernel (la_trie_wg.hip, 128-row trees with
+    uint64[T][4] row masks) over the incremental mirror instead of the host trie."""
     from tests.tiny_model import tiny_decisive_weights
     g = np.load(os.path.join(GOLDEN, 'llama_tiny_noisy_dl128_bf16.npz'))
     dl, bl = int(g['decoding_length']), int(g['branch_length'])
@@ -579,12 +582,14 @@ def test_wide_tree_run_equals_reference_golden_dl128():
     wide_steps = 0
     for r in range(int(g['n_runs'])):
         dk = {'use_lookahead': True, 'decoding_mode': 'hier', 'decoding_length': dl, 'branch_length': bl, 'max_query_length': 2,
-              'stop_words': {}}
+              'stop_words': {}, 'device_trie': device_trie}
         out = model.lookahead_generation(torch.tensor([prompt]), stopping_criteria=max_length, eos_token_id=2, pad_token_id=0,
                                          return_dict_in_generate=True, decoding_kwargs=dk)
         assert out.sequences[0].tolist() == g[f'r{r}_sequences'].tolist(), f'request {r}'
         assert out.kwargs['dls'] == g[f'r{r}_dls'].tolist() and out.kwargs['edls'] == g[f'r{r}_edls'].tolist(), f'request {r}'
         wide_steps += sum(d > 64 for d in out.kwargs['dls'])
+        if device_trie:
+            assert model._dev_trie.rows == 256 and model._dev_trie.algo == 'wg' and model._dev_trie.stats['patches'] > 5
     assert wide_steps >= 10 and max(g['r1_edls'].tolist()) == bl + 1
     with pytest.raises(ValueError):         # a 64-row engine says so instead of truncating the tree
         LlamaForCausalLM(tiny_shape(), tiny_decisive_weights(0, torch.bfloat16), max_length=512).lookahead_generation(

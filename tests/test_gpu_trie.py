@@ -63,8 +63,12 @@ def test_device_hier_get_replays_reference_trace(path, algo):
     assert checked >= 20
 
 
-def test_workgroup_hier_get_wide_trees_match_host_on_large_forest_with_dead_nodes():
-    """the forest of tests/test_trie_wg_model.py (100 x 256-token warm-up, a prompt whose input frequencies were reset = dead nodes, a
+@pytest.mark.parametrize('limits', [(0, 0, 0), (0, 0, -1), (16, 8, -1), (64, 100, 20)], ids=['default', 'chains-256-threads', 'scratch-levels-and-candidates', 'mixed'])
+def test_workgroup_hier_get_wide_trees_match_host_on_large_forest_with_dead_nodes(limits):
+    """limits = la_trie_query.lds_level_cap / lds_cand_cap / one_wave_cap: the library's (LDS level buffers, candidates ordered by the chain
+    form, by one wave up to 256 of them); the chain form by all 256 threads; levels above 16 entries and candidate sets above 8 through the
+    global scratch (the LEVEL form of the ordering: tests/trie_wg_model.py); a mix.
+    The forest of tests/test_trie_wg_model.py (100 x 256-token warm-up, a prompt whose input frequencies were reset = dead nodes, a
     live prompt): 120 queries x 4 mode settings x budgets {16, 64, 128, 256} in batched launches against the host trie, multi-word
     row masks included; the 1-token queries walk subtrees of thousands of entries (global-scratch levels / candidate sets)."""
     rng = random.Random(1)
@@ -87,6 +91,7 @@ def test_workgroup_hier_get_wide_trees_match_host_on_large_forest_with_dead_node
         k = rng.randrange(1, len(ph))
         queries.append(ph[max(0, k - 2):k] if rng.random() < 0.6 else ph[k - 1:k] if rng.random() < 0.5 else [rng.randrange(3, 2000), rng.randrange(3, 2000)])
     dev = DeviceTrie(cache, idx=0, max_rows=256)
+    dev.wg_limits = limits
     n_wide = 0
     for mode, mi, mo in [('mix', 0, 32), ('mix', 2, 8), ('output', 0, 16), ('input', 1, 0)]:
         for dl, bl in [(16, 6), (64, 12), (128, 32), (256, 20)]:
