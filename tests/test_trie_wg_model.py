@@ -1,6 +1,6 @@
 # -*- coding: utf-8 -*-
 """CPU: the level-synchronous retrieval algorithm of the workgroup-per-query device kernel (tests/trie_wg_model.py = the model
-csrc/la_trie_dev.hip::k_trie_hier_get_wg implements) replayed over every golden reference trace — every recorded hier_get, trees wider
+csrc/la_trie_wg.hip::k_trie_hier_get_wg implements, level form and chain form) replayed over every golden reference trace — every recorded hier_get, trees wider
 than 64 rows included — and differentially against the native host trie on a large forest with dead (reset) input nodes."""
 import os
 import random
@@ -13,8 +13,9 @@ from tests import trie_replay as tr
 from tests import trie_wg_model as wg
 
 
+@pytest.mark.parametrize('form', ['levels', 'chains'])
 @pytest.mark.parametrize('path', tr.trace_files(), ids=os.path.basename)
-def test_level_synchronous_model_replays_reference_trace(path):
+def test_level_synchronous_model_replays_reference_trace(path, form):
     trace = tr.load(path)
     init = trace['init']
     cache = LookaheadCache(eos_ids=init['eos_ids'], stop_words={w: 1 for w in init['stop_words']},
@@ -31,7 +32,7 @@ def test_level_synchronous_model_replays_reference_trace(path):
                 continue
             img = wg.image_of(cache, op['idx'])
             got = wg.hier_get(img, list(op['tokens']), op['decoding_length'], op['branch_length'], op['min_input_size'], op['min_output_size'],
-                              op['mode'], stop_words=init['stop_words'])
+                              op['mode'], stop_words=init['stop_words'], form=form)
             exp = op['out']
             ctx = f"op {i}: { {k: v for k, v in op.items() if k != 'out'} }"
             assert got[0] == exp['ids'], ctx
@@ -50,7 +51,8 @@ def test_level_synchronous_model_replays_reference_trace(path):
     assert checked >= 10
 
 
-def test_level_synchronous_model_equals_host_trie_with_dead_nodes_cutoffs_and_wide_trees():
+@pytest.mark.parametrize('form', ['levels', 'chains'])
+def test_level_synchronous_model_equals_host_trie_with_dead_nodes_cutoffs_and_wide_trees(form):
     """large forest (100 x 256-token warm-up), an input-mode prompt in plane 0 and a SECOND prompt whose input frequencies were reset
     (dead nodes that the cut-off rule still emits when the subtree fits the budget): 120 queries x {mix, output, input} x budgets
     {16, 64, 128, 256}."""
@@ -79,7 +81,7 @@ def test_level_synchronous_model_equals_host_trie_with_dead_nodes_cutoffs_and_wi
         for dl, bl in [(16, 6), (64, 12), (128, 32), (256, 20)]:
             for qy in queries[:60 if dl > 64 else 120]:
                 ids, mask, sizes = cache.hier_get(qy, decoding_length=dl, branch_length=bl, min_input_size=mi, min_output_size=mo if dl <= 64 else dl // 2, mode=mode, idx=0)
-                got = wg.hier_get(img, qy, dl, bl, mi, mo if dl <= 64 else dl // 2, mode)
+                got = wg.hier_get(img, qy, dl, bl, mi, mo if dl <= 64 else dl // 2, mode, form=form)
                 assert got[0] == [int(x) for x in ids], (mode, dl, qy)
                 assert got[1] == tr.rows_of(mask)[:len(got[0])], (mode, dl, qy)
                 assert [int(x) for x in got[2]] == [int(x) for x in sizes], (mode, dl, qy)

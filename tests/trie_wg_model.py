@@ -1,5 +1,5 @@
 # -*- coding: utf-8 -*-
-"""CPU model of the workgroup-per-query device retrieval (csrc/la_trie_dev.hip, k_trie_hier_get_wg) over the mirror image arrays.
+"""CPU model of the workgroup-per-query device retrieval (csrc/la_trie_wg.hip, k_trie_hier_get_wg) over the mirror image arrays.
 
 LookaheadCache.hier_get (lookahead_cache.py:408-439) with Tree.get / _match / _dfs_get_freqs / _ravel (:65-154, 224-293) restated as the
 LEVEL-SYNCHRONOUS passes the HIP kernel runs — no recursion, no ordered DFS:
@@ -41,8 +41,12 @@ def _select_desc(vals, r):
     return sorted(vals, reverse=True)[r]
 
 
-def tree_get(t, cur, root, q_rest_last, nrest, max_size, max_length, min_in, min_out, mode):
-    """Tree.get below the matched node `cur` -> (ids, parent positions, sizes); cur < 0 or childless: the single-row answer."""
+def tree_get(t, cur, root, q_rest_last, nrest, max_size, max_length, min_in, min_out, mode, form='levels'):
+    """Tree.get below the matched node `cur` -> (ids, parent positions, sizes); cur < 0 or childless: the single-row answer.
+    form: 'levels' = S4..S6 level by level (the kernel's global-scratch path); 'chains' = the same recurrences unrolled along each entry's
+    ancestor chain (the kernel's LDS path, order_emit_chains): rank within the sibling run, lb = sum over the chain of (1 + rank),
+    ok = lb(parent) < max_size, size = weights of the ok entries below (pruned: BIGC), position = sum over the chain of (1 + sizes of the
+    better siblings)."""
     if cur < 0 or t.ccount[cur] == 0:
         return [q_rest_last if nrest > 0 else int(t.tok[root])], [-1], [0, 0]
     # ---- S2: level-synchronous expansion; entries: node, par (entry index or -1), k, fi, fo, inF; levels: [(start, end)]
@@ -107,6 +111,9 @@ def tree_get(t, cur, root, q_rest_last, nrest, max_size, max_length, min_in, min
 
     def run_of_parent(e):
         return top_run if par[e] < 0 else crun[par[e]]
+
+    if form == 'chains':
+        return _order_chains(t, node, par, fi, fo, fm, levels, top_run, crun, skip, better, max_size, max_length, q_rest_last, nrest, root)
     # ---- S4: ok / rank / lower bound / prune, top-down
     ok, pruned, lb = [False] * n, [False] * n, [0] * n
     for d, (s, e_) in enumerate(levels, start=1):
@@ -156,7 +163,62 @@ def tree_get(t, cur, root, q_rest_last, nrest, max_size, max_length, min_in, min
     return ids, ppos, sizes
 
 
-def hier_get(t, q, decoding_length, branch_length, min_in, min_out, mode, stop_words=()):
+def _order_chains(t, node, par, fi, fo, fm, levels, top_run, crun, skip, better, max_size, max_length, q_rest_last, nrest, root):
+    n = len(node)
+    BIGC = 1 << 16
+    depth = [0] * n
+    for d, (s_, e_) in enumerate(levels, start=1):
+        for e in range(s_, e_):
+            depth[e] = d
+    cand = [depth[e] <= max_length and not skip(e) for e in range(n)]
+
+    def chain(e):                                   # e and its ancestors, or None when one of them is no candidate (an orphan)
+        out = []
+        while e >= 0:
+            if not cand[e]:
+                return None
+            out.append(e)
+            e = par[e]
+        return out
+    rank = [0] * n
+    for e in range(n):
+        if cand[e] and (par[e] < 0 or cand[par[e]]):
+            r0, rn = top_run if par[e] < 0 else crun[par[e]]
+            rank[e] = sum(1 for j in range(r0, r0 + rn) if j != e and cand[j] and better(j, e))
+    lb, ok, pruned = [0] * n, [False] * n, [False] * n
+    for e in range(n):
+        ch = chain(e) if cand[e] else None
+        if ch is None:
+            continue
+        lb[e] = sum(1 + rank[x] for x in ch)
+        ok[e] = lb[e] - 1 - rank[e] < max_size
+        pruned[e] = lb[e] >= max_size
+    size = [0] * n
+    for e in range(n):
+        if ok[e]:
+            for x in chain(e):
+                size[x] += BIGC if pruned[e] else 1
+    before = [0] * n
+    for e in range(n):
+        if ok[e]:
+            r0, rn = top_run if par[e] < 0 else crun[par[e]]
+            before[e] = sum(size[j] for j in range(r0, r0 + rn) if j != e and cand[j] and better(j, e))
+    pos = [0] * n
+    for e in range(n):
+        if ok[e]:
+            pos[e] = sum(1 + before[x] for x in chain(e))
+    emit = [e for e in range(n) if ok[e] and pos[e] < max_size]
+    ids, ppos, sizes = [0] * (1 + len(emit)), [-1] * (1 + len(emit)), [0, 0]
+    ids[0] = q_rest_last if (nrest > 0 and q_rest_last != 0) else int(t.tok[root])
+    for e in emit:
+        ids[pos[e]] = int(t.tok[node[e]])
+        ppos[pos[e]] = pos[par[e]] if par[e] >= 0 else -1
+        sizes[0] += fi[e] > 0
+        sizes[1] += fo[e] > 0
+    return ids, ppos, sizes
+
+
+def hier_get(t, q, decoding_length, branch_length, min_in, min_out, mode, stop_words=(), form='levels'):
     """-> (ids, row masks as Python ints, sizes list) like LookaheadCache.hier_get (masks as per-row integers)."""
     mode = MODE[mode] if isinstance(mode, str) else mode
     nq = len(q)
@@ -182,7 +244,7 @@ def hier_get(t, q, decoding_length, branch_length, min_in, min_out, mode, stop_w
             cur = ch if live else -1
             if cur < 0:
                 break
-        ids, ppos, sizes = tree_get(t, cur, root, q[-1], nrest, decoding_length, branch_length, min_in, min_out, mode)
+        ids, ppos, sizes = tree_get(t, cur, root, q[-1], nrest, decoding_length, branch_length, min_in, min_out, mode, form=form)
         out = (ids, ppos, sizes)
         if len(ids) >= branch_length:
             break
