@@ -27,6 +27,8 @@ the reference's transformers CPU path) run on this box's host cores on the full 
 import argparse
 import json
 import os
+if any(os.environ.get(_k) for _k in ('LA_PF_KIB', 'LA_DEBUG', 'LA_MB_KS2')):
+    os.environ.setdefault('LA_LAB_BUILD', '1')      # kernel-lab knobs exist in the lab build only (csrc/la_knobs.h): the A/B runs take it as the process library
 import sys
 import time
 
@@ -133,8 +135,10 @@ def host_batch_drafts(cache, tails, idxs, DL, BL, ubls):
 
 def _pf_setting():
     """(KiB per consumer workgroup, start delay, gate/up tail KiB) of the weight prefetch in effect (library default or LA_PF_KIB)."""
-    from painlessinferenceacceleration_amd._lib import lab_get
-    return lab_get(7), lab_get(8), lab_get(9)
+    from painlessinferenceacceleration_amd import _lib
+    if not _lib.LAB_BUILD:               # the product library: the constexpr defaults of csrc/la_knobs.h (prefetch off)
+        return 0, 0, 0
+    return _lib.lab_get(7), _lib.lab_get(8), _lib.lab_get(9)
 
 
 _RDZV_KEYS = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'GROUP_WORLD_SIZE', 'ROLE_RANK', 'ROLE_WORLD_SIZE',
@@ -442,7 +446,7 @@ def main():
         # flow on ONE device, with the collectives on host tensors; the measured configuration is always nccl (= RCCL)
         backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
+            dist.init_process_group('nccl', device_id=torch.device('cuda:0' if os.environ.get('BENCH_SHARE_GPU') else f'cuda:{local_rank}'))
         else:
             dist.init_process_group(backend)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
@@ -455,6 +459,9 @@ def main():
     from painlessinferenceacceleration_amd.modeling_llama import LlamaForCausalLM
     from painlessinferenceacceleration_amd.modeling_llama_batch import LlamaForCausalLM as BatchLlama
 
+    if any(os.environ.get(k) for k in ('LA_PF_KIB', 'LA_DEBUG', 'LA_MB_KS2')):
+        from painlessinferenceacceleration_amd import _lib as _libmod
+        assert _libmod.LAB_BUILD, 'LA_PF_KIB / LA_DEBUG / LA_MB_KS2 set kernel-lab knobs: the lab build must be the process library (LA_LAB_BUILD=1)'
     # measurement override of the library's idle-window prefetch default (la_debug_set keys 7 / 8 / 9, scripts/gpu_pf_ab.py)
     if os.environ.get('LA_PF_KIB') is not None:
         from painlessinferenceacceleration_amd._lib import check as _check, lab_set as _lab_set      # every loaded build (bf16 / fp16)

@@ -8,8 +8,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblookahead_hip.so")              # bfloat16 build (BASELINE's dtype; also serves the dtype-free trie calls)
-LIB_PATH_F16 = os.path.join(_HERE, "liblookahead_hip_f16.so")      # float16 build: the same sources compiled with -DLA_DTYPE=1
+# The PRODUCT libraries: every lab knob a constexpr default, no la_lab_* entry point (csrc/la_knobs.h).  The LAB builds of the same sources
+# (-DLA_LAB=1) carry the measurement knobs / A/B switches of include/lookahead_hip_lab.h: engines take them with lab=True (the variant tests),
+# or the whole process with LA_LAB_BUILD=1 in the environment (the A/B scripts under scripts/, bench.py with LA_DEBUG / LA_PF_KIB).
+LAB_BUILD = os.environ.get('LA_LAB_BUILD', '') not in ('', '0')
+LAB_PATH = os.path.join(_HERE, "liblookahead_hip_lab.so")
+LAB_PATH_F16 = os.path.join(_HERE, "liblookahead_hip_lab_f16.so")
+LIB_PATH = LAB_PATH if LAB_BUILD else os.path.join(_HERE, "liblookahead_hip.so")       # bfloat16 build (BASELINE's dtype; also serves the dtype-free trie calls)
+LIB_PATH_F16 = LAB_PATH_F16 if LAB_BUILD else os.path.join(_HERE, "liblookahead_hip_f16.so")      # float16 build: the same sources compiled with -DLA_DTYPE=1
 LA_DTYPE_BF16, LA_DTYPE_F16 = 0, 1
 
 LA_OK = 0
@@ -233,8 +239,8 @@ LAB_PROTOTYPES = {
     "la_lab_set_ptr": (i32, i32, vp),
 }
 
-def _bind(dll, path, want_dtype):
-    for _n, _sig in list(PROTOTYPES.items()) + list(LAB_PROTOTYPES.items()):
+def _bind(dll, path, want_dtype, lab=False):
+    for _n, _sig in list(PROTOTYPES.items()) + (list(LAB_PROTOTYPES.items()) if lab else []):
         _proto(_n, _sig[0], *_sig[1:], dll=dll)
     if dll.la_abi_version() != ABI_VERSION or dll.la_abi_dtype() != want_dtype:
         raise ImportError(f"{path} implements ABI {dll.la_abi_version()} / dtype {dll.la_abi_dtype()}, the bindings expect {ABI_VERSION} / "
@@ -242,23 +248,39 @@ def _bind(dll, path, want_dtype):
     return dll
 
 
-_bind(lib, LIB_PATH, LA_DTYPE_BF16)
+_bind(lib, LIB_PATH, LA_DTYPE_BF16, lab=LAB_BUILD)
 _lib_f16 = None
+_lab_libs = {}       # dtype name -> lab build loaded beside the product libraries (LAB_BUILD: the process libraries themselves)
 _knobs = {}          # (entry point, key) -> value: every knob set through lab_set / debug_set, replayed into a library loaded later
 
 
 def loaded_libs():
-    """every liblookahead_hip build this process has loaded (bf16 always; fp16 once an fp16 engine exists)"""
-    return [d for d in (lib, _lib_f16) if d is not None]
+    """every liblookahead_hip build this process has loaded (bf16 always; fp16 once an fp16 engine exists; lab builds once asked for)"""
+    out = [d for d in (lib, _lib_f16) if d is not None]
+    return out + [d for d in _lab_libs.values() if d not in out]
 
 
-def _set_everywhere(fn, getter, key, value):
-    """One knob on EVERY loaded build, all or nothing: a build that refuses the value must not leave the builds before it on the new value
+def loaded_lab_libs():
+    return [d for d in loaded_libs() if getattr(d, '_is_lab', False)]
+
+
+def _replay(dll, path, lab):
+    """knobs set before this build was loaded must not be dropped silently by it"""
+    for (fn, key), value in _knobs.items():
+        if fn.startswith('la_lab') and not lab:
+            continue
+        rc = getattr(dll, fn)(key, value)
+        if rc != LA_OK:
+            raise LookaheadHipError(f'{path}: {fn}({key}, {value}) replayed from the builds loaded earlier was refused (status {rc})')
+
+
+def _set_everywhere(fn, getter, key, value, libs):
+    """One knob on EVERY build of `libs`, all or nothing: a build that refuses the value must not leave the builds before it on the new value
     (bf16 and fp16 engines of one process would then run different kernels).  The libraries already set are rolled back to the value they
     reported before (la_lab_get; la_debug_set has no getter: its only key is replayed from the recorded value, default 0)."""
     key, value = int(key), int(value)
     done = []
-    for d in loaded_libs():
+    for d in libs:
         before = getattr(d, getter)(key) if getter else _knobs.get((fn, key), 0)
         r = getattr(d, fn)(key, value)
         if r != LA_OK:
@@ -270,21 +292,42 @@ def _set_everywhere(fn, getter, key, value):
     return LA_OK
 
 
+def lab_lib_for(dtype):
+    """The LAB build for a torch dtype (liblookahead_hip_lab.so / _lab_f16.so: the same sources with -DLA_LAB=1), loaded on first use beside
+    the product library — its own knob storage, graph epoch and kernels; engines created with lab=True run on it."""
+    name = str(dtype).replace('torch.', '')
+    if LAB_BUILD:
+        return lib_for(dtype)
+    if name not in ('bfloat16', 'float16'):
+        raise ValueError(f'no liblookahead_hip build for dtype {dtype}: bfloat16 and float16 exist')
+    if name not in _lab_libs:
+        path = LAB_PATH if name == 'bfloat16' else LAB_PATH_F16
+        if not os.path.exists(path):
+            raise ImportError(f'{path} is missing: build it with `bash {os.path.join(_HERE, "csrc", "build.sh")}` (lab builds are skipped under LA_SKIP_LAB=1)')
+        dll = _bind(_load(path), path, LA_DTYPE_BF16 if name == 'bfloat16' else LA_DTYPE_F16, lab=True)
+        dll._is_lab = True
+        _replay(dll, path, True)
+        _lab_libs[name] = dll
+    return _lab_libs[name]
+
+
 def lab_set(key, value):
-    """la_lab_set on EVERY loaded build (each .so has its own knob globals and graph epoch) and on builds loaded later — a knob
-    set before an fp16 engine exists must not be silently ignored by it.  All or nothing: -> the status of the library that refused
-    (the others are rolled back)."""
-    return _set_everywhere('la_lab_set', 'la_lab_get', key, value)
+    """la_lab_set on EVERY loaded lab build (each .so has its own knob globals and graph epoch) and on lab builds loaded later — a knob
+    set before an fp16 lab engine exists must not be silently ignored by it.  The bf16 lab build is loaded if none is yet.  All or nothing:
+    -> the status of the library that refused (the others are rolled back).  The PRODUCT libraries have no knobs: an engine created without
+    lab=True (and outside LA_LAB_BUILD=1) is not affected — by construction."""
+    lab_lib_for('bfloat16')
+    return _set_everywhere('la_lab_set', 'la_lab_get', key, value, loaded_lab_libs())
 
 
 def debug_set(key, value):
     """la_debug_set (the product header's depth probe) on every loaded build, replayed like lab_set"""
-    return _set_everywhere('la_debug_set', None, key, value)
+    return _set_everywhere('la_debug_set', None, key, value, loaded_libs())
 
 
 def lab_get(key, dtype=None):
-    """la_lab_get of the build serving `dtype` (default: bf16)"""
-    return int((lib if dtype is None else lib_for(dtype)).la_lab_get(int(key)))
+    """la_lab_get of the lab build serving `dtype` (default: bf16)"""
+    return int(lab_lib_for('bfloat16' if dtype is None else dtype).la_lab_get(int(key)))
 
 
 def lib_for(dtype):
@@ -297,20 +340,21 @@ def lib_for(dtype):
         return lib
     if name == 'float16':
         if _lib_f16 is None:
-            dll = _bind(_load(LIB_PATH_F16), LIB_PATH_F16, LA_DTYPE_F16)
-            for (fn, key), value in _knobs.items():          # knobs set while only the bf16 build was loaded
-                rc = getattr(dll, fn)(key, value)
-                if rc != LA_OK:                                # a knob the bf16 build runs under must not be dropped silently by this one
-                    raise LookaheadHipError(f'{LIB_PATH_F16}: {fn}({key}, {value}) replayed from the bf16 build was refused (status {rc})')
+            dll = _bind(_load(LIB_PATH_F16), LIB_PATH_F16, LA_DTYPE_F16, lab=LAB_BUILD)
+            dll._is_lab = LAB_BUILD
+            _replay(dll, LIB_PATH_F16, LAB_BUILD)
             _lib_f16 = dll
         return _lib_f16
     raise ValueError(f'no liblookahead_hip build for dtype {dtype}: bfloat16 and float16 exist')
 
 
+lib._is_lab = LAB_BUILD
+
+
 def last_error() -> str:
     """Text of the last error on this thread (each loaded library keeps its own; the non-empty one is reported)."""
     out = []
-    for dll in (lib, _lib_f16):
+    for dll in loaded_libs():
         if dll is not None:
             s = dll.la_last_error()
             if s:

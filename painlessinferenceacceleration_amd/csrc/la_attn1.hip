@@ -23,6 +23,7 @@
 #include <type_traits>
 #include "la_common.h"
 #include "la_kernels.h"
+#include "la_knobs.h"
 
 #define LA_NEG (-1.0e30f)
 
@@ -306,9 +307,6 @@ __device__ __forceinline__ void attn1_rider(const PfDesc& p, int b) {
                  "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]) : "memory");
 }
 
-extern long long* g_la_dbg_times;
-int g_la_attn1_var = 0;       // la_lab_set key 18 (measurement): bit 0 = first K tile requested only after the cursor has arrived (round-4 order), bits 1-2 = force SL (1 -> 1, 2 -> 2, 3 -> 4)
-int g_la_attn_one = 1;        // la_debug_set key 17: 1 = single-launch attention on the single-sequence step (default), 0 = split + combine
 
 static int g_attn1_cus = 0;
 // one-off set-up, called from lk_gemm64r_init (never inside a stream capture): dynamic-LDS limit of the SL = 1 form, CU count

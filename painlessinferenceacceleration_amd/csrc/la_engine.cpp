@@ -11,11 +11,8 @@
 #include <atomic>
 #include "la_kernels.h"
 #include "la_mblock.h"
-extern int g_la_pf_kib, g_la_pf_delay, g_la_pf_tail_kib, g_la_graph_epoch, g_la_graph_reps, g_la_mb_ks2;
-extern int g_la_fork_pf[5], g_la_attn_ride_kib, g_la_attn_ride_delay, g_la_attn_merge_ns, g_la_oproj_probe;
-int g_la_ex_down_ks = 0;       // la_lab_set key 22: K splits of the experts' down projection in the gathered multi-block MoE step (0 = library default)
-int g_la_norm4 = 0;            // la_lab_set key 19 (measured neutral: 5.30 vs 5.37 us per launch, profiles/r04_*): 1 = residual + RMSNorm with four workgroups per row (k_row_norm4) on the single-sequence step
-int g_la_split_head_tail = 0;   // la_debug_set key 14: 1 = separate build-inputs / embed / argmax / accept / publish kernels (A/B)
+#include "la_knobs.h"
+extern int g_la_graph_epoch;
 int g_la_stop_layers = 0;     // la_debug_set key 13 (parity tests): the single-sequence step runs only the first n layers, then the final norm + lm_head
 
 extern void la_set_error(const std::string& s);
@@ -88,7 +85,6 @@ struct la_llama {
     hipEvent_t pf_fork = nullptr, pf_join = nullptr;
 };
 
-int g_la_ex_split = 0;            // la_debug_set key 16: 1 = gathered multi-block MoE with one launch per expert and stage (A/B); 4 = plan and gather as two launches (round-3 form)
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Carver {

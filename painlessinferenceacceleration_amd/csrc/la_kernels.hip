@@ -4,6 +4,7 @@
 #include "la_common.h"
 #include <type_traits>
 #include "la_kernels.h"
+#include "la_knobs.h"
 
 // ---------------------------------------------------------------------------------------------
 // Layout converters (one-off at load time / tests)
@@ -1983,27 +1984,10 @@ __global__ __launch_bounds__(256) void k_moe_accum_all(const float* __restrict__
 // launchers
 // =============================================================================================
 // measurement knobs (la_debug_set, scripts/gpu_ab.py); 0 in production
-int g_la_dbg_noepi = 0;
-int g_la_kskew = 0;
-int g_la_prio_hi = 0;         // s_setprio level of waves 4..7 in the 8-wave GEMMs (measurement knob, key 2)           // K share of waves 0..3 in 1/64ths (8-wave GEMMs); set before the step graph is captured
-long long* g_la_dbg_times = nullptr;
-int g_la_pf_kib = 0;          // idle-window weight prefetch: KiB per consumer workgroup (la_debug_set key 7; read when a step graph is captured)
-int g_la_pf_tail_kib = 0;     // tail prefetch of down_proj from the gate/up launch: KiB per workgroup (key 9)
-int g_la_attn_staged = 0;     // 1: tree attention with K/V staged through LDS once per workgroup (la_debug_set key 10)
-int g_la_graph_reps = 1;      // measurement: repetitions of the step inside the single-sequence graph (key 11)
 int g_la_graph_epoch = 0;     // bumped by la_debug_set when a capture-time knob changes: la_llama_step captures its graph again
-extern int g_la_attn_one;
-int g_la_slab_wt = 0;         // la_lab_set key 23: split-K slabs of the 64-row o_proj / down_proj stored write-through (sc1)
-int g_la_gemm_4w = 0;         // la_debug_set key 15: bit 0 = gate/up as 4 waves x 8 tile-sets (one wave per SIMD) — measurement
-int g_la_pf_delay = 0;        // s_sleep(32) rounds the prefetch workgroups wait before their first load (key 8)
 // forked weight prefetch (round 6; la_lab_set keys 26-30, KiB per consumer workgroup, 0 = off): [0] o_proj under the attention launch,
 // [1] gate/up queued behind it (runs under attention / o_proj / norm), [2] gate/up forked after o_proj (under the post-attention norm),
 // [3] next QKV / lm_head forked after down_proj (under the input norm), [4] down_proj forked after o_proj
-int g_la_fork_pf[5] = {0, 0, 0, 0, 0};
-int g_la_oproj_probe = 0;     // la_lab_set key 34 (TIMING PROBE, results are garbage): bits 0-3 = K splits of o_proj (0 = default), bit 4 = one row-block per workgroup x 8 waves, bit 5 = skip the post-attention norm launch — prices a full-K o_proj with the norm folded into gate/up (review item 1c)
-int g_la_attn_merge_ns = 0;   // la_lab_set key 33: 2 | 4 = key-split attention WITHOUT the combine launch, merged on load by o_proj (k_oproj_merge)
-int g_la_attn_ride_delay = 0; // la_lab_set key 32: s_sleep(32) rounds (~0.85 us each) the riders wait before their first load
-int g_la_attn_ride_kib = 0;   // la_lab_set key 31: KiB per o_proj workgroup pulled into L2 by rider workgroups of the single-launch attention (0 = off)
 
 #define LA_CAND_LDS (8 * LA_TB * 8)      // lm_head: [8 waves][64 tokens] (value, index) candidates behind the reduction buffer
 // leading scalar kernel arguments of the GEMM kernels (kernarg preload, see k_gemm64 / k_gemm64r)

@@ -15,6 +15,7 @@
 #include <type_traits>
 #include "la_common.h"
 #include "la_mblock.h"
+#include "la_knobs.h"
 
 #define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
@@ -32,8 +33,6 @@ __device__ __forceinline__ void mb_k_range(int K16, int ks, int ksplit, int& t0,
     }
 }
 
-extern int g_la_ex_split;       // la_debug_set key 16 (la_engine.cpp)
-extern long long* g_la_dbg_times;
 struct MbArgs {
     const bf16_t* wp;
     const bf16_t* xp;
@@ -2334,15 +2333,6 @@ __global__ __launch_bounds__(256) void k_kv_commit_mb(const bf16_t* __restrict__
 // launchers
 // =============================================================================================================
 static bool g_mb_attr = false;
-int g_la_mb_attn_rot = 0;     // la_lab_set key 21: 1 = the query heads of a kv head start their key-tile lists at different offsets (GQA models; measured neutral at Mistral bs=8 / Mixtral bs=4, profiles/r04_batch_ab2.txt: off)
-int g_la_mb_attn_vring = 0;   // la_lab_set key 20: 1 = multi-block attention with the next tile's V in flight through a per-wave LDS ring (measured 0.5-5 % SLOWER per step, profiles/r04_mb_attention_vring_ab.txt), 0 = V requested per tile (default)
-int g_la_mb_dbg = 0;
-int g_la_mb_mode = 0;         // la_lab_set key 5: unused (was: the wide gate/up launch as two co-resident 256-row workgroups per CU on a 3-slot ring — four waves per SIMD; measured 7 % slower at 512 rows, profiles/r04_wide_gemm_schedule.txt part 5)
-int g_la_mb_pair = 1 | 16 | 32 | 64 | 256 | 4096 | 8192;   // la_debug_set key 6, bit 13 (round 5, default on: down at 512 rows -3...-4 %, 88 MB fewer fabric bytes per launch): fat slab launches over whole multiples of 256 workgroups map one K split to an XCD; bit 12 (round 5, default on: Mistral bs=4 6.76 -> 6.50 ms per step): QKV at <= 4 blocks over <= 128 regions as one region x 128 rows per workgroup; bit 11: the paired gate/up fat launch staged through registers (measured slower: opt-in); bit 8 (round 5, default on): QKV at <= 4 blocks as ONE {lo, hi} region x 256 rows per workgroup (fat waves of 2 x 2 tiles; bit 9: at 5-8 blocks too), bit 6 (round 5, default on): gate/up at <= 4 blocks as ONE region x all token blocks per workgroup (fat waves; bit 7: at every block count), bit 5 (round 5, default on: Mistral bs=8 9.91 -> 9.53 ms per step, profiles/r05_fat_waves.txt): the paired slab / QKV launches as fat waves too; bit 4 (round 5, default on): gate/up at >= 3 blocks as four fat waves per workgroup (k_gemm_fat: the paired geometry, 4 x TW tiles per wave); bit 0: paired form of the wide slab / QKV launches (two weight regions x half the token blocks per workgroup, default on); bit 1: of gate/up too; bit 2: quad form of the QKV launch (four regions x a quarter of the token blocks; bit-identical, measured neutral: opt-in)
-int g_la_mb_ks2 = 0;          // la_debug_set key 12: slab GEMMs of the multi-block step with 2 K splits at >= 5 blocks (measurement)
-int g_la_mb_narrow = 0;       // la_debug_set key 3: 1 = the K-split kernels (k_gemm_mb) for every nblk (A/B measurements)
-int g_la_ex_d4 = 13;          // la_lab_set key 25 (default 13 = bits 0 + 2 + 3: Mixtral bs=4 19.75 -> 18.96 ms per step, profiles/r05_moe_paired_experts.txt): merged-expert launches as two workgroups per CU (bit 0 gate/up, bit 1 down); round 5: two weight regions per workgroup (bit 2 gate/up, bit 3 down) — takes precedence over bits 0 / 1
-int g_la_mb_sch = 1;          // la_lab_set key 24: 1 = round-4 schedule of the wide GEMMs (default), 0 = the round-2 schedule (A/B reference)
 template <int RBV, int TW, int EPI>
 static void wide_launch(dim3 grid, hipStream_t st, const MbArgs& a) {
     // schedule (k_gemm_wide SCH): buffer-addressed pieces everywhere; a fragment read after every MFMA where a wave has >= 3 token tiles

@@ -12,7 +12,7 @@
 #include "la_kernels.h"
 
 #include "la_trie_dev.h"
-extern long long* g_la_dbg_times;
+#include "la_knobs.h"
 
 #define TBIG 1e9
 #define LA_SCAN_SMALL 6

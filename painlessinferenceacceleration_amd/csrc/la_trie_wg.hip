@@ -24,7 +24,7 @@
 #include <stdint.h>
 #include "la_kernels.h"
 #include "la_trie_dev.h"
-extern long long* g_la_dbg_times;
+#include "la_knobs.h"
 
 #define WGT 256
 #define NWV 4

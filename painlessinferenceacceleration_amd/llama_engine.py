@@ -202,13 +202,16 @@ def random_weights(shape, seed=0, std=0.02, device='cpu', dtype=torch.bfloat16, 
     return sd
 
 
+DEFAULT_LAB = False      # engines created without lab=... take the product library; the lab_build fixture of tests/conftest.py flips it for a variant test
+
+
 class LlamaVerifyEngine(object):
     """One GPU: packed weights + KV cache + the captured step graph.  n_slots = 1: one sequence (the bs=1 loop).
     n_slots > 1: the cursor-batch path — every slot owns a max_keys region of the KV cache and the 64 rows of a
     verify block are shared by the active slots (bstep)."""
 
     def __init__(self, shape, state_dict, max_length=2048, device='cuda:0', attn_split=0, gemm_cfg=None,
-                 consume_state_dict=False, balanced=True, n_slots=1, fuse=0, max_blocks=0, kv_ring=False, dtype=None):
+                 consume_state_dict=False, balanced=True, n_slots=1, fuse=0, max_blocks=0, kv_ring=False, dtype=None, lab=None):
         if not torch.cuda.is_available():
             raise RuntimeError('LlamaVerifyEngine needs an MI355X: the verify step has no CPU fallback')
         # The engine computes in the checkpoint's own 16-bit type: bfloat16 (BASELINE) or float16 (what the reference's examples and
@@ -219,7 +222,9 @@ class LlamaVerifyEngine(object):
             if dtype not in (torch.bfloat16, torch.float16):
                 dtype = torch.bfloat16
         self.dtype = dtype
-        self._lib = _lib.lib_for(dtype)
+        # lab=True: the LAB build of the same sources (measurement knobs / A/B switches, _lib.lab_set) instead of the product library
+        self.lab = DEFAULT_LAB if lab is None else bool(lab)
+        self._lib = _lib.lab_lib_for(dtype) if self.lab else _lib.lib_for(dtype)
         self.shape = shape
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)

@@ -1,3 +1,4 @@
+import os; os.environ.setdefault('LA_LAB_BUILD', '1')      # A/B script: the lab build (kernel-lab knobs, phase stamps) is the process library
 # -*- coding: utf-8 -*-
 """Kernel-level A/B on one MI355X: HIP-event time of every kernel class of the verify step at the Llama-2-7B layer
 shape (weights rotated over > 256 MB so the Infinity Cache cannot hold them), each GEMM also with the epilogue switched

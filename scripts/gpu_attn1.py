@@ -1,3 +1,4 @@
+import os; os.environ.setdefault('LA_LAB_BUILD', '1')      # A/B script: the lab build (kernel-lab knobs, phase stamps) is the process library
 # -*- coding: utf-8 -*-
 """Round 4: the single-launch tree attention (la_attn1.hip, la_debug_set key 17) vs key splits + combine at the Llama-2-7B shape,
 by context length; variants of the new kernel (key 18: start rotation off, forced slice counts); phase stamps of one launch.

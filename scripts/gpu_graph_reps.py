@@ -1,3 +1,4 @@
+import os; os.environ.setdefault('LA_LAB_BUILD', '1')      # A/B script: the lab build (kernel-lab knobs, phase stamps) is the process library
 # -*- coding: utf-8 -*-
 """What does a graph launch cost beyond its kernels?  The Llama-2-7B verify step captured n times into ONE graph
 (la_debug_set key 11; same input block each repetition, only the last one publishes): wall time per launch / n against n.

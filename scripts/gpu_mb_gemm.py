@@ -1,3 +1,4 @@
+import os; os.environ.setdefault('LA_LAB_BUILD', '1')      # A/B script: the lab build (kernel-lab knobs, phase stamps) is the process library
 # -*- coding: utf-8 -*-
 """The multi-block gate/up (+SwiGLU) and down GEMMs alone at the Llama-2-7B shape through la_mb_gemm: the one-pass wide kernel
 (k_gemm_wide) vs the K-split kernel (k_gemm_mb, la_debug_set key 3) for nblk = 4 and 8; weights rotate over 3 images so that no

@@ -1,3 +1,4 @@
+import os; os.environ.setdefault('LA_LAB_BUILD', '1')      # A/B script: the lab build (kernel-lab knobs, phase stamps) is the process library
 # -*- coding: utf-8 -*-
 """Paired vs unpaired wide launches (la_debug_set key 6) of the slab GEMMs (o_proj, down_proj) and the QKV GEMM at the Llama-2-7B /
 Mistral-7B / Llama-2-13B shapes for 256 and 512 rows; weights rotate over 3 images (no launch finds them in the Infinity Cache).

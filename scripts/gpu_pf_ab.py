@@ -1,3 +1,4 @@
+import os; os.environ.setdefault('LA_LAB_BUILD', '1')      # A/B script: the lab build (kernel-lab knobs, phase stamps) is the process library
 # -*- coding: utf-8 -*-
 """A/B of the idle-window weight prefetch (la_debug_set keys 7 / 8 / 9) on one MI355X: the Llama-2-7B verify step (64-row T64/B8
 tree, 512-token context) through the captured graph for every (KiB per workgroup, delay, tail KiB) setting — ms per step, HIP-event time

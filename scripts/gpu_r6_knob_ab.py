@@ -1,3 +1,4 @@
+import os; os.environ.setdefault('LA_LAB_BUILD', '1')      # A/B script: the lab build (kernel-lab knobs, phase stamps) is the process library
 # -*- coding: utf-8 -*-
 """Same-box, same-process A/B of kernel-lab knob settings on the Llama-2-7B single-sequence verify step (round 6).
 

@@ -1,3 +1,4 @@
+import os; os.environ.setdefault('LA_LAB_BUILD', '1')      # A/B script: the lab build (kernel-lab knobs, phase stamps) is the process library
 """round 6: one workgroup per query (la_trie_wg.hip) vs one wavefront per query (la_trie_dev.hip) on the round-3 forest; kernel time by HIP
 events around the launch (transfers excluded) and the per-phase stamps of both kernels."""
 import sys, os, time, random, json

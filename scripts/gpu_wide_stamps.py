@@ -1,3 +1,4 @@
+import os; os.environ.setdefault('LA_LAB_BUILD', '1')      # A/B script: the lab build (kernel-lab knobs, phase stamps) is the process library
 # -*- coding: utf-8 -*-
 """Where a wave of the 512-row gate/up launch (k_gemm_wide<4,4,SWIGLU>, schedule 3) spends its main loop: measurement build DBG = 6
 (la_lab_set(4, 6)) sums shader cycles per wave over the stages in four segments — first half, wait for the own DMA pieces, barrier,

@@ -95,8 +95,8 @@ def pack_planned(kind, mats, n_wg):
 @contextlib.contextmanager
 def debug_knob(key, value):
     """la_lab_set(key, value) for the duration of a block (capture-time knobs re-capture the step graphs on both edges)."""
-    old = lib.la_lab_get(key)
-    check(_lib.lab_set(key, value), 'debug_set')          # every loaded build: an fp16 engine reads its own library's knobs
+    old = _lib.lab_get(key)
+    check(_lib.lab_set(key, value), 'lab_set')          # every loaded LAB build: the engines of a variant test are created under the lab_build fixture
     try:
         yield
     finally:

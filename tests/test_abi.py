@@ -22,8 +22,9 @@ def exported_symbols(path=None):
 
 
 def test_every_declared_symbol_is_exported_and_bound():
-    """The product header == the bindings == the library's exports, symbol for symbol; the kernel lab (la_lab_*: measurement knobs
-    and A/B switches) is a separate, undeclared-by-the-product-header set of its own."""
+    """The product header == the bindings == the PRODUCT library's exports, symbol for symbol: no la_lab_* entry point, no knob storage.
+    The kernel lab (la_lab_*: measurement knobs and A/B switches) exists in the LAB builds of the same sources only
+    (liblookahead_hip_lab.so / _lab_f16.so, -DLA_LAB=1), declared by its own header."""
     syms = header_symbols()
     assert len(syms) >= 35
     dll = ctypes.CDLL(_lib.LIB_PATH)
@@ -34,9 +35,15 @@ def test_every_declared_symbol_is_exported_and_bound():
     lab = header_symbols('lookahead_hip_lab.h')
     assert lab == sorted(_lib.LAB_PROTOTYPES) == ['la_lab_get', 'la_lab_set', 'la_lab_set_ptr']
     assert not any(s.startswith('la_lab_') for s in syms), 'the product header does not declare the lab'
-    assert exported_symbols() == sorted(syms + lab)          # nothing exported that no header declares
+    assert exported_symbols() == sorted(syms)                # nothing exported that the product header does not declare: no lab
     # the float16 build (the same sources with -DLA_DTYPE=1) exports the same ABI and reports its dtype
-    assert exported_symbols(_lib.LIB_PATH_F16) == sorted(syms + lab)
+    assert exported_symbols(_lib.LIB_PATH_F16) == sorted(syms)
+    # the lab builds: the product ABI + the three lab entry points
+    assert exported_symbols(_lib.LAB_PATH) == sorted(syms + lab) == exported_symbols(_lib.LAB_PATH_F16)
+    assert not _lib.LAB_BUILD, 'the test suite runs on the product libraries (LA_LAB_BUILD is for the A/B scripts)'
+    import subprocess
+    knob_syms = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert 'g_la_mb_pair' not in knob_syms and 'g_la_pf_kib' not in knob_syms, 'product knobs are constexpr defaults (csrc/la_knobs.h)'
     import torch
     lib16 = _lib.lib_for(torch.float16)
     assert (lib16.la_abi_dtype(), _lib.lib.la_abi_dtype()) == (_lib.LA_DTYPE_F16, _lib.LA_DTYPE_BF16) and lib16.la_abi_version() == _lib.ABI_VERSION
@@ -44,7 +51,8 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_product_debug_key_is_the_depth_probe_only():
     lib = _lib.lib
-    assert lib.la_debug_get(13) == 0 and lib.la_debug_set(13, 5) == 0 and lib.la_debug_get(13) == 5 and lib.la_lab_get(13) == 5
+    assert not hasattr(lib, 'la_lab_get') and not hasattr(lib, 'la_lab_set')
+    assert lib.la_debug_get(13) == 0 and lib.la_debug_set(13, 5) == 0 and lib.la_debug_get(13) == 5
     assert lib.la_debug_set(13, 0) == 0
     for key in (0, 6, 7, 10, 17, 19, 99):
         assert lib.la_debug_set(key, 0) == -1 and lib.la_debug_get(key) == -1      # LA_E_ARG: lab knobs are not reachable here
@@ -122,8 +130,16 @@ def test_qkv_row_perm_is_a_permutation_of_rope_pairs():
 def test_debug_knobs_roundtrip_and_defaults():
     """la_lab_set / la_lab_get: every knob reads back, out-of-range values are refused, and the library defaults are the
     documented ones (everything 0 except key 6 = 12657: the paired wide launches + (round 5) the fat-wave forms of gate/up and of the paired slab / QKV launches, and key 11 = 1 step per graph; round 3: 13 = depth probe,
-    14 = split head / tail kernels, 15 = 4-wave GEMM variants; round 4: 17 = single-launch tree attention, default ON)."""
-    lib = _lib.lib
+    14 = split head / tail kernels, 15 = 4-wave GEMM variants; round 4: 17 = single-launch tree attention, default ON).  Round 6: the
+    knobs live in the LAB build only; its defaults are the product's constexprs (one table, csrc/la_knobs.h)."""
+    import torch
+    lib = _lib.lab_lib_for(torch.bfloat16)
+    import re
+    table = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'painlessinferenceacceleration_amd', 'csrc', 'la_knobs.h')).read()
+    rows = re.findall(r'X\((g_la_\w+),\s*(-?\d+),\s*(\d+),', table)
+    assert len(rows) >= 29
+    for _, dflt, key in rows:
+        assert lib.la_lab_get(int(key)) == int(dflt), key
     defaults = {0: 0, 1: 0, 2: 0, 3: 0, 4: 0, 5: 0, 6: 12657, 7: 0, 8: 0, 9: 0, 10: 0, 11: 1, 12: 0, 13: 0, 14: 0, 15: 0, 16: 0, 17: 1, 18: 0, 19: 0, 20: 0, 21: 0, 22: 0, 23: 0, 24: 1, 25: 13}
     for key, d in defaults.items():
         assert lib.la_lab_get(key) == d, key

@@ -172,6 +172,7 @@ def test_bstep_logits_and_kv_commit_vs_oracle(gqa):
             row += n
 
 
+@pytest.mark.usefixtures('lab_build')
 def test_bstep_graph_equals_eager_and_single_sequence_path():
     """The captured batch graph, its eager twin and the bs=1 step agree bit for bit on the same sequence."""
     shape, sd = tiny_shape(), _bf16_sd(2)

@@ -19,7 +19,7 @@ from tests.gpu_utils import random_tree
 from tests.tiny_model import GOLDEN, load_golden, tiny_shape, tiny_weights
 
 pytestmark = pytest.mark.gpu
-PF_DEFAULT = (_lib.lib.la_lab_get(7), _lib.lib.la_lab_get(8), _lib.lib.la_lab_get(9))     # the library's idle-window prefetch default
+PF_DEFAULT = (0, 0, 0)     # the library's idle-window prefetch default (csrc/la_knobs.h: g_la_pf_kib / g_la_pf_delay / g_la_pf_tail_kib)
 TOL = 2e-2
 
 
@@ -292,6 +292,7 @@ def test_sequential_processor_path_on_device():
     assert torch.equal(eng.logits()[:1], eng2.logits()[:1])        # the committed KV rows are identical
 
 
+@pytest.mark.usefixtures('lab_build')
 def test_fused_norm_gemm_launches_are_bitwise_identical_to_separate_kernels():
     from tests.gpu_utils import debug_knob
     with debug_knob(19, 0):                      # the fused producers run the one-workgroup row stage: compare with that form
@@ -355,6 +356,7 @@ def test_role_fused_gateup_down_launch_is_bitwise_identical():
             assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
 
 
+@pytest.mark.usefixtures('lab_build')
 def test_idle_window_prefetch_is_bitwise_neutral():
     from tests.gpu_utils import split_attention
     with split_attention():                      # the prefetch workgroups ride on the combine launch of the key-split form
@@ -366,8 +368,9 @@ def _idle_window_prefetch_is_bitwise_neutral():
     GEMM's first k-tiles (planned QKV / gate-up / lm_head images, classic o_proj image).  At the Llama-2-7B layer shape and on the
     tiny model (classic images only) every setting must leave tokens, logits and hidden state bit-identical — graph and eager —
     and must stay inside the weight images (an out-of-bounds descriptor would fault the launch)."""
-    from painlessinferenceacceleration_amd._lib import check, lib
+    from painlessinferenceacceleration_amd._lib import check, lab_lib_for
     from painlessinferenceacceleration_amd.llama_engine import random_weights
+    lib = lab_lib_for(torch.bfloat16)
     rs = np.random.RandomState(8)
     try:
         for shape, vocab, seed in ((LlamaShape(3, 4096, 32, 32, 11008, 32000, 1e-5), 32000, 4), (tiny_shape(), tiny_shape().vocab, 1)):
@@ -398,6 +401,7 @@ def _idle_window_prefetch_is_bitwise_neutral():
             lib.la_lab_set(key, val)
 
 
+@pytest.mark.usefixtures('lab_build')
 def test_staged_attention_is_bitwise_identical_end_to_end():
     from tests.gpu_utils import split_attention
     with split_attention():                      # key 10 selects between the two key-split forms
@@ -409,7 +413,8 @@ def _staged_attention_is_bitwise_identical_end_to_end():
     hidden state of whole steps must not change by a bit — long prompts (several stages per workgroup), a sliding window on the
     KV ring (ring-slot addressing of the copies), and the cursor batch (a wave whose token block holds no row of a slot still
     copies for its partner)."""
-    from painlessinferenceacceleration_amd._lib import check, lib
+    from painlessinferenceacceleration_amd._lib import check, lab_lib_for
+    lib = lab_lib_for(torch.bfloat16)
     shape = tiny_shape()
     sd = _bf16_sd(3)
     rs = np.random.RandomState(12)
@@ -457,6 +462,7 @@ def _staged_attention_is_bitwise_identical_end_to_end():
         lib.la_lab_set(10, default_form)
 
 
+@pytest.mark.usefixtures('lab_build')
 @pytest.mark.parametrize('window', [40, 100])
 def test_sliding_window_attention_extension(window):
     """cfg.sliding_window (extension; BASELINE config 3): rows see only committed keys within `window` positions (the

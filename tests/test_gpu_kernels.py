@@ -181,6 +181,7 @@ def test_qkv_post(nh, nkv):
 @pytest.mark.parametrize('nh,nkv,nkeys,nsplit,T', [(2, 2, 0, 1, 64), (2, 2, 70, 2, 64), (4, 1, 333, 4, 17), (2, 2, 640, 8, 64),
                                                    (2, 2, 31, 3, 1), (2, 2, 1500, 8, 64), (2, 2, 1500, 2, 64), (4, 2, 2040, 1, 40),
                                                    (2, 2, 5, 8, 3)])
+@pytest.mark.usefixtures('lab_build')
 def test_tree_attention(nh, nkv, nkeys, nsplit, T):
     """softmax(QK^T/sqrt(d) + tree mask) V with a mask-free prefix: tolerance 2e-2 relative to max|out|
     (bf16 P and bf16 output rounding) against an fp32 torch attention over the same bf16 inputs.  Checked form: the single-launch

@@ -329,6 +329,7 @@ def test_mstep_moe_every_expert_receives_every_row():
         assert float((err < TOL).float().mean()) >= 1.0 - TAIL_FRAC and float(err.max()) < TOL_TAIL and float(err.median()) < 0.75 * TOL, (b, err)
 
 
+@pytest.mark.usefixtures('lab_build')
 @pytest.mark.parametrize('nblk', [2, 3, 4, 5, 7, 8])
 def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
     """la_debug_set key 6: the slab and QKV launches of the wide family with TWO weight regions x HALF the token blocks per
@@ -393,6 +394,7 @@ def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
         lib.la_lab_set(6, default_form)
 
 
+@pytest.mark.usefixtures('lab_build')
 @pytest.mark.parametrize('nblk', [3, 4, 6, 8])
 def test_mb_wide_schedules_are_bitwise_identical(nblk):
     """la_lab_set key 24: the round-4 schedule of k_gemm_wide (buffer-addressed LDS-DMA pieces; one fragment read after every MFMA at
@@ -662,7 +664,7 @@ def test_mstep_mistral_shape_b8_window_ring_paired_launches_vs_oracle():
     B = 8
     eng = LlamaVerifyEngine(shape, sd, max_length=1200, n_slots=B, max_blocks=B, kv_ring=True)
     assert eng.kv_ring and eng.max_keys == 736
-    assert lib.la_lab_get(6) & 1, 'the paired wide launches are the default'
+    assert _lib.lab_get(6) & 1, 'the paired wide launches are the default (csrc/la_knobs.h: the lab build reports the product default)'
     oracle = lo.OracleLlama(shape, sd)
     rs = np.random.RandomState(21)
     lens = [40, 150, 170, 300, 90, 800, 230, 1000]          # < W, ~W, > W, >> W; 800 / 1000 wrap the 736-row ring
@@ -850,6 +852,7 @@ def test_mstep_mixtral8x7b_layer_shape_gathered_experts_vs_oracle_with_forced_ro
     assert bool((hit > 0).all()), 'every expert of every layer received rows (the gathered path ran for all of them)'
 
 
+@pytest.mark.usefixtures('lab_build')
 def test_merged_expert_launch_forms_agree():
     """la_lab_set key 25: the merged-expert launches of the gathered MoE step.  One workgroup per CU (0) and two per CU with 4 weight tiles
     in flight (bits 0 / 1) run the same MFMA chain per output element and sum the K parts in the same fixed order: bit-identical logits.
@@ -891,6 +894,7 @@ def test_merged_expert_launch_forms_agree():
         assert float(err.max()) <= 1e-2, (form, float(err.max()))
 
 
+@pytest.mark.usefixtures('lab_build')
 def test_moe_plan_gather_one_launch_is_bitwise_the_two_launch_form():
     """la_lab_set key 16 bit 2: the expert plan (rows per expert, ascending) and the gather of each expert's packed activation blocks as ONE
     launch (round 5 default: every workgroup derives its expert's row list itself) vs the round-3 pair of launches.  Integer work in front
