@@ -397,7 +397,9 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
             HIPCHK(hipEventRecord(m->pf_fork, st));
             HIPCHK(hipStreamWaitEvent(m->pf_stream, m->pf_fork, 0));
         }
+#if LA_LAB
         KCHK(lk_pf_only(m->pf_stream, &d));
+#endif
         forked = true;
         return LA_OK;
     };
@@ -471,6 +473,7 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
             KCHK(lk_tree_attn_b(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
                                 kf, vf, m->rowmask, m->bstate, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, bsplit > 0 ? bsplit : m->nsplit,
                                 m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window, ring, &pd));
+#if LA_LAB
         else if (g_la_attn_merge_ns > 0 && !long_ctx && c.n_experts == 0 && c.sliding_window <= 0 && (m->o_k / 16) / m->o_ks == 64 &&
                  g_la_attn_merge_ns <= m->nsplit && c.hidden % 64 == 0) {
             // lab knob 33 (review item 1b): key-split attention over NS splits, NO combine launch — o_proj merges the partials on load
@@ -480,7 +483,9 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
             P(KC_O);
             KCHK(lk_oproj_merge(st, L.wo, c.hidden, m->o_k, m->o_ks, g_la_attn_merge_ns, m->opart, m->mpart, m->lpart, m->slabs));
             goto after_oproj;
-        } else {
+        }
+#endif
+        else {
             // riders (la_lab_set key 31): the single-launch attention occupies nh * 4 CUs; the others pull o_proj's first KiB into L2
             PfDesc rd{};
             if (g_la_attn_ride_kib > 0 && !long_ctx) lk_pf_classic(&rd, L.wo, c.hidden, m->o_k, m->o_rb, m->o_ks, g_la_attn_ride_kib, g_la_attn_ride_delay, nullptr);
@@ -494,7 +499,9 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
                                 (g_la_oproj_probe & 15) ? (g_la_oproj_probe & 15) : m->o_ks, m->slabs));
         else
         KCHK(lk_gemm64_slab(st, L.wo, m->attn_xp, c.hidden, m->o_k, m->o_rb, m->o_ks, m->slabs));
+#if LA_LAB
     after_oproj:
+#endif
         P(KC_OTHER);
         if (fork && c.n_experts == 0) {
             PfDesc fd{};
@@ -559,7 +566,9 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
             pd = PfDesc{};
             if (pf_kib > 0 && c.balanced_wg[1] > 0) lk_pf_planned(&pd, L.wgateup, 1, c.ffn, c.hidden, c.balanced_wg[1], pf_kib, pf_dly, nullptr);
             if ((g_la_oproj_probe & 32) && !batch) {}          // timing probe: the post-attention norm launch is skipped (x is stale)
+#if LA_LAB
             else if (norm4) KCHK(lk_resid_norm4(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp, cf, m->norm_gran + (size_t)(2 * l) * 256));
+#endif
             else KCHK(lk_resid_norm(st, m->h, m->slabs, m->o_ks, L.norm2, c.hidden, c.rms_eps, m->xp, cf, &pd));
             P(KC_GATEUP);
             if ((m->fuse & 4) && (m->down_rb & 0xff) == 2) {
@@ -594,8 +603,11 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
                 pd = PfDesc{};
                 if (pf_kib > 0 && c.balanced_wg[2] > 0) lk_pf_planned(&pd, m->w.lm_head, 0, c.vocab, c.hidden, c.balanced_wg[2], pf_kib, pf_dly, nullptr);
             }
+#if LA_LAB
             if (norm4) KCHK(lk_resid_norm4(st, m->h, m->slabs, m->down_ks, nw, c.hidden, c.rms_eps, m->xp, cf, m->norm_gran + (size_t)(2 * l + 1) * 256));
-            else KCHK(lk_resid_norm(st, m->h, m->slabs, m->down_ks, nw, c.hidden, c.rms_eps, m->xp, cf, &pd));
+            else
+#endif
+            KCHK(lk_resid_norm(st, m->h, m->slabs, m->down_ks, nw, c.hidden, c.rms_eps, m->xp, cf, &pd));
         }
     }
     P(KC_LMHEAD);

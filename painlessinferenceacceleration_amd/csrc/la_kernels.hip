@@ -269,11 +269,9 @@ __device__ __forceinline__ void pf_body(const PfDesc& p, int b) {
     pf_wait16(v);
 }
 
-// The same prefetch as its OWN launch (round 6): queued on a second, low-priority stream that forks off the step's stream — a
-// parallel branch of the captured graph — so that it runs UNDER a latency-bound launch of the step (the tree attention leaves
-// half the CUs and nearly all of HBM idle for ~13 us) instead of riding inside it.  One workgroup per consumer workgroup, block
-// id = consumer id (same XCD residue).  Nothing is written: the step's results cannot depend on it.
-__global__ __launch_bounds__(512) void k_pf_only(PfDesc pf) { pf_body(pf, (int)blockIdx.x); }
+#if LA_LAB
+#include "lab/k_pf_only.inc"            // the prefetch workgroups of a descriptor as their own launch (lab knobs 26-30: forked graph branch, measured slower)
+#endif
 
 template <int NS, bool MOE>
 __global__ __launch_bounds__(512) void k_row_norm(const bf16_t* __restrict__ embed, const int* __restrict__ ids,
@@ -290,96 +288,9 @@ __global__ __launch_bounds__(512) void k_row_norm(const bf16_t* __restrict__ emb
                            xp, addend, wrouter, n_experts, top_k, route_w, n_rows, cast_first);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Residual add + RMSNorm with FOUR workgroups per token row (round 4).  k_row_norm gives a row to one workgroup: 64 CUs each
-// pull 80 KiB (4 fp32 slabs + residual + weight) through a memory path that holds ~16 KiB in flight — five round trips while
-// 192 CUs idle (5.3 us per launch, twice per layer).  Here workgroup (t, q) owns a QUARTER of row t: one round trip, then the four
-// quarter sums of squares meet through 8-byte {tag, value} granules (one sc1 store each, polled by one wave with sc1 loads:
-// MI355X_MICROARCH.md handoff-1to1 / Guideline 16 R2 — the data is the flag, no fence on either side) and every workgroup
-// normalises its own quarter.  The four partials are added in the fixed order q = 0..3: deterministic, but a different summation
-// order than k_row_norm's (the rsqrt argument may differ in its last bit).  Granule words are used ONCE per step (one slot per
-// norm of the step, zeroed by k_step_head), so the tag is a constant 1.
-//   LlamaRMSNorm (modeling_llama.py:76-90) + the residual adds of LlamaDecoderLayer (:352-363).
-// ---------------------------------------------------------------------------------------------
-template <int NS>
-__global__ __launch_bounds__(256) void k_row_norm4(bf16_t* __restrict__ h, const float* __restrict__ slabs, const bf16_t* __restrict__ nw,
-                                                    int hidden, float eps, bf16_t* __restrict__ xp, unsigned long long* gran, int cast_first) {
-    __shared__ float sh[4];
-    __shared__ float tot_s;
-    const int t = blockIdx.x >> 2, q = blockIdx.x & 3;
-    const int quarter = hidden >> 2, nchunk = quarter >> 2;           // 4-element chunks of this quarter (<= 512: hidden <= 8192)
-    const int e0 = q * quarter;
-    bf16x4 hv[2], wv[2];
-    f32x4 sl[NS][2];
-#pragma unroll
-    for (int ci = 0; ci < 2; ++ci) {
-        const int c = threadIdx.x + ci * 256;
-        if (c < nchunk) {
-            const int e = e0 + c * 4;
-            hv[ci] = *(const bf16x4*)(h + (size_t)t * hidden + e);
-            wv[ci] = *(const bf16x4*)(nw + e);
-#pragma unroll
-            for (int s2 = 0; s2 < NS; ++s2) sl[s2][ci] = *(const f32x4*)(slabs + ((size_t)s2 * LA_TB + t) * hidden + e);
-        }
-    }
-    float vals[2][4];
-    float ss = 0.f;
-#pragma unroll
-    for (int ci = 0; ci < 2; ++ci) {
-        const int c = threadIdx.x + ci * 256;
-        if (c < nchunk) {
-            bf16x4 ho;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float add = 0.f;
-#pragma unroll
-                for (int s2 = 0; s2 < NS; ++s2) add += sl[s2][ci][j];
-                const float v = bfr(bf2f((bf16_t)hv[ci][j]) + bfr(add));
-                vals[ci][j] = v;
-                ho[j] = (short)f2bf(v);
-                ss += v * v;
-            }
-            *(bf16x4*)(h + (size_t)t * hidden + e0 + c * 4) = ho;
-        }
-    }
-    ss = wave_sum(ss);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = ss;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        unsigned long long* g = gran + (size_t)t * 4;
-        if (threadIdx.x == 0) {
-            const float part = ((sh[0] + sh[1]) + sh[2]) + sh[3];
-            __hip_atomic_store(g + q, (1ull << 32) | (unsigned long long)__float_as_uint(part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // lanes 0..3 poll the four granules of the row (the other lanes idle); bounded: ~1 s of polling aborts the launch
-        unsigned long long x = 0ull;
-        unsigned spins = 0;
-        while (true) {
-            if (threadIdx.x < 4) x = __hip_atomic_load(g + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__ballot(threadIdx.x < 4 && (x >> 32) != 1ull) == 0ull) break;
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 22)) __builtin_trap();
-        }
-        const float p = __uint_as_float((unsigned)x);
-        const float p0 = __shfl(p, 0, 64), p1 = __shfl(p, 1, 64), p2 = __shfl(p, 2, 64), p3 = __shfl(p, 3, 64);
-        if (threadIdx.x == 0) tot_s = ((p0 + p1) + p2) + p3;
-    }
-    __syncthreads();
-    const float rs = 1.0f / sqrtf(tot_s / (float)hidden + eps);
-#pragma unroll
-    for (int ci = 0; ci < 2; ++ci) {
-        const int c = threadIdx.x + ci * 256;
-        if (c < nchunk) {
-            bf16x4 xo;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float nv = cast_first ? bfr(vals[ci][j] * rs) : vals[ci][j] * rs;
-                xo[j] = (short)f2bf(bf2f((bf16_t)wv[ci][j]) * nv);
-            }
-            *(bf16x4*)(xp + xp_offset(t, e0 + c * 4)) = xo;
-        }
-    }
-}
+#if LA_LAB
+#include "lab/k_row_norm4.inc"          // four workgroups per norm row (lab knob 19: measured neutral, never default)
+#endif
 
 // Step head (single-sequence step): k_build_tree_inputs + the embedding row kernel in ONE launch.  Workgroup t expands its own
 // row of the step input (ids / 64-bit ancestor mask / position = committed keys + popcount - 1, the model hook of
@@ -2002,11 +1913,9 @@ static inline int pf_extra(const PfDesc* pf) { return (pf && pf->base && pf->n_c
 static inline PfDesc pf_or_none(const PfDesc* pf) { PfDesc d{}; if (pf_extra(pf)) d = *pf; return d; }
 
 
-int lk_pf_only(hipStream_t st, const PfDesc* pf) {
-    if (!pf_extra(pf)) return 0;
-    k_pf_only<<<pf->n_consumers, 512, 0, st>>>(*pf);
-    LAUNCH_CHECK(); return 0;
-}
+#if LA_LAB
+#include "lab/lk_pf_only.inc"
+#endif
 
 int lk_pack_weight(hipStream_t st, const void* w, const void* w2, int N, int K, int il, void* out) {
     size_t total = (size_t)(il ? 2 * N : N) / 32 * (K / 16) * 64;
@@ -2477,18 +2386,9 @@ int lk_step_head(hipStream_t st, const int* in, int* state, int* pos, uint64_t* 
                                                       (unsigned long long*)gran, gran ? n_gran : 0);
     LAUNCH_CHECK(); return 0;
 }
-// residual + RMSNorm, four workgroups per row (k_row_norm4): gran = 256 zeroed granule words owned by THIS launch of the step
-int lk_resid_norm4(hipStream_t st, void* h, const float* slabs, int n_slabs, const void* nw, int hidden, float eps, void* xp,
-                   int cast_first, uint64_t* gran) {
-    if (hidden > 8192 || (hidden & 15) || !gran) return -1;
-#define RN4(NS) k_row_norm4<NS><<<LA_TB * 4, 256, 0, st>>>((bf16_t*)h, slabs, (const bf16_t*)nw, hidden, eps, (bf16_t*)xp, (unsigned long long*)gran, cast_first)
-    switch (n_slabs) {
-        case 1: RN4(1); break; case 2: RN4(2); break; case 3: RN4(3); break; case 4: RN4(4); break; case 6: RN4(6); break; case 8: RN4(8); break;
-        default: return -1;
-    }
-#undef RN4
-    LAUNCH_CHECK(); return 0;
-}
+#if LA_LAB
+#include "lab/lk_resid_norm4.inc"
+#endif
 // cv / ci: [n_tiles][64] candidates (one per lm_head workgroup and token); host_out: pinned result block or null
 int lk_step_tail(hipStream_t st, const float* cv, const int* ci, int n_tiles, const int* ids, const uint64_t* rowmask, int* state,
                  int* host_out) {

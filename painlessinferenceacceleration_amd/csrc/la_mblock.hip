@@ -2395,9 +2395,11 @@ int lk_mb_init() {
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 2, MB_SWIGLU>, FatGeom<8, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 3, MB_SWIGLU>, FatGeom<8, 3>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 4, MB_SWIGLU>, FatGeom<8, 4>::LDS);
+#if LA_LAB
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 2, MB_SWIGLU, 4, 0, 4, 1>, FatGeom<8, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 3, MB_SWIGLU, 4, 0, 4, 1>, FatGeom<8, 3>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 4, MB_SWIGLU, 4, 0, 4, 1>, FatGeom<8, 4>::LDS);
+#endif
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 2, MB_SWIGLU, 4, 2>, FatGeom<4, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 3, MB_SWIGLU, 4, 2>, FatGeom<4, 3>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 4, MB_SWIGLU, 4, 2>, FatGeom<4, 4>::LDS);
@@ -2548,6 +2550,7 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
     // nblk >= 3: every token block in ONE weight pass (k_gemm_wide): RBV = 4 -> 4 TW token blocks per workgroup, RBV = 2 -> 8 TW
     if (nblk >= 3 && !g_la_mb_narrow) {
         const dim3 grid(n_wg, ksplit, 1);
+#if LA_LAB
         if constexpr (RBV == 4 && EPI == MB_SWIGLU) {           // measurement builds of the 512-row gate/up launch (la_debug_set key 4)
             if (g_la_mb_dbg == 6 && nblk >= 7) {
                 MbArgs p = a; p.dbg_times = g_la_dbg_times;
@@ -2563,6 +2566,7 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                 LAUNCH_CHECK(); return 0;
             }
         }
+#endif
         if constexpr (RBV == 2) {
             // Paired form (MB_SLAB, MB_QKV): TWO adjacent weight regions per workgroup and HALF the token blocks — the RBV = 4 wave
             // grid (2 row groups x 4 token groups) over regions {2 x, 2 x + 1}, grid.z = 2 token halves.  Every workgroup re-reads the
@@ -2598,7 +2602,7 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                 // rows per workgroup leave most of the chip idle — the fuller GQA image (Mistral / Mixtral: 96 regions) at 3-4 blocks is 96
                 // workgroups on 256 CUs, each waiting for 0.5 MB of weights at the HBM-class per-CU rate; two token groups = 192 workgroups
                 // (the second reader of a region finds it in L2).  <= 2 blocks: the 2 x 2 form would run MFMAs on absent blocks.
-                if ((g_la_mb_pair & 4096) && (g_la_mb_pair & 256) && ksplit == 1 && (a.K16 & 1) == 0 && (a.R & 1) == 0 && g_la_mb_dbg == 0 && nblk <= 4 && (nblk <= 2 || n_wg <= 128)) {
+                if ((g_la_mb_pair & 4096) != 0 && (g_la_mb_pair & 256) != 0 && ksplit == 1 && (a.K16 & 1) == 0 && (a.R & 1) == 0 && g_la_mb_dbg == 0 && nblk <= 4 && (nblk <= 2 || n_wg <= 128)) {
                     const dim3 gq(n_wg, 1, (nblk + 1) / 2);
                     if ((a.R & 3) == 0) k_gemm_fat<2, 1, MB_QKV, 4, 0, 2><<<gq, 256, FatGeom<2, 1, 2>::LDS, st>>>(a);
                     else k_gemm_fat<2, 1, MB_QKV, 2, 0, 2><<<gq, 256, FatGeom<2, 1, 2>::LDS, st>>>(a);
@@ -2671,7 +2675,9 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                     }
                 }
                 if (quarters) wide_launch<4, 1, EPI>(dim3(n_wg / 2, ksplit, (nblk + 1) / 2), st, p);
+#if LA_LAB
                 else if (g_la_mb_dbg == 4) k_gemm_wide<4, 2, EPI, 4><<<dim3(n_wg / 2, ksplit, (nblk + 3) / 4), 512, WideGeom<4, 2>::LDS, st>>>(p);   // measurement: no epilogue
+#endif
                 else wide_launch<4, 2, EPI>(dim3(n_wg / 2, ksplit, (nblk + 3) / 4), st, p);
                 LAUNCH_CHECK(); return 0;
             }
@@ -2705,6 +2711,7 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                 const dim3 g2(n_wg / 2, 1, 2);
                 if (fat) {
                     // round 5: the same pair of regions as FOUR fat waves (4 x TW accumulator tiles each, one wave per SIMD): k_gemm_fat
+#if LA_LAB
                     if (g_la_mb_pair & 2048) {                  // bit 11: the register-staged form (k_gemm_fat, STG = 1)
                         switch ((nblk + 1) / 2) {
                             case 2: k_gemm_fat<8, 2, MB_SWIGLU, 4, 0, 4, 1><<<g2, 256, FatGeom<8, 2>::LDS, st>>>(p); break;
@@ -2713,6 +2720,7 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                         }
                         LAUNCH_CHECK(); return 0;
                     }
+#endif
                     switch ((nblk + 1) / 2) {
                         case 2: k_gemm_fat<8, 2, MB_SWIGLU><<<g2, 256, FatGeom<8, 2>::LDS, st>>>(p); break;
                         case 3: k_gemm_fat<8, 3, MB_SWIGLU><<<g2, 256, FatGeom<8, 3>::LDS, st>>>(p); break;

@@ -9,8 +9,8 @@
 // Geometry (7B: o_k = 4096, 4 K splits): a workgroup owns 64 output rows x one K split of 64 k-tiles = 8 heads; each of its 8
 // waves owns ONE head (8 k-tiles), i.e. 64 tokens x 128 dims x NS partials = NS x 32 KiB of fp32 instead of 16 KiB of bf16.
 // Measured (profiles/r06_attn_merge_on_load_ab.txt): slower than the single-launch attention + plain o_proj; kept as lab knob 33.
-#include "la_common.h"
-#include "la_kernels.h"
+#include "../la_common.h"
+#include "../la_kernels.h"
 
 #define LA_NEG (-1.0e30f)
 
