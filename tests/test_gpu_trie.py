@@ -107,6 +107,56 @@ def test_workgroup_hier_get_wide_trees_match_host_on_large_forest_with_dead_node
     assert n_wide > 20
 
 
+@pytest.mark.parametrize('seed', range(4))
+def test_workgroup_hier_get_matches_the_oracle_fuzz(seed):
+    """Differential fuzz against the ORACLE (oracle/trie_oracle.py, the pinned restatement of lookahead_cache.py), not against the host trie:
+    the op stream of tests/test_native_trie.py::test_native_matches_oracle_fuzz (puts in both modes, stream_puts with final flushes = squeezes,
+    fresh, tiny node limits, eos / stop words, vocabularies of 5 .. 2000 tokens) goes through the native trie + its incremental device mirror
+    and through the oracle; every hier_get — all three modes, budgets 2 .. 200, branch lengths 0 / 3 / 12 / 30, 0 .. 3-token queries, both input
+    slots — is answered by the workgroup kernel and must equal the oracle's ids, mask and sizes."""
+    from oracle.trie_oracle import TrieOracle
+    rng = random.Random(2000 + seed)
+    vocab = rng.choice([5, 20, 200, 2000])
+    kw = dict(eos_ids=rng.choice([None, (2,), (2, 3)]), stop_words={4: 1} if seed % 2 else {},
+              max_node=rng.choice([65536, 60]), max_output_node=rng.choice([512, 8]))
+    a, b = LookaheadCache(**kw), TrieOracle(**kw)
+    dev = DeviceTrie(a, idxs=[0, 1], max_rows=256)
+    hist = [rng.randrange(vocab) for _ in range(30)]
+    n_q = n_wide = 0
+    for step in range(1200):
+        r = rng.random()
+        if r < 0.25:
+            toks = [rng.choice(hist) if rng.random() < 0.7 else rng.randrange(vocab) for _ in range(rng.randint(0, 40))]
+            args = dict(branch_length=rng.choice([3, 8, 13, 31]), final=rng.random() < 0.1, mode=rng.choice(['input', 'output']),
+                        idx=rng.choice([0, 1, 2]))
+            a.put(toks, **args); b.put(toks, **args)
+            hist = (hist + toks)[-60:]
+        elif r < 0.5:
+            toks = [rng.choice(hist) if rng.random() < 0.7 else rng.randrange(vocab) for _ in range(rng.randint(0, 13))]
+            args = dict(branch_length=rng.choice([3, 8, 13]), final=rng.random() < 0.08, idx=rng.choice([0, 1]))
+            a.stream_put(toks, **args); b.stream_put(toks, **args)
+            hist = (hist + toks)[-60:]
+        elif r < 0.98:
+            p = rng.randrange(1, len(hist))
+            q = hist[max(0, p - rng.randint(0, 3)):p]
+            dl = rng.choice([2, 7, 16, 64, 100, 200])
+            args = dict(decoding_length=dl, branch_length=rng.choice([0, 3, 12, 30]), min_input_size=rng.choice([0, 0, 1]),
+                        min_output_size=rng.choice([0, dl // 2, 1]), mode=rng.choice(['mix', 'mix', 'input', 'output']))
+            idx = rng.choice([0, 1])
+            ref = b.hier_get(q, idx=idx, **args)
+            got = dev.hier_get([q], idxs=[idx], **args)[0]
+            n = len(ref[0])
+            assert got[0] == [int(x) for x in ref[0]], (step, q, args)
+            assert _rows(got[1])[:n] == (tr.rows_of(ref[1])[:n] if n else []), (step, q, args)
+            assert got[2] == [int(x) for x in ref[2]], (step, q, args)
+            n_q += 1
+            n_wide += n > 64
+        else:
+            a.fresh(); b.fresh()
+    assert n_q > 400 and dev.stats['patches'] > 100, (n_q, dev.stats)
+    print('fuzz', seed, 'queries', n_q, 'wider than 64 rows', n_wide, dev.stats)
+
+
 @pytest.mark.parametrize('algo', ['wg', 'wave'])
 def test_device_hier_get_batched_matches_host_on_large_forest(algo):
     """100 x 256-token warm-up (the reference benchmark's recipe) + an input-mode prompt; 256 queries in one launch,
