@@ -93,3 +93,42 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// Router tail of a Mixtral row (MixtralSparseMoeBlock.forward, mixtral/modeling_mixtral.py:723-729): softmax over the experts' logits in
+// fp32, top-k, renormalise, cast back.  Called by ALL 64 lanes of wave 0 after the per-wave partial logits shr[wave][e] are in LDS; lane e
+// (< E) owns expert e and writes route_row[e] (weight of expert e for this row, 0 = not routed).  Bit-identical to the one-thread form it
+// replaces (rounds 1-5: thread 0 walked lg[] / pr[] / pick[] with dynamic indices — private arrays the compiler keeps in scratch, a chain of
+// dependent scratch round trips worth ~8 us per launch next to the 7 us of the norm itself): same sums in the same order (w = 0..7 per logit,
+// e = 0..n-1 for the denominator, pick order for the renormaliser), max is exact in any order, the earliest expert wins a tie.
+template <int E>
+__device__ __forceinline__ void moe_router_tail(const float (*shr)[E], int n_experts, int top_k, bool live, float* __restrict__ route_row) {
+    const int lane = threadIdx.x & 63;
+    const int e = lane < E ? lane : E - 1;
+    const bool valid = lane < E && lane < n_experts;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += shr[w][e];
+    const float lg = bfr(v);
+    const float lgm = valid ? lg : -INFINITY;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < E; ++i) mx = fmaxf(mx, __shfl(lgm, i, 64));
+    float pr = valid ? expf(lg - mx) : 0.f;
+    float den = 0.f;
+#pragma unroll
+    for (int i = 0; i < E; ++i) den += __shfl(pr, i, 64);            // + 0.f for the lanes past n_experts: exact
+    pr = pr / den;
+    bool taken = false;
+    float ksum = 0.f;
+    for (int k = 0; k < top_k; ++k) {
+        const float cand = (valid && !taken) ? pr : -1.f;             // probabilities are >= 0
+        float m = -1.f;
+#pragma unroll
+        for (int i = 0; i < E; ++i) m = fmaxf(m, __shfl(cand, i, 64));
+        const unsigned long long hit = __ballot(valid && !taken && cand == m);
+        const int best = hit ? __builtin_ctzll(hit) : 0;              // the earliest expert among equals (strict > in the serial scan)
+        ksum += __shfl(pr, best, 64);
+        if (lane == best) taken = true;
+    }
+    if (lane < E) route_row[lane] = (valid && taken && live) ? bfr(pr / ksum) : 0.f;
+}

@@ -423,7 +423,7 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
     const int pf_kib = m->fuse ? 0 : g_la_pf_kib, pf_dly = g_la_pf_delay;
     // four workgroups per norm row (k_row_norm4): single-sequence step with the fused head kernel (it zeroes the granule words); the
     // idle-window prefetch workgroups ride on k_row_norm, so the knob (key 7) keeps the one-workgroup form
-    const bool norm4 = g_la_norm4 && !batch && !g_la_split_head_tail && pf_kib == 0 && (c.hidden & 15) == 0;
+    [[maybe_unused]] const bool norm4 = g_la_norm4 && !batch && !g_la_split_head_tail && pf_kib == 0 && (c.hidden & 15) == 0;
     auto pf_qkv = [&](int l, PfDesc* d) {
         *d = PfDesc{};
         if (pf_kib > 0 && l < c.n_layers && c.balanced_wg[0] > 0)

@@ -186,33 +186,7 @@ __device__ __forceinline__ void row_norm_body(const int t, float* sh, float (*sh
         for (int e = 0; e < LA_MOE_MAX_E; ++e) shr[threadIdx.x >> 6][e] = rl[e];
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float lg[LA_MOE_MAX_E], pr[LA_MOE_MAX_E], outw[LA_MOE_MAX_E];
-        float mx = -INFINITY;
-        for (int e = 0; e < n_experts; ++e) {
-            float v = 0.f;
-            for (int w = 0; w < 8; ++w) v += shr[w][e];
-            lg[e] = bfr(v);
-            mx = fmaxf(mx, lg[e]);
-        }
-        float den = 0.f;
-        for (int e = 0; e < n_experts; ++e) { pr[e] = expf(lg[e] - mx); den += pr[e]; }
-        for (int e = 0; e < n_experts; ++e) { pr[e] = pr[e] / den; outw[e] = 0.f; }
-        unsigned taken = 0u;
-        float ksum = 0.f;
-        int pick[LA_MOE_MAX_E];
-        for (int k = 0; k < top_k; ++k) {
-            int best = -1;
-            for (int e = 0; e < n_experts; ++e)
-                if (!((taken >> e) & 1u) && (best < 0 || pr[e] > pr[best])) best = e;
-            taken |= 1u << best;
-            pick[k] = best;
-            ksum += pr[best];
-        }
-        const bool live = t < n_rows[0];
-        for (int k = 0; k < top_k; ++k) outw[pick[k]] = live ? bfr(pr[pick[k]] / ksum) : 0.f;
-        for (int e = 0; e < LA_MOE_MAX_E; ++e) route_w[t * LA_MOE_MAX_E + e] = e < n_experts ? outw[e] : 0.f;
-    }
+    if (threadIdx.x < 64) moe_router_tail<LA_MOE_MAX_E>(shr, n_experts, top_k, t < n_rows[0], route_w + t * LA_MOE_MAX_E);
 }
 
 // Prefetch for consumer workgroup b (see PfDesc, la_kernels.h): every thread issues NT 16-byte loads back to back over the

@@ -1452,33 +1452,8 @@ __global__ __launch_bounds__(512) void k_row_norm_router_mb(bf16_t* __restrict__
         for (int e = 0; e < LA_MOE_MAX_E; ++e) shr[threadIdx.x >> 6][e] = rl[e];
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float lg[LA_MOE_MAX_E], pr[LA_MOE_MAX_E], outw[LA_MOE_MAX_E];
-        float mx = -INFINITY;
-        for (int e = 0; e < n_experts; ++e) {
-            float v = 0.f;
-            for (int w = 0; w < 8; ++w) v += shr[w][e];
-            lg[e] = bfr(v);
-            mx = fmaxf(mx, lg[e]);
-        }
-        float den = 0.f;
-        for (int e = 0; e < n_experts; ++e) { pr[e] = expf(lg[e] - mx); den += pr[e]; }
-        for (int e = 0; e < n_experts; ++e) { pr[e] = pr[e] / den; outw[e] = 0.f; }
-        unsigned taken = 0u;
-        float ksum = 0.f;
-        int pick[LA_MOE_MAX_E];
-        for (int k = 0; k < top_k; ++k) {
-            int best = -1;
-            for (int e = 0; e < n_experts; ++e)
-                if (!((taken >> e) & 1u) && (best < 0 || pr[e] > pr[best])) best = e;
-            taken |= 1u << best;
-            pick[k] = best;
-            ksum += pr[best];
-        }
-        const bool live = (t & 63) < meta[(t >> 6) * LA_MB_META + LA_MBM_T];
-        for (int k = 0; k < top_k; ++k) outw[pick[k]] = live ? bfr(pr[pick[k]] / ksum) : 0.f;
-        for (int e = 0; e < LA_MOE_MAX_E; ++e) route_w[(size_t)t * LA_MOE_MAX_E + e] = e < n_experts ? outw[e] : 0.f;
-    }
+    if (threadIdx.x < 64)
+        moe_router_tail<LA_MOE_MAX_E>(shr, n_experts, top_k, (t & 63) < meta[(t >> 6) * LA_MB_META + LA_MBM_T], route_w + (size_t)t * LA_MOE_MAX_E);
 }
 
 // residual + accumulated expert outputs (bf16 + bf16) + next RMSNorm over M rows (k_row_norm<0> with an addend)

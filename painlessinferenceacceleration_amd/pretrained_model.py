@@ -66,8 +66,8 @@ def _max_length_of(stopping_criteria, max_length):
 def _custom_stop(stopping_criteria):
     """The user's criteria besides MaxLengthCriteria as one predicate stop(token_row) -> bool, or None when there are none.
     The reference evaluates `stopping_criteria(input_ids, scores)` after every verify step (pretrained_model.py:1225-1226;
-    batch: once per sample on input_ids[i:i+1, :cur+1], pretrained_model_batch.py:1284); scores is None / empty on this
-    path.  The length criterion itself is the `len(seq) >= max_length` test of the loops."""
+    batch: once per sample on input_ids[i:i+1, :cur+1], pretrained_model_batch.py:1284); scores = the tuple collected so far under
+    output_scores, else None.  The length criterion itself is the `len(seq) >= max_length` test of the loops."""
     if stopping_criteria is None or isinstance(stopping_criteria, int) or not callable(stopping_criteria):
         return None
     try:
@@ -78,10 +78,10 @@ def _custom_stop(stopping_criteria):
     if not crit:
         return None
 
-    def stop(token_row, device='cpu'):
+    def stop(token_row, device='cpu', scores=None):
         ids = torch.tensor([list(token_row)], dtype=torch.long, device=device)
         for c in crit:
-            r = c(ids, None)
+            r = c(ids, scores)
             if bool(r.any()) if torch.is_tensor(r) else bool(r):
                 return True
         return False
@@ -182,8 +182,9 @@ class LookaheadPreTrainedModel(object):
             logits_processor = LogitsProcessorList(list(logits_processor))
         sequential = (logits_processor is not None and len(logits_processor) > 0) or \
             bool(model_kwargs.get('decoding_kwargs', {}).get('do_sample', False))
-        if output_scores or output_attentions or output_hidden_states:
-            raise NotImplementedError('scores/attentions/hidden_states are not produced by the device path (SURVEY H8)')
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError('attentions / hidden_states are intermediates the device path never materialises '
+                                      '(fused attention, activations in MFMA fragment order); scores are returned (output_scores)')
         gc = self.generation_config
         pad_token_id = pad_token_id if pad_token_id is not None else getattr(gc, 'pad_token_id', None)
         eos_token_id = eos_token_id if eos_token_id is not None else getattr(gc, 'eos_token_id', None)
@@ -191,6 +192,13 @@ class LookaheadPreTrainedModel(object):
             eos_token_id = [eos_token_id]
         return_dict_in_generate = bool(return_dict_in_generate) if return_dict_in_generate is not None \
             else bool(getattr(gc, 'return_dict_in_generate', False))
+        output_scores = bool(output_scores) if output_scores is not None else bool(getattr(gc, 'output_scores', False))
+        # `scores` as the reference returns them (pretrained_model.py:1092, 1195, 1208-1209): ONE entry per verify step, and that entry
+        # is model_kwargs['next_tokens_scores'] — which only the no-draft branch writes (:795: the prefill and steps whose retrieval
+        # came back empty).  A step WITH drafts therefore appends the previous no-draft step's tensor again (pinned on
+        # tests/golden/llama_tiny_scores_fp32.npz).  decoding_kwargs['fresh_scores'] = True (an extension) appends, on draft steps,
+        # the processed logits row the step's LAST emitted token was picked from instead.
+        scores = () if (return_dict_in_generate and output_scores) else None
 
         if not hasattr(self, 'lookahead_cache') or self.lookahead_cache is None:
             self.lookahead_cache = LookaheadCache()
@@ -256,8 +264,11 @@ class LookaheadPreTrainedModel(object):
         native_mode = {'input': 0, 'output': 1, 'mix': 2}.get(dm.split('_')[1], 2)
         max_query_length = int(decoding_kwargs.get('max_query_length', 2))
         custom_stop = _custom_stop(stopping_criteria)      # user StoppingCriteria: evaluated per step, interpreter loop only
+        fresh_scores = scores is not None and bool(decoding_kwargs.get('fresh_scores', False))
+        if fresh_scores:
+            sequential = True            # the host walk sees every logits row it picks from
         native_loop = (not sequential and streamer is None and dm.split('_')[0] == 'hier' and not wide
-                       and custom_stop is None and gather is None
+                       and custom_stop is None and gather is None and scores is None
                        and not decoding_kwargs.get('device_trie', False)
                        and not decoding_kwargs.get('debug_lookahead', False) and decoding_kwargs.get('native_loop', True)
                        and 1 <= max_query_length <= 8          # la_lookahead_decode's query buffer; longer queries use this loop
@@ -268,22 +279,33 @@ class LookaheadPreTrainedModel(object):
             """next token from one logits row through the processor list (pretrained_model.py:833-839)"""
             ctx = torch.tensor([scores_ids], dtype=torch.long, device=eng.device)
             lg = eng.mlogits() if wide else eng.logits()
-            scores = logits_processor(ctx, lg[row][None].clone()) if logits_processor is not None and \
+            sc = logits_processor(ctx, lg[row][None].clone()) if logits_processor is not None and \
                 len(logits_processor) > 0 else lg[row][None]
+            if scores is not None:
+                picked[0] = sc.clone()
             if do_sample:
-                return int(torch.multinomial(torch.softmax(scores.float(), dim=-1), num_samples=1)[0, 0])
-            return int(torch.argmax(scores, dim=-1)[0])
+                return int(torch.multinomial(torch.softmax(sc.float(), dim=-1), num_samples=1)[0, 0])
+            return int(torch.argmax(sc, dim=-1)[0])
 
+        picked = [None]            # scores of the last pick() call
+        last_scores = None         # what the reference's model_kwargs['next_tokens_scores'] holds
         flushed = False
         try:
             while True:
                 if first:
+                    host_row = sequential or scores is not None      # the last prompt row's logits must stay readable
                     if wide:
                         tok = eng.mprefill(0, seq)
-                        next_tokens = [pick(seq, (len(seq) - 1) % (64 * eng.max_blocks))] if sequential else [tok]
+                        row = (len(seq) - 1) % (64 * eng.max_blocks)
                     else:
-                        tok = eng.prefill(seq, fast=False) if sequential else eng.prefill(seq)
-                        next_tokens = [pick(seq, (len(seq) - 1) % 64)] if sequential else [tok]
+                        tok = eng.prefill(seq, fast=False) if host_row else eng.prefill(seq)
+                        row = (len(seq) - 1) % 64
+                    if host_row:
+                        t = pick(seq, row)                           # sequential: THE pick; otherwise the same argmax, taken for its scores
+                        next_tokens = [t] if sequential else [tok]
+                    else:
+                        next_tokens = [tok]
+                    last_scores = picked[0]
                     decoding_kwargs['dls'].append(1)
                     decoding_kwargs['edls'].append(1)
                     first = False
@@ -322,6 +344,14 @@ class LookaheadPreTrainedModel(object):
                         next_tokens, _ = eng.step_finish()
                     else:
                         next_tokens, _ = eng.step(ids, rowmask, mode=0)
+                    if scores is not None:
+                        if sequential:
+                            if len(ids) <= 1 or fresh_scores:        # no-draft step (:783-795) — or every step (extension)
+                                last_scores = picked[0]
+                        elif len(ids) <= 1:
+                            # device-accepted step without drafts: the block's only logits row, through the (empty) processor list
+                            lg = eng.mlogits() if wide else eng.logits()
+                            last_scores = lg[0][None].clone()
                     decoding_kwargs['dls'].append(len(ids))
                     decoding_kwargs['edls'].append(len(next_tokens))
                     if decoding_kwargs.get('debug_lookahead', False):
@@ -331,10 +361,12 @@ class LookaheadPreTrainedModel(object):
                               f'query:{decoding_kwargs["decoding_qids"]} hits:{decoding_kwargs["sizes"]} '
                               f'accept_token:{next_tokens} accept_word:{words}')
                 seq.extend(next_tokens)
+                if scores is not None:
+                    scores += (last_scores,)
                 if streamer is not None:
                     streamer.put(np.array([next_tokens]))
                 finished = len(seq) >= stop_max_length or any(t in eos_set for t in next_tokens) or \
-                    (custom_stop is not None and custom_stop(seq, out_device))                   # :1225-1231
+                    (custom_stop is not None and custom_stop(seq, out_device, scores))           # :1225-1231
                 if gather is not None:
                     gather.step_update(self.lookahead_cache, next_tokens, branch_length, done=finished)
                 else:
@@ -383,7 +415,9 @@ class LookaheadPreTrainedModel(object):
         sequences = torch.tensor([seq], dtype=torch.long, device=out_device)
         if return_dict_in_generate:
             kwargs = {k: decoding_kwargs[k] for k in ('dls', 'edls', 'fts', 'qts')}
-            return LookaheadDecoderOnlyOutput(sequences=sequences, scores=None, attentions=None, hidden_states=None,
+            if scores is not None:
+                scores = tuple(s_.to(out_device) for s_ in scores)
+            return LookaheadDecoderOnlyOutput(sequences=sequences, scores=scores, attentions=None, hidden_states=None,
                                               kwargs=kwargs)
         return sequences
 

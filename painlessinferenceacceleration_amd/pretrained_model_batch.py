@@ -134,8 +134,9 @@ class LookaheadPreTrainedModel(object):
             logits_processor = LogitsProcessorList(list(logits_processor))
         sequential = (logits_processor is not None and len(logits_processor) > 0) or \
             bool(model_kwargs.get('decoding_kwargs', {}).get('do_sample', False))
-        if output_scores or output_attentions or output_hidden_states:
-            raise NotImplementedError('scores/attentions/hidden_states are not produced by the device path (SURVEY H8)')
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError('attentions / hidden_states are intermediates the device path never materialises '
+                                      '(fused attention, activations in MFMA fragment order); scores are returned (output_scores)')
         gc = self.generation_config
         pad_token_id = pad_token_id if pad_token_id is not None else getattr(gc, 'pad_token_id', None)
         eos_token_id = eos_token_id if eos_token_id is not None else getattr(gc, 'eos_token_id', None)
@@ -143,6 +144,12 @@ class LookaheadPreTrainedModel(object):
             eos_token_id = [eos_token_id]
         return_dict_in_generate = bool(return_dict_in_generate) if return_dict_in_generate is not None \
             else bool(getattr(gc, 'return_dict_in_generate', False))
+        output_scores = bool(output_scores) if output_scores is not None else bool(getattr(gc, 'output_scores', False))
+        # `scores` as the reference's batch loop returns them (pretrained_model_batch.py:1145, 1247, 1263-1264): one [bs, vocab] entry per
+        # loop iteration, and every entry is model_kwargs['next_tokens_scores'] — written by the PREFILL branch only (:789, :807), so the
+        # tuple repeats the processed logits of the last prompt rows (pinned on tests/golden/llama_tiny_scores_fp32.npz)
+        scores = () if (return_dict_in_generate and output_scores) else None
+        prefill_scores = None
         if not hasattr(self, 'lookahead_cache') or self.lookahead_cache is None:
             self.lookahead_cache = LookaheadCache()
         decoding_kwargs = model_kwargs['decoding_kwargs']
@@ -220,29 +227,36 @@ class LookaheadPreTrainedModel(object):
             multi = bool(getattr(eng, 'max_blocks', 0))
             do_sample = bool(decoding_kwargs.get('do_sample', False))
 
+            picked = [None]
+
             def pick(ctx_ids, row):
                 """next token from one logits row through the processor list (pretrained_model_batch.py:840-846)"""
-                scores = row[None]
+                sc = row[None]
                 if logits_processor is not None and len(logits_processor) > 0:
                     ctx = torch.tensor([ctx_ids], dtype=torch.long, device=eng.device)
-                    scores = logits_processor(ctx, scores.clone())
+                    sc = logits_processor(ctx, sc.clone())
+                picked[0] = sc
                 if do_sample:
-                    return int(torch.multinomial(torch.softmax(scores.float(), dim=-1), num_samples=1)[0, 0])
-                return int(torch.argmax(scores, dim=-1)[0])
+                    return int(torch.multinomial(torch.softmax(sc.float(), dim=-1), num_samples=1)[0, 0])
+                return int(torch.argmax(sc, dim=-1)[0])
 
-            if sequential:
+            if sequential or scores is not None:
                 # prompts one slot after the other: the last prompt row's logits stay readable for the processor call of :783
                 # (batch-wise there; the processors are row-wise, so one padded row at a time is the same call)
-                first = {}
+                first, rows_sc = {}, []
                 for i in range(bs):
                     n = len(prompts[i])
                     if multi:
-                        eng.mprefill(i, prompts[i])
+                        tok = eng.mprefill(i, prompts[i])
                         last = (n - 1) % (64 * eng.max_blocks)
-                        first[i] = pick(ids0[i].tolist(), eng.mlogits()[last])
+                        t = pick(ids0[i].tolist(), eng.mlogits()[last])
                     else:
-                        eng.bprefill(i, prompts[i])
-                        first[i] = pick(ids0[i].tolist(), eng.logits()[(n - 1) % 64])
+                        tok = eng.bprefill(i, prompts[i])
+                        t = pick(ids0[i].tolist(), eng.logits()[(n - 1) % 64])
+                    first[i] = t if sequential else tok
+                    rows_sc.append(picked[0].clone())
+                if scores is not None:
+                    prefill_scores = torch.cat(rows_sc, 0).to(out_device)
             else:
                 first = eng.mprefill_many(prompts) if multi else eng.bprefill_many(prompts)
             next_token_list = [[first[i]] for i in range(bs)]
@@ -287,7 +301,7 @@ class LookaheadPreTrainedModel(object):
                 keep = []
                 for k, b in enumerate(batch_indices):                               # :1269-1276 + _early_stop :937-980
                     if len(rows[b]) >= stop_max_length or any(t in eos_set for t in next_token_list[k]) or \
-                            (custom_stop is not None and custom_stop(rows[b], out_device)):                # :1284
+                            (custom_stop is not None and custom_stop(rows[b], out_device, scores)):        # :1284
                         finished_rows[b] = list(rows[b])
                     else:
                         keep.append(b)
@@ -299,6 +313,8 @@ class LookaheadPreTrainedModel(object):
                         mine[b] = [x for x in next_token_list[k] if x != -1]
                     gather.step_update(self.lookahead_cache, mine, branch_length, done=not keep)
                 batch_indices = keep
+                if scores is not None:
+                    scores += (prefill_scores,)
                 te = time.time()
                 decoding_kwargs['fts'].append(te - ts)
                 ts = te
@@ -454,7 +470,7 @@ class LookaheadPreTrainedModel(object):
         sequences = torch.from_numpy(seqs).to(out_device)
         if return_dict_in_generate:
             kwargs = {k: decoding_kwargs[k] for k in ('dls', 'edls', 'fts', 'qts')}
-            return LookaheadDecoderOnlyOutput(sequences=sequences, scores=None, attentions=None, hidden_states=None,
+            return LookaheadDecoderOnlyOutput(sequences=sequences, scores=scores, attentions=None, hidden_states=None,
                                               kwargs=kwargs)
         return sequences
 

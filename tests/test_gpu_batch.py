@@ -472,3 +472,35 @@ def test_kv_ring_engine_generates_up_to_its_max_length():
         assert out.sequences.shape[1] == L
         outs.append(out.sequences.cpu().numpy().tolist())
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize('multi', [False, True])
+def test_batch_output_scores_repeat_the_prefill_scores(multi):
+    """Batch loop under output_scores (pretrained_model_batch.py:789, 807, 1247, 1263: only the prefill branch writes next_tokens_scores):
+    one [bs, vocab] entry per loop iteration, all equal to the last prompt rows' logits — checked against the oracle forward of each
+    prompt at the stated tolerance; tokens as without the flag."""
+    shape = tiny_shape()
+    sd = random_weights(shape, seed=2, device='cpu', decisive=True)
+    model = BatchLlama(shape, dict(sd), max_length=512, max_batch=4, eos_token_id=None, max_blocks=4 if multi else 0)
+    oracle = lo.OracleLlama(shape, sd)
+    rs = np.random.RandomState(11)
+    lens = [50, 37, 44]
+    P = max(lens)
+    ids = np.zeros((3, P), dtype=np.int64)
+    am = np.zeros((3, P), dtype=np.int64)
+    for b, n in enumerate(lens):
+        ids[b, P - n:] = rs.randint(3, shape.vocab, size=n)
+        am[b, P - n:] = 1
+    dk = {'use_lookahead': True, 'decoding_length': 64, 'branch_length': 12, 'stop_words': {}}
+    ref = model.lookahead_generation(torch.from_numpy(ids), stopping_criteria=P + 40, eos_token_id=[None], pad_token_id=0,
+                                     return_dict_in_generate=True, attention_mask=torch.from_numpy(am), decoding_kwargs=dict(dk))
+    out = model.lookahead_generation(torch.from_numpy(ids), stopping_criteria=P + 40, eos_token_id=[None], pad_token_id=0, output_scores=True,
+                                     return_dict_in_generate=True, attention_mask=torch.from_numpy(am), decoding_kwargs=dict(dk))
+    assert out.sequences.tolist() == ref.sequences.tolist()
+    assert len(out.scores) == len(out.kwargs['fts']) and len(out.scores) >= 2
+    for s in out.scores:
+        assert s.shape == (3, shape.vocab) and torch.equal(s, out.scores[0])
+    for b, n in enumerate(lens):
+        p = torch.from_numpy(ids[b, P - n:])
+        lg, _ = oracle.forward(p, torch.tril(torch.ones((n, n), dtype=torch.long)), None)
+        _check_rows(out.scores[0][b][None], lg[-1][None], [0], f'prefill scores of sample {b}')

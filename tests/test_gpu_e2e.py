@@ -808,3 +808,47 @@ def test_sliding_window_kv_ring_is_bitwise_the_windowed_full_cache(window):
             o = [e.bstep([(1, ids, np.asarray(rows, dtype=np.uint64), 0, 16)]) for e in (full, ring)]
             assert o[0] == o[1] and torch.equal(full.logits()[:T], ring.logits()[:T]), step
     assert ring.slot_keys[1] == full.slot_keys[1] > 520
+
+
+def test_output_scores_on_the_device_loop():
+    """output_scores + return_dict_in_generate on the device loop (pretrained_model.py:795, 1195, 1208): the same host loop
+    on the oracle-backed engine (tests/oracle_engine.py, pinned to the reference's own scores in tests/test_host_loop_cpu.py) is the
+    checker — same tokens / dls / edls, one entry per step, every entry within the stated tolerance, draft steps repeat the previous
+    no-draft entry; with a processor list (host-walked path) and with fresh_scores (extension) as well."""
+    from types import SimpleNamespace
+    from transformers import LogitsProcessorList, RepetitionPenaltyLogitsProcessor
+    from painlessinferenceacceleration_amd.pretrained_model import LookaheadPreTrainedModel
+    from tests.oracle_engine import OracleEngine
+    shape = tiny_shape()
+    sd = random_weights(shape, seed=2, device='cpu', decisive=True)
+    model = LlamaForCausalLM(shape, dict(sd), max_length=512, eos_token_id=None)
+
+    class Twin(LookaheadPreTrainedModel):
+        def __init__(self):
+            self.engine = OracleEngine(shape, dict(sd), max_length=512)
+            self.generation_config = SimpleNamespace(eos_token_id=None, pad_token_id=0, return_dict_in_generate=False)
+            self.lookahead_cache = LookaheadCache()
+    twin = Twin()
+    rs = np.random.RandomState(5)
+    prompt = torch.tensor([rs.randint(3, shape.vocab, size=60).tolist()])
+    dk = {'use_lookahead': True, 'decoding_length': 64, 'branch_length': 12, 'stop_words': {}}
+    for procs, extra in ((None, {}), (None, {}), (LogitsProcessorList([RepetitionPenaltyLogitsProcessor(1.05)]), {}),
+                         (None, {'fresh_scores': True})):
+        outs = []
+        for mdl in (model, twin):
+            d = dict(dk); d.update(extra)
+            outs.append(mdl.lookahead_generation(prompt, logits_processor=procs, stopping_criteria=60 + 120, eos_token_id=[None],
+                                                 return_dict_in_generate=True, output_scores=True, decoding_kwargs=d))
+        a, b = outs
+        assert a.sequences[0].tolist() == b.sequences[0].tolist()
+        assert a.kwargs['dls'] == b.kwargs['dls'] and a.kwargs['edls'] == b.kwargs['edls']
+        assert len(a.scores) == len(b.scores) == len(a.kwargs['dls'])
+        for i, (x, y) in enumerate(zip(a.scores, b.scores)):
+            assert x.shape == (1, shape.vocab)
+            x, y = x.float().cpu(), y.float().cpu()
+            fin = torch.isfinite(y)
+            assert torch.equal(fin, torch.isfinite(x))
+            assert float((x[fin] - y[fin]).abs().max()) <= TOL * float(y[fin].abs().max()), i
+            if a.kwargs['dls'][i] > 1 and not extra:
+                assert torch.equal(x, a.scores[i - 1].float().cpu())
+    assert max(a.kwargs['dls']) > 1            # the warmed requests did run draft steps

@@ -67,8 +67,87 @@ def test_generate_front_door_and_unsupported_options():
     b = m.generate(input_ids=prompt, max_new_tokens=30, decoding_kwargs={'use_lookahead': False}, eos_token_id=2)
     n = min(a.shape[1], b.shape[1])
     assert a[0, :n].tolist() == b[0, :n].tolist()
-    with pytest.raises(NotImplementedError):           # scores are not produced by the device path
-        m.lookahead_generation(prompt, stopping_criteria=60, output_scores=True, decoding_kwargs=dict(DK))
+    with pytest.raises(NotImplementedError):           # attention maps / hidden states are never materialised by the device path
+        m.lookahead_generation(prompt, stopping_criteria=60, output_attentions=True, decoding_kwargs=dict(DK))
+    with pytest.raises(NotImplementedError):
+        m.lookahead_generation(prompt, stopping_criteria=60, output_hidden_states=True, decoding_kwargs=dict(DK))
+
+
+def test_output_scores_are_the_tuple_the_reference_returns():
+    """`scores` under output_scores + return_dict_in_generate, against the reference's own run (oracle/gen_golden_scores.py): one entry
+    per verify step, each the processed logits of the most recent NO-DRAFT step (pretrained_model.py:795, 1195, 1208: the draft branch
+    never refreshes model_kwargs['next_tokens_scores']) — with an empty processor list (device accept path) and with
+    RepetitionPenaltyLogitsProcessor (host-walked path).  Tokens / dls / edls as in the reference run; scores to 2e-4 (fp32 forward
+    of the oracle vs the reference's eager graph).  fresh_scores (extension): draft steps carry the row of their last emitted token."""
+    from transformers import LogitsProcessorList, RepetitionPenaltyLogitsProcessor
+    from tests.tiny_model import GOLDEN
+    g = np.load(os.path.join(GOLDEN, 'llama_tiny_scores_fp32.npz'))
+    m = Model(torch.float32)
+    prompt = g['bs1_prompt'].tolist()
+    for r, procs in enumerate([None, LogitsProcessorList([RepetitionPenaltyLogitsProcessor(float(g['penalty']))])]):
+        out = m.lookahead_generation(torch.tensor([prompt]), logits_processor=procs, stopping_criteria=len(prompt) + 64, eos_token_id=2,
+                                     return_dict_in_generate=True, output_scores=True, decoding_kwargs=dict(DK))
+        assert out.sequences[0].tolist() == g[f'bs1_r{r}_sequences'].tolist()
+        assert out.kwargs['dls'] == g[f'bs1_r{r}_dls'].tolist() and out.kwargs['edls'] == g[f'bs1_r{r}_edls'].tolist()
+        ref = g[f'bs1_r{r}_scores']
+        assert len(out.scores) == ref.shape[0] == len(out.kwargs['dls'])
+        got = torch.cat(out.scores, 0).float().numpy()
+        assert got.shape == ref.shape
+        fin = np.isfinite(ref)
+        assert np.array_equal(fin, np.isfinite(got))
+        assert np.abs(got[fin] - ref[fin]).max() < 2e-4
+        dls = out.kwargs['dls']
+        assert any(d > 1 for d in dls)
+        for i, d in enumerate(dls):                      # a step with drafts repeats the previous entry
+            if d > 1:
+                assert np.array_equal(got[i], got[i - 1])
+    # without return_dict_in_generate nothing is collected (pretrained_model.py:1092); generate() forwards the flag
+    seq = m.lookahead_generation(torch.tensor([prompt]), stopping_criteria=len(prompt) + 8, eos_token_id=2, output_scores=True,
+                                 decoding_kwargs=dict(DK))
+    assert torch.is_tensor(seq)
+    m2 = Model(torch.float32)
+    out = m2.generate(input_ids=torch.tensor([prompt]), max_new_tokens=64, eos_token_id=2, return_dict_in_generate=True,
+                      output_scores=True, decoding_kwargs=dict(DK))
+    assert len(out.scores) == len(out.kwargs['dls']) and out.sequences[0].tolist() == g['bs1_r0_sequences'].tolist()
+    # extension: per-step scores of the step's own last pick
+    m3 = Model(torch.float32)
+    m3.generate(input_ids=torch.tensor([prompt]), max_new_tokens=64, eos_token_id=2, decoding_kwargs=dict(DK))     # warm the trie
+    dk = dict(DK); dk['fresh_scores'] = True
+    out = m3.lookahead_generation(torch.tensor([prompt]), stopping_criteria=len(prompt) + 64, eos_token_id=2,
+                                  return_dict_in_generate=True, output_scores=True, decoding_kwargs=dk)
+    assert out.sequences[0].tolist() == g['bs1_r0_sequences'].tolist()
+    seq, pos = out.sequences[0].tolist(), len(prompt)
+    assert max(out.kwargs['dls']) > 1
+    for sc, e in zip(out.scores, out.kwargs['edls']):
+        pos += e
+        assert int(torch.argmax(sc[0])) == seq[pos - 1]          # the row the step's last token was picked from
+
+
+def test_batch_output_scores_are_the_tuple_the_reference_returns():
+    """Batch loop: the reference appends model_kwargs['next_tokens_scores'] once per loop iteration and only its PREFILL branch ever
+    writes it (pretrained_model_batch.py:789, 807, 1247, 1263) — [bs, vocab] of the last prompt rows, repeated.  Against the reference's own
+    run (oracle/gen_golden_scores.py, 3 left-padded prompts); single-block and multi-block engines."""
+    from painlessinferenceacceleration_amd.pretrained_model_batch import LookaheadPreTrainedModel as BatchMixin
+    from tests.oracle_engine import OracleBatchEngine
+    from tests.tiny_model import GOLDEN
+    g = np.load(os.path.join(GOLDEN, 'llama_tiny_scores_fp32.npz'))
+    ids, am = torch.from_numpy(g['b3pad_ids']), torch.from_numpy(g['b3pad_am'])
+    ref = g['b3pad_scores']
+    for max_blocks in (0, 4):
+        class BModel(BatchMixin):
+            def __init__(self):
+                self.engine = OracleBatchEngine(tiny_shape(), tiny_weights(0), max_length=256, n_slots=4, max_blocks=max_blocks)
+                self.generation_config = SimpleNamespace(eos_token_id=2, pad_token_id=0, return_dict_in_generate=False)
+                self.lookahead_cache = LookaheadCache()
+        m = BModel()
+        out = m.lookahead_generation(ids, stopping_criteria=ids.shape[1] + 48, eos_token_id=2, pad_token_id=0, return_dict_in_generate=True,
+                                     output_scores=True, attention_mask=am, decoding_kwargs=dict(DK))
+        assert out.sequences.tolist() == g['b3pad_sequences'].tolist()
+        assert out.kwargs['dls'] == g['b3pad_dls'].tolist() and out.kwargs['edls'] == g['b3pad_edls'].tolist()
+        assert len(out.scores) == ref.shape[0]
+        got = torch.stack(out.scores, 0).float().numpy()
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 2e-4
+        assert all(np.array_equal(got[i], got[0]) for i in range(len(got)))
 
 
 # ------------------------------------------------------------------------------------------------ batch twin
