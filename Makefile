@@ -17,4 +17,5 @@ bench: build
 golden:
 	python oracle/gen_golden.py && python oracle/gen_golden_model.py && python oracle/gen_golden_batch.py && \
 	python oracle/gen_golden_moe.py && python oracle/gen_golden_processors.py && python oracle/gen_golden_mem.py && \
-	python oracle/gen_golden_noisy.py && python oracle/gen_golden_batch_processors.py && python oracle/gen_golden_bench_trace.py
+	python oracle/gen_golden_noisy.py && python oracle/gen_golden_batch_processors.py && python oracle/gen_golden_bench_trace.py && \
+	python oracle/gen_golden_scores.py && python oracle/gen_golden_headdim.py

@@ -43,7 +43,7 @@ extern "C" {
 #define LA_MOE_MAX_E      8   /* experts per mixture-of-experts layer (Mixtral: 8, top-2) */
 
 /* ABI version: bumped when a signature changes. */
-#define LA_ABI_VERSION  11   /* bumped whenever a struct layout or an entry point changes */
+#define LA_ABI_VERSION  12   /* bumped whenever a struct layout or an entry point changes */
 int          la_abi_version(void);   /* == LA_ABI_VERSION of the header the library was built from */
 /* Storage / MFMA-input type of the loaded library: 0 = bfloat16 (liblookahead_hip.so), 1 = float16 (liblookahead_hip_f16.so, the
  * dtype the reference's examples and benchmarks run, lookahead/benchmarks/llama_benchmark.py:27).  The two libraries are the same
@@ -305,6 +305,16 @@ int la_gemm64_qkv(void* stream, const void* d_wp, const void* d_xp, int n_heads,
                   const int32_t* d_pos, const void* d_rope_cos, const void* d_rope_sin,
                   void* d_qf, void* d_kfresh, void* d_vfresh, int variant);
 int la_qkv_row_perm(int n_heads, int n_kv_heads, int32_t* perm /*[(nh+2*nkv)*128], host*/);
+/* Heads narrower than 128 features (LlamaAttention is shape-generic, models/llama/modeling_llama.py:189-308): every kernel of this library
+ * lays a head out as a 128-feature LANE (RoPE pairs (d, d + 64), 8192-element Q / K / V fragments, o_proj's K = n_heads * 128).  A model
+ * with head_dim < 128 (even) runs in the same lanes with zero padding: lane_src[j] = the head's own feature that lane j carries, or -1 for
+ * a padding lane — feature d < head_dim/2 sits in lane d, its rotary partner d + head_dim/2 in lane 64 + d.  The caller builds
+ * [Wq;Wk;Wv] with 128 rows per head (row of lane j = the head's row lane_src[j], zero rows for -1) and o_proj with 128 columns per head
+ * the same way BEFORE la_qkv_row_perm / la_rowplan / la_pack_*, and RoPE tables of 64 columns whose column d < head_dim/2 holds
+ * cos / sin(pos * theta^(-2d / head_dim)) (the rest is never multiplied with a non-zero value).  Zero lanes add exact zeros to every dot
+ * product (q.k, P.v, o_proj), so the results are those of the unpadded model; la_llama_config.head_dim (the real one) sets the softmax
+ * scale 1 / sqrt(head_dim).  Cost: K/V rows, the attention kernels and QKV / o_proj run at the 128-lane width. */
+int la_head_lane_map(int head_dim, int32_t* lane_src /*[128], host*/);
 /* Balanced variants: exactly n_wg workgroups (one per CU: n_wg = CU count, 256 on MI355X), each owning
  * R = rows/n_wg rows per matrix as 32-row blocks with a partial last block.  The weight image is packed by
  * la_pack_planned following la_rowplan (out[i] = source row of packed row i, -1 = zero pad row;
@@ -350,7 +360,7 @@ int la_tree_attn(void* stream, const void* d_qf, const void* d_kmain, const void
 typedef struct la_llama la_llama;
 
 typedef struct la_llama_config {
-    int32_t n_layers, hidden, n_heads, n_kv_heads, head_dim, ffn, vocab;
+    int32_t n_layers, hidden, n_heads, n_kv_heads, head_dim, ffn, vocab;   /* head_dim: even, 8 .. 128; < 128: padded lanes, la_head_lane_map */
     int32_t max_keys;        /* KV capacity per sequence, multiple of 32, >= max_length + 64 */
     int32_t max_pos;         /* rows in the RoPE tables                                       */
     int32_t attn_split;      /* key-range splits per head (0 = auto)                          */
@@ -384,8 +394,8 @@ typedef struct la_llama_config {
 } la_llama_config;
 
 typedef struct la_llama_layer_weights {   /* device pointers, packed by la_pack_weight */
-    const void* wqkv;        /* [(nh+2*nkv)*hd][hidden], rows gathered by la_qkv_row_perm unless gemm_cfg[1] < 0 */
-    const void* wo;          /* [hidden][nh*hd]                */
+    const void* wqkv;        /* [(nh+2*nkv)*128][hidden] (128-feature lanes, la_head_lane_map), rows gathered by la_qkv_row_perm unless gemm_cfg[1] < 0 */
+    const void* wo;          /* [hidden][nh*128]               */
     const void* wgateup;     /* interleaved gate/up [2*ffn][hidden] */
     const void* wdown;       /* [hidden][ffn]                  */
     const void* norm1;       /* input_layernorm weight bf16 [hidden]          */
@@ -403,8 +413,8 @@ typedef struct la_llama_weights {
     const void* embed;       /* [vocab][hidden] bf16 row-major (gather source) */
     const void* lm_head;     /* packed [vocab][hidden]                         */
     const void* final_norm;  /* bf16 [hidden]                                  */
-    const void* rope_cos;    /* bf16 [max_pos][head_dim/2]                     */
-    const void* rope_sin;    /* bf16 [max_pos][head_dim/2]                     */
+    const void* rope_cos;    /* bf16 [max_pos][64]: column d < head_dim/2 = cos(pos * theta^(-2d/head_dim)) */
+    const void* rope_sin;    /* bf16 [max_pos][64]                             */
     const la_llama_layer_weights* layers;   /* host array [n_layers]           */
 } la_llama_weights;
 

@@ -19,7 +19,7 @@ LIB_PATH_F16 = LAB_PATH_F16 if LAB_BUILD else os.path.join(_HERE, "liblookahead_
 LA_DTYPE_BF16, LA_DTYPE_F16 = 0, 1
 
 LA_OK = 0
-ABI_VERSION = 11        # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
+ABI_VERSION = 12        # LA_ABI_VERSION of include/lookahead_hip.h these bindings were written against
 LA_MODE_INPUT, LA_MODE_OUTPUT, LA_MODE_MIX = 0, 1, 2
 LA_TREE_MAX = 64
 LA_MOE_MAX_E = 8
@@ -170,6 +170,7 @@ PROTOTYPES = {
     "la_gemm64_swiglu": (i32, vp, vp, vp, i32, i32, vp, i32),
     "la_gemm64_qkv": (i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, i32),
     "la_qkv_row_perm": (i32, i32, i32, pi32),
+    "la_head_lane_map": (i32, i32, pi32),
     "la_rowplan": (i32, i32, i32, i32, pi32),
     "la_planned_elems": (i64, i32, i32, i32, i32),
     "la_pack_planned": (i32, vp, vp, vp, vp, i32, i32, i32, i32, vp),

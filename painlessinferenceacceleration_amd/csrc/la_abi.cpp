@@ -77,6 +77,15 @@ int la_qkv_row_perm(int nh, int nkv, int32_t* perm) {
     lk_qkv_row_perm(nh, nkv, perm);
     return LA_OK;
 }
+int la_head_lane_map(int head_dim, int32_t* lane_src) {
+    if (!lane_src || head_dim < 2 || head_dim > 128 || (head_dim & 1)) return LA_E_ARG;
+    const int half = head_dim / 2;
+    for (int j = 0; j < 128; ++j) {
+        const int d = j & 63;
+        lane_src[j] = d < half ? (j < 64 ? d : half + d) : -1;
+    }
+    return LA_OK;
+}
 int la_rowplan(int kind, int n_rows, int n_wg, int32_t* out) {
     if (kind < 0 || kind > 2 || n_rows <= 0 || n_wg <= 0) return LA_E_ARG;
     int n = lk_rowplan(kind, n_rows, n_wg, out);

@@ -32,6 +32,7 @@ struct Attn1Args {
     const bf16_t* vfresh;
     bf16_t* attn_xp;
     long long* dbg_times;     // measurement aid: [workgroup][wave][8] wall-clock stamps, null in production
+    float qk;                 // la_qk_scale(head_dim) (attn_scale, la_common.h)
     int n_main;               // workgroups of the attention proper; block ids past it are weight-prefetch riders (round 6, see pf)
     PfDesc pf;                // riders: the first KiB every o_proj workgroup will stream, pulled into its XCD's L2 by the CUs this launch leaves idle
 };
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
             for (int i = 0; i < 16; ++i) {
                 // attn_weights = bf16(QK^T) / sqrt(head_dim) -> bf16 (modeling_llama.py:270); bf16(x / sqrt(128)) == bf16(x * fp32(1 / sqrt(128)))
                 // for every finite bf16 x (tests/test_oracle_llama.py::test_attention_scale_as_multiply_is_exact)
-                const float v = attn_scale(sc[i]);
+                const float v = attn_scale(sc[i], a.qk);
                 sc[i] = v;
                 mx = fmaxf(mx, v);
             }
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(512) void k_tree_attn1(const bf16_t* __restrict__ q
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int kk = (i & 3) + 8 * (i >> 2) + 4 * hh;
-                float v = attn_scale(sc[i]);
+                float v = attn_scale(sc[i], a.qk);
                 const int kidx = (ts + kb) * 32 + kk;                  // committed keys: absolute index = position
                 const bool ok = fresh ? ((rm >> (kb * 32 + kk)) & 1ull) != 0ull : (kidx < nkeys && kidx >= key_lo);
                 v = ok ? v : LA_NEG;
@@ -320,7 +321,7 @@ int lk_attn1_init() {
 }
 int lk_tree_attn1(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh, const void* vfresh,
                   const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys, void* attn_xp, int window, int ring_keys,
-                  const PfDesc* pf) {
+                  const PfDesc* pf, int head_dim) {
     if (nh <= 0 || nkv <= 0 || nh % nkv || nh > 0x7fff || (ring_keys >> 5) >= (1 << 22)) return -1;
     if (lk_gemm64r_init() != 0) return -1;
     // token slices per 32-row block: 2 (measured: every slice count streams the same bytes per CU — all of the head's K/V — and
@@ -332,6 +333,7 @@ int lk_tree_attn1(hipStream_t st, const void* qf, const void* kmain, const void*
     const int W = 32 / SL;
     Attn1Args a{};
     a.kfresh = (const bf16_t*)kfresh; a.vfresh = (const bf16_t*)vfresh; a.attn_xp = (bf16_t*)attn_xp; a.dbg_times = g_la_dbg_times;
+    a.qk = la_qk_scale(head_dim);
     const size_t lds = 8192 + (size_t)8 * 16 * 2 * W * 16 + (size_t)8 * W * 8;
     a.n_main = nh * 2 * SL;
     int riders = 0;

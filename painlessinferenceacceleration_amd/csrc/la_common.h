@@ -17,6 +17,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
+#include <math.h>
 
 // Storage / MFMA-input type of THIS build of the library.  Every kernel is written once; the build compiles the sources twice:
 //   LA_DTYPE 0 -> liblookahead_hip.so      bfloat16, v_mfma_f32_32x32x16_bf16 (BASELINE's dtype)
@@ -62,13 +64,21 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 #else
 #define LA_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), (x), (y), (z))
 #endif
-// attn_weights = (q @ k^T in the storage type) / sqrt(head_dim = 128), rounded to the storage type (modeling_llama.py:270).
-// bf16: x / sqrt(128) == x * fp32(1 / sqrt(128)) after rounding for EVERY finite bf16 x (exhaustive check,
-// tests/test_oracle_llama.py::test_attention_scale_as_multiply_is_exact) — one multiply; fp16: 52 of the 65536 patterns differ, so the
-// fp16 build divides (torch: fp32 division of the upcast value, then one rounding).
-__device__ __forceinline__ float attn_scale(float s) {
-    if constexpr (LA_DTYPE == 1) return bfr(bfr(s) / 11.313708498984761f);
-    else return bfr(bfr(s) * 0.088388346135616302490234375f);
+// attn_weights = (q @ k^T in the storage type) / sqrt(head_dim), rounded to the storage type (modeling_llama.py:270).  `qk` is a kernel
+// argument (la_qk_scale(head_dim), la_kernels.h): bf16 build: fp32(1 / sqrt(head_dim)) — x / sqrt(d) == x * fp32(1 / sqrt(d)) after rounding for
+// EVERY finite bf16 x and every d = 16, 24, .. 128 (exhaustive check, tests/test_oracle_llama.py::test_attention_scale_as_multiply_is_exact;
+// la_llama_create repeats it for the d it is given) — one multiply; fp16 build: fp32(sqrt(head_dim)) — 52 of the 65536 fp16 patterns differ
+// at d = 128 (54 at d = 32), so the fp16 build divides (torch: fp32 division of the upcast value, then one rounding).
+__host__ __device__ __forceinline__ float la_qk_scale(int head_dim) {
+#if LA_DTYPE == 1
+    return (float)sqrt((double)head_dim);
+#else
+    return (float)(1.0 / sqrt((double)head_dim));
+#endif
+}
+__device__ __forceinline__ float attn_scale(float s, float qk) {
+    if constexpr (LA_DTYPE == 1) return bfr(bfr(s) / qk);
+    else return bfr(bfr(s) * qk);
 }
 
 // accumulator register r of a 32x32 MFMA tile -> row inside the tile (col = lane&31)

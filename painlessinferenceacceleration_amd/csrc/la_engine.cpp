@@ -99,8 +99,11 @@ struct Carver {
 
 static void resolve_cfg(la_llama* m) {
     const la_llama_config& c = m->cfg;
-    m->qkv_n = (c.n_heads + 2 * c.n_kv_heads) * c.head_dim;
-    m->o_k = c.n_heads * c.head_dim;
+    // every head occupies a 128-feature LANE of the Q / K / V fragment layouts and of o_proj's K dimension, whatever cfg.head_dim is: a
+    // model with head_dim < 128 arrives with its projections padded to the lane (zero rows / columns at pack time, la_llama_config), the
+    // kernels see 128 everywhere and only the softmax scale (la_qk_scale) knows the real head_dim
+    m->qkv_n = (c.n_heads + 2 * c.n_kv_heads) * 128;
+    m->o_k = c.n_heads * 128;
     // key splits of the tree attention: heads x splits workgroups should fit ONE wave over the CUs (32 heads -> 8, 40 -> 6, 64 -> 4)
     {
         const int cus = c.balanced_wg[1] > 0 ? c.balanced_wg[1] : 256;
@@ -253,7 +256,8 @@ static size_t carve(la_llama* m, char* base) {
 
 static int validate(const la_llama_config* c) {
     if (!c) return LA_E_ARG;
-    if (c->head_dim != 128) { la_set_error("head_dim must be 128"); return LA_E_ARG; }
+    if (c->head_dim < 8 || c->head_dim > 128 || (c->head_dim & 1)) { la_set_error("head_dim must be even, 8 .. 128 (heads narrower than 128 run in padded 128-feature lanes)"); return LA_E_ARG; }
+    if (lk_qk_scale_check(c->head_dim) != 0) { la_set_error("softmax scale: x * fp32(1 / sqrt(head_dim)) is not the rounded quotient for every bf16 x at this head_dim"); return LA_E_ARG; }
     if (c->n_layers <= 0 || c->hidden % 32 || c->hidden > 8192 || c->ffn % 32 || c->vocab % 32 ||
         c->n_heads % c->n_kv_heads || c->max_keys % 32 || c->max_keys < 96 || c->n_slots < 0 || c->n_slots > LA_MAX_SEQ ||
         c->max_blocks < 0 || c->max_blocks > LA_MB_MAX || c->n_experts < 0 || c->n_experts > LA_MOE_MAX_E || (c->n_experts > 0 && (c->top_k < 1 || c->top_k > c->n_experts))) {
@@ -472,14 +476,14 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
         if (batch)
             KCHK(lk_tree_attn_b(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
                                 kf, vf, m->rowmask, m->bstate, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, bsplit > 0 ? bsplit : m->nsplit,
-                                m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window, ring, &pd));
+                                m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window, ring, &pd, c.head_dim));
 #if LA_LAB
         else if (g_la_attn_merge_ns > 0 && !long_ctx && c.n_experts == 0 && c.sliding_window <= 0 && (m->o_k / 16) / m->o_ks == 64 &&
                  g_la_attn_merge_ns <= m->nsplit && c.hidden % 64 == 0) {
             // lab knob 33 (review item 1b): key-split attention over NS splits, NO combine launch — o_proj merges the partials on load
             KCHK(lk_tree_attn(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
                               kf, vf, m->rowmask, m->state, c.n_heads, c.n_kv_heads, m->total_keys, g_la_attn_merge_ns,
-                              m->opart, m->mpart, m->lpart, nullptr, c.sliding_window, ring, nullptr, 0));
+                              m->opart, m->mpart, m->lpart, nullptr, c.sliding_window, ring, nullptr, 0, nullptr, c.head_dim));
             P(KC_O);
             KCHK(lk_oproj_merge(st, L.wo, c.hidden, m->o_k, m->o_ks, g_la_attn_merge_ns, m->opart, m->mpart, m->lpart, m->slabs));
             goto after_oproj;
@@ -491,7 +495,7 @@ static int enqueue_step(la_llama* m, hipStream_t st, Prof* pf, bool batch = fals
             if (g_la_attn_ride_kib > 0 && !long_ctx) lk_pf_classic(&rd, L.wo, c.hidden, m->o_k, m->o_rb, m->o_ks, g_la_attn_ride_kib, g_la_attn_ride_delay, nullptr);
             KCHK(lk_tree_attn(st, m->qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems,
                               kf, vf, m->rowmask, m->state, c.n_heads, c.n_kv_heads, m->total_keys, m->nsplit,
-                              m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window, ring, &pd, long_ctx ? 0 : -1, &rd));
+                              m->opart, m->mpart, m->lpart, m->attn_xp, c.sliding_window, ring, &pd, long_ctx ? 0 : -1, &rd, c.head_dim));
         }
         P(KC_O);
         if (g_la_oproj_probe && !batch)            // timing probe (lab knob 34): another o_proj geometry; numerics are NOT preserved
@@ -748,7 +752,7 @@ static int enqueue_mstep(la_llama* m, hipStream_t st, int nblk, bool wide = fals
         KCHK(lk_mb_tree_attn(st, m->mb_qf, m->kmain + (size_t)l * m->kv_layer_elems, m->vmain + (size_t)l * m->kv_layer_elems, kf, vf,
                              m->mb_rowmask, m->mb_meta, nblk, c.n_heads, c.n_kv_heads, c.max_keys, m->n_slots, mb_split(nblk, c.n_heads, c.balanced_wg[1] > 0 ? c.balanced_wg[1] : 256),
                              m->mb_opart, m->mb_mpart, m->mb_lpart, m->mb_attn_xp, c.sliding_window, c.kv_ring ? 1 : 0,
-                             wide ? (const uint64_t*)(m->mb_in + LA_MIN_XMASK) : nullptr));
+                             wide ? (const uint64_t*)(m->mb_in + LA_MIN_XMASK) : nullptr, c.head_dim));
         MbGemm o{}; o.wp = L.wo; o.xp = m->mb_attn_xp; o.N = c.hidden; o.K = m->o_k; o.nblk = nblk; o.ksplit = o_ks;
         o.slabs = m->mb_slabs; o.slab_rows = npass_rows;
         KCHK(lk_mb_gemm(st, 0, o));

@@ -81,19 +81,22 @@ int lk_qkv_post(hipStream_t st, const float* slabs, int n_slabs, int nh, int nkv
 int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                  const void* vfresh, const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys,
                  int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window = 0, int ring_keys = 0,
-                 const PfDesc* pf = nullptr, int form = -1, const PfDesc* ride = nullptr);      // form: 0 = key splits + combine, -1 = the default (one launch, la_attn1.hip) unless a lab knob says otherwise
+                 const PfDesc* pf = nullptr, int form = -1, const PfDesc* ride = nullptr, int head_dim = 128);      // form: 0 = key splits + combine, -1 = the default (one launch, la_attn1.hip) unless a lab knob says otherwise
 int lk_attn1_init();
+// 0 if the softmax scale of this build (attn_scale, la_common.h) is EXACT for head_dim: the fp16 build divides (always exact); the bf16 build
+// multiplies by fp32(1 / sqrt(head_dim)), which this routine checks against the correctly rounded quotient for every finite bf16 value
+int lk_qk_scale_check(int head_dim);
 // lab (round 6, knob 33): o_proj that merges the key-split attention partials while it builds its x operand (la_oproj_merge.hip)
 int lk_oproj_merge(hipStream_t st, const void* wp, int N, int K, int ksplit, int nsplit, const float* opart, const float* mpart,
                    const float* lpart, float* slabs);
 // single-sequence step, ONE launch (la_attn1.hip): no key-split partials, no combine kernel
 int lk_tree_attn1(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh, const void* vfresh,
                   const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys, void* attn_xp, int window, int ring_keys,
-                  const PfDesc* pf = nullptr);      // pf: weight-prefetch riders for the next launch (o_proj) on the CUs this one leaves idle
+                  const PfDesc* pf = nullptr, int head_dim = 128);      // pf: weight-prefetch riders for the next launch (o_proj) on the CUs this one leaves idle
 int lk_tree_attn_b(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                    const void* vfresh, const uint64_t* rowmask, const int* bstate, int nh, int nkv, int slot_keys,
                    int n_slots, int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window = 0, int ring_keys = 0,
-                   const PfDesc* pf = nullptr);
+                   const PfDesc* pf = nullptr, int head_dim = 128);
 int lk_build_tree_inputs_b(hipStream_t st, const int* in, int* bstate, int* pos, uint64_t* rowmask, int* ids);
 int lk_accept_scan_b(hipStream_t st, const int* in, const int* ids, const uint64_t* rowmask, int* bstate, int n_slots,
                      int slot_keys, int ring = 0);

@@ -1233,6 +1233,7 @@ struct AttnArgs {
     const unsigned long long* rowmask;
     const int* state;
     int nh, nkv, max_keys, nsplit;
+    float qk;       // la_qk_scale(head_dim): softmax scale of the build (attn_scale, la_common.h)
     float* opart;   // [nh][nsplit][64][128]
     float* mpart;   // [nh][nsplit][64]
     float* lpart;
@@ -1355,7 +1356,7 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(const bf16_t*
         if (whole) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float v = attn_scale(sc[i]);
+                const float v = attn_scale(sc[i], a.qk);
                 sc[i] = v;
                 mx = fmaxf(mx, v);
             }
@@ -1365,7 +1366,7 @@ __global__ __launch_bounds__(2 * LA_ATT_PAR * 64) void k_tree_attn(const bf16_t*
                 const int kk = (i & 3) + 8 * (i >> 2) + 4 * hh;
                 // bf16(x / sqrt(128)) == bf16(x * fp32(1 / sqrt(128))) for EVERY finite bf16 x (checked exhaustively over the 65536 bit
                 // patterns, tests/test_oracle_llama.py::test_attention_scale_as_multiply_is_exact): one multiply instead of an IEEE division
-                float v = attn_scale(sc[i]);
+                float v = attn_scale(sc[i], a.qk);
                 const int kidx = (ts + kb) * 32 + kk;      // committed keys: absolute index = position
                 const bool ok = fresh ? ((rm >> (kb * 32 + kk)) & 1ull) != 0ull : (kidx < nk_row && kidx >= key_lo);
                 v = ok ? v : LA_NEG;
@@ -2252,12 +2253,30 @@ int lk_qkv_post(hipStream_t st, const float* slabs, int n_slabs, int nh, int nkv
 }
 static int tree_attn_launch(hipStream_t st, AttnArgs a, int n_slots, void* attn_xp, const PfDesc* pf);
 
+int lk_qk_scale_check(int head_dim) {
+    if (head_dim < 2 || head_dim > 128 || (head_dim & 1)) return -1;
+    if (LA_DTYPE == 1) return 0;                               // the fp16 build divides
+    auto rne = [](float f) -> uint32_t {                       // fp32 -> bf16 bits, round-to-nearest-even (finite inputs)
+        uint32_t u; memcpy(&u, &f, 4);
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    };
+    const float mul = (float)(1.0 / sqrt((double)head_dim)), div = (float)sqrt((double)head_dim);
+    for (uint32_t b = 0; b < 65536u; ++b) {
+        if (((b >> 7) & 0xffu) == 0xffu) continue;             // inf / nan
+        const uint32_t u = b << 16;
+        float x; memcpy(&x, &u, 4);
+        if (rne(x * mul) != rne(x / div)) return 1;
+    }
+    return 0;
+}
+
 int lk_tree_attn_b(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                    const void* vfresh, const uint64_t* rowmask, const int* bstate, int nh, int nkv, int slot_keys,
                    int n_slots, int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window, int ring_keys,
-                   const PfDesc* pf) {
+                   const PfDesc* pf, int head_dim) {
     if (n_slots < 1 || n_slots > LA_MAX_SEQ || (slot_keys & 31)) return -1;
     AttnArgs a{};
+    a.qk = la_qk_scale(head_dim);
     a.dbg_times = g_la_dbg_times;
     a.window = window; a.ring_tiles = ring_keys >> 5;
     a.qf = (const bf16_t*)qf; a.kmain = (const bf16_t*)kmain; a.vmain = (const bf16_t*)vmain;
@@ -2272,8 +2291,9 @@ int lk_tree_attn_b(hipStream_t st, const void* qf, const void* kmain, const void
 int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh,
                  const void* vfresh, const uint64_t* rowmask, const int* state, int nh, int nkv, int max_keys,
                  int nsplit, float* opart, float* mpart, float* lpart, void* attn_xp, int window, int ring_keys,
-                 const PfDesc* pf, int form, const PfDesc* ride) {
+                 const PfDesc* pf, int form, const PfDesc* ride, int head_dim) {
     AttnArgs a{};
+    a.qk = la_qk_scale(head_dim);
     a.dbg_times = g_la_dbg_times;
     a.window = window; a.ring_tiles = ring_keys >> 5;
     a.qf = (const bf16_t*)qf; a.kmain = (const bf16_t*)kmain; a.vmain = (const bf16_t*)vmain;
@@ -2285,7 +2305,7 @@ int lk_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* 
     // default: the single-launch form (la_attn1.hip); la_debug_set(17, 0) = key splits + combine (the A/B switch, and the carrier of
     // the idle-window prefetch workgroups)
     if (g_la_attn_one && form != 0 && !pf_extra(pf) && !g_la_attn_staged)
-        return lk_tree_attn1(st, qf, kmain, vmain, kfresh, vfresh, rowmask, state, nh, nkv, max_keys, attn_xp, window, ring_keys, ride);
+        return lk_tree_attn1(st, qf, kmain, vmain, kfresh, vfresh, rowmask, state, nh, nkv, max_keys, attn_xp, window, ring_keys, ride, head_dim);
     return tree_attn_launch(st, a, 1, attn_xp, pf);
 }
 

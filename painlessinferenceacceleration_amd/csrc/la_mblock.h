@@ -61,7 +61,7 @@ int lk_mb_logits_wgs(int V, int n_wg);
 int lk_mb_argmax(hipStream_t st, const float* cv, const int* ci, int n_tiles, int nblk, int* out_rows);
 int lk_mb_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh, const void* vfresh,
                     const uint64_t* rowmask, const int* meta, int nblk, int nh, int nkv, int slot_keys, int n_slots, int nsplit,
-                    float* opart, float* mpart, float* lpart, void* attn_xp, int window, int ring, const uint64_t* xmask);
+                    float* opart, float* mpart, float* lpart, void* attn_xp, int window, int ring, const uint64_t* xmask, int head_dim = 128);
 int lk_mb_accept_scan(hipStream_t st, const int* meta, const int* ids, const uint64_t* rowmask, const uint64_t* xmask, const int* argmax, int nblk,
                       int slot_keys, int ring, int* bstate, int* d_out);
 int lk_mb_kv_commit(hipStream_t st, const void* kfresh, const void* vfresh, void* kmain, void* vmain, const int* d_out, int nblk,

@@ -1825,6 +1825,7 @@ struct MbAttnArgs {
     const unsigned long long* xmask;                   // [blk][64][3] wide-tree pieces (mode 3): masks over the earlier pieces' rows
     const int* meta;
     int nh, nkv, total_keys, slot_tiles, nsplit, window, ring;      // ring: the slot's main cache is a ring of slot_tiles tiles
+    float qk;                                          // la_qk_scale(head_dim) (attn_scale, la_common.h)
     int rot;                                           // 1: the query heads of a kv head start their tile lists at different offsets (GQA)
     float* opart; float* mpart; float* lpart;          // [blk][nh][nsplit][64][128] ...
     bf16_t* attn_xp;                                   // nsplit == 1: the normalised output goes straight into o_proj's operand image
@@ -1940,7 +1941,7 @@ __global__ __launch_bounds__(512) void k_tree_attn_mb(MbAttnArgs a) {
             const int kk = (i & 3) + 8 * (i >> 2) + 4 * hh;
             // bf16(x / sqrt(128)) == bf16(x * fp32(1 / sqrt(128))) for EVERY finite bf16 x (checked exhaustively over the 65536 bit
             // patterns, tests/test_oracle_llama.py::test_attention_scale_as_multiply_is_exact): one multiply instead of an IEEE division
-            float v = attn_scale(sc[i]);
+            float v = attn_scale(sc[i], a.qk);
             bool ok;
             if (own) ok = ((rm >> (kb * 32 + kk)) & 1ull) != 0ull;
             else if (PIECE && prior && piece) {
@@ -2802,9 +2803,10 @@ int lk_mb_argmax(hipStream_t st, const float* cv, const int* ci, int n_tiles, in
 
 int lk_mb_tree_attn(hipStream_t st, const void* qf, const void* kmain, const void* vmain, const void* kfresh, const void* vfresh,
                     const uint64_t* rowmask, const int* meta, int nblk, int nh, int nkv, int slot_keys, int n_slots, int nsplit,
-                    float* opart, float* mpart, float* lpart, void* attn_xp, int window, int ring, const uint64_t* xmask) {
+                    float* opart, float* mpart, float* lpart, void* attn_xp, int window, int ring, const uint64_t* xmask, int head_dim) {
     if (lk_mb_init() != 0 || nblk < 1 || nblk > LA_MB_MAX || (slot_keys & 31)) return -1;
     MbAttnArgs a{};
+    a.qk = la_qk_scale(head_dim);
     a.xmask = (const unsigned long long*)xmask;
     a.qf = (const bf16_t*)qf; a.kmain = (const bf16_t*)kmain; a.vmain = (const bf16_t*)vmain;
     a.kfresh = (const bf16_t*)kfresh; a.vfresh = (const bf16_t*)vfresh;

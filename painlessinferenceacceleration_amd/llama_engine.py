@@ -242,7 +242,31 @@ class LlamaVerifyEngine(object):
         # torch.cuda.current_stream() returns by default
         self.stream = torch.cuda.Stream(self.device)
         sp = C.c_void_p(self.stream.cuda_stream)
-        hd = shape.head_dim
+        # Every kernel lays a head out as a 128-feature lane (RoPE pairs (d, d + 64), 8192-element Q / K / V fragments).  A model whose
+        # heads are narrower (LlamaAttention is shape-generic, modeling_llama.py:189-308) runs in the same lanes: its q / k / v rows and
+        # o_proj columns are spread over the lanes by la_head_lane_map (feature d -> lane d, its rotary partner d + hd/2 -> lane 64 + d,
+        # zeros elsewhere) BEFORE packing; zero lanes add exact zeros to every dot product, and cfg.head_dim — the real one — sets the
+        # softmax scale.  hd below is the LANE width every size is computed from.
+        self.head_dim = int(shape.head_dim)
+        if not (8 <= self.head_dim <= 128 and self.head_dim % 2 == 0):
+            raise ValueError(f'head_dim={self.head_dim}: even values from 8 to 128 are supported (128-feature lanes)')
+        hd = 128
+        lane_src = np.zeros(128, dtype=np.int32)
+        check(self._lib.la_head_lane_map(self.head_dim, lane_src.ctypes.data_as(_lib.pi32)), 'head_lane_map')
+        self._lane_src = lane_src
+
+        def to_lanes(w, n_h, dim):
+            """[n_h * head_dim, K] rows (dim 0) or [N, n_h * head_dim] columns (dim 1) -> the same with 128 lanes per head"""
+            if self.head_dim == 128:
+                return w
+            w = w.to(self.device)
+            src = torch.from_numpy(lane_src.astype(np.int64)).to(self.device)
+            idx = (torch.arange(n_h, device=self.device)[:, None] * self.head_dim + src.clamp(min=0)[None, :]).reshape(-1)
+            keep = (src >= 0).repeat(n_h)
+            out = w.index_select(dim, idx)
+            shape_ = [1, 1]
+            shape_[dim] = -1
+            return out * keep.reshape(shape_).to(out.dtype)
         self._keep = []
 
         def dev(t):
@@ -325,9 +349,9 @@ class LlamaVerifyEngine(object):
         layers = (_lib.LlamaLayerWeightsC * shape.n_layers)()
         for i in range(shape.n_layers):
             p = f'model.layers.{i}.'
-            qkv = torch.cat([take(p + 'self_attn.q_proj.weight').to(self.device),
-                             take(p + 'self_attn.k_proj.weight').to(self.device),
-                             take(p + 'self_attn.v_proj.weight').to(self.device)], 0)
+            qkv = torch.cat([to_lanes(take(p + 'self_attn.q_proj.weight').to(self.device), shape.n_heads, 0),
+                             to_lanes(take(p + 'self_attn.k_proj.weight').to(self.device), shape.n_kv_heads, 0),
+                             to_lanes(take(p + 'self_attn.v_proj.weight').to(self.device), shape.n_kv_heads, 0)], 0)
             if self.balanced_wg[0]:
                 layers[i].wqkv = pack_planned(0, [qkv]).data_ptr()
                 if self.qkv_mb_wg:
@@ -337,7 +361,7 @@ class LlamaVerifyEngine(object):
                     qkv = qkv.index_select(0, qkv_perm)
                 layers[i].wqkv = pack(qkv).data_ptr()
             del qkv
-            layers[i].wo = pack(take(p + 'self_attn.o_proj.weight')).data_ptr()
+            layers[i].wo = pack(to_lanes(take(p + 'self_attn.o_proj.weight'), shape.n_heads, 1)).data_ptr()
 
             def pack_gateup(gate, up):
                 return (pack_planned(1, [gate, up]) if self.balanced_wg[1] else pack(gate, up)).data_ptr()
@@ -377,7 +401,13 @@ class LlamaVerifyEngine(object):
             torch.cuda.synchronize(self.device)
         self._layers = layers
         self.embed = dev(take('model.embed_tokens.weight'))
-        self.rope_cos, self.rope_sin = rope_tables(hd, self.max_pos, shape.rope_theta, self.device, self.dtype)
+        self.rope_cos, self.rope_sin = rope_tables(self.head_dim, self.max_pos, shape.rope_theta, self.device, self.dtype)
+        if self.head_dim < 128:          # 64 columns per position: the lanes past head_dim / 2 only ever meet zeros
+            padc = torch.ones((self.max_pos, 64), dtype=self.dtype, device=self.device)
+            pads = torch.zeros((self.max_pos, 64), dtype=self.dtype, device=self.device)
+            padc[:, :self.head_dim // 2] = self.rope_cos
+            pads[:, :self.head_dim // 2] = self.rope_sin
+            self.rope_cos, self.rope_sin = padc.contiguous(), pads.contiguous()
         w = _lib.LlamaWeightsC()
         w.embed = self.embed.data_ptr()
         w.lm_head = (pack_planned(2, [take('lm_head.weight')]) if self.balanced_wg[2] else pack(take('lm_head.weight'))).data_ptr()
@@ -388,7 +418,7 @@ class LlamaVerifyEngine(object):
 
         cfg = _lib.LlamaConfigC()
         cfg.n_layers, cfg.hidden, cfg.n_heads, cfg.n_kv_heads = shape.n_layers, shape.hidden, shape.n_heads, shape.n_kv_heads
-        cfg.head_dim, cfg.ffn, cfg.vocab = hd, shape.ffn, shape.vocab
+        cfg.head_dim, cfg.ffn, cfg.vocab = self.head_dim, shape.ffn, shape.vocab
         cfg.max_keys, cfg.max_pos, cfg.attn_split, cfg.rms_eps = self.max_keys, self.max_pos, attn_split, shape.rms_eps
         for i, v in enumerate(gemm_cfg or []):
             cfg.gemm_cfg[i] = int(v)

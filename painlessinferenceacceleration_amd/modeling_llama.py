@@ -26,9 +26,15 @@ class LlamaForCausalLM(LookaheadPreTrainedModel):
         self.device = torch.device(device)
 
     @classmethod
+    def _shape_of(cls, cfg, kw):
+        """LlamaShape of a transformers config.  Family wrappers (modeling_mixtral.py) override this to check the checkpoint's family and to
+        consume their own keywords (sliding_window=...) from kw before the engine sees it."""
+        return LlamaShape.from_hf(cfg)
+
+    @classmethod
     def from_hf(cls, hf_model, **kw):
         """Wrap a transformers LlamaForCausalLM (weights are repacked into HBM; the HF module is not used afterwards)."""
-        shape = LlamaShape.from_hf(hf_model.config)
+        shape = cls._shape_of(hf_model.config, kw)
         kw.setdefault('eos_token_id', getattr(hf_model.config, 'eos_token_id', 2))
         kw.setdefault('pad_token_id', getattr(hf_model.config, 'pad_token_id', 0) or 0)
         return cls(shape, legacy_state_dict(hf_model.state_dict(), shape), **kw)
@@ -51,7 +57,7 @@ class LlamaForCausalLM(LookaheadPreTrainedModel):
         if device.isdigit():
             device = f'cuda:{device}'
         cfg, sd = load_hf_checkpoint(model_dir)
-        shape = LlamaShape.from_hf(cfg)
+        shape = cls._shape_of(cfg, kw)
         kw.setdefault('eos_token_id', getattr(cfg, 'eos_token_id', 2))
         kw.setdefault('pad_token_id', getattr(cfg, 'pad_token_id', 0) or 0)
         model = cls(shape, legacy_state_dict(sd, shape), max_length=max_length, device=device, consume_state_dict=True,

@@ -127,6 +127,21 @@ def test_qkv_row_perm_is_a_permutation_of_rope_pairs():
     assert ((b[:, 1, :] - b[:, 0, :]) == 64).all()
 
 
+def test_head_lane_map_keeps_rotary_partners_64_lanes_apart():
+    """la_head_lane_map: a head of head_dim < 128 features inside its 128-feature lane — feature d < hd/2 in lane d, its rotary partner
+    d + hd/2 (rotate_half, modeling_llama.py:146-151) in lane 64 + d, -1 (zero padding) elsewhere; the identity at 128."""
+    import numpy as np
+    for hd in (8, 32, 64, 96, 128):
+        m = np.zeros(128, dtype=np.int32)
+        assert _lib.lib.la_head_lane_map(hd, m.ctypes.data_as(_lib.pi32)) == 0
+        used = m[m >= 0]
+        assert sorted(used.tolist()) == list(range(hd))
+        for d in range(hd // 2):
+            assert m[d] == d and m[64 + d] == hd // 2 + d
+        assert (m[hd // 2:64] == -1).all() and (m[64 + hd // 2:] == -1).all()
+    assert _lib.lib.la_head_lane_map(130, m.ctypes.data_as(_lib.pi32)) != 0 and _lib.lib.la_head_lane_map(63, m.ctypes.data_as(_lib.pi32)) != 0
+
+
 def test_debug_knobs_roundtrip_and_defaults():
     """la_lab_set / la_lab_get: every knob reads back, out-of-range values are refused, and the library defaults are the
     documented ones (everything 0 except key 6 = 12657: the paired wide launches + (round 5) the fat-wave forms of gate/up and of the paired slab / QKV launches, and key 11 = 1 step per graph; round 3: 13 = depth probe,

@@ -153,3 +153,46 @@ def test_from_pretrained_front_door_runs_the_reference_example_sequence(tmp_path
     out2 = bm.generate(input_ids=two.cuda(), attention_mask=torch.ones_like(two).cuda(), max_new_tokens=32, pad_token_id=2,
                        eos_token_id=None, decoding_kwargs={'use_lookahead': True, 'decoding_length': 64, 'branch_length': 12})
     assert [o.tolist() for o in out2] == ref2
+
+
+def test_family_wrappers_check_the_family_and_map_the_sliding_window():
+    """modeling_mixtral.py (the surface of the reference's models/mistral + models/mixtral drivers): the wrapper refuses a checkpoint
+    of the other family, leaves the sliding window OFF by default (the reference's lookahead path feeds the full mask),
+    and maps sliding_window='config' / an integer / kv_ring onto the engine's shape.  Config objects only: no engine is built."""
+    from painlessinferenceacceleration_amd.modeling_mixtral import MistralForCausalLM, MixtralForCausalLM
+    mis, mix = _hf('mistral').config, _hf('mixtral').config
+    s = MistralForCausalLM._shape_of(mis, {})
+    assert s.n_experts == 0 and s.norm_cast_first and s.sliding_window == 0
+    kw = {'sliding_window': 'config', 'kv_ring': True, 'max_length': 256}
+    s = MistralForCausalLM._shape_of(mis, kw)
+    assert s.sliding_window == 4096 and 'sliding_window' not in kw and kw['kv_ring'] is True      # kv_ring travels on to the engine
+    assert MistralForCausalLM._shape_of(mis, {'sliding_window': 100}).sliding_window == 100
+    s = MixtralForCausalLM._shape_of(mix, {'sliding_window': 'config'})
+    assert s.n_experts == 8 and s.top_k == 2 and s.rope_theta == 1e6 and s.sliding_window == 0     # the checkpoint has no window
+    with pytest.raises(ValueError):
+        MixtralForCausalLM._shape_of(mis, {})
+    with pytest.raises(ValueError):
+        MistralForCausalLM._shape_of(mix, {})
+    with pytest.raises(ValueError):
+        MistralForCausalLM._shape_of(mis, {'kv_ring': True})
+    with pytest.raises(ValueError):
+        MistralForCausalLM._shape_of(mis, {'sliding_window': -5})
+
+
+@pytest.mark.gpu
+def test_mistral_wrapper_window_and_ring_generate_like_the_full_cache_inside_the_window():
+    """MistralForCausalLM.from_hf(..., sliding_window=W, kv_ring=True): while the context stays inside the window the windowed ring
+    engine must emit exactly what the default (full-mask, linear cache) wrapper emits; MixtralForCausalLM.from_hf runs the MoE path."""
+    from painlessinferenceacceleration_amd.modeling_mixtral import MistralForCausalLM, MixtralForCausalLM
+    m = _hf('mistral')
+    prompt = torch.tensor([_prompt(9, 40)])
+    dk = {'use_lookahead': True, 'decoding_length': 64, 'branch_length': 12, 'stop_words': {}}
+    full = MistralForCausalLM.from_hf(m, max_length=256)
+    ring = MistralForCausalLM.from_hf(m, max_length=256, sliding_window=200, kv_ring=True)
+    assert ring.engine.kv_ring and ring.shape.sliding_window == 200 and full.shape.sliding_window == 0
+    a = full.generate(input_ids=prompt, max_new_tokens=60, decoding_kwargs=dict(dk), eos_token_id=None)
+    b = ring.generate(input_ids=prompt, max_new_tokens=60, decoding_kwargs=dict(dk), eos_token_id=None)
+    assert a[0].tolist() == b[0].tolist()
+    moe = MixtralForCausalLM.from_hf(_hf('mixtral'), max_length=256)
+    out = moe.generate(input_ids=prompt, max_new_tokens=16, decoding_kwargs=dict(dk), eos_token_id=None)
+    assert out.shape[1] == 40 + 16

@@ -227,8 +227,10 @@ def test_attention_scale_in_fp16_needs_the_division():
 
 
 def test_attention_scale_as_multiply_is_exact():
-    """The HIP attention kernels compute bf16(scores / sqrt(head_dim)) (modeling_llama.py:270) as bf16(x * fp32(1/sqrt(128))): the two
-    agree for every finite bf16 x, so the multiply is a bit-exact restatement (head_dim = 128 is the only one the kernels serve)."""
+    """The bf16 attention kernels compute bf16(scores / sqrt(head_dim)) (modeling_llama.py:270) as bf16(x * fp32(1 / sqrt(head_dim)))
+    (attn_scale / la_qk_scale, csrc/la_common.h): the two agree for every finite bf16 x at every head_dim the engine accepts a model
+    with (even, 8 .. 128; la_llama_create repeats this check for the value it is given), so the multiply is a bit-exact restatement."""
+    import math
     import numpy as np
     import torch
     bits = (np.arange(65536, dtype=np.uint32) << 16)
@@ -237,6 +239,48 @@ def test_attention_scale_as_multiply_is_exact():
     div = (x / 11.313708498984761).to(torch.bfloat16).view(torch.int16)
     mul = (x * torch.tensor(np.float32(0.088388346135616302490234375))).to(torch.bfloat16).view(torch.int16)
     assert bool((div[fin] == mul[fin]).all())
+    xb = x[fin].to(torch.bfloat16)
+    for hd in range(8, 129, 2):
+        ref = (xb / math.sqrt(hd)).view(torch.int16)                          # what the reference's eager graph does
+        mul = (xb.float() * torch.tensor(np.float32(1.0 / math.sqrt(hd)))).to(torch.bfloat16).view(torch.int16)
+        assert bool((ref == mul).all()), hd
+
+
+@pytest.mark.parametrize('name', ['hd64', 'hd96'])
+def test_oracle_matches_reference_at_narrow_heads(name):
+    """head_dim 64 / 96 (LlamaAttention is shape-generic, modeling_llama.py:189-308): the oracle against the reference's own run
+    (oracle/gen_golden_headdim.py) — logits of the prefill and of the recorded tree forwards (fp32, 2e-4), then tokens / dls / edls of
+    two consecutive requests.  These vectors are what pins the padded-lane path of the engine (tests/test_gpu_e2e.py) to the reference."""
+    g = np.load(os.path.join(GOLDEN, f'llama_tiny_{name}_fp32.npz'))
+    hidden, nh, nkv = [int(x) for x in g['cfg']]
+    over = dict(hidden=hidden, n_heads=nh, n_kv_heads=nkv)
+    shape = tiny_shape(**over)
+    assert shape.head_dim == int(name[2:])
+    torch.set_num_threads(4)
+    model = lo.OracleLlama(shape, tiny_weights(0, torch.float32, cfg=over))
+    prompt = g['prompt'].tolist()
+    P = len(prompt)
+    cache = TrieOracle()
+    for r in range(2):
+        rec = []
+        out = lo.lookahead_generate(model, cache, prompt, P + int(g['max_new']), eos_token_id=2, record=rec)
+        assert out['sequences'] == g[f'r{r}_sequences'].tolist()
+        assert out['dls'] == g[f'r{r}_dls'].tolist() and out['edls'] == g[f'r{r}_edls'].tolist()
+        # replay the recorded forwards: the keys committed before step i are the sequence's first kv tokens
+        seq = g[f'r{r}_sequences'].tolist()
+        for i in g[f'r{r}_steps'].tolist():
+            ids, kv, ref = g[f'r{r}_s{i}_ids'].tolist(), int(g[f'r{r}_s{i}_kv']), g[f'r{r}_s{i}_logits']
+            if kv == 0:
+                T = len(ids)
+                logits, _ = model.forward(torch.tensor(ids), torch.tril(torch.ones((T, T), dtype=torch.long)), None)
+            else:
+                _, past = model.forward(torch.tensor(seq[:kv]), torch.tril(torch.ones((kv, kv), dtype=torch.long)), None)
+                rows = [int(x) for x in g[f'r{r}_s{i}_rows']]
+                T = len(ids)
+                tree = torch.tensor([[(rows[a] >> b) & 1 for b in range(T)] for a in range(T)], dtype=torch.long)
+                full = torch.cat([torch.ones((T, kv), dtype=torch.long), tree], 1)
+                logits, _ = model.forward(torch.tensor(ids), full, past)
+            assert np.abs(logits[:, :64].numpy() - ref).max() < 2e-4 * max(1.0, np.abs(ref).max()), (r, i)
 
 
 def test_oracle_batch_sequential_processor_path_matches_reference():
