@@ -136,7 +136,10 @@ __device__ __forceinline__ void moe_router_tail(const float (*shr)[E], int n_exp
 #pragma unroll
         for (int i = 0; i < E; ++i) m = fmaxf(m, __shfl(cand, i, 64));
         const unsigned long long hit = __ballot(valid && !taken && cand == m);
-        const int best = hit ? __builtin_ctzll(hit) : 0;              // the earliest expert among equals (strict > in the serial scan)
+        const unsigned long long avail = __ballot(valid && !taken);
+        // the earliest expert among equals (strict > in the serial scan); NaN probabilities compare false everywhere: the serial scan then
+        // keeps the first expert not taken yet, and so does this
+        const int best = hit ? __builtin_ctzll(hit) : avail ? __builtin_ctzll(avail) : 0;
         ksum += __shfl(pr, best, 64);
         if (lane == best) taken = true;
     }

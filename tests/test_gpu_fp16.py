@@ -66,6 +66,35 @@ def test_fp16_engine_logits_match_fp16_oracle_prefill_and_tree(P):
     assert err < 1e-2
 
 
+@pytest.mark.parametrize('over', [dict(hidden=256, n_heads=4, n_kv_heads=4), dict(hidden=384, n_heads=4, n_kv_heads=2), dict(hidden=256, n_heads=8, n_kv_heads=8)],
+                         ids=['hd64', 'hd96-gqa', 'hd32'])
+def test_fp16_narrow_heads_in_padded_lanes_vs_fp16_oracle(over):
+    """head_dim < 128 in the float16 build: the softmax scale is a runtime DIVISOR there (fp16(x / sqrt(hd)); the multiply is inexact at
+    hd = 32 and 128, tests/test_oracle_llama.py) — prefill rows and a tree step against the fp16 oracle, where fp16 resolves a wrong
+    scale or a misplaced lane at once (error well inside 1e-2)."""
+    shape = tiny_shape(**over)
+    assert shape.head_dim < 128
+    sd = _f16_sd(7, cfg=over)
+    eng = LlamaVerifyEngine(shape, sd, max_length=512)
+    assert eng.dtype == F16
+    oracle = lo.OracleLlama(shape, sd)
+    rs = np.random.RandomState(shape.head_dim)
+    P, T = 90, 64
+    prompt = rs.randint(3, shape.vocab, size=P).tolist()
+    tok = eng.prefill(prompt)
+    logits_o, past = oracle.forward(torch.tensor(prompt), torch.tril(torch.ones((P, P), dtype=torch.long)), None)
+    _check_rows(eng.logits()[:P - 64], logits_o[64:], range(P - 64), 'fp16 narrow prefill')
+    _, rows = random_tree(rs, T)
+    ids = np.concatenate([[tok], rs.randint(3, shape.vocab, size=T - 1)]).astype(np.int32)
+    eng.step(ids, rows, mode=0)
+    full = torch.cat([torch.ones((T, P), dtype=torch.long), torch.from_numpy(_mask_from_rows(rows, T))], 1)
+    lg, _ = oracle.forward(torch.tensor(ids.tolist()), full, past)
+    _check_rows(eng.logits(), lg, range(T), 'fp16 narrow tree')
+    err = float(((eng.logits()[:T].float().cpu() - lg.float()).abs().amax(-1) / lg.float().abs().amax(-1)).max())
+    print(f'[fp16 narrow heads {over}] max rel err vs the fp16 oracle {err:.4f}')
+    assert err < 1e-2
+
+
 def test_fp16_llama7b_shape_two_layers_vs_oracle():
     """Real GEMM shapes (K = 4096 / 11008, N = 12288 / 4096 / 22016 / 32000) on a 2-layer model, everything in float16."""
     torch.set_num_threads(min(16, os.cpu_count() or 8))
