@@ -55,7 +55,10 @@ extern "C" {
  * key 25: merged-expert launches of the gathered MoE step as TWO workgroups per CU (4 instead of 8 weight tiles in flight per wave,
  *         <= 128 VGPRs): bit 0 = gate/up (default on), bit 1 = down_proj; round 5: TWO adjacent weight regions per workgroup (half the x
  *         traffic and LDS reads per weight byte; another fp32 summation order), bit 2 = gate/up (planned images), bit 3 = down_proj — both on
- *         by default (key 25 = 13), they take precedence over bits 0 / 1. */
+ *         by default (key 25 = 13), they take precedence over bits 0 / 1.
+ * key 35: the paired gate/up launch of the multi-block step at 5-8 blocks, 1 = weights streamed straight into MFMA operand registers
+ *         (k_gemm_fatd: four waves = four {gate, up} row-block pairs x all token tiles, only x through LDS; default), 0 = k_gemm_fat
+ *         (weights and x through the LDS ring); bit-identical. */
 int          la_lab_set(int key, int value);
 int          la_lab_get(int key);          /* current value of a knob (the library default unless la_lab_set changed it) */
 /* key 0: device buffer int64[workgroups][waves][8] the GEMM kernels stamp with wall_clock64() at entry / end of the

@@ -35,7 +35,8 @@
     X(g_la_attn_ride_kib,    0,    31, 0, 128)     /* KiB per o_proj workgroup pulled into L2 by rider workgroups of the attention launch */ \
     X(g_la_attn_ride_delay,  0,    32, 0, 16)      /* their start delay */ \
     X(g_la_attn_merge_ns,    0,    33, 0, 4)       /* 2 | 4 = key-split attention merged on load by o_proj (k_oproj_merge); 1, 3 refused */ \
-    X(g_la_oproj_probe,      0,    34, 0, 63)      /* TIMING PROBE of a full-K o_proj with the norm folded away (results are garbage) */
+    X(g_la_oproj_probe,      0,    34, 0, 63)      /* TIMING PROBE of a full-K o_proj with the norm folded away (results are garbage) */ \
+    X(g_la_fatd,             1,    35, 0, 1)       /* paired gate/up launch at 5-8 blocks with the weights streamed into MFMA operand registers (k_gemm_fatd; 0 = k_gemm_fat) */
 
 #if LA_LAB
 #define LA_KNOB_DECL(name, dflt, key, lo, hi) extern int name;

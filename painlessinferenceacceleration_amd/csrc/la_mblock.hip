@@ -1285,6 +1285,185 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_gemm_fatd (round 6, late; default, lab knob 35 = 0 turns it off): the paired gate/up launch at 5-8 blocks with the WEIGHTS streamed straight
+// into MFMA operand registers instead of through LDS.
+//   Geometry per workgroup as k_gemm_fat<8, TW, MB_SWIGLU>: two adjacent planned regions {G0,G1,U0,U1} x 2 (row-blocks 0..7) x 2 TW token
+//   tiles (TW = 4: 4 blocks = 256 rows, TW = 3: 192; grid.z = the two token halves).  The four waves split the ROW-BLOCKS, not the tokens: wave (rg, q) owns the
+//   SwiGLU pair {G_q, U_q} of region rg = row-blocks {4 rg + q, 4 rg + q + 2} over ALL 8 token tiles: 2 x 8 accumulator tiles (256
+//   registers, as before).  No other wave needs its weight fragments, so they never visit LDS: per k-tile a wave issues 2 buffer loads
+//   (1 KiB each, MFMA A-operand order as packed) into a 4-stage register ring and 8 ds_reads of the x fragments all four waves share —
+//   8 reads per 16 MFMAs as before (4 + 4), but HALF the LDS-DMA pieces (x only: 4 per wave and stage instead of 8) and half the LDS
+//   write traffic.  What this targets: an LDS-DMA piece blocks its wave's issue for 60-185 cycles and with one wave per SIMD nothing else
+//   issues meanwhile (k_gemm_fat header); a plain buffer load issues in a few cycles.
+//   Same MFMA chain per output element (k-tiles ascending into one accumulator): bit-identical to k_gemm_fat / k_gemm_wide.
+//   Needs an even number of 4-stage groups per workgroup: K16 % 8 == 0 (launcher).
+// ---------------------------------------------------------------------------------------------------------------
+template <int TW, int WPOL>
+__global__ __launch_bounds__(256) void k_gemm_fatd(MbArgs a) {
+    constexpr int KS = 2, NW = 4, NTB = 2 * TW, B_STAGE = KS * NTB, NR = 4, NPB = B_STAGE / NW, DA = 4;
+    constexpr int HB = (NPB + 1) / 2;                    // x pieces issued in the first half of a stage (the rest in the second)
+    static_assert(B_STAGE % NW == 0 && NPB >= 2 && NTB + 2 + HB <= 2 * NTB, "x pieces per wave; issue slots of a half stage");
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rg = wave >> 1, q = wave & 1;
+    const int bx = blockIdx.x, bz = blockIdx.z;
+    const int t1 = a.K16;
+    const int nst = t1 / KS;
+    const int zb0 = bz * (NTB / 2);
+    const bf16x8* wg_w = (const bf16x8*)a.wp + (size_t)bx * (unsigned)a.wg_chunks;
+    const __amdgpu_buffer_rsrc_t rs_w = dma_rsrc(wg_w), rs_x = dma_rsrc(a.xp);
+    // weights: row-block 4 rg + q + 2 j (j = 0 gate, 1 up) of the planned pair
+    unsigned a_gstr[2], a_voff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rb = 4 * rg + q + 2 * j;
+        const int nvb = a.nvl[rb];
+        const int rr = (lane & 31) < nvb ? (lane & 31) : nvb - 1;
+        a_gstr[j] = (unsigned)__builtin_amdgcn_readfirstlane(32 * nvb);
+        a_voff[j] = ((unsigned)a.boff[rb] + (unsigned)((lane >> 5) * nvb + rr)) * 16u;
+    }
+    auto loadA = [&](int sidx, int kk, int j) -> u32x4_t {
+        int kt = sidx * KS + kk;
+        kt = kt < t1 ? kt : t1 - 1;
+        return __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)a_voff[j], (int)((unsigned)kt * a_gstr[j]), WPOL);
+    };
+    // x pieces of this wave: p = wave + NW i -> (k-tile p / NTB of the stage, token tile p % NTB)
+    unsigned b_voff[NPB];
+    int b_kk[NPB], b_dst[NPB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int p = wave + NW * i, kk = p / NTB, tb = p % NTB;
+        int xb = zb0 + (tb >> 1);
+        xb = xb < a.nblk ? xb : a.nblk - 1;
+        b_voff[i] = ((unsigned)(((xb * a.K16) * 2 + (tb & 1)) * 64) + (unsigned)lane) * 16u;
+        b_kk[i] = __builtin_amdgcn_readfirstlane(kk);
+        b_dst[i] = __builtin_amdgcn_readfirstlane((kk * NTB + tb) * 1024);
+    }
+    auto issueB = [&](int sidx, int i) {
+        int kt = sidx * KS + b_kk[i];
+        kt = kt < t1 ? kt : t1 - 1;
+        dma_piece<0>(rs_x, lds_raw + (sidx % NR) * (B_STAGE * 1024) + b_dst[i], b_voff[i], (unsigned)kt * 2048u);
+    };
+    f32x16 acc[2][NTB];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int t = 0; t < NTB; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][t][i] = 0.f;
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds_raw + (unsigned)lane * 16u;
+    auto readB = [&](int sidx, int kk, int j, bf16x8 (&fb)[NTB]) {
+        const unsigned B = lds0 + (unsigned)((sidx % NR) * (B_STAGE * 1024) + kk * NTB * 1024);
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[j]) : "v"(B), "n"(j * 1024) : "memory");
+    };
+    u32x4_t ra[DA][KS][2];
+    bf16x8 fb0[NTB], fb1[NTB];
+    // prologue: the weights of stages 0 .. 2 and k-tile 0 of stage 3 FIRST, then x of stages 0 .. NR - 2 — every load pinned in this order.
+    // hipcc merges the vmcnt bookkeeping of the loop's two entries: a stage-0 weight load followed by fewer VMEM operations here than on
+    // the back edge (26) would make the loop head drain the queue on every pass (first build: vmcnt(3) at the head of every fourth stage)
+#pragma unroll
+    for (int sidx = 0; sidx < DA; ++sidx)
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            if (sidx == DA - 1 && kk == 1) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { ra[sidx][kk][j] = loadA(sidx, kk, j); __builtin_amdgcn_sched_barrier(0); }
+        }
+#pragma unroll
+    for (int sidx = 0; sidx < NR - 1; ++sidx)
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) { issueB(sidx, i); __builtin_amdgcn_sched_barrier(0); }
+    // own x pieces of stages 0 AND 1 landed (and every weight load of the prologue with them): the mid-stage wait of the loop counts 12 younger
+    // operations behind the pieces of stage s + 1, and at s = 0 only 8 exist (x of stage 2 + the first half's four)
+    vm_wait<(NR - 3) * NPB>();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < NTB; ++j) readB(0, 0, j, fb0);
+    // one stage; U = s % DA is a compile-time constant through the 4-fold unroll, so every register-ring index is static
+    auto stage = [&](int s, auto uc) {
+        constexpr int U = decltype(uc)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // fb0 (read during the previous half) is complete
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 2 * NTB; ++m) {
+            const int r = m & 1, t = m >> 1;
+            acc[r][t] = LA_MFMA(__builtin_bit_cast(bf16x8, ra[U][0][r]), fb0[t], acc[r][t], 0, 0, 0);
+            if (m < NTB) readB(s, 1, m, fb1);
+            if (m == NTB || m == NTB + 1) ra[(U + 3) % DA][1][m - NTB] = loadA(s + 3, 1, m - NTB);        // freed by the second half of stage s - 1
+            if (m >= NTB + 2 && m < NTB + 2 + HB) issueB(s + NR - 1, m - NTB - 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // own x pieces of stage s + 1: issued in stage s - 2, the last of them as the last VMEM operation of that stage; younger: the 4 + NPB of
+        // stage s - 1 and the 2 + HB of this half
+        vm_wait<4 + NPB + 2 + HB>();
+        __builtin_amdgcn_s_barrier();                                   // stage s + 1 complete for everyone; the slot of stage s - 1 is free
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 2 * NTB; ++m) {
+            const int r = m & 1, t = m >> 1;
+            acc[r][t] = LA_MFMA(__builtin_bit_cast(bf16x8, ra[U][1][r]), fb1[t], acc[r][t], 0, 0, 0);
+            if (m < NTB) readB(s + 1, 0, m, fb0);
+            if (m == NTB || m == NTB + 1) ra[U][0][m - NTB] = loadA(s + DA, 0, m - NTB);                   // freed by the first half of this stage
+            if (m >= NTB + 2 && m < NTB + 2 + NPB - HB) issueB(s + NR - 1, HB + m - NTB - 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int s = 0; s < nst; s += 4) {
+        stage(s, std::integral_constant<int, 0>{});
+        stage(s + 1, std::integral_constant<int, 1>{});
+        stage(s + 2, std::integral_constant<int, 2>{});
+        stage(s + 3, std::integral_constant<int, 3>{});
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    vm_wait<0>();
+
+    // ---- SwiGLU epilogue (as k_gemm_fat<8, TW, MB_SWIGLU>): act = bf16(silu(bf16(g)) * bf16(u)) parked as tile[token][sh + feature - lo]
+    const int tl = lane & 31, hh = lane >> 5;
+    const int sw_lo = a.R * 2 * bx, sw_r = 2 * a.R, sw_sh = sw_lo & 7;
+    const int sw_nch = (sw_sh + sw_r + 7) >> 3;
+    const int sw_stride = (sw_nch * 8) % 64 == 0 ? sw_nch * 8 + 8 : sw_nch * 8;
+    __syncthreads();
+    bf16_t* tile = (bf16_t*)lds_raw;
+    const int nvg = a.nv[4 * rg + q];
+    const int c0 = sw_sh + rg * a.R + 32 * q;
+#pragma unroll
+    for (int t = 0; t < NTB; ++t) {
+        const int blk = zb0 + (t >> 1), tok = (t & 1) * 32 + tl;
+        if (blk >= a.nblk) continue;
+        const int trow = (t >> 1) * 64 + tok;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (8 * (i >> 2) >= nvg) break;
+            const int f = 8 * (i >> 2) + 4 * hh + (i & 3);
+            const float gv = bfr_hw(acc[0][t][i]), uv = bfr_hw(acc[1][t][i]);
+            const float sv = bfr_hw(gv * __builtin_amdgcn_rcpf(1.0f + __expf(-gv)));
+            const bf16_t o = f2bf_hw(sv * uv);
+            if (f < nvg) tile[trow * sw_stride + c0 + f] = o;
+        }
+    }
+    __syncthreads();
+    const int ntok = (NTB / 2) * 64;
+    for (int it = threadIdx.x; it < ntok * sw_nch; it += NW * 64) {
+        const int trow = it % ntok, c = it / ntok, blk = zb0 + (trow >> 6);
+        if (blk >= a.nblk) continue;
+        const int fa_ = (sw_lo & ~7) + 8 * c;
+        bf16_t* dst = a.act_xp + (size_t)blk * 64 * a.N + xp_offset(trow & 63, fa_);
+        const bf16_t* srcp = tile + trow * sw_stride + 8 * c;
+        if (fa_ >= sw_lo && fa_ + 8 <= sw_lo + sw_r) {
+            *(bf16x8*)dst = *(const bf16x8*)srcp;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (fa_ + e >= sw_lo && fa_ + e < sw_lo + sw_r) dst[e] = srcp[e];
+        }
+    }
+}
+#define LA_FATD_LDS (96 * 1024)
+
+// ---------------------------------------------------------------------------------------------------------------
 // Row kernels over M rows: embedding gather + RMSNorm / residual + split-K slab sum + RMSNorm (same arithmetic and rounding
 // points as k_row_norm in la_kernels.hip; LlamaRMSNorm :76-90, LlamaDecoderLayer residual adds :352-363).
 // ---------------------------------------------------------------------------------------------------------------
@@ -2371,6 +2550,8 @@ int lk_mb_init() {
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 2, MB_SWIGLU>, FatGeom<8, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 3, MB_SWIGLU>, FatGeom<8, 3>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 4, MB_SWIGLU>, FatGeom<8, 4>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fatd<4, 0>, LA_FATD_LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fatd<3, 0>, LA_FATD_LDS);
 #if LA_LAB
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 2, MB_SWIGLU, 4, 0, 4, 1>, FatGeom<8, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 3, MB_SWIGLU, 4, 0, 4, 1>, FatGeom<8, 3>::LDS);
@@ -2697,6 +2878,15 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                         LAUNCH_CHECK(); return 0;
                     }
 #endif
+                    // lab knob 35 (round 6, late): weights straight into MFMA operand registers (k_gemm_fatd), 7-8 blocks, K16 % 8 == 0
+                    // round 6 (late; knob 35, default on): weights straight into MFMA operand registers (k_gemm_fatd) at 5-8 blocks; whole groups of
+                    // four stages: K16 % 8 == 0.  Measured (profiles/r06_gateup_direct_weights.txt): 512 rows 115.4 -> 109.1 us per launch at the Mistral
+                    // shape, Mistral bs=8 9.55 -> 9.36 ms per step, Llama-2-7B bs=8 9.94 -> 9.76; bit-identical.
+                    if (g_la_fatd && (nblk + 1) / 2 >= 3 && (a.K16 & 7) == 0 && a.R <= 64) {
+                        if ((nblk + 1) / 2 == 4) k_gemm_fatd<4, 0><<<g2, 256, LA_FATD_LDS, st>>>(p);
+                        else k_gemm_fatd<3, 0><<<g2, 256, LA_FATD_LDS, st>>>(p);
+                        LAUNCH_CHECK(); return 0;
+                    }
                     switch ((nblk + 1) / 2) {
                         case 2: k_gemm_fat<8, 2, MB_SWIGLU><<<g2, 256, FatGeom<8, 2>::LDS, st>>>(p); break;
                         case 3: k_gemm_fat<8, 3, MB_SWIGLU><<<g2, 256, FatGeom<8, 3>::LDS, st>>>(p); break;

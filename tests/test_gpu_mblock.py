@@ -395,6 +395,34 @@ def test_mb_paired_wide_form_is_bitwise_the_unpaired_one(nblk):
 
 
 @pytest.mark.usefixtures('lab_build')
+@pytest.mark.parametrize('nblk', [5, 6, 7, 8])
+def test_mb_direct_weight_gateup_is_bitwise_the_fat_launch(nblk):
+    """la_lab_set key 35 (k_gemm_fatd, the default at 5-8 blocks): the paired gate/up launch with the weight fragments streamed straight
+    into MFMA operand registers (four waves = four {gate, up} row-block pairs x all 6 / 8 token tiles; only x goes through LDS).  Same MFMA
+    chain per output element as k_gemm_fat (knob 35 = 0): the activation image must be equal bit for bit — three model shapes, short and
+    long reductions."""
+    assert lib.la_lab_get(35) == 1
+    try:
+        for F, K in ((11008, 512), (13824, 1024), (14336, 256), (14336, 4096), (11008, 128)):
+            g = torch.Generator(device=DEV).manual_seed(F + K + nblk)
+            x = bf(torch.randn(nblk * 64, K, generator=g, device=DEV))
+            wg_ = bf(torch.randn(F, K, generator=g, device=DEV) * 0.05)
+            wu_ = bf(torch.randn(F, K, generator=g, device=DEV) * 0.05)
+            wp = gu.pack_planned(1, [wg_, wu_], 256)
+            outs = []
+            for knob in (0, 1):
+                check(lib.la_lab_set(35, knob), 'lab_set')
+                act = torch.full((8 * 64 * F,), -1.0, dtype=torch.bfloat16, device=DEV)
+                _mb(1, wp, _pack_blocks(x), F, K, nblk, n_wg=256, act=act)
+                torch.cuda.synchronize()
+                outs.append(act)
+            assert torch.equal(outs[0], outs[1]), (F, K)
+            assert float(outs[0][:nblk * 64 * F].float().abs().sum()) > 0
+    finally:
+        lib.la_lab_set(35, 1)
+
+
+@pytest.mark.usefixtures('lab_build')
 @pytest.mark.parametrize('nblk', [3, 4, 6, 8])
 def test_mb_wide_schedules_are_bitwise_identical(nblk):
     """la_lab_set key 24: the round-4 schedule of k_gemm_wide (buffer-addressed LDS-DMA pieces; one fragment read after every MFMA at
