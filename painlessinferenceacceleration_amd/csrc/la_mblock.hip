@@ -1296,7 +1296,9 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
 //   write traffic.  What this targets: an LDS-DMA piece blocks its wave's issue for 60-185 cycles and with one wave per SIMD nothing else
 //   issues meanwhile (k_gemm_fat header); a plain buffer load issues in a few cycles.
 //   Same MFMA chain per output element (k-tiles ascending into one accumulator): bit-identical to k_gemm_fat / k_gemm_wide.
-//   Needs an even number of 4-stage groups per workgroup: K16 % 8 == 0 (launcher).
+//   Any even number of k-tiles: whole groups of four stages, then 1-3 single stages.
+//   The same split for the slab launches (8 row-blocks x 4 token tiles per workgroup, wave = 2 row-blocks x 4 tiles) was built and measured:
+//   43.8 -> 42.6 us per launch, -0.6 % per Mistral bs=8 step — not kept (profiles/r06_gateup_direct_weights.txt).
 // ---------------------------------------------------------------------------------------------------------------
 template <int TW, int WPOL>
 __global__ __launch_bounds__(256) void k_gemm_fatd(MbArgs a) {
@@ -1411,12 +1413,16 @@ __global__ __launch_bounds__(256) void k_gemm_fatd(MbArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    for (int s = 0; s < nst; s += 4) {
+    int s = 0;
+    for (; s + 4 <= nst; s += 4) {
         stage(s, std::integral_constant<int, 0>{});
         stage(s + 1, std::integral_constant<int, 1>{});
         stage(s + 2, std::integral_constant<int, 2>{});
         stage(s + 3, std::integral_constant<int, 3>{});
     }
+    if (s < nst) stage(s, std::integral_constant<int, 0>{});                // 1-3 stages left (s is a multiple of 4: ring positions 0, 1, 2)
+    if (s + 1 < nst) stage(s + 1, std::integral_constant<int, 1>{});
+    if (s + 2 < nst) stage(s + 2, std::integral_constant<int, 2>{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     vm_wait<0>();
 
@@ -2879,10 +2885,10 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                     }
 #endif
                     // lab knob 35 (round 6, late): weights straight into MFMA operand registers (k_gemm_fatd), 7-8 blocks, K16 % 8 == 0
-                    // round 6 (late; knob 35, default on): weights straight into MFMA operand registers (k_gemm_fatd) at 5-8 blocks; whole groups of
-                    // four stages: K16 % 8 == 0.  Measured (profiles/r06_gateup_direct_weights.txt): 512 rows 115.4 -> 109.1 us per launch at the Mistral
+                    // round 6 (late; knob 35, default on): weights straight into MFMA operand registers (k_gemm_fatd) at 5-8 blocks (an even number of
+                    // k-tiles).  Measured (profiles/r06_gateup_direct_weights.txt): 512 rows 115.4 -> 109.1 us per launch at the Mistral
                     // shape, Mistral bs=8 9.55 -> 9.36 ms per step, Llama-2-7B bs=8 9.94 -> 9.76; bit-identical.
-                    if (g_la_fatd && (nblk + 1) / 2 >= 3 && (a.K16 & 7) == 0 && a.R <= 64) {
+                    if (g_la_fatd && (nblk + 1) / 2 >= 3 && (a.K16 & 1) == 0 && a.R <= 64) {
                         if ((nblk + 1) / 2 == 4) k_gemm_fatd<4, 0><<<g2, 256, LA_FATD_LDS, st>>>(p);
                         else k_gemm_fatd<3, 0><<<g2, 256, LA_FATD_LDS, st>>>(p);
                         LAUNCH_CHECK(); return 0;
