@@ -1298,7 +1298,9 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
 //   Same MFMA chain per output element (k-tiles ascending into one accumulator): bit-identical to k_gemm_fat / k_gemm_wide.
 //   Any even number of k-tiles: whole groups of four stages, then 1-3 single stages.
 //   The same split for the slab launches (8 row-blocks x 4 token tiles per workgroup, wave = 2 row-blocks x 4 tiles) was built and measured:
-//   43.8 -> 42.6 us per launch, -0.6 % per Mistral bs=8 step — not kept (profiles/r06_gateup_direct_weights.txt).
+//   43.8 -> 42.6 us per launch, -0.6 % per Mistral bs=8 step — not kept; neither were the QKV form of it (four regions x 2 / 4 token tiles: +10 % per
+//   launch on GQA / 13B images, where the launch is bound by the weight bytes a CU pulls) and a partner prefetch of the weight stream (each of the two
+//   workgroups of a column touching every other k-tile seven stages ahead: +3.5 % per launch) — profiles/r06_gateup_direct_weights.txt.
 // ---------------------------------------------------------------------------------------------------------------
 template <int TW, int WPOL>
 __global__ __launch_bounds__(256) void k_gemm_fatd(MbArgs a) {
@@ -1384,8 +1386,12 @@ __global__ __launch_bounds__(256) void k_gemm_fatd(MbArgs a) {
 #pragma unroll
     for (int j = 0; j < NTB; ++j) readB(0, 0, j, fb0);
     // one stage; U = s % DA is a compile-time constant through the 4-fold unroll, so every register-ring index is static
-    auto stage = [&](int s, auto uc) {
+    // TAIL: one of the 1-3 single stages behind the four-stage groups.  The compiler drops the weight loads such a stage would issue for stages
+    // that do not exist there (dead), so the hand-counted vmcnt of the mid-stage wait does not hold in those copies of the body: they drain the
+    // queue instead (first build of the remainder path: wrong sums on every reduction with a remainder in the sibling kernels)
+    auto stage = [&](int s, auto uc, auto tailc) {
         constexpr int U = decltype(uc)::value;
+        constexpr bool TAIL = decltype(tailc)::value;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // fb0 (read during the previous half) is complete
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1400,7 +1406,7 @@ __global__ __launch_bounds__(256) void k_gemm_fatd(MbArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // own x pieces of stage s + 1: issued in stage s - 2, the last of them as the last VMEM operation of that stage; younger: the 4 + NPB of
         // stage s - 1 and the 2 + HB of this half
-        vm_wait<4 + NPB + 2 + HB>();
+        if constexpr (TAIL) vm_wait<0>(); else vm_wait<4 + NPB + 2 + HB>();
         __builtin_amdgcn_s_barrier();                                   // stage s + 1 complete for everyone; the slot of stage s - 1 is free
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1412,17 +1418,21 @@ __global__ __launch_bounds__(256) void k_gemm_fatd(MbArgs a) {
             if (m >= NTB + 2 && m < NTB + 2 + NPB - HB) issueB(s + NR - 1, HB + m - NTB - 2);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // the fragment reads of this half are inline asm: the compiler does not know their results are still in flight.  Inside the loop nothing
+        // touches them before the next stage's wait, but at the loop's exit into the 1-3 single stages it may copy registers (phi moves) — of values
+        // that have not landed (seen: bitwise failures of a sibling kernel on reductions with a remainder).  So a stage ends with its reads complete.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     int s = 0;
     for (; s + 4 <= nst; s += 4) {
-        stage(s, std::integral_constant<int, 0>{});
-        stage(s + 1, std::integral_constant<int, 1>{});
-        stage(s + 2, std::integral_constant<int, 2>{});
-        stage(s + 3, std::integral_constant<int, 3>{});
+        stage(s, std::integral_constant<int, 0>{}, std::false_type{});
+        stage(s + 1, std::integral_constant<int, 1>{}, std::false_type{});
+        stage(s + 2, std::integral_constant<int, 2>{}, std::false_type{});
+        stage(s + 3, std::integral_constant<int, 3>{}, std::false_type{});
     }
-    if (s < nst) stage(s, std::integral_constant<int, 0>{});                // 1-3 stages left (s is a multiple of 4: ring positions 0, 1, 2)
-    if (s + 1 < nst) stage(s + 1, std::integral_constant<int, 1>{});
-    if (s + 2 < nst) stage(s + 2, std::integral_constant<int, 2>{});
+    if (s < nst) stage(s, std::integral_constant<int, 0>{}, std::true_type{});                // 1-3 stages left (s is a multiple of 4: ring positions 0, 1, 2)
+    if (s + 1 < nst) stage(s + 1, std::integral_constant<int, 1>{}, std::true_type{});
+    if (s + 2 < nst) stage(s + 2, std::integral_constant<int, 2>{}, std::true_type{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     vm_wait<0>();
 

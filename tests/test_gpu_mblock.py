@@ -403,7 +403,7 @@ def test_mb_direct_weight_gateup_is_bitwise_the_fat_launch(nblk):
     long reductions."""
     assert lib.la_lab_get(35) == 1
     try:
-        for F, K in ((11008, 512), (13824, 1024), (14336, 256), (14336, 4096), (11008, 128), (11008, 5120 + 96), (13824, 32)):
+        for F, K in ((11008, 512), (13824, 1024), (14336, 256), (14336, 4096), (11008, 128), (11008, 5120 + 96), (13824, 32), (14336, 1120), (11008, 2048 + 64), (13824, 96)):
             g = torch.Generator(device=DEV).manual_seed(F + K + nblk)
             x = bf(torch.randn(nblk * 64, K, generator=g, device=DEV))
             wg_ = bf(torch.randn(F, K, generator=g, device=DEV) * 0.05)
