@@ -314,7 +314,10 @@ class LlamaVerifyEngine(object):
         self.qkv_mb_wg = 0
         pairs = (shape.n_heads + 2 * shape.n_kv_heads) * hd // 2
         if max_blocks > 1 and self.balanced_wg[0] and hd == 128:
-            want = pairs // 32 if (pairs % 32 == 0 and (pairs // self.balanced_wg[0]) / 32.0 < 0.6) else 0
+            per_wg = pairs // self.balanced_wg[0]
+            # ... or leaves a pair count per workgroup that is not a multiple of 4 (Llama-2-13B: 30): the RoPE epilogue then stores 4-byte pieces and
+            # 1/16 of the MFMA rows are padding; 240 full workgroups instead: 13B bs=4 10.57 -> 10.45 ms, bs=8 16.00 -> 15.60 (round 6, GPU call 16)
+            want = pairs // 32 if (pairs % 32 == 0 and (per_wg / 32.0 < 0.6 or (per_wg % 4 != 0 and pairs // 32 >= 0.9 * self.balanced_wg[0]))) else 0
             if os.environ.get('LA_QKV_MB_WG') is not None:
                 want = int(os.environ['LA_QKV_MB_WG'])
             if want > 0 and want % 16 == 0 and want < self.balanced_wg[0] and pairs % want == 0 and pairs // want <= 32:
