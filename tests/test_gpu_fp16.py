@@ -117,6 +117,31 @@ def test_fp16_llama7b_shape_two_layers_vs_oracle():
     _check_rows(eng.logits(), lg, range(T), 'fp16 7b-shape tree')
 
 
+def test_fp16_multi_block_prefill_at_the_7b_shape_vs_oracle():
+    """The 5-8 block launches in float16 at real GEMM shapes — among them k_gemm_fatd, the paired gate/up launch with the weights streamed into
+    MFMA operand registers, which only planned (balanced) images reach: a 2-layer Llama-2-7B shape, a 420-token prompt as ONE pass of 7 chained
+    blocks, the rows of its last block against the fp16 oracle, then a 6-block pass (TW = 3) continuing the same sequence."""
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    shape = LlamaShape(2, 4096, 32, 32, 11008, 32000, 1e-5)
+    sd = random_weights(shape, seed=3, std=0.02, device='cpu', dtype=F16)
+    eng = LlamaVerifyEngine(shape, dict(sd), max_length=1024, n_slots=1, max_blocks=8)
+    assert eng.dtype == F16
+    oracle = lo.OracleLlama(shape, sd)
+    rs = np.random.RandomState(5)
+    P = 420
+    prompt = rs.randint(3, 32000, size=P).tolist()
+    eng.mprefill(0, prompt)
+    lg, past = oracle.forward(torch.tensor(prompt), torch.tril(torch.ones((P, P), dtype=torch.long)), None)
+    _check_rows(eng.mlogits()[384:P], lg[384:], range(P - 384), 'fp16 7-block prefill, last block')
+    more = rs.randint(3, 32000, size=6 * 64 - 20).tolist()
+    Q = len(more)
+    eng.mprefill(0, more)
+    full = torch.cat([torch.ones((Q, P), dtype=torch.long), torch.tril(torch.ones((Q, Q), dtype=torch.long))], 1)
+    lg2, _ = oracle.forward(torch.tensor(more), full, past)
+    last = (Q - 1) // 64 * 64
+    _check_rows(eng.mlogits()[last:Q], lg2[last:], range(Q - last), 'fp16 6-block continuation, last block')
+
+
 @pytest.mark.parametrize('native', [False, True])
 def test_fp16_partial_accept_run_equals_the_reference_fp16_golden(native):
     """oracle/gen_golden_noisy.py, float16: the REFERENCE loop (pretrained_model.py:947-1268) on the decisive tiny model with a noisy
