@@ -58,7 +58,9 @@ extern "C" {
  *         by default (key 25 = 13), they take precedence over bits 0 / 1.
  * key 35: the paired gate/up launch of the multi-block step at 5-8 blocks, 1 = weights streamed straight into MFMA operand registers
  *         (k_gemm_fatd: four waves = four {gate, up} row-block pairs x all token tiles, only x through LDS; default), 0 = k_gemm_fat
- *         (weights and x through the LDS ring); bit-identical. */
+ *         (weights and x through the LDS ring); bit-identical.
+ * key 36: the slab launches (o_proj / down) of the multi-block step at 5-8 blocks, 1 = the x fragments of a wave's own token tiles streamed straight
+ *         into MFMA operand registers, only the weights through the LDS ring (k_gemm_fat, STG = 2; default), 0 = both through the ring; bit-identical. */
 int          la_lab_set(int key, int value);
 int          la_lab_get(int key);          /* current value of a knob (the library default unless la_lab_set changed it) */
 /* key 0: device buffer int64[workgroups][waves][8] the GEMM kernels stamp with wall_clock64() at entry / end of the

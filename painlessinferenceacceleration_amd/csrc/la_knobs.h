@@ -36,7 +36,8 @@
     X(g_la_attn_ride_delay,  0,    32, 0, 16)      /* their start delay */ \
     X(g_la_attn_merge_ns,    0,    33, 0, 4)       /* 2 | 4 = key-split attention merged on load by o_proj (k_oproj_merge); 1, 3 refused */ \
     X(g_la_oproj_probe,      0,    34, 0, 63)      /* TIMING PROBE of a full-K o_proj with the norm folded away (results are garbage) */ \
-    X(g_la_fatd,             1,    35, 0, 1)       /* paired gate/up launch at 5-8 blocks with the weights streamed into MFMA operand registers (k_gemm_fatd; 0 = k_gemm_fat) */
+    X(g_la_fatd,             1,    35, 0, 1)       /* paired gate/up launch at 5-8 blocks with the weights streamed into MFMA operand registers (k_gemm_fatd; 0 = k_gemm_fat) */ \
+    X(g_la_fatx,             1,    36, 0, 1)       /* slab launches at 5-8 blocks (two token tiles per wave) with the x fragments streamed into MFMA operand registers (k_gemm_fat, STG = 2) */
 
 #if LA_LAB
 #define LA_KNOB_DECL(name, dflt, key, lo, hi) extern int name;

@@ -1007,7 +1007,7 @@ template <int RBV, int TW, int EPI, int RV = 4, int WPOL = 0, int RPW_ = 4, int 
 __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
     using GEO = FatGeom<RBV, TW, RPW_>;
     constexpr int KS = GEO::KS, RPW = GEO::RPW, NW = GEO::NW, TQ = GEO::TQ, NTBP = GEO::NTBP;
-    constexpr int A_STAGE = GEO::A_STAGE, STAGE = GEO::STAGE, NR = STG ? 2 : GEO::NR, NP = GEO::NP, NPA = GEO::NPA, H = GEO::H;
+    constexpr int A_STAGE = GEO::A_STAGE, STAGE = GEO::STAGE, NR = STG == 1 ? 2 : GEO::NR, NP = GEO::NP, NPA = GEO::NPA, H = GEO::H;
     static_assert((EPI == MB_SWIGLU && (RBV == 8 || RBV == 4) && RPW_ == 4) || ((EPI == MB_SLAB || EPI == MB_QKV) && RBV == 4 && RPW_ == 4) || ((EPI == MB_QKV || EPI == MB_SLAB) && RBV == 2 && RPW_ == 2), "gate/up: one planned region {G0,G1,U0,U1} x all token blocks, or two regions x half of them; slab / QKV: two {lo, hi} regions");
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = threadIdx.x & 63;
@@ -1159,7 +1159,7 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
             }
         }
 
-    } else {
+    } else if constexpr (STG == 1) {
         // ---- register-staged pipeline (see the kernel header): sets sA / sB hold the stages of even / odd parity that are in flight
         u32x4_t sA[NP], sB[NP];
         // (the loads stay in piece order, here as in the loop: hipcc merges the vmcnt bookkeeping of the two loop entries, and a prologue it
@@ -1207,6 +1207,94 @@ __global__ __launch_bounds__(256) void k_gemm_fat(MbArgs a) {
             stage(s + 1, std::integral_constant<int, 1>{}, sA);
         }
         if (s < nst) stage(s, std::integral_constant<int, 0>{}, sB);
+    } else {
+        // ---- STG = 2 (round 6, late; lab knob 36, the default of the two-token-tile slab launch at 5-8 blocks): x DIRECT.  In every form with one row group (RG = 1: the slab, QKV and one-region gate/up launches)
+        // the four waves share the weight row-blocks and each owns ITS token tiles — the x fragments are private to a wave, and a 1 KiB piece of the x
+        // image IS the B-operand fragment.  So x goes global -> VGPR (a four-stage register ring, as the weights of k_gemm_fatd) and only the shared
+        // operand, the weights, goes through the LDS ring: A_STAGE / 4 LDS-DMA pieces per wave and stage instead of (A_STAGE + B_STAGE) / 4, RPW fragment
+        // reads per k-tile instead of RPW + TW.  Same MFMA chain per output element: bit-identical.  Measured on every form it fits (profiles/
+        // r06_gateup_direct_weights.txt): -4.4 % per launch for <4, 2, SLAB> at 512 rows, level or slower for the quarters, QKV and gate/up forms.
+        static_assert(GEO::RG == 1 && NPA >= 1, "x direct: every wave owns its token tiles");
+        constexpr int DX = 4, HA = (NPA + 1) / 2, HA2 = NPA - HA;
+        constexpr int NGX = NMMA > RPW + TW + HA ? NMMA : RPW + TW + HA;
+        unsigned xv[TW];
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+            const int tbg = tq * TW + t;
+            int xb = zb0 + (tbg >> 1);
+            xb = xb < a.nblk ? xb : a.nblk - 1;
+            xv[t] = ((unsigned)(((xb * a.K16) * 2 + (tbg & 1)) * 64) + (unsigned)lane) * 16u;
+        }
+        auto loadXf = [&](int sidx, int kk, int t) -> u32x4_t {
+            int kt = t0 + sidx * KS + kk;
+            kt = kt < t1 ? kt : t1 - 1;
+            return __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xv[t], (int)((unsigned)kt * 2048u), 0);
+        };
+        u32x4_t xr[DX][KS][TW];
+        // prologue: the x loads of stages 0 .. 2 and k-tile 0 of stage 3 first (pinned: see k_gemm_fatd), then the weight pieces of stages 0 .. NR - 2
+#pragma unroll
+        for (int sidx = 0; sidx < DX; ++sidx)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                if (sidx == DX - 1 && kk == 1) continue;
+#pragma unroll
+                for (int t = 0; t < TW; ++t) { xr[sidx][kk][t] = loadXf(sidx, kk, t); __builtin_amdgcn_sched_barrier(0); }
+            }
+#pragma unroll
+        for (int sidx = 0; sidx < NR - 1; ++sidx)
+#pragma unroll
+            for (int q = 0; q < NPA; ++q) { issue_one(sidx, q); __builtin_amdgcn_sched_barrier(0); }
+        vm_wait<0>();
+        __builtin_amdgcn_s_barrier();
+        bf16x8 fbx[TW];                      // (unused operand of read_one)
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) read_one(0, 0, j, fa0, fbx);
+        auto mmaX = [&](int m, const bf16x8 (&fa)[RPW], const u32x4_t (&xb)[TW]) {
+            const int r = m % RPW, t = m / RPW;
+            acc[r][t] = LA_MFMA(fa[r], __builtin_bit_cast(bf16x8, xb[t]), acc[r][t], 0, 0, 0);
+        };
+        auto stage = [&](int s, auto uc, auto tailc) {
+            constexpr int U = decltype(uc)::value;
+            constexpr bool TAIL = decltype(tailc)::value;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < NGX; ++m) {
+                if (m < NMMA) mmaX(m, fa0, xr[U][0]);
+                if (m < RPW) read_one(s, 1, m, fa1, fbx);
+                if (m >= RPW && m < RPW + TW) xr[(U + 3) % DX][1][m - RPW] = loadXf(s + 3, 1, m - RPW);          // freed by the second half of stage s - 1
+                if (m >= RPW + TW && m < RPW + TW + HA) issue_one(s + NR - 1, m - RPW - TW);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // own weight pieces of stage s + 1 (issued in stage s - 2, NR = 4; NR = 3: in stage s - 1).  Younger VMEM operations: what stage s - 2 issued
+            // behind its last piece (the x loads of its second half when that half issues no piece), the 2 TW + NPA of stage s - 1, the TW + HA of this half.
+            // The single stages of a remainder drain the queue (dead loads are dropped there: k_gemm_fatd).
+            if constexpr (TAIL) vm_wait<0>();
+            else if constexpr (NR == 4) vm_wait<(HA2 > 0 ? 0 : TW) + 2 * TW + NPA + TW + HA>();
+            else vm_wait<(HA2 > 0 ? 0 : TW) + TW + HA>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < NGX; ++m) {
+                if (m < NMMA) mmaX(m, fa1, xr[U][1]);
+                if (m < RPW) read_one(s + 1, 0, m, fa0, fbx);
+                if (m >= RPW && m < RPW + TW) xr[U][0][m - RPW] = loadXf(s + DX, 0, m - RPW);                    // freed by the first half of this stage
+                if (m >= RPW + TW && m < RPW + TW + HA2) issue_one(s + NR - 1, HA + m - RPW - TW);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        int s = 0;
+        for (; s + 4 <= nst; s += 4) {
+            stage(s, std::integral_constant<int, 0>{}, std::false_type{});
+            stage(s + 1, std::integral_constant<int, 1>{}, std::false_type{});
+            stage(s + 2, std::integral_constant<int, 2>{}, std::false_type{});
+            stage(s + 3, std::integral_constant<int, 3>{}, std::false_type{});
+        }
+        if (s < nst) stage(s, std::integral_constant<int, 0>{}, std::true_type{});
+        if (s + 1 < nst) stage(s + 1, std::integral_constant<int, 1>{}, std::true_type{});
+        if (s + 2 < nst) stage(s + 2, std::integral_constant<int, 2>{}, std::true_type{});
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     vm_wait<0>();
@@ -2566,6 +2654,7 @@ int lk_mb_init() {
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 2, MB_SWIGLU>, FatGeom<8, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 3, MB_SWIGLU>, FatGeom<8, 3>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fat<8, 4, MB_SWIGLU>, FatGeom<8, 4>::LDS);
+    if (e == hipSuccess) e = set_lds(k_gemm_fat<4, 2, MB_SLAB, 4, 0, 4, 2>, FatGeom<4, 2>::LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fatd<4, 0>, LA_FATD_LDS);
     if (e == hipSuccess) e = set_lds(k_gemm_fatd<3, 0>, LA_FATD_LDS);
 #if LA_LAB
@@ -2829,7 +2918,10 @@ static int launch_mb(hipStream_t st, const MbArgs& a, int n_wg, int ksplit, int 
                         //  30 % slower with the mapping, profiles/r05_fat_waves.txt call 14: measurement only)
                         const unsigned total = gs.x * gs.y * gs.z;
                         p.xcd_map = ((g_la_mb_pair & 8192) && (ksplit == 2 || ksplit == 4 || ksplit == 8) && total % 8 == 0 && (total % 256 == 0 || (g_la_mb_pair & 16384))) ? 1 : 0;
-                        if (quarters) k_gemm_fat<4, 1, EPI><<<gs, 256, FatGeom<4, 1>::LDS, st>>>(p);
+                        // round 6 (late; knob 36, default on): the two-token-tile form with x DIRECT (k_gemm_fat, STG = 2): 43.1 -> 41.2 us per launch at the
+                        // Mistral shape, 512 rows.  The other one-row-group forms (quarters, QKV, one-region gate/up) measured level or slower with it.
+                        if (g_la_fatx && !quarters) k_gemm_fat<4, 2, EPI, 4, 0, 4, 2><<<gs, 256, FatGeom<4, 2>::LDS, st>>>(p);
+                        else if (quarters) k_gemm_fat<4, 1, EPI><<<gs, 256, FatGeom<4, 1>::LDS, st>>>(p);
                         else k_gemm_fat<4, 2, EPI><<<gs, 256, FatGeom<4, 2>::LDS, st>>>(p);
                         LAUNCH_CHECK(); return 0;
                     }

@@ -423,6 +423,36 @@ def test_mb_direct_weight_gateup_is_bitwise_the_fat_launch(nblk):
 
 
 @pytest.mark.usefixtures('lab_build')
+@pytest.mark.parametrize('nblk', [5, 6, 7, 8])
+def test_mb_x_direct_slab_launch_is_bitwise_the_fat_launch(nblk):
+    """la_lab_set key 36 (k_gemm_fat, STG = 2, the default): in the slab launch at 5-8 blocks (one row group: the four waves share the weight
+    row-blocks, each owns two token tiles) the x fragments go straight into MFMA operand registers and only the weights go through the LDS ring.
+    Same MFMA chain per output element as the LDS-DMA form (knob 36 = 0): the fp32 split-K slabs must be equal bit for bit — K splits 1-4, stage
+    counts with and without a remainder, with and without the one-K-split-per-XCD mapping."""
+    assert lib.la_lab_get(36) == 1
+    form = lib.la_lab_get(6)
+    try:
+        for N, K, ks in ((4096, 4096, 4), (4096, 5504, 4), (4096, 14336, 4), (5120, 5120, 3), (512, 512, 2), (1024, 64, 2), (256, 2048 + 32, 1)):
+            g = torch.Generator(device=DEV).manual_seed(N + K + nblk)
+            x = bf(torch.randn(nblk * 64, K, generator=g, device=DEV))
+            wp = gu.pack_weight(bf(torch.randn(N, K, generator=g, device=DEV) * 0.05))
+            rows = (nblk + 3) // 4 * 4 * 64
+            outs = []
+            for knob, pair in ((0, form), (1, form), (1, form & ~8192), (1, form | 16384)):
+                check(lib.la_lab_set(36, knob), 'lab_set')
+                check(lib.la_lab_set(6, pair), 'lab_set')
+                slabs = torch.full((ks, rows, N), float('nan'), dtype=torch.float32, device=DEV)
+                _mb(0, wp, _pack_blocks(x), N, K, nblk, ksplit=ks, slabs=slabs, slab_rows=rows)
+                torch.cuda.synchronize()
+                outs.append(slabs[:, :nblk * 64].clone())
+            assert not torch.isnan(outs[0]).any()
+            assert all(torch.equal(outs[0], o) for o in outs[1:]), (N, K, ks)
+    finally:
+        lib.la_lab_set(36, 1)
+        lib.la_lab_set(6, form)
+
+
+@pytest.mark.usefixtures('lab_build')
 @pytest.mark.parametrize('nblk', [3, 4, 6, 8])
 def test_mb_wide_schedules_are_bitwise_identical(nblk):
     """la_lab_set key 24: the round-4 schedule of k_gemm_wide (buffer-addressed LDS-DMA pieces; one fragment read after every MFMA at
