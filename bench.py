@@ -484,7 +484,7 @@ def main():
         shape.n_layers = args.layers
     K, W, P, B = args.steps, args.warmup, args.prompt_len, args.batch
     assert 1 <= B <= 16, 'sequences per GPU: <= 16 KV slots; more than 8 run as two passes of <= 8 blocks per step'
-    assert B <= 8 or (not args.device_trie and args.decoding_length <= 64), '--batch above 8: host trie, 64-token trees'
+    assert B <= 8 or args.decoding_length <= 64, '--batch above 8: 64-token trees (two passes of <= 8 blocks per step; with --device-trie as the product loop runs them)'
     BL, DL = args.branch_length, args.decoding_length
     if not args.device_trie and not args.host_trie and B == 8 and world == 1 and DL <= 64 and not args.deferred_trie_update:
         args.device_trie = True          # round 6: the workgroup-per-query device trie wins from 8 sequences per GPU on (the product loop's AUTO rule)
@@ -606,20 +606,31 @@ def main():
         if gather is not None:
             gather.overlap(cache, BL)
         ubl = [min(BL, max_length - len(seqs[i]) - 1) for i in range(B)]
+        n_pass = (B + 7) // 8
+        if n_pass > 1 and replay_q[0] is not None:
+            # more than 8 sequences: two engine passes per step, as pretrained_model_batch.py runs them — the host replays the previous step's
+            # update FIRST (one replay covers the stream_put_dev calls of both passes), then ONE synced query launch serves all B sequences
+            if not dev_trie.replay(replay_q[0], BL + 1, calls=n_pass):
+                replay_q[1] = True
+            replay_q[0] = None
         with torch.cuda.stream(eng.stream):
             # round 4: with device-side updates the device image already holds step N's inserts when step N + 1 is queued, so the
             # host's REPLAY of step N (25-50 us per sequence) moves behind the launches and runs while the GPU verifies
             dev_trie.hier_get_dev([seqs[i][-2:] for i in range(B)], idxs=gidx, branch_lengths=ubl, decoding_length=DL, branch_length=BL,
                                   min_input_size=0, min_output_size=DL // 2, mode='mix', sync=replay_q[0] is None)
             qts.append(time.time() - tq)
-            eng.mstep_trie_async(dev_trie, 0, list(range(B)), [16] * B, [seqs[i][-1] for i in range(B)],
-                                 put_idxs=gidx if dev_trie.put_vocab else None, put_branch_length=BL + 1)
-        if replay_q[0] is not None:
-            ok = dev_trie.replay(replay_q[0], BL + 1)
-            replay_q[0] = None
-            if not ok:
-                replay_q[1] = True                   # the host image outgrew the device's: finish this step, then a full image
-        toks_all, Ts = eng.mstep_trie_finish()
+            toks_all, Ts = [], []
+            for g0 in range(0, B, 8):
+                grp = list(range(g0, min(B, g0 + 8)))
+                eng.mstep_trie_async(dev_trie, g0, grp, [16] * len(grp), [seqs[i][-1] for i in grp],
+                                     put_idxs=[gidx[i] for i in grp] if dev_trie.put_vocab else None, put_branch_length=BL + 1)
+                if g0 == 0 and replay_q[0] is not None:
+                    ok = dev_trie.replay(replay_q[0], BL + 1)
+                    replay_q[0] = None
+                    if not ok:
+                        replay_q[1] = True                   # the host image outgrew the device's: finish this step, then a full image
+                t_, T_ = eng.mstep_trie_finish()
+                toks_all.extend(t_); Ts.extend(T_)
         for i in range(B):
             seqs[i].extend(toks_all[i])
             dls.append(Ts[i]); edls.append(len(toks_all[i]))
@@ -628,7 +639,7 @@ def main():
             # block); the host trie repeats the same puts — during the NEXT step — and drops the words it logged
             replay_q[0] = [(gidx[i], toks_all[i]) for i in range(B)]
             if replay_q[1]:                          # rare: capacity passed / squeeze — replay now, the next query syncs a full image
-                dev_trie.replay(replay_q[0], BL + 1)
+                dev_trie.replay(replay_q[0], BL + 1, calls=n_pass)
                 replay_q[0], replay_q[1] = None, False
         elif dist_on:
             gather.step_update(cache, toks_all if B > 1 else toks_all[0], BL)
@@ -705,7 +716,7 @@ def main():
         cache.stream_put_many(put_q[0], branch_length=BL + 1, final=False)
         put_q[0] = None
     if replay_q[0] is not None:          # the last chained step's trie update, replayed inside the timed region
-        dev_trie.replay(replay_q[0], BL + 1)
+        dev_trie.replay(replay_q[0], BL + 1, calls=(B + 7) // 8)
         replay_q[0] = None
     torch.cuda.synchronize()
     if dist_on:
